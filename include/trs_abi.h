@@ -1,0 +1,192 @@
+/*
+ * trs_abi.h -- C ABI of libtrs_hip.so, the MI355X (gfx950) kernels behind the torecsys
+ * embedding-lookup + feature-interaction hot path.
+ *
+ * The reference (p768lwy3/torecsys) is pure Python on PyTorch: it has no FFI of its own, the
+ * "plugin interface" for this path is nn.Module.forward().  Each entry point below therefore
+ * cites the reference forward() (file:line, relative to the reference root) whose ATen ops it
+ * replaces.  The Python host side (torecsys_amd/) mirrors those nn.Modules and calls these
+ * symbols through ctypes; INTEGRATION.md shows the binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *  - plain C: POD arguments only -- device pointers, sizes, dtype codes, a hipStream_t as void*;
+ *  - the CALLER owns every buffer (inputs, outputs, workspaces); the library never allocates,
+ *    frees or keeps a pointer after the call; all tensors are dense, row-major, contiguous;
+ *  - every call only ENQUEUES work on the caller's stream (no hidden synchronisation);
+ *  - return 0 (TRS_OK) or a negative TRS_E* code; trs_last_error_string() (thread-local) explains;
+ *  - no C++ exception crosses this boundary; the library is stateless and re-entrant;
+ *  - dtype codes: TRS_F32 / TRS_BF16 for values, TRS_I64 / TRS_I32 for indices;
+ *  - "offsets" is the per-field row offset vector (N int64, device) added to the raw indices,
+ *    or NULL for none; "err_flag" (device int32, may be NULL) is set to 1 when an index falls
+ *    outside [0,V) -- the row is then skipped (zeros on a gather) instead of read out of bounds.
+ */
+#ifndef TRS_ABI_H_
+#define TRS_ABI_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRS_ABI_VERSION 1
+
+enum { TRS_F32 = 0, TRS_BF16 = 1 };
+enum { TRS_I64 = 0, TRS_I32 = 1 };
+enum {
+  TRS_OK = 0,
+  TRS_EINVAL = -1,     /* NULL pointer / negative size / bad flag */
+  TRS_EDTYPE = -2,     /* unsupported dtype code */
+  TRS_ESHAPE = -3,     /* unsupported shape (e.g. N or E beyond a kernel's limits) */
+  TRS_EALIGN = -4,     /* pointer not aligned for the vector path */
+  TRS_ELAUNCH = -5,    /* hip launch error (hipGetLastError) */
+  TRS_EWORKSPACE = -6  /* workspace too small */
+};
+
+typedef void* trs_stream_t; /* hipStream_t */
+
+int trs_version(void);
+const char* trs_last_error_string(void);
+
+/* ---- K1: row gather ---------------------------------------------------------------------
+ * out[b,n,:] = table[idx[b,n] + offsets[n], :]            (bit-exact copy)
+ * replaces aten::add + aten::embedding in
+ *   torecsys/inputs/base/multi_indices_emb.py:104-105, single_index_emb.py:56-57.            */
+int trs_gather_rows(const void* table, int64_t V, int32_t E, int32_t dtype,
+                    const void* idx, int32_t idx_dtype, const int64_t* offsets,
+                    int64_t B, int32_t N, void* out, int32_t* err_flag, trs_stream_t stream);
+
+/* ---- I3: field-aware gather ---------------------------------------------------------------
+ * out[b, i*N+j, :] = tables[i][idx[b,j] + offsets[j], :]   for i,j in [0,N)
+ * `tables` = device array of N table base pointers (each V x E).
+ * replaces the N lookups + cat of multi_indices_field_aware_emb.py:102-105.                   */
+int trs_fa_gather_rows(const void* const* tables, int64_t V, int32_t E, int32_t dtype,
+                       const void* idx, int32_t idx_dtype, const int64_t* offsets,
+                       int64_t B, int32_t N, void* out, int32_t* err_flag, trs_stream_t stream);
+
+/* ---- row-bucketed index (CSR) ---------------------------------------------------------------
+ * Groups the B*N lookups by destination row: perm[row_start[r] .. row_start[r+1]) lists the
+ * flat positions p = b*N+n with idx[p]+offsets[p%N] == r.  Built once per batch, shared by every
+ * table looked up with the same indices.  row_start: V+1 int32; perm: B*N int32.
+ * Replaces the index_add loop of aten::embedding_dense_backward (reached from
+ * multi_indices_emb.py:105 through autograd) with an atomics-free segmented reduction.       */
+size_t trs_csr_workspace_bytes(int64_t V, int64_t BN);
+int trs_csr_build(const void* idx, int32_t idx_dtype, const int64_t* offsets, int64_t B, int32_t N,
+                  int64_t V, int32_t* row_start, int32_t* perm, void* workspace, size_t ws_bytes,
+                  int32_t* err_flag, trs_stream_t stream);
+
+/* ---- K1 backward: dense-gradient scatter ----------------------------------------------------
+ * grad_table[r,:] = sum_{p in row r} ( g_rows[p,:]  +  g_fm[b_p,:] * (fm_sum[b_p,:] - table[r,:]) )
+ * for EVERY r in [0,V) (rows without lookups are written as zeros: nn.Embedding's default
+ * sparse=False gradient, multi_indices_emb.py:48).  g_rows (B*N x E, may be NULL) is the
+ * gradient of the gathered block; the second term (g_fm B x E, fm_sum B x E fp32, table; all
+ * NULL to disable) is the FM second-order backward dx = g*(S - x) of
+ * layers/ctr/factorization_machine.py:62-73 fused into the same pass.  padding_row (-1: none)
+ * gets a zero gradient (nn.Embedding padding_idx).  fp32 accumulation, one rounding on store.
+ * With fm_sum == NULL, g_fm is a plain per-sample gradient broadcast over the N fields (the
+ * first-order sum's backward).  g_rows_batch_stride (rows; 0 = N) lets g_rows be a (B, N, E) slice
+ * of a larger (B, M, E) tensor: the row of position (b,n) is b*stride + n.
+ * Rows with more than 256 lookups (Zipf-hot rows) are queued in `workspace`
+ * (trs_scatter_workspace_bytes(B*N)) and reduced by whole workgroups.                          */
+size_t trs_scatter_workspace_bytes(int64_t BN);
+int trs_scatter_rows(const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm,
+                     const float* fm_sum, const void* table, const int32_t* row_start,
+                     const int32_t* perm, int64_t BN, int64_t V, int32_t E, int32_t N, int32_t dtype,
+                     int64_t padding_row, void* grad_table, void* workspace, size_t ws_bytes,
+                     trs_stream_t stream);
+
+/* ---- K1+K2(+K8): fused embedding lookup + FM second order ----------------------------------
+ * emb[b,n,:]  = table[idx[b,n]+offsets[n], :]                       (optional, may be NULL)
+ * fm[b,:]     = 0.5 * ((sum_n x)^2 - sum_n x^2)                     (optional, may be NULL)
+ * fm_sum[b,:] = sum_n x   (fp32, optional; saved for the backward)
+ * first[b]    = sum_n first_table[idx[b,n]+offsets[n]]              (optional E=1 first-order term)
+ * replaces multi_indices_emb.py:104-105 + factorization_machine.py:62-73
+ * (+ models/ctr/deep_fm.py:73-89 first-order sum) in one pass over the table rows.           */
+int trs_embed_fm(const void* table, int64_t V, int32_t E, int32_t dtype,
+                 const void* idx, int32_t idx_dtype, const int64_t* offsets, int64_t B, int32_t N,
+                 void* emb, void* fm, float* fm_sum, const void* first_table, void* first,
+                 int32_t* err_flag, trs_stream_t stream);
+
+/* ---- K2: FM layer on a materialised block -------------------------------------------------
+ * fwd: fm[b,:] = 0.5*((sum_n x)^2 - sum_n x^2), fm_sum[b,:] = sum_n x (fp32, optional)
+ * bwd: dx[b,n,:] = g[b,:] * (fm_sum[b,:] - x[b,n,:])
+ * layers/ctr/factorization_machine.py:62-73.                                                  */
+int trs_fm_fwd(const void* x, int64_t B, int32_t N, int32_t E, int32_t dtype, void* fm, float* fm_sum,
+               trs_stream_t stream);
+int trs_fm_bwd(const void* x, const void* g, const float* fm_sum, int64_t B, int32_t N, int32_t E,
+               int32_t dtype, void* dx, trs_stream_t stream);
+
+/* ---- K7: inner-product network ------------------------------------------------------------
+ * fwd: out[b,p(i,j)] = sum_e x[b,i,e]*x[b,j,e], i<j lexicographic, P = N(N-1)/2
+ * bwd: dx[b,i,:] = sum_{j!=i} g[b,p(min,max)] * x[b,j,:]
+ * layers/ctr/inner_product_network.py:68-74.                                                  */
+int trs_pair_dot_fwd(const void* x, int64_t B, int32_t N, int32_t E, int32_t dtype, void* out,
+                     trs_stream_t stream);
+int trs_pair_dot_bwd(const void* x, const void* g, int64_t B, int32_t N, int32_t E, int32_t dtype,
+                     void* dx, trs_stream_t stream);
+
+/* ---- K3: field-aware FM pair products -----------------------------------------------------
+ * fwd: out[b,p(i,j),:] = x[b,i*N+j,:] * x[b,j*N+i,:], i<j      x: (B, N*N, E)
+ * bwd: dx[b,i*N+j,:] = g[b,p,:]*x[b,j*N+i,:]; dx[b,j*N+i,:] = g[b,p,:]*x[b,i*N+j,:]; diagonal 0
+ * layers/ctr/field_aware_factorization_machine.py:69-87.
+ * trs_ffm_fused_fwd gathers straight from the N tables (never materialises (B,N*N,E)):
+ *   out[b,p(i,j),:] = tables[i][g_j,:] * tables[j][g_i,:],  g_n = idx[b,n]+offsets[n].       */
+int trs_ffm_fwd(const void* x, int64_t B, int32_t N, int32_t E, int32_t dtype, void* out,
+                trs_stream_t stream);
+int trs_ffm_bwd(const void* x, const void* g, int64_t B, int32_t N, int32_t E, int32_t dtype,
+                void* dx, trs_stream_t stream);
+int trs_ffm_fused_fwd(const void* const* tables, int64_t V, int32_t E, int32_t dtype,
+                      const void* idx, int32_t idx_dtype, const int64_t* offsets, int64_t B, int32_t N,
+                      void* out, int32_t* err_flag, trs_stream_t stream);
+
+/* ---- K4: cross network ----------------------------------------------------------------------
+ * x_{l+1} = x0 * (x_l W_l^T + b_l) + x0, l = 0..L-1, rows = B*N vectors of length E.
+ * W: (L,E,E) row-major [l][out][in] as nn.Linear.weight; b: (L,E).
+ * bwd reproduces cross_network.py:65: x_0's use as layer 0's linear input is detached.
+ *   dx (rows,E), dW (L,E,E) fp32, db (L,E) fp32 (dW/db are ACCUMULATED into: zero them first).
+ * layers/ctr/cross_network.py:65-79.                                                          */
+size_t trs_cross_workspace_bytes(int64_t rows, int32_t E, int32_t L, int32_t dtype);
+int trs_cross_fwd(const void* x, const void* W, const void* b, int64_t rows, int32_t E, int32_t L,
+                  int32_t dtype, void* out, trs_stream_t stream);
+int trs_cross_bwd(const void* x, const void* W, const void* b, const void* g, int64_t rows, int32_t E,
+                  int32_t L, int32_t dtype, void* dx, float* dW, float* db, void* workspace,
+                  size_t ws_bytes, trs_stream_t stream);
+
+/* ---- K5/K6: compress interaction network, one layer ------------------------------------------
+ * y[b,c,e] = bias[c] + sum_{n,h} Wc[c, n*H+h] * x0[b,n,e] * xk[b,h,e]
+ *   x0: (B,N,E) the embedding block; xk: (B,H,E) previous hidden ((B,N,E) for layer 0);
+ *   Wc: (C, N*H) = nn.Conv1d(N*H, C, 1).weight squeezed; bias (C) or NULL; y: (B,C,E).
+ * The outer product Z[b,(n,h),e] is formed on the fly (never written to memory).
+ * stats (2*C fp32, optional): per-channel sum and sum of squares of y over (B,E), accumulated
+ * (zero first) -- the BatchNorm1d batch statistics.
+ * bwd: given gy (B,C,E): dWc (C,N*H) fp32 accumulated, dx0 (B,N,E) and dxk (B,H,E) written.
+ * layers/ctr/compress_interaction_network.py:125-137.                                          */
+int trs_cin_fwd(const void* x0, const void* xk, const void* Wc, const void* bias, int64_t B, int32_t N,
+                int32_t H, int32_t C, int32_t E, int32_t dtype, void* y, float* stats,
+                trs_stream_t stream);
+int trs_cin_bwd(const void* x0, const void* xk, const void* Wc, const void* gy, int64_t B, int32_t N,
+                int32_t H, int32_t C, int32_t E, int32_t dtype, float* dWc, void* dx0, void* dxk,
+                int32_t accumulate_dx0, trs_stream_t stream);
+
+/* ---- row-sharded tables (multi-GPU lookup) -----------------------------
+ * Bucket the B*N global row ids by owner rank (owner = id / rows_per_rank):
+ *   counts[w]  = number of ids owned by rank w
+ *   send_ids   = ids grouped by owner (local row id = id - owner*rows_per_rank), int64
+ *   send_pos   = for each grouped slot the original flat position p (int32), to un-permute
+ * workspace from trs_bucket_workspace_bytes.                                                   */
+size_t trs_bucket_workspace_bytes(int64_t BN, int32_t world);
+int trs_bucket_by_owner(const void* idx, int32_t idx_dtype, const int64_t* offsets, int64_t B, int32_t N,
+                        int64_t rows_per_rank, int32_t world, int64_t* counts, int64_t* send_ids,
+                        int32_t* send_pos, void* workspace, size_t ws_bytes, trs_stream_t stream);
+/* out[pos[k],:] = rows[k,:]  (un-permute received rows into the (B*N,E) block) */
+int trs_scatter_by_pos(const void* rows, const int32_t* pos, int64_t K, int32_t E, int32_t dtype,
+                       void* out, trs_stream_t stream);
+/* out[k,:] = rows[pos[k],:]  (permute the block gradient into exchange order) */
+int trs_gather_by_pos(const void* rows, const int32_t* pos, int64_t K, int32_t E, int32_t dtype,
+                      void* out, trs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRS_ABI_H_ */

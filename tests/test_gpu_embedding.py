@@ -1,0 +1,228 @@
+"""GPU parity: lookup (I1-I3), dense-gradient scatter, FM (F1) and the fused lookup+FM kernel, through the
+C ABI, against the golden vectors and the CPU oracle.  Gather: bit-exact.  fp32 sums: 1e-5 relative.
+bf16: 1e-2 relative against the fp32 oracle evaluated on bf16-rounded inputs."""
+import pytest
+import torch
+
+from conftest import LAYER_SHAPES, rel_err
+from oracle import cpu_ref as O
+
+pytestmark = pytest.mark.gpu
+
+TOL32 = 1e-5
+TOLBF = 1e-2
+
+
+def _tag(s):
+    return "%d_%d_%d" % s
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "needs a HIP device"
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("shape", LAYER_SHAPES)
+def test_multi_indices_embedding_golden(golden, dev, shape):
+    from torecsys_amd.inputs import MultiIndicesEmbedding
+    G = golden("inputs")
+    t = "multi/" + _tag(shape)
+    fs = G(t + "/field_sizes").tolist()
+    m = MultiIndicesEmbedding(embed_size=shape[2], field_sizes=fs).to(dev)
+    assert list(m.state_dict().keys()) == ["embedding.weight"]
+    m.embedding.weight.data.copy_(G(t + "/weight"))
+    idx = G(t + "/idx").to(dev)
+    out = m(idx)
+    assert out.names == ("B", "N", "E")
+    assert torch.equal(out.rename(None).cpu(), G(t + "/out"))          # bit-exact
+    (out.rename(None) * G(t + "/gout").to(dev)).sum().backward()
+    assert rel_err(m.embedding.weight.grad.cpu(), G(t + "/gweight")) <= TOL32
+    # int32 indices take the same path
+    out32 = m(idx.to(torch.int32))
+    assert torch.equal(out32.rename(None).cpu(), G(t + "/out"))
+    # flatten
+    mf = MultiIndicesEmbedding(embed_size=shape[2], field_sizes=fs, flatten=True).to(dev)
+    yf = mf(idx)
+    assert list(yf.shape) == G(t + "/flatten_shape").tolist() and yf.names == ("B", "N", "E")
+    assert [len(m), len(mf)] == G(t + "/length").tolist()
+    # E = 1 first-order table (element path)
+    m1 = MultiIndicesEmbedding(embed_size=1, field_sizes=fs).to(dev)
+    m1.embedding.weight.data.copy_(G("multi1/" + _tag(shape) + "/weight"))
+    assert torch.equal(m1(idx).rename(None).cpu(), G("multi1/" + _tag(shape) + "/out"))
+
+
+@pytest.mark.parametrize("shape", LAYER_SHAPES)
+def test_single_index_embedding_golden(golden, dev, shape):
+    from torecsys_amd.inputs import SingleIndexEmbedding
+    G = golden("inputs")
+    t = "single/" + _tag(shape)
+    w = G(t + "/weight")
+    m = SingleIndexEmbedding(embed_size=shape[2], field_size=w.shape[0], padding_idx=0).to(dev)
+    assert list(m.state_dict().keys()) == ["embedding.weight"]
+    m.embedding.weight.data.copy_(w)
+    out = m(G(t + "/idx").to(dev))                                      # int32 (B,1)
+    assert out.names == ("B", "N", "E")
+    assert torch.equal(out.rename(None).cpu(), G(t + "/out"))
+    (out.rename(None) * G(t + "/gout").to(dev)).sum().backward()
+    g = m.embedding.weight.grad.cpu()
+    assert rel_err(g, G(t + "/gweight")) <= TOL32
+    assert float(g[0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("shape", LAYER_SHAPES)
+def test_field_aware_embedding_golden(golden, dev, shape):
+    from torecsys_amd.inputs import MultiIndicesFieldAwareEmbedding
+    G = golden("inputs")
+    t = "fa/" + _tag(shape)
+    tm = "multi/" + _tag(shape)
+    ws = G(t + "/weights")
+    N = shape[1]
+    m = MultiIndicesFieldAwareEmbedding(embed_size=ws.shape[2], field_sizes=G(tm + "/field_sizes").tolist()).to(dev)
+    assert list(m.state_dict().keys()) == [f"embeddings.{i}.weight" for i in range(N)]
+    for i, e in enumerate(m.embeddings):
+        e.weight.data.copy_(ws[i])
+    out = m(G(tm + "/idx").to(dev))
+    assert out.names == ("B", "N", "E") and out.shape[1] == N * N
+    ref = O.multi_indices_field_aware_embedding(list(ws), G(tm + "/idx"), O.field_offsets(G(tm + "/field_sizes").tolist()))
+    assert torch.equal(out.rename(None).cpu(), ref)
+    stride = int(G(t + "/out_sub_stride")[0])
+    assert torch.equal(out.rename(None).cpu()[:, ::stride], G(t + "/out_sub"))
+    out.rename(None).sum().backward()
+    assert rel_err(m.embeddings[1].weight.grad.cpu(), G(t + "/gweight1_ones")) <= TOL32
+
+
+@pytest.mark.parametrize("shape", LAYER_SHAPES)
+def test_fm_layer_golden(golden, dev, shape):
+    from torecsys_amd.layers import FactorizationMachineLayer, FMLayer
+    assert FMLayer is FactorizationMachineLayer
+    G = golden("layers")
+    tag = _tag(shape)
+    x = G(f"fm/{tag}/x").to(dev).requires_grad_()
+    lay = FactorizationMachineLayer(dropout_p=0.0)
+    xin = x.refine_names("B", "N", "E")
+    y = lay(xin)
+    assert y.names == ("B", "O")
+    assert rel_err(y.rename(None).cpu(), G(f"fm/{tag}/out")) <= TOL32
+    (y.rename(None) * G(f"fm/{tag}/gout").to(dev)).sum().backward()
+    assert rel_err(x.grad.cpu(), G(f"fm/{tag}/gx")) <= TOL32
+
+
+def _rand_case(B, N, E, V_per_field, seed, dtype, zipf=False):
+    g = torch.Generator().manual_seed(seed)
+    fs = [V_per_field + (i % 3) for i in range(N)]
+    if zipf:
+        cols = []
+        for f in fs:
+            u = torch.rand(B, 1, generator=g)
+            cols.append((f * u ** 6).long().clamp_(0, f - 1))      # heavy head: many repeats of row 0
+        idx = torch.cat(cols, 1)
+    else:
+        idx = torch.cat([torch.randint(0, f, (B, 1), generator=g) for f in fs], 1)
+    w = torch.randn(sum(fs), E, generator=g).to(dtype)
+    w1 = torch.randn(sum(fs), 1, generator=g).to(dtype)
+    return fs, idx, w, w1, g
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,N,E,Vf,zipf", [(1024, 10, 16, 100, False), (512, 39, 64, 50, False),
+                                           (4096, 39, 64, 7, True), (300, 5, 10, 9, False), (64, 3, 128, 4, False)])
+def test_fused_embed_fm_vs_oracle(dev, dtype, B, N, E, Vf, zipf):
+    """embed_fm (lookup + FM + first-order sum in one kernel) and its backward (FM term folded into the
+    segmented scatter; hot rows through the long-row path) against autograd over the oracle."""
+    from torecsys_amd import functional as F_
+    fs, idx, w, w1, g = _rand_case(B, N, E, Vf, 77 + B + N + E, dtype, zipf)
+    off = O.field_offsets(fs)
+    tol = TOL32 if dtype == torch.float32 else TOLBF
+    # oracle in fp32 on the (possibly bf16-rounded) weights
+    wr = w.float().requires_grad_()
+    w1r = w1.float().requires_grad_()
+    emb_r = O.multi_indices_embedding(wr, idx, off)
+    fm_r = O.fm_layer(emb_r)
+    first_r = O.multi_indices_embedding(w1r, idx, off).sum(dim=1)
+    ge = torch.randn(B, N, E, generator=g).to(dtype)
+    gf = torch.randn(B, E, generator=g).to(dtype)
+    g1 = torch.randn(B, 1, generator=g).to(dtype)
+    ((emb_r * ge.float()).sum() + (fm_r * gf.float()).sum() + (first_r * g1.float()).sum()).backward()
+
+    wd = w.to(dev).requires_grad_()
+    w1d = w1.to(dev).requires_grad_()
+    emb, fm, first = F_.embed_fm(wd, idx.to(dev), off.to(dev), w1d)
+    assert torch.equal(emb.cpu(), emb_r.detach().to(dtype))                  # gather is bit-exact
+    assert rel_err(fm.float().cpu(), fm_r.detach()) <= tol
+    assert rel_err(first.float().cpu(), first_r.detach()) <= tol
+    ((emb.float() * ge.to(dev).float()).sum() + (fm.float() * gf.to(dev).float()).sum()
+     + (first.float() * g1.to(dev).float()).sum()).backward()
+    assert rel_err(wd.grad.float().cpu(), wr.grad) <= tol
+    assert rel_err(w1d.grad.float().cpu(), w1r.grad) <= tol
+    # fm only (no block written), fm unused -> gradient only from the block
+    wd2 = w.to(dev).requires_grad_()
+    emb2, fm2, _ = F_.embed_fm(wd2, idx.to(dev), off.to(dev), None)
+    (emb2.float() * ge.to(dev).float()).sum().backward()
+    wr2 = w.float().requires_grad_()
+    (O.multi_indices_embedding(wr2, idx, off) * ge.float()).sum().backward()
+    assert rel_err(wd2.grad.float().cpu(), wr2.grad) <= tol
+
+
+def test_fused_fm_side_channel(dev):
+    """MultiIndicesEmbedding(fuse_fm=True) hands the FM term to FMLayer without a second pass; results and
+    gradients equal the unfused modules."""
+    from torecsys_amd.inputs import MultiIndicesEmbedding
+    from torecsys_amd.layers import FMLayer
+    fs, idx, w, _, g = _rand_case(256, 12, 32, 20, 5, torch.float32)
+    outs = []
+    for fuse in (False, True):
+        m = MultiIndicesEmbedding(embed_size=32, field_sizes=fs, fuse_fm=fuse).to(dev)
+        m.embedding.weight.data.copy_(w)
+        emb = m(idx.to(dev))
+        assert hasattr(emb, "_trs_fused_fm") == fuse
+        y = FMLayer()(emb)
+        (y.rename(None).sum() + (emb.rename(None) ** 2).sum()).backward()
+        outs.append((y.rename(None).detach().cpu(), m.embedding.weight.grad.cpu()))
+    assert rel_err(outs[1][0], outs[0][0]) <= TOL32
+    assert rel_err(outs[1][1], outs[0][1]) <= TOL32
+
+
+def test_gather_properties_full_size(dev):
+    """BASELINE shape (B=65536, N=39, E=64, V=1M, bf16): size-independent properties.
+    gather == index_select bit-exact; FM is invariant to a permutation of the fields; the dense gradient
+    of sum(out) counts the lookups of every row."""
+    from torecsys_amd import functional as F_
+    B, N, E, V = 65536, 39, 64, 1_000_000
+    g = torch.Generator().manual_seed(1234)
+    per = V // N
+    fs = [per] * (N - 1) + [V - per * (N - 1)]
+    off = O.field_offsets(fs).to(dev)
+    idx = torch.cat([torch.randint(0, f, (B, 1), generator=g) for f in fs], 1).to(dev)
+    w = torch.randn(V, E, generator=g).to(torch.bfloat16).to(dev).requires_grad_()
+    emb, fm, _ = F_.embed_fm(w, idx, off, None)
+    ref = w.detach()[(idx + off.view(1, -1)).reshape(-1)].reshape(B, N, E)
+    assert torch.equal(emb, ref)
+    pi = torch.randperm(N, generator=g).to(dev)
+    fm_p = F_.fm_layer(ref[:, pi].contiguous())
+    assert rel_err(fm_p.float(), fm.float()) <= TOLBF
+    s = ref.float().sum(1)
+    fm_ref = 0.5 * (s * s - (ref.float() ** 2).sum(1))
+    assert rel_err(fm.float(), fm_ref) <= TOLBF
+    emb.float().sum().backward()
+    counts = torch.bincount((idx + off.view(1, -1)).reshape(-1), minlength=V).float()
+    assert torch.equal(w.grad.float()[:, 0], counts.to(torch.bfloat16).float())
+    assert torch.equal(w.grad.float()[:, E - 1], counts.to(torch.bfloat16).float())
+
+
+def test_errors(dev):
+    from torecsys_amd import functional as F_
+    from torecsys_amd.inputs import MultiIndicesEmbedding
+    m = MultiIndicesEmbedding(embed_size=8, field_sizes=[3, 4])
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(2, 2, dtype=torch.long))                 # CPU tensors: no fallback
+    m = m.to(dev)
+    with pytest.raises(ValueError):
+        m(torch.zeros(2, 3, dtype=torch.long, device=dev))
+    with pytest.raises(TypeError):
+        F_.gather_rows(m.embedding.weight, torch.zeros(2, 2, device=dev))   # float indices
+    with pytest.raises(TypeError):
+        F_.gather_rows(m.embedding.weight.half(), torch.zeros(2, 2, dtype=torch.long, device=dev))
+    # empty batch
+    out = m(torch.zeros(0, 2, dtype=torch.long, device=dev))
+    assert out.shape == (0, 2, 8)

@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks (developer tool): time each C-ABI kernel at the BASELINE shape with HIP events
+on the launch stream and print algorithmic GB/s.  python tools/kbench.py [--dtype bf16] [--what a,b]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from torecsys_amd import functional as F_  # noqa: E402
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return ts[len(ts) // 2] * 1e-3, ts[0] * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--B", type=int, default=65536)
+    ap.add_argument("--N", type=int, default=39)
+    ap.add_argument("--E", type=int, default=64)
+    ap.add_argument("--V", type=int, default=1_000_000)
+    ap.add_argument("--zipf", action="store_true")
+    ap.add_argument("--what", default="all")
+    a = ap.parse_args()
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    s = 2 if dt == torch.bfloat16 else 4
+    dev = torch.device("cuda:0")
+    B, N, E, V = a.B, a.N, a.E, a.V
+    g = torch.Generator().manual_seed(1234)
+    per = V // N
+    fs = [per] * (N - 1) + [V - per * (N - 1)]
+    off = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(torch.tensor(fs), 0)[:-1]]).to(dev)
+    if a.zipf:
+        cols = []
+        for f in fs:
+            r = torch.rand(B, 1, generator=g, dtype=torch.float64)
+            # Zipf(1.05)-like via inverse power transform
+            cols.append(((f ** r - 1).clamp_(0, f - 1)).long())
+        idx = torch.cat(cols, 1).to(dev)
+    else:
+        idx = torch.cat([torch.randint(0, f, (B, 1), generator=g) for f in fs], 1).to(dev)
+    w = torch.randn(V, E, generator=g).to(dt).to(dev)
+    w1 = torch.randn(V, 1, generator=g).to(dt).to(dev)
+    what = a.what.split(",")
+
+    def want(k):
+        return "all" in what or k in what
+
+    def report(name, t, nbytes):
+        print(f"{name:34s} med {t[0]*1e6:9.1f} us  min {t[1]*1e6:9.1f} us  {nbytes/t[0]/1e9:8.1f} GB/s (alg) "
+              f"{nbytes/t[0]/8e12*100:5.1f}% of 8TB/s", flush=True)
+
+    rd = B * N * (8 + E * s)
+    if want("gather"):
+        t = timeit(lambda: F_._GatherRows.apply(w, idx, off, None))
+        report("gather_rows", t, rd + B * N * E * s)
+    if want("embed_fm"):
+        t = timeit(lambda: F_._EmbedFM.apply(w, idx, off, None, False))
+        report("embed_fm (fm only)", t, rd + B * E * s + B * E * 4)
+        t = timeit(lambda: F_._EmbedFM.apply(w, idx, off, None, True))
+        report("embed_fm (+emb block)", t, rd + B * N * E * s + B * E * s + B * E * 4)
+        t = timeit(lambda: F_._EmbedFM.apply(w, idx, off, w1, True))
+        report("embed_fm (+emb +first)", t, rd + B * N * s + B * N * E * s + B * E * s + B * E * 4)
+        t = timeit(lambda: F_._EmbedFM.apply(w, idx, off, w1, False))
+        report("embed_fm (fm+first, no block)", t, rd + B * N * s + B * E * s + B * E * 4)
+    if want("fm"):
+        x = torch.randn(B, N, E, generator=g).to(dt).to(dev)
+        t = timeit(lambda: F_._FMLayer.apply(x))
+        report("fm_fwd (block)", t, B * N * E * s + B * E * s + B * E * 4)
+    if want("csr"):
+        def csr():
+            F_.clear_caches()
+            return F_.row_buckets(idx, off, V)
+        t = timeit(csr)
+        report("csr_build", t, B * N * (8 + 4 + 4 + 4) + 2 * (V + 1) * 4 * 2)
+    if want("scatter"):
+        rb = F_.row_buckets(idx, off, V)
+        ge = torch.randn(B, N, E, generator=g).to(dt).to(dev)
+        gf = torch.randn(B, E, generator=g).to(dt).to(dev)
+        S = torch.randn(B, E, generator=g).to(dev)
+        t = timeit(lambda: F_.scatter_rows(rb, w, g_rows=ge))
+        report("scatter_rows (g_rows)", t, B * N * (E * s + 4) + V * E * s + V * 4)
+        t = timeit(lambda: F_.scatter_rows(rb, w, g_rows=ge, g_bcast=gf, fm_sum=S))
+        report("scatter_rows (g_rows + fm)", t, B * N * (E * s + 4) + V * E * s * 2 + V * 4)
+        t = timeit(lambda: F_.scatter_rows(rb, w1, g_bcast=gf[:, :1].contiguous()))
+        report("scatter_rows (first-order E=1)", t, B * N * (4) + V * s + V * 4)
+    if want("copy"):
+        x = torch.empty(512 * 1024 * 1024 // 4, dtype=torch.float32, device=dev)
+        y = torch.empty_like(x)
+        t = timeit(lambda: y.copy_(x))
+        report("torch copy 512MB (r+w)", t, 2 * x.numel() * 4)
+
+
+if __name__ == "__main__":
+    main()

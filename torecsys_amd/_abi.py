@@ -1,0 +1,136 @@
+"""ctypes binding of libtrs_hip.so (C ABI declared in include/trs_abi.h).
+
+The library is the only compute path of this package: there is no CPU or eager-PyTorch fallback.
+Loading fails loudly (RuntimeError) when the .so has not been built, and every op raises when it
+is handed a tensor that is not on a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from ctypes import c_char_p, c_int32, c_int64, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtrs_hip.so")
+
+TRS_F32, TRS_BF16 = 0, 1
+TRS_I64, TRS_I32 = 0, 1
+
+_P, _I32, _I64, _SZ = c_void_p, c_int32, c_int64, c_size_t
+
+# name -> (restype, argtypes); must list every symbol of include/trs_abi.h (tests/test_abi.py checks)
+SIGNATURES = {
+    "trs_version": (c_int32, []),
+    "trs_last_error_string": (c_char_p, []),
+    "trs_gather_rows": (c_int32, [_P, _I64, _I32, _I32, _P, _I32, _P, _I64, _I32, _P, _P, _P]),
+    "trs_fa_gather_rows": (c_int32, [_P, _I64, _I32, _I32, _P, _I32, _P, _I64, _I32, _P, _P, _P]),
+    "trs_csr_workspace_bytes": (_SZ, [_I64, _I64]),
+    "trs_csr_build": (c_int32, [_P, _I32, _P, _I64, _I32, _I64, _P, _P, _P, _SZ, _P, _P]),
+    "trs_scatter_workspace_bytes": (_SZ, [_I64]),
+    "trs_scatter_rows": (c_int32, [_P, _I64, _P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _I64, _P, _P, _SZ, _P]),
+    "trs_embed_fm": (c_int32, [_P, _I64, _I32, _I32, _P, _I32, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P]),
+    "trs_fm_fwd": (c_int32, [_P, _I64, _I32, _I32, _I32, _P, _P, _P]),
+    "trs_fm_bwd": (c_int32, [_P, _P, _P, _I64, _I32, _I32, _I32, _P, _P]),
+    "trs_pair_dot_fwd": (c_int32, [_P, _I64, _I32, _I32, _I32, _P, _P]),
+    "trs_pair_dot_bwd": (c_int32, [_P, _P, _I64, _I32, _I32, _I32, _P, _P]),
+    "trs_ffm_fwd": (c_int32, [_P, _I64, _I32, _I32, _I32, _P, _P]),
+    "trs_ffm_bwd": (c_int32, [_P, _P, _I64, _I32, _I32, _I32, _P, _P]),
+    "trs_ffm_fused_fwd": (c_int32, [_P, _I64, _I32, _I32, _P, _I32, _P, _I64, _I32, _P, _P, _P]),
+    "trs_cross_workspace_bytes": (_SZ, [_I64, _I32, _I32, _I32]),
+    "trs_cross_fwd": (c_int32, [_P, _P, _P, _I64, _I32, _I32, _I32, _P, _P]),
+    "trs_cross_bwd": (c_int32, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _P, _SZ, _P]),
+    "trs_cin_fwd": (c_int32, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
+    "trs_cin_bwd": (c_int32, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _I32, _P]),
+    "trs_bucket_workspace_bytes": (_SZ, [_I64, _I32]),
+    "trs_bucket_by_owner": (c_int32, [_P, _I32, _P, _I64, _I32, _I64, _I32, _P, _P, _P, _P, _SZ, _P]),
+    "trs_scatter_by_pos": (c_int32, [_P, _P, _I64, _I32, _I32, _P, _P]),
+    "trs_gather_by_pos": (c_int32, [_P, _P, _I64, _I32, _I32, _P, _P]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load() -> ctypes.CDLL:
+    """dlopen the in-tree library (once).  torch is imported first so that the library binds to the
+    HIP runtime torch already loaded (same SONAME) and shares its streams and allocations."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"torecsys_amd: HIP library not built ({LIB_PATH} missing). Run "
+                "`python -m torecsys_amd.build` (or __graft_entry__.build()). There is no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as e:  # pragma: no cover
+                raise RuntimeError(f"torecsys_amd: {LIB_PATH} does not export {name}; rebuild it") from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def last_error() -> str:
+    s = load().trs_last_error_string()
+    return s.decode("utf-8", "replace") if s else ""
+
+
+def call(name: str, *args):
+    """Call an int-returning entry point; raise RuntimeError with the library's message on failure."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (code {rc}): {last_error()}")
+
+
+def size_query(name: str, *args) -> int:
+    return int(getattr(load(), name)(*args))
+
+
+def value_dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return TRS_F32
+    if t.dtype == torch.bfloat16:
+        return TRS_BF16
+    raise TypeError(f"torecsys_amd: unsupported value dtype {t.dtype} (float32 and bfloat16 only)")
+
+
+def index_dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.int64:
+        return TRS_I64
+    if t.dtype == torch.int32:
+        return TRS_I32
+    raise TypeError(f"torecsys_amd: unsupported index dtype {t.dtype}")
+
+
+def require_device(*tensors: torch.Tensor) -> torch.device:
+    """All tensors must live on one HIP device; anything else is an error (no CPU path)."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "torecsys_amd: tensors must be on a HIP ('cuda') device; this package has no CPU path "
+                f"(got a tensor on {t.device})")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"torecsys_amd: tensors on different devices ({dev} vs {t.device})")
+    return dev
+
+
+def ptr(t) -> c_void_p:
+    return c_void_p(0) if t is None else c_void_p(t.data_ptr())
+
+
+def stream_ptr() -> c_void_p:
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,262 @@
+// K1+K2(+K8): fused embedding lookup + FM second order (+ first-order sum), FM layer fwd/bwd.
+//
+// Layout: one table row of E values is split into L = E*sizeof(T)/16 sixteen-byte vectors; a GROUP
+// of L adjacent lanes owns one sample and walks its N fields, so every lane keeps the running
+// sum / sum-of-squares of its own VE columns in registers -- no cross-lane traffic, no LDS.  A wave
+// therefore covers 64/L samples per instruction and each row read is one full 16*L-byte segment
+// (128 B = one cache line for bf16 E=64).  Rows are fetched CH at a time so CH independent
+// 16-byte loads per lane are in flight (HBM latency ~1 us on a random row).
+// HBM-bound: algorithmic bytes per sample = N*(idx 8 + E*s) read, E*s (+N*E*s with the block) written.
+#include "trs_common.hpp"
+
+namespace trs {
+
+template <typename T, typename IdxT, int LOG2L, bool GATHER>
+__global__ __launch_bounds__(256) void embed_fm_group_kernel(
+    const uint4* __restrict__ src,  // GATHER: table (V x E); else x (B x N x E)
+    const IdxT* __restrict__ idx, const int64_t* __restrict__ offsets, int64_t B, int N, int64_t V,
+    uint4* __restrict__ emb, uint4* __restrict__ fm, float* __restrict__ fm_sum,
+    const T* __restrict__ first_table, T* __restrict__ first, int32_t* __restrict__ err_flag) {
+  constexpr int L = 1 << LOG2L;
+  constexpr int VE = Vec16<T>::VE;
+  constexpr int CH = 8;
+  const int lane_v = threadIdx.x & (L - 1);
+  const int64_t groups = ((int64_t)gridDim.x * blockDim.x) >> LOG2L;
+  for (int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> LOG2L; b < B; b += groups) {
+    float s[VE], q[VE];
+#pragma unroll
+    for (int k = 0; k < VE; ++k) { s[k] = 0.f; q[k] = 0.f; }
+    float f1 = 0.f;
+    for (int n0 = 0; n0 < N; n0 += CH) {
+      int64_t r[CH];
+      uint4 v[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int n = n0 + c;
+        r[c] = -1;
+        if (n < N) {
+          if (GATHER) {
+            r[c] = load_row_id(idx, offsets, b * N + n, n);
+            if (err_flag != nullptr && (r[c] < 0 || r[c] >= V)) { *err_flag = 1; r[c] = -1; }
+          } else {
+            r[c] = b * N + n;
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        v[c] = make_uint4(0, 0, 0, 0);
+        if (r[c] >= 0) v[c] = src[r[c] * L + lane_v];
+      }
+      if (GATHER && first_table != nullptr) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          if ((((n0 + c) & (L - 1)) == lane_v) && r[c] >= 0) f1 += to_f32(first_table[r[c]]);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int n = n0 + c;
+        if (n < N) {
+          float x[VE];
+          Vec16<T>::unpack(v[c], x);
+#pragma unroll
+          for (int k = 0; k < VE; ++k) { s[k] += x[k]; q[k] = fmaf(x[k], x[k], q[k]); }
+          if (GATHER && emb != nullptr) emb[(b * N + n) * L + lane_v] = v[c];
+        }
+      }
+    }
+    if (fm != nullptr) {
+      float o[VE];
+#pragma unroll
+      for (int k = 0; k < VE; ++k) o[k] = 0.5f * (s[k] * s[k] - q[k]);
+      fm[b * L + lane_v] = Vec16<T>::pack(o);
+    }
+    if (fm_sum != nullptr) {
+      float4* dst = reinterpret_cast<float4*>(fm_sum + (b * L + lane_v) * VE);
+#pragma unroll
+      for (int k = 0; k < VE; k += 4) dst[k / 4] = make_float4(s[k], s[k + 1], s[k + 2], s[k + 3]);
+    }
+    if (GATHER && first_table != nullptr) {
+#pragma unroll
+      for (int m = L >> 1; m >= 1; m >>= 1) f1 += __shfl_xor(f1, m, 64);
+      if (lane_v == 0) first[b] = from_f32<T>(f1);
+    }
+  }
+}
+
+// generic path: any E; one thread per (b, e)
+template <typename T, typename IdxT, bool GATHER>
+__global__ __launch_bounds__(256) void embed_fm_elem_kernel(
+    const T* __restrict__ src, const IdxT* __restrict__ idx, const int64_t* __restrict__ offsets, int64_t B,
+    int N, int E, int64_t V, T* __restrict__ emb, T* __restrict__ fm, float* __restrict__ fm_sum,
+    const T* __restrict__ first_table, T* __restrict__ first, int32_t* __restrict__ err_flag) {
+  const int64_t total = B * E;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t b = t / E;
+    const int e = (int)(t - b * E);
+    float s = 0.f, q = 0.f, f1 = 0.f;
+    for (int n = 0; n < N; ++n) {
+      int64_t r = b * N + n;
+      bool ok = true;
+      if (GATHER) {
+        r = load_row_id(idx, offsets, b * N + n, n);
+        if (err_flag != nullptr && (r < 0 || r >= V)) { *err_flag = 1; ok = false; }
+      }
+      T raw = T{};
+      if (ok) raw = src[r * E + e];
+      const float x = to_f32(raw);
+      s += x;
+      q = fmaf(x, x, q);
+      if (GATHER && emb != nullptr) emb[(b * N + n) * E + e] = raw;
+      if (GATHER && first_table != nullptr && e == 0 && ok) f1 += to_f32(first_table[r]);
+    }
+    if (fm != nullptr) fm[t] = from_f32<T>(0.5f * (s * s - q));
+    if (fm_sum != nullptr) fm_sum[t] = s;
+    if (GATHER && first_table != nullptr && e == 0) first[b] = from_f32<T>(f1);
+  }
+}
+
+static int log2_lanes(int row_bytes) {
+  if (row_bytes % 16 != 0) return -1;
+  const int L = row_bytes / 16;
+  if (!is_pow2(L) || L > 64) return -1;
+  int l = 0;
+  while ((1 << l) < L) ++l;
+  return l;
+}
+
+template <typename T, typename IdxT, bool GATHER>
+static int embed_fm_launch(const void* src, const IdxT* idx, const int64_t* offsets, int64_t B, int N, int E,
+                           int64_t V, void* emb, void* fm, float* fm_sum, const void* first_table, void* first,
+                           int32_t* err_flag, hipStream_t s) {
+  const int lg = log2_lanes(E * (int)sizeof(T));
+  const bool al = aligned16(src) && aligned16(emb) && aligned16(fm) && aligned16(fm_sum);
+  if (lg >= 0 && al) {
+    const int L = 1 << lg;
+    const int grid = stream_grid(B * L, 256, 256 * 16);
+#define TRS_EF(LG)                                                                                        \
+  hipLaunchKernelGGL((embed_fm_group_kernel<T, IdxT, LG, GATHER>), dim3(grid), dim3(256), 0, s,            \
+                     (const uint4*)src, idx, offsets, B, N, V, (uint4*)emb, (uint4*)fm, fm_sum,            \
+                     (const T*)first_table, (T*)first, err_flag)
+    switch (lg) {
+      case 0: TRS_EF(0); break;
+      case 1: TRS_EF(1); break;
+      case 2: TRS_EF(2); break;
+      case 3: TRS_EF(3); break;
+      case 4: TRS_EF(4); break;
+      case 5: TRS_EF(5); break;
+      default: TRS_EF(6); break;
+    }
+#undef TRS_EF
+  } else {
+    const int grid = stream_grid(B * E, 256, 256 * 16);
+    hipLaunchKernelGGL((embed_fm_elem_kernel<T, IdxT, GATHER>), dim3(grid), dim3(256), 0, s, (const T*)src, idx,
+                       offsets, B, N, E, V, (T*)emb, (T*)fm, fm_sum, (const T*)first_table, (T*)first, err_flag);
+  }
+  return check_launch(GATHER ? "embed_fm" : "fm_fwd");
+}
+
+// ---- FM backward on a materialised block: dx = g * (S - x)
+template <typename T>
+__global__ __launch_bounds__(256) void fm_bwd_vec_kernel(const uint4* __restrict__ x, const uint4* __restrict__ g,
+                                                         const float* __restrict__ fm_sum, uint4* __restrict__ dx,
+                                                         int64_t total_vecs, int N, int vpr) {
+  constexpr int VE = Vec16<T>::VE;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t per_b = (int64_t)N * vpr;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total_vecs; t += stride) {
+    const int64_t b = t / per_b;
+    const int lv = (int)(t % vpr);
+    float xv[VE], gv[VE], o[VE];
+    Vec16<T>::unpack(x[t], xv);
+    Vec16<T>::unpack(g[b * vpr + lv], gv);
+    const float* sp = fm_sum + (b * vpr + lv) * VE;
+#pragma unroll
+    for (int k = 0; k < VE; ++k) o[k] = gv[k] * (sp[k] - xv[k]);
+    dx[t] = Vec16<T>::pack(o);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void fm_bwd_elem_kernel(const T* __restrict__ x, const T* __restrict__ g,
+                                                          const float* __restrict__ fm_sum, T* __restrict__ dx,
+                                                          int64_t total, int N, int E) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t per_b = (int64_t)N * E;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t b = t / per_b;
+    const int e = (int)(t % E);
+    dx[t] = from_f32<T>(to_f32(g[b * E + e]) * (fm_sum[b * E + e] - to_f32(x[t])));
+  }
+}
+
+template <typename T>
+static int fm_bwd_launch(const void* x, const void* g, const float* fm_sum, int64_t B, int N, int E, void* dx,
+                         hipStream_t s) {
+  const int row_bytes = E * (int)sizeof(T);
+  if (row_bytes % 16 == 0 && aligned16(x) && aligned16(g) && aligned16(dx)) {
+    const int vpr = row_bytes / 16;
+    const int64_t total = B * N * vpr;
+    hipLaunchKernelGGL((fm_bwd_vec_kernel<T>), dim3(stream_grid(total, 256, 256 * 32)), dim3(256), 0, s,
+                       (const uint4*)x, (const uint4*)g, fm_sum, (uint4*)dx, total, N, vpr);
+  } else {
+    const int64_t total = B * N * E;
+    hipLaunchKernelGGL((fm_bwd_elem_kernel<T>), dim3(stream_grid(total, 256, 256 * 32)), dim3(256), 0, s,
+                       (const T*)x, (const T*)g, fm_sum, (T*)dx, total, N, E);
+  }
+  return check_launch("fm_bwd");
+}
+
+}  // namespace trs
+
+using namespace trs;
+
+extern "C" int trs_embed_fm(const void* table, int64_t V, int32_t E, int32_t dtype, const void* idx,
+                            int32_t idx_dtype, const int64_t* offsets, int64_t B, int32_t N, void* emb, void* fm,
+                            float* fm_sum, const void* first_table, void* first, int32_t* err_flag,
+                            trs_stream_t stream) {
+  TRS_REQUIRE(table && idx, TRS_EINVAL, "embed_fm: NULL pointer");
+  TRS_REQUIRE(V > 0 && E > 0 && B >= 0 && N > 0, TRS_EINVAL, "embed_fm: bad size");
+  TRS_REQUIRE(dtype == TRS_F32 || dtype == TRS_BF16, TRS_EDTYPE, "embed_fm: dtype %d", dtype);
+  TRS_REQUIRE(idx_dtype == TRS_I64 || idx_dtype == TRS_I32, TRS_EDTYPE, "embed_fm: idx dtype %d", idx_dtype);
+  TRS_REQUIRE((first_table == nullptr) == (first == nullptr), TRS_EINVAL,
+              "embed_fm: first_table and first must be given together");
+  if (B == 0) return TRS_OK;
+  hipStream_t s = (hipStream_t)stream;
+#define TRS_CALL(T, I)                                                                                    \
+  return embed_fm_launch<T, I, true>(table, (const I*)idx, offsets, B, N, E, V, emb, fm, fm_sum, first_table, \
+                                     first, err_flag, s)
+  if (dtype == TRS_F32) {
+    if (idx_dtype == TRS_I64) TRS_CALL(float, int64_t);
+    TRS_CALL(float, int32_t);
+  }
+  if (idx_dtype == TRS_I64) TRS_CALL(bf16_t, int64_t);
+  TRS_CALL(bf16_t, int32_t);
+#undef TRS_CALL
+}
+
+extern "C" int trs_fm_fwd(const void* x, int64_t B, int32_t N, int32_t E, int32_t dtype, void* fm, float* fm_sum,
+                          trs_stream_t stream) {
+  TRS_REQUIRE(x && (fm || fm_sum), TRS_EINVAL, "fm_fwd: NULL pointer");
+  TRS_REQUIRE(E > 0 && B >= 0 && N > 0, TRS_EINVAL, "fm_fwd: bad size");
+  TRS_REQUIRE(dtype == TRS_F32 || dtype == TRS_BF16, TRS_EDTYPE, "fm_fwd: dtype %d", dtype);
+  if (B == 0) return TRS_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == TRS_F32)
+    return embed_fm_launch<float, int64_t, false>(x, nullptr, nullptr, B, N, E, 0, nullptr, fm, fm_sum, nullptr,
+                                                  nullptr, nullptr, s);
+  return embed_fm_launch<bf16_t, int64_t, false>(x, nullptr, nullptr, B, N, E, 0, nullptr, fm, fm_sum, nullptr,
+                                                 nullptr, nullptr, s);
+}
+
+extern "C" int trs_fm_bwd(const void* x, const void* g, const float* fm_sum, int64_t B, int32_t N, int32_t E,
+                          int32_t dtype, void* dx, trs_stream_t stream) {
+  TRS_REQUIRE(x && g && fm_sum && dx, TRS_EINVAL, "fm_bwd: NULL pointer");
+  TRS_REQUIRE(E > 0 && B >= 0 && N > 0, TRS_EINVAL, "fm_bwd: bad size");
+  TRS_REQUIRE(dtype == TRS_F32 || dtype == TRS_BF16, TRS_EDTYPE, "fm_bwd: dtype %d", dtype);
+  if (B == 0) return TRS_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == TRS_F32) return fm_bwd_launch<float>(x, g, fm_sum, B, N, E, dx, s);
+  return fm_bwd_launch<bf16_t>(x, g, fm_sum, B, N, E, dx, s);
+}

@@ -1,0 +1,298 @@
+// K1: embedding row gather (bit-exact copy), field-aware gather (I3), permute helpers.
+// HBM-bound: every lane moves one 16-byte vector of a table row; a 128-byte bf16 row (E=64) is
+// fetched by 8 adjacent lanes = one full cache line per row, one wave instruction = 8 rows.
+#include "trs_common.hpp"
+
+namespace trs {
+
+static thread_local char g_err[512];
+char* err_buf() { return g_err; }
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(TRS_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return TRS_OK;
+}
+
+// rows = B*N flat positions; vpr = 16-byte vectors per row (E*sizeof(T)/16).
+// SHIFT >= 0: vpr == 1<<SHIFT (no integer division); SHIFT < 0: generic.
+template <typename IdxT, int SHIFT, int UNROLL>
+__global__ __launch_bounds__(256) void gather_rows_vec_kernel(
+    const uint4* __restrict__ table, const IdxT* __restrict__ idx, const int64_t* __restrict__ offsets,
+    uint4* __restrict__ out, int64_t total_vecs, int vpr, int N, int64_t V, int32_t* __restrict__ err_flag) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; t0 < total_vecs; t0 += stride * UNROLL) {
+    uint4 v[UNROLL];
+    bool ok[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t t = t0 + u * stride;
+      ok[u] = t < total_vecs;
+      v[u] = make_uint4(0, 0, 0, 0);
+      if (ok[u]) {
+        int64_t p;
+        int lane_v;
+        if (SHIFT >= 0) {
+          p = t >> SHIFT;
+          lane_v = (int)(t & ((1 << SHIFT) - 1));
+        } else {
+          p = t / vpr;
+          lane_v = (int)(t - p * vpr);
+        }
+        const int n = (int)(p % N);
+        const int64_t r = load_row_id(idx, offsets, p, n);
+        if (err_flag != nullptr && (r < 0 || r >= V)) {
+          *err_flag = 1;
+        } else {
+          v[u] = table[r * vpr + lane_v];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t t = t0 + u * stride;
+      if (ok[u]) out[t] = v[u];
+    }
+  }
+}
+
+// generic element-wise path (row bytes not a multiple of 16, e.g. the E=1 first-order table)
+template <typename T, typename IdxT>
+__global__ __launch_bounds__(256) void gather_rows_elem_kernel(
+    const T* __restrict__ table, const IdxT* __restrict__ idx, const int64_t* __restrict__ offsets,
+    T* __restrict__ out, int64_t total, int E, int N, int64_t V, int32_t* __restrict__ err_flag) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t p = t / E;
+    const int e = (int)(t - p * E);
+    const int n = (int)(p % N);
+    const int64_t r = load_row_id(idx, offsets, p, n);
+    if (err_flag != nullptr && (r < 0 || r >= V)) {
+      *err_flag = 1;
+      out[t] = T{};
+    } else {
+      out[t] = table[r * E + e];
+    }
+  }
+}
+
+template <typename IdxT>
+static int launch_gather_vec(const void* table, const IdxT* idx, const int64_t* offsets, void* out,
+                             int64_t rows, int vpr, int N, int64_t V, int32_t* err_flag, hipStream_t s) {
+  const int64_t total = rows * vpr;
+  constexpr int UNROLL = 4;
+  const int grid = stream_grid((total + UNROLL - 1) / UNROLL, 256, 256 * 32);
+#define TRS_GV(SH)                                                                                  \
+  hipLaunchKernelGGL((gather_rows_vec_kernel<IdxT, SH, UNROLL>), dim3(grid), dim3(256), 0, s,       \
+                     (const uint4*)table, idx, offsets, (uint4*)out, total, vpr, N, V, err_flag)
+  switch (vpr) {
+    case 1: TRS_GV(0); break;
+    case 2: TRS_GV(1); break;
+    case 4: TRS_GV(2); break;
+    case 8: TRS_GV(3); break;
+    case 16: TRS_GV(4); break;
+    case 32: TRS_GV(5); break;
+    case 64: TRS_GV(6); break;
+    default: TRS_GV(-1); break;
+  }
+#undef TRS_GV
+  return check_launch("gather_rows");
+}
+
+template <typename T, typename IdxT>
+static int launch_gather_elem(const void* table, const IdxT* idx, const int64_t* offsets, void* out,
+                              int64_t rows, int E, int N, int64_t V, int32_t* err_flag, hipStream_t s) {
+  const int64_t total = rows * E;
+  const int grid = stream_grid(total, 256, 256 * 32);
+  hipLaunchKernelGGL((gather_rows_elem_kernel<T, IdxT>), dim3(grid), dim3(256), 0, s, (const T*)table, idx,
+                     offsets, (T*)out, total, E, N, V, err_flag);
+  return check_launch("gather_rows(elem)");
+}
+
+template <typename IdxT>
+static int gather_dispatch(const void* table, int64_t V, int E, int dtype, const IdxT* idx,
+                           const int64_t* offsets, int64_t rows, int N, void* out, int32_t* err_flag,
+                           hipStream_t s) {
+  const int row_bytes = E * dtype_size(dtype);
+  if (row_bytes % 16 == 0 && aligned16(table) && aligned16(out)) {
+    return launch_gather_vec<IdxT>(table, idx, offsets, out, rows, row_bytes / 16, N, V, err_flag, s);
+  }
+  if (dtype == TRS_F32) return launch_gather_elem<float, IdxT>(table, idx, offsets, out, rows, E, N, V, err_flag, s);
+  return launch_gather_elem<bf16_t, IdxT>(table, idx, offsets, out, rows, E, N, V, err_flag, s);
+}
+
+// ---- field-aware gather: out[b, i*N + j, :] = tables[i][g(b,j), :]
+template <typename IdxT>
+__global__ __launch_bounds__(256) void fa_gather_vec_kernel(
+    const uint4* const* __restrict__ tables, const IdxT* __restrict__ idx, const int64_t* __restrict__ offsets,
+    uint4* __restrict__ out, int64_t B, int N, int vpr, int64_t V, int32_t* __restrict__ err_flag) {
+  // one item = (b, i, j, vec); consecutive threads walk vec, then j, then i: writes are contiguous.
+  const int64_t per_b = (int64_t)N * N * vpr;
+  const int64_t total = B * per_b;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t b = t / per_b;
+    int rem = (int)(t - b * per_b);
+    const int i = rem / (N * vpr);
+    rem -= i * N * vpr;
+    const int j = rem / vpr;
+    const int lv = rem - j * vpr;
+    const int64_t r = load_row_id(idx, offsets, b * N + j, j);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (err_flag != nullptr && (r < 0 || r >= V)) {
+      *err_flag = 1;
+    } else {
+      v = tables[i][r * vpr + lv];
+    }
+    out[t] = v;
+  }
+}
+
+template <typename T, typename IdxT>
+__global__ __launch_bounds__(256) void fa_gather_elem_kernel(
+    const T* const* __restrict__ tables, const IdxT* __restrict__ idx, const int64_t* __restrict__ offsets,
+    T* __restrict__ out, int64_t B, int N, int E, int64_t V, int32_t* __restrict__ err_flag) {
+  const int64_t per_b = (int64_t)N * N * E;
+  const int64_t total = B * per_b;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t b = t / per_b;
+    int rem = (int)(t - b * per_b);
+    const int i = rem / (N * E);
+    rem -= i * N * E;
+    const int j = rem / E;
+    const int e = rem - j * E;
+    const int64_t r = load_row_id(idx, offsets, b * N + j, j);
+    if (err_flag != nullptr && (r < 0 || r >= V)) {
+      *err_flag = 1;
+      out[t] = T{};
+    } else {
+      out[t] = tables[i][r * E + e];
+    }
+  }
+}
+
+// ---- permutation helpers for the sharded lookup
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void permute_rows_vec_kernel(const uint4* __restrict__ rows,
+                                                               const int32_t* __restrict__ pos,
+                                                               uint4* __restrict__ out, int64_t K, int vpr) {
+  const int64_t total = K * vpr;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t k = t / vpr;
+    const int lv = (int)(t - k * vpr);
+    const int64_t p = pos[k];
+    if (SCATTER) out[p * vpr + lv] = rows[t];
+    else out[t] = rows[p * vpr + lv];
+  }
+}
+template <typename T, bool SCATTER>
+__global__ __launch_bounds__(256) void permute_rows_elem_kernel(const T* __restrict__ rows,
+                                                                const int32_t* __restrict__ pos,
+                                                                T* __restrict__ out, int64_t K, int E) {
+  const int64_t total = K * E;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t k = t / E;
+    const int e = (int)(t - k * E);
+    const int64_t p = pos[k];
+    if (SCATTER) out[p * E + e] = rows[t];
+    else out[t] = rows[p * E + e];
+  }
+}
+
+template <bool SCATTER>
+static int permute_rows(const void* rows, const int32_t* pos, int64_t K, int E, int dtype, void* out,
+                        hipStream_t s) {
+  TRS_REQUIRE(rows && pos && out, TRS_EINVAL, "permute_rows: NULL pointer");
+  TRS_REQUIRE(K >= 0 && E > 0, TRS_EINVAL, "permute_rows: bad size");
+  TRS_REQUIRE(dtype == TRS_F32 || dtype == TRS_BF16, TRS_EDTYPE, "permute_rows: dtype %d", dtype);
+  if (K == 0) return TRS_OK;
+  const int row_bytes = E * dtype_size(dtype);
+  if (row_bytes % 16 == 0 && aligned16(rows) && aligned16(out)) {
+    const int vpr = row_bytes / 16;
+    hipLaunchKernelGGL((permute_rows_vec_kernel<SCATTER>), dim3(stream_grid(K * vpr, 256, 8192)), dim3(256), 0,
+                       s, (const uint4*)rows, pos, (uint4*)out, K, vpr);
+  } else if (dtype == TRS_F32) {
+    hipLaunchKernelGGL((permute_rows_elem_kernel<float, SCATTER>), dim3(stream_grid(K * E, 256, 8192)),
+                       dim3(256), 0, s, (const float*)rows, pos, (float*)out, K, E);
+  } else {
+    hipLaunchKernelGGL((permute_rows_elem_kernel<bf16_t, SCATTER>), dim3(stream_grid(K * E, 256, 8192)),
+                       dim3(256), 0, s, (const bf16_t*)rows, pos, (bf16_t*)out, K, E);
+  }
+  return check_launch("permute_rows");
+}
+
+}  // namespace trs
+
+using namespace trs;
+
+extern "C" int trs_version(void) { return TRS_ABI_VERSION; }
+extern "C" const char* trs_last_error_string(void) { return trs::err_buf(); }
+
+extern "C" int trs_gather_rows(const void* table, int64_t V, int32_t E, int32_t dtype, const void* idx,
+                               int32_t idx_dtype, const int64_t* offsets, int64_t B, int32_t N, void* out,
+                               int32_t* err_flag, trs_stream_t stream) {
+  TRS_REQUIRE(table && idx && out, TRS_EINVAL, "gather_rows: NULL pointer");
+  TRS_REQUIRE(V > 0 && E > 0 && B >= 0 && N > 0, TRS_EINVAL, "gather_rows: bad size V=%lld E=%d B=%lld N=%d",
+              (long long)V, E, (long long)B, N);
+  TRS_REQUIRE(dtype == TRS_F32 || dtype == TRS_BF16, TRS_EDTYPE, "gather_rows: dtype %d", dtype);
+  TRS_REQUIRE(idx_dtype == TRS_I64 || idx_dtype == TRS_I32, TRS_EDTYPE, "gather_rows: idx dtype %d", idx_dtype);
+  if (B == 0) return TRS_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (idx_dtype == TRS_I64)
+    return gather_dispatch<int64_t>(table, V, E, dtype, (const int64_t*)idx, offsets, B * N, N, out, err_flag, s);
+  return gather_dispatch<int32_t>(table, V, E, dtype, (const int32_t*)idx, offsets, B * N, N, out, err_flag, s);
+}
+
+template <typename IdxT>
+static int fa_dispatch(const void* const* tables, int64_t V, int E, int dtype, const IdxT* idx,
+                       const int64_t* offsets, int64_t B, int N, void* out, int32_t* err_flag, hipStream_t s) {
+  const int row_bytes = E * dtype_size(dtype);
+  if (row_bytes % 16 == 0 && aligned16(out)) {
+    const int vpr = row_bytes / 16;
+    const int64_t total = B * N * N * vpr;
+    hipLaunchKernelGGL((fa_gather_vec_kernel<IdxT>), dim3(stream_grid(total, 256, 256 * 32)), dim3(256), 0, s,
+                       (const uint4* const*)tables, idx, offsets, (uint4*)out, B, N, vpr, V, err_flag);
+  } else if (dtype == TRS_F32) {
+    const int64_t total = B * N * N * E;
+    hipLaunchKernelGGL((fa_gather_elem_kernel<float, IdxT>), dim3(stream_grid(total, 256, 256 * 32)), dim3(256),
+                       0, s, (const float* const*)tables, idx, offsets, (float*)out, B, N, E, V, err_flag);
+  } else {
+    const int64_t total = B * N * N * E;
+    hipLaunchKernelGGL((fa_gather_elem_kernel<bf16_t, IdxT>), dim3(stream_grid(total, 256, 256 * 32)), dim3(256),
+                       0, s, (const bf16_t* const*)tables, idx, offsets, (bf16_t*)out, B, N, E, V, err_flag);
+  }
+  return check_launch("fa_gather_rows");
+}
+
+extern "C" int trs_fa_gather_rows(const void* const* tables, int64_t V, int32_t E, int32_t dtype,
+                                  const void* idx, int32_t idx_dtype, const int64_t* offsets, int64_t B,
+                                  int32_t N, void* out, int32_t* err_flag, trs_stream_t stream) {
+  TRS_REQUIRE(tables && idx && out, TRS_EINVAL, "fa_gather_rows: NULL pointer");
+  TRS_REQUIRE(V > 0 && E > 0 && B >= 0 && N > 0, TRS_EINVAL, "fa_gather_rows: bad size");
+  TRS_REQUIRE(dtype == TRS_F32 || dtype == TRS_BF16, TRS_EDTYPE, "fa_gather_rows: dtype %d", dtype);
+  TRS_REQUIRE(idx_dtype == TRS_I64 || idx_dtype == TRS_I32, TRS_EDTYPE, "fa_gather_rows: idx dtype %d", idx_dtype);
+  if (B == 0) return TRS_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (idx_dtype == TRS_I64)
+    return fa_dispatch<int64_t>(tables, V, E, dtype, (const int64_t*)idx, offsets, B, N, out, err_flag, s);
+  return fa_dispatch<int32_t>(tables, V, E, dtype, (const int32_t*)idx, offsets, B, N, out, err_flag, s);
+}
+
+extern "C" int trs_scatter_by_pos(const void* rows, const int32_t* pos, int64_t K, int32_t E, int32_t dtype,
+                                  void* out, trs_stream_t stream) {
+  return permute_rows<true>(rows, pos, K, E, dtype, out, (hipStream_t)stream);
+}
+extern "C" int trs_gather_by_pos(const void* rows, const int32_t* pos, int64_t K, int32_t E, int32_t dtype,
+                                 void* out, trs_stream_t stream) {
+  return permute_rows<false>(rows, pos, K, E, dtype, out, (hipStream_t)stream);
+}

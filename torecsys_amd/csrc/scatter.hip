@@ -1,0 +1,435 @@
+// K1 backward: row-bucketed index (CSR) + atomics-free segmented gradient reduction.
+//
+// nn.Embedding's dense gradient (sparse=False) is "zero V x E, then index_add".  Here the B*N lookups
+// are bucketed by destination row once per batch (count -> exclusive scan -> fill; int32 atomics
+// only on the 4-byte counters), then ONE pass writes every row of the gradient exactly once:
+// a group of L lanes (L = 16-byte vectors per row) owns a table row, walks its bucket, accumulates in
+// fp32 and stores once (zeros for rows nobody looked up).  No zero-fill pass, no read-modify-write,
+// no float atomics; the FM second-order backward dx = g*(S - x) is folded into the same walk:
+//   sum_p g_fm[b_p]*(S[b_p] - W[r]) = sum_p g_fm[b_p]*S[b_p]  -  W[r] * sum_p g_fm[b_p].
+// HBM-bound: reads B*N*(E*s + 4) (+ 2*B*E*s L2-resident FM operands), writes V*E*s.
+#include "trs_common.hpp"
+
+namespace trs {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 16;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+// rows with more than LONG_ROW lookups are reduced by a whole workgroup (Zipf-hot rows)
+constexpr int LONG_ROW = 256;
+
+template <typename IdxT>
+__global__ __launch_bounds__(256) void csr_count_kernel(const IdxT* __restrict__ idx,
+                                                        const int64_t* __restrict__ offsets, int64_t BN, int N,
+                                                        int64_t V, int32_t* __restrict__ count,
+                                                        int32_t* __restrict__ slot, int32_t* __restrict__ err_flag) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < BN; p += stride) {
+    const int64_t r = load_row_id(idx, offsets, p, (int)(p % N));
+    if (r < 0 || r >= V) {
+      if (err_flag != nullptr) *err_flag = 1;
+      slot[p] = -1;
+    } else {
+      slot[p] = atomicAdd(&count[r], 1);
+    }
+  }
+}
+
+__device__ __forceinline__ int block_exclusive_scan(int v, int* total, int* lds /* >= 8 ints */) {
+  // inclusive scan inside the wave
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  if (lane == 63) lds[wave] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < SCAN_THREADS / 64; ++w) {
+    const int s = lds[w];
+    if (w < wave) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_tile_sums_kernel(const int32_t* __restrict__ data, int64_t n,
+                                                                      int32_t* __restrict__ tile_sums) {
+  __shared__ int lds[8];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i)
+    if (base + i < n) s += data[base + i];
+  int tot;
+  block_exclusive_scan(s, &tot, lds);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_sums_kernel(int32_t* __restrict__ tile_sums, int ntiles) {
+  __shared__ int lds[8];
+  int carry = 0;
+  for (int t0 = 0; t0 < ntiles; t0 += SCAN_THREADS) {
+    const int i = t0 + threadIdx.x;
+    const int v = i < ntiles ? tile_sums[i] : 0;
+    int tot;
+    const int ex = block_exclusive_scan(v, &tot, lds);
+    if (i < ntiles) tile_sums[i] = carry + ex;
+    carry += tot;
+  }
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(int32_t* __restrict__ data, int64_t n,
+                                                                  const int32_t* __restrict__ tile_sums) {
+  __shared__ int lds[8];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  int v[SCAN_ITEMS];
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    v[i] = base + i < n ? data[base + i] : 0;
+    s += v[i];
+  }
+  int tot;
+  int run = block_exclusive_scan(s, &tot, lds) + tile_sums[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    if (base + i < n) data[base + i] = run;
+    run += v[i];
+  }
+}
+
+template <typename IdxT>
+__global__ __launch_bounds__(256) void csr_fill_kernel(const IdxT* __restrict__ idx,
+                                                       const int64_t* __restrict__ offsets, int64_t BN, int N,
+                                                       const int32_t* __restrict__ row_start,
+                                                       const int32_t* __restrict__ slot, int32_t* __restrict__ perm) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < BN; p += stride) {
+    const int sl = slot[p];
+    if (sl >= 0) {
+      const int64_t r = load_row_id(idx, offsets, p, (int)(p % N));
+      perm[row_start[r] + sl] = (int32_t)p;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// segmented reduction: one L-lane group per table row (rows with > LONG_ROW lookups are deferred
+// to a queue and reduced by whole workgroups afterwards)
+template <typename T, int LOG2L, bool HAS_G, bool HAS_FM>
+__device__ __forceinline__ void accumulate_bucket(float* acc, float* gsum, const uint4* __restrict__ g_rows,
+                                                  const uint4* __restrict__ g_fm, const float* __restrict__ fm_sum,
+                                                  const int32_t* __restrict__ perm, int beg, int end, int step,
+                                                  int N, int64_t gbs, int lane_v) {
+  constexpr int L = 1 << LOG2L;
+  constexpr int VE = Vec16<T>::VE;
+  constexpr int CH = 4;
+  for (int q = beg; q < end; q += CH * step) {
+    int p[CH];
+    uint4 gv[CH], fv[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) p[c] = (q + c * step) < end ? perm[q + c * step] : -1;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      gv[c] = make_uint4(0, 0, 0, 0);
+      fv[c] = make_uint4(0, 0, 0, 0);
+      if (p[c] >= 0) {
+        if (HAS_G) {
+          int64_t row = p[c];
+          if (gbs != N) {  // g_rows is a strided slice: sample b starts at row b*gbs
+            const unsigned b = (unsigned)p[c] / (unsigned)N;
+            row = (int64_t)b * gbs + ((unsigned)p[c] - b * (unsigned)N);
+          }
+          gv[c] = g_rows[row * L + lane_v];
+        }
+        if (HAS_FM) fv[c] = g_fm[(int64_t)((unsigned)p[c] / (unsigned)N) * L + lane_v];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      if (p[c] >= 0) {
+        if (HAS_G) {
+          float x[VE];
+          Vec16<T>::unpack(gv[c], x);
+#pragma unroll
+          for (int k = 0; k < VE; ++k) acc[k] += x[k];
+        }
+        if (HAS_FM) {
+          float gf[VE];
+          Vec16<T>::unpack(fv[c], gf);
+          if (fm_sum != nullptr) {
+            const float* sp = fm_sum + ((int64_t)((unsigned)p[c] / (unsigned)N) * L + lane_v) * VE;
+#pragma unroll
+            for (int k = 0; k < VE; ++k) {
+              acc[k] = fmaf(gf[k], sp[k], acc[k]);
+              gsum[k] += gf[k];
+            }
+          } else {  // plain per-sample broadcast gradient (first-order sum): no FM weighting
+#pragma unroll
+            for (int k = 0; k < VE; ++k) acc[k] += gf[k];
+          }
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int LOG2L, bool HAS_G, bool HAS_FM>
+__global__ __launch_bounds__(256) void scatter_rows_group_kernel(
+    const uint4* __restrict__ g_rows, const uint4* __restrict__ g_fm, const float* __restrict__ fm_sum,
+    const uint4* __restrict__ table, const int32_t* __restrict__ row_start, const int32_t* __restrict__ perm,
+    int64_t V, int N, int64_t gbs, int64_t padding_row, uint4* __restrict__ grad,
+    int32_t* __restrict__ long_rows /* [0]=count */) {
+  constexpr int L = 1 << LOG2L;
+  constexpr int VE = Vec16<T>::VE;
+  const int lane_v = threadIdx.x & (L - 1);
+  const int64_t groups = ((int64_t)gridDim.x * blockDim.x) >> LOG2L;
+  for (int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> LOG2L; r < V; r += groups) {
+    const int beg = row_start[r], end = row_start[r + 1];
+    float acc[VE], gsum[VE];
+#pragma unroll
+    for (int k = 0; k < VE; ++k) { acc[k] = 0.f; gsum[k] = 0.f; }
+    if (end - beg > LONG_ROW && r != padding_row) {
+      if (lane_v == 0) {
+        const int slot = atomicAdd(&long_rows[0], 1);
+        long_rows[1 + slot] = (int32_t)r;
+      }
+      continue;
+    }
+    if (r != padding_row) {
+      accumulate_bucket<T, LOG2L, HAS_G, HAS_FM>(acc, gsum, g_rows, g_fm, fm_sum, perm, beg, end, 1, N, gbs, lane_v);
+      if (HAS_FM && fm_sum != nullptr && end > beg) {
+        float w[VE];
+        Vec16<T>::unpack(table[r * L + lane_v], w);
+#pragma unroll
+        for (int k = 0; k < VE; ++k) acc[k] = fmaf(-w[k], gsum[k], acc[k]);
+      }
+    }
+    grad[r * L + lane_v] = Vec16<T>::pack(acc);
+  }
+}
+
+// hot rows: one 256-thread workgroup per row, groups stride over the bucket, LDS tree reduction
+template <typename T, int LOG2L, bool HAS_G, bool HAS_FM>
+__global__ __launch_bounds__(256) void scatter_long_rows_kernel(
+    const uint4* __restrict__ g_rows, const uint4* __restrict__ g_fm, const float* __restrict__ fm_sum,
+    const uint4* __restrict__ table, const int32_t* __restrict__ row_start, const int32_t* __restrict__ perm, int N,
+    int64_t gbs, uint4* __restrict__ grad, const int32_t* __restrict__ long_rows) {
+  constexpr int L = 1 << LOG2L;
+  constexpr int VE = Vec16<T>::VE;
+  constexpr int G = 256 / L;  // groups per workgroup
+  __shared__ float red[2][256][VE];
+  const int lane_v = threadIdx.x & (L - 1);
+  const int grp = threadIdx.x >> LOG2L;
+  const int nlong = long_rows[0];
+  for (int i = blockIdx.x; i < nlong; i += gridDim.x) {
+    const int64_t r = long_rows[1 + i];
+    const int beg = row_start[r], end = row_start[r + 1];
+    float acc[VE], gsum[VE];
+#pragma unroll
+    for (int k = 0; k < VE; ++k) { acc[k] = 0.f; gsum[k] = 0.f; }
+    accumulate_bucket<T, LOG2L, HAS_G, HAS_FM>(acc, gsum, g_rows, g_fm, fm_sum, perm, beg + grp, end, G, N, gbs, lane_v);
+#pragma unroll
+    for (int k = 0; k < VE; ++k) { red[0][threadIdx.x][k] = acc[k]; red[1][threadIdx.x][k] = gsum[k]; }
+    __syncthreads();
+    for (int h = G >> 1; h >= 1; h >>= 1) {
+      if (grp < h) {
+#pragma unroll
+        for (int k = 0; k < VE; ++k) {
+          red[0][threadIdx.x][k] += red[0][threadIdx.x + h * L][k];
+          red[1][threadIdx.x][k] += red[1][threadIdx.x + h * L][k];
+        }
+      }
+      __syncthreads();
+    }
+    if (grp == 0) {
+#pragma unroll
+      for (int k = 0; k < VE; ++k) { acc[k] = red[0][threadIdx.x][k]; gsum[k] = red[1][threadIdx.x][k]; }
+      if (HAS_FM && fm_sum != nullptr) {
+        float w[VE];
+        Vec16<T>::unpack(table[r * L + lane_v], w);
+#pragma unroll
+        for (int k = 0; k < VE; ++k) acc[k] = fmaf(-w[k], gsum[k], acc[k]);
+      }
+      grad[r * L + lane_v] = Vec16<T>::pack(acc);
+    }
+    __syncthreads();
+  }
+}
+
+// generic element path (any E): one thread per (row, e)
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_rows_elem_kernel(
+    const T* __restrict__ g_rows, const T* __restrict__ g_fm, const float* __restrict__ fm_sum,
+    const T* __restrict__ table, const int32_t* __restrict__ row_start, const int32_t* __restrict__ perm, int64_t V,
+    int E, int N, int64_t gbs, int64_t padding_row, T* __restrict__ grad) {
+  const int64_t total = V * E;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t r = t / E;
+    const int e = (int)(t - r * E);
+    float acc = 0.f, gsum = 0.f;
+    if (r != padding_row) {
+      const int beg = row_start[r], end = row_start[r + 1];
+      for (int q = beg; q < end; ++q) {
+        const int64_t p = perm[q];
+        const int64_t b = p / N;
+        if (g_rows != nullptr) acc += to_f32(g_rows[(b * gbs + (p - b * N)) * E + e]);
+        if (g_fm != nullptr) {
+          const float gf = to_f32(g_fm[b * E + e]);
+          if (fm_sum != nullptr) {
+            acc = fmaf(gf, fm_sum[b * E + e], acc);
+            gsum += gf;
+          } else {
+            acc += gf;
+          }
+        }
+      }
+      if (g_fm != nullptr && fm_sum != nullptr && end > beg) acc = fmaf(-to_f32(table[t]), gsum, acc);
+    }
+    grad[t] = from_f32<T>(acc);
+  }
+}
+
+static int log2_lanes_sc(int row_bytes) {
+  if (row_bytes % 16 != 0) return -1;
+  const int L = row_bytes / 16;
+  if (!is_pow2(L) || L > 64) return -1;
+  int l = 0;
+  while ((1 << l) < L) ++l;
+  return l;
+}
+
+template <typename T, int LOG2L>
+static void scatter_group_launch(const void* g_rows, const void* g_fm, const float* fm_sum, const void* table,
+                                 const int32_t* row_start, const int32_t* perm, int64_t V, int N, int64_t gbs,
+                                 int64_t padding_row, void* grad, int32_t* long_rows, hipStream_t s) {
+  const int L = 1 << LOG2L;
+  const int grid = stream_grid(V * L, 256, 256 * 32);
+  const bool hg = g_rows != nullptr, hf = g_fm != nullptr;
+#define TRS_SC(HG, HF)                                                                                          \
+  do {                                                                                                          \
+    hipLaunchKernelGGL((scatter_rows_group_kernel<T, LOG2L, HG, HF>), dim3(grid), dim3(256), 0, s,               \
+                       (const uint4*)g_rows, (const uint4*)g_fm, fm_sum, (const uint4*)table, row_start, perm, V, \
+                       N, gbs, padding_row, (uint4*)grad, long_rows);                                                 \
+    hipLaunchKernelGGL((scatter_long_rows_kernel<T, LOG2L, HG, HF>), dim3(512), dim3(256), 0, s,                 \
+                       (const uint4*)g_rows, (const uint4*)g_fm, fm_sum, (const uint4*)table, row_start, perm, N, \
+                       gbs, (uint4*)grad, long_rows);                                                                 \
+  } while (0)
+  if (hg && hf) TRS_SC(true, true);
+  else if (hg) TRS_SC(true, false);
+  else TRS_SC(false, true);
+#undef TRS_SC
+}
+
+template <typename T>
+static int scatter_launch(const void* g_rows, const void* g_fm, const float* fm_sum, const void* table,
+                          const int32_t* row_start, const int32_t* perm, int64_t V, int E, int N, int64_t gbs,
+                          int64_t padding_row, void* grad, int32_t* long_rows, hipStream_t s) {
+  const int lg = log2_lanes_sc(E * (int)sizeof(T));
+  const bool al = aligned16(g_rows) && aligned16(g_fm) && aligned16(table) && aligned16(grad) && aligned16(fm_sum);
+  if (lg >= 0 && al) {
+    switch (lg) {
+      case 0: scatter_group_launch<T, 0>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, s); break;
+      case 1: scatter_group_launch<T, 1>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, s); break;
+      case 2: scatter_group_launch<T, 2>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, s); break;
+      case 3: scatter_group_launch<T, 3>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, s); break;
+      case 4: scatter_group_launch<T, 4>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, s); break;
+      case 5: scatter_group_launch<T, 5>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, s); break;
+      default: scatter_group_launch<T, 6>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, s); break;
+    }
+  } else {
+    hipLaunchKernelGGL((scatter_rows_elem_kernel<T>), dim3(stream_grid(V * E, 256, 256 * 32)), dim3(256), 0, s,
+                       (const T*)g_rows, (const T*)g_fm, fm_sum, (const T*)table, row_start, perm, V, E, N, gbs,
+                       padding_row, (T*)grad);
+  }
+  return check_launch("scatter_rows");
+}
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace trs
+
+using namespace trs;
+
+// workspace layout for csr_build: [slot: BN int32][tile_sums: ntiles int32]
+extern "C" size_t trs_csr_workspace_bytes(int64_t V, int64_t BN) {
+  const size_t ntiles = (size_t)((V + 1 + SCAN_TILE - 1) / SCAN_TILE);
+  return align_up((size_t)BN * 4, 256) + align_up(ntiles * 4, 256) + 256;
+}
+
+extern "C" int trs_csr_build(const void* idx, int32_t idx_dtype, const int64_t* offsets, int64_t B, int32_t N,
+                             int64_t V, int32_t* row_start, int32_t* perm, void* workspace, size_t ws_bytes,
+                             int32_t* err_flag, trs_stream_t stream) {
+  TRS_REQUIRE(idx && row_start && perm && workspace, TRS_EINVAL, "csr_build: NULL pointer");
+  TRS_REQUIRE(V > 0 && B >= 0 && N > 0, TRS_EINVAL, "csr_build: bad size");
+  TRS_REQUIRE(idx_dtype == TRS_I64 || idx_dtype == TRS_I32, TRS_EDTYPE, "csr_build: idx dtype %d", idx_dtype);
+  const int64_t BN = B * N;
+  TRS_REQUIRE(BN < (int64_t)0x7fffffff && V < (int64_t)0x7ffffffe, TRS_ESHAPE,
+              "csr_build: B*N and V must fit int32 (B*N=%lld V=%lld)", (long long)BN, (long long)V);
+  TRS_REQUIRE(ws_bytes >= trs_csr_workspace_bytes(V, BN), TRS_EWORKSPACE, "csr_build: workspace %zu < %zu", ws_bytes,
+              trs_csr_workspace_bytes(V, BN));
+  hipStream_t s = (hipStream_t)stream;
+  int32_t* slot = (int32_t*)workspace;
+  int32_t* tile_sums = (int32_t*)((char*)workspace + align_up((size_t)BN * 4, 256));
+  const int64_t n = V + 1;
+  const int ntiles = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
+  if (hipMemsetAsync(row_start, 0, (size_t)n * 4, s) != hipSuccess) return check_launch("csr_build(memset)");
+  if (BN > 0) {
+    const int grid = stream_grid(BN, 256, 256 * 16);
+    if (idx_dtype == TRS_I64)
+      hipLaunchKernelGGL((csr_count_kernel<int64_t>), dim3(grid), dim3(256), 0, s, (const int64_t*)idx, offsets, BN, N,
+                         V, row_start, slot, err_flag);
+    else
+      hipLaunchKernelGGL((csr_count_kernel<int32_t>), dim3(grid), dim3(256), 0, s, (const int32_t*)idx, offsets, BN, N,
+                         V, row_start, slot, err_flag);
+  }
+  hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(ntiles), dim3(SCAN_THREADS), 0, s, row_start, n, tile_sums);
+  hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, tile_sums, ntiles);
+  hipLaunchKernelGGL(scan_apply_kernel, dim3(ntiles), dim3(SCAN_THREADS), 0, s, row_start, n, tile_sums);
+  if (BN > 0) {
+    const int grid = stream_grid(BN, 256, 256 * 16);
+    if (idx_dtype == TRS_I64)
+      hipLaunchKernelGGL((csr_fill_kernel<int64_t>), dim3(grid), dim3(256), 0, s, (const int64_t*)idx, offsets, BN, N,
+                         row_start, slot, perm);
+    else
+      hipLaunchKernelGGL((csr_fill_kernel<int32_t>), dim3(grid), dim3(256), 0, s, (const int32_t*)idx, offsets, BN, N,
+                         row_start, slot, perm);
+  }
+  return check_launch("csr_build");
+}
+
+extern "C" size_t trs_scatter_workspace_bytes(int64_t BN) {
+  // queue of hot rows: at most BN / LONG_ROW of them, + the counter
+  return align_up((size_t)(BN / LONG_ROW + 2) * 4, 256);
+}
+
+extern "C" int trs_scatter_rows(const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm,
+                                const float* fm_sum, const void* table, const int32_t* row_start,
+                                const int32_t* perm, int64_t BN, int64_t V, int32_t E, int32_t N, int32_t dtype,
+                                int64_t padding_row, void* grad_table, void* workspace, size_t ws_bytes,
+                                trs_stream_t stream) {
+  TRS_REQUIRE(row_start && perm && grad_table && workspace, TRS_EINVAL, "scatter_rows: NULL pointer");
+  TRS_REQUIRE(g_rows || g_fm, TRS_EINVAL, "scatter_rows: need g_rows and/or g_fm");
+  TRS_REQUIRE((fm_sum == nullptr) || (g_fm && table), TRS_EINVAL, "scatter_rows: fm_sum needs g_fm and table");
+  const int64_t gbs = g_rows_batch_stride > 0 ? g_rows_batch_stride : N;
+  TRS_REQUIRE(gbs >= N, TRS_EINVAL, "scatter_rows: g_rows_batch_stride %lld < N", (long long)gbs);
+  TRS_REQUIRE(V > 0 && E > 0 && N > 0 && BN >= 0, TRS_EINVAL, "scatter_rows: bad size");
+  TRS_REQUIRE(dtype == TRS_F32 || dtype == TRS_BF16, TRS_EDTYPE, "scatter_rows: dtype %d", dtype);
+  TRS_REQUIRE(ws_bytes >= trs_scatter_workspace_bytes(BN), TRS_EWORKSPACE, "scatter_rows: workspace %zu < %zu",
+              ws_bytes, trs_scatter_workspace_bytes(BN));
+  hipStream_t s = (hipStream_t)stream;
+  int32_t* long_rows = (int32_t*)workspace;
+  if (hipMemsetAsync(long_rows, 0, 4, s) != hipSuccess) return check_launch("scatter_rows(memset)");
+  if (dtype == TRS_F32)
+    return scatter_launch<float>(g_rows, g_fm, fm_sum, table, row_start, perm, V, E, N, gbs, padding_row,
+                                 grad_table, long_rows, s);
+  return scatter_launch<bf16_t>(g_rows, g_fm, fm_sum, table, row_start, perm, V, E, N, gbs, padding_row, grad_table,
+                                long_rows, s);
+}

@@ -1,0 +1,300 @@
+"""Functional layer: torch.autograd.Functions whose forward/backward are calls into libtrs_hip.so.
+
+Every function takes and returns UN-NAMED tensors on one HIP device (the nn.Modules in
+``inputs.py`` / ``layers.py`` strip and re-apply the reference's tensor names).  There is no CPU path.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _abi
+from ._abi import call, index_dtype_code, ptr, require_device, size_query, stream_ptr, value_dtype_code
+
+CHECK_INDICES = os.environ.get("TRS_CHECK_INDICES", "0") not in ("", "0")
+
+
+def _as_index(idx: torch.Tensor) -> torch.Tensor:
+    """Indices are consumed as int64 or int32 directly (the reference's ``.long()`` /
+    int64-promotion happens inside the kernel); other int dtypes are widened here."""
+    idx = idx.rename(None) if idx.has_names() else idx
+    if idx.dtype not in (torch.int64, torch.int32):
+        if idx.dtype.is_floating_point or idx.dtype == torch.bool:
+            raise TypeError(f"indices must be an integer tensor, got {idx.dtype}")
+        idx = idx.long()
+    return idx.contiguous()
+
+
+class _ErrFlag:
+    def __init__(self, dev):
+        self.t = torch.zeros(1, dtype=torch.int32, device=dev) if CHECK_INDICES else None
+
+    def check(self, what):
+        if self.t is not None and int(self.t.item()) != 0:
+            raise IndexError(f"{what}: index out of range in self")
+
+
+# --------------------------------------------------------------------------------------------
+# Row-bucketed index of one batch (CSR over destination rows), shared by every table looked up
+# with the same index tensor (E=64 embeddings and the E=1 first-order weights).
+# --------------------------------------------------------------------------------------------
+class RowBuckets:
+    __slots__ = ("row_start", "perm", "V", "BN", "N")
+
+    def __init__(self, row_start, perm, V, BN, N):
+        self.row_start, self.perm, self.V, self.BN, self.N = row_start, perm, V, BN, N
+
+
+_bucket_cache: List[tuple] = []   # [(key, idx_tensor_kept_alive, RowBuckets)]
+_BUCKET_CACHE_SIZE = 2
+
+
+def row_buckets(idx: torch.Tensor, offsets: Optional[torch.Tensor], V: int) -> RowBuckets:
+    """Build (or fetch) the CSR for ``idx`` (B,N).  The cache keeps a reference to the index tensor,
+    so its storage cannot be recycled for another batch while the entry is live; in-place edits bump
+    ``_version`` and miss."""
+    key = (idx.data_ptr(), idx._version, tuple(idx.shape), idx.dtype, 0 if offsets is None else offsets.data_ptr(), V)
+    for k, _, rb in _bucket_cache:
+        if k == key:
+            return rb
+    B, N = idx.shape
+    BN = B * N
+    dev = idx.device
+    row_start = torch.empty(V + 1, dtype=torch.int32, device=dev)
+    perm = torch.empty(max(BN, 1), dtype=torch.int32, device=dev)
+    ws_bytes = size_query("trs_csr_workspace_bytes", V, BN)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    flag = _ErrFlag(dev)
+    call("trs_csr_build", ptr(idx), index_dtype_code(idx), ptr(offsets), B, N, V, ptr(row_start), ptr(perm),
+         ptr(ws), ws_bytes, ptr(flag.t), stream_ptr())
+    flag.check("row_buckets")
+    rb = RowBuckets(row_start, perm, V, BN, N)
+    _bucket_cache.append((key, idx, rb))
+    if len(_bucket_cache) > _BUCKET_CACHE_SIZE:
+        _bucket_cache.pop(0)
+    return rb
+
+
+def clear_caches():
+    _bucket_cache.clear()
+
+
+def scatter_rows(rb: RowBuckets, like_table: torch.Tensor, g_rows: Optional[torch.Tensor] = None,
+                 g_bcast: Optional[torch.Tensor] = None, fm_sum: Optional[torch.Tensor] = None,
+                 padding_row: int = -1, g_rows_batch_stride: int = 0) -> torch.Tensor:
+    """Dense gradient of a (V,E) table: see trs_scatter_rows in include/trs_abi.h."""
+    V, E = like_table.shape
+    grad = torch.empty_like(like_table)
+    ws_bytes = size_query("trs_scatter_workspace_bytes", rb.BN)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=like_table.device)
+    call("trs_scatter_rows", ptr(g_rows), g_rows_batch_stride, ptr(g_bcast), ptr(fm_sum),
+         ptr(like_table if fm_sum is not None else None), ptr(rb.row_start), ptr(rb.perm), rb.BN, V, E, rb.N,
+         value_dtype_code(like_table), padding_row, ptr(grad), ptr(ws), ws_bytes, stream_ptr())
+    return grad
+
+
+# --------------------------------------------------------------------------------------------
+# K1: gather
+# --------------------------------------------------------------------------------------------
+class _GatherRows(Function):
+    @staticmethod
+    def forward(ctx, weight, idx, offsets, padding_idx):
+        require_device(weight, idx, offsets)
+        B, N = idx.shape
+        V, E = weight.shape
+        w = weight.contiguous()
+        out = torch.empty(B, N, E, dtype=w.dtype, device=w.device)
+        flag = _ErrFlag(w.device)
+        call("trs_gather_rows", ptr(w), V, E, value_dtype_code(w), ptr(idx), index_dtype_code(idx), ptr(offsets),
+             B, N, ptr(out), ptr(flag.t), stream_ptr())
+        flag.check("gather_rows")
+        ctx.save_for_backward(idx, offsets, weight)
+        ctx.padding_idx = -1 if padding_idx is None else int(padding_idx)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        idx, offsets, weight = ctx.saved_tensors
+        rb = row_buckets(idx, offsets, weight.shape[0])
+        grad = scatter_rows(rb, weight, g_rows=g.contiguous(), padding_row=ctx.padding_idx)
+        return grad, None, None, None
+
+
+def gather_rows(weight: torch.Tensor, idx: torch.Tensor, offsets: Optional[torch.Tensor] = None,
+                padding_idx: Optional[int] = None) -> torch.Tensor:
+    """out[b,n,:] = weight[idx[b,n] + offsets[n], :]; dense-gradient backward."""
+    idx = _as_index(idx)
+    if idx.dim() == 1:
+        idx = idx.unsqueeze(-1)
+    if idx.dim() != 2:
+        raise ValueError(f"indices must be (B, N), got shape {tuple(idx.shape)}")
+    if padding_idx is not None and padding_idx < 0:
+        padding_idx = weight.shape[0] + padding_idx
+    return _GatherRows.apply(weight, idx, offsets, padding_idx)
+
+
+# --------------------------------------------------------------------------------------------
+# K1+K2(+K8): fused lookup + FM (+ first-order sum)
+# --------------------------------------------------------------------------------------------
+class _EmbedFM(Function):
+    @staticmethod
+    def forward(ctx, weight, idx, offsets, first_weight, want_emb):
+        require_device(weight, idx, offsets, first_weight)
+        B, N = idx.shape
+        V, E = weight.shape
+        w = weight.contiguous()
+        dev = w.device
+        emb = torch.empty(B, N, E, dtype=w.dtype, device=dev) if want_emb else None
+        fm = torch.empty(B, E, dtype=w.dtype, device=dev)
+        fm_sum = torch.empty(B, E, dtype=torch.float32, device=dev)
+        first = None
+        fw = None
+        if first_weight is not None:
+            if first_weight.dtype != w.dtype or first_weight.numel() != V:
+                raise ValueError("first-order table must be (V,1) with the embedding table's dtype")
+            fw = first_weight.contiguous()
+            first = torch.empty(B, 1, dtype=w.dtype, device=dev)
+        flag = _ErrFlag(dev)
+        call("trs_embed_fm", ptr(w), V, E, value_dtype_code(w), ptr(idx), index_dtype_code(idx), ptr(offsets), B, N,
+             ptr(emb), ptr(fm), ptr(fm_sum), ptr(fw), ptr(first), ptr(flag.t), stream_ptr())
+        flag.check("embed_fm")
+        ctx.save_for_backward(idx, offsets, weight, first_weight, fm_sum)
+        ctx.want_emb = want_emb
+        ctx.set_materialize_grads(False)   # unused outputs arrive as None, not as zero blocks
+        outs = (emb if want_emb else fm.new_empty(0), fm, first if first is not None else fm.new_empty(0))
+        if not want_emb:
+            ctx.mark_non_differentiable(outs[0])
+        if first is None:
+            ctx.mark_non_differentiable(outs[2])
+        return outs
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_emb, g_fm, g_first):
+        idx, offsets, weight, first_weight, fm_sum = ctx.saved_tensors
+        V = weight.shape[0]
+        rb = row_buckets(idx, offsets, V)
+        gw = gfw = None
+        if ctx.needs_input_grad[0]:
+            has_emb = ctx.want_emb and g_emb is not None
+            has_fm = g_fm is not None
+            if has_emb or has_fm:
+                gw = scatter_rows(rb, weight, g_rows=g_emb.contiguous() if has_emb else None,
+                                  g_bcast=g_fm.contiguous() if has_fm else None, fm_sum=fm_sum if has_fm else None)
+            else:
+                gw = torch.zeros_like(weight)
+        if first_weight is not None and ctx.needs_input_grad[3]:
+            if g_first is not None:
+                gfw = scatter_rows(rb, first_weight.reshape(V, 1), g_bcast=g_first.contiguous().reshape(-1, 1))
+                gfw = gfw.reshape(first_weight.shape)
+            else:
+                gfw = torch.zeros_like(first_weight)
+        return gw, None, None, gfw, None
+
+
+def embed_fm(weight: torch.Tensor, idx: torch.Tensor, offsets: Optional[torch.Tensor] = None,
+             first_weight: Optional[torch.Tensor] = None, want_emb: bool = True
+             ) -> Tuple[Optional[torch.Tensor], torch.Tensor, Optional[torch.Tensor]]:
+    """One pass over the looked-up rows: (emb (B,N,E) | None, fm (B,E), first (B,1) | None)."""
+    idx = _as_index(idx)
+    if idx.dim() != 2:
+        raise ValueError(f"indices must be (B, N), got shape {tuple(idx.shape)}")
+    emb, fm, first = _EmbedFM.apply(weight, idx, offsets, first_weight, want_emb)
+    return (emb if want_emb else None), fm, (first if first_weight is not None else None)
+
+
+# --------------------------------------------------------------------------------------------
+# K2: FM on a materialised block
+# --------------------------------------------------------------------------------------------
+class _FMLayer(Function):
+    @staticmethod
+    def forward(ctx, x):
+        require_device(x)
+        x = x.contiguous()
+        B, N, E = x.shape
+        fm = torch.empty(B, E, dtype=x.dtype, device=x.device)
+        fm_sum = torch.empty(B, E, dtype=torch.float32, device=x.device)
+        call("trs_fm_fwd", ptr(x), B, N, E, value_dtype_code(x), ptr(fm), ptr(fm_sum), stream_ptr())
+        ctx.save_for_backward(x, fm_sum)
+        return fm
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, fm_sum = ctx.saved_tensors
+        B, N, E = x.shape
+        dx = torch.empty_like(x)
+        call("trs_fm_bwd", ptr(x), ptr(g.contiguous()), ptr(fm_sum), B, N, E, value_dtype_code(x), ptr(dx),
+             stream_ptr())
+        return dx
+
+
+def fm_layer(x: torch.Tensor) -> torch.Tensor:
+    if x.dim() != 3:
+        raise ValueError(f"FM input must be (B, N, E), got {tuple(x.shape)}")
+    return _FMLayer.apply(x)
+
+
+# --------------------------------------------------------------------------------------------
+# I3: field-aware gather  (B,N) -> (B,N*N,E)
+# --------------------------------------------------------------------------------------------
+_ptr_table_cache = {}
+
+
+def _pointer_table(tensors: Sequence[torch.Tensor]) -> torch.Tensor:
+    """Device array of base pointers (cached per pointer tuple: a blocking 8*N-byte upload otherwise)."""
+    key = tuple(t.data_ptr() for t in tensors)
+    tab = _ptr_table_cache.get(key)
+    if tab is None:
+        if len(_ptr_table_cache) > 64:
+            _ptr_table_cache.clear()
+        tab = torch.tensor(key, dtype=torch.int64, device=tensors[0].device)
+        _ptr_table_cache[key] = tab
+    return tab
+
+
+class _FAGather(Function):
+    @staticmethod
+    def forward(ctx, idx, offsets, *weights):
+        require_device(idx, offsets, *weights)
+        B, N = idx.shape
+        if len(weights) != N:
+            raise ValueError(f"need {N} tables, got {len(weights)}")
+        V, E = weights[0].shape
+        ws = [w.contiguous() for w in weights]
+        for w in ws:
+            if w.shape != (V, E) or w.dtype != ws[0].dtype:
+                raise ValueError("field-aware tables must share shape and dtype")
+        out = torch.empty(B, N * N, E, dtype=ws[0].dtype, device=ws[0].device)
+        flag = _ErrFlag(out.device)
+        call("trs_fa_gather_rows", ptr(_pointer_table(ws)), V, E, value_dtype_code(ws[0]), ptr(idx),
+             index_dtype_code(idx), ptr(offsets), B, N, ptr(out), ptr(flag.t), stream_ptr())
+        flag.check("fa_gather_rows")
+        ctx.save_for_backward(idx, offsets, *weights)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        idx, offsets, *weights = ctx.saved_tensors
+        B, N = idx.shape
+        V, E = weights[0].shape
+        g = g.contiguous()
+        rb = row_buckets(idx, offsets, V)
+        grads = []
+        for i, w in enumerate(weights):
+            if ctx.needs_input_grad[2 + i]:
+                grads.append(scatter_rows(rb, w, g_rows=g[:, i * N:(i + 1) * N], g_rows_batch_stride=N * N))
+            else:
+                grads.append(None)
+        return (None, None, *grads)
+
+
+def fa_gather_rows(weights: Sequence[torch.Tensor], idx: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
+    idx = _as_index(idx)
+    return _FAGather.apply(idx, offsets, *weights)

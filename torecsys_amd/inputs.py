@@ -1,0 +1,212 @@
+"""Drop-in index -> embedding input modules (same class names, constructor / forward signatures,
+output names and ``state_dict`` keys as ``torecsys.inputs.base``), running on libtrs_hip.so.
+
+Reference: torecsys/inputs/base/{__init__,single_index_emb,multi_indices_emb,
+multi_indices_field_aware_emb}.py and torecsys/inputs/inputs.py.  Class ``__name__``s are kept
+identical because ``Inputs.forward`` dispatches on them (inputs.py:70,84).
+"""
+from __future__ import annotations
+
+from collections import namedtuple
+from typing import Dict, List, Optional, Union
+
+import torch
+import torch.nn as nn
+
+from . import functional as F_
+
+
+def _strip(t: torch.Tensor) -> torch.Tensor:
+    return t.rename(None) if t.has_names() else t
+
+
+def _check_embedding_kwargs(kwargs: dict):
+    # nn.Embedding options the HIP path does not implement are rejected instead of silently ignored
+    if kwargs.get("max_norm") is not None:
+        raise NotImplementedError("torecsys_amd: nn.Embedding(max_norm=...) is not supported")
+    if kwargs.get("scale_grad_by_freq"):
+        raise NotImplementedError("torecsys_amd: nn.Embedding(scale_grad_by_freq=True) is not supported")
+    if kwargs.get("sparse"):
+        raise NotImplementedError("torecsys_amd: nn.Embedding(sparse=True) is not supported (dense gradient only)")
+
+
+def field_offsets(field_sizes: List[int]) -> torch.Tensor:
+    """(N,) int64 row offsets ``(0, *cumsum(field_sizes)[:-1])`` -- multi_indices_emb.py:54.
+    Computed in int64 (the reference goes through float32 and is exact only below 2**24 rows)."""
+    sizes = torch.as_tensor(list(field_sizes), dtype=torch.int64)
+    return torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(sizes, 0)[:-1]])
+
+
+class BaseInput(nn.Module):
+    """inputs/base/__init__.py:11-45."""
+
+    def __init__(self):
+        super().__init__()
+        self.schema = None
+
+    def __len__(self) -> int:
+        return self.length
+
+    def set_schema(self, inputs: Union[str, List[str]], **kwargs):
+        if isinstance(inputs, str):
+            inputs = [inputs]
+        schema = namedtuple('Schema', ['inputs'])
+        self.schema = schema(inputs=inputs)
+
+
+class SingleIndexEmbedding(BaseInput):
+    """single_index_emb.py:14-59: (B,1)|(B,N) any-int indices -> (B,N,E) named ('B','N','E')."""
+
+    def __init__(self, embed_size: int, field_size: int, padding_idx: Optional[int] = None,
+                 nn_embedding: Optional[nn.Parameter] = None, **kwargs):
+        super().__init__()
+        _check_embedding_kwargs(kwargs)
+        if nn_embedding is not None:
+            embed_size = nn_embedding.size('E') if nn_embedding.has_names() else nn_embedding.size(-1)
+            self.embedding = nn.Embedding.from_pretrained(_strip(nn_embedding))
+        else:
+            self.embedding = nn.Embedding(field_size, embed_size, padding_idx=padding_idx, **kwargs)
+        self.length = embed_size
+
+    def forward(self, inputs: torch.Tensor) -> torch.Tensor:
+        out = F_.gather_rows(self.embedding.weight, inputs, None, self.embedding.padding_idx)
+        out.names = ('B', 'N', 'E',)
+        return out
+
+
+class MultiIndicesEmbedding(BaseInput):
+    """multi_indices_emb.py:18-112: one ``sum(field_sizes) x E`` table, per-field offsets,
+    (B,N) -> (B,N,E) (or (B,1,N*E) when ``flatten``).
+
+    ``offsets`` is a non-persistent buffer (same ``state_dict`` as the reference -- only
+    ``embedding.weight`` -- but it follows ``.to()``).  With ``fuse_fm=True`` the lookup
+    kernel also produces the FM second-order term of the same rows and leaves it on the returned tensor
+    for ``FactorizationMachineLayer`` to pick up (one pass over the rows instead of two)."""
+
+    def __init__(self, embed_size: Optional[int] = None, field_sizes: Optional[List[int]] = None,
+                 nn_embedding: Optional[nn.Parameter] = None, device: str = 'cpu',
+                 flatten: Optional[bool] = False, fuse_fm: bool = False, **kwargs):
+        super().__init__()
+        _check_embedding_kwargs(kwargs)
+        if nn_embedding is not None:
+            self.embedding = nn.Embedding.from_pretrained(_strip(nn_embedding))
+        elif field_sizes is not None and embed_size is not None:
+            self.embedding = nn.Embedding(sum(field_sizes), embed_size, **kwargs)
+        else:
+            raise ValueError('missing required arguments')
+        if field_sizes is None:
+            raise ValueError('missing required arguments')
+        self.register_buffer('offsets', field_offsets(field_sizes), persistent=False)
+        self.flatten = flatten
+        self.fuse_fm = fuse_fm
+        self.field_size = self.embedding.num_embeddings
+        self.embed_size = self.embedding.embedding_dim
+        self.padding_idx = self.embedding.padding_idx
+        self.length = self.embed_size * len(field_sizes) if self.flatten else self.embed_size
+        self.to(device)
+
+    def forward(self, inputs: torch.Tensor) -> torch.Tensor:
+        idx = _strip(inputs)
+        if idx.dim() != 2 or idx.shape[1] != self.offsets.numel():
+            raise ValueError(f'inputs must be (B, {self.offsets.numel()}), got {tuple(idx.shape)}')
+        if self.fuse_fm and not self.flatten:
+            out, fm, _ = F_.embed_fm(self.embedding.weight, idx, self.offsets)
+            out._trs_fused_fm = (fm, out._version)
+        else:
+            out = F_.gather_rows(self.embedding.weight, idx, self.offsets, self.padding_idx)
+        if self.flatten:
+            out = out.reshape(out.shape[0], 1, -1)
+        out.names = ('B', 'N', 'E',)
+        return out
+
+
+class MultiIndicesFieldAwareEmbedding(BaseInput):
+    """multi_indices_field_aware_emb.py:24-111: N tables (xavier-uniform), (B,N) -> (B,N*N,E);
+    row i*N+j = table i looked up with field j's index."""
+
+    def __init__(self, embed_size: int, field_sizes: List[int], device: str = 'cpu',
+                 flatten: Optional[bool] = False):
+        super().__init__()
+        self.num_fields = len(field_sizes)
+        self.embeddings = nn.ModuleList([
+            nn.Embedding(sum(field_sizes), embed_size) for _ in range(self.num_fields)
+        ])
+        for embedding in self.embeddings:
+            nn.init.xavier_uniform_(embedding.weight.data)
+        self.register_buffer('offsets', field_offsets(field_sizes), persistent=False)
+        self.flatten = flatten
+        self.length = embed_size
+        self.to(device)
+
+    def forward(self, inputs: torch.Tensor) -> torch.Tensor:
+        idx = _strip(inputs)
+        if idx.dim() != 2 or idx.shape[1] != self.num_fields:
+            raise ValueError(f'inputs must be (B, {self.num_fields}), got {tuple(idx.shape)}')
+        out = F_.fa_gather_rows([e.weight for e in self.embeddings], idx, self.offsets)
+        if self.flatten:
+            out = out.reshape(out.shape[0], 1, -1)
+        out.names = ('B', 'N', 'E',)
+        return out
+
+
+class ValueInput(BaseInput):
+    """inputs/base/value_inp.py:26-44 (pass-through; no kernel)."""
+
+    def __init__(self, num_fields: int, transforms=None):
+        super().__init__()
+        self.num_fields = num_fields
+        self.transforms = transforms
+        self.length = 1
+
+    def forward(self, inputs: torch.Tensor) -> torch.Tensor:
+        inputs = _strip(inputs)
+        if inputs.dim() == 2:
+            inputs = inputs.unsqueeze(dim=-1)
+        if self.transforms:
+            inputs = self.transforms(inputs)
+        inputs.names = ('B', 'N', 'E',)
+        return inputs
+
+
+class Inputs(BaseInput):
+    """Dictionary router, inputs/inputs.py:56-89: for every schema entry gather its named columns,
+    ``unsqueeze`` 1-D ones, ``cat`` on dim 1 and call the embedding module."""
+
+    def __init__(self, schema: Union[Dict[str, nn.Module], None]):
+        super().__init__()
+        self.schema = schema if schema is not None else {}
+        for k, emb_fn in self.schema.items():
+            self.add_module(k, emb_fn)
+        self.length = None
+
+    def forward(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        outputs = {}
+        for k, emb_fn in self.schema.items():
+            if emb_fn.__class__.__name__ in ['ConcatInput', 'StackedInput']:
+                inp_args = [{i: inputs[i] for i in emb_fn.schema.inputs}]
+            else:
+                cols = []
+                for emb_k in emb_fn.schema.inputs:
+                    v = inputs[emb_k]
+                    cols.append(v.unsqueeze(-1) if v.dim() == 1 else v)
+                inp_args = [cols[0] if len(cols) == 1 else torch.cat(cols, dim=1)]
+            outputs[k] = emb_fn(*inp_args)
+        return outputs
+
+    def add_inputs(self, name: Optional[str] = None, model: Optional[nn.Module] = None,
+                   schema: Optional[Dict[str, nn.Module]] = None):
+        if schema is not None:
+            if not isinstance(schema, dict):
+                raise TypeError(f'type of schema is not allowed, given {type(schema).__name__}')
+            for name, model in schema.items():
+                self.add_inputs(name=name, model=model)
+        else:
+            if not isinstance(name, str):
+                raise TypeError(f'type of name is not allowed, given {type(name).__name__}')
+            if name in self.schema:
+                raise AssertionError(f'Given {name} is defined in the schema.')
+            if not isinstance(model, nn.Module):
+                raise TypeError(f'type of model is not not allowed, given {type(model).__name__}')
+            self.schema.update([(name, model)])
+            self.add_module(name, model)
+        return self
