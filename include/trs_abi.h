@@ -143,15 +143,16 @@ int trs_ffm_fused_fwd(const void* const* tables, int64_t V, int32_t E, int32_t d
 /* ---- K4: cross network ----------------------------------------------------------------------
  * x_{l+1} = x0 * (x_l W_l^T + b_l) + x0, l = 0..L-1, rows = B*N vectors of length E.
  * W: (L,E,E) row-major [l][out][in] as nn.Linear.weight; b: (L,E).
- * bwd reproduces cross_network.py:65: x_0's use as layer 0's linear input is detached.
+ * bwd with detach_first=1 reproduces cross_network.py:65 (x_0 enters layer 0's linear map
+ * detached); detach_first=0 gives the textbook gradient.
  *   dx (rows,E), dW (L,E,E) fp32, db (L,E) fp32 (dW/db are ACCUMULATED into: zero them first).
  * layers/ctr/cross_network.py:65-79.                                                          */
 size_t trs_cross_workspace_bytes(int64_t rows, int32_t E, int32_t L, int32_t dtype);
 int trs_cross_fwd(const void* x, const void* W, const void* b, int64_t rows, int32_t E, int32_t L,
                   int32_t dtype, void* out, trs_stream_t stream);
 int trs_cross_bwd(const void* x, const void* W, const void* b, const void* g, int64_t rows, int32_t E,
-                  int32_t L, int32_t dtype, void* dx, float* dW, float* db, void* workspace,
-                  size_t ws_bytes, trs_stream_t stream);
+                  int32_t L, int32_t dtype, int32_t detach_first, void* dx, float* dW, float* db,
+                  void* workspace, size_t ws_bytes, trs_stream_t stream);
 
 /* ---- K5/K6: compress interaction network, one layer ------------------------------------------
  * y[b,c,e] = bias[c] + sum_{n,h} Wc[c, n*H+h] * x0[b,n,e] * xk[b,h,e]

@@ -135,8 +135,8 @@ def test_fused_embed_fm_vs_oracle(dev, dtype, B, N, E, Vf, zipf):
     off = O.field_offsets(fs)
     tol = TOL32 if dtype == torch.float32 else TOLBF
     # oracle in fp32 on the (possibly bf16-rounded) weights
-    wr = w.float().requires_grad_()
-    w1r = w1.float().requires_grad_()
+    wr = w.float().clone().requires_grad_()
+    w1r = w1.float().clone().requires_grad_()
     emb_r = O.multi_indices_embedding(wr, idx, off)
     fm_r = O.fm_layer(emb_r)
     first_r = O.multi_indices_embedding(w1r, idx, off).sum(dim=1)
@@ -159,7 +159,7 @@ def test_fused_embed_fm_vs_oracle(dev, dtype, B, N, E, Vf, zipf):
     wd2 = w.to(dev).requires_grad_()
     emb2, fm2, _ = F_.embed_fm(wd2, idx.to(dev), off.to(dev), None)
     (emb2.float() * ge.to(dev).float()).sum().backward()
-    wr2 = w.float().requires_grad_()
+    wr2 = w.float().clone().requires_grad_()
     (O.multi_indices_embedding(wr2, idx, off) * ge.float()).sum().backward()
     assert rel_err(wd2.grad.float().cpu(), wr2.grad) <= tol
 

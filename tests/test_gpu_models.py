@@ -1,0 +1,92 @@
+"""GPU parity of the four caller models (M1-M4) composed from the drop-in modules, against golden
+logits and embedding-weight gradients captured from the reference models."""
+import pytest
+import torch
+
+from conftest import MODEL_SHAPES, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _tag(s):
+    return "%d_%d_%d" % s
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _set_mlp(dnn, G, pre):
+    i = 0
+    for mod in dnn.model:
+        if isinstance(mod, torch.nn.Linear):
+            mod.weight.data.copy_(G(f"{pre}_w{i}"))
+            mod.bias.data.copy_(G(f"{pre}_b{i}"))
+            i += 1
+
+
+@pytest.mark.parametrize("fuse", [False, True])
+@pytest.mark.parametrize("shape", MODEL_SHAPES)
+def test_models_golden(golden, dev, shape, fuse):
+    from torecsys_amd.inputs import Inputs, MultiIndicesEmbedding
+    from torecsys_amd import models as M
+    G = golden("models")
+    B, N, E = shape
+    t = "model/" + _tag(shape)
+    fs = G(t + "/field_sizes").tolist()
+    emb = MultiIndicesEmbedding(embed_size=E, field_sizes=fs, fuse_fm=fuse)
+    feat = MultiIndicesEmbedding(embed_size=1, field_sizes=fs)
+    emb.set_schema([f"f{i}" for i in range(N)])
+    feat.set_schema([f"f{i}" for i in range(N)])
+    emb.embedding.weight.data.copy_(G(t + "/emb_w"))
+    feat.embedding.weight.data.copy_(G(t + "/feat_w"))
+    inputs = Inputs(schema={"feat_inputs": feat, "emb_inputs": emb}).to(dev)
+    idx = G(t + "/idx").to(dev)
+    batch = {f"f{i}": idx[:, i] for i in range(N)}          # dict of 1-D columns, routed like inputs.py:69-87
+    gout = G(t + "/gout").to(dev)
+
+    def run(model, two, key, tol_out=1e-5, tol_g=5e-5):
+        inputs.zero_grad()
+        model.zero_grad()
+        d = inputs(batch)
+        y = model(**d) if two else model(emb_inputs=d["emb_inputs"])
+        assert y.shape == (B, 1) and not y.has_names()
+        assert rel_err(y.cpu(), G(f"{t}/{key}_out")) <= tol_out
+        (y * gout).sum().backward()
+        assert rel_err(emb.embedding.weight.grad.cpu(), G(f"{t}/{key}_gemb")) <= tol_g
+        if two:
+            assert rel_err(feat.embedding.weight.grad.cpu(), G(f"{t}/{key}_gfeat")) <= tol_g
+
+    m1 = M.FactorizationMachineModel(use_bias=True, dropout_p=0.0)
+    m1.bias.data.copy_(G(t + "/fm_bias"))
+    run(m1.to(dev), True, "fm")
+
+    m2 = M.DeepFactorizationMachineModel(embed_size=E, num_fields=N, deep_layer_sizes=[32, 16], fm_dropout_p=0.0)
+    _set_mlp(m2.deep, G, t + "/deepfm")
+    run(m2.to(dev), True, "deepfm")
+
+    m3 = M.DeepAndCrossNetworkModel(inputs_size=E, num_fields=N, deep_output_size=8, deep_layer_sizes=[16, 16],
+                                    cross_num_layers=3, output_size=1)
+    _set_mlp(m3.deep, G, t + "/dcn")
+    for l, lin in enumerate(m3.cross.model):
+        lin.weight.data.copy_(G(t + "/dcn_cross_W")[l])
+        lin.bias.data.copy_(G(t + "/dcn_cross_b")[l])
+    m3.fc.weight.data.copy_(G(t + "/dcn_fc_w"))
+    m3.fc.bias.data.copy_(G(t + "/dcn_fc_b"))
+    run(m3.to(dev), False, "dcn")
+    assert rel_err(torch.stack([l.weight.grad for l in m3.cross.model]).cpu(), G(t + "/dcn_gcross_W")) <= 5e-5
+
+    m4 = M.XDeepFactorizationMachineModel(embed_size=E, num_fields=N, cin_layer_sizes=[8, 8], deep_layer_sizes=[16, 8])
+    _set_mlp(m4.deep, G, t + "/xdfm")
+    for i, seq in enumerate(m4.cin.model):
+        seq.Conv1d.weight.data.copy_(G(t + f"/xdfm_conv_w{i}"))
+        seq.Conv1d.bias.data.copy_(G(t + f"/xdfm_conv_b{i}"))
+        seq.Batchnorm.weight.data.copy_(G(t + f"/xdfm_bn_w{i}"))
+        seq.Batchnorm.bias.data.copy_(G(t + f"/xdfm_bn_b{i}"))
+    m4.cin.fc.weight.data.copy_(G(t + "/xdfm_fc_w"))
+    m4.cin.fc.bias.data.copy_(G(t + "/xdfm_fc_b"))
+    m4.bias.data.copy_(G(t + "/xdfm_bias"))
+    m4.train()
+    run(m4.to(dev), True, "xdfm", tol_out=2e-5, tol_g=2e-4)

@@ -1,0 +1,455 @@
+// K7 inner-product network (IPN) and K3 field-aware FM pair products (FFM).
+//
+// IPN: per sample the N x E block X is staged in LDS (fp32) and the strict upper triangle of X*X^T
+// is computed with 4x4 register tiles: one lane owns a 4x4 tile of field pairs, streams both row
+// groups with ds_read_b128 along E and does 64 FMAs per 8 LDS reads.  Results are staged in LDS and
+// stored as one contiguous N(N-1)/2 run per sample.  Backward is (G_sym * X) with G_sym the
+// symmetric zero-diagonal matrix of the incoming pair gradients, same tiling.
+// FFM: pure element-wise, HBM-bound: one lane = one 16-byte vector of an output row.
+#include "trs_common.hpp"
+
+namespace trs {
+
+__device__ __forceinline__ int pair_index(int i, int j, int N) {  // i < j, lexicographic
+  return i * N - (i * (i + 1)) / 2 + (j - i - 1);
+}
+
+// --------------------------------------------------------------------------------------------
+// stage one sample's (N x E) block into LDS as fp32, row stride ES floats; rows N..NP-1 zeroed
+template <typename T>
+__device__ __forceinline__ void stage_block(const T* __restrict__ x, float* __restrict__ X, int N, int NP, int E,
+                                            int ES, int lane) {
+  constexpr int VE = Vec16<T>::VE;
+  if ((E % VE) == 0 && ((((uintptr_t)x) & 15u) == 0)) {
+    const int vpr = E / VE;
+    const uint4* xv = reinterpret_cast<const uint4*>(x);
+    for (int v = lane; v < N * vpr; v += 64) {
+      const int n = v / vpr, lv = v - n * vpr;
+      float f[VE];
+      Vec16<T>::unpack(xv[v], f);
+      float4* dst = reinterpret_cast<float4*>(X + n * ES + lv * VE);
+#pragma unroll
+      for (int k = 0; k < VE; k += 4) dst[k / 4] = make_float4(f[k], f[k + 1], f[k + 2], f[k + 3]);
+    }
+  } else {
+    for (int v = lane; v < N * E; v += 64) {
+      const int n = v / E, e = v - n * E;
+      X[n * ES + e] = to_f32(x[v]);
+    }
+  }
+  for (int v = lane; v < (NP - N) * E; v += 64) {
+    const int n = N + v / E, e = v % E;
+    X[n * ES + e] = 0.f;
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// IPN forward.  Block = 4 waves, one sample per wave per iteration (block-uniform trip count).
+template <typename T>
+__global__ __launch_bounds__(256) void pair_dot_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, int64_t B,
+                                                           int N, int E) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int TN = (N + 3) >> 2, NP = TN * 4, ES = E + 4;
+  const int P = N * (N - 1) / 2;
+  const int ntiles = TN * (TN + 1) / 2;
+  const int per_wave = NP * ES + ((P + 3) & ~3);
+  // layout: [tile table: ntiles ushort2 (padded to 16 B)] [wave 0: X | out stage] [wave 1] ...
+  unsigned short* tile_ij = reinterpret_cast<unsigned short*>(smem);
+  float* base = reinterpret_cast<float*>(smem + ((ntiles * 4 + 15) & ~15));
+  float* X = base + wave * per_wave;
+  float* O = X + NP * ES;
+  for (int q = threadIdx.x; q < ntiles; q += blockDim.x) {
+    int ti = 0, rem = q;
+    while (rem >= TN - ti) { rem -= TN - ti; ++ti; }
+    tile_ij[2 * q] = (unsigned short)ti;
+    tile_ij[2 * q + 1] = (unsigned short)(ti + rem);
+  }
+  const int64_t bstride = (int64_t)gridDim.x * 4;
+  for (int64_t b0 = (int64_t)blockIdx.x * 4; b0 < B; b0 += bstride) {
+    const int64_t b = b0 + wave;
+    __syncthreads();  // previous iteration's readers are done with X / O
+    if (b < B) stage_block<T>(x + b * N * E, X, N, NP, E, ES, lane);
+    __syncthreads();
+    if (b < B) {
+      for (int q = lane; q < ntiles; q += 64) {
+        const int ti = tile_ij[2 * q], tj = tile_ij[2 * q + 1];
+        float acc[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[r][c] = 0.f;
+        const float* xa = X + (4 * ti) * ES;
+        const float* xb = X + (4 * tj) * ES;
+        for (int e = 0; e < E; e += 4) {
+          float4 a[4], bb[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            a[r] = *reinterpret_cast<const float4*>(xa + r * ES + e);
+            bb[r] = *reinterpret_cast<const float4*>(xb + r * ES + e);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              acc[r][c] = fmaf(a[r].x, bb[c].x, acc[r][c]);
+              acc[r][c] = fmaf(a[r].y, bb[c].y, acc[r][c]);
+              acc[r][c] = fmaf(a[r].z, bb[c].z, acc[r][c]);
+              acc[r][c] = fmaf(a[r].w, bb[c].w, acc[r][c]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int i = 4 * ti + r, j = 4 * tj + c;
+            if (i < j && j < N) O[pair_index(i, j, N)] = acc[r][c];
+          }
+      }
+    }
+    __syncthreads();
+    if (b < B) {
+      T* o = out + b * P;
+      for (int k = lane; k < P; k += 64) o[k] = from_f32<T>(O[k]);
+    }
+  }
+}
+
+// IPN backward: dx[i,:] = sum_j Gs[i][j] * x[j,:]; lane owns a (4 fields) x (4 columns) tile of dx.
+template <typename T>
+__global__ __launch_bounds__(256) void pair_dot_bwd_kernel(const T* __restrict__ x, const T* __restrict__ g,
+                                                           T* __restrict__ dx, int64_t B, int N, int E) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int TN = (N + 3) >> 2, NP = TN * 4, ES = E + 4, GS = NP + 4;
+  const int P = N * (N - 1) / 2;
+  const int per_wave = NP * ES + NP * GS;
+  float* X = reinterpret_cast<float*>(smem) + wave * per_wave;
+  float* G = X + NP * ES;  // G[j][i], symmetric, zero diagonal and zero padding
+  const int E4 = E >> 2;
+  const int ntiles = TN * E4;
+  const int64_t bstride = (int64_t)gridDim.x * 4;
+  for (int64_t b0 = (int64_t)blockIdx.x * 4; b0 < B; b0 += bstride) {
+    const int64_t b = b0 + wave;
+    __syncthreads();
+    if (b < B) {
+      stage_block<T>(x + b * N * E, X, N, NP, E, ES, lane);
+      const T* gb = g + b * P;
+      for (int v = lane; v < NP * NP; v += 64) {
+        const int i = v / NP, j = v - i * NP;
+        float val = 0.f;
+        if (i != j && i < N && j < N) val = to_f32(gb[i < j ? pair_index(i, j, N) : pair_index(j, i, N)]);
+        G[i * GS + j] = val;
+      }
+    }
+    __syncthreads();
+    if (b < B) {
+      for (int q = lane; q < ntiles; q += 64) {
+        const int ti = q / E4, e = (q - ti * E4) * 4;
+        float acc[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[r][c] = 0.f;
+        for (int j = 0; j < N; ++j) {
+          const float4 gv = *reinterpret_cast<const float4*>(G + j * GS + 4 * ti);
+          const float4 xv = *reinterpret_cast<const float4*>(X + j * ES + e);
+          const float gr[4] = {gv.x, gv.y, gv.z, gv.w};
+          const float xc[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[r][c] = fmaf(gr[r], xc[c], acc[r][c]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 4 * ti + r;
+          if (i < N) {
+            T* d = dx + (b * N + i) * E + e;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) d[c] = from_f32<T>(acc[r][c]);
+          }
+        }
+      }
+    }
+  }
+}
+
+// generic fallbacks (E not a multiple of 4, or the block does not fit LDS)
+template <typename T>
+__global__ __launch_bounds__(256) void pair_dot_fwd_generic(const T* __restrict__ x, T* __restrict__ out, int64_t B,
+                                                            int N, int E) {
+  const int P = N * (N - 1) / 2;
+  const int64_t total = B * P, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t b = t / P;
+    int rem = (int)(t - b * P), i = 0;
+    while (rem >= N - 1 - i) { rem -= N - 1 - i; ++i; }
+    const int j = i + 1 + rem;
+    const T* xi = x + (b * N + i) * E;
+    const T* xj = x + (b * N + j) * E;
+    float acc = 0.f;
+    for (int e = 0; e < E; ++e) acc = fmaf(to_f32(xi[e]), to_f32(xj[e]), acc);
+    out[t] = from_f32<T>(acc);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void pair_dot_bwd_generic(const T* __restrict__ x, const T* __restrict__ g,
+                                                            T* __restrict__ dx, int64_t B, int N, int E) {
+  const int P = N * (N - 1) / 2;
+  const int64_t total = B * N * E, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t b = t / ((int64_t)N * E);
+    const int rem = (int)(t - b * N * E);
+    const int i = rem / E, e = rem - i * E;
+    float acc = 0.f;
+    for (int j = 0; j < N; ++j) {
+      if (j == i) continue;
+      const int p = i < j ? pair_index(i, j, N) : pair_index(j, i, N);
+      acc = fmaf(to_f32(g[b * P + p]), to_f32(x[(b * N + j) * E + e]), acc);
+    }
+    dx[t] = from_f32<T>(acc);
+  }
+}
+
+constexpr size_t LDS_BUDGET = 64 * 1024;  // per block, keeps >= 2 blocks per CU
+
+template <typename T>
+static int pair_dot_fwd_launch(const void* x, void* out, int64_t B, int N, int E, hipStream_t s) {
+  const int TN = (N + 3) / 4, NP = TN * 4, ES = E + 4, P = N * (N - 1) / 2;
+  const size_t lds = (size_t)((TN * (TN + 1) / 2 * 4 + 15) & ~15) + 4 * (size_t)(NP * ES + ((P + 3) & ~3)) * 4;
+  if (E % 4 == 0 && lds <= LDS_BUDGET && N >= 2) {
+    const int grid = (int)std::min<int64_t>((B + 3) / 4, 256 * 8);
+    hipLaunchKernelGGL((pair_dot_fwd_kernel<T>), dim3(grid), dim3(256), lds, s, (const T*)x, (T*)out, B, N, E);
+  } else {
+    hipLaunchKernelGGL((pair_dot_fwd_generic<T>), dim3(stream_grid(B * P, 256, 8192)), dim3(256), 0, s, (const T*)x,
+                       (T*)out, B, N, E);
+  }
+  return check_launch("pair_dot_fwd");
+}
+template <typename T>
+static int pair_dot_bwd_launch(const void* x, const void* g, void* dx, int64_t B, int N, int E, hipStream_t s) {
+  const int TN = (N + 3) / 4, NP = TN * 4, ES = E + 4, GS = NP + 4;
+  const size_t lds = 4 * (size_t)(NP * ES + NP * GS) * 4;
+  if (E % 4 == 0 && lds <= LDS_BUDGET && N >= 2) {
+    const int grid = (int)std::min<int64_t>((B + 3) / 4, 256 * 8);
+    hipLaunchKernelGGL((pair_dot_bwd_kernel<T>), dim3(grid), dim3(256), lds, s, (const T*)x, (const T*)g, (T*)dx, B,
+                       N, E);
+  } else {
+    hipLaunchKernelGGL((pair_dot_bwd_generic<T>), dim3(stream_grid(B * N * E, 256, 8192)), dim3(256), 0, s,
+                       (const T*)x, (const T*)g, (T*)dx, B, N, E);
+  }
+  return check_launch("pair_dot_bwd");
+}
+
+// --------------------------------------------------------------------------------------------
+// FFM on a materialised (B, N*N, E) block.  UNIT = uint4 (16-byte vectors) or T (elements).
+template <typename T, typename UNIT>
+__device__ __forceinline__ UNIT mul_unit(const UNIT& a, const UNIT& b);
+template <>
+__device__ __forceinline__ uint4 mul_unit<float, uint4>(const uint4& a, const uint4& b) {
+  float x[4], y[4];
+  Vec16<float>::unpack(a, x);
+  Vec16<float>::unpack(b, y);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) x[k] *= y[k];
+  return Vec16<float>::pack(x);
+}
+template <>
+__device__ __forceinline__ uint4 mul_unit<bf16_t, uint4>(const uint4& a, const uint4& b) {
+  float x[8], y[8];
+  Vec16<bf16_t>::unpack(a, x);
+  Vec16<bf16_t>::unpack(b, y);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) x[k] *= y[k];
+  return Vec16<bf16_t>::pack(x);
+}
+template <>
+__device__ __forceinline__ float mul_unit<float, float>(const float& a, const float& b) { return a * b; }
+template <>
+__device__ __forceinline__ bf16_t mul_unit<bf16_t, bf16_t>(const bf16_t& a, const bf16_t& b) {
+  return from_f32<bf16_t>(to_f32(a) * to_f32(b));
+}
+template <typename UNIT>
+__device__ __forceinline__ UNIT zero_unit();
+template <>
+__device__ __forceinline__ uint4 zero_unit<uint4>() { return make_uint4(0, 0, 0, 0); }
+template <>
+__device__ __forceinline__ float zero_unit<float>() { return 0.f; }
+template <>
+__device__ __forceinline__ bf16_t zero_unit<bf16_t>() { return bf16_t{0}; }
+
+// forward: items walk the full N x N square per sample, only i < j produce output
+template <typename T, typename UNIT>
+__global__ __launch_bounds__(256) void ffm_fwd_kernel(const UNIT* __restrict__ x, UNIT* __restrict__ out, int64_t B,
+                                                      int N, int upr /* units per row */) {
+  const int P = N * (N - 1) / 2;
+  const int64_t per_b = (int64_t)N * N * upr;
+  const int64_t total = B * per_b, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t b = t / per_b;
+    int rem = (int)(t - b * per_b);
+    const int i = rem / (N * upr);
+    rem -= i * N * upr;
+    const int j = rem / upr, lv = rem - j * upr;
+    if (i < j) {
+      const UNIT a = x[(b * N * N + (int64_t)i * N + j) * upr + lv];
+      const UNIT c = x[(b * N * N + (int64_t)j * N + i) * upr + lv];
+      out[(b * P + pair_index(i, j, N)) * upr + lv] = mul_unit<T, UNIT>(a, c);
+    }
+  }
+}
+// backward: dx[b,i,j] = g[b,pair(i,j)] * x[b,j,i] (i != j), 0 on the diagonal
+template <typename T, typename UNIT>
+__global__ __launch_bounds__(256) void ffm_bwd_kernel(const UNIT* __restrict__ x, const UNIT* __restrict__ g,
+                                                      UNIT* __restrict__ dx, int64_t B, int N, int upr) {
+  const int P = N * (N - 1) / 2;
+  const int64_t per_b = (int64_t)N * N * upr;
+  const int64_t total = B * per_b, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t b = t / per_b;
+    int rem = (int)(t - b * per_b);
+    const int i = rem / (N * upr);
+    rem -= i * N * upr;
+    const int j = rem / upr, lv = rem - j * upr;
+    UNIT r = zero_unit<UNIT>();
+    if (i != j) {
+      const int p = i < j ? pair_index(i, j, N) : pair_index(j, i, N);
+      r = mul_unit<T, UNIT>(g[(b * P + p) * upr + lv], x[(b * N * N + (int64_t)j * N + i) * upr + lv]);
+    }
+    dx[t] = r;
+  }
+}
+// fused: gather straight from the N tables
+template <typename T, typename UNIT, typename IdxT>
+__global__ __launch_bounds__(256) void ffm_fused_fwd_kernel(const UNIT* const* __restrict__ tables,
+                                                            const IdxT* __restrict__ idx,
+                                                            const int64_t* __restrict__ offsets,
+                                                            UNIT* __restrict__ out, int64_t B, int N, int upr,
+                                                            int64_t V, int32_t* __restrict__ err_flag) {
+  const int P = N * (N - 1) / 2;
+  const int64_t per_b = (int64_t)N * N * upr;
+  const int64_t total = B * per_b, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t b = t / per_b;
+    int rem = (int)(t - b * per_b);
+    const int i = rem / (N * upr);
+    rem -= i * N * upr;
+    const int j = rem / upr, lv = rem - j * upr;
+    if (i < j) {
+      const int64_t ri = load_row_id(idx, offsets, b * N + i, i);
+      const int64_t rj = load_row_id(idx, offsets, b * N + j, j);
+      UNIT r = zero_unit<UNIT>();
+      if (err_flag != nullptr && (ri < 0 || ri >= V || rj < 0 || rj >= V)) {
+        *err_flag = 1;
+      } else {
+        r = mul_unit<T, UNIT>(tables[i][rj * upr + lv], tables[j][ri * upr + lv]);
+      }
+      out[(b * P + pair_index(i, j, N)) * upr + lv] = r;
+    }
+  }
+}
+
+}  // namespace trs
+
+using namespace trs;
+
+#define TRS_CHECK_BNE(name)                                                                                  \
+  TRS_REQUIRE(E > 0 && B >= 0 && N > 0, TRS_EINVAL, name ": bad size B=%lld N=%d E=%d", (long long)B, N, E); \
+  TRS_REQUIRE(dtype == TRS_F32 || dtype == TRS_BF16, TRS_EDTYPE, name ": dtype %d", dtype)
+
+extern "C" int trs_pair_dot_fwd(const void* x, int64_t B, int32_t N, int32_t E, int32_t dtype, void* out,
+                                trs_stream_t stream) {
+  TRS_REQUIRE(x && out, TRS_EINVAL, "pair_dot_fwd: NULL pointer");
+  TRS_CHECK_BNE("pair_dot_fwd");
+  if (B == 0 || N < 2) return TRS_OK;
+  if (dtype == TRS_F32) return pair_dot_fwd_launch<float>(x, out, B, N, E, (hipStream_t)stream);
+  return pair_dot_fwd_launch<bf16_t>(x, out, B, N, E, (hipStream_t)stream);
+}
+
+extern "C" int trs_pair_dot_bwd(const void* x, const void* g, int64_t B, int32_t N, int32_t E, int32_t dtype,
+                                void* dx, trs_stream_t stream) {
+  TRS_REQUIRE(x && g && dx, TRS_EINVAL, "pair_dot_bwd: NULL pointer");
+  TRS_CHECK_BNE("pair_dot_bwd");
+  if (B == 0) return TRS_OK;
+  if (N < 2) {
+    if (hipMemsetAsync(dx, 0, (size_t)B * N * E * dtype_size(dtype), (hipStream_t)stream) != hipSuccess)
+      return check_launch("pair_dot_bwd(memset)");
+    return TRS_OK;
+  }
+  if (dtype == TRS_F32) return pair_dot_bwd_launch<float>(x, g, dx, B, N, E, (hipStream_t)stream);
+  return pair_dot_bwd_launch<bf16_t>(x, g, dx, B, N, E, (hipStream_t)stream);
+}
+
+extern "C" int trs_ffm_fwd(const void* x, int64_t B, int32_t N, int32_t E, int32_t dtype, void* out,
+                           trs_stream_t stream) {
+  TRS_REQUIRE(x && out, TRS_EINVAL, "ffm_fwd: NULL pointer");
+  TRS_CHECK_BNE("ffm_fwd");
+  if (B == 0 || N < 2) return TRS_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int rb = E * dtype_size(dtype);
+  const bool vec = rb % 16 == 0 && aligned16(x) && aligned16(out);
+  const int upr = vec ? rb / 16 : E;
+  const int grid = stream_grid(B * N * N * upr, 256, 256 * 32);
+  if (vec && dtype == TRS_F32)
+    hipLaunchKernelGGL((ffm_fwd_kernel<float, uint4>), dim3(grid), dim3(256), 0, s, (const uint4*)x, (uint4*)out, B, N, upr);
+  else if (vec)
+    hipLaunchKernelGGL((ffm_fwd_kernel<bf16_t, uint4>), dim3(grid), dim3(256), 0, s, (const uint4*)x, (uint4*)out, B, N, upr);
+  else if (dtype == TRS_F32)
+    hipLaunchKernelGGL((ffm_fwd_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)out, B, N, upr);
+  else
+    hipLaunchKernelGGL((ffm_fwd_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)out, B, N, upr);
+  return check_launch("ffm_fwd");
+}
+
+extern "C" int trs_ffm_bwd(const void* x, const void* g, int64_t B, int32_t N, int32_t E, int32_t dtype, void* dx,
+                           trs_stream_t stream) {
+  TRS_REQUIRE(x && dx && (g || N < 2), TRS_EINVAL, "ffm_bwd: NULL pointer");
+  TRS_CHECK_BNE("ffm_bwd");
+  if (B == 0) return TRS_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int rb = E * dtype_size(dtype);
+  const bool vec = rb % 16 == 0 && aligned16(x) && aligned16(g) && aligned16(dx);
+  const int upr = vec ? rb / 16 : E;
+  const int grid = stream_grid(B * N * N * upr, 256, 256 * 32);
+  if (vec && dtype == TRS_F32)
+    hipLaunchKernelGGL((ffm_bwd_kernel<float, uint4>), dim3(grid), dim3(256), 0, s, (const uint4*)x, (const uint4*)g, (uint4*)dx, B, N, upr);
+  else if (vec)
+    hipLaunchKernelGGL((ffm_bwd_kernel<bf16_t, uint4>), dim3(grid), dim3(256), 0, s, (const uint4*)x, (const uint4*)g, (uint4*)dx, B, N, upr);
+  else if (dtype == TRS_F32)
+    hipLaunchKernelGGL((ffm_bwd_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)x, (const float*)g, (float*)dx, B, N, upr);
+  else
+    hipLaunchKernelGGL((ffm_bwd_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)g, (bf16_t*)dx, B, N, upr);
+  return check_launch("ffm_bwd");
+}
+
+template <typename IdxT>
+static int ffm_fused_dispatch(const void* const* tables, int64_t V, int E, int dtype, const IdxT* idx,
+                              const int64_t* offsets, int64_t B, int N, void* out, int32_t* err_flag, hipStream_t s) {
+  const int rb = E * dtype_size(dtype);
+  const bool vec = rb % 16 == 0 && aligned16(out);
+  const int upr = vec ? rb / 16 : E;
+  const int grid = stream_grid(B * N * N * upr, 256, 256 * 32);
+  if (vec && dtype == TRS_F32)
+    hipLaunchKernelGGL((ffm_fused_fwd_kernel<float, uint4, IdxT>), dim3(grid), dim3(256), 0, s, (const uint4* const*)tables, idx, offsets, (uint4*)out, B, N, upr, V, err_flag);
+  else if (vec)
+    hipLaunchKernelGGL((ffm_fused_fwd_kernel<bf16_t, uint4, IdxT>), dim3(grid), dim3(256), 0, s, (const uint4* const*)tables, idx, offsets, (uint4*)out, B, N, upr, V, err_flag);
+  else if (dtype == TRS_F32)
+    hipLaunchKernelGGL((ffm_fused_fwd_kernel<float, float, IdxT>), dim3(grid), dim3(256), 0, s, (const float* const*)tables, idx, offsets, (float*)out, B, N, upr, V, err_flag);
+  else
+    hipLaunchKernelGGL((ffm_fused_fwd_kernel<bf16_t, bf16_t, IdxT>), dim3(grid), dim3(256), 0, s, (const bf16_t* const*)tables, idx, offsets, (bf16_t*)out, B, N, upr, V, err_flag);
+  return check_launch("ffm_fused_fwd");
+}
+
+extern "C" int trs_ffm_fused_fwd(const void* const* tables, int64_t V, int32_t E, int32_t dtype, const void* idx,
+                                 int32_t idx_dtype, const int64_t* offsets, int64_t B, int32_t N, void* out,
+                                 int32_t* err_flag, trs_stream_t stream) {
+  TRS_REQUIRE(tables && idx && out, TRS_EINVAL, "ffm_fused_fwd: NULL pointer");
+  TRS_REQUIRE(V > 0, TRS_EINVAL, "ffm_fused_fwd: bad V");
+  TRS_CHECK_BNE("ffm_fused_fwd");
+  TRS_REQUIRE(idx_dtype == TRS_I64 || idx_dtype == TRS_I32, TRS_EDTYPE, "ffm_fused_fwd: idx dtype %d", idx_dtype);
+  if (B == 0 || N < 2) return TRS_OK;
+  if (idx_dtype == TRS_I64)
+    return ffm_fused_dispatch<int64_t>(tables, V, E, dtype, (const int64_t*)idx, offsets, B, N, out, err_flag, (hipStream_t)stream);
+  return ffm_fused_dispatch<int32_t>(tables, V, E, dtype, (const int32_t*)idx, offsets, B, N, out, err_flag, (hipStream_t)stream);
+}

@@ -298,3 +298,152 @@ class _FAGather(Function):
 def fa_gather_rows(weights: Sequence[torch.Tensor], idx: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
     idx = _as_index(idx)
     return _FAGather.apply(idx, offsets, *weights)
+
+
+# --------------------------------------------------------------------------------------------
+# K7: inner-product network
+# --------------------------------------------------------------------------------------------
+class _PairDot(Function):
+    @staticmethod
+    def forward(ctx, x):
+        require_device(x)
+        x = x.contiguous()
+        B, N, E = x.shape
+        out = torch.empty(B, N * (N - 1) // 2, dtype=x.dtype, device=x.device)
+        call("trs_pair_dot_fwd", ptr(x), B, N, E, value_dtype_code(x), ptr(out), stream_ptr())
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        B, N, E = x.shape
+        dx = torch.empty_like(x)
+        call("trs_pair_dot_bwd", ptr(x), ptr(g.contiguous()), B, N, E, value_dtype_code(x), ptr(dx), stream_ptr())
+        return dx
+
+
+def pair_dot(x: torch.Tensor) -> torch.Tensor:
+    if x.dim() != 3:
+        raise ValueError(f"inner-product input must be (B, N, E), got {tuple(x.shape)}")
+    return _PairDot.apply(x)
+
+
+# --------------------------------------------------------------------------------------------
+# K3: field-aware FM pair products
+# --------------------------------------------------------------------------------------------
+class _FFM(Function):
+    @staticmethod
+    def forward(ctx, x, num_fields):
+        require_device(x)
+        x = x.contiguous()
+        B, NN, E = x.shape
+        N = num_fields
+        out = torch.empty(B, N * (N - 1) // 2, E, dtype=x.dtype, device=x.device)
+        call("trs_ffm_fwd", ptr(x), B, N, E, value_dtype_code(x), ptr(out), stream_ptr())
+        ctx.save_for_backward(x)
+        ctx.N = N
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        B, NN, E = x.shape
+        dx = torch.empty_like(x)
+        call("trs_ffm_bwd", ptr(x), ptr(g.contiguous()), B, ctx.N, E, value_dtype_code(x), ptr(dx), stream_ptr())
+        return dx, None
+
+
+def ffm_layer(x: torch.Tensor, num_fields: int) -> torch.Tensor:
+    if x.dim() != 3 or x.shape[1] != num_fields * num_fields:
+        raise ValueError(f"FFM input must be (B, N*N={num_fields * num_fields}, E), got {tuple(x.shape)}")
+    return _FFM.apply(x, num_fields)
+
+
+# --------------------------------------------------------------------------------------------
+# K4: cross network
+# --------------------------------------------------------------------------------------------
+class _Cross(Function):
+    @staticmethod
+    def forward(ctx, x, W, b, detach_first):
+        require_device(x, W, b)
+        x = x.contiguous()
+        L, E, _ = W.shape
+        rows = x.numel() // E
+        Wc = W.to(x.dtype).contiguous()
+        bc = b.to(x.dtype).contiguous()
+        out = torch.empty_like(x)
+        call("trs_cross_fwd", ptr(x), ptr(Wc), ptr(bc), rows, E, L, value_dtype_code(x), ptr(out), stream_ptr())
+        ctx.save_for_backward(x, Wc, bc)
+        ctx.detach_first = bool(detach_first)
+        ctx.param_dtypes = (W.dtype, b.dtype)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, Wc, bc = ctx.saved_tensors
+        L, E, _ = Wc.shape
+        rows = x.numel() // E
+        dx = torch.empty_like(x)
+        dW = torch.zeros(L, E, E, dtype=torch.float32, device=x.device)
+        db = torch.zeros(L, E, dtype=torch.float32, device=x.device)
+        call("trs_cross_bwd", ptr(x), ptr(Wc), ptr(bc), ptr(g.contiguous()), rows, E, L, value_dtype_code(x),
+             1 if ctx.detach_first else 0, ptr(dx), ptr(dW), ptr(db), ptr(None), 0, stream_ptr())
+        return dx, dW.to(ctx.param_dtypes[0]), db.to(ctx.param_dtypes[1]), None
+
+
+def cross_network(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, detach_first: bool = True) -> torch.Tensor:
+    """x: (..., E); W: (L,E,E) stacked nn.Linear weights; b: (L,E)."""
+    if W.dim() != 3 or W.shape[1] != W.shape[2] or x.shape[-1] != W.shape[1] or b.shape != W.shape[:2]:
+        raise ValueError(f"cross_network: bad shapes x{tuple(x.shape)} W{tuple(W.shape)} b{tuple(b.shape)}")
+    return _Cross.apply(x, W, b, detach_first)
+
+
+# --------------------------------------------------------------------------------------------
+# K5: CIN contraction  y[b,c,e] = bias[c] + sum_{n,h} Wc[c,n*H+h] x0[b,n,e] xk[b,h,e]
+# --------------------------------------------------------------------------------------------
+class _CINContract(Function):
+    @staticmethod
+    def forward(ctx, x0, xk, Wc, bias):
+        require_device(x0, xk, Wc, bias)
+        x0 = x0.contiguous()
+        xk = xk.contiguous()
+        B, N, E = x0.shape
+        H = xk.shape[1]
+        C = Wc.shape[0]
+        w = Wc.to(x0.dtype).contiguous()
+        bb = None if bias is None else bias.to(x0.dtype).contiguous()
+        y = torch.empty(B, C, E, dtype=x0.dtype, device=x0.device)
+        call("trs_cin_fwd", ptr(x0), ptr(xk), ptr(w), ptr(bb), B, N, H, C, E, value_dtype_code(x0), ptr(y), ptr(None),
+             stream_ptr())
+        ctx.save_for_backward(x0, xk, w)
+        ctx.meta = (Wc.dtype, None if bias is None else bias.dtype)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x0, xk, w = ctx.saved_tensors
+        B, N, E = x0.shape
+        H, C = xk.shape[1], w.shape[0]
+        gy = gy.contiguous()
+        need_x0, need_xk, need_w, need_b = ctx.needs_input_grad
+        dW = torch.zeros(C, N * H, dtype=torch.float32, device=x0.device) if need_w else None
+        dx0 = torch.empty_like(x0) if need_x0 else None
+        dxk = torch.empty_like(xk) if need_xk else None
+        call("trs_cin_bwd", ptr(x0), ptr(xk), ptr(w), ptr(gy), B, N, H, C, E, value_dtype_code(x0), ptr(dW), ptr(dx0),
+             ptr(dxk), 0, stream_ptr())
+        db = gy.float().sum(dim=(0, 2)).to(ctx.meta[1]) if (need_b and ctx.meta[1] is not None) else None
+        return dx0, dxk, (dW.to(ctx.meta[0]) if need_w else None), db
+
+
+def cin_contract(x0: torch.Tensor, xk: torch.Tensor, Wc: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """x0 (B,N,E), xk (B,H,E), Wc (C,N*H) -> y (B,C,E); the (B,N*H,E) outer product is never materialised."""
+    if x0.dim() != 3 or xk.dim() != 3 or x0.shape[0] != xk.shape[0] or x0.shape[2] != xk.shape[2]:
+        raise ValueError(f"cin_contract: bad shapes x0{tuple(x0.shape)} xk{tuple(xk.shape)}")
+    if Wc.dim() != 2 or Wc.shape[1] != x0.shape[1] * xk.shape[1]:
+        raise ValueError(f"cin_contract: Wc must be (C, N*H={x0.shape[1] * xk.shape[1]}), got {tuple(Wc.shape)}")
+    return _CINContract.apply(x0, xk, Wc, bias)

@@ -65,6 +65,165 @@ class FactorizationMachineLayer(BaseLayer):
         return outputs
 
 
+class FieldAwareFactorizationMachineLayer(BaseLayer):
+    """FFM pair products, (B,N*N,E) -> (B,NC2,E) named ('B','N','E'):
+    out[:,p(i,j)] = x[:,i*N+j] * x[:,j*N+i] for i<j (lexicographic), then dropout.
+    layers/ctr/field_aware_factorization_machine.py:36-94."""
+
+    @property
+    def inputs_size(self):
+        return {'inputs': ('B', 'N^2', 'E',)}
+
+    @property
+    def outputs_size(self):
+        return {'inputs': ('B', 'NC2', 'E',)}
+
+    def __init__(self, num_fields: int, dropout_p: float = 0.0):
+        super().__init__()
+        self.num_fields = num_fields
+        self.dropout = nn.Dropout(0.0 if dropout_p is None else dropout_p)
+
+    def forward(self, field_emb_inputs: torch.Tensor) -> torch.Tensor:
+        outputs = F_.ffm_layer(_strip(field_emb_inputs), self.num_fields)
+        outputs = self.dropout(outputs)
+        outputs.names = ('B', 'N', 'E',)
+        return outputs
+
+
+class InnerProductNetworkLayer(BaseLayer):
+    """Inner-product network, (B,N,E) -> (B,NC2) named ('B','O'):
+    out[:,p(i,j)] = sum_e x[:,i,e]*x[:,j,e], i<j.  layers/ctr/inner_product_network.py:34-79.
+    (The reference's row_idx/col_idx attributes are not needed: the pair order is computed in-kernel.)"""
+
+    @property
+    def inputs_size(self):
+        return {'inputs': ('B', 'N', 'E',)}
+
+    @property
+    def outputs_size(self):
+        return {'inputs': ('B', 'NC2',)}
+
+    def __init__(self, num_fields: int):
+        super().__init__()
+        self.num_fields = num_fields
+        rows, cols = [], []
+        for i in range(num_fields - 1):
+            for j in range(i + 1, num_fields):
+                rows.append(i)
+                cols.append(j)
+        self.row_idx = torch.LongTensor(rows)
+        self.col_idx = torch.LongTensor(cols)
+
+    def forward(self, emb_inputs: torch.Tensor) -> torch.Tensor:
+        x = _strip(emb_inputs)
+        if x.dim() == 3 and x.shape[1] != self.num_fields:
+            raise ValueError(f'expected {self.num_fields} fields, got {x.shape[1]}')
+        outputs = F_.pair_dot(x)
+        outputs.names = ('B', 'O')
+        return outputs
+
+
+class CrossNetworkLayer(BaseLayer):
+    """Cross network, (B,N,E) -> (B,N,E) named ('B','N','O'): x_{l+1} = x0 * (x_l W_l^T + b_l) + x0.
+    layers/ctr/cross_network.py:34-87.  Parameters ``model.{l}.weight`` (E,E) / ``model.{l}.bias`` (E)
+    as in the reference (a ModuleList of nn.Linear).  Reproduced quirks: the residual adds x0, W_l is a
+    full ExE matrix, and the running value starts from ``emb_inputs.detach()`` (:65) so no gradient
+    flows through layer 0's linear input (``faithful_grad=False`` gives the textbook gradient).
+    Not reproduced: the in-place un-naming of the caller's tensor (:68).  Like the reference, only
+    3-D inputs work (its einsum at :78 raises RuntimeError on 2-D inputs)."""
+
+    @property
+    def inputs_size(self):
+        return {'inputs': ('B', 'N', 'E',)}
+
+    @property
+    def outputs_size(self):
+        return {'outputs': ('B', 'N', 'E',)}
+
+    def __init__(self, inputs_size: int, num_layers: int, faithful_grad: bool = True):
+        super().__init__()
+        self.embed_size = inputs_size
+        self.faithful_grad = faithful_grad
+        self.model = nn.ModuleList()
+        for _ in range(num_layers):
+            self.model.append(nn.Linear(inputs_size, inputs_size))
+
+    def forward(self, emb_inputs: torch.Tensor) -> torch.Tensor:
+        x = _strip(emb_inputs)
+        if x.dim() != 3:
+            raise RuntimeError(f'CrossNetworkLayer expects a (B, N, E) tensor, got {x.dim()}-D '
+                               '(the reference einsum(\'ijk,ijk->ijk\') raises for other ranks)')
+        if len(self.model) == 0:
+            outputs = x.detach() if self.faithful_grad else x
+        else:
+            W = torch.stack([layer.weight for layer in self.model])
+            b = torch.stack([layer.bias for layer in self.model])
+            outputs = F_.cross_network(x, W, b, self.faithful_grad)
+        outputs.names = ('B', 'N', 'O',)
+        return outputs
+
+
+class CompressInteractionNetworkLayer(BaseLayer):
+    """Compress Interaction Network, (B,N,E) -> (B,O) named ('B','O').
+    layers/ctr/compress_interaction_network.py:37-184.  Same module tree as the reference
+    (``model.{i}.Conv1d`` / ``.Batchnorm`` / ``.Activation``, ``fc``) so checkpoints load unchanged.
+    Per layer the (B,N*H,E) outer product of the reference (:125-132) is never built: the HIP kernel
+    forms it on the fly and contracts it with the Conv1d(k=1) weight; BatchNorm1d / activation are the
+    layer's own nn.Modules applied to the (B,C,E) result (batch statistics, running stats and any
+    activation therefore behave exactly as in the reference).  Reproduced quirk: unless ``is_direct``
+    EVERY layer has 2*H output channels and is split by ``chunk`` (the guards at :69/:151 never fire)."""
+
+    @property
+    def inputs_size(self):
+        return {'inputs': ('B', 'N', 'E',)}
+
+    @property
+    def outputs_size(self):
+        return {'outputs': ('B', 'O',)}
+
+    def __init__(self, embed_size: int, num_fields: int, output_size: int, layer_sizes: List[int],
+                 is_direct: bool = False, use_bias: bool = True, use_batchnorm: bool = True,
+                 activation: Optional[nn.Module] = nn.ReLU()):
+        super().__init__()
+        self.embed_size = embed_size
+        self.is_direct = is_direct
+        self.layer_sizes = [num_fields] + layer_sizes
+        self.model = nn.ModuleList()
+        for i, (s_i, s_j) in enumerate(zip(self.layer_sizes[:-1], self.layer_sizes[1:])):
+            in_c = self.layer_sizes[0] * s_i
+            out_c = s_j if is_direct or i == (len(self.layer_sizes) - 1) else s_j * 2
+            cin = nn.Sequential()
+            cin.add_module('Conv1d', nn.Conv1d(in_c, out_c, kernel_size=1, bias=use_bias))
+            if use_batchnorm:
+                cin.add_module('Batchnorm', nn.BatchNorm1d(out_c))
+            if activation is not None:
+                cin.add_module('Activation', activation)
+            self.model.append(cin)
+        self.fc = nn.Linear(int(sum(layer_sizes)), output_size)
+
+    def forward(self, emb_inputs: torch.Tensor) -> torch.Tensor:
+        x0 = _strip(emb_inputs)
+        if x0.dim() != 3:
+            raise ValueError(f'CIN input must be (B, N, E), got {tuple(x0.shape)}')
+        hidden = x0                                   # (B,H,E) channels-first, H_0 = N
+        direct_list = []
+        for seq in self.model:
+            conv = seq.Conv1d
+            y = F_.cin_contract(x0, hidden, conv.weight.squeeze(-1), conv.bias)      # (B,C,E)
+            for name, mod in seq.named_children():
+                if name != 'Conv1d':
+                    y = mod(y)
+            if self.is_direct:
+                direct, hidden = y, y
+            else:
+                direct, hidden = torch.chunk(y, 2, dim=1)
+            direct_list.append(direct)
+        pooled = torch.cat(direct_list, dim=1).sum(dim=-1)
+        outputs = self.fc(pooled)
+        outputs.names = ('B', 'O',)
+        return outputs
+
+
 class MultilayerPerceptionLayer(BaseLayer):
     """Linear/activation/dropout stack + output Linear.  layers/ctr/multilayer_perceptron.py:24-84.
     Plain GEMMs: stays on nn.Linear (hipBLASLt); outside the hand-written path, inside the timed step."""
@@ -104,6 +263,8 @@ class MultilayerPerceptionLayer(BaseLayer):
 
 # aliases, layers/ctr/__init__.py:23-35
 FMLayer = FactorizationMachineLayer
+FFMLayer = FieldAwareFactorizationMachineLayer
+CINLayer = CompressInteractionNetworkLayer
 DenseLayer = MultilayerPerceptionLayer
 DNNLayer = MultilayerPerceptionLayer
 FullyConnectLayer = MultilayerPerceptionLayer
