@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py -- CTR samples/s, forward + backward, DeepFM (39 Criteo-shaped fields x dim 64) on N MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one synthetic batch: index lookup (E=64 table + E=1
+first-order table) fused with the FM second-order term, the DeepFM MLP [400,400,400] (nn.Linear ->
+hipBLASLt, outside the hand-written path but inside the timed step), BCE-with-logits loss, and the full
+backward including the dense embedding-table gradients.  No optimizer step: the metric is fwd+bwd.
+Inputs (indices, labels) are resident in HBM before the timed region.
+
+N = 1: BASELINE.json configs[1] (V = 1 M rows, B = 65 536, bf16).
+N > 1: configs[4] scaled weakly: 125 M rows and 65 536 samples per GPU, table row-sharded over the ranks,
+       lookup by RCCL all-to-all, gradient returned by the reverse all-to-all (torecsys_amd/dist.py).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (the fused lookup+FM
+forward kernel, timed live with HIP events on its launch stream) and `cpu_baseline` (the CPU oracle timed
+on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=65536, help="samples per GPU")
+    ap.add_argument("--fields", type=int, default=39)
+    ap.add_argument("--embed", type=int, default=64)
+    ap.add_argument("--rows-per-gpu", type=int, default=0, help="0 = 1M (N=1) / 125M (N>1)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--zipf", action="store_true", help="Zipf(1.05)-like skewed indices instead of uniform")
+    ap.add_argument("--no-fuse", action="store_true", help="separate lookup and FM kernels (drop-in unfused path)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=16384)
+    return ap.parse_args()
+
+
+def field_sizes(total_rows, n_fields):
+    per = total_rows // n_fields
+    return [per] * (n_fields - 1) + [total_rows - per * (n_fields - 1)]
+
+
+def synth_indices(B, sizes, gen, zipf):
+    cols = []
+    for f in sizes:
+        if zipf:
+            r = torch.rand(B, 1, generator=gen, dtype=torch.float64)
+            cols.append((torch.pow(float(f), r) - 1.0).clamp_(0, f - 1).long())
+        else:
+            cols.append(torch.randint(0, f, (B, 1), generator=gen))
+    return torch.cat(cols, dim=1)
+
+
+def cpu_baseline(a, sizes):
+    """Oracle DeepFM fwd+bwd (fp32, all host threads) on a bounded sample of the same workload."""
+    from oracle import cpu_ref as O       # checker / baseline leg only
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    B, N, E = a.cpu_batch, a.fields, a.embed
+    g = torch.Generator().manual_seed(4321)
+    V = sum(sizes)
+    off = O.field_offsets(sizes)
+    idx = synth_indices(B, sizes, g, a.zipf)
+    w = torch.randn(V, E, generator=g).requires_grad_()
+    w1 = torch.randn(V, 1, generator=g).requires_grad_()
+    dims = [N * E, 400, 400, 400, 1]
+    ws = [(torch.randn(o, i, generator=g) / i ** 0.5).requires_grad_() for i, o in zip(dims[:-1], dims[1:])]
+    bs = [torch.zeros(o, requires_grad=True) for o in dims[1:]]
+    y = (torch.rand(B, 1, generator=g) < 0.25).float()
+
+    def step():
+        for t in [w, w1, *ws, *bs]:
+            t.grad = None
+        emb = O.multi_indices_embedding(w, idx, off)
+        feat = O.multi_indices_embedding(w1, idx, off)
+        logit = O.deepfm_model(feat, emb, ws, bs)
+        nn.functional.binary_cross_entropy_with_logits(logit, y).backward()
+
+    step()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if n >= 3 and (el > 10.0 or n >= 12):
+            break
+    return {"value": round(B * n / el, 1), "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"oracle DeepFM fwd+bwd fp32, batch {B} x {n} steps of the same synthetic workload "
+                      f"(V={V}, {N} fields x dim {E}, MLP [400,400,400])"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        a.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from torecsys_amd import _abi
+    from torecsys_amd import models as M
+    from torecsys_amd.inputs import Inputs, MultiIndicesEmbedding
+
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    esz = 2 if dt == torch.bfloat16 else 4
+    B, N, E = a.batch, a.fields, a.embed
+    rows_local = a.rows_per_gpu or (1_000_000 if world == 1 else 125_000_000)
+    V = rows_local * world
+    sizes = field_sizes(V, N)
+    gen = torch.Generator().manual_seed(1234 + rank)
+    idx = synth_indices(B, sizes, gen, a.zipf).to(dev)
+    labels = (torch.rand(B, 1, generator=gen) < 0.25).float().to(dev)
+
+    torch.manual_seed(7)
+    if world == 1:
+        emb = MultiIndicesEmbedding(embed_size=E, field_sizes=sizes, fuse_fm=not a.no_fuse)
+        feat = MultiIndicesEmbedding(embed_size=1, field_sizes=sizes)
+        parallelism = "single"
+    else:
+        from torecsys_amd.dist import RowShardedMultiIndicesEmbedding
+        emb = RowShardedMultiIndicesEmbedding(embed_size=E, field_sizes=sizes, fuse_fm=not a.no_fuse,
+                                              dtype=dt, device=dev)
+        feat = RowShardedMultiIndicesEmbedding(embed_size=1, field_sizes=sizes, dtype=dt, device=dev)
+        parallelism = f"row-sharded table x{world} (all-to-all lookup), data-parallel MLP"
+    emb.set_schema(["c0"])       # the whole (B,N) index block travels as one named column
+    feat.set_schema(["c0"])
+    inputs = Inputs(schema={"feat_inputs": feat, "emb_inputs": emb}).to(dev).to(dt)
+    model = M.DeepFactorizationMachineModel(embed_size=E, num_fields=N, deep_layer_sizes=[400, 400, 400],
+                                            fm_dropout_p=0.0).to(dev).to(dt)
+    if world > 1:
+        for p in model.parameters():
+            dist.broadcast(p.data, 0)
+    batch = {"c0": idx}
+    crit = nn.BCEWithLogitsLoss()
+    params = [p for p in list(inputs.parameters()) + list(model.parameters()) if p.requires_grad]
+
+    def step():
+        for p in params:
+            p.grad = None
+        out = model(**inputs(batch))
+        loss = crit(out.float(), labels)
+        loss.backward()
+        if world > 1:      # data-parallel dense parameters: average their gradients (one flat bucket)
+            ps = [p for p in model.parameters() if p.grad is not None]
+            flat = torch.cat([p.grad.reshape(-1).float() for p in ps])
+            dist.all_reduce(flat)
+            flat.div_(world)
+            o = 0
+            for p in ps:
+                p.grad.copy_(flat[o:o + p.numel()].view_as(p.grad))
+                o += p.numel()
+        return loss
+
+    roof_kernel = "trs_embed_fm" if not a.no_fuse else "trs_gather_rows"
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    _abi.time_kernel(roof_kernel, True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    ktimes = _abi.kernel_times_ms(roof_kernel)
+    _abi.time_kernel(roof_kernel, False)
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    if rank == 0:
+        # algorithmic bytes of one fused lookup+FM forward launch over the rows this rank gathers
+        # (per sample N*(8 + E*s) read, E*s (+ N*E*s block) + 4*E (fp32 sum) written)
+        if not a.no_fuse:
+            alg = B * N * (8 + E * esz) + B * N * E * esz + B * E * esz + B * E * 4
+        else:
+            alg = B * N * (8 + E * esz) + B * N * E * esz
+        if world > 1:
+            alg = None
+        kt = sum(ktimes) / max(1, len(ktimes)) * 1e-3 if ktimes else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(roof_kernel + ("_zipf" if a.zipf else ""))
+            except Exception:  # noqa: BLE001
+                traffic = None
+        roof = None
+        if kt and alg:
+            ach = alg / kt / 1e9
+            roof = {"bound": "hbm", "kernel": roof_kernel.replace("trs_", ""), "achieved": round(ach, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "traffic": traffic, "alg_bytes_per_launch": alg, "avg_launch_us": round(kt * 1e6, 2),
+                    "launches_timed": len(ktimes)}
+        res = {
+            "metric": "CTR samples/sec fwd+bwd (DeepFM, 39 fields x dim 64)",
+            "value": round(B * world * a.steps / el, 1), "unit": "samples/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": ("BASELINE.json configs[1]: DeepFM 39 Criteo-shaped fields, "
+                                    f"{V} total rows, embed_dim {E}, batch {B}, MLP [400,400,400], "
+                                    + ("zipf" if a.zipf else "uniform") + " indices") if world == 1 else
+                       ("BASELINE.json configs[4] (weak-scaled): DeepFM, " f"{V} rows row-sharded over {world} GPUs, "
+                        f"global batch {B * world}"),
+                       "global_batch": B * world, "rows": V, "parallelism": parallelism,
+                       "fused_lookup_fm": not a.no_fuse, "loss": float(loss)},
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(a, field_sizes(1_000_000, N))
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

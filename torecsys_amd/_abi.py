@@ -84,9 +84,40 @@ def last_error() -> str:
     return s.decode("utf-8", "replace") if s else ""
 
 
+# name -> list of (start_event, end_event): filled when a name is registered with time_kernel();
+# the events are recorded on the stream the kernel is launched on (torch's current stream).
+_timed = {}
+
+
+def time_kernel(name: str, enable: bool = True):
+    """Bracket every launch of entry point ``name`` with HIP events (bench.py's live roofline)."""
+    if enable:
+        _timed[name] = []
+    else:
+        _timed.pop(name, None)
+
+
+def kernel_times_ms(name: str):
+    """Elapsed milliseconds of every recorded launch of ``name`` (synchronises), and clears the list."""
+    torch.cuda.synchronize()
+    ev = _timed.get(name, [])
+    out = [a.elapsed_time(b) for a, b in ev]
+    ev.clear()
+    return out
+
+
 def call(name: str, *args):
     """Call an int-returning entry point; raise RuntimeError with the library's message on failure."""
-    rc = getattr(load(), name)(*args)
+    rec = _timed.get(name)
+    if rec is not None:
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = getattr(load(), name)(*args)
+        b.record()
+        rec.append((a, b))
+    else:
+        rc = getattr(load(), name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed (code {rc}): {last_error()}")
 

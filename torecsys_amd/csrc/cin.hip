@@ -133,6 +133,7 @@ using namespace trs;
 extern "C" int trs_cin_fwd(const void* x0, const void* xk, const void* Wc, const void* bias, int64_t B, int32_t N,
                            int32_t H, int32_t C, int32_t E, int32_t dtype, void* y, float* stats,
                            trs_stream_t stream) {
+  if (B == 0) return TRS_OK;  // empty batch: nothing to do (pointers may be NULL)
   TRS_REQUIRE(x0 && xk && Wc && y, TRS_EINVAL, "cin_fwd: NULL pointer");
   TRS_CIN_CHECK("cin_fwd");
   if (B == 0) return TRS_OK;
@@ -158,6 +159,7 @@ extern "C" int trs_cin_fwd(const void* x0, const void* xk, const void* Wc, const
 extern "C" int trs_cin_bwd(const void* x0, const void* xk, const void* Wc, const void* gy, int64_t B, int32_t N,
                            int32_t H, int32_t C, int32_t E, int32_t dtype, float* dWc, void* dx0, void* dxk,
                            int32_t accumulate_dx0, trs_stream_t stream) {
+  if (B == 0) return TRS_OK;  // empty batch: nothing to do (pointers may be NULL)
   TRS_REQUIRE(x0 && xk && Wc && gy, TRS_EINVAL, "cin_bwd: NULL pointer");
   TRS_CIN_CHECK("cin_bwd");
   if (B == 0) return TRS_OK;

@@ -148,6 +148,7 @@ extern "C" size_t trs_cross_workspace_bytes(int64_t, int32_t, int32_t, int32_t) 
 
 extern "C" int trs_cross_fwd(const void* x, const void* W, const void* b, int64_t rows, int32_t E, int32_t L,
                              int32_t dtype, void* out, trs_stream_t stream) {
+  if (rows == 0) return TRS_OK;  // empty batch: nothing to do (pointers may be NULL)
   TRS_REQUIRE(x && out && (L == 0 || (W && b)), TRS_EINVAL, "cross_fwd: NULL pointer");
   TRS_REQUIRE(rows >= 0 && E > 0 && L >= 0, TRS_EINVAL, "cross_fwd: bad size");
   TRS_REQUIRE(dtype == TRS_F32 || dtype == TRS_BF16, TRS_EDTYPE, "cross_fwd: dtype %d", dtype);
@@ -172,6 +173,7 @@ extern "C" int trs_cross_fwd(const void* x, const void* W, const void* b, int64_
 extern "C" int trs_cross_bwd(const void* x, const void* W, const void* b, const void* g, int64_t rows, int32_t E,
                              int32_t L, int32_t dtype, int32_t detach_first, void* dx, float* dW, float* db,
                              void* workspace, size_t ws_bytes, trs_stream_t stream) {
+  if (rows == 0) return TRS_OK;  // empty batch: nothing to do (pointers may be NULL)
   TRS_REQUIRE(x && g && dx && (L == 0 || (W && b && dW && db)), TRS_EINVAL, "cross_bwd: NULL pointer");
   TRS_REQUIRE(rows >= 0 && E > 0 && L >= 0, TRS_EINVAL, "cross_bwd: bad size");
   TRS_REQUIRE(dtype == TRS_F32 || dtype == TRS_BF16, TRS_EDTYPE, "cross_bwd: dtype %d", dtype);

@@ -216,6 +216,7 @@ extern "C" int trs_embed_fm(const void* table, int64_t V, int32_t E, int32_t dty
                             int32_t idx_dtype, const int64_t* offsets, int64_t B, int32_t N, void* emb, void* fm,
                             float* fm_sum, const void* first_table, void* first, int32_t* err_flag,
                             trs_stream_t stream) {
+  if (B == 0) return TRS_OK;  // empty batch: nothing to do (pointers may be NULL)
   TRS_REQUIRE(table && idx, TRS_EINVAL, "embed_fm: NULL pointer");
   TRS_REQUIRE(V > 0 && E > 0 && B >= 0 && N > 0, TRS_EINVAL, "embed_fm: bad size");
   TRS_REQUIRE(dtype == TRS_F32 || dtype == TRS_BF16, TRS_EDTYPE, "embed_fm: dtype %d", dtype);
@@ -238,6 +239,7 @@ extern "C" int trs_embed_fm(const void* table, int64_t V, int32_t E, int32_t dty
 
 extern "C" int trs_fm_fwd(const void* x, int64_t B, int32_t N, int32_t E, int32_t dtype, void* fm, float* fm_sum,
                           trs_stream_t stream) {
+  if (B == 0) return TRS_OK;  // empty batch: nothing to do (pointers may be NULL)
   TRS_REQUIRE(x && (fm || fm_sum), TRS_EINVAL, "fm_fwd: NULL pointer");
   TRS_REQUIRE(E > 0 && B >= 0 && N > 0, TRS_EINVAL, "fm_fwd: bad size");
   TRS_REQUIRE(dtype == TRS_F32 || dtype == TRS_BF16, TRS_EDTYPE, "fm_fwd: dtype %d", dtype);
@@ -252,6 +254,7 @@ extern "C" int trs_fm_fwd(const void* x, int64_t B, int32_t N, int32_t E, int32_
 
 extern "C" int trs_fm_bwd(const void* x, const void* g, const float* fm_sum, int64_t B, int32_t N, int32_t E,
                           int32_t dtype, void* dx, trs_stream_t stream) {
+  if (B == 0) return TRS_OK;  // empty batch: nothing to do (pointers may be NULL)
   TRS_REQUIRE(x && g && fm_sum && dx, TRS_EINVAL, "fm_bwd: NULL pointer");
   TRS_REQUIRE(E > 0 && B >= 0 && N > 0, TRS_EINVAL, "fm_bwd: bad size");
   TRS_REQUIRE(dtype == TRS_F32 || dtype == TRS_BF16, TRS_EDTYPE, "fm_bwd: dtype %d", dtype);

@@ -241,6 +241,7 @@ extern "C" const char* trs_last_error_string(void) { return trs::err_buf(); }
 extern "C" int trs_gather_rows(const void* table, int64_t V, int32_t E, int32_t dtype, const void* idx,
                                int32_t idx_dtype, const int64_t* offsets, int64_t B, int32_t N, void* out,
                                int32_t* err_flag, trs_stream_t stream) {
+  if (B == 0) return TRS_OK;  // empty batch: nothing to do (pointers may be NULL)
   TRS_REQUIRE(table && idx && out, TRS_EINVAL, "gather_rows: NULL pointer");
   TRS_REQUIRE(V > 0 && E > 0 && B >= 0 && N > 0, TRS_EINVAL, "gather_rows: bad size V=%lld E=%d B=%lld N=%d",
               (long long)V, E, (long long)B, N);
@@ -277,6 +278,7 @@ static int fa_dispatch(const void* const* tables, int64_t V, int E, int dtype, c
 extern "C" int trs_fa_gather_rows(const void* const* tables, int64_t V, int32_t E, int32_t dtype,
                                   const void* idx, int32_t idx_dtype, const int64_t* offsets, int64_t B,
                                   int32_t N, void* out, int32_t* err_flag, trs_stream_t stream) {
+  if (B == 0) return TRS_OK;  // empty batch: nothing to do (pointers may be NULL)
   TRS_REQUIRE(tables && idx && out, TRS_EINVAL, "fa_gather_rows: NULL pointer");
   TRS_REQUIRE(V > 0 && E > 0 && B >= 0 && N > 0, TRS_EINVAL, "fa_gather_rows: bad size");
   TRS_REQUIRE(dtype == TRS_F32 || dtype == TRS_BF16, TRS_EDTYPE, "fa_gather_rows: dtype %d", dtype);
@@ -290,9 +292,11 @@ extern "C" int trs_fa_gather_rows(const void* const* tables, int64_t V, int32_t 
 
 extern "C" int trs_scatter_by_pos(const void* rows, const int32_t* pos, int64_t K, int32_t E, int32_t dtype,
                                   void* out, trs_stream_t stream) {
+  if (K == 0) return TRS_OK;  // empty batch: nothing to do (pointers may be NULL)
   return permute_rows<true>(rows, pos, K, E, dtype, out, (hipStream_t)stream);
 }
 extern "C" int trs_gather_by_pos(const void* rows, const int32_t* pos, int64_t K, int32_t E, int32_t dtype,
                                  void* out, trs_stream_t stream) {
+  if (K == 0) return TRS_OK;  // empty batch: nothing to do (pointers may be NULL)
   return permute_rows<false>(rows, pos, K, E, dtype, out, (hipStream_t)stream);
 }
