@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--zipf", action="store_true", help="Zipf(1.05)-like skewed indices instead of uniform")
     ap.add_argument("--no-fuse", action="store_true", help="separate lookup and FM kernels (drop-in unfused path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true", help="use the row-sharded path even with one rank (test)")
     ap.add_argument("--cpu-batch", type=int, default=16384)
     return ap.parse_args()
 
@@ -71,7 +72,7 @@ def synth_indices(B, sizes, gen, zipf):
 def cpu_baseline(a, sizes):
     """Oracle DeepFM fwd+bwd (fp32, all host threads) on a bounded sample of the same workload."""
     from oracle import cpu_ref as O       # checker / baseline leg only
-    threads = os.cpu_count() or 1
+    threads = int(os.environ.get("TRS_CPU_THREADS", "0")) or min(os.cpu_count() or 1, 64)
     torch.set_num_threads(threads)
     B, N, E = a.cpu_batch, a.fields, a.embed
     g = torch.Generator().manual_seed(4321)
@@ -120,8 +121,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    sharded = world > 1 or a.force_sharded
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from torecsys_amd import _abi
@@ -135,11 +138,14 @@ def main():
     V = rows_local * world
     sizes = field_sizes(V, N)
     gen = torch.Generator().manual_seed(1234 + rank)
-    idx = synth_indices(B, sizes, gen, a.zipf).to(dev)
-    labels = (torch.rand(B, 1, generator=gen) < 0.25).float().to(dev)
+    # a ring of distinct batches resident in HBM: every step sees new indices, so nothing derived from
+    # them (row buckets for the backward) can be reused across steps
+    RING = 4
+    idx_ring = [synth_indices(B, sizes, gen, a.zipf).to(dev) for _ in range(RING)]
+    label_ring = [(torch.rand(B, 1, generator=gen) < 0.25).float().to(dev) for _ in range(RING)]
 
     torch.manual_seed(7)
-    if world == 1:
+    if not sharded:
         emb = MultiIndicesEmbedding(embed_size=E, field_sizes=sizes, fuse_fm=not a.no_fuse)
         feat = MultiIndicesEmbedding(embed_size=1, field_sizes=sizes)
         parallelism = "single"
@@ -157,15 +163,17 @@ def main():
     if world > 1:
         for p in model.parameters():
             dist.broadcast(p.data, 0)
-    batch = {"c0": idx}
+    counter = [0]
     crit = nn.BCEWithLogitsLoss()
     params = [p for p in list(inputs.parameters()) + list(model.parameters()) if p.requires_grad]
 
     def step():
+        k = counter[0] % RING
+        counter[0] += 1
         for p in params:
             p.grad = None
-        out = model(**inputs(batch))
-        loss = crit(out.float(), labels)
+        out = model(**inputs({"c0": idx_ring[k]}))
+        loss = crit(out.float(), label_ring[k])
         loss.backward()
         if world > 1:      # data-parallel dense parameters: average their gradients (one flat bucket)
             ps = [p for p in model.parameters() if p.grad is not None]
@@ -207,7 +215,7 @@ def main():
             alg = B * N * (8 + E * esz) + B * N * E * esz + B * E * esz + B * E * 4
         else:
             alg = B * N * (8 + E * esz) + B * N * E * esz
-        if world > 1:
+        if sharded:
             alg = None
         kt = sum(ktimes) / max(1, len(ktimes)) * 1e-3 if ktimes else None
         traffic = None
@@ -241,7 +249,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a, field_sizes(1_000_000, N))
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

@@ -171,15 +171,17 @@ int trs_cin_bwd(const void* x0, const void* xk, const void* Wc, const void* gy, 
                 int32_t accumulate_dx0, trs_stream_t stream);
 
 /* ---- row-sharded tables (multi-GPU lookup) -----------------------------
- * Bucket the B*N global row ids by owner rank (owner = id / rows_per_rank):
- *   counts[w]  = number of ids owned by rank w
- *   send_ids   = ids grouped by owner (local row id = id - owner*rows_per_rank), int64
- *   send_pos   = for each grouped slot the original flat position p (int32), to un-permute
- * workspace from trs_bucket_workspace_bytes.                                                   */
+ * Bucket the B*N global row ids of the local batch by owner rank (owner = id / rows_per_rank):
+ *   counts[w]  = number of ids owned by rank w                                  (W int64)
+ *   send_ids   = LOCAL row ids (id - owner*rows_per_rank) grouped by owner      (B*N int32)
+ *   send_pos   = for each grouped slot k the original flat position p = b*N+n   (B*N int32)
+ *   inv_pos    = inverse permutation, inv_pos[p] = k (may be NULL)              (B*N int32)
+ * Order inside one owner's group is unspecified.  workspace from trs_bucket_workspace_bytes. */
 size_t trs_bucket_workspace_bytes(int64_t BN, int32_t world);
 int trs_bucket_by_owner(const void* idx, int32_t idx_dtype, const int64_t* offsets, int64_t B, int32_t N,
-                        int64_t rows_per_rank, int32_t world, int64_t* counts, int64_t* send_ids,
-                        int32_t* send_pos, void* workspace, size_t ws_bytes, trs_stream_t stream);
+                        int64_t rows_per_rank, int32_t world, int64_t* counts, int32_t* send_ids,
+                        int32_t* send_pos, int32_t* inv_pos, void* workspace, size_t ws_bytes,
+                        trs_stream_t stream);
 /* out[pos[k],:] = rows[k,:]  (un-permute received rows into the (B*N,E) block) */
 int trs_scatter_by_pos(const void* rows, const int32_t* pos, int64_t K, int32_t E, int32_t dtype,
                        void* out, trs_stream_t stream);

@@ -1,0 +1,135 @@
+"""World-size-2 (and 3) CPU runs of the row-sharded lookup on the gloo backend: host logic of
+torecsys_amd/dist.py (owner bucketing contract, all-to-all choreography, un-permute, reverse exchange,
+shard gradient) with the device ops replaced by torch-CPU stand-ins defined HERE (tests may use the
+oracle; the product default is the HIP ops and refuses CPU tensors)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+class CpuOps:
+    """torch-CPU statement of the HipOps contract (tests only)."""
+
+    def bucket_by_owner(self, idx, offsets, rows_per_rank, world):
+        g = (idx.long() + offsets.view(1, -1)).reshape(-1)
+        owner = torch.div(g, rows_per_rank, rounding_mode="floor").clamp_(0, world - 1)
+        order = torch.argsort(owner, stable=True)
+        counts = torch.bincount(owner, minlength=world).to(torch.int64)
+        send_ids = (g - owner * rows_per_rank)[order].to(torch.int32)
+        send_pos = order.to(torch.int32)
+        inv = torch.empty_like(send_pos)
+        inv[order] = torch.arange(order.numel(), dtype=torch.int32)
+        return counts, send_ids, send_pos, inv
+
+    def gather_local(self, weight, ids):
+        return weight.detach()[ids.long()]
+
+    def unpermute(self, rows, inv_pos, B, N, want_fm):
+        from oracle import cpu_ref as O
+        block = rows[inv_pos.long()].reshape(B, N, -1)
+        if not want_fm:
+            return block, None, None
+        return block, O.fm_layer(block.float()).to(block.dtype), block.float().sum(1)
+
+    def permute_grad(self, g_block, send_pos, g_fm, fm_sum, block):
+        if g_fm is not None:
+            dx = g_fm.unsqueeze(1).float() * (fm_sum.unsqueeze(1) - block.float())
+            g_block = dx.to(block.dtype) if g_block is None else g_block + dx.to(block.dtype)
+        E = g_block.shape[-1]
+        return g_block.reshape(-1, E)[send_pos.long()]
+
+    def shard_grad_dense(self, weight, ids, grad_rows):
+        g = torch.zeros_like(weight)
+        g.index_add_(0, ids.long(), grad_rows)
+        return g
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, fuse, sparse, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import cpu_ref as O
+        from torecsys_amd.dist import RowShardedMultiIndicesEmbedding, shard_ranges
+        torch.manual_seed(0)
+        fs = [7, 3, 11, 5, 9]
+        N, E, B = len(fs), 8, 13 + rank          # ragged local batches
+        V = sum(fs)
+        g = torch.Generator().manual_seed(99)
+        W = torch.randn(V, E, generator=g)
+        idx_all = [torch.cat([torch.randint(0, f, (13 + r, 1), generator=g) for f in fs], 1) for r in range(world)]
+        gb_all = [torch.randn(13 + r, N, E, generator=g) for r in range(world)]
+        gf_all = [torch.randn(13 + r, E, generator=g) for r in range(world)]
+        m = RowShardedMultiIndicesEmbedding(embed_size=E, field_sizes=fs, fuse_fm=fuse, ops=CpuOps(),
+                                            dense_grad_max_rows=0 if sparse else 10 ** 9)
+        assert list(m.state_dict().keys()) == ["embedding.weight"]
+        m.load_full_weight(W)
+        per, ranges = shard_ranges(V, world)
+        assert m.row_range == ranges[rank] and m.rows_per_rank == per
+        assert torch.equal(m.full_weight(), W)
+        out = m(idx_all[rank])
+        assert out.names == ("B", "N", "E")
+        off = O.field_offsets(fs)
+        ref = O.multi_indices_embedding(W, idx_all[rank], off)
+        assert torch.equal(out.rename(None), ref), "sharded lookup must be bit-exact"
+        loss = (out.rename(None) * gb_all[rank]).sum()
+        if fuse:
+            fm, ver = out._trs_fused_fm
+            assert torch.allclose(fm, O.fm_layer(ref), rtol=1e-5, atol=1e-5)
+            loss = loss + (fm * gf_all[rank]).sum()
+        loss.backward()
+        gw = m.embedding.weight.grad
+        if sparse:
+            assert gw.is_sparse
+            gw = gw.to_dense()
+        # reference: gradient of the full table summed over every rank's batch
+        Wr = W.clone().requires_grad_()
+        tot = 0
+        for r in range(world):
+            e = O.multi_indices_embedding(Wr, idx_all[r], off)
+            tot = tot + (e * gb_all[r]).sum()
+            if fuse:
+                tot = tot + (O.fm_layer(e) * gf_all[r]).sum()
+        tot.backward()
+        lo, hi = m.row_range
+        assert torch.allclose(gw[: hi - lo], Wr.grad[lo:hi], rtol=1e-5, atol=1e-5)
+        ret[rank] = "ok"
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        ret[rank] = "FAIL: " + traceback.format_exc()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,fuse,sparse", [(2, False, False), (2, True, False), (2, True, True), (3, False, True)])
+def test_row_sharded_lookup_gloo(world, fuse, sparse):
+    assert dist.is_gloo_available()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, fuse, sparse, ret), nprocs=world, join=True)
+    for r in range(world):
+        assert ret.get(r) == "ok", ret.get(r)
+
+
+def test_default_ops_refuse_cpu():
+    from torecsys_amd.dist import HipOps
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        HipOps().bucket_by_owner(torch.zeros(2, 2, dtype=torch.long), torch.zeros(2, dtype=torch.long), 4, 2)

@@ -1,0 +1,62 @@
+"""GPU: the row-sharded lookup with the real HIP ops and RCCL (backend 'nccl'), world size 1 on the single
+test GPU (all-to-all with itself): bit-exact block, FM and gradients equal the unsharded modules."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pg():
+    assert torch.cuda.is_available()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    yield
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("fuse,sparse", [(False, False), (True, False), (True, True)])
+def test_sharded_equals_unsharded(pg, dtype, fuse, sparse):
+    from torecsys_amd.dist import RowShardedMultiIndicesEmbedding
+    from torecsys_amd.inputs import MultiIndicesEmbedding
+    from torecsys_amd.layers import FMLayer
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    fs = [50 + 3 * i for i in range(39)]
+    B, N, E = 1000, 39, 64
+    idx = torch.cat([torch.randint(0, f, (B, 1), generator=g) for f in fs], 1).to(dev)
+    W = torch.randn(sum(fs), E, generator=g).to(dtype)
+    gb = torch.randn(B, N, E, generator=g).to(dtype).to(dev)
+    res = []
+    for sharded in (False, True):
+        if sharded:
+            m = RowShardedMultiIndicesEmbedding(embed_size=E, field_sizes=fs, fuse_fm=fuse, dtype=dtype, device=dev,
+                                                dense_grad_max_rows=0 if sparse else 10 ** 9)
+            m.load_full_weight(W.to(dev))
+        else:
+            m = MultiIndicesEmbedding(embed_size=E, field_sizes=fs, fuse_fm=fuse).to(dev).to(dtype)
+            m.embedding.weight.data.copy_(W)
+        out = m(idx)
+        y = FMLayer()(out)
+        ((out.rename(None).float() * gb.float()).sum() + (y.rename(None).float() ** 2).sum()).backward()
+        gw = m.embedding.weight.grad
+        if gw.is_sparse:
+            gw = gw.to_dense()
+        res.append((out.rename(None).detach(), y.rename(None).detach().float(), gw.float()))
+    assert torch.equal(res[0][0], res[1][0])
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_err(res[1][1], res[0][1]) <= tol
+    assert rel_err(res[1][2], res[0][2]) <= tol

@@ -1,0 +1,221 @@
+"""Row-sharded embedding table over the GPUs of one node (one process per GPU, torch.distributed).
+
+New design (the reference has no distributed code at all -- SURVEY.md section 2.3 / 8e): the concatenated
+``sum(field_sizes) x E`` table of ``MultiIndicesEmbedding`` (multi_indices_emb.py:48) is split ROW-wise
+into ``world`` contiguous ranges; every rank keeps its local batch (data parallel) and
+
+  forward   1. bucket the local (B*N) global row ids by owner rank           (HIP: trs_bucket_by_owner)
+            2. all-to-all the per-owner counts, then the local row ids        (int32 on the wire)
+            3. owners gather the requested rows from their shard              (HIP: trs_gather_rows)
+            4. all-to-all the rows back                                        (bf16 / fp32 on the wire)
+            5. un-permute into the (B,N,E) block -- fused with the FM second-order term when asked
+               (HIP: trs_embed_fm with the received rows as the "table" and the inverse permutation
+               as the index)
+  backward  the block gradient is permuted into exchange order, sent back by the reverse all-to-all and
+            reduced into the owner's shard: a sparse reduce-scatter keyed by row id.  The shard gradient is
+            dense for small shards and an (uncoalesced) sparse COO tensor otherwise -- at 125 M rows per
+            GPU a dense gradient would be 16 GB per step (documented divergence from nn.Embedding's
+            sparse=False default).
+
+``backend='nccl'`` is RCCL on ROCm (xGMI links); the same code runs on ``gloo`` with CPU tensors when a
+CPU ``ops`` object is injected (tests only -- the default ops are the HIP kernels and refuse CPU tensors).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import functional as F_
+from ._abi import call, index_dtype_code, ptr, require_device, size_query, stream_ptr, value_dtype_code
+from .inputs import BaseInput, field_offsets
+
+DENSE_GRAD_MAX_ROWS = 8_000_000      # shards up to this many rows get a dense gradient
+
+
+class HipOps:
+    """Device-side pieces of the sharded lookup, on libtrs_hip.so."""
+
+    def bucket_by_owner(self, idx: torch.Tensor, offsets: torch.Tensor, rows_per_rank: int, world: int):
+        require_device(idx, offsets)
+        B, N = idx.shape
+        BN = B * N
+        dev = idx.device
+        counts = torch.empty(world, dtype=torch.int64, device=dev)
+        send_ids = torch.empty(BN, dtype=torch.int32, device=dev)
+        send_pos = torch.empty(BN, dtype=torch.int32, device=dev)
+        inv_pos = torch.empty(BN, dtype=torch.int32, device=dev)
+        ws_bytes = size_query("trs_bucket_workspace_bytes", BN, world)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        call("trs_bucket_by_owner", ptr(idx), index_dtype_code(idx), ptr(offsets), B, N, rows_per_rank, world,
+             ptr(counts), ptr(send_ids), ptr(send_pos), ptr(inv_pos), ptr(ws), ws_bytes, stream_ptr())
+        return counts, send_ids, send_pos, inv_pos
+
+    def gather_local(self, weight: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+        K = ids.numel()
+        V, E = weight.shape
+        out = torch.empty(K, E, dtype=weight.dtype, device=weight.device)
+        if K:
+            call("trs_gather_rows", ptr(weight), V, E, value_dtype_code(weight), ptr(ids), index_dtype_code(ids),
+                 ptr(None), K, 1, ptr(out), ptr(None), stream_ptr())
+        return out
+
+    def unpermute(self, rows: torch.Tensor, inv_pos: torch.Tensor, B: int, N: int, want_fm: bool):
+        """block[p] = rows[inv_pos[p]]; with ``want_fm`` also FM second order + the fp32 field sum."""
+        K, E = rows.shape
+        block = torch.empty(B, N, E, dtype=rows.dtype, device=rows.device)
+        fm = fm_sum = None
+        if want_fm:
+            fm = torch.empty(B, E, dtype=rows.dtype, device=rows.device)
+            fm_sum = torch.empty(B, E, dtype=torch.float32, device=rows.device)
+        if B:
+            call("trs_embed_fm", ptr(rows), max(K, 1), E, value_dtype_code(rows), ptr(inv_pos), index_dtype_code(inv_pos),
+                 ptr(None), B, N, ptr(block), ptr(fm), ptr(fm_sum), ptr(None), ptr(None), ptr(None), stream_ptr())
+        return block, fm, fm_sum
+
+    def permute_grad(self, g_block: Optional[torch.Tensor], send_pos: torch.Tensor, g_fm, fm_sum, block):
+        """rows of d(block) in exchange order: g_block[pos[k]] (+ g_fm*(S - x) when the FM term was fused)."""
+        B, N, E = block.shape
+        if g_fm is not None:
+            dx = torch.empty_like(block)
+            call("trs_fm_bwd", ptr(block), ptr(g_fm.contiguous()), ptr(fm_sum), B, N, E, value_dtype_code(block), ptr(dx),
+                 stream_ptr())
+            g_block = dx if g_block is None else g_block + dx
+        g_block = g_block.contiguous()
+        K = send_pos.numel()
+        out = torch.empty(K, E, dtype=g_block.dtype, device=g_block.device)
+        if K:
+            call("trs_gather_by_pos", ptr(g_block), ptr(send_pos), K, E, value_dtype_code(g_block), ptr(out), stream_ptr())
+        return out
+
+    def shard_grad_dense(self, weight: torch.Tensor, ids: torch.Tensor, grad_rows: torch.Tensor) -> torch.Tensor:
+        rb = F_.row_buckets(ids.view(-1, 1), None, weight.shape[0])
+        return F_.scatter_rows(rb, weight, g_rows=grad_rows.contiguous())
+
+
+def shard_ranges(num_rows: int, world: int):
+    per = (num_rows + world - 1) // world
+    return per, [(min(num_rows, r * per), min(num_rows, (r + 1) * per)) for r in range(world)]
+
+
+def _all_to_all(out: torch.Tensor, inp: torch.Tensor, out_splits: List[int], in_splits: List[int], group):
+    dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+
+
+class _ShardedLookup(Function):
+    """(local shard, local batch of indices) -> (B,N,E) block [+ FM]; gradient flows back to the shard owners."""
+
+    @staticmethod
+    def forward(ctx, weight, idx, mod):
+        ops, group, world = mod.ops, mod.group, mod.world
+        B, N = idx.shape
+        E = weight.shape[1]
+        counts, send_ids, send_pos, inv_pos = ops.bucket_by_owner(idx, mod.offsets, mod.rows_per_rank, world)
+        recv_counts = torch.empty_like(counts)
+        dist.all_to_all_single(recv_counts, counts, group=group)
+        send_splits = counts.tolist()            # host sync: split sizes are needed as Python ints
+        recv_splits = recv_counts.tolist()
+        K = sum(recv_splits)
+        recv_ids = torch.empty(K, dtype=torch.int32, device=idx.device)
+        _all_to_all(recv_ids, send_ids, recv_splits, send_splits, group)
+        rows = ops.gather_local(weight, recv_ids)                                   # (K,E) rows of my shard
+        back = torch.empty(B * N, E, dtype=weight.dtype, device=weight.device)
+        _all_to_all(back, rows, send_splits, recv_splits, group)
+        block, fm, fm_sum = ops.unpermute(back, inv_pos, B, N, mod.fuse_fm)
+        ctx.mod = mod
+        ctx.splits = (send_splits, recv_splits)
+        ctx.save_for_backward(weight, recv_ids, send_pos, block if mod.fuse_fm else None, fm_sum)
+        ctx.set_materialize_grads(False)
+        if fm is None:
+            fm = block.new_empty(0)
+            ctx.mark_non_differentiable(fm)
+        return block, fm
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_block, g_fm):
+        mod = ctx.mod
+        ops, group = mod.ops, mod.group
+        weight, recv_ids, send_pos, block, fm_sum = ctx.saved_tensors
+        send_splits, recv_splits = ctx.splits
+        E = weight.shape[1]
+        if g_block is None and g_fm is None:
+            return None, None, None
+        if block is None:
+            block = g_block     # shape carrier only
+        g_rows = ops.permute_grad(g_block, send_pos, g_fm if mod.fuse_fm else None, fm_sum, block)
+        recv_g = torch.empty(sum(recv_splits), E, dtype=g_rows.dtype, device=g_rows.device)
+        _all_to_all(recv_g, g_rows, recv_splits, send_splits, group)               # reverse exchange
+        if weight.shape[0] <= mod.dense_grad_max_rows:
+            gw = ops.shard_grad_dense(weight, recv_ids, recv_g)
+        else:
+            gw = torch.sparse_coo_tensor(recv_ids.long().unsqueeze(0), recv_g, size=weight.shape)
+        return gw, None, None
+
+
+class RowShardedMultiIndicesEmbedding(BaseInput):
+    """``MultiIndicesEmbedding`` (multi_indices_emb.py:18-112) with the table row-sharded over the process
+    group: same constructor core (embed_size, field_sizes, flatten), same forward contract ((B,N) local
+    indices -> (B,N,E) named ('B','N','E')).  ``embedding.weight`` holds THIS rank's rows
+    [rank*rows_per_rank, ...); ``full_state_dict()`` / ``load_full_weight()`` convert to/from the unsharded
+    ``embedding.weight`` of the reference."""
+
+    def __init__(self, embed_size: int, field_sizes: List[int], flatten: bool = False, fuse_fm: bool = False,
+                 dtype: torch.dtype = torch.float32, device='cpu', process_group=None, ops=None,
+                 dense_grad_max_rows: int = DENSE_GRAD_MAX_ROWS):
+        super().__init__()
+        if not dist.is_initialized():
+            raise RuntimeError("RowShardedMultiIndicesEmbedding needs torch.distributed to be initialised")
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self.rank = dist.get_rank(process_group)
+        self.ops = ops if ops is not None else HipOps()
+        self.num_rows = int(sum(field_sizes))
+        self.rows_per_rank, ranges = shard_ranges(self.num_rows, self.world)
+        self.row_range = ranges[self.rank]
+        n_local = max(self.row_range[1] - self.row_range[0], 1)
+        self.embedding = nn.Embedding(n_local, embed_size, device=device, dtype=dtype)
+        self.register_buffer('offsets', field_offsets(field_sizes).to(device), persistent=False)
+        self.flatten = flatten
+        self.fuse_fm = fuse_fm and not flatten
+        self.field_size = self.num_rows
+        self.embed_size = embed_size
+        self.padding_idx = None
+        self.dense_grad_max_rows = dense_grad_max_rows
+        self.length = embed_size * len(field_sizes) if flatten else embed_size
+
+    def forward(self, inputs: torch.Tensor) -> torch.Tensor:
+        idx = inputs.rename(None) if inputs.has_names() else inputs
+        if idx.dim() != 2 or idx.shape[1] != self.offsets.numel():
+            raise ValueError(f'inputs must be (B, {self.offsets.numel()}), got {tuple(idx.shape)}')
+        if idx.dtype not in (torch.int64, torch.int32):
+            idx = idx.long()
+        out, fm = _ShardedLookup.apply(self.embedding.weight, idx.contiguous(), self)
+        if self.fuse_fm:
+            out._trs_fused_fm = (fm, out._version)
+        if self.flatten:
+            out = out.reshape(out.shape[0], 1, -1)
+        out.names = ('B', 'N', 'E',)
+        return out
+
+    @torch.no_grad()
+    def load_full_weight(self, full: torch.Tensor):
+        lo, hi = self.row_range
+        self.embedding.weight[: hi - lo].copy_(full[lo:hi])
+
+    @torch.no_grad()
+    def full_weight(self) -> torch.Tensor:
+        lo, hi = self.row_range
+        parts = [torch.empty(self.rows_per_rank, self.embed_size, dtype=self.embedding.weight.dtype,
+                             device=self.embedding.weight.device) for _ in range(self.world)]
+        mine = torch.zeros_like(parts[0])
+        mine[: hi - lo] = self.embedding.weight[: hi - lo]
+        dist.all_gather(parts, mine, group=self.group)
+        return torch.cat(parts, 0)[: self.num_rows]
+
+    def full_state_dict(self):
+        return {'embedding.weight': self.full_weight()}

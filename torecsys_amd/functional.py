@@ -43,24 +43,31 @@ class _ErrFlag:
 # with the same index tensor (E=64 embeddings and the E=1 first-order weights).
 # --------------------------------------------------------------------------------------------
 class RowBuckets:
-    __slots__ = ("row_start", "perm", "V", "BN", "N")
+    __slots__ = ("row_start", "perm", "V", "BN", "N", "ready")
 
     def __init__(self, row_start, perm, V, BN, N):
         self.row_start, self.perm, self.V, self.BN, self.N = row_start, perm, V, BN, N
+        self.ready = None        # event recorded on the build stream (side-stream prefetch)
+
+    def wait(self):
+        """Make the current stream wait for the build (no-op when built on this stream)."""
+        if self.ready is not None:
+            torch.cuda.current_stream().wait_event(self.ready)
+            self.row_start.record_stream(torch.cuda.current_stream())
+            self.perm.record_stream(torch.cuda.current_stream())
 
 
 _bucket_cache: List[tuple] = []   # [(key, idx_tensor_kept_alive, RowBuckets)]
 _BUCKET_CACHE_SIZE = 2
+_side_streams = {}
+PREFETCH_BUCKETS = os.environ.get("TRS_PREFETCH_BUCKETS", "1") not in ("", "0")
 
 
-def row_buckets(idx: torch.Tensor, offsets: Optional[torch.Tensor], V: int) -> RowBuckets:
-    """Build (or fetch) the CSR for ``idx`` (B,N).  The cache keeps a reference to the index tensor,
-    so its storage cannot be recycled for another batch while the entry is live; in-place edits bump
-    ``_version`` and miss."""
-    key = (idx.data_ptr(), idx._version, tuple(idx.shape), idx.dtype, 0 if offsets is None else offsets.data_ptr(), V)
-    for k, _, rb in _bucket_cache:
-        if k == key:
-            return rb
+def _bucket_key(idx, offsets, V):
+    return (idx.data_ptr(), idx._version, tuple(idx.shape), idx.dtype, 0 if offsets is None else offsets.data_ptr(), V)
+
+
+def _build_buckets(idx, offsets, V) -> RowBuckets:
     B, N = idx.shape
     BN = B * N
     dev = idx.device
@@ -72,11 +79,51 @@ def row_buckets(idx: torch.Tensor, offsets: Optional[torch.Tensor], V: int) -> R
     call("trs_csr_build", ptr(idx), index_dtype_code(idx), ptr(offsets), B, N, V, ptr(row_start), ptr(perm),
          ptr(ws), ws_bytes, ptr(flag.t), stream_ptr())
     flag.check("row_buckets")
-    rb = RowBuckets(row_start, perm, V, BN, N)
+    return RowBuckets(row_start, perm, V, BN, N)
+
+
+def row_buckets(idx: torch.Tensor, offsets: Optional[torch.Tensor], V: int) -> RowBuckets:
+    """Build (or fetch) the CSR for ``idx`` (B,N).  The cache keeps a reference to the index tensor,
+    so its storage cannot be recycled for another batch while the entry is live; in-place edits bump
+    ``_version`` and miss."""
+    key = _bucket_key(idx, offsets, V)
+    for k, _, rb in _bucket_cache:
+        if k == key:
+            rb.wait()
+            return rb
+    rb = _build_buckets(idx, offsets, V)
     _bucket_cache.append((key, idx, rb))
     if len(_bucket_cache) > _BUCKET_CACHE_SIZE:
         _bucket_cache.pop(0)
     return rb
+
+
+def prefetch_row_buckets(idx: torch.Tensor, offsets: Optional[torch.Tensor], V: int) -> None:
+    """Start building the CSR of this batch on a side stream at FORWARD time: it depends only on the
+    indices, is latency-bound (int32 atomics), and hides behind the forward/backward of the dense part
+    of the model; the backward's scatter then just waits on an event."""
+    if not PREFETCH_BUCKETS:
+        return
+    key = _bucket_key(idx, offsets, V)
+    for k, _, _rb in _bucket_cache:
+        if k == key:
+            return
+    dev = idx.device
+    side = _side_streams.get(dev)
+    if side is None:
+        side = _side_streams[dev] = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream()
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        rb = _build_buckets(idx, offsets, V)
+        rb.ready = torch.cuda.Event()
+        rb.ready.record(side)
+    idx.record_stream(side)
+    if offsets is not None:
+        offsets.record_stream(side)
+    _bucket_cache.append((key, idx, rb))
+    if len(_bucket_cache) > _BUCKET_CACHE_SIZE:
+        _bucket_cache.pop(0)
 
 
 def clear_caches():
@@ -112,6 +159,8 @@ class _GatherRows(Function):
         call("trs_gather_rows", ptr(w), V, E, value_dtype_code(w), ptr(idx), index_dtype_code(idx), ptr(offsets),
              B, N, ptr(out), ptr(flag.t), stream_ptr())
         flag.check("gather_rows")
+        if weight.requires_grad:
+            prefetch_row_buckets(idx, offsets, V)
         ctx.save_for_backward(idx, offsets, weight)
         ctx.padding_idx = -1 if padding_idx is None else int(padding_idx)
         return out
@@ -163,6 +212,8 @@ class _EmbedFM(Function):
         call("trs_embed_fm", ptr(w), V, E, value_dtype_code(w), ptr(idx), index_dtype_code(idx), ptr(offsets), B, N,
              ptr(emb), ptr(fm), ptr(fm_sum), ptr(fw), ptr(first), ptr(flag.t), stream_ptr())
         flag.check("embed_fm")
+        if weight.requires_grad or (first_weight is not None and first_weight.requires_grad):
+            prefetch_row_buckets(idx, offsets, V)
         ctx.save_for_backward(idx, offsets, weight, first_weight, fm_sum)
         ctx.want_emb = want_emb
         ctx.set_materialize_grads(False)   # unused outputs arrive as None, not as zero blocks
@@ -275,6 +326,8 @@ class _FAGather(Function):
         call("trs_fa_gather_rows", ptr(_pointer_table(ws)), V, E, value_dtype_code(ws[0]), ptr(idx),
              index_dtype_code(idx), ptr(offsets), B, N, ptr(out), ptr(flag.t), stream_ptr())
         flag.check("fa_gather_rows")
+        if any(w.requires_grad for w in weights):
+            prefetch_row_buckets(idx, offsets, V)
         ctx.save_for_backward(idx, offsets, *weights)
         return out
 
