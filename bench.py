@@ -72,7 +72,7 @@ def synth_indices(B, sizes, gen, zipf):
 def cpu_baseline(a, sizes):
     """Oracle DeepFM fwd+bwd (fp32, all host threads) on a bounded sample of the same workload."""
     from oracle import cpu_ref as O       # checker / baseline leg only
-    threads = int(os.environ.get("TRS_CPU_THREADS", "0")) or min(os.cpu_count() or 1, 64)
+    threads = int(os.environ.get("TRS_CPU_THREADS", "0")) or min(os.cpu_count() or 1, 16)
     torch.set_num_threads(threads)
     B, N, E = a.cpu_batch, a.fields, a.embed
     g = torch.Generator().manual_seed(4321)
@@ -248,9 +248,16 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a, field_sizes(1_000_000, N))
-        print(json.dumps(res), flush=True)
+    else:
+        res = None
     if sharded:
         dist.destroy_process_group()
+    if res is not None:
+        # RCCL writes a version banner through C stdio; flush it first so the JSON line is the LAST line
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":

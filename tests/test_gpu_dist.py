@@ -57,6 +57,6 @@ def test_sharded_equals_unsharded(pg, dtype, fuse, sparse):
             gw = gw.to_dense()
         res.append((out.rename(None).detach(), y.rename(None).detach().float(), gw.float()))
     assert torch.equal(res[0][0], res[1][0])
-    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    tol = 1e-5 if dtype == torch.float32 else (2e-2 if sparse else 1e-2)   # sparse bf16: torch coalesces in bf16
     assert rel_err(res[1][1], res[0][1]) <= tol
     assert rel_err(res[1][2], res[0][2]) <= tol
