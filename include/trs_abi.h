@@ -146,10 +146,12 @@ int trs_ffm_fused_fwd(const void* const* tables, int64_t V, int32_t E, int32_t d
  * bwd with detach_first=1 reproduces cross_network.py:65 (x_0 enters layer 0's linear map
  * detached); detach_first=0 gives the textbook gradient.
  *   dx (rows,E), dW (L,E,E) fp32, db (L,E) fp32 (dW/db are ACCUMULATED into: zero them first).
+ * workspace (trs_cross_workspace_bytes; may be 0 / NULL for fp32) holds the W fragments re-packed for
+ * the MFMA path (bf16, E % 32 == 0, E <= 128); without it the generic VALU kernels run.
  * layers/ctr/cross_network.py:65-79.                                                          */
 size_t trs_cross_workspace_bytes(int64_t rows, int32_t E, int32_t L, int32_t dtype);
 int trs_cross_fwd(const void* x, const void* W, const void* b, int64_t rows, int32_t E, int32_t L,
-                  int32_t dtype, void* out, trs_stream_t stream);
+                  int32_t dtype, void* out, void* workspace, size_t ws_bytes, trs_stream_t stream);
 int trs_cross_bwd(const void* x, const void* W, const void* b, const void* g, int64_t rows, int32_t E,
                   int32_t L, int32_t dtype, int32_t detach_first, void* dx, float* dW, float* db,
                   void* workspace, size_t ws_bytes, trs_stream_t stream);

@@ -190,3 +190,24 @@ def test_cin_contract_vs_oracle(dev, dtype, B, N, E, H, C):
     (y.float() * gy.to(dev).float()).sum().backward()
     for a, r in zip(td, ts):
         assert rel_err(a.grad.float().cpu(), r.grad) <= 2 * tol
+
+
+@pytest.mark.parametrize("B,N,E,L", [(37, 5, 32, 2), (129, 39, 64, 6), (64, 3, 96, 3), (50, 7, 128, 4), (20, 4, 128, 6)])
+def test_cross_mfma_bf16_vs_oracle(dev, B, N, E, L):
+    """bf16 MFMA cross path (E % 32 == 0; ragged row counts; resident and non-resident weight fragments)."""
+    from torecsys_amd import functional as F_
+    g = torch.Generator().manual_seed(B * 3 + N + E + L)
+    x = (0.5 * torch.randn(B, N, E, generator=g)).bfloat16()
+    W = (torch.randn(L, E, E, generator=g) / E ** 0.5).bfloat16()
+    b = (0.1 * torch.randn(L, E, generator=g)).bfloat16()
+    gc = torch.randn(B, N, E, generator=g).bfloat16()
+    xd, Wd, bd = x.to(dev).requires_grad_(), W.to(dev).requires_grad_(), b.to(dev).requires_grad_()
+    xr, Wr, br = x.float().requires_grad_(), W.float().requires_grad_(), b.float().requires_grad_()
+    y = F_.cross_network(xd, Wd, bd)
+    yr = O.cross_network(xr, list(Wr), list(br))
+    assert rel_err(y.float().cpu(), yr.detach()) <= TOLBF
+    (y.float() * gc.to(dev).float()).sum().backward()
+    (yr * gc.float()).sum().backward()
+    assert rel_err(xd.grad.float().cpu(), xr.grad) <= 2 * TOLBF
+    assert rel_err(Wd.grad.float().cpu(), Wr.grad) <= 2 * TOLBF
+    assert rel_err(bd.grad.float().cpu(), br.grad) <= 2 * TOLBF

@@ -97,6 +97,26 @@ def main():
         report("scatter_rows (g_rows + fm)", t, B * N * (E * s + 4) + V * E * s * 2 + V * 4)
         t = timeit(lambda: F_.scatter_rows(rb, w1, g_bcast=gf[:, :1].contiguous()))
         report("scatter_rows (first-order E=1)", t, B * N * (4) + V * s + V * 4)
+    if want("cross"):
+        L = 6
+        x = (0.5 * torch.randn(B, N, E, generator=g)).to(dt).to(dev).requires_grad_()
+        W = (torch.randn(L, E, E, generator=g) / E ** 0.5).to(dt).to(dev).requires_grad_()
+        bb = (0.1 * torch.randn(L, E, generator=g)).to(dt).to(dev).requires_grad_()
+        t = timeit(lambda: F_._Cross.apply(x.detach(), W.detach(), bb.detach(), True), iters=5, warm=1)
+        report(f"cross_fwd L={L}", t, 2 * B * N * E * s)
+        print(f"    -> {2*B*N*E*E*L/t[0]/1e12:.1f} TFLOP/s")
+        y = F_._Cross.apply(x, W, bb, True)
+        gy = torch.randn_like(y)
+        t = timeit(lambda: torch.autograd.grad(y, (x, W, bb), gy, retain_graph=True), iters=3, warm=1)
+        report(f"cross_bwd L={L}", t, 3 * B * N * E * s)
+    if want("ipn"):
+        x = torch.randn(B, N, E, generator=g).to(dt).to(dev).requires_grad_()
+        t = timeit(lambda: F_._PairDot.apply(x.detach()), iters=10)
+        report("pair_dot_fwd", t, B * N * E * s + B * (N * (N - 1) // 2) * s)
+        y = F_._PairDot.apply(x)
+        gy = torch.randn_like(y)
+        t = timeit(lambda: torch.autograd.grad(y, x, gy, retain_graph=True), iters=10)
+        report("pair_dot_bwd", t, 2 * B * N * E * s + B * (N * (N - 1) // 2) * s)
     if want("copy"):
         x = torch.empty(512 * 1024 * 1024 // 4, dtype=torch.float32, device=dev)
         y = torch.empty_like(x)

@@ -10,10 +10,13 @@
 
 namespace trs {
 
+// cross_mfma.hip; both return 1 if the shape is not covered by the MFMA path
+size_t cross_mfma_workspace_bytes(int E, int L);
 int cross_mfma_fwd(const void* x, const void* W, const void* b, int64_t rows, int E, int L, void* out,
-                   hipStream_t s);  // cross_mfma.hip; returns 1 if the shape is not covered
+                   void* workspace, size_t ws_bytes, hipStream_t s);
 int cross_mfma_bwd(const void* x, const void* W, const void* b, const void* g, int64_t rows, int E, int L,
-                   void* dx, float* dW, float* db, int detach_first, hipStream_t s);
+                   void* dx, float* dW, float* db, int detach_first, void* workspace, size_t ws_bytes,
+                   hipStream_t s);
 
 constexpr int CR = 16;  // rows per tile (generic path)
 
@@ -144,10 +147,14 @@ __global__ __launch_bounds__(256) void cross_bwd_generic(const T* __restrict__ x
 
 using namespace trs;
 
-extern "C" size_t trs_cross_workspace_bytes(int64_t, int32_t, int32_t, int32_t) { return 0; }
+extern "C" size_t trs_cross_workspace_bytes(int64_t rows, int32_t E, int32_t L, int32_t dtype) {
+  (void)rows;
+  if (dtype != TRS_BF16 || E <= 0 || L <= 0) return 0;
+  return cross_mfma_workspace_bytes(E, L);
+}
 
 extern "C" int trs_cross_fwd(const void* x, const void* W, const void* b, int64_t rows, int32_t E, int32_t L,
-                             int32_t dtype, void* out, trs_stream_t stream) {
+                             int32_t dtype, void* out, void* workspace, size_t ws_bytes, trs_stream_t stream) {
   if (rows == 0) return TRS_OK;  // empty batch: nothing to do (pointers may be NULL)
   TRS_REQUIRE(x && out && (L == 0 || (W && b)), TRS_EINVAL, "cross_fwd: NULL pointer");
   TRS_REQUIRE(rows >= 0 && E > 0 && L >= 0, TRS_EINVAL, "cross_fwd: bad size");
@@ -155,7 +162,7 @@ extern "C" int trs_cross_fwd(const void* x, const void* W, const void* b, int64_
   if (rows == 0) return TRS_OK;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == TRS_BF16 && L > 0) {
-    const int rc = cross_mfma_fwd(x, W, b, rows, E, L, out, s);
+    const int rc = cross_mfma_fwd(x, W, b, rows, E, L, out, workspace, ws_bytes, s);
     if (rc <= 0) return rc;
   }
   const size_t lds = (size_t)3 * CR * E * 4;
@@ -177,11 +184,10 @@ extern "C" int trs_cross_bwd(const void* x, const void* W, const void* b, const 
   TRS_REQUIRE(x && g && dx && (L == 0 || (W && b && dW && db)), TRS_EINVAL, "cross_bwd: NULL pointer");
   TRS_REQUIRE(rows >= 0 && E > 0 && L >= 0, TRS_EINVAL, "cross_bwd: bad size");
   TRS_REQUIRE(dtype == TRS_F32 || dtype == TRS_BF16, TRS_EDTYPE, "cross_bwd: dtype %d", dtype);
-  (void)workspace; (void)ws_bytes;
   if (rows == 0) return TRS_OK;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == TRS_BF16 && L > 0) {
-    const int rc = cross_mfma_bwd(x, W, b, g, rows, E, L, dx, dW, db, detach_first, s);
+    const int rc = cross_mfma_bwd(x, W, b, g, rows, E, L, dx, dW, db, detach_first, workspace, ws_bytes, s);
     if (rc <= 0) return rc;
   }
   int R = CR;

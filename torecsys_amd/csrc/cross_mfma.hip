@@ -1,7 +1,225 @@
-// MFMA cross-network path (bf16): placeholder until the kernel lands -- reports "shape not covered".
+// K4 on the matrix cores (bf16): x_{l+1} = x0 * (x_l W_l^T + b_l) + x0 for all L layers of a 16-row tile
+// without leaving registers.
+//
+// Formulation: Y^T = W * X^T with v_mfma_f32_16x16x32_bf16:  A = W tile (M = e_out, K = e_in),
+// B = X^T (K = e_in, N = 16 rows), D = Y^T (M = e_out, N = rows).  D's lane layout is
+// (col = lane&15 -> row r of x, rows 4*(lane>>4)+i -> e_out slot), B's is (col = lane&15 -> r,
+// k = 8*(lane>>4)+j).  The rows of W are fed in a permuted order
+//     e_out(mt, q, i) = 32*(mt>>1) + 8*q + 4*(mt&1) + i          (mt = M-tile, q = lane>>4, i = reg)
+// so that the 16 outputs a lane holds for its row r are exactly the 8-element chunks [32c+8q, 32c+8q+8)
+// of that row: the NEXT layer's B operand is the lane's own registers (converted to bf16, no shuffle,
+// no LDS), x0/out move as 16-byte vectors, and the elementwise epilogue x0*(u+b)+x0 is lane-local (the
+// bias enters as the accumulator's initial value).  W_l fragments are pre-packed once per call into
+// fragment order (1 KiB per (layer, mt, ks), lane-linear -> conflict-free ds_read_b128) and kept in LDS.
+// HBM traffic: x read once, out written once (2*E*2 bytes per row); FLOPs 2*E*E*L per row on MFMA.
 #include "trs_common.hpp"
+
 namespace trs {
-int cross_mfma_fwd(const void*, const void*, const void*, int64_t, int, int, void*, hipStream_t) { return 1; }
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// e_out of D-row slot (mt, m) where m = 4*q + i is the row inside the 16-row M tile
+__host__ __device__ __forceinline__ int cross_row_of_slot(int mt, int m) {
+  return 32 * (mt >> 1) + 8 * (m >> 2) + 4 * (mt & 1) + (m & 3);
+}
+
+// Pre-pack: Wp[(l*NT + mt)*KS + ks][lane][8] = W_l[row(mt, lane&15)][32*ks + 8*(lane>>4) + 0..7]
+// TRANSPOSE: pack W_l^T instead (used by the backward's data-gradient chain g_l = W_l^T du_l).
+template <bool TRANSPOSE>
+__global__ __launch_bounds__(256) void cross_prepack_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ b,
+                                                            bf16_t* __restrict__ Wp, float* __restrict__ bp, int E,
+                                                            int L) {
+  const int NT = E / 16, KS = E / 32;
+  const int total = L * NT * KS * 64;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+    const int lane = t & 63;
+    int f = t >> 6;
+    const int ks = f % KS;
+    f /= KS;
+    const int mt = f % NT;
+    const int l = f / NT;
+    const int row = cross_row_of_slot(mt, lane & 15);
+    const int k0 = 32 * ks + 8 * (lane >> 4);
+    const bf16_t* Wl = W + (size_t)l * E * E;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      Wp[(size_t)t * 8 + j] = TRANSPOSE ? Wl[(size_t)(k0 + j) * E + row] : Wl[(size_t)row * E + k0 + j];
+  }
+  if (bp != nullptr)
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < L * E; t += gridDim.x * blockDim.x) bp[t] = to_f32(b[t]);
+}
+
+template <int NT>
+struct XTile {
+  float v[NT][4];  // D layout: v[mt][i] <-> e = 32*(mt>>1) + 8*q + 4*(mt&1) + i of row r = lane&15
+};
+
+template <int NT>
+__device__ __forceinline__ void load_tile(const uint4* __restrict__ x, int64_t row, int64_t rows, int E, int q,
+                                          XTile<NT>& t, uint4* raw) {
+  constexpr int KS = NT / 2;
+#pragma unroll
+  for (int c = 0; c < KS; ++c) {
+    uint4 u = make_uint4(0, 0, 0, 0);
+    if (row < rows) u = x[(row * E + 32 * c + 8 * q) >> 3];
+    raw[c] = u;
+    float f[8];
+    Vec16<bf16_t>::unpack(u, f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      t.v[2 * c][i] = f[i];
+      t.v[2 * c + 1][i] = f[4 + i];
+    }
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void pack_tile(const XTile<NT>& t, uint4* raw) {
+  constexpr int KS = NT / 2;
+#pragma unroll
+  for (int c = 0; c < KS; ++c) {
+    float f[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[i] = t.v[2 * c][i];
+      f[4 + i] = t.v[2 * c + 1][i];
+    }
+    raw[c] = Vec16<bf16_t>::pack(f);
+  }
+}
+
+// one layer for TP tiles at once: acc[t][mt] = bias + sum_ks A[mt][ks] * B[t][ks]; every A fragment read
+// from LDS feeds TP MFMAs, and the TP independent chains let the MFMA of one tile overlap the VALU
+// epilogue of the other inside a single wave.
+template <int NT, int TP>
+__device__ __forceinline__ void layer_matmul(const uint4* __restrict__ Wfrag /* [NT][KS][64] */,
+                                             const float* __restrict__ bias /* [E] or null */,
+                                             const uint4 (*B)[NT / 2], int lane, int q, f32x4 (*acc)[NT]) {
+  constexpr int KS = NT / 2;
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt) {
+    f32x4 init = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (bias != nullptr) {
+      const float4 bv = *reinterpret_cast<const float4*>(bias + 32 * (mt >> 1) + 8 * q + 4 * (mt & 1));
+      init = f32x4{bv.x, bv.y, bv.z, bv.w};
+    }
+#pragma unroll
+    for (int t = 0; t < TP; ++t) acc[t][mt] = init;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const uint4 a = Wfrag[(mt * KS + ks) * 64 + lane];
+#pragma unroll
+      for (int t = 0; t < TP; ++t)
+        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                             __builtin_bit_cast(bf16x8, B[t][ks]), acc[t][mt], 0, 0, 0);
+    }
+  }
+}
+
+// RESIDENT: all layers' fragments + biases are copied into LDS once per workgroup; otherwise they are
+// read from the pre-packed global buffer (L1/L2-resident) -- large E*E*L only.
+template <int NT, bool RESIDENT>
+__global__ __launch_bounds__(256) void cross_mfma_fwd_kernel(const uint4* __restrict__ x,
+                                                             const uint4* __restrict__ Wp,
+                                                             const float* __restrict__ bp, int64_t rows, int L,
+                                                             uint4* __restrict__ out) {
+  constexpr int KS = NT / 2;
+  constexpr int E = NT * 16;
+  constexpr int TP = NT <= 4 ? 2 : 1;           // tiles per wave iteration
+  constexpr int FRAG_PER_LAYER = NT * KS * 64;  // uint4 units
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint4* Wl = Wp;
+  const float* bl = bp;
+  if (RESIDENT) {
+    uint4* Ws = reinterpret_cast<uint4*>(smem);
+    float* bs = reinterpret_cast<float*>(smem + (size_t)L * FRAG_PER_LAYER * 16);
+    for (int i = threadIdx.x; i < L * FRAG_PER_LAYER; i += blockDim.x) Ws[i] = Wp[i];
+    for (int i = threadIdx.x; i < L * E; i += blockDim.x) bs[i] = bp[i];
+    __syncthreads();
+    Wl = Ws;
+    bl = bs;
+  }
+  const int lane = threadIdx.x & 63, q = lane >> 4, r = lane & 15;
+  const int64_t ngroups = (rows + 16 * TP - 1) / (16 * TP);
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t grp = wave; grp < ngroups; grp += nwaves) {
+    XTile<NT> x0[TP], cur[TP];
+    uint4 B[TP][KS];
+    int64_t row[TP];
+#pragma unroll
+    for (int t = 0; t < TP; ++t) {
+      row[t] = (grp * TP + t) * 16 + r;
+      load_tile<NT>(x, row[t], rows, E, q, x0[t], B[t]);
+    }
+    for (int l = 0; l < L; ++l) {
+      f32x4 acc[TP][NT];
+      layer_matmul<NT, TP>(Wl + (size_t)l * FRAG_PER_LAYER, bl + l * E, B, lane, q, acc);
+#pragma unroll
+      for (int t = 0; t < TP; ++t) {
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) cur[t].v[mt][i] = fmaf(x0[t].v[mt][i], acc[t][mt][i], x0[t].v[mt][i]);
+        pack_tile<NT>(cur[t], B[t]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TP; ++t) {
+      if (row[t] < rows) {
+#pragma unroll
+        for (int c = 0; c < KS; ++c) out[(row[t] * E + 32 * c + 8 * q) >> 3] = B[t][c];
+      }
+    }
+  }
+}
+
+static size_t cross_pack_bytes(int E, int L) { return (size_t)L * E * E * 2; }
+
+size_t cross_mfma_workspace_bytes(int E, int L) {
+  // [Wp fwd][Wp transposed][bias fp32], each 256-byte aligned
+  auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+  return 2 * al(cross_pack_bytes(E, L)) + al((size_t)L * E * 4);
+}
+
+static bool cross_mfma_covers(int E, int L) { return E % 32 == 0 && E >= 32 && E <= 128 && L >= 1; }
+
+int cross_mfma_fwd(const void* x, const void* W, const void* b, int64_t rows, int E, int L, void* out,
+                   void* workspace, size_t ws_bytes, hipStream_t s) {
+  if (!cross_mfma_covers(E, L) || !aligned16(x) || !aligned16(out) || workspace == nullptr) return 1;
+  if (ws_bytes < cross_mfma_workspace_bytes(E, L)) return fail(TRS_EWORKSPACE, "cross_fwd: workspace too small");
+  auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+  bf16_t* Wp = (bf16_t*)workspace;
+  float* bp = (float*)((char*)workspace + 2 * al(cross_pack_bytes(E, L)));
+  hipLaunchKernelGGL((cross_prepack_kernel<false>), dim3(std::min(64, (L * E * E / 8 + 255) / 256)), dim3(256), 0, s,
+                     (const bf16_t*)W, (const bf16_t*)b, Wp, bp, E, L);
+  const size_t lds = cross_pack_bytes(E, L) + (size_t)L * E * 4;
+  const bool resident = lds <= 64 * 1024;
+  const int64_t ntiles = (rows + 15) / 16;
+  const int grid = (int)std::min<int64_t>((ntiles + 7) / 8, resident ? 256 * 3 : 256 * 8);
+#define TRS_CF(NT_)                                                                                              \
+  do {                                                                                                           \
+    if (resident)                                                                                                \
+      hipLaunchKernelGGL((cross_mfma_fwd_kernel<NT_, true>), dim3(grid), dim3(256), lds, s, (const uint4*)x,     \
+                         (const uint4*)Wp, bp, rows, L, (uint4*)out);                                            \
+    else                                                                                                         \
+      hipLaunchKernelGGL((cross_mfma_fwd_kernel<NT_, false>), dim3(grid), dim3(256), 0, s, (const uint4*)x,      \
+                         (const uint4*)Wp, bp, rows, L, (uint4*)out);                                            \
+  } while (0)
+  switch (E / 16) {
+    case 2: TRS_CF(2); break;
+    case 4: TRS_CF(4); break;
+    case 6: TRS_CF(6); break;
+    default: TRS_CF(8); break;
+  }
+#undef TRS_CF
+  return check_launch("cross_fwd(mfma)");
+}
+
 int cross_mfma_bwd(const void*, const void*, const void*, const void*, int64_t, int, int, void*, float*, float*, int,
-                   hipStream_t) { return 1; }
+                   void*, size_t, hipStream_t) {
+  return 1;  // not covered yet: the generic kernel handles the backward
+}
+
 }  // namespace trs

@@ -18,19 +18,36 @@ constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 // rows with more than LONG_ROW lookups are reduced by a whole workgroup (Zipf-hot rows)
 constexpr int LONG_ROW = 256;
 
+// 4 independent lookups per thread per iteration: 4 index loads, then 4 returning atomics in flight
 template <typename IdxT>
 __global__ __launch_bounds__(256) void csr_count_kernel(const IdxT* __restrict__ idx,
                                                         const int64_t* __restrict__ offsets, int64_t BN, int N,
                                                         int64_t V, int32_t* __restrict__ count,
                                                         int32_t* __restrict__ slot, int32_t* __restrict__ err_flag) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < BN; p += stride) {
-    const int64_t r = load_row_id(idx, offsets, p, (int)(p % N));
-    if (r < 0 || r >= V) {
-      if (err_flag != nullptr) *err_flag = 1;
-      slot[p] = -1;
-    } else {
-      slot[p] = atomicAdd(&count[r], 1);
+  constexpr int U = 4;
+  const unsigned n_items = (unsigned)BN, uN = (unsigned)N;
+  const unsigned stride = gridDim.x * blockDim.x;
+  for (unsigned p0 = blockIdx.x * blockDim.x + threadIdx.x; p0 < n_items; p0 += stride * U) {
+    int64_t r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned p = p0 + u * stride;
+      r[u] = -1;
+      if (p < n_items) {
+        r[u] = load_row_id(idx, offsets, (int64_t)p, (int)(p % uN));
+        if (r[u] < 0 || r[u] >= V) {
+          if (err_flag != nullptr) *err_flag = 1;
+          r[u] = -1;
+        }
+      }
+    }
+    int sl[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) sl[u] = r[u] >= 0 ? atomicAdd(&count[r[u]], 1) : -1;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned p = p0 + u * stride;
+      if (p < n_items) slot[p] = sl[u];
     }
   }
 }
@@ -109,13 +126,24 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const IdxT* __restrict__ 
                                                        const int64_t* __restrict__ offsets, int64_t BN, int N,
                                                        const int32_t* __restrict__ row_start,
                                                        const int32_t* __restrict__ slot, int32_t* __restrict__ perm) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < BN; p += stride) {
-    const int sl = slot[p];
-    if (sl >= 0) {
-      const int64_t r = load_row_id(idx, offsets, p, (int)(p % N));
-      perm[row_start[r] + sl] = (int32_t)p;
+  constexpr int U = 4;
+  const unsigned n_items = (unsigned)BN, uN = (unsigned)N;
+  const unsigned stride = gridDim.x * blockDim.x;
+  for (unsigned p0 = blockIdx.x * blockDim.x + threadIdx.x; p0 < n_items; p0 += stride * U) {
+    int sl[U];
+    int64_t r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned p = p0 + u * stride;
+      sl[u] = p < n_items ? slot[p] : -1;
+      r[u] = sl[u] >= 0 ? load_row_id(idx, offsets, (int64_t)p, (int)(p % uN)) : 0;
     }
+    int base[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) base[u] = sl[u] >= 0 ? row_start[r[u]] : 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (sl[u] >= 0) perm[base[u] + sl[u]] = (int32_t)(p0 + u * stride);
   }
 }
 

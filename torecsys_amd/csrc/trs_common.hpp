@@ -26,12 +26,18 @@ struct bf16_t {
 
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t bits16) { return __uint_as_float(bits16 << 16); }
 
-// round-to-nearest-even, NaN preserved (same rounding as at::BFloat16)
+// round-to-nearest-even (same rounding as at::BFloat16); lowers to the gfx950 hardware convert
+// v_cvt_pk_bf16_f32 -- the bit-twiddling form costs ~5 VALU ops per element and made bf16 epilogues
+// VALU-bound.
+typedef __attribute__((ext_vector_type(2))) __bf16 trs_bf16x2;
+__device__ __forceinline__ uint32_t f32x2_to_bf16x2_bits(float lo, float hi) {
+  trs_bf16x2 v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(uint32_t, v);
+}
 __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return u >> 16;
+  return (uint32_t)__builtin_bit_cast(unsigned short, (__bf16)f);
 }
 
 __device__ __forceinline__ float to_f32(float x) { return x; }
@@ -68,10 +74,10 @@ struct Vec16<bf16_t> {
   }
   static __device__ __forceinline__ uint4 pack(const float* f) {
     uint4 u;
-    u.x = f32_to_bf16_bits(f[0]) | (f32_to_bf16_bits(f[1]) << 16);
-    u.y = f32_to_bf16_bits(f[2]) | (f32_to_bf16_bits(f[3]) << 16);
-    u.z = f32_to_bf16_bits(f[4]) | (f32_to_bf16_bits(f[5]) << 16);
-    u.w = f32_to_bf16_bits(f[6]) | (f32_to_bf16_bits(f[7]) << 16);
+    u.x = f32x2_to_bf16x2_bits(f[0], f[1]);
+    u.y = f32x2_to_bf16x2_bits(f[2], f[3]);
+    u.z = f32x2_to_bf16x2_bits(f[4], f[5]);
+    u.w = f32x2_to_bf16x2_bits(f[6], f[7]);
     return u;
   }
 };

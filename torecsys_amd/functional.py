@@ -63,8 +63,25 @@ _side_streams = {}
 PREFETCH_BUCKETS = os.environ.get("TRS_PREFETCH_BUCKETS", "1") not in ("", "0")
 
 
+_offsets_content = {}     # offsets tensor (ptr, version) -> tuple of its values (read back once)
+
+
+def _offsets_key(offsets):
+    """Content key of a per-field offsets vector, so two modules built from the same field sizes (the E=64
+    table and the E=1 first-order table of one model) share the row buckets of a batch."""
+    if offsets is None:
+        return None
+    k = (offsets.data_ptr(), offsets._version, offsets.numel())
+    v = _offsets_content.get(k)
+    if v is None:
+        if len(_offsets_content) > 256:
+            _offsets_content.clear()
+        v = _offsets_content[k] = tuple(offsets.tolist())
+    return v
+
+
 def _bucket_key(idx, offsets, V):
-    return (idx.data_ptr(), idx._version, tuple(idx.shape), idx.dtype, 0 if offsets is None else offsets.data_ptr(), V)
+    return (idx.data_ptr(), idx._version, tuple(idx.shape), idx.dtype, _offsets_key(offsets), V)
 
 
 def _build_buckets(idx, offsets, V) -> RowBuckets:
@@ -428,7 +445,10 @@ class _Cross(Function):
         Wc = W.to(x.dtype).contiguous()
         bc = b.to(x.dtype).contiguous()
         out = torch.empty_like(x)
-        call("trs_cross_fwd", ptr(x), ptr(Wc), ptr(bc), rows, E, L, value_dtype_code(x), ptr(out), stream_ptr())
+        ws_bytes = size_query("trs_cross_workspace_bytes", rows, E, L, value_dtype_code(x))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
+        call("trs_cross_fwd", ptr(x), ptr(Wc), ptr(bc), rows, E, L, value_dtype_code(x), ptr(out), ptr(ws), ws_bytes,
+             stream_ptr())
         ctx.save_for_backward(x, Wc, bc)
         ctx.detach_first = bool(detach_first)
         ctx.param_dtypes = (W.dtype, b.dtype)
@@ -443,8 +463,10 @@ class _Cross(Function):
         dx = torch.empty_like(x)
         dW = torch.zeros(L, E, E, dtype=torch.float32, device=x.device)
         db = torch.zeros(L, E, dtype=torch.float32, device=x.device)
+        ws_bytes = size_query("trs_cross_workspace_bytes", rows, E, L, value_dtype_code(x))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
         call("trs_cross_bwd", ptr(x), ptr(Wc), ptr(bc), ptr(g.contiguous()), rows, E, L, value_dtype_code(x),
-             1 if ctx.detach_first else 0, ptr(dx), ptr(dW), ptr(db), ptr(None), 0, stream_ptr())
+             1 if ctx.detach_first else 0, ptr(dx), ptr(dW), ptr(db), ptr(ws), ws_bytes, stream_ptr())
         return dx, dW.to(ctx.param_dtypes[0]), db.to(ctx.param_dtypes[1]), None
 
 
