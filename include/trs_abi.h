@@ -88,8 +88,9 @@ int trs_csr_build(const void* idx, int32_t idx_dtype, const int64_t* offsets, in
  * first-order sum's backward).  g_rows_batch_stride (rows; 0 = N) lets g_rows be a (B, N, E) slice
  * of a larger (B, M, E) tensor: the row of position (b,n) is b*stride + n.
  * Rows with more than 256 lookups (Zipf-hot rows) are queued in `workspace`
- * (trs_scatter_workspace_bytes(B*N)) and reduced by whole workgroups.                          */
-size_t trs_scatter_workspace_bytes(int64_t BN);
+ * (trs_scatter_workspace_bytes) and reduced by whole workgroups; the workspace also holds the
+ * per-sample [g*S | g] rows the FM term is read from.                         */
+size_t trs_scatter_workspace_bytes(int64_t BN, int32_t N, int32_t E, int32_t dtype);
 int trs_scatter_rows(const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm,
                      const float* fm_sum, const void* table, const int32_t* row_start,
                      const int32_t* perm, int64_t BN, int64_t V, int32_t E, int32_t N, int32_t dtype,

@@ -34,7 +34,7 @@ def test_exports_every_declared_symbol(lib):
 def test_version_and_sizes(lib):
     assert lib.trs_version() == 1
     assert lib.trs_csr_workspace_bytes(1000, 100) >= 400
-    assert lib.trs_scatter_workspace_bytes(100000) >= 8
+    assert lib.trs_scatter_workspace_bytes(100000, 10, 16, 1) >= 8
 
 
 def test_argument_errors_without_gpu(lib):

@@ -62,7 +62,12 @@ __global__ __launch_bounds__(256) void embed_fm_group_kernel(
           Vec16<T>::unpack(v[c], x);
 #pragma unroll
           for (int k = 0; k < VE; ++k) { s[k] += x[k]; q[k] = fmaf(x[k], x[k], q[k]); }
-          if (GATHER && emb != nullptr) emb[(b * N + n) * L + lane_v] = v[c];
+          if (GATHER && emb != nullptr) {
+            typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+            const u32x4 w = {v[c].x, v[c].y, v[c].z, v[c].w};
+            // streaming store: the block is consumed by a later kernel, keep L2 for the table rows
+            __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(&emb[(b * N + n) * L + lane_v]));
+          }
         }
       }
     }

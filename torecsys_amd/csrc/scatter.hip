@@ -160,13 +160,14 @@ __device__ __forceinline__ void accumulate_bucket(float* acc, float* gsum, const
   constexpr int CH = 4;
   for (int q = beg; q < end; q += CH * step) {
     int p[CH];
-    uint4 gv[CH], fv[CH];
+    uint4 gv[CH], fv[CH], tv[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) p[c] = (q + c * step) < end ? perm[q + c * step] : -1;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       gv[c] = make_uint4(0, 0, 0, 0);
       fv[c] = make_uint4(0, 0, 0, 0);
+      tv[c] = make_uint4(0, 0, 0, 0);
       if (p[c] >= 0) {
         if (HAS_G) {
           int64_t row = p[c];
@@ -176,7 +177,15 @@ __device__ __forceinline__ void accumulate_bucket(float* acc, float* gsum, const
           }
           gv[c] = g_rows[row * L + lane_v];
         }
-        if (HAS_FM) fv[c] = g_fm[(int64_t)((unsigned)p[c] / (unsigned)N) * L + lane_v];
+        if (HAS_FM) {
+          const int64_t b = (int64_t)((unsigned)p[c] / (unsigned)N);
+          if (fm_sum != nullptr) {  // FM mode: g_fm points at TG = [g*S | g] rows of 2*L vectors
+            tv[c] = g_fm[b * 2 * L + lane_v];
+            fv[c] = g_fm[b * 2 * L + L + lane_v];
+          } else {
+            fv[c] = g_fm[b * L + lane_v];
+          }
+        }
       }
     }
 #pragma unroll
@@ -192,10 +201,11 @@ __device__ __forceinline__ void accumulate_bucket(float* acc, float* gsum, const
           float gf[VE];
           Vec16<T>::unpack(fv[c], gf);
           if (fm_sum != nullptr) {
-            const float* sp = fm_sum + ((int64_t)((unsigned)p[c] / (unsigned)N) * L + lane_v) * VE;
+            float tg[VE];
+            Vec16<T>::unpack(tv[c], tg);
 #pragma unroll
             for (int k = 0; k < VE; ++k) {
-              acc[k] = fmaf(gf[k], sp[k], acc[k]);
+              acc[k] += tg[k];
               gsum[k] += gf[k];
             }
           } else {  // plain per-sample broadcast gradient (first-order sum): no FM weighting
@@ -291,12 +301,53 @@ __global__ __launch_bounds__(256) void scatter_long_rows_kernel(
   }
 }
 
-// generic element path (any E): one thread per (row, e)
+// TG[b] = [ g_fm[b,:] * fm_sum[b,:]  |  g_fm[b,:] ]  (2*E values per sample, table dtype): the FM backward
+// operands of one sample become ONE contiguous 2*E*s-byte read per lookup (instead of a g_fm row plus a
+// 4*E-byte fp32 fm_sum row at two random addresses).
+template <typename T>
+__global__ __launch_bounds__(256) void build_tg_kernel(const uint4* __restrict__ g_fm, const float* __restrict__ fm_sum,
+                                                       uint4* __restrict__ tg, int64_t B, int L) {
+  constexpr int VE = Vec16<T>::VE;
+  const int64_t total = B * L, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t b = t / L;
+    const int lv = (int)(t - b * L);
+    const uint4 gv = g_fm[t];
+    float g[VE], o[VE];
+    Vec16<T>::unpack(gv, g);
+    const float* sp = fm_sum + t * VE;
+#pragma unroll
+    for (int k = 0; k < VE; ++k) o[k] = g[k] * sp[k];
+    tg[b * 2 * L + lv] = Vec16<T>::pack(o);
+    tg[b * 2 * L + L + lv] = gv;
+  }
+}
+
+// generic element path (any E): one thread per (row, e); hot rows are queued like in the group path
+template <typename T>
+__device__ __forceinline__ float elem_term(const T* __restrict__ g_rows, const T* __restrict__ g_fm,
+                                           const float* __restrict__ fm_sum, int64_t p, int E, int N, int64_t gbs, int e,
+                                           float* gsum) {
+  const int64_t b = p / N;
+  float acc = 0.f;
+  if (g_rows != nullptr) acc += to_f32(g_rows[(b * gbs + (p - b * N)) * E + e]);
+  if (g_fm != nullptr) {
+    const float gf = to_f32(g_fm[b * E + e]);
+    if (fm_sum != nullptr) {
+      acc = fmaf(gf, fm_sum[b * E + e], acc);
+      *gsum += gf;
+    } else {
+      acc += gf;
+    }
+  }
+  return acc;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void scatter_rows_elem_kernel(
     const T* __restrict__ g_rows, const T* __restrict__ g_fm, const float* __restrict__ fm_sum,
     const T* __restrict__ table, const int32_t* __restrict__ row_start, const int32_t* __restrict__ perm, int64_t V,
-    int E, int N, int64_t gbs, int64_t padding_row, T* __restrict__ grad) {
+    int E, int N, int64_t gbs, int64_t padding_row, T* __restrict__ grad, int32_t* __restrict__ long_rows) {
   const int64_t total = V * E;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
@@ -305,23 +356,50 @@ __global__ __launch_bounds__(256) void scatter_rows_elem_kernel(
     float acc = 0.f, gsum = 0.f;
     if (r != padding_row) {
       const int beg = row_start[r], end = row_start[r + 1];
-      for (int q = beg; q < end; ++q) {
-        const int64_t p = perm[q];
-        const int64_t b = p / N;
-        if (g_rows != nullptr) acc += to_f32(g_rows[(b * gbs + (p - b * N)) * E + e]);
-        if (g_fm != nullptr) {
-          const float gf = to_f32(g_fm[b * E + e]);
-          if (fm_sum != nullptr) {
-            acc = fmaf(gf, fm_sum[b * E + e], acc);
-            gsum += gf;
-          } else {
-            acc += gf;
-          }
+      if (end - beg > LONG_ROW) {
+        if (e == 0) {
+          const int slot = atomicAdd(&long_rows[0], 1);
+          long_rows[1 + slot] = (int32_t)r;
         }
+        continue;
       }
+      for (int q = beg; q < end; ++q) acc += elem_term<T>(g_rows, g_fm, fm_sum, perm[q], E, N, gbs, e, &gsum);
       if (g_fm != nullptr && fm_sum != nullptr && end > beg) acc = fmaf(-to_f32(table[t]), gsum, acc);
     }
     grad[t] = from_f32<T>(acc);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_long_rows_elem_kernel(
+    const T* __restrict__ g_rows, const T* __restrict__ g_fm, const float* __restrict__ fm_sum,
+    const T* __restrict__ table, const int32_t* __restrict__ row_start, const int32_t* __restrict__ perm, int E, int N,
+    int64_t gbs, T* __restrict__ grad, const int32_t* __restrict__ long_rows) {
+  __shared__ float red[2][4];
+  const int nlong = long_rows[0];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = blockIdx.x; i < nlong; i += gridDim.x) {
+    const int64_t r = long_rows[1 + i];
+    const int beg = row_start[r], end = row_start[r + 1];
+    for (int e = 0; e < E; ++e) {
+      float acc = 0.f, gsum = 0.f;
+      for (int q = beg + threadIdx.x; q < end; q += blockDim.x)
+        acc += elem_term<T>(g_rows, g_fm, fm_sum, perm[q], E, N, gbs, e, &gsum);
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) {
+        acc += __shfl_xor(acc, m, 64);
+        gsum += __shfl_xor(gsum, m, 64);
+      }
+      __syncthreads();
+      if (lane == 0) { red[0][wave] = acc; red[1][wave] = gsum; }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        acc = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        gsum = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        if (g_fm != nullptr && fm_sum != nullptr) acc = fmaf(-to_f32(table[r * E + e]), gsum, acc);
+        grad[r * E + e] = from_f32<T>(acc);
+      }
+    }
   }
 }
 
@@ -337,8 +415,14 @@ static int log2_lanes_sc(int row_bytes) {
 template <typename T, int LOG2L>
 static void scatter_group_launch(const void* g_rows, const void* g_fm, const float* fm_sum, const void* table,
                                  const int32_t* row_start, const int32_t* perm, int64_t V, int N, int64_t gbs,
-                                 int64_t padding_row, void* grad, int32_t* long_rows, hipStream_t s) {
+                                 int64_t padding_row, void* grad, int32_t* long_rows, void* tg, int64_t B,
+                                 hipStream_t s) {
   const int L = 1 << LOG2L;
+  if (g_fm != nullptr && fm_sum != nullptr) {
+    hipLaunchKernelGGL((build_tg_kernel<T>), dim3(stream_grid(B * L, 256, 4096)), dim3(256), 0, s, (const uint4*)g_fm,
+                       fm_sum, (uint4*)tg, B, L);
+    g_fm = tg;
+  }
   const int grid = stream_grid(V * L, 256, 256 * 32);
   const bool hg = g_rows != nullptr, hf = g_fm != nullptr;
 #define TRS_SC(HG, HF)                                                                                          \
@@ -359,23 +443,25 @@ static void scatter_group_launch(const void* g_rows, const void* g_fm, const flo
 template <typename T>
 static int scatter_launch(const void* g_rows, const void* g_fm, const float* fm_sum, const void* table,
                           const int32_t* row_start, const int32_t* perm, int64_t V, int E, int N, int64_t gbs,
-                          int64_t padding_row, void* grad, int32_t* long_rows, hipStream_t s) {
+                          int64_t padding_row, void* grad, int32_t* long_rows, void* tg, int64_t B, hipStream_t s) {
   const int lg = log2_lanes_sc(E * (int)sizeof(T));
   const bool al = aligned16(g_rows) && aligned16(g_fm) && aligned16(table) && aligned16(grad) && aligned16(fm_sum);
   if (lg >= 0 && al) {
     switch (lg) {
-      case 0: scatter_group_launch<T, 0>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, s); break;
-      case 1: scatter_group_launch<T, 1>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, s); break;
-      case 2: scatter_group_launch<T, 2>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, s); break;
-      case 3: scatter_group_launch<T, 3>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, s); break;
-      case 4: scatter_group_launch<T, 4>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, s); break;
-      case 5: scatter_group_launch<T, 5>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, s); break;
-      default: scatter_group_launch<T, 6>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, s); break;
+      case 0: scatter_group_launch<T, 0>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, B, s); break;
+      case 1: scatter_group_launch<T, 1>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, B, s); break;
+      case 2: scatter_group_launch<T, 2>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, B, s); break;
+      case 3: scatter_group_launch<T, 3>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, B, s); break;
+      case 4: scatter_group_launch<T, 4>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, B, s); break;
+      case 5: scatter_group_launch<T, 5>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, B, s); break;
+      default: scatter_group_launch<T, 6>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, B, s); break;
     }
   } else {
     hipLaunchKernelGGL((scatter_rows_elem_kernel<T>), dim3(stream_grid(V * E, 256, 256 * 32)), dim3(256), 0, s,
                        (const T*)g_rows, (const T*)g_fm, fm_sum, (const T*)table, row_start, perm, V, E, N, gbs,
-                       padding_row, (T*)grad);
+                       padding_row, (T*)grad, long_rows);
+    hipLaunchKernelGGL((scatter_long_rows_elem_kernel<T>), dim3(512), dim3(256), 0, s, (const T*)g_rows,
+                       (const T*)g_fm, fm_sum, (const T*)table, row_start, perm, E, N, gbs, (T*)grad, long_rows);
   }
   return check_launch("scatter_rows");
 }
@@ -395,7 +481,7 @@ extern "C" size_t trs_csr_workspace_bytes(int64_t V, int64_t BN) {
 extern "C" int trs_csr_build(const void* idx, int32_t idx_dtype, const int64_t* offsets, int64_t B, int32_t N,
                              int64_t V, int32_t* row_start, int32_t* perm, void* workspace, size_t ws_bytes,
                              int32_t* err_flag, trs_stream_t stream) {
-  TRS_REQUIRE(idx && row_start && perm && workspace, TRS_EINVAL, "csr_build: NULL pointer");
+  TRS_REQUIRE(row_start && workspace && (B == 0 || (idx && perm)), TRS_EINVAL, "csr_build: NULL pointer");
   TRS_REQUIRE(V > 0 && B >= 0 && N > 0, TRS_EINVAL, "csr_build: bad size");
   TRS_REQUIRE(idx_dtype == TRS_I64 || idx_dtype == TRS_I32, TRS_EDTYPE, "csr_build: idx dtype %d", idx_dtype);
   const int64_t BN = B * N;
@@ -433,9 +519,12 @@ extern "C" int trs_csr_build(const void* idx, int32_t idx_dtype, const int64_t* 
   return check_launch("csr_build");
 }
 
-extern "C" size_t trs_scatter_workspace_bytes(int64_t BN) {
-  // queue of hot rows: at most BN / LONG_ROW of them, + the counter
-  return align_up((size_t)(BN / LONG_ROW + 2) * 4, 256);
+static size_t long_row_queue_bytes(int64_t BN) { return align_up((size_t)(BN / LONG_ROW + 2) * 4, 256); }
+
+extern "C" size_t trs_scatter_workspace_bytes(int64_t BN, int32_t N, int32_t E, int32_t dtype) {
+  // [queue of hot rows: at most BN / LONG_ROW of them, + the counter][TG: (BN/N) x 2E values]
+  const int64_t B = N > 0 ? (BN + N - 1) / N : 0;
+  return long_row_queue_bytes(BN) + align_up((size_t)B * 2 * E * dtype_size(dtype), 256);
 }
 
 extern "C" int trs_scatter_rows(const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm,
@@ -450,14 +539,17 @@ extern "C" int trs_scatter_rows(const void* g_rows, int64_t g_rows_batch_stride,
   TRS_REQUIRE(gbs >= N, TRS_EINVAL, "scatter_rows: g_rows_batch_stride %lld < N", (long long)gbs);
   TRS_REQUIRE(V > 0 && E > 0 && N > 0 && BN >= 0, TRS_EINVAL, "scatter_rows: bad size");
   TRS_REQUIRE(dtype == TRS_F32 || dtype == TRS_BF16, TRS_EDTYPE, "scatter_rows: dtype %d", dtype);
-  TRS_REQUIRE(ws_bytes >= trs_scatter_workspace_bytes(BN), TRS_EWORKSPACE, "scatter_rows: workspace %zu < %zu",
-              ws_bytes, trs_scatter_workspace_bytes(BN));
+  TRS_REQUIRE(ws_bytes >= trs_scatter_workspace_bytes(BN, N, E, dtype), TRS_EWORKSPACE,
+              "scatter_rows: workspace %zu < %zu", ws_bytes, trs_scatter_workspace_bytes(BN, N, E, dtype));
+  TRS_REQUIRE(BN % N == 0, TRS_EINVAL, "scatter_rows: B*N=%lld not a multiple of N=%d", (long long)BN, N);
+  void* tg = (char*)workspace + long_row_queue_bytes(BN);
+  const int64_t B = BN / N;
   hipStream_t s = (hipStream_t)stream;
   int32_t* long_rows = (int32_t*)workspace;
   if (hipMemsetAsync(long_rows, 0, 4, s) != hipSuccess) return check_launch("scatter_rows(memset)");
   if (dtype == TRS_F32)
     return scatter_launch<float>(g_rows, g_fm, fm_sum, table, row_start, perm, V, E, N, gbs, padding_row,
-                                 grad_table, long_rows, s);
+                                 grad_table, long_rows, tg, B, s);
   return scatter_launch<bf16_t>(g_rows, g_fm, fm_sum, table, row_start, perm, V, E, N, gbs, padding_row, grad_table,
-                                long_rows, s);
+                                long_rows, tg, B, s);
 }

@@ -153,7 +153,7 @@ def scatter_rows(rb: RowBuckets, like_table: torch.Tensor, g_rows: Optional[torc
     """Dense gradient of a (V,E) table: see trs_scatter_rows in include/trs_abi.h."""
     V, E = like_table.shape
     grad = torch.empty_like(like_table)
-    ws_bytes = size_query("trs_scatter_workspace_bytes", rb.BN)
+    ws_bytes = size_query("trs_scatter_workspace_bytes", rb.BN, rb.N, E, value_dtype_code(like_table))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=like_table.device)
     call("trs_scatter_rows", ptr(g_rows), g_rows_batch_stride, ptr(g_bcast), ptr(fm_sum),
          ptr(like_table if fm_sum is not None else None), ptr(rb.row_start), ptr(rb.perm), rb.BN, V, E, rb.N,
