@@ -175,12 +175,193 @@ __global__ __launch_bounds__(256) void cross_mfma_fwd_kernel(const uint4* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward on the matrix cores.  Workgroup = 8 waves, wave w owns the 16-row tile w of a 128-row group.
+// Per tile, in registers: recompute x_1..x_{L-1} (kept as bf16 B fragments), then for l = L-1..0
+//   u_l  = W_l x_l + b_l (recomputed, MFMA)          du = g * x0          dx0 += g * (u_l + 1)
+//   g    = W_l^T du      (MFMA on the transposed fragments; skipped for l = 0 when detach_first)
+// dW_l = du^T x_l contracts over ROWS, which live on lanes in the layout above, so du and x_l are staged
+// transposed in LDS ([e][128 rows], bf16) once per layer and every wave accumulates its share of the E x E
+// output tiles (K = 128 rows = 4 MFMAs per tile) in registers across the whole kernel; db_l rides along as
+// one extra tile against an all-ones B operand.  Per-workgroup partial dW/db go to a workspace and are
+// summed by a second kernel (no float atomics).
+constexpr int BW_WAVES = 8;
+constexpr int BW_ROWS = 16 * BW_WAVES;          // rows per workgroup iteration
+constexpr int BW_STR = BW_ROWS * 2 + 16;        // bytes per staged e-row (pad: conflict-free b128 reads)
+
+template <int NT, int L>
+__global__ __launch_bounds__(512, 1) void cross_mfma_bwd_kernel(
+    const uint4* __restrict__ x, const uint4* __restrict__ gout, const uint4* __restrict__ Wp,
+    const uint4* __restrict__ WTp, const float* __restrict__ bp, int64_t rows, uint4* __restrict__ dx,
+    float* __restrict__ dWpart, float* __restrict__ dbpart, int detach_first) {
+  constexpr int KS = NT / 2;
+  constexpr int E = NT * 16;
+  constexpr int FRAG = NT * KS * 64;                       // uint4 per layer
+  constexpr int OUT_TILES = NT * NT;                       // 16x16 tiles of dW_l
+  constexpr int TPW = (OUT_TILES + BW_WAVES - 1) / BW_WAVES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* Ws = reinterpret_cast<uint4*>(smem);
+  uint4* WTs = Ws + L * FRAG;
+  float* bs = reinterpret_cast<float*>(WTs + L * FRAG);
+  char* duT = reinterpret_cast<char*>(bs + L * E);
+  char* xT = duT + E * BW_STR;
+  for (int i = threadIdx.x; i < L * FRAG; i += blockDim.x) { Ws[i] = Wp[i]; WTs[i] = WTp[i]; }
+  for (int i = threadIdx.x; i < L * E; i += blockDim.x) bs[i] = bp[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, r = lane & 15;
+  f32x4 dWacc[L][TPW];
+  f32x4 dbacc[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    dbacc[l] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) dWacc[l][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);  // 8 x bf16(1.0)
+  const int64_t ngroups = (rows + BW_ROWS - 1) / BW_ROWS;
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t row = grp * BW_ROWS + wave * 16 + r;
+    XTile<NT> x0, g, dx0;
+    uint4 Bx[L][KS];
+    uint4 Bg[KS];
+    load_tile<NT>(x, row, rows, E, q, x0, Bx[0]);
+    load_tile<NT>(gout, row, rows, E, q, g, Bg);
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dx0.v[mt][i] = 0.f;
+    // forward recompute of x_1 .. x_{L-1}
+#pragma unroll
+    for (int l = 0; l + 1 < L; ++l) {
+      f32x4 acc[1][NT];
+      layer_matmul<NT, 1>(Ws + l * FRAG, bs + l * E, &Bx[l], lane, q, acc);
+      XTile<NT> nx;
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) nx.v[mt][i] = fmaf(x0.v[mt][i], acc[0][mt][i], x0.v[mt][i]);
+      pack_tile<NT>(nx, Bx[l + 1]);
+    }
+#pragma unroll
+    for (int l = L - 1; l >= 0; --l) {
+      f32x4 acc[1][NT];
+      layer_matmul<NT, 1>(Ws + l * FRAG, bs + l * E, &Bx[l], lane, q, acc);   // u_l
+      XTile<NT> du;
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          du.v[mt][i] = g.v[mt][i] * x0.v[mt][i];
+          dx0.v[mt][i] = fmaf(g.v[mt][i], acc[0][mt][i] + 1.f, dx0.v[mt][i]);
+        }
+      uint4 Bdu[KS];
+      pack_tile<NT>(du, Bdu);
+      // stage du^T and x_l^T: element (e, row) as bf16 at [e][row]
+      {
+        const int col = (wave * 16 + r) * 2;
+#pragma unroll
+        for (int c = 0; c < KS; ++c) {
+          const unsigned wd[4] = {Bdu[c].x, Bdu[c].y, Bdu[c].z, Bdu[c].w};
+          const unsigned wx[4] = {Bx[l][c].x, Bx[l][c].y, Bx[l][c].z, Bx[l][c].w};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int e = 32 * c + 8 * q + j;
+            const unsigned short hd = (unsigned short)(j & 1 ? wd[j >> 1] >> 16 : wd[j >> 1] & 0xffffu);
+            const unsigned short hx = (unsigned short)(j & 1 ? wx[j >> 1] >> 16 : wx[j >> 1] & 0xffffu);
+            *reinterpret_cast<unsigned short*>(duT + e * BW_STR + col) = hd;
+            *reinterpret_cast<unsigned short*>(xT + e * BW_STR + col) = hx;
+          }
+        }
+      }
+      // data-gradient chain (register-only: overlaps the staging barrier)
+      XTile<NT> gn;
+      const bool need_g = (l > 0) || (detach_first == 0);
+      if (need_g) {
+        f32x4 ga[1][NT];
+        layer_matmul<NT, 1>(WTs + l * FRAG, nullptr, &Bdu, lane, q, ga);
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) gn.v[mt][i] = ga[0][mt][i];
+      }
+      __syncthreads();
+      // dW_l tiles: out tile t = wave*TPW + k -> (mo, no);  A = duT[16*mo + m][rows], B = xT[16*no + n][rows]
+#pragma unroll
+      for (int k = 0; k < TPW; ++k) {
+        const int t = wave * TPW + k;
+        if (t < OUT_TILES) {
+          const int mo = t / NT, no = t - mo * NT;
+#pragma unroll
+          for (int kk = 0; kk < BW_ROWS / 32; ++kk) {
+            const uint4 a = *reinterpret_cast<const uint4*>(duT + (16 * mo + r) * BW_STR + (32 * kk + 8 * q) * 2);
+            const uint4 b = *reinterpret_cast<const uint4*>(xT + (16 * no + r) * BW_STR + (32 * kk + 8 * q) * 2);
+            dWacc[l][k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                                  __builtin_bit_cast(bf16x8, b), dWacc[l][k], 0, 0, 0);
+          }
+        }
+      }
+      if (wave < NT) {   // db_l rows 16*wave .. +15: du^T x ones
+#pragma unroll
+        for (int kk = 0; kk < BW_ROWS / 32; ++kk) {
+          const uint4 a = *reinterpret_cast<const uint4*>(duT + (16 * wave + r) * BW_STR + (32 * kk + 8 * q) * 2);
+          dbacc[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                             __builtin_bit_cast(bf16x8, ones), dbacc[l], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+      if (need_g) g = gn;
+    }
+    if (row < rows) {
+      XTile<NT> o;
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o.v[mt][i] = dx0.v[mt][i] + (detach_first ? 0.f : g.v[mt][i]);
+      uint4 raw[KS];
+      pack_tile<NT>(o, raw);
+#pragma unroll
+      for (int c = 0; c < KS; ++c) dx[(row * E + 32 * c + 8 * q) >> 3] = raw[c];
+    }
+  }
+  // partial results of this workgroup: D layout -> (row m = 4q+i, col n = r)
+  float* myW = dWpart + (size_t)blockIdx.x * L * E * E;
+  float* myb = dbpart + (size_t)blockIdx.x * L * E;
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+      const int t = wave * TPW + k;
+      if (t < OUT_TILES) {
+        const int mo = t / NT, no = t - mo * NT;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) myW[(size_t)l * E * E + (16 * mo + 4 * q + i) * E + 16 * no + r] = dWacc[l][k][i];
+      }
+    }
+    if (wave < NT && r == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) myb[l * E + 16 * wave + 4 * q + i] = dbacc[l][i];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void cross_reduce_partials_kernel(const float* __restrict__ part, int nparts,
+                                                                    int n, float* __restrict__ out) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * n + i];
+    out[i] += s;
+  }
+}
+
+constexpr int BW_MAX_BLOCKS = 256;
+
 static size_t cross_pack_bytes(int E, int L) { return (size_t)L * E * E * 2; }
 
 size_t cross_mfma_workspace_bytes(int E, int L) {
-  // [Wp fwd][Wp transposed][bias fp32], each 256-byte aligned
+  // [Wp fwd][Wp transposed][bias fp32][per-workgroup dW partials][db partials], each 256-byte aligned
   auto al = [](size_t v) { return (v + 255) / 256 * 256; };
-  return 2 * al(cross_pack_bytes(E, L)) + al((size_t)L * E * 4);
+  return 2 * al(cross_pack_bytes(E, L)) + al((size_t)L * E * 4) + al((size_t)BW_MAX_BLOCKS * L * E * E * 4) +
+         al((size_t)BW_MAX_BLOCKS * L * E * 4);
 }
 
 static bool cross_mfma_covers(int E, int L) { return E % 32 == 0 && E >= 32 && E <= 128 && L >= 1; }
@@ -217,9 +398,69 @@ int cross_mfma_fwd(const void* x, const void* W, const void* b, int64_t rows, in
   return check_launch("cross_fwd(mfma)");
 }
 
-int cross_mfma_bwd(const void*, const void*, const void*, const void*, int64_t, int, int, void*, float*, float*, int,
-                   void*, size_t, hipStream_t) {
-  return 1;  // not covered yet: the generic kernel handles the backward
+template <int NT, int L>
+static int cross_bwd_launch(const void* x, const void* g, const uint4* Wp, const uint4* WTp, const float* bp, int64_t rows,
+                            void* dx, float* dWpart, float* dbpart, float* dW, float* db, int detach_first,
+                            hipStream_t s) {
+  constexpr int E = NT * 16;
+  const size_t lds = (size_t)2 * L * E * E * 2 + (size_t)L * E * 4 + (size_t)2 * E * BW_STR;
+  auto kern = cross_mfma_bwd_kernel<NT, L>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return check_launch("cross_bwd(mfma): LDS attribute");
+    attr_set = true;
+  }
+  const int64_t ngroups = (rows + BW_ROWS - 1) / BW_ROWS;
+  const int grid = (int)std::min<int64_t>(ngroups, BW_MAX_BLOCKS);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, (const uint4*)x, (const uint4*)g, Wp, WTp, bp, rows,
+                     (uint4*)dx, dWpart, dbpart, detach_first);
+  hipLaunchKernelGGL(cross_reduce_partials_kernel, dim3((L * E * E + 255) / 256), dim3(256), 0, s, dWpart, grid,
+                     L * E * E, dW);
+  hipLaunchKernelGGL(cross_reduce_partials_kernel, dim3((L * E + 255) / 256), dim3(256), 0, s, dbpart, grid, L * E, db);
+  return check_launch("cross_bwd(mfma)");
+}
+
+int cross_mfma_bwd(const void* x, const void* W, const void* b, const void* g, int64_t rows, int E, int L, void* dx,
+                   float* dW, float* db, int detach_first, void* workspace, size_t ws_bytes, hipStream_t s) {
+  if (!(E == 32 || E == 64) || L < 1 || L > 6 || !aligned16(x) || !aligned16(g) || !aligned16(dx) ||
+      workspace == nullptr)
+    return 1;
+  if (ws_bytes < cross_mfma_workspace_bytes(E, L)) return fail(TRS_EWORKSPACE, "cross_bwd: workspace too small");
+  auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+  char* ws = (char*)workspace;
+  bf16_t* Wp = (bf16_t*)ws;
+  bf16_t* WTp = (bf16_t*)(ws + al(cross_pack_bytes(E, L)));
+  float* bp = (float*)(ws + 2 * al(cross_pack_bytes(E, L)));
+  float* dWpart = (float*)((char*)bp + al((size_t)L * E * 4));
+  float* dbpart = (float*)((char*)dWpart + al((size_t)BW_MAX_BLOCKS * L * E * E * 4));
+  const int pgrid = std::min(64, (L * E * E / 8 + 255) / 256);
+  hipLaunchKernelGGL((cross_prepack_kernel<false>), dim3(pgrid), dim3(256), 0, s, (const bf16_t*)W, (const bf16_t*)b, Wp,
+                     bp, E, L);
+  hipLaunchKernelGGL((cross_prepack_kernel<true>), dim3(pgrid), dim3(256), 0, s, (const bf16_t*)W, (const bf16_t*)b, WTp,
+                     (float*)nullptr, E, L);
+#define TRS_CB(NT_, L_)                                                                                              \
+  return cross_bwd_launch<NT_, L_>(x, g, (const uint4*)Wp, (const uint4*)WTp, bp, rows, dx, dWpart, dbpart, dW, db,  \
+                                   detach_first, s)
+  if (E == 32) {
+    switch (L) {
+      case 1: TRS_CB(2, 1);
+      case 2: TRS_CB(2, 2);
+      case 3: TRS_CB(2, 3);
+      case 4: TRS_CB(2, 4);
+      case 5: TRS_CB(2, 5);
+      default: TRS_CB(2, 6);
+    }
+  }
+  switch (L) {
+    case 1: TRS_CB(4, 1);
+    case 2: TRS_CB(4, 2);
+    case 3: TRS_CB(4, 3);
+    case 4: TRS_CB(4, 4);
+    case 5: TRS_CB(4, 5);
+    default: TRS_CB(4, 6);
+  }
+#undef TRS_CB
 }
 
 }  // namespace trs
