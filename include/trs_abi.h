@@ -173,6 +173,20 @@ int trs_cin_bwd(const void* x0, const void* xk, const void* Wc, const void* gy, 
                 int32_t H, int32_t C, int32_t E, int32_t dtype, float* dWc, void* dx0, void* dxk,
                 int32_t accumulate_dx0, trs_stream_t stream);
 
+/* ---- K5 on the matrix cores: channels-last CIN contraction (bf16) ------------------------------
+ * Same contraction as trs_cin_fwd with activations stored channels-last:
+ *   x0T (B,E,ld0): x0T[b,e,n] = x0[b,n,e], row stride ld0 (multiple of 8, zero-filled past N)
+ *   xkT rows = B*E pixels of stride ldk (multiple of 8, >= 32*ceil(H/32), zero-filled past H):
+ *       xkT[b*E+e, h] = xk[b,h,e]   (a strided view of the previous layer's yT is fine)
+ *   yT  (B,E,C): yT[b,e,c] = y[b,c,e]
+ * Requirements: C % 32 == 0, E % 16 == 0, H <= 256.  workspace: trs_cin_cl_workspace_bytes.
+ * The x0[n] factor multiplies the MFMA result, so the outer product never exists even in registers.
+ * layers/ctr/compress_interaction_network.py:125-137.                                          */
+size_t trs_cin_cl_workspace_bytes(int32_t N, int32_t H, int32_t C);
+int trs_cin_cl_fwd(const void* x0T, int32_t ld0, const void* xkT, int32_t ldk, const void* Wc,
+                   const void* bias, int64_t B, int32_t N, int32_t H, int32_t C, int32_t E, int32_t dtype,
+                   void* yT, void* workspace, size_t ws_bytes, trs_stream_t stream);
+
 /* ---- row-sharded tables (multi-GPU lookup) -----------------------------
  * Bucket the B*N global row ids of the local batch by owner rank (owner = id / rows_per_rank):
  *   counts[w]  = number of ids owned by rank w                                  (W int64)

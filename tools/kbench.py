@@ -117,6 +117,19 @@ def main():
         gy = torch.randn_like(y)
         t = timeit(lambda: torch.autograd.grad(y, x, gy, retain_graph=True), iters=10)
         report("pair_dot_bwd", t, 2 * B * N * E * s + B * (N * (N - 1) // 2) * s)
+    if want("cin"):
+        Bc = a.B // 8 if a.B >= 8192 else a.B
+        for (H, C) in ((39, 256), (128, 256)):
+            ld0 = ((N + 31) // 32) * 32
+            x0T = torch.zeros(Bc, E, ld0, dtype=dt, device=dev)
+            x0T[:, :, :N] = (0.5 * torch.randn(Bc, E, N, generator=g)).to(dt).to(dev)
+            xkT = x0T if H == N else (0.5 * torch.randn(Bc, E, H, generator=g)).to(dt).to(dev)
+            W = (torch.randn(C, N * H, generator=g) / (N * H) ** 0.5).to(dt).to(dev)
+            bias = torch.zeros(C, dtype=dt, device=dev)
+            t = timeit(lambda: F_._CINContractCL.apply(x0T, xkT, W, bias, N, H), iters=5, warm=1)
+            fl = 2.0 * Bc * E * C * N * (H + 1)
+            print(f"cin_cl_fwd B={Bc} N={N} H={H} C={C}: med {t[0]*1e3:.3f} ms  {fl/t[0]/1e12:.1f} TFLOP/s "
+                  f"({fl/t[0]/2.5e15*100:.1f}% of 2.5 PF)", flush=True)
     if want("copy"):
         x = torch.empty(512 * 1024 * 1024 // 4, dtype=torch.float32, device=dev)
         y = torch.empty_like(x)

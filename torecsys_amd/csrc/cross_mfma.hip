@@ -176,21 +176,21 @@ __global__ __launch_bounds__(256) void cross_mfma_fwd_kernel(const uint4* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward on the matrix cores.  Workgroup = 8 waves, wave w owns the 16-row tile w of a 128-row group.
+// backward on the matrix cores.  Workgroup = BW_WAVES waves, wave w owns the 16-row tile w of a row group.
 // Per tile, in registers: recompute x_1..x_{L-1} (kept as bf16 B fragments), then for l = L-1..0
 //   u_l  = W_l x_l + b_l (recomputed, MFMA)          du = g * x0          dx0 += g * (u_l + 1)
 //   g    = W_l^T du      (MFMA on the transposed fragments; skipped for l = 0 when detach_first)
 // dW_l = du^T x_l contracts over ROWS, which live on lanes in the layout above, so du and x_l are staged
-// transposed in LDS ([e][128 rows], bf16) once per layer and every wave accumulates its share of the E x E
-// output tiles (K = 128 rows = 4 MFMAs per tile) in registers across the whole kernel; db_l rides along as
+// transposed in LDS ([e][rows of the group], bf16) once per layer and every wave accumulates its share of the E x E
+// output tiles (K = rows of the group) in registers across the whole kernel; db_l rides along as
 // one extra tile against an all-ones B operand.  Per-workgroup partial dW/db go to a workspace and are
 // summed by a second kernel (no float atomics).
-constexpr int BW_WAVES = 8;
+constexpr int BW_WAVES = 4;  // one wave per SIMD: the whole 512-register file per wave, no spills at L = 6
 constexpr int BW_ROWS = 16 * BW_WAVES;          // rows per workgroup iteration
 constexpr int BW_STR = BW_ROWS * 2 + 16;        // bytes per staged e-row (pad: conflict-free b128 reads)
 
 template <int NT, int L>
-__global__ __launch_bounds__(512, 1) void cross_mfma_bwd_kernel(
+__global__ __launch_bounds__(64 * BW_WAVES, 1) void cross_mfma_bwd_kernel(
     const uint4* __restrict__ x, const uint4* __restrict__ gout, const uint4* __restrict__ Wp,
     const uint4* __restrict__ WTp, const float* __restrict__ bp, int64_t rows, uint4* __restrict__ dx,
     float* __restrict__ dWpart, float* __restrict__ dbpart, int detach_first) {
@@ -219,13 +219,44 @@ __global__ __launch_bounds__(512, 1) void cross_mfma_bwd_kernel(
   }
   const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);  // 8 x bf16(1.0)
   const int64_t ngroups = (rows + BW_ROWS - 1) / BW_ROWS;
+  // software prefetch: the raw 16-byte vectors of the NEXT group's x / g tiles are loaded while this group
+  // is being processed (one wave per SIMD: nothing else would hide the HBM latency)
+  uint4 nx_raw[KS], ng_raw[KS];
+  auto fetch = [&](int64_t grp_) {
+    const int64_t row_ = grp_ * BW_ROWS + wave * 16 + r;
+#pragma unroll
+    for (int c = 0; c < KS; ++c) {
+      nx_raw[c] = make_uint4(0, 0, 0, 0);
+      ng_raw[c] = make_uint4(0, 0, 0, 0);
+      if (grp_ < ngroups && row_ < rows) {
+        nx_raw[c] = x[(row_ * E + 32 * c + 8 * q) >> 3];
+        ng_raw[c] = gout[(row_ * E + 32 * c + 8 * q) >> 3];
+      }
+    }
+  };
+  fetch(blockIdx.x);
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int64_t row = grp * BW_ROWS + wave * 16 + r;
-    XTile<NT> x0, g, dx0;
+    XTile<NT> g, dx0;
     uint4 Bx[L][KS];
-    uint4 Bg[KS];
-    load_tile<NT>(x, row, rows, E, q, x0, Bx[0]);
-    load_tile<NT>(gout, row, rows, E, q, g, Bg);
+#pragma unroll
+    for (int c = 0; c < KS; ++c) {
+      Bx[0][c] = nx_raw[c];
+      float f[8];
+      Vec16<bf16_t>::unpack(ng_raw[c], f);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        g.v[2 * c][i] = f[i];
+        g.v[2 * c + 1][i] = f[4 + i];
+      }
+    }
+    fetch(grp + gridDim.x);
+    // x0 is bf16 in memory: its fp32 values are re-derived from Bx[0] where needed (saves 16 registers)
+    auto x0v = [&](int mt, int i) -> float {
+      const uint4& u = Bx[0][mt >> 1];
+      const unsigned w = (mt & 1) ? (i < 2 ? u.z : u.w) : (i < 2 ? u.x : u.y);
+      return (i & 1) ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16);
+    };
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
@@ -239,7 +270,7 @@ __global__ __launch_bounds__(512, 1) void cross_mfma_bwd_kernel(
 #pragma unroll
       for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) nx.v[mt][i] = fmaf(x0.v[mt][i], acc[0][mt][i], x0.v[mt][i]);
+        for (int i = 0; i < 4; ++i) nx.v[mt][i] = fmaf(x0v(mt, i), acc[0][mt][i], x0v(mt, i));
       pack_tile<NT>(nx, Bx[l + 1]);
     }
 #pragma unroll
@@ -251,25 +282,31 @@ __global__ __launch_bounds__(512, 1) void cross_mfma_bwd_kernel(
       for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          du.v[mt][i] = g.v[mt][i] * x0.v[mt][i];
+          du.v[mt][i] = g.v[mt][i] * x0v(mt, i);
           dx0.v[mt][i] = fmaf(g.v[mt][i], acc[0][mt][i] + 1.f, dx0.v[mt][i]);
         }
       uint4 Bdu[KS];
       pack_tile<NT>(du, Bdu);
-      // stage du^T and x_l^T: element (e, row) as bf16 at [e][row]
+      // stage du^T and x_l^T as bf16 at [e][row].  Lane pairs (r, r^1) trade one dword so that every lane
+      // writes a full dword = rows (r&~1, r|1) of ONE e (even lanes take element 2h, odd lanes 2h+1); the
+      // byte column is XOR-swizzled with ((e>>3)&3)<<5 so the four q-groups of a wave hit different banks.
       {
-        const int col = (wave * 16 + r) * 2;
+        const int colpair = (wave * 16 + (r & ~1)) * 2;
+        const int odd = r & 1;
 #pragma unroll
         for (int c = 0; c < KS; ++c) {
           const unsigned wd[4] = {Bdu[c].x, Bdu[c].y, Bdu[c].z, Bdu[c].w};
           const unsigned wx[4] = {Bx[l][c].x, Bx[l][c].y, Bx[l][c].z, Bx[l][c].w};
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int e = 32 * c + 8 * q + j;
-            const unsigned short hd = (unsigned short)(j & 1 ? wd[j >> 1] >> 16 : wd[j >> 1] & 0xffffu);
-            const unsigned short hx = (unsigned short)(j & 1 ? wx[j >> 1] >> 16 : wx[j >> 1] & 0xffffu);
-            *reinterpret_cast<unsigned short*>(duT + e * BW_STR + col) = hd;
-            *reinterpret_cast<unsigned short*>(xT + e * BW_STR + col) = hx;
+          for (int h = 0; h < 4; ++h) {
+            const unsigned od = __shfl_xor(wd[h], 1, 64), ox = __shfl_xor(wx[h], 1, 64);
+            // even lane: (mine.lo, other.lo) -> element 2h ; odd lane: (other.hi, mine.hi) -> element 2h+1
+            const unsigned vd = odd ? ((od >> 16) | (wd[h] & 0xffff0000u)) : ((wd[h] & 0xffffu) | (od << 16));
+            const unsigned vx = odd ? ((ox >> 16) | (wx[h] & 0xffff0000u)) : ((wx[h] & 0xffffu) | (ox << 16));
+            const int e = 32 * c + 8 * q + 2 * h + odd;
+            const int off = e * BW_STR + (colpair ^ (q << 5));
+            *reinterpret_cast<unsigned*>(duT + off) = vd;
+            *reinterpret_cast<unsigned*>(xT + off) = vx;
           }
         }
       }
@@ -293,8 +330,11 @@ __global__ __launch_bounds__(512, 1) void cross_mfma_bwd_kernel(
           const int mo = t / NT, no = t - mo * NT;
 #pragma unroll
           for (int kk = 0; kk < BW_ROWS / 32; ++kk) {
-            const uint4 a = *reinterpret_cast<const uint4*>(duT + (16 * mo + r) * BW_STR + (32 * kk + 8 * q) * 2);
-            const uint4 b = *reinterpret_cast<const uint4*>(xT + (16 * no + r) * BW_STR + (32 * kk + 8 * q) * 2);
+            const int sw = ((r >> 3) & 1) << 5;   // ((e>>3)&3)<<5 with e = 16*tile + r  ->  bit 3 of r (bit 4 of e is 0)
+            const uint4 a = *reinterpret_cast<const uint4*>(duT + (16 * mo + r) * BW_STR +
+                                                            (((32 * kk + 8 * q) * 2) ^ (sw | ((mo & 1) << 6))));
+            const uint4 b = *reinterpret_cast<const uint4*>(xT + (16 * no + r) * BW_STR +
+                                                            (((32 * kk + 8 * q) * 2) ^ (sw | ((no & 1) << 6))));
             dWacc[l][k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
                                                                   __builtin_bit_cast(bf16x8, b), dWacc[l][k], 0, 0, 0);
           }
@@ -303,7 +343,8 @@ __global__ __launch_bounds__(512, 1) void cross_mfma_bwd_kernel(
       if (wave < NT) {   // db_l rows 16*wave .. +15: du^T x ones
 #pragma unroll
         for (int kk = 0; kk < BW_ROWS / 32; ++kk) {
-          const uint4 a = *reinterpret_cast<const uint4*>(duT + (16 * wave + r) * BW_STR + (32 * kk + 8 * q) * 2);
+          const uint4 a = *reinterpret_cast<const uint4*>(
+              duT + (16 * wave + r) * BW_STR + (((32 * kk + 8 * q) * 2) ^ ((((r >> 3) & 1) << 5) | ((wave & 1) << 6))));
           dbacc[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
                                                              __builtin_bit_cast(bf16x8, ones), dbacc[l], 0, 0, 0);
         }
@@ -413,7 +454,7 @@ static int cross_bwd_launch(const void* x, const void* g, const uint4* Wp, const
   }
   const int64_t ngroups = (rows + BW_ROWS - 1) / BW_ROWS;
   const int grid = (int)std::min<int64_t>(ngroups, BW_MAX_BLOCKS);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, (const uint4*)x, (const uint4*)g, Wp, WTp, bp, rows,
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * BW_WAVES), lds, s, (const uint4*)x, (const uint4*)g, Wp, WTp, bp, rows,
                      (uint4*)dx, dWpart, dbpart, detach_first);
   hipLaunchKernelGGL(cross_reduce_partials_kernel, dim3((L * E * E + 255) / 256), dim3(256), 0, s, dWpart, grid,
                      L * E * E, dW);

@@ -522,3 +522,70 @@ def cin_contract(x0: torch.Tensor, xk: torch.Tensor, Wc: torch.Tensor, bias: Opt
     if Wc.dim() != 2 or Wc.shape[1] != x0.shape[1] * xk.shape[1]:
         raise ValueError(f"cin_contract: Wc must be (C, N*H={x0.shape[1] * xk.shape[1]}), got {tuple(Wc.shape)}")
     return _CINContract.apply(x0, xk, Wc, bias)
+
+
+# --------------------------------------------------------------------------------------------
+# K5, channels-last (MFMA) form: x0T (B,E,ld0), xkT (B,E,>=H) view, -> yT (B,E,C)
+# --------------------------------------------------------------------------------------------
+def cin_cl_supported(x: torch.Tensor, out_channels: Sequence[int], hidden_sizes: Sequence[int]) -> bool:
+    """Whole-stack check for the channels-last MFMA path: bf16 on device, E % 16 == 0, every layer's
+    C % 32 == 0, field count N <= 256, hidden widths multiples of 32 in {32,64,128,256}."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] % 16 == 0 and x.shape[1] <= 256):
+        return False
+    if any(c % 32 != 0 for c in out_channels):
+        return False
+    return all(h in (32, 64, 128, 256) for h in hidden_sizes)
+
+
+class _CINContractCL(Function):
+    @staticmethod
+    def forward(ctx, x0T, xkT, Wc, bias, N, H):
+        require_device(x0T, xkT, Wc, bias)
+        B, E, ld0 = x0T.shape
+        ldk = xkT.stride(1)
+        C = Wc.shape[0]
+        if xkT.stride(2) != 1 or xkT.stride(0) != E * ldk or x0T.stride() != (E * ld0, ld0, 1):
+            raise ValueError("cin_contract_cl: x0T must be contiguous and xkT a (B,E,>=H) view with unit inner stride")
+        w = Wc.to(torch.bfloat16).contiguous()
+        bb = None if bias is None else bias.to(torch.bfloat16).contiguous()
+        yT = torch.empty(B, E, C, dtype=torch.bfloat16, device=x0T.device)
+        ws_bytes = size_query("trs_cin_cl_workspace_bytes", N, H, C)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x0T.device)
+        call("trs_cin_cl_fwd", ptr(x0T), ld0, ptr(xkT), ldk, ptr(w), ptr(bb), B, N, H, C, E, _abi.TRS_BF16, ptr(yT),
+             ptr(ws), ws_bytes, stream_ptr())
+        ctx.save_for_backward(x0T, xkT, w)
+        ctx.meta = (N, H, Wc.dtype, None if bias is None else bias.dtype)
+        return yT
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gyT):
+        x0T, xkT, w = ctx.saved_tensors
+        N, H, wdt, bdt = ctx.meta
+        B, E, _ = x0T.shape
+        C = w.shape[0]
+        # channels-first views for the (generic) backward kernels; MFMA backward kernels are the next step
+        x0 = x0T[:, :, :N].transpose(1, 2).contiguous()
+        xk = xkT[:, :, :H].transpose(1, 2).contiguous()
+        gy = gyT.transpose(1, 2).contiguous()
+        need_x0, need_xk, need_w, need_b = ctx.needs_input_grad[:4]
+        dW = torch.zeros(C, N * H, dtype=torch.float32, device=w.device) if need_w else None
+        dx0 = torch.empty_like(x0) if need_x0 else None
+        dxk = torch.empty_like(xk) if need_xk else None
+        call("trs_cin_bwd", ptr(x0), ptr(xk), ptr(w), ptr(gy), B, N, H, C, E, _abi.TRS_BF16, ptr(dW), ptr(dx0), ptr(dxk),
+             0, stream_ptr())
+        dx0T = dxkT = None
+        if need_x0:
+            dx0T = torch.zeros_like(x0T)
+            dx0T[:, :, :N] = dx0.transpose(1, 2)
+        if need_xk:
+            dxkT = torch.zeros(xkT.shape, dtype=xkT.dtype, device=xkT.device)
+            dxkT[:, :, :H] = dxk.transpose(1, 2)
+        db = gyT.float().sum(dim=(0, 1)).to(bdt) if (need_b and bdt is not None) else None
+        return dx0T, dxkT, (dW.to(wdt) if need_w else None), db, None, None
+
+
+def cin_contract_cl(x0T: torch.Tensor, xkT: torch.Tensor, Wc: torch.Tensor, bias: Optional[torch.Tensor], N: int,
+                    H: int) -> torch.Tensor:
+    """channels-last CIN contraction on the matrix cores: x0T (B,E,ld0>=N, zero padded), xkT (B,E,>=H view)."""
+    return _CINContractCL.apply(x0T, xkT, Wc, bias, N, H)

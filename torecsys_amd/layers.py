@@ -205,6 +205,10 @@ class CompressInteractionNetworkLayer(BaseLayer):
         x0 = _strip(emb_inputs)
         if x0.dim() != 3:
             raise ValueError(f'CIN input must be (B, N, E), got {tuple(x0.shape)}')
+        outs = [seq.Conv1d.out_channels for seq in self.model]
+        hiddens = [c if self.is_direct else c // 2 for c in outs[:-1]]      # widths fed to layers 1..
+        if F_.cin_cl_supported(x0, outs, hiddens) and (x0.shape[1] + 31) // 32 in (1, 2, 4, 8):
+            return self._forward_channels_last(x0)
         hidden = x0                                   # (B,H,E) channels-first, H_0 = N
         direct_list = []
         for seq in self.model:
@@ -220,6 +224,35 @@ class CompressInteractionNetworkLayer(BaseLayer):
             direct_list.append(direct)
         pooled = torch.cat(direct_list, dim=1).sum(dim=-1)
         outputs = self.fc(pooled)
+        outputs.names = ('B', 'O',)
+        return outputs
+
+    def _forward_channels_last(self, x0: torch.Tensor) -> torch.Tensor:
+        """bf16 MFMA path: activations are kept channels-last, (B,E,C) -- which is the reference's own
+        ``align_to('B','E','N')`` orientation (:105) -- so every layer's output is directly the next layer's
+        matrix-core operand; BatchNorm1d sees the (B*E, C) view (same per-channel statistics over (B,E))."""
+        B, N, E = x0.shape
+        ld0 = ((N + 31) // 32) * 32
+        x0T = x0.new_zeros(B, E, ld0)
+        x0T[:, :, :N] = x0.transpose(1, 2)
+        hiddenT, H = x0T, N
+        pooled = []
+        for seq in self.model:
+            conv = seq.Conv1d
+            C = conv.out_channels
+            yT = F_.cin_contract_cl(x0T, hiddenT, conv.weight.squeeze(-1), conv.bias, N, H)      # (B,E,C)
+            y2 = yT.reshape(B * E, C)
+            for name, mod in seq.named_children():
+                if name != 'Conv1d':
+                    y2 = mod(y2)
+            yT = y2.reshape(B, E, C)
+            if self.is_direct:
+                directT, hiddenT, H = yT, yT, C
+            else:
+                directT, hiddenT = torch.chunk(yT, 2, dim=2)
+                H = C // 2
+            pooled.append(directT.sum(dim=1))
+        outputs = self.fc(torch.cat(pooled, dim=1))
         outputs.names = ('B', 'O',)
         return outputs
 
