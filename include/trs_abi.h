@@ -186,6 +186,22 @@ size_t trs_cin_cl_workspace_bytes(int32_t N, int32_t H, int32_t C);
 int trs_cin_cl_fwd(const void* x0T, int32_t ld0, const void* xkT, int32_t ldk, const void* Wc,
                    const void* bias, int64_t B, int32_t N, int32_t H, int32_t C, int32_t E, int32_t dtype,
                    void* yT, void* workspace, size_t ws_bytes, trs_stream_t stream);
+/* data gradients of the same contraction, channels-last: given gyT (B,E,C)
+ *   dx0T (B,E,ld0)  : dx0T[b,e,n] = sum_{c,h} gy*Wc*xk   (zeros past N)
+ *   dxkT rows of stride ldo (>= 32*ceil(H/32)): dxkT[b*E+e,h] = sum_{c,n} gy*Wc*x0
+ * Requirements: C in {32,64,128,256}, E % 16 == 0.  bias gradient = sum of gy over (b,e) (caller).  */
+size_t trs_cin_cl_bwd_data_workspace_bytes(int32_t N, int32_t H, int32_t C);
+int trs_cin_cl_bwd_data(const void* x0T, int32_t ld0, const void* xkT, int32_t ldk, const void* gyT,
+                        const void* Wc, int64_t B, int32_t N, int32_t H, int32_t C, int32_t E,
+                        int32_t dtype, void* dx0T, void* dxkT, int32_t ldo, void* workspace,
+                        size_t ws_bytes, trs_stream_t stream);
+
+/* weight gradient of the same contraction on the matrix cores; CHANNELS-FIRST operands (the sum runs over
+ * pixels, which must be the contiguous axis): gy (B,C,E), x0 (B,N,E), xk (B,H,E) bf16;
+ * dW (C, N*H) fp32 is ACCUMULATED into (zero it first).  C in {64,128,256}, E in {32,64,128}.       */
+size_t trs_cin_dw_workspace_bytes(int64_t B, int32_t N, int32_t H, int32_t C);
+int trs_cin_dw(const void* gy, const void* x0, const void* xk, int64_t B, int32_t N, int32_t H, int32_t C,
+               int32_t E, int32_t dtype, float* dW, void* workspace, size_t ws_bytes, trs_stream_t stream);
 
 /* ---- row-sharded tables (multi-GPU lookup) -----------------------------
  * Bucket the B*N global row ids of the local batch by owner rank (owner = id / rows_per_rank):

@@ -130,6 +130,12 @@ def main():
             fl = 2.0 * Bc * E * C * N * (H + 1)
             print(f"cin_cl_fwd B={Bc} N={N} H={H} C={C}: med {t[0]*1e3:.3f} ms  {fl/t[0]/1e12:.1f} TFLOP/s "
                   f"({fl/t[0]/2.5e15*100:.1f}% of 2.5 PF)", flush=True)
+            x0r, xkr, Wr = x0T.clone().requires_grad_(), (None if H == N else xkT.clone().requires_grad_()), W.clone().requires_grad_()
+            yT = F_._CINContractCL.apply(x0r, x0r if H == N else xkr, Wr, bias, N, H)
+            gy = torch.randn_like(yT)
+            ins = (x0r, Wr) if H == N else (x0r, xkr, Wr)
+            t = timeit(lambda: torch.autograd.grad(yT, ins, gy, retain_graph=True), iters=3, warm=1)
+            print(f"cin_cl_bwd (data+dW+transposes): med {t[0]*1e3:.3f} ms  {2*fl/t[0]/1e12:.1f} TFLOP/s", flush=True)
     if want("copy"):
         x = torch.empty(512 * 1024 * 1024 // 4, dtype=torch.float32, device=dev)
         y = torch.empty_like(x)

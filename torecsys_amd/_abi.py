@@ -46,6 +46,11 @@ SIGNATURES = {
     "trs_cin_bwd": (c_int32, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _I32, _P]),
     "trs_cin_cl_workspace_bytes": (_SZ, [_I32, _I32, _I32]),
     "trs_cin_cl_fwd": (c_int32, [_P, _I32, _P, _I32, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _SZ, _P]),
+    "trs_cin_cl_bwd_data_workspace_bytes": (_SZ, [_I32, _I32, _I32]),
+    "trs_cin_cl_bwd_data": (c_int32, [_P, _I32, _P, _I32, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _I32, _P,
+                                      _SZ, _P]),
+    "trs_cin_dw_workspace_bytes": (_SZ, [_I64, _I32, _I32, _I32]),
+    "trs_cin_dw": (c_int32, [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _SZ, _P]),
     "trs_bucket_workspace_bytes": (_SZ, [_I64, _I32]),
     "trs_bucket_by_owner": (c_int32, [_P, _I32, _P, _I64, _I32, _I64, _I32, _P, _P, _P, _P, _P, _SZ, _P]),
     "trs_scatter_by_pos": (c_int32, [_P, _P, _I64, _I32, _I32, _P, _P]),

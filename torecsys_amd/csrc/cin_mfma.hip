@@ -216,6 +216,423 @@ int cin_cl_fwd(const void* x0T, int ld0, const void* xkT, int ldk, const void* W
   return check_launch("cin_cl_fwd");
 }
 
+// =============================================================================================
+// backward, data gradients (channels-last):  S_n[h,pix] = sum_c Wc[c,(n,h)] * gy[c,pix]   (MFMA, K = c)
+//     dxk[h,pix] = sum_n x0[n,pix] * S_n[h,pix]          dx0[n,pix] = sum_h xk[h,pix] * S_n[h,pix]
+// Same skeleton as the forward: wave = P pixel tiles, the W^T fragments of one (h-pair tile jh, field n) step
+// are staged in LDS and shared by the 4 waves.  dxk accumulates in registers (h on the D rows, permuted so a
+// lane owns 8 consecutive h -> 16-byte stores); dx0[n] is a reduction over h = over the D rows: 8 FMAs per
+// lane, two cross-lane adds (q groups), then one lane per pixel adds into a per-wave fp32 LDS array [n][pixel].
+// WpT[((jh*N + n)*2 + ct2)*KC + kc][lane][8] = Wc[32*kc + 8*(lane>>4) + 0..7][n*H + hslot(jh,ct2,lane&15)]
+__global__ __launch_bounds__(256) void cin_prepack_bwd_kernel(const bf16_t* __restrict__ Wc, bf16_t* __restrict__ WpT,
+                                                              int C, int N, int H, int KSH, int KC) {
+  const int64_t total = (int64_t)KSH * N * 2 * KC * 64;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(t & 63);
+    int64_t f = t >> 6;
+    const int kc = (int)(f % KC); f /= KC;
+    const int ct2 = (int)(f & 1); f >>= 1;
+    const int n = (int)(f % N);
+    const int jh = (int)(f / N);
+    const int h = cin_chan_of_slot(jh, ct2, lane & 15);
+    const int c0 = 32 * kc + 8 * (lane >> 4);
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj)
+      WpT[t * 8 + jj] = h < H ? Wc[(size_t)(c0 + jj) * N * H + (size_t)n * H + h] : bf16_t{0};
+  }
+}
+
+template <int KC, int P>
+__global__ __launch_bounds__(256) void cin_cl_bwd_data_kernel(const bf16_t* __restrict__ x0T, int ld0,
+                                                              const bf16_t* __restrict__ xkT, int ldk,
+                                                              const bf16_t* __restrict__ gyT,
+                                                              const uint4* __restrict__ WpT, bf16_t* __restrict__ dx0T,
+                                                              bf16_t* __restrict__ dxkT, int ldo, int64_t B, int N,
+                                                              int H, int C, int E) {
+  constexpr int PIX = 16 * P;
+  constexpr int FR = 2 * KC * 64;  // uint4 per (jh,n) step
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* Abuf = reinterpret_cast<uint4*>(smem);                                   // [2][FR]
+  float* dx0s_all = reinterpret_cast<float*>(smem + 2 * FR * 16);                 // [4][N][PIX] fp32
+  unsigned short* x0s_all = reinterpret_cast<unsigned short*>(dx0s_all + (size_t)4 * N * PIX);  // [4][N][PIX]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, r = lane & 15;
+  float* dx0s = dx0s_all + (size_t)wave * N * PIX;
+  unsigned short* x0w = x0s_all + (size_t)wave * N * PIX;
+  const int items_per_b = E / PIX;
+  const int64_t nitems = B * items_per_b;
+  const int KSH = (H + 31) / 32;
+  const int nsteps = KSH * N;
+  for (int64_t it0 = (int64_t)blockIdx.x * 4; it0 < nitems; it0 += (int64_t)gridDim.x * 4) {
+    const int64_t it = it0 + wave;
+    const bool live = it < nitems;
+    const int64_t b = live ? it / items_per_b : 0;
+    const int e0 = live ? (int)(it - b * items_per_b) * PIX : 0;
+    const int64_t pix0 = b * E + e0;
+    uint4 Bg[P][KC];
+#pragma unroll
+    for (int t = 0; t < P; ++t)
+#pragma unroll
+      for (int kc = 0; kc < KC; ++kc) {
+        Bg[t][kc] = make_uint4(0, 0, 0, 0);
+        if (live) Bg[t][kc] = *reinterpret_cast<const uint4*>(gyT + (pix0 + 16 * t + r) * (int64_t)C + 32 * kc + 8 * q);
+      }
+    __syncthreads();
+    for (int v = lane; v < N * PIX; v += 64) dx0s[v] = 0.f;
+    if (live) {
+      for (int v = lane; v < PIX * ((N + 7) / 8); v += 64) {
+        const int p = v % PIX, ch = v / PIX;
+        const uint4 u = *reinterpret_cast<const uint4*>(x0T + (pix0 + p) * ld0 + 8 * ch);
+        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          const int n = 8 * ch + jj;
+          if (n < N) x0w[n * PIX + p] = (unsigned short)(jj & 1 ? w[jj >> 1] >> 16 : w[jj >> 1] & 0xffffu);
+        }
+      }
+    }
+    for (int i = threadIdx.x; i < FR; i += 256) Abuf[i] = WpT[i];
+    __syncthreads();
+    f32x4 acc[P][2];
+    float xkd[P][2][4];
+    for (int step = 0; step < nsteps; ++step) {
+      const int jh = step / N, n = step - jh * N;
+      const uint4* A = Abuf + (step & 1) * FR;
+      uint4 nxt[(FR + 255) / 256];
+      if (step + 1 < nsteps) {
+#pragma unroll
+        for (int k = 0; k < (FR + 255) / 256; ++k) {
+          const int i = threadIdx.x + 256 * k;
+          if (i < FR) nxt[k] = WpT[(size_t)(step + 1) * FR + i];
+        }
+      }
+      if (n == 0) {
+#pragma unroll
+        for (int t = 0; t < P; ++t) {
+          acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+          acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+          uint4 u = make_uint4(0, 0, 0, 0);
+          if (live) u = *reinterpret_cast<const uint4*>(xkT + (pix0 + 16 * t + r) * ldk + 32 * jh + 8 * q);
+          float f[8];
+          Vec16<bf16_t>::unpack(u, f);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { xkd[t][0][i] = f[i]; xkd[t][1][i] = f[4 + i]; }
+        }
+      }
+      f32x4 S[P][2];
+#pragma unroll
+      for (int t = 0; t < P; ++t) { S[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; S[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int ct2 = 0; ct2 < 2; ++ct2)
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+          const uint4 a = A[(ct2 * KC + kc) * 64 + lane];
+#pragma unroll
+          for (int t = 0; t < P; ++t)
+            S[t][ct2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                                __builtin_bit_cast(bf16x8, Bg[t][kc]), S[t][ct2], 0, 0, 0);
+        }
+#pragma unroll
+      for (int t = 0; t < P; ++t) {
+        const float xv = __uint_as_float((unsigned)x0w[n * PIX + 16 * t + r] << 16);
+        float part = 0.f;
+#pragma unroll
+        for (int ct2 = 0; ct2 < 2; ++ct2)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            acc[t][ct2][i] = fmaf(xv, S[t][ct2][i], acc[t][ct2][i]);
+            part = fmaf(xkd[t][ct2][i], S[t][ct2][i], part);
+          }
+        part += __shfl_xor(part, 16, 64);
+        part += __shfl_xor(part, 32, 64);
+        if (q == (n & 3)) dx0s[n * PIX + 16 * t + r] += part;   // one lane per pixel; the wave owns this array
+      }
+      if (n == N - 1 && live) {
+#pragma unroll
+        for (int t = 0; t < P; ++t) {
+          float f[8];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { f[i] = acc[t][0][i]; f[4 + i] = acc[t][1][i]; }
+          *reinterpret_cast<uint4*>(dxkT + (pix0 + 16 * t + r) * (int64_t)ldo + 32 * jh + 8 * q) = Vec16<bf16_t>::pack(f);
+        }
+      }
+      if (step + 1 < nsteps) {
+        uint4* Anext = Abuf + ((step + 1) & 1) * FR;
+#pragma unroll
+        for (int k = 0; k < (FR + 255) / 256; ++k) {
+          const int i = threadIdx.x + 256 * k;
+          if (i < FR) Anext[i] = nxt[k];
+        }
+      }
+      __syncthreads();
+    }
+    // dx0^T rows of my pixels: [pixel][n] from the LDS [n][pixel] accumulator (zeros past N)
+    if (live) {
+      for (int v = lane; v < PIX * (ld0 / 8); v += 64) {
+        const int p = v % PIX, ch = v / PIX;
+        float f[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          const int n = 8 * ch + jj;
+          f[jj] = n < N ? dx0s[n * PIX + p] : 0.f;
+        }
+        *reinterpret_cast<uint4*>(dx0T + (pix0 + p) * ld0 + 8 * ch) = Vec16<bf16_t>::pack(f);
+      }
+    }
+  }
+}
+
+size_t cin_mfma_bwd_data_workspace_bytes(int N, int H, int C) {
+  const int KSH = (H + 31) / 32, KC = C / 32;
+  return (size_t)KSH * N * 2 * KC * 64 * 16 + 256;
+}
+
+int cin_cl_bwd_data(const void* x0T, int ld0, const void* xkT, int ldk, const void* gyT, const void* Wc, int64_t B, int N,
+                    int H, int C, int E, void* dx0T, void* dxkT, int ldo, void* workspace, size_t ws_bytes,
+                    hipStream_t s) {
+  const int KSH = (H + 31) / 32, KC = C / 32;
+  if (C % 32 != 0 || E % 16 != 0 || !(KC == 1 || KC == 2 || KC == 4 || KC == 8) || ld0 % 8 != 0 || ldk % 8 != 0 ||
+      ldk < 32 * KSH || ldo < 32 * KSH || ldo % 8 != 0 || workspace == nullptr)
+    return 1;
+  if (ws_bytes < cin_mfma_bwd_data_workspace_bytes(N, H, C)) return fail(TRS_EWORKSPACE, "cin_cl_bwd_data: workspace");
+  bf16_t* WpT = (bf16_t*)workspace;
+  const int64_t total = (int64_t)KSH * N * 2 * KC * 64;
+  hipLaunchKernelGGL(cin_prepack_bwd_kernel, dim3((int)std::min<int64_t>((total + 255) / 256, 2048)), dim3(256), 0, s,
+                     (const bf16_t*)Wc, WpT, C, N, H, KSH, KC);
+  const int P = E % 32 == 0 ? 2 : 1;
+  const int64_t nitems = B * (E / (16 * P));
+  const int grid = (int)std::min<int64_t>((nitems + 3) / 4, 256 * 2);
+  const size_t lds = (size_t)2 * 2 * KC * 64 * 16 + (size_t)4 * N * 16 * P * (4 + 2);
+  if (lds > 64 * 1024) return 1;
+#define TRS_CINB(KC_, P_)                                                                                           \
+  hipLaunchKernelGGL((cin_cl_bwd_data_kernel<KC_, P_>), dim3(grid), dim3(256), lds, s, (const bf16_t*)x0T, ld0,      \
+                     (const bf16_t*)xkT, ldk, (const bf16_t*)gyT, (const uint4*)WpT, (bf16_t*)dx0T, (bf16_t*)dxkT,   \
+                     ldo, B, N, H, C, E)
+#define TRS_CINB_P(KC_)              \
+  do {                               \
+    if (P == 2) TRS_CINB(KC_, 2);    \
+    else TRS_CINB(KC_, 1);           \
+  } while (0)
+  switch (KC) {
+    case 1: TRS_CINB_P(1); break;
+    case 2: TRS_CINB_P(2); break;
+    case 4: TRS_CINB_P(4); break;
+    default: TRS_CINB_P(8); break;
+  }
+#undef TRS_CINB_P
+#undef TRS_CINB
+  return check_launch("cin_cl_bwd_data");
+}
+
+// =============================================================================================
+// backward, weight gradient (channels-FIRST operands: the contraction runs over pixels, so pixels must be
+// the contiguous K axis):   dW[c,(n,h)] = sum_{b,e} gy[b,c,e] * x0[b,n,e] * xk[b,h,e]
+// GEMM view per field n:  dW_n (C x H) = (gy .* x0_n) (C x pixels) * xk^T (pixels x H).
+// Workgroup = 8 waves owns NG = 2 fields x all C x HB h-tiles and streams a range of samples; per sample the
+// gy tile (C x E) and the xk tile (16*HB x E) are staged once in LDS (rows padded to E*2+16 bytes:
+// conflict-free ds_read_b128) and shared by all waves; wave w = (field w>>2, channel quarter w&3) scales its
+// gy fragments by x0[n] (8 mul + 4 cvt per fragment, reused for HB MFMAs) and accumulates CTW x HB 16x16
+// tiles in registers over the whole sample range.  Partial sums per sample-split go to a workspace and are
+// reduced by a second kernel (no float atomics).
+constexpr int DW_NG = 2;      // fields per workgroup
+constexpr int DW_WAVES = 8;
+
+template <int CTW /* c tiles per wave: C = 64*CTW */, int HB /* h tiles per block */, int KE /* E/32 */>
+__global__ __launch_bounds__(512) void cin_dw_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x0,
+                                                     const bf16_t* __restrict__ xk, float* __restrict__ dWpart,
+                                                     int64_t B, int N, int H, int nsplit) {
+  constexpr int C = 64 * CTW;
+  constexpr int E = 32 * KE;
+  constexpr int RS = E * 2 + 16;            // padded row stride in bytes
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // [2 buffers] x { gy_s [C][RS] | xk_s [16*HB][RS] | x0_s [DW_NG][RS] }
+  constexpr int BUF = (C + 16 * HB + DW_NG) * RS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, r = lane & 15;
+  const int ng = (N + DW_NG - 1) / DW_NG;
+  const int hb_count = (H + 16 * HB - 1) / (16 * HB);
+  int bid = blockIdx.x;
+  const int g = bid % ng; bid /= ng;                 // field group fastest: co-scheduled blocks share samples
+  const int hb = bid % hb_count; bid /= hb_count;
+  const int split = bid;
+  const int nloc = wave >> 2, cq = wave & 3;
+  const int n = g * DW_NG + nloc;
+  const bool n_ok = n < N;
+  const int64_t per = (B + nsplit - 1) / nsplit;
+  const int64_t b_lo = split * per, b_hi = b_lo + per < B ? b_lo + per : B;
+  f32x4 acc[CTW][HB];
+#pragma unroll
+  for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+    for (int ht = 0; ht < HB; ++ht) acc[ct][ht] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int VPR = E / 8;                          // 16-byte vectors per row
+  constexpr int TOTV = (C + 16 * HB + DW_NG) * VPR;   // vectors per sample stage
+  constexpr int NV = (TOTV + 511) / 512;
+  auto src_vec = [&](int64_t b, int v, bool& ok) -> const uint4* {
+    const int row = v / VPR, col = v - row * VPR;
+    ok = true;
+    if (row < C) return reinterpret_cast<const uint4*>(gy + ((b * C + row) * (int64_t)E)) + col;
+    if (row < C + 16 * HB) {
+      const int h = 16 * HB * hb + (row - C);
+      ok = h < H;
+      return reinterpret_cast<const uint4*>(xk + ((b * H + (ok ? h : 0)) * (int64_t)E)) + col;
+    }
+    const int nn = g * DW_NG + (row - C - 16 * HB);
+    ok = nn < N;
+    return reinterpret_cast<const uint4*>(x0 + ((b * N + (ok ? nn : 0)) * (int64_t)E)) + col;
+  };
+  uint4 stage[NV];
+  auto fetch = [&](int64_t b) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int v = threadIdx.x + 512 * k;
+      stage[k] = make_uint4(0, 0, 0, 0);
+      if (v < TOTV && b < b_hi) {
+        bool ok;
+        const uint4* p = src_vec(b, v, ok);
+        if (ok) stage[k] = *p;
+      }
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int v = threadIdx.x + 512 * k;
+      if (v < TOTV) {
+        const int row = v / VPR, col = v - row * VPR;
+        *reinterpret_cast<uint4*>(smem + (size_t)buf * BUF + row * RS + col * 16) = stage[k];
+      }
+    }
+  };
+  if (b_lo < b_hi) {
+    fetch(b_lo);
+    commit(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int64_t b = b_lo; b < b_hi; ++b) {
+    fetch(b + 1);
+    const char* base = smem + (size_t)cur * BUF;
+    const char* gy_s = base;
+    const char* xk_s = base + C * RS;
+    const char* x0_s = base + (C + 16 * HB) * RS + nloc * RS;
+#pragma unroll
+    for (int ke = 0; ke < KE; ++ke) {
+      const int eoff = (32 * ke + 8 * q) * 2;
+      float xf[8];
+      Vec16<bf16_t>::unpack(*reinterpret_cast<const uint4*>(x0_s + eoff), xf);
+      uint4 Bx[HB];
+#pragma unroll
+      for (int ht = 0; ht < HB; ++ht) Bx[ht] = *reinterpret_cast<const uint4*>(xk_s + (16 * ht + r) * RS + eoff);
+#pragma unroll
+      for (int ct = 0; ct < CTW; ++ct) {
+        float gf[8];
+        Vec16<bf16_t>::unpack(*reinterpret_cast<const uint4*>(gy_s + (16 * (CTW * cq + ct) + r) * RS + eoff), gf);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gf[k] *= xf[k];
+        const uint4 a = Vec16<bf16_t>::pack(gf);
+#pragma unroll
+        for (int ht = 0; ht < HB; ++ht)
+          acc[ct][ht] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                                __builtin_bit_cast(bf16x8, Bx[ht]), acc[ct][ht], 0, 0, 0);
+      }
+    }
+    commit(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (n_ok) {
+    float* out = dWpart + (size_t)split * C * N * H;
+#pragma unroll
+    for (int ct = 0; ct < CTW; ++ct)
+#pragma unroll
+      for (int ht = 0; ht < HB; ++ht) {
+        const int h = 16 * HB * hb + 16 * ht + r;
+        if (h < H) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int c = 16 * (CTW * cq + ct) + 4 * q + i;
+            out[(size_t)c * N * H + (size_t)n * H + h] = acc[ct][ht][i];
+          }
+        }
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void cin_reduce_partials_kernel(const float* __restrict__ part, int nparts, int64_t n,
+                                                                  float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * n + i];
+    out[i] += s;
+  }
+}
+
+static int cin_dw_splits(int64_t B, int N, int H, int HBt) {
+  const int ng = (N + DW_NG - 1) / DW_NG;
+  const int hbc = (H + 16 * HBt - 1) / (16 * HBt);
+  int s = (int)std::max<int64_t>(1, 256 / std::max(1, ng * hbc));   // one workgroup per CU (LDS-bound)
+  s = (int)std::min<int64_t>(s, std::max<int64_t>(1, B / 8));
+  return std::min(s, 32);
+}
+
+size_t cin_dw_workspace_bytes(int64_t B, int N, int H, int C) {
+  return (size_t)32 * C * N * H * 4 + 256;
+}
+
+// gy (B,C,E), x0 (B,N,E), xk (B,H,E) contiguous bf16; dW (C, N*H) fp32 accumulated into.
+int cin_dw(const void* gy, const void* x0, const void* xk, int64_t B, int N, int H, int C, int E, float* dW,
+           void* workspace, size_t ws_bytes, hipStream_t s) {
+  if (!(C == 64 || C == 128 || C == 256) || !(E == 32 || E == 64 || E == 128) || workspace == nullptr ||
+      !aligned16(gy) || !aligned16(x0) || !aligned16(xk))
+    return 1;
+  if (ws_bytes < cin_dw_workspace_bytes(B, N, H, C)) return fail(TRS_EWORKSPACE, "cin_dw: workspace too small");
+  const int CTW = C / 64, KE = E / 32;
+  // h tiles per block: accumulators CTW*HB*4 registers <= 128
+  int HB = (H + 15) / 16;
+  const int hb_cap = CTW == 4 ? 8 : 8;
+  if (HB > hb_cap) HB = hb_cap;
+  if (HB != 1 && HB != 2 && HB != 4 && HB != 8) HB = HB > 4 ? 8 : (HB > 2 ? 4 : (HB > 1 ? 2 : 1));
+  const int nsplit = cin_dw_splits(B, N, H, HB);
+  const int ng = (N + DW_NG - 1) / DW_NG, hbc = (H + 16 * HB - 1) / (16 * HB);
+  const int grid = ng * hbc * nsplit;
+  const size_t lds = (size_t)2 * (C + 16 * HB + DW_NG) * (E * 2 + 16);
+  float* part = (float*)workspace;
+#define TRS_DW(CTW_, HB_, KE_)                                                                                   \
+  do {                                                                                                           \
+    auto kern = cin_dw_kernel<CTW_, HB_, KE_>;                                                                   \
+    static bool attr_set = false;                                                                                \
+    if (!attr_set && lds > 64 * 1024) {                                                                          \
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+        return check_launch("cin_dw: LDS attribute");                                                            \
+      attr_set = true;                                                                                           \
+    }                                                                                                            \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, (const bf16_t*)gy, (const bf16_t*)x0, (const bf16_t*)xk, \
+                       part, B, N, H, nsplit);                                                                   \
+  } while (0)
+#define TRS_DW_KE(CTW_, HB_)                   \
+  do {                                         \
+    if (KE == 1) TRS_DW(CTW_, HB_, 1);         \
+    else if (KE == 2) TRS_DW(CTW_, HB_, 2);    \
+    else TRS_DW(CTW_, HB_, 4);                 \
+  } while (0)
+#define TRS_DW_HB(CTW_)                        \
+  do {                                         \
+    if (HB == 1) TRS_DW_KE(CTW_, 1);           \
+    else if (HB == 2) TRS_DW_KE(CTW_, 2);      \
+    else if (HB == 4) TRS_DW_KE(CTW_, 4);      \
+    else TRS_DW_KE(CTW_, 8);                   \
+  } while (0)
+  if (CTW == 1) TRS_DW_HB(1);
+  else if (CTW == 2) TRS_DW_HB(2);
+  else TRS_DW_HB(4);
+#undef TRS_DW_HB
+#undef TRS_DW_KE
+#undef TRS_DW
+  const int64_t n = (int64_t)C * N * H;
+  hipLaunchKernelGGL(cin_reduce_partials_kernel, dim3((int)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, s,
+                     part, nsplit, n, dW);
+  return check_launch("cin_dw");
+}
+
 // channels-first entry points keep using the generic kernels for now
 int cin_mfma_fwd(const void*, const void*, const void*, const void*, int64_t, int, int, int, int, void*, float*,
                  hipStream_t) { return 1; }
@@ -240,5 +657,40 @@ extern "C" int trs_cin_cl_fwd(const void* x0T, int32_t ld0, const void* xkT, int
   TRS_REQUIRE(dtype == TRS_BF16, TRS_EDTYPE, "cin_cl_fwd: bf16 only (dtype %d)", dtype);
   const int rc = cin_cl_fwd(x0T, ld0, xkT, ldk, Wc, bias, B, N, H, C, E, yT, workspace, ws_bytes, (hipStream_t)stream);
   if (rc == 1) return fail(TRS_ESHAPE, "cin_cl_fwd: shape not covered (need C%%32==0, E%%16==0, H<=256, padded rows)");
+  return rc;
+}
+
+extern "C" size_t trs_cin_cl_bwd_data_workspace_bytes(int32_t N, int32_t H, int32_t C) {
+  if (N <= 0 || H <= 0 || C <= 0) return 0;
+  return cin_mfma_bwd_data_workspace_bytes(N, H, C);
+}
+
+extern "C" int trs_cin_cl_bwd_data(const void* x0T, int32_t ld0, const void* xkT, int32_t ldk, const void* gyT,
+                                   const void* Wc, int64_t B, int32_t N, int32_t H, int32_t C, int32_t E,
+                                   int32_t dtype, void* dx0T, void* dxkT, int32_t ldo, void* workspace,
+                                   size_t ws_bytes, trs_stream_t stream) {
+  if (B == 0) return TRS_OK;
+  TRS_REQUIRE(x0T && xkT && gyT && Wc && dx0T && dxkT, TRS_EINVAL, "cin_cl_bwd_data: NULL pointer");
+  TRS_REQUIRE(B > 0 && N > 0 && H > 0 && C > 0 && E > 0, TRS_EINVAL, "cin_cl_bwd_data: bad size");
+  TRS_REQUIRE(dtype == TRS_BF16, TRS_EDTYPE, "cin_cl_bwd_data: bf16 only (dtype %d)", dtype);
+  const int rc = cin_cl_bwd_data(x0T, ld0, xkT, ldk, gyT, Wc, B, N, H, C, E, dx0T, dxkT, ldo, workspace, ws_bytes,
+                                 (hipStream_t)stream);
+  if (rc == 1) return fail(TRS_ESHAPE, "cin_cl_bwd_data: shape not covered (C in {32,64,128,256}, E%%16==0)");
+  return rc;
+}
+
+extern "C" size_t trs_cin_dw_workspace_bytes(int64_t B, int32_t N, int32_t H, int32_t C) {
+  if (N <= 0 || H <= 0 || C <= 0) return 0;
+  return cin_dw_workspace_bytes(B, N, H, C);
+}
+
+extern "C" int trs_cin_dw(const void* gy, const void* x0, const void* xk, int64_t B, int32_t N, int32_t H, int32_t C,
+                          int32_t E, int32_t dtype, float* dW, void* workspace, size_t ws_bytes, trs_stream_t stream) {
+  if (B == 0) return TRS_OK;
+  TRS_REQUIRE(gy && x0 && xk && dW, TRS_EINVAL, "cin_dw: NULL pointer");
+  TRS_REQUIRE(B > 0 && N > 0 && H > 0 && C > 0 && E > 0, TRS_EINVAL, "cin_dw: bad size");
+  TRS_REQUIRE(dtype == TRS_BF16, TRS_EDTYPE, "cin_dw: bf16 only (dtype %d)", dtype);
+  const int rc = cin_dw(gy, x0, xk, B, N, H, C, E, dW, workspace, ws_bytes, (hipStream_t)stream);
+  if (rc == 1) return fail(TRS_ESHAPE, "cin_dw: shape not covered (C in {64,128,256}, E in {32,64,128})");
   return rc;
 }

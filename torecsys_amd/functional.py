@@ -564,25 +564,55 @@ class _CINContractCL(Function):
         N, H, wdt, bdt = ctx.meta
         B, E, _ = x0T.shape
         C = w.shape[0]
-        # channels-first views for the (generic) backward kernels; MFMA backward kernels are the next step
-        x0 = x0T[:, :, :N].transpose(1, 2).contiguous()
-        xk = xkT[:, :, :H].transpose(1, 2).contiguous()
-        gy = gyT.transpose(1, 2).contiguous()
         need_x0, need_xk, need_w, need_b = ctx.needs_input_grad[:4]
-        dW = torch.zeros(C, N * H, dtype=torch.float32, device=w.device) if need_w else None
-        dx0 = torch.empty_like(x0) if need_x0 else None
-        dxk = torch.empty_like(xk) if need_xk else None
-        call("trs_cin_bwd", ptr(x0), ptr(xk), ptr(w), ptr(gy), B, N, H, C, E, _abi.TRS_BF16, ptr(dW), ptr(dx0), ptr(dxk),
-             0, stream_ptr())
-        dx0T = dxkT = None
-        if need_x0:
-            dx0T = torch.zeros_like(x0T)
-            dx0T[:, :, :N] = dx0.transpose(1, 2)
-        if need_xk:
-            dxkT = torch.zeros(xkT.shape, dtype=xkT.dtype, device=xkT.device)
-            dxkT[:, :, :H] = dxk.transpose(1, 2)
+        gyT = gyT.contiguous()
+        dev = x0T.device
+        ld0, ldk = x0T.shape[2], xkT.stride(1)
         db = gyT.float().sum(dim=(0, 1)).to(bdt) if (need_b and bdt is not None) else None
-        return dx0T, dxkT, (dW.to(wdt) if need_w else None), db, None, None
+        dx0T = dxkT = dW = None
+        mfma_data = C in (32, 64, 128, 256)
+        mfma_dw = C in (64, 128, 256) and E in (32, 64, 128)
+        if need_x0 or need_xk:
+            if mfma_data:
+                ldo = ((H + 31) // 32) * 32
+                dx0T = torch.empty_like(x0T)
+                dxk_pad = torch.empty(B, E, ldo, dtype=torch.bfloat16, device=dev)
+                ws_bytes = size_query("trs_cin_cl_bwd_data_workspace_bytes", N, H, C)
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+                call("trs_cin_cl_bwd_data", ptr(x0T), ld0, ptr(xkT), ldk, ptr(gyT), ptr(w), B, N, H, C, E, _abi.TRS_BF16,
+                     ptr(dx0T), ptr(dxk_pad), ldo, ptr(ws), ws_bytes, stream_ptr())
+                if tuple(dxk_pad.shape) == tuple(xkT.shape):     # already zero past H (zero weight fragments)
+                    dxkT = dxk_pad
+                else:
+                    dxkT = torch.zeros(xkT.shape, dtype=xkT.dtype, device=dev)
+                    dxkT[:, :, :H] = dxk_pad[:, :, :H]
+        if (need_x0 or need_xk) and not mfma_data or (need_w and not mfma_dw):
+            # generic channels-first kernels for shapes the MFMA kernels do not cover
+            x0 = x0T[:, :, :N].transpose(1, 2).contiguous()
+            xk = xkT[:, :, :H].transpose(1, 2).contiguous()
+            gy = gyT.transpose(1, 2).contiguous()
+            gW = torch.zeros(C, N * H, dtype=torch.float32, device=dev) if (need_w and not mfma_dw) else None
+            gx0 = torch.empty_like(x0) if not mfma_data else None
+            gxk = torch.empty_like(xk) if not mfma_data else None
+            call("trs_cin_bwd", ptr(x0), ptr(xk), ptr(w), ptr(gy), B, N, H, C, E, _abi.TRS_BF16, ptr(gW), ptr(gx0),
+                 ptr(gxk), 0, stream_ptr())
+            if not mfma_data:
+                dx0T = torch.zeros_like(x0T)
+                dx0T[:, :, :N] = gx0.transpose(1, 2)
+                dxkT = torch.zeros(xkT.shape, dtype=xkT.dtype, device=dev)
+                dxkT[:, :, :H] = gxk.transpose(1, 2)
+            if gW is not None:
+                dW = gW
+        if need_w and mfma_dw:
+            x0 = x0T[:, :, :N].transpose(1, 2).contiguous()          # channels-first copies: pixels contiguous
+            xk = xkT[:, :, :H].transpose(1, 2).contiguous()
+            gy = gyT.transpose(1, 2).contiguous()
+            dW = torch.zeros(C, N * H, dtype=torch.float32, device=dev)
+            ws_bytes = size_query("trs_cin_dw_workspace_bytes", B, N, H, C)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            call("trs_cin_dw", ptr(gy), ptr(x0), ptr(xk), B, N, H, C, E, _abi.TRS_BF16, ptr(dW), ptr(ws), ws_bytes,
+                 stream_ptr())
+        return (dx0T if need_x0 else None, dxkT if need_xk else None, (dW.to(wdt) if need_w else None), db, None, None)
 
 
 def cin_contract_cl(x0T: torch.Tensor, xkT: torch.Tensor, Wc: torch.Tensor, bias: Optional[torch.Tensor], N: int,
