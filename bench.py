@@ -25,10 +25,21 @@ import os
 import sys
 import time
 
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if "--no-tunableop" not in sys.argv:
+    # The MLP GEMMs (nn.Linear, outside the hand-written path) go through PyTorch's TunableOp: solutions tuned
+    # once on an MI355X for exactly these shapes are shipped in torecsys_amd/tuning/; shapes missing from the
+    # file (or a library-version mismatch) are tuned during warm-up (~15 s).
+    _rank = os.environ.get("LOCAL_RANK", "0")
+    os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
+    os.environ.setdefault("PYTORCH_TUNABLEOP_TUNING", "1")
+    os.environ.setdefault("PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS", "60")
+    os.environ.setdefault("PYTORCH_TUNABLEOP_MAX_TUNING_ITERATIONS", "30")
+    os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", os.path.join(ROOT, "torecsys_amd", "tuning", "tunableop_results.csv"))
+
 import torch
 import torch.nn as nn
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
@@ -49,6 +60,9 @@ def parse():
     ap.add_argument("--no-fuse", action="store_true", help="separate lookup and FM kernels (drop-in unfused path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true", help="use the row-sharded path even with one rank (test)")
+    ap.add_argument("--model", default="deepfm", choices=["deepfm", "fm", "dcn", "xdeepfm"],
+                    help="deepfm = the headline metric (BASELINE configs[1]); dcn / xdeepfm = configs[2] / [3]")
+    ap.add_argument("--no-tunableop", action="store_true", help="do not use PyTorch TunableOp for the nn.Linear GEMMs")
     ap.add_argument("--cpu-batch", type=int, default=16384)
     return ap.parse_args()
 
@@ -158,8 +172,18 @@ def main():
     emb.set_schema(["c0"])       # the whole (B,N) index block travels as one named column
     feat.set_schema(["c0"])
     inputs = Inputs(schema={"feat_inputs": feat, "emb_inputs": emb}).to(dev).to(dt)
-    model = M.DeepFactorizationMachineModel(embed_size=E, num_fields=N, deep_layer_sizes=[400, 400, 400],
-                                            fm_dropout_p=0.0).to(dev).to(dt)
+    if a.model == "deepfm":
+        model = M.DeepFactorizationMachineModel(embed_size=E, num_fields=N, deep_layer_sizes=[400, 400, 400],
+                                                fm_dropout_p=0.0)
+    elif a.model == "fm":
+        model = M.FactorizationMachineModel(use_bias=True, dropout_p=0.0)
+    elif a.model == "dcn":
+        model = M.DeepAndCrossNetworkModel(inputs_size=E, num_fields=N, deep_output_size=64,
+                                           deep_layer_sizes=[400, 400, 400], cross_num_layers=6)
+    else:
+        model = M.XDeepFactorizationMachineModel(embed_size=E, num_fields=N, cin_layer_sizes=[128, 128, 128],
+                                                 deep_layer_sizes=[400, 400, 400])
+    model = model.to(dev).to(dt)
     if world > 1:
         for p in model.parameters():
             dist.broadcast(p.data, 0)
@@ -172,7 +196,8 @@ def main():
         counter[0] += 1
         for p in params:
             p.grad = None
-        out = model(**inputs({"c0": idx_ring[k]}))
+        d = inputs({"c0": idx_ring[k]})
+        out = model(**d) if a.model != "dcn" else model(emb_inputs=d["emb_inputs"])
         loss = crit(out.float(), label_ring[k])
         loss.backward()
         if world > 1:      # data-parallel dense parameters: average their gradients (one flat bucket)
@@ -233,7 +258,8 @@ def main():
                     "traffic": traffic, "alg_bytes_per_launch": alg, "avg_launch_us": round(kt * 1e6, 2),
                     "launches_timed": len(ktimes)}
         res = {
-            "metric": "CTR samples/sec fwd+bwd (DeepFM, 39 fields x dim 64)",
+            "metric": "CTR samples/sec fwd+bwd (DeepFM, 39 fields x dim 64)" if a.model == "deepfm" else
+                      f"CTR samples/sec fwd+bwd ({a.model}, 39 fields x dim 64)",
             "value": round(B * world * a.steps / el, 1), "unit": "samples/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
@@ -242,7 +268,7 @@ def main():
                                     + ("zipf" if a.zipf else "uniform") + " indices") if world == 1 else
                        ("BASELINE.json configs[4] (weak-scaled): DeepFM, " f"{V} rows row-sharded over {world} GPUs, "
                         f"global batch {B * world}"),
-                       "global_batch": B * world, "rows": V, "parallelism": parallelism,
+                       "model": a.model, "global_batch": B * world, "rows": V, "parallelism": parallelism,
                        "fused_lookup_fm": not a.no_fuse, "loss": float(loss)},
             "roofline": roof,
         }
