@@ -171,7 +171,7 @@ def main():
         parallelism = f"row-sharded table x{world} (all-to-all lookup), data-parallel MLP"
     emb.set_schema(["c0"])       # the whole (B,N) index block travels as one named column
     feat.set_schema(["c0"])
-    inputs = Inputs(schema={"feat_inputs": feat, "emb_inputs": emb}).to(dev).to(dt)
+    inputs = Inputs(schema={"emb_inputs": emb, "feat_inputs": feat}).to(dev).to(dt)
     if a.model == "deepfm":
         model = M.DeepFactorizationMachineModel(embed_size=E, num_fields=N, deep_layer_sizes=[400, 400, 400],
                                                 fm_dropout_p=0.0)

@@ -176,7 +176,9 @@ class _GatherRows(Function):
         call("trs_gather_rows", ptr(w), V, E, value_dtype_code(w), ptr(idx), index_dtype_code(idx), ptr(offsets),
              B, N, ptr(out), ptr(flag.t), stream_ptr())
         flag.check("gather_rows")
-        if weight.requires_grad:
+        if weight.requires_grad and E * w.element_size() >= 16:
+            # (narrow tables -- the E=1 first-order weights -- leave the prefetch to the wide table that shares
+            # their indices, so the bucket build overlaps the dense part of the model, not the lookups)
             prefetch_row_buckets(idx, offsets, V)
         ctx.save_for_backward(idx, offsets, weight)
         ctx.padding_idx = -1 if padding_idx is None else int(padding_idx)
