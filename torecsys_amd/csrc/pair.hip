@@ -166,8 +166,12 @@ __global__ __launch_bounds__(256) void pair_dot_bwd_kernel(const T* __restrict__
           const int i = 4 * ti + r;
           if (i < N) {
             T* d = dx + (b * N + i) * E + e;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) d[c] = from_f32<T>(acc[r][c]);
+            if (sizeof(T) == 4) {
+              *reinterpret_cast<float4*>(d) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+            } else {
+              *reinterpret_cast<uint2*>(d) = make_uint2(f32x2_to_bf16x2_bits(acc[r][0], acc[r][1]),
+                                                        f32x2_to_bf16x2_bits(acc[r][2], acc[r][3]));
+            }
           }
         }
       }
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(256) void pair_dot_bwd_generic(const T* __restrict_
   }
 }
 
-constexpr size_t LDS_BUDGET = 64 * 1024;  // per block, keeps >= 2 blocks per CU
+constexpr size_t LDS_BUDGET = 80 * 1024;  // per block: 2 blocks per CU out of 160 KiB
 
 template <typename T>
 static int pair_dot_fwd_launch(const void* x, void* out, int64_t B, int N, int E, hipStream_t s) {
@@ -220,6 +224,13 @@ static int pair_dot_fwd_launch(const void* x, void* out, int64_t B, int N, int E
   const size_t lds = (size_t)((TN * (TN + 1) / 2 * 4 + 15) & ~15) + 4 * (size_t)(NP * ES + ((P + 3) & ~3)) * 4;
   if (E % 4 == 0 && lds <= LDS_BUDGET && N >= 2) {
     const int grid = (int)std::min<int64_t>((B + 3) / 4, 256 * 8);
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)pair_dot_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)LDS_BUDGET) != hipSuccess)
+        return check_launch("pair_dot_fwd: LDS attribute");
+      attr_set = true;
+    }
     hipLaunchKernelGGL((pair_dot_fwd_kernel<T>), dim3(grid), dim3(256), lds, s, (const T*)x, (T*)out, B, N, E);
   } else {
     hipLaunchKernelGGL((pair_dot_fwd_generic<T>), dim3(stream_grid(B * P, 256, 8192)), dim3(256), 0, s, (const T*)x,
@@ -233,6 +244,13 @@ static int pair_dot_bwd_launch(const void* x, const void* g, void* dx, int64_t B
   const size_t lds = 4 * (size_t)(NP * ES + NP * GS) * 4;
   if (E % 4 == 0 && lds <= LDS_BUDGET && N >= 2) {
     const int grid = (int)std::min<int64_t>((B + 3) / 4, 256 * 8);
+    static bool attr_set = false;   // more than 64 KiB of dynamic LDS needs the attribute
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)pair_dot_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)LDS_BUDGET) != hipSuccess)
+        return check_launch("pair_dot_bwd: LDS attribute");
+      attr_set = true;
+    }
     hipLaunchKernelGGL((pair_dot_bwd_kernel<T>), dim3(grid), dim3(256), lds, s, (const T*)x, (const T*)g, (T*)dx, B,
                        N, E);
   } else {

@@ -106,29 +106,54 @@ def _all_to_all(out: torch.Tensor, inp: torch.Tensor, out_splits: List[int], in_
     dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
 
 
+class RoutePlan:
+    """Everything about one batch of indices that does not depend on the table: who owns each lookup, the
+    per-peer split sizes (host ints) and the local row ids every peer asked this rank for.  Tables looked up
+    with the same index tensor (the E=64 embeddings and the E=1 first-order weights of one model) share it,
+    so the bucketing, the count exchange (one host sync) and the id all-to-all happen once per batch."""
+    __slots__ = ("send_pos", "inv_pos", "send_splits", "recv_splits", "recv_ids")
+
+
+_route_cache: List[tuple] = []      # [(key, idx kept alive, RoutePlan)]
+
+
+def _route_plan(idx: torch.Tensor, mod) -> "RoutePlan":
+    key = (idx.data_ptr(), idx._version, tuple(idx.shape), idx.dtype, mod.route_key)
+    for k, _, p in _route_cache:
+        if k == key:
+            return p
+    ops, group, world = mod.ops, mod.group, mod.world
+    counts, send_ids, send_pos, inv_pos = ops.bucket_by_owner(idx, mod.offsets, mod.rows_per_rank, world)
+    recv_counts = torch.empty_like(counts)
+    dist.all_to_all_single(recv_counts, counts, group=group)
+    p = RoutePlan()
+    p.send_splits = counts.tolist()            # host sync: split sizes are needed as Python ints
+    p.recv_splits = recv_counts.tolist()
+    p.send_pos, p.inv_pos = send_pos, inv_pos
+    p.recv_ids = torch.empty(sum(p.recv_splits), dtype=torch.int32, device=idx.device)
+    _all_to_all(p.recv_ids, send_ids, p.recv_splits, p.send_splits, group)
+    _route_cache.append((key, idx, p))
+    if len(_route_cache) > 2:
+        _route_cache.pop(0)
+    return p
+
+
 class _ShardedLookup(Function):
     """(local shard, local batch of indices) -> (B,N,E) block [+ FM]; gradient flows back to the shard owners."""
 
     @staticmethod
     def forward(ctx, weight, idx, mod):
-        ops, group, world = mod.ops, mod.group, mod.world
+        ops, group = mod.ops, mod.group
         B, N = idx.shape
         E = weight.shape[1]
-        counts, send_ids, send_pos, inv_pos = ops.bucket_by_owner(idx, mod.offsets, mod.rows_per_rank, world)
-        recv_counts = torch.empty_like(counts)
-        dist.all_to_all_single(recv_counts, counts, group=group)
-        send_splits = counts.tolist()            # host sync: split sizes are needed as Python ints
-        recv_splits = recv_counts.tolist()
-        K = sum(recv_splits)
-        recv_ids = torch.empty(K, dtype=torch.int32, device=idx.device)
-        _all_to_all(recv_ids, send_ids, recv_splits, send_splits, group)
-        rows = ops.gather_local(weight, recv_ids)                                   # (K,E) rows of my shard
+        plan = _route_plan(idx, mod)
+        rows = ops.gather_local(weight, plan.recv_ids)                              # (K,E) rows of my shard
         back = torch.empty(B * N, E, dtype=weight.dtype, device=weight.device)
-        _all_to_all(back, rows, send_splits, recv_splits, group)
-        block, fm, fm_sum = ops.unpermute(back, inv_pos, B, N, mod.fuse_fm)
+        _all_to_all(back, rows, plan.send_splits, plan.recv_splits, group)
+        block, fm, fm_sum = ops.unpermute(back, plan.inv_pos, B, N, mod.fuse_fm)
         ctx.mod = mod
-        ctx.splits = (send_splits, recv_splits)
-        ctx.save_for_backward(weight, recv_ids, send_pos, block if mod.fuse_fm else None, fm_sum)
+        ctx.splits = (plan.send_splits, plan.recv_splits)
+        ctx.save_for_backward(weight, plan.recv_ids, plan.send_pos, block if mod.fuse_fm else None, fm_sum)
         ctx.set_materialize_grads(False)
         if fm is None:
             fm = block.new_empty(0)
@@ -186,6 +211,7 @@ class RowShardedMultiIndicesEmbedding(BaseInput):
         self.embed_size = embed_size
         self.padding_idx = None
         self.dense_grad_max_rows = dense_grad_max_rows
+        self.route_key = (tuple(int(f) for f in field_sizes), self.world, id(process_group))
         self.length = embed_size * len(field_sizes) if flatten else embed_size
 
     def forward(self, inputs: torch.Tensor) -> torch.Tensor:
