@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--model", default="deepfm", choices=["deepfm", "fm", "dcn", "xdeepfm"],
                     help="deepfm = the headline metric (BASELINE configs[1]); dcn / xdeepfm = configs[2] / [3]")
     ap.add_argument("--no-tunableop", action="store_true", help="do not use PyTorch TunableOp for the nn.Linear GEMMs")
+    ap.add_argument("--microbatches", type=int, default=0,
+                    help="sharded path: split each rank's batch into M micro-batches on 2 alternating streams so the "
+                         "all-to-all of one overlaps the dense compute of the other (0 = 4 when N > 1, else 1)")
     ap.add_argument("--cpu-batch", type=int, default=16384)
     return ap.parse_args()
 
@@ -191,15 +194,48 @@ def main():
     crit = nn.BCEWithLogitsLoss()
     params = [p for p in list(inputs.parameters()) + list(model.parameters()) if p.requires_grad]
 
+    MB = a.microbatches or (4 if world > 1 else 1)
+    if not sharded:
+        MB = 1
+    assert B % MB == 0
+    mbs = B // MB
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)] if MB > 1 else None
+
+    def fwd_loss(ix, lab, scale):
+        d = inputs({"c0": ix})
+        out = model(**d) if a.model != "dcn" else model(emb_inputs=d["emb_inputs"])
+        return crit(out.float(), lab) * scale
+
     def step():
         k = counter[0] % RING
         counter[0] += 1
         for p in params:
             p.grad = None
-        d = inputs({"c0": idx_ring[k]})
-        out = model(**d) if a.model != "dcn" else model(emb_inputs=d["emb_inputs"])
-        loss = crit(out.float(), label_ring[k])
-        loss.backward()
+        if MB == 1:
+            loss = fwd_loss(idx_ring[k], label_ring[k], 1.0)
+            loss.backward()
+        else:
+            # software pipeline over micro-batches: forward(m+1) (routing, all-to-all, gather) overlaps
+            # backward(m) on the other stream; backward passes are ordered by events so that gradient
+            # accumulation into shared parameters never runs on two streams at once
+            main = torch.cuda.current_stream()
+            for st in streams:
+                st.wait_stream(main)
+            prev_bwd = None
+            total = None
+            for m in range(MB):
+                st = streams[m & 1]
+                with torch.cuda.stream(st):
+                    lm = fwd_loss(idx_ring[k][m * mbs:(m + 1) * mbs], label_ring[k][m * mbs:(m + 1) * mbs], 1.0 / MB)
+                    if prev_bwd is not None:
+                        st.wait_event(prev_bwd)
+                    lm.backward()
+                    prev_bwd = torch.cuda.Event()
+                    prev_bwd.record(st)
+                    total = lm.detach() if total is None else total + lm.detach()
+            for st in streams:
+                main.wait_stream(st)
+            loss = total
         if world > 1:      # data-parallel dense parameters: average their gradients (one flat bucket)
             ps = [p for p in model.parameters() if p.grad is not None]
             flat = torch.cat([p.grad.reshape(-1).float() for p in ps])
@@ -269,6 +305,7 @@ def main():
                        ("BASELINE.json configs[4] (weak-scaled): DeepFM, " f"{V} rows row-sharded over {world} GPUs, "
                         f"global batch {B * world}"),
                        "model": a.model, "global_batch": B * world, "rows": V, "parallelism": parallelism,
+                       "microbatches": MB,
                        "fused_lookup_fm": not a.no_fuse, "loss": float(loss)},
             "roofline": roof,
         }

@@ -140,6 +140,12 @@ int trs_ffm_bwd(const void* x, const void* g, int64_t B, int32_t N, int32_t E, i
 int trs_ffm_fused_fwd(const void* const* tables, int64_t V, int32_t E, int32_t dtype,
                       const void* idx, int32_t idx_dtype, const int64_t* offsets, int64_t B, int32_t N,
                       void* out, int32_t* err_flag, trs_stream_t stream);
+/* dense gradients of the N tables of trs_ffm_fused_fwd (row_start/perm from trs_csr_build on the same
+ * indices): grad_tables[i][r,:] = sum_{(b,j) in row r, j != i} gout[b,p(i,j),:] * tables[j][g_i,:]      */
+int trs_ffm_fused_bwd(const void* const* tables, int64_t V, int32_t E, int32_t dtype, const void* idx,
+                      int32_t idx_dtype, const int64_t* offsets, const void* gout,
+                      const int32_t* row_start, const int32_t* perm, int64_t B, int32_t N,
+                      void* const* grad_tables, trs_stream_t stream);
 
 /* ---- K4: cross network ----------------------------------------------------------------------
  * x_{l+1} = x0 * (x_l W_l^T + b_l) + x0, l = 0..L-1, rows = B*N vectors of length E.

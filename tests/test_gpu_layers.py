@@ -257,3 +257,38 @@ def test_cin_channels_last_mfma_vs_oracle(dev, B, N, E, sizes, direct):
     assert rel_err(g_cl[0], xg.grad.float().cpu()) <= 3e-2
     assert rel_err(g_cl[1], lay.model[0].Conv1d.weight.grad.float().cpu()) <= 3e-2
     assert rel_err(g_cl[2], lay.fc.weight.grad.float().cpu()) <= 3e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,N,E", [(64, 6, 16), (33, 12, 8), (40, 39, 64), (17, 5, 10)])
+def test_fused_ffm_equals_two_module_path(dev, dtype, B, N, E):
+    """FusedFieldAwareFM (tables -> pair products, nothing materialised) == field-aware lookup + FFM layer, forward
+    (exact: one multiply per element) and all N table gradients."""
+    from torecsys_amd.fused import FusedFieldAwareFM
+    from torecsys_amd.inputs import MultiIndicesFieldAwareEmbedding
+    from torecsys_amd.layers import FFMLayer
+    g = torch.Generator().manual_seed(B + N + E)
+    fs = [3 + (i % 5) for i in range(N)]
+    idx = torch.cat([torch.randint(0, f, (B, 1), generator=g) for f in fs], 1).to(dev)
+    torch.manual_seed(1)
+    fa = MultiIndicesFieldAwareEmbedding(embed_size=E, field_sizes=fs).to(dev).to(dtype)
+    fused = FusedFieldAwareFM(embed_size=E, field_sizes=fs).to(dev).to(dtype)
+    fused.load_state_dict(fa.state_dict())
+    go = torch.randn(B, N * (N - 1) // 2, E, generator=g).to(dtype).to(dev)
+    y_ref = FFMLayer(num_fields=N)(fa(idx))
+    (y_ref.rename(None).float() * go.float()).sum().backward()
+    y = fused(idx)
+    assert y.names == ("B", "N", "E")
+    assert torch.equal(y.rename(None), y_ref.rename(None))
+    (y.rename(None).float() * go.float()).sum().backward()
+    tol = TOL32 if dtype == torch.float32 else 2 * TOLBF
+    for a, b in zip(fused.embeddings, fa.embeddings):
+        assert rel_err(a.weight.grad.float().cpu(), b.weight.grad.float().cpu()) <= tol
+    # and against the oracle in fp32
+    if dtype == torch.float32:
+        ws = [e.weight.detach().cpu().clone().requires_grad_() for e in fa.embeddings]
+        off = O.field_offsets(fs)
+        yo = O.ffm_layer(O.multi_indices_field_aware_embedding(ws, idx.cpu(), off), N)
+        assert rel_err(y.rename(None).detach().cpu(), yo.detach()) <= TOL32
+        (yo * go.cpu()).sum().backward()
+        assert rel_err(fused.embeddings[2].weight.grad.cpu(), ws[2].grad) <= TOL32

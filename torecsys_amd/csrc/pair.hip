@@ -368,6 +368,59 @@ __global__ __launch_bounds__(256) void ffm_fused_fwd_kernel(const UNIT* const* _
   }
 }
 
+// fused FFM backward: for table i and row r,
+//   grad_i[r,:] = sum over lookups p=(b,j) of row r with j != i of  gout[b, pair(i,j), :] * tables[j][g(b,i), :]
+// one UNIT-lane group per (table, row) walks the row's bucket of the shared CSR; every gradient row is
+// written exactly once (zeros for rows nobody looked up) -- dense gradients like nn.Embedding's default.
+template <typename T, typename UNIT, typename IdxT>
+__global__ __launch_bounds__(256) void ffm_fused_bwd_kernel(const UNIT* const* __restrict__ tables,
+                                                            const IdxT* __restrict__ idx,
+                                                            const int64_t* __restrict__ offsets,
+                                                            const UNIT* __restrict__ gout,
+                                                            const int32_t* __restrict__ row_start,
+                                                            const int32_t* __restrict__ perm, int N, int upr, int64_t V,
+                                                            UNIT* const* __restrict__ grads) {
+  const int P = N * (N - 1) / 2;
+  const int64_t per_table = V * upr;
+  const int64_t total = (int64_t)N * per_table, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int i = (int)(t / per_table);
+    const int64_t rem = t - (int64_t)i * per_table;
+    const int64_t r = rem / upr;
+    const int lv = (int)(rem - r * upr);
+    const int beg = row_start[r], end = row_start[r + 1];
+    float acc[sizeof(UNIT) / sizeof(T)];
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(UNIT) / sizeof(T)); ++k) acc[k] = 0.f;
+    for (int q = beg; q < end; ++q) {
+      const int p = perm[q];
+      const int64_t b = p / N;
+      const int j = (int)(p - b * N);
+      if (j == i) continue;
+      const int pidx = i < j ? pair_index(i, j, N) : pair_index(j, i, N);
+      const int64_t ri = load_row_id(idx, offsets, b * N + i, i);
+      const UNIT gv = gout[(b * P + pidx) * upr + lv];
+      const UNIT tv = tables[j][ri * upr + lv];
+      if constexpr (sizeof(UNIT) == 16) {
+        float gf[Vec16<T>::VE], tf[Vec16<T>::VE];
+        Vec16<T>::unpack(*reinterpret_cast<const uint4*>(&gv), gf);
+        Vec16<T>::unpack(*reinterpret_cast<const uint4*>(&tv), tf);
+#pragma unroll
+        for (int k = 0; k < Vec16<T>::VE; ++k) acc[k] = fmaf(gf[k], tf[k], acc[k]);
+      } else {
+        acc[0] = fmaf(to_f32(*reinterpret_cast<const T*>(&gv)), to_f32(*reinterpret_cast<const T*>(&tv)), acc[0]);
+      }
+    }
+    if constexpr (sizeof(UNIT) == 16) {
+      const uint4 o = Vec16<T>::pack(acc);
+      grads[i][rem] = *reinterpret_cast<const UNIT*>(&o);
+    } else {
+      const T o = from_f32<T>(acc[0]);
+      grads[i][rem] = *reinterpret_cast<const UNIT*>(&o);
+    }
+  }
+}
+
 }  // namespace trs
 
 using namespace trs;
@@ -475,4 +528,37 @@ extern "C" int trs_ffm_fused_fwd(const void* const* tables, int64_t V, int32_t E
   if (idx_dtype == TRS_I64)
     return ffm_fused_dispatch<int64_t>(tables, V, E, dtype, (const int64_t*)idx, offsets, B, N, out, err_flag, (hipStream_t)stream);
   return ffm_fused_dispatch<int32_t>(tables, V, E, dtype, (const int32_t*)idx, offsets, B, N, out, err_flag, (hipStream_t)stream);
+}
+
+template <typename IdxT>
+static int ffm_fused_bwd_dispatch(const void* const* tables, int64_t V, int E, int dtype, const IdxT* idx,
+                                  const int64_t* offsets, const void* gout, const int32_t* row_start,
+                                  const int32_t* perm, int N, void* const* grads, hipStream_t s) {
+  const int rb = E * dtype_size(dtype);
+  const bool vec = rb % 16 == 0 && aligned16(gout);
+  const int upr = vec ? rb / 16 : E;
+  const int grid = stream_grid((int64_t)N * V * upr, 256, 256 * 32);
+  if (vec && dtype == TRS_F32)
+    hipLaunchKernelGGL((ffm_fused_bwd_kernel<float, uint4, IdxT>), dim3(grid), dim3(256), 0, s, (const uint4* const*)tables, idx, offsets, (const uint4*)gout, row_start, perm, N, upr, V, (uint4* const*)grads);
+  else if (vec)
+    hipLaunchKernelGGL((ffm_fused_bwd_kernel<bf16_t, uint4, IdxT>), dim3(grid), dim3(256), 0, s, (const uint4* const*)tables, idx, offsets, (const uint4*)gout, row_start, perm, N, upr, V, (uint4* const*)grads);
+  else if (dtype == TRS_F32)
+    hipLaunchKernelGGL((ffm_fused_bwd_kernel<float, float, IdxT>), dim3(grid), dim3(256), 0, s, (const float* const*)tables, idx, offsets, (const float*)gout, row_start, perm, N, upr, V, (float* const*)grads);
+  else
+    hipLaunchKernelGGL((ffm_fused_bwd_kernel<bf16_t, bf16_t, IdxT>), dim3(grid), dim3(256), 0, s, (const bf16_t* const*)tables, idx, offsets, (const bf16_t*)gout, row_start, perm, N, upr, V, (bf16_t* const*)grads);
+  return check_launch("ffm_fused_bwd");
+}
+
+extern "C" int trs_ffm_fused_bwd(const void* const* tables, int64_t V, int32_t E, int32_t dtype, const void* idx,
+                                 int32_t idx_dtype, const int64_t* offsets, const void* gout,
+                                 const int32_t* row_start, const int32_t* perm, int64_t B, int32_t N,
+                                 void* const* grad_tables, trs_stream_t stream) {
+  TRS_REQUIRE(tables && grad_tables && row_start, TRS_EINVAL, "ffm_fused_bwd: NULL pointer");
+  TRS_REQUIRE(V > 0, TRS_EINVAL, "ffm_fused_bwd: bad V");
+  TRS_CHECK_BNE("ffm_fused_bwd");
+  TRS_REQUIRE(idx_dtype == TRS_I64 || idx_dtype == TRS_I32, TRS_EDTYPE, "ffm_fused_bwd: idx dtype %d", idx_dtype);
+  TRS_REQUIRE(B == 0 || (idx && gout && perm), TRS_EINVAL, "ffm_fused_bwd: NULL pointer");
+  if (idx_dtype == TRS_I64)
+    return ffm_fused_bwd_dispatch<int64_t>(tables, V, E, dtype, (const int64_t*)idx, offsets, gout, row_start, perm, N, grad_tables, (hipStream_t)stream);
+  return ffm_fused_bwd_dispatch<int32_t>(tables, V, E, dtype, (const int32_t*)idx, offsets, gout, row_start, perm, N, grad_tables, (hipStream_t)stream);
 }

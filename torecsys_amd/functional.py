@@ -621,3 +621,46 @@ def cin_contract_cl(x0T: torch.Tensor, xkT: torch.Tensor, Wc: torch.Tensor, bias
                     H: int) -> torch.Tensor:
     """channels-last CIN contraction on the matrix cores: x0T (B,E,ld0>=N, zero padded), xkT (B,E,>=H view)."""
     return _CINContractCL.apply(x0T, xkT, Wc, bias, N, H)
+
+
+# --------------------------------------------------------------------------------------------
+# K3 fused: field-aware lookup + pair products straight from the N tables
+# --------------------------------------------------------------------------------------------
+class _FFMFused(Function):
+    @staticmethod
+    def forward(ctx, idx, offsets, *weights):
+        require_device(idx, offsets, *weights)
+        B, N = idx.shape
+        if len(weights) != N:
+            raise ValueError(f"need {N} tables, got {len(weights)}")
+        V, E = weights[0].shape
+        ws = [w.contiguous() for w in weights]
+        out = torch.empty(B, N * (N - 1) // 2, E, dtype=ws[0].dtype, device=ws[0].device)
+        flag = _ErrFlag(out.device)
+        call("trs_ffm_fused_fwd", ptr(_pointer_table(ws)), V, E, value_dtype_code(ws[0]), ptr(idx), index_dtype_code(idx),
+             ptr(offsets), B, N, ptr(out), ptr(flag.t), stream_ptr())
+        flag.check("ffm_fused_fwd")
+        if any(w.requires_grad for w in weights):
+            prefetch_row_buckets(idx, offsets, V)
+        ctx.save_for_backward(idx, offsets, *weights)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        idx, offsets, *weights = ctx.saved_tensors
+        B, N = idx.shape
+        V, E = weights[0].shape
+        ws = [w.contiguous() for w in weights]
+        rb = row_buckets(idx, offsets, V)
+        grads = [torch.empty_like(w) for w in ws]
+        call("trs_ffm_fused_bwd", ptr(_pointer_table(ws)), V, E, value_dtype_code(ws[0]), ptr(idx), index_dtype_code(idx),
+             ptr(offsets), ptr(g.contiguous()), ptr(rb.row_start), ptr(rb.perm), B, N, ptr(_pointer_table(grads)),
+             stream_ptr())
+        return (None, None, *grads)
+
+
+def ffm_fused(weights: Sequence[torch.Tensor], idx: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
+    """(B,N) indices + N field-aware tables -> (B, N(N-1)/2, E) pair products; (B,N*N,E) is never materialised."""
+    idx = _as_index(idx)
+    return _FFMFused.apply(idx, offsets, *weights)
