@@ -65,7 +65,8 @@ def parse():
     ap.add_argument("--no-tunableop", action="store_true", help="do not use PyTorch TunableOp for the nn.Linear GEMMs")
     ap.add_argument("--microbatches", type=int, default=0,
                     help="sharded path: split each rank's batch into M micro-batches on 2 alternating streams so the "
-                         "all-to-all of one overlaps the dense compute of the other (0 = 4 when N > 1, else 1)")
+                         "all-to-all of one overlaps the dense compute of the other (default 1: measured slower on "
+                         "one GPU -- per-micro-batch host syncs and sparse-gradient accumulation outweigh the overlap)")
     ap.add_argument("--cpu-batch", type=int, default=16384)
     return ap.parse_args()
 
@@ -194,7 +195,7 @@ def main():
     crit = nn.BCEWithLogitsLoss()
     params = [p for p in list(inputs.parameters()) + list(model.parameters()) if p.requires_grad]
 
-    MB = a.microbatches or (4 if world > 1 else 1)
+    MB = a.microbatches or 1
     if not sharded:
         MB = 1
     assert B % MB == 0
