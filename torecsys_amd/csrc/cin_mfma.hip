@@ -47,13 +47,17 @@ __global__ __launch_bounds__(256) void cin_prepack_fwd_kernel(const bf16_t* __re
   }
 }
 
+constexpr int CIN_NS = 2;   // fields per pipeline step (one barrier per 2*KS*CIN_NS*P MFMAs per wave)
+
 template <int KS, int P>
 __global__ __launch_bounds__(256) void cin_cl_fwd_kernel(const bf16_t* __restrict__ x0T, int ld0,
                                                          const bf16_t* __restrict__ xkT, int ldk,
                                                          const uint4* __restrict__ Wp, const float* __restrict__ bias,
                                                          bf16_t* __restrict__ yT, int64_t B, int N, int C, int E) {
   constexpr int PIX = 16 * P;
-  constexpr int FR = 2 * KS * 64;                      // uint4 per (j,n) step
+  constexpr int FR1 = 2 * KS * 64;                     // uint4 per (j,n)
+  constexpr int FR = CIN_NS * FR1;                     // uint4 per step
+  constexpr int NPF = (FR + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* Abuf = reinterpret_cast<uint4*>(smem);                          // [2][FR]
   unsigned short* x0s = reinterpret_cast<unsigned short*>(smem + 2 * FR * 16);  // [4 waves][N][PIX]
@@ -62,14 +66,22 @@ __global__ __launch_bounds__(256) void cin_cl_fwd_kernel(const bf16_t* __restric
   const int items_per_b = E / PIX;
   const int64_t nitems = B * items_per_b;
   const int nj = C / 32;
-  const int nsteps = nj * N;
+  const int npairs = (N + CIN_NS - 1) / CIN_NS;
+  const int nsteps = nj * npairs;
+  // fragment index of (j, n) in Wp is (j*N + n); a step covers n0 .. n0+CIN_NS-1 of one j
+  auto step_src = [&](int step, int i) -> const uint4* {
+    const int j = step / npairs, n0 = (step - j * npairs) * CIN_NS;
+    const int sub = i / FR1;
+    const int n = n0 + sub;
+    if (n >= N) return nullptr;
+    return Wp + ((size_t)(j * N + n)) * FR1 + (i - sub * FR1);
+  };
   for (int64_t it0 = (int64_t)blockIdx.x * 4; it0 < nitems; it0 += (int64_t)gridDim.x * 4) {
     const int64_t it = it0 + wave;
     const bool live = it < nitems;
     const int64_t b = live ? it / items_per_b : 0;
     const int e0 = live ? (int)(it - b * items_per_b) * PIX : 0;
     const int64_t pix0 = b * E + e0;                                     // first pixel row of this wave
-    // B operands: xk^T rows of my pixels
     uint4 Bf[P][KS];
 #pragma unroll
     for (int t = 0; t < P; ++t)
@@ -79,7 +91,6 @@ __global__ __launch_bounds__(256) void cin_cl_fwd_kernel(const bf16_t* __restric
         if (live) Bf[t][ks] = *reinterpret_cast<const uint4*>(xkT + (pix0 + 16 * t + r) * ldk + 32 * ks + 8 * q);
       }
     __syncthreads();   // previous item's readers of x0s / Abuf are done
-    // x0 of my pixels -> LDS [n][pixel] (bf16)
     if (live) {
       for (int v = lane; v < PIX * ((N + 7) / 8); v += 64) {
         const int p = v % PIX, ch = v / PIX;
@@ -92,23 +103,28 @@ __global__ __launch_bounds__(256) void cin_cl_fwd_kernel(const bf16_t* __restric
         }
       }
     }
-    // stage step 0
-    for (int i = threadIdx.x; i < FR; i += 256) Abuf[i] = Wp[i];
+    for (int i = threadIdx.x; i < FR; i += 256) {
+      const uint4* src = step_src(0, i);
+      Abuf[i] = src ? *src : make_uint4(0, 0, 0, 0);
+    }
     __syncthreads();
     f32x4 acc[P][2];
     for (int step = 0; step < nsteps; ++step) {
-      const int j = step / N, n = step - j * N;
+      const int j = step / npairs, n0 = (step - j * npairs) * CIN_NS;
       const uint4* A = Abuf + (step & 1) * FR;
-      // prefetch the next step's fragments into registers
-      uint4 nxt[(FR + 255) / 256];
+      uint4 nxt[NPF];
       if (step + 1 < nsteps) {
 #pragma unroll
-        for (int k = 0; k < (FR + 255) / 256; ++k) {
+        for (int k = 0; k < NPF; ++k) {
           const int i = threadIdx.x + 256 * k;
-          if (i < FR) nxt[k] = Wp[(size_t)(step + 1) * FR + i];
+          nxt[k] = make_uint4(0, 0, 0, 0);
+          if (i < FR) {
+            const uint4* src = step_src(step + 1, i);
+            if (src) nxt[k] = *src;
+          }
         }
       }
-      if (n == 0) {
+      if (n0 == 0) {
 #pragma unroll
         for (int ct2 = 0; ct2 < 2; ++ct2) {
           const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + 32 * j + 8 * q + 4 * ct2)
@@ -117,28 +133,34 @@ __global__ __launch_bounds__(256) void cin_cl_fwd_kernel(const bf16_t* __restric
           for (int t = 0; t < P; ++t) acc[t][ct2] = f32x4{bv.x, bv.y, bv.z, bv.w};
         }
       }
-      f32x4 T[P][2];
 #pragma unroll
-      for (int t = 0; t < P; ++t) { T[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; T[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      for (int sub = 0; sub < CIN_NS; ++sub) {
+        const int n = n0 + sub;
+        if (n < N) {
+          f32x4 T[P][2];
 #pragma unroll
-      for (int ct2 = 0; ct2 < 2; ++ct2)
+          for (int t = 0; t < P; ++t) { T[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; T[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const uint4 a = A[(ct2 * KS + ks) * 64 + lane];
+          for (int ct2 = 0; ct2 < 2; ++ct2)
 #pragma unroll
-          for (int t = 0; t < P; ++t)
-            T[t][ct2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
-                                                                __builtin_bit_cast(bf16x8, Bf[t][ks]), T[t][ct2], 0, 0, 0);
+            for (int ks = 0; ks < KS; ++ks) {
+              const uint4 a = A[sub * FR1 + (ct2 * KS + ks) * 64 + lane];
+#pragma unroll
+              for (int t = 0; t < P; ++t)
+                T[t][ct2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                                    __builtin_bit_cast(bf16x8, Bf[t][ks]), T[t][ct2], 0, 0, 0);
+            }
+#pragma unroll
+          for (int t = 0; t < P; ++t) {
+            const float xv = __uint_as_float((unsigned)x0w[n * PIX + 16 * t + r] << 16);
+#pragma unroll
+            for (int ct2 = 0; ct2 < 2; ++ct2)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc[t][ct2][i] = fmaf(xv, T[t][ct2][i], acc[t][ct2][i]);
+          }
         }
-#pragma unroll
-      for (int t = 0; t < P; ++t) {
-        const float xv = __uint_as_float((unsigned)x0w[n * PIX + 16 * t + r] << 16);
-#pragma unroll
-        for (int ct2 = 0; ct2 < 2; ++ct2)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc[t][ct2][i] = fmaf(xv, T[t][ct2][i], acc[t][ct2][i]);
       }
-      if (n == N - 1 && live) {
+      if (n0 + CIN_NS >= N && live) {
 #pragma unroll
         for (int t = 0; t < P; ++t) {
           float f[8];
@@ -150,7 +172,7 @@ __global__ __launch_bounds__(256) void cin_cl_fwd_kernel(const bf16_t* __restric
       if (step + 1 < nsteps) {
         uint4* Anext = Abuf + ((step + 1) & 1) * FR;
 #pragma unroll
-        for (int k = 0; k < (FR + 255) / 256; ++k) {
+        for (int k = 0; k < NPF; ++k) {
           const int i = threadIdx.x + 256 * k;
           if (i < FR) Anext[i] = nxt[k];
         }
@@ -193,7 +215,7 @@ int cin_cl_fwd(const void* x0T, int ld0, const void* xkT, int ldk, const void* W
   const int P = E % 64 == 0 ? 4 : (E % 32 == 0 ? 2 : 1);
   const int64_t nitems = B * (E / (16 * P));
   const int grid = (int)std::min<int64_t>((nitems + 3) / 4, 256 * 2);
-  const size_t lds = (size_t)2 * 2 * KS * 64 * 16 + (size_t)4 * N * 16 * P * 2;
+  const size_t lds = (size_t)2 * CIN_NS * 2 * KS * 64 * 16 + (size_t)4 * N * 16 * P * 2;
   if (lds > 64 * 1024) return 1;
 #define TRS_CINF(KS_, P_)                                                                                          \
   hipLaunchKernelGGL((cin_cl_fwd_kernel<KS_, P_>), dim3(grid), dim3(256), lds, s, (const bf16_t*)x0T, ld0,          \
@@ -250,7 +272,9 @@ __global__ __launch_bounds__(256) void cin_cl_bwd_data_kernel(const bf16_t* __re
                                                               bf16_t* __restrict__ dxkT, int ldo, int64_t B, int N,
                                                               int H, int C, int E) {
   constexpr int PIX = 16 * P;
-  constexpr int FR = 2 * KC * 64;  // uint4 per (jh,n) step
+  constexpr int FR1 = 2 * KC * 64;   // uint4 per (jh,n)
+  constexpr int FR = CIN_NS * FR1;   // uint4 per step
+  constexpr int NPF = (FR + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* Abuf = reinterpret_cast<uint4*>(smem);                                   // [2][FR]
   float* dx0s_all = reinterpret_cast<float*>(smem + 2 * FR * 16);                 // [4][N][PIX] fp32
@@ -261,7 +285,15 @@ __global__ __launch_bounds__(256) void cin_cl_bwd_data_kernel(const bf16_t* __re
   const int items_per_b = E / PIX;
   const int64_t nitems = B * items_per_b;
   const int KSH = (H + 31) / 32;
-  const int nsteps = KSH * N;
+  const int npairs = (N + CIN_NS - 1) / CIN_NS;
+  const int nsteps = KSH * npairs;
+  auto step_src = [&](int step, int i) -> const uint4* {
+    const int jh = step / npairs, n0 = (step - jh * npairs) * CIN_NS;
+    const int sub = i / FR1;
+    const int n = n0 + sub;
+    if (n >= N) return nullptr;
+    return WpT + ((size_t)(jh * N + n)) * FR1 + (i - sub * FR1);
+  };
   for (int64_t it0 = (int64_t)blockIdx.x * 4; it0 < nitems; it0 += (int64_t)gridDim.x * 4) {
     const int64_t it = it0 + wave;
     const bool live = it < nitems;
@@ -290,22 +322,29 @@ __global__ __launch_bounds__(256) void cin_cl_bwd_data_kernel(const bf16_t* __re
         }
       }
     }
-    for (int i = threadIdx.x; i < FR; i += 256) Abuf[i] = WpT[i];
+    for (int i = threadIdx.x; i < FR; i += 256) {
+      const uint4* src = step_src(0, i);
+      Abuf[i] = src ? *src : make_uint4(0, 0, 0, 0);
+    }
     __syncthreads();
     f32x4 acc[P][2];
     float xkd[P][2][4];
     for (int step = 0; step < nsteps; ++step) {
-      const int jh = step / N, n = step - jh * N;
+      const int jh = step / npairs, n0 = (step - jh * npairs) * CIN_NS;
       const uint4* A = Abuf + (step & 1) * FR;
-      uint4 nxt[(FR + 255) / 256];
+      uint4 nxt[NPF];
       if (step + 1 < nsteps) {
 #pragma unroll
-        for (int k = 0; k < (FR + 255) / 256; ++k) {
+        for (int k = 0; k < NPF; ++k) {
           const int i = threadIdx.x + 256 * k;
-          if (i < FR) nxt[k] = WpT[(size_t)(step + 1) * FR + i];
+          nxt[k] = make_uint4(0, 0, 0, 0);
+          if (i < FR) {
+            const uint4* src = step_src(step + 1, i);
+            if (src) nxt[k] = *src;
+          }
         }
       }
-      if (n == 0) {
+      if (n0 == 0) {
 #pragma unroll
         for (int t = 0; t < P; ++t) {
           acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -318,35 +357,41 @@ __global__ __launch_bounds__(256) void cin_cl_bwd_data_kernel(const bf16_t* __re
           for (int i = 0; i < 4; ++i) { xkd[t][0][i] = f[i]; xkd[t][1][i] = f[4 + i]; }
         }
       }
-      f32x4 S[P][2];
 #pragma unroll
-      for (int t = 0; t < P; ++t) { S[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; S[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      for (int sub = 0; sub < CIN_NS; ++sub) {
+        const int n = n0 + sub;
+        if (n < N) {
+          f32x4 S[P][2];
 #pragma unroll
-      for (int ct2 = 0; ct2 < 2; ++ct2)
+          for (int t = 0; t < P; ++t) { S[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; S[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) {
-          const uint4 a = A[(ct2 * KC + kc) * 64 + lane];
+          for (int ct2 = 0; ct2 < 2; ++ct2)
 #pragma unroll
-          for (int t = 0; t < P; ++t)
-            S[t][ct2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
-                                                                __builtin_bit_cast(bf16x8, Bg[t][kc]), S[t][ct2], 0, 0, 0);
-        }
+            for (int kc = 0; kc < KC; ++kc) {
+              const uint4 a = A[sub * FR1 + (ct2 * KC + kc) * 64 + lane];
 #pragma unroll
-      for (int t = 0; t < P; ++t) {
-        const float xv = __uint_as_float((unsigned)x0w[n * PIX + 16 * t + r] << 16);
-        float part = 0.f;
+              for (int t = 0; t < P; ++t)
+                S[t][ct2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                                    __builtin_bit_cast(bf16x8, Bg[t][kc]), S[t][ct2], 0, 0, 0);
+            }
 #pragma unroll
-        for (int ct2 = 0; ct2 < 2; ++ct2)
+          for (int t = 0; t < P; ++t) {
+            const float xv = __uint_as_float((unsigned)x0w[n * PIX + 16 * t + r] << 16);
+            float part = 0.f;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            acc[t][ct2][i] = fmaf(xv, S[t][ct2][i], acc[t][ct2][i]);
-            part = fmaf(xkd[t][ct2][i], S[t][ct2][i], part);
+            for (int ct2 = 0; ct2 < 2; ++ct2)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                acc[t][ct2][i] = fmaf(xv, S[t][ct2][i], acc[t][ct2][i]);
+                part = fmaf(xkd[t][ct2][i], S[t][ct2][i], part);
+              }
+            part += __shfl_xor(part, 16, 64);
+            part += __shfl_xor(part, 32, 64);
+            if (q == (n & 3)) dx0s[n * PIX + 16 * t + r] += part;   // one lane per pixel; the wave owns this array
           }
-        part += __shfl_xor(part, 16, 64);
-        part += __shfl_xor(part, 32, 64);
-        if (q == (n & 3)) dx0s[n * PIX + 16 * t + r] += part;   // one lane per pixel; the wave owns this array
+        }
       }
-      if (n == N - 1 && live) {
+      if (n0 + CIN_NS >= N && live) {
 #pragma unroll
         for (int t = 0; t < P; ++t) {
           float f[8];
@@ -358,14 +403,13 @@ __global__ __launch_bounds__(256) void cin_cl_bwd_data_kernel(const bf16_t* __re
       if (step + 1 < nsteps) {
         uint4* Anext = Abuf + ((step + 1) & 1) * FR;
 #pragma unroll
-        for (int k = 0; k < (FR + 255) / 256; ++k) {
+        for (int k = 0; k < NPF; ++k) {
           const int i = threadIdx.x + 256 * k;
           if (i < FR) Anext[i] = nxt[k];
         }
       }
       __syncthreads();
     }
-    // dx0^T rows of my pixels: [pixel][n] from the LDS [n][pixel] accumulator (zeros past N)
     if (live) {
       for (int v = lane; v < PIX * (ld0 / 8); v += 64) {
         const int p = v % PIX, ch = v / PIX;
@@ -398,19 +442,23 @@ int cin_cl_bwd_data(const void* x0T, int ld0, const void* xkT, int ldk, const vo
   const int64_t total = (int64_t)KSH * N * 2 * KC * 64;
   hipLaunchKernelGGL(cin_prepack_bwd_kernel, dim3((int)std::min<int64_t>((total + 255) / 256, 2048)), dim3(256), 0, s,
                      (const bf16_t*)Wc, WpT, C, N, H, KSH, KC);
-  const int P = E % 32 == 0 ? 2 : 1;
+  // pixel tiles per wave: the gy fragments (P*KC*4 registers) must leave room for the accumulators
+  int P = E % 64 == 0 && KC <= 4 ? 4 : (E % 32 == 0 ? 2 : 1);
+  auto lds_for = [&](int P_) { return (size_t)2 * CIN_NS * 2 * KC * 64 * 16 + (size_t)4 * N * 16 * P_ * (4 + 2); };
+  while (P > 1 && lds_for(P) > 64 * 1024) P >>= 1;
+  const size_t lds = lds_for(P);
+  if (lds > 64 * 1024) return 1;
   const int64_t nitems = B * (E / (16 * P));
   const int grid = (int)std::min<int64_t>((nitems + 3) / 4, 256 * 2);
-  const size_t lds = (size_t)2 * 2 * KC * 64 * 16 + (size_t)4 * N * 16 * P * (4 + 2);
-  if (lds > 64 * 1024) return 1;
 #define TRS_CINB(KC_, P_)                                                                                           \
   hipLaunchKernelGGL((cin_cl_bwd_data_kernel<KC_, P_>), dim3(grid), dim3(256), lds, s, (const bf16_t*)x0T, ld0,      \
                      (const bf16_t*)xkT, ldk, (const bf16_t*)gyT, (const uint4*)WpT, (bf16_t*)dx0T, (bf16_t*)dxkT,   \
                      ldo, B, N, H, C, E)
-#define TRS_CINB_P(KC_)              \
-  do {                               \
-    if (P == 2) TRS_CINB(KC_, 2);    \
-    else TRS_CINB(KC_, 1);           \
+#define TRS_CINB_P(KC_)                \
+  do {                                 \
+    if (P == 4) TRS_CINB(KC_, 4);      \
+    else if (P == 2) TRS_CINB(KC_, 2); \
+    else TRS_CINB(KC_, 1);             \
   } while (0)
   switch (KC) {
     case 1: TRS_CINB_P(1); break;
