@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void cin_prepack_bwd_kernel(const bf16_t* __re
   }
 }
 
-template <int KC, int P>
+template <int KC, int P, int NS>
 __global__ __launch_bounds__(256) void cin_cl_bwd_data_kernel(const bf16_t* __restrict__ x0T, int ld0,
                                                               const bf16_t* __restrict__ xkT, int ldk,
                                                               const bf16_t* __restrict__ gyT,
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void cin_cl_bwd_data_kernel(const bf16_t* __re
                                                               int H, int C, int E) {
   constexpr int PIX = 16 * P;
   constexpr int FR1 = 2 * KC * 64;   // uint4 per (jh,n)
-  constexpr int FR = CIN_NS * FR1;   // uint4 per step
+  constexpr int FR = NS * FR1;   // uint4 per step
   constexpr int NPF = (FR + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* Abuf = reinterpret_cast<uint4*>(smem);                                   // [2][FR]
@@ -285,10 +285,10 @@ __global__ __launch_bounds__(256) void cin_cl_bwd_data_kernel(const bf16_t* __re
   const int items_per_b = E / PIX;
   const int64_t nitems = B * items_per_b;
   const int KSH = (H + 31) / 32;
-  const int npairs = (N + CIN_NS - 1) / CIN_NS;
+  const int npairs = (N + NS - 1) / NS;
   const int nsteps = KSH * npairs;
   auto step_src = [&](int step, int i) -> const uint4* {
-    const int jh = step / npairs, n0 = (step - jh * npairs) * CIN_NS;
+    const int jh = step / npairs, n0 = (step - jh * npairs) * NS;
     const int sub = i / FR1;
     const int n = n0 + sub;
     if (n >= N) return nullptr;
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void cin_cl_bwd_data_kernel(const bf16_t* __re
     f32x4 acc[P][2];
     float xkd[P][2][4];
     for (int step = 0; step < nsteps; ++step) {
-      const int jh = step / npairs, n0 = (step - jh * npairs) * CIN_NS;
+      const int jh = step / npairs, n0 = (step - jh * npairs) * NS;
       const uint4* A = Abuf + (step & 1) * FR;
       uint4 nxt[NPF];
       if (step + 1 < nsteps) {
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void cin_cl_bwd_data_kernel(const bf16_t* __re
         }
       }
 #pragma unroll
-      for (int sub = 0; sub < CIN_NS; ++sub) {
+      for (int sub = 0; sub < NS; ++sub) {
         const int n = n0 + sub;
         if (n < N) {
           f32x4 S[P][2];
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void cin_cl_bwd_data_kernel(const bf16_t* __re
           }
         }
       }
-      if (n0 + CIN_NS >= N && live) {
+      if (n0 + NS >= N && live) {
 #pragma unroll
         for (int t = 0; t < P; ++t) {
           float f[8];
@@ -444,16 +444,23 @@ int cin_cl_bwd_data(const void* x0T, int ld0, const void* xkT, int ldk, const vo
                      (const bf16_t*)Wc, WpT, C, N, H, KSH, KC);
   // pixel tiles per wave: the gy fragments (P*KC*4 registers) must leave room for the accumulators
   int P = E % 64 == 0 && KC <= 4 ? 4 : (E % 32 == 0 ? 2 : 1);
-  auto lds_for = [&](int P_) { return (size_t)2 * CIN_NS * 2 * KC * 64 * 16 + (size_t)4 * N * 16 * P_ * (4 + 2); };
-  while (P > 1 && lds_for(P) > 64 * 1024) P >>= 1;
-  const size_t lds = lds_for(P);
+  int NS = 2;   // fields per pipeline step; 1 when two would not fit 64 KiB of LDS (C = 256)
+  auto lds_for = [&](int P_, int NS_) { return (size_t)2 * NS_ * 2 * KC * 64 * 16 + (size_t)4 * N * 16 * P_ * (4 + 2); };
+  if (lds_for(P, NS) > 64 * 1024) NS = 1;
+  while (P > 1 && lds_for(P, NS) > 64 * 1024) P >>= 1;
+  const size_t lds = lds_for(P, NS);
   if (lds > 64 * 1024) return 1;
   const int64_t nitems = B * (E / (16 * P));
   const int grid = (int)std::min<int64_t>((nitems + 3) / 4, 256 * 2);
-#define TRS_CINB(KC_, P_)                                                                                           \
-  hipLaunchKernelGGL((cin_cl_bwd_data_kernel<KC_, P_>), dim3(grid), dim3(256), lds, s, (const bf16_t*)x0T, ld0,      \
+#define TRS_CINB2(KC_, P_, NS_)                                                                                     \
+  hipLaunchKernelGGL((cin_cl_bwd_data_kernel<KC_, P_, NS_>), dim3(grid), dim3(256), lds, s, (const bf16_t*)x0T, ld0, \
                      (const bf16_t*)xkT, ldk, (const bf16_t*)gyT, (const uint4*)WpT, (bf16_t*)dx0T, (bf16_t*)dxkT,   \
                      ldo, B, N, H, C, E)
+#define TRS_CINB(KC_, P_)              \
+  do {                                 \
+    if (NS == 2) TRS_CINB2(KC_, P_, 2); \
+    else TRS_CINB2(KC_, P_, 1);        \
+  } while (0)
 #define TRS_CINB_P(KC_)                \
   do {                                 \
     if (P == 4) TRS_CINB(KC_, 4);      \
@@ -468,6 +475,7 @@ int cin_cl_bwd_data(const void* x0T, int ld0, const void* xkT, int ldk, const vo
   }
 #undef TRS_CINB_P
 #undef TRS_CINB
+#undef TRS_CINB2
   return check_launch("cin_cl_bwd_data");
 }
 
