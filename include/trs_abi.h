@@ -97,6 +97,17 @@ int trs_scatter_rows(const void* g_rows, int64_t g_rows_batch_stride, const void
                      int64_t padding_row, void* grad_table, void* workspace, size_t ws_bytes,
                      trs_stream_t stream);
 
+/* Same walk, but the finished row sum is APPLIED to the table row in place by a fused sparse optimizer
+ *  instead of being written out: optimizer 1 = SGD  w -= lr*g;
+ * 2 = Adagrad  state += g*g, w -= lr*g/(sqrt(state)+eps)  (state: V x E fp32).  Exactly equivalent to the
+ * dense torch.optim.SGD / Adagrad step (no momentum / weight decay): rows nobody looked up have zero gradient
+ * and are not touched -- neither the dense V x E gradient nor a dense optimizer pass over the table exists.  */
+int trs_scatter_rows_update(const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm,
+                            const float* fm_sum, void* table, const int32_t* row_start, const int32_t* perm,
+                            int64_t BN, int64_t V, int32_t E, int32_t N, int32_t dtype, int64_t padding_row,
+                            int32_t optimizer, float lr, float eps, float* state, void* workspace,
+                            size_t ws_bytes, trs_stream_t stream);
+
 /* ---- K1+K2(+K8): fused embedding lookup + FM second order ----------------------------------
  * emb[b,n,:]  = table[idx[b,n]+offsets[n], :]                       (optional, may be NULL)
  * fm[b,:]     = 0.5 * ((sum_n x)^2 - sum_n x^2)                     (optional, may be NULL)

@@ -226,3 +226,41 @@ def test_errors(dev):
     # empty batch
     out = m(torch.zeros(0, 2, dtype=torch.long, device=dev))
     assert out.shape == (0, 2, 8)
+
+
+@pytest.mark.parametrize("kind", ["sgd", "adagrad"])
+@pytest.mark.parametrize("dtype,E", [(torch.float32, 16), (torch.float32, 10), (torch.bfloat16, 64)])
+def test_fused_sparse_optimizer_equals_dense_step(dev, kind, dtype, E):
+    """set_fused_optimizer(): the in-backward row update equals a dense torch.optim step on the dense-gradient path
+    (two steps, Zipf-ish indices so hot rows take the long-row kernel), and no .grad is produced."""
+    from torecsys_amd.inputs import MultiIndicesEmbedding
+    from torecsys_amd.layers import FMLayer
+    from torecsys_amd.optim import FusedSparseAdagrad, FusedSparseSGD
+    fs, idx0, w, _, g = _rand_case(2048, 7, E, 6, 31 + E, dtype, zipf=True)
+    _, idx1, _, _, _ = _rand_case(2048, 7, E, 6, 77 + E, dtype, zipf=True)
+    lr = 0.05
+    mods = []
+    for fused in (False, True):
+        m = MultiIndicesEmbedding(embed_size=E, field_sizes=fs, fuse_fm=(E * w.element_size()) % 16 == 0).to(dev).to(dtype)
+        m.embedding.weight.data.copy_(w)
+        if fused:
+            m.set_fused_optimizer(FusedSparseSGD(lr) if kind == "sgd" else FusedSparseAdagrad(lr, eps=1e-10))
+            opt = None
+        else:
+            opt = (torch.optim.SGD(m.parameters(), lr=lr) if kind == "sgd"
+                   else torch.optim.Adagrad(m.parameters(), lr=lr, eps=1e-10))
+        for idx in (idx0, idx1):
+            emb = m(idx.to(dev))
+            y = FMLayer()(emb)
+            loss = (y.rename(None).float() ** 2).mean() + emb.rename(None).float().sum() * 1e-3
+            if opt is not None:
+                opt.zero_grad()
+            loss.backward()
+            if opt is not None:
+                opt.step()
+            else:
+                assert m.embedding.weight.grad is None
+        mods.append(m.embedding.weight.detach().float().cpu())
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert rel_err(mods[1], mods[0]) <= tol
+    assert not torch.equal(mods[0], w.float())

@@ -147,6 +147,60 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const IdxT* __restrict__ 
   }
 }
 
+// Where a finished row sum goes: written out as the gradient row (mode 0), or applied in place to the table
+// row by a fused sparse optimizer -- SGD (mode 1) or Adagrad (mode 2).  Both are exactly equivalent to their
+// dense torch.optim counterparts (no momentum / weight decay): rows nobody looked up have a zero gradient
+// and are not touched, so neither the dense V x E gradient nor a dense optimizer pass over the table exists.
+struct RowSink {
+  int mode;
+  float lr, eps;
+  float* state;  // Adagrad accumulator (V x E fp32) or null
+};
+
+template <typename T>
+__device__ __forceinline__ void sink_vec(const RowSink& k, uint4* __restrict__ out, int64_t vec, const float* acc,
+                                         bool touched) {
+  constexpr int VE = Vec16<T>::VE;
+  if (k.mode == 0) {
+    out[vec] = Vec16<T>::pack(acc);
+    return;
+  }
+  if (!touched) return;
+  float w[VE];
+  Vec16<T>::unpack(out[vec], w);
+  if (k.mode == 1) {
+#pragma unroll
+    for (int i = 0; i < VE; ++i) w[i] = fmaf(-k.lr, acc[i], w[i]);
+  } else {
+    float* st = k.state + vec * VE;
+#pragma unroll
+    for (int i = 0; i < VE; ++i) {
+      const float s2 = fmaf(acc[i], acc[i], st[i]);
+      st[i] = s2;
+      w[i] -= k.lr * acc[i] / (sqrtf(s2) + k.eps);
+    }
+  }
+  out[vec] = Vec16<T>::pack(w);
+}
+
+template <typename T>
+__device__ __forceinline__ void sink_elem(const RowSink& k, T* __restrict__ out, int64_t idx, float acc, bool touched) {
+  if (k.mode == 0) {
+    out[idx] = from_f32<T>(acc);
+    return;
+  }
+  if (!touched) return;
+  float w = to_f32(out[idx]);
+  if (k.mode == 1) {
+    w = fmaf(-k.lr, acc, w);
+  } else {
+    const float s2 = fmaf(acc, acc, k.state[idx]);
+    k.state[idx] = s2;
+    w -= k.lr * acc / (sqrtf(s2) + k.eps);
+  }
+  out[idx] = from_f32<T>(w);
+}
+
 // ---------------------------------------------------------------------------------------------
 // segmented reduction: one L-lane group per table row (rows with > LONG_ROW lookups are deferred
 // to a queue and reduced by whole workgroups afterwards)
@@ -223,7 +277,7 @@ __global__ __launch_bounds__(256) void scatter_rows_group_kernel(
     const uint4* __restrict__ g_rows, const uint4* __restrict__ g_fm, const float* __restrict__ fm_sum,
     const uint4* __restrict__ table, const int32_t* __restrict__ row_start, const int32_t* __restrict__ perm,
     int64_t V, int N, int64_t gbs, int64_t padding_row, uint4* __restrict__ grad,
-    int32_t* __restrict__ long_rows /* [0]=count */) {
+    int32_t* __restrict__ long_rows /* [0]=count */, RowSink sink) {
   constexpr int L = 1 << LOG2L;
   constexpr int VE = Vec16<T>::VE;
   const int lane_v = threadIdx.x & (L - 1);
@@ -249,7 +303,7 @@ __global__ __launch_bounds__(256) void scatter_rows_group_kernel(
         for (int k = 0; k < VE; ++k) acc[k] = fmaf(-w[k], gsum[k], acc[k]);
       }
     }
-    grad[r * L + lane_v] = Vec16<T>::pack(acc);
+    sink_vec<T>(sink, grad, r * L + lane_v, acc, end > beg && r != padding_row);
   }
 }
 
@@ -258,7 +312,7 @@ template <typename T, int LOG2L, bool HAS_G, bool HAS_FM>
 __global__ __launch_bounds__(256) void scatter_long_rows_kernel(
     const uint4* __restrict__ g_rows, const uint4* __restrict__ g_fm, const float* __restrict__ fm_sum,
     const uint4* __restrict__ table, const int32_t* __restrict__ row_start, const int32_t* __restrict__ perm, int N,
-    int64_t gbs, uint4* __restrict__ grad, const int32_t* __restrict__ long_rows) {
+    int64_t gbs, uint4* __restrict__ grad, const int32_t* __restrict__ long_rows, RowSink sink) {
   constexpr int L = 1 << LOG2L;
   constexpr int VE = Vec16<T>::VE;
   constexpr int G = 256 / L;  // groups per workgroup
@@ -295,7 +349,7 @@ __global__ __launch_bounds__(256) void scatter_long_rows_kernel(
 #pragma unroll
         for (int k = 0; k < VE; ++k) acc[k] = fmaf(-w[k], gsum[k], acc[k]);
       }
-      grad[r * L + lane_v] = Vec16<T>::pack(acc);
+      sink_vec<T>(sink, grad, r * L + lane_v, acc, true);
     }
     __syncthreads();
   }
@@ -347,15 +401,18 @@ template <typename T>
 __global__ __launch_bounds__(256) void scatter_rows_elem_kernel(
     const T* __restrict__ g_rows, const T* __restrict__ g_fm, const float* __restrict__ fm_sum,
     const T* __restrict__ table, const int32_t* __restrict__ row_start, const int32_t* __restrict__ perm, int64_t V,
-    int E, int N, int64_t gbs, int64_t padding_row, T* __restrict__ grad, int32_t* __restrict__ long_rows) {
+    int E, int N, int64_t gbs, int64_t padding_row, T* __restrict__ grad, int32_t* __restrict__ long_rows,
+    RowSink sink) {
   const int64_t total = V * E;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
     const int64_t r = t / E;
     const int e = (int)(t - r * E);
     float acc = 0.f, gsum = 0.f;
+    bool touched = false;
     if (r != padding_row) {
       const int beg = row_start[r], end = row_start[r + 1];
+      touched = end > beg;
       if (end - beg > LONG_ROW) {
         if (e == 0) {
           const int slot = atomicAdd(&long_rows[0], 1);
@@ -366,7 +423,7 @@ __global__ __launch_bounds__(256) void scatter_rows_elem_kernel(
       for (int q = beg; q < end; ++q) acc += elem_term<T>(g_rows, g_fm, fm_sum, perm[q], E, N, gbs, e, &gsum);
       if (g_fm != nullptr && fm_sum != nullptr && end > beg) acc = fmaf(-to_f32(table[t]), gsum, acc);
     }
-    grad[t] = from_f32<T>(acc);
+    sink_elem<T>(sink, grad, t, acc, touched);
   }
 }
 
@@ -374,7 +431,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void scatter_long_rows_elem_kernel(
     const T* __restrict__ g_rows, const T* __restrict__ g_fm, const float* __restrict__ fm_sum,
     const T* __restrict__ table, const int32_t* __restrict__ row_start, const int32_t* __restrict__ perm, int E, int N,
-    int64_t gbs, T* __restrict__ grad, const int32_t* __restrict__ long_rows) {
+    int64_t gbs, T* __restrict__ grad, const int32_t* __restrict__ long_rows, RowSink sink) {
   __shared__ float red[2][4];
   const int nlong = long_rows[0];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -397,7 +454,7 @@ __global__ __launch_bounds__(256) void scatter_long_rows_elem_kernel(
         acc = red[0][0] + red[0][1] + red[0][2] + red[0][3];
         gsum = red[1][0] + red[1][1] + red[1][2] + red[1][3];
         if (g_fm != nullptr && fm_sum != nullptr) acc = fmaf(-to_f32(table[r * E + e]), gsum, acc);
-        grad[r * E + e] = from_f32<T>(acc);
+        sink_elem<T>(sink, grad, r * E + e, acc, true);
       }
     }
   }
@@ -416,7 +473,7 @@ template <typename T, int LOG2L>
 static void scatter_group_launch(const void* g_rows, const void* g_fm, const float* fm_sum, const void* table,
                                  const int32_t* row_start, const int32_t* perm, int64_t V, int N, int64_t gbs,
                                  int64_t padding_row, void* grad, int32_t* long_rows, void* tg, int64_t B,
-                                 hipStream_t s) {
+                                 RowSink sink, hipStream_t s) {
   const int L = 1 << LOG2L;
   if (g_fm != nullptr && fm_sum != nullptr) {
     hipLaunchKernelGGL((build_tg_kernel<T>), dim3(stream_grid(B * L, 256, 4096)), dim3(256), 0, s, (const uint4*)g_fm,
@@ -429,10 +486,10 @@ static void scatter_group_launch(const void* g_rows, const void* g_fm, const flo
   do {                                                                                                          \
     hipLaunchKernelGGL((scatter_rows_group_kernel<T, LOG2L, HG, HF>), dim3(grid), dim3(256), 0, s,               \
                        (const uint4*)g_rows, (const uint4*)g_fm, fm_sum, (const uint4*)table, row_start, perm, V, \
-                       N, gbs, padding_row, (uint4*)grad, long_rows);                                                 \
+                       N, gbs, padding_row, (uint4*)grad, long_rows, sink);                                           \
     hipLaunchKernelGGL((scatter_long_rows_kernel<T, LOG2L, HG, HF>), dim3(512), dim3(256), 0, s,                 \
                        (const uint4*)g_rows, (const uint4*)g_fm, fm_sum, (const uint4*)table, row_start, perm, N, \
-                       gbs, (uint4*)grad, long_rows);                                                                 \
+                       gbs, (uint4*)grad, long_rows, sink);                                                           \
   } while (0)
   if (hg && hf) TRS_SC(true, true);
   else if (hg) TRS_SC(true, false);
@@ -443,25 +500,26 @@ static void scatter_group_launch(const void* g_rows, const void* g_fm, const flo
 template <typename T>
 static int scatter_launch(const void* g_rows, const void* g_fm, const float* fm_sum, const void* table,
                           const int32_t* row_start, const int32_t* perm, int64_t V, int E, int N, int64_t gbs,
-                          int64_t padding_row, void* grad, int32_t* long_rows, void* tg, int64_t B, hipStream_t s) {
+                          int64_t padding_row, void* grad, int32_t* long_rows, void* tg, int64_t B, RowSink sink,
+                          hipStream_t s) {
   const int lg = log2_lanes_sc(E * (int)sizeof(T));
   const bool al = aligned16(g_rows) && aligned16(g_fm) && aligned16(table) && aligned16(grad) && aligned16(fm_sum);
   if (lg >= 0 && al) {
     switch (lg) {
-      case 0: scatter_group_launch<T, 0>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, B, s); break;
-      case 1: scatter_group_launch<T, 1>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, B, s); break;
-      case 2: scatter_group_launch<T, 2>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, B, s); break;
-      case 3: scatter_group_launch<T, 3>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, B, s); break;
-      case 4: scatter_group_launch<T, 4>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, B, s); break;
-      case 5: scatter_group_launch<T, 5>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, B, s); break;
-      default: scatter_group_launch<T, 6>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, B, s); break;
+      case 0: scatter_group_launch<T, 0>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, B, sink, s); break;
+      case 1: scatter_group_launch<T, 1>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, B, sink, s); break;
+      case 2: scatter_group_launch<T, 2>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, B, sink, s); break;
+      case 3: scatter_group_launch<T, 3>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, B, sink, s); break;
+      case 4: scatter_group_launch<T, 4>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, B, sink, s); break;
+      case 5: scatter_group_launch<T, 5>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, B, sink, s); break;
+      default: scatter_group_launch<T, 6>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, B, sink, s); break;
     }
   } else {
     hipLaunchKernelGGL((scatter_rows_elem_kernel<T>), dim3(stream_grid(V * E, 256, 256 * 32)), dim3(256), 0, s,
                        (const T*)g_rows, (const T*)g_fm, fm_sum, (const T*)table, row_start, perm, V, E, N, gbs,
-                       padding_row, (T*)grad, long_rows);
+                       padding_row, (T*)grad, long_rows, sink);
     hipLaunchKernelGGL((scatter_long_rows_elem_kernel<T>), dim3(512), dim3(256), 0, s, (const T*)g_rows,
-                       (const T*)g_fm, fm_sum, (const T*)table, row_start, perm, E, N, gbs, (T*)grad, long_rows);
+                       (const T*)g_fm, fm_sum, (const T*)table, row_start, perm, E, N, gbs, (T*)grad, long_rows, sink);
   }
   return check_launch("scatter_rows");
 }
@@ -527,7 +585,7 @@ extern "C" size_t trs_scatter_workspace_bytes(int64_t BN, int32_t N, int32_t E, 
   return long_row_queue_bytes(BN) + align_up((size_t)B * 2 * E * dtype_size(dtype), 256);
 }
 
-extern "C" int trs_scatter_rows(const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm,
+static int scatter_rows_impl(RowSink sink, const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm,
                                 const float* fm_sum, const void* table, const int32_t* row_start,
                                 const int32_t* perm, int64_t BN, int64_t V, int32_t E, int32_t N, int32_t dtype,
                                 int64_t padding_row, void* grad_table, void* workspace, size_t ws_bytes,
@@ -549,7 +607,28 @@ extern "C" int trs_scatter_rows(const void* g_rows, int64_t g_rows_batch_stride,
   if (hipMemsetAsync(long_rows, 0, 4, s) != hipSuccess) return check_launch("scatter_rows(memset)");
   if (dtype == TRS_F32)
     return scatter_launch<float>(g_rows, g_fm, fm_sum, table, row_start, perm, V, E, N, gbs, padding_row,
-                                 grad_table, long_rows, tg, B, s);
+                                 grad_table, long_rows, tg, B, sink, s);
   return scatter_launch<bf16_t>(g_rows, g_fm, fm_sum, table, row_start, perm, V, E, N, gbs, padding_row, grad_table,
-                                long_rows, tg, B, s);
+                                long_rows, tg, B, sink, s);
+}
+
+extern "C" int trs_scatter_rows(const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm, const float* fm_sum,
+                                const void* table, const int32_t* row_start, const int32_t* perm, int64_t BN, int64_t V,
+                                int32_t E, int32_t N, int32_t dtype, int64_t padding_row, void* grad_table,
+                                void* workspace, size_t ws_bytes, trs_stream_t stream) {
+  return scatter_rows_impl(RowSink{0, 0.f, 0.f, nullptr}, g_rows, g_rows_batch_stride, g_fm, fm_sum, table, row_start,
+                           perm, BN, V, E, N, dtype, padding_row, grad_table, workspace, ws_bytes, stream);
+}
+
+extern "C" int trs_scatter_rows_update(const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm,
+                                       const float* fm_sum, void* table, const int32_t* row_start, const int32_t* perm,
+                                       int64_t BN, int64_t V, int32_t E, int32_t N, int32_t dtype, int64_t padding_row,
+                                       int32_t optimizer, float lr, float eps, float* state, void* workspace,
+                                       size_t ws_bytes, trs_stream_t stream) {
+  TRS_REQUIRE(table, TRS_EINVAL, "scatter_rows_update: NULL table");
+  TRS_REQUIRE(optimizer == 1 || optimizer == 2, TRS_EINVAL, "scatter_rows_update: optimizer %d (1 = SGD, 2 = Adagrad)",
+              optimizer);
+  TRS_REQUIRE(optimizer == 1 || state != nullptr, TRS_EINVAL, "scatter_rows_update: Adagrad needs the state buffer");
+  return scatter_rows_impl(RowSink{optimizer, lr, eps, state}, g_rows, g_rows_batch_stride, g_fm, fm_sum, table,
+                           row_start, perm, BN, V, E, N, dtype, padding_row, table, workspace, ws_bytes, stream);
 }

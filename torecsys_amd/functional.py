@@ -161,12 +161,37 @@ def scatter_rows(rb: RowBuckets, like_table: torch.Tensor, g_rows: Optional[torc
     return grad
 
 
+def scatter_rows_update(rb: RowBuckets, table: torch.Tensor, opt, g_rows: Optional[torch.Tensor] = None,
+                        g_bcast: Optional[torch.Tensor] = None, fm_sum: Optional[torch.Tensor] = None,
+                        padding_row: int = -1) -> None:
+    """Fused sparse optimizer step: the bucketed gradient of every looked-up row is applied to ``table`` in
+    place (see trs_scatter_rows_update); no gradient tensor is produced."""
+    V, E = table.shape
+    if not table.is_contiguous():
+        raise ValueError("fused optimizer needs a contiguous table")
+    ws_bytes = size_query("trs_scatter_workspace_bytes", rb.BN, rb.N, E, value_dtype_code(table))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=table.device)
+    state = opt.state_for(table)
+    call("trs_scatter_rows_update", ptr(g_rows), 0, ptr(g_bcast), ptr(fm_sum), ptr(table), ptr(rb.row_start),
+         ptr(rb.perm), rb.BN, V, E, rb.N, value_dtype_code(table), padding_row, opt.kind, float(opt.lr), float(opt.eps),
+         ptr(state), ptr(ws), ws_bytes, stream_ptr())
+
+
+def _apply_or_grad(rb, weight, opt, **kw):
+    """dense gradient (default) or in-place fused optimizer step (returns None)."""
+    if opt is None:
+        return scatter_rows(rb, weight, **kw)
+    with torch.no_grad():
+        scatter_rows_update(rb, weight.data, opt, **kw)
+    return None
+
+
 # --------------------------------------------------------------------------------------------
 # K1: gather
 # --------------------------------------------------------------------------------------------
 class _GatherRows(Function):
     @staticmethod
-    def forward(ctx, weight, idx, offsets, padding_idx):
+    def forward(ctx, weight, idx, offsets, padding_idx, opt=None):
         require_device(weight, idx, offsets)
         B, N = idx.shape
         V, E = weight.shape
@@ -182,6 +207,7 @@ class _GatherRows(Function):
             prefetch_row_buckets(idx, offsets, V)
         ctx.save_for_backward(idx, offsets, weight)
         ctx.padding_idx = -1 if padding_idx is None else int(padding_idx)
+        ctx.opt = opt
         return out
 
     @staticmethod
@@ -189,12 +215,12 @@ class _GatherRows(Function):
     def backward(ctx, g):
         idx, offsets, weight = ctx.saved_tensors
         rb = row_buckets(idx, offsets, weight.shape[0])
-        grad = scatter_rows(rb, weight, g_rows=g.contiguous(), padding_row=ctx.padding_idx)
-        return grad, None, None, None
+        grad = _apply_or_grad(rb, weight, ctx.opt, g_rows=g.contiguous(), padding_row=ctx.padding_idx)
+        return grad, None, None, None, None
 
 
 def gather_rows(weight: torch.Tensor, idx: torch.Tensor, offsets: Optional[torch.Tensor] = None,
-                padding_idx: Optional[int] = None) -> torch.Tensor:
+                padding_idx: Optional[int] = None, opt=None) -> torch.Tensor:
     """out[b,n,:] = weight[idx[b,n] + offsets[n], :]; dense-gradient backward."""
     idx = _as_index(idx)
     if idx.dim() == 1:
@@ -203,7 +229,7 @@ def gather_rows(weight: torch.Tensor, idx: torch.Tensor, offsets: Optional[torch
         raise ValueError(f"indices must be (B, N), got shape {tuple(idx.shape)}")
     if padding_idx is not None and padding_idx < 0:
         padding_idx = weight.shape[0] + padding_idx
-    return _GatherRows.apply(weight, idx, offsets, padding_idx)
+    return _GatherRows.apply(weight, idx, offsets, padding_idx, opt)
 
 
 # --------------------------------------------------------------------------------------------
@@ -211,7 +237,7 @@ def gather_rows(weight: torch.Tensor, idx: torch.Tensor, offsets: Optional[torch
 # --------------------------------------------------------------------------------------------
 class _EmbedFM(Function):
     @staticmethod
-    def forward(ctx, weight, idx, offsets, first_weight, want_emb):
+    def forward(ctx, weight, idx, offsets, first_weight, want_emb, opt=None):
         require_device(weight, idx, offsets, first_weight)
         B, N = idx.shape
         V, E = weight.shape
@@ -235,6 +261,7 @@ class _EmbedFM(Function):
             prefetch_row_buckets(idx, offsets, V)
         ctx.save_for_backward(idx, offsets, weight, first_weight, fm_sum)
         ctx.want_emb = want_emb
+        ctx.opt = opt
         ctx.set_materialize_grads(False)   # unused outputs arrive as None, not as zero blocks
         outs = (emb if want_emb else fm.new_empty(0), fm, first if first is not None else fm.new_empty(0))
         if not want_emb:
@@ -254,27 +281,28 @@ class _EmbedFM(Function):
             has_emb = ctx.want_emb and g_emb is not None
             has_fm = g_fm is not None
             if has_emb or has_fm:
-                gw = scatter_rows(rb, weight, g_rows=g_emb.contiguous() if has_emb else None,
-                                  g_bcast=g_fm.contiguous() if has_fm else None, fm_sum=fm_sum if has_fm else None)
-            else:
+                gw = _apply_or_grad(rb, weight, ctx.opt, g_rows=g_emb.contiguous() if has_emb else None,
+                                    g_bcast=g_fm.contiguous() if has_fm else None, fm_sum=fm_sum if has_fm else None)
+            elif ctx.opt is None:
                 gw = torch.zeros_like(weight)
         if first_weight is not None and ctx.needs_input_grad[3]:
             if g_first is not None:
-                gfw = scatter_rows(rb, first_weight.reshape(V, 1), g_bcast=g_first.contiguous().reshape(-1, 1))
-                gfw = gfw.reshape(first_weight.shape)
-            else:
+                gfw = _apply_or_grad(rb, first_weight.reshape(V, 1), ctx.opt,
+                                     g_bcast=g_first.contiguous().reshape(-1, 1))
+                gfw = None if gfw is None else gfw.reshape(first_weight.shape)
+            elif ctx.opt is None:
                 gfw = torch.zeros_like(first_weight)
-        return gw, None, None, gfw, None
+        return gw, None, None, gfw, None, None
 
 
 def embed_fm(weight: torch.Tensor, idx: torch.Tensor, offsets: Optional[torch.Tensor] = None,
-             first_weight: Optional[torch.Tensor] = None, want_emb: bool = True
+             first_weight: Optional[torch.Tensor] = None, want_emb: bool = True, opt=None
              ) -> Tuple[Optional[torch.Tensor], torch.Tensor, Optional[torch.Tensor]]:
     """One pass over the looked-up rows: (emb (B,N,E) | None, fm (B,E), first (B,1) | None)."""
     idx = _as_index(idx)
     if idx.dim() != 2:
         raise ValueError(f"indices must be (B, N), got shape {tuple(idx.shape)}")
-    emb, fm, first = _EmbedFM.apply(weight, idx, offsets, first_weight, want_emb)
+    emb, fm, first = _EmbedFM.apply(weight, idx, offsets, first_weight, want_emb, opt)
     return (emb if want_emb else None), fm, (first if first_weight is not None else None)
 
 

@@ -43,6 +43,13 @@ class BaseInput(nn.Module):
     def __init__(self):
         super().__init__()
         self.schema = None
+        self.fused_optimizer = None
+
+    def set_fused_optimizer(self, opt):
+        """Apply ``opt`` (torecsys_amd.optim.FusedSparseSGD / FusedSparseAdagrad) to this module's table rows inside
+        the backward pass: no dense gradient is produced, ``weight.grad`` stays None.  Returns self."""
+        self.fused_optimizer = opt
+        return self
 
     def __len__(self) -> int:
         return self.length
@@ -69,7 +76,7 @@ class SingleIndexEmbedding(BaseInput):
         self.length = embed_size
 
     def forward(self, inputs: torch.Tensor) -> torch.Tensor:
-        out = F_.gather_rows(self.embedding.weight, inputs, None, self.embedding.padding_idx)
+        out = F_.gather_rows(self.embedding.weight, inputs, None, self.embedding.padding_idx, self.fused_optimizer)
         out.names = ('B', 'N', 'E',)
         return out
 
@@ -110,10 +117,10 @@ class MultiIndicesEmbedding(BaseInput):
         if idx.dim() != 2 or idx.shape[1] != self.offsets.numel():
             raise ValueError(f'inputs must be (B, {self.offsets.numel()}), got {tuple(idx.shape)}')
         if self.fuse_fm and not self.flatten:
-            out, fm, _ = F_.embed_fm(self.embedding.weight, idx, self.offsets)
+            out, fm, _ = F_.embed_fm(self.embedding.weight, idx, self.offsets, opt=self.fused_optimizer)
             out._trs_fused_fm = (fm, out._version)
         else:
-            out = F_.gather_rows(self.embedding.weight, idx, self.offsets, self.padding_idx)
+            out = F_.gather_rows(self.embedding.weight, idx, self.offsets, self.padding_idx, self.fused_optimizer)
         if self.flatten:
             out = out.reshape(out.shape[0], 1, -1)
         out.names = ('B', 'N', 'E',)

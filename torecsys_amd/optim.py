@@ -1,0 +1,47 @@
+"""Fused sparse optimizers for embedding tables.
+
+The reference trains every parameter with a dense optimizer over a dense ``V x E`` gradient
+(trainer/torecsys_pipeline.py:562-578).  For SGD and Adagrad (no momentum, no weight decay) the dense step only
+changes rows that were looked up, so it can be applied by the kernel that reduces the bucketed gradient:
+``module.set_fused_optimizer(FusedSparseSGD(lr))`` makes the backward pass update the table rows in place --
+bit-for-bit the same rows a dense ``torch.optim.SGD`` / ``Adagrad`` step would produce up to fp32 summation order --
+without ever forming the dense gradient or sweeping the table.  The other parameters keep a normal optimizer.
+"""
+from __future__ import annotations
+
+import torch
+
+
+class _FusedSparse:
+    kind = 0
+
+    def __init__(self, lr: float, eps: float = 0.0):
+        if lr < 0:
+            raise ValueError(f"invalid learning rate {lr}")
+        self.lr, self.eps = float(lr), float(eps)
+
+    def state_for(self, table: torch.Tensor):
+        return None
+
+
+class FusedSparseSGD(_FusedSparse):
+    """w[r] -= lr * g[r] for every looked-up row r (== torch.optim.SGD(lr) without momentum / weight decay)."""
+    kind = 1
+
+
+class FusedSparseAdagrad(_FusedSparse):
+    """state[r] += g[r]^2 ; w[r] -= lr * g[r] / (sqrt(state[r]) + eps)   (== torch.optim.Adagrad(lr, eps=eps))."""
+    kind = 2
+
+    def __init__(self, lr: float = 1e-2, eps: float = 1e-10, initial_accumulator_value: float = 0.0):
+        super().__init__(lr, eps)
+        self.initial = float(initial_accumulator_value)
+        self._state = {}
+
+    def state_for(self, table: torch.Tensor):
+        key = (table.data_ptr(), tuple(table.shape))
+        st = self._state.get(key)
+        if st is None:
+            st = torch.full(table.shape, self.initial, dtype=torch.float32, device=table.device)
+            self._state[key] = st
+        return st
