@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--model", default="deepfm", choices=["deepfm", "fm", "dcn", "xdeepfm"],
                     help="deepfm = the headline metric (BASELINE configs[1]); dcn / xdeepfm = configs[2] / [3]")
     ap.add_argument("--no-tunableop", action="store_true", help="do not use PyTorch TunableOp for the nn.Linear GEMMs")
+    ap.add_argument("--optimizer", default="none", choices=["none", "sgd", "adagrad"],
+                    help="none (default): the metric is fwd+bwd.  sgd/adagrad: also take an optimizer step -- fused sparse "
+                         "update inside the embedding backward (no dense table gradient), torch.optim for the MLP")
     ap.add_argument("--microbatches", type=int, default=0,
                     help="sharded path: split each rank's batch into M micro-batches on 2 alternating streams so the "
                          "all-to-all of one overlaps the dense compute of the other (default 1: measured slower on "
@@ -194,6 +197,16 @@ def main():
     counter = [0]
     crit = nn.BCEWithLogitsLoss()
     params = [p for p in list(inputs.parameters()) + list(model.parameters()) if p.requires_grad]
+    dense_opt = None
+    if a.optimizer != "none":
+        if sharded:
+            raise SystemExit("--optimizer is wired for the single-GPU path only")
+        from torecsys_amd.optim import FusedSparseAdagrad, FusedSparseSGD
+        fo = FusedSparseSGD(0.01) if a.optimizer == "sgd" else FusedSparseAdagrad(0.01)
+        emb.set_fused_optimizer(fo)
+        feat.set_fused_optimizer(fo)
+        dense_opt = (torch.optim.SGD(model.parameters(), lr=0.01) if a.optimizer == "sgd"
+                     else torch.optim.Adagrad(model.parameters(), lr=0.01))
 
     MB = a.microbatches or 1
     if not sharded:
@@ -215,6 +228,8 @@ def main():
         if MB == 1:
             loss = fwd_loss(idx_ring[k], label_ring[k], 1.0)
             loss.backward()
+            if dense_opt is not None:
+                dense_opt.step()
         else:
             # software pipeline over micro-batches: forward(m+1) (routing, all-to-all, gather) overlaps
             # backward(m) on the other stream; backward passes are ordered by events so that gradient
@@ -306,7 +321,7 @@ def main():
                        ("BASELINE.json configs[4] (weak-scaled): DeepFM, " f"{V} rows row-sharded over {world} GPUs, "
                         f"global batch {B * world}"),
                        "model": a.model, "global_batch": B * world, "rows": V, "parallelism": parallelism,
-                       "microbatches": MB,
+                       "microbatches": MB, "optimizer": a.optimizer,
                        "fused_lookup_fm": not a.no_fuse, "loss": float(loss)},
             "roofline": roof,
         }
