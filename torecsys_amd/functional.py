@@ -115,11 +115,37 @@ def row_buckets(idx: torch.Tensor, offsets: Optional[torch.Tensor], V: int) -> R
     return rb
 
 
+_pending_prefetch: List[tuple] = []
+_defer_depth = [0]
+
+
+class defer_prefetch:
+    """Context manager: bucket prefetches requested inside are launched when the block exits.  ``Inputs.forward``
+    wraps its loop over the embedding modules with it, so the (atomics-heavy) bucket build starts after ALL
+    lookups of the batch have been enqueued and overlaps the dense part of the model instead of the lookups."""
+
+    def __enter__(self):
+        _defer_depth[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _defer_depth[0] -= 1
+        if _defer_depth[0] == 0:
+            reqs = list(_pending_prefetch)
+            _pending_prefetch.clear()
+            for idx, offsets, V in reqs:
+                prefetch_row_buckets(idx, offsets, V)
+        return False
+
+
 def prefetch_row_buckets(idx: torch.Tensor, offsets: Optional[torch.Tensor], V: int) -> None:
     """Start building the CSR of this batch on a side stream at FORWARD time: it depends only on the
     indices, is latency-bound (int32 atomics), and hides behind the forward/backward of the dense part
     of the model; the backward's scatter then just waits on an event."""
     if not PREFETCH_BUCKETS:
+        return
+    if _defer_depth[0] > 0:
+        _pending_prefetch.append((idx, offsets, V))
         return
     key = _bucket_key(idx, offsets, V)
     for k, _, _rb in _bucket_cache:

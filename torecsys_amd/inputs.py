@@ -188,16 +188,17 @@ class Inputs(BaseInput):
 
     def forward(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         outputs = {}
-        for k, emb_fn in self.schema.items():
-            if emb_fn.__class__.__name__ in ['ConcatInput', 'StackedInput']:
-                inp_args = [{i: inputs[i] for i in emb_fn.schema.inputs}]
-            else:
-                cols = []
-                for emb_k in emb_fn.schema.inputs:
-                    v = inputs[emb_k]
-                    cols.append(v.unsqueeze(-1) if v.dim() == 1 else v)
-                inp_args = [cols[0] if len(cols) == 1 else torch.cat(cols, dim=1)]
-            outputs[k] = emb_fn(*inp_args)
+        with F_.defer_prefetch():      # row-bucket builds start once every lookup of the batch is enqueued
+            for k, emb_fn in self.schema.items():
+                if emb_fn.__class__.__name__ in ['ConcatInput', 'StackedInput']:
+                    inp_args = [{i: inputs[i] for i in emb_fn.schema.inputs}]
+                else:
+                    cols = []
+                    for emb_k in emb_fn.schema.inputs:
+                        v = inputs[emb_k]
+                        cols.append(v.unsqueeze(-1) if v.dim() == 1 else v)
+                    inp_args = [cols[0] if len(cols) == 1 else torch.cat(cols, dim=1)]
+                outputs[k] = emb_fn(*inp_args)
         return outputs
 
     def add_inputs(self, name: Optional[str] = None, model: Optional[nn.Module] = None,
