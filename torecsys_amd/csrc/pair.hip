@@ -216,6 +216,192 @@ __global__ __launch_bounds__(256) void pair_dot_bwd_generic(const T* __restrict_
   }
 }
 
+// --------------------------------------------------------------------------------------------
+// IPN on the matrix cores (bf16):  G = X X^T per sample (N x E block), strict upper triangle stored.
+// Both MFMA operands are ROWS of X: A[m = field i][k = 8 consecutive e] and B[k = 8 consecutive e][n = field j]
+// are the same 16-byte loads straight from the (B,N,E) block -- no LDS, no transposes.  One wave = one sample,
+// NT = ceil(N/16) row tiles x KS = E/32 k-steps of fragments in registers (24 VGPRs at N=39, E=64), then
+// NT(NT+1)/2 tile pairs x KS v_mfma_f32_16x16x32_bf16.  D[m = i][n = j] lands with j on lanes: each register
+// is a run of 16 consecutive pair slots of one i.
+typedef __attribute__((ext_vector_type(8))) __bf16 pd_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float pd_f32x4;
+
+template <int NT, int KS>
+__global__ __launch_bounds__(256) void pair_dot_fwd_mfma_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out,
+                                                                int64_t B, int N, int E) {
+  const int lane = threadIdx.x & 63, q = lane >> 4, r = lane & 15;
+  const int P = N * (N - 1) / 2;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t b = wave; b < B; b += nwaves) {
+    uint4 F[NT][KS];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int row = 16 * t + r;
+        F[t][ks] = make_uint4(0, 0, 0, 0);
+        if (row < N) F[t][ks] = *reinterpret_cast<const uint4*>(x + (b * N + row) * (int64_t)E + 32 * ks + 8 * q);
+      }
+    bf16_t* o = out + b * P;
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+      for (int tj = ti; tj < NT; ++tj) {
+        pd_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pd_bf16x8, F[ti][ks]),
+                                                        __builtin_bit_cast(pd_bf16x8, F[tj][ks]), acc, 0, 0, 0);
+        const int j = 16 * tj + r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = 16 * ti + 4 * q + k;
+          if (i < j && j < N) o[pair_index(i, j, N)] = from_f32<bf16_t>(acc[k]);
+        }
+      }
+  }
+}
+
+// backward on the matrix cores: dX = Gs X, Gs = symmetric zero-diagonal matrix of the pair gradients.
+// D[m = i][n = e] = sum_j A[m = i][k = j] B[k = j][n = e]:  A = rows of Gs (built per sample in LDS as bf16,
+// padded to NP = 16*NT columns), B = X^T -- 8 consecutive j of one column e, read from an LDS copy of X with
+// 8 two-byte reads per fragment (the copy is written row-major with 16-byte stores).
+template <int NT, int KE /* E/16 column tiles */>
+__global__ __launch_bounds__(256) void pair_dot_bwd_mfma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ g,
+                                                                bf16_t* __restrict__ dx, int64_t B, int N, int E) {
+  constexpr int NP = 16 * NT;            // padded field count
+  constexpr int KJ = (NP + 31) / 32;     // k-steps over j
+  constexpr int NPK = 32 * KJ;
+  constexpr int GS = NPK + 8;            // Gs row stride (bf16 elements): 16-byte aligned, conflict-spreading pad
+  constexpr int EC = 16 * KE;
+  constexpr int XS = EC + 8;             // X row stride
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, r = lane & 15;
+  unsigned short* Gs = reinterpret_cast<unsigned short*>(smem) + (size_t)wave * (NP * GS + NPK * XS);
+  unsigned short* Xs = Gs + NP * GS;
+  const int P = N * (N - 1) / 2;
+  const int64_t bstride = (int64_t)gridDim.x * 4;
+  for (int64_t b0 = (int64_t)blockIdx.x * 4; b0 < B; b0 += bstride) {
+    const int64_t b = b0 + wave;
+    __syncthreads();
+    if (b < B) {
+      // zero Gs (diagonal + padding), X rows >= N
+      for (int v = lane; v < (NP * GS) / 8; v += 64) reinterpret_cast<uint4*>(Gs)[v] = make_uint4(0, 0, 0, 0);
+      for (int v = lane; v < (NPK * XS) / 8; v += 64) reinterpret_cast<uint4*>(Xs)[v] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    if (b < B) {
+      const bf16_t* gb = g + b * P;
+      for (int i = 0; i < N - 1; ++i) {                     // row i of the triangle: pairs (i, i+1..N-1) are contiguous
+        const int base = pair_index(i, i + 1, N);
+        for (int j = i + 1 + lane; j < N; j += 64) {
+          const unsigned short v = gb[base + (j - i - 1)].v;
+          Gs[i * GS + j] = v;
+          Gs[j * GS + i] = v;
+        }
+      }
+      for (int v = lane; v < N * (EC / 8); v += 64) {
+        const int row = v / (EC / 8), c8 = v - row * (EC / 8);
+        *reinterpret_cast<uint4*>(Xs + row * XS + 8 * c8) =
+            *reinterpret_cast<const uint4*>(x + (b * N + row) * (int64_t)E + 8 * c8);
+      }
+    }
+    __syncthreads();
+    if (b < B) {
+#pragma unroll
+      for (int te = 0; te < KE; ++te) {
+        uint4 Bf[KJ];
+#pragma unroll
+        for (int kj = 0; kj < KJ; ++kj) {
+          unsigned w[4];
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            const int j0 = 32 * kj + 8 * q + 2 * h;
+            w[h] = (unsigned)Xs[j0 * XS + 16 * te + r] | ((unsigned)Xs[(j0 + 1) * XS + 16 * te + r] << 16);
+          }
+          Bf[kj] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+          pd_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kj = 0; kj < KJ; ++kj) {
+            const uint4 a = *reinterpret_cast<const uint4*>(Gs + (16 * ti + r) * GS + 32 * kj + 8 * q);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pd_bf16x8, a),
+                                                          __builtin_bit_cast(pd_bf16x8, Bf[kj]), acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int i = 16 * ti + 4 * q + k;
+            if (i < N) dx[(b * N + i) * (int64_t)E + 16 * te + r] = from_f32<bf16_t>(acc[k]);
+          }
+        }
+      }
+    }
+  }
+}
+
+static bool pair_mfma_ok(int N, int E) { return N >= 2 && N <= 64 && (E == 32 || E == 64 || E == 128); }
+
+static int pair_dot_fwd_mfma(const void* x, void* out, int64_t B, int N, int E, hipStream_t s) {
+  const int NT = (N + 15) / 16, KS = E / 32;
+  const int grid = (int)std::min<int64_t>((B + 3) / 4, 256 * 8);
+#define TRS_PF(NT_, KS_)                                                                                      \
+  hipLaunchKernelGGL((pair_dot_fwd_mfma_kernel<NT_, KS_>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x,      \
+                     (bf16_t*)out, B, N, E)
+#define TRS_PF_K(NT_)               \
+  do {                              \
+    if (KS == 1) TRS_PF(NT_, 1);    \
+    else if (KS == 2) TRS_PF(NT_, 2); \
+    else TRS_PF(NT_, 4);            \
+  } while (0)
+  switch (NT) {
+    case 1: TRS_PF_K(1); break;
+    case 2: TRS_PF_K(2); break;
+    case 3: TRS_PF_K(3); break;
+    default: TRS_PF_K(4); break;
+  }
+#undef TRS_PF_K
+#undef TRS_PF
+  return check_launch("pair_dot_fwd(mfma)");
+}
+
+static int pair_dot_bwd_mfma(const void* x, const void* g, void* dx, int64_t B, int N, int E, hipStream_t s) {
+  const int NT = (N + 15) / 16, KE = E / 16;
+  const int NP = 16 * NT, NPK = 32 * ((NP + 31) / 32);
+  const size_t lds = (size_t)4 * (NP * (NPK + 8) + NPK * (E + 8)) * 2;
+  const int grid = (int)std::min<int64_t>((B + 3) / 4, 256 * 8);
+#define TRS_PB(NT_, KE_)                                                                                      \
+  do {                                                                                                        \
+    auto kern = pair_dot_bwd_mfma_kernel<NT_, KE_>;                                                           \
+    static bool attr_set = false;                                                                             \
+    if (!attr_set && lds > 64 * 1024) {                                                                       \
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=     \
+          hipSuccess)                                                                                         \
+        return check_launch("pair_dot_bwd(mfma): LDS attribute");                                             \
+      attr_set = true;                                                                                        \
+    }                                                                                                         \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)g, (bf16_t*)dx,  \
+                       B, N, E);                                                                              \
+  } while (0)
+#define TRS_PB_K(NT_)               \
+  do {                              \
+    if (KE == 2) TRS_PB(NT_, 2);    \
+    else if (KE == 4) TRS_PB(NT_, 4); \
+    else TRS_PB(NT_, 8);            \
+  } while (0)
+  switch (NT) {
+    case 1: TRS_PB_K(1); break;
+    case 2: TRS_PB_K(2); break;
+    case 3: TRS_PB_K(3); break;
+    default: TRS_PB_K(4); break;
+  }
+#undef TRS_PB_K
+#undef TRS_PB
+  return check_launch("pair_dot_bwd(mfma)");
+}
+
 constexpr size_t LDS_BUDGET = 80 * 1024;  // per block: 2 blocks per CU out of 160 KiB
 
 template <typename T>
@@ -436,6 +622,7 @@ extern "C" int trs_pair_dot_fwd(const void* x, int64_t B, int32_t N, int32_t E, 
   TRS_CHECK_BNE("pair_dot_fwd");
   if (B == 0 || N < 2) return TRS_OK;
   if (dtype == TRS_F32) return pair_dot_fwd_launch<float>(x, out, B, N, E, (hipStream_t)stream);
+  if (pair_mfma_ok(N, E) && aligned16(x)) return pair_dot_fwd_mfma(x, out, B, N, E, (hipStream_t)stream);
   return pair_dot_fwd_launch<bf16_t>(x, out, B, N, E, (hipStream_t)stream);
 }
 
@@ -451,6 +638,7 @@ extern "C" int trs_pair_dot_bwd(const void* x, const void* g, int64_t B, int32_t
     return TRS_OK;
   }
   if (dtype == TRS_F32) return pair_dot_bwd_launch<float>(x, g, dx, B, N, E, (hipStream_t)stream);
+  if (pair_mfma_ok(N, E) && aligned16(x)) return pair_dot_bwd_mfma(x, g, dx, B, N, E, (hipStream_t)stream);
   return pair_dot_bwd_launch<bf16_t>(x, g, dx, B, N, E, (hipStream_t)stream);
 }
 
