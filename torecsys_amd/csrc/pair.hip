@@ -278,9 +278,15 @@ __global__ __launch_bounds__(256) void pair_dot_bwd_mfma_kernel(const bf16_t* __
   constexpr int XS = EC + 8;             // X row stride
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, r = lane & 15;
-  unsigned short* Gs = reinterpret_cast<unsigned short*>(smem) + (size_t)wave * (NP * GS + NPK * XS);
-  unsigned short* Xs = Gs + NP * GS;
   const int P = N * (N - 1) / 2;
+  const int PL = (P + 7) & ~7;
+  unsigned short* lut = reinterpret_cast<unsigned short*>(smem);   // pair -> (i << 8 | j), shared by the block
+  unsigned short* Gs = lut + PL + (size_t)wave * (NP * GS + NPK * XS);
+  unsigned short* Xs = Gs + NP * GS;
+  for (int i = threadIdx.x; i < N - 1; i += blockDim.x) {
+    const int base = pair_index(i, i + 1, N);
+    for (int j = i + 1; j < N; ++j) lut[base + (j - i - 1)] = (unsigned short)((i << 8) | j);
+  }
   const int64_t bstride = (int64_t)gridDim.x * 4;
   for (int64_t b0 = (int64_t)blockIdx.x * 4; b0 < B; b0 += bstride) {
     const int64_t b = b0 + wave;
@@ -293,12 +299,21 @@ __global__ __launch_bounds__(256) void pair_dot_bwd_mfma_kernel(const bf16_t* __
     __syncthreads();
     if (b < B) {
       const bf16_t* gb = g + b * P;
-      for (int i = 0; i < N - 1; ++i) {                     // row i of the triangle: pairs (i, i+1..N-1) are contiguous
-        const int base = pair_index(i, i + 1, N);
-        for (int j = i + 1 + lane; j < N; j += 64) {
-          const unsigned short v = gb[base + (j - i - 1)].v;
-          Gs[i * GS + j] = v;
-          Gs[j * GS + i] = v;
+      for (int p0 = lane; p0 < P; p0 += 256) {              // 4 independent coalesced loads in flight per lane
+        unsigned short v[4], ij[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int pp = p0 + 64 * u;
+          v[u] = pp < P ? gb[pp].v : (unsigned short)0;
+          ij[u] = pp < P ? lut[pp] : (unsigned short)0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (p0 + 64 * u < P) {
+            const int i = ij[u] >> 8, j = ij[u] & 255;
+            Gs[i * GS + j] = v[u];
+            Gs[j * GS + i] = v[u];
+          }
         }
       }
       for (int v = lane; v < N * (EC / 8); v += 64) {
@@ -370,7 +385,8 @@ static int pair_dot_fwd_mfma(const void* x, void* out, int64_t B, int N, int E, 
 static int pair_dot_bwd_mfma(const void* x, const void* g, void* dx, int64_t B, int N, int E, hipStream_t s) {
   const int NT = (N + 15) / 16, KE = E / 16;
   const int NP = 16 * NT, NPK = 32 * ((NP + 31) / 32);
-  const size_t lds = (size_t)4 * (NP * (NPK + 8) + NPK * (E + 8)) * 2;
+  const int P = N * (N - 1) / 2;
+  const size_t lds = (size_t)((P + 7) & ~7) * 2 + (size_t)4 * (NP * (NPK + 8) + NPK * (E + 8)) * 2;
   const int grid = (int)std::min<int64_t>((B + 3) / 4, 256 * 8);
 #define TRS_PB(NT_, KE_)                                                                                      \
   do {                                                                                                        \
