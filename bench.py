@@ -227,6 +227,8 @@ def main():
             p.grad = None
         if MB == 1:
             loss = fwd_loss(idx_ring[k], label_ring[k], 1.0)
+            if sharded:      # input-pipeline style hint: start routing the next batch before this backward
+                emb.prefetch_route(idx_ring[(k + 1) % RING])
             loss.backward()
             if dense_opt is not None:
                 dense_opt.step()

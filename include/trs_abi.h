@@ -235,6 +235,12 @@ int trs_bucket_by_owner(const void* idx, int32_t idx_dtype, const int64_t* offse
 /* out[pos[k],:] = rows[k,:]  (un-permute received rows into the (B*N,E) block) */
 int trs_scatter_by_pos(const void* rows, const int32_t* pos, int64_t K, int32_t E, int32_t dtype,
                        void* out, trs_stream_t stream);
+/* out[k,:] = g_block[pos[k],:] + g_fm[b,:]*(fm_sum[b,:] - x[pos[k],:]), b = pos[k]/N: the block gradient (and
+ * the FM second-order backward when the FM term was fused into the sharded lookup) in exchange order, one pass.
+ * g_block or the (g_fm, fm_sum, x) triple may be NULL.                                                       */
+int trs_permute_grad(const void* g_block, const void* g_fm, const float* fm_sum, const void* x,
+                     const int32_t* pos, int64_t K, int32_t N, int32_t E, int32_t dtype, void* out,
+                     trs_stream_t stream);
 /* out[k,:] = rows[pos[k],:]  (permute the block gradient into exchange order) */
 int trs_gather_by_pos(const void* rows, const int32_t* pos, int64_t K, int32_t E, int32_t dtype,
                       void* out, trs_stream_t stream);

@@ -84,6 +84,8 @@ def _worker(rank, world, port, fuse, sparse, ret):
         per, ranges = shard_ranges(V, world)
         assert m.row_range == ranges[rank] and m.rows_per_rank == per
         assert torch.equal(m.full_weight(), W)
+        if fuse:                         # exercise the routed-ahead path (input-pipeline hint) on half the cases
+            m.prefetch_route(idx_all[rank])
         out = m(idx_all[rank])
         assert out.names == ("B", "N", "E")
         off = O.field_offsets(fs)

@@ -213,6 +213,56 @@ static int fm_bwd_launch(const void* x, const void* g, const float* fm_sum, int6
   return check_launch("fm_bwd");
 }
 
+// rows of d(block) in exchange order for the sharded lookup:
+//   out[k,:] = g_block[pos[k],:] + g_fm[b,:] * (fm_sum[b,:] - x[pos[k],:]),   b = pos[k] / N
+// (either term optional) -- one pass instead of fm_bwd + add + permute.
+template <typename T>
+__global__ __launch_bounds__(256) void permute_grad_vec_kernel(const uint4* __restrict__ g_block,
+                                                               const uint4* __restrict__ g_fm,
+                                                               const float* __restrict__ fm_sum,
+                                                               const uint4* __restrict__ x, const int32_t* __restrict__ pos,
+                                                               uint4* __restrict__ out, int64_t K, int N, int vpr) {
+  constexpr int VE = Vec16<T>::VE;
+  const int64_t total = K * vpr, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t k = t / vpr;
+    const int lv = (int)(t - k * vpr);
+    const int64_t p = pos[k];
+    float o[VE];
+#pragma unroll
+    for (int i = 0; i < VE; ++i) o[i] = 0.f;
+    if (g_block != nullptr) Vec16<T>::unpack(g_block[p * vpr + lv], o);
+    if (g_fm != nullptr) {
+      const int64_t b = p / N;
+      float gf[VE], xv[VE];
+      Vec16<T>::unpack(g_fm[b * vpr + lv], gf);
+      Vec16<T>::unpack(x[p * vpr + lv], xv);
+      const float* sp = fm_sum + (b * vpr + lv) * VE;
+#pragma unroll
+      for (int i = 0; i < VE; ++i) o[i] = fmaf(gf[i], sp[i] - xv[i], o[i]);
+    }
+    out[t] = Vec16<T>::pack(o);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void permute_grad_elem_kernel(const T* __restrict__ g_block, const T* __restrict__ g_fm,
+                                                                const float* __restrict__ fm_sum, const T* __restrict__ x,
+                                                                const int32_t* __restrict__ pos, T* __restrict__ out,
+                                                                int64_t K, int N, int E) {
+  const int64_t total = K * E, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t k = t / E;
+    const int e = (int)(t - k * E);
+    const int64_t p = pos[k];
+    float o = g_block ? to_f32(g_block[p * E + e]) : 0.f;
+    if (g_fm != nullptr) {
+      const int64_t b = p / N;
+      o = fmaf(to_f32(g_fm[b * E + e]), fm_sum[b * E + e] - to_f32(x[p * E + e]), o);
+    }
+    out[t] = from_f32<T>(o);
+  }
+}
+
 }  // namespace trs
 
 using namespace trs;
@@ -267,4 +317,37 @@ extern "C" int trs_fm_bwd(const void* x, const void* g, const float* fm_sum, int
   hipStream_t s = (hipStream_t)stream;
   if (dtype == TRS_F32) return fm_bwd_launch<float>(x, g, fm_sum, B, N, E, dx, s);
   return fm_bwd_launch<bf16_t>(x, g, fm_sum, B, N, E, dx, s);
+}
+
+extern "C" int trs_permute_grad(const void* g_block, const void* g_fm, const float* fm_sum, const void* x,
+                                const int32_t* pos, int64_t K, int32_t N, int32_t E, int32_t dtype, void* out,
+                                trs_stream_t stream) {
+  if (K == 0) return TRS_OK;
+  TRS_REQUIRE(pos && out && (g_block || g_fm), TRS_EINVAL, "permute_grad: NULL pointer");
+  TRS_REQUIRE(g_fm == nullptr || (fm_sum && x), TRS_EINVAL, "permute_grad: g_fm needs fm_sum and x");
+  TRS_REQUIRE(K > 0 && N > 0 && E > 0, TRS_EINVAL, "permute_grad: bad size");
+  TRS_REQUIRE(dtype == TRS_F32 || dtype == TRS_BF16, TRS_EDTYPE, "permute_grad: dtype %d", dtype);
+  hipStream_t s = (hipStream_t)stream;
+  const int rb = E * dtype_size(dtype);
+  const bool vec = rb % 16 == 0 && aligned16(g_block) && aligned16(g_fm) && aligned16(x) && aligned16(out) &&
+                   aligned16(fm_sum);
+  if (vec) {
+    const int vpr = rb / 16;
+    const int grid = stream_grid(K * vpr, 256, 256 * 32);
+    if (dtype == TRS_F32)
+      hipLaunchKernelGGL((permute_grad_vec_kernel<float>), dim3(grid), dim3(256), 0, s, (const uint4*)g_block,
+                         (const uint4*)g_fm, fm_sum, (const uint4*)x, pos, (uint4*)out, K, N, vpr);
+    else
+      hipLaunchKernelGGL((permute_grad_vec_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, (const uint4*)g_block,
+                         (const uint4*)g_fm, fm_sum, (const uint4*)x, pos, (uint4*)out, K, N, vpr);
+  } else {
+    const int grid = stream_grid(K * E, 256, 256 * 32);
+    if (dtype == TRS_F32)
+      hipLaunchKernelGGL((permute_grad_elem_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)g_block,
+                         (const float*)g_fm, fm_sum, (const float*)x, pos, (float*)out, K, N, E);
+    else
+      hipLaunchKernelGGL((permute_grad_elem_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)g_block,
+                         (const bf16_t*)g_fm, fm_sum, (const bf16_t*)x, pos, (bf16_t*)out, K, N, E);
+  }
+  return check_launch("permute_grad");
 }

@@ -78,18 +78,17 @@ class HipOps:
         return block, fm, fm_sum
 
     def permute_grad(self, g_block: Optional[torch.Tensor], send_pos: torch.Tensor, g_fm, fm_sum, block):
-        """rows of d(block) in exchange order: g_block[pos[k]] (+ g_fm*(S - x) when the FM term was fused)."""
+        """rows of d(block) in exchange order: g_block[pos[k]] (+ g_fm*(S - x) when the FM term was fused) -- one
+        kernel (trs_permute_grad)."""
         B, N, E = block.shape
-        if g_fm is not None:
-            dx = torch.empty_like(block)
-            call("trs_fm_bwd", ptr(block), ptr(g_fm.contiguous()), ptr(fm_sum), B, N, E, value_dtype_code(block), ptr(dx),
-                 stream_ptr())
-            g_block = dx if g_block is None else g_block + dx
-        g_block = g_block.contiguous()
         K = send_pos.numel()
-        out = torch.empty(K, E, dtype=g_block.dtype, device=g_block.device)
+        gb = None if g_block is None else g_block.contiguous()
+        gf = None if g_fm is None else g_fm.contiguous()
+        out = torch.empty(K, E, dtype=block.dtype, device=block.device)
         if K:
-            call("trs_gather_by_pos", ptr(g_block), ptr(send_pos), K, E, value_dtype_code(g_block), ptr(out), stream_ptr())
+            call("trs_permute_grad", ptr(gb), ptr(gf), ptr(fm_sum if gf is not None else None),
+                 ptr(block if gf is not None else None), ptr(send_pos), K, N, E, value_dtype_code(block), ptr(out),
+                 stream_ptr())
         return out
 
     def shard_grad_dense(self, weight: torch.Tensor, ids: torch.Tensor, grad_rows: torch.Tensor) -> torch.Tensor:
@@ -117,21 +116,73 @@ class RoutePlan:
 _route_cache: List[tuple] = []      # [(key, idx kept alive, RoutePlan)]
 
 
-def _route_plan(idx: torch.Tensor, mod) -> "RoutePlan":
-    key = (idx.data_ptr(), idx._version, tuple(idx.shape), idx.dtype, mod.route_key)
-    for k, _, p in _route_cache:
-        if k == key:
-            return p
+class _PendingRoute:
+    """First half of a route plan (owner bucketing + count exchange), started early for the NEXT batch -- the way
+    a data loader prefetches -- so that the host-side read of the split sizes finds them already copied to pinned
+    memory and never stalls the launch queue behind the current step's work."""
+    __slots__ = ("send_ids", "send_pos", "inv_pos", "host_counts", "ready")
+
+
+def _route_key(idx, mod):
+    return (idx.data_ptr(), idx._version, tuple(idx.shape), idx.dtype, mod.route_key)
+
+
+_pending_routes: List[tuple] = []    # [(key, idx kept alive, _PendingRoute)]
+
+
+def _start_route(idx: torch.Tensor, mod) -> "_PendingRoute":
     ops, group, world = mod.ops, mod.group, mod.world
     counts, send_ids, send_pos, inv_pos = ops.bucket_by_owner(idx, mod.offsets, mod.rows_per_rank, world)
     recv_counts = torch.empty_like(counts)
     dist.all_to_all_single(recv_counts, counts, group=group)
+    pr = _PendingRoute()
+    pr.send_ids, pr.send_pos, pr.inv_pos = send_ids, send_pos, inv_pos
+    both = torch.stack([counts, recv_counts])
+    if both.is_cuda:
+        pr.host_counts = torch.empty(both.shape, dtype=both.dtype, pin_memory=True)
+        pr.host_counts.copy_(both, non_blocking=True)
+        pr.ready = torch.cuda.Event()
+        pr.ready.record()
+    else:
+        pr.host_counts, pr.ready = both, None
+    return pr
+
+
+def prefetch_route(idx: torch.Tensor, mod) -> None:
+    """Start routing ``idx`` (a batch that will be looked up soon) now; the next ``forward`` picks it up."""
+    idx = idx.rename(None) if idx.has_names() else idx
+    if idx.dtype not in (torch.int64, torch.int32):
+        idx = idx.long()
+    idx = idx.contiguous()
+    key = _route_key(idx, mod)
+    if any(k == key for k, _, _ in _pending_routes) or any(k == key for k, _, _ in _route_cache):
+        return
+    _pending_routes.append((key, idx, _start_route(idx, mod)))
+    if len(_pending_routes) > 2:
+        _pending_routes.pop(0)
+
+
+def _route_plan(idx: torch.Tensor, mod) -> "RoutePlan":
+    key = _route_key(idx, mod)
+    for k, _, p in _route_cache:
+        if k == key:
+            return p
+    pr = None
+    for i, (k, _, cand) in enumerate(_pending_routes):
+        if k == key:
+            pr = cand
+            _pending_routes.pop(i)
+            break
+    if pr is None:
+        pr = _start_route(idx, mod)
+    if pr.ready is not None:
+        pr.ready.synchronize()                 # waits for the tiny count copy only (long done when prefetched)
     p = RoutePlan()
-    p.send_splits = counts.tolist()            # host sync: split sizes are needed as Python ints
-    p.recv_splits = recv_counts.tolist()
-    p.send_pos, p.inv_pos = send_pos, inv_pos
+    p.send_splits = pr.host_counts[0].tolist()
+    p.recv_splits = pr.host_counts[1].tolist()
+    p.send_pos, p.inv_pos = pr.send_pos, pr.inv_pos
     p.recv_ids = torch.empty(sum(p.recv_splits), dtype=torch.int32, device=idx.device)
-    _all_to_all(p.recv_ids, send_ids, p.recv_splits, p.send_splits, group)
+    _all_to_all(p.recv_ids, pr.send_ids, p.recv_splits, p.send_splits, mod.group)
     _route_cache.append((key, idx, p))
     if len(_route_cache) > 2:
         _route_cache.pop(0)
@@ -227,6 +278,11 @@ class RowShardedMultiIndicesEmbedding(BaseInput):
             out = out.reshape(out.shape[0], 1, -1)
         out.names = ('B', 'N', 'E',)
         return out
+
+    def prefetch_route(self, next_inputs: torch.Tensor) -> None:
+        """Hint: ``next_inputs`` is the index batch of the NEXT step.  Owner bucketing and the count exchange start
+        now, so the next forward never blocks the host on the split sizes (see _PendingRoute)."""
+        prefetch_route(next_inputs, self)
 
     @torch.no_grad()
     def load_full_weight(self, full: torch.Tensor):
