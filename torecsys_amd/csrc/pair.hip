@@ -633,7 +633,7 @@ using namespace trs;
 
 extern "C" int trs_pair_dot_fwd(const void* x, int64_t B, int32_t N, int32_t E, int32_t dtype, void* out,
                                 trs_stream_t stream) {
-  if (B == 0) return TRS_OK;  // empty batch: nothing to do (pointers may be NULL)
+  if (B == 0 || N < 2) return TRS_OK;  // empty batch / no pairs: nothing to do (pointers may be NULL)
   TRS_REQUIRE(x && out, TRS_EINVAL, "pair_dot_fwd: NULL pointer");
   TRS_CHECK_BNE("pair_dot_fwd");
   if (B == 0 || N < 2) return TRS_OK;
@@ -645,9 +645,8 @@ extern "C" int trs_pair_dot_fwd(const void* x, int64_t B, int32_t N, int32_t E, 
 extern "C" int trs_pair_dot_bwd(const void* x, const void* g, int64_t B, int32_t N, int32_t E, int32_t dtype,
                                 void* dx, trs_stream_t stream) {
   if (B == 0) return TRS_OK;  // empty batch: nothing to do (pointers may be NULL)
-  TRS_REQUIRE(x && g && dx, TRS_EINVAL, "pair_dot_bwd: NULL pointer");
+  TRS_REQUIRE(x && dx && (g || N < 2), TRS_EINVAL, "pair_dot_bwd: NULL pointer");
   TRS_CHECK_BNE("pair_dot_bwd");
-  if (B == 0) return TRS_OK;
   if (N < 2) {
     if (hipMemsetAsync(dx, 0, (size_t)B * N * E * dtype_size(dtype), (hipStream_t)stream) != hipSuccess)
       return check_launch("pair_dot_bwd(memset)");
@@ -660,7 +659,7 @@ extern "C" int trs_pair_dot_bwd(const void* x, const void* g, int64_t B, int32_t
 
 extern "C" int trs_ffm_fwd(const void* x, int64_t B, int32_t N, int32_t E, int32_t dtype, void* out,
                            trs_stream_t stream) {
-  if (B == 0) return TRS_OK;  // empty batch: nothing to do (pointers may be NULL)
+  if (B == 0 || N < 2) return TRS_OK;  // empty batch / no pairs: nothing to do (pointers may be NULL)
   TRS_REQUIRE(x && out, TRS_EINVAL, "ffm_fwd: NULL pointer");
   TRS_CHECK_BNE("ffm_fwd");
   if (B == 0 || N < 2) return TRS_OK;
@@ -723,7 +722,7 @@ static int ffm_fused_dispatch(const void* const* tables, int64_t V, int E, int d
 extern "C" int trs_ffm_fused_fwd(const void* const* tables, int64_t V, int32_t E, int32_t dtype, const void* idx,
                                  int32_t idx_dtype, const int64_t* offsets, int64_t B, int32_t N, void* out,
                                  int32_t* err_flag, trs_stream_t stream) {
-  if (B == 0) return TRS_OK;  // empty batch: nothing to do (pointers may be NULL)
+  if (B == 0 || N < 2) return TRS_OK;  // empty batch / no pairs: nothing to do (pointers may be NULL)
   TRS_REQUIRE(tables && idx && out, TRS_EINVAL, "ffm_fused_fwd: NULL pointer");
   TRS_REQUIRE(V > 0, TRS_EINVAL, "ffm_fused_fwd: bad V");
   TRS_CHECK_BNE("ffm_fused_fwd");
