@@ -280,9 +280,7 @@ class _LinearSplitK(torch.autograd.Function):
             gx = (g2 @ weight).reshape(x.shape)
         if ctx.needs_input_grad[1]:
             rows, S = g2.shape[0], g2.shape[0] // _LinearSplitK.SPLIT_ROWS
-            if g2.shape[1] == 1 and x2.is_contiguous():
-                gw = torch.mv(x2.t(), g2.reshape(-1)).view(1, -1)        # rank-1 output: a GEMV, not a GEMM
-            elif S >= 4 and rows % S == 0 and 32 <= g2.shape[1] <= 1024 and 32 <= x2.shape[1] <= 1024 \
+            if S >= 4 and rows % S == 0 and 32 <= g2.shape[1] <= 1024 and 32 <= x2.shape[1] <= 1024 \
                     and g2.is_contiguous() and x2.is_contiguous():
                 part = torch.bmm(g2.view(S, rows // S, -1).transpose(1, 2), x2.view(S, rows // S, -1),
                                  out_dtype=torch.float32)
