@@ -288,7 +288,13 @@ class _LinearSplitK(torch.autograd.Function):
             else:
                 gw = g2.t() @ x2
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g2.sum(0)
+            rows = g2.shape[0]
+            if g2.shape[1] <= 8 and rows % 1024 == 0 and rows >= 8192 and g2.is_contiguous():
+                # a (rows x 1) column summed to one value is a single-workgroup reduction in ATen (60 us at 65 536
+                # rows); two stages keep the whole chip busy
+                gb = g2.view(rows // 1024, 1024, -1).float().sum(1).sum(0).to(g2.dtype)
+            else:
+                gb = g2.sum(0)
         return gx, gw, gb
 
 
