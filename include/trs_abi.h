@@ -220,6 +220,14 @@ size_t trs_cin_dw_workspace_bytes(int64_t B, int32_t N, int32_t H, int32_t C);
 int trs_cin_dw(const void* gy, const void* x0, const void* xk, int64_t B, int32_t N, int32_t H, int32_t C,
                int32_t E, int32_t dtype, float* dW, void* workspace, size_t ws_bytes, trs_stream_t stream);
 
+/* ---- MLP backward epilogue (the GEMMs stay on hipBLASLt) -----------------------------------------------
+ * y = relu(linear(x)):  gz = gy * (y > 0) and gb[c] = sum_r gz[r,c] (fp32) in ONE pass over (rows, C) instead of
+ * ATen's threshold_backward + column sum.  C*sizeof(T) must be a multiple of 16 and <= 4096.
+ * layers/ctr/multilayer_perceptron.py:53-61 (Linear_i / Activation_i pairs).                                 */
+size_t trs_relu_bwd_bias_workspace_bytes(int64_t rows, int32_t C);
+int trs_relu_bwd_bias(const void* gy, const void* y, int64_t rows, int32_t C, int32_t dtype, void* gz,
+                      float* gb, void* workspace, size_t ws_bytes, trs_stream_t stream);
+
 /* ---- row-sharded tables (multi-GPU lookup) -----------------------------
  * Bucket the B*N global row ids of the local batch by owner rank (owner = id / rows_per_rank):
  *   counts[w]  = number of ids owned by rank w                                  (W int64)

@@ -718,3 +718,25 @@ def ffm_fused(weights: Sequence[torch.Tensor], idx: torch.Tensor, offsets: torch
     """(B,N) indices + N field-aware tables -> (B, N(N-1)/2, E) pair products; (B,N*N,E) is never materialised."""
     idx = _as_index(idx)
     return _FFMFused.apply(idx, offsets, *weights)
+
+
+# --------------------------------------------------------------------------------------------
+# MLP backward epilogue: relu backward + bias gradient in one pass (GEMMs stay on hipBLASLt)
+# --------------------------------------------------------------------------------------------
+def relu_bwd_bias_supported(y: torch.Tensor) -> bool:
+    row_bytes = y.shape[-1] * y.element_size()
+    return (y.is_cuda and y.dtype in (torch.float32, torch.bfloat16) and y.is_contiguous()
+            and row_bytes % 16 == 0 and row_bytes <= 4096)
+
+
+def relu_bwd_bias(gy: torch.Tensor, y: torch.Tensor):
+    """gz = gy * (y > 0), gb = gz.sum(0) (fp32) for y = relu(...) of shape (rows, C)."""
+    rows, C = y.shape
+    gy = gy.contiguous()
+    gz = torch.empty_like(gy)
+    gb = torch.empty(C, dtype=torch.float32, device=y.device)
+    ws_bytes = size_query("trs_relu_bwd_bias_workspace_bytes", rows, C)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=y.device)
+    call("trs_relu_bwd_bias", ptr(gy), ptr(y), rows, C, value_dtype_code(y), ptr(gz), ptr(gb), ptr(ws), ws_bytes,
+         stream_ptr())
+    return gz, gb

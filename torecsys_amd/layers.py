@@ -265,17 +265,32 @@ class _LinearSplitK(torch.autograd.Function):
     SPLIT_ROWS = 2048
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
+    def forward(ctx, x, weight, bias, fuse_relu):
+        y = torch.nn.functional.linear(x, weight, bias)
         ctx.has_bias = bias is not None
-        return torch.nn.functional.linear(x, weight, bias)
+        ctx.fuse_relu = bool(fuse_relu) and bias is not None and F_.relu_bwd_bias_supported(y.reshape(-1, y.shape[-1]))
+        if fuse_relu:
+            y = torch.relu_(y)
+        if ctx.fuse_relu:
+            ctx.save_for_backward(x, weight, y)          # relu output: its sign pattern is the backward mask
+        else:
+            ctx.save_for_backward(x, weight, y if fuse_relu else None)
+        ctx.relu = bool(fuse_relu)
+        return y
 
     @staticmethod
     def backward(ctx, g):
-        x, weight = ctx.saved_tensors
+        x, weight, y = ctx.saved_tensors
+        gx = gw = gb = None
+        if ctx.fuse_relu:
+            # one HIP pass: relu backward + bias gradient (ATen: threshold_backward, then a column sum re-reading it)
+            gz, gbf = F_.relu_bwd_bias(g.reshape(-1, g.shape[-1]), y.reshape(-1, y.shape[-1]))
+            g = gz.reshape(g.shape)
+            gb = gbf.to(weight.dtype)
+        elif ctx.relu:
+            g = g * (y > 0).to(g.dtype)
         g2 = g.reshape(-1, g.shape[-1])
         x2 = x.reshape(-1, x.shape[-1])
-        gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = (g2 @ weight).reshape(x.shape)
         if ctx.needs_input_grad[1]:
@@ -287,7 +302,7 @@ class _LinearSplitK(torch.autograd.Function):
                 gw = part.sum(0).to(weight.dtype)
             else:
                 gw = g2.t() @ x2
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if ctx.has_bias and ctx.needs_input_grad[2] and gb is None:
             rows = g2.shape[0]
             if g2.shape[1] <= 8 and rows % 1024 == 0 and rows >= 8192 and g2.is_contiguous():
                 # a (rows x 1) column summed to one value is a single-workgroup reduction in ATen (60 us at 65 536
@@ -295,7 +310,7 @@ class _LinearSplitK(torch.autograd.Function):
                 gb = g2.view(rows // 1024, 1024, -1).float().sum(1).sum(0).to(g2.dtype)
             else:
                 gb = g2.sum(0)
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
 class MultilayerPerceptionLayer(BaseLayer):
@@ -330,11 +345,18 @@ class MultilayerPerceptionLayer(BaseLayer):
     def forward(self, emb_inputs: torch.Tensor) -> torch.Tensor:
         outputs = _strip(emb_inputs)
         split_k = outputs.is_cuda and outputs.dtype in (torch.bfloat16, torch.float16) and torch.is_grad_enabled()
-        for mod in self.model:
+        mods = list(self.model)
+        i = 0
+        while i < len(mods):
+            mod = mods[i]
             if split_k and isinstance(mod, nn.Linear):
-                outputs = _LinearSplitK.apply(outputs, mod.weight, mod.bias)
+                # Linear followed by a plain nn.ReLU: the activation and its backward are folded into the Function
+                fuse = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
+                outputs = _LinearSplitK.apply(outputs, mod.weight, mod.bias, fuse)
+                i += 2 if fuse else 1
             else:
                 outputs = mod(outputs)
+                i += 1
         if outputs.dim() == 2:
             outputs.names = ('B', 'O',)
         elif outputs.dim() == 3:
