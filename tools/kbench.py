@@ -136,6 +136,17 @@ def main():
             ins = (x0r, Wr) if H == N else (x0r, xkr, Wr)
             t = timeit(lambda: torch.autograd.grad(yT, ins, gy, retain_graph=True), iters=3, warm=1)
             print(f"cin_cl_bwd (data+dW+transposes): med {t[0]*1e3:.3f} ms  {2*fl/t[0]/1e12:.1f} TFLOP/s", flush=True)
+    if want("mlp"):
+        C = 400
+        gy = torch.randn(B, C, generator=g).to(dt).to(dev)
+        yy = torch.relu(torch.randn(B, C, generator=g)).to(dt).to(dev)
+        t = timeit(lambda: F_.relu_bwd_bias(gy, yy))
+        report("relu_bwd_bias (fused)", t, 3 * B * C * s)
+        def aten():
+            gz = torch.ops.aten.threshold_backward(gy, yy, 0)
+            return gz, gz.sum(0)
+        t = timeit(aten)
+        report("ATen threshold_backward + sum", t, 4 * B * C * s)
     if want("copy"):
         x = torch.empty(512 * 1024 * 1024 // 4, dtype=torch.float32, device=dev)
         y = torch.empty_like(x)

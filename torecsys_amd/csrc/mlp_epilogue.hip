@@ -25,16 +25,34 @@ __global__ __launch_bounds__(RB_THREADS) void relu_bwd_bias_kernel(const uint4* 
 #pragma unroll
   for (int k = 0; k < VE; ++k) acc[k] = 0.f;
   if (rl < rstep) {
-    for (int64_t r = r0 + rl; r < r1; r += rstep) {
-      float g[VE], a[VE];
-      Vec16<T>::unpack(gy[r * vpr + cv], g);
-      Vec16<T>::unpack(y[r * vpr + cv], a);
+    constexpr int U = 4;   // independent row loads in flight per thread
+    for (int64_t rb = r0 + rl; rb < r1; rb += (int64_t)rstep * U) {
+      uint4 gv[U], yv[U];
 #pragma unroll
-      for (int k = 0; k < VE; ++k) {
-        g[k] = a[k] > 0.f ? g[k] : 0.f;
-        acc[k] += g[k];
+      for (int u = 0; u < U; ++u) {
+        const int64_t r = rb + (int64_t)u * rstep;
+        gv[u] = make_uint4(0, 0, 0, 0);
+        yv[u] = make_uint4(0, 0, 0, 0);
+        if (r < r1) {
+          gv[u] = gy[r * vpr + cv];
+          yv[u] = y[r * vpr + cv];
+        }
       }
-      gz[r * vpr + cv] = Vec16<T>::pack(g);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t r = rb + (int64_t)u * rstep;
+        if (r < r1) {
+          float g[VE], a[VE];
+          Vec16<T>::unpack(gv[u], g);
+          Vec16<T>::unpack(yv[u], a);
+#pragma unroll
+          for (int k = 0; k < VE; ++k) {
+            g[k] = a[k] > 0.f ? g[k] : 0.f;
+            acc[k] += g[k];
+          }
+          gz[r * vpr + cv] = Vec16<T>::pack(g);
+        }
+      }
     }
   }
 #pragma unroll
@@ -50,13 +68,32 @@ __global__ __launch_bounds__(RB_THREADS) void relu_bwd_bias_kernel(const uint4* 
   }
 }
 
+// out[c] = sum over bands of part[band][c]: 16 band lanes x 16 columns per workgroup, 8 loads in flight per thread
 __global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ part, int nbands, int C,
                                                               float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, bl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float s = 0.f;
   if (c < C) {
-    float s = 0.f;
-    for (int b = 0; b < nbands; ++b) s += part[(size_t)b * C + c];
-    out[c] = s;
+    for (int b0 = bl; b0 < nbands; b0 += 16 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int b = b0 + 16 * u;
+        v[u] = b < nbands ? part[(size_t)b * C + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+  }
+  red[bl][cl] = s;
+  __syncthreads();
+  if (bl == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += red[j][cl];
+    out[c] = t;
   }
 }
 
@@ -66,7 +103,7 @@ using namespace trs;
 
 extern "C" size_t trs_relu_bwd_bias_workspace_bytes(int64_t rows, int32_t C) {
   (void)rows;
-  return (size_t)512 * C * 4 + 256;
+  return (size_t)2048 * C * 4 + 256;
 }
 
 extern "C" int trs_relu_bwd_bias(const void* gy, const void* y, int64_t rows, int32_t C, int32_t dtype, void* gz,
@@ -85,7 +122,7 @@ extern "C" int trs_relu_bwd_bias(const void* gy, const void* y, int64_t rows, in
   TRS_REQUIRE(gy && y && gz, TRS_EINVAL, "relu_bwd_bias: NULL pointer");
   TRS_REQUIRE(aligned16(gy) && aligned16(y) && aligned16(gz), TRS_EALIGN, "relu_bwd_bias: 16-byte alignment");
   const int vpr = row_bytes / 16;
-  int nbands = (int)std::min<int64_t>(512, (rows + 63) / 64);
+  int nbands = (int)std::min<int64_t>(2048, (rows + 31) / 32);
   const int rows_per_band = (int)((rows + nbands - 1) / nbands);
   nbands = (int)((rows + rows_per_band - 1) / rows_per_band);
   TRS_REQUIRE(ws_bytes >= (size_t)nbands * C * 4, TRS_EWORKSPACE, "relu_bwd_bias: workspace too small");
@@ -96,6 +133,6 @@ extern "C" int trs_relu_bwd_bias(const void* gy, const void* y, int64_t rows, in
   else
     hipLaunchKernelGGL((relu_bwd_bias_kernel<bf16_t>), dim3(nbands), dim3(RB_THREADS), 0, s, (const uint4*)gy,
                        (const uint4*)y, (uint4*)gz, part, rows, vpr, rows_per_band);
-  hipLaunchKernelGGL(colsum_partials_kernel, dim3((C + 255) / 256), dim3(256), 0, s, part, nbands, C, gb);
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3((C + 15) / 16), dim3(256), 0, s, part, nbands, C, gb);
   return check_launch("relu_bwd_bias");
 }
