@@ -229,11 +229,15 @@ typedef __attribute__((ext_vector_type(4))) float pd_f32x4;
 template <int NT, int KS>
 __global__ __launch_bounds__(256) void pair_dot_fwd_mfma_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out,
                                                                 int64_t B, int N, int E) {
-  const int lane = threadIdx.x & 63, q = lane >> 4, r = lane & 15;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, r = lane & 15;
   const int P = N * (N - 1) / 2;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  // per-wave staging of one sample's pair slots: the D tiles scatter 2-byte results (issue-bound as direct
+  // global stores: 70 % of wave cycles in issue stalls); from LDS the row leaves as P/64 coalesced stores
+  unsigned short* O = reinterpret_cast<unsigned short*>(smem) + (size_t)wave * ((P + 7) & ~7);
+  const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t b = wave; b < B; b += nwaves) {
+  for (int64_t b = wid; b < B; b += nwaves) {
     uint4 F[NT][KS];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -243,7 +247,6 @@ __global__ __launch_bounds__(256) void pair_dot_fwd_mfma_kernel(const bf16_t* __
         F[t][ks] = make_uint4(0, 0, 0, 0);
         if (row < N) F[t][ks] = *reinterpret_cast<const uint4*>(x + (b * N + row) * (int64_t)E + 32 * ks + 8 * q);
       }
-    bf16_t* o = out + b * P;
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
@@ -257,9 +260,13 @@ __global__ __launch_bounds__(256) void pair_dot_fwd_mfma_kernel(const bf16_t* __
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int i = 16 * ti + 4 * q + k;
-          if (i < j && j < N) o[pair_index(i, j, N)] = from_f32<bf16_t>(acc[k]);
+          if (i < j && j < N) O[pair_index(i, j, N)] = from_f32<bf16_t>(acc[k]).v;
         }
       }
+    __builtin_amdgcn_wave_barrier();
+    unsigned short* o = reinterpret_cast<unsigned short*>(out + b * P);
+    for (int k = lane; k < P; k += 64) o[k] = O[k];
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -287,17 +294,15 @@ __global__ __launch_bounds__(256) void pair_dot_bwd_mfma_kernel(const bf16_t* __
     const int base = pair_index(i, i + 1, N);
     for (int j = i + 1; j < N; ++j) lut[base + (j - i - 1)] = (unsigned short)((i << 8) | j);
   }
-  const int64_t bstride = (int64_t)gridDim.x * 4;
-  for (int64_t b0 = (int64_t)blockIdx.x * 4; b0 < B; b0 += bstride) {
-    const int64_t b = b0 + wave;
-    __syncthreads();
-    if (b < B) {
-      // zero Gs (diagonal + padding), X rows >= N
-      for (int v = lane; v < (NP * GS) / 8; v += 64) reinterpret_cast<uint4*>(Gs)[v] = make_uint4(0, 0, 0, 0);
-      for (int v = lane; v < (NPK * XS) / 8; v += 64) reinterpret_cast<uint4*>(Xs)[v] = make_uint4(0, 0, 0, 0);
-    }
-    __syncthreads();
-    if (b < B) {
+  // Gs / Xs belong to this wave alone.  Zero them once: the diagonal of Gs, its padding and the X rows >= N are
+  // never written afterwards, every other entry is overwritten for each sample.
+  for (int v = lane; v < (NP * GS) / 8; v += 64) reinterpret_cast<uint4*>(Gs)[v] = make_uint4(0, 0, 0, 0);
+  for (int v = lane; v < (NPK * XS) / 8; v += 64) reinterpret_cast<uint4*>(Xs)[v] = make_uint4(0, 0, 0, 0);
+  __syncthreads();   // lut complete (block-wide), zero fill visible
+  const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t b = wid; b < B; b += nwaves) {
+    {
       const bf16_t* gb = g + b * P;
       for (int p0 = lane; p0 < P; p0 += 256) {              // 4 independent coalesced loads in flight per lane
         unsigned short v[4], ij[4];
@@ -322,8 +327,8 @@ __global__ __launch_bounds__(256) void pair_dot_bwd_mfma_kernel(const bf16_t* __
             *reinterpret_cast<const uint4*>(x + (b * N + row) * (int64_t)E + 8 * c8);
       }
     }
-    __syncthreads();
-    if (b < B) {
+    __builtin_amdgcn_wave_barrier();
+    {
 #pragma unroll
       for (int te = 0; te < KE; ++te) {
         uint4 Bf[KJ];
@@ -354,6 +359,7 @@ __global__ __launch_bounds__(256) void pair_dot_bwd_mfma_kernel(const bf16_t* __
         }
       }
     }
+    __builtin_amdgcn_wave_barrier();   // the next sample overwrites Gs / Xs
   }
 }
 
@@ -362,8 +368,9 @@ static bool pair_mfma_ok(int N, int E) { return N >= 2 && N <= 64 && (E == 32 ||
 static int pair_dot_fwd_mfma(const void* x, void* out, int64_t B, int N, int E, hipStream_t s) {
   const int NT = (N + 15) / 16, KS = E / 32;
   const int grid = (int)std::min<int64_t>((B + 3) / 4, 256 * 8);
+  const size_t lds_f = (size_t)4 * (((N * (N - 1) / 2) + 7) & ~7) * 2;
 #define TRS_PF(NT_, KS_)                                                                                      \
-  hipLaunchKernelGGL((pair_dot_fwd_mfma_kernel<NT_, KS_>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x,      \
+  hipLaunchKernelGGL((pair_dot_fwd_mfma_kernel<NT_, KS_>), dim3(grid), dim3(256), lds_f, s, (const bf16_t*)x,  \
                      (bf16_t*)out, B, N, E)
 #define TRS_PF_K(NT_)               \
   do {                              \
