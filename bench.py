@@ -71,6 +71,8 @@ def parse():
                          "all-to-all of one overlaps the dense compute of the other (default 1: measured slower on "
                          "one GPU -- per-micro-batch host syncs and sparse-gradient accumulation outweigh the overlap)")
     ap.add_argument("--cpu-batch", type=int, default=16384)
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the step (forward+backward[+optimizer]) in a hipGraph and replay it; single-GPU path")
     return ap.parse_args()
 
 
@@ -266,16 +268,40 @@ def main():
         return loss
 
     roof_kernel = "trs_embed_fm" if not a.no_fuse else "trs_gather_rows"
-    for _ in range(a.warmup):
-        step()
+    use_graph = a.graph and world == 1 and MB == 1 and not sharded and a.optimizer in ("none", "sgd")
+    eager_step = step
+    for _ in range(a.warmup if not use_graph else max(3, a.warmup // 2)):
+        eager_step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     _abi.time_kernel(roof_kernel, True)
+    if use_graph:
+        from torecsys_amd.graph import GraphedStep
+
+        def graph_fn(ix, lab):
+            l_ = fwd_loss(ix, lab, 1.0)
+            l_.backward()
+            if dense_opt is not None:
+                dense_opt.step()
+            return l_
+
+        # the roofline kernel is bracketed by two captured device-timestamp marks (one sample per replay)
+        gstep = GraphedStep(graph_fn, (idx_ring[0], label_ring[0]), params=params, warmup=1)
+
+        def step():
+            k = counter[0] % RING
+            counter[0] += 1
+            return gstep(idx_ring[k], label_ring[k])      # copies the batch into the static buffers, replays
+
+        for _ in range(a.warmup):
+            step()
+        _abi.kernel_times_ms(roof_kernel)      # drop the warm-up samples
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for i in range(a.steps):
         loss = step()
+    enqueue_s = time.perf_counter() - t0      # host time to enqueue K steps (== el when the host is the bound)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -323,8 +349,9 @@ def main():
                        ("BASELINE.json configs[4] (weak-scaled): DeepFM, " f"{V} rows row-sharded over {world} GPUs, "
                         f"global batch {B * world}"),
                        "model": a.model, "global_batch": B * world, "rows": V, "parallelism": parallelism,
-                       "microbatches": MB, "optimizer": a.optimizer,
-                       "fused_lookup_fm": not a.no_fuse, "loss": float(loss)},
+                       "microbatches": MB, "optimizer": a.optimizer, "hipgraph": bool(use_graph),
+                       "fused_lookup_fm": not a.no_fuse, "loss": float(loss),
+                       "host_enqueue_ms_per_step": round(enqueue_s / a.steps * 1e3, 4)},
             "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -49,6 +49,15 @@ typedef void* trs_stream_t; /* hipStream_t */
 int trs_version(void);
 const char* trs_last_error_string(void);
 
+/* ---- diagnostics: device-side timestamps that survive hipGraph replay -----------------------
+ * Enqueues a one-lane kernel that appends the device wall clock (constant rate, trs_wall_clock_khz())
+ * to a ring in device memory:  i = ring[0]++;  ring[1 + i % capacity] = wall_clock64().
+ * Two marks bracketing a launch on the same stream measure it like a HIP event pair does, but each
+ * replay of a captured graph appends a new sample (a captured event pair only keeps the last one).
+ * ring: capacity+1 uint64, zero-initialised by the caller.  No reference counterpart (measurement only). */
+int trs_mark_timestamp(uint64_t* ring, int32_t capacity, trs_stream_t stream);
+int64_t trs_wall_clock_khz(void);
+
 /* ---- K1: row gather ---------------------------------------------------------------------
  * out[b,n,:] = table[idx[b,n] + offsets[n], :]            (bit-exact copy)
  * replaces aten::add + aten::embedding in

@@ -1,0 +1,100 @@
+"""hipGraph capture of a whole step (torecsys_amd.graph.GraphedStep): replayed steps must reproduce eager steps
+(forward bit for bit; gradients up to the summation order inside a row bucket, which the bucket build does not fix),
+and the device-timestamp marks that time a kernel inside a graph must agree with HIP events."""
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _deepfm(dev, dt, N, E, sizes):
+    from torecsys_amd.inputs import Inputs, MultiIndicesEmbedding
+    from torecsys_amd import models as M
+    torch.manual_seed(3)
+    emb = MultiIndicesEmbedding(embed_size=E, field_sizes=sizes, fuse_fm=True)
+    feat = MultiIndicesEmbedding(embed_size=1, field_sizes=sizes)
+    emb.set_schema(["c0"]); feat.set_schema(["c0"])
+    inputs = Inputs(schema={"emb_inputs": emb, "feat_inputs": feat}).to(dev).to(dt)
+    model = M.DeepFactorizationMachineModel(E, N, [64, 32], fm_dropout_p=0.0).to(dev).to(dt)
+    return inputs, model, emb, feat
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_graphed_step_matches_eager(dev, dt):
+    from torecsys_amd.graph import GraphedStep
+    B, N, E = 512, 7, 32
+    sizes = [50, 3, 1000, 17, 400, 9, 121]
+    inputs, model, emb, feat = _deepfm(dev, dt, N, E, sizes)
+    params = list(inputs.parameters()) + list(model.parameters())
+    g = torch.Generator().manual_seed(0)
+    batches = [(torch.stack([torch.randint(0, s, (B,), generator=g) for s in sizes], 1).to(dev),
+                (torch.rand(B, 1, generator=g) < 0.3).float().to(dev)) for _ in range(3)]
+    crit = torch.nn.BCEWithLogitsLoss()
+
+    def fn(ix, lab):
+        loss = crit(model(**inputs({"c0": ix})).float(), lab)
+        loss.backward()
+        return loss
+
+    eager = []
+    for ix, lab in batches:
+        for p in params:
+            p.grad = None
+        loss = fn(ix, lab)
+        eager.append((loss.detach().clone(), emb.embedding.weight.grad.clone(), feat.embedding.weight.grad.clone(),
+                      model.deep.model.Linear_0.weight.grad.clone()))
+    del loss        # a live autograd graph of an eager step pins the AccumulateGrad nodes to the eager stream
+    step = GraphedStep(fn, batches[0], params=params, warmup=2)
+    for (ix, lab), (l0, ge, gf, gw) in zip(batches, eager):
+        loss = step(ix, lab)
+        torch.cuda.synchronize()
+        assert torch.equal(loss.detach(), l0)
+        tol = 1e-5 if dt == torch.float32 else 1e-2      # the path's fp32 / bf16 tolerances (summation order)
+        assert rel_err(emb.embedding.weight.grad.float().cpu(), ge.float().cpu()) <= tol
+        assert rel_err(feat.embedding.weight.grad.float().cpu(), gf.float().cpu()) <= tol
+        assert rel_err(model.deep.model.Linear_0.weight.grad.float().cpu(), gw.float().cpu()) <= tol
+    with pytest.raises(ValueError):
+        step(batches[0][0][:10], batches[0][1][:10])
+
+
+def test_timestamp_marks_agree_with_events(dev):
+    """_abi.time_kernel: HIP events in eager mode, trs_mark_timestamp pairs inside a capture."""
+    from torecsys_amd import _abi
+    from torecsys_amd import functional as F_
+    B, N, E, V = 32768, 39, 64, 200_000
+    w = torch.randn(V, E, device=dev, dtype=torch.bfloat16)
+    idx = torch.randint(0, V // N, (B, N), device=dev)
+    off = (torch.arange(N, device=dev) * (V // N))
+    assert _abi.size_query("trs_wall_clock_khz") > 0
+
+    def launch():
+        return F_.embed_fm(w, idx, off)
+
+    for _ in range(3):
+        launch()
+    _abi.time_kernel("trs_embed_fm", True)
+    try:
+        for _ in range(5):
+            launch()
+        ev = _abi.kernel_times_ms("trs_embed_fm")
+        assert len(ev) == 5
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            out = launch()
+        for _ in range(5):
+            gr.replay()
+        mk = _abi.kernel_times_ms("trs_embed_fm")
+        assert len(mk) == 5
+    finally:
+        _abi.time_kernel("trs_embed_fm", False)
+    a, b = sorted(ev)[2], sorted(mk)[2]
+    assert 0.5 * a <= b <= 1.5 * a + 0.01, (ev, mk)
+    assert out[0].shape == (B, N, E)

@@ -1,8 +1,8 @@
 """Developer tool: torch.profiler table of one DeepFM bench step (which ATen ops own the non-GEMM kernels)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench
-sys.argv = ["bench.py", "--steps", "3", "--warmup", "3", "--no-cpu-baseline", "--no-tunableop"]
+import bench  # noqa: E402  (bench sets the TunableOp env before torch loads; pass --no-tunableop to skip)
+sys.argv = ["bench.py", "--steps", "3", "--warmup", "3", "--no-cpu-baseline"] + sys.argv[1:]
 from torch.profiler import profile, ProfilerActivity
 import torch.nn as nn
 a = bench.parse()

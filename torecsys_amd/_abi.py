@@ -25,6 +25,8 @@ _P, _I32, _I64, _SZ = c_void_p, c_int32, c_int64, c_size_t
 SIGNATURES = {
     "trs_version": (c_int32, []),
     "trs_last_error_string": (c_char_p, []),
+    "trs_mark_timestamp": (c_int32, [_P, _I32, _P]),
+    "trs_wall_clock_khz": (_I64, []),
     "trs_gather_rows": (c_int32, [_P, _I64, _I32, _I32, _P, _I32, _P, _I64, _I32, _P, _P, _P]),
     "trs_fa_gather_rows": (c_int32, [_P, _I64, _I32, _I32, _P, _I32, _P, _I64, _I32, _P, _P, _P]),
     "trs_csr_workspace_bytes": (_SZ, [_I64, _I64]),
@@ -102,20 +104,91 @@ def last_error() -> str:
 _timed = {}
 
 
+_hip = None
+
+
+def _hiprt():
+    """The HIP runtime torch already loaded (same SONAME), for the event calls of the timing hook."""
+    global _hip
+    if _hip is None:
+        try:
+            _hip = ctypes.CDLL("libamdhip64.so.7")       # resolves to the already loaded object by SONAME
+        except OSError:
+            _hip = ctypes.CDLL("libamdhip64.so")
+        _hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        _hip.hipEventRecordWithFlags.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]
+        _hip.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        _hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+        _hip.hipEventDestroy.argtypes = [ctypes.c_void_p]
+    return _hip
+
+
+class _HipEvent:
+    def __init__(self):
+        self.h = ctypes.c_void_p()
+        if _hiprt().hipEventCreate(ctypes.byref(self.h)) != 0:
+            raise RuntimeError("hipEventCreate failed")
+
+    def record(self, stream, external):
+        rt = _hiprt()
+        rc = rt.hipEventRecordWithFlags(self.h, stream, 1) if external else rt.hipEventRecord(self.h, stream)
+        if rc != 0:
+            raise RuntimeError(f"hipEventRecord{'WithFlags(external)' if external else ''} failed (hipError {rc})")
+
+    def elapsed_time(self, other) -> float:
+        ms = ctypes.c_float()
+        rc = _hiprt().hipEventElapsedTime(ctypes.byref(ms), self.h, other.h)
+        if rc != 0:
+            raise RuntimeError(f"hipEventElapsedTime failed ({rc})")
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            _hip.hipEventDestroy(self.h)
+        except Exception:
+            pass
+
+
+_MARK_CAP = 4096          # timestamp ring entries (two per timed launch)
+_rings = {}
+
+
+def _mark_ring(name: str) -> torch.Tensor:
+    r = _rings.get(name)
+    if r is None:
+        # allocated outside any capture pool (is_current_stream_capturing() callers create it before capturing)
+        raise RuntimeError(f"time_kernel({name!r}) must be enabled before the capture starts")
+    return r
+
+
 def time_kernel(name: str, enable: bool = True):
-    """Bracket every launch of entry point ``name`` with HIP events (bench.py's live roofline)."""
+    """Bracket every launch of entry point ``name`` with HIP events (bench.py's live roofline); launches captured
+    into a hipGraph are bracketed with device-side timestamp marks instead (see trs_mark_timestamp)."""
     if enable:
         _timed[name] = []
+        _rings[name] = torch.zeros(_MARK_CAP + 1, dtype=torch.int64, device="cuda")
     else:
         _timed.pop(name, None)
+        _rings.pop(name, None)
 
 
 def kernel_times_ms(name: str):
-    """Elapsed milliseconds of every recorded launch of ``name`` (synchronises), and clears the list."""
+    """Elapsed milliseconds of every recorded launch of ``name`` (synchronises), and clears the records: HIP event
+    pairs of eager launches followed by the timestamp-mark pairs of graph replays."""
     torch.cuda.synchronize()
     ev = _timed.get(name, [])
     out = [a.elapsed_time(b) for a, b in ev]
     ev.clear()
+    ring = _rings.get(name)
+    if ring is not None:
+        host = ring.cpu()
+        n = int(host[0])
+        if n > _MARK_CAP:
+            n = 0       # wrapped: pairs can no longer be told apart
+        khz = float(load().trs_wall_clock_khz())
+        if khz > 0:
+            out += [float(host[2 + 2 * j] - host[1 + 2 * j]) / khz for j in range(n // 2)]
+        ring.zero_()
     return out
 
 
@@ -123,12 +196,21 @@ def call(name: str, *args):
     """Call an int-returning entry point; raise RuntimeError with the library's message on failure."""
     rec = _timed.get(name)
     if rec is not None:
-        a = torch.cuda.Event(enable_timing=True)
-        b = torch.cuda.Event(enable_timing=True)
-        a.record()
-        rc = getattr(load(), name)(*args)
-        b.record()
-        rec.append((a, b))
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if torch.cuda.is_current_stream_capturing():
+            # a captured event pair keeps only the latest replay (and ROCm refuses external event records in a
+            # capture): bracket the launch with two device-side timestamp marks instead; each replay appends a sample
+            ring = _mark_ring(name)
+            lib = load()
+            lib.trs_mark_timestamp(ctypes.c_void_p(ring.data_ptr()), _MARK_CAP, st)
+            rc = getattr(lib, name)(*args)
+            lib.trs_mark_timestamp(ctypes.c_void_p(ring.data_ptr()), _MARK_CAP, st)
+        else:
+            a, b = _HipEvent(), _HipEvent()
+            a.record(st, 0)
+            rc = getattr(load(), name)(*args)
+            b.record(st, 0)
+            rec.append((a, b))
     else:
         rc = getattr(load(), name)(*args)
     if rc != 0:

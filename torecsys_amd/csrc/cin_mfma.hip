@@ -483,80 +483,93 @@ int cin_cl_bwd_data(const void* x0T, int ld0, const void* xkT, int ldk, const vo
 // backward, weight gradient (channels-FIRST operands: the contraction runs over pixels, so pixels must be
 // the contiguous K axis):   dW[c,(n,h)] = sum_{b,e} gy[b,c,e] * x0[b,n,e] * xk[b,h,e]
 // GEMM view per field n:  dW_n (C x H) = (gy .* x0_n) (C x pixels) * xk^T (pixels x H).
-// Workgroup = 8 waves owns NG = 2 fields x all C x HB h-tiles and streams a range of samples; per sample the
-// gy tile (C x E) and the xk tile (16*HB x E) are staged once in LDS (rows padded to E*2+16 bytes:
-// conflict-free ds_read_b128) and shared by all waves; wave w = (field w>>2, channel quarter w&3) scales its
-// gy fragments by x0[n] (8 mul + 4 cvt per fragment, reused for HB MFMAs) and accumulates CTW x HB 16x16
-// tiles in registers over the whole sample range.  Partial sums per sample-split go to a workspace and are
-// reduced by a second kernel (no float atomics).
-constexpr int DW_NG = 2;      // fields per workgroup
+// Workgroup = 8 waves owns a (NG = 8 fields) x (CB channels) x (16*HW*WH h) block of dW and streams a range of
+// samples.  Per sample the gy tile (CB x E), the xk tile and the 8 x0 rows are staged once in LDS (rows padded to
+// E*2+16 bytes: conflict-free ds_read_b128).  Wave w = (field quad w&1, channel pair (w>>1)%CW, h part) owns
+// 4 fields x 2 c-tiles x HW h-tiles = up to 32 accumulator tiles: a gy fragment read from LDS is scaled by four
+// x0 rows (one A operand per field) and every A operand is used for HW MFMAs, so a wave reads 2+HW fragments
+// from LDS per 8*HW MFMAs and the block pulls (CB + 16*HW*WH + 8) rows from L2 per 64*HW MFMAs per wave --
+// half the L2 bytes per flop of a 2-field x all-C tiling, which is what bounds this kernel.
+// Partial sums per sample-split go to a workspace and are reduced by a second kernel (no float atomics).
+constexpr int DW_NG = 8;      // fields per workgroup
+constexpr int DW_NW = 4;      // fields per wave
 constexpr int DW_WAVES = 8;
 
-template <int CTW /* c tiles per wave: C = 64*CTW */, int HB /* h tiles per block */, int KE /* E/32 */>
+template <int WH /* waves along h: 1 -> CB = 128, 2 -> CB = 64 */, int HW /* h tiles per wave */, int KE /* E/32 */>
 __global__ __launch_bounds__(512) void cin_dw_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x0,
                                                      const bf16_t* __restrict__ xk, float* __restrict__ dWpart,
-                                                     int64_t B, int N, int H, int nsplit) {
-  constexpr int C = 64 * CTW;
+                                                     int64_t B, int N, int H, int C, int nsplit) {
+  constexpr int CW = 4 / WH;                // waves along c
+  constexpr int CB = 32 * CW;               // channels per block
+  constexpr int HBK = 16 * HW * WH;         // h per block
   constexpr int E = 32 * KE;
   constexpr int RS = E * 2 + 16;            // padded row stride in bytes
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // [2 buffers] x { gy_s [C][RS] | xk_s [16*HB][RS] | x0_s [DW_NG][RS] }
-  constexpr int BUF = (C + 16 * HB + DW_NG) * RS;
+  // [2 buffers] x { gy_s [CB][RS] | xk_s [HBK][RS] | x0_s [DW_NG][RS] }
+  constexpr int ROWS = CB + HBK + DW_NG;
+  constexpr int BUF = ROWS * RS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, r = lane & 15;
   const int ng = (N + DW_NG - 1) / DW_NG;
-  const int hb_count = (H + 16 * HB - 1) / (16 * HB);
+  const int cbc = C / CB;
+  const int hb_count = (H + HBK - 1) / HBK;
   int bid = blockIdx.x;
-  const int g = bid % ng; bid /= ng;                 // field group fastest: co-scheduled blocks share samples
+  const int g = bid % ng; bid /= ng;                 // field group fastest: co-scheduled blocks share samples in L2
+  const int cb = bid % cbc; bid /= cbc;
   const int hb = bid % hb_count; bid /= hb_count;
   const int split = bid;
-  const int nloc = wave >> 2, cq = wave & 3;
-  const int n = g * DW_NG + nloc;
-  const bool n_ok = n < N;
+  const int nq = wave & 1, cw = (wave >> 1) % CW, hw = (wave >> 1) / CW;
   const int64_t per = (B + nsplit - 1) / nsplit;
   const int64_t b_lo = split * per, b_hi = b_lo + per < B ? b_lo + per : B;
-  f32x4 acc[CTW][HB];
+  f32x4 acc[DW_NW][2][HW];
 #pragma unroll
-  for (int ct = 0; ct < CTW; ++ct)
+  for (int nn = 0; nn < DW_NW; ++nn)
 #pragma unroll
-    for (int ht = 0; ht < HB; ++ht) acc[ct][ht] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int ht = 0; ht < HW; ++ht) acc[nn][ct][ht] = f32x4{0.f, 0.f, 0.f, 0.f};
   constexpr int VPR = E / 8;                          // 16-byte vectors per row
-  constexpr int TOTV = (C + 16 * HB + DW_NG) * VPR;   // vectors per sample stage
+  constexpr int TOTV = ROWS * VPR;                    // vectors per sample stage
   constexpr int NV = (TOTV + 511) / 512;
-  auto src_vec = [&](int64_t b, int v, bool& ok) -> const uint4* {
-    const int row = v / VPR, col = v - row * VPR;
-    ok = true;
-    if (row < C) return reinterpret_cast<const uint4*>(gy + ((b * C + row) * (int64_t)E)) + col;
-    if (row < C + 16 * HB) {
-      const int h = 16 * HB * hb + (row - C);
-      ok = h < H;
-      return reinterpret_cast<const uint4*>(xk + ((b * H + (ok ? h : 0)) * (int64_t)E)) + col;
+  // per-thread source pointers advance by a fixed per-sample stride: precompute both
+  const bf16_t* src[NV];
+  int sstride[NV];
+  int doff[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int v = threadIdx.x + 512 * k;
+    src[k] = nullptr; sstride[k] = 0; doff[k] = 0;
+    if (v < TOTV) {
+      const int row = v / VPR, col = v - row * VPR;
+      doff[k] = row * RS + col * 16;
+      if (row < CB) {
+        sstride[k] = C * E;
+        src[k] = gy + b_lo * sstride[k] + (int64_t)(CB * cb + row) * E + col * 8;
+      } else if (row < CB + HBK) {
+        const int h = HBK * hb + (row - CB);
+        sstride[k] = H * E;
+        if (h < H) src[k] = xk + b_lo * sstride[k] + (int64_t)h * E + col * 8;
+      } else {
+        const int nn = g * DW_NG + (row - CB - HBK);
+        sstride[k] = N * E;
+        if (nn < N) src[k] = x0 + b_lo * sstride[k] + (int64_t)nn * E + col * 8;
+      }
     }
-    const int nn = g * DW_NG + (row - C - 16 * HB);
-    ok = nn < N;
-    return reinterpret_cast<const uint4*>(x0 + ((b * N + (ok ? nn : 0)) * (int64_t)E)) + col;
-  };
+  }
   uint4 stage[NV];
-  auto fetch = [&](int64_t b) {
+  auto fetch = [&](int64_t b) {     // called with consecutive b starting at b_lo
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-      const int v = threadIdx.x + 512 * k;
       stage[k] = make_uint4(0, 0, 0, 0);
-      if (v < TOTV && b < b_hi) {
-        bool ok;
-        const uint4* p = src_vec(b, v, ok);
-        if (ok) stage[k] = *p;
+      if (src[k] != nullptr && b < b_hi) {
+        stage[k] = *reinterpret_cast<const uint4*>(src[k]);
+        src[k] += sstride[k];
       }
     }
   };
   auto commit = [&](int buf) {
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      const int v = threadIdx.x + 512 * k;
-      if (v < TOTV) {
-        const int row = v / VPR, col = v - row * VPR;
-        *reinterpret_cast<uint4*>(smem + (size_t)buf * BUF + row * RS + col * 16) = stage[k];
-      }
-    }
+    for (int k = 0; k < NV; ++k)
+      if (threadIdx.x + 512 * k < TOTV) *reinterpret_cast<uint4*>(smem + (size_t)buf * BUF + doff[k]) = stage[k];
   };
   if (b_lo < b_hi) {
     fetch(b_lo);
@@ -567,46 +580,54 @@ __global__ __launch_bounds__(512) void cin_dw_kernel(const bf16_t* __restrict__ 
   for (int64_t b = b_lo; b < b_hi; ++b) {
     fetch(b + 1);
     const char* base = smem + (size_t)cur * BUF;
-    const char* gy_s = base;
-    const char* xk_s = base + C * RS;
-    const char* x0_s = base + (C + 16 * HB) * RS + nloc * RS;
+    const char* gy_s = base + (32 * cw) * RS;
+    const char* xk_s = base + (CB + 16 * HW * hw) * RS;
+    const char* x0_s = base + (CB + HBK + DW_NW * nq) * RS;
 #pragma unroll
     for (int ke = 0; ke < KE; ++ke) {
       const int eoff = (32 * ke + 8 * q) * 2;
-      float xf[8];
-      Vec16<bf16_t>::unpack(*reinterpret_cast<const uint4*>(x0_s + eoff), xf);
-      uint4 Bx[HB];
+      float xf[DW_NW][8];
 #pragma unroll
-      for (int ht = 0; ht < HB; ++ht) Bx[ht] = *reinterpret_cast<const uint4*>(xk_s + (16 * ht + r) * RS + eoff);
+      for (int nn = 0; nn < DW_NW; ++nn) Vec16<bf16_t>::unpack(*reinterpret_cast<const uint4*>(x0_s + nn * RS + eoff), xf[nn]);
+      uint4 Bx[HW];
 #pragma unroll
-      for (int ct = 0; ct < CTW; ++ct) {
+      for (int ht = 0; ht < HW; ++ht) Bx[ht] = *reinterpret_cast<const uint4*>(xk_s + (16 * ht + r) * RS + eoff);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
         float gf[8];
-        Vec16<bf16_t>::unpack(*reinterpret_cast<const uint4*>(gy_s + (16 * (CTW * cq + ct) + r) * RS + eoff), gf);
+        Vec16<bf16_t>::unpack(*reinterpret_cast<const uint4*>(gy_s + (16 * ct + r) * RS + eoff), gf);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) gf[k] *= xf[k];
-        const uint4 a = Vec16<bf16_t>::pack(gf);
+        for (int nn = 0; nn < DW_NW; ++nn) {
+          float p[8];
 #pragma unroll
-        for (int ht = 0; ht < HB; ++ht)
-          acc[ct][ht] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
-                                                                __builtin_bit_cast(bf16x8, Bx[ht]), acc[ct][ht], 0, 0, 0);
+          for (int k = 0; k < 8; ++k) p[k] = gf[k] * xf[nn][k];
+          const uint4 a = Vec16<bf16_t>::pack(p);
+#pragma unroll
+          for (int ht = 0; ht < HW; ++ht)
+            acc[nn][ct][ht] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, Bx[ht]), acc[nn][ct][ht], 0, 0, 0);
+        }
       }
     }
     commit(cur ^ 1);
     __syncthreads();
     cur ^= 1;
   }
-  if (n_ok) {
-    float* out = dWpart + (size_t)split * C * N * H;
+  float* out = dWpart + (size_t)split * C * N * H;
 #pragma unroll
-    for (int ct = 0; ct < CTW; ++ct)
+  for (int nn = 0; nn < DW_NW; ++nn) {
+    const int n = g * DW_NG + DW_NW * nq + nn;
+    if (n >= N) continue;
 #pragma unroll
-      for (int ht = 0; ht < HB; ++ht) {
-        const int h = 16 * HB * hb + 16 * ht + r;
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int ht = 0; ht < HW; ++ht) {
+        const int h = HBK * hb + 16 * (HW * hw + ht) + r;
         if (h < H) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const int c = 16 * (CTW * cq + ct) + 4 * q + i;
-            out[(size_t)c * N * H + (size_t)n * H + h] = acc[ct][ht][i];
+            const int c = CB * cb + 32 * cw + 16 * ct + 4 * q + i;
+            out[(size_t)c * N * H + (size_t)n * H + h] = acc[nn][ct][ht][i];
           }
         }
       }
@@ -622,14 +643,6 @@ __global__ __launch_bounds__(256) void cin_reduce_partials_kernel(const float* _
   }
 }
 
-static int cin_dw_splits(int64_t B, int N, int H, int HBt) {
-  const int ng = (N + DW_NG - 1) / DW_NG;
-  const int hbc = (H + 16 * HBt - 1) / (16 * HBt);
-  int s = (int)std::max<int64_t>(1, 256 / std::max(1, ng * hbc));   // one workgroup per CU (LDS-bound)
-  s = (int)std::min<int64_t>(s, std::max<int64_t>(1, B / 8));
-  return std::min(s, 32);
-}
-
 size_t cin_dw_workspace_bytes(int64_t B, int N, int H, int C) {
   return (size_t)32 * C * N * H * 4 + 256;
 }
@@ -641,46 +654,57 @@ int cin_dw(const void* gy, const void* x0, const void* xk, int64_t B, int N, int
       !aligned16(gy) || !aligned16(x0) || !aligned16(xk))
     return 1;
   if (ws_bytes < cin_dw_workspace_bytes(B, N, H, C)) return fail(TRS_EWORKSPACE, "cin_dw: workspace too small");
-  const int CTW = C / 64, KE = E / 32;
-  // h tiles per block: accumulators CTW*HB*4 registers <= 128
-  int HB = (H + 15) / 16;
-  const int hb_cap = CTW == 4 ? 8 : 8;
-  if (HB > hb_cap) HB = hb_cap;
-  if (HB != 1 && HB != 2 && HB != 4 && HB != 8) HB = HB > 4 ? 8 : (HB > 2 ? 4 : (HB > 1 ? 2 : 1));
-  const int nsplit = cin_dw_splits(B, N, H, HB);
-  const int ng = (N + DW_NG - 1) / DW_NG, hbc = (H + 16 * HB - 1) / (16 * HB);
-  const int grid = ng * hbc * nsplit;
-  const size_t lds = (size_t)2 * (C + 16 * HB + DW_NG) * (E * 2 + 16);
+  const int KE = E / 32;
+  const int tiles = (H + 15) / 16;
+  // narrow H: all waves share the h range and split 128 channels; otherwise two wave groups split h
+  const int hw_cap = KE == 4 ? 2 : 4;    // E = 128 stages more vectors per thread: keep the accumulators small
+  int WH, HW;
+  if (tiles <= hw_cap && C % 128 == 0) {
+    WH = 1; HW = tiles;
+  } else {
+    WH = 2; HW = 1;
+    int best = 1 << 30;
+    for (int cand = hw_cap; cand >= 1; --cand) {
+      const int cover = (tiles + 2 * cand - 1) / (2 * cand) * (2 * cand);
+      if (cover < best) { best = cover; HW = cand; }
+    }
+  }
+  const int CB = 32 * (4 / WH), HBK = 16 * HW * WH;
+  const int ng = (N + DW_NG - 1) / DW_NG, cbc = C / CB, hbc = (H + HBK - 1) / HBK;
+  int nsplit = (int)std::max<int64_t>(1, 256 / std::max(1, ng * cbc * hbc));   // one workgroup per CU
+  nsplit = (int)std::min<int64_t>(nsplit, std::max<int64_t>(1, B / 8));
+  nsplit = std::min(nsplit, 32);
+  const int grid = ng * cbc * hbc * nsplit;
+  const size_t lds = (size_t)2 * (CB + HBK + DW_NG) * (E * 2 + 16);
   float* part = (float*)workspace;
-#define TRS_DW(CTW_, HB_, KE_)                                                                                   \
+#define TRS_DW(WH_, HW_, KE_)                                                                                    \
   do {                                                                                                           \
-    auto kern = cin_dw_kernel<CTW_, HB_, KE_>;                                                                   \
-    static bool attr_set = false;                                                                                \
-    if (!attr_set && lds > 64 * 1024) {                                                                          \
+    auto kern = cin_dw_kernel<WH_, HW_, KE_>;                                                                    \
+    static size_t attr_lds = 0;                                                                                  \
+    if (lds > 64 * 1024 && lds > attr_lds) {                                                                     \
       if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
         return check_launch("cin_dw: LDS attribute");                                                            \
-      attr_set = true;                                                                                           \
+      attr_lds = lds;                                                                                            \
     }                                                                                                            \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, (const bf16_t*)gy, (const bf16_t*)x0, (const bf16_t*)xk, \
-                       part, B, N, H, nsplit);                                                                   \
+                       part, B, N, H, C, nsplit);                                                                \
   } while (0)
-#define TRS_DW_KE(CTW_, HB_)                   \
+#define TRS_DW_KE(WH_, HW_)                    \
   do {                                         \
-    if (KE == 1) TRS_DW(CTW_, HB_, 1);         \
-    else if (KE == 2) TRS_DW(CTW_, HB_, 2);    \
-    else TRS_DW(CTW_, HB_, 4);                 \
+    if (KE == 1) TRS_DW(WH_, HW_, 1);          \
+    else if (KE == 2) TRS_DW(WH_, HW_, 2);     \
+    else TRS_DW(WH_, HW_, 4);                  \
   } while (0)
-#define TRS_DW_HB(CTW_)                        \
+#define TRS_DW_HW(WH_)                         \
   do {                                         \
-    if (HB == 1) TRS_DW_KE(CTW_, 1);           \
-    else if (HB == 2) TRS_DW_KE(CTW_, 2);      \
-    else if (HB == 4) TRS_DW_KE(CTW_, 4);      \
-    else TRS_DW_KE(CTW_, 8);                   \
+    if (HW == 1) TRS_DW_KE(WH_, 1);            \
+    else if (HW == 2) TRS_DW_KE(WH_, 2);       \
+    else if (HW == 3) TRS_DW_KE(WH_, 3);       \
+    else TRS_DW_KE(WH_, 4);                    \
   } while (0)
-  if (CTW == 1) TRS_DW_HB(1);
-  else if (CTW == 2) TRS_DW_HB(2);
-  else TRS_DW_HB(4);
-#undef TRS_DW_HB
+  if (WH == 1) TRS_DW_HW(1);
+  else TRS_DW_HW(2);
+#undef TRS_DW_HW
 #undef TRS_DW_KE
 #undef TRS_DW
   const int64_t n = (int64_t)C * N * H;

@@ -231,9 +231,31 @@ static int permute_rows(const void* rows, const int32_t* pos, int64_t K, int E, 
   return check_launch("permute_rows");
 }
 
+__global__ void mark_timestamp_kernel(unsigned long long* ring, int capacity) {
+  if (threadIdx.x == 0) {
+    const unsigned long long i = ring[0];
+    ring[0] = i + 1;
+    ring[1 + (i % (unsigned long long)capacity)] = wall_clock64();
+  }
+}
+
 }  // namespace trs
 
 using namespace trs;
+
+extern "C" int trs_mark_timestamp(uint64_t* ring, int32_t capacity, trs_stream_t stream) {
+  TRS_REQUIRE(ring != nullptr && capacity > 0, TRS_EINVAL, "mark_timestamp: NULL ring or capacity <= 0");
+  hipLaunchKernelGGL(mark_timestamp_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)ring,
+                     (int)capacity);
+  return check_launch("mark_timestamp");
+}
+
+extern "C" int64_t trs_wall_clock_khz(void) {
+  int dev = 0, khz = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return 0;
+  return khz;
+}
 
 extern "C" int trs_version(void) { return TRS_ABI_VERSION; }
 extern "C" const char* trs_last_error_string(void) { return trs::err_buf(); }

@@ -1,0 +1,87 @@
+"""hipGraph capture of one training step.
+
+A CTR step at batch 65 536 is ~110 kernel launches of 5-250 us each; enqueueing them from Python costs ~1.6 ms of
+host time, which is the whole budget of the step on an MI355X.  ``GraphedStep`` records the step once (forward,
+loss, backward and, when given, the optimizer) into a hipGraph and replays it with one launch; every kernel of
+this package is capture safe (no allocation, no host read-back and no synchronisation inside the C ABI; the side
+stream that builds the row buckets forks from and joins the capturing stream).
+
+    step = GraphedStep(lambda idx, label: loss_fn(model(**inputs({'c0': idx})), label), (idx0, label0))
+    for idx, label in loader:
+        loss = step(idx, label)        # copies the batch into the static buffers, replays
+
+The callable must be shape-static and must not branch on tensor values.  Scalars passed by value to kernels (the
+learning rate of a fused sparse optimizer) are frozen at capture time; call ``recapture()`` after changing them.
+The row-sharded multi-GPU lookup reads its all-to-all split sizes on the host and therefore stays eager.
+"""
+from typing import Callable, Iterable, Optional, Sequence
+
+import warnings
+
+import torch
+
+from . import functional as F_
+
+__all__ = ["GraphedStep"]
+
+
+class GraphedStep:
+    def __init__(self, fn: Callable[..., torch.Tensor], example_inputs: Sequence[torch.Tensor],
+                 params: Optional[Iterable[torch.nn.Parameter]] = None, warmup: int = 3):
+        """``fn(*static_inputs) -> loss`` runs forward AND backward (and optimizer.step() if wanted).
+        ``params``: parameters whose ``.grad`` must be dropped before capture so that the captured backward
+        allocates them from the graph's private pool (they then stay valid, updated in place, after every replay).
+        At least one eager warm-up iteration always runs (on a side stream) before the capture."""
+        if not all(t.is_cuda for t in example_inputs):
+            raise RuntimeError("GraphedStep: inputs must live on the HIP device (no CPU path)")
+        self._fn = fn
+        self._params = list(params) if params is not None else []
+        self._static = [t.clone() for t in example_inputs]
+        self._warmup = int(warmup)
+        self._graph = None
+        self.output = None
+        self.recapture()
+
+    def recapture(self):
+        # eager warm-up on a side stream: lazy initialisation (hipBLASLt workspaces, TunableOp tuning, kernel
+        # attributes) must not happen inside the capture
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            with torch.cuda.stream(s):
+                for _ in range(max(1, self._warmup)):
+                    for p in self._params:
+                        p.grad = None
+                    self._fn(*self._static)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        for w in caught:
+            if "AccumulateGrad node's stream does not match" in str(w.message):
+                # the capture would pull the legacy default stream into the graph (hipStreamEndCapture crashes on it)
+                raise RuntimeError(
+                    "GraphedStep: an autograd graph of an earlier eager step is still alive (a loss or output tensor "
+                    "is still referenced), so the parameters' AccumulateGrad nodes are bound to that step's stream. "
+                    "Drop those references (del loss) before capturing.")
+            warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
+        for p in self._params:
+            p.grad = None
+        # the warm-up left row buckets of the static index buffer in the per-batch cache: a hit would keep their
+        # construction (and the event they wait on) OUT of the graph and replay stale buckets for every later batch
+        F_.clear_caches()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self.output = self._fn(*self._static)
+        torch.cuda.synchronize()
+        F_.clear_caches()          # entries made during the capture point into the graph's private pool
+
+    def __call__(self, *inputs: torch.Tensor) -> torch.Tensor:
+        if len(inputs) != len(self._static):
+            raise ValueError(f"GraphedStep: expected {len(self._static)} inputs, got {len(inputs)}")
+        for dst, src in zip(self._static, inputs):
+            if dst.shape != src.shape or dst.dtype != src.dtype:
+                raise ValueError(f"GraphedStep: input {tuple(src.shape)}/{src.dtype} does not match the captured "
+                                 f"{tuple(dst.shape)}/{dst.dtype}")
+            dst.copy_(src, non_blocking=True)
+        self._graph.replay()
+        return self.output
