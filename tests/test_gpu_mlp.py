@@ -1,0 +1,72 @@
+"""The MLP stack (layers/ctr/multilayer_perceptron.py:24-84) stays on hipBLASLt GEMMs, but on the HIP device with
+bf16 parameters they are arranged differently (zero-padded hidden widths, bias+ReLU epilogue, split-K weight
+gradient, fused ReLU-backward + bias gradient).  Results must match a plain torch.nn stack."""
+import copy
+
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _plain(mlp):
+    return copy.deepcopy(mlp.model)
+
+
+@pytest.mark.parametrize("rows,shape3d", [(8192, True), (4096, False), (512, True)])
+@pytest.mark.parametrize("sizes", [[400, 400, 400], [200, 136], [512, 300]])
+def test_mlp_bf16_matches_plain_stack(dev, rows, shape3d, sizes):
+    from torecsys_amd.layers import MultilayerPerceptionLayer, _pad_width
+    torch.manual_seed(1)
+    K = 96
+    mlp = MultilayerPerceptionLayer(K, 3, sizes).to(dev).bfloat16()
+    ref = _plain(mlp)
+    x = torch.randn(rows, K, device=dev, dtype=torch.bfloat16)
+    if shape3d:
+        x = x.view(rows // 4, 4, K)
+    xa = x.clone().requires_grad_()
+    xb = x.clone().requires_grad_()
+    ya = mlp(xa).rename(None)
+    yb = ref(xb)
+    assert ya.shape == yb.shape
+    assert rel_err(ya.float().cpu(), yb.float().cpu()) <= 2e-2
+    g = torch.randn_like(yb)
+    ya.backward(g)
+    yb.backward(g)
+    assert rel_err(xa.grad.float().cpu(), xb.grad.float().cpu()) <= 3e-2
+    for (n, pa), (_, pb) in zip(mlp.model.named_parameters(), ref.named_parameters()):
+        assert pa.grad.shape == pb.grad.shape == pa.shape, n
+        assert pa.grad.is_contiguous()
+        assert rel_err(pa.grad.float().cpu(), pb.grad.float().cpu()) <= 3e-2, n
+    padded = any('_trs_padded' in m.__dict__ for m in mlp.model if isinstance(m, nn.Linear))
+    expect = rows >= 4096 and any(_pad_width(s) != s for s in sizes)
+    assert padded == expect
+
+
+def test_padded_weights_follow_parameter_updates(dev):
+    from torecsys_amd.layers import MultilayerPerceptionLayer
+    torch.manual_seed(2)
+    mlp = MultilayerPerceptionLayer(64, 1, [400, 400]).to(dev).bfloat16()
+    x = torch.randn(4096, 64, device=dev, dtype=torch.bfloat16, requires_grad=True)
+    y0 = mlp(x).rename(None).detach().clone()
+    with torch.no_grad():
+        for p in mlp.parameters():
+            p.mul_(0.5)                       # in-place update, like an optimizer step
+    y1 = mlp(x).rename(None).detach()
+    ref = _plain(mlp)
+    assert rel_err(y1.float().cpu(), ref(x).detach().float().cpu()) <= 2e-2
+    assert not torch.equal(y0, y1)
+    sd = {k: torch.randn_like(v) * 0.05 for k, v in mlp.state_dict().items()}
+    mlp.load_state_dict(sd)                   # copy_ into the parameters: version bump
+    assert rel_err(mlp(x).rename(None).detach().float().cpu(), _plain(mlp)(x).detach().float().cpu()) <= 2e-2
+    assert set(mlp.state_dict().keys()) == set(sd.keys())
+    assert mlp.model.Linear_0.weight.shape == (400, 64)

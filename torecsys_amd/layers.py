@@ -257,60 +257,113 @@ class CompressInteractionNetworkLayer(BaseLayer):
         return outputs
 
 
+PAD_MULTIPLE = 128        # hidden widths are zero-padded to a multiple of this inside the GEMMs
+PAD_MIN_WIDTH = 192
+PAD_MIN_ROWS = 4096
+
+
+def _pad_width(width: int) -> int:
+    """Width the GEMMs run at: hipBLASLt's macro tiles are 128/256 wide, a 400-wide layer runs 1.5-1.6x slower
+    than a zero-padded 512-wide one (measured, tools/mlp_pad_probe.py) although it does 28 % more flops."""
+    if width < PAD_MIN_WIDTH or width % PAD_MULTIPLE == 0:
+        return width
+    return (width + PAD_MULTIPLE - 1) // PAD_MULTIPLE * PAD_MULTIPLE
+
+
+class _PaddedLinear:
+    """Zero-padded copies of one nn.Linear's weight/bias, refreshed when the parameters change (optimizer steps bump
+    ``_version``; ``.to()`` / ``load_state_dict`` change storage or version) and on every hipGraph capture, where the
+    refresh must be part of the replayed work.  The parameters themselves keep the reference's shapes."""
+    __slots__ = ("w", "b", "key")
+
+    @staticmethod
+    def get(mod: nn.Linear, in_pad: int, out_pad: int):
+        w, b = mod.weight, mod.bias
+        st = mod.__dict__.get('_trs_padded')
+        if st is None or st.w.shape != (out_pad, in_pad) or st.w.dtype != w.dtype or st.w.device != w.device:
+            st = _PaddedLinear()
+            st.w = torch.zeros(out_pad, in_pad, dtype=w.dtype, device=w.device)
+            st.b = torch.zeros(out_pad, dtype=w.dtype, device=w.device) if b is not None else None
+            st.key = None
+            mod.__dict__['_trs_padded'] = st
+        key = (w.data_ptr(), w._version, None if b is None else (b.data_ptr(), b._version))
+        if st.key != key or torch.cuda.is_current_stream_capturing():
+            with torch.no_grad():
+                st.w[:w.shape[0], :w.shape[1]].copy_(w)
+                if b is not None:
+                    st.b[:b.shape[0]].copy_(b)
+            st.key = key
+        return st.w, st.b
+
+
 class _LinearSplitK(torch.autograd.Function):
-    """``F.linear`` whose weight gradient ``g^T x`` (K = the batch, 65 536 rows against a few hundred outputs) is
-    computed as a split-K batched GEMM with fp32 partial sums: one GEMM with such a deep K and a tiny output runs at
-    ~120 TFLOP/s in hipBLASLt, 32 slices of 2 048 rows at ~370.  Same math (fp32 accumulation), plain PyTorch ops."""
+    """``F.linear`` (+ optional ReLU) for the MLP stack on the HIP device, plain PyTorch / hipBLASLt GEMMs arranged
+    for this shape class (tens of thousands of rows against a few hundred features):
+      * forward: bias and ReLU ride in the GEMM epilogue (``torch._addmm_activation``) instead of a second pass;
+      * the GEMMs can run on zero-padded copies of the weights (``w_pad``/``b_pad``, see _PaddedLinear): the padded
+        output columns are exactly 0 and feed zero weight columns of the next layer, so results are unchanged;
+      * weight gradient ``g^T x`` (K = the batch) as a split-K batched GEMM with fp32 partial sums: one GEMM with
+        such a deep K and a tiny output runs at ~120 TFLOP/s in hipBLASLt, 32 slices of 2 048 rows at ~370;
+      * ReLU backward + bias gradient in one HIP pass (trs_relu_bwd_bias).
+    Gradients are returned for the un-padded parameters (a strided slice folded into the final cast)."""
 
     SPLIT_ROWS = 2048
 
     @staticmethod
-    def forward(ctx, x, weight, bias, fuse_relu):
-        y = torch.nn.functional.linear(x, weight, bias)
+    def forward(ctx, x, weight, bias, fuse_relu, w_pad, b_pad):
+        W = weight if w_pad is None else w_pad
+        Bv = bias if w_pad is None else b_pad
+        x2 = x.reshape(-1, x.shape[-1])
+        if fuse_relu and Bv is not None and x2.is_cuda:
+            y = torch._addmm_activation(Bv, x2, W.t(), use_gelu=False).reshape(*x.shape[:-1], W.shape[0])
+        else:
+            y = torch.nn.functional.linear(x, W, Bv)
+            if fuse_relu:
+                y = torch.relu_(y)
         ctx.has_bias = bias is not None
         ctx.fuse_relu = bool(fuse_relu) and bias is not None and F_.relu_bwd_bias_supported(y.reshape(-1, y.shape[-1]))
-        if fuse_relu:
-            y = torch.relu_(y)
-        if ctx.fuse_relu:
-            ctx.save_for_backward(x, weight, y)          # relu output: its sign pattern is the backward mask
-        else:
-            ctx.save_for_backward(x, weight, y if fuse_relu else None)
         ctx.relu = bool(fuse_relu)
+        ctx.wshape = tuple(weight.shape)
+        ctx.wdtype = weight.dtype
+        ctx.save_for_backward(x, W, y if fuse_relu else None)      # relu output: its sign pattern is the backward mask
         return y
 
     @staticmethod
     def backward(ctx, g):
-        x, weight, y = ctx.saved_tensors
+        x, W, y = ctx.saved_tensors
+        out_f, in_f = ctx.wshape
         gx = gw = gb = None
         if ctx.fuse_relu:
             # one HIP pass: relu backward + bias gradient (ATen: threshold_backward, then a column sum re-reading it)
             gz, gbf = F_.relu_bwd_bias(g.reshape(-1, g.shape[-1]), y.reshape(-1, y.shape[-1]))
             g = gz.reshape(g.shape)
-            gb = gbf.to(weight.dtype)
+            gb = gbf[:out_f].to(ctx.wdtype)
         elif ctx.relu:
             g = g * (y > 0).to(g.dtype)
         g2 = g.reshape(-1, g.shape[-1])
         x2 = x.reshape(-1, x.shape[-1])
         if ctx.needs_input_grad[0]:
-            gx = (g2 @ weight).reshape(x.shape)
+            gx = (g2 @ W).reshape(x.shape)
         if ctx.needs_input_grad[1]:
             rows, S = g2.shape[0], g2.shape[0] // _LinearSplitK.SPLIT_ROWS
             if S >= 4 and rows % S == 0 and 32 <= g2.shape[1] <= 1024 and 32 <= x2.shape[1] <= 1024 \
                     and g2.is_contiguous() and x2.is_contiguous():
                 part = torch.bmm(g2.view(S, rows // S, -1).transpose(1, 2), x2.view(S, rows // S, -1),
                                  out_dtype=torch.float32)
-                gw = part.sum(0).to(weight.dtype)
+                gw = part.sum(0)[:out_f, :in_f].to(ctx.wdtype)
             else:
-                gw = g2.t() @ x2
+                gw = (g2.t() @ x2)[:out_f, :in_f]
+                if not gw.is_contiguous():
+                    gw = gw.contiguous()
         if ctx.has_bias and ctx.needs_input_grad[2] and gb is None:
             rows = g2.shape[0]
             if g2.shape[1] <= 8 and rows % 1024 == 0 and rows >= 8192 and g2.is_contiguous():
                 # a (rows x 1) column summed to one value is a single-workgroup reduction in ATen (60 us at 65 536
                 # rows); two stages keep the whole chip busy
-                gb = g2.view(rows // 1024, 1024, -1).float().sum(1).sum(0).to(g2.dtype)
+                gb = g2.view(rows // 1024, 1024, -1).float().sum(1).sum(0)[:out_f].to(g2.dtype)
             else:
-                gb = g2.sum(0)
-        return gx, gw, gb, None
+                gb = g2.sum(0)[:out_f]
+        return gx, gw, gb, None, None, None
 
 
 class MultilayerPerceptionLayer(BaseLayer):
@@ -346,13 +399,27 @@ class MultilayerPerceptionLayer(BaseLayer):
         outputs = _strip(emb_inputs)
         split_k = outputs.is_cuda and outputs.dtype in (torch.bfloat16, torch.float16) and torch.is_grad_enabled()
         mods = list(self.model)
+        rows = outputs.numel() // max(1, outputs.shape[-1])
+        # zero-padded hidden widths: only for plain Linear(+ReLU) stacks (an active Dropout would draw a different
+        # random stream on the wider activations)
+        pad = split_k and rows >= PAD_MIN_ROWS and all(
+            isinstance(m, (nn.Linear, nn.ReLU)) or (isinstance(m, nn.Dropout) and (m.p == 0.0 or not m.training))
+            for m in mods)
+        width = outputs.shape[-1]          # current (possibly padded) activation width
         i = 0
         while i < len(mods):
             mod = mods[i]
             if split_k and isinstance(mod, nn.Linear):
                 # Linear followed by a plain nn.ReLU: the activation and its backward are folded into the Function
                 fuse = i + 1 < len(mods) and type(mods[i + 1]) is nn.ReLU
-                outputs = _LinearSplitK.apply(outputs, mod.weight, mod.bias, fuse)
+                last = not any(isinstance(m, nn.Linear) for m in mods[i + 1:])
+                out_pad = _pad_width(mod.out_features) if pad and not last else mod.out_features
+                if pad and (width != mod.in_features or out_pad != mod.out_features):
+                    w_pad, b_pad = _PaddedLinear.get(mod, width, out_pad)
+                else:
+                    w_pad = b_pad = None
+                outputs = _LinearSplitK.apply(outputs, mod.weight, mod.bias, fuse, w_pad, b_pad)
+                width = out_pad
                 i += 2 if fuse else 1
             else:
                 outputs = mod(outputs)
