@@ -264,3 +264,62 @@ def test_fused_sparse_optimizer_equals_dense_step(dev, kind, dtype, E):
     tol = 2e-5 if dtype == torch.float32 else 2e-2
     assert rel_err(mods[1], mods[0]) <= tol
     assert not torch.equal(mods[0], w.float())
+
+
+def _check_csr(rb, rows_flat, V):
+    """row_start = exclusive prefix sum of the per-row lookup counts; perm lists, row by row, exactly the flat
+    lookup positions that hit the row (any order inside a row)."""
+    valid = (rows_flat >= 0) & (rows_flat < V)
+    counts = torch.bincount(rows_flat[valid], minlength=V)
+    expect_start = torch.zeros(V + 1, dtype=torch.int64, device=rows_flat.device)
+    expect_start[1:] = counts.cumsum(0)
+    assert torch.equal(rb.row_start.long(), expect_start)
+    total = int(expect_start[-1])
+    perm = rb.perm[:total].long()
+    assert torch.equal(perm.sort().values, valid.nonzero().flatten())       # a permutation of the valid lookups
+    got_rows = rows_flat[perm]
+    assert torch.equal(got_rows, got_rows.sort().values)                    # grouped by destination row
+    assert torch.equal(torch.bincount(got_rows, minlength=V), counts)
+
+
+@pytest.mark.parametrize("case", ["criteo", "tiny_fields", "spill", "unsorted_offsets", "int32", "huge_field", "zipf"])
+def test_row_buckets_partitioned_and_fallback(dev, case):
+    """trs_csr_build: the partitioned LDS-counter build (B >= 2048, per-field ranges) and its device-side fall-back
+    to the global-atomic build must produce the same CSR as a bincount/sort restatement."""
+    from torecsys_amd import functional as F_
+    g = torch.Generator().manual_seed(11)
+    B = 4096
+    if case == "tiny_fields":
+        sizes = [1, 2, 3, 1, 7, 40000, 5]
+    elif case == "huge_field":
+        sizes = [100, 70000, 9]          # 5 chunks in one field
+    else:
+        sizes = [2564] * 13 + [20000, 17, 1, 333, 15361, 15360, 15359]
+    N = len(sizes)
+    V = sum(sizes)
+    off = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)[:-1]), dtype=torch.int64)
+    if case == "zipf":
+        idx = torch.stack([(torch.rand(B, generator=g) ** 6 * s).long().clamp_(max=s - 1) for s in sizes], 1)
+    else:
+        idx = torch.stack([torch.randint(0, s, (B,), generator=g) for s in sizes], 1)
+    if case == "spill":                   # legal for nn.Embedding: idx + offset < V but outside the field's own range
+        idx[5, 0] = sizes[0] + 3
+        idx[77, 3] = 40
+    if case == "unsorted_offsets":
+        off = off.flip(0).contiguous()
+        idx = idx.flip(1).contiguous()
+    if case == "int32":
+        idx = idx.int()
+    idx, off = idx.to(dev), off.to(dev)
+    F_.clear_caches()
+    rb = F_.row_buckets(idx, off, V)
+    torch.cuda.synchronize()
+    rows_flat = (idx.long() + off.view(1, -1)).reshape(-1)
+    _check_csr(rb, rows_flat, V)
+    # and the gradient built from it
+    w = torch.randn(V, 16, device=dev, requires_grad=True)
+    out = F_.gather_rows(w, idx, off)
+    gout = torch.randn_like(out)
+    out.backward(gout)
+    ref = torch.zeros(V, 16, device=dev).index_add_(0, rows_flat, gout.reshape(-1, 16))
+    assert rel_err(w.grad.cpu(), ref.cpu()) <= 1e-5
