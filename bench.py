@@ -63,7 +63,7 @@ def parse():
     ap.add_argument("--model", default="deepfm", choices=["deepfm", "fm", "dcn", "xdeepfm"],
                     help="deepfm = the headline metric (BASELINE configs[1]); dcn / xdeepfm = configs[2] / [3]")
     ap.add_argument("--no-tunableop", action="store_true", help="do not use PyTorch TunableOp for the nn.Linear GEMMs")
-    ap.add_argument("--optimizer", default="none", choices=["none", "sgd", "adagrad"],
+    ap.add_argument("--optimizer", default="none", choices=["none", "sgd", "adagrad", "adam"],
                     help="none (default): the metric is fwd+bwd.  sgd/adagrad: also take an optimizer step -- fused sparse "
                          "update inside the embedding backward (no dense table gradient), torch.optim for the MLP")
     ap.add_argument("--microbatches", type=int, default=0,
@@ -203,12 +203,13 @@ def main():
     if a.optimizer != "none":
         if sharded:
             raise SystemExit("--optimizer is wired for the single-GPU path only")
-        from torecsys_amd.optim import FusedSparseAdagrad, FusedSparseSGD
-        fo = FusedSparseSGD(0.01) if a.optimizer == "sgd" else FusedSparseAdagrad(0.01)
+        from torecsys_amd.optim import FusedSparseAdagrad, FusedSparseAdam, FusedSparseSGD
+        fo = {"sgd": FusedSparseSGD(0.01), "adagrad": FusedSparseAdagrad(0.01), "adam": FusedSparseAdam(1e-3)}[a.optimizer]
         emb.set_fused_optimizer(fo)
         feat.set_fused_optimizer(fo)
-        dense_opt = (torch.optim.SGD(model.parameters(), lr=0.01) if a.optimizer == "sgd"
-                     else torch.optim.Adagrad(model.parameters(), lr=0.01))
+        dense_opt = {"sgd": lambda: torch.optim.SGD(model.parameters(), lr=0.01),
+                     "adagrad": lambda: torch.optim.Adagrad(model.parameters(), lr=0.01),
+                     "adam": lambda: torch.optim.Adam(model.parameters(), lr=1e-3)}[a.optimizer]()
 
     MB = a.microbatches or 1
     if not sharded:

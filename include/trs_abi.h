@@ -117,6 +117,16 @@ int trs_scatter_rows_update(const void* g_rows, int64_t g_rows_batch_stride, con
                             int32_t optimizer, float lr, float eps, float* state, void* workspace,
                             size_t ws_bytes, trs_stream_t stream);
 
+/* Same pass with a lazy Adam step (torch.optim.SparseAdam semantics: moments and weights of looked-up rows only;
+ * the reference trains with dense Adam, trainer/torecsys_pipeline.py:562-578, which cannot exist at 1 B rows):
+ *   m = m + (g - m)(1 - beta1);  v = v + (g*g - v)(1 - beta2);  w -= step_size * m / (sqrt(v) + eps)
+ * with step_size = lr * sqrt(1 - beta2^t) / (1 - beta1^t) computed by the caller; exp_avg / exp_avg_sq: V x E fp32. */
+int trs_scatter_rows_update_adam(const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm,
+                                 const float* fm_sum, void* table, const int32_t* row_start, const int32_t* perm,
+                                 int64_t BN, int64_t V, int32_t E, int32_t N, int32_t dtype, int64_t padding_row,
+                                 float step_size, float beta1, float beta2, float eps, float* exp_avg,
+                                 float* exp_avg_sq, void* workspace, size_t ws_bytes, trs_stream_t stream);
+
 /* ---- K1+K2(+K8): fused embedding lookup + FM second order ----------------------------------
  * emb[b,n,:]  = table[idx[b,n]+offsets[n], :]                       (optional, may be NULL)
  * fm[b,:]     = 0.5 * ((sum_n x)^2 - sum_n x^2)                     (optional, may be NULL)

@@ -266,6 +266,46 @@ def test_fused_sparse_optimizer_equals_dense_step(dev, kind, dtype, E):
     assert not torch.equal(mods[0], w.float())
 
 
+@pytest.mark.parametrize("dtype,E", [(torch.float32, 16), (torch.float32, 10), (torch.bfloat16, 64)])
+def test_fused_sparse_adam_equals_torch_sparse_adam(dev, dtype, E):
+    """FusedSparseAdam (lazy Adam inside the scatter pass) == torch.optim.SparseAdam fed the coalesced sparse
+    gradient of the same lookups, three steps; fp32 master copy on the torch side for the bf16 table."""
+    from torecsys_amd.inputs import MultiIndicesEmbedding
+    from torecsys_amd.layers import FMLayer
+    from torecsys_amd.optim import FusedSparseAdam
+    fs, idx0, w, _, g = _rand_case(2048, 7, E, 6, 5 + E, dtype, zipf=True)
+    batches = [idx0] + [_rand_case(2048, 7, E, 6, 100 + k + E, dtype, zipf=True)[1] for k in range(2)]
+    lr, betas, eps = 0.01, (0.9, 0.99), 1e-8
+    fuse = (E * w.element_size()) % 16 == 0
+    off = torch.tensor([0] + list(torch.tensor(fs).cumsum(0)[:-1]), device=dev)
+
+    def loss_of(m, idx):
+        emb = m(idx.to(dev))
+        y = FMLayer()(emb)
+        return (y.rename(None).float() ** 2).mean() + emb.rename(None).float().sum() * 1e-3
+
+    fused = MultiIndicesEmbedding(embed_size=E, field_sizes=fs, fuse_fm=fuse).to(dev).to(dtype)
+    fused.embedding.weight.data.copy_(w)
+    fused.set_fused_optimizer(FusedSparseAdam(lr, betas=betas, eps=eps))
+    plain = MultiIndicesEmbedding(embed_size=E, field_sizes=fs, fuse_fm=fuse).to(dev).to(dtype)
+    plain.embedding.weight.data.copy_(w)
+    master = torch.nn.Parameter(w.to(dev).float().clone())
+    ref_opt = torch.optim.SparseAdam([master], lr=lr, betas=betas, eps=eps)
+    for idx in batches:
+        loss_of(fused, idx).backward()
+        assert fused.embedding.weight.grad is None
+        plain.embedding.weight.grad = None
+        loss_of(plain, idx).backward()
+        rows = (idx.to(dev) + off.view(1, -1)).reshape(-1).unique()
+        G = plain.embedding.weight.grad.float()
+        master.grad = torch.sparse_coo_tensor(rows.unsqueeze(0), G[rows], size=G.shape)
+        ref_opt.step()
+        plain.embedding.weight.data.copy_(master.data)      # keep the forward of the reference path in step
+    tol = 5e-5 if dtype == torch.float32 else 2e-2
+    assert rel_err(fused.embedding.weight.detach().float().cpu(), master.detach().cpu()) <= tol
+    assert not torch.equal(master.detach().cpu(), w.float())
+
+
 def _check_csr(rb, rows_flat, V):
     """row_start = exclusive prefix sum of the per-row lookup counts; perm lists, row by row, exactly the flat
     lookup positions that hit the row (any order inside a row)."""

@@ -278,9 +278,11 @@ __global__ __launch_bounds__(CSR2_THREADS) void csr2_pass_kernel(const int32_t* 
 // dense torch.optim counterparts (no momentum / weight decay): rows nobody looked up have a zero gradient
 // and are not touched, so neither the dense V x E gradient nor a dense optimizer pass over the table exists.
 struct RowSink {
-  int mode;
-  float lr, eps;
-  float* state;  // Adagrad accumulator (V x E fp32) or null
+  int mode;      // 0 write gradient, 1 SGD, 2 Adagrad, 3 Adam (lazy / SparseAdam semantics)
+  float lr, eps; // Adam: lr = lr * sqrt(1 - beta2^t) / (1 - beta1^t), computed by the caller
+  float* state;  // Adagrad accumulator / Adam exp_avg (V x E fp32) or null
+  float beta1 = 0.f, beta2 = 0.f;
+  float* state2 = nullptr;  // Adam exp_avg_sq
 };
 
 template <typename T>
@@ -297,13 +299,24 @@ __device__ __forceinline__ void sink_vec(const RowSink& k, uint4* __restrict__ o
   if (k.mode == 1) {
 #pragma unroll
     for (int i = 0; i < VE; ++i) w[i] = fmaf(-k.lr, acc[i], w[i]);
-  } else {
+  } else if (k.mode == 2) {
     float* st = k.state + vec * VE;
 #pragma unroll
     for (int i = 0; i < VE; ++i) {
       const float s2 = fmaf(acc[i], acc[i], st[i]);
       st[i] = s2;
       w[i] -= k.lr * acc[i] / (sqrtf(s2) + k.eps);
+    }
+  } else {
+    float* m1 = k.state + vec * VE;
+    float* m2 = k.state2 + vec * VE;
+#pragma unroll
+    for (int i = 0; i < VE; ++i) {
+      const float a = m1[i] + (acc[i] - m1[i]) * (1.f - k.beta1);
+      const float v = m2[i] + (acc[i] * acc[i] - m2[i]) * (1.f - k.beta2);
+      m1[i] = a;
+      m2[i] = v;
+      w[i] -= k.lr * a / (sqrtf(v) + k.eps);
     }
   }
   out[vec] = Vec16<T>::pack(w);
@@ -319,10 +332,16 @@ __device__ __forceinline__ void sink_elem(const RowSink& k, T* __restrict__ out,
   float w = to_f32(out[idx]);
   if (k.mode == 1) {
     w = fmaf(-k.lr, acc, w);
-  } else {
+  } else if (k.mode == 2) {
     const float s2 = fmaf(acc, acc, k.state[idx]);
     k.state[idx] = s2;
     w -= k.lr * acc / (sqrtf(s2) + k.eps);
+  } else {
+    const float a = k.state[idx] + (acc - k.state[idx]) * (1.f - k.beta1);
+    const float v = k.state2[idx] + (acc * acc - k.state2[idx]) * (1.f - k.beta2);
+    k.state[idx] = a;
+    k.state2[idx] = v;
+    w -= k.lr * a / (sqrtf(v) + k.eps);
   }
   out[idx] = from_f32<T>(w);
 }
@@ -790,4 +809,21 @@ extern "C" int trs_scatter_rows_update(const void* g_rows, int64_t g_rows_batch_
   TRS_REQUIRE(optimizer == 1 || state != nullptr, TRS_EINVAL, "scatter_rows_update: Adagrad needs the state buffer");
   return scatter_rows_impl(RowSink{optimizer, lr, eps, state}, g_rows, g_rows_batch_stride, g_fm, fm_sum, table,
                            row_start, perm, BN, V, E, N, dtype, padding_row, table, workspace, ws_bytes, stream);
+}
+
+extern "C" int trs_scatter_rows_update_adam(const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm,
+                                            const float* fm_sum, void* table, const int32_t* row_start,
+                                            const int32_t* perm, int64_t BN, int64_t V, int32_t E, int32_t N,
+                                            int32_t dtype, int64_t padding_row, float step_size, float beta1,
+                                            float beta2, float eps, float* exp_avg, float* exp_avg_sq, void* workspace,
+                                            size_t ws_bytes, trs_stream_t stream) {
+  TRS_REQUIRE(table && exp_avg && exp_avg_sq, TRS_EINVAL, "scatter_rows_update_adam: NULL table / moment buffer");
+  TRS_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, TRS_EINVAL,
+              "scatter_rows_update_adam: betas (%g, %g) must be in [0, 1)", (double)beta1, (double)beta2);
+  RowSink sink{3, step_size, eps, exp_avg};
+  sink.beta1 = beta1;
+  sink.beta2 = beta2;
+  sink.state2 = exp_avg_sq;
+  return scatter_rows_impl(sink, g_rows, g_rows_batch_stride, g_fm, fm_sum, table, row_start, perm, BN, V, E, N, dtype,
+                           padding_row, table, workspace, ws_bytes, stream);
 }

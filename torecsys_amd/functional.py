@@ -197,6 +197,12 @@ def scatter_rows_update(rb: RowBuckets, table: torch.Tensor, opt, g_rows: Option
         raise ValueError("fused optimizer needs a contiguous table")
     ws_bytes = size_query("trs_scatter_workspace_bytes", rb.BN, rb.N, E, value_dtype_code(table))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=table.device)
+    if opt.kind == 3:
+        m1, m2 = opt.state_for(table)
+        call("trs_scatter_rows_update_adam", ptr(g_rows), 0, ptr(g_bcast), ptr(fm_sum), ptr(table), ptr(rb.row_start),
+             ptr(rb.perm), rb.BN, V, E, rb.N, value_dtype_code(table), padding_row, float(opt.next_step_size(table)),
+             float(opt.beta1), float(opt.beta2), float(opt.eps), ptr(m1), ptr(m2), ptr(ws), ws_bytes, stream_ptr())
+        return
     state = opt.state_for(table)
     call("trs_scatter_rows_update", ptr(g_rows), 0, ptr(g_bcast), ptr(fm_sum), ptr(table), ptr(rb.row_start),
          ptr(rb.perm), rb.BN, V, E, rb.N, value_dtype_code(table), padding_row, opt.kind, float(opt.lr), float(opt.eps),
