@@ -272,6 +272,14 @@ int trs_permute_grad(const void* g_block, const void* g_fm, const float* fm_sum,
 int trs_gather_by_pos(const void* rows, const int32_t* pos, int64_t K, int32_t E, int32_t dtype,
                       void* out, trs_stream_t stream);
 
+/* ---- index staging: pack per-field columns into the (B,N) index matrix --------
+ * out[b, c] = src_j[b * width_j + t]  for the c-th output column = column t of source j.
+ * replaces the per-field unsqueeze + torch.cat of inputs/inputs.py:75-80 by one pass.
+ * srcs / widths are HOST arrays (nsrc device pointers, their column counts); sum(widths) <= 256.
+ * src_dtype / out_dtype: TRS_I64 | TRS_I32 (narrowing to int32 is the caller's responsibility).   */
+int trs_pack_columns(const void* const* srcs, const int32_t* widths, int32_t nsrc, int32_t src_dtype,
+                     int64_t B, void* out, int32_t out_dtype, trs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

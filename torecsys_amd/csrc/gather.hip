@@ -231,6 +231,34 @@ static int permute_rows(const void* rows, const int32_t* pos, int64_t K, int E, 
   return check_launch("permute_rows");
 }
 
+// ---- index staging: per-field columns -> (B, W) index matrix ---------------------------------------
+constexpr int PACK_MAX_W = 256;
+constexpr int PACK_TB = 64;          // samples per tile
+struct PackArgs {
+  const void* col[PACK_MAX_W];       // base pointer of output column c inside its source
+  int32_t stride[PACK_MAX_W];        // elements between consecutive samples in that source
+};
+
+template <typename SrcT, typename DstT>
+__global__ __launch_bounds__(256) void pack_columns_kernel(PackArgs a, int W, int64_t B, DstT* __restrict__ out) {
+  extern __shared__ char pack_smem[];
+  DstT* tile = reinterpret_cast<DstT*>(pack_smem);      // [PACK_TB][W + 1]
+  const int64_t b0 = (int64_t)blockIdx.x * PACK_TB;
+  const int nb = (int)((B - b0) < PACK_TB ? (B - b0) : PACK_TB);
+  // read: consecutive lanes walk the samples of one column (contiguous for 1-D sources)
+  for (int e = threadIdx.x; e < W * PACK_TB; e += 256) {
+    const int c = e / PACK_TB, bl = e - c * PACK_TB;
+    if (bl < nb) tile[bl * (W + 1) + c] = (DstT) reinterpret_cast<const SrcT*>(a.col[c])[(b0 + bl) * a.stride[c]];
+  }
+  __syncthreads();
+  // write: rows of the index matrix are contiguous
+  const int total = nb * W;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int bl = e / W, c = e - bl * W;
+    out[b0 * W + e] = tile[bl * (W + 1) + c];
+  }
+}
+
 __global__ void mark_timestamp_kernel(unsigned long long* ring, int capacity) {
   if (threadIdx.x == 0) {
     const unsigned long long i = ring[0];
@@ -242,6 +270,41 @@ __global__ void mark_timestamp_kernel(unsigned long long* ring, int capacity) {
 }  // namespace trs
 
 using namespace trs;
+
+extern "C" int trs_pack_columns(const void* const* srcs, const int32_t* widths, int32_t nsrc, int32_t src_dtype,
+                                int64_t B, void* out, int32_t out_dtype, trs_stream_t stream) {
+  if (B == 0) return TRS_OK;
+  TRS_REQUIRE(srcs && widths && out, TRS_EINVAL, "pack_columns: NULL pointer");
+  TRS_REQUIRE(nsrc > 0 && B > 0, TRS_EINVAL, "pack_columns: bad size");
+  TRS_REQUIRE((src_dtype == TRS_I64 || src_dtype == TRS_I32) && (out_dtype == TRS_I64 || out_dtype == TRS_I32),
+              TRS_EDTYPE, "pack_columns: dtypes %d -> %d", src_dtype, out_dtype);
+  PackArgs a;
+  int W = 0;
+  const int esz = src_dtype == TRS_I64 ? 8 : 4;
+  for (int j = 0; j < nsrc; ++j) {
+    TRS_REQUIRE(srcs[j] != nullptr && widths[j] > 0, TRS_EINVAL, "pack_columns: source %d is NULL or empty", j);
+    TRS_REQUIRE(W + widths[j] <= PACK_MAX_W, TRS_ESHAPE, "pack_columns: more than %d columns", PACK_MAX_W);
+    for (int t = 0; t < widths[j]; ++t) {
+      a.col[W] = (const char*)srcs[j] + (size_t)t * esz;
+      a.stride[W] = widths[j];
+      ++W;
+    }
+  }
+  const int grid = (int)((B + PACK_TB - 1) / PACK_TB);
+  const size_t lds = (size_t)PACK_TB * (W + 1) * (out_dtype == TRS_I64 ? 8 : 4);
+  TRS_REQUIRE(lds <= 64 * 1024, TRS_ESHAPE, "pack_columns: %d columns of %d-byte indices exceed the 64 KB tile", W,
+              out_dtype == TRS_I64 ? 8 : 4);
+  hipStream_t s = (hipStream_t)stream;
+  if (src_dtype == TRS_I64 && out_dtype == TRS_I64)
+    hipLaunchKernelGGL((pack_columns_kernel<int64_t, int64_t>), dim3(grid), dim3(256), lds, s, a, W, B, (int64_t*)out);
+  else if (src_dtype == TRS_I64)
+    hipLaunchKernelGGL((pack_columns_kernel<int64_t, int32_t>), dim3(grid), dim3(256), lds, s, a, W, B, (int32_t*)out);
+  else if (out_dtype == TRS_I64)
+    hipLaunchKernelGGL((pack_columns_kernel<int32_t, int64_t>), dim3(grid), dim3(256), lds, s, a, W, B, (int64_t*)out);
+  else
+    hipLaunchKernelGGL((pack_columns_kernel<int32_t, int32_t>), dim3(grid), dim3(256), lds, s, a, W, B, (int32_t*)out);
+  return check_launch("pack_columns");
+}
 
 extern "C" int trs_mark_timestamp(uint64_t* ring, int32_t capacity, trs_stream_t stream) {
   TRS_REQUIRE(ring != nullptr && capacity > 0, TRS_EINVAL, "mark_timestamp: NULL ring or capacity <= 0");

@@ -5,6 +5,7 @@ Every function takes and returns UN-NAMED tensors on one HIP device (the nn.Modu
 """
 from __future__ import annotations
 
+import ctypes
 import os
 from typing import List, Optional, Sequence, Tuple
 
@@ -171,6 +172,46 @@ def prefetch_row_buckets(idx: torch.Tensor, offsets: Optional[torch.Tensor], V: 
 
 def clear_caches():
     _bucket_cache.clear()
+
+
+# --------------------------------------------------------------------------------------------
+# N2: index staging -- per-field columns -> one (B, N) index matrix
+# --------------------------------------------------------------------------------------------
+def pack_columns_supported(cols: Sequence[torch.Tensor]) -> bool:
+    """One-pass packing applies to >= 2 integer (int64 / int32, one dtype) contiguous HIP tensors of shape (B,) or
+    (B, k) with the same B whose total width fits the kernel's tile."""
+    if len(cols) < 2:
+        return False
+    c0 = cols[0]
+    if not c0.is_cuda or c0.dtype not in (torch.int64, torch.int32) or c0.dim() not in (1, 2):
+        return False
+    W = 0
+    for c in cols:
+        if (not c.is_cuda or c.device != c0.device or c.dtype != c0.dtype or c.dim() not in (1, 2)
+                or c.shape[0] != c0.shape[0] or not c.is_contiguous() or c.has_names()):
+            return False
+        W += 1 if c.dim() == 1 else c.shape[1]
+    return 0 < W <= (127 if c0.dtype == torch.int64 else 255)
+
+
+def pack_columns(cols: Sequence[torch.Tensor], out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """``torch.cat([c.unsqueeze(-1) if c.dim() == 1 else c for c in cols], dim=1)`` in one kernel
+    (inputs/inputs.py:75-80); ``out_dtype=torch.int32`` narrows on the way (caller guarantees the range)."""
+    if not pack_columns_supported(cols):
+        raise ValueError("pack_columns: need >= 2 contiguous int64/int32 HIP tensors of shape (B,) or (B,k), same B")
+    c0 = cols[0]
+    B = c0.shape[0]
+    widths = [1 if c.dim() == 1 else int(c.shape[1]) for c in cols]
+    out_dtype = out_dtype or c0.dtype
+    if out_dtype not in (torch.int64, torch.int32):
+        raise TypeError(f"pack_columns: out_dtype {out_dtype}")
+    out = torch.empty(B, sum(widths), dtype=out_dtype, device=c0.device)
+    n = len(cols)
+    srcs = (ctypes.c_void_p * n)(*[c.data_ptr() for c in cols])
+    wid = (ctypes.c_int32 * n)(*widths)
+    call("trs_pack_columns", srcs, wid, n, index_dtype_code(c0), B, ptr(out),
+         _abi.TRS_I64 if out_dtype == torch.int64 else _abi.TRS_I32, stream_ptr())
+    return out
 
 
 def scatter_rows(rb: RowBuckets, like_table: torch.Tensor, g_rows: Optional[torch.Tensor] = None,

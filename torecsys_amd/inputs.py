@@ -177,7 +177,10 @@ class ValueInput(BaseInput):
 
 class Inputs(BaseInput):
     """Dictionary router, inputs/inputs.py:56-89: for every schema entry gather its named columns,
-    ``unsqueeze`` 1-D ones, ``cat`` on dim 1 and call the embedding module."""
+    ``unsqueeze`` 1-D ones, ``cat`` on dim 1 and call the embedding module.  Integer columns on the HIP device are
+    packed by one kernel (trs_pack_columns) instead of N unsqueezes + a cat, and schema entries that name the same
+    columns (the E=64 and the E=1 table of one model) receive the SAME index tensor, so the row buckets of the batch
+    are built once."""
 
     def __init__(self, schema: Union[Dict[str, nn.Module], None]):
         super().__init__()
@@ -188,16 +191,23 @@ class Inputs(BaseInput):
 
     def forward(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         outputs = {}
+        packed = {}                    # tuple of column names -> packed tensor (shared between schema entries)
         with F_.defer_prefetch():      # row-bucket builds start once every lookup of the batch is enqueued
             for k, emb_fn in self.schema.items():
                 if emb_fn.__class__.__name__ in ['ConcatInput', 'StackedInput']:
                     inp_args = [{i: inputs[i] for i in emb_fn.schema.inputs}]
                 else:
-                    cols = []
-                    for emb_k in emb_fn.schema.inputs:
-                        v = inputs[emb_k]
-                        cols.append(v.unsqueeze(-1) if v.dim() == 1 else v)
-                    inp_args = [cols[0] if len(cols) == 1 else torch.cat(cols, dim=1)]
+                    names = tuple(emb_fn.schema.inputs)
+                    inp = packed.get(names)
+                    if inp is None:
+                        raw = [inputs[emb_k] for emb_k in names]
+                        if F_.pack_columns_supported(raw):
+                            inp = F_.pack_columns(raw)
+                        else:
+                            cols = [v.unsqueeze(-1) if v.dim() == 1 else v for v in raw]
+                            inp = cols[0] if len(cols) == 1 else torch.cat(cols, dim=1)
+                        packed[names] = inp
+                    inp_args = [inp]
                 outputs[k] = emb_fn(*inp_args)
         return outputs
 
