@@ -71,6 +71,9 @@ def parse():
                          "all-to-all of one overlaps the dense compute of the other (default 1: measured slower on "
                          "one GPU -- per-micro-batch host syncs and sparse-gradient accumulation outweigh the overlap)")
     ap.add_argument("--cpu-batch", type=int, default=16384)
+    ap.add_argument("--host-indices", action="store_true",
+                    help="index batches start in host memory: packed into pinned int32 buffers and copied over PCIe "
+                         "inside the timed region (IndexStager), overlapped with the previous step; single-GPU path")
     ap.add_argument("--graph", action="store_true",
                     help="capture the step (forward+backward[+optimizer]) in a hipGraph and replay it; single-GPU path")
     return ap.parse_args()
@@ -223,13 +226,28 @@ def main():
         out = model(**d) if a.model != "dcn" else model(emb_inputs=d["emb_inputs"])
         return crit(out.float(), lab) * scale
 
+    host_idx = a.host_indices and not sharded and MB == 1
+    if host_idx:
+        from torecsys_amd.staging import IndexStager
+        host_ring = [t.cpu().numpy() for t in idx_ring]          # (B,N) int64 arrays in pageable host memory
+        stager = IndexStager(B, N, dev, depth=3)
+        staged = [stager.stage(host_ring[0])]
+
+    def next_indices(k):
+        """index batch of step k: resident in HBM (default) or staged from the host, next batch's copy in flight"""
+        if not host_idx:
+            return idx_ring[k]
+        cur = staged.pop(0).wait()
+        staged.append(stager.stage(host_ring[(k + 1) % RING]))
+        return cur
+
     def step():
         k = counter[0] % RING
         counter[0] += 1
         for p in params:
             p.grad = None
         if MB == 1:
-            loss = fwd_loss(idx_ring[k], label_ring[k], 1.0)
+            loss = fwd_loss(next_indices(k), label_ring[k], 1.0)
             if sharded:      # input-pipeline style hint: start routing the next batch before this backward
                 emb.prefetch_route(idx_ring[(k + 1) % RING])
             loss.backward()
@@ -293,7 +311,7 @@ def main():
         def step():
             k = counter[0] % RING
             counter[0] += 1
-            return gstep(idx_ring[k], label_ring[k])      # copies the batch into the static buffers, replays
+            return gstep(next_indices(k), label_ring[k])      # copies the batch into the static buffers, replays
 
         for _ in range(a.warmup):
             step()
@@ -350,7 +368,7 @@ def main():
                        ("BASELINE.json configs[4] (weak-scaled): DeepFM, " f"{V} rows row-sharded over {world} GPUs, "
                         f"global batch {B * world}"),
                        "model": a.model, "global_batch": B * world, "rows": V, "parallelism": parallelism,
-                       "microbatches": MB, "optimizer": a.optimizer, "hipgraph": bool(use_graph),
+                       "microbatches": MB, "optimizer": a.optimizer, "hipgraph": bool(use_graph), "indices_from_host": bool(host_idx),
                        "fused_lookup_fm": not a.no_fuse, "loss": float(loss),
                        "host_enqueue_ms_per_step": round(enqueue_s / a.steps * 1e3, 4)},
             "roofline": roof,

@@ -272,6 +272,42 @@ int trs_permute_grad(const void* g_block, const void* g_fm, const float* fm_sum,
 int trs_gather_by_pos(const void* rows, const int32_t* pos, int64_t K, int32_t E, int32_t dtype,
                       void* out, trs_stream_t stream);
 
+/* ---- OuterProductNetwork / BilinearInteraction on the (i<j) pair pattern -------
+ * Pair p = (i_p, j_p), i<j, lexicographic (the order of inner_product_network.py:51-52); NC2 = N(N-1)/2.
+ *
+ * OPN 'vec' / 'num'  (outer_product_network.py:123-129):
+ *   out[b,p] = sum_e x[b,i_p,e] * x[b,j_p,e] * kern[p,e]      kern (NC2,E); kern_is_num: kern (NC2), no e index
+ * bwd: gx (B,N,E) and gkern_vec (NC2,E) fp32, ACCUMULATED into (for 'num' the caller sums it over e);
+ * either may be NULL.                                                                              */
+int trs_opn_vec_fwd(const void* x, const void* kern, int32_t kern_is_num, int64_t B, int32_t N, int32_t E,
+                    int32_t dtype, void* out, trs_stream_t stream);
+size_t trs_opn_vec_bwd_workspace_bytes(int64_t B, int32_t N, int32_t E);
+int trs_opn_vec_bwd(const void* g, const void* x, const void* kern, int32_t kern_is_num, int64_t B, int32_t N,
+                    int32_t E, int32_t dtype, void* gx, float* gkern_vec, void* workspace, size_t ws_bytes,
+                    trs_stream_t stream);
+
+/* pair product:  out[b,p,:] = a[b,i_p,:] * c[b,j_p,:] + bias[(bias_per_pair ? p : 0), :]   (bias may be NULL)
+ * Bilinear 'all' (bilinear_interaction.py:72-76) is  a = x W (one GEMM), c = x, shared bias.
+ * bwd: ga[b,i,:] = sum_{p: i_p=i} g[b,p,:] c[b,j_p,:],  gc[b,j,:] = sum_{p: j_p=j} g[b,p,:] a[b,i_p,:].   */
+int trs_pair_mul_fwd(const void* a, const void* c, const void* bias, int32_t bias_per_pair, int64_t B, int32_t N,
+                     int32_t E, int32_t dtype, void* out, trs_stream_t stream);
+int trs_pair_mul_bwd(const void* g, const void* a, const void* c, int64_t B, int32_t N, int32_t E, int32_t dtype,
+                     void* ga, void* gc, trs_stream_t stream);
+
+/* per-pair bilinear form:  T[b,p,:] = x[b,i_p,:] @ W[(w_per_pair ? p : 0)]     W (NC2 | 1, E, E) row-major [e][h]
+ *   mode 0 (OPN 'mat', outer_product_network.py:107-121 with W[p][e][h] = kernel[h,p,e]):
+ *           out[b,p]   = sum_h T[b,p,h] * x[b,j_p,h]
+ *   mode 1 (Bilinear 'each', bilinear_interaction.py:144-149):
+ *           out[b,p,h] = T[b,p,h] * x[b,j_p,h] + bias[(bias_per_pair ? p : 0), h]
+ * bwd_data: gx (B,N,E); gT (B,NC2,E) = dL/dT, written when not NULL (the weight gradient
+ * dW[p] = sum_b x[b,i_p,:]^T gT[b,p,:] is a plain GEMM per field over it).                          */
+int trs_pair_bilinear_fwd(const void* x, const void* W, int32_t w_per_pair, const void* bias, int32_t bias_per_pair,
+                          int32_t mode, int64_t B, int32_t N, int32_t E, int32_t dtype, void* out,
+                          trs_stream_t stream);
+int trs_pair_bilinear_bwd_data(const void* g, const void* x, const void* W, int32_t w_per_pair, int32_t mode,
+                               int64_t B, int32_t N, int32_t E, int32_t dtype, void* gx, void* gT,
+                               trs_stream_t stream);
+
 /* ---- index staging: pack per-field columns into the (B,N) index matrix --------
  * out[b, c] = src_j[b * width_j + t]  for the c-th output column = column t of source j.
  * replaces the per-field unsqueeze + torch.cat of inputs/inputs.py:75-80 by one pass.

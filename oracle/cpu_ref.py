@@ -267,3 +267,44 @@ def shard_bounds(num_rows: int, world: int) -> torch.Tensor:
 def sharded_lookup(shards: Sequence[torch.Tensor], gidx: torch.Tensor, bounds: torch.Tensor) -> torch.Tensor:
     """Gather global row ids from a row-sharded table == lookup in the concatenated table."""
     return F.embedding(gidx, torch.cat(list(shards), dim=0))
+
+
+# ---------------------------------------------------------------------------------------------
+# SURVEY.md 8f N3: the other pair-pattern layers (same (i<j) pair order as the inner product)
+# ---------------------------------------------------------------------------------------------
+def outer_product_layer(x: torch.Tensor, kernel: torch.Tensor, kernel_type: str = "mat") -> torch.Tensor:
+    """(B,N,E) -> (B,NC2).  outer_product_network.py:94-129.
+    'mat': kernel (E,NC2,E): out[b,p] = sum_h sum_e x[b,i_p,e] * K[h,p,e] * x[b,j_p,h]   (:107-121)
+    'vec': kernel (1,NC2,E): out[b,p] = sum_e x[b,i_p,e] * x[b,j_p,e] * K[0,p,e]          (:123-129)
+    'num': kernel (1,NC2,1): out[b,p] = K[0,p,0] * sum_e x[b,i_p,e] * x[b,j_p,e]."""
+    r, c = pair_indices(x.shape[1])
+    p, q = x[:, r], x[:, c]
+    if kernel_type == "mat":
+        kp = (p.unsqueeze(1) * kernel.unsqueeze(0)).sum(dim=-1)      # (B,E_h,NC2)
+        return (kp.permute(0, 2, 1) * q).sum(dim=-1)
+    if kernel_type in ("vec", "num"):
+        return (p * q * kernel).sum(dim=-1)
+    raise ValueError('kernel_type only allows: ["mat", "num", "vec"].')
+
+
+def afm_layer(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor):
+    """(B,N,E) -> ((B,E), (B,NC2,1)).  attentional_factorization_machine.py:86-125 with both dropouts at p = 0:
+    prod[b,p,:] = x_i * x_j;  score = softmax_p(W2 relu(W1 prod + b1) + b2);  out[b,:] = sum_p score[b,p] prod[b,p,:]."""
+    r, c = pair_indices(x.shape[1])
+    prod = x[:, r] * x[:, c]
+    h = torch.relu(torch.nn.functional.linear(prod, w1, b1))
+    attn = torch.softmax(torch.nn.functional.linear(h, w2, b2), dim=1)
+    return (prod * attn).sum(dim=1), attn
+
+
+def bilinear_layer(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, bilinear_type: str = "all") -> torch.Tensor:
+    """(B,N,E) -> (B,NC2,E).  bilinear_interaction.py:230-255.
+    'all'  (:72-76):   out[b,p,:] = (x[b,i_p,:] @ W) * x[b,j_p,:] + bias,        W (E,E), bias (E)
+    'each' (:144-149): out[b,p,:] = (x[b,i_p,:] @ W[p]) * x[b,j_p,:] + bias[p],  W (NC2,E,E), bias (NC2,E)."""
+    r, c = pair_indices(x.shape[1])
+    p, q = x[:, r], x[:, c]
+    if bilinear_type == "all":
+        return torch.matmul(p, weight) * q + bias
+    if bilinear_type == "each":
+        return torch.einsum("bpe,peh->bph", p, weight) * q + bias
+    raise ValueError('bilinear_type only allows: ["all", "each", "interaction"].')

@@ -51,6 +51,12 @@ def golden():
 LAYER_SHAPES = [(8, 4, 128), (16, 6, 64), (32, 12, 8), (32, 10, 16), (8, 39, 64)]
 MODEL_SHAPES = [(32, 10, 16), (16, 39, 64), (16, 6, 64)]
 CIN_CASES = ["a", "b", "c", "d", "e", "f"]
+PAIR_SHAPES = [(8, 4, 128), (16, 6, 64), (32, 12, 8), (32, 10, 16), (8, 12, 64), (4, 39, 64)]   # pairs.npz (8f N3 layers)
+
+
+def pair_heavy_ok(N, E):
+    """make_golden_pairs.py skips the per-pair E x E parameter variants ('mat', 'each') above 300 k elements"""
+    return N * (N - 1) // 2 * E * E <= 300_000
 
 
 def rel_err(a, b):

@@ -221,3 +221,65 @@ def test_models(golden, shape):
     (y * gout).sum().backward()
     assert rel_err(ew.grad, G(t + "/xdfm_gemb")) <= 5e-5
     assert rel_err(fw.grad, G(t + "/xdfm_gfeat")) <= 1e-5
+
+
+# ---- OuterProductNetwork / AFM / BilinearInteraction (tests/golden/make_golden_pairs.py) ----
+from conftest import PAIR_SHAPES, pair_heavy_ok  # noqa: E402
+
+
+@pytest.mark.parametrize("shape", PAIR_SHAPES)
+def test_outer_product_afm_bilinear(golden, shape):
+    G = golden("pairs")
+    B, N, E = shape
+    t = _tag(shape)
+    x = G(f"x/{t}")
+    for kt in ("mat", "vec", "num"):
+        if kt == "mat" and not pair_heavy_ok(N, E):
+            assert not G.has(f"opn_mat/{t}/out")
+            continue
+        xa = x.clone().requires_grad_()
+        k = G(f"opn_{kt}/{t}/kernel").requires_grad_()
+        y = O.outer_product_layer(xa, k, kt)
+        assert rel_err(y, G(f"opn_{kt}/{t}/out")) <= 2e-6
+        assert G(f"opn_{kt}/{t}/names") == ["B", "O"]
+        (y * G(f"opn_{kt}/{t}/gout")).sum().backward()
+        assert rel_err(xa.grad, G(f"opn_{kt}/{t}/gx")) <= 2e-6
+        assert rel_err(k.grad, G(f"opn_{kt}/{t}/gkernel")) <= 2e-6
+    # AFM
+    xa = G(f"afm/{t}/x").requires_grad_()
+    ps = [G(f"afm/{t}/{n}").requires_grad_() for n in ("W1", "b1", "W2", "b2")]
+    y, attn = O.afm_layer(xa, *ps)
+    assert rel_err(y, G(f"afm/{t}/out")) <= TOL * 2
+    assert rel_err(attn, G(f"afm/{t}/attn")) <= TOL * 2
+    assert G(f"afm/{t}/names") == ["B", "E"] and G(f"afm/{t}/attn_names") == ["None"] * 3
+    ((y * G(f"afm/{t}/gout")).sum() + (attn * G(f"afm/{t}/gattn")).sum()).backward()
+    assert rel_err(xa.grad, G(f"afm/{t}/gx")) <= 5e-6
+    for p_, n in zip(ps, ("gW1", "gb1", "gW2", "gb2")):
+        assert rel_err(p_.grad, G(f"afm/{t}/{n}")) <= 1e-5, n
+    # Bilinear
+    for bt in ("all", "each"):
+        if bt == "each" and not pair_heavy_ok(N, E):
+            continue
+        xa = x.clone().requires_grad_()
+        W = G(f"bil_{bt}/{t}/W").requires_grad_()
+        b = G(f"bil_{bt}/{t}/b").requires_grad_()
+        y = O.bilinear_layer(xa, W, b, bt)
+        assert rel_err(y, G(f"bil_{bt}/{t}/out")) <= 2e-6
+        assert G(f"bil_{bt}/{t}/names") == ["B", "N", "O"]
+        (y * G(f"bil_{bt}/{t}/gout")).sum().backward()
+        assert rel_err(xa.grad, G(f"bil_{bt}/{t}/gx")) <= 2e-6
+        assert rel_err(W.grad, G(f"bil_{bt}/{t}/gW")) <= 2e-6
+        assert rel_err(b.grad, G(f"bil_{bt}/{t}/gb")) <= 2e-6
+
+
+def test_pair_layer_quirks_in_reference(golden):
+    """bias=False cannot be constructed in the reference (int64 Parameter, bilinear_interaction.py:62),
+    'interaction' is NotImplemented (:214), an unknown OPN kernel type is a ValueError (outer_product_network.py:66)."""
+    G = golden("pairs")
+    assert G("raises/bil_nobias") == ["RuntimeError"]
+    assert G("raises/bil_interaction") == ["NotImplementedError"]
+    assert G("raises/opn_badtype") == ["ValueError"]
+    with pytest.raises(ValueError):
+        O.outer_product_layer(torch.zeros(2, 3, 4), torch.zeros(1, 3, 4), "cube")
+    with pytest.raises(ValueError):
+        O.bilinear_layer(torch.zeros(2, 3, 4), torch.zeros(4, 4), torch.zeros(4), "interaction")

@@ -1,0 +1,512 @@
+// the other layers built on the (i<j) field-pair pattern of the inner product (pair.hip):
+//   OuterProductNetworkLayer   layers/ctr/outer_product_network.py:94-129   ('mat' / 'vec' / 'num' kernels)
+//   BilinearInteractionLayer   layers/ctr/bilinear_interaction.py:230-255   ('all' / 'each')
+//   (AttentionalFactorizationMachineLayer lives in afm.hip)
+// The reference gathers p = x[:, row_idx] and q = x[:, col_idx] -- two (B, NC2, E) tensors, 6.2 GB each at
+// B = 65 536, N = 39, E = 64 bf16 -- before any arithmetic.  Here a workgroup keeps the (N x E) block of a
+// sample in LDS and walks the pairs; nothing of size B*NC2*E exists unless the layer's own output has it.
+//
+// Kernels in this file (fp32 math, T = float | bf16):
+//   pairw_dot_*      out[b,p]   = sum_e x_i[e] x_j[e] k[p,e]              OPN 'vec' / 'num'
+//   pair_mul_*       out[b,p,:] = a_i[:] * c_j[:] + bias                   Bilinear 'all' after T = x W (one GEMM)
+//   pair_bil_*       T = x_i W_p;  out[b,p] = sum_h T_h x_j[h]  (OPN 'mat')  |  out[b,p,:] = T * x_j + bias_p ('each')
+// Lane layout: a group of EL lanes (EL = min(64, pow2 >= E)) owns one pair at a time, lanes run along e / h, so
+// per-pair parameter rows are read coalesced and the E-reductions are wavefront reductions (DPP / ds_swizzle).
+#include <algorithm>
+
+#include "trs_common.hpp"
+
+namespace trs {
+
+__device__ __forceinline__ void pair_ij(int p, int N, int* i_out, int* j_out) {
+  // p = i*(2N-i-1)/2 + (j-i-1), i < j
+  const float d = (float)(2 * N - 1);
+  int i = (int)((d - sqrtf(fmaxf(d * d - 8.f * (float)p, 0.f))) * 0.5f);
+  if (i < 0) i = 0;
+  if (i > N - 2) i = N - 2;
+  while (i > 0 && i * (2 * N - i - 1) / 2 > p) --i;
+  while (i < N - 2 && (i + 1) * (2 * N - i - 2) / 2 <= p) ++i;
+  *i_out = i;
+  *j_out = p - i * (2 * N - i - 1) / 2 + i + 1;
+}
+
+__device__ __forceinline__ float group_reduce(float v, int EL) {
+  // sum over the EL-lane group (EL a power of two <= 64)
+  for (int o = EL >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename T>
+__device__ __forceinline__ void stage_block(const T* __restrict__ src, float* __restrict__ dst, int n) {
+  for (int e = threadIdx.x; e < n; e += blockDim.x) dst[e] = to_f32(src[e]);
+}
+
+static inline int pow2_lanes(int E) {
+  int el = 1;
+  while (el < E && el < 64) el <<= 1;
+  return el;
+}
+
+// ---------------------------------------------------------------------------------------------
+// OPN 'vec' / 'num':  out[b,p] = sum_e x_i[e] x_j[e] k[p*kp + e*ke]      (vec: kp=E, ke=1; num: kp=1, ke=0)
+template <typename T>
+__global__ __launch_bounds__(256) void pairw_dot_fwd_kernel(const T* __restrict__ x, const T* __restrict__ kern, int kp,
+                                                            int ke, int64_t B, int N, int E, int EL,
+                                                            T* __restrict__ out) {
+  extern __shared__ float smem[];
+  float* xs = smem;                      // [N][E]
+  const int P = N * (N - 1) / 2;
+  const int groups = blockDim.x / EL, grp = threadIdx.x / EL, e0 = threadIdx.x % EL;
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    stage_block(x + b * N * E, xs, N * E);
+    __syncthreads();
+    for (int p = grp; p < P; p += groups) {
+      int i, j;
+      pair_ij(p, N, &i, &j);
+      float acc = 0.f;
+      for (int e = e0; e < E; e += EL) acc = fmaf(xs[i * E + e] * xs[j * E + e], to_f32(kern[(int64_t)p * kp + e * ke]), acc);
+      acc = group_reduce(acc, EL);
+      if (e0 == 0) out[b * P + p] = from_f32<T>(acc);
+    }
+  }
+}
+
+// data gradient: gx_i[e] += g k x_j[e], gx_j[e] += g k x_i[e]   (per-sample LDS accumulators, ds_add_f32)
+template <typename T>
+__global__ __launch_bounds__(256) void pairw_dot_bwd_data_kernel(const T* __restrict__ g, const T* __restrict__ x,
+                                                                 const T* __restrict__ kern, int kp, int ke, int64_t B,
+                                                                 int N, int E, int EL, T* __restrict__ gx) {
+  extern __shared__ float smem[];
+  float* xs = smem;
+  float* gs = smem + N * E;
+  const int P = N * (N - 1) / 2;
+  const int groups = blockDim.x / EL, grp = threadIdx.x / EL, e0 = threadIdx.x % EL;
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    stage_block(x + b * N * E, xs, N * E);
+    for (int e = threadIdx.x; e < N * E; e += blockDim.x) gs[e] = 0.f;
+    __syncthreads();
+    for (int p = grp; p < P; p += groups) {
+      int i, j;
+      pair_ij(p, N, &i, &j);
+      const float gp = to_f32(g[b * P + p]);
+      for (int e = e0; e < E; e += EL) {
+        const float w = gp * to_f32(kern[(int64_t)p * kp + e * ke]);
+        atomicAdd(&gs[i * E + e], w * xs[j * E + e]);
+        atomicAdd(&gs[j * E + e], w * xs[i * E + e]);
+      }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < N * E; e += blockDim.x) gx[b * N * E + e] = from_f32<T>(gs[e]);
+  }
+}
+
+// weight gradient: gk[p,e] = sum_b g[b,p] x_i[e] x_j[e].  A workgroup owns a range of samples and walks the pairs
+// in chunks of PC whose fp32 partial (PC x E) lives in LDS; every (pair, e) slot is owned by one fixed lane, so
+// the accumulation needs no atomics and is deterministic.  Partials per workgroup go to the workspace.
+template <typename T>
+__global__ __launch_bounds__(256) void pairw_dot_bwd_weight_kernel(const T* __restrict__ g, const T* __restrict__ x,
+                                                                   int64_t B, int N, int E, int EL, int PC,
+                                                                   float* __restrict__ partial /* [grid][P][E] */) {
+  extern __shared__ float smem[];
+  float* xs = smem;                 // [N][E]
+  float* acc = smem + N * E;        // [PC][E]
+  const int P = N * (N - 1) / 2;
+  const int groups = blockDim.x / EL, grp = threadIdx.x / EL, e0 = threadIdx.x % EL;
+  const int64_t per = (B + gridDim.x - 1) / gridDim.x;
+  const int64_t b_lo = (int64_t)blockIdx.x * per, b_hi = b_lo + per < B ? b_lo + per : B;
+  float* mine = partial + (size_t)blockIdx.x * P * E;
+  for (int p0 = 0; p0 < P; p0 += PC) {
+    const int pc = P - p0 < PC ? P - p0 : PC;
+    __syncthreads();
+    for (int e = threadIdx.x; e < pc * E; e += blockDim.x) acc[e] = 0.f;
+    for (int64_t b = b_lo; b < b_hi; ++b) {
+      __syncthreads();
+      stage_block(x + b * N * E, xs, N * E);
+      __syncthreads();
+      for (int q = grp; q < pc; q += groups) {
+        int i, j;
+        pair_ij(p0 + q, N, &i, &j);
+        const float gp = to_f32(g[b * P + p0 + q]);
+        for (int e = e0; e < E; e += EL) acc[q * E + e] = fmaf(gp, xs[i * E + e] * xs[j * E + e], acc[q * E + e]);
+      }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < pc * E; e += blockDim.x) mine[(size_t)p0 * E + e] = acc[e];
+  }
+}
+
+__global__ __launch_bounds__(256) void pairx_reduce_partials_kernel(const float* __restrict__ part, int nparts, int64_t n,
+                                                                    float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * n + i];
+    out[i] += s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pair product with optional bias:  out[b,p,:] = a[b,i,:] * c[b,j,:] + bias[p*bp, :]     (bp = 0 shared, 1 per pair)
+template <typename T>
+__global__ __launch_bounds__(256) void pair_mul_fwd_kernel(const T* __restrict__ a, const T* __restrict__ c,
+                                                           const T* __restrict__ bias, int bp, int64_t B, int N, int E,
+                                                           T* __restrict__ out) {
+  extern __shared__ float smem[];
+  float* as = smem;
+  float* cs = smem + N * E;
+  constexpr int VE = Vec16<T>::VE;
+  const int P = N * (N - 1) / 2;
+  const int vpr = E / VE;                     // 16-byte vectors per row (E % VE == 0 checked by the host)
+  const int groups = blockDim.x / vpr, grp = threadIdx.x / vpr, v = threadIdx.x % vpr;
+  const bool active = grp < groups;
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    stage_block(a + b * N * E, as, N * E);
+    stage_block(c + b * N * E, cs, N * E);
+    __syncthreads();
+    if (!active) continue;
+    uint4* orow = reinterpret_cast<uint4*>(out + (b * P) * (int64_t)E);
+    for (int p = grp; p < P; p += groups) {
+      int i, j;
+      pair_ij(p, N, &i, &j);
+      float r[VE];
+#pragma unroll
+      for (int k = 0; k < VE; ++k) {
+        const int e = v * VE + k;
+        r[k] = as[i * E + e] * cs[j * E + e];
+        if (bias != nullptr) r[k] += to_f32(bias[(int64_t)p * bp * E + e]);
+      }
+      const uint4 u = Vec16<T>::pack(r);
+      __builtin_nontemporal_store(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, u),
+                                  reinterpret_cast<__attribute__((ext_vector_type(4))) unsigned*>(orow + (int64_t)p * vpr + v));
+    }
+  }
+}
+
+// ga[b,i,:] = sum_{p: i_p = i} g[b,p,:] c[b,j_p,:],   gc[b,j,:] = sum_{p: j_p = j} g[b,p,:] a[b,i_p,:]
+template <typename T>
+__global__ __launch_bounds__(256) void pair_mul_bwd_kernel(const T* __restrict__ g, const T* __restrict__ a,
+                                                           const T* __restrict__ c, int64_t B, int N, int E,
+                                                           T* __restrict__ ga, T* __restrict__ gc) {
+  extern __shared__ float smem[];
+  float* as = smem;
+  float* cs = smem + N * E;
+  float* gas = smem + 2 * N * E;
+  float* gcs = smem + 3 * N * E;
+  constexpr int VE = Vec16<T>::VE;
+  const int P = N * (N - 1) / 2;
+  const int vpr = E / VE;
+  const int groups = blockDim.x / vpr, grp = threadIdx.x / vpr, v = threadIdx.x % vpr;
+  const bool active = grp < groups;
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    stage_block(a + b * N * E, as, N * E);
+    stage_block(c + b * N * E, cs, N * E);
+    for (int e = threadIdx.x; e < 2 * N * E; e += blockDim.x) gas[e] = 0.f;      // gas and gcs are adjacent
+    __syncthreads();
+    if (active) {
+      const uint4* grow = reinterpret_cast<const uint4*>(g + (b * P) * (int64_t)E);
+      for (int p = grp; p < P; p += groups) {
+        int i, j;
+        pair_ij(p, N, &i, &j);
+        float gv[VE];
+        Vec16<T>::unpack(grow[(int64_t)p * vpr + v], gv);
+#pragma unroll
+        for (int k = 0; k < VE; ++k) {
+          const int e = v * VE + k;
+          atomicAdd(&gas[i * E + e], gv[k] * cs[j * E + e]);
+          atomicAdd(&gcs[j * E + e], gv[k] * as[i * E + e]);
+        }
+      }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < N * E; e += blockDim.x) {
+      ga[b * N * E + e] = from_f32<T>(gas[e]);
+      gc[b * N * E + e] = from_f32<T>(gcs[e]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-pair bilinear form, generic path:  T[h] = sum_e x_i[e] W[p*wp][e][h]
+//   MODE 0 (OPN 'mat'):        out[b,p]   = sum_h T[h] x_j[h]
+//   MODE 1 (Bilinear 'each'):  out[b,p,h] = T[h] x_j[h] + bias[p*bp][h]
+// A workgroup stages S samples and every wave walks the pairs with its lanes along h, so a row of W_p is read
+// once (coalesced) per S samples.  This is the any-shape / fp32 path; bf16 with E = 64 takes pair_bil_mfma_*.
+template <typename T, int MODE, int S>
+__global__ __launch_bounds__(256) void pair_bil_fwd_kernel(const T* __restrict__ x, const T* __restrict__ W, int wp,
+                                                           const T* __restrict__ bias, int bp, int64_t B, int N, int E,
+                                                           T* __restrict__ out) {
+  extern __shared__ float smem[];
+  float* xs = smem;                    // [S][N][E]
+  const int P = N * (N - 1) / 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  for (int64_t b0 = (int64_t)blockIdx.x * S; b0 < B; b0 += (int64_t)gridDim.x * S) {
+    const int ns = (int)(B - b0 < S ? B - b0 : S);
+    __syncthreads();
+    stage_block(x + b0 * N * E, xs, ns * N * E);
+    __syncthreads();
+    for (int p = wave; p < P; p += nwaves) {
+      int i, j;
+      pair_ij(p, N, &i, &j);
+      const T* Wp = W + (int64_t)p * wp * E * E;
+      float rsum[S];
+#pragma unroll
+      for (int s = 0; s < S; ++s) rsum[s] = 0.f;
+      for (int h0 = 0; h0 < E; h0 += 64) {
+        const int h = h0 + lane;
+        float t[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) t[s] = 0.f;
+        if (h < E) {
+          for (int e = 0; e < E; ++e) {
+            const float w = to_f32(Wp[(int64_t)e * E + h]);
+#pragma unroll
+            for (int s = 0; s < S; ++s) t[s] = fmaf(xs[(s * N + i) * E + e], w, t[s]);
+          }
+#pragma unroll
+          for (int s = 0; s < S; ++s) {
+            if (s < ns) {
+              const float tv = t[s] * xs[(s * N + j) * E + h];
+              if (MODE == 0) {
+                rsum[s] += tv;
+              } else {
+                float r = tv;
+                if (bias != nullptr) r += to_f32(bias[(int64_t)p * bp * E + h]);
+                out[((b0 + s) * P + p) * (int64_t)E + h] = from_f32<T>(r);
+              }
+            }
+          }
+        }
+      }
+      if (MODE == 0) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          const float r = group_reduce(rsum[s], 64);        // wavefront reduction over h
+          if (lane == 0 && s < ns) out[(b0 + s) * P + p] = from_f32<T>(r);
+        }
+      }
+    }
+  }
+}
+
+// data gradient of the bilinear form (recomputes T):
+//   MODE 0: gT[h] = g[b,p] x_j[h];    gx_j[h] += g[b,p] T[h]
+//   MODE 1: gT[h] = g[b,p,h] x_j[h];  gx_j[h] += g[b,p,h] T[h]
+//   gx_i[e] += sum_h gT[h] W_p[e][h];  gT is also written out (B,P,E) when gT_out != NULL (weight gradient GEMMs)
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void pair_bil_bwd_data_kernel(const T* __restrict__ g, const T* __restrict__ x,
+                                                                const T* __restrict__ W, int wp, int64_t B, int N,
+                                                                int E, T* __restrict__ gx, T* __restrict__ gT_out) {
+  extern __shared__ float smem[];
+  float* xs = smem;                    // [N][E]
+  float* gs = smem + N * E;            // [N][E]
+  float* gts = smem + 2 * N * E;       // [nwaves][E]
+  const int P = N * (N - 1) / 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  float* gt = gts + wave * E;
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    stage_block(x + b * N * E, xs, N * E);
+    for (int e = threadIdx.x; e < N * E; e += blockDim.x) gs[e] = 0.f;
+    __syncthreads();
+    for (int p = wave; p < P; p += nwaves) {
+      int i, j;
+      pair_ij(p, N, &i, &j);
+      const T* Wp = W + (int64_t)p * wp * E * E;
+      for (int h = lane; h < E; h += 64) {
+        float t = 0.f;
+        for (int e = 0; e < E; ++e) t = fmaf(xs[i * E + e], to_f32(Wp[(int64_t)e * E + h]), t);
+        const float gv = MODE == 0 ? to_f32(g[b * P + p]) : to_f32(g[(b * P + p) * (int64_t)E + h]);
+        const float gth = gv * xs[j * E + h];
+        gt[h] = gth;
+        if (gT_out != nullptr) gT_out[(b * P + p) * (int64_t)E + h] = from_f32<T>(gth);
+        atomicAdd(&gs[j * E + h], gv * t);
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int e = lane; e < E; e += 64) {
+        float r = 0.f;
+        const T* row = Wp + (int64_t)e * E;
+        for (int h = 0; h < E; ++h) r = fmaf(gt[h], to_f32(row[h]), r);
+        atomicAdd(&gs[i * E + e], r);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < N * E; e += blockDim.x) gx[b * N * E + e] = from_f32<T>(gs[e]);
+  }
+}
+
+static int sample_grid(int64_t B, int per_block = 1) {
+  const int64_t need = (B + per_block - 1) / per_block;
+  return (int)std::min<int64_t>(need, 256 * 8);
+}
+
+}  // namespace trs
+
+using namespace trs;
+
+#define TRS_PAIRX_COMMON(name)                                                                             \
+  TRS_REQUIRE(B >= 0 && N >= 0 && E > 0, TRS_EINVAL, name ": bad size");                                   \
+  TRS_REQUIRE(dtype == TRS_F32 || dtype == TRS_BF16, TRS_EDTYPE, name ": dtype %d", dtype);                \
+  TRS_REQUIRE(N <= 256, TRS_ESHAPE, name ": N = %d > 256 fields", N)
+
+extern "C" int trs_opn_vec_fwd(const void* x, const void* kern, int32_t kern_is_num, int64_t B, int32_t N, int32_t E,
+                               int32_t dtype, void* out, trs_stream_t stream) {
+  TRS_PAIRX_COMMON("opn_vec_fwd");
+  if (B == 0 || N < 2) return TRS_OK;
+  TRS_REQUIRE(x && kern && out, TRS_EINVAL, "opn_vec_fwd: NULL pointer");
+  const size_t lds = (size_t)N * E * 4;
+  TRS_REQUIRE(lds <= 64 * 1024, TRS_ESHAPE, "opn_vec_fwd: N*E = %d exceeds the 16384-element LDS block", N * E);
+  const int EL = pow2_lanes(E), kp = kern_is_num ? 1 : E, ke = kern_is_num ? 0 : 1;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == TRS_F32)
+    hipLaunchKernelGGL((pairw_dot_fwd_kernel<float>), dim3(sample_grid(B)), dim3(256), lds, s, (const float*)x,
+                       (const float*)kern, kp, ke, B, N, E, EL, (float*)out);
+  else
+    hipLaunchKernelGGL((pairw_dot_fwd_kernel<bf16_t>), dim3(sample_grid(B)), dim3(256), lds, s, (const bf16_t*)x,
+                       (const bf16_t*)kern, kp, ke, B, N, E, EL, (bf16_t*)out);
+  return check_launch("opn_vec_fwd");
+}
+
+static int opn_vec_weight_blocks(int64_t B) { return (int)std::min<int64_t>(256, std::max<int64_t>(1, B / 16)); }
+static int opn_vec_chunk(int N, int E) {
+  const int budget = 48 * 1024 / 4 - N * E;          // floats left for the partial after the x block
+  return std::max(1, budget / E);
+}
+
+extern "C" size_t trs_opn_vec_bwd_workspace_bytes(int64_t B, int32_t N, int32_t E) {
+  if (B <= 0 || N < 2 || E <= 0) return 256;
+  return (size_t)opn_vec_weight_blocks(B) * (size_t)(N * (N - 1) / 2) * E * 4 + 256;
+}
+
+extern "C" int trs_opn_vec_bwd(const void* g, const void* x, const void* kern, int32_t kern_is_num, int64_t B, int32_t N,
+                               int32_t E, int32_t dtype, void* gx, float* gkern_vec, void* workspace, size_t ws_bytes,
+                               trs_stream_t stream) {
+  TRS_PAIRX_COMMON("opn_vec_bwd");
+  if (B == 0 || N < 2) return TRS_OK;
+  TRS_REQUIRE(g && x && kern, TRS_EINVAL, "opn_vec_bwd: NULL pointer");
+  TRS_REQUIRE((size_t)N * E * 4 * 2 <= 64 * 1024, TRS_ESHAPE, "opn_vec_bwd: N*E = %d exceeds the 8192-element LDS block",
+              N * E);
+  const int EL = pow2_lanes(E), kp = kern_is_num ? 1 : E, ke = kern_is_num ? 0 : 1;
+  hipStream_t s = (hipStream_t)stream;
+  if (gx != nullptr) {
+    const size_t lds = (size_t)N * E * 4 * 2;
+    if (dtype == TRS_F32)
+      hipLaunchKernelGGL((pairw_dot_bwd_data_kernel<float>), dim3(sample_grid(B)), dim3(256), lds, s, (const float*)g,
+                         (const float*)x, (const float*)kern, kp, ke, B, N, E, EL, (float*)gx);
+    else
+      hipLaunchKernelGGL((pairw_dot_bwd_data_kernel<bf16_t>), dim3(sample_grid(B)), dim3(256), lds, s,
+                         (const bf16_t*)g, (const bf16_t*)x, (const bf16_t*)kern, kp, ke, B, N, E, EL, (bf16_t*)gx);
+  }
+  if (gkern_vec != nullptr) {
+    // gkern_vec: (NC2, E) fp32, accumulated into ('num': the caller sums it over e)
+    TRS_REQUIRE(workspace != nullptr && ws_bytes >= trs_opn_vec_bwd_workspace_bytes(B, N, E), TRS_EWORKSPACE,
+                "opn_vec_bwd: workspace too small");
+    const int P = N * (N - 1) / 2, nblk = opn_vec_weight_blocks(B), PC = std::min(P, opn_vec_chunk(N, E));
+    const size_t lds = (size_t)(N * E + PC * E) * 4;
+    float* part = (float*)workspace;
+    if (dtype == TRS_F32)
+      hipLaunchKernelGGL((pairw_dot_bwd_weight_kernel<float>), dim3(nblk), dim3(256), lds, s, (const float*)g,
+                         (const float*)x, B, N, E, EL, PC, part);
+    else
+      hipLaunchKernelGGL((pairw_dot_bwd_weight_kernel<bf16_t>), dim3(nblk), dim3(256), lds, s, (const bf16_t*)g,
+                         (const bf16_t*)x, B, N, E, EL, PC, part);
+    const int64_t n = (int64_t)P * E;
+    hipLaunchKernelGGL(pairx_reduce_partials_kernel, dim3((int)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, s,
+                       part, nblk, n, gkern_vec);
+  }
+  return check_launch("opn_vec_bwd");
+}
+
+extern "C" int trs_pair_mul_fwd(const void* a, const void* c, const void* bias, int32_t bias_per_pair, int64_t B,
+                                int32_t N, int32_t E, int32_t dtype, void* out, trs_stream_t stream) {
+  TRS_PAIRX_COMMON("pair_mul_fwd");
+  if (B == 0 || N < 2) return TRS_OK;
+  TRS_REQUIRE(a && c && out, TRS_EINVAL, "pair_mul_fwd: NULL pointer");
+  const int VE = dtype == TRS_F32 ? 4 : 8;
+  TRS_REQUIRE(E % VE == 0 && E / VE <= 256, TRS_ESHAPE, "pair_mul_fwd: E = %d must be a multiple of %d (16-byte rows)", E,
+              VE);
+  TRS_REQUIRE(aligned16(a) && aligned16(c) && aligned16(out), TRS_EALIGN, "pair_mul_fwd: pointers must be 16-byte aligned");
+  const size_t lds = (size_t)N * E * 4 * 2;
+  TRS_REQUIRE(lds <= 64 * 1024, TRS_ESHAPE, "pair_mul_fwd: N*E = %d exceeds the 8192-element LDS block", N * E);
+  hipStream_t s = (hipStream_t)stream;
+  const int bp = bias_per_pair ? 1 : 0;
+  if (dtype == TRS_F32)
+    hipLaunchKernelGGL((pair_mul_fwd_kernel<float>), dim3(sample_grid(B)), dim3(256), lds, s, (const float*)a,
+                       (const float*)c, (const float*)bias, bp, B, N, E, (float*)out);
+  else
+    hipLaunchKernelGGL((pair_mul_fwd_kernel<bf16_t>), dim3(sample_grid(B)), dim3(256), lds, s, (const bf16_t*)a,
+                       (const bf16_t*)c, (const bf16_t*)bias, bp, B, N, E, (bf16_t*)out);
+  return check_launch("pair_mul_fwd");
+}
+
+extern "C" int trs_pair_mul_bwd(const void* g, const void* a, const void* c, int64_t B, int32_t N, int32_t E,
+                                int32_t dtype, void* ga, void* gc, trs_stream_t stream) {
+  TRS_PAIRX_COMMON("pair_mul_bwd");
+  if (B == 0 || N < 2) return TRS_OK;
+  TRS_REQUIRE(g && a && c && ga && gc, TRS_EINVAL, "pair_mul_bwd: NULL pointer");
+  const int VE = dtype == TRS_F32 ? 4 : 8;
+  TRS_REQUIRE(E % VE == 0 && E / VE <= 256, TRS_ESHAPE, "pair_mul_bwd: E = %d must be a multiple of %d (16-byte rows)", E,
+              VE);
+  TRS_REQUIRE(aligned16(g), TRS_EALIGN, "pair_mul_bwd: g must be 16-byte aligned");
+  const size_t lds = (size_t)N * E * 4 * 4;
+  TRS_REQUIRE(lds <= 64 * 1024, TRS_ESHAPE, "pair_mul_bwd: N*E = %d exceeds the 4096-element LDS block", N * E);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == TRS_F32)
+    hipLaunchKernelGGL((pair_mul_bwd_kernel<float>), dim3(sample_grid(B)), dim3(256), lds, s, (const float*)g,
+                       (const float*)a, (const float*)c, B, N, E, (float*)ga, (float*)gc);
+  else
+    hipLaunchKernelGGL((pair_mul_bwd_kernel<bf16_t>), dim3(sample_grid(B)), dim3(256), lds, s, (const bf16_t*)g,
+                       (const bf16_t*)a, (const bf16_t*)c, B, N, E, (bf16_t*)ga, (bf16_t*)gc);
+  return check_launch("pair_mul_bwd");
+}
+
+extern "C" int trs_pair_bilinear_fwd(const void* x, const void* W, int32_t w_per_pair, const void* bias,
+                                     int32_t bias_per_pair, int32_t mode, int64_t B, int32_t N, int32_t E, int32_t dtype,
+                                     void* out, trs_stream_t stream) {
+  TRS_PAIRX_COMMON("pair_bilinear_fwd");
+  if (B == 0 || N < 2) return TRS_OK;
+  TRS_REQUIRE(x && W && out, TRS_EINVAL, "pair_bilinear_fwd: NULL pointer");
+  TRS_REQUIRE(mode == 0 || mode == 1, TRS_EINVAL, "pair_bilinear_fwd: mode %d (0 = sum over h, 1 = per-h output)", mode);
+  TRS_REQUIRE((size_t)N * E * 4 <= 64 * 1024, TRS_ESHAPE, "pair_bilinear_fwd: N*E = %d exceeds the LDS block", N * E);
+  const int S = (size_t)N * E * 4 * 4 <= 64 * 1024 && B >= 4 ? 4 : 1;
+  const size_t lds = (size_t)S * N * E * 4;
+  const int wp = w_per_pair ? 1 : 0, bp = bias_per_pair ? 1 : 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = sample_grid(B, S);
+#define TRS_BIL(T_, MODE_, S_)                                                                                       \
+  hipLaunchKernelGGL((pair_bil_fwd_kernel<T_, MODE_, S_>), dim3(grid), dim3(256), lds, s, (const T_*)x, (const T_*)W, \
+                     wp, (const T_*)bias, bp, B, N, E, (T_*)out)
+  if (dtype == TRS_F32) {
+    if (mode == 0) { if (S == 4) TRS_BIL(float, 0, 4); else TRS_BIL(float, 0, 1); }
+    else { if (S == 4) TRS_BIL(float, 1, 4); else TRS_BIL(float, 1, 1); }
+  } else {
+    if (mode == 0) { if (S == 4) TRS_BIL(bf16_t, 0, 4); else TRS_BIL(bf16_t, 0, 1); }
+    else { if (S == 4) TRS_BIL(bf16_t, 1, 4); else TRS_BIL(bf16_t, 1, 1); }
+  }
+#undef TRS_BIL
+  return check_launch("pair_bilinear_fwd");
+}
+
+extern "C" int trs_pair_bilinear_bwd_data(const void* g, const void* x, const void* W, int32_t w_per_pair, int32_t mode,
+                                          int64_t B, int32_t N, int32_t E, int32_t dtype, void* gx, void* gT,
+                                          trs_stream_t stream) {
+  TRS_PAIRX_COMMON("pair_bilinear_bwd_data");
+  if (B == 0 || N < 2) return TRS_OK;
+  TRS_REQUIRE(g && x && W && gx, TRS_EINVAL, "pair_bilinear_bwd_data: NULL pointer");
+  TRS_REQUIRE(mode == 0 || mode == 1, TRS_EINVAL, "pair_bilinear_bwd_data: mode %d", mode);
+  const size_t lds = ((size_t)2 * N * E + 4 * E) * 4;
+  TRS_REQUIRE(lds <= 64 * 1024, TRS_ESHAPE, "pair_bilinear_bwd_data: N*E = %d exceeds the LDS block", N * E);
+  const int wp = w_per_pair ? 1 : 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = sample_grid(B);
+#define TRS_BILB(T_, MODE_)                                                                                          \
+  hipLaunchKernelGGL((pair_bil_bwd_data_kernel<T_, MODE_>), dim3(grid), dim3(256), lds, s, (const T_*)g, (const T_*)x, \
+                     (const T_*)W, wp, B, N, E, (T_*)gx, (T_*)gT)
+  if (dtype == TRS_F32) { if (mode == 0) TRS_BILB(float, 0); else TRS_BILB(float, 1); }
+  else { if (mode == 0) TRS_BILB(bf16_t, 0); else TRS_BILB(bf16_t, 1); }
+#undef TRS_BILB
+  return check_launch("pair_bilinear_bwd_data");
+}

@@ -504,6 +504,143 @@ def pair_dot(x: torch.Tensor) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------------------------
+# N3: outer-product network / bilinear interaction on the pair pattern
+# --------------------------------------------------------------------------------------------
+def _pair_start(i: int, N: int) -> int:
+    return i * (2 * N - i - 1) // 2
+
+
+class _OPNVec(Function):
+    """out[b,p] = sum_e x_i x_j kern[p,e]  ('vec': kern (P,E); 'num': kern (P,))."""
+
+    @staticmethod
+    def forward(ctx, x, kern, is_num):
+        require_device(x, kern)
+        x = x.contiguous()
+        kern = kern.contiguous().to(x.dtype)
+        B, N, E = x.shape
+        out = torch.empty(B, N * (N - 1) // 2, dtype=x.dtype, device=x.device)
+        call("trs_opn_vec_fwd", ptr(x), ptr(kern), int(is_num), B, N, E, value_dtype_code(x), ptr(out), stream_ptr())
+        ctx.save_for_backward(x, kern)
+        ctx.is_num = bool(is_num)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, kern = ctx.saved_tensors
+        B, N, E = x.shape
+        P = N * (N - 1) // 2
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gk = torch.zeros(P, E, dtype=torch.float32, device=x.device) if ctx.needs_input_grad[1] else None
+        ws_bytes = size_query("trs_opn_vec_bwd_workspace_bytes", B, N, E)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        call("trs_opn_vec_bwd", ptr(g.contiguous()), ptr(x), ptr(kern), int(ctx.is_num), B, N, E, value_dtype_code(x),
+             ptr(gx), ptr(gk), ptr(ws), ws_bytes, stream_ptr())
+        if gk is not None:
+            gk = (gk.sum(-1) if ctx.is_num else gk).to(kern.dtype)
+        return gx, gk, None
+
+
+def opn_vec(x: torch.Tensor, kern: torch.Tensor, is_num: bool) -> torch.Tensor:
+    if x.dim() != 3:
+        raise ValueError(f"outer-product input must be (B, N, E), got {tuple(x.shape)}")
+    return _OPNVec.apply(x, kern, is_num)
+
+
+class _PairMul(Function):
+    """out[b,p,:] = a[b,i_p,:] * c[b,j_p,:] + bias."""
+
+    @staticmethod
+    def forward(ctx, a, c, bias, bias_per_pair):
+        require_device(a, c, bias)
+        a, c = a.contiguous(), c.contiguous()
+        B, N, E = a.shape
+        bias_c = None if bias is None else bias.contiguous().to(a.dtype)
+        out = torch.empty(B, N * (N - 1) // 2, E, dtype=a.dtype, device=a.device)
+        call("trs_pair_mul_fwd", ptr(a), ptr(c), ptr(bias_c), int(bool(bias_per_pair)), B, N, E, value_dtype_code(a),
+             ptr(out), stream_ptr())
+        ctx.save_for_backward(a, c)
+        ctx.bias_per_pair = bool(bias_per_pair)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        a, c = ctx.saved_tensors
+        B, N, E = a.shape
+        g = g.contiguous()
+        ga, gc = torch.empty_like(a), torch.empty_like(c)
+        call("trs_pair_mul_bwd", ptr(g), ptr(a), ptr(c), B, N, E, value_dtype_code(a), ptr(ga), ptr(gc), stream_ptr())
+        gb = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum(0, dtype=torch.float32) if ctx.bias_per_pair else g.reshape(-1, E).sum(0, dtype=torch.float32)
+            gb = gb.to(g.dtype)
+        return ga, gc, gb, None
+
+
+def pair_mul(a: torch.Tensor, c: torch.Tensor, bias: Optional[torch.Tensor] = None, bias_per_pair: bool = False):
+    if a.dim() != 3 or a.shape != c.shape:
+        raise ValueError(f"pair_mul operands must both be (B, N, E), got {tuple(a.shape)} and {tuple(c.shape)}")
+    return _PairMul.apply(a, c, bias, bias_per_pair)
+
+
+class _PairBilinear(Function):
+    """T = x_i W_p;  mode 0: out[b,p] = sum_h T_h x_j[h]  |  mode 1: out[b,p,:] = T * x_j + bias_p.   W (P,E,E) [e][h]."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias, mode):
+        require_device(x, W, bias)
+        x = x.contiguous()
+        B, N, E = x.shape
+        P = N * (N - 1) // 2
+        if tuple(W.shape) != (P, E, E):
+            raise ValueError(f"per-pair weights must be ({P}, {E}, {E}), got {tuple(W.shape)}")
+        Wc = W.contiguous().to(x.dtype)
+        bias_c = None if bias is None else bias.contiguous().to(x.dtype)
+        out = torch.empty((B, P) if mode == 0 else (B, P, E), dtype=x.dtype, device=x.device)
+        call("trs_pair_bilinear_fwd", ptr(x), ptr(Wc), 1, ptr(bias_c), 1, int(mode), B, N, E, value_dtype_code(x),
+             ptr(out), stream_ptr())
+        ctx.save_for_backward(x, Wc)
+        ctx.mode = int(mode)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        B, N, E = x.shape
+        P = N * (N - 1) // 2
+        g = g.contiguous()
+        need_w = ctx.needs_input_grad[1]
+        gx = torch.empty_like(x)
+        gT = torch.empty(B, P, E, dtype=x.dtype, device=x.device) if need_w else None
+        call("trs_pair_bilinear_bwd_data", ptr(g), ptr(x), ptr(W), 1, ctx.mode, B, N, E, value_dtype_code(x), ptr(gx),
+             ptr(gT), stream_ptr())
+        gW = gb = None
+        if need_w:
+            # dW[p] = sum_b x[b,i_p,:]^T gT[b,p,:]: for field i the pairs (i, i+1..N-1) are adjacent, so one plain GEMM
+            # (E x B) @ (B x n_i*E) per field covers them (K = the batch; hipBLASLt)
+            gW = torch.empty(P, E, E, dtype=x.dtype, device=x.device)
+            gT2 = gT.view(B, P * E)
+            for i in range(N - 1):
+                p0, n_i = _pair_start(i, N), N - 1 - i
+                blk = x[:, i, :].t() @ gT2[:, p0 * E:(p0 + n_i) * E]              # (E, n_i*E)
+                gW[p0:p0 + n_i] = blk.view(E, n_i, E).permute(1, 0, 2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum(0, dtype=torch.float32).to(g.dtype)
+        return gx, gW, gb, None
+
+
+def pair_bilinear(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], mode: int) -> torch.Tensor:
+    if x.dim() != 3:
+        raise ValueError(f"pair-bilinear input must be (B, N, E), got {tuple(x.shape)}")
+    return _PairBilinear.apply(x, W, bias, mode)
+
+
+# --------------------------------------------------------------------------------------------
 # K3: field-aware FM pair products
 # --------------------------------------------------------------------------------------------
 class _FFM(Function):

@@ -10,6 +10,8 @@ from __future__ import annotations
 from abc import ABC, abstractmethod
 from typing import Dict, List, Optional, Tuple
 
+import math
+
 import torch
 import torch.nn as nn
 
@@ -121,6 +123,181 @@ class InnerProductNetworkLayer(BaseLayer):
         outputs = F_.pair_dot(x)
         outputs.names = ('B', 'O')
         return outputs
+
+
+def _pair_index_lists(num_fields: int):
+    rows, cols = [], []
+    for i in range(num_fields - 1):
+        for j in range(i + 1, num_fields):
+            rows.append(i)
+            cols.append(j)
+    return torch.LongTensor(rows), torch.LongTensor(cols)
+
+
+class OuterProductNetworkLayer(BaseLayer):
+    """Outer-product network, (B,N,E) -> (B,NC2) named ('B','O').  layers/ctr/outer_product_network.py:36-129.
+    ``kernel`` keeps the reference's shape and initialisation (xavier normal, :68-69):
+      'mat' (E,NC2,E): out[b,p] = sum_h sum_e x_i[e] kernel[h,p,e] x_j[h]      (:107-121)
+      'vec' (1,NC2,E): out[b,p] = sum_e x_i[e] x_j[e] kernel[0,p,e]             (:123-129)
+      'num' (1,NC2,1): out[b,p] = kernel[0,p,0] sum_e x_i[e] x_j[e]
+    The (B,NC2,E) gathers p, q and the (B,E,NC2,E) product of the 'mat' branch are never formed."""
+
+    @property
+    def inputs_size(self):
+        return {'inputs': ('B', 'N', 'E',)}
+
+    @property
+    def outputs_size(self):
+        return {'inputs': ('B', 'NC2',)}
+
+    def __init__(self, embed_size: int, num_fields: int, kernel_type: Optional[str] = 'mat'):
+        super().__init__()
+        self.row_idx, self.col_idx = _pair_index_lists(num_fields)
+        num_pairs = num_fields * (num_fields - 1) // 2
+        if kernel_type == 'mat':
+            kernel_size = (embed_size, num_pairs, embed_size)
+        elif kernel_type == 'vec':
+            kernel_size = (1, num_pairs, embed_size)
+        elif kernel_type == 'num':
+            kernel_size = (1, num_pairs, 1)
+        else:
+            raise ValueError('kernel_type only allows: ["mat", "num", "vec"].')
+        self.kernel_type = kernel_type
+        self.embed_size, self.num_fields = embed_size, num_fields
+        self.kernel = nn.Parameter(torch.zeros(kernel_size))
+        nn.init.xavier_normal_(self.kernel.data)
+
+    def extra_repr(self) -> str:
+        return f'kernel_type={self.kernel_type}'
+
+    def forward(self, emb_inputs: torch.Tensor) -> torch.Tensor:
+        x = _strip(emb_inputs)
+        if x.dim() != 3 or x.shape[1] != self.num_fields or x.shape[2] != self.embed_size:
+            raise ValueError(f'expected (B, {self.num_fields}, {self.embed_size}), got {tuple(x.shape)}')
+        if self.kernel_type == 'mat':
+            # W[p][e][h] = kernel[h,p,e]: the per-pair matrix applied to x_i (autograd routes the gradient back)
+            outputs = F_.pair_bilinear(x, self.kernel.permute(1, 2, 0), None, 0)
+        elif self.kernel_type == 'vec':
+            outputs = F_.opn_vec(x, self.kernel[0], False)
+        else:
+            outputs = F_.opn_vec(x, self.kernel[0, :, 0], True)
+        outputs.names = ('B', 'O')
+        return outputs
+
+
+class FieldAllTypeBilinear(BaseLayer):
+    """``y = (x1 @ W) * x2 + b`` with one (E,E) matrix for every pair.  bilinear_interaction.py:11-80."""
+
+    @property
+    def inputs_size(self):
+        return {'inputs1': ('B', 'NC2', 'E',), 'inputs2': ('B', 'NC2', 'E',)}
+
+    @property
+    def outputs_size(self):
+        return {'outputs': ('B', 'NC2', 'E',)}
+
+    def __init__(self, in1_features, in2_features, bias=True):
+        super().__init__()
+        self.in1_features, self.in2_features = in1_features, in2_features
+        self.weight = nn.Parameter(torch.Tensor(in1_features, in2_features))
+        if bias:
+            self.bias = nn.Parameter(torch.Tensor(in2_features))
+        else:
+            # the reference registers nn.Parameter(torch.tensor([0])) here (:62): an int64 tensor cannot require grad
+            raise RuntimeError('Only Tensors of floating point and complex dtype can require gradients '
+                               '(bias=False cannot be constructed in the reference either)')
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        bound = 1 / math.sqrt(self.weight.shape[0])
+        nn.init.uniform_(self.weight, -bound, bound)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, input1, input2):
+        return torch.mul(torch.matmul(input1, self.weight), input2) + self.bias
+
+    def extra_repr(self):
+        return f'in1_features={self.in1_features}, in2_features={self.in2_features}, bias={self.bias is not None}'
+
+
+class FieldEachTypeBilinear(BaseLayer):
+    """``y[:,p] = (x1[:,p] @ W[p]) * x2[:,p] + b[p]``, one matrix per pair.  bilinear_interaction.py:82-152."""
+
+    @property
+    def inputs_size(self):
+        return {'inputs1': ('B', 'NC2', 'E',), 'inputs2': ('B', 'NC2', 'E',)}
+
+    @property
+    def outputs_size(self):
+        return {'outputs': ('B', 'NC2', 'E',)}
+
+    def __init__(self, in_features, in1_features, in2_features, bias=True):
+        super().__init__()
+        self.in1_features, self.in2_features = in1_features, in2_features
+        self.weight = nn.Parameter(torch.Tensor(in_features, in1_features, in2_features))
+        if bias:
+            self.bias = nn.Parameter(torch.Tensor(in_features, in2_features))
+        else:
+            raise RuntimeError('Only Tensors of floating point and complex dtype can require gradients '
+                               '(bias=False cannot be constructed in the reference either)')
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        bound = 1 / math.sqrt(self.weight.shape[0])
+        nn.init.uniform_(self.weight, -bound, bound)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, input1, input2):
+        out = torch.matmul(input1.unsqueeze(-2), self.weight).squeeze(-2)
+        return torch.mul(out, input2) + self.bias
+
+    def extra_repr(self):
+        return f'in1_features={self.in1_features}, in2_features={self.in2_features}, bias={self.bias is not None}'
+
+
+class BilinearInteractionLayer(BaseLayer):
+    """Bilinear interaction (FiBiNET), (B,N,E) -> (B,NC2,E) named ('B','N','O').  bilinear_interaction.py:155-255.
+    'all':  out[b,p,:] = (x_i @ W) * x_j + b    -- x @ W is ONE (B*N,E)x(E,E) GEMM, the pair products one HIP pass
+    'each': out[b,p,:] = (x_i @ W[p]) * x_j + b[p]
+    Parameters ``bilinear.weight`` / ``bilinear.bias`` as in the reference; 'interaction' is NotImplemented there
+    (:214) and here; bias=False raises as it does there."""
+
+    @property
+    def inputs_size(self):
+        return {'inputs': ('B', 'N', 'E',)}
+
+    @property
+    def outputs_size(self):
+        return {'outputs': ('B', 'NC2', 'E',)}
+
+    def __init__(self, embed_size: int, num_fields: int, bilinear_type: str = 'all', bias: bool = True):
+        super().__init__()
+        self.row_idx, self.col_idx = _pair_index_lists(num_fields)
+        num_interaction = num_fields * (num_fields - 1) // 2
+        self.bilinear_type = bilinear_type
+        self.embed_size, self.num_fields = embed_size, num_fields
+        if bilinear_type == 'all':
+            self.bilinear = FieldAllTypeBilinear(embed_size, embed_size, bias=bias)
+        elif bilinear_type == 'each':
+            self.bilinear = FieldEachTypeBilinear(num_interaction, embed_size, embed_size, bias=bias)
+        elif bilinear_type == 'interaction':
+            raise NotImplementedError()
+        else:
+            raise ValueError('bilinear_type only allows: ["all", "each", "interaction"].')
+
+    def extra_repr(self) -> str:
+        return f'bilinear_type={self.bilinear_type}'
+
+    def forward(self, emb_inputs: torch.Tensor) -> torch.Tensor:
+        x = _strip(emb_inputs)
+        if x.dim() != 3 or x.shape[1] != self.num_fields or x.shape[2] != self.embed_size:
+            raise ValueError(f'expected (B, {self.num_fields}, {self.embed_size}), got {tuple(x.shape)}')
+        if self.bilinear_type == 'all':
+            output = F_.pair_mul(torch.matmul(x, self.bilinear.weight), x, self.bilinear.bias, False)
+        else:
+            output = F_.pair_bilinear(x, self.bilinear.weight, self.bilinear.bias, 1)
+        output.names = ('B', 'N', 'O',)
+        return output
 
 
 class CrossNetworkLayer(BaseLayer):
