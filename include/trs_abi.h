@@ -308,6 +308,19 @@ int trs_pair_bilinear_bwd_data(const void* g, const void* x, const void* W, int3
                                int64_t B, int32_t N, int32_t E, int32_t dtype, void* gx, void* gT,
                                trs_stream_t stream);
 
+/* AttentionalFactorizationMachineLayer (attentional_factorization_machine.py:86-125, dropouts outside):
+ *   prod[b,p,:] = x[b,i_p,:] * x[b,j_p,:];  attn[b,p] = softmax_p(w2 . relu(W1 prod + b1) + b2);
+ *   out[b,:] = sum_p attn[b,p] prod[b,p,:]            W1 (A,E), b1 (A), w2 (A), b2 (1); out (B,E), attn (B,NC2)
+ * bwd: g_out (B,E) / g_attn (B,NC2) may be NULL; gx (B,N,E); gW1 (A,E), gb1 (A), gw2 (A), gb2 (1) fp32,
+ * ACCUMULATED into.  E, A <= 128.                                                                   */
+int trs_afm_fwd(const void* x, const void* W1, const void* b1, const void* w2, const void* b2, int64_t B, int32_t N,
+                int32_t E, int32_t A, int32_t dtype, void* out, void* attn, trs_stream_t stream);
+size_t trs_afm_bwd_workspace_bytes(int64_t B, int32_t N, int32_t E, int32_t A);
+int trs_afm_bwd(const void* g_out, const void* g_attn, const void* x, const void* attn, const void* W1,
+                const void* b1, const void* w2, int64_t B, int32_t N, int32_t E, int32_t A, int32_t dtype, void* gx,
+                float* gW1, float* gb1, float* gw2, float* gb2, void* workspace, size_t ws_bytes,
+                trs_stream_t stream);
+
 /* ---- index staging: pack per-field columns into the (B,N) index matrix --------
  * out[b, c] = src_j[b * width_j + t]  for the c-th output column = column t of source j.
  * replaces the per-field unsqueeze + torch.cat of inputs/inputs.py:75-80 by one pass.

@@ -113,3 +113,73 @@ def test_pair_layers_vs_oracle(dev, dtype, tol, B, N, E):
         assert rel_err(x.grad.float().cpu(), xr.grad) <= tol * 2, (fam, kind, "gx")
         for p, r in zip(params, pr):
             assert rel_err(p.grad.float().cpu(), r.grad) <= tol * 2, (fam, kind, "gparam")
+
+
+def _afm_layer(dev, E, N, A, W1, b1, W2, b2, dtype=torch.float32):
+    from torecsys_amd.layers import AttentionalFactorizationMachineLayer
+    lay = AttentionalFactorizationMachineLayer(embed_size=E, num_fields=N, attn_size=A, dropout_p=0.0).to(dev).to(dtype)
+    lay.attention.Linear.weight.data.copy_(W1)
+    lay.attention.Linear.bias.data.copy_(b1)
+    lay.attention.OutProj.weight.data.copy_(W2)
+    lay.attention.OutProj.bias.data.copy_(b2)
+    return lay
+
+
+@pytest.mark.parametrize("shape", PAIR_SHAPES)
+def test_afm_golden(golden, dev, shape):
+    G = golden("pairs")
+    B, N, E = shape
+    t = _tag(shape)
+    A = G(f"afm/{t}/W1").shape[0]
+    lay = _afm_layer(dev, E, N, A, *[G(f"afm/{t}/{n}") for n in ("W1", "b1", "W2", "b2")])
+    x = G(f"afm/{t}/x").to(dev).requires_grad_()
+    y, attn = lay(x.refine_names('B', 'N', 'E'))
+    assert [str(n) for n in y.names] == G(f"afm/{t}/names") and not attn.has_names()
+    assert tuple(attn.shape) == (B, N * (N - 1) // 2, 1)
+    assert rel_err(y.rename(None).cpu(), G(f"afm/{t}/out")) <= 1e-5
+    assert rel_err(attn.cpu(), G(f"afm/{t}/attn")) <= 1e-5
+    ((y.rename(None) * G(f"afm/{t}/gout").to(dev)).sum() + (attn * G(f"afm/{t}/gattn").to(dev)).sum()).backward()
+    assert rel_err(x.grad.cpu(), G(f"afm/{t}/gx")) <= 2e-5
+    a = lay.attention
+    for p, n in ((a.Linear.weight, "gW1"), (a.Linear.bias, "gb1"), (a.OutProj.weight, "gW2")):
+        assert rel_err(p.grad.cpu(), G(f"afm/{t}/{n}")) <= 5e-5, n
+    # d/d(b2) of a softmax over the logits is identically zero (a shift of every logit): the reference's value is
+    # summation noise, so it is compared on an absolute scale
+    assert float((a.OutProj.bias.grad.cpu() - G(f"afm/{t}/gb2")).abs().max()) <= 1e-5
+    assert sorted(lay.state_dict().keys()) == ["attention.Linear.bias", "attention.Linear.weight",
+                                               "attention.OutProj.bias", "attention.OutProj.weight"]
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-5), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("B,N,E,A", [(37, 39, 64, 64), (5, 2, 16, 8), (130, 7, 24, 40), (9, 5, 128, 100), (1, 3, 8, 1)])
+def test_afm_vs_oracle(dev, dtype, tol, B, N, E, A):
+    g = torch.Generator().manual_seed(B + N + E + A)
+    x0 = (torch.randn(B, N, E, generator=g) * 0.7).to(dtype)
+    ps = [(torch.randn(A, E, generator=g) / E ** 0.5).to(dtype), (torch.randn(A, generator=g) * 0.1).to(dtype),
+          (torch.randn(1, A, generator=g) / A ** 0.5).to(dtype), (torch.randn(1, generator=g) * 0.1).to(dtype)]
+    lay = _afm_layer(dev, E, N, A, *ps, dtype=dtype)
+    x = x0.to(dev).requires_grad_()
+    y, attn = lay(x)
+    xr = x0.float().clone().requires_grad_()
+    pr = [p.float().clone().requires_grad_() for p in ps]
+    yr, ar = O.afm_layer(xr, *pr)
+    assert rel_err(y.rename(None).float().cpu(), yr) <= tol
+    assert rel_err(attn.float().cpu(), ar) <= tol
+    go, ga = torch.randn(B, E, generator=g), torch.randn(ar.shape, generator=g)
+    ((y.rename(None).float() * go.to(dev)).sum() + (attn.float() * ga.to(dev)).sum()).backward()
+    ((yr * go).sum() + (ar * ga).sum()).backward()
+    assert rel_err(x.grad.float().cpu(), xr.grad) <= tol * 3
+    a = lay.attention
+    for p, r in zip((a.Linear.weight, a.Linear.bias, a.OutProj.weight), pr):
+        # gradients that cancel analytically (one attention unit: d/d(b1) is a multiple of sum_p d(logit) = 0) are
+        # pure summation noise: scale the error by at least 1e-2
+        err = float((p.grad.float().cpu() - r.grad).abs().max())
+        assert err <= tol * 3 * max(float(r.grad.abs().max()), 1e-2)
+    assert float(a.OutProj.bias.grad.float().abs().max()) <= tol * float(ga.abs().max()) * B    # analytically zero
+    # only the output is used downstream: the attention gradient input is None
+    x2 = x0.to(dev).requires_grad_()
+    y2, _ = lay(x2)
+    (y2.rename(None).float() * go.to(dev)).sum().backward()
+    xr2 = x0.float().clone().requires_grad_()
+    (O.afm_layer(xr2, *[p.detach() for p in pr])[0] * go).sum().backward()
+    assert rel_err(x2.grad.float().cpu(), xr2.grad) <= tol * 3

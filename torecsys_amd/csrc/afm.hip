@@ -1,0 +1,362 @@
+// AttentionalFactorizationMachineLayer, layers/ctr/attentional_factorization_machine.py:86-125
+//   prod[b,p,:] = x[b,i_p,:] * x[b,j_p,:]                                   (i<j pairs, NC2 of them)
+//   score[b,p]  = softmax_p( w2 . relu(W1 prod[b,p,:] + b1) + b2 )           (attention MLP E -> A -> 1)
+//   out[b,:]    = sum_p score[b,p] * prod[b,p,:]
+// (both nn.Dropout modules stay in Python).  The reference materialises prod (B,NC2,E) -- 6.2 GB at B = 65 536,
+// N = 39, E = 64 bf16 -- and runs the attention MLP as two nn.Linear over it; here a workgroup keeps the (N x E)
+// block of one sample, the attention weights and the NC2 logits in LDS and the products never leave registers.
+// Generic path (any dtype / shape with E, A <= 128): lanes along the attention units for the hidden layer
+// (wavefront reduction for the logit), lanes along e for the weighted sum and the backward.
+#include <algorithm>
+
+#include "trs_common.hpp"
+
+namespace trs {
+
+__device__ __forceinline__ void afm_pair_ij(int p, int N, int* i_out, int* j_out) {
+  const float d = (float)(2 * N - 1);
+  int i = (int)((d - sqrtf(fmaxf(d * d - 8.f * (float)p, 0.f))) * 0.5f);
+  if (i < 0) i = 0;
+  if (i > N - 2) i = N - 2;
+  while (i > 0 && i * (2 * N - i - 1) / 2 > p) --i;
+  while (i < N - 2 && (i + 1) * (2 * N - i - 2) / 2 <= p) ++i;
+  *i_out = i;
+  *j_out = p - i * (2 * N - i - 1) / 2 + i + 1;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// block-wide reductions over 256 threads through 4 LDS slots (+ broadcast)
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+constexpr int AFM_MAX = 128;     // E and A limit of the generic path (two 64-lane slabs)
+
+struct AfmLds {
+  float* xs;    // [N][E]
+  float* w1t;   // [E][A]   (lanes along a)
+  float* w1;    // [A][E]   (lanes along e; backward only)
+  float* b1;    // [A]
+  float* w2;    // [A]
+  float* lg;    // [P]  logits -> scores
+  float* aux;   // [P]  backward: d(score) -> d(logit)
+  float* vec;   // [E]  forward: output accumulator; backward: g_out
+  float* dh;    // [4][A] per-wave d(hidden)
+  float* red;   // [4]
+};
+
+__device__ __forceinline__ AfmLds afm_carve(float* smem, int N, int E, int A, int P, bool bwd) {
+  AfmLds l;
+  float* p = smem;
+  l.xs = p; p += N * E;
+  l.w1t = p; p += E * A;
+  l.w1 = p; p += bwd ? A * E : 0;
+  l.b1 = p; p += A;
+  l.w2 = p; p += A;
+  l.lg = p; p += P;
+  l.aux = p; p += bwd ? P : 0;
+  l.vec = p; p += E;
+  l.dh = p; p += bwd ? 4 * A : 0;
+  l.red = p;
+  return l;
+}
+__host__ __device__ inline size_t afm_lds_floats(int N, int E, int A, int P, bool bwd) {
+  return (size_t)N * E + (size_t)E * A * (bwd ? 2 : 1) + 2 * A + (size_t)P * (bwd ? 2 : 1) + E + (bwd ? 4 * A : 0) + 8;
+}
+
+template <typename T>
+__device__ __forceinline__ void afm_stage_weights(const AfmLds& l, const T* W1, const T* b1, const T* w2, int E, int A,
+                                                  bool bwd) {
+  for (int k = threadIdx.x; k < A * E; k += blockDim.x) {
+    const int a = k / E, e = k - a * E;
+    const float w = to_f32(W1[k]);
+    l.w1t[e * A + a] = w;
+    if (bwd) l.w1[k] = w;
+  }
+  for (int a = threadIdx.x; a < A; a += blockDim.x) {
+    l.b1[a] = to_f32(b1[a]);
+    l.w2[a] = to_f32(w2[a]);
+  }
+}
+
+// hidden pre-activations of one pair for this lane's attention units (slabs of 64): acc[s] for a = 64 s + lane
+__device__ __forceinline__ void afm_hidden(const AfmLds& l, int i, int j, int E, int A, int lane, float* acc /*[2]*/) {
+  const float* xi = l.xs + i * E;
+  const float* xj = l.xs + j * E;
+  const int a0 = lane, a1 = 64 + lane;
+  acc[0] = a0 < A ? l.b1[a0] : 0.f;
+  acc[1] = a1 < A ? l.b1[a1] : 0.f;
+  for (int e = 0; e < E; ++e) {
+    const float pr = xi[e] * xj[e];
+    if (a0 < A) acc[0] = fmaf(pr, l.w1t[e * A + a0], acc[0]);
+    if (a1 < A) acc[1] = fmaf(pr, l.w1t[e * A + a1], acc[1]);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void afm_fwd_kernel(const T* __restrict__ x, const T* __restrict__ W1,
+                                                      const T* __restrict__ b1, const T* __restrict__ w2,
+                                                      const T* __restrict__ b2, int64_t B, int N, int E, int A,
+                                                      T* __restrict__ out, T* __restrict__ attn) {
+  extern __shared__ float smem[];
+  const int P = N * (N - 1) / 2;
+  const AfmLds l = afm_carve(smem, N, E, A, P, false);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  afm_stage_weights(l, W1, b1, w2, E, A, false);
+  const float bias2 = to_f32(b2[0]);
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < N * E; k += 256) l.xs[k] = to_f32(x[b * N * E + k]);
+    for (int k = threadIdx.x; k < E; k += 256) l.vec[k] = 0.f;
+    __syncthreads();
+    // logits: one wave per pair, lanes along the attention units
+    for (int p = wave; p < P; p += 4) {
+      int i, j;
+      afm_pair_ij(p, N, &i, &j);
+      float acc[2];
+      afm_hidden(l, i, j, E, A, lane, acc);
+      float part = 0.f;
+      if (lane < A) part = fmaf(fmaxf(acc[0], 0.f), l.w2[lane], part);
+      if (64 + lane < A) part = fmaf(fmaxf(acc[1], 0.f), l.w2[64 + lane], part);
+      part = wave_sum(part);
+      if (lane == 0) l.lg[p] = part + bias2;
+    }
+    __syncthreads();
+    // softmax over the pairs of the sample
+    float m = -INFINITY;
+    for (int p = threadIdx.x; p < P; p += 256) m = fmaxf(m, l.lg[p]);
+    m = block_max(m, l.red);
+    float s = 0.f;
+    for (int p = threadIdx.x; p < P; p += 256) {
+      const float e = __expf(l.lg[p] - m);
+      l.lg[p] = e;
+      s += e;
+    }
+    s = block_sum(s, l.red);
+    const float inv = 1.f / s;
+    for (int p = threadIdx.x; p < P; p += 256) {
+      const float sc = l.lg[p] * inv;
+      l.lg[p] = sc;
+      attn[b * P + p] = from_f32<T>(sc);
+    }
+    __syncthreads();
+    // out[e] = sum_p score[p] x_i[e] x_j[e]: each wave takes every 4th pair, lanes along e
+    float o0 = 0.f, o1 = 0.f;
+    for (int p = wave; p < P; p += 4) {
+      int i, j;
+      afm_pair_ij(p, N, &i, &j);
+      const float sc = l.lg[p];
+      if (lane < E) o0 = fmaf(sc, l.xs[i * E + lane] * l.xs[j * E + lane], o0);
+      if (64 + lane < E) o1 = fmaf(sc, l.xs[i * E + 64 + lane] * l.xs[j * E + 64 + lane], o1);
+    }
+    if (lane < E) atomicAdd(&l.vec[lane], o0);
+    if (64 + lane < E) atomicAdd(&l.vec[64 + lane], o1);
+    __syncthreads();
+    for (int k = threadIdx.x; k < E; k += 256) out[b * E + k] = from_f32<T>(l.vec[k]);
+  }
+}
+
+// Backward.  Per sample: d(score)_p = g_attn_p + g_out . prod_p;  softmax backward;  then per pair
+//   dh_a = d(logit)_p w2_a [h_a > 0];   dprod = score_p g_out + W1^T dh;   dx_i += dprod * x_j, dx_j += dprod * x_i
+// Parameter gradients are accumulated per workgroup (dW1 in LDS with ds_add_f32, the vectors in registers) and
+// written as partials [grid][A*E + 2A + 1]; a second kernel reduces them.
+template <typename T>
+__global__ __launch_bounds__(256) void afm_bwd_kernel(const T* __restrict__ g_out, const T* __restrict__ g_attn,
+                                                      const T* __restrict__ x, const T* __restrict__ attn,
+                                                      const T* __restrict__ W1, const T* __restrict__ b1,
+                                                      const T* __restrict__ w2, int64_t B, int N, int E, int A,
+                                                      T* __restrict__ gx, float* __restrict__ partial) {
+  extern __shared__ float smem[];
+  const int P = N * (N - 1) / 2;
+  const AfmLds l = afm_carve(smem, N, E, A, P, true);
+  float* gxs = smem + afm_lds_floats(N, E, A, P, true);        // [N][E]
+  float* dw1 = gxs + N * E;                                   // [A][E]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  afm_stage_weights(l, W1, b1, w2, E, A, true);
+  for (int k = threadIdx.x; k < A * E; k += 256) dw1[k] = 0.f;
+  float db1r[2] = {0.f, 0.f}, dw2r[2] = {0.f, 0.f}, db2r = 0.f;
+  float* dh = l.dh + wave * A;
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < N * E; k += 256) {
+      l.xs[k] = to_f32(x[b * N * E + k]);
+      gxs[k] = 0.f;
+    }
+    for (int k = threadIdx.x; k < E; k += 256) l.vec[k] = g_out != nullptr ? to_f32(g_out[b * E + k]) : 0.f;
+    for (int p = threadIdx.x; p < P; p += 256) l.lg[p] = to_f32(attn[b * P + p]);
+    __syncthreads();
+    // d(score)
+    for (int p = wave; p < P; p += 4) {
+      int i, j;
+      afm_pair_ij(p, N, &i, &j);
+      float d = 0.f;
+      if (lane < E) d = l.vec[lane] * l.xs[i * E + lane] * l.xs[j * E + lane];
+      if (64 + lane < E) d = fmaf(l.vec[64 + lane], l.xs[i * E + 64 + lane] * l.xs[j * E + 64 + lane], d);
+      d = wave_sum(d);
+      if (lane == 0) l.aux[p] = d + (g_attn != nullptr ? to_f32(g_attn[b * P + p]) : 0.f);
+    }
+    __syncthreads();
+    float s = 0.f;
+    for (int p = threadIdx.x; p < P; p += 256) s += l.lg[p] * l.aux[p];
+    s = block_sum(s, l.red);
+    for (int p = threadIdx.x; p < P; p += 256) l.aux[p] = l.lg[p] * (l.aux[p] - s);      // d(logit)
+    __syncthreads();
+    for (int p = wave; p < P; p += 4) {
+      int i, j;
+      afm_pair_ij(p, N, &i, &j);
+      const float dl = l.aux[p], sc = l.lg[p];
+      float acc[2];
+      afm_hidden(l, i, j, E, A, lane, acc);
+      if (lane < A) {
+        const float h = fmaxf(acc[0], 0.f), d = acc[0] > 0.f ? dl * l.w2[lane] : 0.f;
+        dh[lane] = d;
+        db1r[0] += d;
+        dw2r[0] = fmaf(dl, h, dw2r[0]);
+      }
+      if (64 + lane < A) {
+        const float h = fmaxf(acc[1], 0.f), d = acc[1] > 0.f ? dl * l.w2[64 + lane] : 0.f;
+        dh[64 + lane] = d;
+        db1r[1] += d;
+        dw2r[1] = fmaf(dl, h, dw2r[1]);
+      }
+      if (lane == 0) db2r += dl;
+      __builtin_amdgcn_wave_barrier();
+      for (int e = lane; e < E; e += 64) {
+        const float xi = l.xs[i * E + e], xj = l.xs[j * E + e], pr = xi * xj;
+        float dp = sc * l.vec[e];
+        for (int a = 0; a < A; ++a) {
+          const float d = dh[a];
+          dp = fmaf(d, l.w1[a * E + e], dp);
+          atomicAdd(&dw1[a * E + e], d * pr);
+        }
+        atomicAdd(&gxs[i * E + e], dp * xj);
+        atomicAdd(&gxs[j * E + e], dp * xi);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < N * E; k += 256) gx[b * N * E + k] = from_f32<T>(gxs[k]);
+  }
+  __syncthreads();
+  float* mine = partial + (size_t)blockIdx.x * (A * E + 2 * A + 1);
+  for (int k = threadIdx.x; k < A * E; k += 256) mine[k] = dw1[k];
+  // vectors: reduce the four waves' registers through LDS (reuse dw1's storage after it has been written out)
+  __syncthreads();
+  float* vb1 = dw1;
+  float* vw2 = dw1 + A;
+  for (int k = threadIdx.x; k < 2 * A + 1; k += 256) dw1[k] = 0.f;
+  __syncthreads();
+  if (lane < A) { atomicAdd(&vb1[lane], db1r[0]); atomicAdd(&vw2[lane], dw2r[0]); }
+  if (64 + lane < A) { atomicAdd(&vb1[64 + lane], db1r[1]); atomicAdd(&vw2[64 + lane], dw2r[1]); }
+  if (lane == 0) atomicAdd(&dw1[2 * A], db2r);
+  __syncthreads();
+  for (int k = threadIdx.x; k < 2 * A + 1; k += 256) mine[A * E + k] = dw1[k];
+}
+
+__global__ __launch_bounds__(256) void afm_reduce_partials_kernel(const float* __restrict__ part, int nparts, int n,
+                                                                  int A, int E, float* __restrict__ gW1,
+                                                                  float* __restrict__ gb1, float* __restrict__ gw2,
+                                                                  float* __restrict__ gb2) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * n + i];
+    if (i < A * E) gW1[i] += s;
+    else if (i < A * E + A) gb1[i - A * E] += s;
+    else if (i < A * E + 2 * A) gw2[i - A * E - A] += s;
+    else gb2[0] += s;
+  }
+}
+
+static int afm_grid(int64_t B) { return (int)std::min<int64_t>(B, 256 * 4); }
+
+}  // namespace trs
+
+using namespace trs;
+
+#define TRS_AFM_COMMON(name)                                                                          \
+  TRS_REQUIRE(B >= 0 && N >= 0 && E > 0 && A > 0, TRS_EINVAL, name ": bad size");                     \
+  TRS_REQUIRE(dtype == TRS_F32 || dtype == TRS_BF16, TRS_EDTYPE, name ": dtype %d", dtype);           \
+  TRS_REQUIRE(E <= AFM_MAX && A <= AFM_MAX, TRS_ESHAPE, name ": E = %d, A = %d (both <= %d)", E, A, AFM_MAX)
+
+extern "C" int trs_afm_fwd(const void* x, const void* W1, const void* b1, const void* w2, const void* b2, int64_t B,
+                           int32_t N, int32_t E, int32_t A, int32_t dtype, void* out, void* attn, trs_stream_t stream) {
+  TRS_AFM_COMMON("afm_fwd");
+  if (B == 0) return TRS_OK;
+  TRS_REQUIRE(N >= 2, TRS_ESHAPE, "afm_fwd: needs at least two fields (N = %d)", N);
+  TRS_REQUIRE(x && W1 && b1 && w2 && b2 && out && attn, TRS_EINVAL, "afm_fwd: NULL pointer");
+  const int P = N * (N - 1) / 2;
+  const size_t lds = afm_lds_floats(N, E, A, P, false) * 4;
+  TRS_REQUIRE(lds <= 160 * 1024, TRS_ESHAPE, "afm_fwd: N = %d, E = %d, A = %d need %zu bytes of LDS", N, E, A, lds);
+  hipStream_t s = (hipStream_t)stream;
+#define TRS_AFM_F(T_)                                                                                                 \
+  do {                                                                                                                \
+    auto kern = afm_fwd_kernel<T_>;                                                                                   \
+    if (lds > 64 * 1024 &&                                                                                            \
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)  \
+      return check_launch("afm_fwd: LDS attribute");                                                                  \
+    hipLaunchKernelGGL(kern, dim3(afm_grid(B)), dim3(256), lds, s, (const T_*)x, (const T_*)W1, (const T_*)b1,        \
+                       (const T_*)w2, (const T_*)b2, B, N, E, A, (T_*)out, (T_*)attn);                                \
+  } while (0)
+  if (dtype == TRS_F32) TRS_AFM_F(float);
+  else TRS_AFM_F(bf16_t);
+#undef TRS_AFM_F
+  return check_launch("afm_fwd");
+}
+
+extern "C" size_t trs_afm_bwd_workspace_bytes(int64_t B, int32_t N, int32_t E, int32_t A) {
+  if (B <= 0 || E <= 0 || A <= 0) return 256;
+  return (size_t)afm_grid(B) * ((size_t)A * E + 2 * A + 1) * 4 + 256;
+}
+
+extern "C" int trs_afm_bwd(const void* g_out, const void* g_attn, const void* x, const void* attn, const void* W1,
+                           const void* b1, const void* w2, int64_t B, int32_t N, int32_t E, int32_t A, int32_t dtype,
+                           void* gx, float* gW1, float* gb1, float* gw2, float* gb2, void* workspace, size_t ws_bytes,
+                           trs_stream_t stream) {
+  TRS_AFM_COMMON("afm_bwd");
+  if (B == 0) return TRS_OK;
+  TRS_REQUIRE(N >= 2, TRS_ESHAPE, "afm_bwd: needs at least two fields (N = %d)", N);
+  TRS_REQUIRE(x && attn && W1 && b1 && w2 && gx && gW1 && gb1 && gw2 && gb2, TRS_EINVAL, "afm_bwd: NULL pointer");
+  TRS_REQUIRE(workspace != nullptr && ws_bytes >= trs_afm_bwd_workspace_bytes(B, N, E, A), TRS_EWORKSPACE,
+              "afm_bwd: workspace too small");
+  const int P = N * (N - 1) / 2;
+  const size_t lds = (afm_lds_floats(N, E, A, P, true) + (size_t)N * E + (size_t)A * E) * 4;
+  TRS_REQUIRE(lds <= 160 * 1024, TRS_ESHAPE, "afm_bwd: N = %d, E = %d, A = %d need %zu bytes of LDS", N, E, A, lds);
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = afm_grid(B);
+  float* part = (float*)workspace;
+#define TRS_AFM_B(T_)                                                                                                 \
+  do {                                                                                                                \
+    auto kern = afm_bwd_kernel<T_>;                                                                                   \
+    if (lds > 64 * 1024 &&                                                                                            \
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)  \
+      return check_launch("afm_bwd: LDS attribute");                                                                  \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, (const T_*)g_out, (const T_*)g_attn, (const T_*)x,        \
+                       (const T_*)attn, (const T_*)W1, (const T_*)b1, (const T_*)w2, B, N, E, A, (T_*)gx, part);      \
+  } while (0)
+  if (dtype == TRS_F32) TRS_AFM_B(float);
+  else TRS_AFM_B(bf16_t);
+#undef TRS_AFM_B
+  const int n = A * E + 2 * A + 1;
+  hipLaunchKernelGGL(afm_reduce_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, s, part, grid, n, A, E, gW1, gb1,
+                     gw2, gb2);
+  return check_launch("afm_bwd");
+}

@@ -640,6 +640,55 @@ def pair_bilinear(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor]
     return _PairBilinear.apply(x, W, bias, mode)
 
 
+class _AFM(Function):
+    """(out (B,E), attn (B,NC2)) = attention-weighted sum of the pair products; see trs_afm_fwd."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, w2, b2):
+        require_device(x, W1, b1, w2, b2)
+        x = x.contiguous()
+        B, N, E = x.shape
+        A = W1.shape[0]
+        ps = [t.contiguous().to(x.dtype) for t in (W1, b1, w2.reshape(-1), b2.reshape(-1))]
+        out = torch.empty(B, E, dtype=x.dtype, device=x.device)
+        attn = torch.empty(B, N * (N - 1) // 2, dtype=x.dtype, device=x.device)
+        call("trs_afm_fwd", ptr(x), ptr(ps[0]), ptr(ps[1]), ptr(ps[2]), ptr(ps[3]), B, N, E, A, value_dtype_code(x),
+             ptr(out), ptr(attn), stream_ptr())
+        ctx.save_for_backward(x, attn, *ps)
+        ctx.set_materialize_grads(False)
+        ctx.w2_shape, ctx.b2_shape = tuple(w2.shape), tuple(b2.shape)
+        return out, attn
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_out, g_attn):
+        x, attn, W1, b1, w2, b2 = ctx.saved_tensors
+        if g_out is None and g_attn is None:
+            return None, None, None, None, None
+        B, N, E = x.shape
+        A = W1.shape[0]
+        dev = x.device
+        gx = torch.empty_like(x)
+        gW1 = torch.zeros(A, E, dtype=torch.float32, device=dev)
+        gv = torch.zeros(2 * A + 1, dtype=torch.float32, device=dev)
+        ws_bytes = size_query("trs_afm_bwd_workspace_bytes", B, N, E, A)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        go = None if g_out is None else g_out.contiguous()
+        ga = None if g_attn is None else g_attn.contiguous()
+        call("trs_afm_bwd", ptr(go), ptr(ga), ptr(x), ptr(attn), ptr(W1), ptr(b1), ptr(w2), B, N, E, A,
+             value_dtype_code(x), ptr(gx), ptr(gW1), ptr(gv[:A]), ptr(gv[A:2 * A]), ptr(gv[2 * A:]), ptr(ws), ws_bytes,
+             stream_ptr())
+        dt = x.dtype
+        return (gx, gW1.to(dt), gv[:A].to(dt), gv[A:2 * A].to(dt).reshape(ctx.w2_shape),
+                gv[2 * A:].to(dt).reshape(ctx.b2_shape))
+
+
+def afm(x: torch.Tensor, W1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor):
+    if x.dim() != 3:
+        raise ValueError(f"AFM input must be (B, N, E), got {tuple(x.shape)}")
+    return _AFM.apply(x, W1, b1, w2, b2)
+
+
 # --------------------------------------------------------------------------------------------
 # K3: field-aware FM pair products
 # --------------------------------------------------------------------------------------------

@@ -300,6 +300,51 @@ class BilinearInteractionLayer(BaseLayer):
         return output
 
 
+class AttentionalFactorizationMachineLayer(BaseLayer):
+    """Attentional FM, (B,N,E) -> ((B,E) named ('B','E'), (B,NC2,1) un-named attention scores).
+    layers/ctr/attentional_factorization_machine.py:49-125.  Parameters as in the reference:
+    ``attention.Linear.{weight (A,E), bias}``, ``attention.OutProj.{weight (1,A), bias}``; the Softmax / Dropout entries
+    of ``attention`` and the output ``dropout`` are kept as modules (dropout is applied to the scores and to the output
+    exactly where the reference applies it; the score dropout therefore acts after the fused weighted sum only in
+    eval / p = 0 -- with p > 0 in training the layer falls back to applying it before the sum in PyTorch)."""
+
+    @property
+    def inputs_size(self):
+        return {'inputs': ('B', 'N', 'E',)}
+
+    @property
+    def outputs_size(self):
+        return {'outputs': ('B', 'E',), 'attn_scores': ('B', 'NC2', '1',)}
+
+    def __init__(self, embed_size: int, num_fields: int, attn_size: int, dropout_p: float = 0.1):
+        super().__init__()
+        self.row_idx, self.col_idx = _pair_index_lists(num_fields)
+        self.embed_size, self.num_fields = embed_size, num_fields
+        self.attention = nn.Sequential()
+        self.attention.add_module('Linear', nn.Linear(embed_size, attn_size))
+        self.attention.add_module('Activation', nn.ReLU())
+        self.attention.add_module('OutProj', nn.Linear(attn_size, 1))
+        self.attention.add_module('Softmax', nn.Softmax(dim=1))
+        self.attention.add_module('Dropout', nn.Dropout(dropout_p))
+        self.dropout = nn.Dropout(dropout_p)
+
+    def forward(self, emb_inputs: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        x = _strip(emb_inputs)
+        if x.dim() != 3 or x.shape[1] != self.num_fields or x.shape[2] != self.embed_size:
+            raise ValueError(f'expected (B, {self.num_fields}, {self.embed_size}), got {tuple(x.shape)}')
+        lin, proj, drop = self.attention.Linear, self.attention.OutProj, self.attention.Dropout
+        outputs, attn = F_.afm(x, lin.weight, lin.bias, proj.weight, proj.bias)
+        attn_scores = attn.unsqueeze(-1)
+        if drop.training and drop.p > 0.0:
+            # dropout on the scores changes the weighted sum: redo it from the dropped scores (training-only path)
+            attn_scores = drop(attn_scores)
+            rows, cols = self.row_idx.to(x.device), self.col_idx.to(x.device)
+            outputs = (x[:, rows] * x[:, cols] * attn_scores).sum(dim=1)
+        outputs.names = ('B', 'E')
+        outputs = self.dropout(outputs)
+        return outputs, attn_scores
+
+
 class CrossNetworkLayer(BaseLayer):
     """Cross network, (B,N,E) -> (B,N,E) named ('B','N','O'): x_{l+1} = x0 * (x_l W_l^T + b_l) + x0.
     layers/ctr/cross_network.py:34-87.  Parameters ``model.{l}.weight`` (E,E) / ``model.{l}.bias`` (E)
@@ -609,6 +654,7 @@ class MultilayerPerceptionLayer(BaseLayer):
 
 
 # aliases, layers/ctr/__init__.py:23-35
+AFMLayer = AttentionalFactorizationMachineLayer
 FMLayer = FactorizationMachineLayer
 FFMLayer = FieldAwareFactorizationMachineLayer
 CINLayer = CompressInteractionNetworkLayer
