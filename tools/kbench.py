@@ -117,6 +117,35 @@ def main():
         gy = torch.randn_like(y)
         t = timeit(lambda: torch.autograd.grad(y, x, gy, retain_graph=True), iters=10)
         report("pair_dot_bwd", t, 2 * B * N * E * s + B * (N * (N - 1) // 2) * s)
+    if want("pairx"):
+        from torecsys_amd.layers import (AttentionalFactorizationMachineLayer, BilinearInteractionLayer,
+                                         OuterProductNetworkLayer)
+        P = N * (N - 1) // 2
+        Bp = a.B // 8 if a.B >= 8192 else a.B          # the (B,NC2,E) outputs are 6.2 GB at B = 65536
+        x = (0.5 * torch.randn(Bp, N, E, generator=g)).to(dt).to(dev).requires_grad_()
+        fl_bil = 2.0 * Bp * P * E * E
+
+        def run(name, lay, out_elems, flops):
+            lay = lay.to(dev).to(dt)
+            f = lambda: lay(x.detach())
+            t = timeit(f, iters=3, warm=1)
+            yb = out_elems * s + Bp * N * E * s
+            print(f"{name:34s} fwd med {t[0]*1e6:9.1f} us  {yb/t[0]/1e9:7.1f} GB/s (alg)  {flops/t[0]/1e12:7.1f} TFLOP/s",
+                  flush=True)
+            y = lay(x)
+            y = y[0] if isinstance(y, tuple) else y
+            gy = torch.randn_like(y.rename(None))
+            ins = (x,) + tuple(lay.parameters())
+            t = timeit(lambda: torch.autograd.grad(y.rename(None), ins, gy, retain_graph=True), iters=3, warm=1)
+            print(f"{'':34s} bwd med {t[0]*1e6:9.1f} us  {2*flops/t[0]/1e12:7.1f} TFLOP/s", flush=True)
+
+        print(f"pair layers at B={Bp} N={N} E={E}")
+        run("opn vec", OuterProductNetworkLayer(E, N, "vec"), Bp * P, 3.0 * Bp * P * E)
+        run("opn num", OuterProductNetworkLayer(E, N, "num"), Bp * P, 2.0 * Bp * P * E)
+        run("opn mat", OuterProductNetworkLayer(E, N, "mat"), Bp * P, fl_bil)
+        run("bilinear all", BilinearInteractionLayer(E, N, "all"), Bp * P * E, 2.0 * Bp * N * E * E)
+        run("bilinear each", BilinearInteractionLayer(E, N, "each"), Bp * P * E, fl_bil)
+        run("afm A=64", AttentionalFactorizationMachineLayer(E, N, 64, 0.0), Bp * E + Bp * P, 2.0 * Bp * P * E * 64)
     if want("cin"):
         Bc = a.B // 8 if a.B >= 8192 else a.B
         for (H, C) in ((39, 256), (128, 256)):

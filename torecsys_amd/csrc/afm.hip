@@ -175,11 +175,32 @@ __global__ __launch_bounds__(256) void afm_fwd_kernel(const T* __restrict__ x, c
   }
 }
 
+// Conflict-free pair schedule (same construction as pairx.hip): rounds of pairs that share no field, so the four
+// waves can add into the per-field LDS gradient block with plain read-modify-writes inside a round.
+__host__ __device__ inline int afm_rounds(int N) { return (N & 1) ? N : N - 1; }
+__host__ __device__ inline int afm_width(int N) { return (N + 1) / 2; }
+__device__ __forceinline__ void afm_build_schedule(int* sched, int N) {
+  const int M = (N & 1) ? N + 1 : N;
+  const int R = M - 1, H = M / 2;
+  for (int t = threadIdx.x; t < R * H; t += blockDim.x) {
+    const int r = t / H, k = t - r * H;
+    int a, b;
+    if (k == 0) { a = r; b = M - 1; }
+    else { a = (r + k) % R; b = (r - k + R) % R; }
+    int v = -1;
+    if (a < N && b < N) {
+      const int i = a < b ? a : b, j = a < b ? b : a;
+      v = (i << 16) | j;
+    }
+    sched[t] = v;
+  }
+}
+
 // Backward.  Per sample: d(score)_p = g_attn_p + g_out . prod_p;  softmax backward;  then per pair
 //   dh_a = d(logit)_p w2_a [h_a > 0];   dprod = score_p g_out + W1^T dh;   dx_i += dprod * x_j, dx_j += dprod * x_i
-// Parameter gradients are accumulated per workgroup (dW1 in LDS with ds_add_f32, the vectors in registers) and
-// written as partials [grid][A*E + 2A + 1]; a second kernel reduces them.
-template <typename T>
+// dW1[a][e] += dh_a prod_e is accumulated in registers (lane = e, AMAX values per e slab) over every pair and sample
+// of the workgroup; all parameter gradients leave as partials [grid][A*E + 2A + 1] reduced by a second kernel.
+template <typename T, int AMAX, int ES>
 __global__ __launch_bounds__(256) void afm_bwd_kernel(const T* __restrict__ g_out, const T* __restrict__ g_attn,
                                                       const T* __restrict__ x, const T* __restrict__ attn,
                                                       const T* __restrict__ W1, const T* __restrict__ b1,
@@ -189,10 +210,18 @@ __global__ __launch_bounds__(256) void afm_bwd_kernel(const T* __restrict__ g_ou
   const int P = N * (N - 1) / 2;
   const AfmLds l = afm_carve(smem, N, E, A, P, true);
   float* gxs = smem + afm_lds_floats(N, E, A, P, true);        // [N][E]
-  float* dw1 = gxs + N * E;                                   // [A][E]
+  float* dw1 = gxs + N * E;                                   // [A][E]  (block reduction at the end)
+  const int R = afm_rounds(N), H = afm_width(N);
+  int* sched = reinterpret_cast<int*>(dw1 + A * E);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   afm_stage_weights(l, W1, b1, w2, E, A, true);
+  afm_build_schedule(sched, N);
   for (int k = threadIdx.x; k < A * E; k += 256) dw1[k] = 0.f;
+  float dw1r[ES][AMAX];
+#pragma unroll
+  for (int es = 0; es < ES; ++es)
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) dw1r[es][a] = 0.f;
   float db1r[2] = {0.f, 0.f}, dw2r[2] = {0.f, 0.f}, db2r = 0.f;
   float* dh = l.dh + wave * A;
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
@@ -220,46 +249,66 @@ __global__ __launch_bounds__(256) void afm_bwd_kernel(const T* __restrict__ g_ou
     s = block_sum(s, l.red);
     for (int p = threadIdx.x; p < P; p += 256) l.aux[p] = l.lg[p] * (l.aux[p] - s);      // d(logit)
     __syncthreads();
-    for (int p = wave; p < P; p += 4) {
-      int i, j;
-      afm_pair_ij(p, N, &i, &j);
-      const float dl = l.aux[p], sc = l.lg[p];
-      float acc[2];
-      afm_hidden(l, i, j, E, A, lane, acc);
-      if (lane < A) {
-        const float h = fmaxf(acc[0], 0.f), d = acc[0] > 0.f ? dl * l.w2[lane] : 0.f;
-        dh[lane] = d;
-        db1r[0] += d;
-        dw2r[0] = fmaf(dl, h, dw2r[0]);
-      }
-      if (64 + lane < A) {
-        const float h = fmaxf(acc[1], 0.f), d = acc[1] > 0.f ? dl * l.w2[64 + lane] : 0.f;
-        dh[64 + lane] = d;
-        db1r[1] += d;
-        dw2r[1] = fmaf(dl, h, dw2r[1]);
-      }
-      if (lane == 0) db2r += dl;
-      __builtin_amdgcn_wave_barrier();
-      for (int e = lane; e < E; e += 64) {
-        const float xi = l.xs[i * E + e], xj = l.xs[j * E + e], pr = xi * xj;
-        float dp = sc * l.vec[e];
-        for (int a = 0; a < A; ++a) {
-          const float d = dh[a];
-          dp = fmaf(d, l.w1[a * E + e], dp);
-          atomicAdd(&dw1[a * E + e], d * pr);
+    for (int r = 0; r < R; ++r) {
+      for (int k = wave; k < H; k += 4) {
+        const int ij = sched[r * H + k];
+        if (ij < 0) continue;
+        const int i = ij >> 16, j = ij & 0xffff, p = i * (2 * N - i - 1) / 2 + j - i - 1;
+        const float dl = l.aux[p], sc = l.lg[p];
+        float acc[2];
+        afm_hidden(l, i, j, E, A, lane, acc);
+        if (lane < A) {
+          const float h = fmaxf(acc[0], 0.f), d = acc[0] > 0.f ? dl * l.w2[lane] : 0.f;
+          dh[lane] = d;
+          db1r[0] += d;
+          dw2r[0] = fmaf(dl, h, dw2r[0]);
         }
-        atomicAdd(&gxs[i * E + e], dp * xj);
-        atomicAdd(&gxs[j * E + e], dp * xi);
+        if (64 + lane < A) {
+          const float h = fmaxf(acc[1], 0.f), d = acc[1] > 0.f ? dl * l.w2[64 + lane] : 0.f;
+          dh[64 + lane] = d;
+          db1r[1] += d;
+          dw2r[1] = fmaf(dl, h, dw2r[1]);
+        }
+        if (lane == 0) db2r += dl;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int es = 0; es < ES; ++es) {
+          const int e = 64 * es + lane;
+          if (e < E) {
+            const float xi = l.xs[i * E + e], xj = l.xs[j * E + e], pr = xi * xj;
+            float dp = sc * l.vec[e];
+#pragma unroll
+            for (int a = 0; a < AMAX; ++a) {
+              if (a < A) {
+                const float d = dh[a];
+                dp = fmaf(d, l.w1[a * E + e], dp);
+                dw1r[es][a] = fmaf(d, pr, dw1r[es][a]);
+              }
+            }
+            gxs[i * E + e] = fmaf(dp, xj, gxs[i * E + e]);
+            gxs[j * E + e] = fmaf(dp, xi, gxs[j * E + e]);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
       }
-      __builtin_amdgcn_wave_barrier();
+      __syncthreads();
     }
-    __syncthreads();
     for (int k = threadIdx.x; k < N * E; k += 256) gx[b * N * E + k] = from_f32<T>(gxs[k]);
+  }
+  __syncthreads();
+  // block reduction of the register accumulators (four waves) through LDS, once per workgroup
+#pragma unroll
+  for (int es = 0; es < ES; ++es) {
+    const int e = 64 * es + lane;
+    if (e < E) {
+#pragma unroll
+      for (int a = 0; a < AMAX; ++a)
+        if (a < A) atomicAdd(&dw1[a * E + e], dw1r[es][a]);
+    }
   }
   __syncthreads();
   float* mine = partial + (size_t)blockIdx.x * (A * E + 2 * A + 1);
   for (int k = threadIdx.x; k < A * E; k += 256) mine[k] = dw1[k];
-  // vectors: reduce the four waves' registers through LDS (reuse dw1's storage after it has been written out)
   __syncthreads();
   float* vb1 = dw1;
   float* vw2 = dw1 + A;
@@ -338,22 +387,36 @@ extern "C" int trs_afm_bwd(const void* g_out, const void* g_attn, const void* x,
   TRS_REQUIRE(workspace != nullptr && ws_bytes >= trs_afm_bwd_workspace_bytes(B, N, E, A), TRS_EWORKSPACE,
               "afm_bwd: workspace too small");
   const int P = N * (N - 1) / 2;
-  const size_t lds = (afm_lds_floats(N, E, A, P, true) + (size_t)N * E + (size_t)A * E) * 4;
+  const size_t lds = (afm_lds_floats(N, E, A, P, true) + (size_t)N * E + (size_t)A * E +
+                      (size_t)afm_rounds(N) * afm_width(N)) * 4;
   TRS_REQUIRE(lds <= 160 * 1024, TRS_ESHAPE, "afm_bwd: N = %d, E = %d, A = %d need %zu bytes of LDS", N, E, A, lds);
   hipStream_t s = (hipStream_t)stream;
   const int grid = afm_grid(B);
   float* part = (float*)workspace;
-#define TRS_AFM_B(T_)                                                                                                 \
+#define TRS_AFM_B(T_, AMAX_, ES_)                                                                                     \
   do {                                                                                                                \
-    auto kern = afm_bwd_kernel<T_>;                                                                                   \
+    auto kern = afm_bwd_kernel<T_, AMAX_, ES_>;                                                                       \
     if (lds > 64 * 1024 &&                                                                                            \
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)  \
       return check_launch("afm_bwd: LDS attribute");                                                                  \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, (const T_*)g_out, (const T_*)g_attn, (const T_*)x,        \
                        (const T_*)attn, (const T_*)W1, (const T_*)b1, (const T_*)w2, B, N, E, A, (T_*)gx, part);      \
   } while (0)
-  if (dtype == TRS_F32) TRS_AFM_B(float);
-  else TRS_AFM_B(bf16_t);
+#define TRS_AFM_BT(T_)                                   \
+  do {                                                   \
+    if (E <= 64) {                                       \
+      if (A <= 32) TRS_AFM_B(T_, 32, 1);                 \
+      else if (A <= 64) TRS_AFM_B(T_, 64, 1);            \
+      else TRS_AFM_B(T_, 128, 1);                        \
+    } else {                                             \
+      if (A <= 32) TRS_AFM_B(T_, 32, 2);                 \
+      else if (A <= 64) TRS_AFM_B(T_, 64, 2);            \
+      else TRS_AFM_B(T_, 128, 2);                        \
+    }                                                    \
+  } while (0)
+  if (dtype == TRS_F32) TRS_AFM_BT(float);
+  else TRS_AFM_BT(bf16_t);
+#undef TRS_AFM_BT
 #undef TRS_AFM_B
   const int n = A * E + 2 * A + 1;
   hipLaunchKernelGGL(afm_reduce_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, s, part, grid, n, A, E, gW1, gb1,

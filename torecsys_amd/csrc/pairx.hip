@@ -49,6 +49,43 @@ static inline int pow2_lanes(int E) {
 
 // ---------------------------------------------------------------------------------------------
 // OPN 'vec' / 'num':  out[b,p] = sum_e x_i[e] x_j[e] k[p*kp + e*ke]      (vec: kp=E, ke=1; num: kp=1, ke=0)
+// (i,j) of every pair, packed (i << 16) | j, built once per workgroup
+__device__ __forceinline__ void build_pair_lut(int* lut, int N) {
+  const int P = N * (N - 1) / 2;
+  for (int p = threadIdx.x; p < P; p += blockDim.x) {
+    int i, j;
+    pair_ij(p, N, &i, &j);
+    lut[p] = (i << 16) | j;
+  }
+}
+
+// Conflict-free pair schedule (round-robin tournament, circle method): the NC2 pairs are split into R rounds of
+// at most H pairs that share no field, so the lane groups of a workgroup can add into per-field LDS accumulators
+// with plain read-modify-writes inside a round (ds_add_f32 on one address runs at ~1 lane per clock: the backward
+// kernels were bound by it) and synchronise between rounds.  sched[r*H + k] = (i << 16) | j, or -1.
+__host__ __device__ inline int sched_rounds(int N) { return (N & 1) ? N : N - 1; }
+__host__ __device__ inline int sched_width(int N) { return (N + 1) / 2; }
+__device__ __forceinline__ void build_round_schedule(int* sched, int N) {
+  const int M = (N & 1) ? N + 1 : N;          // even number of players; player M-1 is a dummy when N is odd
+  const int R = M - 1, H = M / 2;
+  for (int t = threadIdx.x; t < R * H; t += blockDim.x) {
+    const int r = t / H, k = t - r * H;
+    int a, b;
+    if (k == 0) {
+      a = r; b = M - 1;
+    } else {
+      a = (r + k) % R; b = (r - k + R) % R;
+    }
+    int v = -1;
+    if (a < N && b < N) {
+      const int i = a < b ? a : b, j = a < b ? b : a;
+      v = (i << 16) | j;
+    }
+    sched[t] = v;
+  }
+}
+__device__ __forceinline__ int pair_index(int i, int j, int N) { return i * (2 * N - i - 1) / 2 + j - i - 1; }
+
 template <typename T>
 __global__ __launch_bounds__(256) void pairw_dot_fwd_kernel(const T* __restrict__ x, const T* __restrict__ kern, int kp,
                                                             int ke, int64_t B, int N, int E, int EL,
@@ -56,23 +93,43 @@ __global__ __launch_bounds__(256) void pairw_dot_fwd_kernel(const T* __restrict_
   extern __shared__ float smem[];
   float* xs = smem;                      // [N][E]
   const int P = N * (N - 1) / 2;
+  int* lut = reinterpret_cast<int*>(smem + N * E);
   const int groups = blockDim.x / EL, grp = threadIdx.x / EL, e0 = threadIdx.x % EL;
+  build_pair_lut(lut, N);
+  constexpr int U = 4;                   // pairs in flight per lane group: their parameter rows are independent loads
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
     __syncthreads();
     stage_block(x + b * N * E, xs, N * E);
     __syncthreads();
-    for (int p = grp; p < P; p += groups) {
-      int i, j;
-      pair_ij(p, N, &i, &j);
-      float acc = 0.f;
-      for (int e = e0; e < E; e += EL) acc = fmaf(xs[i * E + e] * xs[j * E + e], to_f32(kern[(int64_t)p * kp + e * ke]), acc);
-      acc = group_reduce(acc, EL);
-      if (e0 == 0) out[b * P + p] = from_f32<T>(acc);
+    for (int p0 = grp; p0 < P; p0 += groups * U) {
+      float kv[U], acc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int p = p0 + u * groups;
+        kv[u] = (p < P && e0 < E) ? to_f32(kern[(int64_t)p * kp + e0 * ke]) : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int p = p0 + u * groups;
+        acc[u] = 0.f;
+        if (p < P) {
+          const int ij = lut[p], i = ij >> 16, j = ij & 0xffff;
+          if (e0 < E) acc[u] = xs[i * E + e0] * xs[j * E + e0] * kv[u];
+          for (int e = e0 + EL; e < E; e += EL)
+            acc[u] = fmaf(xs[i * E + e] * xs[j * E + e], to_f32(kern[(int64_t)p * kp + e * ke]), acc[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int p = p0 + u * groups;
+        const float r = group_reduce(acc[u], EL);
+        if (e0 == 0 && p < P) out[b * P + p] = from_f32<T>(r);
+      }
     }
   }
 }
 
-// data gradient: gx_i[e] += g k x_j[e], gx_j[e] += g k x_i[e]   (per-sample LDS accumulators, ds_add_f32)
+// data gradient: gx_i[e] += g k x_j[e], gx_j[e] += g k x_i[e]   (per-sample LDS accumulators, conflict-free rounds)
 template <typename T>
 __global__ __launch_bounds__(256) void pairw_dot_bwd_data_kernel(const T* __restrict__ g, const T* __restrict__ x,
                                                                  const T* __restrict__ kern, int kp, int ke, int64_t B,
@@ -81,23 +138,29 @@ __global__ __launch_bounds__(256) void pairw_dot_bwd_data_kernel(const T* __rest
   float* xs = smem;
   float* gs = smem + N * E;
   const int P = N * (N - 1) / 2;
+  const int R = sched_rounds(N), H = sched_width(N);
+  int* sched = reinterpret_cast<int*>(smem + 2 * N * E);
   const int groups = blockDim.x / EL, grp = threadIdx.x / EL, e0 = threadIdx.x % EL;
+  build_round_schedule(sched, N);
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
     __syncthreads();
     stage_block(x + b * N * E, xs, N * E);
     for (int e = threadIdx.x; e < N * E; e += blockDim.x) gs[e] = 0.f;
     __syncthreads();
-    for (int p = grp; p < P; p += groups) {
-      int i, j;
-      pair_ij(p, N, &i, &j);
-      const float gp = to_f32(g[b * P + p]);
-      for (int e = e0; e < E; e += EL) {
-        const float w = gp * to_f32(kern[(int64_t)p * kp + e * ke]);
-        atomicAdd(&gs[i * E + e], w * xs[j * E + e]);
-        atomicAdd(&gs[j * E + e], w * xs[i * E + e]);
+    for (int r = 0; r < R; ++r) {
+      for (int k = grp; k < H; k += groups) {
+        const int ij = sched[r * H + k];
+        if (ij < 0) continue;
+        const int i = ij >> 16, j = ij & 0xffff, p = pair_index(i, j, N);
+        const float gp = to_f32(g[b * P + p]);
+        for (int e = e0; e < E; e += EL) {
+          const float w = gp * to_f32(kern[(int64_t)p * kp + e * ke]);
+          gs[i * E + e] = fmaf(w, xs[j * E + e], gs[i * E + e]);
+          gs[j * E + e] = fmaf(w, xs[i * E + e], gs[j * E + e]);
+        }
       }
+      __syncthreads();
     }
-    __syncthreads();
     for (int e = threadIdx.x; e < N * E; e += blockDim.x) gx[b * N * E + e] = from_f32<T>(gs[e]);
   }
 }
@@ -113,7 +176,9 @@ __global__ __launch_bounds__(256) void pairw_dot_bwd_weight_kernel(const T* __re
   float* xs = smem;                 // [N][E]
   float* acc = smem + N * E;        // [PC][E]
   const int P = N * (N - 1) / 2;
+  int* lut = reinterpret_cast<int*>(smem + N * E + PC * E);
   const int groups = blockDim.x / EL, grp = threadIdx.x / EL, e0 = threadIdx.x % EL;
+  build_pair_lut(lut, N);
   const int64_t per = (B + gridDim.x - 1) / gridDim.x;
   const int64_t b_lo = (int64_t)blockIdx.x * per, b_hi = b_lo + per < B ? b_lo + per : B;
   float* mine = partial + (size_t)blockIdx.x * P * E;
@@ -126,8 +191,7 @@ __global__ __launch_bounds__(256) void pairw_dot_bwd_weight_kernel(const T* __re
       stage_block(x + b * N * E, xs, N * E);
       __syncthreads();
       for (int q = grp; q < pc; q += groups) {
-        int i, j;
-        pair_ij(p0 + q, N, &i, &j);
+        const int ij = lut[p0 + q], i = ij >> 16, j = ij & 0xffff;
         const float gp = to_f32(g[b * P + p0 + q]);
         for (int e = e0; e < E; e += EL) acc[q * E + e] = fmaf(gp, xs[i * E + e] * xs[j * E + e], acc[q * E + e]);
       }
@@ -157,9 +221,11 @@ __global__ __launch_bounds__(256) void pair_mul_fwd_kernel(const T* __restrict__
   float* cs = smem + N * E;
   constexpr int VE = Vec16<T>::VE;
   const int P = N * (N - 1) / 2;
+  int* lut = reinterpret_cast<int*>(smem + 2 * N * E);
   const int vpr = E / VE;                     // 16-byte vectors per row (E % VE == 0 checked by the host)
   const int groups = blockDim.x / vpr, grp = threadIdx.x / vpr, v = threadIdx.x % vpr;
   const bool active = grp < groups;
+  build_pair_lut(lut, N);
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
     __syncthreads();
     stage_block(a + b * N * E, as, N * E);
@@ -167,15 +233,17 @@ __global__ __launch_bounds__(256) void pair_mul_fwd_kernel(const T* __restrict__
     __syncthreads();
     if (!active) continue;
     uint4* orow = reinterpret_cast<uint4*>(out + (b * P) * (int64_t)E);
+    float bsh[VE];                          // shared bias: loaded once
+#pragma unroll
+    for (int k = 0; k < VE; ++k) bsh[k] = (bias != nullptr && bp == 0) ? to_f32(bias[v * VE + k]) : 0.f;
     for (int p = grp; p < P; p += groups) {
-      int i, j;
-      pair_ij(p, N, &i, &j);
+      const int ij = lut[p], i = ij >> 16, j = ij & 0xffff;
       float r[VE];
 #pragma unroll
       for (int k = 0; k < VE; ++k) {
         const int e = v * VE + k;
-        r[k] = as[i * E + e] * cs[j * E + e];
-        if (bias != nullptr) r[k] += to_f32(bias[(int64_t)p * bp * E + e]);
+        r[k] = fmaf(as[i * E + e], cs[j * E + e], bsh[k]);
+        if (bias != nullptr && bp != 0) r[k] += to_f32(bias[(int64_t)p * E + e]);
       }
       const uint4 u = Vec16<T>::pack(r);
       __builtin_nontemporal_store(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, u),
@@ -196,31 +264,37 @@ __global__ __launch_bounds__(256) void pair_mul_bwd_kernel(const T* __restrict__
   float* gcs = smem + 3 * N * E;
   constexpr int VE = Vec16<T>::VE;
   const int P = N * (N - 1) / 2;
+  const int R = sched_rounds(N), H = sched_width(N);
+  int* sched = reinterpret_cast<int*>(smem + 4 * N * E);
   const int vpr = E / VE;
   const int groups = blockDim.x / vpr, grp = threadIdx.x / vpr, v = threadIdx.x % vpr;
   const bool active = grp < groups;
+  build_round_schedule(sched, N);
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
     __syncthreads();
     stage_block(a + b * N * E, as, N * E);
     stage_block(c + b * N * E, cs, N * E);
     for (int e = threadIdx.x; e < 2 * N * E; e += blockDim.x) gas[e] = 0.f;      // gas and gcs are adjacent
     __syncthreads();
-    if (active) {
-      const uint4* grow = reinterpret_cast<const uint4*>(g + (b * P) * (int64_t)E);
-      for (int p = grp; p < P; p += groups) {
-        int i, j;
-        pair_ij(p, N, &i, &j);
-        float gv[VE];
-        Vec16<T>::unpack(grow[(int64_t)p * vpr + v], gv);
+    const uint4* grow = reinterpret_cast<const uint4*>(g + (b * P) * (int64_t)E);
+    for (int r = 0; r < R; ++r) {
+      if (active) {
+        for (int k = grp; k < H; k += groups) {
+          const int ij = sched[r * H + k];
+          if (ij < 0) continue;
+          const int i = ij >> 16, j = ij & 0xffff, p = pair_index(i, j, N);
+          float gv[VE];
+          Vec16<T>::unpack(grow[(int64_t)p * vpr + v], gv);
 #pragma unroll
-        for (int k = 0; k < VE; ++k) {
-          const int e = v * VE + k;
-          atomicAdd(&gas[i * E + e], gv[k] * cs[j * E + e]);
-          atomicAdd(&gcs[j * E + e], gv[k] * as[i * E + e]);
+          for (int q = 0; q < VE; ++q) {
+            const int e = v * VE + q;
+            gas[i * E + e] = fmaf(gv[q], cs[j * E + e], gas[i * E + e]);
+            gcs[j * E + e] = fmaf(gv[q], as[i * E + e], gcs[j * E + e]);
+          }
         }
       }
+      __syncthreads();
     }
-    __syncthreads();
     for (int e = threadIdx.x; e < N * E; e += blockDim.x) {
       ga[b * N * E + e] = from_f32<T>(gas[e]);
       gc[b * N * E + e] = from_f32<T>(gcs[e]);
@@ -304,36 +378,42 @@ __global__ __launch_bounds__(256) void pair_bil_bwd_data_kernel(const T* __restr
   float* gs = smem + N * E;            // [N][E]
   float* gts = smem + 2 * N * E;       // [nwaves][E]
   const int P = N * (N - 1) / 2;
+  const int R = sched_rounds(N), H = sched_width(N);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  int* sched = reinterpret_cast<int*>(gts + nwaves * E);
   float* gt = gts + wave * E;
+  build_round_schedule(sched, N);
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
     __syncthreads();
     stage_block(x + b * N * E, xs, N * E);
     for (int e = threadIdx.x; e < N * E; e += blockDim.x) gs[e] = 0.f;
     __syncthreads();
-    for (int p = wave; p < P; p += nwaves) {
-      int i, j;
-      pair_ij(p, N, &i, &j);
-      const T* Wp = W + (int64_t)p * wp * E * E;
-      for (int h = lane; h < E; h += 64) {
-        float t = 0.f;
-        for (int e = 0; e < E; ++e) t = fmaf(xs[i * E + e], to_f32(Wp[(int64_t)e * E + h]), t);
-        const float gv = MODE == 0 ? to_f32(g[b * P + p]) : to_f32(g[(b * P + p) * (int64_t)E + h]);
-        const float gth = gv * xs[j * E + h];
-        gt[h] = gth;
-        if (gT_out != nullptr) gT_out[(b * P + p) * (int64_t)E + h] = from_f32<T>(gth);
-        atomicAdd(&gs[j * E + h], gv * t);
+    for (int r = 0; r < R; ++r) {
+      for (int k = wave; k < H; k += nwaves) {
+        const int ij = sched[r * H + k];
+        if (ij < 0) continue;
+        const int i = ij >> 16, j = ij & 0xffff, p = pair_index(i, j, N);
+        const T* Wp = W + (int64_t)p * wp * E * E;
+        for (int h = lane; h < E; h += 64) {
+          float t = 0.f;
+          for (int e = 0; e < E; ++e) t = fmaf(xs[i * E + e], to_f32(Wp[(int64_t)e * E + h]), t);
+          const float gv = MODE == 0 ? to_f32(g[b * P + p]) : to_f32(g[(b * P + p) * (int64_t)E + h]);
+          const float gth = gv * xs[j * E + h];
+          gt[h] = gth;
+          if (gT_out != nullptr) gT_out[(b * P + p) * (int64_t)E + h] = from_f32<T>(gth);
+          gs[j * E + h] = fmaf(gv, t, gs[j * E + h]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int e = lane; e < E; e += 64) {
+          float acc = 0.f;
+          const T* row = Wp + (int64_t)e * E;
+          for (int h = 0; h < E; ++h) acc = fmaf(gt[h], to_f32(row[h]), acc);
+          gs[i * E + e] += acc;
+        }
+        __builtin_amdgcn_wave_barrier();
       }
-      __builtin_amdgcn_wave_barrier();
-      for (int e = lane; e < E; e += 64) {
-        float r = 0.f;
-        const T* row = Wp + (int64_t)e * E;
-        for (int h = 0; h < E; ++h) r = fmaf(gt[h], to_f32(row[h]), r);
-        atomicAdd(&gs[i * E + e], r);
-      }
-      __builtin_amdgcn_wave_barrier();
+      __syncthreads();
     }
-    __syncthreads();
     for (int e = threadIdx.x; e < N * E; e += blockDim.x) gx[b * N * E + e] = from_f32<T>(gs[e]);
   }
 }
@@ -357,8 +437,8 @@ extern "C" int trs_opn_vec_fwd(const void* x, const void* kern, int32_t kern_is_
   TRS_PAIRX_COMMON("opn_vec_fwd");
   if (B == 0 || N < 2) return TRS_OK;
   TRS_REQUIRE(x && kern && out, TRS_EINVAL, "opn_vec_fwd: NULL pointer");
-  const size_t lds = (size_t)N * E * 4;
-  TRS_REQUIRE(lds <= 64 * 1024, TRS_ESHAPE, "opn_vec_fwd: N*E = %d exceeds the 16384-element LDS block", N * E);
+  const size_t lds = (size_t)N * E * 4 + (size_t)N * (N - 1) / 2 * 4;
+  TRS_REQUIRE(lds <= 64 * 1024, TRS_ESHAPE, "opn_vec_fwd: N = %d, E = %d exceed the 64 KB LDS block", N, E);
   const int EL = pow2_lanes(E), kp = kern_is_num ? 1 : E, ke = kern_is_num ? 0 : 1;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == TRS_F32)
@@ -372,7 +452,7 @@ extern "C" int trs_opn_vec_fwd(const void* x, const void* kern, int32_t kern_is_
 
 static int opn_vec_weight_blocks(int64_t B) { return (int)std::min<int64_t>(256, std::max<int64_t>(1, B / 16)); }
 static int opn_vec_chunk(int N, int E) {
-  const int budget = 48 * 1024 / 4 - N * E;          // floats left for the partial after the x block
+  const int budget = 48 * 1024 / 4 - N * E - N * (N - 1) / 2;   // floats left after the x block and the pair table
   return std::max(1, budget / E);
 }
 
@@ -387,12 +467,14 @@ extern "C" int trs_opn_vec_bwd(const void* g, const void* x, const void* kern, i
   TRS_PAIRX_COMMON("opn_vec_bwd");
   if (B == 0 || N < 2) return TRS_OK;
   TRS_REQUIRE(g && x && kern, TRS_EINVAL, "opn_vec_bwd: NULL pointer");
-  TRS_REQUIRE((size_t)N * E * 4 * 2 <= 64 * 1024, TRS_ESHAPE, "opn_vec_bwd: N*E = %d exceeds the 8192-element LDS block",
-              N * E);
+  const size_t lut_bytes = (size_t)N * (N - 1) / 2 * 4;
+  const size_t sched_bytes = (size_t)sched_rounds(N) * sched_width(N) * 4;
+  TRS_REQUIRE((size_t)N * E * 4 * 2 + sched_bytes <= 64 * 1024, TRS_ESHAPE,
+              "opn_vec_bwd: N = %d, E = %d exceed the 64 KB LDS block", N, E);
   const int EL = pow2_lanes(E), kp = kern_is_num ? 1 : E, ke = kern_is_num ? 0 : 1;
   hipStream_t s = (hipStream_t)stream;
   if (gx != nullptr) {
-    const size_t lds = (size_t)N * E * 4 * 2;
+    const size_t lds = (size_t)N * E * 4 * 2 + sched_bytes;
     if (dtype == TRS_F32)
       hipLaunchKernelGGL((pairw_dot_bwd_data_kernel<float>), dim3(sample_grid(B)), dim3(256), lds, s, (const float*)g,
                          (const float*)x, (const float*)kern, kp, ke, B, N, E, EL, (float*)gx);
@@ -405,7 +487,7 @@ extern "C" int trs_opn_vec_bwd(const void* g, const void* x, const void* kern, i
     TRS_REQUIRE(workspace != nullptr && ws_bytes >= trs_opn_vec_bwd_workspace_bytes(B, N, E), TRS_EWORKSPACE,
                 "opn_vec_bwd: workspace too small");
     const int P = N * (N - 1) / 2, nblk = opn_vec_weight_blocks(B), PC = std::min(P, opn_vec_chunk(N, E));
-    const size_t lds = (size_t)(N * E + PC * E) * 4;
+    const size_t lds = (size_t)(N * E + PC * E) * 4 + lut_bytes;
     float* part = (float*)workspace;
     if (dtype == TRS_F32)
       hipLaunchKernelGGL((pairw_dot_bwd_weight_kernel<float>), dim3(nblk), dim3(256), lds, s, (const float*)g,
@@ -429,8 +511,8 @@ extern "C" int trs_pair_mul_fwd(const void* a, const void* c, const void* bias, 
   TRS_REQUIRE(E % VE == 0 && E / VE <= 256, TRS_ESHAPE, "pair_mul_fwd: E = %d must be a multiple of %d (16-byte rows)", E,
               VE);
   TRS_REQUIRE(aligned16(a) && aligned16(c) && aligned16(out), TRS_EALIGN, "pair_mul_fwd: pointers must be 16-byte aligned");
-  const size_t lds = (size_t)N * E * 4 * 2;
-  TRS_REQUIRE(lds <= 64 * 1024, TRS_ESHAPE, "pair_mul_fwd: N*E = %d exceeds the 8192-element LDS block", N * E);
+  const size_t lds = (size_t)N * E * 4 * 2 + (size_t)N * (N - 1) / 2 * 4;
+  TRS_REQUIRE(lds <= 64 * 1024, TRS_ESHAPE, "pair_mul_fwd: N = %d, E = %d exceed the 64 KB LDS block", N, E);
   hipStream_t s = (hipStream_t)stream;
   const int bp = bias_per_pair ? 1 : 0;
   if (dtype == TRS_F32)
@@ -451,8 +533,8 @@ extern "C" int trs_pair_mul_bwd(const void* g, const void* a, const void* c, int
   TRS_REQUIRE(E % VE == 0 && E / VE <= 256, TRS_ESHAPE, "pair_mul_bwd: E = %d must be a multiple of %d (16-byte rows)", E,
               VE);
   TRS_REQUIRE(aligned16(g), TRS_EALIGN, "pair_mul_bwd: g must be 16-byte aligned");
-  const size_t lds = (size_t)N * E * 4 * 4;
-  TRS_REQUIRE(lds <= 64 * 1024, TRS_ESHAPE, "pair_mul_bwd: N*E = %d exceeds the 4096-element LDS block", N * E);
+  const size_t lds = (size_t)N * E * 4 * 4 + (size_t)sched_rounds(N) * sched_width(N) * 4;
+  TRS_REQUIRE(lds <= 64 * 1024, TRS_ESHAPE, "pair_mul_bwd: N = %d, E = %d exceed the 64 KB LDS block", N, E);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == TRS_F32)
     hipLaunchKernelGGL((pair_mul_bwd_kernel<float>), dim3(sample_grid(B)), dim3(256), lds, s, (const float*)g,
@@ -497,7 +579,7 @@ extern "C" int trs_pair_bilinear_bwd_data(const void* g, const void* x, const vo
   if (B == 0 || N < 2) return TRS_OK;
   TRS_REQUIRE(g && x && W && gx, TRS_EINVAL, "pair_bilinear_bwd_data: NULL pointer");
   TRS_REQUIRE(mode == 0 || mode == 1, TRS_EINVAL, "pair_bilinear_bwd_data: mode %d", mode);
-  const size_t lds = ((size_t)2 * N * E + 4 * E) * 4;
+  const size_t lds = ((size_t)2 * N * E + 4 * E + (size_t)sched_rounds(N) * sched_width(N)) * 4;
   TRS_REQUIRE(lds <= 64 * 1024, TRS_ESHAPE, "pair_bilinear_bwd_data: N*E = %d exceeds the LDS block", N * E);
   const int wp = w_per_pair ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;

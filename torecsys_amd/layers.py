@@ -180,7 +180,8 @@ class OuterProductNetworkLayer(BaseLayer):
         elif self.kernel_type == 'vec':
             outputs = F_.opn_vec(x, self.kernel[0], False)
         else:
-            outputs = F_.opn_vec(x, self.kernel[0, :, 0], True)
+            # one scalar per pair: the inner-product kernel (MFMA Gram matrix per sample) times the kernel row
+            outputs = F_.pair_dot(x) * self.kernel[0, :, 0].to(x.dtype)
         outputs.names = ('B', 'O')
         return outputs
 
