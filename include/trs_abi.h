@@ -308,6 +308,15 @@ int trs_pair_bilinear_bwd_data(const void* g, const void* x, const void* W, int3
                                int64_t B, int32_t N, int32_t E, int32_t dtype, void* gx, void* gT,
                                trs_stream_t stream);
 
+/* GEMM route of the same form for training batch sizes: T[b,p,:] = x[b,i_p,:] @ W_p comes from one plain GEMM per
+ * field i (pairs (i, j>i) are adjacent: (B x E) @ (E x n_i*E)) into a (B,NC2,E) buffer; these passes finish it.
+ *   fwd  mode 0: out[b,p] = sum_h T[b,p,h] x[b,j_p,h]       mode 1: T <- T * x_j + bias   (in place; out unused)
+ *   bwd  gv = g[b,p] (mode 0) | g[b,p,h] (mode 1):  gxj[b,j_p,:] = sum_i gv * T[b,p,:];  T <- gv * x_j  (= dL/dT)   */
+int trs_pair_epilogue_fwd(void* T, const void* x, const void* bias, int32_t bias_per_pair, int32_t mode, int64_t B,
+                          int32_t N, int32_t E, int32_t dtype, void* out, trs_stream_t stream);
+int trs_pair_epilogue_bwd(const void* g, const void* x, void* T, int32_t mode, int64_t B, int32_t N, int32_t E,
+                          int32_t dtype, void* gxj, trs_stream_t stream);
+
 /* AttentionalFactorizationMachineLayer (attentional_factorization_machine.py:86-125, dropouts outside):
  *   prod[b,p,:] = x[b,i_p,:] * x[b,j_p,:];  attn[b,p] = softmax_p(w2 . relu(W1 prod + b1) + b2);
  *   out[b,:] = sum_p attn[b,p] prod[b,p,:]            W1 (A,E), b1 (A), w2 (A), b2 (1); out (B,E), attn (B,NC2)

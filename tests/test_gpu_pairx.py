@@ -183,3 +183,35 @@ def test_afm_vs_oracle(dev, dtype, tol, B, N, E, A):
     xr2 = x0.float().clone().requires_grad_()
     (O.afm_layer(xr2, *[p.detach() for p in pr])[0] * go).sum().backward()
     assert rel_err(x2.grad.float().cpu(), xr2.grad) <= tol * 3
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-5), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("N,E", [(39, 64), (7, 32), (12, 16)])
+def test_pair_bilinear_gemm_route_matches_oracle(dev, dtype, tol, N, E):
+    """B >= 256 takes the per-field GEMM route (trs_pair_epilogue_*); same checks as the one-kernel route."""
+    from torecsys_amd import functional as F_
+    from torecsys_amd.layers import BilinearInteractionLayer, OuterProductNetworkLayer
+    B = 300
+    g = torch.Generator().manual_seed(N + E)
+    x0 = (torch.randn(B, N, E, generator=g) * 0.5).to(dtype)
+    assert F_._pair_gemm_route(x0.to(dev))
+    for fam, kind in (("opn", "mat"), ("bil", "each")):
+        torch.manual_seed(9)
+        if fam == "opn":
+            lay = OuterProductNetworkLayer(E, N, kind).to(dev).to(dtype)
+            params = [lay.kernel]
+        else:
+            lay = BilinearInteractionLayer(E, N, kind).to(dev).to(dtype)
+            params = [lay.bilinear.weight, lay.bilinear.bias]
+        x = x0.to(dev).requires_grad_()
+        y = lay(x).rename(None)
+        xr = x0.float().clone().requires_grad_()
+        pr = [p.detach().float().cpu().requires_grad_() for p in params]
+        yr = O.outer_product_layer(xr, pr[0], kind) if fam == "opn" else O.bilinear_layer(xr, pr[0], pr[1], kind)
+        assert rel_err(y.float().cpu(), yr) <= tol, (fam, kind)
+        go = torch.randn(yr.shape, generator=g)
+        (y.float() * go.to(dev)).sum().backward()
+        (yr * go).sum().backward()
+        assert rel_err(x.grad.float().cpu(), xr.grad) <= tol * 2, (fam, kind, "gx")
+        for p, r in zip(params, pr):
+            assert rel_err(p.grad.float().cpu(), r.grad) <= tol * 2, (fam, kind, "gparam")

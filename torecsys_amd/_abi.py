@@ -32,6 +32,8 @@ SIGNATURES = {
     "trs_pair_mul_bwd": (c_int32, [_P, _P, _P, _I64, _I32, _I32, _I32, _P, _P, _P]),
     "trs_pair_bilinear_fwd": (c_int32, [_P, _P, _I32, _P, _I32, _I32, _I64, _I32, _I32, _I32, _P, _P]),
     "trs_pair_bilinear_bwd_data": (c_int32, [_P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _P, _P, _P]),
+    "trs_pair_epilogue_fwd": (c_int32, [_P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _P, _P]),
+    "trs_pair_epilogue_bwd": (c_int32, [_P, _P, _P, _I32, _I64, _I32, _I32, _I32, _P, _P]),
     "trs_afm_fwd": (c_int32, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _P, _P]),
     "trs_afm_bwd_workspace_bytes": (_SZ, [_I64, _I32, _I32, _I32]),
     "trs_afm_bwd": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _SZ, _P]),

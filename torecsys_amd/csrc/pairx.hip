@@ -418,6 +418,107 @@ __global__ __launch_bounds__(256) void pair_bil_bwd_data_kernel(const T* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Epilogues for the GEMM route of the per-pair bilinear form.  At training batch sizes T[b,p,:] = x[b,i_p,:] W_p is
+// produced by one plain GEMM per field i (all pairs (i, j>i) are adjacent columns: (B x E) @ (E x n_i*E), hipBLASLt)
+// into a (B, NC2, E) buffer; these passes turn it into the layer output and, in the backward, into dL/dT (in
+// place) and the x_j half of the input gradient.
+//   fwd  MODE 0: out[b,p]  = sum_h T[b,p,h] x[b,j_p,h]          MODE 1: T[b,p,h] = T[b,p,h] x[b,j_p,h] + bias (in place)
+//   bwd  MODE 0: gv = g[b,p]   MODE 1: gv = g[b,p,h]:   gxj[b,j_p,h] += gv T[b,p,h];   T[b,p,h] <- gv x[b,j_p,h]
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void pair_epi_fwd_kernel(T* __restrict__ Tb, const T* __restrict__ x,
+                                                           const T* __restrict__ bias, int bp, int64_t B, int N, int E,
+                                                           T* __restrict__ out) {
+  extern __shared__ float smem[];
+  float* xs = smem;
+  constexpr int VE = Vec16<T>::VE;
+  const int P = N * (N - 1) / 2;
+  int* lut = reinterpret_cast<int*>(smem + N * E);
+  const int vpr = E / VE;
+  const int groups = blockDim.x / vpr, grp = threadIdx.x / vpr, v = threadIdx.x % vpr;
+  const bool active = grp < groups;
+  build_pair_lut(lut, N);
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    stage_block(x + b * N * E, xs, N * E);
+    __syncthreads();
+    if (!active) continue;
+    uint4* trow = reinterpret_cast<uint4*>(Tb + (b * P) * (int64_t)E);
+    for (int p = grp; p < P; p += groups) {
+      const int j = lut[p] & 0xffff;
+      float t[VE];
+      Vec16<T>::unpack(trow[(int64_t)p * vpr + v], t);
+      if (MODE == 0) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < VE; ++k) acc = fmaf(t[k], xs[j * E + v * VE + k], acc);
+        for (int o = vpr >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);      // vpr is a power of two (host)
+        if (v == 0) out[b * P + p] = from_f32<T>(acc);
+      } else {
+#pragma unroll
+        for (int k = 0; k < VE; ++k) {
+          const int e = v * VE + k;
+          t[k] = t[k] * xs[j * E + e];
+          if (bias != nullptr) t[k] += to_f32(bias[(int64_t)p * bp * E + e]);
+        }
+        trow[(int64_t)p * vpr + v] = Vec16<T>::pack(t);
+      }
+    }
+  }
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void pair_epi_bwd_kernel(const T* __restrict__ g, const T* __restrict__ x,
+                                                           T* __restrict__ Tb, int64_t B, int N, int E,
+                                                           T* __restrict__ gxj) {
+  extern __shared__ float smem[];
+  float* xs = smem;
+  float* gs = smem + N * E;
+  constexpr int VE = Vec16<T>::VE;
+  const int P = N * (N - 1) / 2;
+  const int R = sched_rounds(N), H = sched_width(N);
+  int* sched = reinterpret_cast<int*>(smem + 2 * N * E);
+  const int vpr = E / VE;
+  const int groups = blockDim.x / vpr, grp = threadIdx.x / vpr, v = threadIdx.x % vpr;
+  const bool active = grp < groups;
+  build_round_schedule(sched, N);
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    stage_block(x + b * N * E, xs, N * E);
+    for (int e = threadIdx.x; e < N * E; e += blockDim.x) gs[e] = 0.f;
+    __syncthreads();
+    uint4* trow = reinterpret_cast<uint4*>(Tb + (b * P) * (int64_t)E);
+    const uint4* grow = reinterpret_cast<const uint4*>(g + (b * P) * (int64_t)E);      // MODE 1 only
+    for (int r = 0; r < R; ++r) {
+      if (active) {
+        for (int k = grp; k < H; k += groups) {
+          const int ij = sched[r * H + k];
+          if (ij < 0) continue;
+          const int i = ij >> 16, j = ij & 0xffff, p = pair_index(i, j, N);
+          float t[VE], gv[VE];
+          Vec16<T>::unpack(trow[(int64_t)p * vpr + v], t);
+          if (MODE == 0) {
+            const float gp = to_f32(g[b * P + p]);
+#pragma unroll
+            for (int q = 0; q < VE; ++q) gv[q] = gp;
+          } else {
+            Vec16<T>::unpack(grow[(int64_t)p * vpr + v], gv);
+          }
+#pragma unroll
+          for (int q = 0; q < VE; ++q) {
+            const int e = v * VE + q;
+            gs[j * E + e] = fmaf(gv[q], t[q], gs[j * E + e]);
+            t[q] = gv[q] * xs[j * E + e];
+          }
+          trow[(int64_t)p * vpr + v] = Vec16<T>::pack(t);
+        }
+      }
+      __syncthreads();
+    }
+    for (int e = threadIdx.x; e < N * E; e += blockDim.x) gxj[b * N * E + e] = from_f32<T>(gs[e]);
+  }
+}
+
 static int sample_grid(int64_t B, int per_block = 1) {
   const int64_t need = (B + per_block - 1) / per_block;
   return (int)std::min<int64_t>(need, 256 * 8);
@@ -591,4 +692,51 @@ extern "C" int trs_pair_bilinear_bwd_data(const void* g, const void* x, const vo
   else { if (mode == 0) TRS_BILB(bf16_t, 0); else TRS_BILB(bf16_t, 1); }
 #undef TRS_BILB
   return check_launch("pair_bilinear_bwd_data");
+}
+
+static bool pow2_i(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+extern "C" int trs_pair_epilogue_fwd(void* T, const void* x, const void* bias, int32_t bias_per_pair, int32_t mode,
+                                     int64_t B, int32_t N, int32_t E, int32_t dtype, void* out, trs_stream_t stream) {
+  TRS_PAIRX_COMMON("pair_epilogue_fwd");
+  if (B == 0 || N < 2) return TRS_OK;
+  TRS_REQUIRE(T && x && (mode == 1 || out), TRS_EINVAL, "pair_epilogue_fwd: NULL pointer");
+  TRS_REQUIRE(mode == 0 || mode == 1, TRS_EINVAL, "pair_epilogue_fwd: mode %d", mode);
+  const int VE = dtype == TRS_F32 ? 4 : 8;
+  TRS_REQUIRE(E % VE == 0 && pow2_i(E / VE) && E / VE <= 64, TRS_ESHAPE,
+              "pair_epilogue_fwd: E = %d must be %d times a power of two <= 64", E, VE);
+  TRS_REQUIRE(aligned16(T), TRS_EALIGN, "pair_epilogue_fwd: T must be 16-byte aligned");
+  const size_t lds = (size_t)N * E * 4 + (size_t)N * (N - 1) / 2 * 4;
+  TRS_REQUIRE(lds <= 64 * 1024, TRS_ESHAPE, "pair_epilogue_fwd: N = %d, E = %d exceed the 64 KB LDS block", N, E);
+  hipStream_t s = (hipStream_t)stream;
+  const int bp = bias_per_pair ? 1 : 0, grid = sample_grid(B);
+#define TRS_EPI(T_, M_)                                                                                               \
+  hipLaunchKernelGGL((pair_epi_fwd_kernel<T_, M_>), dim3(grid), dim3(256), lds, s, (T_*)T, (const T_*)x, (const T_*)bias, \
+                     bp, B, N, E, (T_*)out)
+  if (dtype == TRS_F32) { if (mode == 0) TRS_EPI(float, 0); else TRS_EPI(float, 1); }
+  else { if (mode == 0) TRS_EPI(bf16_t, 0); else TRS_EPI(bf16_t, 1); }
+#undef TRS_EPI
+  return check_launch("pair_epilogue_fwd");
+}
+
+extern "C" int trs_pair_epilogue_bwd(const void* g, const void* x, void* T, int32_t mode, int64_t B, int32_t N,
+                                     int32_t E, int32_t dtype, void* gxj, trs_stream_t stream) {
+  TRS_PAIRX_COMMON("pair_epilogue_bwd");
+  if (B == 0 || N < 2) return TRS_OK;
+  TRS_REQUIRE(g && x && T && gxj, TRS_EINVAL, "pair_epilogue_bwd: NULL pointer");
+  TRS_REQUIRE(mode == 0 || mode == 1, TRS_EINVAL, "pair_epilogue_bwd: mode %d", mode);
+  const int VE = dtype == TRS_F32 ? 4 : 8;
+  TRS_REQUIRE(E % VE == 0 && E / VE <= 256, TRS_ESHAPE, "pair_epilogue_bwd: E = %d must be a multiple of %d", E, VE);
+  TRS_REQUIRE(aligned16(T) && (mode == 0 || aligned16(g)), TRS_EALIGN, "pair_epilogue_bwd: 16-byte alignment");
+  const size_t lds = (size_t)N * E * 4 * 2 + (size_t)sched_rounds(N) * sched_width(N) * 4;
+  TRS_REQUIRE(lds <= 64 * 1024, TRS_ESHAPE, "pair_epilogue_bwd: N = %d, E = %d exceed the 64 KB LDS block", N, E);
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = sample_grid(B);
+#define TRS_EPIB(T_, M_)                                                                                              \
+  hipLaunchKernelGGL((pair_epi_bwd_kernel<T_, M_>), dim3(grid), dim3(256), lds, s, (const T_*)g, (const T_*)x, (T_*)T, B, \
+                     N, E, (T_*)gxj)
+  if (dtype == TRS_F32) { if (mode == 0) TRS_EPIB(float, 0); else TRS_EPIB(float, 1); }
+  else { if (mode == 0) TRS_EPIB(bf16_t, 0); else TRS_EPIB(bf16_t, 1); }
+#undef TRS_EPIB
+  return check_launch("pair_epilogue_bwd");
 }

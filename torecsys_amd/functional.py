@@ -586,8 +586,34 @@ def pair_mul(a: torch.Tensor, c: torch.Tensor, bias: Optional[torch.Tensor] = No
     return _PairMul.apply(a, c, bias, bias_per_pair)
 
 
+PAIR_GEMM_MIN_BATCH = 256      # below this the one-kernel path (weights streamed per sample group) is used
+
+
+def _pair_gemm_route(x: torch.Tensor) -> bool:
+    B, N, E = x.shape
+    ve = 16 // x.element_size()
+    vpr = E // ve if E % ve == 0 else 0
+    return (B >= PAIR_GEMM_MIN_BATCH and vpr > 0 and (vpr & (vpr - 1)) == 0 and vpr <= 64
+            and (N * E * 8 + N * N * 2 + 64) <= 64 * 1024)
+
+
+def _pair_T(x: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
+    """T[b,p,:] = x[b,i_p,:] @ W[p]: one plain GEMM per field i over its adjacent pairs (i, i+1..N-1)."""
+    B, N, E = x.shape
+    P = N * (N - 1) // 2
+    T = torch.empty(B, P, E, dtype=x.dtype, device=x.device)
+    T2 = T.view(B, P * E)
+    for i in range(N - 1):
+        p0, n_i = _pair_start(i, N), N - 1 - i
+        Wcat = W[p0:p0 + n_i].permute(1, 0, 2).reshape(E, n_i * E)          # [e][(q,h)] = W[p0+q][e][h]
+        torch.mm(x[:, i, :], Wcat, out=T2[:, p0 * E:(p0 + n_i) * E])
+    return T
+
+
 class _PairBilinear(Function):
-    """T = x_i W_p;  mode 0: out[b,p] = sum_h T_h x_j[h]  |  mode 1: out[b,p,:] = T * x_j + bias_p.   W (P,E,E) [e][h]."""
+    """T = x_i W_p;  mode 0: out[b,p] = sum_h T_h x_j[h]  |  mode 1: out[b,p,:] = T * x_j + bias_p.   W (P,E,E) [e][h].
+    Two routes: one HIP kernel that streams W_p per group of samples (small batches, any shape), or -- at training
+    batch sizes -- plain per-field GEMMs for T / dL/dx_i / dL/dW around HIP epilogue passes (trs_pair_epilogue_*)."""
 
     @staticmethod
     def forward(ctx, x, W, bias, mode):
@@ -599,9 +625,18 @@ class _PairBilinear(Function):
             raise ValueError(f"per-pair weights must be ({P}, {E}, {E}), got {tuple(W.shape)}")
         Wc = W.contiguous().to(x.dtype)
         bias_c = None if bias is None else bias.contiguous().to(x.dtype)
-        out = torch.empty((B, P) if mode == 0 else (B, P, E), dtype=x.dtype, device=x.device)
-        call("trs_pair_bilinear_fwd", ptr(x), ptr(Wc), 1, ptr(bias_c), 1, int(mode), B, N, E, value_dtype_code(x),
-             ptr(out), stream_ptr())
+        ctx.gemm = _pair_gemm_route(x)
+        if ctx.gemm:
+            T = _pair_T(x, Wc)
+            out = torch.empty(B, P, dtype=x.dtype, device=x.device) if mode == 0 else None
+            call("trs_pair_epilogue_fwd", ptr(T), ptr(x), ptr(bias_c), 1, int(mode), B, N, E, value_dtype_code(x),
+                 ptr(out), stream_ptr())
+            if mode == 1:
+                out = T
+        else:
+            out = torch.empty((B, P) if mode == 0 else (B, P, E), dtype=x.dtype, device=x.device)
+            call("trs_pair_bilinear_fwd", ptr(x), ptr(Wc), 1, ptr(bias_c), 1, int(mode), B, N, E, value_dtype_code(x),
+                 ptr(out), stream_ptr())
         ctx.save_for_backward(x, Wc)
         ctx.mode = int(mode)
         ctx.has_bias = bias is not None
@@ -615,10 +650,23 @@ class _PairBilinear(Function):
         P = N * (N - 1) // 2
         g = g.contiguous()
         need_w = ctx.needs_input_grad[1]
-        gx = torch.empty_like(x)
-        gT = torch.empty(B, P, E, dtype=x.dtype, device=x.device) if need_w else None
-        call("trs_pair_bilinear_bwd_data", ptr(g), ptr(x), ptr(W), 1, ctx.mode, B, N, E, value_dtype_code(x), ptr(gx),
-             ptr(gT), stream_ptr())
+        if ctx.gemm:
+            gT = _pair_T(x, W)                                  # recomputed, then overwritten by dL/dT in place
+            gx = torch.empty_like(x)
+            call("trs_pair_epilogue_bwd", ptr(g), ptr(x), ptr(gT), ctx.mode, B, N, E, value_dtype_code(x), ptr(gx),
+                 stream_ptr())
+            gT2 = gT.view(B, P * E)
+            gxi = torch.empty(B, E, dtype=x.dtype, device=x.device)
+            for i in range(N - 1):                              # dL/dx_i = dL/dT[:, pairs of i] @ Wcat_i^T
+                p0, n_i = _pair_start(i, N), N - 1 - i
+                Wcat = W[p0:p0 + n_i].permute(1, 0, 2).reshape(E, n_i * E)
+                torch.mm(gT2[:, p0 * E:(p0 + n_i) * E], Wcat.t(), out=gxi)
+                gx[:, i, :] += gxi
+        else:
+            gx = torch.empty_like(x)
+            gT = torch.empty(B, P, E, dtype=x.dtype, device=x.device) if need_w else None
+            call("trs_pair_bilinear_bwd_data", ptr(g), ptr(x), ptr(W), 1, ctx.mode, B, N, E, value_dtype_code(x), ptr(gx),
+                 ptr(gT), stream_ptr())
         gW = gb = None
         if need_w:
             # dW[p] = sum_b x[b,i_p,:]^T gT[b,p,:]: for field i the pairs (i, i+1..N-1) are adjacent, so one plain GEMM
