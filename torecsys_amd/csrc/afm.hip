@@ -175,6 +175,145 @@ __global__ __launch_bounds__(256) void afm_fwd_kernel(const T* __restrict__ x, c
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 fast path, forward.  The attention hidden layer is a GEMM over (pairs x E) @ (E x A) per sample:
+//   hidden^T[a][p] = W1[a][:] . prod[p][:]         (MFMA 16x16x32 bf16, fp32 accumulate)
+// A operand: W1 rows (16 attention units per tile), fragments resident in registers for the whole kernel;
+// B operand: prod^T for 16 pairs, built on the fly -- lane (pair n = l&15, e chunk q = l>>4) multiplies the two
+// 16-byte runs x_i[8q..8q+7], x_j[8q..8q+7] it reads from the LDS copy of the sample (rows padded to E*2+16 bytes:
+// conflict-free ds_read_b128) and packs them to bf16.  D: lane holds, for its pair, four attention units per tile;
+// relu / w2 / the reduction over units happen in registers + two cross-lane adds; logits land in LDS for the softmax.
+// The pair products never exist in memory.
+typedef __attribute__((ext_vector_type(8))) __bf16 afm_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float afm_f32x4;
+
+template <int AT /* A/16 */, int KS /* E/32 */>
+__global__ __launch_bounds__(256) void afm_fwd_mfma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W1,
+                                                           const bf16_t* __restrict__ b1, const bf16_t* __restrict__ w2,
+                                                           const bf16_t* __restrict__ b2, int64_t B, int N,
+                                                           bf16_t* __restrict__ out, bf16_t* __restrict__ attn) {
+  constexpr int E = 32 * KS, A = 16 * AT, RS = E * 2 + 16;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int P = N * (N - 1) / 2, PT = (P + 15) / 16;
+  char* xs = smem_raw;                                           // [N][RS] bf16 rows
+  float* lg = reinterpret_cast<float*>(smem_raw + ((N * RS + 15) & ~15));      // [PT*16]
+  int* lut = reinterpret_cast<int*>(lg + PT * 16);               // [PT*16]  (i << 16) | j, padded with pair 0
+  float* vec = reinterpret_cast<float*>(lut + PT * 16);          // [E]
+  float* red = vec + E;                                          // [8]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, n = lane & 15;
+  for (int p = threadIdx.x; p < PT * 16; p += 256) {
+    int i = 0, j = 1;
+    if (p < P) afm_pair_ij(p, N, &i, &j);
+    lut[p] = (i << 16) | j;
+  }
+  // resident A fragments (W1) and this lane's b1 / w2 values (attention unit a = 16 mt + 4 q + r)
+  uint4 Wf[AT][KS];
+  float b1v[AT][4], w2v[AT][4];
+#pragma unroll
+  for (int mt = 0; mt < AT; ++mt) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      Wf[mt][ks] = *reinterpret_cast<const uint4*>(W1 + (size_t)(16 * mt + n) * E + 32 * ks + 8 * q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      b1v[mt][r] = to_f32(b1[16 * mt + 4 * q + r]);
+      w2v[mt][r] = to_f32(w2[16 * mt + 4 * q + r]);
+    }
+  }
+  const float bias2 = to_f32(b2[0]);
+  constexpr int VPR = E / 8;                                     // 16-byte vectors per x row
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    for (int v = threadIdx.x; v < N * VPR; v += 256) {
+      const int row = v / VPR, col = v - row * VPR;
+      *reinterpret_cast<uint4*>(xs + row * RS + col * 16) =
+          *reinterpret_cast<const uint4*>(x + (b * N + row) * (int64_t)E + col * 8);
+    }
+    for (int k = threadIdx.x; k < E; k += 256) vec[k] = 0.f;
+    __syncthreads();
+    // online softmax (flash-attention style): running max / normaliser per wave, the weighted sum of the pair
+    // products accumulates in registers (lane: pair column n, e runs 8q..8q+7 per k slab) while the logits are made
+    float run_m = -INFINITY, run_l = 0.f;
+    float ov[KS][8];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) ov[ks][k] = 0.f;
+    for (int pt = wave; pt < PT; pt += 4) {
+      const int ij = lut[pt * 16 + n], i = ij >> 16, j = ij & 0xffff;
+      afm_f32x4 acc[AT];
+#pragma unroll
+      for (int mt = 0; mt < AT; ++mt) acc[mt] = afm_f32x4{0.f, 0.f, 0.f, 0.f};
+      float pr[KS][8];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        float xj[8];
+        Vec16<bf16_t>::unpack(*reinterpret_cast<const uint4*>(xs + i * RS + (32 * ks + 8 * q) * 2), pr[ks]);
+        Vec16<bf16_t>::unpack(*reinterpret_cast<const uint4*>(xs + j * RS + (32 * ks + 8 * q) * 2), xj);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pr[ks][k] *= xj[k];
+        const uint4 bf = Vec16<bf16_t>::pack(pr[ks]);
+#pragma unroll
+        for (int mt = 0; mt < AT; ++mt)
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(afm_bf16x8, Wf[mt][ks]),
+                                                            __builtin_bit_cast(afm_bf16x8, bf), acc[mt], 0, 0, 0);
+      }
+      float part = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < AT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part = fmaf(fmaxf(acc[mt][r] + b1v[mt][r], 0.f), w2v[mt][r], part);
+      part += __shfl_xor(part, 16, 64);
+      part += __shfl_xor(part, 32, 64);
+      const bool valid = pt * 16 + n < P;
+      const float lgv = valid ? part + bias2 : -INFINITY;
+      if (q == 0) lg[pt * 16 + n] = lgv;
+      // lane-local online softmax over this lane's pair column (no cross-lane traffic per tile)
+      const float new_m = fmaxf(run_m, lgv);
+      const float scale = new_m == -INFINITY ? 1.f : __expf(run_m - new_m);      // 0 on the first valid pair
+      const float w = valid ? __expf(lgv - new_m) : 0.f;
+      run_l = run_l * scale + w;
+      run_m = new_m;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ov[ks][k] = fmaf(w, pr[ks][k], ov[ks][k] * scale);
+    }
+    // combine the 16 pair columns of each wave and the four waves
+    float wm = run_m;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) wm = fmaxf(wm, __shfl_xor(wm, o, 64));
+    if (lane == 0) red[wave] = wm;
+    __syncthreads();
+    const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float f = run_m == -INFINITY ? 0.f : __expf(run_m - m);
+    float ls = run_l * f;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) ls += __shfl_xor(ls, o, 64);
+    if (lane == 0) red[4 + wave] = ls;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float v = ov[ks][k] * f;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);             // over the 16 pair columns
+        if (n == 0) atomicAdd(&vec[32 * ks + 8 * q + k], v);
+      }
+    __syncthreads();
+    const float sum = red[4] + red[5] + red[6] + red[7];
+    const float inv = 1.f / sum;
+    for (int p = threadIdx.x; p < P; p += 256) attn[b * P + p] = from_f32<bf16_t>(__expf(lg[p] - m) * inv);
+    __syncthreads();
+    for (int k = threadIdx.x; k < E; k += 256) out[b * E + k] = from_f32<bf16_t>(vec[k] * inv);
+  }
+}
+
+static size_t afm_fwd_mfma_lds(int N, int E) {
+  const int P = N * (N - 1) / 2, PT = (P + 15) / 16;
+  return (size_t)((N * (E * 2 + 16) + 15) & ~15) + (size_t)PT * 16 * 8 + (size_t)E * 4 + 64;
+}
+
 // Conflict-free pair schedule (same construction as pairx.hip): rounds of pairs that share no field, so the four
 // waves can add into the per-field LDS gradient block with plain read-modify-writes inside a round.
 __host__ __device__ inline int afm_rounds(int N) { return (N & 1) ? N : N - 1; }
@@ -353,9 +492,37 @@ extern "C" int trs_afm_fwd(const void* x, const void* W1, const void* b1, const 
   TRS_REQUIRE(N >= 2, TRS_ESHAPE, "afm_fwd: needs at least two fields (N = %d)", N);
   TRS_REQUIRE(x && W1 && b1 && w2 && b2 && out && attn, TRS_EINVAL, "afm_fwd: NULL pointer");
   const int P = N * (N - 1) / 2;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == TRS_BF16 && (E == 32 || E == 64 || E == 128) && A % 16 == 0 && A <= 128 &&
+      afm_fwd_mfma_lds(N, E) <= 64 * 1024 && aligned16(x) && aligned16(W1)) {
+    const size_t lds = afm_fwd_mfma_lds(N, E);
+    const int grid = (int)std::min<int64_t>(B, 256 * 4);
+#define TRS_AFM_M(AT_, KS_)                                                                                       \
+  hipLaunchKernelGGL((afm_fwd_mfma_kernel<AT_, KS_>), dim3(grid), dim3(256), lds, s, (const bf16_t*)x,            \
+                     (const bf16_t*)W1, (const bf16_t*)b1, (const bf16_t*)w2, (const bf16_t*)b2, B, N, (bf16_t*)out, \
+                     (bf16_t*)attn)
+#define TRS_AFM_MK(AT_)                                 \
+  do {                                                  \
+    if (E == 32) TRS_AFM_M(AT_, 1);                     \
+    else if (E == 64) TRS_AFM_M(AT_, 2);                \
+    else TRS_AFM_M(AT_, 4);                             \
+  } while (0)
+    switch (A / 16) {
+      case 1: TRS_AFM_MK(1); break;
+      case 2: TRS_AFM_MK(2); break;
+      case 3: TRS_AFM_MK(3); break;
+      case 4: TRS_AFM_MK(4); break;
+      case 5: TRS_AFM_MK(5); break;
+      case 6: TRS_AFM_MK(6); break;
+      case 7: TRS_AFM_MK(7); break;
+      default: TRS_AFM_MK(8); break;
+    }
+#undef TRS_AFM_MK
+#undef TRS_AFM_M
+    return check_launch("afm_fwd(mfma)");
+  }
   const size_t lds = afm_lds_floats(N, E, A, P, false) * 4;
   TRS_REQUIRE(lds <= 160 * 1024, TRS_ESHAPE, "afm_fwd: N = %d, E = %d, A = %d need %zu bytes of LDS", N, E, A, lds);
-  hipStream_t s = (hipStream_t)stream;
 #define TRS_AFM_F(T_)                                                                                                 \
   do {                                                                                                                \
     auto kern = afm_fwd_kernel<T_>;                                                                                   \
