@@ -152,7 +152,8 @@ def test_afm_golden(golden, dev, shape):
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-5), (torch.bfloat16, 3e-2)])
 @pytest.mark.parametrize("B,N,E,A", [(37, 39, 64, 64), (5, 2, 16, 8), (130, 7, 24, 40), (9, 5, 128, 100), (1, 3, 8, 1),
-                                     (64, 10, 32, 16), (33, 12, 128, 32), (20, 39, 64, 128), (3, 2, 64, 48)])
+                                     (64, 10, 32, 16), (33, 12, 128, 32), (20, 39, 64, 128), (3, 2, 64, 48),
+                                     (40, 9, 32, 64), (17, 6, 64, 96), (9, 4, 32, 128), (300, 2, 64, 32), (70, 34, 64, 32)])
 def test_afm_vs_oracle(dev, dtype, tol, B, N, E, A):
     g = torch.Generator().manual_seed(B + N + E + A)
     x0 = (torch.randn(B, N, E, generator=g) * 0.7).to(dtype)

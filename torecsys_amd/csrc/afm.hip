@@ -460,6 +460,303 @@ __global__ __launch_bounds__(256) void afm_bwd_kernel(const T* __restrict__ g_ou
   for (int k = threadIdx.x; k < 2 * A + 1; k += 256) mine[A * E + k] = dw1[k];
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 fast path, backward: three chained GEMMs per tile of 16 pairs, all on MFMA 16x16x32 bf16.
+//   (1) hidden^T[a][p]  = W1 . prod^T              rows of W1 fed in a permuted order so that a lane's outputs are
+//                                                   8-element runs of attention units: they ARE the B operand of (2)
+//   (2) dprod^T[e][p]   = W1^T . dh                 dh = d(logit)_p w2 [hidden > 0]
+//   (3) dW1[a][e]      += dh^T(a x pairs) . prod(pairs x e)      K = pairs: both operands go through a small per-wave
+//                                                   LDS transpose (2-byte stores, 16-byte fragment loads), 32 pairs a step
+// Tiles are taken from the conflict-free round schedule (16 field-disjoint pairs), every wave owns whole rounds and
+// a private fp32 copy of the (N x E) input-gradient block, so dx_i += dprod * x_j needs no atomics at all.
+template <int AT /* A/16, even */, int KS /* E/32 */>
+__global__ __launch_bounds__(256) void afm_bwd_mfma_kernel(const bf16_t* __restrict__ g_out,
+                                                           const bf16_t* __restrict__ g_attn,
+                                                           const bf16_t* __restrict__ x, const bf16_t* __restrict__ attn,
+                                                           const bf16_t* __restrict__ W1, const bf16_t* __restrict__ b1,
+                                                           const bf16_t* __restrict__ w2, int64_t B, int N,
+                                                           bf16_t* __restrict__ gx, float* __restrict__ partial) {
+  constexpr int E = 32 * KS, A = 16 * AT, ET = 2 * KS, AKS = AT / 2, RS = E * 2 + 16, TS = 80;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int P = N * (N - 1) / 2, PP = (P + 15) & ~15;
+  const int R = afm_rounds(N), H = afm_width(N), TPR = (H + 15) / 16;
+  char* sp = smem_raw;
+  char* xs = sp; sp += (N * RS + 15) & ~15;
+  float* lg = reinterpret_cast<float*>(sp); sp += PP * 4;
+  float* aux = reinterpret_cast<float*>(sp); sp += PP * 4;
+  int* lutp = reinterpret_cast<int*>(sp); sp += PP * 4;
+  float* go = reinterpret_cast<float*>(sp); sp += E * 4;
+  float* red = reinterpret_cast<float*>(sp); sp += 64;
+  int* sched = reinterpret_cast<int*>(sp); sp += R * TPR * 16 * 4;
+  float* gxs_all = reinterpret_cast<float*>(sp); sp += 4 * N * E * 4;
+  char* dhT_all = sp; sp += 4 * A * TS;
+  char* prT_all = sp;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, n = lane & 15;
+  float* gxs = gxs_all + wave * N * E;
+  char* dhT = dhT_all + wave * A * TS;
+  char* prT = prT_all + wave * E * TS;
+  for (int p = threadIdx.x; p < PP; p += 256) {
+    int i = 0, j = 1;
+    if (p < P) afm_pair_ij(p, N, &i, &j);
+    lutp[p] = (i << 16) | j;
+  }
+  {
+    const int M = (N & 1) ? N + 1 : N;
+    for (int t = threadIdx.x; t < R * TPR * 16; t += 256) {
+      const int r = t / (TPR * 16), k = t - r * (TPR * 16);
+      int v = -1;
+      if (k < H) {
+        int a_, b_;
+        if (k == 0) { a_ = r; b_ = M - 1; }
+        else { a_ = (r + k) % R; b_ = (r - k + R) % R; }
+        if (a_ < N && b_ < N) v = ((a_ < b_ ? a_ : b_) << 16) | (a_ < b_ ? b_ : a_);
+      }
+      sched[t] = v;
+    }
+  }
+  // resident operands.  amap(t, m): row m of tile t <-> unit 32 (t>>1) + 8 (m>>2) + 4 (t&1) + (m&3)
+  uint4 Wf[AT][KS], Vf[ET][AKS];
+  float b1v[AT][4], w2v[AT][4];
+#pragma unroll
+  for (int mt = 0; mt < AT; ++mt) {
+    const int arow = 32 * (mt >> 1) + 8 * (n >> 2) + 4 * (mt & 1) + (n & 3);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      Wf[mt][ks] = *reinterpret_cast<const uint4*>(W1 + (size_t)arow * E + 32 * ks + 8 * q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int a = 32 * (mt >> 1) + 8 * q + 4 * (mt & 1) + r;
+      b1v[mt][r] = to_f32(b1[a]);
+      w2v[mt][r] = to_f32(w2[a]);
+    }
+  }
+#pragma unroll
+  for (int et = 0; et < ET; ++et) {
+    const int erow = 32 * (et >> 1) + 8 * (n >> 2) + 4 * (et & 1) + (n & 3);
+#pragma unroll
+    for (int u = 0; u < AKS; ++u) {
+      uint32_t w[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t lo = W1[(size_t)(32 * u + 8 * q + 2 * k) * E + erow].v;
+        const uint32_t hi = W1[(size_t)(32 * u + 8 * q + 2 * k + 1) * E + erow].v;
+        w[k] = lo | (hi << 16);
+      }
+      Vf[et][u] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+  afm_f32x4 acc3[AT][ET];
+#pragma unroll
+  for (int mt = 0; mt < AT; ++mt)
+#pragma unroll
+    for (int et = 0; et < ET; ++et) acc3[mt][et] = afm_f32x4{0.f, 0.f, 0.f, 0.f};
+  float db1r[AT][4], dw2r[AT][4], db2r = 0.f;
+#pragma unroll
+  for (int mt = 0; mt < AT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { db1r[mt][r] = 0.f; dw2r[mt][r] = 0.f; }
+  constexpr int VPR = E / 8;
+
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    for (int v = threadIdx.x; v < N * VPR; v += 256) {
+      const int row = v / VPR, col = v - row * VPR;
+      *reinterpret_cast<uint4*>(xs + row * RS + col * 16) =
+          *reinterpret_cast<const uint4*>(x + (b * N + row) * (int64_t)E + col * 8);
+    }
+    for (int k = threadIdx.x; k < E; k += 256) go[k] = g_out != nullptr ? to_f32(g_out[b * E + k]) : 0.f;
+    for (int p = threadIdx.x; p < P; p += 256) lg[p] = to_f32(attn[b * P + p]);
+    for (int k = lane; k < N * E; k += 64) gxs[k] = 0.f;
+    __syncthreads();
+    // d(score)_p = g_attn_p + g_out . prod_p      (one pair per thread, 16-byte row reads)
+    for (int p = threadIdx.x; p < P; p += 256) {
+      const int ij = lutp[p], i = ij >> 16, j = ij & 0xffff;
+      float d = 0.f;
+#pragma unroll
+      for (int c = 0; c < VPR; ++c) {
+        float xi[8], xj[8];
+        Vec16<bf16_t>::unpack(*reinterpret_cast<const uint4*>(xs + i * RS + c * 16), xi);
+        Vec16<bf16_t>::unpack(*reinterpret_cast<const uint4*>(xs + j * RS + c * 16), xj);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d = fmaf(go[8 * c + k], xi[k] * xj[k], d);
+      }
+      aux[p] = d + (g_attn != nullptr ? to_f32(g_attn[b * P + p]) : 0.f);
+    }
+    __syncthreads();
+    float s = 0.f;
+    for (int p = threadIdx.x; p < P; p += 256) s += lg[p] * aux[p];
+    s = block_sum(s, red);
+    for (int p = threadIdx.x; p < P; p += 256) aux[p] = lg[p] * (aux[p] - s);       // d(logit)
+    __syncthreads();
+    int tiles_done = 0;
+    for (int r = wave; r < R; r += 4) {
+      for (int t = 0; t < TPR; ++t) {
+        const int ent = sched[(r * TPR + t) * 16 + n];
+        const bool valid = ent >= 0;
+        const int i = valid ? ent >> 16 : 0, j = valid ? ent & 0xffff : 1;
+        const int p = i * (2 * N - i - 1) / 2 + j - i - 1;
+        const float dlv = valid ? aux[p] : 0.f, scv = valid ? lg[p] : 0.f;
+        float xi[KS][8], xj[KS][8];
+        afm_f32x4 acc1[AT];
+#pragma unroll
+        for (int mt = 0; mt < AT; ++mt) acc1[mt] = afm_f32x4{0.f, 0.f, 0.f, 0.f};
+        const int col = 16 * (tiles_done & 1) + n;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          Vec16<bf16_t>::unpack(*reinterpret_cast<const uint4*>(xs + i * RS + (32 * ks + 8 * q) * 2), xi[ks]);
+          Vec16<bf16_t>::unpack(*reinterpret_cast<const uint4*>(xs + j * RS + (32 * ks + 8 * q) * 2), xj[ks]);
+          float pr[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) pr[k] = xi[ks][k] * xj[ks][k];
+          const uint4 bf = Vec16<bf16_t>::pack(pr);
+#pragma unroll
+          for (int mt = 0; mt < AT; ++mt)
+            acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(afm_bf16x8, Wf[mt][ks]),
+                                                               __builtin_bit_cast(afm_bf16x8, bf), acc1[mt], 0, 0, 0);
+          // prod^T for GEMM (3): element (e = 32 ks + 8 q + k, pair column col)
+          const uint32_t words[4] = {bf.x, bf.y, bf.z, bf.w};
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            *reinterpret_cast<uint16_t*>(prT + (32 * ks + 8 * q + k) * TS + col * 2) =
+                (uint16_t)(words[k >> 1] >> (16 * (k & 1)));
+        }
+        // d(hidden), parameter-vector gradients, B operand of GEMM (2)
+        uint4 Bdh[AKS];
+#pragma unroll
+        for (int u = 0; u < AKS; ++u) {
+          float run[8];
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const int mt = 2 * u + h2;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+              const float pre = acc1[mt][r4] + b1v[mt][r4];
+              const float d = pre > 0.f ? dlv * w2v[mt][r4] : 0.f;
+              db1r[mt][r4] += d;
+              dw2r[mt][r4] = fmaf(dlv, fmaxf(pre, 0.f), dw2r[mt][r4]);
+              run[4 * h2 + r4] = d;
+            }
+          }
+          Bdh[u] = Vec16<bf16_t>::pack(run);
+          const uint32_t words[4] = {Bdh[u].x, Bdh[u].y, Bdh[u].z, Bdh[u].w};
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            *reinterpret_cast<uint16_t*>(dhT + (32 * u + 8 * q + k) * TS + col * 2) =
+                (uint16_t)(words[k >> 1] >> (16 * (k & 1)));
+        }
+        if (q == 0) db2r += dlv;
+        // GEMM (2): dprod^T = W1^T . dh
+        afm_f32x4 acc2[ET];
+#pragma unroll
+        for (int et = 0; et < ET; ++et) {
+          acc2[et] = afm_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int u = 0; u < AKS; ++u)
+            acc2[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(afm_bf16x8, Vf[et][u]),
+                                                               __builtin_bit_cast(afm_bf16x8, Bdh[u]), acc2[et], 0, 0, 0);
+        }
+        if (valid) {
+#pragma unroll
+          for (int v = 0; v < KS; ++v) {
+            const int e0 = 32 * v + 8 * q;
+            float* gi = gxs + i * E + e0;
+            float* gj = gxs + j * E + e0;
+            float4 a0 = *reinterpret_cast<float4*>(gi), a1 = *reinterpret_cast<float4*>(gi + 4);
+            float4 c0 = *reinterpret_cast<float4*>(gj), c1 = *reinterpret_cast<float4*>(gj + 4);
+            float dp[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+              dp[k] = (k < 4 ? acc2[2 * v][k & 3] : acc2[2 * v + 1][k & 3]) + scv * go[e0 + k];
+            a0.x = fmaf(dp[0], xj[v][0], a0.x); a0.y = fmaf(dp[1], xj[v][1], a0.y);
+            a0.z = fmaf(dp[2], xj[v][2], a0.z); a0.w = fmaf(dp[3], xj[v][3], a0.w);
+            a1.x = fmaf(dp[4], xj[v][4], a1.x); a1.y = fmaf(dp[5], xj[v][5], a1.y);
+            a1.z = fmaf(dp[6], xj[v][6], a1.z); a1.w = fmaf(dp[7], xj[v][7], a1.w);
+            c0.x = fmaf(dp[0], xi[v][0], c0.x); c0.y = fmaf(dp[1], xi[v][1], c0.y);
+            c0.z = fmaf(dp[2], xi[v][2], c0.z); c0.w = fmaf(dp[3], xi[v][3], c0.w);
+            c1.x = fmaf(dp[4], xi[v][4], c1.x); c1.y = fmaf(dp[5], xi[v][5], c1.y);
+            c1.z = fmaf(dp[6], xi[v][6], c1.z); c1.w = fmaf(dp[7], xi[v][7], c1.w);
+            *reinterpret_cast<float4*>(gi) = a0; *reinterpret_cast<float4*>(gi + 4) = a1;
+            *reinterpret_cast<float4*>(gj) = c0; *reinterpret_cast<float4*>(gj + 4) = c1;
+          }
+        }
+        ++tiles_done;
+        const bool last = (r + 4 >= R) && (t == TPR - 1);
+        if ((tiles_done & 1) == 0 || last) {
+          if (tiles_done & 1) {
+            // odd tile count: the second half of the 32-pair step is empty
+#pragma unroll
+            for (int u = 0; u < AKS; ++u)
+#pragma unroll
+              for (int k = 0; k < 8; ++k)
+                *reinterpret_cast<uint16_t*>(dhT + (32 * u + 8 * q + k) * TS + (16 + n) * 2) = 0;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+              for (int k = 0; k < 8; ++k)
+                *reinterpret_cast<uint16_t*>(prT + (32 * ks + 8 * q + k) * TS + (16 + n) * 2) = 0;   // 0 * stale NaN
+          }
+          __builtin_amdgcn_wave_barrier();
+          // GEMM (3): dW1 += dh^T . prod over the 32 staged pairs
+          uint4 Bf[ET];
+#pragma unroll
+          for (int et = 0; et < ET; ++et) Bf[et] = *reinterpret_cast<const uint4*>(prT + (16 * et + n) * TS + q * 16);
+#pragma unroll
+          for (int mt = 0; mt < AT; ++mt) {
+            const uint4 Af = *reinterpret_cast<const uint4*>(dhT + (16 * mt + n) * TS + q * 16);
+#pragma unroll
+            for (int et = 0; et < ET; ++et)
+              acc3[mt][et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(afm_bf16x8, Af),
+                                                                     __builtin_bit_cast(afm_bf16x8, Bf[et]), acc3[mt][et],
+                                                                     0, 0, 0);
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (tiles_done & 1) ++tiles_done;        // keep the column parity aligned for the next sample
+        }
+      }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < N * E; k += 256)
+      gx[b * N * E + k] = from_f32<bf16_t>(gxs_all[k] + gxs_all[N * E + k] + gxs_all[2 * N * E + k] + gxs_all[3 * N * E + k]);
+  }
+  // ---- parameter gradients of this workgroup -> partial[A*E + 2A + 1]
+  __syncthreads();
+  float* dw1 = gxs_all;                         // [A][E] + [2A+1], reuses the gradient blocks
+  for (int k = threadIdx.x; k < A * E + 2 * A + 1; k += 256) dw1[k] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < AT; ++mt)
+#pragma unroll
+    for (int et = 0; et < ET; ++et)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&dw1[(16 * mt + 4 * q + r) * E + 16 * et + n], acc3[mt][et][r]);
+#pragma unroll
+  for (int mt = 0; mt < AT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v1 = db1r[mt][r], v2 = dw2r[mt][r];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { v1 += __shfl_xor(v1, o, 64); v2 += __shfl_xor(v2, o, 64); }
+      if (n == 0) {
+        const int a = 32 * (mt >> 1) + 8 * q + 4 * (mt & 1) + r;
+        atomicAdd(&dw1[A * E + a], v1);
+        atomicAdd(&dw1[A * E + A + a], v2);
+      }
+    }
+  db2r = wave_sum(db2r);
+  if (lane == 0) atomicAdd(&dw1[A * E + 2 * A], db2r);
+  __syncthreads();
+  float* mine = partial + (size_t)blockIdx.x * (A * E + 2 * A + 1);
+  for (int k = threadIdx.x; k < A * E + 2 * A + 1; k += 256) mine[k] = dw1[k];
+}
+
+static size_t afm_bwd_mfma_lds(int N, int E, int A) {
+  const int P = N * (N - 1) / 2, PP = (P + 15) & ~15;
+  const int R = afm_rounds(N), H = afm_width(N), TPR = (H + 15) / 16;
+  const size_t grad = std::max<size_t>((size_t)4 * N * E * 4, ((size_t)A * E + 2 * A + 1) * 4);
+  return (size_t)((N * (E * 2 + 16) + 15) & ~15) + (size_t)PP * 12 + (size_t)E * 4 + 64 + (size_t)R * TPR * 64 + grad +
+         (size_t)4 * (A + E) * 80 + 64;
+}
+
 __global__ __launch_bounds__(256) void afm_reduce_partials_kernel(const float* __restrict__ part, int nparts, int n,
                                                                   int A, int E, float* __restrict__ gW1,
                                                                   float* __restrict__ gb1, float* __restrict__ gw2,
@@ -558,8 +855,41 @@ extern "C" int trs_afm_bwd(const void* g_out, const void* g_attn, const void* x,
                       (size_t)afm_rounds(N) * afm_width(N)) * 4;
   TRS_REQUIRE(lds <= 160 * 1024, TRS_ESHAPE, "afm_bwd: N = %d, E = %d, A = %d need %zu bytes of LDS", N, E, A, lds);
   hipStream_t s = (hipStream_t)stream;
-  const int grid = afm_grid(B);
   float* part = (float*)workspace;
+  if (dtype == TRS_BF16 && (E == 32 || E == 64 || E == 128) && A % 32 == 0 && A <= 128 && (A / 16) * (E / 32) <= 12 &&
+      afm_bwd_mfma_lds(N, E, A) <= 160 * 1024 && aligned16(x) && aligned16(W1)) {
+    const size_t mlds = afm_bwd_mfma_lds(N, E, A);
+    const int mgrid = (int)std::min<int64_t>(B, 256);
+#define TRS_AFM_BM(AT_, KS_)                                                                                          \
+  do {                                                                                                                \
+    auto kern = afm_bwd_mfma_kernel<AT_, KS_>;                                                                        \
+    if (mlds > 64 * 1024 &&                                                                                           \
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds) != hipSuccess) \
+      return check_launch("afm_bwd: LDS attribute");                                                                  \
+    hipLaunchKernelGGL(kern, dim3(mgrid), dim3(256), mlds, s, (const bf16_t*)g_out, (const bf16_t*)g_attn,            \
+                       (const bf16_t*)x, (const bf16_t*)attn, (const bf16_t*)W1, (const bf16_t*)b1, (const bf16_t*)w2, \
+                       B, N, (bf16_t*)gx, part);                                                                      \
+  } while (0)
+#define TRS_AFM_BMK(AT_)                                 \
+  do {                                                   \
+    if (E == 32) TRS_AFM_BM(AT_, 1);                     \
+    else if (E == 64) TRS_AFM_BM(AT_, 2);                \
+    else TRS_AFM_BM(AT_, 4);                             \
+  } while (0)
+    switch (A / 32) {
+      case 1: TRS_AFM_BMK(2); break;
+      case 2: TRS_AFM_BMK(4); break;
+      case 3: TRS_AFM_BMK(6); break;
+      default: TRS_AFM_BMK(8); break;
+    }
+#undef TRS_AFM_BMK
+#undef TRS_AFM_BM
+    const int n = A * E + 2 * A + 1;
+    hipLaunchKernelGGL(afm_reduce_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, s, part, mgrid, n, A, E, gW1,
+                       gb1, gw2, gb2);
+    return check_launch("afm_bwd(mfma)");
+  }
+  const int grid = afm_grid(B);
 #define TRS_AFM_B(T_, AMAX_, ES_)                                                                                     \
   do {                                                                                                                \
     auto kern = afm_bwd_kernel<T_, AMAX_, ES_>;                                                                       \
