@@ -7,6 +7,8 @@
 // block of one sample, the attention weights and the NC2 logits in LDS and the products never leave registers.
 // Generic path (any dtype / shape with E, A <= 128): lanes along the attention units for the hidden layer
 // (wavefront reduction for the logit), lanes along e for the weighted sum and the backward.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "trs_common.hpp"
@@ -609,10 +611,21 @@ __global__ __launch_bounds__(256) void afm_bwd_mfma_kernel(const bf16_t* __restr
 #pragma unroll
           for (int k = 0; k < 8; ++k) pr[k] = xi[ks][k] * xj[ks][k];
           const uint4 bf = Vec16<bf16_t>::pack(pr);
+          // the ReLU mask is a discontinuity: a product rounded to bf16 (2^-9) flips it for pre-activations near 0 and
+          // every flip moves the gradients by a whole term.  Feed the rounding residual as a second bf16 operand
+          // (hi + lo carries ~16 mantissa bits), so the pre-activations match an fp32 evaluation of the bf16 inputs.
+          float hi[8];
+          Vec16<bf16_t>::unpack(bf, hi);
 #pragma unroll
-          for (int mt = 0; mt < AT; ++mt)
+          for (int k = 0; k < 8; ++k) hi[k] = pr[k] - hi[k];
+          const uint4 bl = Vec16<bf16_t>::pack(hi);
+#pragma unroll
+          for (int mt = 0; mt < AT; ++mt) {
             acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(afm_bf16x8, Wf[mt][ks]),
                                                                __builtin_bit_cast(afm_bf16x8, bf), acc1[mt], 0, 0, 0);
+            acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(afm_bf16x8, Wf[mt][ks]),
+                                                               __builtin_bit_cast(afm_bf16x8, bl), acc1[mt], 0, 0, 0);
+          }
           // prod^T for GEMM (3): element (e = 32 ks + 8 q + k, pair column col)
           const uint32_t words[4] = {bf.x, bf.y, bf.z, bf.w};
 #pragma unroll
@@ -790,7 +803,8 @@ extern "C" int trs_afm_fwd(const void* x, const void* W1, const void* b1, const 
   TRS_REQUIRE(x && W1 && b1 && w2 && b2 && out && attn, TRS_EINVAL, "afm_fwd: NULL pointer");
   const int P = N * (N - 1) / 2;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == TRS_BF16 && (E == 32 || E == 64 || E == 128) && A % 16 == 0 && A <= 128 &&
+  static const bool no_mfma = getenv("TRS_AFM_GENERIC") != nullptr;      // tests pin the MFMA path to the generic one
+  if (!no_mfma && dtype == TRS_BF16 && (E == 32 || E == 64 || E == 128) && A % 16 == 0 && A <= 128 &&
       afm_fwd_mfma_lds(N, E) <= 64 * 1024 && aligned16(x) && aligned16(W1)) {
     const size_t lds = afm_fwd_mfma_lds(N, E);
     const int grid = (int)std::min<int64_t>(B, 256 * 4);
@@ -856,7 +870,9 @@ extern "C" int trs_afm_bwd(const void* g_out, const void* g_attn, const void* x,
   TRS_REQUIRE(lds <= 160 * 1024, TRS_ESHAPE, "afm_bwd: N = %d, E = %d, A = %d need %zu bytes of LDS", N, E, A, lds);
   hipStream_t s = (hipStream_t)stream;
   float* part = (float*)workspace;
-  if (dtype == TRS_BF16 && (E == 32 || E == 64 || E == 128) && A % 32 == 0 && A <= 128 && (A / 16) * (E / 32) <= 12 &&
+  static const bool no_mfma = getenv("TRS_AFM_GENERIC") != nullptr;
+  if (!no_mfma && dtype == TRS_BF16 && (E == 32 || E == 64 || E == 128) && A % 32 == 0 && A <= 128 &&
+      (A / 16) * (E / 32) <= 12 &&
       afm_bwd_mfma_lds(N, E, A) <= 160 * 1024 && aligned16(x) && aligned16(W1)) {
     const size_t mlds = afm_bwd_mfma_lds(N, E, A);
     const int mgrid = (int)std::min<int64_t>(B, 256);
