@@ -306,7 +306,8 @@ def main():
             return l_
 
         # the roofline kernel is bracketed by two captured device-timestamp marks (one sample per replay)
-        gstep = GraphedStep(graph_fn, (idx_ring[0], label_ring[0]), params=params, warmup=1)
+        gstep = GraphedStep(graph_fn, (idx_ring[0].int() if host_idx else idx_ring[0], label_ring[0]), params=params,
+                            warmup=1)      # staged batches arrive as int32
 
         def step():
             k = counter[0] % RING

@@ -729,7 +729,9 @@ extern "C" int trs_csr_build(const void* idx, int32_t idx_dtype, const int64_t* 
     gate = flags;
   }
   if (BN > 0) {
-    const int grid = stream_grid(BN, 256, 256 * 16);
+    // behind the partitioned build these kernels normally exit at once: a small grid keeps them off the CUs (the
+    // grid-stride loops still cover every lookup when the fall-back flag is set)
+    const int grid = part ? 256 : stream_grid(BN, 256, 256 * 16);
     if (idx_dtype == TRS_I64)
       hipLaunchKernelGGL((csr_count_kernel<int64_t>), dim3(grid), dim3(256), 0, s, (const int64_t*)idx, offsets, BN, N,
                          V, row_start, slot, err_flag, gate);
@@ -744,7 +746,9 @@ extern "C" int trs_csr_build(const void* idx, int32_t idx_dtype, const int64_t* 
     hipLaunchKernelGGL((csr2_pass_kernel<true>), dim3((int)max_items), dim3(CSR2_THREADS), 0, s, rowT, offsets, B, N, V,
                        row_start, perm, flags, (int)chunk);
   if (BN > 0) {
-    const int grid = stream_grid(BN, 256, 256 * 16);
+    // behind the partitioned build these kernels normally exit at once: a small grid keeps them off the CUs (the
+    // grid-stride loops still cover every lookup when the fall-back flag is set)
+    const int grid = part ? 256 : stream_grid(BN, 256, 256 * 16);
     if (idx_dtype == TRS_I64)
       hipLaunchKernelGGL((csr_fill_kernel<int64_t>), dim3(grid), dim3(256), 0, s, (const int64_t*)idx, offsets, BN, N,
                          row_start, slot, perm, gate);
