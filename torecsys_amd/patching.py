@@ -15,6 +15,9 @@ _LAYER_NAMES = [
     "CrossNetworkLayer",
     "CompressInteractionNetworkLayer", "CINLayer",
     "InnerProductNetworkLayer",
+    "OuterProductNetworkLayer",
+    "AttentionalFactorizationMachineLayer", "AFMLayer",
+    "BilinearInteractionLayer", "FieldAllTypeBilinear", "FieldEachTypeBilinear",
 ]
 _INPUT_NAMES = ["SingleIndexEmbedding", "MultiIndicesEmbedding", "MultiIndicesFieldAwareEmbedding"]
 _saved = {}
