@@ -272,6 +272,28 @@ int trs_permute_grad(const void* g_block, const void* g_fm, const float* fm_sum,
 int trs_gather_by_pos(const void* rows, const int32_t* pos, int64_t K, int32_t E, int32_t dtype,
                       void* out, trs_stream_t stream);
 
+/* ---- CIN layer glue on channels-last activations y (B,E,C) bf16 ---------------------------------
+ * BatchNorm1d + ReLU + chunk(2) + sum over E of the direct half, compress_interaction_network.py:137-181:
+ *   z = relu(y * scale[c] + shift[c])      scale = gamma * invstd, shift = beta - mean * scale (fp32, caller)
+ *   hidden[b,e,c-Hs] = z  for c >= Hs ;   pooled[b,c] = sum_e z[b,e,c]  for c < D
+ *   (split layers: D = Hs = C/2;  is_direct layers: D = C, Hs = 0)
+ * stats: partial (trs_cin_glue_blocks(B), 2, C) fp32 = per-workgroup column sums / sums of squares of y.
+ * bwd_reduce: partial (blocks, 2, C) = [sum gz*mask, sum gz*mask*xhat] with gz = g_pooled (c < D) + g_hidden
+ * (c >= Hs), mask = [z > 0], xhat = (y - mean) * invstd;  g_hidden / g_pooled may be NULL.
+ * bwd_apply: gy = scale * (gz*mask - c1 - xhat * c2), c1 = dbeta/R, c2 = dgamma/R (zeros with running stats). */
+int32_t trs_cin_glue_blocks(int64_t B);
+int trs_cin_glue_stats(const void* y, int64_t B, int32_t E, int32_t C, int32_t dtype, float* partial,
+                       trs_stream_t stream);
+int trs_cin_glue_fwd(const void* y, const float* scale, const float* shift, int64_t B, int32_t E, int32_t C, int32_t D,
+                     int32_t Hs, int32_t dtype, void* hidden, void* pooled, trs_stream_t stream);
+int trs_cin_glue_bwd_reduce(const void* y, const void* g_hidden, const void* g_pooled, const float* scale,
+                            const float* shift, const float* mean, const float* invstd, int64_t B, int32_t E, int32_t C,
+                            int32_t D, int32_t Hs, int32_t dtype, float* partial, trs_stream_t stream);
+int trs_cin_glue_bwd_apply(const void* y, const void* g_hidden, const void* g_pooled, const float* scale,
+                           const float* shift, const float* mean, const float* invstd, const float* c1, const float* c2,
+                           int64_t B, int32_t E, int32_t C, int32_t D, int32_t Hs, int32_t dtype, void* gy,
+                           trs_stream_t stream);
+
 /* ---- OuterProductNetwork / BilinearInteraction on the (i<j) pair pattern -------
  * Pair p = (i_p, j_p), i<j, lexicographic (the order of inner_product_network.py:51-52); NC2 = N(N-1)/2.
  *

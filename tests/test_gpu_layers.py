@@ -292,3 +292,56 @@ def test_fused_ffm_equals_two_module_path(dev, dtype, B, N, E):
         assert rel_err(y.rename(None).detach().cpu(), yo.detach()) <= TOL32
         (yo * go.cpu()).sum().backward()
         assert rel_err(fused.embeddings[2].weight.grad.cpu(), ws[2].grad) <= TOL32
+
+
+@pytest.mark.parametrize("mode", ["train", "eval", "nobn", "direct", "noaffine"])
+@pytest.mark.parametrize("B,E,C", [(33, 64, 256), (7, 16, 64), (130, 8, 128)])
+def test_cin_glue_matches_aten_sequence(dev, mode, B, E, C):
+    """trs_cin_glue_* (BatchNorm1d + ReLU + chunk + sum over E in two passes) against the ATen sequence the layer
+    used before: outputs, input gradient, BatchNorm parameter gradients and running statistics."""
+    import copy
+    from torecsys_amd import functional as F_
+    g = torch.Generator().manual_seed(B + E + C)
+    y0 = (torch.randn(B, E, C, generator=g) * 1.5 + 0.3).bfloat16().to(dev)
+    bn = None
+    if mode != "nobn":
+        bn = torch.nn.BatchNorm1d(C, affine=(mode != "noaffine")).to(dev)
+        if bn.affine:
+            bn.weight.data.copy_(torch.rand(C, generator=g) + 0.5)
+            bn.bias.data.copy_(torch.randn(C, generator=g) * 0.2)
+        bn.running_mean.copy_(torch.randn(C, generator=g) * 0.1)
+        bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+        bn = bn.bfloat16()
+        if mode == "eval":
+            bn.eval()
+    ref_bn = copy.deepcopy(bn)
+    D, Hs = (C, 0) if mode == "direct" else (C // 2, C // 2)
+    assert F_.cin_glue_supported(y0, D, Hs)
+    ya = y0.clone().requires_grad_()
+    hidden, pooled = F_.cin_glue(ya, bn, D, Hs)
+    yb = y0.clone().requires_grad_()
+    z = yb.reshape(B * E, C)
+    if ref_bn is not None:
+        z = ref_bn(z)
+    z = torch.relu(z).reshape(B, E, C)
+    ref_hidden, ref_pooled = z[:, :, Hs:], z[:, :, :D].sum(dim=1)
+    assert hidden.shape == ref_hidden.shape and pooled.shape == ref_pooled.shape
+    assert rel_err(hidden.float().cpu(), ref_hidden.float().cpu()) <= 2e-2
+    assert rel_err(pooled.float().cpu(), ref_pooled.float().cpu()) <= 2e-2
+    gh = torch.randn(hidden.shape, generator=g).bfloat16().to(dev)
+    gp = torch.randn(pooled.shape, generator=g).bfloat16().to(dev)
+    ((hidden.float() * gh.float()).sum() + (pooled.float() * gp.float()).sum()).backward()
+    ((ref_hidden.float() * gh.float()).sum() + (ref_pooled.float() * gp.float()).sum()).backward()
+    assert rel_err(ya.grad.float().cpu(), yb.grad.float().cpu()) <= 3e-2
+    if bn is not None:
+        if bn.affine:
+            assert rel_err(bn.weight.grad.float().cpu(), ref_bn.weight.grad.float().cpu()) <= 3e-2
+            assert rel_err(bn.bias.grad.float().cpu(), ref_bn.bias.grad.float().cpu()) <= 3e-2
+        assert rel_err(bn.running_mean.float().cpu(), ref_bn.running_mean.float().cpu()) <= 2e-2
+        assert rel_err(bn.running_var.float().cpu(), ref_bn.running_var.float().cpu()) <= 2e-2
+        assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked)
+    # only one of the two outputs used downstream
+    yc = y0.clone().requires_grad_()
+    h2, p2 = F_.cin_glue(yc, copy.deepcopy(ref_bn), D, Hs)
+    (p2.float() * gp.float()).sum().backward()
+    assert torch.isfinite(yc.grad.float()).all()

@@ -25,6 +25,11 @@ _P, _I32, _I64, _SZ = c_void_p, c_int32, c_int64, c_size_t
 SIGNATURES = {
     "trs_version": (c_int32, []),
     "trs_last_error_string": (c_char_p, []),
+    "trs_cin_glue_blocks": (c_int32, [_I64]),
+    "trs_cin_glue_stats": (c_int32, [_P, _I64, _I32, _I32, _I32, _P, _P]),
+    "trs_cin_glue_fwd": (c_int32, [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
+    "trs_cin_glue_bwd_reduce": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P]),
+    "trs_cin_glue_bwd_apply": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "trs_opn_vec_fwd": (c_int32, [_P, _P, _I32, _I64, _I32, _I32, _I32, _P, _P]),
     "trs_opn_vec_bwd_workspace_bytes": (_SZ, [_I64, _I32, _I32]),
     "trs_opn_vec_bwd": (c_int32, [_P, _P, _P, _I32, _I64, _I32, _I32, _I32, _P, _P, _P, _SZ, _P]),

@@ -1,0 +1,275 @@
+// CIN layer glue on the channels-last activations (B, E, C) bf16:  BatchNorm1d (batch or running statistics) +
+// ReLU + the direct / hidden split + the sum over E of the direct half, layers/ctr/compress_interaction_network.py
+// :137-181 (Batchnorm, Activation, chunk(2, dim=1), cat(direct).sum over E).
+// The ATen sequence costs ~5.6 ms per layer at B = 65 536, E = 64, C = 256 (statistics, transform, relu, a copy of
+// the hidden half, the pooled reduction and two casts: 7 passes over a 2.1 GB tensor) and ~6 ms in the backward;
+// here the forward is two passes (column statistics; normalise + relu + write the hidden half + pool the direct
+// half in registers -- the direct half is never written) and the backward two (reduce dgamma/dbeta; apply).
+// Thread layout: 256 threads = (256 / vpr) rows x vpr 16-byte column vectors, vpr = C / 8; a workgroup walks one
+// sample (E rows) at a time, so the pooled sums are plain register accumulations.
+#include <algorithm>
+
+#include "trs_common.hpp"
+
+namespace trs {
+
+constexpr int GLUE_THREADS = 256;
+
+struct GlueIdx {
+  int vpr, rpp, v, rr, c0;
+};
+__device__ __forceinline__ GlueIdx glue_idx(int C) {
+  GlueIdx g;
+  g.vpr = C / 8;
+  g.rpp = GLUE_THREADS / g.vpr;
+  g.v = threadIdx.x % g.vpr;
+  g.rr = threadIdx.x / g.vpr;
+  g.c0 = g.v * 8;
+  return g;
+}
+
+// reduce the per-row-group partial vectors of a workgroup: part[k] (8 columns per thread) -> out[c] for rr == 0
+__device__ __forceinline__ void glue_block_reduce(float* lds, const GlueIdx& g, int C, const float* part, float* out8) {
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) lds[g.rr * C + g.c0 + k] = part[k];
+  __syncthreads();
+  if (g.rr == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float s = 0.f;
+      for (int r = 0; r < g.rpp; ++r) s += lds[r * C + g.c0 + k];
+      out8[k] = s;
+    }
+  }
+}
+
+// pass 1: per-workgroup column sums / sums of squares  ->  partial[blk][2][C]
+__global__ __launch_bounds__(GLUE_THREADS) void glue_stats_kernel(const bf16_t* __restrict__ y, int64_t B, int E, int C,
+                                                                  float* __restrict__ partial) {
+  extern __shared__ float lds[];
+  const GlueIdx g = glue_idx(C);
+  float s[8], ss[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { s[k] = 0.f; ss[k] = 0.f; }
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    const uint4* rows = reinterpret_cast<const uint4*>(y + b * E * (int64_t)C);
+    for (int e = g.rr; e < E; e += g.rpp) {
+      float x[8];
+      Vec16<bf16_t>::unpack(rows[(int64_t)e * g.vpr + g.v], x);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { s[k] += x[k]; ss[k] = fmaf(x[k], x[k], ss[k]); }
+    }
+  }
+  float o[8];
+  glue_block_reduce(lds, g, C, s, o);
+  if (g.rr == 0)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) partial[((size_t)blockIdx.x * 2 + 0) * C + g.c0 + k] = o[k];
+  glue_block_reduce(lds, g, C, ss, o);
+  if (g.rr == 0)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) partial[((size_t)blockIdx.x * 2 + 1) * C + g.c0 + k] = o[k];
+}
+
+// pass 2: z = relu(y * scale + shift);  hidden[b,e,c-Hs] = z for c >= Hs;  pooled[b,c] = sum_e z for c < D
+__global__ __launch_bounds__(GLUE_THREADS) void glue_apply_fwd_kernel(const bf16_t* __restrict__ y,
+                                                                      const float* __restrict__ scale,
+                                                                      const float* __restrict__ shift, int64_t B, int E,
+                                                                      int C, int D, int Hs, bf16_t* __restrict__ hidden,
+                                                                      bf16_t* __restrict__ pooled) {
+  extern __shared__ float lds[];
+  const GlueIdx g = glue_idx(C);
+  float a[8], sh[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { a[k] = scale[g.c0 + k]; sh[k] = shift[g.c0 + k]; }
+  const bool is_hidden = g.c0 >= Hs, is_direct = g.c0 < D;
+  const int HW = C - Hs;
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    const uint4* rows = reinterpret_cast<const uint4*>(y + b * E * (int64_t)C);
+    float pool[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pool[k] = 0.f;
+    for (int e = g.rr; e < E; e += g.rpp) {
+      float x[8];
+      Vec16<bf16_t>::unpack(rows[(int64_t)e * g.vpr + g.v], x);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        x[k] = fmaxf(fmaf(x[k], a[k], sh[k]), 0.f);
+        pool[k] += x[k];
+      }
+      if (is_hidden)
+        *reinterpret_cast<uint4*>(hidden + (b * E + e) * (int64_t)HW + (g.c0 - Hs)) = Vec16<bf16_t>::pack(x);
+    }
+    float o[8];
+    glue_block_reduce(lds, g, C, pool, o);
+    if (g.rr == 0 && is_direct) *reinterpret_cast<uint4*>(pooled + b * (int64_t)D + g.c0) = Vec16<bf16_t>::pack(o);
+  }
+}
+
+// gradient wrt z before the relu mask: pooled gradient broadcast over e (c < D) + hidden gradient (c >= Hs)
+__device__ __forceinline__ void glue_gz(const bf16_t* __restrict__ g_hidden, const float* gp8, bool is_hidden,
+                                        bool is_direct, int64_t row, int HW, int hc, float* gz) {
+#pragma unroll
+  for (int k = 0; k < 8; ++k) gz[k] = is_direct ? gp8[k] : 0.f;
+  if (is_hidden && g_hidden != nullptr) {
+    float gh[8];
+    Vec16<bf16_t>::unpack(*reinterpret_cast<const uint4*>(g_hidden + row * (int64_t)HW + hc), gh);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) gz[k] += gh[k];
+  }
+}
+
+// backward pass 1: dbeta[c] = sum gz*[z>0], dgamma[c] = sum gz*[z>0]*xhat  ->  partial[blk][2][C]
+__global__ __launch_bounds__(GLUE_THREADS) void glue_bwd_reduce_kernel(
+    const bf16_t* __restrict__ y, const bf16_t* __restrict__ g_hidden, const bf16_t* __restrict__ g_pooled,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, int64_t B, int E, int C, int D, int Hs, float* __restrict__ partial) {
+  extern __shared__ float lds[];
+  const GlueIdx g = glue_idx(C);
+  float a[8], sh[8], mu[8], is[8], db[8], dg[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    a[k] = scale[g.c0 + k]; sh[k] = shift[g.c0 + k]; mu[k] = mean[g.c0 + k]; is[k] = invstd[g.c0 + k];
+    db[k] = 0.f; dg[k] = 0.f;
+  }
+  const bool is_hidden = g.c0 >= Hs, is_direct = g.c0 < D;
+  const int HW = C - Hs;
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    const uint4* rows = reinterpret_cast<const uint4*>(y + b * E * (int64_t)C);
+    float gp8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) gp8[k] = 0.f;
+    if (is_direct && g_pooled != nullptr)
+      Vec16<bf16_t>::unpack(*reinterpret_cast<const uint4*>(g_pooled + b * (int64_t)D + g.c0), gp8);
+    for (int e = g.rr; e < E; e += g.rpp) {
+      float x[8], gz[8];
+      Vec16<bf16_t>::unpack(rows[(int64_t)e * g.vpr + g.v], x);
+      glue_gz(g_hidden, gp8, is_hidden, is_direct, b * E + e, HW, g.c0 - Hs, gz);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float m = fmaf(x[k], a[k], sh[k]) > 0.f ? gz[k] : 0.f;
+        db[k] += m;
+        dg[k] = fmaf(m, (x[k] - mu[k]) * is[k], dg[k]);
+      }
+    }
+  }
+  float o[8];
+  glue_block_reduce(lds, g, C, db, o);
+  if (g.rr == 0)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) partial[((size_t)blockIdx.x * 2 + 0) * C + g.c0 + k] = o[k];
+  glue_block_reduce(lds, g, C, dg, o);
+  if (g.rr == 0)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) partial[((size_t)blockIdx.x * 2 + 1) * C + g.c0 + k] = o[k];
+}
+
+// backward pass 2: gy = scale * (gz*[z>0] - c1 - xhat * c2)     c1 = dbeta / R, c2 = dgamma / R (0 with running stats)
+__global__ __launch_bounds__(GLUE_THREADS) void glue_bwd_apply_kernel(
+    const bf16_t* __restrict__ y, const bf16_t* __restrict__ g_hidden, const bf16_t* __restrict__ g_pooled,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ c1, const float* __restrict__ c2, int64_t B, int E, int C,
+    int D, int Hs, bf16_t* __restrict__ gy) {
+  const GlueIdx g = glue_idx(C);
+  float a[8], sh[8], mu[8], is[8], k1[8], k2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    a[k] = scale[g.c0 + k]; sh[k] = shift[g.c0 + k]; mu[k] = mean[g.c0 + k]; is[k] = invstd[g.c0 + k];
+    k1[k] = c1[g.c0 + k]; k2[k] = c2[g.c0 + k];
+  }
+  const bool is_hidden = g.c0 >= Hs, is_direct = g.c0 < D;
+  const int HW = C - Hs;
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    const uint4* rows = reinterpret_cast<const uint4*>(y + b * E * (int64_t)C);
+    uint4* out = reinterpret_cast<uint4*>(gy + b * E * (int64_t)C);
+    float gp8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) gp8[k] = 0.f;
+    if (is_direct && g_pooled != nullptr)
+      Vec16<bf16_t>::unpack(*reinterpret_cast<const uint4*>(g_pooled + b * (int64_t)D + g.c0), gp8);
+    for (int e = g.rr; e < E; e += g.rpp) {
+      float x[8], gz[8];
+      Vec16<bf16_t>::unpack(rows[(int64_t)e * g.vpr + g.v], x);
+      glue_gz(g_hidden, gp8, is_hidden, is_direct, b * E + e, HW, g.c0 - Hs, gz);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float m = fmaf(x[k], a[k], sh[k]) > 0.f ? gz[k] : 0.f;
+        gz[k] = a[k] * (m - k1[k] - (x[k] - mu[k]) * is[k] * k2[k]);
+      }
+      out[(int64_t)e * g.vpr + g.v] = Vec16<bf16_t>::pack(gz);
+    }
+  }
+}
+
+static int glue_grid(int64_t B) { return (int)std::min<int64_t>(B, 1024); }
+static bool glue_shape_ok(int C, int D, int Hs) {
+  const int vpr = C / 8;
+  return C % 8 == 0 && vpr >= 1 && vpr <= GLUE_THREADS && GLUE_THREADS % vpr == 0 && D % 8 == 0 && Hs % 8 == 0 &&
+         D >= 0 && D <= C && Hs >= 0 && Hs <= C;
+}
+
+}  // namespace trs
+
+using namespace trs;
+
+#define TRS_GLUE_COMMON(name)                                                                              \
+  TRS_REQUIRE(B >= 0 && E > 0 && C > 0, TRS_EINVAL, name ": bad size");                                    \
+  TRS_REQUIRE(dtype == TRS_BF16, TRS_EDTYPE, name ": bf16 only (dtype %d)", dtype);                        \
+  TRS_REQUIRE(glue_shape_ok(C, D, Hs), TRS_ESHAPE,                                                         \
+              name ": C = %d must be 8 x a divisor of 256, D = %d and Hs = %d multiples of 8 within C", C, D, Hs)
+
+extern "C" int32_t trs_cin_glue_blocks(int64_t B) { return B > 0 ? glue_grid(B) : 0; }
+
+/* partial: (trs_cin_glue_blocks(B), 2, C) fp32 = per-workgroup column sums and sums of squares of y (B,E,C) */
+extern "C" int trs_cin_glue_stats(const void* y, int64_t B, int32_t E, int32_t C, int32_t dtype, float* partial,
+                                  trs_stream_t stream) {
+  const int D = 0, Hs = 0;
+  TRS_GLUE_COMMON("cin_glue_stats");
+  if (B == 0) return TRS_OK;
+  TRS_REQUIRE(y && partial && aligned16(y), TRS_EINVAL, "cin_glue_stats: NULL or unaligned pointer");
+  hipLaunchKernelGGL(glue_stats_kernel, dim3(glue_grid(B)), dim3(GLUE_THREADS), (size_t)GLUE_THREADS * 8 * 4,
+                     (hipStream_t)stream, (const bf16_t*)y, B, E, C, partial);
+  return check_launch("cin_glue_stats");
+}
+
+extern "C" int trs_cin_glue_fwd(const void* y, const float* scale, const float* shift, int64_t B, int32_t E, int32_t C,
+                                int32_t D, int32_t Hs, int32_t dtype, void* hidden, void* pooled, trs_stream_t stream) {
+  TRS_GLUE_COMMON("cin_glue_fwd");
+  if (B == 0) return TRS_OK;
+  TRS_REQUIRE(y && scale && shift && (hidden || Hs == C) && (pooled || D == 0), TRS_EINVAL, "cin_glue_fwd: NULL pointer");
+  TRS_REQUIRE(aligned16(y) && aligned16(hidden) && aligned16(pooled), TRS_EALIGN, "cin_glue_fwd: 16-byte alignment");
+  hipLaunchKernelGGL(glue_apply_fwd_kernel, dim3(glue_grid(B)), dim3(GLUE_THREADS), (size_t)GLUE_THREADS * 8 * 4,
+                     (hipStream_t)stream, (const bf16_t*)y, scale, shift, B, E, C, D, Hs, (bf16_t*)hidden,
+                     (bf16_t*)pooled);
+  return check_launch("cin_glue_fwd");
+}
+
+extern "C" int trs_cin_glue_bwd_reduce(const void* y, const void* g_hidden, const void* g_pooled, const float* scale,
+                                       const float* shift, const float* mean, const float* invstd, int64_t B, int32_t E,
+                                       int32_t C, int32_t D, int32_t Hs, int32_t dtype, float* partial,
+                                       trs_stream_t stream) {
+  TRS_GLUE_COMMON("cin_glue_bwd_reduce");
+  if (B == 0) return TRS_OK;
+  TRS_REQUIRE(y && scale && shift && mean && invstd && partial, TRS_EINVAL, "cin_glue_bwd_reduce: NULL pointer");
+  TRS_REQUIRE(aligned16(y) && aligned16(g_hidden) && aligned16(g_pooled), TRS_EALIGN, "cin_glue_bwd_reduce: alignment");
+  hipLaunchKernelGGL(glue_bwd_reduce_kernel, dim3(glue_grid(B)), dim3(GLUE_THREADS), (size_t)GLUE_THREADS * 8 * 4,
+                     (hipStream_t)stream, (const bf16_t*)y, (const bf16_t*)g_hidden, (const bf16_t*)g_pooled, scale,
+                     shift, mean, invstd, B, E, C, D, Hs, partial);
+  return check_launch("cin_glue_bwd_reduce");
+}
+
+extern "C" int trs_cin_glue_bwd_apply(const void* y, const void* g_hidden, const void* g_pooled, const float* scale,
+                                      const float* shift, const float* mean, const float* invstd, const float* c1,
+                                      const float* c2, int64_t B, int32_t E, int32_t C, int32_t D, int32_t Hs,
+                                      int32_t dtype, void* gy, trs_stream_t stream) {
+  TRS_GLUE_COMMON("cin_glue_bwd_apply");
+  if (B == 0) return TRS_OK;
+  TRS_REQUIRE(y && scale && shift && mean && invstd && c1 && c2 && gy, TRS_EINVAL, "cin_glue_bwd_apply: NULL pointer");
+  TRS_REQUIRE(aligned16(y) && aligned16(g_hidden) && aligned16(g_pooled) && aligned16(gy), TRS_EALIGN,
+              "cin_glue_bwd_apply: alignment");
+  hipLaunchKernelGGL(glue_bwd_apply_kernel, dim3(glue_grid(B)), dim3(GLUE_THREADS), 0, (hipStream_t)stream,
+                     (const bf16_t*)y, (const bf16_t*)g_hidden, (const bf16_t*)g_pooled, scale, shift, mean, invstd, c1, c2,
+                     B, E, C, D, Hs, (bf16_t*)gy);
+  return check_launch("cin_glue_bwd_apply");
+}

@@ -504,6 +504,112 @@ def pair_dot(x: torch.Tensor) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------------------------
+# F4 glue: BatchNorm1d + ReLU + direct/hidden split + pooled sum on channels-last CIN activations
+# --------------------------------------------------------------------------------------------
+def cin_glue_supported(yT: torch.Tensor, D: int, Hs: int) -> bool:
+    C = yT.shape[-1]
+    vpr = C // 8
+    return (yT.is_cuda and yT.dtype == torch.bfloat16 and yT.dim() == 3 and yT.is_contiguous() and C % 8 == 0
+            and 1 <= vpr <= 256 and 256 % vpr == 0 and D % 8 == 0 and Hs % 8 == 0)
+
+
+class _CINGlue(Function):
+    """(hidden (B,E,C-Hs), pooled (B,D)) from the contraction output y (B,E,C): z = relu(bn(y)), hidden = z[..., Hs:],
+    pooled = z[..., :D].sum(1).  BatchNorm1d semantics (batch statistics + running-stat update in training, running
+    statistics in eval, affine optional) are reproduced here; see trs_cin_glue_*."""
+
+    @staticmethod
+    def forward(ctx, yT, gamma, beta, running_mean, running_var, training, momentum, eps, D, Hs):
+        require_device(yT)
+        B, E, C = yT.shape
+        dev = yT.device
+        R = B * E
+        use_batch = bool(training) or running_mean is None
+        if gamma is None and running_mean is None and not training and momentum is None and eps is None:
+            use_batch = False                      # no BatchNorm module at all: identity statistics
+        if eps is None:
+            mean = torch.zeros(C, dtype=torch.float32, device=dev)
+            invstd = torch.ones(C, dtype=torch.float32, device=dev)
+            use_batch = False
+        elif use_batch:
+            nblk = size_query("trs_cin_glue_blocks", B)
+            part = torch.empty(nblk, 2, C, dtype=torch.float32, device=dev)
+            call("trs_cin_glue_stats", ptr(yT), B, E, C, value_dtype_code(yT), ptr(part), stream_ptr())
+            tot = part.double().sum(0)
+            mean64 = tot[0] / R
+            var64 = (tot[1] / R - mean64 * mean64).clamp_min_(0.0)
+            mean = mean64.float()
+            invstd = (var64 + eps).rsqrt().float()
+            if training and running_mean is not None:
+                with torch.no_grad():
+                    m = float(momentum)
+                    running_mean.mul_(1.0 - m).add_(mean64.to(running_mean.dtype), alpha=m)
+                    unbiased = var64 * (R / max(R - 1, 1))
+                    running_var.mul_(1.0 - m).add_(unbiased.to(running_var.dtype), alpha=m)
+        else:
+            mean = running_mean.float()
+            invstd = (running_var.double() + eps).rsqrt().float()
+        g32 = gamma.float() if gamma is not None else torch.ones(C, dtype=torch.float32, device=dev)
+        b32 = beta.float() if beta is not None else torch.zeros(C, dtype=torch.float32, device=dev)
+        scale = (g32 * invstd).contiguous()
+        shift = (b32 - mean * scale).contiguous()
+        hidden = torch.empty(B, E, C - Hs, dtype=yT.dtype, device=dev)
+        pooled = torch.empty(B, D, dtype=yT.dtype, device=dev)
+        call("trs_cin_glue_fwd", ptr(yT), ptr(scale), ptr(shift), B, E, C, D, Hs, value_dtype_code(yT), ptr(hidden),
+             ptr(pooled), stream_ptr())
+        ctx.save_for_backward(yT, scale, shift, mean.contiguous(), invstd.contiguous())
+        ctx.meta = (use_batch, D, Hs, gamma is not None, beta is not None,
+                    None if gamma is None else gamma.dtype)
+        ctx.set_materialize_grads(False)
+        return hidden, pooled
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_hidden, g_pooled):
+        yT, scale, shift, mean, invstd = ctx.saved_tensors
+        use_batch, D, Hs, has_gamma, has_beta, pdtype = ctx.meta
+        B, E, C = yT.shape
+        dev = yT.device
+        R = B * E
+        gh = None if g_hidden is None else g_hidden.contiguous()
+        gp = None if g_pooled is None else g_pooled.contiguous()
+        nblk = size_query("trs_cin_glue_blocks", B)
+        part = torch.empty(nblk, 2, C, dtype=torch.float32, device=dev)
+        call("trs_cin_glue_bwd_reduce", ptr(yT), ptr(gh), ptr(gp), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), B, E, C,
+             D, Hs, value_dtype_code(yT), ptr(part), stream_ptr())
+        tot = part.double().sum(0)
+        dbeta, dgamma = tot[0], tot[1]
+        if use_batch:
+            c1 = (dbeta / R).float().contiguous()
+            c2 = (dgamma / R).float().contiguous()
+        else:
+            c1 = torch.zeros(C, dtype=torch.float32, device=dev)
+            c2 = c1
+        gy = torch.empty_like(yT)
+        call("trs_cin_glue_bwd_apply", ptr(yT), ptr(gh), ptr(gp), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(c1),
+             ptr(c2), B, E, C, D, Hs, value_dtype_code(yT), ptr(gy), stream_ptr())
+        ggamma = dgamma.to(pdtype) if has_gamma and ctx.needs_input_grad[1] else None
+        gbeta = dbeta.to(pdtype) if has_beta and ctx.needs_input_grad[2] else None
+        return gy, ggamma, gbeta, None, None, None, None, None, None, None
+
+
+def cin_glue(yT, bn: Optional[torch.nn.Module], D: int, Hs: int):
+    """BatchNorm1d ``bn`` (or None) + ReLU + split + pooled sum on yT (B,E,C) bf16 -> (hidden (B,E,C-Hs), pooled (B,D))."""
+    if bn is None:
+        return _CINGlue.apply(yT, None, None, None, None, False, None, None, D, Hs)
+    momentum = bn.momentum
+    if bn.training and bn.track_running_stats:
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+            if momentum is None:                              # cumulative moving average
+                momentum = 1.0 / float(bn.num_batches_tracked)
+    use_running = (not bn.training) and bn.track_running_stats
+    return _CINGlue.apply(yT, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
+                          bn.running_var if bn.track_running_stats else None,
+                          bn.training or not use_running, momentum if momentum is not None else 0.0, bn.eps, D, Hs)
+
+
+# --------------------------------------------------------------------------------------------
 # N3: outer-product network / bilinear interaction on the pair pattern
 # --------------------------------------------------------------------------------------------
 def _pair_start(i: int, N: int) -> int:

@@ -464,10 +464,20 @@ class CompressInteractionNetworkLayer(BaseLayer):
             conv = seq.Conv1d
             C = conv.out_channels
             yT = F_.cin_contract_cl(x0T, hiddenT, conv.weight.squeeze(-1), conv.bias, N, H)      # (B,E,C)
+            D, Hs = (C, 0) if self.is_direct else (C // 2, C // 2)
+            rest = [(name, mod) for name, mod in seq.named_children() if name != 'Conv1d']
+            names = [name for name, _ in rest]
+            fusable = (names in (['Batchnorm', 'Activation'], ['Activation']) and type(rest[-1][1]) is nn.ReLU
+                       and (len(rest) == 1 or type(rest[0][1]) is nn.BatchNorm1d) and F_.cin_glue_supported(yT, D, Hs))
+            if fusable:
+                # BatchNorm1d + ReLU + chunk + the sum over E of the direct half in two HIP passes (trs_cin_glue_*)
+                hiddenT, pool = F_.cin_glue(yT, rest[0][1] if len(rest) == 2 else None, D, Hs)
+                H = C - Hs
+                pooled.append(pool)
+                continue
             y2 = yT.reshape(B * E, C)
-            for name, mod in seq.named_children():
-                if name != 'Conv1d':
-                    y2 = mod(y2)
+            for name, mod in rest:
+                y2 = mod(y2)
             yT = y2.reshape(B, E, C)
             if self.is_direct:
                 directT, hiddenT, H = yT, yT, C
