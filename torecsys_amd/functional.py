@@ -982,7 +982,7 @@ def cin_cl_supported(x: torch.Tensor, out_channels: Sequence[int], hidden_sizes:
 
 class _CINContractCL(Function):
     @staticmethod
-    def forward(ctx, x0T, xkT, Wc, bias, N, H):
+    def forward(ctx, x0T, xkT, Wc, bias, N, H, x0_cf=None):
         require_device(x0T, xkT, Wc, bias)
         B, E, ld0 = x0T.shape
         ldk = xkT.stride(1)
@@ -997,6 +997,7 @@ class _CINContractCL(Function):
         call("trs_cin_cl_fwd", ptr(x0T), ld0, ptr(xkT), ldk, ptr(w), ptr(bb), B, N, H, C, E, _abi.TRS_BF16, ptr(yT),
              ptr(ws), ws_bytes, stream_ptr())
         ctx.save_for_backward(x0T, xkT, w)
+        ctx.x0_cf = x0_cf        # the caller's channels-first (B,N,E) input, if it has one (saves a transpose per layer)
         ctx.meta = (N, H, Wc.dtype, None if bias is None else bias.dtype)
         return yT
 
@@ -1011,7 +1012,16 @@ class _CINContractCL(Function):
         gyT = gyT.contiguous()
         dev = x0T.device
         ld0, ldk = x0T.shape[2], xkT.stride(1)
-        db = gyT.float().sum(dim=(0, 1)).to(bdt) if (need_b and bdt is not None) else None
+        db = None
+        if need_b and bdt is not None:
+            if cin_glue_supported(gyT, 0, 0):
+                # column sums of the (B,E,C) gradient by the glue statistics kernel (one bf16 read, fp32 partials)
+                nblk = size_query("trs_cin_glue_blocks", B)
+                part = torch.empty(nblk, 2, C, dtype=torch.float32, device=gyT.device)
+                call("trs_cin_glue_stats", ptr(gyT), B, E, C, value_dtype_code(gyT), ptr(part), stream_ptr())
+                db = part[:, 0].double().sum(0).to(bdt)
+            else:
+                db = gyT.float().sum(dim=(0, 1)).to(bdt)
         dx0T = dxkT = dW = None
         mfma_data = C in (32, 64, 128, 256)
         mfma_dw = C in (64, 128, 256) and E in (32, 64, 128)
@@ -1047,21 +1057,29 @@ class _CINContractCL(Function):
             if gW is not None:
                 dW = gW
         if need_w and mfma_dw:
-            x0 = x0T[:, :, :N].transpose(1, 2).contiguous()          # channels-first copies: pixels contiguous
-            xk = xkT[:, :, :H].transpose(1, 2).contiguous()
+            x0_cf = ctx.x0_cf
+            if x0_cf is not None and tuple(x0_cf.shape) == (B, N, E) and x0_cf.is_contiguous():
+                x0 = x0_cf
+            else:
+                x0 = x0T[:, :, :N].transpose(1, 2).contiguous()      # channels-first copies: pixels contiguous
+            if xkT.data_ptr() == x0T.data_ptr() and H == N:
+                xk = x0                                               # first layer: xk is x0
+            else:
+                xk = xkT[:, :, :H].transpose(1, 2).contiguous()
             gy = gyT.transpose(1, 2).contiguous()
             dW = torch.zeros(C, N * H, dtype=torch.float32, device=dev)
             ws_bytes = size_query("trs_cin_dw_workspace_bytes", B, N, H, C)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             call("trs_cin_dw", ptr(gy), ptr(x0), ptr(xk), B, N, H, C, E, _abi.TRS_BF16, ptr(dW), ptr(ws), ws_bytes,
                  stream_ptr())
-        return (dx0T if need_x0 else None, dxkT if need_xk else None, (dW.to(wdt) if need_w else None), db, None, None)
+        return (dx0T if need_x0 else None, dxkT if need_xk else None, (dW.to(wdt) if need_w else None), db, None, None,
+                None)
 
 
 def cin_contract_cl(x0T: torch.Tensor, xkT: torch.Tensor, Wc: torch.Tensor, bias: Optional[torch.Tensor], N: int,
-                    H: int) -> torch.Tensor:
+                    H: int, x0_cf: Optional[torch.Tensor] = None) -> torch.Tensor:
     """channels-last CIN contraction on the matrix cores: x0T (B,E,ld0>=N, zero padded), xkT (B,E,>=H view)."""
-    return _CINContractCL.apply(x0T, xkT, Wc, bias, N, H)
+    return _CINContractCL.apply(x0T, xkT, Wc, bias, N, H, None if x0_cf is None else x0_cf.detach())
 
 
 # --------------------------------------------------------------------------------------------
