@@ -83,7 +83,8 @@ def test_pair_layer_constructor_errors(dev):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
-@pytest.mark.parametrize("B,N,E", [(37, 39, 64), (5, 2, 16), (130, 7, 24), (64, 5, 128), (1, 3, 8)])
+@pytest.mark.parametrize("B,N,E", [(37, 39, 64), (5, 2, 16), (130, 7, 24), (64, 5, 128), (1, 3, 8), (96, 39, 64),
+                                   (70, 12, 16), (257, 2, 64)])
 def test_pair_layers_vs_oracle(dev, dtype, tol, B, N, E):
     from torecsys_amd.layers import BilinearInteractionLayer, OuterProductNetworkLayer
     if dtype == torch.bfloat16 and E % 8 != 0:

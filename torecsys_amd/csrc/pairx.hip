@@ -129,6 +129,69 @@ __global__ __launch_bounds__(256) void pairw_dot_fwd_kernel(const T* __restrict_
   }
 }
 
+// Register-resident variant for the common case (E <= 64, NC2 <= 1024): a 1024-thread workgroup in which every LANE
+// owns one pair for every sample the workgroup processes.  The lane walks e itself, so there is no cross-lane
+// reduction at all; the x block sits in LDS with a row stride of E+1 floats, which spreads the lanes' different
+// field rows over the banks (same field -> same address -> broadcast).
+// MODE 0 (forward): the lane's parameter row kern[p][0..E) lives in registers -- nothing is re-read per sample -- and
+// the results of a sample leave as one coalesced run.  MODE 1 (weight gradient): gk[p][e] += g[b,p] x_i[e] x_j[e]
+// accumulates in the same registers over all samples: one pass over the batch, no atomics, no LDS partials;
+// per-workgroup partials [grid][NC2][E] are reduced afterwards.
+constexpr int PAIRW_EMAX = 64;
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(1024) void pairw_reg_kernel(const T* __restrict__ x, const T* __restrict__ kern /* MODE 0 */,
+                                                         const T* __restrict__ g /* MODE 1 */, int64_t B, int N, int E,
+                                                         T* __restrict__ out /* MODE 0 */,
+                                                         float* __restrict__ partial /* MODE 1 */) {
+  extern __shared__ float smem[];
+  float* xs = smem;                                   // [N][E+1]
+  const int P = N * (N - 1) / 2, RS = E + 1;
+  const int p = threadIdx.x;
+  const bool own = p < P;
+  int i = 0, j = 1;
+  if (own) pair_ij(p, N, &i, &j);
+  float reg[PAIRW_EMAX];
+#pragma unroll
+  for (int e = 0; e < PAIRW_EMAX; ++e) reg[e] = (MODE == 0 && own && e < E) ? to_f32(kern[(int64_t)p * E + e]) : 0.f;
+  const float* xi = xs + i * RS;
+  const float* xj = xs + j * RS;
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < N * E; k += blockDim.x) {
+      const int row = k / E;
+      xs[row * RS + (k - row * E)] = to_f32(x[b * N * E + k]);
+    }
+    __syncthreads();
+    if (own) {
+      if (MODE == 0) {
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < PAIRW_EMAX; ++e)
+          if (e < E) acc = fmaf(xi[e] * xj[e], reg[e], acc);
+        out[b * P + p] = from_f32<T>(acc);
+      } else {
+        const float gp = to_f32(g[b * P + p]);
+#pragma unroll
+        for (int e = 0; e < PAIRW_EMAX; ++e)
+          if (e < E) reg[e] = fmaf(gp, xi[e] * xj[e], reg[e]);
+      }
+    }
+  }
+  if (MODE == 1 && own) {
+    float* mine = partial + ((size_t)blockIdx.x * P + p) * E;
+#pragma unroll
+    for (int e = 0; e < PAIRW_EMAX; ++e)
+      if (e < E) mine[e] = reg[e];
+  }
+}
+
+static bool pairw_reg_ok(int N, int E, bool is_num) {
+  const int P = N * (N - 1) / 2;
+  return !is_num && E <= PAIRW_EMAX && P <= 1024 && (size_t)N * (E + 1) * 4 <= 64 * 1024;
+}
+static int pairw_reg_grid(int64_t B) { return (int)std::min<int64_t>(512, std::max<int64_t>(1, B / 4)); }
+
 // data gradient: gx_i[e] += g k x_j[e], gx_j[e] += g k x_i[e]   (per-sample LDS accumulators, conflict-free rounds)
 template <typename T>
 __global__ __launch_bounds__(256) void pairw_dot_bwd_data_kernel(const T* __restrict__ g, const T* __restrict__ x,
@@ -277,8 +340,35 @@ __global__ __launch_bounds__(256) void pair_mul_bwd_kernel(const T* __restrict__
     for (int e = threadIdx.x; e < 2 * N * E; e += blockDim.x) gas[e] = 0.f;      // gas and gcs are adjacent
     __syncthreads();
     const uint4* grow = reinterpret_cast<const uint4*>(g + (b * P) * (int64_t)E);
+    // one pair per lane group and round when H <= groups (the usual case): the gradient row of the NEXT round is
+    // loaded before this round's barrier, so the global-load latency overlaps the LDS updates
+    const bool simple = H <= groups;
+    uint4 nxt = make_uint4(0, 0, 0, 0);
+    int nij = -1;
+    if (simple && active && grp < H) {
+      nij = sched[grp];
+      if (nij >= 0) nxt = grow[(int64_t)pair_index(nij >> 16, nij & 0xffff, N) * vpr + v];
+    }
     for (int r = 0; r < R; ++r) {
-      if (active) {
+      if (active && simple) {
+        const int ij = nij;
+        const uint4 cur = nxt;
+        if (r + 1 < R && grp < H) {
+          nij = sched[(r + 1) * H + grp];
+          if (nij >= 0) nxt = grow[(int64_t)pair_index(nij >> 16, nij & 0xffff, N) * vpr + v];
+        }
+        if (grp < H && ij >= 0) {
+          const int i = ij >> 16, j = ij & 0xffff;
+          float gv[VE];
+          Vec16<T>::unpack(cur, gv);
+#pragma unroll
+          for (int q = 0; q < VE; ++q) {
+            const int e = v * VE + q;
+            gas[i * E + e] = fmaf(gv[q], cs[j * E + e], gas[i * E + e]);
+            gcs[j * E + e] = fmaf(gv[q], as[i * E + e], gcs[j * E + e]);
+          }
+        }
+      } else if (active) {
         for (int k = grp; k < H; k += groups) {
           const int ij = sched[r * H + k];
           if (ij < 0) continue;
@@ -542,6 +632,16 @@ extern "C" int trs_opn_vec_fwd(const void* x, const void* kern, int32_t kern_is_
   TRS_REQUIRE(lds <= 64 * 1024, TRS_ESHAPE, "opn_vec_fwd: N = %d, E = %d exceed the 64 KB LDS block", N, E);
   const int EL = pow2_lanes(E), kp = kern_is_num ? 1 : E, ke = kern_is_num ? 0 : 1;
   hipStream_t s = (hipStream_t)stream;
+  if (pairw_reg_ok(N, E, kern_is_num != 0) && B >= 64) {
+    const size_t rl = (size_t)N * (E + 1) * 4;
+    if (dtype == TRS_F32)
+      hipLaunchKernelGGL((pairw_reg_kernel<float, 0>), dim3(pairw_reg_grid(B)), dim3(1024), rl, s, (const float*)x,
+                         (const float*)kern, (const float*)nullptr, B, N, E, (float*)out, (float*)nullptr);
+    else
+      hipLaunchKernelGGL((pairw_reg_kernel<bf16_t, 0>), dim3(pairw_reg_grid(B)), dim3(1024), rl, s, (const bf16_t*)x,
+                         (const bf16_t*)kern, (const bf16_t*)nullptr, B, N, E, (bf16_t*)out, (float*)nullptr);
+    return check_launch("opn_vec_fwd(reg)");
+  }
   if (dtype == TRS_F32)
     hipLaunchKernelGGL((pairw_dot_fwd_kernel<float>), dim3(sample_grid(B)), dim3(256), lds, s, (const float*)x,
                        (const float*)kern, kp, ke, B, N, E, EL, (float*)out);
@@ -552,6 +652,7 @@ extern "C" int trs_opn_vec_fwd(const void* x, const void* kern, int32_t kern_is_
 }
 
 static int opn_vec_weight_blocks(int64_t B) { return (int)std::min<int64_t>(256, std::max<int64_t>(1, B / 16)); }
+static int opn_vec_ws_blocks(int64_t B) { return std::max(opn_vec_weight_blocks(B), pairw_reg_grid(B)); }
 static int opn_vec_chunk(int N, int E) {
   const int budget = 48 * 1024 / 4 - N * E - N * (N - 1) / 2;   // floats left after the x block and the pair table
   return std::max(1, budget / E);
@@ -559,7 +660,7 @@ static int opn_vec_chunk(int N, int E) {
 
 extern "C" size_t trs_opn_vec_bwd_workspace_bytes(int64_t B, int32_t N, int32_t E) {
   if (B <= 0 || N < 2 || E <= 0) return 256;
-  return (size_t)opn_vec_weight_blocks(B) * (size_t)(N * (N - 1) / 2) * E * 4 + 256;
+  return (size_t)opn_vec_ws_blocks(B) * (size_t)(N * (N - 1) / 2) * E * 4 + 256;
 }
 
 extern "C" int trs_opn_vec_bwd(const void* g, const void* x, const void* kern, int32_t kern_is_num, int64_t B, int32_t N,
@@ -587,10 +688,21 @@ extern "C" int trs_opn_vec_bwd(const void* g, const void* x, const void* kern, i
     // gkern_vec: (NC2, E) fp32, accumulated into ('num': the caller sums it over e)
     TRS_REQUIRE(workspace != nullptr && ws_bytes >= trs_opn_vec_bwd_workspace_bytes(B, N, E), TRS_EWORKSPACE,
                 "opn_vec_bwd: workspace too small");
-    const int P = N * (N - 1) / 2, nblk = opn_vec_weight_blocks(B), PC = std::min(P, opn_vec_chunk(N, E));
+    const int P = N * (N - 1) / 2;
+    int nblk = opn_vec_weight_blocks(B);
+    const int PC = std::min(P, opn_vec_chunk(N, E));
     const size_t lds = (size_t)(N * E + PC * E) * 4 + lut_bytes;
     float* part = (float*)workspace;
-    if (dtype == TRS_F32)
+    if (pairw_reg_ok(N, E, false) && B >= 64) {
+      nblk = pairw_reg_grid(B);
+      const size_t rl = (size_t)N * (E + 1) * 4;
+      if (dtype == TRS_F32)
+        hipLaunchKernelGGL((pairw_reg_kernel<float, 1>), dim3(nblk), dim3(1024), rl, s, (const float*)x,
+                           (const float*)nullptr, (const float*)g, B, N, E, (float*)nullptr, part);
+      else
+        hipLaunchKernelGGL((pairw_reg_kernel<bf16_t, 1>), dim3(nblk), dim3(1024), rl, s, (const bf16_t*)x,
+                           (const bf16_t*)nullptr, (const bf16_t*)g, B, N, E, (bf16_t*)nullptr, part);
+    } else if (dtype == TRS_F32)
       hipLaunchKernelGGL((pairw_dot_bwd_weight_kernel<float>), dim3(nblk), dim3(256), lds, s, (const float*)g,
                          (const float*)x, B, N, E, EL, PC, part);
     else

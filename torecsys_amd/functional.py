@@ -654,6 +654,20 @@ def opn_vec(x: torch.Tensor, kern: torch.Tensor, is_num: bool) -> torch.Tensor:
     return _OPNVec.apply(x, kern, is_num)
 
 
+def _pair_bias_grad(g: torch.Tensor, per_pair: bool) -> torch.Tensor:
+    """sum of a (B, P, E) gradient over b (per-pair bias) or over (b, p) (shared bias), fp32 accumulation."""
+    B, P, E = g.shape
+    if not per_pair and cin_glue_supported(g, 0, 0):
+        # column sums of the (B*P, E) matrix: one bf16 read with fp32 partials per workgroup (trs_cin_glue_stats)
+        # instead of a cast to fp32 plus a two-stage ATen reduction (three passes over a multi-GB tensor)
+        nblk = size_query("trs_cin_glue_blocks", B)
+        part = torch.empty(nblk, 2, E, dtype=torch.float32, device=g.device)
+        call("trs_cin_glue_stats", ptr(g), B, P, E, value_dtype_code(g), ptr(part), stream_ptr())
+        return part[:, 0].double().sum(0).to(g.dtype)
+    gb = g.sum(0, dtype=torch.float32) if per_pair else g.reshape(-1, E).sum(0, dtype=torch.float32)
+    return gb.to(g.dtype)
+
+
 class _PairMul(Function):
     """out[b,p,:] = a[b,i_p,:] * c[b,j_p,:] + bias."""
 
@@ -681,8 +695,7 @@ class _PairMul(Function):
         call("trs_pair_mul_bwd", ptr(g), ptr(a), ptr(c), B, N, E, value_dtype_code(a), ptr(ga), ptr(gc), stream_ptr())
         gb = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g.sum(0, dtype=torch.float32) if ctx.bias_per_pair else g.reshape(-1, E).sum(0, dtype=torch.float32)
-            gb = gb.to(g.dtype)
+            gb = _pair_bias_grad(g, ctx.bias_per_pair)
         return ga, gc, gb, None
 
 
@@ -784,7 +797,7 @@ class _PairBilinear(Function):
                 blk = x[:, i, :].t() @ gT2[:, p0 * E:(p0 + n_i) * E]              # (E, n_i*E)
                 gW[p0:p0 + n_i] = blk.view(E, n_i, E).permute(1, 0, 2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g.sum(0, dtype=torch.float32).to(g.dtype)
+            gb = _pair_bias_grad(g, True)
         return gx, gW, gb, None
 
 

@@ -294,7 +294,13 @@ class BilinearInteractionLayer(BaseLayer):
         if x.dim() != 3 or x.shape[1] != self.num_fields or x.shape[2] != self.embed_size:
             raise ValueError(f'expected (B, {self.num_fields}, {self.embed_size}), got {tuple(x.shape)}')
         if self.bilinear_type == 'all':
-            output = F_.pair_mul(torch.matmul(x, self.bilinear.weight), x, self.bilinear.bias, False)
+            W = self.bilinear.weight
+            if x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and torch.is_grad_enabled():
+                # x @ W with the split-K weight gradient of the MLP stack (K = B*N rows against an E x E output)
+                T = _LinearSplitK.apply(x, W.t(), None, False, None, None)
+            else:
+                T = torch.matmul(x, W)
+            output = F_.pair_mul(T, x, self.bilinear.bias, False)
         else:
             output = F_.pair_bilinear(x, self.bilinear.weight, self.bilinear.bias, 1)
         output.names = ('B', 'N', 'O',)
