@@ -479,6 +479,8 @@ __global__ __launch_bounds__(256) void afm_bwd_mfma_kernel(const bf16_t* __restr
                                                            const bf16_t* __restrict__ w2, int64_t B, int N,
                                                            bf16_t* __restrict__ gx, float* __restrict__ partial) {
   constexpr int E = 32 * KS, A = 16 * AT, ET = 2 * KS, AKS = AT / 2, RS = E * 2 + 16, TS = 80;
+  constexpr int GS = E + 8;      // row stride (floats) of the per-wave gradient blocks: rows of different fields must not
+                                 // start on the same LDS bank (E floats = a whole number of bank sweeps -> 16-way conflicts)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int P = N * (N - 1) / 2, PP = (P + 15) & ~15;
   const int R = afm_rounds(N), H = afm_width(N), TPR = (H + 15) / 16;
@@ -490,11 +492,11 @@ __global__ __launch_bounds__(256) void afm_bwd_mfma_kernel(const bf16_t* __restr
   float* go = reinterpret_cast<float*>(sp); sp += E * 4;
   float* red = reinterpret_cast<float*>(sp); sp += 64;
   int* sched = reinterpret_cast<int*>(sp); sp += R * TPR * 16 * 4;
-  float* gxs_all = reinterpret_cast<float*>(sp); sp += 4 * N * E * 4;
+  float* gxs_all = reinterpret_cast<float*>(sp); sp += 4 * N * GS * 4;
   char* dhT_all = sp; sp += 4 * A * TS;
   char* prT_all = sp;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, n = lane & 15;
-  float* gxs = gxs_all + wave * N * E;
+  float* gxs = gxs_all + wave * N * GS;
   char* dhT = dhT_all + wave * A * TS;
   char* prT = prT_all + wave * E * TS;
   for (int p = threadIdx.x; p < PP; p += 256) {
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(256) void afm_bwd_mfma_kernel(const bf16_t* __restr
     }
     for (int k = threadIdx.x; k < E; k += 256) go[k] = g_out != nullptr ? to_f32(g_out[b * E + k]) : 0.f;
     for (int p = threadIdx.x; p < P; p += 256) lg[p] = to_f32(attn[b * P + p]);
-    for (int k = lane; k < N * E; k += 64) gxs[k] = 0.f;
+    for (int k = lane; k < N * GS; k += 64) gxs[k] = 0.f;
     __syncthreads();
     // d(score)_p = g_attn_p + g_out . prod_p      (one pair per thread, 16-byte row reads)
     for (int p = threadIdx.x; p < P; p += 256) {
@@ -672,8 +674,8 @@ __global__ __launch_bounds__(256) void afm_bwd_mfma_kernel(const bf16_t* __restr
 #pragma unroll
           for (int v = 0; v < KS; ++v) {
             const int e0 = 32 * v + 8 * q;
-            float* gi = gxs + i * E + e0;
-            float* gj = gxs + j * E + e0;
+            float* gi = gxs + i * GS + e0;
+            float* gj = gxs + j * GS + e0;
             float4 a0 = *reinterpret_cast<float4*>(gi), a1 = *reinterpret_cast<float4*>(gi + 4);
             float4 c0 = *reinterpret_cast<float4*>(gj), c1 = *reinterpret_cast<float4*>(gj + 4);
             float dp[8];
@@ -728,8 +730,10 @@ __global__ __launch_bounds__(256) void afm_bwd_mfma_kernel(const bf16_t* __restr
       }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < N * E; k += 256)
-      gx[b * N * E + k] = from_f32<bf16_t>(gxs_all[k] + gxs_all[N * E + k] + gxs_all[2 * N * E + k] + gxs_all[3 * N * E + k]);
+    for (int k = threadIdx.x; k < N * E; k += 256) {
+      const int row = k / E, o = row * GS + (k - row * E);
+      gx[b * N * E + k] = from_f32<bf16_t>(gxs_all[o] + gxs_all[N * GS + o] + gxs_all[2 * N * GS + o] + gxs_all[3 * N * GS + o]);
+    }
   }
   // ---- parameter gradients of this workgroup -> partial[A*E + 2A + 1]
   __syncthreads();
@@ -765,7 +769,7 @@ __global__ __launch_bounds__(256) void afm_bwd_mfma_kernel(const bf16_t* __restr
 static size_t afm_bwd_mfma_lds(int N, int E, int A) {
   const int P = N * (N - 1) / 2, PP = (P + 15) & ~15;
   const int R = afm_rounds(N), H = afm_width(N), TPR = (H + 15) / 16;
-  const size_t grad = std::max<size_t>((size_t)4 * N * E * 4, ((size_t)A * E + 2 * A + 1) * 4);
+  const size_t grad = std::max<size_t>((size_t)4 * N * (E + 8) * 4, ((size_t)A * E + 2 * A + 1) * 4);
   return (size_t)((N * (E * 2 + 16) + 15) & ~15) + (size_t)PP * 12 + (size_t)E * 4 + 64 + (size_t)R * TPR * 64 + grad +
          (size_t)4 * (A + E) * 80 + 64;
 }
