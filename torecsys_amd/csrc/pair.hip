@@ -270,11 +270,14 @@ __global__ __launch_bounds__(256) void pair_dot_fwd_mfma_kernel(const bf16_t* __
   }
 }
 
-// backward on the matrix cores: dX = Gs X, Gs = symmetric zero-diagonal matrix of the pair gradients.
-// D[m = i][n = e] = sum_j A[m = i][k = j] B[k = j][n = e]:  A = rows of Gs (built per sample in LDS as bf16,
-// padded to NP = 16*NT columns), B = X^T -- 8 consecutive j of one column e, read from an LDS copy of X with
-// 8 two-byte reads per fragment (the copy is written row-major with 16-byte stores).
-template <int NT, int KE /* E/16 column tiles */>
+// backward on the matrix cores: dX = Gs X, Gs = symmetric zero-diagonal matrix of the pair gradients, computed
+// TRANSPOSED so that both operands are 16-byte LDS reads and the result leaves as 16-byte stores:
+//   D^T[m = e][n = i] = sum_j A[m = e][k = j] B[k = j][n = i]
+// A = X^T (an LDS copy of the sample written transposed, [e][j], 2-byte stores; rows fed in a permuted order so
+// that a lane's outputs for field i are runs of 8 consecutive e), B = Gs (symmetric: row i, 8 consecutive j).
+// The first version (D = Gs X) needed 8 two-byte LDS reads per B fragment and stored dx as scattered 2-byte
+// global stores (48 per lane and sample): it ran at 34 % of the HBM roofline.
+template <int NT, int KE /* E/16 row tiles of D^T */>
 __global__ __launch_bounds__(256) void pair_dot_bwd_mfma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ g,
                                                                 bf16_t* __restrict__ dx, int64_t B, int N, int E) {
   constexpr int NP = 16 * NT;            // padded field count
@@ -282,22 +285,22 @@ __global__ __launch_bounds__(256) void pair_dot_bwd_mfma_kernel(const bf16_t* __
   constexpr int NPK = 32 * KJ;
   constexpr int GS = NPK + 8;            // Gs row stride (bf16 elements): 16-byte aligned, conflict-spreading pad
   constexpr int EC = 16 * KE;
-  constexpr int XS = EC + 8;             // X row stride
+  constexpr int XTS = NPK + 8;           // X^T row stride
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, r = lane & 15;
   const int P = N * (N - 1) / 2;
   const int PL = (P + 7) & ~7;
   unsigned short* lut = reinterpret_cast<unsigned short*>(smem);   // pair -> (i << 8 | j), shared by the block
-  unsigned short* Gs = lut + PL + (size_t)wave * (NP * GS + NPK * XS);
-  unsigned short* Xs = Gs + NP * GS;
+  unsigned short* Gs = lut + PL + (size_t)wave * (NP * GS + EC * XTS);
+  unsigned short* XT = Gs + NP * GS;
   for (int i = threadIdx.x; i < N - 1; i += blockDim.x) {
     const int base = pair_index(i, i + 1, N);
     for (int j = i + 1; j < N; ++j) lut[base + (j - i - 1)] = (unsigned short)((i << 8) | j);
   }
-  // Gs / Xs belong to this wave alone.  Zero them once: the diagonal of Gs, its padding and the X rows >= N are
-  // never written afterwards, every other entry is overwritten for each sample.
+  // Gs / XT belong to this wave alone.  Zero them once: the diagonal of Gs, its padding and the X^T columns >= N
+  // are never written afterwards, every other entry is overwritten for each sample.
   for (int v = lane; v < (NP * GS) / 8; v += 64) reinterpret_cast<uint4*>(Gs)[v] = make_uint4(0, 0, 0, 0);
-  for (int v = lane; v < (NPK * XS) / 8; v += 64) reinterpret_cast<uint4*>(Xs)[v] = make_uint4(0, 0, 0, 0);
+  for (int v = lane; v < (EC * XTS) / 8; v += 64) reinterpret_cast<uint4*>(XT)[v] = make_uint4(0, 0, 0, 0);
   __syncthreads();   // lut complete (block-wide), zero fill visible
   const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -323,43 +326,48 @@ __global__ __launch_bounds__(256) void pair_dot_bwd_mfma_kernel(const bf16_t* __
       }
       for (int v = lane; v < N * (EC / 8); v += 64) {
         const int row = v / (EC / 8), c8 = v - row * (EC / 8);
-        *reinterpret_cast<uint4*>(Xs + row * XS + 8 * c8) =
-            *reinterpret_cast<const uint4*>(x + (b * N + row) * (int64_t)E + 8 * c8);
+        const uint4 xv = *reinterpret_cast<const uint4*>(x + (b * N + row) * (int64_t)E + 8 * c8);
+        const unsigned w[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) XT[(8 * c8 + k) * XTS + row] = (unsigned short)(w[k >> 1] >> (16 * (k & 1)));
       }
     }
     __builtin_amdgcn_wave_barrier();
     {
+      uint4 Bg[NT][KJ];                  // Gs fragments: field i = 16 ti + r, j run 32 kj + 8 q
 #pragma unroll
-      for (int te = 0; te < KE; ++te) {
-        uint4 Bf[KJ];
+      for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
-        for (int kj = 0; kj < KJ; ++kj) {
-          unsigned w[4];
+        for (int kj = 0; kj < KJ; ++kj)
+          Bg[ti][kj] = *reinterpret_cast<const uint4*>(Gs + (16 * ti + r) * GS + 32 * kj + 8 * q);
 #pragma unroll
-          for (int h = 0; h < 4; ++h) {
-            const int j0 = 32 * kj + 8 * q + 2 * h;
-            w[h] = (unsigned)Xs[j0 * XS + 16 * te + r] | ((unsigned)Xs[(j0 + 1) * XS + 16 * te + r] << 16);
-          }
-          Bf[kj] = make_uint4(w[0], w[1], w[2], w[3]);
-        }
+      for (int u = 0; u < KE / 2; ++u) {
+        uint4 Ax[2][KJ];                 // X^T fragments of the tile pair u: row e = 32 u + 8 (r>>2) + 4 h + (r&3)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int kj = 0; kj < KJ; ++kj)
+            Ax[h][kj] = *reinterpret_cast<const uint4*>(XT + (32 * u + 8 * (r >> 2) + 4 * h + (r & 3)) * XTS + 32 * kj + 8 * q);
 #pragma unroll
         for (int ti = 0; ti < NT; ++ti) {
-          pd_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          pd_f32x4 acc[2];
 #pragma unroll
-          for (int kj = 0; kj < KJ; ++kj) {
-            const uint4 a = *reinterpret_cast<const uint4*>(Gs + (16 * ti + r) * GS + 32 * kj + 8 * q);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pd_bf16x8, a),
-                                                          __builtin_bit_cast(pd_bf16x8, Bf[kj]), acc, 0, 0, 0);
+          for (int h = 0; h < 2; ++h) {
+            acc[h] = pd_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kj = 0; kj < KJ; ++kj)
+              acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pd_bf16x8, Ax[h][kj]),
+                                                               __builtin_bit_cast(pd_bf16x8, Bg[ti][kj]), acc[h], 0, 0, 0);
           }
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int i = 16 * ti + 4 * q + k;
-            if (i < N) dx[(b * N + i) * (int64_t)E + 16 * te + r] = from_f32<bf16_t>(acc[k]);
+          const int i = 16 * ti + r;
+          if (i < N) {
+            const float run[8] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3], acc[1][0], acc[1][1], acc[1][2], acc[1][3]};
+            *reinterpret_cast<uint4*>(dx + (b * N + i) * (int64_t)E + 32 * u + 8 * q) = Vec16<bf16_t>::pack(run);
           }
         }
       }
     }
-    __builtin_amdgcn_wave_barrier();   // the next sample overwrites Gs / Xs
+    __builtin_amdgcn_wave_barrier();   // the next sample overwrites Gs / XT
   }
 }
 
@@ -393,7 +401,7 @@ static int pair_dot_bwd_mfma(const void* x, const void* g, void* dx, int64_t B, 
   const int NT = (N + 15) / 16, KE = E / 16;
   const int NP = 16 * NT, NPK = 32 * ((NP + 31) / 32);
   const int P = N * (N - 1) / 2;
-  const size_t lds = (size_t)((P + 7) & ~7) * 2 + (size_t)4 * (NP * (NPK + 8) + NPK * (E + 8)) * 2;
+  const size_t lds = (size_t)((P + 7) & ~7) * 2 + (size_t)4 * (NP * (NPK + 8) + E * (NPK + 8)) * 2;
   const int grid = (int)std::min<int64_t>((B + 3) / 4, 256 * 8);
 #define TRS_PB(NT_, KE_)                                                                                      \
   do {                                                                                                        \
