@@ -241,16 +241,22 @@ def main():
         staged.append(stager.stage(host_ring[(k + 1) % RING]))
         return cur
 
+    phases = [0.0, 0.0, 0.0, 0]          # host seconds in forward / route prefetch / backward, steps (TRS_BENCH_PHASES=1)
+
     def step():
         k = counter[0] % RING
         counter[0] += 1
         for p in params:
             p.grad = None
         if MB == 1:
+            t0 = time.perf_counter()
             loss = fwd_loss(next_indices(k), label_ring[k], 1.0)
-            if sharded:      # input-pipeline style hint: start routing the next batch before this backward
-                emb.prefetch_route(idx_ring[(k + 1) % RING])
+            t1 = time.perf_counter()
+            if sharded:      # input-pipeline style hint: start routing the batch after the next one before this backward
+                emb.prefetch_route(idx_ring[(k + 2) % RING])
+            t2 = time.perf_counter()
             loss.backward()
+            phases[0] += t1 - t0; phases[1] += t2 - t1; phases[2] += time.perf_counter() - t2; phases[3] += 1
             if dense_opt is not None:
                 dense_opt.step()
         else:
@@ -294,7 +300,8 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    _abi.time_kernel(roof_kernel, True)
+    if not sharded:          # the sharded step reports no single-kernel roofline (alg bytes depend on the routing)
+        _abi.time_kernel(roof_kernel, True)
     if use_graph:
         from torecsys_amd.graph import GraphedStep
 
@@ -318,10 +325,21 @@ def main():
             step()
         _abi.kernel_times_ms(roof_kernel)      # drop the warm-up samples
     torch.cuda.synchronize()
+    phases[:] = [0.0, 0.0, 0.0, 0]
+    dev_allocs0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
     t0 = time.perf_counter()
     for i in range(a.steps):
         loss = step()
     enqueue_s = time.perf_counter() - t0      # host time to enqueue K steps (== el when the host is the bound)
+    if os.environ.get("TRS_BENCH_PHASES") and phases[3]:
+        print("host ms/step  forward %.3f  prefetch %.3f  backward %.3f  (over the %d timed eager steps)" %
+              tuple([1e3 * v / phases[3] for v in phases[:3]] + [phases[3]]), file=sys.stderr)
+        print("device allocations (hipMalloc) inside the timed region:",
+              torch.cuda.memory_stats().get("num_device_alloc", 0) - dev_allocs0,
+              " reserved GB: %.2f" % (torch.cuda.memory_reserved() / 2**30), file=sys.stderr)
+        if sharded:
+            from torecsys_amd import dist as _d
+            print("route plans:", _d.route_stats, file=sys.stderr)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
