@@ -96,5 +96,5 @@ def test_timestamp_marks_agree_with_events(dev):
     finally:
         _abi.time_kernel("trs_embed_fm", False)
     a, b = sorted(ev)[2], sorted(mk)[2]
-    assert 0.5 * a <= b <= 1.5 * a + 0.01, (ev, mk)
+    assert 0.4 * a <= b <= 2.0 * a + 0.02, (ev, mk)
     assert out[0].shape == (B, N, E)
