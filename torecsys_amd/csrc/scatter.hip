@@ -16,7 +16,10 @@ constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 16;
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 // rows with more than LONG_ROW lookups are reduced by a whole workgroup (Zipf-hot rows)
-constexpr int LONG_ROW = 256;
+constexpr int LONG_ROW = 64;
+// element path (rows that are not 16-byte multiples, e.g. the E = 1 first-order table): one THREAD walks a row's bucket,
+// so already moderately hot rows stall their wave; rows above this go to the queue and are reduced by whole waves
+constexpr int LONG_ROW_ELEM = 32;
 
 // 4 independent lookups per thread per iteration: 4 index loads, then 4 returning atomics in flight
 template <typename IdxT>
@@ -558,7 +561,7 @@ __global__ __launch_bounds__(256) void scatter_rows_elem_kernel(
     if (r != padding_row) {
       const int beg = row_start[r], end = row_start[r + 1];
       touched = end > beg;
-      if (end - beg > LONG_ROW) {
+      if (end - beg > LONG_ROW_ELEM) {
         if (e == 0) {
           const int slot = atomicAdd(&long_rows[0], 1);
           long_rows[1 + slot] = (int32_t)r;
@@ -577,27 +580,22 @@ __global__ __launch_bounds__(256) void scatter_long_rows_elem_kernel(
     const T* __restrict__ g_rows, const T* __restrict__ g_fm, const float* __restrict__ fm_sum,
     const T* __restrict__ table, const int32_t* __restrict__ row_start, const int32_t* __restrict__ perm, int E, int N,
     int64_t gbs, T* __restrict__ grad, const int32_t* __restrict__ long_rows, RowSink sink) {
-  __shared__ float red[2][4];
+  // one wave per queued row: lanes stride the bucket, wavefront reduction, no workgroup barriers
   const int nlong = long_rows[0];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i = blockIdx.x; i < nlong; i += gridDim.x) {
+  const int lane = threadIdx.x & 63;
+  const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int i = wid; i < nlong; i += nwaves) {
     const int64_t r = long_rows[1 + i];
     const int beg = row_start[r], end = row_start[r + 1];
     for (int e = 0; e < E; ++e) {
       float acc = 0.f, gsum = 0.f;
-      for (int q = beg + threadIdx.x; q < end; q += blockDim.x)
-        acc += elem_term<T>(g_rows, g_fm, fm_sum, perm[q], E, N, gbs, e, &gsum);
+      for (int q = beg + lane; q < end; q += 64) acc += elem_term<T>(g_rows, g_fm, fm_sum, perm[q], E, N, gbs, e, &gsum);
 #pragma unroll
       for (int m = 32; m >= 1; m >>= 1) {
         acc += __shfl_xor(acc, m, 64);
         gsum += __shfl_xor(gsum, m, 64);
       }
-      __syncthreads();
-      if (lane == 0) { red[0][wave] = acc; red[1][wave] = gsum; }
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        acc = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        gsum = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+      if (lane == 0) {
         if (g_fm != nullptr && fm_sum != nullptr) acc = fmaf(-to_f32(table[r * E + e]), gsum, acc);
         sink_elem<T>(sink, grad, r * E + e, acc, true);
       }
@@ -759,10 +757,10 @@ extern "C" int trs_csr_build(const void* idx, int32_t idx_dtype, const int64_t* 
   return check_launch("csr_build");
 }
 
-static size_t long_row_queue_bytes(int64_t BN) { return align_up((size_t)(BN / LONG_ROW + 2) * 4, 256); }
+static size_t long_row_queue_bytes(int64_t BN) { return align_up((size_t)(BN / LONG_ROW_ELEM + 2) * 4, 256); }
 
 extern "C" size_t trs_scatter_workspace_bytes(int64_t BN, int32_t N, int32_t E, int32_t dtype) {
-  // [queue of hot rows: at most BN / LONG_ROW of them, + the counter][TG: (BN/N) x 2E values]
+  // [queue of hot rows: at most BN / LONG_ROW_ELEM of them, + the counter][TG: (BN/N) x 2E values]
   const int64_t B = N > 0 ? (BN + N - 1) / N : 0;
   return long_row_queue_bytes(BN) + align_up((size_t)B * 2 * E * dtype_size(dtype), 256);
 }
