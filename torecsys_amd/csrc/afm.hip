@@ -15,17 +15,6 @@
 
 namespace trs {
 
-__device__ __forceinline__ void afm_pair_ij(int p, int N, int* i_out, int* j_out) {
-  const float d = (float)(2 * N - 1);
-  int i = (int)((d - sqrtf(fmaxf(d * d - 8.f * (float)p, 0.f))) * 0.5f);
-  if (i < 0) i = 0;
-  if (i > N - 2) i = N - 2;
-  while (i > 0 && i * (2 * N - i - 1) / 2 > p) --i;
-  while (i < N - 2 && (i + 1) * (2 * N - i - 2) / 2 <= p) ++i;
-  *i_out = i;
-  *j_out = p - i * (2 * N - i - 1) / 2 + i + 1;
-}
-
 __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
@@ -133,7 +122,7 @@ __global__ __launch_bounds__(256) void afm_fwd_kernel(const T* __restrict__ x, c
     // logits: one wave per pair, lanes along the attention units
     for (int p = wave; p < P; p += 4) {
       int i, j;
-      afm_pair_ij(p, N, &i, &j);
+      pair_ij(p, N, &i, &j);
       float acc[2];
       afm_hidden(l, i, j, E, A, lane, acc);
       float part = 0.f;
@@ -165,7 +154,7 @@ __global__ __launch_bounds__(256) void afm_fwd_kernel(const T* __restrict__ x, c
     float o0 = 0.f, o1 = 0.f;
     for (int p = wave; p < P; p += 4) {
       int i, j;
-      afm_pair_ij(p, N, &i, &j);
+      pair_ij(p, N, &i, &j);
       const float sc = l.lg[p];
       if (lane < E) o0 = fmaf(sc, l.xs[i * E + lane] * l.xs[j * E + lane], o0);
       if (64 + lane < E) o1 = fmaf(sc, l.xs[i * E + 64 + lane] * l.xs[j * E + 64 + lane], o1);
@@ -205,7 +194,7 @@ __global__ __launch_bounds__(256) void afm_fwd_mfma_kernel(const bf16_t* __restr
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, n = lane & 15;
   for (int p = threadIdx.x; p < PT * 16; p += 256) {
     int i = 0, j = 1;
-    if (p < P) afm_pair_ij(p, N, &i, &j);
+    if (p < P) pair_ij(p, N, &i, &j);
     lut[p] = (i << 16) | j;
   }
   // resident A fragments (W1) and this lane's b1 / w2 values (attention unit a = 16 mt + 4 q + r)
@@ -316,25 +305,13 @@ static size_t afm_fwd_mfma_lds(int N, int E) {
   return (size_t)((N * (E * 2 + 16) + 15) & ~15) + (size_t)PT * 16 * 8 + (size_t)E * 4 + 64;
 }
 
-// Conflict-free pair schedule (same construction as pairx.hip): rounds of pairs that share no field, so the four
-// waves can add into the per-field LDS gradient block with plain read-modify-writes inside a round.
-__host__ __device__ inline int afm_rounds(int N) { return (N & 1) ? N : N - 1; }
-__host__ __device__ inline int afm_width(int N) { return (N + 1) / 2; }
+// Conflict-free pair schedule (trs_common.hpp): rounds of pairs that share no field, so the four waves can add into
+// the per-field LDS gradient block with plain read-modify-writes inside a round.
+__host__ __device__ inline int afm_rounds(int N) { return sched_rounds(N); }
+__host__ __device__ inline int afm_width(int N) { return sched_width(N); }
 __device__ __forceinline__ void afm_build_schedule(int* sched, int N) {
-  const int M = (N & 1) ? N + 1 : N;
-  const int R = M - 1, H = M / 2;
-  for (int t = threadIdx.x; t < R * H; t += blockDim.x) {
-    const int r = t / H, k = t - r * H;
-    int a, b;
-    if (k == 0) { a = r; b = M - 1; }
-    else { a = (r + k) % R; b = (r - k + R) % R; }
-    int v = -1;
-    if (a < N && b < N) {
-      const int i = a < b ? a : b, j = a < b ? b : a;
-      v = (i << 16) | j;
-    }
-    sched[t] = v;
-  }
+  const int R = sched_rounds(N), H = sched_width(N);
+  for (int t = threadIdx.x; t < R * H; t += blockDim.x) sched[t] = sched_entry(t / H, t % H, N);
 }
 
 // Backward.  Per sample: d(score)_p = g_attn_p + g_out . prod_p;  softmax backward;  then per pair
@@ -377,7 +354,7 @@ __global__ __launch_bounds__(256) void afm_bwd_kernel(const T* __restrict__ g_ou
     // d(score)
     for (int p = wave; p < P; p += 4) {
       int i, j;
-      afm_pair_ij(p, N, &i, &j);
+      pair_ij(p, N, &i, &j);
       float d = 0.f;
       if (lane < E) d = l.vec[lane] * l.xs[i * E + lane] * l.xs[j * E + lane];
       if (64 + lane < E) d = fmaf(l.vec[64 + lane], l.xs[i * E + 64 + lane] * l.xs[j * E + 64 + lane], d);
@@ -501,22 +478,12 @@ __global__ __launch_bounds__(256) void afm_bwd_mfma_kernel(const bf16_t* __restr
   char* prT = prT_all + wave * E * TS;
   for (int p = threadIdx.x; p < PP; p += 256) {
     int i = 0, j = 1;
-    if (p < P) afm_pair_ij(p, N, &i, &j);
+    if (p < P) pair_ij(p, N, &i, &j);
     lutp[p] = (i << 16) | j;
   }
-  {
-    const int M = (N & 1) ? N + 1 : N;
-    for (int t = threadIdx.x; t < R * TPR * 16; t += 256) {
-      const int r = t / (TPR * 16), k = t - r * (TPR * 16);
-      int v = -1;
-      if (k < H) {
-        int a_, b_;
-        if (k == 0) { a_ = r; b_ = M - 1; }
-        else { a_ = (r + k) % R; b_ = (r - k + R) % R; }
-        if (a_ < N && b_ < N) v = ((a_ < b_ ? a_ : b_) << 16) | (a_ < b_ ? b_ : a_);
-      }
-      sched[t] = v;
-    }
+  for (int t = threadIdx.x; t < R * TPR * 16; t += 256) {
+    const int r = t / (TPR * 16), k = t - r * (TPR * 16);
+    sched[t] = k < H ? sched_entry(r, k, N) : -1;
   }
   // resident operands.  amap(t, m): row m of tile t <-> unit 32 (t>>1) + 8 (m>>2) + 4 (t&1) + (m&3)
   uint4 Wf[AT][KS], Vf[ET][AKS];

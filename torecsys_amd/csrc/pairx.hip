@@ -18,18 +18,6 @@
 
 namespace trs {
 
-__device__ __forceinline__ void pair_ij(int p, int N, int* i_out, int* j_out) {
-  // p = i*(2N-i-1)/2 + (j-i-1), i < j
-  const float d = (float)(2 * N - 1);
-  int i = (int)((d - sqrtf(fmaxf(d * d - 8.f * (float)p, 0.f))) * 0.5f);
-  if (i < 0) i = 0;
-  if (i > N - 2) i = N - 2;
-  while (i > 0 && i * (2 * N - i - 1) / 2 > p) --i;
-  while (i < N - 2 && (i + 1) * (2 * N - i - 2) / 2 <= p) ++i;
-  *i_out = i;
-  *j_out = p - i * (2 * N - i - 1) / 2 + i + 1;
-}
-
 __device__ __forceinline__ float group_reduce(float v, int EL) {
   // sum over the EL-lane group (EL a power of two <= 64)
   for (int o = EL >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -59,30 +47,10 @@ __device__ __forceinline__ void build_pair_lut(int* lut, int N) {
   }
 }
 
-// Conflict-free pair schedule (round-robin tournament, circle method): the NC2 pairs are split into R rounds of
-// at most H pairs that share no field, so the lane groups of a workgroup can add into per-field LDS accumulators
-// with plain read-modify-writes inside a round (ds_add_f32 on one address runs at ~1 lane per clock: the backward
-// kernels were bound by it) and synchronise between rounds.  sched[r*H + k] = (i << 16) | j, or -1.
-__host__ __device__ inline int sched_rounds(int N) { return (N & 1) ? N : N - 1; }
-__host__ __device__ inline int sched_width(int N) { return (N + 1) / 2; }
+// Conflict-free pair schedule (see trs_common.hpp): sched[r*H + k] = (i << 16) | j, or -1.
 __device__ __forceinline__ void build_round_schedule(int* sched, int N) {
-  const int M = (N & 1) ? N + 1 : N;          // even number of players; player M-1 is a dummy when N is odd
-  const int R = M - 1, H = M / 2;
-  for (int t = threadIdx.x; t < R * H; t += blockDim.x) {
-    const int r = t / H, k = t - r * H;
-    int a, b;
-    if (k == 0) {
-      a = r; b = M - 1;
-    } else {
-      a = (r + k) % R; b = (r - k + R) % R;
-    }
-    int v = -1;
-    if (a < N && b < N) {
-      const int i = a < b ? a : b, j = a < b ? b : a;
-      v = (i << 16) | j;
-    }
-    sched[t] = v;
-  }
+  const int R = sched_rounds(N), H = sched_width(N);
+  for (int t = threadIdx.x; t < R * H; t += blockDim.x) sched[t] = sched_entry(t / H, t % H, N);
 }
 __device__ __forceinline__ int pair_index(int i, int j, int N) { return i * (2 * N - i - 1) / 2 + j - i - 1; }
 

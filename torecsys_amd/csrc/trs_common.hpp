@@ -82,6 +82,40 @@ struct Vec16<bf16_t> {
   }
 };
 
+// ---------------------------------------------------------------- (i<j) field pairs
+// pair index p = i*(2N-i-1)/2 + (j-i-1), lexicographic in (i, j) -- the order of the reference's row_idx / col_idx
+// lists (layers/ctr/inner_product_network.py:43-52).
+__device__ __forceinline__ void pair_ij(int p, int N, int* i_out, int* j_out) {
+  const float d = (float)(2 * N - 1);
+  int i = (int)((d - sqrtf(fmaxf(d * d - 8.f * (float)p, 0.f))) * 0.5f);
+  if (i < 0) i = 0;
+  if (i > N - 2) i = N - 2;
+  while (i > 0 && i * (2 * N - i - 1) / 2 > p) --i;
+  while (i < N - 2 && (i + 1) * (2 * N - i - 2) / 2 <= p) ++i;
+  *i_out = i;
+  *j_out = p - i * (2 * N - i - 1) / 2 + i + 1;
+}
+__host__ __device__ inline int pair_index_of(int i, int j, int N) { return i * (2 * N - i - 1) / 2 + j - i - 1; }
+
+// Conflict-free pair schedule (round-robin tournament, circle method): the NC2 pairs are split into R rounds of at
+// most H pairs that share no field, so the units of a workgroup can add into per-field LDS accumulators with plain
+// read-modify-writes inside a round (ds_add_f32 on one address runs at ~1 lane per clock) and synchronise between
+// rounds.  Entry (r, k) = (i << 16) | j, or -1 (the dummy player of an odd N).
+__host__ __device__ inline int sched_rounds(int N) { return (N & 1) ? N : N - 1; }
+__host__ __device__ inline int sched_width(int N) { return (N + 1) / 2; }
+__device__ __forceinline__ int sched_entry(int r, int k, int N) {
+  const int M = (N & 1) ? N + 1 : N;          // even number of players; player M-1 is a dummy when N is odd
+  const int R = M - 1;
+  int a, b;
+  if (k == 0) {
+    a = r; b = M - 1;
+  } else {
+    a = (r + k) % R; b = (r - k + R) % R;
+  }
+  if (a >= N || b >= N) return -1;
+  return ((a < b ? a : b) << 16) | (a < b ? b : a);
+}
+
 // ---------------------------------------------------------------- index loads
 template <typename IdxT>
 __device__ __forceinline__ int64_t load_row_id(const IdxT* __restrict__ idx, const int64_t* __restrict__ offsets,
