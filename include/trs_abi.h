@@ -330,6 +330,14 @@ int trs_pair_bilinear_bwd_data(const void* g, const void* x, const void* W, int3
                                int64_t B, int32_t N, int32_t E, int32_t dtype, void* gx, void* gT,
                                trs_stream_t stream);
 
+/* The same forward on the matrix cores (bf16, E = 32 | 64), one kernel, no (B,NC2,E) intermediate:
+ * Wt (NC2, E, E) = the per-pair matrices TRANSPOSED, Wt[p][h][e] = W[p][e][h] (for OPN 'mat' that is kernel[h,p,e]
+ * itself); tasks (ntasks, 3) int32 on the device = (i, j0, count <= 3): every pair exactly once, the pairs of a task
+ * share i and are adjacent in p.  mode / bias / out as trs_pair_bilinear_fwd (bias per pair, (NC2,E), or NULL).   */
+int trs_pair_bilinear_fwd_mfma(const void* x, const void* Wt, const void* bias, const int32_t* tasks, int32_t ntasks,
+                               int32_t mode, int64_t B, int32_t N, int32_t E, int32_t dtype, void* out,
+                               trs_stream_t stream);
+
 /* GEMM route of the same form for training batch sizes: T[b,p,:] = x[b,i_p,:] @ W_p comes from one plain GEMM per
  * field i (pairs (i, j>i) are adjacent: (B x E) @ (E x n_i*E)) into a (B,NC2,E) buffer; these passes finish it.
  *   fwd  mode 0: out[b,p] = sum_h T[b,p,h] x[b,j_p,h]       mode 1: T <- T * x_j + bias   (in place; out unused)

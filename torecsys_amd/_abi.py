@@ -37,6 +37,7 @@ SIGNATURES = {
     "trs_pair_mul_bwd": (c_int32, [_P, _P, _P, _I64, _I32, _I32, _I32, _P, _P, _P]),
     "trs_pair_bilinear_fwd": (c_int32, [_P, _P, _I32, _P, _I32, _I32, _I64, _I32, _I32, _I32, _P, _P]),
     "trs_pair_bilinear_bwd_data": (c_int32, [_P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _P, _P, _P]),
+    "trs_pair_bilinear_fwd_mfma": (c_int32, [_P, _P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _P, _P]),
     "trs_pair_epilogue_fwd": (c_int32, [_P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _P, _P]),
     "trs_pair_epilogue_bwd": (c_int32, [_P, _P, _P, _I32, _I64, _I32, _I32, _I32, _P, _P]),
     "trs_afm_fwd": (c_int32, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _P, _P]),

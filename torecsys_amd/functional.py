@@ -729,6 +729,23 @@ def _pair_T(x: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
     return T
 
 
+_pair_task_cache = {}
+
+
+def _pair_tasks(N: int, device) -> torch.Tensor:
+    """(ntasks, 3) int32 = (i, j0, count <= 3): the pairs of field i in runs of three adjacent pairs."""
+    key = (N, str(device))
+    t = _pair_task_cache.get(key)
+    if t is None:
+        rows = [(i, j0, min(3, N - j0)) for i in range(N - 1) for j0 in range(i + 1, N, 3)]
+        t = _pair_task_cache[key] = torch.tensor(rows, dtype=torch.int32, device=device)
+    return t
+
+
+def _pair_mfma_fwd_ok(x: torch.Tensor) -> bool:
+    return x.dtype == torch.bfloat16 and x.shape[2] in (32, 64) and x.shape[1] >= 2 and x.shape[0] >= 16
+
+
 class _PairBilinear(Function):
     """T = x_i W_p;  mode 0: out[b,p] = sum_h T_h x_j[h]  |  mode 1: out[b,p,:] = T * x_j + bias_p.   W (P,E,E) [e][h].
     Two routes: one HIP kernel that streams W_p per group of samples (small batches, any shape), or -- at training
@@ -745,7 +762,15 @@ class _PairBilinear(Function):
         Wc = W.contiguous().to(x.dtype)
         bias_c = None if bias is None else bias.contiguous().to(x.dtype)
         ctx.gemm = _pair_gemm_route(x)
-        if ctx.gemm:
+        if _pair_mfma_fwd_ok(x):
+            # forward on the matrix cores in one kernel (W_p^T fragments resident per wave); the backward below still
+            # takes the GEMM / one-kernel VALU routes
+            Wt = Wc.transpose(1, 2).contiguous()
+            tasks = _pair_tasks(N, x.device)
+            out = torch.empty((B, P) if mode == 0 else (B, P, E), dtype=x.dtype, device=x.device)
+            call("trs_pair_bilinear_fwd_mfma", ptr(x), ptr(Wt), ptr(bias_c), ptr(tasks), tasks.shape[0], int(mode), B, N, E,
+                 value_dtype_code(x), ptr(out), stream_ptr())
+        elif ctx.gemm:
             T = _pair_T(x, Wc)
             out = torch.empty(B, P, dtype=x.dtype, device=x.device) if mode == 0 else None
             call("trs_pair_epilogue_fwd", ptr(T), ptr(x), ptr(bias_c), 1, int(mode), B, N, E, value_dtype_code(x),
