@@ -338,6 +338,21 @@ int trs_pair_bilinear_fwd_mfma(const void* x, const void* Wt, const void* bias, 
                                int32_t mode, int64_t B, int32_t N, int32_t E, int32_t dtype, void* out,
                                trs_stream_t stream);
 
+/* Backward of the same on the matrix cores (bf16, E = 32 | 64).  gv = g[b,p] (mode 0) | g[b,p,h] (mode 1); dL/dT = gv * x_j.
+ * data:   gx_i = sum_j W_p (gv x_j)   -- tasks_i (nti,3) = (i, j0, count) as in the forward, W resident;
+ *         gx_j = sum_i gv * (x_i W_p) -- tasks_j (ntj,3) = (j, i0, count): pairs (i0..i0+count-1, j), Wt resident;
+ *         every (sample, task) writes one row into contrib_i (B,nti,E) / contrib_j (B,ntj,E) (bf16 scratch), then
+ *         gx[b,f,:] = sum of the rows of field f's tasks;  seg_i / seg_j (N+1) = first task of each field.
+ * weight: gW (NC2,E,E) [e][h] = sum_b x_i^T (gv x_j), K = samples through per-wave LDS transposes.               */
+int trs_pair_bilinear_bwd_data_mfma(const void* g, const void* x, const void* W, const void* Wt,
+                                    const int32_t* tasks_i, int32_t nti, const int32_t* seg_i,
+                                    const int32_t* tasks_j, int32_t ntj, const int32_t* seg_j, int32_t mode, int64_t B,
+                                    int32_t N, int32_t E, int32_t dtype, void* contrib_i, void* contrib_j, void* gx,
+                                    trs_stream_t stream);
+size_t trs_pair_bilinear_bwd_w_mfma_workspace_bytes(int64_t B, int32_t N, int32_t E);
+int trs_pair_bilinear_bwd_w_mfma(const void* g, const void* x, int32_t mode, int64_t B, int32_t N, int32_t E,
+                                 int32_t dtype, void* gW, void* workspace, size_t ws_bytes, trs_stream_t stream);
+
 /* GEMM route of the same form for training batch sizes: T[b,p,:] = x[b,i_p,:] @ W_p comes from one plain GEMM per
  * field i (pairs (i, j>i) are adjacent: (B x E) @ (E x n_i*E)) into a (B,NC2,E) buffer; these passes finish it.
  *   fwd  mode 0: out[b,p] = sum_h T[b,p,h] x[b,j_p,h]       mode 1: T <- T * x_j + bias   (in place; out unused)

@@ -38,6 +38,10 @@ SIGNATURES = {
     "trs_pair_bilinear_fwd": (c_int32, [_P, _P, _I32, _P, _I32, _I32, _I64, _I32, _I32, _I32, _P, _P]),
     "trs_pair_bilinear_bwd_data": (c_int32, [_P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _P, _P, _P]),
     "trs_pair_bilinear_fwd_mfma": (c_int32, [_P, _P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _P, _P]),
+    "trs_pair_bilinear_bwd_data_mfma": (c_int32, [_P, _P, _P, _P, _P, _I32, _P, _P, _I32, _P, _I32, _I64, _I32, _I32, _I32,
+                                                  _P, _P, _P, _P]),
+    "trs_pair_bilinear_bwd_w_mfma_workspace_bytes": (_SZ, [_I64, _I32, _I32]),
+    "trs_pair_bilinear_bwd_w_mfma": (c_int32, [_P, _P, _I32, _I64, _I32, _I32, _I32, _P, _P, _SZ, _P]),
     "trs_pair_epilogue_fwd": (c_int32, [_P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _P, _P]),
     "trs_pair_epilogue_bwd": (c_int32, [_P, _P, _P, _I32, _I64, _I32, _I32, _I32, _P, _P]),
     "trs_afm_fwd": (c_int32, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _P, _P]),

@@ -732,13 +732,22 @@ def _pair_T(x: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
 _pair_task_cache = {}
 
 
-def _pair_tasks(N: int, device) -> torch.Tensor:
-    """(ntasks, 3) int32 = (i, j0, count <= 3): the pairs of field i in runs of three adjacent pairs."""
+def _pair_tasks(N: int, device):
+    """Task lists of the MFMA per-pair kernels, cached per (N, device):
+    tasks_i (nti,3) = (i, j0, count <= 3): pairs (i, j0..j0+count-1);  seg_i (N+1): first task of field i;
+    tasks_j (ntj,3) = (j, i0, count <= 3): pairs (i0..i0+count-1, j);  seg_j (N+1): first task of field j."""
     key = (N, str(device))
     t = _pair_task_cache.get(key)
     if t is None:
-        rows = [(i, j0, min(3, N - j0)) for i in range(N - 1) for j0 in range(i + 1, N, 3)]
-        t = _pair_task_cache[key] = torch.tensor(rows, dtype=torch.int32, device=device)
+        ti, si, tj, sj = [], [0], [], [0]
+        for i in range(N):
+            ti += [(i, j0, min(3, N - j0)) for j0 in range(i + 1, N, 3)]
+            si.append(len(ti))
+        for j in range(N):
+            tj += [(j, i0, min(3, j - i0)) for i0 in range(0, j, 3)]
+            sj.append(len(tj))
+        mk = lambda rows: torch.tensor(rows, dtype=torch.int32, device=device)
+        t = _pair_task_cache[key] = (mk(ti), mk(si), mk(tj), mk(sj))
     return t
 
 
@@ -763,10 +772,9 @@ class _PairBilinear(Function):
         bias_c = None if bias is None else bias.contiguous().to(x.dtype)
         ctx.gemm = _pair_gemm_route(x)
         if _pair_mfma_fwd_ok(x):
-            # forward on the matrix cores in one kernel (W_p^T fragments resident per wave); the backward below still
-            # takes the GEMM / one-kernel VALU routes
+            # forward on the matrix cores in one kernel (W_p^T fragments resident per wave)
             Wt = Wc.transpose(1, 2).contiguous()
-            tasks = _pair_tasks(N, x.device)
+            tasks = _pair_tasks(N, x.device)[0]
             out = torch.empty((B, P) if mode == 0 else (B, P, E), dtype=x.dtype, device=x.device)
             call("trs_pair_bilinear_fwd_mfma", ptr(x), ptr(Wt), ptr(bias_c), ptr(tasks), tasks.shape[0], int(mode), B, N, E,
                  value_dtype_code(x), ptr(out), stream_ptr())
@@ -794,6 +802,25 @@ class _PairBilinear(Function):
         P = N * (N - 1) // 2
         g = g.contiguous()
         need_w = ctx.needs_input_grad[1]
+        if _pair_mfma_fwd_ok(x):
+            # three MFMA kernels: dL/dx_i and dL/dx_j as per-task contribution rows + one reduction, dL/dW with K = batch
+            ti, si, tj, sj = _pair_tasks(N, x.device)
+            Wt = W.transpose(1, 2).contiguous()
+            ci = torch.empty(B, ti.shape[0], E, dtype=x.dtype, device=x.device)
+            cj = torch.empty(B, tj.shape[0], E, dtype=x.dtype, device=x.device)
+            gx = torch.empty_like(x)
+            call("trs_pair_bilinear_bwd_data_mfma", ptr(g), ptr(x), ptr(W), ptr(Wt), ptr(ti), ti.shape[0], ptr(si), ptr(tj),
+                 tj.shape[0], ptr(sj), ctx.mode, B, N, E, value_dtype_code(x), ptr(ci), ptr(cj), ptr(gx), stream_ptr())
+            gW = gb = None
+            if need_w:
+                gW = torch.empty(P, E, E, dtype=x.dtype, device=x.device)
+                ws_bytes = size_query("trs_pair_bilinear_bwd_w_mfma_workspace_bytes", B, N, E)
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+                call("trs_pair_bilinear_bwd_w_mfma", ptr(g), ptr(x), ctx.mode, B, N, E, value_dtype_code(x), ptr(gW),
+                     ptr(ws), ws_bytes, stream_ptr())
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                gb = _pair_bias_grad(g, True)
+            return gx, gW, gb, None
         if ctx.gemm:
             gT = _pair_T(x, W)                                  # recomputed, then overwritten by dL/dT in place
             gx = torch.empty_like(x)
