@@ -352,19 +352,28 @@ __device__ __forceinline__ void sink_elem(const RowSink& k, T* __restrict__ out,
 // ---------------------------------------------------------------------------------------------
 // segmented reduction: one L-lane group per table row (rows with > LONG_ROW lookups are deferred
 // to a queue and reduced by whole workgroups afterwards)
-template <typename T, int LOG2L, bool HAS_G, bool HAS_FM>
+template <typename T, int LOG2L, bool HAS_G, bool HAS_FM, int CH = 4>
 __device__ __forceinline__ void accumulate_bucket(float* acc, float* gsum, const uint4* __restrict__ g_rows,
                                                   const uint4* __restrict__ g_fm, const float* __restrict__ fm_sum,
                                                   const int32_t* __restrict__ perm, int beg, int end, int step,
                                                   int N, int64_t gbs, int lane_v) {
   constexpr int L = 1 << LOG2L;
   constexpr int VE = Vec16<T>::VE;
-  constexpr int CH = 4;
+  // CH lookups in flight per lane; the bucket positions of the NEXT round are fetched while this round's gradient rows
+  // are on their way (two dependent latencies per round otherwise: perm, then the rows it points at)
+  int pn[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) pn[c] = (beg + c * step) < end ? perm[beg + c * step] : -1;
   for (int q = beg; q < end; q += CH * step) {
     int p[CH];
     uint4 gv[CH], fv[CH], tv[CH];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) p[c] = (q + c * step) < end ? perm[q + c * step] : -1;
+    for (int c = 0; c < CH; ++c) p[c] = pn[c];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int qn = q + (CH + c) * step;
+      pn[c] = qn < end ? perm[qn] : -1;
+    }
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       gv[c] = make_uint4(0, 0, 0, 0);
@@ -474,7 +483,7 @@ __global__ __launch_bounds__(256) void scatter_long_rows_kernel(
     float acc[VE], gsum[VE];
 #pragma unroll
     for (int k = 0; k < VE; ++k) { acc[k] = 0.f; gsum[k] = 0.f; }
-    accumulate_bucket<T, LOG2L, HAS_G, HAS_FM>(acc, gsum, g_rows, g_fm, fm_sum, perm, beg + grp, end, G, N, gbs, lane_v);
+    accumulate_bucket<T, LOG2L, HAS_G, HAS_FM, 8>(acc, gsum, g_rows, g_fm, fm_sum, perm, beg + grp, end, G, N, gbs, lane_v);
 #pragma unroll
     for (int k = 0; k < VE; ++k) { red[0][threadIdx.x][k] = acc[k]; red[1][threadIdx.x][k] = gsum[k]; }
     __syncthreads();
