@@ -363,3 +363,32 @@ def test_row_buckets_partitioned_and_fallback(dev, case):
     out.backward(gout)
     ref = torch.zeros(V, 16, device=dev).index_add_(0, rows_flat, gout.reshape(-1, 16))
     assert rel_err(w.grad.cpu(), ref.cpu()) <= 1e-5
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("fuse", [False, True])
+def test_very_hot_rows_are_chunked(dev, dtype, tol, fuse):
+    """A row that collects thousands of lookups is cut into 1024-lookup chunks reduced by different workgroups and
+    finished by a second pass (Zipf head rows): same gradient as index_add, with and without the folded FM term."""
+    from torecsys_amd.inputs import MultiIndicesEmbedding
+    from torecsys_amd.layers import FMLayer
+    g = torch.Generator().manual_seed(5)
+    B, E = 5000, 64
+    fs = [50, 7, 300]
+    idx = torch.stack([torch.randint(0, s, (B,), generator=g) for s in fs], 1)
+    idx[:, 0] = 3                          # 5000 lookups of one row -> 5 chunks
+    idx[: 2500, 1] = 1                     # 2500+ lookups -> 3 chunks
+    idx[: 1100, 2] = 42                    # just above one chunk
+    w = torch.randn(sum(fs), E, generator=g)
+    m = MultiIndicesEmbedding(embed_size=E, field_sizes=fs, fuse_fm=fuse).to(dev).to(dtype)
+    m.embedding.weight.data.copy_(w)
+    emb = m(idx.to(dev))
+    y = FMLayer()(emb)
+    gy = torch.randn(B, E, generator=g)
+    ge = torch.randn(B, len(fs), E, generator=g)
+    ((y.rename(None).float() * gy.to(dev)).sum() + (emb.rename(None).float() * ge.to(dev)).sum()).backward()
+    wr = m.embedding.weight.detach().float().cpu().requires_grad_()
+    off = O.field_offsets(fs)
+    er = O.multi_indices_embedding(wr, idx, off)
+    ((O.fm_layer(er) * gy).sum() + (er * ge).sum()).backward()
+    assert rel_err(m.embedding.weight.grad.float().cpu(), wr.grad) <= tol

@@ -20,6 +20,9 @@ constexpr int LONG_ROW = 64;
 // element path (rows that are not 16-byte multiples, e.g. the E = 1 first-order table): one THREAD walks a row's bucket,
 // so already moderately hot rows stall their wave; rows above this go to the queue and are reduced by whole waves
 constexpr int LONG_ROW_ELEM = 32;
+// very hot rows (a Zipf head row collects thousands of lookups) are cut into chunks of LONG_CHUNK lookups that
+// different workgroups reduce; a second pass adds the chunk partials of a row.  Queue entries are (row, chunk).
+constexpr int LONG_CHUNK = 1024;
 
 // 4 independent lookups per thread per iteration: 4 index loads, then 4 returning atomics in flight
 template <typename IdxT>
@@ -446,8 +449,12 @@ __global__ __launch_bounds__(256) void scatter_rows_group_kernel(
     for (int k = 0; k < VE; ++k) { acc[k] = 0.f; gsum[k] = 0.f; }
     if (end - beg > LONG_ROW && r != padding_row) {
       if (lane_v == 0) {
-        const int slot = atomicAdd(&long_rows[0], 1);
-        long_rows[1 + slot] = (int32_t)r;
+        const int nch = (end - beg + LONG_CHUNK - 1) / LONG_CHUNK;
+        const int slot = atomicAdd(&long_rows[0], nch);      // the chunks of a row are adjacent in the queue
+        for (int c = 0; c < nch; ++c) {
+          long_rows[1 + 2 * (slot + c)] = (int32_t)r;
+          long_rows[2 + 2 * (slot + c)] = c;
+        }
       }
       continue;
     }
@@ -464,12 +471,15 @@ __global__ __launch_bounds__(256) void scatter_rows_group_kernel(
   }
 }
 
-// hot rows: one 256-thread workgroup per row, groups stride over the bucket, LDS tree reduction
+// hot rows: one 256-thread workgroup per (row, chunk) queue entry, groups stride over the chunk, LDS tree reduction.
+// Rows of a single chunk are finished here; otherwise the chunk's partial sums go to scratch[entry][2][E] (fp32)
+// and scatter_long_rows_finish_kernel adds the chunks of the row.
 template <typename T, int LOG2L, bool HAS_G, bool HAS_FM>
 __global__ __launch_bounds__(256) void scatter_long_rows_kernel(
     const uint4* __restrict__ g_rows, const uint4* __restrict__ g_fm, const float* __restrict__ fm_sum,
     const uint4* __restrict__ table, const int32_t* __restrict__ row_start, const int32_t* __restrict__ perm, int N,
-    int64_t gbs, uint4* __restrict__ grad, const int32_t* __restrict__ long_rows, RowSink sink) {
+    int64_t gbs, uint4* __restrict__ grad, const int32_t* __restrict__ long_rows, float* __restrict__ scratch,
+    RowSink sink) {
   constexpr int L = 1 << LOG2L;
   constexpr int VE = Vec16<T>::VE;
   constexpr int G = 256 / L;  // groups per workgroup
@@ -478,8 +488,11 @@ __global__ __launch_bounds__(256) void scatter_long_rows_kernel(
   const int grp = threadIdx.x >> LOG2L;
   const int nlong = long_rows[0];
   for (int i = blockIdx.x; i < nlong; i += gridDim.x) {
-    const int64_t r = long_rows[1 + i];
-    const int beg = row_start[r], end = row_start[r + 1];
+    const int64_t r = long_rows[1 + 2 * i];
+    const int c = long_rows[2 + 2 * i];
+    const int rbeg = row_start[r], rend = row_start[r + 1];
+    const int beg = rbeg + c * LONG_CHUNK, end = rend < beg + LONG_CHUNK ? rend : beg + LONG_CHUNK;
+    const bool single = rend - rbeg <= LONG_CHUNK;
     float acc[VE], gsum[VE];
 #pragma unroll
     for (int k = 0; k < VE; ++k) { acc[k] = 0.f; gsum[k] = 0.f; }
@@ -500,15 +513,54 @@ __global__ __launch_bounds__(256) void scatter_long_rows_kernel(
     if (grp == 0) {
 #pragma unroll
       for (int k = 0; k < VE; ++k) { acc[k] = red[0][threadIdx.x][k]; gsum[k] = red[1][threadIdx.x][k]; }
-      if (HAS_FM && fm_sum != nullptr) {
-        float w[VE];
-        Vec16<T>::unpack(table[r * L + lane_v], w);
+      if (single) {
+        if (HAS_FM && fm_sum != nullptr) {
+          float w[VE];
+          Vec16<T>::unpack(table[r * L + lane_v], w);
 #pragma unroll
-        for (int k = 0; k < VE; ++k) acc[k] = fmaf(-w[k], gsum[k], acc[k]);
+          for (int k = 0; k < VE; ++k) acc[k] = fmaf(-w[k], gsum[k], acc[k]);
+        }
+        sink_vec<T>(sink, grad, r * L + lane_v, acc, true);
+      } else {
+        float* sa = scratch + ((size_t)i * 2) * (L * VE) + lane_v * VE;
+#pragma unroll
+        for (int k = 0; k < VE; ++k) { sa[k] = acc[k]; sa[L * VE + k] = gsum[k]; }
       }
-      sink_vec<T>(sink, grad, r * L + lane_v, acc, true);
     }
     __syncthreads();
+  }
+}
+
+template <typename T, int LOG2L, bool HAS_FM>
+__global__ __launch_bounds__(256) void scatter_long_rows_finish_kernel(
+    const float* __restrict__ fm_sum, const uint4* __restrict__ table, const int32_t* __restrict__ row_start,
+    uint4* __restrict__ grad, const int32_t* __restrict__ long_rows, const float* __restrict__ scratch, RowSink sink) {
+  constexpr int L = 1 << LOG2L;
+  constexpr int VE = Vec16<T>::VE;
+  const int lane_v = threadIdx.x & (L - 1);
+  const int nlong = long_rows[0];
+  const int groups = (gridDim.x * blockDim.x) >> LOG2L;
+  for (int i = (blockIdx.x * blockDim.x + threadIdx.x) >> LOG2L; i < nlong; i += groups) {
+    if (long_rows[2 + 2 * i] != 0) continue;                 // only the first chunk of a row finishes it
+    const int64_t r = long_rows[1 + 2 * i];
+    const int len = row_start[r + 1] - row_start[r];
+    if (len <= LONG_CHUNK) continue;                         // single-chunk rows were finished by the first pass
+    const int nch = (len + LONG_CHUNK - 1) / LONG_CHUNK;
+    float acc[VE], gsum[VE];
+#pragma unroll
+    for (int k = 0; k < VE; ++k) { acc[k] = 0.f; gsum[k] = 0.f; }
+    for (int c = 0; c < nch; ++c) {
+      const float* sa = scratch + ((size_t)(i + c) * 2) * (L * VE) + lane_v * VE;
+#pragma unroll
+      for (int k = 0; k < VE; ++k) { acc[k] += sa[k]; gsum[k] += sa[L * VE + k]; }
+    }
+    if (HAS_FM && fm_sum != nullptr) {
+      float w[VE];
+      Vec16<T>::unpack(table[r * L + lane_v], w);
+#pragma unroll
+      for (int k = 0; k < VE; ++k) acc[k] = fmaf(-w[k], gsum[k], acc[k]);
+    }
+    sink_vec<T>(sink, grad, r * L + lane_v, acc, true);
   }
 }
 
@@ -624,8 +676,8 @@ static int log2_lanes_sc(int row_bytes) {
 template <typename T, int LOG2L>
 static void scatter_group_launch(const void* g_rows, const void* g_fm, const float* fm_sum, const void* table,
                                  const int32_t* row_start, const int32_t* perm, int64_t V, int N, int64_t gbs,
-                                 int64_t padding_row, void* grad, int32_t* long_rows, void* tg, int64_t B,
-                                 RowSink sink, hipStream_t s) {
+                                 int64_t padding_row, void* grad, int32_t* long_rows, void* tg, float* scratch,
+                                 int64_t B, RowSink sink, hipStream_t s) {
   const int L = 1 << LOG2L;
   if (g_fm != nullptr && fm_sum != nullptr) {
     hipLaunchKernelGGL((build_tg_kernel<T>), dim3(stream_grid(B * L, 256, 4096)), dim3(256), 0, s, (const uint4*)g_fm,
@@ -639,9 +691,11 @@ static void scatter_group_launch(const void* g_rows, const void* g_fm, const flo
     hipLaunchKernelGGL((scatter_rows_group_kernel<T, LOG2L, HG, HF>), dim3(grid), dim3(256), 0, s,               \
                        (const uint4*)g_rows, (const uint4*)g_fm, fm_sum, (const uint4*)table, row_start, perm, V, \
                        N, gbs, padding_row, (uint4*)grad, long_rows, sink);                                           \
-    hipLaunchKernelGGL((scatter_long_rows_kernel<T, LOG2L, HG, HF>), dim3(512), dim3(256), 0, s,                 \
+    hipLaunchKernelGGL((scatter_long_rows_kernel<T, LOG2L, HG, HF>), dim3(1024), dim3(256), 0, s,                \
                        (const uint4*)g_rows, (const uint4*)g_fm, fm_sum, (const uint4*)table, row_start, perm, N, \
-                       gbs, (uint4*)grad, long_rows, sink);                                                           \
+                       gbs, (uint4*)grad, long_rows, scratch, sink);                                                  \
+    hipLaunchKernelGGL((scatter_long_rows_finish_kernel<T, LOG2L, HF>), dim3(64), dim3(256), 0, s, fm_sum,           \
+                       (const uint4*)table, row_start, (uint4*)grad, long_rows, scratch, sink);                       \
   } while (0)
   if (hg && hf) TRS_SC(true, true);
   else if (hg) TRS_SC(true, false);
@@ -652,19 +706,19 @@ static void scatter_group_launch(const void* g_rows, const void* g_fm, const flo
 template <typename T>
 static int scatter_launch(const void* g_rows, const void* g_fm, const float* fm_sum, const void* table,
                           const int32_t* row_start, const int32_t* perm, int64_t V, int E, int N, int64_t gbs,
-                          int64_t padding_row, void* grad, int32_t* long_rows, void* tg, int64_t B, RowSink sink,
-                          hipStream_t s) {
+                          int64_t padding_row, void* grad, int32_t* long_rows, void* tg, float* scratch, int64_t B,
+                          RowSink sink, hipStream_t s) {
   const int lg = log2_lanes_sc(E * (int)sizeof(T));
   const bool al = aligned16(g_rows) && aligned16(g_fm) && aligned16(table) && aligned16(grad) && aligned16(fm_sum);
   if (lg >= 0 && al) {
     switch (lg) {
-      case 0: scatter_group_launch<T, 0>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, B, sink, s); break;
-      case 1: scatter_group_launch<T, 1>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, B, sink, s); break;
-      case 2: scatter_group_launch<T, 2>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, B, sink, s); break;
-      case 3: scatter_group_launch<T, 3>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, B, sink, s); break;
-      case 4: scatter_group_launch<T, 4>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, B, sink, s); break;
-      case 5: scatter_group_launch<T, 5>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, B, sink, s); break;
-      default: scatter_group_launch<T, 6>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, B, sink, s); break;
+      case 0: scatter_group_launch<T, 0>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s); break;
+      case 1: scatter_group_launch<T, 1>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s); break;
+      case 2: scatter_group_launch<T, 2>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s); break;
+      case 3: scatter_group_launch<T, 3>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s); break;
+      case 4: scatter_group_launch<T, 4>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s); break;
+      case 5: scatter_group_launch<T, 5>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s); break;
+      default: scatter_group_launch<T, 6>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s); break;
     }
   } else {
     hipLaunchKernelGGL((scatter_rows_elem_kernel<T>), dim3(stream_grid(V * E, 256, 256 * 32)), dim3(256), 0, s,
@@ -766,12 +820,17 @@ extern "C" int trs_csr_build(const void* idx, int32_t idx_dtype, const int64_t* 
   return check_launch("csr_build");
 }
 
-static size_t long_row_queue_bytes(int64_t BN) { return align_up((size_t)(BN / LONG_ROW_ELEM + 2) * 4, 256); }
+static size_t long_row_entries(int64_t BN) { return (size_t)(BN / LONG_ROW + BN / LONG_CHUNK + 2); }
+static size_t long_row_queue_bytes(int64_t BN) {
+  // (row, chunk) pairs on the vector path, single row ids on the element path: room for the larger of the two
+  return align_up(std::max(long_row_entries(BN) * 8 + 8, (size_t)(BN / LONG_ROW_ELEM + 2) * 4), 256);
+}
 
 extern "C" size_t trs_scatter_workspace_bytes(int64_t BN, int32_t N, int32_t E, int32_t dtype) {
-  // [queue of hot rows: at most BN / LONG_ROW_ELEM of them, + the counter][TG: (BN/N) x 2E values]
+  // [queue of hot rows + the counter][TG: (BN/N) x 2E values][chunk partials of very hot rows: entries x 2E fp32]
   const int64_t B = N > 0 ? (BN + N - 1) / N : 0;
-  return long_row_queue_bytes(BN) + align_up((size_t)B * 2 * E * dtype_size(dtype), 256);
+  return long_row_queue_bytes(BN) + align_up((size_t)B * 2 * E * dtype_size(dtype), 256) +
+         align_up(long_row_entries(BN) * 2 * E * 4, 256);
 }
 
 static int scatter_rows_impl(RowSink sink, const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm,
@@ -791,14 +850,15 @@ static int scatter_rows_impl(RowSink sink, const void* g_rows, int64_t g_rows_ba
   TRS_REQUIRE(BN % N == 0, TRS_EINVAL, "scatter_rows: B*N=%lld not a multiple of N=%d", (long long)BN, N);
   void* tg = (char*)workspace + long_row_queue_bytes(BN);
   const int64_t B = BN / N;
+  float* scratch = (float*)((char*)tg + align_up((size_t)B * 2 * E * dtype_size(dtype), 256));
   hipStream_t s = (hipStream_t)stream;
   int32_t* long_rows = (int32_t*)workspace;
   if (hipMemsetAsync(long_rows, 0, 4, s) != hipSuccess) return check_launch("scatter_rows(memset)");
   if (dtype == TRS_F32)
     return scatter_launch<float>(g_rows, g_fm, fm_sum, table, row_start, perm, V, E, N, gbs, padding_row,
-                                 grad_table, long_rows, tg, B, sink, s);
+                                 grad_table, long_rows, tg, scratch, B, sink, s);
   return scatter_launch<bf16_t>(g_rows, g_fm, fm_sum, table, row_start, perm, V, E, N, gbs, padding_row, grad_table,
-                                long_rows, tg, B, sink, s);
+                                long_rows, tg, scratch, B, sink, s);
 }
 
 extern "C" int trs_scatter_rows(const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm, const float* fm_sum,
