@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--zipf", action="store_true", help="Zipf(1.05)-like skewed indices instead of uniform")
     ap.add_argument("--no-fuse", action="store_true", help="separate lookup and FM kernels (drop-in unfused path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--time-every", type=int, default=4,
+                    help="bracket every n-th launch of the roofline kernel with HIP events (1 = all launches)")
     ap.add_argument("--force-sharded", action="store_true", help="use the row-sharded path even with one rank (test)")
     ap.add_argument("--model", default="deepfm", choices=["deepfm", "fm", "dcn", "xdeepfm"],
                     help="deepfm = the headline metric (BASELINE configs[1]); dcn / xdeepfm = configs[2] / [3]")
@@ -301,7 +303,10 @@ def main():
     if world > 1:
         dist.barrier()
     if not sharded:          # the sharded step reports no single-kernel roofline (alg bytes depend on the routing)
-        _abi.time_kernel(roof_kernel, True)
+        # HIP events around every `--time-every`-th launch inside the timed region: bracketing all of them makes the
+        # host wait on the runtime's profiling signals and more than doubles the step (see _abi.time_kernel)
+        every = max(1, min(a.time_every, a.steps))
+        _abi.time_kernel(roof_kernel, True, expect=a.steps // every + 2, every=every)
     if use_graph:
         from torecsys_amd.graph import GraphedStep
 
@@ -327,10 +332,21 @@ def main():
     torch.cuda.synchronize()
     phases[:] = [0.0, 0.0, 0.0, 0]
     dev_allocs0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
+    prof = None
+    if os.environ.get("TRS_BENCH_CPROFILE"):      # developer diagnostic: which host call blocks inside the timed region
+        import cProfile
+        prof = cProfile.Profile()
     t0 = time.perf_counter()
+    if prof:
+        prof.enable()
     for i in range(a.steps):
         loss = step()
-    enqueue_s = time.perf_counter() - t0      # host time to enqueue K steps (== el when the host is the bound)
+    if prof:
+        prof.disable()
+    enqueue_s = time.perf_counter() - t0
+    if prof:
+        import pstats
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(18)      # host time to enqueue K steps (== el when the host is the bound)
     if os.environ.get("TRS_BENCH_PHASES") and phases[3]:
         print("host ms/step  forward %.3f  prefetch %.3f  backward %.3f  (over the %d timed eager steps)" %
               tuple([1e3 * v / phases[3] for v in phases[:3]] + [phases[3]]), file=sys.stderr)

@@ -272,6 +272,16 @@ int trs_permute_grad(const void* g_block, const void* g_fm, const float* fm_sum,
 int trs_gather_by_pos(const void* rows, const int32_t* pos, int64_t K, int32_t E, int32_t dtype,
                       void* out, trs_stream_t stream);
 
+/* ---- Linear with one output unit (the logit layer of the DeepFM / xDeepFM MLP, multilayer_perceptron.py:51) -------
+ * out[r] = h[r,:] . w + bias[0]: a row-wise dot product, not a GEMM.  h (rows, C), w (C); C * sizeof(T) / 16 must be
+ * a power of two <= 64.  bwd: gh (rows, C) = g[r] * w (may be NULL); gw (C), gb (1) fp32 ACCUMULATED into (both or
+ * neither).                                                                                                          */
+int trs_rowdot_fwd(const void* h, const void* w, const void* bias, int64_t rows, int32_t C, int32_t dtype, void* out,
+                   trs_stream_t stream);
+size_t trs_rowdot_bwd_workspace_bytes(int64_t rows, int32_t C);
+int trs_rowdot_bwd(const void* g, const void* h, const void* w, int64_t rows, int32_t C, int32_t dtype, void* gh,
+                   float* gw, float* gb, void* workspace, size_t ws_bytes, trs_stream_t stream);
+
 /* ---- CIN layer glue on channels-last activations y (B,E,C) bf16 ---------------------------------
  * BatchNorm1d + ReLU + chunk(2) + sum over E of the direct half, compress_interaction_network.py:137-181:
  *   z = relu(y * scale[c] + shift[c])      scale = gamma * invstd, shift = beta - mean * scale (fp32, caller)

@@ -70,3 +70,55 @@ def test_padded_weights_follow_parameter_updates(dev):
     assert rel_err(mlp(x).rename(None).detach().float().cpu(), _plain(mlp)(x).detach().float().cpu()) <= 2e-2
     assert set(mlp.state_dict().keys()) == set(sd.keys())
     assert mlp.model.Linear_0.weight.shape == (400, 64)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,C", [(65536, 512), (8192, 400), (1000, 64), (7, 8), (1, 128), (4099, 256)])
+def test_rowdot_matches_linear(dev, dtype, rows, C):
+    """one-output Linear as a row-wise dot product (trs_rowdot_fwd / trs_rowdot_bwd) against fp32 torch math"""
+    from torecsys_amd import functional as F_
+    torch.manual_seed(rows + C)
+    h = torch.randn(rows, C, device=dev, dtype=dtype)
+    w = (torch.randn(1, C, device=dev) / C ** 0.5).to(dtype)
+    b = torch.randn(1, device=dev).to(dtype)
+    if not F_.rowdot_supported(h):
+        pytest.skip("row length not a power-of-two number of 16-byte vectors")
+    ha, wa, ba = h.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    out = F_._RowDot.apply(ha, wa, ba, None, None)
+    hf, wf, bf = h.float().requires_grad_(), w.float().requires_grad_(), b.float().requires_grad_()
+    ref = hf @ wf.t() + bf
+    assert out.shape == (rows, 1) and out.dtype == dtype
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_err(out.float().cpu(), ref.detach().cpu()) <= tol
+    g = torch.randn(rows, 1, device=dev)
+    out.backward(g.to(dtype))
+    ref.backward(g.to(dtype).float())
+    assert rel_err(ha.grad.float().cpu(), hf.grad.cpu()) <= tol
+    assert wa.grad.shape == w.shape and ba.grad.shape == b.shape
+    assert rel_err(wa.grad.float().cpu(), wf.grad.cpu()) <= tol
+    assert abs(float(ba.grad.float()) - float(bf.grad)) <= tol * max(1.0, abs(float(bf.grad)), rows ** 0.5)
+
+
+def test_mlp_logit_layer_uses_rowdot(dev):
+    """DeepFM's deep tower ends in Linear(400, 1): that layer must run as trs_rowdot (and match the plain stack)"""
+    from torecsys_amd import _abi
+    from torecsys_amd.layers import MultilayerPerceptionLayer
+    torch.manual_seed(5)
+    mlp = MultilayerPerceptionLayer(128, 1, [400, 400]).to(dev).bfloat16()
+    ref = _plain(mlp)
+    x = torch.randn(8192, 128, device=dev, dtype=torch.bfloat16)
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    _abi.time_kernel("trs_rowdot_fwd", True)
+    try:
+        ya = mlp(xa).rename(None)
+        assert len(_abi.kernel_times_ms("trs_rowdot_fwd")) == 1
+    finally:
+        _abi.time_kernel("trs_rowdot_fwd", False)
+    yb = ref(xb)
+    assert rel_err(ya.float().cpu(), yb.float().cpu()) <= 2e-2
+    g = torch.randn_like(yb)
+    ya.backward(g)
+    yb.backward(g)
+    assert rel_err(xa.grad.float().cpu(), xb.grad.float().cpu()) <= 3e-2
+    for (n, pa), (_, pb) in zip(mlp.model.named_parameters(), ref.named_parameters()):
+        assert rel_err(pa.grad.float().cpu(), pb.grad.float().cpu()) <= 3e-2, n

@@ -30,7 +30,7 @@ def step(k, rec):
     t0 = time.perf_counter(); d = inputs({"c0": ring[k % 4]})
     t1 = time.perf_counter(); out = model(**d)
     t2 = time.perf_counter(); loss = crit(out.float(), lab)
-    t3 = time.perf_counter(); emb.prefetch_route(ring[(k + 1) % 4])
+    t3 = time.perf_counter(); emb.prefetch_route(ring[(k + 2) % 4])
     t4 = time.perf_counter(); loss.backward()
     t5 = time.perf_counter()
     if rec:
@@ -39,8 +39,14 @@ if "--time-kernel" in sys.argv:
     from torecsys_amd import _abi
     _abi.time_kernel("trs_embed_fm", True)
 for k in range(5): step(k, False)
+import cProfile, pstats
+pr_ = cProfile.Profile() if "--cprofile" in sys.argv else None
 torch.cuda.synchronize(); t = time.perf_counter()
+if pr_: pr_.enable()
 for k in range(20): step(k, True)
+if pr_: pr_.disable()
 torch.cuda.synchronize(); el = time.perf_counter() - t
+if pr_:
+    pstats.Stats(pr_).sort_stats("tottime").print_stats(22)
 print("ms/step", round(el / 20 * 1e3, 3), {k_: round(v / 20 * 1e3, 3) for k_, v in T.items()})
 dist.destroy_process_group()

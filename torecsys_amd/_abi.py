@@ -25,6 +25,9 @@ _P, _I32, _I64, _SZ = c_void_p, c_int32, c_int64, c_size_t
 SIGNATURES = {
     "trs_version": (c_int32, []),
     "trs_last_error_string": (c_char_p, []),
+    "trs_rowdot_fwd": (c_int32, [_P, _P, _P, _I64, _I32, _I32, _P, _P]),
+    "trs_rowdot_bwd_workspace_bytes": (_SZ, [_I64, _I32]),
+    "trs_rowdot_bwd": (c_int32, [_P, _P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _SZ, _P]),
     "trs_cin_glue_blocks": (c_int32, [_I64]),
     "trs_cin_glue_stats": (c_int32, [_P, _I64, _I32, _I32, _I32, _P, _P]),
     "trs_cin_glue_fwd": (c_int32, [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
@@ -194,15 +197,29 @@ def _mark_ring(name: str) -> torch.Tensor:
     return r
 
 
-def time_kernel(name: str, enable: bool = True):
-    """Bracket every launch of entry point ``name`` with HIP events (bench.py's live roofline); launches captured
-    into a hipGraph are bracketed with device-side timestamp marks instead (see trs_mark_timestamp)."""
+_every = {}              # name -> [period, launches seen]
+
+
+def time_kernel(name: str, enable: bool = True, expect: int = 0, every: int = 1):
+    """Bracket launches of entry point ``name`` with HIP events (bench.py's live roofline); launches captured
+    into a hipGraph are bracketed with device-side timestamp marks instead (see trs_mark_timestamp).
+    ``expect``: number of launches that will be timed -- their events are created NOW (hipEventCreate costs ~0.4 ms
+    here, which inside a timed region is enough to push a step from GPU-bound into host/GPU lock-step).
+    ``every``: bracket only every ``every``-th eager launch.  A recorded timing event holds one of the runtime's
+    profiling signals until it is read; with two records per step the host ends up waiting on the oldest one and
+    the step runs in host/GPU lock-step (measured: 3.3 ms instead of 1.3 ms for the DeepFM step), so bench.py
+    samples the kernel instead of bracketing all of its launches."""
     if enable:
         _timed[name] = []
+        _every[name] = [max(1, int(every)), 0]
         _rings[name] = torch.zeros(_MARK_CAP + 1, dtype=torch.int64, device="cuda")
+        fresh = [_HipEvent() for _ in range(max(0, 2 * expect - len(_HipEvent._free)))]
+        for ev in fresh:
+            ev.release()
     else:
         _timed.pop(name, None)
         _rings.pop(name, None)
+        _every.pop(name, None)
 
 
 def kernel_times_ms(name: str):
@@ -232,7 +249,7 @@ def call(name: str, *args):
     """Call an int-returning entry point; raise RuntimeError with the library's message on failure."""
     rec = _timed.get(name)
     if rec is not None:
-        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        st = stream_ptr()
         if torch.cuda.is_current_stream_capturing():
             # a captured event pair keeps only the latest replay (and ROCm refuses external event records in a
             # capture): bracket the launch with two device-side timestamp marks instead; each replay appends a sample
@@ -242,11 +259,16 @@ def call(name: str, *args):
             rc = getattr(lib, name)(*args)
             lib.trs_mark_timestamp(ctypes.c_void_p(ring.data_ptr()), _MARK_CAP, st)
         else:
-            a, b = _HipEvent(), _HipEvent()
-            a.record(st, 0)
-            rc = getattr(load(), name)(*args)
-            b.record(st, 0)
-            rec.append((a, b))
+            ev = _every[name]
+            ev[1] += 1
+            if ev[1] % ev[0] == 0:
+                a, b = _HipEvent(), _HipEvent()
+                a.record(st, 0)
+                rc = getattr(load(), name)(*args)
+                b.record(st, 0)
+                rec.append((a, b))
+            else:
+                rc = getattr(load(), name)(*args)
     else:
         rc = getattr(load(), name)(*args)
     if rc != 0:
@@ -273,6 +295,11 @@ def index_dtype_code(t: torch.Tensor) -> int:
     raise TypeError(f"torecsys_amd: unsupported index dtype {t.dtype}")
 
 
+def current_stream_of(dev: torch.device) -> torch.cuda.Stream:
+    """torch.cuda.current_stream(dev) with an explicit index (the argument-less form costs a hipGetDeviceCount)."""
+    return torch.cuda.current_stream(dev.index if dev.index is not None else torch._C._cuda_getDevice())
+
+
 def require_device(*tensors: torch.Tensor) -> torch.device:
     """All tensors must live on one HIP device; anything else is an error (no CPU path)."""
     dev = None
@@ -295,4 +322,7 @@ def ptr(t) -> c_void_p:
 
 
 def stream_ptr() -> c_void_p:
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    # torch.cuda.current_stream() with no device argument resolves the device through torch.cuda.is_available(), i.e.
+    # hipGetDeviceCount -- 50-200 us per call on this runtime, ~20 calls per training step.  The raw-stream query
+    # with an explicit device index is a sub-microsecond C call.
+    return c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))

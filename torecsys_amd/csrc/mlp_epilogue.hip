@@ -4,6 +4,8 @@
 // in ONE pass (ATen: threshold_backward, then a column-sum that re-reads gz).  HBM-bound: 2 reads + 1 write of
 // rows x C elements.  Each workgroup owns a band of rows, every thread keeps the column sums of its 16-byte
 // column vector in registers, bands are combined through a [bands][C] fp32 partial buffer by a second kernel.
+#include <algorithm>
+
 #include "trs_common.hpp"
 
 namespace trs {
@@ -97,9 +99,158 @@ __global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __res
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Linear with ONE output unit (the logit layer of the DeepFM / xDeepFM MLP): out[r] = h[r,:] . w + b.
+// As a GEMM it is a 1-column problem (hipBLASLt: 20 us forward, 28 us input gradient, 86 us weight gradient at
+// 65 536 x 512); it is a row-wise dot product and its transpose -- HBM-bound passes over h.
+// Lanes along the columns (one 16-byte vector per lane), LPR = C/VE lanes per row, 256/LPR rows per workgroup pass.
+template <typename T>
+__global__ __launch_bounds__(256) void rowdot_fwd_kernel(const uint4* __restrict__ h, const uint4* __restrict__ w,
+                                                         const T* __restrict__ bias, int64_t rows, int lpr,
+                                                         T* __restrict__ out) {
+  constexpr int VE = Vec16<T>::VE;
+  const int v = threadIdx.x % lpr, rr = threadIdx.x / lpr, rpp = 256 / lpr;
+  float wv[VE];
+  Vec16<T>::unpack(w[v], wv);
+  const float b0 = bias != nullptr ? to_f32(bias[0]) : 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * rpp + rr; r < rows; r += (int64_t)gridDim.x * rpp) {
+    float x[VE];
+    Vec16<T>::unpack(h[r * lpr + v], x);
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < VE; ++k) acc = fmaf(x[k], wv[k], acc);
+    for (int o = lpr >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);          // lpr is a power of two <= 64
+    if (v == 0) out[r] = from_f32<T>(acc + b0);
+  }
+}
+
+// gh[r,:] = g[r] * w;  partial[blk][c] = sum over the workgroup's rows of g[r] * h[r,c];  partial[blk][C] = sum g[r]
+template <typename T>
+__global__ __launch_bounds__(256) void rowdot_bwd_kernel(const T* __restrict__ g, const uint4* __restrict__ h,
+                                                         const uint4* __restrict__ w, int64_t rows, int lpr,
+                                                         uint4* __restrict__ gh, float* __restrict__ partial) {
+  constexpr int VE = Vec16<T>::VE;
+  __shared__ float red[256][VE + 1];
+  const int v = threadIdx.x % lpr, rr = threadIdx.x / lpr, rpp = 256 / lpr;
+  const int C = lpr * VE;
+  float wv[VE], gw[VE], gb = 0.f;
+  Vec16<T>::unpack(w[v], wv);
+#pragma unroll
+  for (int k = 0; k < VE; ++k) gw[k] = 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * rpp + rr; r < rows; r += (int64_t)gridDim.x * rpp) {
+    const float gr = to_f32(g[r]);
+    if (partial != nullptr) {
+      float x[VE];
+      Vec16<T>::unpack(h[r * lpr + v], x);
+#pragma unroll
+      for (int k = 0; k < VE; ++k) gw[k] = fmaf(gr, x[k], gw[k]);
+      if (v == 0) gb += gr;
+    }
+    if (gh != nullptr) {
+      float o[VE];
+#pragma unroll
+      for (int k = 0; k < VE; ++k) o[k] = gr * wv[k];
+      gh[r * lpr + v] = Vec16<T>::pack(o);
+    }
+  }
+  if (partial == nullptr) return;
+#pragma unroll
+  for (int k = 0; k < VE; ++k) red[threadIdx.x][k] = gw[k];
+  red[threadIdx.x][VE] = gb;
+  __syncthreads();
+  if (rr == 0) {
+    float* mine = partial + (size_t)blockIdx.x * (C + 1);
+#pragma unroll
+    for (int k = 0; k < VE; ++k) {
+      float t = 0.f;
+      for (int q = 0; q < rpp; ++q) t += red[q * lpr + v][k];
+      mine[v * VE + k] = t;
+    }
+    if (v == 0) {
+      float t = 0.f;
+      for (int q = 0; q < rpp; ++q) t += red[q * lpr][VE];
+      mine[C] = t;
+    }
+  }
+}
+
+__global__ void rowdot_accumulate_kernel(const float* __restrict__ tmp, int C, float* __restrict__ gw,
+                                         float* __restrict__ gb) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) gw[c] += tmp[c];
+  else if (c == C) gb[0] += tmp[C];
+}
+
+static int rowdot_blocks(int64_t rows, int lpr) {
+  const int rpp = 256 / lpr;
+  return (int)std::min<int64_t>((rows + rpp - 1) / rpp, 1023);
+}
+static bool rowdot_shape_ok(int C, int dtype) {
+  const int ve = dtype == TRS_F32 ? 4 : 8;
+  const int lpr = C % ve == 0 ? C / ve : 0;
+  return lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0;
+}
+
 }  // namespace trs
 
 using namespace trs;
+
+/* Linear with one output unit: out[r] = h[r,:] . w + bias[0]        h (rows, C), w (C), C * sizeof(T) / 16 a power of
+ * two <= 64 (C = 512 bf16, 256 fp32, ...).  bwd: gh (rows, C) = g[r] * w (may be NULL); gw (C) and gb (1) fp32 =
+ * sum_r g[r] h[r,:] and sum_r g[r], ACCUMULATED into (may both be NULL); workspace: partial sums per workgroup.    */
+extern "C" int trs_rowdot_fwd(const void* h, const void* w, const void* bias, int64_t rows, int32_t C, int32_t dtype,
+                              void* out, trs_stream_t stream) {
+  TRS_REQUIRE(rows >= 0 && C > 0, TRS_EINVAL, "rowdot_fwd: bad size");
+  if (rows == 0) return TRS_OK;
+  TRS_REQUIRE(h && w && out, TRS_EINVAL, "rowdot_fwd: NULL pointer");
+  TRS_REQUIRE(dtype == TRS_F32 || dtype == TRS_BF16, TRS_EDTYPE, "rowdot_fwd: dtype %d", dtype);
+  TRS_REQUIRE(rowdot_shape_ok(C, dtype), TRS_ESHAPE, "rowdot_fwd: C = %d (C*elem/16 must be a power of two <= 64)", C);
+  TRS_REQUIRE(aligned16(h) && aligned16(w), TRS_EALIGN, "rowdot_fwd: 16-byte alignment");
+  const int lpr = C / (dtype == TRS_F32 ? 4 : 8);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == TRS_F32)
+    hipLaunchKernelGGL((rowdot_fwd_kernel<float>), dim3(rowdot_blocks(rows, lpr)), dim3(256), 0, s, (const uint4*)h,
+                       (const uint4*)w, (const float*)bias, rows, lpr, (float*)out);
+  else
+    hipLaunchKernelGGL((rowdot_fwd_kernel<bf16_t>), dim3(rowdot_blocks(rows, lpr)), dim3(256), 0, s, (const uint4*)h,
+                       (const uint4*)w, (const bf16_t*)bias, rows, lpr, (bf16_t*)out);
+  return check_launch("rowdot_fwd");
+}
+
+extern "C" size_t trs_rowdot_bwd_workspace_bytes(int64_t rows, int32_t C) {
+  return (size_t)1024 * (size_t)(C + 1) * 4 + 256;
+}
+
+extern "C" int trs_rowdot_bwd(const void* g, const void* h, const void* w, int64_t rows, int32_t C, int32_t dtype,
+                              void* gh, float* gw, float* gb, void* workspace, size_t ws_bytes, trs_stream_t stream) {
+  TRS_REQUIRE(rows >= 0 && C > 0, TRS_EINVAL, "rowdot_bwd: bad size");
+  if (rows == 0) return TRS_OK;
+  TRS_REQUIRE(g && h && w, TRS_EINVAL, "rowdot_bwd: NULL pointer");
+  TRS_REQUIRE((gw == nullptr) == (gb == nullptr), TRS_EINVAL, "rowdot_bwd: gw and gb go together");
+  TRS_REQUIRE(dtype == TRS_F32 || dtype == TRS_BF16, TRS_EDTYPE, "rowdot_bwd: dtype %d", dtype);
+  TRS_REQUIRE(rowdot_shape_ok(C, dtype), TRS_ESHAPE, "rowdot_bwd: C = %d (C*elem/16 must be a power of two <= 64)", C);
+  TRS_REQUIRE(aligned16(h) && aligned16(w) && aligned16(gh), TRS_EALIGN, "rowdot_bwd: 16-byte alignment");
+  TRS_REQUIRE(gw == nullptr || (workspace != nullptr && ws_bytes >= trs_rowdot_bwd_workspace_bytes(rows, C)),
+              TRS_EWORKSPACE, "rowdot_bwd: workspace too small");
+  const int lpr = C / (dtype == TRS_F32 ? 4 : 8);
+  const int grid = rowdot_blocks(rows, lpr);
+  hipStream_t s = (hipStream_t)stream;
+  float* part = gw != nullptr ? (float*)workspace : nullptr;
+  if (dtype == TRS_F32)
+    hipLaunchKernelGGL((rowdot_bwd_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)g, (const uint4*)h,
+                       (const uint4*)w, rows, lpr, (uint4*)gh, part);
+  else
+    hipLaunchKernelGGL((rowdot_bwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)g, (const uint4*)h,
+                       (const uint4*)w, rows, lpr, (uint4*)gh, part);
+  if (gw != nullptr) {
+    // column sums of the (grid, C+1) partials; the last column is sum g
+    float* tmp = part + (size_t)grid * (C + 1);          // C+1 floats behind the partials (inside the 1024-block budget)
+    if (grid >= 1024) return fail(TRS_EWORKSPACE, "rowdot_bwd: internal workspace layout");
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3((C + 1 + 15) / 16), dim3(256), 0, s, part, grid, C + 1, tmp);
+    hipLaunchKernelGGL(rowdot_accumulate_kernel, dim3((C + 1 + 255) / 256), dim3(256), 0, s, tmp, C, gw, gb);
+  }
+  return check_launch("rowdot_bwd");
+}
 
 extern "C" size_t trs_relu_bwd_bias_workspace_bytes(int64_t rows, int32_t C) {
   (void)rows;

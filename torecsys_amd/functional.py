@@ -53,9 +53,10 @@ class RowBuckets:
     def wait(self):
         """Make the current stream wait for the build (no-op when built on this stream)."""
         if self.ready is not None:
-            torch.cuda.current_stream().wait_event(self.ready)
-            self.row_start.record_stream(torch.cuda.current_stream())
-            self.perm.record_stream(torch.cuda.current_stream())
+            cur = _abi.current_stream_of(self.row_start.device)
+            cur.wait_event(self.ready)
+            self.row_start.record_stream(cur)
+            self.perm.record_stream(cur)
 
 
 _bucket_cache: List[tuple] = []   # [(key, idx_tensor_kept_alive, RowBuckets)]
@@ -156,12 +157,15 @@ def prefetch_row_buckets(idx: torch.Tensor, offsets: Optional[torch.Tensor], V: 
     side = _side_streams.get(dev)
     if side is None:
         side = _side_streams[dev] = torch.cuda.Stream(device=dev)
-    main = torch.cuda.current_stream()
+    main = _abi.current_stream_of(dev)
     side.wait_stream(main)
-    with torch.cuda.stream(side):
+    torch.cuda.set_stream(side)          # not `with torch.cuda.stream(side)`: its constructor and __enter__ each resolve
+    try:                                 # the current device through hipGetDeviceCount (~0.1 ms apiece)
         rb = _build_buckets(idx, offsets, V)
         rb.ready = torch.cuda.Event()
         rb.ready.record(side)
+    finally:
+        torch.cuda.set_stream(main)
     idx.record_stream(side)
     if offsets is not None:
         offsets.record_stream(side)
@@ -1193,6 +1197,50 @@ def ffm_fused(weights: Sequence[torch.Tensor], idx: torch.Tensor, offsets: torch
 # --------------------------------------------------------------------------------------------
 # MLP backward epilogue: relu backward + bias gradient in one pass (GEMMs stay on hipBLASLt)
 # --------------------------------------------------------------------------------------------
+def rowdot_supported(h2: torch.Tensor) -> bool:
+    """one-output Linear as a row-wise dot product: rows of 16-byte vectors, a power of two of them, at most 64"""
+    if not (h2.is_cuda and h2.dim() == 2 and h2.dtype in (torch.float32, torch.bfloat16) and h2.is_contiguous()):
+        return False
+    ve = 16 // h2.element_size()
+    lpr = h2.shape[1] // ve if h2.shape[1] % ve == 0 else 0
+    return 1 <= lpr <= 64 and (lpr & (lpr - 1)) == 0
+
+
+class _RowDot(Function):
+    """out (rows, 1) = h (rows, C) @ w (1, C)^T + b (1): trs_rowdot_fwd / trs_rowdot_bwd.  ``w_use`` / ``b_use`` are
+    the (possibly zero-padded) tensors the kernels read; gradients are returned for ``weight`` / ``bias``."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias, w_use, b_use):
+        W = (weight if w_use is None else w_use).reshape(-1).contiguous()
+        Bv = bias if w_use is None else b_use
+        h2 = h.reshape(-1, h.shape[-1])
+        out = torch.empty(h2.shape[0], 1, dtype=h.dtype, device=h.device)
+        call("trs_rowdot_fwd", ptr(h2), ptr(W), ptr(Bv), h2.shape[0], h2.shape[1], value_dtype_code(h2), ptr(out),
+             stream_ptr())
+        ctx.save_for_backward(h2, W)
+        ctx.meta = (tuple(h.shape), tuple(weight.shape), weight.dtype, bias is not None)
+        return out.reshape(*h.shape[:-1], 1)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        h2, W = ctx.saved_tensors
+        hshape, wshape, wdt, has_bias = ctx.meta
+        rows, C = h2.shape
+        g2 = g.reshape(-1).contiguous()
+        need_h, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])
+        gh = torch.empty_like(h2) if need_h else None
+        gw = torch.zeros(C + 1, dtype=torch.float32, device=h2.device) if need_w else None
+        ws_bytes = size_query("trs_rowdot_bwd_workspace_bytes", rows, C)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=h2.device) if need_w else None
+        call("trs_rowdot_bwd", ptr(g2), ptr(h2), ptr(W), rows, C, value_dtype_code(h2), ptr(gh),
+             ptr(gw), ptr(gw[C:]) if need_w else ptr(None), ptr(ws), ws_bytes if need_w else 0, stream_ptr())
+        g_weight = gw[:wshape[1]].to(wdt).reshape(wshape) if (need_w and ctx.needs_input_grad[1]) else None
+        g_bias = gw[C:].to(wdt) if (need_w and has_bias and ctx.needs_input_grad[2]) else None
+        return (gh.reshape(hshape) if need_h else None), g_weight, g_bias, None, None
+
+
 def relu_bwd_bias_supported(y: torch.Tensor) -> bool:
     row_bytes = y.shape[-1] * y.element_size()
     return (y.is_cuda and y.dtype in (torch.float32, torch.bfloat16) and y.is_contiguous()

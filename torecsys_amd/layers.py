@@ -658,7 +658,12 @@ class MultilayerPerceptionLayer(BaseLayer):
                     w_pad, b_pad = _PaddedLinear.get(mod, width, out_pad)
                 else:
                     w_pad = b_pad = None
-                outputs = _LinearSplitK.apply(outputs, mod.weight, mod.bias, fuse, w_pad, b_pad)
+                if (mod.out_features == 1 and not fuse and mod.bias is not None
+                        and F_.rowdot_supported(outputs.reshape(-1, outputs.shape[-1]))):
+                    # the logit layer: a row-wise dot product, not a GEMM (trs_rowdot_*)
+                    outputs = F_._RowDot.apply(outputs, mod.weight, mod.bias, w_pad, b_pad)
+                else:
+                    outputs = _LinearSplitK.apply(outputs, mod.weight, mod.bias, fuse, w_pad, b_pad)
                 width = out_pad
                 i += 2 if fuse else 1
             else:

@@ -70,8 +70,9 @@ class StagedBatch:
     def wait(self) -> torch.Tensor:
         """Make the CURRENT stream wait for the copy (no host block) and return the (B, N) device tensor."""
         if self._event is not None:
-            torch.cuda.current_stream().wait_event(self._event)
-            self._tensor.record_stream(torch.cuda.current_stream())
+            cur = torch.cuda.current_stream(self._tensor.device.index)
+            cur.wait_event(self._event)
+            self._tensor.record_stream(cur)
             self._event = None
         return self._tensor
 
@@ -97,9 +98,13 @@ class IndexStager:
         if self._done[k] is not None:
             self._done[k].synchronize()          # the copy that last used this pinned buffer must have finished
         pack_host(columns, self._np[k], self.names)
-        with torch.cuda.stream(self._stream):
+        prev = torch.cuda.current_stream(self.device.index if self.device.index is not None else torch.cuda.current_device())
+        torch.cuda.set_stream(self._stream)
+        try:
             dev = self._host[k].to(self.device, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self._stream)
+        finally:
+            torch.cuda.set_stream(prev)
         self._done[k] = ev
         return StagedBatch(dev, ev)
