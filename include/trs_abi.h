@@ -282,6 +282,13 @@ size_t trs_rowdot_bwd_workspace_bytes(int64_t rows, int32_t C);
 int trs_rowdot_bwd(const void* g, const void* h, const void* w, int64_t rows, int32_t C, int32_t dtype, void* gh,
                    float* gw, float* gb, void* workspace, size_t ws_bytes, trs_stream_t stream);
 
+/* ---- finish of a split-K weight gradient (the K = batch GEMM of multilayer_perceptron.py's nn.Linear backward) -----
+ * part (S, R, Cc) fp32 partial products  ->  gw (out_rows, out_cols) = sum_s part[s, :out_rows, :out_cols] cast to
+ * dtype (the un-padded corner when the GEMMs ran on zero-padded weights); gb (out_rows) = cast(gb_f32) (both or
+ * neither; needs out_rows <= 256 * ceil(out_cols / 256)).                                                          */
+int trs_wgrad_finish(const float* part, int32_t S, int32_t R, int32_t Cc, int32_t out_rows, int32_t out_cols,
+                     int32_t dtype, void* gw, const float* gb_f32, void* gb, trs_stream_t stream);
+
 /* ---- CIN layer glue on channels-last activations y (B,E,C) bf16 ---------------------------------
  * BatchNorm1d + ReLU + chunk(2) + sum over E of the direct half, compress_interaction_network.py:137-181:
  *   z = relu(y * scale[c] + shift[c])      scale = gamma * invstd, shift = beta - mean * scale (fp32, caller)

@@ -191,6 +191,34 @@ static bool rowdot_shape_ok(int C, int dtype) {
   return lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0;
 }
 
+// Finish of the split-K weight gradient: gw[r,c] = sum_s part[s,r,c] for the un-padded (out_rows x out_cols) corner of
+// the (S, R, Cc) fp32 partial products, cast to the parameter dtype; blockIdx.y == gridDim.y-1 also casts the fp32
+// bias gradient.  One launch instead of ATen's sum(0) + strided slice copy + cast (+ slice + cast for the bias).
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ part, int S, int R, int Cc,
+                                                          int out_rows, int out_cols, T* __restrict__ gw,
+                                                          const float* __restrict__ gbf, T* __restrict__ gb) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if ((int)blockIdx.y == out_rows) {           // the extra row of workgroups: bias gradient
+    if (gb != nullptr && c < out_rows) gb[c] = from_f32<T>(gbf[c]);
+    return;
+  }
+  if (c >= out_cols) return;
+  const int r = blockIdx.y;
+  const float* p = part + (size_t)r * Cc + c;
+  const size_t stride = (size_t)R * Cc;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int s = 0;
+  for (; s + 4 <= S; s += 4) {
+    a0 += p[(size_t)s * stride];
+    a1 += p[(size_t)(s + 1) * stride];
+    a2 += p[(size_t)(s + 2) * stride];
+    a3 += p[(size_t)(s + 3) * stride];
+  }
+  for (; s < S; ++s) a0 += p[(size_t)s * stride];
+  gw[(size_t)r * out_cols + c] = from_f32<T>((a0 + a1) + (a2 + a3));
+}
+
 }  // namespace trs
 
 using namespace trs;
@@ -286,4 +314,24 @@ extern "C" int trs_relu_bwd_bias(const void* gy, const void* y, int64_t rows, in
                        (const uint4*)y, (uint4*)gz, part, rows, vpr, rows_per_band);
   hipLaunchKernelGGL(colsum_partials_kernel, dim3((C + 15) / 16), dim3(256), 0, s, part, nbands, C, gb);
   return check_launch("relu_bwd_bias");
+}
+
+extern "C" int trs_wgrad_finish(const float* part, int32_t S, int32_t R, int32_t Cc, int32_t out_rows, int32_t out_cols,
+                                int32_t dtype, void* gw, const float* gb_f32, void* gb, trs_stream_t stream) {
+  TRS_REQUIRE(S > 0 && R > 0 && Cc > 0 && out_rows > 0 && out_cols > 0 && out_rows <= R && out_cols <= Cc, TRS_EINVAL,
+              "wgrad_finish: bad size");
+  TRS_REQUIRE(part && gw, TRS_EINVAL, "wgrad_finish: NULL pointer");
+  TRS_REQUIRE((gb == nullptr) == (gb_f32 == nullptr), TRS_EINVAL, "wgrad_finish: gb and gb_f32 go together");
+  TRS_REQUIRE(dtype == TRS_F32 || dtype == TRS_BF16, TRS_EDTYPE, "wgrad_finish: dtype %d", dtype);
+  TRS_REQUIRE(gb == nullptr || out_rows <= ((out_cols + 255) / 256) * 256, TRS_ESHAPE,
+              "wgrad_finish: out_rows %d exceeds the bias row of workgroups", out_rows);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((out_cols + 255) / 256, out_rows + 1);
+  if (dtype == TRS_F32)
+    hipLaunchKernelGGL((wgrad_finish_kernel<float>), grid, dim3(256), 0, s, part, S, R, Cc, out_rows, out_cols,
+                       (float*)gw, gb_f32, (float*)gb);
+  else
+    hipLaunchKernelGGL((wgrad_finish_kernel<bf16_t>), grid, dim3(256), 0, s, part, S, R, Cc, out_rows, out_cols,
+                       (bf16_t*)gw, gb_f32, (bf16_t*)gb);
+  return check_launch("wgrad_finish");
 }

@@ -1206,6 +1206,11 @@ def rowdot_supported(h2: torch.Tensor) -> bool:
     return 1 <= lpr <= 64 and (lpr & (lpr - 1)) == 0
 
 
+def rowdot_width_supported(C: int, elem_size: int) -> bool:
+    lpr = C * elem_size // 16 if (C * elem_size) % 16 == 0 else 0
+    return 1 <= lpr <= 64 and (lpr & (lpr - 1)) == 0
+
+
 class _RowDot(Function):
     """out (rows, 1) = h (rows, C) @ w (1, C)^T + b (1): trs_rowdot_fwd / trs_rowdot_bwd.  ``w_use`` / ``b_use`` are
     the (possibly zero-padded) tensors the kernels read; gradients are returned for ``weight`` / ``bias``."""
