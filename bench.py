@@ -226,7 +226,8 @@ def main():
     def fwd_loss(ix, lab, scale):
         d = inputs({"c0": ix})
         out = model(**d) if a.model != "dcn" else model(emb_inputs=d["emb_inputs"])
-        return crit(out.float(), lab) * scale
+        loss = crit(out.float(), lab)
+        return loss if scale == 1.0 else loss * scale
 
     host_idx = a.host_indices and not sharded and MB == 1
     if host_idx:
@@ -332,6 +333,11 @@ def main():
     torch.cuda.synchronize()
     phases[:] = [0.0, 0.0, 0.0, 0]
     dev_allocs0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
+    # no cyclic-GC pass inside the timed region: a generation-2 collection over the imported torch modules takes
+    # ~65 ms here, i.e. tens of steps (seen as one 65 ms step in the row-sharded run); objects are freed by refcount
+    import gc
+    gc.collect()
+    gc.disable()
     prof = None
     if os.environ.get("TRS_BENCH_CPROFILE"):      # developer diagnostic: which host call blocks inside the timed region
         import cProfile
@@ -339,17 +345,22 @@ def main():
     t0 = time.perf_counter()
     if prof:
         prof.enable()
+    stamps = []
     for i in range(a.steps):
         loss = step()
+        stamps.append(time.perf_counter())
     if prof:
         prof.disable()
     enqueue_s = time.perf_counter() - t0
+    gc.enable()
     if prof:
         import pstats
         pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(18)      # host time to enqueue K steps (== el when the host is the bound)
     if os.environ.get("TRS_BENCH_PHASES") and phases[3]:
         print("host ms/step  forward %.3f  prefetch %.3f  backward %.3f  (over the %d timed eager steps)" %
               tuple([1e3 * v / phases[3] for v in phases[:3]] + [phases[3]]), file=sys.stderr)
+        print("host ms per step call:", " ".join("%.2f" % ((b_ - a_) * 1e3) for a_, b_ in zip([t0] + stamps, stamps)),
+              file=sys.stderr)
         print("device allocations (hipMalloc) inside the timed region:",
               torch.cuda.memory_stats().get("num_device_alloc", 0) - dev_allocs0,
               " reserved GB: %.2f" % (torch.cuda.memory_reserved() / 2**30), file=sys.stderr)
