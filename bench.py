@@ -342,6 +342,8 @@ def main():
     if os.environ.get("TRS_BENCH_CPROFILE"):      # developer diagnostic: which host call blocks inside the timed region
         import cProfile
         prof = cProfile.Profile()
+    span0, span1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    span0.record()          # device-side cross-check of the wall clock (one event pair around the whole region)
     t0 = time.perf_counter()
     if prof:
         prof.enable()
@@ -352,10 +354,15 @@ def main():
     if prof:
         prof.disable()
     enqueue_s = time.perf_counter() - t0
+    span1.record()
     gc.enable()
     if prof:
         import pstats
         pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(18)      # host time to enqueue K steps (== el when the host is the bound)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
     if os.environ.get("TRS_BENCH_PHASES") and phases[3]:
         print("host ms/step  forward %.3f  prefetch %.3f  backward %.3f  (over the %d timed eager steps)" %
               tuple([1e3 * v / phases[3] for v in phases[:3]] + [phases[3]]), file=sys.stderr)
@@ -367,10 +374,26 @@ def main():
         if sharded:
             from torecsys_amd import dist as _d
             print("route plans:", _d.route_stats, file=sys.stderr)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    el = time.perf_counter() - t0
+        # how fast is THIS box: a dense bf16 GEMM and a device copy (boxes of the pool differ in sustained clocks)
+        ga = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+        gb_ = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+        src_ = torch.empty(1 << 28, dtype=torch.uint8, device=dev)
+        dst_ = torch.empty_like(src_)
+        for _ in range(3):
+            ga @ gb_
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        for _ in range(20):
+            ga @ gb_
+        e1.record()
+        for _ in range(20):
+            dst_.copy_(src_)
+        e2.record()
+        torch.cuda.synchronize()
+        print("box probe: bf16 GEMM 8192^3 %.0f TFLOP/s, device copy %.0f GB/s (read+write)" %
+              (20 * 2 * 8192 ** 3 / (e0.elapsed_time(e1) * 1e-3) / 1e12,
+               20 * 2 * (1 << 28) / (e1.elapsed_time(e2) * 1e-3) / 1e9), file=sys.stderr)
+    device_span_ms = span0.elapsed_time(span1)
     ktimes = _abi.kernel_times_ms(roof_kernel)
     _abi.time_kernel(roof_kernel, False)
     if world > 1:
@@ -416,7 +439,8 @@ def main():
                        "model": a.model, "global_batch": B * world, "rows": V, "parallelism": parallelism,
                        "microbatches": MB, "optimizer": a.optimizer, "hipgraph": bool(use_graph), "indices_from_host": bool(host_idx),
                        "fused_lookup_fm": not a.no_fuse, "loss": float(loss),
-                       "host_enqueue_ms_per_step": round(enqueue_s / a.steps * 1e3, 4)},
+                       "host_enqueue_ms_per_step": round(enqueue_s / a.steps * 1e3, 4),
+                       "device_span_ms_per_step": round(device_span_ms / a.steps, 4)},
             "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:
