@@ -122,3 +122,36 @@ def test_mlp_logit_layer_uses_rowdot(dev):
     assert rel_err(xa.grad.float().cpu(), xb.grad.float().cpu()) <= 3e-2
     for (n, pa), (_, pb) in zip(mlp.model.named_parameters(), ref.named_parameters()):
         assert rel_err(pa.grad.float().cpu(), pb.grad.float().cpu()) <= 3e-2, n
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("S,R,Cc,out_rows,out_cols,with_bias", [
+    (32, 512, 2496, 400, 2496, True), (8, 512, 512, 400, 400, True), (4, 64, 96, 64, 96, False),
+    (5, 128, 40, 100, 33, True), (1, 16, 300, 16, 300, True)])
+def test_wgrad_finish_matches_torch(dev, dtype, S, R, Cc, out_rows, out_cols, with_bias):
+    """trs_wgrad_finish = part.sum(0)[:out_rows, :out_cols].to(dtype) (+ the bias-gradient cast) in one launch"""
+    from torecsys_amd import _abi
+    torch.manual_seed(S * R + Cc)
+    part = torch.randn(S, R, Cc, device=dev)
+    gbf = torch.randn(R, device=dev)
+    gw = torch.empty(out_rows, out_cols, dtype=dtype, device=dev)
+    gb = torch.empty(out_rows, dtype=dtype, device=dev) if with_bias else None
+    _abi.call("trs_wgrad_finish", _abi.ptr(part), S, R, Cc, out_rows, out_cols, _abi.value_dtype_code(gw), _abi.ptr(gw),
+              _abi.ptr(gbf) if with_bias else _abi.ptr(None), _abi.ptr(gb), _abi.stream_ptr())
+    ref = part.sum(0)[:out_rows, :out_cols]
+    tol = 1e-6 if dtype == torch.float32 else 8e-3
+    assert rel_err(gw.float().cpu(), ref.cpu()) <= tol
+    if with_bias:
+        assert torch.equal(gb.cpu(), gbf[:out_rows].to(dtype).cpu())
+
+
+def test_wgrad_finish_rejects_bad_arguments(dev):
+    from torecsys_amd import _abi
+    part = torch.zeros(2, 8, 8, device=dev)
+    gw = torch.empty(8, 8, device=dev)
+    with pytest.raises(RuntimeError):          # out_rows > R
+        _abi.call("trs_wgrad_finish", _abi.ptr(part), 2, 8, 8, 9, 8, 0, _abi.ptr(gw), _abi.ptr(None), _abi.ptr(None),
+                  _abi.stream_ptr())
+    with pytest.raises(RuntimeError):          # gb without gb_f32
+        _abi.call("trs_wgrad_finish", _abi.ptr(part), 2, 8, 8, 8, 8, 0, _abi.ptr(gw), _abi.ptr(None), _abi.ptr(gw),
+                  _abi.stream_ptr())

@@ -113,14 +113,27 @@ __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const uint4* __restrict
   float wv[VE];
   Vec16<T>::unpack(w[v], wv);
   const float b0 = bias != nullptr ? to_f32(bias[0]) : 0.f;
-  for (int64_t r = (int64_t)blockIdx.x * rpp + rr; r < rows; r += (int64_t)gridDim.x * rpp) {
-    float x[VE];
-    Vec16<T>::unpack(h[r * lpr + v], x);
-    float acc = 0.f;
+  constexpr int U = 4;          // independent row loads in flight per thread (one load per iteration is latency-bound)
+  const int64_t step = (int64_t)gridDim.x * rpp;
+  for (int64_t r0 = (int64_t)blockIdx.x * rpp + rr; r0 < rows; r0 += step * U) {
+    uint4 raw[U];
 #pragma unroll
-    for (int k = 0; k < VE; ++k) acc = fmaf(x[k], wv[k], acc);
-    for (int o = lpr >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);          // lpr is a power of two <= 64
-    if (v == 0) out[r] = from_f32<T>(acc + b0);
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = r0 + u * step;
+      raw[u] = make_uint4(0, 0, 0, 0);
+      if (r < rows) raw[u] = h[r * lpr + v];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = r0 + u * step;
+      float x[VE];
+      Vec16<T>::unpack(raw[u], x);
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < VE; ++k) acc = fmaf(x[k], wv[k], acc);
+      for (int o = lpr >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);          // lpr is a power of two <= 64
+      if (v == 0 && r < rows) out[r] = from_f32<T>(acc + b0);
+    }
   }
 }
 
@@ -137,20 +150,38 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const T* __restrict__ g
   Vec16<T>::unpack(w[v], wv);
 #pragma unroll
   for (int k = 0; k < VE; ++k) gw[k] = 0.f;
-  for (int64_t r = (int64_t)blockIdx.x * rpp + rr; r < rows; r += (int64_t)gridDim.x * rpp) {
-    const float gr = to_f32(g[r]);
-    if (partial != nullptr) {
-      float x[VE];
-      Vec16<T>::unpack(h[r * lpr + v], x);
+  constexpr int U = 4;
+  const int64_t step = (int64_t)gridDim.x * rpp;
+  for (int64_t r0 = (int64_t)blockIdx.x * rpp + rr; r0 < rows; r0 += step * U) {
+    uint4 raw[U];
+    float gr[U];
 #pragma unroll
-      for (int k = 0; k < VE; ++k) gw[k] = fmaf(gr, x[k], gw[k]);
-      if (v == 0) gb += gr;
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = r0 + u * step;
+      raw[u] = make_uint4(0, 0, 0, 0);
+      gr[u] = 0.f;
+      if (r < rows) {
+        gr[u] = to_f32(g[r]);
+        if (partial != nullptr) raw[u] = h[r * lpr + v];
+      }
     }
-    if (gh != nullptr) {
-      float o[VE];
 #pragma unroll
-      for (int k = 0; k < VE; ++k) o[k] = gr * wv[k];
-      gh[r * lpr + v] = Vec16<T>::pack(o);
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = r0 + u * step;
+      if (r >= rows) continue;
+      if (partial != nullptr) {
+        float x[VE];
+        Vec16<T>::unpack(raw[u], x);
+#pragma unroll
+        for (int k = 0; k < VE; ++k) gw[k] = fmaf(gr[u], x[k], gw[k]);
+        if (v == 0) gb += gr[u];
+      }
+      if (gh != nullptr) {
+        float o[VE];
+#pragma unroll
+        for (int k = 0; k < VE; ++k) o[k] = gr[u] * wv[k];
+        gh[r * lpr + v] = Vec16<T>::pack(o);
+      }
     }
   }
   if (partial == nullptr) return;
@@ -301,7 +332,7 @@ extern "C" int trs_relu_bwd_bias(const void* gy, const void* y, int64_t rows, in
   TRS_REQUIRE(gy && y && gz, TRS_EINVAL, "relu_bwd_bias: NULL pointer");
   TRS_REQUIRE(aligned16(gy) && aligned16(y) && aligned16(gz), TRS_EALIGN, "relu_bwd_bias: 16-byte alignment");
   const int vpr = row_bytes / 16;
-  int nbands = (int)std::min<int64_t>(2048, (rows + 31) / 32);
+  int nbands = (int)std::min<int64_t>(1024, (rows + 31) / 32);
   const int rows_per_band = (int)((rows + nbands - 1) / nbands);
   nbands = (int)((rows + rows_per_band - 1) / rows_per_band);
   TRS_REQUIRE(ws_bytes >= (size_t)nbands * C * 4, TRS_EWORKSPACE, "relu_bwd_bias: workspace too small");
