@@ -295,7 +295,7 @@ def test_fused_ffm_equals_two_module_path(dev, dtype, B, N, E):
 
 
 @pytest.mark.parametrize("mode", ["train", "eval", "nobn", "direct", "noaffine"])
-@pytest.mark.parametrize("B,E,C", [(33, 64, 256), (7, 16, 64), (130, 8, 128)])
+@pytest.mark.parametrize("B,E,C", [(33, 64, 256), (7, 16, 64), (130, 8, 128), (5, 32, 512)])
 def test_cin_glue_matches_aten_sequence(dev, mode, B, E, C):
     """trs_cin_glue_* (BatchNorm1d + ReLU + chunk + sum over E in two passes) against the ATen sequence the layer
     used before: outputs, input gradient, BatchNorm parameter gradients and running statistics."""
@@ -319,6 +319,15 @@ def test_cin_glue_matches_aten_sequence(dev, mode, B, E, C):
     assert F_.cin_glue_supported(y0, D, Hs)
     ya = y0.clone().requires_grad_()
     hidden, pooled = F_.cin_glue(ya, bn, D, Hs)
+    # shapes with E == 8 * (256 / (C / 8)) also get channels-first copies of the hidden half and of the input gradient
+    cf = bool(F_.size_query("trs_cin_glue_cf_supported", E, C))
+    assert cf == ((E, C) in ((64, 256), (32, 512)))
+    seen_cf = []
+    ya.register_hook(lambda g_: seen_cf.append((g_.detach().clone(), getattr(g_, '_trs_cf', None))))
+    if cf and C > Hs:
+        assert torch.equal(hidden._trs_cf, hidden.detach().transpose(1, 2).contiguous())
+    else:
+        assert getattr(hidden, '_trs_cf', None) is None
     yb = y0.clone().requires_grad_()
     z = yb.reshape(B * E, C)
     if ref_bn is not None:
@@ -333,6 +342,10 @@ def test_cin_glue_matches_aten_sequence(dev, mode, B, E, C):
     ((hidden.float() * gh.float()).sum() + (pooled.float() * gp.float()).sum()).backward()
     ((ref_hidden.float() * gh.float()).sum() + (ref_pooled.float() * gp.float()).sum()).backward()
     assert rel_err(ya.grad.float().cpu(), yb.grad.float().cpu()) <= 3e-2
+    if cf:
+        gy_seen, gy_cf = seen_cf[0]
+        assert gy_cf is not None, "the channels-first gradient copy did not ride on the gradient tensor"
+        assert torch.equal(gy_cf, gy_seen.transpose(1, 2).contiguous())
     if bn is not None:
         if bn.affine:
             assert rel_err(bn.weight.grad.float().cpu(), ref_bn.weight.grad.float().cpu()) <= 3e-2

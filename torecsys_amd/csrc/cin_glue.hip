@@ -202,7 +202,137 @@ __global__ __launch_bounds__(GLUE_THREADS) void glue_bwd_apply_kernel(
   }
 }
 
+// ---- variants that ALSO emit a channels-first copy of their output (the weight-gradient kernel trs_cin_dw reads
+// (B, channels, E) operands: without the copy PyTorch transposes the 1-2 GB tensors once per layer and step).
+// Requires E == 8 * rpp (E = 64 with C = 256): a thread then owns 8 CONSECUTIVE e for its 8 channels, i.e. an 8 x 8
+// register tile whose transpose is eight 16-byte vectors along e; they go through an XOR-swizzled LDS tile
+// [channel][E] so that the global writes are whole rows.
+__device__ __forceinline__ uint4 glue_pack_col(float (*t)[8], int k) {
+  float col[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) col[j] = t[j][k];
+  return Vec16<bf16_t>::pack(col);
+}
+
+__global__ __launch_bounds__(GLUE_THREADS) void glue_apply_fwd_cf_kernel(const bf16_t* __restrict__ y,
+                                                                         const float* __restrict__ scale,
+                                                                         const float* __restrict__ shift, int64_t B,
+                                                                         int E, int C, int D, int Hs,
+                                                                         bf16_t* __restrict__ hidden,
+                                                                         bf16_t* __restrict__ hidden_cf,
+                                                                         bf16_t* __restrict__ pooled) {
+  extern __shared__ float lds[];
+  const GlueIdx g = glue_idx(C);
+  float a[8], sh[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { a[k] = scale[g.c0 + k]; sh[k] = shift[g.c0 + k]; }
+  const bool is_hidden = g.c0 >= Hs, is_direct = g.c0 < D;
+  const int HW = C - Hs;
+  const int e0 = g.rr * 8;
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    const uint4* rows = reinterpret_cast<const uint4*>(y + b * E * (int64_t)C);
+    uint4 raw[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) raw[j] = rows[(int64_t)(e0 + j) * g.vpr + g.v];
+    float t[8][8], pool[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pool[k] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      Vec16<bf16_t>::unpack(raw[j], t[j]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        t[j][k] = fmaxf(fmaf(t[j][k], a[k], sh[k]), 0.f);
+        pool[k] += t[j][k];
+      }
+      if (is_hidden)
+        *reinterpret_cast<uint4*>(hidden + (b * E + e0 + j) * (int64_t)HW + (g.c0 - Hs)) = Vec16<bf16_t>::pack(t[j]);
+    }
+    // channels-first copy through an LDS tile [channel][E (+8 pad)] so that the global writes are whole 128-byte rows
+    // (16-byte pieces written straight from the registers reach only ~1.9 TB/s)
+    bf16_t* tile = reinterpret_cast<bf16_t*>(lds + GLUE_THREADS * 8);
+    const int TS = E + 8;
+    __syncthreads();
+    if (is_hidden) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        *reinterpret_cast<uint4*>(tile + (g.c0 - Hs + k) * TS + (e0 ^ ((((g.c0 - Hs) >> 3) & (g.rpp - 1)) << 3))) = glue_pack_col(t, k);
+    }
+    __syncthreads();
+    {
+      const int vpe = E / 8;                       // 16-byte vectors per channel row
+      uint4* dst = reinterpret_cast<uint4*>(hidden_cf + b * HW * (int64_t)E);
+      for (int i = threadIdx.x; i < HW * vpe; i += GLUE_THREADS) {
+        const int ch = i / vpe, ve = i - ch * vpe;
+        dst[i] = *reinterpret_cast<const uint4*>(tile + ch * TS + ((ve ^ ((ch >> 3) & (vpe - 1))) << 3));
+      }
+    }
+    float o[8];
+    glue_block_reduce(lds, g, C, pool, o);
+    if (g.rr == 0 && is_direct) *reinterpret_cast<uint4*>(pooled + b * (int64_t)D + g.c0) = Vec16<bf16_t>::pack(o);
+  }
+}
+
+__global__ __launch_bounds__(GLUE_THREADS) void glue_bwd_apply_cf_kernel(
+    const bf16_t* __restrict__ y, const bf16_t* __restrict__ g_hidden, const bf16_t* __restrict__ g_pooled,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ c1, const float* __restrict__ c2, int64_t B, int E, int C,
+    int D, int Hs, bf16_t* __restrict__ gy, bf16_t* __restrict__ gy_cf) {
+  const GlueIdx g = glue_idx(C);
+  float a[8], sh[8], mu[8], is[8], k1[8], k2[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    a[k] = scale[g.c0 + k]; sh[k] = shift[g.c0 + k]; mu[k] = mean[g.c0 + k]; is[k] = invstd[g.c0 + k];
+    k1[k] = c1[g.c0 + k]; k2[k] = c2[g.c0 + k];
+  }
+  const bool is_hidden = g.c0 >= Hs, is_direct = g.c0 < D;
+  const int HW = C - Hs;
+  const int e0 = g.rr * 8;
+  extern __shared__ float lds[];
+  bf16_t* tile = reinterpret_cast<bf16_t*>(lds);       // [C][E + 8]: see glue_apply_fwd_cf_kernel
+  const int TS = E + 8;
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    const uint4* rows = reinterpret_cast<const uint4*>(y + b * E * (int64_t)C);
+    uint4* out = reinterpret_cast<uint4*>(gy + b * E * (int64_t)C);
+    float gp8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) gp8[k] = 0.f;
+    if (is_direct && g_pooled != nullptr)
+      Vec16<bf16_t>::unpack(*reinterpret_cast<const uint4*>(g_pooled + b * (int64_t)D + g.c0), gp8);
+    uint4 raw[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) raw[j] = rows[(int64_t)(e0 + j) * g.vpr + g.v];
+    float t[8][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float x[8];
+      Vec16<bf16_t>::unpack(raw[j], x);
+      glue_gz(g_hidden, gp8, is_hidden, is_direct, b * E + e0 + j, HW, g.c0 - Hs, t[j]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float m = fmaf(x[k], a[k], sh[k]) > 0.f ? t[j][k] : 0.f;
+        t[j][k] = a[k] * (m - k1[k] - (x[k] - mu[k]) * is[k] * k2[k]);
+      }
+      out[(int64_t)(e0 + j) * g.vpr + g.v] = Vec16<bf16_t>::pack(t[j]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      *reinterpret_cast<uint4*>(tile + (g.c0 + k) * TS + (e0 ^ (((g.c0 >> 3) & (g.rpp - 1)) << 3))) = glue_pack_col(t, k);
+    __syncthreads();
+    {
+      const int vpe = E / 8;
+      uint4* dst = reinterpret_cast<uint4*>(gy_cf + b * C * (int64_t)E);
+      for (int i = threadIdx.x; i < C * vpe; i += GLUE_THREADS) {
+        const int ch = i / vpe, ve = i - ch * vpe;
+        dst[i] = *reinterpret_cast<const uint4*>(tile + ch * TS + ((ve ^ ((ch >> 3) & (vpe - 1))) << 3));
+      }
+    }
+  }
+}
+
 static int glue_grid(int64_t B) { return (int)std::min<int64_t>(B, 1024); }
+static bool glue_cf_ok(int C, int E) { return C % 8 == 0 && C / 8 <= GLUE_THREADS && E == 8 * (GLUE_THREADS / (C / 8)); }
 static bool glue_shape_ok(int C, int D, int Hs) {
   const int vpr = C / 8;
   return C % 8 == 0 && vpr >= 1 && vpr <= GLUE_THREADS && GLUE_THREADS % vpr == 0 && D % 8 == 0 && Hs % 8 == 0 &&
@@ -272,4 +402,42 @@ extern "C" int trs_cin_glue_bwd_apply(const void* y, const void* g_hidden, const
                      (const bf16_t*)y, (const bf16_t*)g_hidden, (const bf16_t*)g_pooled, scale, shift, mean, invstd, c1, c2,
                      B, E, C, D, Hs, (bf16_t*)gy);
   return check_launch("cin_glue_bwd_apply");
+}
+
+/* channels-first by-products: see glue_apply_fwd_cf_kernel */
+extern "C" int trs_cin_glue_cf_supported(int32_t E, int32_t C) { return glue_cf_ok(C, E) ? 1 : 0; }
+
+extern "C" int trs_cin_glue_fwd_cf(const void* y, const float* scale, const float* shift, int64_t B, int32_t E, int32_t C,
+                                   int32_t D, int32_t Hs, int32_t dtype, void* hidden, void* hidden_cf, void* pooled,
+                                   trs_stream_t stream) {
+  TRS_GLUE_COMMON("cin_glue_fwd_cf");
+  TRS_REQUIRE(glue_cf_ok(C, E), TRS_ESHAPE, "cin_glue_fwd_cf: needs E == 8 * (256 / (C / 8)) (E = %d, C = %d)", E, C);
+  if (B == 0) return TRS_OK;
+  TRS_REQUIRE(y && scale && shift && ((hidden && hidden_cf) || Hs == C) && (pooled || D == 0), TRS_EINVAL,
+              "cin_glue_fwd_cf: NULL pointer");
+  TRS_REQUIRE(aligned16(y) && aligned16(hidden) && aligned16(hidden_cf) && aligned16(pooled), TRS_EALIGN,
+              "cin_glue_fwd_cf: 16-byte alignment");
+  hipLaunchKernelGGL(glue_apply_fwd_cf_kernel, dim3(glue_grid(B)), dim3(GLUE_THREADS),
+                     (size_t)GLUE_THREADS * 8 * 4 + (size_t)(C - Hs) * (E + 8) * 2, (hipStream_t)stream, (const bf16_t*)y, scale, shift, B, E, C, D, Hs, (bf16_t*)hidden,
+                     (bf16_t*)hidden_cf, (bf16_t*)pooled);
+  return check_launch("cin_glue_fwd_cf");
+}
+
+extern "C" int trs_cin_glue_bwd_apply_cf(const void* y, const void* g_hidden, const void* g_pooled, const float* scale,
+                                         const float* shift, const float* mean, const float* invstd, const float* c1,
+                                         const float* c2, int64_t B, int32_t E, int32_t C, int32_t D, int32_t Hs,
+                                         int32_t dtype, void* gy, void* gy_cf, trs_stream_t stream) {
+  TRS_GLUE_COMMON("cin_glue_bwd_apply_cf");
+  TRS_REQUIRE(glue_cf_ok(C, E), TRS_ESHAPE, "cin_glue_bwd_apply_cf: needs E == 8 * (256 / (C / 8)) (E = %d, C = %d)", E,
+              C);
+  if (B == 0) return TRS_OK;
+  TRS_REQUIRE(y && scale && shift && mean && invstd && c1 && c2 && gy && gy_cf, TRS_EINVAL,
+              "cin_glue_bwd_apply_cf: NULL pointer");
+  TRS_REQUIRE(aligned16(y) && aligned16(g_hidden) && aligned16(g_pooled) && aligned16(gy) && aligned16(gy_cf), TRS_EALIGN,
+              "cin_glue_bwd_apply_cf: alignment");
+  hipLaunchKernelGGL(glue_bwd_apply_cf_kernel, dim3(glue_grid(B)), dim3(GLUE_THREADS), (size_t)C * (E + 8) * 2,
+                     (hipStream_t)stream,
+                     (const bf16_t*)y, (const bf16_t*)g_hidden, (const bf16_t*)g_pooled, scale, shift, mean, invstd, c1, c2,
+                     B, E, C, D, Hs, (bf16_t*)gy, (bf16_t*)gy_cf);
+  return check_launch("cin_glue_bwd_apply_cf");
 }

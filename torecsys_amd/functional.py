@@ -559,17 +559,27 @@ class _CINGlue(Function):
         shift = (b32 - mean * scale).contiguous()
         hidden = torch.empty(B, E, C - Hs, dtype=yT.dtype, device=dev)
         pooled = torch.empty(B, D, dtype=yT.dtype, device=dev)
-        call("trs_cin_glue_fwd", ptr(yT), ptr(scale), ptr(shift), B, E, C, D, Hs, value_dtype_code(yT), ptr(hidden),
-             ptr(pooled), stream_ptr())
+        cf = C > Hs and bool(size_query("trs_cin_glue_cf_supported", E, C))
+        if cf:
+            # also emit the hidden half channels-first (B, C-Hs, E): the next layer's weight-gradient kernel reads
+            # that layout (otherwise one transposing copy per layer and step); it rides on the returned tensor
+            hidden_cf = torch.empty(B, C - Hs, E, dtype=yT.dtype, device=dev)
+            call("trs_cin_glue_fwd_cf", ptr(yT), ptr(scale), ptr(shift), B, E, C, D, Hs, value_dtype_code(yT),
+                 ptr(hidden), ptr(hidden_cf), ptr(pooled), stream_ptr())
+        else:
+            hidden_cf = yT.new_empty(0)
+            call("trs_cin_glue_fwd", ptr(yT), ptr(scale), ptr(shift), B, E, C, D, Hs, value_dtype_code(yT), ptr(hidden),
+                 ptr(pooled), stream_ptr())
+        ctx.mark_non_differentiable(hidden_cf)
         ctx.save_for_backward(yT, scale, shift, mean.contiguous(), invstd.contiguous())
         ctx.meta = (use_batch, D, Hs, gamma is not None, beta is not None,
                     None if gamma is None else gamma.dtype)
         ctx.set_materialize_grads(False)
-        return hidden, pooled
+        return hidden, pooled, hidden_cf
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, g_hidden, g_pooled):
+    def backward(ctx, g_hidden, g_pooled, _g_cf=None):
         yT, scale, shift, mean, invstd = ctx.saved_tensors
         use_batch, D, Hs, has_gamma, has_beta, pdtype = ctx.meta
         B, E, C = yT.shape
@@ -590,8 +600,14 @@ class _CINGlue(Function):
             c1 = torch.zeros(C, dtype=torch.float32, device=dev)
             c2 = c1
         gy = torch.empty_like(yT)
-        call("trs_cin_glue_bwd_apply", ptr(yT), ptr(gh), ptr(gp), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(c1),
-             ptr(c2), B, E, C, D, Hs, value_dtype_code(yT), ptr(gy), stream_ptr())
+        if size_query("trs_cin_glue_cf_supported", E, C):
+            gy_cf = torch.empty(B, C, E, dtype=yT.dtype, device=dev)      # (B,C,E) copy for trs_cin_dw, see forward
+            call("trs_cin_glue_bwd_apply_cf", ptr(yT), ptr(gh), ptr(gp), ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
+                 ptr(c1), ptr(c2), B, E, C, D, Hs, value_dtype_code(yT), ptr(gy), ptr(gy_cf), stream_ptr())
+            gy._trs_cf = gy_cf
+        else:
+            call("trs_cin_glue_bwd_apply", ptr(yT), ptr(gh), ptr(gp), ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
+                 ptr(c1), ptr(c2), B, E, C, D, Hs, value_dtype_code(yT), ptr(gy), stream_ptr())
         ggamma = dgamma.to(pdtype) if has_gamma and ctx.needs_input_grad[1] else None
         gbeta = dbeta.to(pdtype) if has_beta and ctx.needs_input_grad[2] else None
         return gy, ggamma, gbeta, None, None, None, None, None, None, None
@@ -600,7 +616,7 @@ class _CINGlue(Function):
 def cin_glue(yT, bn: Optional[torch.nn.Module], D: int, Hs: int):
     """BatchNorm1d ``bn`` (or None) + ReLU + split + pooled sum on yT (B,E,C) bf16 -> (hidden (B,E,C-Hs), pooled (B,D))."""
     if bn is None:
-        return _CINGlue.apply(yT, None, None, None, None, False, None, None, D, Hs)
+        return _glue_out(_CINGlue.apply(yT, None, None, None, None, False, None, None, D, Hs))
     momentum = bn.momentum
     if bn.training and bn.track_running_stats:
         if bn.num_batches_tracked is not None:
@@ -608,9 +624,18 @@ def cin_glue(yT, bn: Optional[torch.nn.Module], D: int, Hs: int):
             if momentum is None:                              # cumulative moving average
                 momentum = 1.0 / float(bn.num_batches_tracked)
     use_running = (not bn.training) and bn.track_running_stats
-    return _CINGlue.apply(yT, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
-                          bn.running_var if bn.track_running_stats else None,
-                          bn.training or not use_running, momentum if momentum is not None else 0.0, bn.eps, D, Hs)
+    return _glue_out(_CINGlue.apply(yT, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
+                                    bn.running_var if bn.track_running_stats else None,
+                                    bn.training or not use_running, momentum if momentum is not None else 0.0, bn.eps,
+                                    D, Hs))
+
+
+def _glue_out(res):
+    """(hidden, pooled, hidden_cf) -> (hidden, pooled); the channels-first copy rides on ``hidden`` as ``_trs_cf``"""
+    hidden, pooled, hidden_cf = res
+    if hidden_cf.numel() > 0:
+        hidden._trs_cf = hidden_cf
+    return hidden, pooled
 
 
 # --------------------------------------------------------------------------------------------
@@ -1051,7 +1076,7 @@ def cin_cl_supported(x: torch.Tensor, out_channels: Sequence[int], hidden_sizes:
 
 class _CINContractCL(Function):
     @staticmethod
-    def forward(ctx, x0T, xkT, Wc, bias, N, H, x0_cf=None):
+    def forward(ctx, x0T, xkT, Wc, bias, N, H, x0_cf=None, xk_cf=None):
         require_device(x0T, xkT, Wc, bias)
         B, E, ld0 = x0T.shape
         ldk = xkT.stride(1)
@@ -1067,6 +1092,7 @@ class _CINContractCL(Function):
              ptr(ws), ws_bytes, stream_ptr())
         ctx.save_for_backward(x0T, xkT, w)
         ctx.x0_cf = x0_cf        # the caller's channels-first (B,N,E) input, if it has one (saves a transpose per layer)
+        ctx.xk_cf = xk_cf        # likewise the hidden state (B,H,E), emitted by the glue pass of the previous layer
         ctx.meta = (N, H, Wc.dtype, None if bias is None else bias.dtype)
         return yT
 
@@ -1078,6 +1104,7 @@ class _CINContractCL(Function):
         B, E, _ = x0T.shape
         C = w.shape[0]
         need_x0, need_xk, need_w, need_b = ctx.needs_input_grad[:4]
+        gy_cf = getattr(gyT, '_trs_cf', None)      # (B,C,E) copy emitted by the glue backward, if any
         gyT = gyT.contiguous()
         dev = x0T.device
         ld0, ldk = x0T.shape[2], xkT.stride(1)
@@ -1131,24 +1158,32 @@ class _CINContractCL(Function):
                 x0 = x0_cf
             else:
                 x0 = x0T[:, :, :N].transpose(1, 2).contiguous()      # channels-first copies: pixels contiguous
+            xk_cf = ctx.xk_cf
             if xkT.data_ptr() == x0T.data_ptr() and H == N:
                 xk = x0                                               # first layer: xk is x0
+            elif xk_cf is not None and tuple(xk_cf.shape) == (B, H, E) and xk_cf.is_contiguous():
+                xk = xk_cf
             else:
                 xk = xkT[:, :, :H].transpose(1, 2).contiguous()
-            gy = gyT.transpose(1, 2).contiguous()
+            if gy_cf is not None and tuple(gy_cf.shape) == (B, C, E) and gy_cf.is_contiguous():
+                gy = gy_cf
+            else:
+                gy = gyT.transpose(1, 2).contiguous()
             dW = torch.zeros(C, N * H, dtype=torch.float32, device=dev)
             ws_bytes = size_query("trs_cin_dw_workspace_bytes", B, N, H, C)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             call("trs_cin_dw", ptr(gy), ptr(x0), ptr(xk), B, N, H, C, E, _abi.TRS_BF16, ptr(dW), ptr(ws), ws_bytes,
                  stream_ptr())
         return (dx0T if need_x0 else None, dxkT if need_xk else None, (dW.to(wdt) if need_w else None), db, None, None,
-                None)
+                None, None)
 
 
 def cin_contract_cl(x0T: torch.Tensor, xkT: torch.Tensor, Wc: torch.Tensor, bias: Optional[torch.Tensor], N: int,
-                    H: int, x0_cf: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """channels-last CIN contraction on the matrix cores: x0T (B,E,ld0>=N, zero padded), xkT (B,E,>=H view)."""
-    return _CINContractCL.apply(x0T, xkT, Wc, bias, N, H, None if x0_cf is None else x0_cf.detach())
+                    H: int, x0_cf: Optional[torch.Tensor] = None, xk_cf: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """channels-last CIN contraction on the matrix cores: x0T (B,E,ld0>=N, zero padded), xkT (B,E,>=H view).
+    ``x0_cf`` / ``xk_cf``: channels-first copies (B,N,E) / (B,H,E) of the same values when the caller has them."""
+    return _CINContractCL.apply(x0T, xkT, Wc, bias, N, H, None if x0_cf is None else x0_cf.detach(),
+                                None if xk_cf is None else xk_cf.detach())
 
 
 # --------------------------------------------------------------------------------------------

@@ -470,7 +470,8 @@ class CompressInteractionNetworkLayer(BaseLayer):
             conv = seq.Conv1d
             C = conv.out_channels
             yT = F_.cin_contract_cl(x0T, hiddenT, conv.weight.squeeze(-1), conv.bias, N, H,
-                                    x0_cf=x0 if x0.is_contiguous() else None)                    # (B,E,C)
+                                    x0_cf=x0 if x0.is_contiguous() else None,
+                                    xk_cf=getattr(hiddenT, '_trs_cf', None))                     # (B,E,C)
             D, Hs = (C, 0) if self.is_direct else (C // 2, C // 2)
             rest = [(name, mod) for name, mod in seq.named_children() if name != 'Conv1d']
             names = [name for name, _ in rest]
