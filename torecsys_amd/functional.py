@@ -174,17 +174,6 @@ def prefetch_row_buckets(idx: torch.Tensor, offsets: Optional[torch.Tensor], V: 
         _bucket_cache.pop(0)
 
 
-_aux_streams = {}
-
-
-def aux_stream(dev: torch.device) -> torch.cuda.Stream:
-    """A second compute stream per device (not the row-bucket stream) for work that may overlap the main stream."""
-    st = _aux_streams.get(dev)
-    if st is None:
-        st = _aux_streams[dev] = torch.cuda.Stream(device=dev)
-    return st
-
-
 def clear_caches():
     _bucket_cache.clear()
 

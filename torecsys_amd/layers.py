@@ -501,7 +501,6 @@ class CompressInteractionNetworkLayer(BaseLayer):
 PAD_MULTIPLE = 128        # hidden widths are zero-padded to a multiple of this inside the GEMMs
 PAD_MIN_WIDTH = 192
 PAD_MIN_ROWS = 4096
-OVERLAP_FIRST_WGRAD = True   # _MLPStack: first layer's weight gradient on a second stream (overlaps the embedding backward)
 
 
 def _pad_width(width: int) -> int:
@@ -680,50 +679,19 @@ class _MLPStack(torch.autograd.Function):
             gbf = None
             if fuse:
                 g2, gbf = F_.relu_bwd_bias(g2, y)
-            S = rows // _LinearSplitK.SPLIT_ROWS
-            split = (need_w and S >= 4 and rows % S == 0 and 32 <= g2.shape[1] <= 1024 and 32 <= xin.shape[1] <= 4096
-                     and xin.is_contiguous())
-            # first layer of the stack: its weight gradient (compute-bound, the largest GEMM of the backward) does not
-            # feed anything downstream, while its input gradient is what the embedding backward (HBM-bound scatter)
-            # waits for -- run the weight gradient on a second stream so that the two overlap; the backward pass's
-            # final callback joins the streams
-            fork = OVERLAP_FIRST_WGRAD and l == 0 and need_x and split and rows >= PAD_MIN_ROWS
-            main = side = None
-            if fork:
-                main = F_._abi.current_stream_of(xin.device)
-                side = F_.aux_stream(xin.device)
-                ready = torch.cuda.Event()
-                ready.record(main)
             gx = (g2 @ W) if need_x else None
+            S = rows // _LinearSplitK.SPLIT_ROWS
             if need_w or (need_b and gbf is not None):
-                if split:
-                    if fork:
-                        side.wait_event(ready)
-                        torch.cuda.set_stream(side)
-                    try:
-                        part = torch.bmm(g2.view(S, rows // S, -1).transpose(1, 2), xin.view(S, rows // S, -1),
-                                         out_dtype=torch.float32)
-                        gw = torch.empty(out_f, in_f, dtype=wdt, device=xin.device)
-                        with_b = need_b and gbf is not None and out_f <= (in_f + 255) // 256 * 256
-                        gb = torch.empty(out_f, dtype=wdt, device=xin.device) if with_b else None
-                        F_.call("trs_wgrad_finish", F_.ptr(part), S, part.shape[1], part.shape[2], out_f, in_f,
-                                F_.value_dtype_code(gw), F_.ptr(gw), F_.ptr(gbf) if with_b else F_.ptr(None),
-                                F_.ptr(gb), F_.stream_ptr())
-                    finally:
-                        if fork:
-                            torch.cuda.set_stream(main)
-                    if fork:
-                        for t in (g2, xin, gbf):
-                            if t is not None:
-                                t.record_stream(side)
-                        for t in (gw, gb):
-                            if t is not None:
-                                t.record_stream(main)
-                        done = torch.cuda.Event()
-                        done.record(side)
-                        dev_index = xin.device.index
-                        torch.autograd.Variable._execution_engine.queue_callback(
-                            lambda: torch.cuda.current_stream(dev_index).wait_event(done))
+                if need_w and S >= 4 and rows % S == 0 and 32 <= g2.shape[1] <= 1024 and 32 <= xin.shape[1] <= 4096 \
+                        and xin.is_contiguous():
+                    part = torch.bmm(g2.view(S, rows // S, -1).transpose(1, 2), xin.view(S, rows // S, -1),
+                                     out_dtype=torch.float32)
+                    gw = torch.empty(out_f, in_f, dtype=wdt, device=xin.device)
+                    with_b = need_b and gbf is not None and out_f <= (in_f + 255) // 256 * 256
+                    gb = torch.empty(out_f, dtype=wdt, device=xin.device) if with_b else None
+                    F_.call("trs_wgrad_finish", F_.ptr(part), S, part.shape[1], part.shape[2], out_f, in_f,
+                            F_.value_dtype_code(gw), F_.ptr(gw), F_.ptr(gbf) if with_b else F_.ptr(None), F_.ptr(gb),
+                            F_.stream_ptr())
                     grads[4 * l] = gw
                     if with_b:
                         grads[4 * l + 1] = gb
