@@ -331,6 +331,8 @@ def main():
             step()
         _abi.kernel_times_ms(roof_kernel)      # drop the warm-up samples
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     phases[:] = [0.0, 0.0, 0.0, 0]
     dev_allocs0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
     # no cyclic-GC pass inside the timed region: a generation-2 collection over the imported torch modules takes
@@ -356,13 +358,14 @@ def main():
     enqueue_s = time.perf_counter() - t0
     span1.record()
     gc.enable()
-    if prof:
-        import pstats
-        pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(18)      # host time to enqueue K steps (== el when the host is the bound)
     torch.cuda.synchronize()
+    span1.synchronize()      # belt and braces: the region's last event has completed
     if world > 1:
         dist.barrier()
     el = time.perf_counter() - t0
+    if prof:
+        import pstats
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(18)
     if os.environ.get("TRS_BENCH_PHASES") and phases[3]:
         print("host ms/step  forward %.3f  prefetch %.3f  backward %.3f  (over the %d timed eager steps)" %
               tuple([1e3 * v / phases[3] for v in phases[:3]] + [phases[3]]), file=sys.stderr)
