@@ -288,6 +288,10 @@ int trs_rowdot_bwd(const void* g, const void* h, const void* w, int64_t rows, in
  * neither; needs out_rows <= 256 * ceil(out_cols / 256)).                                                          */
 int trs_wgrad_finish(const float* part, int32_t S, int32_t R, int32_t Cc, int32_t out_rows, int32_t out_cols,
                      int32_t dtype, void* gw, const float* gb_f32, void* gb, trs_stream_t stream);
+/* the same for partial products stored transposed, part (S, Cc, R) (slices of x^T g):
+ * gw[r, c] = sum_s part[s, c, r] for r < out_rows <= R, c < out_cols <= Cc.                                          */
+int trs_wgrad_finish_t(const float* part, int32_t S, int32_t Cc, int32_t R, int32_t out_rows, int32_t out_cols,
+                       int32_t dtype, void* gw, const float* gb_f32, void* gb, trs_stream_t stream);
 
 /* ---- CIN layer glue on channels-last activations y (B,E,C) bf16 ---------------------------------
  * BatchNorm1d + ReLU + chunk(2) + sum over E of the direct half, compress_interaction_network.py:137-181:

@@ -155,3 +155,47 @@ def test_wgrad_finish_rejects_bad_arguments(dev):
     with pytest.raises(RuntimeError):          # gb without gb_f32
         _abi.call("trs_wgrad_finish", _abi.ptr(part), 2, 8, 8, 8, 8, 0, _abi.ptr(gw), _abi.ptr(None), _abi.ptr(gw),
                   _abi.stream_ptr())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("S,Cc,R,out_rows,out_cols,with_bias", [
+    (16, 2496, 512, 400, 2496, True), (4, 96, 64, 64, 96, False), (5, 40, 128, 100, 33, True), (1, 300, 16, 16, 300, True)])
+def test_wgrad_finish_transposed_matches_torch(dev, dtype, S, Cc, R, out_rows, out_cols, with_bias):
+    """trs_wgrad_finish_t: part (S, Cc, R) holds slices of x^T g; gw = part.sum(0).t()[:out_rows, :out_cols]"""
+    from torecsys_amd import _abi
+    torch.manual_seed(S * R + Cc)
+    part = torch.randn(S, Cc, R, device=dev)
+    gbf = torch.randn(R, device=dev)
+    gw = torch.empty(out_rows, out_cols, dtype=dtype, device=dev)
+    gb = torch.empty(out_rows, dtype=dtype, device=dev) if with_bias else None
+    _abi.call("trs_wgrad_finish_t", _abi.ptr(part), S, Cc, R, out_rows, out_cols, _abi.value_dtype_code(gw),
+              _abi.ptr(gw), _abi.ptr(gbf) if with_bias else _abi.ptr(None), _abi.ptr(gb), _abi.stream_ptr())
+    ref = part.sum(0).t()[:out_rows, :out_cols]
+    tol = 1e-6 if dtype == torch.float32 else 8e-3
+    assert rel_err(gw.float().cpu(), ref.cpu()) <= tol
+    if with_bias:
+        assert torch.equal(gb.cpu(), gbf[:out_rows].to(dtype).cpu())
+
+
+def test_mlp_wide_first_layer_uses_transposed_split(dev):
+    """a 2496-wide first layer at 16 384 rows takes the x^T g split (trs_wgrad_finish_t) and still matches nn.Linear"""
+    from torecsys_amd import _abi
+    from torecsys_amd.layers import MultilayerPerceptionLayer
+    torch.manual_seed(11)
+    mlp = MultilayerPerceptionLayer(2496, 1, [400, 400]).to(dev).bfloat16()
+    ref = _plain(mlp)
+    x = (torch.randn(16384, 2496, device=dev) * 0.5).bfloat16()
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    ya, yb = mlp(xa).rename(None), ref(xb)
+    g = torch.randn_like(yb)
+    _abi.time_kernel("trs_wgrad_finish_t", True)
+    try:
+        ya.backward(g)
+        assert len(_abi.kernel_times_ms("trs_wgrad_finish_t")) == 1
+    finally:
+        _abi.time_kernel("trs_wgrad_finish_t", False)
+    yb.backward(g)
+    assert rel_err(xa.grad.float().cpu(), xb.grad.float().cpu()) <= 3e-2
+    for (n, pa), (_, pb) in zip(mlp.model.named_parameters(), ref.named_parameters()):
+        assert pa.grad.shape == pb.grad.shape
+        assert rel_err(pa.grad.float().cpu(), pb.grad.float().cpu()) <= 3e-2, n

@@ -250,6 +250,48 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restri
   gw[(size_t)r * out_cols + c] = from_f32<T>((a0 + a1) + (a2 + a3));
 }
 
+// The same finish for partial products stored TRANSPOSED, part (S, Cc, R) = slices of x^T g: for a wide input layer
+// (2496 x 512) hipBLASLt runs that orientation 1.5x faster than g^T x.  32 x 32 tiles through LDS so that both the
+// reads (along r) and the writes (along c) are coalesced.
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_finish_t_kernel(const float* __restrict__ part, int S, int Cc, int R,
+                                                            int out_rows, int out_cols, T* __restrict__ gw,
+                                                            const float* __restrict__ gbf, T* __restrict__ gb) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+  if ((int)blockIdx.y == (out_cols + 31) / 32) {                // the extra row of workgroups: bias gradient
+    const int r = blockIdx.x * 32 + tx;
+    if (gb != nullptr && ty == 0 && r < out_rows) gb[r] = from_f32<T>(gbf[r]);
+    return;
+  }
+  const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const size_t stride = (size_t)Cc * R;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (c < out_cols && r < out_rows) {
+      const float* p = part + (size_t)c * R + r;
+      float a0 = 0.f, a1 = 0.f;
+      int sidx = 0;
+      for (; sidx + 2 <= S; sidx += 2) {
+        a0 += p[(size_t)sidx * stride];
+        a1 += p[(size_t)(sidx + 1) * stride];
+      }
+      if (sidx < S) a0 += p[(size_t)sidx * stride];
+      acc[i] = a0 + a1;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) tile[ty + 8 * i][tx] = acc[i];     // tile[c - c0][r - r0]
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    if (r < out_rows && c < out_cols) gw[(size_t)r * out_cols + c] = from_f32<T>(tile[tx][ty + 8 * i]);
+  }
+}
+
 }  // namespace trs
 
 using namespace trs;
@@ -365,4 +407,22 @@ extern "C" int trs_wgrad_finish(const float* part, int32_t S, int32_t R, int32_t
     hipLaunchKernelGGL((wgrad_finish_kernel<bf16_t>), grid, dim3(256), 0, s, part, S, R, Cc, out_rows, out_cols,
                        (bf16_t*)gw, gb_f32, (bf16_t*)gb);
   return check_launch("wgrad_finish");
+}
+
+extern "C" int trs_wgrad_finish_t(const float* part, int32_t S, int32_t Cc, int32_t R, int32_t out_rows, int32_t out_cols,
+                                  int32_t dtype, void* gw, const float* gb_f32, void* gb, trs_stream_t stream) {
+  TRS_REQUIRE(S > 0 && R > 0 && Cc > 0 && out_rows > 0 && out_cols > 0 && out_rows <= R && out_cols <= Cc, TRS_EINVAL,
+              "wgrad_finish_t: bad size");
+  TRS_REQUIRE(part && gw, TRS_EINVAL, "wgrad_finish_t: NULL pointer");
+  TRS_REQUIRE((gb == nullptr) == (gb_f32 == nullptr), TRS_EINVAL, "wgrad_finish_t: gb and gb_f32 go together");
+  TRS_REQUIRE(dtype == TRS_F32 || dtype == TRS_BF16, TRS_EDTYPE, "wgrad_finish_t: dtype %d", dtype);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((out_rows + 31) / 32, (out_cols + 31) / 32 + 1);
+  if (dtype == TRS_F32)
+    hipLaunchKernelGGL((wgrad_finish_t_kernel<float>), grid, dim3(256), 0, s, part, S, Cc, R, out_rows, out_cols,
+                       (float*)gw, gb_f32, (float*)gb);
+  else
+    hipLaunchKernelGGL((wgrad_finish_t_kernel<bf16_t>), grid, dim3(256), 0, s, part, S, Cc, R, out_rows, out_cols,
+                       (bf16_t*)gw, gb_f32, (bf16_t*)gb);
+  return check_launch("wgrad_finish_t");
 }

@@ -617,6 +617,8 @@ class _MLPStack(torch.autograd.Function):
     ``spec``: per layer (fuse_relu, rowdot); ``tensors``: per layer weight, bias, w_use, b_use (the last two: the
     zero-padded copies the GEMMs read, or None)."""
 
+    SPLIT_ROWS_WIDE = 4096      # rows per split-K slice of a wide-input layer's weight gradient
+
     @staticmethod
     def forward(ctx, x, spec, *tensors):
         cur = x.reshape(-1, x.shape[-1])
@@ -684,14 +686,26 @@ class _MLPStack(torch.autograd.Function):
             if need_w or (need_b and gbf is not None):
                 if need_w and S >= 4 and rows % S == 0 and 32 <= g2.shape[1] <= 1024 and 32 <= xin.shape[1] <= 4096 \
                         and xin.is_contiguous():
-                    part = torch.bmm(g2.view(S, rows // S, -1).transpose(1, 2), xin.view(S, rows // S, -1),
-                                     out_dtype=torch.float32)
                     gw = torch.empty(out_f, in_f, dtype=wdt, device=xin.device)
-                    with_b = need_b and gbf is not None and out_f <= (in_f + 255) // 256 * 256
-                    gb = torch.empty(out_f, dtype=wdt, device=xin.device) if with_b else None
-                    F_.call("trs_wgrad_finish", F_.ptr(part), S, part.shape[1], part.shape[2], out_f, in_f,
-                            F_.value_dtype_code(gw), F_.ptr(gw), F_.ptr(gbf) if with_b else F_.ptr(None), F_.ptr(gb),
-                            F_.stream_ptr())
+                    St = rows // _MLPStack.SPLIT_ROWS_WIDE
+                    if xin.shape[1] >= 2 * g2.shape[1] and St >= 4 and rows % St == 0:
+                        # wide input (the 2496-wide first layer): slices of x^T g, 16 of them at 65 536 rows -- hipBLASLt
+                        # runs that orientation in 190 us against 282 us for 32 slices of g^T x (tools/wgrad_probe3.py)
+                        part = torch.bmm(xin.view(St, rows // St, -1).transpose(1, 2), g2.view(St, rows // St, -1),
+                                         out_dtype=torch.float32)
+                        with_b = need_b and gbf is not None
+                        gb = torch.empty(out_f, dtype=wdt, device=xin.device) if with_b else None
+                        F_.call("trs_wgrad_finish_t", F_.ptr(part), St, part.shape[1], part.shape[2], out_f, in_f,
+                                F_.value_dtype_code(gw), F_.ptr(gw), F_.ptr(gbf) if with_b else F_.ptr(None), F_.ptr(gb),
+                                F_.stream_ptr())
+                    else:
+                        part = torch.bmm(g2.view(S, rows // S, -1).transpose(1, 2), xin.view(S, rows // S, -1),
+                                         out_dtype=torch.float32)
+                        with_b = need_b and gbf is not None and out_f <= (in_f + 255) // 256 * 256
+                        gb = torch.empty(out_f, dtype=wdt, device=xin.device) if with_b else None
+                        F_.call("trs_wgrad_finish", F_.ptr(part), S, part.shape[1], part.shape[2], out_f, in_f,
+                                F_.value_dtype_code(gw), F_.ptr(gw), F_.ptr(gbf) if with_b else F_.ptr(None), F_.ptr(gb),
+                                F_.stream_ptr())
                     grads[4 * l] = gw
                     if with_b:
                         grads[4 * l + 1] = gb
