@@ -537,6 +537,16 @@ class _PaddedLinear:
         return st.w, st.b
 
 
+def _split_count(rows: int, slice_rows: int, max_slices: int = 384) -> int:
+    """Number of split-K slices of a weight gradient over ``rows``: slices of ``slice_rows`` rows, but no more than
+    ``max_slices`` of them (at 2.5 M rows -- DCN's per-field MLP -- 1 248 slices of 2 048 rows write and re-read 1.3 GB
+    of fp32 partials per layer and run no faster than 312-384 slices: tools/wgrad_probe4.py); 0 = do not split."""
+    s = min(rows // slice_rows, max_slices)
+    while s >= 4 and rows % s:
+        s -= 1
+    return s if s >= 4 else 0
+
+
 class _LinearSplitK(torch.autograd.Function):
     """``F.linear`` (+ optional ReLU) for the MLP stack on the HIP device, plain PyTorch / hipBLASLt GEMMs arranged
     for this shape class (tens of thousands of rows against a few hundred features):
@@ -586,7 +596,7 @@ class _LinearSplitK(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = (g2 @ W).reshape(x.shape)
         if ctx.needs_input_grad[1]:
-            rows, S = g2.shape[0], g2.shape[0] // _LinearSplitK.SPLIT_ROWS
+            rows, S = g2.shape[0], _split_count(g2.shape[0], _LinearSplitK.SPLIT_ROWS)
             if S >= 4 and rows % S == 0 and 32 <= g2.shape[1] <= 1024 and 32 <= x2.shape[1] <= 1024 \
                     and g2.is_contiguous() and x2.is_contiguous():
                 part = torch.bmm(g2.view(S, rows // S, -1).transpose(1, 2), x2.view(S, rows // S, -1),
@@ -682,13 +692,13 @@ class _MLPStack(torch.autograd.Function):
             if fuse:
                 g2, gbf = F_.relu_bwd_bias(g2, y)
             gx = (g2 @ W) if need_x else None
-            S = rows // _LinearSplitK.SPLIT_ROWS
+            S = _split_count(rows, _LinearSplitK.SPLIT_ROWS)
             if need_w or (need_b and gbf is not None):
                 if need_w and S >= 4 and rows % S == 0 and 32 <= g2.shape[1] <= 1024 and 32 <= xin.shape[1] <= 4096 \
                         and xin.is_contiguous():
                     gw = torch.empty(out_f, in_f, dtype=wdt, device=xin.device)
-                    St = rows // _MLPStack.SPLIT_ROWS_WIDE
-                    if xin.shape[1] >= 2 * g2.shape[1] and St >= 4 and rows % St == 0:
+                    St = _split_count(rows, _MLPStack.SPLIT_ROWS_WIDE)
+                    if xin.shape[1] >= 2 * g2.shape[1] and St >= 4:
                         # wide input (the 2496-wide first layer): slices of x^T g, 16 of them at 65 536 rows -- hipBLASLt
                         # runs that orientation in 190 us against 282 us for 32 slices of g^T x (tools/wgrad_probe3.py)
                         part = torch.bmm(xin.view(St, rows // St, -1).transpose(1, 2), g2.view(St, rows // St, -1),
