@@ -392,3 +392,25 @@ def test_very_hot_rows_are_chunked(dev, dtype, tol, fuse):
     er = O.multi_indices_embedding(wr, idx, off)
     ((O.fm_layer(er) * gy).sum() + (er * ge).sum()).backward()
     assert rel_err(m.embedding.weight.grad.float().cpu(), wr.grad) <= tol
+
+
+def test_out_of_range_lookup_is_sanitised_and_reported_lazily(dev):
+    """without TRS_CHECK_INDICES the kernels still range-check: an out-of-range lookup reads as a zero row, gets no
+    gradient, and functional.index_errors_seen() reports it afterwards (no host read-back inside the lookup)"""
+    from torecsys_amd import functional as F_
+    from torecsys_amd.inputs import MultiIndicesEmbedding
+    if F_.CHECK_INDICES:
+        pytest.skip("TRS_CHECK_INDICES=1 raises at the call instead")
+    torch.manual_seed(0)
+    emb = MultiIndicesEmbedding(embed_size=16, field_sizes=[5, 7, 11]).to(dev)
+    F_.index_errors_seen()                                  # clear
+    idx = torch.tensor([[1, 2, 3], [4, 6, 10]], device=dev)
+    out = emb(idx).rename(None)
+    assert not F_.index_errors_seen()
+    bad = torch.tensor([[1, 2, 3], [4, 6, 11]], device=dev)  # field 2 has 11 rows: 11 + offset 12 = 23 = V -> outside
+    out_bad = emb(bad).rename(None)
+    assert torch.equal(out_bad[0], out[0]) and torch.equal(out_bad[1, :2], out[1, :2])
+    assert torch.count_nonzero(out_bad[1, 2]) == 0
+    out_bad.sum().backward()
+    assert torch.isfinite(emb.embedding.weight.grad).all()
+    assert F_.index_errors_seen() and not F_.index_errors_seen()

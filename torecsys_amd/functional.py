@@ -30,13 +30,41 @@ def _as_index(idx: torch.Tensor) -> torch.Tensor:
     return idx.contiguous()
 
 
+_lazy_flags = {}          # device -> persistent int32[1]: "some lookup was out of range" (never read unless asked)
+
+
 class _ErrFlag:
+    """Out-of-range flag of one lookup.  The kernels range-check every row id when they are handed a flag (an
+    out-of-range lookup then reads as a zero row and contributes no gradient instead of touching foreign memory).
+    With TRS_CHECK_INDICES=1 the flag is private to the call and read back at once (IndexError, like nn.Embedding);
+    otherwise the calls share one persistent flag per device that nobody waits for -- ``index_errors_seen()`` reads it."""
+
     def __init__(self, dev):
-        self.t = torch.zeros(1, dtype=torch.int32, device=dev) if CHECK_INDICES else None
+        if CHECK_INDICES:
+            self.t, self.lazy = torch.zeros(1, dtype=torch.int32, device=dev), False
+        else:
+            t = _lazy_flags.get(dev)
+            if t is None:
+                t = _lazy_flags[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.t, self.lazy = t, True
 
     def check(self, what):
-        if self.t is not None and int(self.t.item()) != 0:
+        if not self.lazy and int(self.t.item()) != 0:
             raise IndexError(f"{what}: index out of range in self")
+
+
+def index_errors_seen(device=None, reset: bool = True) -> bool:
+    """True when a lookup since the last call had a row id outside its table (synchronises).  Only meaningful without
+    TRS_CHECK_INDICES=1 (which raises at the offending call instead)."""
+    seen = False
+    for dev, t in list(_lazy_flags.items()):
+        if device is not None and torch.device(device) != dev:
+            continue
+        if int(t.item()) != 0:
+            seen = True
+            if reset:
+                t.zero_()
+    return seen
 
 
 # --------------------------------------------------------------------------------------------
