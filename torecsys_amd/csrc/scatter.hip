@@ -442,8 +442,16 @@ __global__ __launch_bounds__(256) void scatter_rows_group_kernel(
   constexpr int VE = Vec16<T>::VE;
   const int lane_v = threadIdx.x & (L - 1);
   const int64_t groups = ((int64_t)gridDim.x * blockDim.x) >> LOG2L;
-  for (int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> LOG2L; r < V; r += groups) {
-    const int beg = row_start[r], end = row_start[r + 1];
+  int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> LOG2L;
+  int nbeg = 0, nend = 0;
+  if (r < V) { nbeg = row_start[r]; nend = row_start[r + 1]; }
+  for (; r < V; r += groups) {
+    const int beg = nbeg, end = nend;
+    // the bucket bounds of the NEXT row and this row's table values (FM term) are requested before the dependent
+    // perm -> gradient-row chain of this bucket starts, so their latency hides behind it
+    if (r + groups < V) { nbeg = row_start[r + groups]; nend = row_start[r + groups + 1]; }
+    uint4 wraw = make_uint4(0, 0, 0, 0);
+    if (HAS_FM && fm_sum != nullptr) wraw = table[r * L + lane_v];
     float acc[VE], gsum[VE];
 #pragma unroll
     for (int k = 0; k < VE; ++k) { acc[k] = 0.f; gsum[k] = 0.f; }
@@ -462,7 +470,7 @@ __global__ __launch_bounds__(256) void scatter_rows_group_kernel(
       accumulate_bucket<T, LOG2L, HAS_G, HAS_FM>(acc, gsum, g_rows, g_fm, fm_sum, perm, beg, end, 1, N, gbs, lane_v);
       if (HAS_FM && fm_sum != nullptr && end > beg) {
         float w[VE];
-        Vec16<T>::unpack(table[r * L + lane_v], w);
+        Vec16<T>::unpack(wraw, w);
 #pragma unroll
         for (int k = 0; k < VE; ++k) acc[k] = fmaf(-w[k], gsum[k], acc[k]);
       }
