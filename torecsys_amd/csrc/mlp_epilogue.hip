@@ -123,16 +123,43 @@ __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const uint4* __restrict
       raw[u] = make_uint4(0, 0, 0, 0);
       if (r < rows) raw[u] = h[r * lpr + v];
     }
+    float acc[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int64_t r = r0 + u * step;
       float x[VE];
       Vec16<T>::unpack(raw[u], x);
-      float acc = 0.f;
+      acc[u] = 0.f;
 #pragma unroll
-      for (int k = 0; k < VE; ++k) acc = fmaf(x[k], wv[k], acc);
-      for (int o = lpr >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);          // lpr is a power of two <= 64
-      if (v == 0 && r < rows) out[r] = from_f32<T>(acc + b0);
+      for (int k = 0; k < VE; ++k) acc[u] = fmaf(x[k], wv[k], acc[u]);
+    }
+    if (lpr >= 4) {
+      // reduce the U = 4 row sums together: two exchange steps leave each lane with ONE row's partial (row index =
+      // two bits of v), the remaining log2(lpr) - 2 steps run on a single value: lpr-lane sums of 4 rows in
+      // log2(lpr) + 1 shuffles instead of 4 log2(lpr)
+      const int h1 = lpr >> 1, h2 = lpr >> 2;
+      const bool up1 = (v & h1) != 0, up2 = (v & h2) != 0;
+      // step 1 (distance lpr/2): lower half keeps rows 0,1, upper half rows 2,3
+      const float s0 = up1 ? acc[0] : acc[2], s1 = up1 ? acc[1] : acc[3];
+      float k0 = (up1 ? acc[2] : acc[0]) + __shfl_xor(s0, h1, 64);
+      float k1 = (up1 ? acc[3] : acc[1]) + __shfl_xor(s1, h1, 64);
+      // step 2 (distance lpr/4): keep one of the two
+      const float s2 = up2 ? k0 : k1;
+      float k = (up2 ? k1 : k0) + __shfl_xor(s2, h2, 64);
+      for (int o = lpr >> 3; o > 0; o >>= 1) k += __shfl_xor(k, o, 64);
+      // the lanes with the low log2(lpr)-2 bits of v clear hold row u = 2*up1 + up2
+      if ((v & (h2 - 1)) == 0) {
+        const int u = (up1 ? 2 : 0) + (up2 ? 1 : 0);
+        const int64_t r = r0 + u * step;
+        if (r < rows) out[r] = from_f32<T>(k + b0);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t r = r0 + u * step;
+        float a = acc[u];
+        for (int o = lpr >> 1; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        if (v == 0 && r < rows) out[r] = from_f32<T>(a + b0);
+      }
     }
   }
 }
@@ -212,6 +239,10 @@ __global__ void rowdot_accumulate_kernel(const float* __restrict__ tmp, int C, f
   else if (c == C) gb[0] += tmp[C];
 }
 
+static int rowdot_fwd_blocks(int64_t rows, int lpr) {      // no partial buffer to bound the forward's grid
+  const int rpp = 256 / lpr;
+  return (int)std::min<int64_t>((rows + (int64_t)rpp * 4 - 1) / ((int64_t)rpp * 4), 8192);
+}
 static int rowdot_blocks(int64_t rows, int lpr) {
   const int rpp = 256 / lpr;
   return (int)std::min<int64_t>((rows + rpp - 1) / rpp, 1023);
@@ -310,10 +341,10 @@ extern "C" int trs_rowdot_fwd(const void* h, const void* w, const void* bias, in
   const int lpr = C / (dtype == TRS_F32 ? 4 : 8);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == TRS_F32)
-    hipLaunchKernelGGL((rowdot_fwd_kernel<float>), dim3(rowdot_blocks(rows, lpr)), dim3(256), 0, s, (const uint4*)h,
+    hipLaunchKernelGGL((rowdot_fwd_kernel<float>), dim3(rowdot_fwd_blocks(rows, lpr)), dim3(256), 0, s, (const uint4*)h,
                        (const uint4*)w, (const float*)bias, rows, lpr, (float*)out);
   else
-    hipLaunchKernelGGL((rowdot_fwd_kernel<bf16_t>), dim3(rowdot_blocks(rows, lpr)), dim3(256), 0, s, (const uint4*)h,
+    hipLaunchKernelGGL((rowdot_fwd_kernel<bf16_t>), dim3(rowdot_fwd_blocks(rows, lpr)), dim3(256), 0, s, (const uint4*)h,
                        (const uint4*)w, (const bf16_t*)bias, rows, lpr, (bf16_t*)out);
   return check_launch("rowdot_fwd");
 }
