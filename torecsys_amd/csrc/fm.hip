@@ -4,8 +4,11 @@
 // of L adjacent lanes owns one sample and walks its N fields, so every lane keeps the running
 // sum / sum-of-squares of its own VE columns in registers -- no cross-lane traffic, no LDS.  A wave
 // therefore covers 64/L samples per instruction and each row read is one full 16*L-byte segment
-// (128 B = one cache line for bf16 E=64).  Rows are fetched CH at a time so CH independent
-// 16-byte loads per lane are in flight (HBM latency ~1 us on a random row).
+// (128 B = one cache line for bf16 E=64).  Rows are fetched CH = 4 at a time (4 independent 16-byte loads per lane
+// in flight; HBM latency ~1 us on a random row): 60 VGPRs, 8 waves per SIMD, so the 2048 workgroups of the
+// B = 65 536 launch are all resident at once.  CH = 8 needed 83 VGPRs (5 waves per SIMD: the grid then ran as one
+// full round plus a 60 % one) and was 8 % slower inside the training step (142 -> 130 us) although each wave had
+// twice the loads in flight.
 // HBM-bound: algorithmic bytes per sample = N*(idx 8 + E*s) read, E*s (+N*E*s with the block) written.
 #include "trs_common.hpp"
 
@@ -19,7 +22,7 @@ __global__ __launch_bounds__(256) void embed_fm_group_kernel(
     const T* __restrict__ first_table, T* __restrict__ first, int32_t* __restrict__ err_flag) {
   constexpr int L = 1 << LOG2L;
   constexpr int VE = Vec16<T>::VE;
-  constexpr int CH = 8;
+  constexpr int CH = 4;
   const int lane_v = threadIdx.x & (L - 1);
   const int64_t groups = ((int64_t)gridDim.x * blockDim.x) >> LOG2L;
   for (int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> LOG2L; b < B; b += groups) {

@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void scatter_rows_group_kernel(
       continue;
     }
     if (r != padding_row) {
-      accumulate_bucket<T, LOG2L, HAS_G, HAS_FM>(acc, gsum, g_rows, g_fm, fm_sum, perm, beg, end, 1, N, gbs, lane_v);
+      accumulate_bucket<T, LOG2L, HAS_G, HAS_FM, (HAS_FM ? 2 : 4)>(acc, gsum, g_rows, g_fm, fm_sum, perm, beg, end, 1, N, gbs, lane_v);
       if (HAS_FM && fm_sum != nullptr && end > beg) {
         float w[VE];
         Vec16<T>::unpack(wraw, w);
