@@ -8,7 +8,7 @@ straight from the N tables.  ``EmbeddingFM`` = ``MultiIndicesEmbedding`` + ``Fac
 """
 from __future__ import annotations
 
-from typing import List, Optional
+from typing import List
 
 import torch
 import torch.nn as nn
