@@ -101,8 +101,9 @@ __global__ __launch_bounds__(256) void embed_fm_elem_kernel(
     const T* __restrict__ first_table, T* __restrict__ first, int32_t* __restrict__ err_flag) {
   const int64_t total = B * E;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const bool f32 = total < ((int64_t)1 << 32);
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-    const int64_t b = t / E;
+    const int64_t b = udiv_fast(t, E, f32);
     const int e = (int)(t - b * E);
     float s = 0.f, q = 0.f, f1 = 0.f;
     for (int n = 0; n < N; ++n) {
@@ -173,17 +174,19 @@ __global__ __launch_bounds__(256) void fm_bwd_vec_kernel(const uint4* __restrict
                                                          int64_t total_vecs, int N, int vpr) {
   constexpr int VE = Vec16<T>::VE;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  const int64_t per_b = (int64_t)N * vpr;
+  const int per_b = N * vpr;
+  const bool f32 = total_vecs < ((int64_t)1 << 32);
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total_vecs; t += stride) {
-    const int64_t b = t / per_b;
-    const int lv = (int)(t % vpr);
+    const int64_t b = udiv_fast(t, per_b, f32);
+    const int64_t row = udiv_fast(t, vpr, f32);
+    const int lv = (int)(t - row * vpr);
     float xv[VE], gv[VE], o[VE];
     Vec16<T>::unpack(x[t], xv);
     Vec16<T>::unpack(g[b * vpr + lv], gv);
     const float* sp = fm_sum + (b * vpr + lv) * VE;
 #pragma unroll
     for (int k = 0; k < VE; ++k) o[k] = gv[k] * (sp[k] - xv[k]);
-    dx[t] = Vec16<T>::pack(o);
+    store_stream(&dx[t], Vec16<T>::pack(o));
   }
 }
 template <typename T>
@@ -227,8 +230,9 @@ __global__ __launch_bounds__(256) void permute_grad_vec_kernel(const uint4* __re
                                                                uint4* __restrict__ out, int64_t K, int N, int vpr) {
   constexpr int VE = Vec16<T>::VE;
   const int64_t total = K * vpr, stride = (int64_t)gridDim.x * blockDim.x;
+  const bool f32 = total < ((int64_t)1 << 32);
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-    const int64_t k = t / vpr;
+    const int64_t k = udiv_fast(t, vpr, f32);
     const int lv = (int)(t - k * vpr);
     const int64_t p = pos[k];
     float o[VE];
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(256) void permute_grad_vec_kernel(const uint4* __re
     for (int i = 0; i < VE; ++i) o[i] = 0.f;
     if (g_block != nullptr) Vec16<T>::unpack(g_block[p * vpr + lv], o);
     if (g_fm != nullptr) {
-      const int64_t b = p / N;
+      const int64_t b = (int64_t)((unsigned)p / (unsigned)N);       // pos is int32
       float gf[VE], xv[VE];
       Vec16<T>::unpack(g_fm[b * vpr + lv], gf);
       Vec16<T>::unpack(x[p * vpr + lv], xv);
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(256) void permute_grad_vec_kernel(const uint4* __re
 #pragma unroll
       for (int i = 0; i < VE; ++i) o[i] = fmaf(gf[i], sp[i] - xv[i], o[i]);
     }
-    out[t] = Vec16<T>::pack(o);
+    store_stream(&out[t], Vec16<T>::pack(o));
   }
 }
 template <typename T>

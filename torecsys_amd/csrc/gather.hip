@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void gather_rows_vec_kernel(
           p = t / vpr;
           lane_v = (int)(t - p * vpr);
         }
-        const int n = (int)(p % N);
+        // flat positions fit 32 bits (checked by trs_gather_rows): a 32-bit remainder instead of the emulated 64-bit one
+        const int n = (int)((unsigned)p % (unsigned)N);
         const int64_t r = load_row_id(idx, offsets, p, n);
         if (err_flag != nullptr && (r < 0 || r >= V)) {
           *err_flag = 1;
@@ -58,7 +59,12 @@ __global__ __launch_bounds__(256) void gather_rows_vec_kernel(
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const int64_t t = t0 + u * stride;
-      if (ok[u]) out[t] = v[u];
+      if (ok[u]) {
+        // streaming store: the gathered block is consumed by a later kernel, keep L2 for the table rows
+        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+        const u32x4 w = {v[u].x, v[u].y, v[u].z, v[u].w};
+        __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(&out[t]));
+      }
     }
   }
 }
@@ -69,10 +75,11 @@ __global__ __launch_bounds__(256) void gather_rows_elem_kernel(
     const T* __restrict__ table, const IdxT* __restrict__ idx, const int64_t* __restrict__ offsets,
     T* __restrict__ out, int64_t total, int E, int N, int64_t V, int32_t* __restrict__ err_flag) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const bool f32 = total < ((int64_t)1 << 32);
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-    const int64_t p = t / E;
+    const int64_t p = udiv_fast(t, E, f32);
     const int e = (int)(t - p * E);
-    const int n = (int)(p % N);
+    const int n = (int)(p - udiv_fast(p, N, f32) * N);
     const int64_t r = load_row_id(idx, offsets, p, n);
     if (err_flag != nullptr && (r < 0 || r >= V)) {
       *err_flag = 1;
@@ -134,24 +141,25 @@ __global__ __launch_bounds__(256) void fa_gather_vec_kernel(
     const uint4* const* __restrict__ tables, const IdxT* __restrict__ idx, const int64_t* __restrict__ offsets,
     uint4* __restrict__ out, int64_t B, int N, int vpr, int64_t V, int32_t* __restrict__ err_flag) {
   // one item = (b, i, j, vec); consecutive threads walk vec, then j, then i: writes are contiguous.
-  const int64_t per_b = (int64_t)N * N * vpr;
+  const int per_b = N * N * vpr;
   const int64_t total = B * per_b;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const bool f32 = total < ((int64_t)1 << 32);
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-    const int64_t b = t / per_b;
-    int rem = (int)(t - b * per_b);
-    const int i = rem / (N * vpr);
+    const int64_t b = udiv_fast(t, per_b, f32);
+    unsigned rem = (unsigned)(t - b * per_b);
+    const unsigned i = rem / (unsigned)(N * vpr);
     rem -= i * N * vpr;
-    const int j = rem / vpr;
-    const int lv = rem - j * vpr;
-    const int64_t r = load_row_id(idx, offsets, b * N + j, j);
+    const unsigned j = rem / (unsigned)vpr;
+    const int lv = (int)(rem - j * vpr);
+    const int64_t r = load_row_id(idx, offsets, b * N + j, (int)j);
     uint4 v = make_uint4(0, 0, 0, 0);
     if (err_flag != nullptr && (r < 0 || r >= V)) {
       *err_flag = 1;
     } else {
       v = tables[i][r * vpr + lv];
     }
-    out[t] = v;
+    store_stream(&out[t], v);      // 12.8 GB at B = 65 536, N = 39: never re-read by this kernel
   }
 }
 
@@ -186,12 +194,13 @@ __global__ __launch_bounds__(256) void permute_rows_vec_kernel(const uint4* __re
                                                                uint4* __restrict__ out, int64_t K, int vpr) {
   const int64_t total = K * vpr;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const bool f32 = total < ((int64_t)1 << 32);
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-    const int64_t k = t / vpr;
+    const int64_t k = udiv_fast(t, vpr, f32);
     const int lv = (int)(t - k * vpr);
     const int64_t p = pos[k];
-    if (SCATTER) out[p * vpr + lv] = rows[t];
-    else out[t] = rows[p * vpr + lv];
+    if (SCATTER) store_stream(&out[p * vpr + lv], rows[t]);
+    else store_stream(&out[t], rows[p * vpr + lv]);
   }
 }
 template <typename T, bool SCATTER>
@@ -332,7 +341,8 @@ extern "C" int trs_gather_rows(const void* table, int64_t V, int32_t E, int32_t 
               (long long)V, E, (long long)B, N);
   TRS_REQUIRE(dtype == TRS_F32 || dtype == TRS_BF16, TRS_EDTYPE, "gather_rows: dtype %d", dtype);
   TRS_REQUIRE(idx_dtype == TRS_I64 || idx_dtype == TRS_I32, TRS_EDTYPE, "gather_rows: idx dtype %d", idx_dtype);
-  if (B == 0) return TRS_OK;
+  TRS_REQUIRE(B * (int64_t)N < ((int64_t)1 << 32), TRS_ESHAPE, "gather_rows: B*N = %lld lookups must fit 32 bits",
+              (long long)(B * (int64_t)N));
   hipStream_t s = (hipStream_t)stream;
   if (idx_dtype == TRS_I64)
     return gather_dispatch<int64_t>(table, V, E, dtype, (const int64_t*)idx, offsets, B * N, N, out, err_flag, s);

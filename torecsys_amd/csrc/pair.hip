@@ -519,14 +519,15 @@ template <typename T, typename UNIT>
 __global__ __launch_bounds__(256) void ffm_fwd_kernel(const UNIT* __restrict__ x, UNIT* __restrict__ out, int64_t B,
                                                       int N, int upr /* units per row */) {
   const int P = N * (N - 1) / 2;
-  const int64_t per_b = (int64_t)N * N * upr;
+  const int per_b = N * N * upr;
   const int64_t total = B * per_b, stride = (int64_t)gridDim.x * blockDim.x;
+  const bool f32 = total < ((int64_t)1 << 32);
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-    const int64_t b = t / per_b;
-    int rem = (int)(t - b * per_b);
-    const int i = rem / (N * upr);
+    const int64_t b = udiv_fast(t, per_b, f32);
+    unsigned rem = (unsigned)(t - b * per_b);
+    const int i = (int)(rem / (unsigned)(N * upr));
     rem -= i * N * upr;
-    const int j = rem / upr, lv = rem - j * upr;
+    const int j = (int)(rem / (unsigned)upr), lv = (int)rem - j * upr;
     if (i < j) {
       const UNIT a = x[(b * N * N + (int64_t)i * N + j) * upr + lv];
       const UNIT c = x[(b * N * N + (int64_t)j * N + i) * upr + lv];
@@ -539,14 +540,15 @@ template <typename T, typename UNIT>
 __global__ __launch_bounds__(256) void ffm_bwd_kernel(const UNIT* __restrict__ x, const UNIT* __restrict__ g,
                                                       UNIT* __restrict__ dx, int64_t B, int N, int upr) {
   const int P = N * (N - 1) / 2;
-  const int64_t per_b = (int64_t)N * N * upr;
+  const int per_b = N * N * upr;
   const int64_t total = B * per_b, stride = (int64_t)gridDim.x * blockDim.x;
+  const bool f32 = total < ((int64_t)1 << 32);
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-    const int64_t b = t / per_b;
-    int rem = (int)(t - b * per_b);
-    const int i = rem / (N * upr);
+    const int64_t b = udiv_fast(t, per_b, f32);
+    unsigned rem = (unsigned)(t - b * per_b);
+    const int i = (int)(rem / (unsigned)(N * upr));
     rem -= i * N * upr;
-    const int j = rem / upr, lv = rem - j * upr;
+    const int j = (int)(rem / (unsigned)upr), lv = (int)rem - j * upr;
     UNIT r = zero_unit<UNIT>();
     if (i != j) {
       const int p = i < j ? pair_index(i, j, N) : pair_index(j, i, N);

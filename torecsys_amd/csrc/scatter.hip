@@ -622,8 +622,9 @@ __global__ __launch_bounds__(256) void scatter_rows_elem_kernel(
     RowSink sink) {
   const int64_t total = V * E;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const bool f32 = total < ((int64_t)1 << 32);
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-    const int64_t r = t / E;
+    const int64_t r = udiv_fast(t, E, f32);
     const int e = (int)(t - r * E);
     float acc = 0.f, gsum = 0.f;
     bool touched = false;

@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256) void bucket_count_kernel(const IdxT* __restric
   __syncthreads();
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < BN; p += stride) {
-    const int64_t r = load_row_id(idx, offsets, p, (int)(p % N));
+    const int64_t r = load_row_id(idx, offsets, p, (int)((uint64_t)p < ((uint64_t)1 << 32) ? (unsigned)p % (unsigned)N : p % N));
     int w = (int)(r / per);
     w = w < 0 ? 0 : (w >= W ? W - 1 : w);
     atomicAdd(&hist[w], 1);
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void bucket_fill_kernel(const IdxT* __restrict
   for (int w = threadIdx.x; w < W; w += blockDim.x) hist[w] = 0;
   __syncthreads();
   for (int64_t p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
-    const int64_t r = load_row_id(idx, offsets, p, (int)(p % N));
+    const int64_t r = load_row_id(idx, offsets, p, (int)((uint64_t)p < ((uint64_t)1 << 32) ? (unsigned)p % (unsigned)N : p % N));
     int w = (int)(r / per);
     w = w < 0 ? 0 : (w >= W ? W - 1 : w);
     atomicAdd(&hist[w], 1);
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void bucket_fill_kernel(const IdxT* __restrict
   for (int w = threadIdx.x; w < W; w += blockDim.x) hist[w] = 0;
   __syncthreads();
   for (int64_t p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
-    const int64_t r = load_row_id(idx, offsets, p, (int)(p % N));
+    const int64_t r = load_row_id(idx, offsets, p, (int)((uint64_t)p < ((uint64_t)1 << 32) ? (unsigned)p % (unsigned)N : p % N));
     int w = (int)(r / per);
     w = w < 0 ? 0 : (w >= W ? W - 1 : w);
     const long long slot = base[w] + atomicAdd(&hist[w], 1);

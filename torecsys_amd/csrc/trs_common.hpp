@@ -138,4 +138,17 @@ inline int stream_grid(int64_t work_items, int block, int max_blocks = 256 * 16)
   return (int)g;
 }
 
+// Flat element counters are int64 in the kernels' loops, but almost always fit 32 bits: a runtime-divisor 64-bit
+// division is ~80 emulated instructions per element, the 32-bit one a float reciprocal + fix-up.  ``fits32`` is uniform
+// over the launch (total element count < 2^32).
+__device__ __forceinline__ int64_t udiv_fast(int64_t a, int d, bool fits32) {
+  return fits32 ? (int64_t)((unsigned)a / (unsigned)d) : a / d;
+}
+// 16-byte streaming store: the destination is consumed by a later kernel, keep L2 for data that is re-read
+__device__ __forceinline__ void store_stream(uint4* dst, const uint4& v) {
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  const u32x4 w = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(dst));
+}
+
 }  // namespace trs
