@@ -296,7 +296,9 @@ __device__ __forceinline__ void sink_vec(const RowSink& k, uint4* __restrict__ o
                                          bool touched) {
   constexpr int VE = Vec16<T>::VE;
   if (k.mode == 0) {
-    out[vec] = Vec16<T>::pack(acc);
+    // dense gradient table: written once, read by the optimizer much later -- stream it past L2 (which the [g*S | g]
+    // rows of the FM term want to keep)
+    store_stream(&out[vec], Vec16<T>::pack(acc));
     return;
   }
   if (!touched) return;
