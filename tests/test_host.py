@@ -137,3 +137,24 @@ def test_patch_rebinds_reference_aliases():
     finally:
         for m in (pkg, lay, mdl, inp):
             sys.modules.pop(m.__name__, None)
+
+
+def test_split_count_rules():
+    """split-K slice count of the MLP weight gradients (layers._split_count): divides the rows, at least 4 slices of
+    at least ``slice_rows`` rows, never more than 384"""
+    from torecsys_amd.layers import _split_count
+    assert _split_count(65536, 2048) == 32 and _split_count(65536, 4096) == 16
+    assert _split_count(16384, 2048) == 8 and _split_count(8192, 2048) == 4
+    assert _split_count(4096, 2048) == 0                     # fewer than 4 slices: do not split
+    for rows in (65536 * 39, 8192 * 39, 65536 * 39 // 3, 3 * 2 ** 20):
+        s = _split_count(rows, 2048)
+        assert 4 <= s <= 384 and rows % s == 0 and rows // s >= 2048
+    assert _split_count(1000003, 2048) == 0                  # a prime row count cannot be cut evenly
+
+
+def test_rowdot_width_rule():
+    from torecsys_amd.functional import rowdot_width_supported
+    assert rowdot_width_supported(512, 2) and rowdot_width_supported(8, 2) and rowdot_width_supported(128, 4)
+    assert not rowdot_width_supported(400, 2)                # 50 vectors: not a power of two
+    assert not rowdot_width_supported(1024, 2)               # 128 vectors: more than a wavefront
+    assert not rowdot_width_supported(12, 2)                 # not a multiple of 16 bytes
