@@ -661,7 +661,17 @@ __global__ __launch_bounds__(256) void scatter_long_rows_elem_kernel(
     const int beg = row_start[r], end = row_start[r + 1];
     for (int e = 0; e < E; ++e) {
       float acc = 0.f, gsum = 0.f;
-      for (int q = beg + lane; q < end; q += 64) acc += elem_term<T>(g_rows, g_fm, fm_sum, perm[q], E, N, gbs, e, &gsum);
+      // 4 bucket positions per lane per round: their perm entries are fetched first, then the 4 gradient values --
+      // a row of 13 000 lookups (the Zipf head of a field) is otherwise 200 rounds of two dependent latencies
+      constexpr int U = 4;
+      for (int q = beg + lane; q < end; q += 64 * U) {
+        int pp[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) pp[u] = (q + 64 * u) < end ? perm[q + 64 * u] : -1;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (pp[u] >= 0) acc += elem_term<T>(g_rows, g_fm, fm_sum, pp[u], E, N, gbs, e, &gsum);
+      }
 #pragma unroll
       for (int m = 32; m >= 1; m >>= 1) {
         acc += __shfl_xor(acc, m, 64);
@@ -735,7 +745,7 @@ static int scatter_launch(const void* g_rows, const void* g_fm, const float* fm_
     hipLaunchKernelGGL((scatter_rows_elem_kernel<T>), dim3(stream_grid(V * E, 256, 256 * 32)), dim3(256), 0, s,
                        (const T*)g_rows, (const T*)g_fm, fm_sum, (const T*)table, row_start, perm, V, E, N, gbs,
                        padding_row, (T*)grad, long_rows, sink);
-    hipLaunchKernelGGL((scatter_long_rows_elem_kernel<T>), dim3(512), dim3(256), 0, s, (const T*)g_rows,
+    hipLaunchKernelGGL((scatter_long_rows_elem_kernel<T>), dim3(2048), dim3(256), 0, s, (const T*)g_rows,
                        (const T*)g_fm, fm_sum, (const T*)table, row_start, perm, E, N, gbs, (T*)grad, long_rows, sink);
   }
   return check_launch("scatter_rows");
