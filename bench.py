@@ -28,14 +28,24 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if "--no-tunableop" not in sys.argv:
     # The MLP GEMMs (nn.Linear, outside the hand-written path) go through PyTorch's TunableOp: solutions tuned
-    # once on an MI355X for exactly these shapes are shipped in torecsys_amd/tuning/; shapes missing from the
-    # file (or a library-version mismatch) are tuned during warm-up (~15 s).
+    # once on an MI355X for exactly these shapes are shipped as ONE file (torecsys_amd/tuning/tunableop_mi355x.csv);
+    # TunableOp reads / rewrites "<name><device ordinal>.csv", so every rank works on its own scratch copy.  Shapes
+    # missing from the file (or a library-version mismatch) are tuned during warm-up (~15 s).
+    import shutil
+    import tempfile
     _rank = os.environ.get("LOCAL_RANK", "0")
+    _tdir = os.path.join(tempfile.gettempdir(), "trs_tunableop_%d" % os.getuid())
+    os.makedirs(_tdir, exist_ok=True)
+    try:
+        shutil.copyfile(os.path.join(ROOT, "torecsys_amd", "tuning", "tunableop_mi355x.csv"),
+                        os.path.join(_tdir, "tunableop_results%s.csv" % _rank))
+    except OSError:
+        pass
     os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
     os.environ.setdefault("PYTORCH_TUNABLEOP_TUNING", "1")
     os.environ.setdefault("PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS", "60")
     os.environ.setdefault("PYTORCH_TUNABLEOP_MAX_TUNING_ITERATIONS", "30")
-    os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", os.path.join(ROOT, "torecsys_amd", "tuning", "tunableop_results.csv"))
+    os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", os.path.join(_tdir, "tunableop_results.csv"))
 
 import torch
 import torch.nn as nn
@@ -156,7 +166,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from torecsys_amd import _abi
-    from torecsys_amd import models as M
+    from harness import ctr_models as M
     from torecsys_amd.inputs import Inputs, MultiIndicesEmbedding
 
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32

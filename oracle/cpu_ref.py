@@ -143,6 +143,39 @@ def batchnorm_channels(y: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor
     return F.batch_norm(y, running_mean, running_var, weight, bias, training, momentum, eps)
 
 
+def cin_contraction(x0: torch.Tensor, hidden: torch.Tensor, conv_weight: torch.Tensor,
+                    conv_bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """One CIN layer's contraction: x0 (B,E,N), hidden (B,E,H) -> y (B,C,E).
+
+    compress_interaction_network.py:125-137: the outer product over the field dims per
+    (b,e), Z[b,(n,h),e] = x0[b,e,n]*hidden[b,e,h] (flatten order n*H+h, :125-132), then
+    Conv1d(k=1) = a channel-mixing GEMM with ``conv_weight`` (C, N*H, 1) (:137)."""
+    B, E, N = x0.shape
+    H = hidden.shape[2]
+    z = x0.unsqueeze(3) * hidden.unsqueeze(2)            # (B,E,N,H)
+    z = z.reshape(B, E, N * H).permute(0, 2, 1)          # (B,N*H,E)
+    return F.conv1d(z, conv_weight, conv_bias)           # (B,C,E)
+
+
+def cin_glue(y: torch.Tensor, bn_weight: Optional[torch.Tensor], bn_bias: Optional[torch.Tensor],
+             running_mean: Optional[torch.Tensor], running_var: Optional[torch.Tensor],
+             use_batchnorm: bool, is_direct: bool, training: bool, activation=torch.relu):
+    """The rest of one CIN layer on the contraction result y (B,C,E) -> (z, direct, hidden (B,E,H')).
+
+    compress_interaction_network.py:137-171: BatchNorm1d (batch statistics when ``training``),
+    activation, and -- unless ``is_direct`` -- ``chunk(2, dim=1)`` into ``direct`` and the next
+    layer's ``hidden`` (EVERY layer is split: the ``i != len-1`` guard at :151 is always true)."""
+    if use_batchnorm:
+        y = batchnorm_channels(y, bn_weight, bn_bias, running_mean, running_var, training)
+    if activation is not None:
+        y = activation(y)
+    if is_direct:
+        direct, hid = y, y
+    else:
+        direct, hid = torch.chunk(y, 2, dim=1)
+    return y, direct, hid.permute(0, 2, 1)
+
+
 def cin_layer(x: torch.Tensor,
               conv_weights: Sequence[torch.Tensor], conv_biases: Sequence[Optional[torch.Tensor]],
               fc_weight: torch.Tensor, fc_bias: torch.Tensor,
@@ -154,39 +187,24 @@ def cin_layer(x: torch.Tensor,
               return_intermediates: bool = False):
     """Compress Interaction Network, (B,N,E) -> (B,O).
 
-    compress_interaction_network.py:114-182.  Per layer k: outer product over the
-    field dims per (b,e): Z[b,(n,h),e] = x0[b,e,n]*xk[b,e,h] (flatten order n*H+h,
-    :125-132); Conv1d(k=1) = channel-mixing GEMM (:137); BatchNorm1d (batch stats
-    when ``training``); activation; unless ``is_direct`` EVERY layer (incl. the
-    last -- the ``i != len-1`` guard at :151 is always true) is split by
-    ``chunk(2, dim=1)`` into ``direct`` and ``hidden``; out = fc(sum_e cat(direct)).
+    compress_interaction_network.py:114-182: per layer ``cin_contraction`` then ``cin_glue``
+    (see there); out = fc(sum_e cat(direct)) (:176-181).
     ``conv_weights[k]`` has shape (C_out, N*H_k, 1) like nn.Conv1d.
     Running statistics, if given, are updated in place like nn.BatchNorm1d.
+    ``activation`` may be a list of callables, one per layer (tests use it to replay a mask).
     """
     x0 = x.permute(0, 2, 1)                      # (B,E,N)
     hidden = x0
     directs: List[torch.Tensor] = []
     inter = []
-    B, E, N = x0.shape
     for k, w in enumerate(conv_weights):
-        H = hidden.shape[2]
-        z = x0.unsqueeze(3) * hidden.unsqueeze(2)            # (B,E,N,H)
-        z = z.reshape(B, E, N * H).permute(0, 2, 1)          # (B,N*H,E)
-        y = F.conv1d(z, w, conv_biases[k])                   # (B,C,E)
-        pre_bn = y
-        if bn_weights is not None:
-            y = batchnorm_channels(
-                y, bn_weights[k], bn_biases[k],
-                None if bn_running_means is None else bn_running_means[k],
-                None if bn_running_vars is None else bn_running_vars[k],
-                training)
-        if activation is not None:
-            y = activation(y)
-        if is_direct:
-            direct, hid = y, y
-        else:
-            direct, hid = torch.chunk(y, 2, dim=1)
-        hidden = hid.permute(0, 2, 1)                        # (B,E,H')
+        pre_bn = cin_contraction(x0, hidden, w, conv_biases[k])
+        act = activation[k] if isinstance(activation, (list, tuple)) else activation
+        y, direct, hidden = cin_glue(
+            pre_bn, None if bn_weights is None else bn_weights[k], None if bn_biases is None else bn_biases[k],
+            None if bn_running_means is None else bn_running_means[k],
+            None if bn_running_vars is None else bn_running_vars[k],
+            bn_weights is not None, is_direct, training, act)
         directs.append(direct)
         inter.append((pre_bn, y))
     pooled = torch.cat(directs, dim=1).sum(dim=-1)           # (B,sum H)

@@ -63,3 +63,20 @@ def rel_err(a, b):
     a = a.double()
     b = b.double()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def rel_err_rows(a, b, floor_frac=1e-2):
+    """Worst PER-ROW relative error: every leading-index row is normalised by its OWN largest reference magnitude
+    (floored at ``floor_frac`` of the global one, so an all-zero row does not divide by zero), so a row of small
+    values that is wrong cannot hide behind a large value elsewhere in the tensor, as it can in ``rel_err``."""
+    a = a.double().reshape(a.shape[0], -1)
+    b = b.double().reshape(b.shape[0], -1)
+    scale = b.abs().amax(dim=1).clamp_min(floor_frac * float(b.abs().max().clamp_min(1e-30)))
+    return float(((a - b).abs().amax(dim=1) / scale).max())
+
+
+def sum_err(a, b, terms_abs):
+    """Error of a computed sum relative to the magnitude of what was summed: max |a-b| / terms_abs, where
+    ``terms_abs`` = sum_i |term_i| of the reference (same shape as b).  This is the norm in which a floating-point
+    sum is backward stable; |b| itself can be arbitrarily small through cancellation."""
+    return float(((a.double() - b.double()).abs() / terms_abs.double().clamp_min(1e-30)).max())

@@ -17,7 +17,7 @@ def dev():
 
 def _deepfm(dev, dt, N, E, sizes):
     from torecsys_amd.inputs import Inputs, MultiIndicesEmbedding
-    from torecsys_amd import models as M
+    from harness import ctr_models as M
     torch.manual_seed(3)
     emb = MultiIndicesEmbedding(embed_size=E, field_sizes=sizes, fuse_fm=True)
     feat = MultiIndicesEmbedding(embed_size=1, field_sizes=sizes)

@@ -31,7 +31,7 @@ def _set_mlp(dnn, G, pre):
 @pytest.mark.parametrize("shape", MODEL_SHAPES)
 def test_models_golden(golden, dev, shape, fuse):
     from torecsys_amd.inputs import Inputs, MultiIndicesEmbedding
-    from torecsys_amd import models as M
+    from harness import ctr_models as M
     G = golden("models")
     B, N, E = shape
     t = "model/" + _tag(shape)

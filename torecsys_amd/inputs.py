@@ -213,18 +213,22 @@ class Inputs(BaseInput):
 
     def add_inputs(self, name: Optional[str] = None, model: Optional[nn.Module] = None,
                    schema: Optional[Dict[str, nn.Module]] = None):
-        if schema is not None:
-            if not isinstance(schema, dict):
-                raise TypeError(f'type of schema is not allowed, given {type(schema).__name__}')
-            for name, model in schema.items():
-                self.add_inputs(name=name, model=model)
+        """Register more input fields after construction: one ``name`` -> ``model`` pair, or a whole ``schema`` dict
+        (which wins when both are given).  Same contract as inputs/inputs.py:91-130: TypeError for a non-dict schema,
+        a non-str name or a non-Module model; AssertionError for a name that is already routed.  Returns self."""
+        if schema is None:
+            entries = [(name, model)]
+        elif isinstance(schema, dict):
+            entries = list(schema.items())
         else:
-            if not isinstance(name, str):
-                raise TypeError(f'type of name is not allowed, given {type(name).__name__}')
-            if name in self.schema:
-                raise AssertionError(f'Given {name} is defined in the schema.')
-            if not isinstance(model, nn.Module):
-                raise TypeError(f'type of model is not not allowed, given {type(model).__name__}')
-            self.schema.update([(name, model)])
-            self.add_module(name, model)
+            raise TypeError(f'schema must be a dict of name -> nn.Module, got {type(schema).__name__}')
+        for key, module in entries:
+            if not isinstance(key, str):
+                raise TypeError(f'input field name must be a str, got {type(key).__name__}')
+            if key in self.schema:
+                raise AssertionError(f'input field {key!r} is already in the schema')
+            if not isinstance(module, nn.Module):
+                raise TypeError(f'input field {key!r} must map to an nn.Module, got {type(module).__name__}')
+            self.schema[key] = module
+            self.add_module(key, module)
         return self
