@@ -80,3 +80,18 @@ def sum_err(a, b, terms_abs):
     ``terms_abs`` = sum_i |term_i| of the reference (same shape as b).  This is the norm in which a floating-point
     sum is backward stable; |b| itself can be arbitrarily small through cancellation."""
     return float(((a.double() - b.double()).abs() / terms_abs.double().clamp_min(1e-30)).max())
+
+
+BF16_U = 2.0 ** -8        # relative size of one bf16 rounding (round to nearest: 2**-9), doubled for two roundings
+
+
+def batch_sum_err(a, b, terms_sq_sum, tol):
+    """For a gradient that is a SUM OVER THE BATCH of signed terms (BatchNorm gamma / beta, biases), computed by a
+    pipeline that stores its activations in bf16: every term carries an independent rounding error of relative
+    size <= BF16_U per bf16 store it went through (contraction output, hidden state, their gradients: 3-5 stores), so
+    the sum is off by a few BF16_U * sqrt(sum_i t_i^2) however much the terms cancel in the sum itself; the worst of
+    several hundred channels sits ~4 standard deviations out.  Returns max over elements of
+    |a-b| / (tol * max|b| + 8 * BF16_U * sqrt(sum t^2)); parity means <= 1."""
+    a, b = a.double(), b.double()
+    allowed = tol * b.abs().max() + 8.0 * BF16_U * terms_sq_sum.double().sqrt()
+    return float(((a - b).abs() / allowed.clamp_min(1e-30)).max())

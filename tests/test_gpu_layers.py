@@ -159,8 +159,8 @@ def test_layers_bf16_vs_oracle(dev, B, N, E):
     xd.grad = None
     xr.grad = None
     gc = torch.randn(B, N, E, generator=g).bfloat16()
-    y = F_.cross_network(xd, Wd, bd)
-    yr = O.cross_network(xr, list(Wr), list(br))
+    y = F_.cross_network(xd, Wd, bd, detach)
+    yr = O.cross_network(xr, list(Wr), list(br), detach)
     assert rel_err(y.float().cpu(), yr.detach()) <= TOLBF
     (y.float() * gc.to(dev).float()).sum().backward()
     (yr * gc.float()).sum().backward()
@@ -192,9 +192,13 @@ def test_cin_contract_vs_oracle(dev, dtype, B, N, E, H, C):
         assert rel_err(a.grad.float().cpu(), r.grad) <= 2 * tol
 
 
-@pytest.mark.parametrize("B,N,E,L", [(37, 5, 32, 2), (129, 39, 64, 6), (64, 3, 96, 3), (50, 7, 128, 4), (20, 4, 128, 6)])
-def test_cross_mfma_bf16_vs_oracle(dev, B, N, E, L):
-    """bf16 MFMA cross path (E % 32 == 0; ragged row counts; resident and non-resident weight fragments)."""
+@pytest.mark.parametrize("detach", [True, False])
+@pytest.mark.parametrize("B,N,E,L", [(37, 5, 32, 2), (129, 39, 64, 6), (64, 3, 96, 3), (50, 7, 128, 4), (20, 4, 128, 6),
+                                     (601, 39, 64, 6), (1, 1, 64, 1), (700, 39, 32, 5), (333, 3, 64, 3)])
+def test_cross_mfma_bf16_vs_oracle(dev, B, N, E, L, detach):
+    """bf16 MFMA cross path (E % 32 == 0; ragged row counts; resident and non-resident weight fragments; row counts
+    that give a workgroup of the backward kernel zero, one and several 64-row groups; with and without the reference's
+    detached first input)."""
     from torecsys_amd import functional as F_
     g = torch.Generator().manual_seed(B * 3 + N + E + L)
     x = (0.5 * torch.randn(B, N, E, generator=g)).bfloat16()
@@ -203,8 +207,8 @@ def test_cross_mfma_bf16_vs_oracle(dev, B, N, E, L):
     gc = torch.randn(B, N, E, generator=g).bfloat16()
     xd, Wd, bd = x.to(dev).requires_grad_(), W.to(dev).requires_grad_(), b.to(dev).requires_grad_()
     xr, Wr, br = x.float().requires_grad_(), W.float().requires_grad_(), b.float().requires_grad_()
-    y = F_.cross_network(xd, Wd, bd)
-    yr = O.cross_network(xr, list(Wr), list(br))
+    y = F_.cross_network(xd, Wd, bd, detach)
+    yr = O.cross_network(xr, list(Wr), list(br), detach)
     assert rel_err(y.float().cpu(), yr.detach()) <= TOLBF
     (y.float() * gc.to(dev).float()).sum().backward()
     (yr * gc.float()).sum().backward()

@@ -319,6 +319,12 @@ def require_device(*tensors: torch.Tensor) -> torch.device:
             dev = t.device
         elif t.device != dev:
             raise RuntimeError(f"torecsys_amd: tensors on different devices ({dev} vs {t.device})")
+    if dev is not None and dev.index is not None and dev.index != torch._C._cuda_getDevice():
+        # the library enqueues on the CURRENT device's current stream (stream_ptr()) and never switches devices:
+        # tensors of another device would be touched from the wrong device's stream (a fault, or an unordered race)
+        raise RuntimeError(
+            f"torecsys_amd: tensors live on {dev} but the current device is cuda:{torch._C._cuda_getDevice()}; "
+            f"run under `with torch.cuda.device({dev.index})` (or torch.cuda.set_device) -- one process per GPU")
     return dev
 
 

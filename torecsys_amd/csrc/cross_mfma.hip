@@ -385,6 +385,236 @@ __global__ __launch_bounds__(64 * BW_WAVES, 1) void cross_mfma_bwd_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward, role-specialised workgroup (the shipped path).
+//
+// The weight gradient dW_l = du_l^T x_l contracts over ROWS for every layer; its fp32 accumulators (E*E*L values:
+// 384 registers per lane at E = 64, L = 6) are what forced one wave per SIMD, and in a symmetric design -- every
+// wave owning a row tile AND a share of the accumulators -- du^T / x^T of all waves must be exchanged through LDS
+// with two barriers per layer in the middle of every wave's dependent chain (the first version of this kernel: 2.1 ms
+// at 2.5 M rows, half of its wave cycles spent waiting).  Here the two kinds of work get their own waves, 8 waves
+// (two per SIMD, 256 registers each) per workgroup:
+//   * waves 0..3 ("chain"): per step one layer of the gradient chain for one 16-row tile each, never touching dW.
+//     They hand du_l and x_l to the other four waves as plain bf16 ROWS ([row][e], 16-byte stores of the registers
+//     they already hold -- no shuffles, no transposing VALU work) in a double-buffered LDS slab;
+//   * waves 4..7 ("dW"): each owns a quarter of the E*E*L accumulators (96 registers at E = 64, L = 6) and nothing
+//     else; one step behind, they read the slab with ds_read_b64_tr_b16 -- the LDS transpose read delivers [row][e]
+//     data with rows along K, i.e. directly as the A (du^T) and B (x) operands -- and issue independent MFMAs.
+// One barrier per step.  Waves w and w+4 of a workgroup land on the same SIMD, so every SIMD hosts one chain wave
+// (MFMA + VALU epilogues, 16 MFMAs per step) beside one dW wave (MFMA only, 8 per step): the two instruction mixes
+// complement each other.  db_l = column sums of du_l is taken by the dW waves from the A operands they already hold
+// (VALU adds beside the MFMAs) and reduced across lanes once at the end.
+constexpr int B2_CHAIN = 4;                         // chain waves per workgroup (one 16-row tile each)
+constexpr int B2_DW = 4;                            // weight-gradient waves
+constexpr int B2_ROWS = B2_CHAIN * 16;              // rows per workgroup step (64)
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+// 8 k-values (rows k0 .. k0+7 of the slab) x this lane's column: two transpose reads of a [4 rows][16 cols] block.
+// Lane i of a 16-lane group supplies the address of 4 contiguous bf16 of row (i>>2), columns 4*(i&3)..+3, and
+// receives column i of the block (element j = row j).
+__device__ __forceinline__ s16x8 slab_frag(const char* slab, int str, int k0, int col0, int i) {
+  typedef __attribute__((address_space(3))) s16x4* lds_p;
+  const char* p = slab + (k0 + (i >> 2)) * str + (col0 + 4 * (i & 3)) * 2;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p + 4 * str));
+  return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <int NT, int L>
+__global__ __launch_bounds__(64 * (B2_CHAIN + B2_DW), 2) void cross_mfma_bwd2_kernel(
+    const uint4* __restrict__ x, const uint4* __restrict__ gout, const uint4* __restrict__ Wp,
+    const uint4* __restrict__ WTp, const float* __restrict__ bp, int64_t rows, uint4* __restrict__ dx,
+    float* __restrict__ dWpart, float* __restrict__ dbpart, int detach_first) {
+  constexpr int KS = NT / 2;
+  constexpr int E = NT * 16;
+  constexpr int FRAG = NT * KS * 64;            // uint4 per layer
+  constexpr int STR = E * 2 + 16;               // bytes per slab row (pad: conflict-free 16-byte row stores and tr reads)
+  constexpr int SLAB = B2_ROWS * STR;           // one tensor of one buffer
+  constexpr int TPW = NT * NT / B2_DW;          // dW output tiles per dW wave: tiles t = w', w'+4, ... -> (t / NT, t % NT)
+  static_assert((NT * NT) % B2_DW == 0, "E must be a multiple of 32");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* Ws = reinterpret_cast<uint4*>(smem);
+  uint4* WTs = Ws + L * FRAG;
+  float* bs = reinterpret_cast<float*>(WTs + L * FRAG);
+  char* stage = reinterpret_cast<char*>(bs + L * E);          // [buffer 2][du | x][B2_ROWS][STR]
+  for (int i = threadIdx.x; i < L * FRAG; i += blockDim.x) { Ws[i] = Wp[i]; WTs[i] = WTp[i]; }
+  for (int i = threadIdx.x; i < L * E; i += blockDim.x) bs[i] = bp[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, r = lane & 15;
+  const int64_t ngroups = (rows + B2_ROWS - 1) / B2_ROWS;
+  int step0 = 0;                                 // global step counter at the start of the group (buffer parity)
+
+  if (wave < B2_CHAIN) {
+    // ------------------------------------------------------------------ chain waves
+    uint4 nx_raw[KS], ng_raw[KS];
+    auto fetch = [&](int64_t grp_) {
+      const int64_t row_ = grp_ * B2_ROWS + wave * 16 + r;
+#pragma unroll
+      for (int c = 0; c < KS; ++c) {
+        nx_raw[c] = make_uint4(0, 0, 0, 0);
+        ng_raw[c] = make_uint4(0, 0, 0, 0);
+        if (grp_ < ngroups && row_ < rows) {
+          nx_raw[c] = x[(row_ * E + 32 * c + 8 * q) >> 3];
+          ng_raw[c] = gout[(row_ * E + 32 * c + 8 * q) >> 3];
+        }
+      }
+    };
+    fetch(blockIdx.x);
+    char* const myrow = stage + (wave * 16 + r) * STR + 16 * q;
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x, step0 += L + 1) {
+      XTile<NT> g, dx0;
+      uint4 Bx[L][1][KS];
+#pragma unroll
+      for (int c = 0; c < KS; ++c) {
+        Bx[0][0][c] = nx_raw[c];
+        float f[8];
+        Vec16<bf16_t>::unpack(ng_raw[c], f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          g.v[2 * c][i] = f[i];
+          g.v[2 * c + 1][i] = f[4 + i];
+        }
+      }
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dx0.v[mt][i] = 0.f;
+      fetch(grp + gridDim.x);
+      // x0 is bf16 in memory: its fp32 values are re-derived from Bx[0] where needed
+      auto x0v = [&](int mt, int i) -> float {
+        const uint4& u = Bx[0][0][mt >> 1];
+        const unsigned w = (mt & 1) ? (i < 2 ? u.z : u.w) : (i < 2 ? u.x : u.y);
+        return (i & 1) ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16);
+      };
+      // step 0: forward recompute of x_1 .. x_{L-1} (bf16 B fragments, the values the forward kernel produced)
+#pragma unroll
+      for (int l = 0; l + 1 < L; ++l) {
+        f32x4 acc[1][NT];
+        layer_matmul<NT, 1>(Ws + l * FRAG, bs + l * E, Bx[l], lane, q, acc);
+        XTile<NT> nx;
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) nx.v[mt][i] = fmaf(x0v(mt, i), acc[0][mt][i], x0v(mt, i));
+        pack_tile<NT>(nx, Bx[l + 1][0]);
+      }
+      __syncthreads();
+      // steps 1..L: layers L-1 .. 0
+#pragma unroll
+      for (int l = L - 1; l >= 0; --l) {
+        char* rowp = myrow + (((step0 + (L - l)) & 1) ? 2 * SLAB : 0);
+        f32x4 acc[1][NT];
+        layer_matmul<NT, 1>(Ws + l * FRAG, bs + l * E, Bx[l], lane, q, acc);   // u_l
+        XTile<NT> du;
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            du.v[mt][i] = g.v[mt][i] * x0v(mt, i);
+            dx0.v[mt][i] = fmaf(g.v[mt][i], acc[0][mt][i] + 1.f, dx0.v[mt][i]);
+          }
+        uint4 Bdu[1][KS];
+        pack_tile<NT>(du, Bdu[0]);
+        // hand du_l and x_l to the dW waves as plain rows
+#pragma unroll
+        for (int c = 0; c < KS; ++c) {
+          *reinterpret_cast<uint4*>(rowp + 64 * c) = Bdu[0][c];
+          *reinterpret_cast<uint4*>(rowp + SLAB + 64 * c) = Bx[l][0][c];
+        }
+        const bool need_g = (l > 0) || (detach_first == 0);
+        if (need_g) {
+          f32x4 ga[1][NT];
+          layer_matmul<NT, 1>(WTs + l * FRAG, nullptr, Bdu, lane, q, ga);
+#pragma unroll
+          for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g.v[mt][i] = ga[0][mt][i];
+        }
+        __syncthreads();
+      }
+      const int64_t row = grp * B2_ROWS + wave * 16 + r;
+      if (row < rows) {
+        XTile<NT> o;
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o.v[mt][i] = dx0.v[mt][i] + (detach_first ? 0.f : g.v[mt][i]);
+        uint4 raw[KS];
+        pack_tile<NT>(o, raw);
+#pragma unroll
+        for (int c = 0; c < KS; ++c) dx[(row * E + 32 * c + 8 * q) >> 3] = raw[c];
+      }
+    }
+  } else {
+    // ------------------------------------------------------------------ dW waves
+    const int wq = wave - B2_CHAIN;
+    f32x4 dWacc[L][TPW];
+    float dbacc[L];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      dbacc[l] = 0.f;
+#pragma unroll
+      for (int k = 0; k < TPW; ++k) dWacc[l][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    auto consume = [&](const char* buf, f32x4 (&acc)[TPW], float& db) {
+#pragma unroll
+      for (int ks = 0; ks < B2_ROWS / 32; ++ks) {
+#pragma unroll
+        for (int k = 0; k < TPW; ++k) {
+          const int t = wq + B2_DW * k, mo = t / NT, no = t % NT;
+          const s16x8 A = slab_frag(buf, STR, 32 * ks + 8 * q, 16 * mo, r);
+          const s16x8 Bf = slab_frag(buf + SLAB, STR, 32 * ks + 8 * q, 16 * no, r);
+          acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, Bf),
+                                                           acc[k], 0, 0, 0);
+          if (no == mo % NT && (NT >= B2_DW ? mo == wq : true)) {
+            // db: this lane's 8 rows of column e_out = 16*mo + r (every mo is taken by exactly one wave)
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += bf16_bits_to_f32((uint32_t)(uint16_t)A[j]);
+            db += sum;
+          }
+        }
+      }
+    };
+    bool first = true;
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x, step0 += L + 1) {
+      // step 0: layer 0 of the previous group (written in its last step)
+      if (!first) consume(stage + (((step0 - 1) & 1) ? 2 * SLAB : 0), dWacc[0], dbacc[0]);
+      first = false;
+      __syncthreads();
+#pragma unroll
+      for (int l = L - 1; l >= 0; --l) {
+        // step L-l: the chain waves are on layer l; these waves take layer l+1, written one step earlier
+        if (l + 1 < L)
+          consume(stage + (((step0 + (L - l) - 1) & 1) ? 2 * SLAB : 0), dWacc[l + 1 < L ? l + 1 : 0],
+                  dbacc[l + 1 < L ? l + 1 : 0]);
+        __syncthreads();
+      }
+    }
+    if (!first) consume(stage + (((step0 - 1) & 1) ? 2 * SLAB : 0), dWacc[0], dbacc[0]);
+    // partial results of this workgroup: D layout -> (row m = 4q+i -> e_out, col n = r -> e_in)
+    float* myW = dWpart + (size_t)blockIdx.x * L * E * E;
+    float* myb = dbpart + (size_t)blockIdx.x * L * E;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+#pragma unroll
+      for (int k = 0; k < TPW; ++k) {
+        const int t = wq + B2_DW * k, mo = t / NT, no = t % NT;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) myW[(size_t)l * E * E + (16 * mo + 4 * q + i) * E + 16 * no + r] = dWacc[l][k][i];
+        if (no == mo % NT && (NT >= B2_DW ? mo == wq : true)) {
+          float v = dbacc[l];            // the four q-groups hold different rows of the same column
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
+          if (q == 0) myb[l * E + 16 * mo + r] = v;
+        }
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void cross_reduce_partials_kernel(const float* __restrict__ part, int nparts,
                                                                     int n, float* __restrict__ out) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -444,18 +674,18 @@ static int cross_bwd_launch(const void* x, const void* g, const uint4* Wp, const
                             void* dx, float* dWpart, float* dbpart, float* dW, float* db, int detach_first,
                             hipStream_t s) {
   constexpr int E = NT * 16;
-  const size_t lds = (size_t)2 * L * E * E * 2 + (size_t)L * E * 4 + (size_t)2 * E * BW_STR;
-  auto kern = cross_mfma_bwd_kernel<NT, L>;
+  const size_t lds = (size_t)2 * L * E * E * 2 + (size_t)L * E * 4 + (size_t)4 * B2_ROWS * (E * 2 + 16);
+  auto kern = cross_mfma_bwd2_kernel<NT, L>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return check_launch("cross_bwd(mfma): LDS attribute");
     attr_set = true;
   }
-  const int64_t ngroups = (rows + BW_ROWS - 1) / BW_ROWS;
+  const int64_t ngroups = (rows + B2_ROWS - 1) / B2_ROWS;
   const int grid = (int)std::min<int64_t>(ngroups, BW_MAX_BLOCKS);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * BW_WAVES), lds, s, (const uint4*)x, (const uint4*)g, Wp, WTp, bp, rows,
-                     (uint4*)dx, dWpart, dbpart, detach_first);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (B2_CHAIN + B2_DW)), lds, s, (const uint4*)x, (const uint4*)g, Wp, WTp,
+                     bp, rows, (uint4*)dx, dWpart, dbpart, detach_first);
   hipLaunchKernelGGL(cross_reduce_partials_kernel, dim3((L * E * E + 255) / 256), dim3(256), 0, s, dWpart, grid,
                      L * E * E, dW);
   hipLaunchKernelGGL(cross_reduce_partials_kernel, dim3((L * E + 255) / 256), dim3(256), 0, s, dbpart, grid, L * E, db);

@@ -271,6 +271,12 @@ def scatter_rows_update(rb: RowBuckets, table: torch.Tensor, opt, g_rows: Option
     ws_bytes = size_query("trs_scatter_workspace_bytes", rb.BN, rb.N, E, value_dtype_code(table))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=table.device)
     if opt.kind == 3:
+        if torch.cuda.is_current_stream_capturing():
+            # the bias-corrected step size lr*sqrt(1-b2^t)/(1-b1^t) is computed on the host per step and passed by
+            # value: a captured launch would replay the capture-time t for ever (~0.18*lr with default betas)
+            raise RuntimeError("torecsys_amd: FusedSparseAdam cannot be captured into a hipGraph (its per-step bias "
+                               "correction is a host-side scalar); use FusedSparseSGD / FusedSparseAdagrad under "
+                               "GraphedStep, or run the Adam step eagerly")
         m1, m2 = opt.state_for(table)
         call("trs_scatter_rows_update_adam", ptr(g_rows), 0, ptr(g_bcast), ptr(fm_sum), ptr(table), ptr(rb.row_start),
              ptr(rb.perm), rb.BN, V, E, rb.N, value_dtype_code(table), padding_row, float(opt.next_step_size(table)),

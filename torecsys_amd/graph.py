@@ -12,6 +12,8 @@ stream that builds the row buckets forks from and joins the capturing stream).
 
 The callable must be shape-static and must not branch on tensor values.  Scalars passed by value to kernels (the
 learning rate of a fused sparse optimizer) are frozen at capture time; call ``recapture()`` after changing them.
+``FusedSparseAdam`` refuses to be captured: its bias-corrected step size changes every step and is a host scalar
+(FusedSparseSGD / FusedSparseAdagrad have no per-step host state and capture fine).
 The row-sharded multi-GPU lookup reads its all-to-all split sizes on the host and therefore stays eager.
 """
 from typing import Callable, Iterable, Optional, Sequence
