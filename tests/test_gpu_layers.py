@@ -159,8 +159,8 @@ def test_layers_bf16_vs_oracle(dev, B, N, E):
     xd.grad = None
     xr.grad = None
     gc = torch.randn(B, N, E, generator=g).bfloat16()
-    y = F_.cross_network(xd, Wd, bd, detach)
-    yr = O.cross_network(xr, list(Wr), list(br), detach)
+    y = F_.cross_network(xd, Wd, bd)
+    yr = O.cross_network(xr, list(Wr), list(br))
     assert rel_err(y.float().cpu(), yr.detach()) <= TOLBF
     (y.float() * gc.to(dev).float()).sum().backward()
     (yr * gc.float()).sum().backward()

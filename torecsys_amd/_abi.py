@@ -14,7 +14,7 @@ from ctypes import c_char_p, c_int32, c_int64, c_size_t, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtrs_hip.so")
+LIB_PATH = os.environ.get("TRS_LIB_PATH") or os.path.join(_HERE, "libtrs_hip.so")      # TRS_LIB_PATH: developer override
 
 TRS_F32, TRS_BF16 = 0, 1
 TRS_I64, TRS_I32 = 0, 1

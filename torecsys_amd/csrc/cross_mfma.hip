@@ -25,8 +25,6 @@ __host__ __device__ __forceinline__ int cross_row_of_slot(int mt, int m) {
 }
 
 // Pre-pack: Wp[(l*NT + mt)*KS + ks][lane][8] = W_l[row(mt, lane&15)][32*ks + 8*(lane>>4) + 0..7]
-// TRANSPOSE: pack W_l^T instead (used by the backward's data-gradient chain g_l = W_l^T du_l).
-template <bool TRANSPOSE>
 __global__ __launch_bounds__(256) void cross_prepack_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ b,
                                                             bf16_t* __restrict__ Wp, float* __restrict__ bp, int E,
                                                             int L) {
@@ -44,7 +42,7 @@ __global__ __launch_bounds__(256) void cross_prepack_kernel(const bf16_t* __rest
     const bf16_t* Wl = W + (size_t)l * E * E;
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      Wp[(size_t)t * 8 + j] = TRANSPOSE ? Wl[(size_t)(k0 + j) * E + row] : Wl[(size_t)row * E + k0 + j];
+      Wp[(size_t)t * 8 + j] = Wl[(size_t)row * E + k0 + j];
   }
   if (bp != nullptr)
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < L * E; t += gridDim.x * blockDim.x) bp[t] = to_f32(b[t]);
@@ -176,216 +174,6 @@ __global__ __launch_bounds__(256) void cross_mfma_fwd_kernel(const uint4* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward on the matrix cores.  Workgroup = BW_WAVES waves, wave w owns the 16-row tile w of a row group.
-// Per tile, in registers: recompute x_1..x_{L-1} (kept as bf16 B fragments), then for l = L-1..0
-//   u_l  = W_l x_l + b_l (recomputed, MFMA)          du = g * x0          dx0 += g * (u_l + 1)
-//   g    = W_l^T du      (MFMA on the transposed fragments; skipped for l = 0 when detach_first)
-// dW_l = du^T x_l contracts over ROWS, which live on lanes in the layout above, so du and x_l are staged
-// transposed in LDS ([e][rows of the group], bf16) once per layer and every wave accumulates its share of the E x E
-// output tiles (K = rows of the group) in registers across the whole kernel; db_l rides along as
-// one extra tile against an all-ones B operand.  Per-workgroup partial dW/db go to a workspace and are
-// summed by a second kernel (no float atomics).
-constexpr int BW_WAVES = 4;  // one wave per SIMD: the whole 512-register file per wave, no spills at L = 6
-constexpr int BW_ROWS = 16 * BW_WAVES;          // rows per workgroup iteration
-constexpr int BW_STR = BW_ROWS * 2 + 16;        // bytes per staged e-row (pad: conflict-free b128 reads)
-
-template <int NT, int L>
-__global__ __launch_bounds__(64 * BW_WAVES, 1) void cross_mfma_bwd_kernel(
-    const uint4* __restrict__ x, const uint4* __restrict__ gout, const uint4* __restrict__ Wp,
-    const uint4* __restrict__ WTp, const float* __restrict__ bp, int64_t rows, uint4* __restrict__ dx,
-    float* __restrict__ dWpart, float* __restrict__ dbpart, int detach_first) {
-  constexpr int KS = NT / 2;
-  constexpr int E = NT * 16;
-  constexpr int FRAG = NT * KS * 64;                       // uint4 per layer
-  constexpr int OUT_TILES = NT * NT;                       // 16x16 tiles of dW_l
-  constexpr int TPW = (OUT_TILES + BW_WAVES - 1) / BW_WAVES;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint4* Ws = reinterpret_cast<uint4*>(smem);
-  uint4* WTs = Ws + L * FRAG;
-  float* bs = reinterpret_cast<float*>(WTs + L * FRAG);
-  char* duT = reinterpret_cast<char*>(bs + L * E);
-  char* xT = duT + E * BW_STR;
-  for (int i = threadIdx.x; i < L * FRAG; i += blockDim.x) { Ws[i] = Wp[i]; WTs[i] = WTp[i]; }
-  for (int i = threadIdx.x; i < L * E; i += blockDim.x) bs[i] = bp[i];
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, r = lane & 15;
-  f32x4 dWacc[L][TPW];
-  f32x4 dbacc[L];
-#pragma unroll
-  for (int l = 0; l < L; ++l) {
-    dbacc[l] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) dWacc[l][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);  // 8 x bf16(1.0)
-  const int64_t ngroups = (rows + BW_ROWS - 1) / BW_ROWS;
-  // software prefetch: the raw 16-byte vectors of the NEXT group's x / g tiles are loaded while this group
-  // is being processed (one wave per SIMD: nothing else would hide the HBM latency)
-  uint4 nx_raw[KS], ng_raw[KS];
-  auto fetch = [&](int64_t grp_) {
-    const int64_t row_ = grp_ * BW_ROWS + wave * 16 + r;
-#pragma unroll
-    for (int c = 0; c < KS; ++c) {
-      nx_raw[c] = make_uint4(0, 0, 0, 0);
-      ng_raw[c] = make_uint4(0, 0, 0, 0);
-      if (grp_ < ngroups && row_ < rows) {
-        nx_raw[c] = x[(row_ * E + 32 * c + 8 * q) >> 3];
-        ng_raw[c] = gout[(row_ * E + 32 * c + 8 * q) >> 3];
-      }
-    }
-  };
-  fetch(blockIdx.x);
-  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    const int64_t row = grp * BW_ROWS + wave * 16 + r;
-    XTile<NT> g, dx0;
-    uint4 Bx[L][KS];
-#pragma unroll
-    for (int c = 0; c < KS; ++c) {
-      Bx[0][c] = nx_raw[c];
-      float f[8];
-      Vec16<bf16_t>::unpack(ng_raw[c], f);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        g.v[2 * c][i] = f[i];
-        g.v[2 * c + 1][i] = f[4 + i];
-      }
-    }
-    fetch(grp + gridDim.x);
-    // x0 is bf16 in memory: its fp32 values are re-derived from Bx[0] where needed (saves 16 registers)
-    auto x0v = [&](int mt, int i) -> float {
-      const uint4& u = Bx[0][mt >> 1];
-      const unsigned w = (mt & 1) ? (i < 2 ? u.z : u.w) : (i < 2 ? u.x : u.y);
-      return (i & 1) ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16);
-    };
-#pragma unroll
-    for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) dx0.v[mt][i] = 0.f;
-    // forward recompute of x_1 .. x_{L-1}
-#pragma unroll
-    for (int l = 0; l + 1 < L; ++l) {
-      f32x4 acc[1][NT];
-      layer_matmul<NT, 1>(Ws + l * FRAG, bs + l * E, &Bx[l], lane, q, acc);
-      XTile<NT> nx;
-#pragma unroll
-      for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) nx.v[mt][i] = fmaf(x0v(mt, i), acc[0][mt][i], x0v(mt, i));
-      pack_tile<NT>(nx, Bx[l + 1]);
-    }
-#pragma unroll
-    for (int l = L - 1; l >= 0; --l) {
-      f32x4 acc[1][NT];
-      layer_matmul<NT, 1>(Ws + l * FRAG, bs + l * E, &Bx[l], lane, q, acc);   // u_l
-      XTile<NT> du;
-#pragma unroll
-      for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          du.v[mt][i] = g.v[mt][i] * x0v(mt, i);
-          dx0.v[mt][i] = fmaf(g.v[mt][i], acc[0][mt][i] + 1.f, dx0.v[mt][i]);
-        }
-      uint4 Bdu[KS];
-      pack_tile<NT>(du, Bdu);
-      // stage du^T and x_l^T as bf16 at [e][row].  Lane pairs (r, r^1) trade one dword so that every lane
-      // writes a full dword = rows (r&~1, r|1) of ONE e (even lanes take element 2h, odd lanes 2h+1); the
-      // byte column is XOR-swizzled with ((e>>3)&3)<<5 so the four q-groups of a wave hit different banks.
-      {
-        const int colpair = (wave * 16 + (r & ~1)) * 2;
-        const int odd = r & 1;
-#pragma unroll
-        for (int c = 0; c < KS; ++c) {
-          const unsigned wd[4] = {Bdu[c].x, Bdu[c].y, Bdu[c].z, Bdu[c].w};
-          const unsigned wx[4] = {Bx[l][c].x, Bx[l][c].y, Bx[l][c].z, Bx[l][c].w};
-#pragma unroll
-          for (int h = 0; h < 4; ++h) {
-            const unsigned od = __shfl_xor(wd[h], 1, 64), ox = __shfl_xor(wx[h], 1, 64);
-            // even lane: (mine.lo, other.lo) -> element 2h ; odd lane: (other.hi, mine.hi) -> element 2h+1
-            const unsigned vd = odd ? ((od >> 16) | (wd[h] & 0xffff0000u)) : ((wd[h] & 0xffffu) | (od << 16));
-            const unsigned vx = odd ? ((ox >> 16) | (wx[h] & 0xffff0000u)) : ((wx[h] & 0xffffu) | (ox << 16));
-            const int e = 32 * c + 8 * q + 2 * h + odd;
-            const int off = e * BW_STR + (colpair ^ (q << 5));
-            *reinterpret_cast<unsigned*>(duT + off) = vd;
-            *reinterpret_cast<unsigned*>(xT + off) = vx;
-          }
-        }
-      }
-      // data-gradient chain (register-only: overlaps the staging barrier)
-      XTile<NT> gn;
-      const bool need_g = (l > 0) || (detach_first == 0);
-      if (need_g) {
-        f32x4 ga[1][NT];
-        layer_matmul<NT, 1>(WTs + l * FRAG, nullptr, &Bdu, lane, q, ga);
-#pragma unroll
-        for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) gn.v[mt][i] = ga[0][mt][i];
-      }
-      __syncthreads();
-      // dW_l tiles: out tile t = wave*TPW + k -> (mo, no);  A = duT[16*mo + m][rows], B = xT[16*no + n][rows]
-#pragma unroll
-      for (int k = 0; k < TPW; ++k) {
-        const int t = wave * TPW + k;
-        if (t < OUT_TILES) {
-          const int mo = t / NT, no = t - mo * NT;
-#pragma unroll
-          for (int kk = 0; kk < BW_ROWS / 32; ++kk) {
-            const int sw = ((r >> 3) & 1) << 5;   // ((e>>3)&3)<<5 with e = 16*tile + r  ->  bit 3 of r (bit 4 of e is 0)
-            const uint4 a = *reinterpret_cast<const uint4*>(duT + (16 * mo + r) * BW_STR +
-                                                            (((32 * kk + 8 * q) * 2) ^ (sw | ((mo & 1) << 6))));
-            const uint4 b = *reinterpret_cast<const uint4*>(xT + (16 * no + r) * BW_STR +
-                                                            (((32 * kk + 8 * q) * 2) ^ (sw | ((no & 1) << 6))));
-            dWacc[l][k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
-                                                                  __builtin_bit_cast(bf16x8, b), dWacc[l][k], 0, 0, 0);
-          }
-        }
-      }
-      if (wave < NT) {   // db_l rows 16*wave .. +15: du^T x ones
-#pragma unroll
-        for (int kk = 0; kk < BW_ROWS / 32; ++kk) {
-          const uint4 a = *reinterpret_cast<const uint4*>(
-              duT + (16 * wave + r) * BW_STR + (((32 * kk + 8 * q) * 2) ^ ((((r >> 3) & 1) << 5) | ((wave & 1) << 6))));
-          dbacc[l] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
-                                                             __builtin_bit_cast(bf16x8, ones), dbacc[l], 0, 0, 0);
-        }
-      }
-      __syncthreads();
-      if (need_g) g = gn;
-    }
-    if (row < rows) {
-      XTile<NT> o;
-#pragma unroll
-      for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o.v[mt][i] = dx0.v[mt][i] + (detach_first ? 0.f : g.v[mt][i]);
-      uint4 raw[KS];
-      pack_tile<NT>(o, raw);
-#pragma unroll
-      for (int c = 0; c < KS; ++c) dx[(row * E + 32 * c + 8 * q) >> 3] = raw[c];
-    }
-  }
-  // partial results of this workgroup: D layout -> (row m = 4q+i, col n = r)
-  float* myW = dWpart + (size_t)blockIdx.x * L * E * E;
-  float* myb = dbpart + (size_t)blockIdx.x * L * E;
-#pragma unroll
-  for (int l = 0; l < L; ++l) {
-#pragma unroll
-    for (int k = 0; k < TPW; ++k) {
-      const int t = wave * TPW + k;
-      if (t < OUT_TILES) {
-        const int mo = t / NT, no = t - mo * NT;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) myW[(size_t)l * E * E + (16 * mo + 4 * q + i) * E + 16 * no + r] = dWacc[l][k][i];
-      }
-    }
-    if (wave < NT && r == 0) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) myb[l * E + 16 * wave + 4 * q + i] = dbacc[l][i];
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // backward, role-specialised workgroup (the shipped path).
 //
 // The weight gradient dW_l = du_l^T x_l contracts over ROWS for every layer; its fp32 accumulators (E*E*L values:
@@ -393,54 +181,117 @@ __global__ __launch_bounds__(64 * BW_WAVES, 1) void cross_mfma_bwd_kernel(
 // wave owning a row tile AND a share of the accumulators -- du^T / x^T of all waves must be exchanged through LDS
 // with two barriers per layer in the middle of every wave's dependent chain (the first version of this kernel: 2.1 ms
 // at 2.5 M rows, half of its wave cycles spent waiting).  Here the two kinds of work get their own waves, 8 waves
-// (two per SIMD, 256 registers each) per workgroup:
-//   * waves 0..3 ("chain"): per step one layer of the gradient chain for one 16-row tile each, never touching dW.
-//     They hand du_l and x_l to the other four waves as plain bf16 ROWS ([row][e], 16-byte stores of the registers
-//     they already hold -- no shuffles, no transposing VALU work) in a double-buffered LDS slab;
+// (two per SIMD, 256 registers each) per workgroup, 64 rows per group, L+1 steps per group, one barrier per step:
+//   * waves 0..3 ("chain"): one 16-row tile each, never touching dW.  Step 0 recomputes x_1 .. x_{L-1} and leaves
+//     them in LDS as plain bf16 rows (the "x store"; 16-byte stores of the registers the wave already holds -- no
+//     shuffles, no transposing VALU work) and keeps u_l + 1 of every layer as packed bf16 registers; steps 1..L run
+//     the gradient chain of layers L-1 .. 0 (du = g*x0, dx0 += g*(u_l+1), g <- W_l^T du: ONE matmul per step) and
+//     hand du_l over as rows in a double-buffered slab.  Keeping x_l in LDS instead of registers is what leaves
+//     the wave room to have its W fragments in flight ahead of the MFMAs that consume them;
 //   * waves 4..7 ("dW"): each owns a quarter of the E*E*L accumulators (96 registers at E = 64, L = 6) and nothing
-//     else; one step behind, they read the slab with ds_read_b64_tr_b16 -- the LDS transpose read delivers [row][e]
-//     data with rows along K, i.e. directly as the A (du^T) and B (x) operands -- and issue independent MFMAs.
-// One barrier per step.  Waves w and w+4 of a workgroup land on the same SIMD, so every SIMD hosts one chain wave
-// (MFMA + VALU epilogues, 16 MFMAs per step) beside one dW wave (MFMA only, 8 per step): the two instruction mixes
-// complement each other.  db_l = column sums of du_l is taken by the dW waves from the A operands they already hold
-// (VALU adds beside the MFMAs) and reduced across lanes once at the end.
+//     else; one step behind, they read du_l and x_l with ds_read_b64_tr_b16 -- the LDS transpose read delivers
+//     [row][e] data with rows along K, i.e. directly as the A (du^T) and B (x) operands -- and issue independent MFMAs.
+// Waves w and w+4 of a workgroup land on the same SIMD, so every SIMD hosts one chain wave (MFMA + VALU epilogues)
+// beside one dW wave (MFMA only).  db_l = column sums of du_l is taken by the dW waves from the A operands they
+// already hold (VALU adds beside the MFMAs) and reduced across lanes once at the end.
+//
+// Row layout in LDS (x store and du slab): [16-column panel][row][16 columns] bf16, i.e. 32-byte row pieces, rows
+// contiguous inside a panel -- a transpose read of a 16-lane group then covers 128 contiguous bytes (bank-conflict
+// free; a row-major slab with padded rows costs a 4-way conflict on every transpose read).
+// Only ONE copy of the W fragments lives in LDS: the A operand of g <- W_l^T du (W_l^T in the same permuted slot
+// order) is fetched from the forward fragments with the transpose read as well (wt_frag below).
+// LDS at E = 64, L = 6: W fragments 48 KiB + biases 1.5 KiB + x store 48 KiB + du slab 16 KiB = 113.5 KiB.
 constexpr int B2_CHAIN = 4;                         // chain waves per workgroup (one 16-row tile each)
 constexpr int B2_DW = 4;                            // weight-gradient waves
 constexpr int B2_ROWS = B2_CHAIN * 16;              // rows per workgroup step (64)
+constexpr int B2_PANEL = B2_ROWS * 32;              // bytes of one 16-column panel
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
-// 8 k-values (rows k0 .. k0+7 of the slab) x this lane's column: two transpose reads of a [4 rows][16 cols] block.
-// Lane i of a 16-lane group supplies the address of 4 contiguous bf16 of row (i>>2), columns 4*(i&3)..+3, and
+// 8 k-values (rows k0 .. k0+7) x this lane's column of panel ``panel``: two transpose reads of a [4 rows][16 cols]
+// block.  Lane i of a 16-lane group supplies the address of 4 contiguous bf16 of row (i>>2), columns 4*(i&3)..+3, and
 // receives column i of the block (element j = row j).
-__device__ __forceinline__ s16x8 slab_frag(const char* slab, int str, int k0, int col0, int i) {
+__device__ __forceinline__ s16x8 rows_frag(const char* tensor, int k0, int panel, int i) {
   typedef __attribute__((address_space(3))) s16x4* lds_p;
-  const char* p = slab + (k0 + (i >> 2)) * str + (col0 + 4 * (i & 3)) * 2;
+  const char* p = tensor + panel * B2_PANEL + (k0 + (i >> 2)) * 32 + (i & 3) * 8;
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p + 4 * str));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p + 4 * 32));
   return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+// fp32 value (mt, i) of a row held as bf16 B fragments (the D-layout slot order of XTile)
+template <int KS>
+__device__ __forceinline__ float frag_value(const uint4 (&B)[KS], int mt, int i) {
+  const uint4& u = B[mt >> 1];
+  const unsigned w = (mt & 1) ? (i < 2 ? u.z : u.w) : (i < 2 ? u.x : u.y);
+  return (i & 1) ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16);
+}
+
+// A operand of g^T = W^T du^T for output slot tile mt' and k-step ks', read out of the FORWARD fragments of the layer
+// (Wl: [mt][ks][64 lanes][8 bf16], lane 16*b + m of fragment (mt, ks) holds W[row(mt, m)][32*ks + 8*b .. +7]).
+// Wanted per lane (q' = lane>>4, m' = lane&15): W[32*ks' + 8*q' + j][row(mt', m')], j = 0..7.  With
+// row(mt, m) = 32*(mt>>1) + 8*(m>>2) + 4*(mt&1) + (m&3): rows 32*ks' + 8*q' + (0..3 | 4..7) are lanes 4*q' + (0..3) of
+// fragment rows mt = 2*ks' (| 2*ks'+1), and column row(mt', 4*b' + d') is element 4*(mt'&1) + d' of the chunk of lane
+// group b' in fragment column mt'>>1 -- so source lane s = 4*j + b' of a transpose read points at 4 contiguous bf16.
+template <int KS>
+__device__ __forceinline__ bf16x8 wt_frag(const uint4* Wl, int mtp, int ksp, int lane) {
+  typedef __attribute__((address_space(3))) s16x4* lds_p;
+  const int qp = lane >> 4, sl = lane & 15;
+  const char* p = reinterpret_cast<const char*>(Wl) + ((2 * ksp) * KS + (mtp >> 1)) * 1024 +
+                  (16 * (sl & 3) + 4 * qp + (sl >> 2)) * 16 + 8 * (mtp & 1);
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p + KS * 1024));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// acc[mt] = bias + sum_ks A[mt][ks] * B[ks] with every A fragment of the layer requested before the first MFMA
+// (TRANSPOSED: the fragments of W^T, no bias)
+template <int NT, bool TRANSPOSED>
+__device__ __forceinline__ void layer_matmul_pre(const uint4* Wl, const float* bias, const uint4 (&B)[NT / 2], int lane,
+                                                 int q, f32x4 (&acc)[NT]) {
+  constexpr int KS = NT / 2;
+  bf16x8 A[NT][KS];
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      A[mt][ks] = TRANSPOSED ? wt_frag<KS>(Wl, mt, ks, lane) : __builtin_bit_cast(bf16x8, Wl[(mt * KS + ks) * 64 + lane]);
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt) {
+    if (!TRANSPOSED) {
+      const float4 bv = *reinterpret_cast<const float4*>(bias + 32 * (mt >> 1) + 8 * q + 4 * (mt & 1));
+      acc[mt] = f32x4{bv.x, bv.y, bv.z, bv.w};
+    } else {
+      acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+      acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[mt][ks], __builtin_bit_cast(bf16x8, B[ks]), acc[mt], 0, 0, 0);
 }
 
 template <int NT, int L>
 __global__ __launch_bounds__(64 * (B2_CHAIN + B2_DW), 2) void cross_mfma_bwd2_kernel(
     const uint4* __restrict__ x, const uint4* __restrict__ gout, const uint4* __restrict__ Wp,
-    const uint4* __restrict__ WTp, const float* __restrict__ bp, int64_t rows, uint4* __restrict__ dx,
-    float* __restrict__ dWpart, float* __restrict__ dbpart, int detach_first) {
+    const float* __restrict__ bp, int64_t rows, uint4* __restrict__ dx, float* __restrict__ dWpart,
+    float* __restrict__ dbpart, int detach_first) {
   constexpr int KS = NT / 2;
   constexpr int E = NT * 16;
   constexpr int FRAG = NT * KS * 64;            // uint4 per layer
-  constexpr int STR = E * 2 + 16;               // bytes per slab row (pad: conflict-free 16-byte row stores and tr reads)
-  constexpr int SLAB = B2_ROWS * STR;           // one tensor of one buffer
-  constexpr int TPW = NT * NT / B2_DW;          // dW output tiles per dW wave: tiles t = w', w'+4, ... -> (t / NT, t % NT)
+  constexpr int TENSOR = NT * B2_PANEL;         // one (64-row x E) bf16 tensor in the panel layout
+  constexpr int TPW = NT * NT / B2_DW;          // dW output tiles per dW wave: tiles t = w'*TPW + k -> (t / NT, t % NT)
   static_assert((NT * NT) % B2_DW == 0, "E must be a multiple of 32");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* Ws = reinterpret_cast<uint4*>(smem);
-  uint4* WTs = Ws + L * FRAG;
-  float* bs = reinterpret_cast<float*>(WTs + L * FRAG);
-  char* stage = reinterpret_cast<char*>(bs + L * E);          // [buffer 2][du | x][B2_ROWS][STR]
-  for (int i = threadIdx.x; i < L * FRAG; i += blockDim.x) { Ws[i] = Wp[i]; WTs[i] = WTp[i]; }
-  for (int i = threadIdx.x; i < L * E; i += blockDim.x) bs[i] = bp[i];
+  float* bs = reinterpret_cast<float*>(Ws + L * FRAG);
+  char* xstore = reinterpret_cast<char*>(bs + L * E);         // [layer L][panel NT][B2_ROWS][32 B]
+  char* duslab = xstore + L * TENSOR;                         // [buffer 2][panel NT][B2_ROWS][32 B]
+  for (int i = threadIdx.x; i < L * FRAG; i += blockDim.x) Ws[i] = Wp[i];
+  for (int i = threadIdx.x; i < L * E; i += blockDim.x) bs[i] = bp[i] + 1.f;      // the backward only ever needs u_l + 1
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, r = lane & 15;
   const int64_t ngroups = (rows + B2_ROWS - 1) / B2_ROWS;
@@ -449,28 +300,30 @@ __global__ __launch_bounds__(64 * (B2_CHAIN + B2_DW), 2) void cross_mfma_bwd2_ke
   if (wave < B2_CHAIN) {
     // ------------------------------------------------------------------ chain waves
     uint4 nx_raw[KS], ng_raw[KS];
+    // Prefetch of a later group's rows.  The loads are UNCONDITIONAL (row index clamped into the tensor, out-of-range
+    // rows zeroed when consumed): loads under a branch make hipcc's wait-count insertion pessimistic -- it then waits
+    // for these just-issued loads wherever an older load is consumed, i.e. one exposed HBM round trip per group.
     auto fetch = [&](int64_t grp_) {
-      const int64_t row_ = grp_ * B2_ROWS + wave * 16 + r;
+      int64_t row_ = grp_ * B2_ROWS + wave * 16 + r;
+      row_ = row_ < rows ? row_ : rows - 1;
 #pragma unroll
       for (int c = 0; c < KS; ++c) {
-        nx_raw[c] = make_uint4(0, 0, 0, 0);
-        ng_raw[c] = make_uint4(0, 0, 0, 0);
-        if (grp_ < ngroups && row_ < rows) {
-          nx_raw[c] = x[(row_ * E + 32 * c + 8 * q) >> 3];
-          ng_raw[c] = gout[(row_ * E + 32 * c + 8 * q) >> 3];
-        }
+        nx_raw[c] = x[(row_ * E + 32 * c + 8 * q) >> 3];
+        ng_raw[c] = gout[(row_ * E + 32 * c + 8 * q) >> 3];
       }
     };
     fetch(blockIdx.x);
-    char* const myrow = stage + (wave * 16 + r) * STR + 16 * q;
+    // this lane's 16-byte pieces of a row tensor: piece c covers columns 32c+8q .. +7 -> panel 2c + (q>>1), half q&1
+    const int piece0 = (q >> 1) * B2_PANEL + (wave * 16 + r) * 32 + (q & 1) * 16;
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x, step0 += L + 1) {
       XTile<NT> g, dx0;
-      uint4 Bx[L][1][KS];
+      uint4 B0[1][KS];
+      const bool live = grp * B2_ROWS + wave * 16 + r < rows;
 #pragma unroll
       for (int c = 0; c < KS; ++c) {
-        Bx[0][0][c] = nx_raw[c];
+        B0[0][c] = live ? nx_raw[c] : make_uint4(0, 0, 0, 0);
         float f[8];
-        Vec16<bf16_t>::unpack(ng_raw[c], f);
+        Vec16<bf16_t>::unpack(live ? ng_raw[c] : make_uint4(0, 0, 0, 0), f);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           g.v[2 * c][i] = f[i];
@@ -482,51 +335,62 @@ __global__ __launch_bounds__(64 * (B2_CHAIN + B2_DW), 2) void cross_mfma_bwd2_ke
 #pragma unroll
         for (int i = 0; i < 4; ++i) dx0.v[mt][i] = 0.f;
       fetch(grp + gridDim.x);
-      // x0 is bf16 in memory: its fp32 values are re-derived from Bx[0] where needed
-      auto x0v = [&](int mt, int i) -> float {
-        const uint4& u = Bx[0][0][mt >> 1];
-        const unsigned w = (mt & 1) ? (i < 2 ? u.z : u.w) : (i < 2 ? u.x : u.y);
-        return (i & 1) ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16);
-      };
-      // step 0: forward recompute of x_1 .. x_{L-1} (bf16 B fragments, the values the forward kernel produced)
+      // step 0: forward recompute; x_1 .. x_{L-1} go to the x store (x_0 follows in step 1, see below); u_l + 1 of every
+      // layer stays in registers as packed bf16 (the backward needs it once, in dx0 += g_{l+1} * (u_l + 1))
+      uint4 U1[L][KS];
+      {
+        uint4 Bl[1][KS];
 #pragma unroll
-      for (int l = 0; l + 1 < L; ++l) {
-        f32x4 acc[1][NT];
-        layer_matmul<NT, 1>(Ws + l * FRAG, bs + l * E, Bx[l], lane, q, acc);
-        XTile<NT> nx;
+        for (int c = 0; c < KS; ++c) Bl[0][c] = B0[0][c];
 #pragma unroll
-        for (int mt = 0; mt < NT; ++mt)
+        for (int l = 0; l < L; ++l) {
+          f32x4 acc[1][NT];
+          layer_matmul_pre<NT, false>(Ws + l * FRAG, bs + l * E, Bl[0], lane, q, acc[0]);
+          XTile<NT> up;                    // u_l + 1 (the +1 rides in the bias)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) nx.v[mt][i] = fmaf(x0v(mt, i), acc[0][mt][i], x0v(mt, i));
-        pack_tile<NT>(nx, Bx[l + 1][0]);
+          for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) up.v[mt][i] = acc[0][mt][i];
+          pack_tile<NT>(up, U1[l]);
+          if (l + 1 < L) {
+            XTile<NT> nx;
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) nx.v[mt][i] = frag_value<KS>(B0[0], mt, i) * up.v[mt][i];
+            pack_tile<NT>(nx, Bl[0]);
+#pragma unroll
+            for (int c = 0; c < KS; ++c)
+              *reinterpret_cast<uint4*>(xstore + (l + 1) * TENSOR + piece0 + 2 * c * B2_PANEL) = Bl[0][c];
+          }
+        }
       }
       __syncthreads();
       // steps 1..L: layers L-1 .. 0
 #pragma unroll
       for (int l = L - 1; l >= 0; --l) {
-        char* rowp = myrow + (((step0 + (L - l)) & 1) ? 2 * SLAB : 0);
-        f32x4 acc[1][NT];
-        layer_matmul<NT, 1>(Ws + l * FRAG, bs + l * E, Bx[l], lane, q, acc);   // u_l
+        char* slab = duslab + (((step0 + (L - l)) & 1) ? TENSOR : 0);
+        if (l == L - 1) {
+          // x_0 of THIS group: only now, the dW waves read the previous group's x_0 during step 0
+#pragma unroll
+          for (int c = 0; c < KS; ++c) *reinterpret_cast<uint4*>(xstore + piece0 + 2 * c * B2_PANEL) = B0[0][c];
+        }
         XTile<NT> du;
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            du.v[mt][i] = g.v[mt][i] * x0v(mt, i);
-            dx0.v[mt][i] = fmaf(g.v[mt][i], acc[0][mt][i] + 1.f, dx0.v[mt][i]);
+            du.v[mt][i] = g.v[mt][i] * frag_value<KS>(B0[0], mt, i);
+            dx0.v[mt][i] = fmaf(g.v[mt][i], frag_value<KS>(U1[l], mt, i), dx0.v[mt][i]);
           }
         uint4 Bdu[1][KS];
         pack_tile<NT>(du, Bdu[0]);
-        // hand du_l and x_l to the dW waves as plain rows
 #pragma unroll
-        for (int c = 0; c < KS; ++c) {
-          *reinterpret_cast<uint4*>(rowp + 64 * c) = Bdu[0][c];
-          *reinterpret_cast<uint4*>(rowp + SLAB + 64 * c) = Bx[l][0][c];
-        }
+        for (int c = 0; c < KS; ++c) *reinterpret_cast<uint4*>(slab + piece0 + 2 * c * B2_PANEL) = Bdu[0][c];
         const bool need_g = (l > 0) || (detach_first == 0);
         if (need_g) {
           f32x4 ga[1][NT];
-          layer_matmul<NT, 1>(WTs + l * FRAG, nullptr, Bdu, lane, q, ga);
+          layer_matmul_pre<NT, true>(Ws + l * FRAG, nullptr, Bdu[0], lane, q, ga[0]);
 #pragma unroll
           for (int mt = 0; mt < NT; ++mt)
 #pragma unroll
@@ -558,42 +422,42 @@ __global__ __launch_bounds__(64 * (B2_CHAIN + B2_DW), 2) void cross_mfma_bwd2_ke
 #pragma unroll
       for (int k = 0; k < TPW; ++k) dWacc[l][k] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    auto consume = [&](const char* buf, f32x4 (&acc)[TPW], float& db) {
+    auto consume = [&](const char* du_t, const char* x_t, f32x4 (&acc)[TPW], float& db) {
 #pragma unroll
       for (int ks = 0; ks < B2_ROWS / 32; ++ks) {
 #pragma unroll
         for (int k = 0; k < TPW; ++k) {
-          const int t = wq + B2_DW * k, mo = t / NT, no = t % NT;
-          const s16x8 A = slab_frag(buf, STR, 32 * ks + 8 * q, 16 * mo, r);
-          const s16x8 Bf = slab_frag(buf + SLAB, STR, 32 * ks + 8 * q, 16 * no, r);
+          const int t = wq * TPW + k, mo = t / NT, no = t % NT;      // NT = 4: one output row tile, all four column tiles
+          const s16x8 A = rows_frag(du_t, 32 * ks + 8 * q, mo, r);
+          const s16x8 Bf = rows_frag(x_t, 32 * ks + 8 * q, no, r);
           acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, Bf),
                                                            acc[k], 0, 0, 0);
-          if (no == mo % NT && (NT >= B2_DW ? mo == wq : true)) {
-            // db: this lane's 8 rows of column e_out = 16*mo + r (every mo is taken by exactly one wave)
+          if (k == 0) {
+            // db: this lane's 8 rows of column e_out = 16*mo + r; the wave whose first tile has no == 0 owns row tile mo
             float sum = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) sum += bf16_bits_to_f32((uint32_t)(uint16_t)A[j]);
-            db += sum;
+            db += (no == 0) ? sum : 0.f;
           }
         }
       }
     };
     bool first = true;
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x, step0 += L + 1) {
-      // step 0: layer 0 of the previous group (written in its last step)
-      if (!first) consume(stage + (((step0 - 1) & 1) ? 2 * SLAB : 0), dWacc[0], dbacc[0]);
+      // step 0: layer 0 of the previous group (its du was written in that group's last step)
+      if (!first) consume(duslab + (((step0 - 1) & 1) ? TENSOR : 0), xstore, dWacc[0], dbacc[0]);
       first = false;
       __syncthreads();
 #pragma unroll
       for (int l = L - 1; l >= 0; --l) {
-        // step L-l: the chain waves are on layer l; these waves take layer l+1, written one step earlier
+        // step L-l: the chain waves are on layer l; these waves take layer l+1, whose du was written one step earlier
         if (l + 1 < L)
-          consume(stage + (((step0 + (L - l) - 1) & 1) ? 2 * SLAB : 0), dWacc[l + 1 < L ? l + 1 : 0],
-                  dbacc[l + 1 < L ? l + 1 : 0]);
+          consume(duslab + (((step0 + (L - l) - 1) & 1) ? TENSOR : 0), xstore + (l + 1 < L ? l + 1 : 0) * TENSOR,
+                  dWacc[l + 1 < L ? l + 1 : 0], dbacc[l + 1 < L ? l + 1 : 0]);
         __syncthreads();
       }
     }
-    if (!first) consume(stage + (((step0 - 1) & 1) ? 2 * SLAB : 0), dWacc[0], dbacc[0]);
+    if (!first) consume(duslab + (((step0 - 1) & 1) ? TENSOR : 0), xstore, dWacc[0], dbacc[0]);
     // partial results of this workgroup: D layout -> (row m = 4q+i -> e_out, col n = r -> e_in)
     float* myW = dWpart + (size_t)blockIdx.x * L * E * E;
     float* myb = dbpart + (size_t)blockIdx.x * L * E;
@@ -601,10 +465,10 @@ __global__ __launch_bounds__(64 * (B2_CHAIN + B2_DW), 2) void cross_mfma_bwd2_ke
     for (int l = 0; l < L; ++l) {
 #pragma unroll
       for (int k = 0; k < TPW; ++k) {
-        const int t = wq + B2_DW * k, mo = t / NT, no = t % NT;
+        const int t = wq * TPW + k, mo = t / NT, no = t % NT;
 #pragma unroll
         for (int i = 0; i < 4; ++i) myW[(size_t)l * E * E + (16 * mo + 4 * q + i) * E + 16 * no + r] = dWacc[l][k][i];
-        if (no == mo % NT && (NT >= B2_DW ? mo == wq : true)) {
+        if (k == 0 && no == 0) {
           float v = dbacc[l];            // the four q-groups hold different rows of the same column
           v += __shfl_xor(v, 16, 64);
           v += __shfl_xor(v, 32, 64);
@@ -615,23 +479,29 @@ __global__ __launch_bounds__(64 * (B2_CHAIN + B2_DW), 2) void cross_mfma_bwd2_ke
   }
 }
 
+// out[i] += sum_p part[p][i]: 64 elements per workgroup, the partials split four ways over threadIdx.y (fixed order:
+// the sum does not depend on timing)
 __global__ __launch_bounds__(256) void cross_reduce_partials_kernel(const float* __restrict__ part, int nparts,
                                                                     int n, float* __restrict__ out) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * n + i];
-    out[i] += s;
-  }
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + tx;
+  float s = 0.f;
+  if (i < n)
+    for (int p = ty; p < nparts; p += 4) s += part[(size_t)p * n + i];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && i < n) out[i] += (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
 }
 
-constexpr int BW_MAX_BLOCKS = 256;
+constexpr int BW_MAX_BLOCKS = 256;      // one persistent workgroup per CU
 
 static size_t cross_pack_bytes(int E, int L) { return (size_t)L * E * E * 2; }
 
 size_t cross_mfma_workspace_bytes(int E, int L) {
-  // [Wp fwd][Wp transposed][bias fp32][per-workgroup dW partials][db partials], each 256-byte aligned
+  // [W fragments][bias fp32][per-workgroup dW partials][db partials], each 256-byte aligned
   auto al = [](size_t v) { return (v + 255) / 256 * 256; };
-  return 2 * al(cross_pack_bytes(E, L)) + al((size_t)L * E * 4) + al((size_t)BW_MAX_BLOCKS * L * E * E * 4) +
+  return al(cross_pack_bytes(E, L)) + al((size_t)L * E * 4) + al((size_t)BW_MAX_BLOCKS * L * E * E * 4) +
          al((size_t)BW_MAX_BLOCKS * L * E * 4);
 }
 
@@ -643,8 +513,8 @@ int cross_mfma_fwd(const void* x, const void* W, const void* b, int64_t rows, in
   if (ws_bytes < cross_mfma_workspace_bytes(E, L)) return fail(TRS_EWORKSPACE, "cross_fwd: workspace too small");
   auto al = [](size_t v) { return (v + 255) / 256 * 256; };
   bf16_t* Wp = (bf16_t*)workspace;
-  float* bp = (float*)((char*)workspace + 2 * al(cross_pack_bytes(E, L)));
-  hipLaunchKernelGGL((cross_prepack_kernel<false>), dim3(std::min(64, (L * E * E / 8 + 255) / 256)), dim3(256), 0, s,
+  float* bp = (float*)((char*)workspace + al(cross_pack_bytes(E, L)));
+  hipLaunchKernelGGL((cross_prepack_kernel), dim3(std::min(64, (L * E * E / 8 + 255) / 256)), dim3(256), 0, s,
                      (const bf16_t*)W, (const bf16_t*)b, Wp, bp, E, L);
   const size_t lds = cross_pack_bytes(E, L) + (size_t)L * E * 4;
   const bool resident = lds <= 64 * 1024;
@@ -670,11 +540,11 @@ int cross_mfma_fwd(const void* x, const void* W, const void* b, int64_t rows, in
 }
 
 template <int NT, int L>
-static int cross_bwd_launch(const void* x, const void* g, const uint4* Wp, const uint4* WTp, const float* bp, int64_t rows,
+static int cross_bwd_launch(const void* x, const void* g, const uint4* Wp, const float* bp, int64_t rows,
                             void* dx, float* dWpart, float* dbpart, float* dW, float* db, int detach_first,
                             hipStream_t s) {
   constexpr int E = NT * 16;
-  const size_t lds = (size_t)2 * L * E * E * 2 + (size_t)L * E * 4 + (size_t)4 * B2_ROWS * (E * 2 + 16);
+  const size_t lds = (size_t)L * E * E * 2 + (size_t)L * E * 4 + (size_t)(L + 2) * NT * B2_PANEL;
   auto kern = cross_mfma_bwd2_kernel<NT, L>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -684,11 +554,11 @@ static int cross_bwd_launch(const void* x, const void* g, const uint4* Wp, const
   }
   const int64_t ngroups = (rows + B2_ROWS - 1) / B2_ROWS;
   const int grid = (int)std::min<int64_t>(ngroups, BW_MAX_BLOCKS);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (B2_CHAIN + B2_DW)), lds, s, (const uint4*)x, (const uint4*)g, Wp, WTp,
-                     bp, rows, (uint4*)dx, dWpart, dbpart, detach_first);
-  hipLaunchKernelGGL(cross_reduce_partials_kernel, dim3((L * E * E + 255) / 256), dim3(256), 0, s, dWpart, grid,
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (B2_CHAIN + B2_DW)), lds, s, (const uint4*)x, (const uint4*)g, Wp, bp, rows,
+                     (uint4*)dx, dWpart, dbpart, detach_first);
+  hipLaunchKernelGGL(cross_reduce_partials_kernel, dim3((L * E * E + 63) / 64), dim3(256), 0, s, dWpart, grid,
                      L * E * E, dW);
-  hipLaunchKernelGGL(cross_reduce_partials_kernel, dim3((L * E + 255) / 256), dim3(256), 0, s, dbpart, grid, L * E, db);
+  hipLaunchKernelGGL(cross_reduce_partials_kernel, dim3((L * E + 63) / 64), dim3(256), 0, s, dbpart, grid, L * E, db);
   return check_launch("cross_bwd(mfma)");
 }
 
@@ -701,18 +571,14 @@ int cross_mfma_bwd(const void* x, const void* W, const void* b, const void* g, i
   auto al = [](size_t v) { return (v + 255) / 256 * 256; };
   char* ws = (char*)workspace;
   bf16_t* Wp = (bf16_t*)ws;
-  bf16_t* WTp = (bf16_t*)(ws + al(cross_pack_bytes(E, L)));
-  float* bp = (float*)(ws + 2 * al(cross_pack_bytes(E, L)));
+  float* bp = (float*)(ws + al(cross_pack_bytes(E, L)));
   float* dWpart = (float*)((char*)bp + al((size_t)L * E * 4));
   float* dbpart = (float*)((char*)dWpart + al((size_t)BW_MAX_BLOCKS * L * E * E * 4));
   const int pgrid = std::min(64, (L * E * E / 8 + 255) / 256);
-  hipLaunchKernelGGL((cross_prepack_kernel<false>), dim3(pgrid), dim3(256), 0, s, (const bf16_t*)W, (const bf16_t*)b, Wp,
-                     bp, E, L);
-  hipLaunchKernelGGL((cross_prepack_kernel<true>), dim3(pgrid), dim3(256), 0, s, (const bf16_t*)W, (const bf16_t*)b, WTp,
-                     (float*)nullptr, E, L);
+  hipLaunchKernelGGL((cross_prepack_kernel), dim3(pgrid), dim3(256), 0, s, (const bf16_t*)W, (const bf16_t*)b, Wp, bp, E,
+                     L);
 #define TRS_CB(NT_, L_)                                                                                              \
-  return cross_bwd_launch<NT_, L_>(x, g, (const uint4*)Wp, (const uint4*)WTp, bp, rows, dx, dWpart, dbpart, dW, db,  \
-                                   detach_first, s)
+  return cross_bwd_launch<NT_, L_>(x, g, (const uint4*)Wp, bp, rows, dx, dWpart, dbpart, dW, db, detach_first, s)
   if (E == 32) {
     switch (L) {
       case 1: TRS_CB(2, 1);
