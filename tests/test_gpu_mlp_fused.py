@@ -1,0 +1,111 @@
+"""the per-field MLP (DeepAndCrossNetwork's deep branch, models/ctr/deep_and_cross_network.py:71-87 ->
+layers/ctr/multilayer_perceptron.py:63-84) as one HIP kernel per direction (trs_mlp_fused_*), against the oracle's
+``mlp`` in fp32 on the same bf16-rounded parameters: output, input gradient, every weight / bias gradient."""
+import pytest
+import torch
+
+from conftest import rel_err, rel_err_rows
+from oracle import cpu_ref as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-2            # north_star: 1e-2 relative for bf16
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _params(widths, g):
+    Ws = [(torch.randn(o, i, generator=g) / i ** 0.5).bfloat16() for i, o in zip(widths[:-1], widths[1:])]
+    bs = [(0.1 * torch.randn(o, generator=g)).bfloat16() for o in widths[1:]]
+    return Ws, bs
+
+
+@pytest.mark.parametrize("shape,widths", [((700, 7), [64, 400, 400, 400, 64]),      # the DCN stack, ragged last tile
+                                          ((4096,), [16, 72, 8]),                  # widths that are not multiples of 32
+                                          ((33, 130), [64, 512, 64]),              # the widest supported layer
+                                          ((5000,), [32, 104, 200, 40]),
+                                          ((4224,), [128, 96, 96, 96, 96, 96, 24])])
+def test_fused_mlp_vs_oracle(dev, shape, widths):
+    from torecsys_amd import functional as F_
+    g = torch.Generator().manual_seed(sum(widths) + shape[0])
+    Ws, bs = _params(widths, g)
+    x = torch.randn(*shape, widths[0], generator=g).bfloat16()
+    gy = torch.randn(*shape, widths[-1], generator=g).bfloat16()
+    xd = x.to(dev).requires_grad_()
+    Wd = [w.to(dev).requires_grad_() for w in Ws]
+    bd = [b.to(dev).requires_grad_() for b in bs]
+    assert F_.mlp_fused_supported(xd, widths)
+    y = F_.fused_mlp(xd, Wd, bd)
+    assert y.shape == (*shape, widths[-1]) and y.dtype == torch.bfloat16
+    y.backward(gy.to(dev))
+    rows = lambda t: t.reshape(-1, t.shape[-1])
+    # forward against the oracle as it is
+    yo = O.mlp(x.float(), [w.float() for w in Ws], [b.float() for b in bs])
+    assert rel_err(y.float().cpu(), yo) <= TOL
+    assert rel_err_rows(rows(y.float().cpu()), rows(yo), floor_frac=5e-2) <= 2 * TOL
+    # gradients against the oracle UNDER THE KERNEL'S OWN ReLU MASKS (a hidden unit whose pre-activation bf16
+    # rounding moves across zero changes the gradient by a whole term -- see tests/test_gpu_cin_parity.py): the
+    # masks are the bit masks the forward kernel hands to the backward kernel
+    _, hidden, masks = F_.fused_mlp_forward_raw(rows(x).to(dev), [w.to(dev) for w in Ws], [b.to(dev) for b in bs])
+    unpacked = []
+    for l, m in enumerate(masks):
+        bits = ((m.cpu().unsqueeze(-1) >> torch.arange(8, dtype=torch.uint8)) & 1).reshape(m.shape[0], -1)
+        unpacked.append(bits[:, :widths[l + 1]].float().reshape(*shape, widths[l + 1]))
+        h = hidden[l].float().cpu()
+        assert torch.equal(h[:, :widths[l + 1]] > 0, bits[:, :widths[l + 1]].bool())      # mask == sign of what was stored
+        assert float(h[:, widths[l + 1]:].abs().max() if h.shape[1] > widths[l + 1] else 0.0) == 0.0
+    it = iter(unpacked)
+    xr = x.float().requires_grad_()
+    Wr = [w.float().requires_grad_() for w in Ws]
+    br = [b.float().requires_grad_() for b in bs]
+    yr = O.mlp(xr, Wr, br, activation=lambda t: t * next(it))
+    yr.backward(gy.float())
+    flips = sum(float(((a > 0).float() != m).float().mean()) for a, m in zip(
+        [torch.relu(torch.nn.functional.linear(x.float(), Ws[0].float(), bs[0].float()))], unpacked[:1]))
+    assert flips <= 2e-2
+    assert rel_err(xd.grad.float().cpu(), xr.grad) <= TOL
+    assert rel_err_rows(rows(xd.grad.float().cpu()), rows(xr.grad), floor_frac=5e-2) <= 2 * TOL
+    for l, (a, b) in enumerate(zip(Wd, Wr)):
+        assert rel_err(a.grad.float().cpu(), b.grad) <= TOL, ("dW", l)
+    for l, (a, b) in enumerate(zip(bd, br)):
+        assert rel_err(a.grad.float().cpu(), b.grad) <= TOL, ("db", l)
+
+
+def test_mlp_layer_takes_fused_path_and_matches_gemm_path(dev):
+    """MultilayerPerceptionLayer on a (B,N,E) block: the fused kernels and the hipBLASLt arrangement they replace give
+    the same numbers (both bf16; compared with each other at 2e-2 and each with the oracle above / in test_gpu_mlp.py)."""
+    from torecsys_amd import functional as F_
+    from torecsys_amd.layers import DNNLayer
+    torch.manual_seed(5)
+    lay = DNNLayer(inputs_size=64, output_size=64, layer_sizes=[400, 400, 400]).to(dev).bfloat16()
+    x = torch.randn(256, 39, 64, device=dev).bfloat16()
+    calls = []
+    orig = F_.fused_mlp
+    F_.fused_mlp = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        xa = x.clone().requires_grad_()
+        ya = lay(xa)
+    finally:
+        F_.fused_mlp = orig
+    assert calls, "the layer did not take the fused path"
+    assert ya.names == ("B", "N", "O")
+    go = torch.randn_like(ya.rename(None))
+    ya.rename(None).backward(go)
+    ga = [p.grad.clone() for p in lay.parameters()]
+    lay.zero_grad()
+    saved = F_.FUSED_MLP
+    F_.FUSED_MLP = False
+    try:
+        xb = x.clone().requires_grad_()
+        yb = lay(xb)
+    finally:
+        F_.FUSED_MLP = saved
+    yb.rename(None).backward(go)
+    assert rel_err(ya.rename(None).float(), yb.rename(None).float()) <= 2e-2
+    assert rel_err(xa.grad.float(), xb.grad.float()) <= 2e-2
+    for a, p in zip(ga, lay.parameters()):
+        assert rel_err(a.float(), p.grad.float()) <= 2e-2

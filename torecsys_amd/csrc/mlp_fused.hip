@@ -1,0 +1,519 @@
+// the per-field MLP of DeepAndCrossNetwork (models/ctr/deep_and_cross_network.py:71-87 applies
+// MultilayerPerceptionLayer, layers/ctr/multilayer_perceptron.py:63-84, to every (sample, field) row of the (B,N,E)
+// block: B*N = 2.5 M rows of 64 -> 400 -> 400 -> 400 -> 64) as ONE kernel per direction, bf16 on the matrix cores.
+//
+// A workgroup (8 waves) owns 128 rows at a time and walks the whole layer stack with the activations of those rows in
+// LDS: a layer's input is read from LDS as MFMA B operands (16-byte reads of [row][k]), its output goes back to LDS
+// from the accumulators as 16-byte row pieces (the W rows are fed in the permuted slot order of cross_mfma.hip, so a
+// lane's 8 outputs of a column pair are 8 consecutive columns of its row) and becomes the next layer's input.  The
+// weights (0.74 MB for the DCN stack: they do not fit in LDS) are pre-packed once per call into MFMA fragment order
+// and streamed from L2 straight into registers: the output columns of a layer are split over the 8 waves, so every
+// weight byte is loaded once per workgroup and no weight passes through LDS.  HBM sees the rows once per tensor:
+//   forward : x read; every hidden activation written once (the weight-gradient GEMMs need them) + a 1-bit ReLU mask;
+//   backward: the output gradient read; d(pre-activation) of every layer written once (again for the weight
+//             gradients), the masks read (52 bytes per row and layer instead of a 832-byte activation row), column
+//             sums (bias gradients) accumulated on chip, dx written.
+// The unfused pipeline (hipBLASLt GEMMs + trs_relu_bwd_bias) moves ~16 GB of hidden activations per step and pads the
+// 400-wide layers to 512 columns; here the widths are padded to 32 (416).  The weight gradients stay GEMMs with
+// K = rows (torch.bmm split-K + trs_wgrad_finish) on the tensors this kernel writes.
+#include <algorithm>
+
+#include "trs_common.hpp"
+
+namespace trs {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 mf_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float mf_f32x4;
+
+constexpr int MF_ROWS = 128;          // rows per workgroup pass
+constexpr int MF_MT = MF_ROWS / 16;   // 16-row tiles
+constexpr int MF_WAVES = 8;
+constexpr int MF_MAXP = 2;            // 32-column pairs per wave: widths up to 8 * 2 * 32 = 512
+constexpr int MF_MAXL = 8;
+constexpr int MF_MASK_STR = 64;       // mask bytes per row (512 columns / 8)
+
+// column of D-row slot m (= 4*q + i) of 16-column tile mt: the two tiles of a pair interleave 4-column groups, so that
+// a lane's (tile 2p, tile 2p+1) outputs are the 8 consecutive columns 32p + 8q .. +7 of its row
+__host__ __device__ __forceinline__ int mf_col_of_slot(int mt, int m) {
+  return 32 * (mt >> 1) + 8 * (m >> 2) + 4 * (mt & 1) + (m & 3);
+}
+
+// Fragment order: frag (mt, ks) = 64 lanes x 8 bf16; lane (m = lane&15, q = lane>>4) holds
+//   forward : W[col(mt, m)][32*ks + 8*q + j]        (out = W's rows, contraction over W's columns)
+//   backward: W[32*ks + 8*q + j][col(mt, m)]        (out = W's columns, contraction over W's rows)
+// zero outside the logical (out_f, in_f) matrix.  bias -> fp32, zero padded.
+__global__ __launch_bounds__(256) void mlp_prepack_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ b,
+                                                          int out_f, int in_f, int transpose, int NTt /* out tiles */,
+                                                          int KS, bf16_t* __restrict__ Wf, float* __restrict__ bf,
+                                                          int bias_n) {
+  const int total = NTt * KS * 64;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+    const int lane = t & 63;
+    const int f = t >> 6;
+    const int ks = f % KS, mt = f / KS;
+    const int oc = mf_col_of_slot(mt, lane & 15);
+    const int k0 = 32 * ks + 8 * (lane >> 4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + j;
+      bf16_t v{0};
+      if (!transpose) {
+        if (oc < out_f && k < in_f) v = W[(size_t)oc * in_f + k];
+      } else {
+        if (oc < in_f && k < out_f) v = W[(size_t)k * in_f + oc];
+      }
+      Wf[(size_t)t * 8 + j] = v;
+    }
+  }
+  if (bf != nullptr)
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < bias_n; t += gridDim.x * blockDim.x)
+      bf[t] = (b != nullptr && t < out_f) ? to_f32(b[t]) : 0.f;
+}
+
+struct MlpStep {
+  const uint4* wf;    // fragment-order weights of this step
+  const float* bias;  // fp32, padded (forward) or null
+  void* out;          // global output of the step (rows x out_stride elements), may be null
+  uint8_t* mask;      // forward: mask written for this step's output; backward: mask applied to this step's output
+  float* colsum;      // backward: partial column sums of this step's INPUT, [gridDim.x][K] (may be null)
+  int K, N;           // padded contraction / output widths (multiples of 32)
+  int out_stride;     // elements per global output row
+  int relu;           // forward: ReLU on the output
+};
+struct MlpArgs {
+  MlpStep step[MF_MAXL];
+  int nsteps;
+  const void* in;     // (rows x in_stride) bf16
+  int in_stride;      // elements per input row (= its logical width, a multiple of 8)
+  int nbias;          // forward: total padded bias entries (copied to LDS)
+  int64_t rows;
+  int act_str;        // bytes per LDS activation row
+};
+
+// tiles of the step owned by this wave: wide outputs split the 32-column pairs over the 8 waves (all 8 row tiles
+// each); narrow outputs (<= 4 pairs) also split the row tiles so that no wave idles
+struct MlpShare {
+  int npw;              // pairs of this wave (0..MF_MAXP)
+  int pair[MF_MAXP];
+  int mt0, mcnt;        // row tiles mt0 .. mt0+mcnt-1
+};
+__device__ __forceinline__ MlpShare mlp_share(int N, int wave) {
+  MlpShare s;
+  const int npairs = N >> 5;
+  if (npairs > 4) {
+    s.mt0 = 0;
+    s.mcnt = MF_MT;
+    s.npw = 0;
+#pragma unroll
+    for (int i = 0; i < MF_MAXP; ++i) {
+      s.pair[i] = wave + MF_WAVES * i;
+      if (s.pair[i] < npairs) s.npw = i + 1;
+    }
+  } else {
+    const int ng = npairs <= 1 ? 1 : (npairs == 2 ? 2 : 4);     // pair groups; MF_WAVES / ng row groups
+    const int mg = MF_WAVES / ng;
+    s.mcnt = MF_MT / mg;
+    s.mt0 = (wave / ng) * s.mcnt;
+    s.pair[0] = wave % ng;
+    s.pair[1] = 0;
+    s.npw = s.pair[0] < npairs ? 1 : 0;
+  }
+  return s;
+}
+
+// acc[mi][2*pi + h] (+)= sum_k W-frag(pair pi, half h, ks) x act rows of tile mt0+mi
+__device__ __forceinline__ void mlp_gemm(const char* act, int act_str, const uint4* __restrict__ wf, int K,
+                                         const MlpShare& sh, int lane, mf_f32x4 (&acc)[MF_MT][2 * MF_MAXP]) {
+  const int KS = K >> 5;
+  const int r = lane & 15, q = lane >> 4;
+  const char* arow = act + (sh.mt0 * 16 + r) * act_str + q * 16;
+  for (int ks = 0; ks < KS; ++ks) {
+    uint4 B[MF_MT];
+#pragma unroll
+    for (int mi = 0; mi < MF_MT; ++mi)
+      if (mi < sh.mcnt) B[mi] = *reinterpret_cast<const uint4*>(arow + mi * 16 * act_str + ks * 64);
+#pragma unroll
+    for (int pi = 0; pi < MF_MAXP; ++pi) {
+      if (pi < sh.npw) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const uint4 a = wf[((size_t)(2 * sh.pair[pi] + h) * KS + ks) * 64 + lane];
+#pragma unroll
+          for (int mi = 0; mi < MF_MT; ++mi)
+            if (mi < sh.mcnt)
+              acc[mi][2 * pi + h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                  __builtin_bit_cast(mf_bf16x8, a), __builtin_bit_cast(mf_bf16x8, B[mi]), acc[mi][2 * pi + h], 0, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+// LDS rows [0, MF_ROWS) x ncols(bf16) -> global (row0 + r, .) ; 16-byte pieces, whole rows coalesced
+__device__ __forceinline__ void mlp_copy_out(const char* act, int act_str, void* out, int out_stride, int ncols,
+                                             int64_t row0, int64_t rows) {
+  if (out == nullptr) return;
+  const int cpr = ncols >> 3;   // 16-byte chunks per row
+  for (int t = threadIdx.x; t < MF_ROWS * cpr; t += blockDim.x) {
+    const int r = t / cpr, c = t - r * cpr;
+    if (row0 + r < rows)
+      store_stream(reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(out) + (row0 + r) * out_stride) + c,
+                   *reinterpret_cast<const uint4*>(act + r * act_str + c * 16));
+  }
+}
+
+// global rows (row0 + r, 0 .. in_stride) -> LDS rows, zero-filled up to ``ncols`` columns and past the last row
+__device__ __forceinline__ void mlp_load_in(char* act, int act_str, const void* in, int in_stride, int ncols, int64_t row0,
+                                            int64_t rows) {
+  const int cpr = ncols >> 3, cin = in_stride >> 3;
+  for (int t = threadIdx.x; t < MF_ROWS * cpr; t += blockDim.x) {
+    const int r = t / cpr, c = t - r * cpr;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row0 + r < rows && c < cin)
+      v = *(reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(in) + (row0 + r) * in_stride) + c);
+    *reinterpret_cast<uint4*>(act + r * act_str + c * 16) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_fwd_kernel(MlpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* act = smem;                                          // [MF_ROWS][act_str]
+  uint8_t* mask = reinterpret_cast<uint8_t*>(act + MF_ROWS * a.act_str);   // [MF_ROWS][MF_MASK_STR]
+  float* bias_s = reinterpret_cast<float*>(mask + MF_ROWS * MF_MASK_STR);   // all layers' padded biases, back to back
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, r = lane & 15;
+  for (int i = threadIdx.x; i < a.nbias; i += blockDim.x) bias_s[i] = a.step[0].bias[i];
+  const int64_t ntiles = (a.rows + MF_ROWS - 1) / MF_ROWS;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t row0 = tile * MF_ROWS;
+    mlp_load_in(act, a.act_str, a.in, a.in_stride, a.step[0].K, row0, a.rows);
+    __syncthreads();
+    int boff = 0;
+    for (int l = 0; l < a.nsteps; ++l) {
+      const MlpStep st = a.step[l];
+      const MlpShare sh = mlp_share(st.N, wave);
+      mf_f32x4 acc[MF_MT][2 * MF_MAXP];
+#pragma unroll
+      for (int pi = 0; pi < MF_MAXP; ++pi)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          mf_f32x4 init = mf_f32x4{0.f, 0.f, 0.f, 0.f};
+          if (pi < sh.npw) {
+            const float4 bv = *reinterpret_cast<const float4*>(bias_s + boff + 32 * sh.pair[pi] + 8 * q + 4 * h);
+            init = mf_f32x4{bv.x, bv.y, bv.z, bv.w};
+          }
+#pragma unroll
+          for (int mi = 0; mi < MF_MT; ++mi) acc[mi][2 * pi + h] = init;
+        }
+      mlp_gemm(act, a.act_str, st.wf, st.K, sh, lane, acc);
+      __syncthreads();      // every wave is done reading the layer's input (and the previous copy-out has left LDS)
+#pragma unroll
+      for (int pi = 0; pi < MF_MAXP; ++pi) {
+        if (pi < sh.npw) {
+#pragma unroll
+          for (int mi = 0; mi < MF_MT; ++mi) {
+            if (mi < sh.mcnt) {
+              float v[8];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                v[i] = acc[mi][2 * pi][i];
+                v[4 + i] = acc[mi][2 * pi + 1][i];
+              }
+              unsigned bits = 0;
+              if (st.relu) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                  bits |= (v[j] > 0.f ? 1u : 0u) << j;
+                  v[j] = fmaxf(v[j], 0.f);
+                }
+              }
+              const int row = (sh.mt0 + mi) * 16 + r;
+              *reinterpret_cast<uint4*>(act + row * a.act_str + (32 * sh.pair[pi] + 8 * q) * 2) = Vec16<bf16_t>::pack(v);
+              if (st.relu) mask[row * MF_MASK_STR + 4 * sh.pair[pi] + q] = (uint8_t)bits;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      mlp_copy_out(act, a.act_str, st.out, st.out_stride, l + 1 < a.nsteps ? st.N : st.out_stride, row0, a.rows);
+      if (st.mask != nullptr && st.relu) {
+        for (int t = threadIdx.x; t < MF_ROWS * (MF_MASK_STR / 16); t += blockDim.x) {
+          const int rr = t >> 2, c = t & 3;
+          if (row0 + rr < a.rows)
+            *(reinterpret_cast<uint4*>(st.mask + (row0 + rr) * MF_MASK_STR) + c) =
+                *reinterpret_cast<const uint4*>(mask + rr * MF_MASK_STR + c * 16);
+        }
+      }
+      boff += st.N;
+    }
+    __syncthreads();        // the last copy-out has read LDS before the next tile's rows land in it
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward (data)
+// step s works on layer l = L-1-s: input = d(pre-activation of layer l) (rows x N_l) in LDS, output = d(input of layer l)
+// = d(output of layer l-1), masked by layer l-1's ReLU mask into d(pre-activation of layer l-1).
+__global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_bwd_kernel(MlpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* act = smem;
+  uint8_t* mask = reinterpret_cast<uint8_t*>(act + MF_ROWS * a.act_str);            // [MF_ROWS][MF_MASK_STR]
+  float* scratch = reinterpret_cast<float*>(mask + MF_ROWS * MF_MASK_STR);           // [8 row slices][512]
+  float* csum = scratch + 8 * 512;                                                    // [nsteps][512] running column sums
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, r = lane & 15;
+  for (int i = threadIdx.x; i < a.nsteps * 512; i += blockDim.x) csum[i] = 0.f;
+  const int64_t ntiles = (a.rows + MF_ROWS - 1) / MF_ROWS;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t row0 = tile * MF_ROWS;
+    mlp_load_in(act, a.act_str, a.in, a.in_stride, a.step[0].K, row0, a.rows);
+    __syncthreads();
+    for (int s = 0; s < a.nsteps; ++s) {
+      const MlpStep st = a.step[s];
+      const MlpShare sh = mlp_share(st.N, wave);
+      // the ReLU mask this step's output needs: 16 bytes per thread, in flight during the GEMM
+      uint4 mraw = make_uint4(0, 0, 0, 0);
+      const int mrow = threadIdx.x >> 2, mc = threadIdx.x & 3;
+      if (st.mask != nullptr && row0 + mrow < a.rows)
+        mraw = *(reinterpret_cast<const uint4*>(st.mask + (row0 + mrow) * MF_MASK_STR) + mc);
+      // column sums of the step's input (the bias gradient of its layer): 8 row slices x 16-byte column chunks
+      if (st.colsum != nullptr) {
+        const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
+        if (c < (st.K >> 3)) {
+          float sum[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) sum[j] = 0.f;
+#pragma unroll 4
+          for (int rr = 0; rr < 16; ++rr) {
+            float f[8];
+            Vec16<bf16_t>::unpack(*reinterpret_cast<const uint4*>(act + (sl * 16 + rr) * a.act_str + c * 16), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum[j] += f[j];
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) scratch[sl * 512 + c * 8 + j] = sum[j];
+        }
+      }
+      mf_f32x4 acc[MF_MT][2 * MF_MAXP];
+#pragma unroll
+      for (int mi = 0; mi < MF_MT; ++mi)
+#pragma unroll
+        for (int t = 0; t < 2 * MF_MAXP; ++t) acc[mi][t] = mf_f32x4{0.f, 0.f, 0.f, 0.f};
+      mlp_gemm(act, a.act_str, st.wf, st.K, sh, lane, acc);
+      if (st.mask != nullptr) *reinterpret_cast<uint4*>(mask + mrow * MF_MASK_STR + mc * 16) = mraw;
+      __syncthreads();
+      if (st.colsum != nullptr && threadIdx.x < st.K) {
+        float t = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) t += scratch[sl * 512 + threadIdx.x];
+        csum[s * 512 + threadIdx.x] += t;
+      }
+#pragma unroll
+      for (int pi = 0; pi < MF_MAXP; ++pi) {
+        if (pi < sh.npw) {
+#pragma unroll
+          for (int mi = 0; mi < MF_MT; ++mi) {
+            if (mi < sh.mcnt) {
+              float v[8];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                v[i] = acc[mi][2 * pi][i];
+                v[4 + i] = acc[mi][2 * pi + 1][i];
+              }
+              const int row = (sh.mt0 + mi) * 16 + r;
+              if (st.mask != nullptr) {
+                const unsigned bits = mask[row * MF_MASK_STR + 4 * sh.pair[pi] + q];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = ((bits >> j) & 1u) ? v[j] : 0.f;
+              }
+              *reinterpret_cast<uint4*>(act + row * a.act_str + (32 * sh.pair[pi] + 8 * q) * 2) = Vec16<bf16_t>::pack(v);
+            }
+          }
+        }
+      }
+      __syncthreads();
+      mlp_copy_out(act, a.act_str, st.out, st.out_stride, s + 1 < a.nsteps ? st.N : st.out_stride, row0, a.rows);
+    }
+    __syncthreads();
+  }
+  for (int s = 0; s < a.nsteps; ++s)
+    if (a.step[s].colsum != nullptr && threadIdx.x < a.step[s].K)
+      a.step[s].colsum[(size_t)blockIdx.x * a.step[s].K + threadIdx.x] = csum[s * 512 + threadIdx.x];
+}
+
+// out[i] = sum_p part[p][i]
+__global__ __launch_bounds__(256) void mlp_colsum_reduce_kernel(const float* __restrict__ part, int nparts, int n,
+                                                                float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + tx;
+  float s = 0.f;
+  if (i < n)
+    for (int p = ty; p < nparts; p += 4) s += part[(size_t)p * n + i];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && i < n) out[i] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
+
+static inline int pad32(int v) { return (v + 31) / 32 * 32; }
+constexpr int MF_GRID = 256;
+
+static bool mlp_fused_covers(int L, const int32_t* w) {
+  if (L < 1 || L > MF_MAXL) return false;
+  for (int i = 0; i <= L; ++i)
+    if (w[i] < 8 || w[i] % 8 != 0 || pad32(w[i]) > 32 * MF_MAXP * MF_WAVES) return false;
+  return true;
+}
+
+static int mlp_act_str(int L, const int32_t* w) {
+  int mx = 0;
+  for (int i = 0; i <= L; ++i) mx = std::max(mx, pad32(w[i]));
+  return mx * 2 + 16;
+}
+
+static size_t mlp_frag_bytes(int L, const int32_t* w) {
+  size_t b = 0;
+  for (int l = 0; l < L; ++l) b += (size_t)pad32(w[l]) * pad32(w[l + 1]) * 2;
+  return (b + 255) / 256 * 256;
+}
+
+}  // namespace trs
+
+using namespace trs;
+
+/* workspace: [fragment-order weights][fp32 biases (forward) | column-sum partials (backward)] */
+extern "C" size_t trs_mlp_fused_workspace_bytes(int32_t num_layers, const int32_t* widths) {
+  if (!mlp_fused_covers(num_layers, widths)) return 0;
+  size_t sum = 0;
+  for (int l = 0; l <= num_layers; ++l) sum += (size_t)pad32(widths[l]);
+  return mlp_frag_bytes(num_layers, widths) + (size_t)MF_GRID * sum * 4 + 4096;
+}
+
+extern "C" int trs_mlp_fused_supported(int32_t num_layers, const int32_t* widths) {
+  if (!mlp_fused_covers(num_layers, widths)) return 0;
+  const size_t lds = (size_t)MF_ROWS * mlp_act_str(num_layers, widths) + MF_ROWS * MF_MASK_STR + 8 * 512 * 4 +
+                     (size_t)num_layers * 512 * 4;
+  return lds <= 160 * 1024 ? 1 : 0;
+}
+
+extern "C" int trs_mlp_fused_fwd(const void* x, int64_t rows, int32_t num_layers, const int32_t* widths,
+                                 const void* const* weights, const void* const* biases, void* const* hidden,
+                                 void* const* masks, void* y, int32_t dtype, void* workspace, size_t ws_bytes,
+                                 trs_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  TRS_REQUIRE(dtype == TRS_BF16, TRS_EDTYPE, "mlp_fused_fwd: bf16 only");
+  TRS_REQUIRE(trs_mlp_fused_supported(num_layers, widths), TRS_ESHAPE, "mlp_fused_fwd: unsupported layer widths");
+  TRS_REQUIRE(x && y && weights && biases && hidden && masks && workspace, TRS_EINVAL, "mlp_fused_fwd: NULL pointer");
+  TRS_REQUIRE(ws_bytes >= trs_mlp_fused_workspace_bytes(num_layers, widths), TRS_EWORKSPACE,
+              "mlp_fused_fwd: workspace too small");
+  if (rows == 0) return TRS_OK;
+  const int L = num_layers;
+  MlpArgs a;
+  a.nsteps = L;
+  a.in = x;
+  a.in_stride = widths[0];
+  a.rows = rows;
+  a.nbias = 0;
+  a.act_str = mlp_act_str(L, widths);
+  char* wsp = (char*)workspace;
+  float* bias_base = (float*)(wsp + mlp_frag_bytes(L, widths));
+  size_t woff = 0, boff = 0;
+  for (int l = 0; l < L; ++l) {
+    const int K = pad32(widths[l]), N = pad32(widths[l + 1]);
+    bf16_t* wf = (bf16_t*)(wsp + woff);
+    float* bf = bias_base + boff;
+    hipLaunchKernelGGL(mlp_prepack_kernel, dim3(std::min(256, (N / 16 * (K / 32) * 64 + 255) / 256)), dim3(256), 0, s,
+                       (const bf16_t*)weights[l], (const bf16_t*)biases[l], widths[l + 1], widths[l], 0, N / 16, K / 32, wf,
+                       bf, N);
+    MlpStep& st = a.step[l];
+    st.wf = (const uint4*)wf;
+    st.bias = bf;
+    st.K = K;
+    st.N = N;
+    st.relu = l + 1 < L ? 1 : 0;
+    st.out = l + 1 < L ? hidden[l] : y;
+    st.out_stride = l + 1 < L ? N : widths[L];
+    st.mask = l + 1 < L ? (uint8_t*)masks[l] : nullptr;
+    st.colsum = nullptr;
+    woff += (size_t)K * N * 2;
+    boff += N;
+  }
+  a.nbias = (int)boff;
+  const size_t lds = (size_t)MF_ROWS * a.act_str + MF_ROWS * MF_MASK_STR + boff * 4;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)mlp_fused_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+        hipSuccess)
+      return check_launch("mlp_fused_fwd: LDS attribute");
+    attr = true;
+  }
+  const int64_t ntiles = (rows + MF_ROWS - 1) / MF_ROWS;
+  hipLaunchKernelGGL(mlp_fused_fwd_kernel, dim3((int)std::min<int64_t>(ntiles, MF_GRID)), dim3(64 * MF_WAVES), lds, s, a);
+  return check_launch("mlp_fused_fwd");
+}
+
+/* gz[l] (l = 0..L-2): d(pre-activation of layer l), (rows x pad32(widths[l+1])) bf16 -- d(pre-activation) of the last
+ * layer is gy itself.  gbias[l] (l = 0..L-1): pad32(widths[l+1]) fp32 each, written.  gx: (rows x widths[0]). */
+extern "C" int trs_mlp_fused_bwd_data(const void* gy, int64_t rows, int32_t num_layers, const int32_t* widths,
+                                      const void* const* weights, const void* const* masks, void* const* gz,
+                                      float* const* gbias, void* gx, int32_t dtype, void* workspace, size_t ws_bytes,
+                                      trs_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  TRS_REQUIRE(dtype == TRS_BF16, TRS_EDTYPE, "mlp_fused_bwd_data: bf16 only");
+  TRS_REQUIRE(trs_mlp_fused_supported(num_layers, widths), TRS_ESHAPE, "mlp_fused_bwd_data: unsupported layer widths");
+  TRS_REQUIRE(gy && weights && masks && gz && gbias && workspace, TRS_EINVAL, "mlp_fused_bwd_data: NULL pointer");
+  TRS_REQUIRE(ws_bytes >= trs_mlp_fused_workspace_bytes(num_layers, widths), TRS_EWORKSPACE,
+              "mlp_fused_bwd_data: workspace too small");
+  const int L = num_layers;
+  if (rows == 0) {
+    for (int l = 0; l < L; ++l)
+      if (hipMemsetAsync(gbias[l], 0, (size_t)pad32(widths[l + 1]) * 4, s) != hipSuccess) return check_launch("mlp_fused_bwd_data");
+    return TRS_OK;
+  }
+  MlpArgs a;
+  a.nsteps = L;
+  a.in = gy;
+  a.in_stride = widths[L];
+  a.rows = rows;
+  a.nbias = 0;
+  a.act_str = mlp_act_str(L, widths);
+  const int64_t ntiles = (rows + MF_ROWS - 1) / MF_ROWS;
+  const int grid = (int)std::min<int64_t>(ntiles, MF_GRID);
+  char* wsp = (char*)workspace;
+  float* part_base = (float*)(wsp + mlp_frag_bytes(L, widths));
+  size_t woff = 0, poff = 0;
+  for (int sidx = 0; sidx < L; ++sidx) {
+    const int l = L - 1 - sidx;
+    const int K = pad32(widths[l + 1]), N = pad32(widths[l]);      // contraction over layer l's outputs, output = its inputs
+    bf16_t* wf = (bf16_t*)(wsp + woff);
+    hipLaunchKernelGGL(mlp_prepack_kernel, dim3(std::min(256, (N / 16 * (K / 32) * 64 + 255) / 256)), dim3(256), 0, s,
+                       (const bf16_t*)weights[l], (const bf16_t*)nullptr, widths[l + 1], widths[l], 1, N / 16, K / 32, wf,
+                       (float*)nullptr, 0);
+    MlpStep& st = a.step[sidx];
+    st.wf = (const uint4*)wf;
+    st.bias = nullptr;
+    st.K = K;
+    st.N = N;
+    st.relu = 0;
+    st.out = l > 0 ? gz[l - 1] : gx;
+    st.out_stride = l > 0 ? N : widths[0];
+    st.mask = l > 0 ? (uint8_t*)masks[l - 1] : nullptr;
+    st.colsum = part_base + poff;
+    woff += (size_t)K * N * 2;
+    poff += (size_t)grid * K;
+  }
+  const size_t lds = (size_t)MF_ROWS * a.act_str + MF_ROWS * MF_MASK_STR + 8 * 512 * 4 + (size_t)L * 512 * 4;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)mlp_fused_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+        hipSuccess)
+      return check_launch("mlp_fused_bwd_data: LDS attribute");
+    attr = true;
+  }
+  hipLaunchKernelGGL(mlp_fused_bwd_kernel, dim3(grid), dim3(64 * MF_WAVES), lds, s, a);
+  for (int sidx = 0; sidx < L; ++sidx) {
+    const int l = L - 1 - sidx;
+    const int K = a.step[sidx].K;
+    hipLaunchKernelGGL(mlp_colsum_reduce_kernel, dim3((K + 63) / 64), dim3(256), 0, s, a.step[sidx].colsum, grid, K,
+                       gbias[l]);
+  }
+  return check_launch("mlp_fused_bwd_data");
+}

@@ -1332,3 +1332,122 @@ def relu_bwd_bias(gy: torch.Tensor, y: torch.Tensor):
     call("trs_relu_bwd_bias", ptr(gy), ptr(y), rows, C, value_dtype_code(y), ptr(gz), ptr(gb), ptr(ws), ws_bytes,
          stream_ptr())
     return gz, gb
+
+
+# --------------------------------------------------------------------------------------------
+# N4: per-field MLP (Linear -> ReLU ... -> Linear on every row of a (B,N,E) block) as one kernel per direction
+# --------------------------------------------------------------------------------------------
+FUSED_MLP = os.environ.get("TRS_FUSED_MLP", "1") not in ("", "0")
+FUSED_MLP_MIN_ROWS = 4096
+
+
+def _pad32(v: int) -> int:
+    return (v + 31) // 32 * 32
+
+
+def _i32_array(vals):
+    return (ctypes.c_int32 * len(vals))(*[int(v) for v in vals])
+
+
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[0 if t is None else t.data_ptr() for t in tensors])
+
+
+def mlp_fused_supported(x: torch.Tensor, widths: Sequence[int]) -> bool:
+    """bf16 rows on the HIP device, every width a multiple of 8 and at most 512, enough rows to fill the chip"""
+    if not (FUSED_MLP and x.is_cuda and x.dtype == torch.bfloat16 and x.numel() // max(1, x.shape[-1]) >= FUSED_MLP_MIN_ROWS):
+        return False
+    if len(widths) < 2 or len(widths) > 9 or any(w % 8 or w > 512 for w in widths):
+        return False
+    return bool(_abi.load().trs_mlp_fused_supported(len(widths) - 1, _i32_array(widths)))
+
+
+def fused_mlp_forward_raw(x2: torch.Tensor, Ws: Sequence[torch.Tensor], bs: Sequence[torch.Tensor]):
+    """trs_mlp_fused_fwd on rows x2 (rows, widths[0]): returns (y (rows, widths[L]), hidden [(rows, pad32(w))] -- the
+    ReLU outputs of the hidden layers, zero in the padding columns --, masks [(rows, 64) uint8: bit j of byte c says
+    hidden column 8c+j is positive])."""
+    L = len(Ws)
+    widths = [Ws[0].shape[1]] + [w.shape[0] for w in Ws]
+    rows, dev = x2.shape[0], x2.device
+    hidden = [torch.empty(rows, _pad32(widths[l + 1]), dtype=torch.bfloat16, device=dev) for l in range(L - 1)]
+    masks = [torch.empty(rows, 64, dtype=torch.uint8, device=dev) for _ in range(L - 1)]
+    y = torch.empty(rows, widths[L], dtype=torch.bfloat16, device=dev)
+    wl = _i32_array(widths)
+    ws_bytes = size_query("trs_mlp_fused_workspace_bytes", L, wl)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    call("trs_mlp_fused_fwd", ptr(x2), rows, L, wl, _ptr_array(Ws), _ptr_array(bs), _ptr_array(hidden),
+         _ptr_array(masks), ptr(y), _abi.TRS_BF16, ptr(ws), ws_bytes, stream_ptr())
+    return y, hidden, masks
+
+
+class _FusedMLP(Function):
+    """y = Linear_{L-1}(relu(... relu(Linear_0(x)))) on the rows of x (..., widths[0]); params = W0, b0, W1, b1, ...
+    (nn.Linear layout).  Forward and the data gradient are one HIP kernel each (trs_mlp_fused_*); the weight gradients
+    are GEMMs with K = rows on the tensors those kernels leave behind (hidden activations, pre-activation gradients)."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        require_device(x, *params)
+        L = len(params) // 2
+        Ws = [params[2 * l].contiguous() for l in range(L)]
+        bs = [params[2 * l + 1].contiguous() for l in range(L)]
+        widths = [Ws[0].shape[1]] + [w.shape[0] for w in Ws]
+        x2 = x.reshape(-1, widths[0]).contiguous()
+        y, hidden, masks = fused_mlp_forward_raw(x2, Ws, bs)
+        ctx.save_for_backward(x2, *Ws, *hidden, *masks)
+        ctx.meta = (L, widths, tuple(x.shape), [p.dtype for p in params])
+        return y.reshape(*x.shape[:-1], widths[L])
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        L, widths, xshape, pdt = ctx.meta
+        saved = ctx.saved_tensors
+        x2, Ws = saved[0], saved[1:1 + L]
+        hidden, masks = saved[1 + L:L + L], saved[L + L:]
+        rows, dev = x2.shape[0], x2.device
+        gy2 = gy.reshape(rows, widths[L]).contiguous()
+        gz = [torch.empty(rows, _pad32(widths[l + 1]), dtype=torch.bfloat16, device=dev) for l in range(L - 1)]
+        gb = [torch.empty(_pad32(widths[l + 1]), dtype=torch.float32, device=dev) for l in range(L)]
+        gx = torch.empty_like(x2) if ctx.needs_input_grad[0] else torch.empty_like(x2)
+        wl = _i32_array(widths)
+        ws_bytes = size_query("trs_mlp_fused_workspace_bytes", L, wl)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        call("trs_mlp_fused_bwd_data", ptr(gy2), rows, L, wl, _ptr_array(Ws), _ptr_array(masks), _ptr_array(gz),
+             _ptr_array(gb), ptr(gx), _abi.TRS_BF16, ptr(ws), ws_bytes, stream_ptr())
+        grads = []
+        for l in range(L):
+            inp = x2 if l == 0 else hidden[l - 1]               # (rows, widths[l] | pad32)
+            g = gy2 if l == L - 1 else gz[l]                    # (rows, widths[l+1] | pad32)
+            gw = gbias = None
+            if ctx.needs_input_grad[1 + 2 * l]:
+                gw = _wgrad_rows(g, inp, widths[l + 1], widths[l], pdt[2 * l])
+            if ctx.needs_input_grad[2 + 2 * l]:
+                gbias = gb[l][:widths[l + 1]].to(pdt[2 * l + 1])
+            grads += [gw, gbias]
+        return (gx.reshape(xshape) if ctx.needs_input_grad[0] else None, *grads)
+
+
+def _wgrad_rows(g: torch.Tensor, inp: torch.Tensor, out_f: int, in_f: int, dtype) -> torch.Tensor:
+    """dW = g^T @ inp over the rows (K = rows): split-K batched GEMM with fp32 partials, folded / sliced / cast by
+    trs_wgrad_finish (the padding columns of g / inp are dropped there)."""
+    rows = g.shape[0]
+    S = 0
+    for cand in (384, 320, 256, 192, 128, 96, 64, 48, 32, 24, 16, 12, 8, 6, 4):
+        if rows % cand == 0 and rows // cand >= 1024:
+            S = cand
+            break
+    if S == 0:
+        return (g.t() @ inp)[:out_f, :in_f].contiguous().to(dtype)
+    part = torch.bmm(g.view(S, rows // S, -1).transpose(1, 2), inp.view(S, rows // S, -1), out_dtype=torch.float32)
+    gw = torch.empty(out_f, in_f, dtype=dtype, device=g.device)
+    call("trs_wgrad_finish", ptr(part), S, part.shape[1], part.shape[2], out_f, in_f, value_dtype_code(gw), ptr(gw),
+         ptr(None), ptr(None), stream_ptr())
+    return gw
+
+
+def fused_mlp(x: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor]) -> torch.Tensor:
+    params = []
+    for w, b in zip(weights, biases):
+        params += [w, b]
+    return _FusedMLP.apply(x, *params)

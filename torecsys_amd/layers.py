@@ -796,6 +796,38 @@ class MultilayerPerceptionLayer(BaseLayer):
             out.names = ('B', 'N', 'O',)
         return out
 
+    def _forward_fused(self, outputs: torch.Tensor, mods) -> Optional[torch.Tensor]:
+        """Narrow stacks (every width <= 512: the per-field MLP of DeepAndCrossNetwork, 64 -> 400 -> 400 -> 400 -> 64 on
+        B*N rows) as ONE kernel per direction with the activations of a row tile kept in LDS (trs_mlp_fused_*,
+        SURVEY.md 8f N4); None when the stack is not Linear -> ReLU ... -> Linear with biases or does not fit."""
+        lin = [m for m in mods if not isinstance(m, nn.Dropout)]
+        Ws, bs = [], []
+        i = 0
+        while i < len(lin):
+            mod = lin[i]
+            if not isinstance(mod, nn.Linear) or mod.bias is None or mod.weight.dtype != outputs.dtype:
+                return None
+            relu = i + 1 < len(lin) and type(lin[i + 1]) is nn.ReLU
+            last = i + (2 if relu else 1) >= len(lin)
+            if relu == last:                      # hidden layers carry a ReLU, the output layer does not
+                return None
+            Ws.append(mod.weight)
+            bs.append(mod.bias)
+            i += 2 if relu else 1
+        if len(Ws) < 2:
+            return None
+        widths = [Ws[0].shape[1]] + [w.shape[0] for w in Ws]
+        if any(a.shape[1] != b for a, b in zip(Ws[1:], widths[1:-1])) or outputs.shape[-1] != widths[0]:
+            return None
+        if not F_.mlp_fused_supported(outputs, widths):
+            return None
+        out = F_.fused_mlp(outputs, Ws, bs)
+        if out.dim() == 2:
+            out.names = ('B', 'O',)
+        elif out.dim() == 3:
+            out.names = ('B', 'N', 'O',)
+        return out
+
     def forward(self, emb_inputs: torch.Tensor) -> torch.Tensor:
         outputs = _strip(emb_inputs)
         split_k = outputs.is_cuda and outputs.dtype in (torch.bfloat16, torch.float16) and torch.is_grad_enabled()
@@ -808,6 +840,9 @@ class MultilayerPerceptionLayer(BaseLayer):
             for m in mods)
         width = outputs.shape[-1]          # current (possibly padded) activation width
         if pad and outputs.dtype == torch.bfloat16:
+            fused = self._forward_fused(outputs, mods)
+            if fused is not None:
+                return fused
             stacked = self._forward_stacked(outputs, mods)
             if stacked is not None:
                 return stacked
