@@ -176,6 +176,21 @@ def main():
             return gz, gz.sum(0)
         t = timeit(aten)
         report("ATen threshold_backward + sum", t, 4 * B * C * s)
+    if want("mlpf"):
+        rows_ = B * N
+        widths = [64, 400, 400, 400, 64]
+        Ws = [(torch.randn(o, i, generator=g) / i ** 0.5).to(dt).to(dev).requires_grad_() for i, o in zip(widths[:-1], widths[1:])]
+        bs = [(0.1 * torch.randn(o, generator=g)).to(dt).to(dev).requires_grad_() for o in widths[1:]]
+        xx = torch.randn(rows_, 64, generator=g).to(dt).to(dev).requires_grad_()
+        fl = 2.0 * rows_ * sum(i * o for i, o in zip(widths[:-1], widths[1:]))
+        t = timeit(lambda: F_.fused_mlp(xx.detach(), [w.detach() for w in Ws], [b_.detach() for b_ in bs]), iters=5, warm=1)
+        print(f"fused MLP fwd  rows={rows_} {widths}: med {t[0]*1e3:.3f} ms  {fl/t[0]/1e12:.1f} TFLOP/s", flush=True)
+        y = F_.fused_mlp(xx, Ws, bs)
+        gy = torch.randn_like(y)
+        t = timeit(lambda: torch.autograd.grad(y, (xx,), gy, retain_graph=True), iters=5, warm=1)
+        print(f"fused MLP bwd (data only): med {t[0]*1e3:.3f} ms  {fl/t[0]/1e12:.1f} TFLOP/s", flush=True)
+        t = timeit(lambda: torch.autograd.grad(y, (xx, *Ws, *bs), gy, retain_graph=True), iters=3, warm=1)
+        print(f"fused MLP bwd (data + weight gradients): med {t[0]*1e3:.3f} ms  {2*fl/t[0]/1e12:.1f} TFLOP/s", flush=True)
     if want("copy"):
         x = torch.empty(512 * 1024 * 1024 // 4, dtype=torch.float32, device=dev)
         y = torch.empty_like(x)

@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libtrs_hip.so")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off",
+FLAGS = ["-O3", "-std=c++20", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-result"]
 
 

@@ -121,31 +121,85 @@ __device__ __forceinline__ MlpShare mlp_share(int N, int wave) {
   return s;
 }
 
-// acc[mi][2*pi + h] (+)= sum_k W-frag(pair pi, half h, ks) x act rows of tile mt0+mi
-__device__ __forceinline__ void mlp_gemm(const char* act, int act_str, const uint4* __restrict__ wf, int K,
-                                         const MlpShare& sh, int lane, mf_f32x4 (&acc)[MF_MT][2 * MF_MAXP]) {
+// acc[mi][2*pi + h] (+)= sum_k W-frag(pair pi, half h, ks) x act rows of tile mt0+mi, for MCNT row tiles and NPW column
+// pairs known at compile time (runtime bounds put a scalar branch in front of every MFMA).
+// The weight fragments come from L2 (~0.5 us): the fragments of k-step ks+1 are requested before the MFMAs of k-step ks
+// are issued (register double buffer); PREFETCH_B does the same for the LDS reads of the activations, otherwise they are
+// read per k-step in two halves (16 registers of B operands instead of 64).
+template <int MCNT, int NPW, bool PREFETCH_B>
+__device__ __forceinline__ void mlp_gemm_t(const char* act, int act_str, const uint4* __restrict__ wf, int K,
+                                           const MlpShare& sh, int lane, mf_f32x4 (&acc)[MF_MT][2 * MF_MAXP]) {
   const int KS = K >> 5;
   const int r = lane & 15, q = lane >> 4;
   const char* arow = act + (sh.mt0 * 16 + r) * act_str + q * 16;
-  for (int ks = 0; ks < KS; ++ks) {
-    uint4 B[MF_MT];
+  const uint4* wbase[NPW];
 #pragma unroll
-    for (int mi = 0; mi < MF_MT; ++mi)
-      if (mi < sh.mcnt) B[mi] = *reinterpret_cast<const uint4*>(arow + mi * 16 * act_str + ks * 64);
+  for (int pi = 0; pi < NPW; ++pi) wbase[pi] = wf + ((size_t)(2 * sh.pair[pi]) * KS) * 64 + lane;
+  uint4 A[2 * NPW], An[2 * NPW];
+  auto loadA = [&](int ks, uint4 (&dst)[2 * NPW]) {
 #pragma unroll
-    for (int pi = 0; pi < MF_MAXP; ++pi) {
-      if (pi < sh.npw) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const uint4 a = wf[((size_t)(2 * sh.pair[pi] + h) * KS + ks) * 64 + lane];
-#pragma unroll
-          for (int mi = 0; mi < MF_MT; ++mi)
-            if (mi < sh.mcnt)
-              acc[mi][2 * pi + h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                  __builtin_bit_cast(mf_bf16x8, a), __builtin_bit_cast(mf_bf16x8, B[mi]), acc[mi][2 * pi + h], 0, 0, 0);
-        }
-      }
+    for (int pi = 0; pi < NPW; ++pi) {
+      dst[2 * pi] = wbase[pi][(size_t)ks * 64];
+      dst[2 * pi + 1] = wbase[pi][(size_t)(KS + ks) * 64];
     }
+  };
+  loadA(0, A);
+  if constexpr (PREFETCH_B) {
+    uint4 B[MCNT], Bn[MCNT];
+#pragma unroll
+    for (int mi = 0; mi < MCNT; ++mi) B[mi] = *reinterpret_cast<const uint4*>(arow + mi * 16 * act_str);
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + 1 < KS) {
+        loadA(ks + 1, An);
+#pragma unroll
+        for (int mi = 0; mi < MCNT; ++mi) Bn[mi] = *reinterpret_cast<const uint4*>(arow + mi * 16 * act_str + (ks + 1) * 64);
+      }
+#pragma unroll
+      for (int t = 0; t < 2 * NPW; ++t)
+#pragma unroll
+        for (int mi = 0; mi < MCNT; ++mi)
+          acc[mi][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_bf16x8, A[t]),
+                                                               __builtin_bit_cast(mf_bf16x8, B[mi]), acc[mi][t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 2 * NPW; ++t) A[t] = An[t];
+#pragma unroll
+      for (int mi = 0; mi < MCNT; ++mi) B[mi] = Bn[mi];
+    }
+  } else {
+    constexpr int HALF = MCNT >= 2 ? MCNT / 2 : 1;
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + 1 < KS) loadA(ks + 1, An);
+#pragma unroll
+      for (int m0 = 0; m0 < MCNT; m0 += HALF) {
+        uint4 Bh[HALF];
+#pragma unroll
+        for (int mi = 0; mi < HALF; ++mi) Bh[mi] = *reinterpret_cast<const uint4*>(arow + (m0 + mi) * 16 * act_str + ks * 64);
+#pragma unroll
+        for (int t = 0; t < 2 * NPW; ++t)
+#pragma unroll
+          for (int mi = 0; mi < HALF; ++mi)
+            acc[m0 + mi][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(mf_bf16x8, A[t]), __builtin_bit_cast(mf_bf16x8, Bh[mi]), acc[m0 + mi][t], 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < 2 * NPW; ++t) A[t] = An[t];
+    }
+  }
+}
+
+// run ``body.template operator()<MCNT, NPW>()`` for this wave's share (wave-uniform dispatch)
+template <typename F>
+__device__ __forceinline__ void mlp_dispatch(const MlpShare& sh, F&& body) {
+  if (sh.npw == 0) return;
+  if (sh.mcnt == 8) {
+    if (sh.npw == 2) body.template operator()<8, 2>();
+    else body.template operator()<8, 1>();
+  } else if (sh.mcnt == 4) {
+    body.template operator()<4, 1>();
+  } else if (sh.mcnt == 2) {
+    body.template operator()<2, 1>();
+  } else {
+    body.template operator()<1, 1>();
   }
 }
 
@@ -205,35 +259,33 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_fwd_kernel(MlpArgs
 #pragma unroll
           for (int mi = 0; mi < MF_MT; ++mi) acc[mi][2 * pi + h] = init;
         }
-      mlp_gemm(act, a.act_str, st.wf, st.K, sh, lane, acc);
+      mlp_dispatch(sh, [&]<int MCNT, int NPW>() { mlp_gemm_t<MCNT, NPW, false>(act, a.act_str, st.wf, st.K, sh, lane, acc); });
       __syncthreads();      // every wave is done reading the layer's input (and the previous copy-out has left LDS)
+      mlp_dispatch(sh, [&]<int MCNT, int NPW>() {
 #pragma unroll
-      for (int pi = 0; pi < MF_MAXP; ++pi) {
-        if (pi < sh.npw) {
+        for (int pi = 0; pi < NPW; ++pi) {
 #pragma unroll
-          for (int mi = 0; mi < MF_MT; ++mi) {
-            if (mi < sh.mcnt) {
-              float v[8];
+          for (int mi = 0; mi < MCNT; ++mi) {
+            float v[8];
 #pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                v[i] = acc[mi][2 * pi][i];
-                v[4 + i] = acc[mi][2 * pi + 1][i];
-              }
-              unsigned bits = 0;
-              if (st.relu) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                  bits |= (v[j] > 0.f ? 1u : 0u) << j;
-                  v[j] = fmaxf(v[j], 0.f);
-                }
-              }
-              const int row = (sh.mt0 + mi) * 16 + r;
-              *reinterpret_cast<uint4*>(act + row * a.act_str + (32 * sh.pair[pi] + 8 * q) * 2) = Vec16<bf16_t>::pack(v);
-              if (st.relu) mask[row * MF_MASK_STR + 4 * sh.pair[pi] + q] = (uint8_t)bits;
+            for (int i = 0; i < 4; ++i) {
+              v[i] = acc[mi][2 * pi][i];
+              v[4 + i] = acc[mi][2 * pi + 1][i];
             }
+            unsigned bits = 0;
+            if (st.relu) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                bits |= (v[j] > 0.f ? 1u : 0u) << j;
+                v[j] = fmaxf(v[j], 0.f);
+              }
+            }
+            const int row = (sh.mt0 + mi) * 16 + r;
+            *reinterpret_cast<uint4*>(act + row * a.act_str + (32 * sh.pair[pi] + 8 * q) * 2) = Vec16<bf16_t>::pack(v);
+            if (st.relu) mask[row * MF_MASK_STR + 4 * sh.pair[pi] + q] = (uint8_t)bits;
           }
         }
-      }
+      });
       __syncthreads();
       mlp_copy_out(act, a.act_str, st.out, st.out_stride, l + 1 < a.nsteps ? st.N : st.out_stride, row0, a.rows);
       if (st.mask != nullptr && st.relu) {
@@ -274,6 +326,13 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_bwd_kernel(MlpArgs
       const int mrow = threadIdx.x >> 2, mc = threadIdx.x & 3;
       if (st.mask != nullptr && row0 + mrow < a.rows)
         mraw = *(reinterpret_cast<const uint4*>(st.mask + (row0 + mrow) * MF_MASK_STR) + mc);
+      mf_f32x4 acc[MF_MT][2 * MF_MAXP];
+#pragma unroll
+      for (int mi = 0; mi < MF_MT; ++mi)
+#pragma unroll
+        for (int t = 0; t < 2 * MF_MAXP; ++t) acc[mi][t] = mf_f32x4{0.f, 0.f, 0.f, 0.f};
+      mlp_dispatch(sh, [&]<int MCNT, int NPW>() { mlp_gemm_t<MCNT, NPW, false>(act, a.act_str, st.wf, st.K, sh, lane, acc); });
+      __builtin_amdgcn_sched_barrier(0);
       // column sums of the step's input (the bias gradient of its layer): 8 row slices x 16-byte column chunks
       if (st.colsum != nullptr) {
         const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
@@ -292,12 +351,6 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_bwd_kernel(MlpArgs
           for (int j = 0; j < 8; ++j) scratch[sl * 512 + c * 8 + j] = sum[j];
         }
       }
-      mf_f32x4 acc[MF_MT][2 * MF_MAXP];
-#pragma unroll
-      for (int mi = 0; mi < MF_MT; ++mi)
-#pragma unroll
-        for (int t = 0; t < 2 * MF_MAXP; ++t) acc[mi][t] = mf_f32x4{0.f, 0.f, 0.f, 0.f};
-      mlp_gemm(act, a.act_str, st.wf, st.K, sh, lane, acc);
       if (st.mask != nullptr) *reinterpret_cast<uint4*>(mask + mrow * MF_MASK_STR + mc * 16) = mraw;
       __syncthreads();
       if (st.colsum != nullptr && threadIdx.x < st.K) {
@@ -306,29 +359,27 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_bwd_kernel(MlpArgs
         for (int sl = 0; sl < 8; ++sl) t += scratch[sl * 512 + threadIdx.x];
         csum[s * 512 + threadIdx.x] += t;
       }
+      mlp_dispatch(sh, [&]<int MCNT, int NPW>() {
 #pragma unroll
-      for (int pi = 0; pi < MF_MAXP; ++pi) {
-        if (pi < sh.npw) {
+        for (int pi = 0; pi < NPW; ++pi) {
 #pragma unroll
-          for (int mi = 0; mi < MF_MT; ++mi) {
-            if (mi < sh.mcnt) {
-              float v[8];
+          for (int mi = 0; mi < MCNT; ++mi) {
+            float v[8];
 #pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                v[i] = acc[mi][2 * pi][i];
-                v[4 + i] = acc[mi][2 * pi + 1][i];
-              }
-              const int row = (sh.mt0 + mi) * 16 + r;
-              if (st.mask != nullptr) {
-                const unsigned bits = mask[row * MF_MASK_STR + 4 * sh.pair[pi] + q];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = ((bits >> j) & 1u) ? v[j] : 0.f;
-              }
-              *reinterpret_cast<uint4*>(act + row * a.act_str + (32 * sh.pair[pi] + 8 * q) * 2) = Vec16<bf16_t>::pack(v);
+            for (int i = 0; i < 4; ++i) {
+              v[i] = acc[mi][2 * pi][i];
+              v[4 + i] = acc[mi][2 * pi + 1][i];
             }
+            const int row = (sh.mt0 + mi) * 16 + r;
+            if (st.mask != nullptr) {
+              const unsigned bits = mask[row * MF_MASK_STR + 4 * sh.pair[pi] + q];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] = ((bits >> j) & 1u) ? v[j] : 0.f;
+            }
+            *reinterpret_cast<uint4*>(act + row * a.act_str + (32 * sh.pair[pi] + 8 * q) * 2) = Vec16<bf16_t>::pack(v);
           }
         }
-      }
+      });
       __syncthreads();
       mlp_copy_out(act, a.act_str, st.out, st.out_stride, s + 1 < a.nsteps ? st.N : st.out_stride, row0, a.rows);
     }
