@@ -127,6 +127,16 @@ int trs_scatter_rows_update_adam(const void* g_rows, int64_t g_rows_batch_stride
                                  float step_size, float beta1, float beta2, float eps, float* exp_avg,
                                  float* exp_avg_sq, void* workspace, size_t ws_bytes, trs_stream_t stream);
 
+/* The same fused optimizer step when the bucketed rows are a COMPACT list of U distinct table rows (the owner side of
+ * a row-sharded table: a 125 M-row shard cannot afford a V-sized bucket index per step):  row_start (U+1) / perm (K)
+ * bucket the K gradient rows g_rows (K,E) by compact row u, row_map[u] is the table row that compact row u updates
+ * (distinct values).  optimizer 1 = SGD, 2 = Adagrad (state), 3 = lazy Adam (lr = bias-corrected step size, state =
+ * exp_avg, state2 = exp_avg_sq); state buffers are V x E fp32.  Workspace: trs_scatter_workspace_bytes(K, 1, E, dtype). */
+int trs_scatter_rows_update_mapped(const void* g_rows, void* table, const int32_t* row_map, const int32_t* row_start,
+                                   const int32_t* perm, int64_t K, int64_t U, int64_t V, int32_t E, int32_t dtype,
+                                   int32_t optimizer, float lr, float eps, float beta1, float beta2, float* state,
+                                   float* state2, void* workspace, size_t ws_bytes, trs_stream_t stream);
+
 /* ---- K1+K2(+K8): fused embedding lookup + FM second order ----------------------------------
  * emb[b,n,:]  = table[idx[b,n]+offsets[n], :]                       (optional, may be NULL)
  * fm[b,:]     = 0.5 * ((sum_n x)^2 - sum_n x^2)                     (optional, may be NULL)

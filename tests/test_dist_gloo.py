@@ -30,8 +30,46 @@ class CpuOps:
         inv[order] = torch.arange(order.numel(), dtype=torch.int32)
         return counts, send_ids, send_pos, inv
 
-    def gather_local(self, weight, ids):
-        return weight.detach()[ids.long()]
+    def gather_local(self, weight, ids, n_valid=None):
+        out = weight.detach()[ids.long().clamp(0, weight.shape[0] - 1)]
+        if n_valid is not None:
+            out = out * ((ids >= 0) & (ids < n_valid)).unsqueeze(-1).to(out.dtype)
+        return out
+
+    def unique_route(self, idx, offsets, rows_per_rank, world):
+        g = (idx.long() + offsets.view(1, -1)).reshape(-1)
+        uniq, inv = torch.unique(g, return_inverse=True)
+        owner = torch.div(uniq, rows_per_rank, rounding_mode="floor").clamp_(0, world - 1)
+        return (torch.bincount(owner, minlength=world).to(torch.int64), (uniq - owner * rows_per_rank).to(torch.int32),
+                inv.to(torch.int32))
+
+    def reduce_grad_unique(self, g_block, inv, rows, g_fm, fm_sum):
+        U, E = rows.shape
+        K = inv.numel()
+        g = torch.zeros(K, E) if g_block is None else g_block.reshape(K, E).float().clone()
+        if g_fm is not None:
+            N = K // g_fm.shape[0]
+            x = rows[inv.long()].float().reshape(-1, N, E)
+            g = g + (g_fm.unsqueeze(1).float() * (fm_sum.unsqueeze(1) - x)).reshape(K, E)
+        out = torch.zeros(U, E)
+        out.index_add_(0, inv.long(), g)
+        return out.to(rows.dtype)
+
+    def shard_update(self, weight, ids, grad_rows, opt, dense_index):
+        with torch.no_grad():
+            g = torch.zeros_like(weight, dtype=torch.float32)
+            g.index_add_(0, ids.long(), grad_rows.float())
+            touched = torch.zeros(weight.shape[0], dtype=torch.bool)
+            touched[ids.long()] = True
+            w = weight.data
+            if opt.kind == 1:
+                w[touched] -= (opt.lr * g[touched]).to(w.dtype)
+            elif opt.kind == 2:
+                st = opt.state_for(w)
+                st[touched] += g[touched] ** 2
+                w[touched] -= (opt.lr * g[touched] / (st[touched].sqrt() + opt.eps)).to(w.dtype)
+            else:
+                raise NotImplementedError
 
     def unpermute(self, rows, inv_pos, B, N, want_fm):
         from oracle import cpu_ref as O
@@ -61,7 +99,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, fuse, sparse, ret):
+def _worker(rank, world, port, fuse, sparse, ret, dedup=False, optimizer=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -75,10 +113,18 @@ def _worker(rank, world, port, fuse, sparse, ret):
         g = torch.Generator().manual_seed(99)
         W = torch.randn(V, E, generator=g)
         idx_all = [torch.cat([torch.randint(0, f, (13 + r, 1), generator=g) for f in fs], 1) for r in range(world)]
+        if dedup:                        # plenty of duplicate lookups inside every local batch
+            for t in idx_all:
+                t[1::2] = t[0::2][: t[1::2].shape[0]]
         gb_all = [torch.randn(13 + r, N, E, generator=g) for r in range(world)]
         gf_all = [torch.randn(13 + r, E, generator=g) for r in range(world)]
         m = RowShardedMultiIndicesEmbedding(embed_size=E, field_sizes=fs, fuse_fm=fuse, ops=CpuOps(),
-                                            dense_grad_max_rows=0 if sparse else 10 ** 9)
+                                            dense_grad_max_rows=0 if sparse else 10 ** 9, dedup=dedup)
+        opt = None
+        if optimizer is not None:
+            from torecsys_amd.optim import FusedSparseAdagrad, FusedSparseSGD
+            opt = FusedSparseSGD(0.1) if optimizer == "sgd" else FusedSparseAdagrad(0.1, eps=1e-10)
+            m.set_fused_optimizer(opt)
         assert list(m.state_dict().keys()) == ["embedding.weight"]
         m.load_full_weight(W)
         per, ranges = shard_ranges(V, world)
@@ -98,7 +144,9 @@ def _worker(rank, world, port, fuse, sparse, ret):
             loss = loss + (fm * gf_all[rank]).sum()
         loss.backward()
         gw = m.embedding.weight.grad
-        if sparse:
+        if opt is not None:
+            assert gw is None, "the fused optimizer leaves no gradient tensor"
+        elif sparse:
             assert gw.is_sparse
             gw = gw.to_dense()
         # reference: gradient of the full table summed over every rank's batch
@@ -111,7 +159,16 @@ def _worker(rank, world, port, fuse, sparse, ret):
                 tot = tot + (O.fm_layer(e) * gf_all[r]).sum()
         tot.backward()
         lo, hi = m.row_range
-        assert torch.allclose(gw[: hi - lo], Wr.grad[lo:hi], rtol=1e-5, atol=1e-5)
+        if opt is None:
+            assert torch.allclose(gw[: hi - lo], Wr.grad[lo:hi], rtol=1e-5, atol=1e-5)
+        else:
+            # the owner's rows after its in-backward step == a dense torch.optim step on the full-table gradient
+            Wd = W.clone().requires_grad_()
+            Wd.grad = Wr.grad.clone()
+            ref_opt = (torch.optim.SGD([Wd], lr=0.1) if optimizer == "sgd"
+                       else torch.optim.Adagrad([Wd], lr=0.1, eps=1e-10))
+            ref_opt.step()
+            assert torch.allclose(m.embedding.weight.data[: hi - lo], Wd.data[lo:hi], rtol=1e-5, atol=1e-5)
         ret[rank] = "ok"
     except Exception as e:  # noqa: BLE001
         import traceback
@@ -120,15 +177,34 @@ def _worker(rank, world, port, fuse, sparse, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,fuse,sparse", [(2, False, False), (2, True, False), (2, True, True), (3, False, True)])
-def test_row_sharded_lookup_gloo(world, fuse, sparse):
+def _run(world, *args):
     assert dist.is_gloo_available()
     mgr = mp.Manager()
     ret = mgr.dict()
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, fuse, sparse, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, *args[:2], ret, *args[2:]), nprocs=world, join=True)
     for r in range(world):
         assert ret.get(r) == "ok", ret.get(r)
+
+
+@pytest.mark.parametrize("world,fuse,sparse", [(2, False, False), (2, True, False), (2, True, True), (3, False, True)])
+def test_row_sharded_lookup_gloo(world, fuse, sparse):
+    _run(world, fuse, sparse)
+
+
+@pytest.mark.parametrize("world,fuse,sparse", [(2, False, False), (2, True, False), (3, True, True)])
+def test_row_sharded_lookup_dedup_gloo(world, fuse, sparse):
+    """every distinct row id travels once: the block stays bit-exact, duplicate lookups' gradients are summed before
+    the reverse exchange"""
+    _run(world, fuse, sparse, True)
+
+
+@pytest.mark.parametrize("world,fuse,sparse,dedup,optimizer", [(2, False, False, False, "sgd"), (2, True, True, False, "adagrad"),
+                                                               (3, True, True, True, "sgd"), (1, True, False, False, "adagrad")])
+def test_row_sharded_fused_optimizer_gloo(world, fuse, sparse, dedup, optimizer):
+    """set_fused_optimizer on the sharded module: the owner steps its rows inside the backward pass (no gradient
+    tensor), equal to a dense torch.optim step on the full table"""
+    _run(world, fuse, sparse, dedup, optimizer)
 
 
 def test_default_ops_refuse_cpu():

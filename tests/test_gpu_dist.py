@@ -60,3 +60,71 @@ def test_sharded_equals_unsharded(pg, dtype, fuse, sparse):
     tol = 1e-5 if dtype == torch.float32 else (2e-2 if sparse else 1e-2)   # sparse bf16: torch coalesces in bf16
     assert rel_err(res[1][1], res[0][1]) <= tol
     assert rel_err(res[1][2], res[0][2]) <= tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("fuse", [False, True])
+def test_sharded_dedup_equals_unsharded(pg, dtype, fuse):
+    """dedup=True: distinct row ids travel once; block bit-exact, gradients equal the unsharded module's (duplicates
+    inside the batch are plentiful: 1000 lookups per field over ~50-160 rows)."""
+    from torecsys_amd.dist import RowShardedMultiIndicesEmbedding
+    from torecsys_amd.inputs import MultiIndicesEmbedding
+    from torecsys_amd.layers import FMLayer
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(4)
+    fs = [50 + 3 * i for i in range(39)]
+    B, N, E = 1000, 39, 64
+    idx = torch.cat([torch.randint(0, f, (B, 1), generator=g) for f in fs], 1).to(dev)
+    W = torch.randn(sum(fs), E, generator=g).to(dtype)
+    gb = torch.randn(B, N, E, generator=g).to(dtype).to(dev)
+    res = []
+    for sharded in (False, True):
+        if sharded:
+            m = RowShardedMultiIndicesEmbedding(embed_size=E, field_sizes=fs, fuse_fm=fuse, dtype=dtype, device=dev, dedup=True)
+            m.load_full_weight(W.to(dev))
+        else:
+            m = MultiIndicesEmbedding(embed_size=E, field_sizes=fs, fuse_fm=fuse).to(dev).to(dtype)
+            m.embedding.weight.data.copy_(W)
+        out = m(idx)
+        y = FMLayer()(out)
+        ((out.rename(None).float() * gb.float()).sum() + (y.rename(None).float() ** 2).sum()).backward()
+        res.append((out.rename(None).detach(), y.rename(None).detach().float(), m.embedding.weight.grad.float()))
+    assert torch.equal(res[0][0], res[1][0])
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_err(res[1][1], res[0][1]) <= tol
+    assert rel_err(res[1][2], res[0][2]) <= tol
+
+
+@pytest.mark.parametrize("big_shard", [False, True])
+@pytest.mark.parametrize("kind", ["sgd", "adagrad", "adam"])
+def test_sharded_fused_optimizer_matches_unsharded(pg, kind, big_shard):
+    """set_fused_optimizer on the sharded module == the fused optimizer on the unsharded module (same kernels on the
+    owner; ``big_shard`` forces the compact-row path a 125 M-row shard takes: torch.unique + trs_scatter_rows_update_mapped)."""
+    from torecsys_amd.dist import RowShardedMultiIndicesEmbedding
+    from torecsys_amd.inputs import MultiIndicesEmbedding
+    from torecsys_amd.optim import FusedSparseAdagrad, FusedSparseAdam, FusedSparseSGD
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(6)
+    fs = [40 + 5 * i for i in range(12)]
+    B, N, E = 700, 12, 64
+    W = torch.randn(sum(fs), E, generator=g)
+    mk = {"sgd": lambda: FusedSparseSGD(0.05), "adagrad": lambda: FusedSparseAdagrad(0.05),
+          "adam": lambda: FusedSparseAdam(0.01)}[kind]
+    outs = []
+    for sharded in (False, True):
+        if sharded:
+            m = RowShardedMultiIndicesEmbedding(embed_size=E, field_sizes=fs, dtype=torch.float32, device=dev,
+                                                dense_grad_max_rows=0 if big_shard else 10 ** 9)
+            m.load_full_weight(W.to(dev))
+        else:
+            m = MultiIndicesEmbedding(embed_size=E, field_sizes=fs).to(dev)
+            m.embedding.weight.data.copy_(W)
+        m.set_fused_optimizer(mk())
+        gg = torch.Generator().manual_seed(7)
+        for _ in range(3):                      # three steps: the optimizer state carries over
+            idx = torch.cat([torch.randint(0, f, (B, 1), generator=gg) for f in fs], 1).to(dev)
+            gb = torch.randn(B, N, E, generator=gg).to(dev)
+            (m(idx).rename(None) * gb).sum().backward()
+            assert m.embedding.weight.grad is None
+        outs.append(m.embedding.weight.detach().clone())
+    assert rel_err(outs[1], outs[0]) <= 1e-5

@@ -70,6 +70,13 @@ def test_padded_weights_follow_parameter_updates(dev):
     assert rel_err(mlp(x).rename(None).detach().float().cpu(), _plain(mlp)(x).detach().float().cpu()) <= 2e-2
     assert set(mlp.state_dict().keys()) == set(sd.keys())
     assert mlp.model.Linear_0.weight.shape == (400, 64)
+    # writes through .data do NOT bump _version (p.data.add_-style optimizers, clipping, EMA swap-in, broadcasts):
+    # the padded copies must follow them as well
+    for p in mlp.parameters():
+        v = p._version
+        p.data.mul_(-1.5)
+        assert p._version == v
+    assert rel_err(mlp(x).rename(None).detach().float().cpu(), _plain(mlp)(x).detach().float().cpu()) <= 2e-2
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

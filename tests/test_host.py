@@ -158,3 +158,33 @@ def test_rowdot_width_rule():
     assert not rowdot_width_supported(400, 2)                # 50 vectors: not a power of two
     assert not rowdot_width_supported(1024, 2)               # 128 vectors: more than a wavefront
     assert not rowdot_width_supported(12, 2)                 # not a multiple of 16 bytes
+
+
+def test_fused_optimizer_state_dict_roundtrip():
+    """FusedSparse* state is keyed by the nn.Parameter, follows it across devices and survives a checkpoint
+    (a resume silently reset accumulators / moments / step counts)."""
+    import torch.nn as nn
+    from torecsys_amd.optim import FusedSparseAdagrad, FusedSparseAdam
+    p = nn.Parameter(torch.zeros(5, 4))
+    ada = FusedSparseAdagrad(0.1, initial_accumulator_value=0.5)
+    st = ada.state_for(p.data, p)
+    assert st.shape == (5, 4) and float(st[0, 0]) == 0.5
+    st.add_(1.0)
+    assert ada.state_for(p.data, p) is st                       # same parameter -> same state, new .data tensor or not
+    sd = ada.state_dict([("emb.embedding.weight", p)])
+    assert list(sd["tables"]) == ["emb.embedding.weight"]
+    p2 = nn.Parameter(torch.zeros(5, 4))
+    ada2 = FusedSparseAdagrad(0.7)
+    ada2.load_state_dict(sd, [("emb.embedding.weight", p2)])
+    assert ada2.lr == 0.1 and torch.equal(ada2.state_for(p2.data, p2), st)
+    adam = FusedSparseAdam(1e-3)
+    for _ in range(3):
+        adam.next_step_size(p.data, p)
+    adam.state_for(p.data, p)[0].fill_(2.0)
+    sd = adam.state_dict([("w", p)])
+    adam2 = FusedSparseAdam(1e-3)
+    adam2.load_state_dict(sd, {"w": p2}.items())
+    assert abs(adam2.next_step_size(p2.data, p2) - adam.next_step_size(p.data, p)) < 1e-12      # both at step 4
+    assert torch.equal(adam2.state_for(p2.data, p2)[0], adam.state_for(p.data, p)[0])
+    with pytest.raises(KeyError):
+        FusedSparseAdam().load_state_dict(sd, [("other", p2)])

@@ -69,6 +69,8 @@ SIGNATURES = {
     "trs_scatter_rows_update_adam": (c_int32, [_P, _I64, _P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _I64,
                                                ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P, _P,
                                                _P, _SZ, _P]),
+    "trs_scatter_rows_update_mapped": (c_int32, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, ctypes.c_float,
+                                                 ctypes.c_float, ctypes.c_float, ctypes.c_float, _P, _P, _P, _SZ, _P]),
     "trs_embed_fm": (c_int32, [_P, _I64, _I32, _I32, _P, _I32, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "trs_fm_fwd": (c_int32, [_P, _I64, _I32, _I32, _I32, _P, _P, _P]),
     "trs_fm_bwd": (c_int32, [_P, _P, _P, _I64, _I32, _I32, _I32, _P, _P]),

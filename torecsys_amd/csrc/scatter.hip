@@ -289,7 +289,11 @@ struct RowSink {
   float* state;  // Adagrad accumulator / Adam exp_avg (V x E fp32) or null
   float beta1 = 0.f, beta2 = 0.f;
   float* state2 = nullptr;  // Adam exp_avg_sq
+  // Optional: the bucketed rows are a COMPACT list of distinct table rows (row_map[r] = table row of bucket row r):
+  // the owner side of a row-sharded table, whose 125 M-row shard cannot afford a V-sized bucket index per step.
+  const int32_t* row_map = nullptr;
 };
+__device__ __forceinline__ int64_t sink_row(const RowSink& k, int64_t r) { return k.row_map ? (int64_t)k.row_map[r] : r; }
 
 template <typename T>
 __device__ __forceinline__ void sink_vec(const RowSink& k, uint4* __restrict__ out, int64_t vec, const float* acc,
@@ -477,7 +481,7 @@ __global__ __launch_bounds__(256) void scatter_rows_group_kernel(
         for (int k = 0; k < VE; ++k) acc[k] = fmaf(-w[k], gsum[k], acc[k]);
       }
     }
-    sink_vec<T>(sink, grad, r * L + lane_v, acc, end > beg && r != padding_row);
+    sink_vec<T>(sink, grad, sink_row(sink, r) * L + lane_v, acc, end > beg && r != padding_row);
   }
 }
 
@@ -530,7 +534,7 @@ __global__ __launch_bounds__(256) void scatter_long_rows_kernel(
 #pragma unroll
           for (int k = 0; k < VE; ++k) acc[k] = fmaf(-w[k], gsum[k], acc[k]);
         }
-        sink_vec<T>(sink, grad, r * L + lane_v, acc, true);
+        sink_vec<T>(sink, grad, sink_row(sink, r) * L + lane_v, acc, true);
       } else {
         float* sa = scratch + ((size_t)i * 2) * (L * VE) + lane_v * VE;
 #pragma unroll
@@ -570,7 +574,7 @@ __global__ __launch_bounds__(256) void scatter_long_rows_finish_kernel(
 #pragma unroll
       for (int k = 0; k < VE; ++k) acc[k] = fmaf(-w[k], gsum[k], acc[k]);
     }
-    sink_vec<T>(sink, grad, r * L + lane_v, acc, true);
+    sink_vec<T>(sink, grad, sink_row(sink, r) * L + lane_v, acc, true);
   }
 }
 
@@ -643,7 +647,7 @@ __global__ __launch_bounds__(256) void scatter_rows_elem_kernel(
       for (int q = beg; q < end; ++q) acc += elem_term<T>(g_rows, g_fm, fm_sum, perm[q], E, N, gbs, e, &gsum);
       if (g_fm != nullptr && fm_sum != nullptr && end > beg) acc = fmaf(-to_f32(table[t]), gsum, acc);
     }
-    sink_elem<T>(sink, grad, t, acc, touched);
+    sink_elem<T>(sink, grad, sink_row(sink, r) * E + e, acc, touched);
   }
 }
 
@@ -679,7 +683,7 @@ __global__ __launch_bounds__(256) void scatter_long_rows_elem_kernel(
       }
       if (lane == 0) {
         if (g_fm != nullptr && fm_sum != nullptr) acc = fmaf(-to_f32(table[r * E + e]), gsum, acc);
-        sink_elem<T>(sink, grad, r * E + e, acc, true);
+        sink_elem<T>(sink, grad, sink_row(sink, r) * E + e, acc, true);
       }
     }
   }
@@ -918,4 +922,24 @@ extern "C" int trs_scatter_rows_update_adam(const void* g_rows, int64_t g_rows_b
   sink.state2 = exp_avg_sq;
   return scatter_rows_impl(sink, g_rows, g_rows_batch_stride, g_fm, fm_sum, table, row_start, perm, BN, V, E, N, dtype,
                            padding_row, table, workspace, ws_bytes, stream);
+}
+
+/* see include/trs_abi.h: the fused sparse optimizer step on a COMPACT list of distinct rows */
+extern "C" int trs_scatter_rows_update_mapped(const void* g_rows, void* table, const int32_t* row_map,
+                                              const int32_t* row_start, const int32_t* perm, int64_t K, int64_t U,
+                                              int64_t V, int32_t E, int32_t dtype, int32_t optimizer, float lr, float eps,
+                                              float beta1, float beta2, float* state, float* state2, void* workspace,
+                                              size_t ws_bytes, trs_stream_t stream) {
+  TRS_REQUIRE(g_rows && table && row_map, TRS_EINVAL, "scatter_rows_update_mapped: NULL pointer");
+  TRS_REQUIRE(optimizer >= 1 && optimizer <= 3, TRS_EINVAL, "scatter_rows_update_mapped: optimizer %d", optimizer);
+  TRS_REQUIRE(optimizer == 1 || state != nullptr, TRS_EINVAL, "scatter_rows_update_mapped: missing optimizer state");
+  TRS_REQUIRE(optimizer != 3 || state2 != nullptr, TRS_EINVAL, "scatter_rows_update_mapped: Adam needs both moments");
+  TRS_REQUIRE(U > 0 && U <= V, TRS_EINVAL, "scatter_rows_update_mapped: bad row counts");
+  RowSink sink{optimizer, lr, eps, state};
+  sink.beta1 = beta1;
+  sink.beta2 = beta2;
+  sink.state2 = state2;
+  sink.row_map = row_map;
+  return scatter_rows_impl(sink, g_rows, 0, nullptr, nullptr, table, row_start, perm, K, U, E, 1, dtype, -1, table,
+                           workspace, ws_bytes, stream);
 }

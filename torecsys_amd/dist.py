@@ -17,6 +17,13 @@ into ``world`` contiguous ranges; every rank keeps its local batch (data paralle
             GPU a dense gradient would be 16 GB per step (documented divergence from nn.Embedding's
             sparse=False default).
 
+With ``set_fused_optimizer(opt)`` the owner applies the optimizer step to the rows it received gradients for inside
+the backward pass (no gradient tensor at all: the mandatory mode for 125 M-row shards).
+``dedup=True`` sends every distinct row id of the local batch once (torch.unique before the exchange): the block is
+rebuilt from the distinct rows and the gradients of duplicate lookups are summed before they travel -- pays on skewed
+(Zipf) data, costs a sort on uniform data, default off.  A process group of one rank takes no collective and no host
+read at all (the step is then capturable into a hipGraph).
+
 ``backend='nccl'`` is RCCL on ROCm (xGMI links); the same code runs on ``gloo`` with CPU tensors when a
 CPU ``ops`` object is injected (tests only -- the default ops are the HIP kernels and refuse CPU tensors).
 """
@@ -55,14 +62,53 @@ class HipOps:
              ptr(counts), ptr(send_ids), ptr(send_pos), ptr(inv_pos), ptr(ws), ws_bytes, stream_ptr())
         return counts, send_ids, send_pos, inv_pos
 
-    def gather_local(self, weight: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    def gather_local(self, weight: torch.Tensor, ids: torch.Tensor, n_valid: Optional[int] = None) -> torch.Tensor:
+        """rows ``ids`` of this rank's shard.  Ids outside [0, n_valid) -- a global id past the table, a negative id,
+        the short last shard -- read as zero rows and raise the device-side index flag
+        (functional.index_errors_seen() / TRS_CHECK_INDICES=1) instead of touching foreign memory."""
         K = ids.numel()
         V, E = weight.shape
         out = torch.empty(K, E, dtype=weight.dtype, device=weight.device)
         if K:
-            call("trs_gather_rows", ptr(weight), V, E, value_dtype_code(weight), ptr(ids), index_dtype_code(ids),
-                 ptr(None), K, 1, ptr(out), ptr(None), stream_ptr())
+            flag = F_._ErrFlag(weight.device)
+            call("trs_gather_rows", ptr(weight), V if n_valid is None else min(V, n_valid), E, value_dtype_code(weight),
+                 ptr(ids), index_dtype_code(ids), ptr(None), K, 1, ptr(out), ptr(flag.t), stream_ptr())
+            flag.check("sharded lookup")
         return out
+
+    def unique_route(self, idx: torch.Tensor, offsets: torch.Tensor, rows_per_rank: int, world: int):
+        """De-duplicated routing: (counts per owner (W int64), LOCAL ids of the distinct rows grouped by owner (U int32),
+        slot of every lookup in that list (B*N int32))."""
+        require_device(idx, offsets)
+        g = (idx.long() + offsets.view(1, -1)).reshape(-1)
+        uniq, inv = torch.unique(g, return_inverse=True)            # ascending global ids: grouped by owner already
+        owner = torch.div(uniq, rows_per_rank, rounding_mode="floor").clamp_(0, world - 1)
+        counts = torch.bincount(owner, minlength=world).to(torch.int64)
+        return counts, (uniq - owner * rows_per_rank).to(torch.int32), inv.to(torch.int32)
+
+    def reduce_grad_unique(self, g_block, inv, rows, g_fm, fm_sum):
+        """gradient of the U distinct rows: sum over the lookups that point at each (+ the folded FM term, with the
+        received rows standing in for the table) -- the row-bucket reduction of the unsharded backward on a U-row space."""
+        U, E = rows.shape
+        K = inv.numel()
+        rb = F_.row_buckets(inv.view(K, 1), None, U)
+        gb = None if g_block is None else g_block.reshape(K, 1, E).contiguous()
+        if g_fm is not None:
+            # lookups per sample: the FM operands are indexed by sample = lookup // N
+            rb = F_.RowBuckets(rb.row_start, rb.perm, rb.V, rb.BN, K // g_fm.shape[0])
+            return F_.scatter_rows(rb, rows, g_rows=gb, g_bcast=g_fm.contiguous(), fm_sum=fm_sum)
+        return F_.scatter_rows(rb, rows, g_rows=gb)
+
+    def shard_update(self, weight: torch.Tensor, ids: torch.Tensor, grad_rows: torch.Tensor, opt, dense_index: bool):
+        """fused optimizer step on the owner: rows ``ids`` (with repeats) of ``weight`` receive ``grad_rows``"""
+        with torch.no_grad():
+            if dense_index:
+                rb = F_.row_buckets(ids.view(-1, 1), None, weight.shape[0])
+                F_.scatter_rows_update(rb, weight.data, opt, g_rows=grad_rows.contiguous(), key=weight)
+            else:
+                uniq, inv = torch.unique(ids, return_inverse=True)
+                rb = F_.row_buckets(inv.to(torch.int32).view(-1, 1), None, uniq.numel())
+                F_.scatter_rows_update_mapped(rb, weight.data, opt, grad_rows, uniq.to(torch.int32), key=weight)
 
     def unpermute(self, rows: torch.Tensor, inv_pos: torch.Tensor, B: int, N: int, want_fm: bool):
         """block[p] = rows[inv_pos[p]]; with ``want_fm`` also FM second order + the fp32 field sum."""
@@ -134,11 +180,18 @@ route_stats = {"prefetched": 0, "cached": 0, "cold": 0}     # how forward passes
 
 def _start_route(idx: torch.Tensor, mod) -> "_PendingRoute":
     ops, group, world = mod.ops, mod.group, mod.world
-    counts, send_ids, send_pos, inv_pos = ops.bucket_by_owner(idx, mod.offsets, mod.rows_per_rank, world)
+    pr = _PendingRoute()
+    if mod.dedup:
+        counts, send_ids, inv = ops.unique_route(idx, mod.offsets, mod.rows_per_rank, world)
+        pr.send_ids, pr.send_pos, pr.inv_pos = send_ids, None, inv
+    else:
+        counts, send_ids, send_pos, inv_pos = ops.bucket_by_owner(idx, mod.offsets, mod.rows_per_rank, world)
+        pr.send_ids, pr.send_pos, pr.inv_pos = send_ids, send_pos, inv_pos
+    if world == 1:
+        pr.host_counts, pr.ready = None, None        # one rank: everything stays local, nothing to read back
+        return pr
     recv_counts = torch.empty_like(counts)
     dist.all_to_all_single(recv_counts, counts, group=group)
-    pr = _PendingRoute()
-    pr.send_ids, pr.send_pos, pr.inv_pos = send_ids, send_pos, inv_pos
     both = torch.stack([counts, recv_counts])
     if both.is_cuda:
         pr.host_counts = torch.empty(both.shape, dtype=both.dtype, pin_memory=True)
@@ -180,18 +233,31 @@ def _route_plan(idx: torch.Tensor, mod) -> "RoutePlan":
     if pr is None:
         route_stats["cold"] += 1
         pr = _start_route(idx, mod)
-    if pr.ready is not None:
-        pr.ready.synchronize()                 # waits for the tiny count copy only (long done when prefetched)
     p = RoutePlan()
-    p.send_splits = pr.host_counts[0].tolist()
-    p.recv_splits = pr.host_counts[1].tolist()
     p.send_pos, p.inv_pos = pr.send_pos, pr.inv_pos
-    p.recv_ids = torch.empty(sum(p.recv_splits), dtype=torch.int32, device=idx.device)
-    _all_to_all(p.recv_ids, pr.send_ids, p.recv_splits, p.send_splits, mod.group)
+    if mod.world == 1:
+        n = int(pr.send_ids.numel())                 # a shape, not a device value: no synchronisation
+        p.send_splits, p.recv_splits, p.recv_ids = [n], [n], pr.send_ids
+    else:
+        if pr.ready is not None:
+            pr.ready.synchronize()                 # waits for the tiny count copy only (long done when prefetched)
+        p.send_splits = pr.host_counts[0].tolist()
+        p.recv_splits = pr.host_counts[1].tolist()
+        p.recv_ids = torch.empty(sum(p.recv_splits), dtype=torch.int32, device=idx.device)
+        _all_to_all(p.recv_ids, pr.send_ids, p.recv_splits, p.send_splits, mod.group)
     _route_cache.append((key, idx, p))
     if len(_route_cache) > 2:
         _route_cache.pop(0)
     return p
+
+
+def _exchange(out_rows: int, inp: torch.Tensor, out_splits, in_splits, mod) -> torch.Tensor:
+    """all-to-all of row blocks; a one-rank group hands the tensor through"""
+    if mod.world == 1:
+        return inp
+    out = torch.empty(out_rows, inp.shape[1], dtype=inp.dtype, device=inp.device)
+    _all_to_all(out, inp, out_splits, in_splits, mod.group)
+    return out
 
 
 class _ShardedLookup(Function):
@@ -199,17 +265,16 @@ class _ShardedLookup(Function):
 
     @staticmethod
     def forward(ctx, weight, idx, mod):
-        ops, group = mod.ops, mod.group
+        ops = mod.ops
         B, N = idx.shape
-        E = weight.shape[1]
         plan = _route_plan(idx, mod)
-        rows = ops.gather_local(weight, plan.recv_ids)                              # (K,E) rows of my shard
-        back = torch.empty(B * N, E, dtype=weight.dtype, device=weight.device)
-        _all_to_all(back, rows, plan.send_splits, plan.recv_splits, group)
+        rows = ops.gather_local(weight, plan.recv_ids, mod.row_range[1] - mod.row_range[0])     # rows of my shard
+        back = _exchange(sum(plan.send_splits), rows, plan.send_splits, plan.recv_splits, mod)
         block, fm, fm_sum = ops.unpermute(back, plan.inv_pos, B, N, mod.fuse_fm)
         ctx.mod = mod
         ctx.splits = (plan.send_splits, plan.recv_splits)
-        ctx.save_for_backward(weight, plan.recv_ids, plan.send_pos, block if mod.fuse_fm else None, fm_sum)
+        ctx.save_for_backward(weight, plan.recv_ids, plan.send_pos if plan.send_pos is not None else plan.inv_pos,
+                              block if mod.fuse_fm else None, fm_sum, back if mod.dedup else None)
         ctx.set_materialize_grads(False)
         if fm is None:
             fm = block.new_empty(0)
@@ -220,18 +285,25 @@ class _ShardedLookup(Function):
     @once_differentiable
     def backward(ctx, g_block, g_fm):
         mod = ctx.mod
-        ops, group = mod.ops, mod.group
-        weight, recv_ids, send_pos, block, fm_sum = ctx.saved_tensors
+        ops = mod.ops
+        weight, recv_ids, pos, block, fm_sum, back = ctx.saved_tensors
         send_splits, recv_splits = ctx.splits
-        E = weight.shape[1]
         if g_block is None and g_fm is None:
             return None, None, None
-        if block is None:
-            block = g_block     # shape carrier only
-        g_rows = ops.permute_grad(g_block, send_pos, g_fm if mod.fuse_fm else None, fm_sum, block)
-        recv_g = torch.empty(sum(recv_splits), E, dtype=g_rows.dtype, device=g_rows.device)
-        _all_to_all(recv_g, g_rows, recv_splits, send_splits, group)               # reverse exchange
-        if weight.shape[0] <= mod.dense_grad_max_rows:
+        if mod.dedup:
+            # one gradient row per DISTINCT row of the local batch (duplicates summed before they travel)
+            g_rows = ops.reduce_grad_unique(g_block, pos, back, g_fm if mod.fuse_fm else None, fm_sum)
+        else:
+            if block is None:
+                block = g_block     # shape carrier only
+            g_rows = ops.permute_grad(g_block, pos, g_fm if mod.fuse_fm else None, fm_sum, block)
+        recv_g = _exchange(sum(recv_splits), g_rows, recv_splits, send_splits, mod)              # reverse exchange
+        dense_index = weight.shape[0] <= mod.dense_grad_max_rows
+        if mod.fused_optimizer is not None:
+            # the owner steps its rows right here: no gradient tensor of any kind (weight.grad stays None)
+            ops.shard_update(weight, recv_ids, recv_g, mod.fused_optimizer, dense_index)
+            return None, None, None
+        if dense_index:
             gw = ops.shard_grad_dense(weight, recv_ids, recv_g)
         else:
             gw = torch.sparse_coo_tensor(recv_ids.long().unsqueeze(0), recv_g, size=weight.shape)
@@ -247,7 +319,7 @@ class RowShardedMultiIndicesEmbedding(BaseInput):
 
     def __init__(self, embed_size: int, field_sizes: List[int], flatten: bool = False, fuse_fm: bool = False,
                  dtype: torch.dtype = torch.float32, device='cpu', process_group=None, ops=None,
-                 dense_grad_max_rows: int = DENSE_GRAD_MAX_ROWS):
+                 dense_grad_max_rows: int = DENSE_GRAD_MAX_ROWS, dedup: bool = False):
         super().__init__()
         if not dist.is_initialized():
             raise RuntimeError("RowShardedMultiIndicesEmbedding needs torch.distributed to be initialised")
@@ -267,7 +339,8 @@ class RowShardedMultiIndicesEmbedding(BaseInput):
         self.embed_size = embed_size
         self.padding_idx = None
         self.dense_grad_max_rows = dense_grad_max_rows
-        self.route_key = (tuple(int(f) for f in field_sizes), self.world, id(process_group))
+        self.dedup = bool(dedup)
+        self.route_key = (tuple(int(f) for f in field_sizes), self.world, id(process_group), self.dedup)
         self.length = embed_size * len(field_sizes) if flatten else embed_size
 
     def forward(self, inputs: torch.Tensor) -> torch.Tensor:

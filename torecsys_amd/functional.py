@@ -262,7 +262,7 @@ def scatter_rows(rb: RowBuckets, like_table: torch.Tensor, g_rows: Optional[torc
 
 def scatter_rows_update(rb: RowBuckets, table: torch.Tensor, opt, g_rows: Optional[torch.Tensor] = None,
                         g_bcast: Optional[torch.Tensor] = None, fm_sum: Optional[torch.Tensor] = None,
-                        padding_row: int = -1) -> None:
+                        padding_row: int = -1, key=None) -> None:
     """Fused sparse optimizer step: the bucketed gradient of every looked-up row is applied to ``table`` in
     place (see trs_scatter_rows_update); no gradient tensor is produced."""
     V, E = table.shape
@@ -277,15 +277,40 @@ def scatter_rows_update(rb: RowBuckets, table: torch.Tensor, opt, g_rows: Option
             raise RuntimeError("torecsys_amd: FusedSparseAdam cannot be captured into a hipGraph (its per-step bias "
                                "correction is a host-side scalar); use FusedSparseSGD / FusedSparseAdagrad under "
                                "GraphedStep, or run the Adam step eagerly")
-        m1, m2 = opt.state_for(table)
+        m1, m2 = opt.state_for(table, key)
         call("trs_scatter_rows_update_adam", ptr(g_rows), 0, ptr(g_bcast), ptr(fm_sum), ptr(table), ptr(rb.row_start),
-             ptr(rb.perm), rb.BN, V, E, rb.N, value_dtype_code(table), padding_row, float(opt.next_step_size(table)),
+             ptr(rb.perm), rb.BN, V, E, rb.N, value_dtype_code(table), padding_row, float(opt.next_step_size(table, key)),
              float(opt.beta1), float(opt.beta2), float(opt.eps), ptr(m1), ptr(m2), ptr(ws), ws_bytes, stream_ptr())
         return
-    state = opt.state_for(table)
+    state = opt.state_for(table, key)
     call("trs_scatter_rows_update", ptr(g_rows), 0, ptr(g_bcast), ptr(fm_sum), ptr(table), ptr(rb.row_start),
          ptr(rb.perm), rb.BN, V, E, rb.N, value_dtype_code(table), padding_row, opt.kind, float(opt.lr), float(opt.eps),
          ptr(state), ptr(ws), ws_bytes, stream_ptr())
+
+
+def scatter_rows_update_mapped(rb: RowBuckets, table: torch.Tensor, opt, g_rows: torch.Tensor, row_map: torch.Tensor,
+                               key=None):
+    """Fused sparse optimizer step where the bucketed rows are a compact list of distinct table rows:
+    ``rb`` buckets the K rows of ``g_rows`` by compact row u (rb.V = U), ``row_map[u]`` (int32, distinct) is the table
+    row that u updates.  See trs_scatter_rows_update_mapped."""
+    V, E = table.shape
+    if not table.is_contiguous():
+        raise ValueError("fused optimizer needs a contiguous table")
+    if row_map.dtype != torch.int32 or row_map.numel() != rb.V:
+        raise ValueError("row_map must be int32 with one entry per bucketed row")
+    ws_bytes = size_query("trs_scatter_workspace_bytes", rb.BN, 1, E, value_dtype_code(table))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=table.device)
+    lr, st1, st2, b1, b2 = float(opt.lr), None, None, 0.0, 0.0
+    if opt.kind == 3:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("torecsys_amd: FusedSparseAdam cannot be captured into a hipGraph")
+        st1, st2 = opt.state_for(table, key)
+        lr, b1, b2 = float(opt.next_step_size(table, key)), float(opt.beta1), float(opt.beta2)
+    elif opt.kind == 2:
+        st1 = opt.state_for(table, key)
+    call("trs_scatter_rows_update_mapped", ptr(g_rows.contiguous()), ptr(table), ptr(row_map), ptr(rb.row_start),
+         ptr(rb.perm), rb.BN, rb.V, V, E, value_dtype_code(table), opt.kind, lr, float(opt.eps), b1, b2, ptr(st1), ptr(st2),
+         ptr(ws), ws_bytes, stream_ptr())
 
 
 def _apply_or_grad(rb, weight, opt, **kw):
@@ -293,7 +318,7 @@ def _apply_or_grad(rb, weight, opt, **kw):
     if opt is None:
         return scatter_rows(rb, weight, **kw)
     with torch.no_grad():
-        scatter_rows_update(rb, weight.data, opt, **kw)
+        scatter_rows_update(rb, weight.data, opt, key=weight, **kw)
     return None
 
 
@@ -312,7 +337,7 @@ class _GatherRows(Function):
         call("trs_gather_rows", ptr(w), V, E, value_dtype_code(w), ptr(idx), index_dtype_code(idx), ptr(offsets),
              B, N, ptr(out), ptr(flag.t), stream_ptr())
         flag.check("gather_rows")
-        if weight.requires_grad and E * w.element_size() >= 16:
+        if ctx.needs_input_grad[0] and E * w.element_size() >= 16:      # False under torch.no_grad(): no backward, no buckets
             # (narrow tables -- the E=1 first-order weights -- leave the prefetch to the wide table that shares
             # their indices, so the bucket build overlaps the dense part of the model, not the lookups)
             prefetch_row_buckets(idx, offsets, V)
@@ -368,7 +393,7 @@ class _EmbedFM(Function):
         call("trs_embed_fm", ptr(w), V, E, value_dtype_code(w), ptr(idx), index_dtype_code(idx), ptr(offsets), B, N,
              ptr(emb), ptr(fm), ptr(fm_sum), ptr(fw), ptr(first), ptr(flag.t), stream_ptr())
         flag.check("embed_fm")
-        if weight.requires_grad or (first_weight is not None and first_weight.requires_grad):
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[3]:
             prefetch_row_buckets(idx, offsets, V)
         ctx.save_for_backward(idx, offsets, weight, first_weight, fm_sum)
         ctx.want_emb = want_emb
@@ -484,7 +509,7 @@ class _FAGather(Function):
         call("trs_fa_gather_rows", ptr(_pointer_table(ws)), V, E, value_dtype_code(ws[0]), ptr(idx),
              index_dtype_code(idx), ptr(offsets), B, N, ptr(out), ptr(flag.t), stream_ptr())
         flag.check("fa_gather_rows")
-        if any(w.requires_grad for w in weights):
+        if any(ctx.needs_input_grad[2:]):
             prefetch_row_buckets(idx, offsets, V)
         ctx.save_for_backward(idx, offsets, *weights)
         return out
@@ -1237,7 +1262,7 @@ class _FFMFused(Function):
         call("trs_ffm_fused_fwd", ptr(_pointer_table(ws)), V, E, value_dtype_code(ws[0]), ptr(idx), index_dtype_code(idx),
              ptr(offsets), B, N, ptr(out), ptr(flag.t), stream_ptr())
         flag.check("ffm_fused_fwd")
-        if any(w.requires_grad for w in weights):
+        if any(ctx.needs_input_grad[2:]):
             prefetch_row_buckets(idx, offsets, V)
         ctx.save_for_backward(idx, offsets, *weights)
         return out

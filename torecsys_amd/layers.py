@@ -512,8 +512,8 @@ def _pad_width(width: int) -> int:
 
 
 class _PaddedLinear:
-    """Zero-padded copies of one nn.Linear's weight/bias, refreshed when the parameters change (optimizer steps bump
-    ``_version``; ``.to()`` / ``load_state_dict`` change storage or version) and on every hipGraph capture, where the
+    """Zero-padded copies of one nn.Linear's weight/bias, refreshed on every training forward (one small copy per
+    layer; parameters the user owns can change without any version bump) and on every hipGraph capture, where the
     refresh must be part of the replayed work.  The parameters themselves keep the reference's shapes."""
     __slots__ = ("w", "b", "key")
 
@@ -527,8 +527,11 @@ class _PaddedLinear:
             st.b = torch.zeros(out_pad, dtype=w.dtype, device=w.device) if b is not None else None
             st.key = None
             mod.__dict__['_trs_padded'] = st
+        # refreshed on EVERY forward that can be followed by a parameter update (grad mode): in-place writes through
+        # ``p.data`` (p.data.add_(), clipping, EMA swap-in, dist.broadcast(p.data)) do not bump ``_version``, so a
+        # version key would leave the padded copy stale.  Inference (no_grad) keeps the (ptr, version) key.
         key = (w.data_ptr(), w._version, None if b is None else (b.data_ptr(), b._version))
-        if st.key != key or torch.cuda.is_current_stream_capturing():
+        if st.key != key or torch.is_grad_enabled() or torch.cuda.is_current_stream_capturing():
             with torch.no_grad():
                 st.w[:w.shape[0], :w.shape[1]].copy_(w)
                 if b is not None:
