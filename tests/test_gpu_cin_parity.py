@@ -75,11 +75,15 @@ def _device_f64(x0, xk, W, bias, gy, same, chunk=128):
     return torch.cat(ys), torch.cat(g0), torch.cat(gk), Wd.grad, bd.grad
 
 
-@pytest.mark.parametrize("H", [39, 128])
-def test_cin_contraction_kernels_alone(dev, H):
+@pytest.mark.parametrize("B,N,H,C,E", [(4096, 39, 39, 256, 64), (4096, 39, 128, 256, 64), (1001, 10, 10, 64, 32),
+                                       (1001, 10, 32, 128, 32), (515, 6, 6, 64, 16), (515, 6, 64, 32, 16),
+                                       (130, 40, 64, 32, 128), (262, 26, 256, 64, 32)],
+                         ids=lambda v: str(v))
+def test_cin_contraction_kernels_alone(dev, B, N, H, C, E):
+    """BASELINE shapes plus the narrow ones (one or two 16-pixel tiles per wave, partial last step, short samples)."""
     from torecsys_amd import functional as F_
-    B, N, C, E, S = 4096, 39, 256, 64, 32
-    x0, xk, W, bias, gy = _operands(B, N, H, C, E, seed=100 + H)
+    S = 32
+    x0, xk, W, bias, gy = _operands(B, N, H, C, E, seed=100 + H + E)
     same = H == N
     x0T = _channels_last(x0, _pad32(N)).to(dev).requires_grad_()
     xkT = x0T if same else _channels_last(xk, _pad32(H)).to(dev).requires_grad_()

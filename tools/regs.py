@@ -10,7 +10,10 @@ import os
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.abspath(sys.argv[1])
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
-cmd = ["hipcc", "-O3", "-std=c++20", "--offload-arch=gfx950", "-ffp-contract=off", f"-I{root}/include",
+sys.path.insert(0, root)
+from torecsys_amd.build import FILE_FLAGS  # noqa: E402
+cmd = ["hipcc", "-O3", "-std=c++20", "--offload-arch=gfx950", "-ffp-contract=off", *FILE_FLAGS.get(os.path.basename(src), []),
+       f"-I{root}/include",
        f"-I{root}/torecsys_amd/csrc", "-c", src, "-o", "/tmp/_regs.o", "-Rpass-analysis=kernel-resource-usage"]
 out = subprocess.run(cmd, capture_output=True, text=True, cwd="/tmp").stderr
 cur = None

@@ -19,6 +19,9 @@ ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++20", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-result"]
+# per-file additions.  cin_mfma: the SLP vectoriser turns the fp32 FMAs that sit between MFMAs into v_pk_fma_f32, which
+# costs more issue time beside the matrix pipe than the two single FMAs it replaces
+FILE_FLAGS = {"cin_mfma.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():
@@ -37,7 +40,7 @@ def _compile(src, force):
     if (not force and os.path.exists(obj)
             and os.path.getmtime(obj) >= max(os.path.getmtime(path), _deps_mtime())):
         return obj, ""
-    cmd = [HIPCC, *FLAGS, "-c", path, "-o", obj]
+    cmd = [HIPCC, *FLAGS, *FILE_FLAGS.get(src, []), "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

@@ -21,61 +21,87 @@ namespace trs {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 __host__ __device__ __forceinline__ int cin_chan_of_slot(int j, int ct2, int m) {
   return 32 * j + 8 * (m >> 2) + 4 * ct2 + (m & 3);
 }
 
-// Wp[((j*N + n)*2 + ct2)*KS + ks][lane][8] = Wc[chan(j,ct2,lane&15)][n*H + 32*ks + 8*(lane>>4) + 0..7] (0 past H)
+// Wp[((j*NP + n)*2 + ct2)*KS + ks][lane][8] = Wc[chan(j,ct2,lane&15)][n*H + 32*ks + 8*(lane>>4) + 0..7]
+// (0 past H and for the field slots N <= n < NP that pad the last pipeline step)
 __global__ __launch_bounds__(256) void cin_prepack_fwd_kernel(const bf16_t* __restrict__ Wc, bf16_t* __restrict__ Wp,
-                                                              int C, int N, int H, int KS) {
-  const int64_t total = (int64_t)(C / 32) * N * 2 * KS * 64;
+                                                              int C, int N, int NP, int H, int KS) {
+  const int64_t total = (int64_t)(C / 32) * NP * 2 * KS * 64;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int lane = (int)(t & 63);
     int64_t f = t >> 6;
     const int ks = (int)(f % KS); f /= KS;
     const int ct2 = (int)(f & 1); f >>= 1;
-    const int n = (int)(f % N);
-    const int j = (int)(f / N);
+    const int n = (int)(f % NP);
+    const int j = (int)(f / NP);
     const int c = cin_chan_of_slot(j, ct2, lane & 15);
     const int h0 = 32 * ks + 8 * (lane >> 4);
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj) {
       const int h = h0 + jj;
-      Wp[t * 8 + jj] = h < H ? Wc[(size_t)c * N * H + (size_t)n * H + h] : bf16_t{0};
+      Wp[t * 8 + jj] = (h < H && n < N) ? Wc[(size_t)c * N * H + (size_t)n * H + h] : bf16_t{0};
     }
   }
 }
 
-constexpr int CIN_NS = 2;   // fields per pipeline step (one barrier per 2*KS*CIN_NS*P MFMAs per wave)
-
-template <int KS, int P>
-__global__ __launch_bounds__(256) void cin_cl_fwd_kernel(const bf16_t* __restrict__ x0T, int ld0,
-                                                         const bf16_t* __restrict__ xkT, int ldk,
-                                                         const uint4* __restrict__ Wp, const float* __restrict__ bias,
-                                                         bf16_t* __restrict__ yT, int64_t B, int N, int C, int E) {
+// Pipeline step = NS fields of one channel-pair tile j = G = 2*NS groups (field, 16-channel tile) of KS*P MFMAs each.
+// Inside a step everything is software-pipelined at group granularity: the KS fragments of group g+1 are read from LDS
+// before the MFMAs of group g are issued (two register sets), and the x0 scaling of group g-1's result (4 FMAs per
+// pixel tile) is placed between the MFMAs of group g (two result sets), so a wave keeps the matrix pipe fed without
+// leaning on the other wave of its SIMD.  The fragment stream is continuous over the items a workgroup walks (the
+// step after an item's last is the next item's first), fetched one step ahead with unconditional, clamped loads.
+// Fields past N in the last step have zero fragments and zero x0 rows.
+template <int KS, int P, int NS>
+__global__ __launch_bounds__(256, 2) void cin_cl_fwd_kernel(const bf16_t* __restrict__ x0T, int ld0,
+                                                            const bf16_t* __restrict__ xkT, int ldk,
+                                                            const uint4* __restrict__ Wp, const float* __restrict__ bias,
+                                                            bf16_t* __restrict__ yT, int64_t B, int N, int C, int E) {
   constexpr int PIX = 16 * P;
+  constexpr int G = 2 * NS;
   constexpr int FR1 = 2 * KS * 64;                     // uint4 per (j,n)
-  constexpr int FR = CIN_NS * FR1;                     // uint4 per step
+  constexpr int FR = NS * FR1;                         // uint4 per step
   constexpr int NPF = (FR + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* Abuf = reinterpret_cast<uint4*>(smem);                          // [2][FR]
-  unsigned short* x0s = reinterpret_cast<unsigned short*>(smem + 2 * FR * 16);  // [4 waves][N][PIX]
+  float* bs = reinterpret_cast<float*>(smem + 2 * FR * 16);              // [C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, r = lane & 15;
-  unsigned short* x0w = x0s + (size_t)wave * N * PIX;
   const int items_per_b = E / PIX;
   const int64_t nitems = B * items_per_b;
   const int nj = C / 32;
-  const int npairs = (N + CIN_NS - 1) / CIN_NS;
+  const int npairs = (N + NS - 1) / NS;
   const int nsteps = nj * npairs;
-  // fragment index of (j, n) in Wp is (j*N + n); a step covers n0 .. n0+CIN_NS-1 of one j
-  auto step_src = [&](int step, int i) -> const uint4* {
-    const int j = step / npairs, n0 = (step - j * npairs) * CIN_NS;
-    const int sub = i / FR1;
-    const int n = n0 + sub;
-    if (n >= N) return nullptr;
-    return Wp + ((size_t)(j * N + n)) * FR1 + (i - sub * FR1);
-  };
+  const int NP = npairs * NS;                                            // field slots incl. the zero ones
+  unsigned short* x0w = reinterpret_cast<unsigned short*>(bs + C) + (size_t)wave * NP * PIX;   // [NP][16][P]
+  for (int i = threadIdx.x; i < C; i += 256) bs[i] = bias ? bias[i] : 0.f;
+  for (int v = lane; v < (NP - N) * PIX; v += 64) x0w[N * PIX + v] = 0;
+  // A step's fragments are FR consecutive vectors of Wp.  The loads are issued by hand: the optimiser moves ordinary
+  // loads of read-only memory next to their use (the LDS store at the end of the step), which would expose the whole
+  // L2 round trip every step; an asm load stays where it is written and is waited for by the s_waitcnt of the commit.
+#define TRS_CIN_FETCH(dst, step)                                                              \
+  _Pragma("unroll") for (int k = 0; k < NPF; ++k) {                                           \
+    const int i_ = threadIdx.x + 256 * k;                                                     \
+    const uint4* p_ = Wp + (size_t)(step) * FR + (FR % 256 == 0 || i_ < FR ? i_ : FR - 1);    \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[k]) : "v"(p_));                 \
+  }
+#define TRS_CIN_COMMIT(par_, src)                                                             \
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
+  _Pragma("unroll") for (int k = 0; k < NPF; ++k) {                                           \
+    asm volatile("" : "+v"(src[k]));                                                          \
+    const int i_ = threadIdx.x + 256 * k;                                                     \
+    if (FR % 256 == 0 || i_ < FR) Abuf[(par_) * FR + i_] = __builtin_bit_cast(uint4, src[k]); \
+  }
+  {
+    u32x4 first[NPF];
+    TRS_CIN_FETCH(first, 0)
+    TRS_CIN_COMMIT(0, first)
+  }
+  int par = 0;
+  __syncthreads();
   for (int64_t it0 = (int64_t)blockIdx.x * 4; it0 < nitems; it0 += (int64_t)gridDim.x * 4) {
     const int64_t it = it0 + wave;
     const bool live = it < nitems;
@@ -87,80 +113,94 @@ __global__ __launch_bounds__(256) void cin_cl_fwd_kernel(const bf16_t* __restric
     for (int t = 0; t < P; ++t)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        Bf[t][ks] = make_uint4(0, 0, 0, 0);
-        if (live) Bf[t][ks] = *reinterpret_cast<const uint4*>(xkT + (pix0 + 16 * t + r) * ldk + 32 * ks + 8 * q);
+        const uint4 v = *reinterpret_cast<const uint4*>(xkT + (pix0 + 16 * t + r) * ldk + 32 * ks + 8 * q);
+        Bf[t][ks] = live ? v : make_uint4(0, 0, 0, 0);
       }
-    __syncthreads();   // previous item's readers of x0s / Abuf are done
-    if (live) {
-      for (int v = lane; v < PIX * ((N + 7) / 8); v += 64) {
-        const int p = v % PIX, ch = v / PIX;
-        const uint4 u = *reinterpret_cast<const uint4*>(x0T + (pix0 + p) * ld0 + 8 * ch);
-        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+    // x0 of this wave's pixels, [field][r][t]: the scale factors of a lane's P pixel tiles are one LDS read.  The
+    // array is the wave's own (LDS operations of one wave complete in order: no barrier)
+    for (int v = lane; v < PIX * ((N + 7) / 8); v += 64) {
+      const int p = v % PIX, ch = v / PIX;
+      const uint4 u = *reinterpret_cast<const uint4*>(x0T + (pix0 + p) * ld0 + 8 * ch);
+      const unsigned w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-          const int n = 8 * ch + jj;
-          if (n < N) x0w[n * PIX + p] = (unsigned short)(jj & 1 ? w[jj >> 1] >> 16 : w[jj >> 1] & 0xffffu);
-        }
+      for (int jj = 0; jj < 8; ++jj) {
+        const int n = 8 * ch + jj;
+        if (n < N) x0w[(n * 16 + (p & 15)) * P + (p >> 4)] = (unsigned short)(jj & 1 ? w[jj >> 1] >> 16 : w[jj >> 1] & 0xffffu);
       }
     }
-    for (int i = threadIdx.x; i < FR; i += 256) {
-      const uint4* src = step_src(0, i);
-      Abuf[i] = src ? *src : make_uint4(0, 0, 0, 0);
-    }
-    __syncthreads();
+    // the xk fragments are waited for here, once: inside the loop the only loads in flight are the next step's
+#pragma unroll
+    for (int t = 0; t < P; ++t)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(Bf[t][ks].x), "v"(Bf[t][ks].y), "v"(Bf[t][ks].z), "v"(Bf[t][ks].w));
     f32x4 acc[P][2];
-    for (int step = 0; step < nsteps; ++step) {
-      const int j = step / npairs, n0 = (step - j * npairs) * CIN_NS;
-      const uint4* A = Abuf + (step & 1) * FR;
-      uint4 nxt[NPF];
-      if (step + 1 < nsteps) {
+    int step = 0;
+    for (int j = 0; j < nj; ++j) {
 #pragma unroll
-        for (int k = 0; k < NPF; ++k) {
-          const int i = threadIdx.x + 256 * k;
-          nxt[k] = make_uint4(0, 0, 0, 0);
-          if (i < FR) {
-            const uint4* src = step_src(step + 1, i);
-            if (src) nxt[k] = *src;
+      for (int ct2 = 0; ct2 < 2; ++ct2) {
+        const float4 bv = *reinterpret_cast<const float4*>(bs + 32 * j + 8 * q + 4 * ct2);
+#pragma unroll
+        for (int t = 0; t < P; ++t) acc[t][ct2] = f32x4{bv.x, bv.y, bv.z, bv.w};
+      }
+      // one basic block per step: the next step's loads stay at its top (nothing to sink them into)
+      for (int n0 = 0; n0 < NP; n0 += NS) {
+      const uint4* A = Abuf + par * FR;
+      u32x4 nxt[NPF];
+      step = step + 1 < nsteps ? step + 1 : 0;
+      TRS_CIN_FETCH(nxt, step)
+      __builtin_amdgcn_sched_barrier(0);
+      uint4 Af[2][KS];
+      f32x4 T[2][P];
+      unsigned xraw[2][(P + 1) / 2];            // x0 of group g's field at this lane's P pixel tiles, bf16 pairs
+      auto loadA = [&](int g) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) Af[g & 1][ks] = A[(g * KS + ks) * 64 + lane];
+      };
+      auto loadX = [&](int g) {                 // read while group g's MFMAs run, used between those of group g+1
+        const unsigned short* xp = x0w + ((n0 + (g >> 1)) * 16 + r) * P;
+        if constexpr (P == 4) {
+          const uint2 u = *reinterpret_cast<const uint2*>(xp);
+          xraw[g & 1][0] = u.x; xraw[g & 1][1] = u.y;
+        } else if constexpr (P == 2) {
+          xraw[g & 1][0] = *reinterpret_cast<const unsigned*>(xp);
+        } else {
+          xraw[g & 1][0] = *xp;
+        }
+      };
+      auto scale = [&](int g, int t) {         // acc[t][ct2] += x0[n, pixel tile t] * T of group g = (field n0 + g/2, tile g&1)
+        const unsigned w = xraw[g & 1][t >> 1];
+        const float xv = __uint_as_float(t & 1 ? w & 0xffff0000u : w << 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][g & 1][i] = fmaf(xv, T[g & 1][t][i], acc[t][g & 1][i]);
+      };
+      loadA(0);
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        if (g + 1 < G) loadA(g + 1);
+        loadX(g);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+          for (int t = 0; t < P; ++t)
+            T[g & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8, Af[g & 1][ks]), __builtin_bit_cast(bf16x8, Bf[t][ks]),
+                ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : T[g & 1][t], 0, 0, 0);
+          if (g > 0) {
+#pragma unroll
+            for (int t = 0; t < P; ++t)
+              if ((t * KS) / P == ks) scale(g - 1, t);
           }
-        }
-      }
-      if (n0 == 0) {
-#pragma unroll
-        for (int ct2 = 0; ct2 < 2; ++ct2) {
-          const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + 32 * j + 8 * q + 4 * ct2)
-                                 : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-          for (int t = 0; t < P; ++t) acc[t][ct2] = f32x4{bv.x, bv.y, bv.z, bv.w};
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
 #pragma unroll
-      for (int sub = 0; sub < CIN_NS; ++sub) {
-        const int n = n0 + sub;
-        if (n < N) {
-          f32x4 T[P][2];
-#pragma unroll
-          for (int t = 0; t < P; ++t) { T[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; T[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-          for (int ct2 = 0; ct2 < 2; ++ct2)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-              const uint4 a = A[sub * FR1 + (ct2 * KS + ks) * 64 + lane];
-#pragma unroll
-              for (int t = 0; t < P; ++t)
-                T[t][ct2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
-                                                                    __builtin_bit_cast(bf16x8, Bf[t][ks]), T[t][ct2], 0, 0, 0);
-            }
-#pragma unroll
-          for (int t = 0; t < P; ++t) {
-            const float xv = __uint_as_float((unsigned)x0w[n * PIX + 16 * t + r] << 16);
-#pragma unroll
-            for (int ct2 = 0; ct2 < 2; ++ct2)
-#pragma unroll
-              for (int i = 0; i < 4; ++i) acc[t][ct2][i] = fmaf(xv, T[t][ct2][i], acc[t][ct2][i]);
-          }
-        }
+      for (int t = 0; t < P; ++t) scale(G - 1, t);
+      TRS_CIN_COMMIT(par ^ 1, nxt)
+      par ^= 1;
+      __syncthreads();
       }
-      if (n0 + CIN_NS >= N && live) {
+      if (live) {
 #pragma unroll
         for (int t = 0; t < P; ++t) {
           float f[8];
@@ -169,22 +209,18 @@ __global__ __launch_bounds__(256) void cin_cl_fwd_kernel(const bf16_t* __restric
           *reinterpret_cast<uint4*>(yT + (pix0 + 16 * t + r) * (int64_t)C + 32 * j + 8 * q) = Vec16<bf16_t>::pack(f);
         }
       }
-      if (step + 1 < nsteps) {
-        uint4* Anext = Abuf + ((step + 1) & 1) * FR;
-#pragma unroll
-        for (int k = 0; k < NPF; ++k) {
-          const int i = threadIdx.x + 256 * k;
-          if (i < FR) Anext[i] = nxt[k];
-        }
-      }
-      __syncthreads();
     }
   }
 }
 
+#undef TRS_CIN_FETCH
+#undef TRS_CIN_COMMIT
+
+static size_t cin_fwd_frag_bytes(int NP, int KS, int C) { return (size_t)(C / 32) * NP * 2 * KS * 64 * 16; }
+
 size_t cin_mfma_fwd_workspace_bytes(int N, int H, int C) {
   const int KS = (H + 31) / 32;
-  return (size_t)(C / 32) * N * 2 * KS * 64 * 16 + (size_t)C * 4 + 512;
+  return cin_fwd_frag_bytes(N + 2, KS, C) + (size_t)C * 4 + 512;   // up to two padding field slots
 }
 
 __global__ void cin_bias_to_f32_kernel(const bf16_t* __restrict__ b, float* __restrict__ o, int C) {
@@ -206,34 +242,60 @@ int cin_cl_fwd(const void* x0T, int ld0, const void* xkT, int ldk, const void* W
       !aligned16(yT) || workspace == nullptr)
     return 1;
   if (ws_bytes < cin_mfma_fwd_workspace_bytes(N, H, C)) return fail(TRS_EWORKSPACE, "cin_cl_fwd: workspace too small");
+  int P = E % 64 == 0 ? 4 : (E % 32 == 0 ? 2 : 1);
+  if (KS == 8 && P == 4) P = 2;                        // the xk fragments (P*KS*4 registers) must leave room for the rest
+  // fields per pipeline step: the one that pads N least, three when both do (fewer barriers) and the stage fits
+  auto lds_for = [&](int NS_) {
+    const int np = (N + NS_ - 1) / NS_ * NS_;
+    return (size_t)2 * NS_ * 2 * KS * 64 * 16 + (size_t)C * 4 + (size_t)4 * np * 16 * P * 2;
+  };
+  int NS = 2;
+  if (KS <= 4 && (N + 2) / 3 * 3 <= (N + 1) / 2 * 2 && lds_for(3) <= 78 * 1024) NS = 3;
+  const size_t lds = lds_for(NS);
+  if (lds > 78 * 1024) return 1;                       // two workgroups per CU
+  const int NP = (N + NS - 1) / NS * NS;
   bf16_t* Wp = (bf16_t*)workspace;
-  float* bf = (float*)((char*)workspace + (size_t)(C / 32) * N * 2 * KS * 64 * 16);
-  const int64_t total = (int64_t)(C / 32) * N * 2 * KS * 64;
+  float* bf = (float*)((char*)workspace + cin_fwd_frag_bytes(NP, KS, C));
+  const int64_t total = (int64_t)(C / 32) * NP * 2 * KS * 64;
   hipLaunchKernelGGL(cin_prepack_fwd_kernel, dim3((int)std::min<int64_t>((total + 255) / 256, 2048)), dim3(256), 0, s,
-                     (const bf16_t*)Wc, Wp, C, N, H, KS);
+                     (const bf16_t*)Wc, Wp, C, N, NP, H, KS);
   if (bias) hipLaunchKernelGGL(cin_bias_to_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const bf16_t*)bias, bf, C);
-  const int P = E % 64 == 0 ? 4 : (E % 32 == 0 ? 2 : 1);
   const int64_t nitems = B * (E / (16 * P));
   const int grid = (int)std::min<int64_t>((nitems + 3) / 4, 256 * 2);
-  const size_t lds = (size_t)2 * CIN_NS * 2 * KS * 64 * 16 + (size_t)4 * N * 16 * P * 2;
-  if (lds > 64 * 1024) return 1;
-#define TRS_CINF(KS_, P_)                                                                                          \
-  hipLaunchKernelGGL((cin_cl_fwd_kernel<KS_, P_>), dim3(grid), dim3(256), lds, s, (const bf16_t*)x0T, ld0,          \
-                     (const bf16_t*)xkT, ldk, (const uint4*)Wp, bias ? bf : (const float*)nullptr, (bf16_t*)yT, B, N, \
-                     C, E)
+#define TRS_CINF(KS_, P_, NS_)                                                                                      \
+  do {                                                                                                              \
+    auto kern = cin_cl_fwd_kernel<KS_, P_, NS_>;                                                                    \
+    static size_t attr_lds = 0;                                                                                     \
+    if (lds > 64 * 1024 && lds > attr_lds) {                                                                        \
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+        return check_launch("cin_cl_fwd: LDS attribute");                                                           \
+      attr_lds = lds;                                                                                               \
+    }                                                                                                               \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, (const bf16_t*)x0T, ld0, (const bf16_t*)xkT, ldk,       \
+                       (const uint4*)Wp, bias ? bf : (const float*)nullptr, (bf16_t*)yT, B, N, C, E);               \
+  } while (0)
+#define TRS_CINF_NS(KS_, P_)         \
+  do {                               \
+    if (NS == 3) TRS_CINF(KS_, P_, 3); \
+    else TRS_CINF(KS_, P_, 2);       \
+  } while (0)
 #define TRS_CINF_P(KS_)              \
   do {                               \
-    if (P == 4) TRS_CINF(KS_, 4);    \
-    else if (P == 2) TRS_CINF(KS_, 2); \
-    else TRS_CINF(KS_, 1);           \
+    if (P == 4) TRS_CINF_NS(KS_, 4); \
+    else if (P == 2) TRS_CINF_NS(KS_, 2); \
+    else TRS_CINF_NS(KS_, 1);        \
   } while (0)
   switch (KS) {
     case 1: TRS_CINF_P(1); break;
     case 2: TRS_CINF_P(2); break;
     case 4: TRS_CINF_P(4); break;
-    default: TRS_CINF_P(8); break;
+    default:
+      if (P == 2) TRS_CINF(8, 2, 2);
+      else TRS_CINF(8, 1, 2);
+      break;
   }
 #undef TRS_CINF_P
+#undef TRS_CINF_NS
 #undef TRS_CINF
   return check_launch("cin_cl_fwd");
 }

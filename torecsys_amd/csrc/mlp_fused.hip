@@ -123,9 +123,9 @@ __device__ __forceinline__ MlpShare mlp_share(int N, int wave) {
 
 // acc[mi][2*pi + h] (+)= sum_k W-frag(pair pi, half h, ks) x act rows of tile mt0+mi, for MCNT row tiles and NPW column
 // pairs known at compile time (runtime bounds put a scalar branch in front of every MFMA).
-// The weight fragments come from L2 (~0.5 us): the fragments of k-step ks+1 are requested before the MFMAs of k-step ks
-// are issued (register double buffer); PREFETCH_B does the same for the LDS reads of the activations, otherwise they are
-// read per k-step in two halves (16 registers of B operands instead of 64).
+// The weight fragments come from L2: they are requested two k-steps before the MFMAs that consume them (an L2 round
+// trip under load outlasts one k-step of 16-32 MFMAs); PREFETCH_B (not used: registers) prefetches the LDS reads of the
+// activations one k-step ahead, otherwise they are read per k-step in two halves (16 registers of B operands instead of 64).
 template <int MCNT, int NPW, bool PREFETCH_B>
 __device__ __forceinline__ void mlp_gemm_t(const char* act, int act_str, const uint4* __restrict__ wf, int K,
                                            const MlpShare& sh, int lane, mf_f32x4 (&acc)[MF_MT][2 * MF_MAXP]) {
@@ -167,8 +167,10 @@ __device__ __forceinline__ void mlp_gemm_t(const char* act, int act_str, const u
     }
   } else {
     constexpr int HALF = MCNT >= 2 ? MCNT / 2 : 1;
+    uint4 Ann[2 * NPW];                          // fragments two k-steps ahead: an L2 round trip outlasts one k-step
+    if (1 < KS) loadA(1, An);
     for (int ks = 0; ks < KS; ++ks) {
-      if (ks + 1 < KS) loadA(ks + 1, An);
+      if (ks + 2 < KS) loadA(ks + 2, Ann);
 #pragma unroll
       for (int m0 = 0; m0 < MCNT; m0 += HALF) {
         uint4 Bh[HALF];
@@ -182,7 +184,10 @@ __device__ __forceinline__ void mlp_gemm_t(const char* act, int act_str, const u
                 __builtin_bit_cast(mf_bf16x8, A[t]), __builtin_bit_cast(mf_bf16x8, Bh[mi]), acc[m0 + mi][t], 0, 0, 0);
       }
 #pragma unroll
-      for (int t = 0; t < 2 * NPW; ++t) A[t] = An[t];
+      for (int t = 0; t < 2 * NPW; ++t) {
+        A[t] = An[t];
+        An[t] = Ann[t];
+      }
     }
   }
 }
