@@ -148,7 +148,11 @@ def main():
         run("afm A=64", AttentionalFactorizationMachineLayer(E, N, 64, 0.0), Bp * E + Bp * P, 2.0 * Bp * P * E * 64)
     if want("cin"):
         Bc = a.B // 8 if a.B >= 8192 else a.B
+        import os as _os
+        only = _os.environ.get("TRS_KB_CIN_H")
         for (H, C) in ((39, 256), (128, 256)):
+            if only and int(only) != H:
+                continue
             ld0 = ((N + 31) // 32) * 32
             x0T = torch.zeros(Bc, E, ld0, dtype=dt, device=dev)
             x0T[:, :, :N] = (0.5 * torch.randn(Bc, E, N, generator=g)).to(dt).to(dev)
@@ -165,6 +169,10 @@ def main():
             ins = (x0r, Wr) if H == N else (x0r, xkr, Wr)
             t = timeit(lambda: torch.autograd.grad(yT, ins, gy, retain_graph=True), iters=3, warm=1)
             print(f"cin_cl_bwd (data+dW+transposes): med {t[0]*1e3:.3f} ms  {2*fl/t[0]/1e12:.1f} TFLOP/s", flush=True)
+            t = timeit(lambda: torch.autograd.grad(yT, ins[:-1], gy, retain_graph=True), iters=5, warm=1)
+            print(f"cin_cl_bwd data only H={H}: med {t[0]*1e3:.3f} ms  {fl/t[0]/1e12:.1f} TFLOP/s", flush=True)
+            t = timeit(lambda: torch.autograd.grad(yT, ins[-1:], gy, retain_graph=True), iters=5, warm=1)
+            print(f"cin_cl_bwd dW only (+transposes) H={H}: med {t[0]*1e3:.3f} ms  {fl/t[0]/1e12:.1f} TFLOP/s", flush=True)
     if want("mlp"):
         C = 400
         gy = torch.randn(B, C, generator=g).to(dt).to(dev)

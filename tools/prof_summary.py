@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--title", default="rocprofv3 --kernel-trace --stats summary")
     ap.add_argument("--cmd", default="")
+    ap.add_argument("--calls", default=None, help="regex: also list the last --ncalls launches of matching kernels in launch order")
+    ap.add_argument("--ncalls", type=int, default=40)
     a = ap.parse_args()
     c = sqlite3.connect(a.db)
     rows = c.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
@@ -32,6 +34,11 @@ def main():
     for name, calls, total, avg, pct in rows:
         lines.append(f"| `{short(name)}` | {calls} | {total:.1f} | {avg:.2f} | {pct:.2f} |")
     lines.append(f"| **all kernels** | {sum(r[1] for r in rows)} | {tot:.1f} | | 100 |")
+    if a.calls:
+        seq = c.execute("select name, start, end from kernels order by start").fetchall()
+        seq = [(short(n), (e - st) / 1e3) for n, st, e in seq if re.search(a.calls, n)][-a.ncalls:]
+        lines += ["", f"last {len(seq)} launches matching `{a.calls}`, in launch order (us)", "", "| kernel | us |", "|---|---:|"]
+        lines += [f"| `{n}` | {d:.1f} |" for n, d in seq]
     txt = "\n".join(lines) + "\n"
     if a.out:
         open(a.out, "w").write(txt)

@@ -7,4 +7,4 @@ mkdir -p "$(dirname "$out")"
 cd /tmp && rm -rf /tmp/trc && rocprofv3 --kernel-trace --stats -d /tmp/trc -o t -- "$@" > /tmp/trc.log 2>&1
 cd "$R"
 db=$(find /tmp/trc -name "*.db" | head -1)
-python tools/prof_summary.py "$db" --out "$out" --title "$title" --cmd "rocprofv3 --kernel-trace --stats -- $*"
+python tools/prof_summary.py "$db" --out "$out" --title "$title" --cmd "rocprofv3 --kernel-trace --stats -- $*" ${TRS_TRACE_CALLS:+--calls "$TRS_TRACE_CALLS"}

@@ -303,157 +303,233 @@ int cin_cl_fwd(const void* x0T, int ld0, const void* xkT, int ldk, const void* W
 // =============================================================================================
 // backward, data gradients (channels-last):  S_n[h,pix] = sum_c Wc[c,(n,h)] * gy[c,pix]   (MFMA, K = c)
 //     dxk[h,pix] = sum_n x0[n,pix] * S_n[h,pix]          dx0[n,pix] = sum_h xk[h,pix] * S_n[h,pix]
-// Same skeleton as the forward: wave = P pixel tiles, the W^T fragments of one (h-pair tile jh, field n) step
-// are staged in LDS and shared by the 4 waves.  dxk accumulates in registers (h on the D rows, permuted so a
-// lane owns 8 consecutive h -> 16-byte stores); dx0[n] is a reduction over h = over the D rows: 8 FMAs per
-// lane, two cross-lane adds (q groups), then one lane per pixel adds into a per-wave fp32 LDS array [n][pixel].
-// WpT[((jh*N + n)*2 + ct2)*KC + kc][lane][8] = Wc[32*kc + 8*(lane>>4) + 0..7][n*H + hslot(jh,ct2,lane&15)]
+// Same pipeline as the forward (wave = P pixel tiles of one sample, the W^T fragments of NS fields of one 32-h tile
+// staged per step, groups of KC*P MFMAs software-pipelined against the VALU work of the previous group).  Both
+// results are linear in S, so the contraction over c may be cut into passes of 32*KC channels whose partial S go
+// through the same epilogue: with C = 256 the gy fragments of a pass are 64 registers instead of 128, which is what
+// lets a wave keep four pixel tiles (an LDS fragment then feeds four MFMAs) at two waves per SIMD.
+// dxk accumulates in registers (h on the D rows, permuted so a lane owns 8 consecutive h -> 16-byte stores).
+// dx0[n] is a reduction over h = over the D rows: 8 FMAs per lane and tile, then the four tiles' partials are summed
+// over the four 16-lane rows with three v_permlane swaps (every row ends up with one tile's total) and all 64 lanes
+// add into the wave's fp32 LDS array [n][pixel] with one ds_add_f32.
+// WpT[((((jh*npass + pass)*NP + n)*2 + ct2)*KC + kc][lane][8]
+//     = Wc[32*(pass*KC + kc) + 8*(lane>>4) + 0..7][n*H + hslot(jh,ct2,lane&15)]      (0 for n >= N, h >= H)
 __global__ __launch_bounds__(256) void cin_prepack_bwd_kernel(const bf16_t* __restrict__ Wc, bf16_t* __restrict__ WpT,
-                                                              int C, int N, int H, int KSH, int KC) {
-  const int64_t total = (int64_t)KSH * N * 2 * KC * 64;
+                                                              int C, int N, int NP, int H, int KSH, int KC, int npass) {
+  const int64_t total = (int64_t)KSH * npass * NP * 2 * KC * 64;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int lane = (int)(t & 63);
     int64_t f = t >> 6;
     const int kc = (int)(f % KC); f /= KC;
     const int ct2 = (int)(f & 1); f >>= 1;
-    const int n = (int)(f % N);
-    const int jh = (int)(f / N);
+    const int n = (int)(f % NP); f /= NP;
+    const int pass = (int)(f % npass);
+    const int jh = (int)(f / npass);
     const int h = cin_chan_of_slot(jh, ct2, lane & 15);
-    const int c0 = 32 * kc + 8 * (lane >> 4);
+    const int c0 = 32 * (pass * KC + kc) + 8 * (lane >> 4);
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj)
-      WpT[t * 8 + jj] = h < H ? Wc[(size_t)(c0 + jj) * N * H + (size_t)n * H + h] : bf16_t{0};
+      WpT[t * 8 + jj] = (h < H && n < N) ? Wc[(size_t)(c0 + jj) * N * H + (size_t)n * H + h] : bf16_t{0};
   }
 }
 
-template <int KC, int P, int NS>
-__global__ __launch_bounds__(256) void cin_cl_bwd_data_kernel(const bf16_t* __restrict__ x0T, int ld0,
-                                                              const bf16_t* __restrict__ xkT, int ldk,
-                                                              const bf16_t* __restrict__ gyT,
-                                                              const uint4* __restrict__ WpT, bf16_t* __restrict__ dx0T,
-                                                              bf16_t* __restrict__ dxkT, int ldo, int64_t B, int N,
-                                                              int H, int C, int E) {
+// sum the P per-lane partials over the four 16-lane rows; returns the total of tile cin_red_tile(q) in every lane of row q
+template <int P>
+__device__ __forceinline__ float cin_row_reduce(const float (&part)[P]) {
+  if constexpr (P == 4) {
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(part[0]), __float_as_uint(part[1]), false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(part[2]), __float_as_uint(part[3]), false, false);
+    const float x = __uint_as_float(a[0]) + __uint_as_float(a[1]);     // rows 0,1: tile 0 (two partials); rows 2,3: tile 1
+    const float y = __uint_as_float(b[0]) + __uint_as_float(b[1]);     // the same for tiles 2, 3
+    const auto c = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(c[0]) + __uint_as_float(c[1]);              // rows: tile 0, 2, 1, 3
+  } else if constexpr (P == 2) {
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(part[0]), __float_as_uint(part[1]), false, false);
+    const float x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto c = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(c[0]) + __uint_as_float(c[1]);              // rows 0,1: tile 0; rows 2,3: tile 1
+  } else {
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(part[0]), __float_as_uint(part[0]), false, false);
+    const float x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto c = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(c[0]) + __uint_as_float(c[1]);              // every row: tile 0
+  }
+}
+template <int P>
+__device__ __forceinline__ int cin_red_tile(int q) { return P == 4 ? ((q & 1) * 2 + (q >> 1)) : (P == 2 ? (q >> 1) : 0); }
+template <int P>
+__device__ __forceinline__ bool cin_red_owner(int q) { return P == 4 ? true : (P == 2 ? (q & 1) == 0 : q == 0); }
+
+template <int KC, int P, int NS, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 1) void cin_cl_bwd_data_kernel(
+    const bf16_t* __restrict__ x0T, int ld0, const bf16_t* __restrict__ xkT, int ldk, const bf16_t* __restrict__ gyT,
+    const uint4* __restrict__ WpT, bf16_t* __restrict__ dx0T, bf16_t* __restrict__ dxkT, int ldo, int64_t B, int N, int H,
+    int C, int E, int npass) {
+  constexpr int NT = 64 * WAVES;
   constexpr int PIX = 16 * P;
-  constexpr int FR1 = 2 * KC * 64;   // uint4 per (jh,n)
-  constexpr int FR = NS * FR1;   // uint4 per step
-  constexpr int NPF = (FR + 255) / 256;
+  constexpr int G = 2 * NS;
+  constexpr int FR1 = 2 * KC * 64;   // uint4 per (jh,pass,n)
+  constexpr int FR = NS * FR1;       // uint4 per step
+  constexpr int NPF = (FR + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* Abuf = reinterpret_cast<uint4*>(smem);                                   // [2][FR]
-  float* dx0s_all = reinterpret_cast<float*>(smem + 2 * FR * 16);                 // [4][N][PIX] fp32
-  unsigned short* x0s_all = reinterpret_cast<unsigned short*>(dx0s_all + (size_t)4 * N * PIX);  // [4][N][PIX]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, r = lane & 15;
-  float* dx0s = dx0s_all + (size_t)wave * N * PIX;
-  unsigned short* x0w = x0s_all + (size_t)wave * N * PIX;
   const int items_per_b = E / PIX;
   const int64_t nitems = B * items_per_b;
   const int KSH = (H + 31) / 32;
   const int npairs = (N + NS - 1) / NS;
-  const int nsteps = KSH * npairs;
-  auto step_src = [&](int step, int i) -> const uint4* {
-    const int jh = step / npairs, n0 = (step - jh * npairs) * NS;
-    const int sub = i / FR1;
-    const int n = n0 + sub;
-    if (n >= N) return nullptr;
-    return WpT + ((size_t)(jh * N + n)) * FR1 + (i - sub * FR1);
-  };
-  for (int64_t it0 = (int64_t)blockIdx.x * 4; it0 < nitems; it0 += (int64_t)gridDim.x * 4) {
+  const int NP = npairs * NS;
+  const int nsteps = KSH * npass * npairs;
+  float* dx0s = reinterpret_cast<float*>(smem + 2 * FR * 16) + (size_t)wave * NP * PIX;                // [NP][PIX] fp32
+  unsigned short* x0w = reinterpret_cast<unsigned short*>(smem + 2 * FR * 16 + (size_t)WAVES * NP * PIX * 4) +
+                        (size_t)wave * NP * PIX;                                                       // [NP][16][P]
+  for (int v = lane; v < (NP - N) * PIX; v += 64) x0w[N * PIX + v] = 0;
+#define TRS_CIN_FETCH(dst, step)                                                              \
+  _Pragma("unroll") for (int k = 0; k < NPF; ++k) {                                           \
+    const int i_ = threadIdx.x + NT * k;                                                      \
+    const uint4* p_ = WpT + (size_t)(step) * FR + (FR % NT == 0 || i_ < FR ? i_ : FR - 1);    \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[k]) : "v"(p_));                 \
+  }
+#define TRS_CIN_COMMIT(par_, src)                                                             \
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                            \
+  _Pragma("unroll") for (int k = 0; k < NPF; ++k) {                                           \
+    asm volatile("" : "+v"(src[k]));                                                          \
+    const int i_ = threadIdx.x + NT * k;                                                      \
+    if (FR % NT == 0 || i_ < FR) Abuf[(par_) * FR + i_] = __builtin_bit_cast(uint4, src[k]);  \
+  }
+  {
+    u32x4 first[NPF];
+    TRS_CIN_FETCH(first, 0)
+    TRS_CIN_COMMIT(0, first)
+  }
+  int par = 0;
+  __syncthreads();
+  for (int64_t it0 = (int64_t)blockIdx.x * WAVES; it0 < nitems; it0 += (int64_t)gridDim.x * WAVES) {
     const int64_t it = it0 + wave;
     const bool live = it < nitems;
     const int64_t b = live ? it / items_per_b : 0;
     const int e0 = live ? (int)(it - b * items_per_b) * PIX : 0;
     const int64_t pix0 = b * E + e0;
-    uint4 Bg[P][KC];
-#pragma unroll
-    for (int t = 0; t < P; ++t)
-#pragma unroll
-      for (int kc = 0; kc < KC; ++kc) {
-        Bg[t][kc] = make_uint4(0, 0, 0, 0);
-        if (live) Bg[t][kc] = *reinterpret_cast<const uint4*>(gyT + (pix0 + 16 * t + r) * (int64_t)C + 32 * kc + 8 * q);
-      }
-    __syncthreads();
     for (int v = lane; v < N * PIX; v += 64) dx0s[v] = 0.f;
-    if (live) {
-      for (int v = lane; v < PIX * ((N + 7) / 8); v += 64) {
-        const int p = v % PIX, ch = v / PIX;
-        const uint4 u = *reinterpret_cast<const uint4*>(x0T + (pix0 + p) * ld0 + 8 * ch);
-        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+    for (int v = lane; v < PIX * ((N + 7) / 8); v += 64) {
+      const int p = v % PIX, ch = v / PIX;
+      const uint4 u = *reinterpret_cast<const uint4*>(x0T + (pix0 + p) * ld0 + 8 * ch);
+      const unsigned w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-          const int n = 8 * ch + jj;
-          if (n < N) x0w[n * PIX + p] = (unsigned short)(jj & 1 ? w[jj >> 1] >> 16 : w[jj >> 1] & 0xffffu);
-        }
+      for (int jj = 0; jj < 8; ++jj) {
+        const int n = 8 * ch + jj;
+        if (n < N) x0w[(n * 16 + (p & 15)) * P + (p >> 4)] = (unsigned short)(jj & 1 ? w[jj >> 1] >> 16 : w[jj >> 1] & 0xffffu);
       }
     }
-    for (int i = threadIdx.x; i < FR; i += 256) {
-      const uint4* src = step_src(0, i);
-      Abuf[i] = src ? *src : make_uint4(0, 0, 0, 0);
-    }
-    __syncthreads();
-    f32x4 acc[P][2];
-    float xkd[P][2][4];
-    for (int step = 0; step < nsteps; ++step) {
-      const int jh = step / npairs, n0 = (step - jh * npairs) * NS;
-      const uint4* A = Abuf + (step & 1) * FR;
-      uint4 nxt[NPF];
-      if (step + 1 < nsteps) {
+    uint4 Bg[P][KC];
+    int step = 0;
+    for (int jh = 0; jh < KSH; ++jh) {
+      f32x4 acc[P][2];
+      float xkd[P][2][4];
 #pragma unroll
-        for (int k = 0; k < NPF; ++k) {
-          const int i = threadIdx.x + 256 * k;
-          nxt[k] = make_uint4(0, 0, 0, 0);
-          if (i < FR) {
-            const uint4* src = step_src(step + 1, i);
-            if (src) nxt[k] = *src;
-          }
-        }
+      for (int t = 0; t < P; ++t) {
+        acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const uint4 u = *reinterpret_cast<const uint4*>(xkT + (pix0 + 16 * t + r) * ldk + 32 * jh + 8 * q);
+        float f[8];
+        Vec16<bf16_t>::unpack(u, f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { xkd[t][0][i] = live ? f[i] : 0.f; xkd[t][1][i] = live ? f[4 + i] : 0.f; }
       }
-      if (n0 == 0) {
+      for (int pass = 0; pass < npass; ++pass) {
+        if (npass > 1 || jh == 0) {
 #pragma unroll
-        for (int t = 0; t < P; ++t) {
-          acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-          acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-          uint4 u = make_uint4(0, 0, 0, 0);
-          if (live) u = *reinterpret_cast<const uint4*>(xkT + (pix0 + 16 * t + r) * ldk + 32 * jh + 8 * q);
-          float f[8];
-          Vec16<bf16_t>::unpack(u, f);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { xkd[t][0][i] = f[i]; xkd[t][1][i] = f[4 + i]; }
-        }
-      }
-#pragma unroll
-      for (int sub = 0; sub < NS; ++sub) {
-        const int n = n0 + sub;
-        if (n < N) {
-          f32x4 S[P][2];
-#pragma unroll
-          for (int t = 0; t < P; ++t) { S[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; S[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-          for (int ct2 = 0; ct2 < 2; ++ct2)
+          for (int t = 0; t < P; ++t)
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc) {
-              const uint4 a = A[sub * FR1 + (ct2 * KC + kc) * 64 + lane];
+              const uint4 v = *reinterpret_cast<const uint4*>(gyT + (pix0 + 16 * t + r) * (int64_t)C + 32 * (pass * KC + kc) + 8 * q);
+              Bg[t][kc] = live ? v : make_uint4(0, 0, 0, 0);
+            }
+        }
+        // everything loaded so far is waited for here: inside the step loop only the next step's fragments are in flight
+#pragma unroll
+        for (int t = 0; t < P; ++t) {
+#pragma unroll
+          for (int kc = 0; kc < KC; ++kc) asm volatile("" ::"v"(Bg[t][kc].x), "v"(Bg[t][kc].y), "v"(Bg[t][kc].z), "v"(Bg[t][kc].w));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(xkd[t][0][i]), "v"(xkd[t][1][i]));
+        }
+        for (int n0 = 0; n0 < NP; n0 += NS) {      // one basic block per step
+          const uint4* A = Abuf + par * FR;
+          u32x4 nxt[NPF];
+          step = step + 1 < nsteps ? step + 1 : 0;
+          TRS_CIN_FETCH(nxt, step)
+          __builtin_amdgcn_sched_barrier(0);
+          uint4 Af[2][KC];
+          f32x4 T[2][P];
+          unsigned xraw[2][(P + 1) / 2];
+          float part[P];
+          auto loadA = [&](int g) {
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) Af[g & 1][kc] = A[(g * KC + kc) * 64 + lane];
+          };
+          auto loadX = [&](int g) {
+            const unsigned short* xp = x0w + ((n0 + (g >> 1)) * 16 + r) * P;
+            if constexpr (P == 4) {
+              const uint2 u = *reinterpret_cast<const uint2*>(xp);
+              xraw[g & 1][0] = u.x; xraw[g & 1][1] = u.y;
+            } else if constexpr (P == 2) {
+              xraw[g & 1][0] = *reinterpret_cast<const unsigned*>(xp);
+            } else {
+              xraw[g & 1][0] = *xp;
+            }
+          };
+          auto scale = [&](int g, int t) {       // group g = (field n0 + g/2, h half-tile g&1)
+            const unsigned w = xraw[g & 1][t >> 1];
+            const float xv = __uint_as_float(t & 1 ? w & 0xffff0000u : w << 16);
+            float pt = (g & 1) ? part[t] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              acc[t][g & 1][i] = fmaf(xv, T[g & 1][t][i], acc[t][g & 1][i]);
+              pt = fmaf(xkd[t][g & 1][i], T[g & 1][t][i], pt);
+            }
+            part[t] = pt;
+          };
+          // dx0s[field][pixel] += total: a plain read-modify-write (the array is this wave's; an LDS float atomic costs
+          // ~150 LDS cycles per wave instruction).  The old value is read one group ahead of the add.
+          float dold = 0.f;
+          auto dx0_slot = [&](int g) { return dx0s + (n0 + (g >> 1)) * PIX + 16 * cin_red_tile<P>(q) + r; };
+          auto reduce = [&](int g) {             // after both half-tiles of field n0 + g/2 went through scale()
+            const float z = cin_row_reduce<P>(part);
+            if (cin_red_owner<P>(q)) *dx0_slot(g) = dold + z;
+          };
+          loadA(0);
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            if (g + 1 < G) loadA(g + 1);
+            loadX(g);
+            if (g & 1) dold = *dx0_slot(g);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
 #pragma unroll
               for (int t = 0; t < P; ++t)
-                S[t][ct2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
-                                                                    __builtin_bit_cast(bf16x8, Bg[t][kc]), S[t][ct2], 0, 0, 0);
-            }
+                T[g & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, Af[g & 1][kc]), __builtin_bit_cast(bf16x8, Bg[t][kc]),
+                    kc == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : T[g & 1][t], 0, 0, 0);
+              if (g > 0) {
 #pragma unroll
-          for (int t = 0; t < P; ++t) {
-            const float xv = __uint_as_float((unsigned)x0w[n * PIX + 16 * t + r] << 16);
-            float part = 0.f;
-#pragma unroll
-            for (int ct2 = 0; ct2 < 2; ++ct2)
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                acc[t][ct2][i] = fmaf(xv, S[t][ct2][i], acc[t][ct2][i]);
-                part = fmaf(xkd[t][ct2][i], S[t][ct2][i], part);
+                for (int t = 0; t < P; ++t)
+                  if ((t * KC) / P == kc) scale(g - 1, t);
+                if (kc == KC - 1 && ((g - 1) & 1)) reduce(g - 1);
               }
-            part += __shfl_xor(part, 16, 64);
-            part += __shfl_xor(part, 32, 64);
-            if (q == (n & 3)) dx0s[n * PIX + 16 * t + r] += part;   // one lane per pixel; the wave owns this array
+              __builtin_amdgcn_sched_barrier(0);
+            }
           }
+#pragma unroll
+          for (int t = 0; t < P; ++t) scale(G - 1, t);
+          reduce(G - 1);
+          TRS_CIN_COMMIT(par ^ 1, nxt)
+          par ^= 1;
+          __syncthreads();
         }
       }
-      if (n0 + NS >= N && live) {
+      if (live) {
 #pragma unroll
         for (int t = 0; t < P; ++t) {
           float f[8];
@@ -462,15 +538,6 @@ __global__ __launch_bounds__(256) void cin_cl_bwd_data_kernel(const bf16_t* __re
           *reinterpret_cast<uint4*>(dxkT + (pix0 + 16 * t + r) * (int64_t)ldo + 32 * jh + 8 * q) = Vec16<bf16_t>::pack(f);
         }
       }
-      if (step + 1 < nsteps) {
-        uint4* Anext = Abuf + ((step + 1) & 1) * FR;
-#pragma unroll
-        for (int k = 0; k < NPF; ++k) {
-          const int i = threadIdx.x + 256 * k;
-          if (i < FR) Anext[i] = nxt[k];
-        }
-      }
-      __syncthreads();
     }
     if (live) {
       for (int v = lane; v < PIX * (ld0 / 8); v += 64) {
@@ -486,58 +553,94 @@ __global__ __launch_bounds__(256) void cin_cl_bwd_data_kernel(const bf16_t* __re
     }
   }
 }
+#undef TRS_CIN_FETCH
+#undef TRS_CIN_COMMIT
+
+static size_t cin_bwd_frag_bytes(int KSH, int NP, int KCT) { return (size_t)KSH * NP * 2 * KCT * 64 * 16; }
 
 size_t cin_mfma_bwd_data_workspace_bytes(int N, int H, int C) {
-  const int KSH = (H + 31) / 32, KC = C / 32;
-  return (size_t)KSH * N * 2 * KC * 64 * 16 + 256;
+  const int KSH = (H + 31) / 32, KCT = C / 32;
+  return cin_bwd_frag_bytes(KSH, N + 2, KCT) + 256;
+}
+
+// 0: C = 256 in two passes of 128 channels, eight waves per workgroup; 1: one pass, 512-register waves (TRS_CIN_BWD_ONEPASS=1)
+static int cin_bwd_onepass() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("TRS_CIN_BWD_ONEPASS");
+    v = e && e[0] == '1' ? 1 : 0;
+  }
+  return v;
 }
 
 int cin_cl_bwd_data(const void* x0T, int ld0, const void* xkT, int ldk, const void* gyT, const void* Wc, int64_t B, int N,
                     int H, int C, int E, void* dx0T, void* dxkT, int ldo, void* workspace, size_t ws_bytes,
                     hipStream_t s) {
-  const int KSH = (H + 31) / 32, KC = C / 32;
-  if (C % 32 != 0 || E % 16 != 0 || !(KC == 1 || KC == 2 || KC == 4 || KC == 8) || ld0 % 8 != 0 || ldk % 8 != 0 ||
+  const int KSH = (H + 31) / 32, KCT = C / 32;
+  if (C % 32 != 0 || E % 16 != 0 || !(KCT == 1 || KCT == 2 || KCT == 4 || KCT == 8) || ld0 % 8 != 0 || ldk % 8 != 0 ||
       ldk < 32 * KSH || ldo < 32 * KSH || ldo % 8 != 0 || workspace == nullptr)
     return 1;
   if (ws_bytes < cin_mfma_bwd_data_workspace_bytes(N, H, C)) return fail(TRS_EWORKSPACE, "cin_cl_bwd_data: workspace");
+  const int P = E % 64 == 0 ? 4 : (E % 32 == 0 ? 2 : 1);
+  const bool onepass = KCT == 8 && P == 4 && cin_bwd_onepass();
+  const int KC = KCT == 8 && !onepass ? 4 : KCT;
+  const int npass = KCT / KC;
+  const int WAVES = onepass ? 4 : 8;
+  auto lds_for = [&](int NS_) {
+    const int np = (N + NS_ - 1) / NS_ * NS_;
+    return (size_t)2 * NS_ * 2 * KC * 64 * 16 + (size_t)WAVES * np * 16 * P * (4 + 2);
+  };
+  int NS = 1;
+  const size_t cap = 156 * 1024;
+  if ((N + 2) / 3 * 3 <= (N + 1) / 2 * 2 && lds_for(3) <= cap && KC <= 4) NS = 3;
+  else if (lds_for(2) <= cap) NS = 2;
+  const size_t lds = lds_for(NS);
+  if (lds > cap) return 1;
+  const int NP = (N + NS - 1) / NS * NS;
   bf16_t* WpT = (bf16_t*)workspace;
-  const int64_t total = (int64_t)KSH * N * 2 * KC * 64;
+  const int64_t total = (int64_t)KSH * npass * NP * 2 * KC * 64;
   hipLaunchKernelGGL(cin_prepack_bwd_kernel, dim3((int)std::min<int64_t>((total + 255) / 256, 2048)), dim3(256), 0, s,
-                     (const bf16_t*)Wc, WpT, C, N, H, KSH, KC);
-  // pixel tiles per wave: the gy fragments (P*KC*4 registers) must leave room for the accumulators
-  int P = E % 64 == 0 && KC <= 4 ? 4 : (E % 32 == 0 ? 2 : 1);
-  int NS = 2;   // fields per pipeline step; 1 when two would not fit 64 KiB of LDS (C = 256)
-  auto lds_for = [&](int P_, int NS_) { return (size_t)2 * NS_ * 2 * KC * 64 * 16 + (size_t)4 * N * 16 * P_ * (4 + 2); };
-  if (lds_for(P, NS) > 64 * 1024) NS = 1;
-  while (P > 1 && lds_for(P, NS) > 64 * 1024) P >>= 1;
-  const size_t lds = lds_for(P, NS);
-  if (lds > 64 * 1024) return 1;
+                     (const bf16_t*)Wc, WpT, C, N, NP, H, KSH, KC, npass);
   const int64_t nitems = B * (E / (16 * P));
-  const int grid = (int)std::min<int64_t>((nitems + 3) / 4, 256 * 2);
-#define TRS_CINB2(KC_, P_, NS_)                                                                                     \
-  hipLaunchKernelGGL((cin_cl_bwd_data_kernel<KC_, P_, NS_>), dim3(grid), dim3(256), lds, s, (const bf16_t*)x0T, ld0, \
-                     (const bf16_t*)xkT, ldk, (const bf16_t*)gyT, (const uint4*)WpT, (bf16_t*)dx0T, (bf16_t*)dxkT,   \
-                     ldo, B, N, H, C, E)
-#define TRS_CINB(KC_, P_)              \
-  do {                                 \
-    if (NS == 2) TRS_CINB2(KC_, P_, 2); \
-    else TRS_CINB2(KC_, P_, 1);        \
+  const int grid = (int)std::min<int64_t>((nitems + WAVES - 1) / WAVES, 256);
+#define TRS_CINB(KC_, P_, NS_, W_)                                                                                  \
+  do {                                                                                                              \
+    auto kern = cin_cl_bwd_data_kernel<KC_, P_, NS_, W_>;                                                           \
+    static size_t attr_lds = 0;                                                                                     \
+    if (lds > 64 * 1024 && lds > attr_lds) {                                                                        \
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+        return check_launch("cin_cl_bwd_data: LDS attribute");                                                      \
+      attr_lds = lds;                                                                                               \
+    }                                                                                                               \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * W_), lds, s, (const bf16_t*)x0T, ld0, (const bf16_t*)xkT, ldk,   \
+                       (const bf16_t*)gyT, (const uint4*)WpT, (bf16_t*)dx0T, (bf16_t*)dxkT, ldo, B, N, H, C, E,     \
+                       npass);                                                                                      \
   } while (0)
-#define TRS_CINB_P(KC_)                \
-  do {                                 \
-    if (P == 4) TRS_CINB(KC_, 4);      \
-    else if (P == 2) TRS_CINB(KC_, 2); \
-    else TRS_CINB(KC_, 1);             \
+#define TRS_CINB_NS(KC_, P_)              \
+  do {                                    \
+    if (NS == 3) TRS_CINB(KC_, P_, 3, 8); \
+    else if (NS == 2) TRS_CINB(KC_, P_, 2, 8); \
+    else TRS_CINB(KC_, P_, 1, 8);         \
   } while (0)
-  switch (KC) {
-    case 1: TRS_CINB_P(1); break;
-    case 2: TRS_CINB_P(2); break;
-    case 4: TRS_CINB_P(4); break;
-    default: TRS_CINB_P(8); break;
+#define TRS_CINB_P(KC_)                   \
+  do {                                    \
+    if (P == 4) TRS_CINB_NS(KC_, 4);      \
+    else if (P == 2) TRS_CINB_NS(KC_, 2); \
+    else TRS_CINB_NS(KC_, 1);             \
+  } while (0)
+  if (onepass) {
+    if (NS == 2) TRS_CINB(8, 4, 2, 4);
+    else TRS_CINB(8, 4, 1, 4);
+  } else {
+    switch (KC) {
+      case 1: TRS_CINB_P(1); break;
+      case 2: TRS_CINB_P(2); break;
+      default: TRS_CINB_P(4); break;
+    }
   }
 #undef TRS_CINB_P
+#undef TRS_CINB_NS
 #undef TRS_CINB
-#undef TRS_CINB2
   return check_launch("cin_cl_bwd_data");
 }
 
