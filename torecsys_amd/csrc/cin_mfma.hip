@@ -657,14 +657,18 @@ int cin_cl_bwd_data(const void* x0T, int ld0, const void* xkT, int ldk, const vo
 // half the L2 bytes per flop of a 2-field x all-C tiling, which is what bounds this kernel.
 // Partial sums per sample-split go to a workspace and are reduced by a second kernel (no float atomics).
 constexpr int DW_NG = 8;      // fields per workgroup
-constexpr int DW_NW = 4;      // fields per wave
 constexpr int DW_WAVES = 8;
 
-template <int WH /* waves along h: 1 -> CB = 128, 2 -> CB = 64 */, int HW /* h tiles per wave */, int KE /* E/32 */>
+// NW fields per wave (DW_NG / NW field groups), WH wave groups along h, the other waves along c (32 channels each):
+// every gy fragment is unpacked once and scaled by NW x0 rows, and every scaled fragment feeds HW MFMAs -- the VALU cost
+// per MFMA is (16 + 8/NW) / HW instructions, so wide layers run NW = 2, HW = 8 (all of H = 128 in one wave: 2.5 per
+// MFMA; the NW = 4, HW = 4 split of the same workgroup tile needs 4.5 and is VALU-bound).
+template <int NW, int WH, int HW /* h tiles per wave */, int KE /* E/32 */>
 __global__ __launch_bounds__(512) void cin_dw_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x0,
                                                      const bf16_t* __restrict__ xk, float* __restrict__ dWpart,
                                                      int64_t B, int N, int H, int C, int nsplit) {
-  constexpr int CW = 4 / WH;                // waves along c
+  constexpr int FG = DW_NG / NW;            // field groups (waves along the fields)
+  constexpr int CW = DW_WAVES / (FG * WH);  // waves along c
   constexpr int CB = 32 * CW;               // channels per block
   constexpr int HBK = 16 * HW * WH;         // h per block
   constexpr int E = 32 * KE;
@@ -682,12 +686,12 @@ __global__ __launch_bounds__(512) void cin_dw_kernel(const bf16_t* __restrict__ 
   const int cb = bid % cbc; bid /= cbc;
   const int hb = bid % hb_count; bid /= hb_count;
   const int split = bid;
-  const int nq = wave & 1, cw = (wave >> 1) % CW, hw = (wave >> 1) / CW;
+  const int nq = wave % FG, cw = (wave / FG) % CW, hw = (wave / FG) / CW;
   const int64_t per = (B + nsplit - 1) / nsplit;
   const int64_t b_lo = split * per, b_hi = b_lo + per < B ? b_lo + per : B;
-  f32x4 acc[DW_NW][2][HW];
+  f32x4 acc[NW][2][HW];
 #pragma unroll
-  for (int nn = 0; nn < DW_NW; ++nn)
+  for (int nn = 0; nn < NW; ++nn)
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -747,13 +751,13 @@ __global__ __launch_bounds__(512) void cin_dw_kernel(const bf16_t* __restrict__ 
     const char* base = smem + (size_t)cur * BUF;
     const char* gy_s = base + (32 * cw) * RS;
     const char* xk_s = base + (CB + 16 * HW * hw) * RS;
-    const char* x0_s = base + (CB + HBK + DW_NW * nq) * RS;
+    const char* x0_s = base + (CB + HBK + NW * nq) * RS;
 #pragma unroll
     for (int ke = 0; ke < KE; ++ke) {
       const int eoff = (32 * ke + 8 * q) * 2;
-      float xf[DW_NW][8];
+      float xf[NW][8];
 #pragma unroll
-      for (int nn = 0; nn < DW_NW; ++nn) Vec16<bf16_t>::unpack(*reinterpret_cast<const uint4*>(x0_s + nn * RS + eoff), xf[nn]);
+      for (int nn = 0; nn < NW; ++nn) Vec16<bf16_t>::unpack(*reinterpret_cast<const uint4*>(x0_s + nn * RS + eoff), xf[nn]);
       uint4 Bx[HW];
 #pragma unroll
       for (int ht = 0; ht < HW; ++ht) Bx[ht] = *reinterpret_cast<const uint4*>(xk_s + (16 * ht + r) * RS + eoff);
@@ -762,7 +766,7 @@ __global__ __launch_bounds__(512) void cin_dw_kernel(const bf16_t* __restrict__ 
         float gf[8];
         Vec16<bf16_t>::unpack(*reinterpret_cast<const uint4*>(gy_s + (16 * ct + r) * RS + eoff), gf);
 #pragma unroll
-        for (int nn = 0; nn < DW_NW; ++nn) {
+        for (int nn = 0; nn < NW; ++nn) {
           float p[8];
 #pragma unroll
           for (int k = 0; k < 8; ++k) p[k] = gf[k] * xf[nn][k];
@@ -780,8 +784,8 @@ __global__ __launch_bounds__(512) void cin_dw_kernel(const bf16_t* __restrict__ 
   }
   float* out = dWpart + (size_t)split * C * N * H;
 #pragma unroll
-  for (int nn = 0; nn < DW_NW; ++nn) {
-    const int n = g * DW_NG + DW_NW * nq + nn;
+  for (int nn = 0; nn < NW; ++nn) {
+    const int n = g * DW_NG + NW * nq + nn;
     if (n >= N) continue;
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
@@ -821,10 +825,13 @@ int cin_dw(const void* gy, const void* x0, const void* xk, int64_t B, int N, int
   if (ws_bytes < cin_dw_workspace_bytes(B, N, H, C)) return fail(TRS_EWORKSPACE, "cin_dw: workspace too small");
   const int KE = E / 32;
   const int tiles = (H + 15) / 16;
-  // narrow H: all waves share the h range and split 128 channels; otherwise two wave groups split h
+  // wide H (5..8 tiles per 128-h block): two fields x 32 channels x 8 h-tiles per wave; narrow H: four fields per wave,
+  // all waves share the h range and split 128 channels; otherwise two wave groups split h
   const int hw_cap = KE == 4 ? 2 : 4;    // E = 128 stages more vectors per thread: keep the accumulators small
-  int WH, HW;
-  if (tiles <= hw_cap && C % 128 == 0) {
+  int NW = 4, WH, HW;
+  if (KE <= 2 && (tiles + 7) / 8 * 8 - tiles <= 3) {
+    NW = 2; WH = 1; HW = 8;
+  } else if (tiles <= hw_cap && C % 128 == 0) {
     WH = 1; HW = tiles;
   } else {
     WH = 2; HW = 1;
@@ -834,7 +841,7 @@ int cin_dw(const void* gy, const void* x0, const void* xk, int64_t B, int N, int
       if (cover < best) { best = cover; HW = cand; }
     }
   }
-  const int CB = 32 * (4 / WH), HBK = 16 * HW * WH;
+  const int CB = 32 * (DW_WAVES / ((DW_NG / NW) * WH)), HBK = 16 * HW * WH;
   const int ng = (N + DW_NG - 1) / DW_NG, cbc = C / CB, hbc = (H + HBK - 1) / HBK;
   int nsplit = (int)std::max<int64_t>(1, 256 / std::max(1, ng * cbc * hbc));   // one workgroup per CU
   nsplit = (int)std::min<int64_t>(nsplit, std::max<int64_t>(1, B / 8));
@@ -842,9 +849,9 @@ int cin_dw(const void* gy, const void* x0, const void* xk, int64_t B, int N, int
   const int grid = ng * cbc * hbc * nsplit;
   const size_t lds = (size_t)2 * (CB + HBK + DW_NG) * (E * 2 + 16);
   float* part = (float*)workspace;
-#define TRS_DW(WH_, HW_, KE_)                                                                                    \
+#define TRS_DW(NW_, WH_, HW_, KE_)                                                                               \
   do {                                                                                                           \
-    auto kern = cin_dw_kernel<WH_, HW_, KE_>;                                                                    \
+    auto kern = cin_dw_kernel<NW_, WH_, HW_, KE_>;                                                               \
     static size_t attr_lds = 0;                                                                                  \
     if (lds > 64 * 1024 && lds > attr_lds) {                                                                     \
       if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
@@ -856,9 +863,9 @@ int cin_dw(const void* gy, const void* x0, const void* xk, int64_t B, int N, int
   } while (0)
 #define TRS_DW_KE(WH_, HW_)                    \
   do {                                         \
-    if (KE == 1) TRS_DW(WH_, HW_, 1);          \
-    else if (KE == 2) TRS_DW(WH_, HW_, 2);     \
-    else TRS_DW(WH_, HW_, 4);                  \
+    if (KE == 1) TRS_DW(4, WH_, HW_, 1);       \
+    else if (KE == 2) TRS_DW(4, WH_, HW_, 2);  \
+    else TRS_DW(4, WH_, HW_, 4);               \
   } while (0)
 #define TRS_DW_HW(WH_)                         \
   do {                                         \
@@ -867,7 +874,10 @@ int cin_dw(const void* gy, const void* x0, const void* xk, int64_t B, int N, int
     else if (HW == 3) TRS_DW_KE(WH_, 3);       \
     else TRS_DW_KE(WH_, 4);                    \
   } while (0)
-  if (WH == 1) TRS_DW_HW(1);
+  if (NW == 2) {
+    if (KE == 1) TRS_DW(2, 1, 8, 1);
+    else TRS_DW(2, 1, 8, 2);
+  } else if (WH == 1) TRS_DW_HW(1);
   else TRS_DW_HW(2);
 #undef TRS_DW_HW
 #undef TRS_DW_KE
