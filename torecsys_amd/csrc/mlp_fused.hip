@@ -167,10 +167,8 @@ __device__ __forceinline__ void mlp_gemm_t(const char* act, int act_str, const u
     }
   } else {
     constexpr int HALF = MCNT >= 2 ? MCNT / 2 : 1;
-    uint4 Ann[2 * NPW];                          // fragments two k-steps ahead: an L2 round trip outlasts one k-step
-    if (1 < KS) loadA(1, An);
-    for (int ks = 0; ks < KS; ++ks) {
-      if (ks + 2 < KS) loadA(ks + 2, Ann);
+    if (1 < KS) loadA(1, An);                    // one k-step ahead (deeper costs 8 more register moves per k-step and the
+    for (int ks = 0; ks < KS; ++ks) {            // compiler drains the loads at the top of the loop body anyway)
 #pragma unroll
       for (int m0 = 0; m0 < MCNT; m0 += HALF) {
         uint4 Bh[HALF];
@@ -184,10 +182,8 @@ __device__ __forceinline__ void mlp_gemm_t(const char* act, int act_str, const u
                 __builtin_bit_cast(mf_bf16x8, A[t]), __builtin_bit_cast(mf_bf16x8, Bh[mi]), acc[m0 + mi][t], 0, 0, 0);
       }
 #pragma unroll
-      for (int t = 0; t < 2 * NPW; ++t) {
-        A[t] = An[t];
-        An[t] = Ann[t];
-      }
+      for (int t = 0; t < 2 * NPW; ++t) A[t] = An[t];
+      if (ks + 2 < KS) loadA(ks + 2, An);
     }
   }
 }
@@ -209,17 +205,6 @@ __device__ __forceinline__ void mlp_dispatch(const MlpShare& sh, F&& body) {
 }
 
 // LDS rows [0, MF_ROWS) x ncols(bf16) -> global (row0 + r, .) ; 16-byte pieces, whole rows coalesced
-__device__ __forceinline__ void mlp_copy_out(const char* act, int act_str, void* out, int out_stride, int ncols,
-                                             int64_t row0, int64_t rows) {
-  if (out == nullptr) return;
-  const int cpr = ncols >> 3;   // 16-byte chunks per row
-  for (int t = threadIdx.x; t < MF_ROWS * cpr; t += blockDim.x) {
-    const int r = t / cpr, c = t - r * cpr;
-    if (row0 + r < rows)
-      store_stream(reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(out) + (row0 + r) * out_stride) + c,
-                   *reinterpret_cast<const uint4*>(act + r * act_str + c * 16));
-  }
-}
 
 // global rows (row0 + r, 0 .. in_stride) -> LDS rows, zero-filled up to ``ncols`` columns and past the last row
 __device__ __forceinline__ void mlp_load_in(char* act, int act_str, const void* in, int in_stride, int ncols, int64_t row0,
@@ -265,7 +250,8 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_fwd_kernel(MlpArgs
           for (int mi = 0; mi < MF_MT; ++mi) acc[mi][2 * pi + h] = init;
         }
       mlp_dispatch(sh, [&]<int MCNT, int NPW>() { mlp_gemm_t<MCNT, NPW, false>(act, a.act_str, st.wf, st.K, sh, lane, acc); });
-      __syncthreads();      // every wave is done reading the layer's input (and the previous copy-out has left LDS)
+      const int out_cols = l + 1 < a.nsteps ? st.N : st.out_stride;
+      __syncthreads();      // every wave is done reading the layer's input
       mlp_dispatch(sh, [&]<int MCNT, int NPW>() {
 #pragma unroll
         for (int pi = 0; pi < NPW; ++pi) {
@@ -279,20 +265,29 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_fwd_kernel(MlpArgs
             }
             unsigned bits = 0;
             if (st.relu) {
+              // one compare per value feeds both the mask bit (bits = 2*bits + carry) and the select; fmaxf would add
+              // two v_max (it canonicalises NaNs first) -- a NaN reads as "not positive" either way
 #pragma unroll
-              for (int j = 0; j < 8; ++j) {
-                bits |= (v[j] > 0.f ? 1u : 0u) << j;
-                v[j] = fmaxf(v[j], 0.f);
+              for (int j = 7; j >= 0; --j) {
+                const bool pos = v[j] > 0.f;
+                bits = bits + bits + (pos ? 1u : 0u);
+                v[j] = pos ? v[j] : 0.f;
               }
             }
             const int row = (sh.mt0 + mi) * 16 + r;
-            *reinterpret_cast<uint4*>(act + row * a.act_str + (32 * sh.pair[pi] + 8 * q) * 2) = Vec16<bf16_t>::pack(v);
+            const int col = 32 * sh.pair[pi] + 8 * q;
+            const uint4 pk = Vec16<bf16_t>::pack(v);
+            *reinterpret_cast<uint4*>(act + row * a.act_str + col * 2) = pk;
+            // the step's global output (hidden activations kept for the weight gradients / the result) leaves from the
+            // registers: 16 bytes per lane, 64 contiguous bytes per row and wave; the stores drain under the next
+            // layer's MFMAs (a separate LDS -> global pass cost 0.45 ms per 400-wide layer with the matrix pipe idle)
+            if (st.out != nullptr && row0 + row < a.rows && col < out_cols)
+              store_stream(reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(st.out) + (row0 + row) * st.out_stride + col), pk);
             if (st.relu) mask[row * MF_MASK_STR + 4 * sh.pair[pi] + q] = (uint8_t)bits;
           }
         }
       });
       __syncthreads();
-      mlp_copy_out(act, a.act_str, st.out, st.out_stride, l + 1 < a.nsteps ? st.N : st.out_stride, row0, a.rows);
       if (st.mask != nullptr && st.relu) {
         for (int t = threadIdx.x; t < MF_ROWS * (MF_MASK_STR / 16); t += blockDim.x) {
           const int rr = t >> 2, c = t & 3;
@@ -357,6 +352,7 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_bwd_kernel(MlpArgs
         }
       }
       if (st.mask != nullptr) *reinterpret_cast<uint4*>(mask + mrow * MF_MASK_STR + mc * 16) = mraw;
+      const int out_cols = s + 1 < a.nsteps ? st.N : st.out_stride;
       __syncthreads();
       if (st.colsum != nullptr && threadIdx.x < st.K) {
         float t = 0.f;
@@ -379,14 +375,18 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_bwd_kernel(MlpArgs
             if (st.mask != nullptr) {
               const unsigned bits = mask[row * MF_MASK_STR + 4 * sh.pair[pi] + q];
 #pragma unroll
-              for (int j = 0; j < 8; ++j) v[j] = ((bits >> j) & 1u) ? v[j] : 0.f;
+              for (int j = 0; j < 8; ++j)      // sign-extended 1-bit field (0 / all ones) ANDed onto the value: 2 instructions
+                v[j] = __int_as_float(__float_as_int(v[j]) & __builtin_amdgcn_sbfe((int)bits, j, 1));
             }
-            *reinterpret_cast<uint4*>(act + row * a.act_str + (32 * sh.pair[pi] + 8 * q) * 2) = Vec16<bf16_t>::pack(v);
+            const int col = 32 * sh.pair[pi] + 8 * q;
+            const uint4 pk = Vec16<bf16_t>::pack(v);
+            *reinterpret_cast<uint4*>(act + row * a.act_str + col * 2) = pk;
+            if (st.out != nullptr && row0 + row < a.rows && col < out_cols)      // as in the forward: from the registers
+              store_stream(reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(st.out) + (row0 + row) * st.out_stride + col), pk);
           }
         }
       });
       __syncthreads();
-      mlp_copy_out(act, a.act_str, st.out, st.out_stride, s + 1 < a.nsteps ? st.N : st.out_stride, row0, a.rows);
     }
     __syncthreads();
   }
