@@ -204,8 +204,6 @@ __device__ __forceinline__ void mlp_dispatch(const MlpShare& sh, F&& body) {
   }
 }
 
-// LDS rows [0, MF_ROWS) x ncols(bf16) -> global (row0 + r, .) ; 16-byte pieces, whole rows coalesced
-
 // global rows (row0 + r, 0 .. in_stride) -> LDS rows, zero-filled up to ``ncols`` columns and past the last row
 __device__ __forceinline__ void mlp_load_in(char* act, int act_str, const void* in, int in_stride, int ncols, int64_t row0,
                                             int64_t rows) {
