@@ -19,9 +19,11 @@ ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++20", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-result"]
-# per-file additions.  cin_mfma: the SLP vectoriser turns the fp32 FMAs that sit between MFMAs into v_pk_fma_f32, which
-# costs more issue time beside the matrix pipe than the two single FMAs it replaces
-FILE_FLAGS = {"cin_mfma.hip": ["-fno-slp-vectorize"]}
+# per-file additions.  The SLP vectoriser turns fp32 arithmetic that sits between MFMAs into v_pk_* instructions, which
+# cost more issue time beside the matrix pipe than the two single ones they replace (CIN forward 1.58 vs 1.18 ms, cross
+# backward 1.15 vs 1.04 ms)
+FILE_FLAGS = {"cin_mfma.hip": ["-fno-slp-vectorize"], "cross_mfma.hip": ["-fno-slp-vectorize"],
+              "mlp_fused.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():
