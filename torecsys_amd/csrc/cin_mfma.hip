@@ -361,7 +361,7 @@ template <int P>
 __device__ __forceinline__ bool cin_red_owner(int q) { return P == 4 ? true : (P == 2 ? (q & 1) == 0 : q == 0); }
 
 template <int KC, int P, int NS, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 1 : 1) void cin_cl_bwd_data_kernel(
+__global__ __launch_bounds__(64 * WAVES) void cin_cl_bwd_data_kernel(
     const bf16_t* __restrict__ x0T, int ld0, const bf16_t* __restrict__ xkT, int ldk, const bf16_t* __restrict__ gyT,
     const uint4* __restrict__ WpT, bf16_t* __restrict__ dx0T, bf16_t* __restrict__ dxkT, int ldo, int64_t B, int N, int H,
     int C, int E, int npass) {
@@ -563,16 +563,6 @@ size_t cin_mfma_bwd_data_workspace_bytes(int N, int H, int C) {
   return cin_bwd_frag_bytes(KSH, N + 2, KCT) + 256;
 }
 
-// 0: C = 256 in two passes of 128 channels, eight waves per workgroup; 1: one pass, 512-register waves (TRS_CIN_BWD_ONEPASS=1)
-static int cin_bwd_onepass() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("TRS_CIN_BWD_ONEPASS");
-    v = e && e[0] == '1' ? 1 : 0;
-  }
-  return v;
-}
-
 int cin_cl_bwd_data(const void* x0T, int ld0, const void* xkT, int ldk, const void* gyT, const void* Wc, int64_t B, int N,
                     int H, int C, int E, void* dx0T, void* dxkT, int ldo, void* workspace, size_t ws_bytes,
                     hipStream_t s) {
@@ -582,10 +572,11 @@ int cin_cl_bwd_data(const void* x0T, int ld0, const void* xkT, int ldk, const vo
     return 1;
   if (ws_bytes < cin_mfma_bwd_data_workspace_bytes(N, H, C)) return fail(TRS_EWORKSPACE, "cin_cl_bwd_data: workspace");
   const int P = E % 64 == 0 ? 4 : (E % 32 == 0 ? 2 : 1);
-  const bool onepass = KCT == 8 && P == 4 && cin_bwd_onepass();
-  const int KC = KCT == 8 && !onepass ? 4 : KCT;
+  // C = 256: two passes of 128 channels (one pass with 512-register waves and four waves per workgroup measured 1.06 vs
+  // 0.93 ms: the accumulators end up in AGPRs and are copied out for every VALU use)
+  const int KC = KCT == 8 ? 4 : KCT;
   const int npass = KCT / KC;
-  const int WAVES = onepass ? 4 : 8;
+  const int WAVES = 8;
   auto lds_for = [&](int NS_) {
     const int np = (N + NS_ - 1) / NS_ * NS_;
     return (size_t)2 * NS_ * 2 * KC * 64 * 16 + (size_t)WAVES * np * 16 * P * (4 + 2);
@@ -628,15 +619,10 @@ int cin_cl_bwd_data(const void* x0T, int ld0, const void* xkT, int ldk, const vo
     else if (P == 2) TRS_CINB_NS(KC_, 2); \
     else TRS_CINB_NS(KC_, 1);             \
   } while (0)
-  if (onepass) {
-    if (NS == 2) TRS_CINB(8, 4, 2, 4);
-    else TRS_CINB(8, 4, 1, 4);
-  } else {
-    switch (KC) {
-      case 1: TRS_CINB_P(1); break;
-      case 2: TRS_CINB_P(2); break;
-      default: TRS_CINB_P(4); break;
-    }
+  switch (KC) {
+    case 1: TRS_CINB_P(1); break;
+    case 2: TRS_CINB_P(2); break;
+    default: TRS_CINB_P(4); break;
   }
 #undef TRS_CINB_P
 #undef TRS_CINB_NS
