@@ -362,6 +362,10 @@ def main():
         return loss
 
     roof_kernel = "trs_embed_fm" if not a.no_fuse else "trs_gather_rows"
+    from torecsys_amd import inputs as _inputs_mod
+    if (_inputs_mod.PAIR_FIRST_ORDER and not a.no_fuse and not sharded and a.optimizer == "none"
+            and a.model in ("deepfm", "fm")):
+        roof_kernel = "trs_embed_fm_fields"     # TRS_PAIR_FIRST_ORDER=1: the first-order lookup rides in the same launch
     use_graph = a.graph and world == 1 and MB == 1 and not sharded and a.optimizer in ("none", "sgd")
     eager_step = step
     for _ in range(a.warmup if not use_graph else max(3, a.warmup // 2)):

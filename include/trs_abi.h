@@ -106,6 +106,17 @@ int trs_scatter_rows(const void* g_rows, int64_t g_rows_batch_stride, const void
                      int64_t padding_row, void* grad_table, void* workspace, size_t ws_bytes,
                      trs_stream_t stream);
 
+/* trs_scatter_rows plus the dense gradient of the companion first-order table (V x 1) of the same lookups in the same
+ * bucket walk: grad_first[r] = sum over the lookups (b,n) of row r of g_first[b,n]  (g_first: (B,N), one value per
+ * lookup; every row of grad_first is written).  Rows must be whole 16-byte vectors (E*sizeof(dtype) % 16 == 0).
+ * Replaces the second embedding backward of the (B,N,1) first-order lookup (torch embedding_dense_backward of
+ * multi_indices_emb.py:104-105 at embed_size = 1).                                                               */
+int trs_scatter_rows_first(const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm, const float* fm_sum,
+                           const void* table, const int32_t* row_start, const int32_t* perm, int64_t BN, int64_t V,
+                           int32_t E, int32_t N, int32_t dtype, int64_t padding_row, void* grad_table,
+                           const void* g_first, void* grad_first, void* workspace, size_t ws_bytes,
+                           trs_stream_t stream);
+
 /* Same walk, but the finished row sum is APPLIED to the table row in place by a fused sparse optimizer
  *  instead of being written out: optimizer 1 = SGD  w -= lr*g;
  * 2 = Adagrad  state += g*g, w -= lr*g/(sqrt(state)+eps)  (state: V x E fp32).  Exactly equivalent to the
@@ -148,6 +159,15 @@ int trs_embed_fm(const void* table, int64_t V, int32_t E, int32_t dtype,
                  const void* idx, int32_t idx_dtype, const int64_t* offsets, int64_t B, int32_t N,
                  void* emb, void* fm, float* fm_sum, const void* first_table, void* first,
                  int32_t* err_flag, trs_stream_t stream);
+
+/* The same pass when the first-order term stays a per-field tensor, as the reference's models consume it
+ * (``feat_inputs`` (B,N,1) of models/ctr/deep_fm.py:73-89, factorization_machine.py model, xdeep_fm.py):
+ * first_vals[b,n] = first_table[idx[b,n]+offsets[n]]  (0 for an out-of-range lookup) -- replaces the separate
+ * MultiIndicesEmbedding(embed_size=1) lookup (multi_indices_emb.py:104-105) of the same index block.            */
+int trs_embed_fm_fields(const void* table, int64_t V, int32_t E, int32_t dtype,
+                        const void* idx, int32_t idx_dtype, const int64_t* offsets, int64_t B, int32_t N,
+                        void* emb, void* fm, float* fm_sum, const void* first_table, void* first_vals,
+                        int32_t* err_flag, trs_stream_t stream);
 
 /* ---- K2: FM layer on a materialised block -------------------------------------------------
  * fwd: fm[b,:] = 0.5*((sum_n x)^2 - sum_n x^2), fm_sum[b,:] = sum_n x (fp32, optional)

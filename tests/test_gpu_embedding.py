@@ -164,6 +164,93 @@ def test_fused_embed_fm_vs_oracle(dev, dtype, B, N, E, Vf, zipf):
     assert rel_err(wd2.grad.float().cpu(), wr2.grad) <= tol
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,N,E,Vf,zipf", [(1024, 10, 16, 100, False), (512, 39, 64, 50, False),
+                                           (4096, 39, 64, 7, True), (8192, 5, 8, 3, True), (64, 3, 128, 4, False)])
+def test_embed_fm_fields_vs_oracle(dev, dtype, B, N, E, Vf, zipf):
+    """trs_embed_fm_fields / trs_scatter_rows_first: the per-field first-order lookup (B,N,1) rides in the wide table's
+    lookup kernel and its gradient in the wide table's bucket walk (hot rows through the long-row kernels); values are
+    bit-exact gathers, both tables' gradients against autograd over the oracle with one gradient value per lookup."""
+    from torecsys_amd import functional as F_
+    fs, idx, w, w1, g = _rand_case(B, N, E, Vf, 177 + B + N + E, dtype, zipf)
+    off = O.field_offsets(fs)
+    tol = TOL32 if dtype == torch.float32 else TOLBF
+    wr = w.float().clone().requires_grad_()
+    w1r = w1.float().clone().requires_grad_()
+    emb_r = O.multi_indices_embedding(wr, idx, off)
+    fm_r = O.fm_layer(emb_r)
+    first_r = O.multi_indices_embedding(w1r, idx, off)                         # (B,N,1): not summed
+    ge = torch.randn(B, N, E, generator=g).to(dtype)
+    gf = torch.randn(B, E, generator=g).to(dtype)
+    g1 = torch.randn(B, N, 1, generator=g).to(dtype)
+    ((emb_r * ge.float()).sum() + (fm_r * gf.float()).sum() + (first_r * g1.float()).sum()).backward()
+
+    wd = w.to(dev).requires_grad_()
+    w1d = w1.to(dev).requires_grad_()
+    emb, fm, first = F_.embed_fm_fields(wd, w1d, idx.to(dev), off.to(dev))
+    assert first.shape == (B, N, 1)
+    assert torch.equal(emb.cpu(), emb_r.detach().to(dtype))
+    assert torch.equal(first.cpu(), first_r.detach().to(dtype))
+    assert rel_err(fm.float().cpu(), fm_r.detach()) <= tol
+    ((emb.float() * ge.to(dev).float()).sum() + (fm.float() * gf.to(dev).float()).sum()
+     + (first.float() * g1.to(dev).float()).sum()).backward()
+    assert rel_err(wd.grad.float().cpu(), wr.grad) <= tol
+    assert rel_err(w1d.grad.float().cpu(), w1r.grad) <= tol
+    assert w1d.grad.shape == w1.shape
+    # only the first-order output used: the wide table gets no walk of its own, the E = 1 table its own scatter
+    wd2, w1d2 = w.to(dev).requires_grad_(), w1.to(dev).requires_grad_()
+    _, _, first2 = F_.embed_fm_fields(wd2, w1d2, idx.to(dev), off.to(dev))
+    (first2.float() * g1.to(dev).float()).sum().backward()
+    assert rel_err(w1d2.grad.float().cpu(), w1r.grad) <= tol
+    assert float(wd2.grad.float().abs().max()) == 0.0
+
+
+def test_inputs_pairs_first_order_table_with_wide_table(dev, monkeypatch):
+    """Inputs routes MultiIndicesEmbedding(E, fuse_fm) and MultiIndicesEmbedding(1) over the same columns through ONE
+    lookup pass and ONE bucket walk (either schema order); outputs, names and gradients equal the two separate modules.
+    A fused optimizer, a padding row or different columns keep the modules separate."""
+    from torecsys_amd import functional as F_
+    from torecsys_amd import inputs as I_
+    from torecsys_amd.inputs import Inputs, MultiIndicesEmbedding
+    from torecsys_amd.layers import FMLayer
+    monkeypatch.setattr(I_, "PAIR_FIRST_ORDER", True)          # opt-in switch (TRS_PAIR_FIRST_ORDER=1)
+    fs, idx, w, w1, g = _rand_case(2048, 12, 32, 20, 9, torch.bfloat16, True)
+    calls = []
+    real = F_.embed_fm_fields
+
+    def spy(*a, **k):
+        calls.append(1)
+        return real(*a, **k)
+
+    res = []
+    for order, paired in (("ef", True), ("fe", True), ("ef", False)):
+        emb = MultiIndicesEmbedding(embed_size=32, field_sizes=fs, fuse_fm=True).to(dev).to(torch.bfloat16)
+        feat = MultiIndicesEmbedding(embed_size=1, field_sizes=fs).to(dev).to(torch.bfloat16)
+        emb.embedding.weight.data.copy_(w)
+        feat.embedding.weight.data.copy_(w1)
+        emb.set_schema(["c0"])
+        feat.set_schema(["c0"] if paired else ["c1"])
+        schema = {"emb_inputs": emb, "feat_inputs": feat} if order == "ef" else {"feat_inputs": feat, "emb_inputs": emb}
+        inp = Inputs(schema=schema)
+        calls.clear()
+        F_.embed_fm_fields = spy
+        try:
+            d = inp({"c0": idx.to(dev), "c1": idx.to(dev)})
+        finally:
+            F_.embed_fm_fields = real
+        assert len(calls) == (1 if paired else 0)
+        assert list(d.keys()) == list(schema.keys())
+        assert d["emb_inputs"].names == ("B", "N", "E") and d["feat_inputs"].names == ("B", "N", "E")
+        assert hasattr(d["emb_inputs"], "_trs_fused_fm")
+        y = FMLayer()(d["emb_inputs"]).rename(None).float().sum(1, keepdim=True) + d["feat_inputs"].rename(None).float().sum(1)
+        (y.sum() + (d["emb_inputs"].rename(None).float() ** 2).sum()).backward()
+        res.append((d["emb_inputs"].rename(None).detach().cpu(), d["feat_inputs"].rename(None).detach().cpu(),
+                    emb.embedding.weight.grad.float().cpu(), feat.embedding.weight.grad.float().cpu()))
+    for k in (0, 1):
+        assert torch.equal(res[k][0], res[2][0]) and torch.equal(res[k][1], res[2][1])
+        assert rel_err(res[k][2], res[2][2]) <= TOLBF and rel_err(res[k][3], res[2][3]) <= TOLBF
+
+
 def test_fused_fm_side_channel(dev):
     """MultiIndicesEmbedding(fuse_fm=True) hands the FM term to FMLayer without a second pass; results and
     gradients equal the unfused modules."""

@@ -19,7 +19,8 @@ __global__ __launch_bounds__(256) void embed_fm_group_kernel(
     const uint4* __restrict__ src,  // GATHER: table (V x E); else x (B x N x E)
     const IdxT* __restrict__ idx, const int64_t* __restrict__ offsets, int64_t B, int N, int64_t V,
     uint4* __restrict__ emb, uint4* __restrict__ fm, float* __restrict__ fm_sum,
-    const T* __restrict__ first_table, T* __restrict__ first, int32_t* __restrict__ err_flag) {
+    const T* __restrict__ first_table, T* __restrict__ first, int32_t* __restrict__ err_flag,
+    T* __restrict__ first_vals = nullptr /* (B,N): the companion table's value of every lookup */) {
   constexpr int L = 1 << LOG2L;
   constexpr int VE = Vec16<T>::VE;
   constexpr int CH = 4;
@@ -54,7 +55,11 @@ __global__ __launch_bounds__(256) void embed_fm_group_kernel(
       if (GATHER && first_table != nullptr) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-          if ((((n0 + c) & (L - 1)) == lane_v) && r[c] >= 0) f1 += to_f32(first_table[r[c]]);
+          if ((((n0 + c) & (L - 1)) == lane_v) && n0 + c < N) {
+            const T fv = r[c] >= 0 ? first_table[r[c]] : T{};
+            f1 += to_f32(fv);
+            if (first_vals != nullptr) first_vals[b * N + n0 + c] = fv;
+          }
         }
       }
 #pragma unroll
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(256) void embed_fm_group_kernel(
     if (GATHER && first_table != nullptr) {
 #pragma unroll
       for (int m = L >> 1; m >= 1; m >>= 1) f1 += __shfl_xor(f1, m, 64);
-      if (lane_v == 0) first[b] = from_f32<T>(f1);
+      if (lane_v == 0 && first != nullptr) first[b] = from_f32<T>(f1);
     }
   }
 }
@@ -98,7 +103,8 @@ template <typename T, typename IdxT, bool GATHER>
 __global__ __launch_bounds__(256) void embed_fm_elem_kernel(
     const T* __restrict__ src, const IdxT* __restrict__ idx, const int64_t* __restrict__ offsets, int64_t B,
     int N, int E, int64_t V, T* __restrict__ emb, T* __restrict__ fm, float* __restrict__ fm_sum,
-    const T* __restrict__ first_table, T* __restrict__ first, int32_t* __restrict__ err_flag) {
+    const T* __restrict__ first_table, T* __restrict__ first, int32_t* __restrict__ err_flag,
+    T* __restrict__ first_vals = nullptr) {
   const int64_t total = B * E;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const bool f32 = total < ((int64_t)1 << 32);
@@ -119,11 +125,15 @@ __global__ __launch_bounds__(256) void embed_fm_elem_kernel(
       s += x;
       q = fmaf(x, x, q);
       if (GATHER && emb != nullptr) emb[(b * N + n) * E + e] = raw;
-      if (GATHER && first_table != nullptr && e == 0 && ok) f1 += to_f32(first_table[r]);
+      if (GATHER && first_table != nullptr && e == 0) {
+        const T fv = ok ? first_table[r] : T{};
+        f1 += to_f32(fv);
+        if (first_vals != nullptr) first_vals[b * N + n] = fv;
+      }
     }
     if (fm != nullptr) fm[t] = from_f32<T>(0.5f * (s * s - q));
     if (fm_sum != nullptr) fm_sum[t] = s;
-    if (GATHER && first_table != nullptr && e == 0) first[b] = from_f32<T>(f1);
+    if (GATHER && first_table != nullptr && e == 0 && first != nullptr) first[b] = from_f32<T>(f1);
   }
 }
 
@@ -139,7 +149,7 @@ static int log2_lanes(int row_bytes) {
 template <typename T, typename IdxT, bool GATHER>
 static int embed_fm_launch(const void* src, const IdxT* idx, const int64_t* offsets, int64_t B, int N, int E,
                            int64_t V, void* emb, void* fm, float* fm_sum, const void* first_table, void* first,
-                           int32_t* err_flag, hipStream_t s) {
+                           int32_t* err_flag, hipStream_t s, void* first_vals = nullptr) {
   const int lg = log2_lanes(E * (int)sizeof(T));
   const bool al = aligned16(src) && aligned16(emb) && aligned16(fm) && aligned16(fm_sum);
   if (lg >= 0 && al) {
@@ -148,7 +158,7 @@ static int embed_fm_launch(const void* src, const IdxT* idx, const int64_t* offs
 #define TRS_EF(LG)                                                                                        \
   hipLaunchKernelGGL((embed_fm_group_kernel<T, IdxT, LG, GATHER>), dim3(grid), dim3(256), 0, s,            \
                      (const uint4*)src, idx, offsets, B, N, V, (uint4*)emb, (uint4*)fm, fm_sum,            \
-                     (const T*)first_table, (T*)first, err_flag)
+                     (const T*)first_table, (T*)first, err_flag, (T*)first_vals)
     switch (lg) {
       case 0: TRS_EF(0); break;
       case 1: TRS_EF(1); break;
@@ -162,7 +172,8 @@ static int embed_fm_launch(const void* src, const IdxT* idx, const int64_t* offs
   } else {
     const int grid = stream_grid(B * E, 256, 256 * 16);
     hipLaunchKernelGGL((embed_fm_elem_kernel<T, IdxT, GATHER>), dim3(grid), dim3(256), 0, s, (const T*)src, idx,
-                       offsets, B, N, E, V, (T*)emb, (T*)fm, fm_sum, (const T*)first_table, (T*)first, err_flag);
+                       offsets, B, N, E, V, (T*)emb, (T*)fm, fm_sum, (const T*)first_table, (T*)first, err_flag,
+                       (T*)first_vals);
   }
   return check_launch(GATHER ? "embed_fm" : "fm_fwd");
 }
@@ -274,22 +285,21 @@ __global__ __launch_bounds__(256) void permute_grad_elem_kernel(const T* __restr
 
 using namespace trs;
 
-extern "C" int trs_embed_fm(const void* table, int64_t V, int32_t E, int32_t dtype, const void* idx,
-                            int32_t idx_dtype, const int64_t* offsets, int64_t B, int32_t N, void* emb, void* fm,
-                            float* fm_sum, const void* first_table, void* first, int32_t* err_flag,
-                            trs_stream_t stream) {
+static int embed_fm_entry(const void* table, int64_t V, int32_t E, int32_t dtype, const void* idx, int32_t idx_dtype,
+                          const int64_t* offsets, int64_t B, int32_t N, void* emb, void* fm, float* fm_sum,
+                          const void* first_table, void* first, void* first_vals, int32_t* err_flag,
+                          trs_stream_t stream) {
   if (B == 0) return TRS_OK;  // empty batch: nothing to do (pointers may be NULL)
   TRS_REQUIRE(table && idx, TRS_EINVAL, "embed_fm: NULL pointer");
   TRS_REQUIRE(V > 0 && E > 0 && B >= 0 && N > 0, TRS_EINVAL, "embed_fm: bad size");
   TRS_REQUIRE(dtype == TRS_F32 || dtype == TRS_BF16, TRS_EDTYPE, "embed_fm: dtype %d", dtype);
   TRS_REQUIRE(idx_dtype == TRS_I64 || idx_dtype == TRS_I32, TRS_EDTYPE, "embed_fm: idx dtype %d", idx_dtype);
-  TRS_REQUIRE((first_table == nullptr) == (first == nullptr), TRS_EINVAL,
-              "embed_fm: first_table and first must be given together");
-  if (B == 0) return TRS_OK;
+  TRS_REQUIRE((first_table == nullptr) == (first == nullptr && first_vals == nullptr), TRS_EINVAL,
+              "embed_fm: first_table and its output must be given together");
   hipStream_t s = (hipStream_t)stream;
 #define TRS_CALL(T, I)                                                                                    \
   return embed_fm_launch<T, I, true>(table, (const I*)idx, offsets, B, N, E, V, emb, fm, fm_sum, first_table, \
-                                     first, err_flag, s)
+                                     first, err_flag, s, first_vals)
   if (dtype == TRS_F32) {
     if (idx_dtype == TRS_I64) TRS_CALL(float, int64_t);
     TRS_CALL(float, int32_t);
@@ -297,6 +307,24 @@ extern "C" int trs_embed_fm(const void* table, int64_t V, int32_t E, int32_t dty
   if (idx_dtype == TRS_I64) TRS_CALL(bf16_t, int64_t);
   TRS_CALL(bf16_t, int32_t);
 #undef TRS_CALL
+}
+
+extern "C" int trs_embed_fm(const void* table, int64_t V, int32_t E, int32_t dtype, const void* idx,
+                            int32_t idx_dtype, const int64_t* offsets, int64_t B, int32_t N, void* emb, void* fm,
+                            float* fm_sum, const void* first_table, void* first, int32_t* err_flag,
+                            trs_stream_t stream) {
+  return embed_fm_entry(table, V, E, dtype, idx, idx_dtype, offsets, B, N, emb, fm, fm_sum, first_table, first, nullptr,
+                        err_flag, stream);
+}
+
+/* see include/trs_abi.h: the same pass, with the companion table's value of every lookup (B,N) instead of their sum */
+extern "C" int trs_embed_fm_fields(const void* table, int64_t V, int32_t E, int32_t dtype, const void* idx,
+                                   int32_t idx_dtype, const int64_t* offsets, int64_t B, int32_t N, void* emb, void* fm,
+                                   float* fm_sum, const void* first_table, void* first_vals, int32_t* err_flag,
+                                   trs_stream_t stream) {
+  TRS_REQUIRE(B == 0 || (first_table && first_vals), TRS_EINVAL, "embed_fm_fields: NULL first-order pointer");
+  return embed_fm_entry(table, V, E, dtype, idx, idx_dtype, offsets, B, N, emb, fm, fm_sum, first_table, nullptr,
+                        first_vals, err_flag, stream);
 }
 
 extern "C" int trs_fm_fwd(const void* x, int64_t B, int32_t N, int32_t E, int32_t dtype, void* fm, float* fm_sum,

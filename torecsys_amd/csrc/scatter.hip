@@ -361,11 +361,14 @@ __device__ __forceinline__ void sink_elem(const RowSink& k, T* __restrict__ out,
 // ---------------------------------------------------------------------------------------------
 // segmented reduction: one L-lane group per table row (rows with > LONG_ROW lookups are deferred
 // to a queue and reduced by whole workgroups afterwards)
-template <typename T, int LOG2L, bool HAS_G, bool HAS_FM, int CH = 4>
+// HAS_F1: a companion E = 1 table (the first-order term of the same lookups) rides in the same walk: g_first holds one
+// value per lookup (B*N), every lane of the group adds the same ones into *f1
+template <typename T, int LOG2L, bool HAS_G, bool HAS_FM, int CH = 4, bool HAS_F1 = false>
 __device__ __forceinline__ void accumulate_bucket(float* acc, float* gsum, const uint4* __restrict__ g_rows,
                                                   const uint4* __restrict__ g_fm, const float* __restrict__ fm_sum,
                                                   const int32_t* __restrict__ perm, int beg, int end, int step,
-                                                  int N, int64_t gbs, int lane_v) {
+                                                  int N, int64_t gbs, int lane_v, const T* __restrict__ g_first = nullptr,
+                                                  float* f1 = nullptr) {
   constexpr int L = 1 << LOG2L;
   constexpr int VE = Vec16<T>::VE;
   // CH lookups in flight per lane; the bucket positions of the NEXT round are fetched while this round's gradient rows
@@ -376,6 +379,7 @@ __device__ __forceinline__ void accumulate_bucket(float* acc, float* gsum, const
   for (int q = beg; q < end; q += CH * step) {
     int p[CH];
     uint4 gv[CH], fv[CH], tv[CH];
+    float fr[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) p[c] = pn[c];
 #pragma unroll
@@ -388,7 +392,9 @@ __device__ __forceinline__ void accumulate_bucket(float* acc, float* gsum, const
       gv[c] = make_uint4(0, 0, 0, 0);
       fv[c] = make_uint4(0, 0, 0, 0);
       tv[c] = make_uint4(0, 0, 0, 0);
+      fr[c] = 0.f;
       if (p[c] >= 0) {
+        if (HAS_F1) fr[c] = to_f32(g_first[p[c]]);
         if (HAS_G) {
           int64_t row = p[c];
           if (gbs != N) {  // g_rows is a strided slice: sample b starts at row b*gbs
@@ -410,6 +416,7 @@ __device__ __forceinline__ void accumulate_bucket(float* acc, float* gsum, const
     }
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
+      if (HAS_F1) *f1 += fr[c];
       if (p[c] >= 0) {
         if (HAS_G) {
           float x[VE];
@@ -438,12 +445,13 @@ __device__ __forceinline__ void accumulate_bucket(float* acc, float* gsum, const
   }
 }
 
-template <typename T, int LOG2L, bool HAS_G, bool HAS_FM>
+template <typename T, int LOG2L, bool HAS_G, bool HAS_FM, bool HAS_F1 = false>
 __global__ __launch_bounds__(256) void scatter_rows_group_kernel(
     const uint4* __restrict__ g_rows, const uint4* __restrict__ g_fm, const float* __restrict__ fm_sum,
     const uint4* __restrict__ table, const int32_t* __restrict__ row_start, const int32_t* __restrict__ perm,
     int64_t V, int N, int64_t gbs, int64_t padding_row, uint4* __restrict__ grad,
-    int32_t* __restrict__ long_rows /* [0]=count */, RowSink sink) {
+    int32_t* __restrict__ long_rows /* [0]=count */, RowSink sink, const T* __restrict__ g_first = nullptr,
+    T* __restrict__ grad_first = nullptr) {
   constexpr int L = 1 << LOG2L;
   constexpr int VE = Vec16<T>::VE;
   const int lane_v = threadIdx.x & (L - 1);
@@ -472,8 +480,10 @@ __global__ __launch_bounds__(256) void scatter_rows_group_kernel(
       }
       continue;
     }
+    float f1 = 0.f;
     if (r != padding_row) {
-      accumulate_bucket<T, LOG2L, HAS_G, HAS_FM, (HAS_FM ? 2 : 4)>(acc, gsum, g_rows, g_fm, fm_sum, perm, beg, end, 1, N, gbs, lane_v);
+      accumulate_bucket<T, LOG2L, HAS_G, HAS_FM, (HAS_FM ? 2 : 4), HAS_F1>(acc, gsum, g_rows, g_fm, fm_sum, perm, beg, end, 1, N,
+                                                                       gbs, lane_v, g_first, &f1);
       if (HAS_FM && fm_sum != nullptr && end > beg) {
         float w[VE];
         Vec16<T>::unpack(wraw, w);
@@ -482,6 +492,38 @@ __global__ __launch_bounds__(256) void scatter_rows_group_kernel(
       }
     }
     sink_vec<T>(sink, grad, sink_row(sink, r) * L + lane_v, acc, end > beg && r != padding_row);
+    if (HAS_F1 && lane_v == 0) grad_first[r] = from_f32<T>(f1);      // dense companion gradient: every row written
+  }
+}
+
+// companion (E = 1) gradient of the hot rows the group kernel queued: one wave per queued row (its first chunk entry),
+// lanes stride the whole bucket, wavefront reduction
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_first_long_kernel(const T* __restrict__ g_first,
+                                                                 const int32_t* __restrict__ row_start,
+                                                                 const int32_t* __restrict__ perm,
+                                                                 const int32_t* __restrict__ long_rows,
+                                                                 T* __restrict__ grad_first) {
+  const int nlong = long_rows[0];
+  const int lane = threadIdx.x & 63;
+  const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int i = wid; i < nlong; i += nwaves) {
+    if (long_rows[2 + 2 * i] != 0) continue;
+    const int64_t r = long_rows[1 + 2 * i];
+    const int beg = row_start[r], end = row_start[r + 1];
+    float acc = 0.f;
+    constexpr int U = 4;
+    for (int q = beg + lane; q < end; q += 64 * U) {
+      int pp[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) pp[u] = (q + 64 * u) < end ? perm[q + 64 * u] : -1;
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (pp[u] >= 0) acc += to_f32(g_first[pp[u]]);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if (lane == 0) grad_first[r] = from_f32<T>(acc);
   }
 }
 
@@ -702,7 +744,8 @@ template <typename T, int LOG2L>
 static void scatter_group_launch(const void* g_rows, const void* g_fm, const float* fm_sum, const void* table,
                                  const int32_t* row_start, const int32_t* perm, int64_t V, int N, int64_t gbs,
                                  int64_t padding_row, void* grad, int32_t* long_rows, void* tg, float* scratch,
-                                 int64_t B, RowSink sink, hipStream_t s) {
+                                 int64_t B, RowSink sink, hipStream_t s, const void* g_first = nullptr,
+                                 void* grad_first = nullptr) {
   const int L = 1 << LOG2L;
   if (g_fm != nullptr && fm_sum != nullptr) {
     hipLaunchKernelGGL((build_tg_kernel<T>), dim3(stream_grid(B * L, 256, 4096)), dim3(256), 0, s, (const uint4*)g_fm,
@@ -713,9 +756,15 @@ static void scatter_group_launch(const void* g_rows, const void* g_fm, const flo
   const bool hg = g_rows != nullptr, hf = g_fm != nullptr;
 #define TRS_SC(HG, HF)                                                                                          \
   do {                                                                                                          \
-    hipLaunchKernelGGL((scatter_rows_group_kernel<T, LOG2L, HG, HF>), dim3(grid), dim3(256), 0, s,               \
-                       (const uint4*)g_rows, (const uint4*)g_fm, fm_sum, (const uint4*)table, row_start, perm, V, \
-                       N, gbs, padding_row, (uint4*)grad, long_rows, sink);                                           \
+    if (g_first != nullptr)                                                                                     \
+      hipLaunchKernelGGL((scatter_rows_group_kernel<T, LOG2L, HG, HF, true>), dim3(grid), dim3(256), 0, s,       \
+                         (const uint4*)g_rows, (const uint4*)g_fm, fm_sum, (const uint4*)table, row_start, perm, \
+                         V, N, gbs, padding_row, (uint4*)grad, long_rows, sink, (const T*)g_first,               \
+                         (T*)grad_first);                                                                        \
+    else                                                                                                        \
+      hipLaunchKernelGGL((scatter_rows_group_kernel<T, LOG2L, HG, HF>), dim3(grid), dim3(256), 0, s,             \
+                         (const uint4*)g_rows, (const uint4*)g_fm, fm_sum, (const uint4*)table, row_start, perm, \
+                         V, N, gbs, padding_row, (uint4*)grad, long_rows, sink);                                 \
     hipLaunchKernelGGL((scatter_long_rows_kernel<T, LOG2L, HG, HF>), dim3(1024), dim3(256), 0, s,                \
                        (const uint4*)g_rows, (const uint4*)g_fm, fm_sum, (const uint4*)table, row_start, perm, N, \
                        gbs, (uint4*)grad, long_rows, scratch, sink);                                                  \
@@ -726,26 +775,30 @@ static void scatter_group_launch(const void* g_rows, const void* g_fm, const flo
   else if (hg) TRS_SC(true, false);
   else TRS_SC(false, true);
 #undef TRS_SC
+  if (g_first != nullptr)
+    hipLaunchKernelGGL((scatter_first_long_kernel<T>), dim3(64), dim3(256), 0, s, (const T*)g_first, row_start, perm,
+                       long_rows, (T*)grad_first);
 }
 
 template <typename T>
 static int scatter_launch(const void* g_rows, const void* g_fm, const float* fm_sum, const void* table,
                           const int32_t* row_start, const int32_t* perm, int64_t V, int E, int N, int64_t gbs,
                           int64_t padding_row, void* grad, int32_t* long_rows, void* tg, float* scratch, int64_t B,
-                          RowSink sink, hipStream_t s) {
+                          RowSink sink, hipStream_t s, const void* g_first = nullptr, void* grad_first = nullptr) {
   const int lg = log2_lanes_sc(E * (int)sizeof(T));
   const bool al = aligned16(g_rows) && aligned16(g_fm) && aligned16(table) && aligned16(grad) && aligned16(fm_sum);
   if (lg >= 0 && al) {
     switch (lg) {
-      case 0: scatter_group_launch<T, 0>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s); break;
-      case 1: scatter_group_launch<T, 1>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s); break;
-      case 2: scatter_group_launch<T, 2>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s); break;
-      case 3: scatter_group_launch<T, 3>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s); break;
-      case 4: scatter_group_launch<T, 4>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s); break;
-      case 5: scatter_group_launch<T, 5>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s); break;
-      default: scatter_group_launch<T, 6>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s); break;
+      case 0: scatter_group_launch<T, 0>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s, g_first, grad_first); break;
+      case 1: scatter_group_launch<T, 1>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s, g_first, grad_first); break;
+      case 2: scatter_group_launch<T, 2>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s, g_first, grad_first); break;
+      case 3: scatter_group_launch<T, 3>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s, g_first, grad_first); break;
+      case 4: scatter_group_launch<T, 4>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s, g_first, grad_first); break;
+      case 5: scatter_group_launch<T, 5>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s, g_first, grad_first); break;
+      default: scatter_group_launch<T, 6>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s, g_first, grad_first); break;
     }
   } else {
+    if (g_first != nullptr) return 1;   // the companion table rides only in the 16-byte-vector walk
     hipLaunchKernelGGL((scatter_rows_elem_kernel<T>), dim3(stream_grid(V * E, 256, 256 * 32)), dim3(256), 0, s,
                        (const T*)g_rows, (const T*)g_fm, fm_sum, (const T*)table, row_start, perm, V, E, N, gbs,
                        padding_row, (T*)grad, long_rows, sink);
@@ -862,7 +915,7 @@ static int scatter_rows_impl(RowSink sink, const void* g_rows, int64_t g_rows_ba
                                 const float* fm_sum, const void* table, const int32_t* row_start,
                                 const int32_t* perm, int64_t BN, int64_t V, int32_t E, int32_t N, int32_t dtype,
                                 int64_t padding_row, void* grad_table, void* workspace, size_t ws_bytes,
-                                trs_stream_t stream) {
+                                trs_stream_t stream, const void* g_first = nullptr, void* grad_first = nullptr) {
   TRS_REQUIRE(row_start && perm && grad_table && workspace, TRS_EINVAL, "scatter_rows: NULL pointer");
   TRS_REQUIRE(g_rows || g_fm, TRS_EINVAL, "scatter_rows: need g_rows and/or g_fm");
   TRS_REQUIRE((fm_sum == nullptr) || (g_fm && table), TRS_EINVAL, "scatter_rows: fm_sum needs g_fm and table");
@@ -879,11 +932,27 @@ static int scatter_rows_impl(RowSink sink, const void* g_rows, int64_t g_rows_ba
   hipStream_t s = (hipStream_t)stream;
   int32_t* long_rows = (int32_t*)workspace;
   if (hipMemsetAsync(long_rows, 0, 4, s) != hipSuccess) return check_launch("scatter_rows(memset)");
+  int rc;
   if (dtype == TRS_F32)
-    return scatter_launch<float>(g_rows, g_fm, fm_sum, table, row_start, perm, V, E, N, gbs, padding_row,
-                                 grad_table, long_rows, tg, scratch, B, sink, s);
-  return scatter_launch<bf16_t>(g_rows, g_fm, fm_sum, table, row_start, perm, V, E, N, gbs, padding_row, grad_table,
-                                long_rows, tg, scratch, B, sink, s);
+    rc = scatter_launch<float>(g_rows, g_fm, fm_sum, table, row_start, perm, V, E, N, gbs, padding_row, grad_table,
+                               long_rows, tg, scratch, B, sink, s, g_first, grad_first);
+  else
+    rc = scatter_launch<bf16_t>(g_rows, g_fm, fm_sum, table, row_start, perm, V, E, N, gbs, padding_row, grad_table,
+                                long_rows, tg, scratch, B, sink, s, g_first, grad_first);
+  if (rc == 1) return fail(TRS_ESHAPE, "scatter_rows_first: rows must be whole 16-byte vectors (E*sizeof %% 16 == 0)");
+  return rc;
+}
+
+/* see include/trs_abi.h: the dense gradients of an embedding table AND of its first-order (E = 1) companion in one walk */
+extern "C" int trs_scatter_rows_first(const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm,
+                                      const float* fm_sum, const void* table, const int32_t* row_start,
+                                      const int32_t* perm, int64_t BN, int64_t V, int32_t E, int32_t N, int32_t dtype,
+                                      int64_t padding_row, void* grad_table, const void* g_first, void* grad_first,
+                                      void* workspace, size_t ws_bytes, trs_stream_t stream) {
+  TRS_REQUIRE(g_first && grad_first, TRS_EINVAL, "scatter_rows_first: NULL first-order pointer");
+  return scatter_rows_impl(RowSink{0, 0.f, 0.f, nullptr}, g_rows, g_rows_batch_stride, g_fm, fm_sum, table, row_start,
+                           perm, BN, V, E, N, dtype, padding_row, grad_table, workspace, ws_bytes, stream, g_first,
+                           grad_first);
 }
 
 extern "C" int trs_scatter_rows(const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm, const float* fm_sum,

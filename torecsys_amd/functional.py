@@ -260,6 +260,23 @@ def scatter_rows(rb: RowBuckets, like_table: torch.Tensor, g_rows: Optional[torc
     return grad
 
 
+def scatter_rows_first(rb: RowBuckets, like_table: torch.Tensor, like_first: torch.Tensor, g_first: torch.Tensor,
+                       g_rows: Optional[torch.Tensor] = None, g_bcast: Optional[torch.Tensor] = None,
+                       fm_sum: Optional[torch.Tensor] = None, padding_row: int = -1
+                       ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Dense gradients of a (V,E) table and of its first-order companion (V,1) in one bucket walk: ``g_first`` holds
+    one value per lookup (B,N[,1]).  See trs_scatter_rows_first in include/trs_abi.h."""
+    V, E = like_table.shape
+    grad = torch.empty_like(like_table)
+    gfirst = torch.empty_like(like_first)
+    ws_bytes = size_query("trs_scatter_workspace_bytes", rb.BN, rb.N, E, value_dtype_code(like_table))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=like_table.device)
+    call("trs_scatter_rows_first", ptr(g_rows), 0, ptr(g_bcast), ptr(fm_sum),
+         ptr(like_table if fm_sum is not None else None), ptr(rb.row_start), ptr(rb.perm), rb.BN, V, E, rb.N,
+         value_dtype_code(like_table), padding_row, ptr(grad), ptr(g_first), ptr(gfirst), ptr(ws), ws_bytes, stream_ptr())
+    return grad, gfirst
+
+
 def scatter_rows_update(rb: RowBuckets, table: torch.Tensor, opt, g_rows: Optional[torch.Tensor] = None,
                         g_bcast: Optional[torch.Tensor] = None, fm_sum: Optional[torch.Tensor] = None,
                         padding_row: int = -1, key=None) -> None:
@@ -372,8 +389,12 @@ def gather_rows(weight: torch.Tensor, idx: torch.Tensor, offsets: Optional[torch
 # K1+K2(+K8): fused lookup + FM (+ first-order sum)
 # --------------------------------------------------------------------------------------------
 class _EmbedFM(Function):
+    """``fields=True``: the first-order output is the per-field tensor (B,N,1) the reference's models consume (one value
+    per lookup, trs_embed_fm_fields) instead of its sum (B,1); the backward then takes both tables' dense gradients from
+    one bucket walk (trs_scatter_rows_first)."""
+
     @staticmethod
-    def forward(ctx, weight, idx, offsets, first_weight, want_emb, opt=None):
+    def forward(ctx, weight, idx, offsets, first_weight, want_emb, opt=None, fields=False):
         require_device(weight, idx, offsets, first_weight)
         B, N = idx.shape
         V, E = weight.shape
@@ -388,16 +409,20 @@ class _EmbedFM(Function):
             if first_weight.dtype != w.dtype or first_weight.numel() != V:
                 raise ValueError("first-order table must be (V,1) with the embedding table's dtype")
             fw = first_weight.contiguous()
-            first = torch.empty(B, 1, dtype=w.dtype, device=dev)
+            first = torch.empty((B, N, 1) if fields else (B, 1), dtype=w.dtype, device=dev)
+        elif fields:
+            raise ValueError("fields=True needs the first-order table")
         flag = _ErrFlag(dev)
-        call("trs_embed_fm", ptr(w), V, E, value_dtype_code(w), ptr(idx), index_dtype_code(idx), ptr(offsets), B, N,
-             ptr(emb), ptr(fm), ptr(fm_sum), ptr(fw), ptr(first), ptr(flag.t), stream_ptr())
+        call("trs_embed_fm_fields" if fields else "trs_embed_fm", ptr(w), V, E, value_dtype_code(w), ptr(idx),
+             index_dtype_code(idx), ptr(offsets), B, N, ptr(emb), ptr(fm), ptr(fm_sum), ptr(fw), ptr(first), ptr(flag.t),
+             stream_ptr())
         flag.check("embed_fm")
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[3]:
             prefetch_row_buckets(idx, offsets, V)
         ctx.save_for_backward(idx, offsets, weight, first_weight, fm_sum)
         ctx.want_emb = want_emb
         ctx.opt = opt
+        ctx.fields = bool(fields)
         ctx.set_materialize_grads(False)   # unused outputs arrive as None, not as zero blocks
         outs = (emb if want_emb else fm.new_empty(0), fm, first if first is not None else fm.new_empty(0))
         if not want_emb:
@@ -410,12 +435,19 @@ class _EmbedFM(Function):
     @once_differentiable
     def backward(ctx, g_emb, g_fm, g_first):
         idx, offsets, weight, first_weight, fm_sum = ctx.saved_tensors
-        V = weight.shape[0]
+        V, E = weight.shape
         rb = row_buckets(idx, offsets, V)
         gw = gfw = None
+        has_emb = ctx.want_emb and g_emb is not None
+        has_fm = g_fm is not None
+        if (ctx.fields and ctx.opt is None and g_first is not None and (has_emb or has_fm)
+                and ctx.needs_input_grad[0] and ctx.needs_input_grad[3] and (E * weight.element_size()) % 16 == 0):
+            gw, gfw = scatter_rows_first(rb, weight, first_weight, g_first.contiguous(),
+                                         g_rows=g_emb.contiguous() if has_emb else None,
+                                         g_bcast=g_fm.contiguous() if has_fm else None,
+                                         fm_sum=fm_sum if has_fm else None)
+            return gw, None, None, gfw, None, None, None
         if ctx.needs_input_grad[0]:
-            has_emb = ctx.want_emb and g_emb is not None
-            has_fm = g_fm is not None
             if has_emb or has_fm:
                 gw = _apply_or_grad(rb, weight, ctx.opt, g_rows=g_emb.contiguous() if has_emb else None,
                                     g_bcast=g_fm.contiguous() if has_fm else None, fm_sum=fm_sum if has_fm else None)
@@ -423,12 +455,15 @@ class _EmbedFM(Function):
                 gw = torch.zeros_like(weight)
         if first_weight is not None and ctx.needs_input_grad[3]:
             if g_first is not None:
-                gfw = _apply_or_grad(rb, first_weight.reshape(V, 1), ctx.opt,
-                                     g_bcast=g_first.contiguous().reshape(-1, 1))
+                if ctx.fields:       # one gradient value per lookup: the E = 1 table's own bucketed scatter
+                    gfw = _apply_or_grad(rb, first_weight.reshape(V, 1), ctx.opt, g_rows=g_first.contiguous())
+                else:
+                    gfw = _apply_or_grad(rb, first_weight.reshape(V, 1), ctx.opt,
+                                         g_bcast=g_first.contiguous().reshape(-1, 1))
                 gfw = None if gfw is None else gfw.reshape(first_weight.shape)
             elif ctx.opt is None:
                 gfw = torch.zeros_like(first_weight)
-        return gw, None, None, gfw, None, None
+        return gw, None, None, gfw, None, None, None
 
 
 def embed_fm(weight: torch.Tensor, idx: torch.Tensor, offsets: Optional[torch.Tensor] = None,
@@ -438,8 +473,19 @@ def embed_fm(weight: torch.Tensor, idx: torch.Tensor, offsets: Optional[torch.Te
     idx = _as_index(idx)
     if idx.dim() != 2:
         raise ValueError(f"indices must be (B, N), got shape {tuple(idx.shape)}")
-    emb, fm, first = _EmbedFM.apply(weight, idx, offsets, first_weight, want_emb, opt)
+    emb, fm, first = _EmbedFM.apply(weight, idx, offsets, first_weight, want_emb, opt, False)
     return (emb if want_emb else None), fm, (first if first_weight is not None else None)
+
+
+def embed_fm_fields(weight: torch.Tensor, first_weight: torch.Tensor, idx: torch.Tensor,
+                    offsets: Optional[torch.Tensor] = None, opt=None
+                    ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """The lookup of an embedding table, the FM term of the looked-up rows and the per-field lookup of the first-order
+    table that shares the indices, in one pass: (emb (B,N,E), fm (B,E), first (B,N,1))."""
+    idx = _as_index(idx)
+    if idx.dim() != 2:
+        raise ValueError(f"indices must be (B, N), got shape {tuple(idx.shape)}")
+    return _EmbedFM.apply(weight, idx, offsets, first_weight, True, opt, True)
 
 
 # --------------------------------------------------------------------------------------------

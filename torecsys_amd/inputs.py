@@ -7,6 +7,7 @@ identical because ``Inputs.forward`` dispatches on them (inputs.py:70,84).
 """
 from __future__ import annotations
 
+import os
 from collections import namedtuple
 from typing import Dict, List, Optional, Union
 
@@ -175,6 +176,14 @@ class ValueInput(BaseInput):
         return inputs
 
 
+# TRS_PAIR_FIRST_ORDER=1: Inputs serves the E = 1 first-order table of an FM-family model from the wide table's lookup
+# kernel and bucket walk (trs_embed_fm_fields / trs_scatter_rows_first) instead of its own two launches.  Off by default:
+# measured on the DeepFM step it is a loss -- the lookup kernel goes from 133 to 162 us and the walk from 176 to 210 us
+# (one more dependent 2-byte access per lookup in the two bandwidth-critical kernels) while the separate E = 1 launches
+# it removes cost 17 + 28 us: 1.62 vs 1.58 ms per step, and the roofline kernel itself gets slower.
+PAIR_FIRST_ORDER = os.environ.get("TRS_PAIR_FIRST_ORDER", "0") == "1"
+
+
 class Inputs(BaseInput):
     """Dictionary router, inputs/inputs.py:56-89: for every schema entry gather its named columns,
     ``unsqueeze`` 1-D ones, ``cat`` on dim 1 and call the embedding module.  Integer columns on the HIP device are
@@ -189,11 +198,55 @@ class Inputs(BaseInput):
             self.add_module(k, emb_fn)
         self.length = None
 
+    def _first_order_partner(self, key: str) -> Optional[str]:
+        """The schema entry whose lookup can ride in ``key``'s kernels: ``key`` is a fuse_fm MultiIndicesEmbedding and
+        the partner a MultiIndicesEmbedding(embed_size=1) over the same columns and the same per-field row layout (the
+        E-wide table and the first-order weights of one FM-family model).  Decided per call: fused optimizers, dtypes
+        and devices can change between steps."""
+        a = self.schema[key]
+        if not PAIR_FIRST_ORDER:
+            return None
+        if type(a) is not MultiIndicesEmbedding or not a.fuse_fm or a.flatten or a.padding_idx is not None:
+            return None
+        if getattr(a, 'fused_optimizer', None) is not None or not a.embedding.weight.is_cuda:
+            return None
+        wa = a.embedding.weight
+        if (wa.shape[1] * wa.element_size()) % 16 != 0:
+            return None
+        for k, f in self.schema.items():
+            if k == key or type(f) is not MultiIndicesEmbedding:
+                continue
+            if (f.embed_size != 1 or f.flatten or f.fuse_fm or f.padding_idx is not None
+                    or getattr(f, 'fused_optimizer', None) is not None):
+                continue
+            wf = f.embedding.weight
+            if (tuple(f.schema.inputs) != tuple(a.schema.inputs) or wf.shape[0] != wa.shape[0] or wf.dtype != wa.dtype
+                    or wf.device != wa.device or wf.requires_grad != wa.requires_grad):
+                continue
+            same = self._same_layout.get((key, k))
+            if same is None:      # one device comparison per pair and process (the offsets are construction-time buffers)
+                same = f.offsets.numel() == a.offsets.numel() and bool(torch.equal(f.offsets, a.offsets))
+                self._same_layout[(key, k)] = same
+            if same:
+                return k
+        return None
+
     def forward(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         outputs = {}
         packed = {}                    # tuple of column names -> packed tensor (shared between schema entries)
+        if not hasattr(self, '_same_layout'):
+            self._same_layout = {}
+        partner = {}                   # first-order entry -> the wide entry that computes it
+        for k in self.schema:
+            p = self._first_order_partner(k)
+            if p is not None and p not in partner:
+                partner[p] = k
         with F_.defer_prefetch():      # row-bucket builds start once every lookup of the batch is enqueued
             for k, emb_fn in self.schema.items():
+                if k in outputs:       # a first-order table already served by its partner's pass
+                    continue
+                if k in partner and partner[k] not in outputs:
+                    continue           # served when its partner runs (below, or later in this loop)
                 if emb_fn.__class__.__name__ in ['ConcatInput', 'StackedInput']:
                     inp_args = [{i: inputs[i] for i in emb_fn.schema.inputs}]
                 else:
@@ -208,8 +261,23 @@ class Inputs(BaseInput):
                             inp = cols[0] if len(cols) == 1 else torch.cat(cols, dim=1)
                         packed[names] = inp
                     inp_args = [inp]
-                outputs[k] = emb_fn(*inp_args)
-        return outputs
+                feat_key = next((f for f, w in partner.items() if w == k), None)
+                if feat_key is not None:
+                    # one lookup pass and one bucket walk for the wide table and its first-order companion
+                    feat_fn = self.schema[feat_key]
+                    idx = inp_args[0].rename(None) if inp_args[0].has_names() else inp_args[0]
+                    if idx.dim() != 2 or idx.shape[1] != emb_fn.offsets.numel():
+                        raise ValueError(f'inputs must be (B, {emb_fn.offsets.numel()}), got {tuple(idx.shape)}')
+                    out, fm, first = F_.embed_fm_fields(emb_fn.embedding.weight, feat_fn.embedding.weight, idx,
+                                                        emb_fn.offsets)
+                    out._trs_fused_fm = (fm, out._version)
+                    out.names = ('B', 'N', 'E',)
+                    first.names = ('B', 'N', 'E',)
+                    outputs[k] = out
+                    outputs[feat_key] = first
+                else:
+                    outputs[k] = emb_fn(*inp_args)
+        return {k: outputs[k] for k in self.schema}      # schema order, as the reference returns it
 
     def add_inputs(self, name: Optional[str] = None, model: Optional[nn.Module] = None,
                    schema: Optional[Dict[str, nn.Module]] = None):
