@@ -187,6 +187,15 @@ int trs_pair_dot_fwd(const void* x, int64_t B, int32_t N, int32_t E, int32_t dty
 int trs_pair_dot_bwd(const void* x, const void* g, int64_t B, int32_t N, int32_t E, int32_t dtype,
                      void* dx, trs_stream_t stream);
 
+/* K7 fused with K1: out[b,p(i,j)] = <row(b,i), row(b,j)> with row(b,n) = table[idx[b,n]+offsets[n], :] read straight from
+ * the embedding table (one wave per sample; an out-of-range id reads as a zero row and sets *err_flag); emb (optional,
+ * may be NULL): the looked-up (B,N,E) block, written on the way for the backward / other consumers.  bf16 tables whose
+ * rows the matrix-core path covers (E % 32 == 0, E <= 128, N <= 64); TRS_ESHAPE otherwise (callers then use
+ * trs_gather_rows + trs_pair_dot_fwd).  Replaces multi_indices_emb.py:104-105 + inner_product_network.py:68-74.   */
+int trs_embed_pair_dot(const void* table, int64_t V, int32_t E, int32_t dtype, const void* idx, int32_t idx_dtype,
+                       const int64_t* offsets, int64_t B, int32_t N, void* emb, void* out, int32_t* err_flag,
+                       trs_stream_t stream);
+
 /* ---- K3: field-aware FM pair products -----------------------------------------------------
  * fwd: out[b,p(i,j),:] = x[b,i*N+j,:] * x[b,j*N+i,:], i<j      x: (B, N*N, E)
  * bwd: dx[b,i*N+j,:] = g[b,p,:]*x[b,j*N+i,:]; dx[b,j*N+i,:] = g[b,p,:]*x[b,i*N+j,:]; diagonal 0

@@ -251,6 +251,62 @@ def test_inputs_pairs_first_order_table_with_wide_table(dev, monkeypatch):
         assert rel_err(res[k][2], res[2][2]) <= TOLBF and rel_err(res[k][3], res[2][3]) <= TOLBF
 
 
+@pytest.mark.parametrize("B,N,E,Vf,zipf", [(1024, 10, 32, 100, False), (777, 39, 64, 50, False),
+                                           (4096, 39, 64, 7, True), (300, 17, 128, 9, False), (64, 2, 64, 4, False)])
+def test_embed_ipn_vs_oracle(dev, B, N, E, Vf, zipf):
+    """trs_embed_pair_dot (K7 fused with K1): inner products straight from the table rows, the block written on the way;
+    values against the oracle's lookup + inner-product network, table gradient against autograd over the oracle;
+    without the block (inference) the same products."""
+    from torecsys_amd import functional as F_
+    dtype = torch.bfloat16
+    fs, idx, w, _, g = _rand_case(B, N, E, Vf, 277 + B + N + E, dtype, zipf)
+    off = O.field_offsets(fs)
+    wr = w.float().clone().requires_grad_()
+    emb_r = O.multi_indices_embedding(wr, idx, off)
+    ipn_r = O.inner_product_layer(emb_r)
+    P = N * (N - 1) // 2
+    ge = torch.randn(B, N, E, generator=g).to(dtype)
+    gp = torch.randn(B, P, generator=g).to(dtype)
+    ((emb_r * ge.float()).sum() + (ipn_r * gp.float()).sum()).backward()
+    assert F_.embed_ipn_supported(w.to(dev), N)
+    wd = w.to(dev).requires_grad_()
+    emb, ipn = F_.embed_ipn(wd, idx.to(dev), off.to(dev))
+    assert torch.equal(emb.cpu(), emb_r.detach().to(dtype))                  # the lookup is bit-exact
+    assert rel_err(ipn.float().cpu(), ipn_r.detach()) <= TOLBF
+    ((emb.float() * ge.to(dev).float()).sum() + (ipn.float() * gp.to(dev).float()).sum()).backward()
+    assert rel_err(wd.grad.float().cpu(), wr.grad) <= 2 * TOLBF              # two bf16 roundings: dx, then the row sums
+    with torch.no_grad():
+        none, ipn2 = F_.embed_ipn(w.to(dev), idx.to(dev), off.to(dev), want_emb=False)
+    assert none is None and torch.equal(ipn2, ipn.detach())
+    # an out-of-range id reads as a zero row and is reported
+    bad = idx.clone()
+    bad[0, 0] = fs[0] + 10 ** 6
+    with torch.no_grad():
+        _, ipn3 = F_.embed_ipn(w.to(dev), bad.to(dev), off.to(dev), want_emb=False)
+    assert float(ipn3[0, :N - 1].float().abs().max()) == 0.0 and F_.index_errors_seen()
+
+
+def test_fused_ipn_side_channel(dev):
+    """MultiIndicesEmbedding(fuse_ipn=True) hands the inner products to InnerProductNetworkLayer without a second pass;
+    results and gradients equal the unfused modules (fp32 tables fall back to the plain lookup)."""
+    from torecsys_amd.inputs import MultiIndicesEmbedding
+    from torecsys_amd.layers import InnerProductNetworkLayer
+    fs, idx, w, _, g = _rand_case(512, 12, 32, 20, 15, torch.bfloat16)
+    outs = []
+    for fuse in (False, True):
+        m = MultiIndicesEmbedding(embed_size=32, field_sizes=fs, fuse_ipn=fuse).to(dev).to(torch.bfloat16)
+        m.embedding.weight.data.copy_(w)
+        emb = m(idx.to(dev))
+        assert hasattr(emb, "_trs_fused_ipn") == fuse
+        y = InnerProductNetworkLayer(num_fields=12)(emb)
+        (y.rename(None).float().sum() + (emb.rename(None).float() ** 2).sum()).backward()
+        outs.append((y.rename(None).detach().float().cpu(), m.embedding.weight.grad.float().cpu()))
+    assert rel_err(outs[1][0], outs[0][0]) <= TOLBF
+    assert rel_err(outs[1][1], outs[0][1]) <= TOLBF
+    m32 = MultiIndicesEmbedding(embed_size=32, field_sizes=fs, fuse_ipn=True).to(dev)
+    assert not hasattr(m32(idx.to(dev)), "_trs_fused_ipn")
+
+
 def test_fused_fm_side_channel(dev):
     """MultiIndicesEmbedding(fuse_fm=True) hands the FM term to FMLayer without a second pass; results and
     gradients equal the unfused modules."""

@@ -117,6 +117,14 @@ def main():
         gy = torch.randn_like(y)
         t = timeit(lambda: torch.autograd.grad(y, x, gy, retain_graph=True), iters=10)
         report("pair_dot_bwd", t, 2 * B * N * E * s + B * (N * (N - 1) // 2) * s)
+        Pn = N * (N - 1) // 2
+        with torch.no_grad():
+            t = timeit(lambda: F_.gather_rows(w, idx, off), iters=10)
+            t2 = timeit(lambda: F_.embed_ipn(w, idx, off, want_emb=True), iters=10)
+            report("gather_rows alone (for comparison)", t, B * N * (8 + 2 * E * s))
+            report("embed_ipn (lookup + inner products, block written)", t2, B * N * (8 + 2 * E * s) + B * Pn * s)
+            t3 = timeit(lambda: F_.embed_ipn(w, idx, off, want_emb=False), iters=10)
+            report("embed_ipn (no block: inference)", t3, B * N * (8 + E * s) + B * Pn * s)
     if want("pairx"):
         from torecsys_amd.layers import (AttentionalFactorizationMachineLayer, BilinearInteractionLayer,
                                          OuterProductNetworkLayer)

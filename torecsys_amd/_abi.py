@@ -78,6 +78,7 @@ SIGNATURES = {
     "trs_fm_fwd": (c_int32, [_P, _I64, _I32, _I32, _I32, _P, _P, _P]),
     "trs_fm_bwd": (c_int32, [_P, _P, _P, _I64, _I32, _I32, _I32, _P, _P]),
     "trs_pair_dot_fwd": (c_int32, [_P, _I64, _I32, _I32, _I32, _P, _P]),
+    "trs_embed_pair_dot": (c_int32, [_P, _I64, _I32, _I32, _P, _I32, _P, _I64, _I32, _P, _P, _P, _P]),
     "trs_pair_dot_bwd": (c_int32, [_P, _P, _I64, _I32, _I32, _I32, _P, _P]),
     "trs_ffm_fwd": (c_int32, [_P, _I64, _I32, _I32, _I32, _P, _P]),
     "trs_ffm_bwd": (c_int32, [_P, _P, _I64, _I32, _I32, _I32, _P, _P]),

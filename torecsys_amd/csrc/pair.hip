@@ -226,9 +226,17 @@ __global__ __launch_bounds__(256) void pair_dot_bwd_generic(const T* __restrict_
 typedef __attribute__((ext_vector_type(8))) __bf16 pd_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float pd_f32x4;
 
-template <int NT, int KS>
+// GATHER: the rows come straight from the embedding table (K7 fused with K1: row id = idx[b,n] + offsets[n], an
+// out-of-range id reads as a zero row and raises err_flag), and -- when ``emb`` is given -- the looked-up block is written
+// on the way (the fragments a lane holds are exactly its 16-byte pieces of the rows), so the (B,N,E) block is neither
+// written first and read back nor, at inference, written at all.
+template <int NT, int KS, bool GATHER = false, typename IdxT = int64_t>
 __global__ __launch_bounds__(256) void pair_dot_fwd_mfma_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out,
-                                                                int64_t B, int N, int E) {
+                                                                int64_t B, int N, int E,
+                                                                const IdxT* __restrict__ idx = nullptr,
+                                                                const int64_t* __restrict__ offsets = nullptr,
+                                                                int64_t V = 0, bf16_t* __restrict__ emb = nullptr,
+                                                                int32_t* __restrict__ err_flag = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, r = lane & 15;
   const int P = N * (N - 1) / 2;
@@ -239,14 +247,46 @@ __global__ __launch_bounds__(256) void pair_dot_fwd_mfma_kernel(const bf16_t* __
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t b = wid; b < B; b += nwaves) {
     uint4 F[NT][KS];
+    int64_t rid[NT];
+    if (GATHER) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int row = 16 * t + r;
+        rid[t] = -1;
+        if (row < N) {
+          rid[t] = load_row_id(idx, offsets, b * N + row, row);
+          if (rid[t] < 0 || rid[t] >= V) {
+            if (err_flag != nullptr) *err_flag = 1;
+            rid[t] = -1;
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int row = 16 * t + r;
         F[t][ks] = make_uint4(0, 0, 0, 0);
-        if (row < N) F[t][ks] = *reinterpret_cast<const uint4*>(x + (b * N + row) * (int64_t)E + 32 * ks + 8 * q);
+        if (GATHER) {
+          if (rid[t] >= 0) F[t][ks] = *reinterpret_cast<const uint4*>(x + rid[t] * (int64_t)E + 32 * ks + 8 * q);
+        } else if (row < N) {
+          F[t][ks] = *reinterpret_cast<const uint4*>(x + (b * N + row) * (int64_t)E + 32 * ks + 8 * q);
+        }
       }
+    if (GATHER && emb != nullptr) {
+      typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int row = 16 * t + r;
+          if (row < N) {
+            const u32x4 w = {F[t][ks].x, F[t][ks].y, F[t][ks].z, F[t][ks].w};
+            __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(emb + (b * N + row) * (int64_t)E + 32 * ks + 8 * q));
+          }
+        }
+    }
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
@@ -395,6 +435,32 @@ static int pair_dot_fwd_mfma(const void* x, void* out, int64_t B, int N, int E, 
 #undef TRS_PF_K
 #undef TRS_PF
   return check_launch("pair_dot_fwd(mfma)");
+}
+
+template <typename IdxT>
+static int embed_pair_dot_mfma(const void* table, const IdxT* idx, const int64_t* offsets, int64_t V, void* emb, void* out,
+                               int32_t* err_flag, int64_t B, int N, int E, hipStream_t s) {
+  const int NT = (N + 15) / 16, KS = E / 32;
+  const int grid = (int)std::min<int64_t>((B + 3) / 4, 256 * 8);
+  const size_t lds_f = (size_t)4 * (((N * (N - 1) / 2) + 7) & ~7) * 2;
+#define TRS_PG(NT_, KS_)                                                                                           \
+  hipLaunchKernelGGL((pair_dot_fwd_mfma_kernel<NT_, KS_, true, IdxT>), dim3(grid), dim3(256), lds_f, s,             \
+                     (const bf16_t*)table, (bf16_t*)out, B, N, E, idx, offsets, V, (bf16_t*)emb, err_flag)
+#define TRS_PG_K(NT_)               \
+  do {                              \
+    if (KS == 1) TRS_PG(NT_, 1);    \
+    else if (KS == 2) TRS_PG(NT_, 2); \
+    else TRS_PG(NT_, 4);            \
+  } while (0)
+  switch (NT) {
+    case 1: TRS_PG_K(1); break;
+    case 2: TRS_PG_K(2); break;
+    case 3: TRS_PG_K(3); break;
+    default: TRS_PG_K(4); break;
+  }
+#undef TRS_PG_K
+#undef TRS_PG
+  return check_launch("embed_pair_dot");
 }
 
 static int pair_dot_bwd_mfma(const void* x, const void* g, void* dx, int64_t B, int N, int E, hipStream_t s) {
@@ -657,6 +723,23 @@ extern "C" int trs_pair_dot_fwd(const void* x, int64_t B, int32_t N, int32_t E, 
   if (dtype == TRS_F32) return pair_dot_fwd_launch<float>(x, out, B, N, E, (hipStream_t)stream);
   if (pair_mfma_ok(N, E) && aligned16(x)) return pair_dot_fwd_mfma(x, out, B, N, E, (hipStream_t)stream);
   return pair_dot_fwd_launch<bf16_t>(x, out, B, N, E, (hipStream_t)stream);
+}
+
+/* see include/trs_abi.h: the inner-product network straight from the embedding table (K7 fused with K1) */
+extern "C" int trs_embed_pair_dot(const void* table, int64_t V, int32_t E, int32_t dtype, const void* idx,
+                                  int32_t idx_dtype, const int64_t* offsets, int64_t B, int32_t N, void* emb, void* out,
+                                  int32_t* err_flag, trs_stream_t stream) {
+  if (B == 0) return TRS_OK;
+  TRS_REQUIRE(table && idx && (out || N < 2), TRS_EINVAL, "embed_pair_dot: NULL pointer");
+  TRS_REQUIRE(V > 0 && E > 0 && N > 0, TRS_EINVAL, "embed_pair_dot: bad size");
+  TRS_REQUIRE(idx_dtype == TRS_I64 || idx_dtype == TRS_I32, TRS_EDTYPE, "embed_pair_dot: idx dtype %d", idx_dtype);
+  if (dtype != TRS_BF16 || !pair_mfma_ok(N, E) || N < 2 || !aligned16(table) || !aligned16(emb))
+    return fail(TRS_ESHAPE, "embed_pair_dot: needs bf16 rows the matrix-core path covers (use gather_rows + pair_dot_fwd)");
+  if (idx_dtype == TRS_I64)
+    return embed_pair_dot_mfma<int64_t>(table, (const int64_t*)idx, offsets, V, emb, out, err_flag, B, N, E,
+                                        (hipStream_t)stream);
+  return embed_pair_dot_mfma<int32_t>(table, (const int32_t*)idx, offsets, V, emb, out, err_flag, B, N, E,
+                                      (hipStream_t)stream);
 }
 
 extern "C" int trs_pair_dot_bwd(const void* x, const void* g, int64_t B, int32_t N, int32_t E, int32_t dtype,

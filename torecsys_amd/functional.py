@@ -612,6 +612,71 @@ def pair_dot(x: torch.Tensor) -> torch.Tensor:
     return _PairDot.apply(x)
 
 
+def embed_ipn_supported(weight: torch.Tensor, N: int) -> bool:
+    """the lookup + inner-product kernel covers bf16 tables whose rows the matrix-core pair kernel covers"""
+    return (weight.is_cuda and weight.dtype == torch.bfloat16 and weight.dim() == 2 and weight.shape[1] in (32, 64, 128)
+            and 2 <= N <= 64)
+
+
+class _EmbedIPN(Function):
+    """K7 fused with K1 (trs_embed_pair_dot): (emb (B,N,E), ipn (B,NC2)) in one pass over the table rows.  The block is
+    written only when someone needs it: the caller (``want_emb``) or the backward (it is the ``x`` of trs_pair_dot_bwd);
+    at inference with ``want_emb=False`` the (B,N,E) block never exists."""
+
+    @staticmethod
+    def forward(ctx, weight, idx, offsets, want_emb, opt=None):
+        require_device(weight, idx, offsets)
+        B, N = idx.shape
+        V, E = weight.shape
+        w = weight.contiguous()
+        need_block = want_emb or ctx.needs_input_grad[0]
+        emb = torch.empty(B, N, E, dtype=w.dtype, device=w.device) if need_block else None
+        out = torch.empty(B, N * (N - 1) // 2, dtype=w.dtype, device=w.device)
+        flag = _ErrFlag(w.device)
+        call("trs_embed_pair_dot", ptr(w), V, E, value_dtype_code(w), ptr(idx), index_dtype_code(idx), ptr(offsets), B, N,
+             ptr(emb), ptr(out), ptr(flag.t), stream_ptr())
+        flag.check("embed_pair_dot")
+        if ctx.needs_input_grad[0]:
+            prefetch_row_buckets(idx, offsets, V)
+        ctx.save_for_backward(idx, offsets, weight, emb if ctx.needs_input_grad[0] else None)
+        ctx.want_emb = want_emb
+        ctx.opt = opt
+        ctx.set_materialize_grads(False)
+        if not want_emb:
+            blk = out.new_empty(0)
+            ctx.mark_non_differentiable(blk)
+            return blk, out
+        return emb, out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_emb, g_out):
+        idx, offsets, weight, emb = ctx.saved_tensors
+        V, E = weight.shape
+        B, N = idx.shape
+        g_rows = None
+        if g_out is not None:
+            g_rows = torch.empty_like(emb)
+            call("trs_pair_dot_bwd", ptr(emb), ptr(g_out.contiguous()), B, N, E, value_dtype_code(emb), ptr(g_rows),
+                 stream_ptr())
+        if ctx.want_emb and g_emb is not None:
+            g_rows = g_emb.contiguous() if g_rows is None else g_rows.add_(g_emb)
+        if g_rows is None:
+            return (torch.zeros_like(weight) if ctx.opt is None else None), None, None, None, None
+        rb = row_buckets(idx, offsets, V)
+        return _apply_or_grad(rb, weight, ctx.opt, g_rows=g_rows), None, None, None, None
+
+
+def embed_ipn(weight: torch.Tensor, idx: torch.Tensor, offsets: Optional[torch.Tensor] = None, want_emb: bool = True,
+              opt=None) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
+    """Lookup + inner-product network in one kernel: (emb (B,N,E) | None, ipn (B, N(N-1)/2))."""
+    idx = _as_index(idx)
+    if idx.dim() != 2:
+        raise ValueError(f"indices must be (B, N), got shape {tuple(idx.shape)}")
+    emb, out = _EmbedIPN.apply(weight, idx, offsets, want_emb, opt)
+    return (emb if want_emb else None), out
+
+
 # --------------------------------------------------------------------------------------------
 # F4 glue: BatchNorm1d + ReLU + direct/hidden split + pooled sum on channels-last CIN activations
 # --------------------------------------------------------------------------------------------

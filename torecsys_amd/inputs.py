@@ -89,11 +89,12 @@ class MultiIndicesEmbedding(BaseInput):
     ``offsets`` is a non-persistent buffer (same ``state_dict`` as the reference -- only
     ``embedding.weight`` -- but it follows ``.to()``).  With ``fuse_fm=True`` the lookup
     kernel also produces the FM second-order term of the same rows and leaves it on the returned tensor
-    for ``FactorizationMachineLayer`` to pick up (one pass over the rows instead of two)."""
+    for ``FactorizationMachineLayer`` to pick up (one pass over the rows instead of two); ``fuse_ipn=True`` does the
+    same for ``InnerProductNetworkLayer`` (bf16 tables the matrix-core pair kernel covers; plain lookup otherwise)."""
 
     def __init__(self, embed_size: Optional[int] = None, field_sizes: Optional[List[int]] = None,
                  nn_embedding: Optional[nn.Parameter] = None, device: str = 'cpu',
-                 flatten: Optional[bool] = False, fuse_fm: bool = False, **kwargs):
+                 flatten: Optional[bool] = False, fuse_fm: bool = False, fuse_ipn: bool = False, **kwargs):
         super().__init__()
         _check_embedding_kwargs(kwargs)
         if nn_embedding is not None:
@@ -107,6 +108,7 @@ class MultiIndicesEmbedding(BaseInput):
         self.register_buffer('offsets', field_offsets(field_sizes), persistent=False)
         self.flatten = flatten
         self.fuse_fm = fuse_fm
+        self.fuse_ipn = fuse_ipn
         self.field_size = self.embedding.num_embeddings
         self.embed_size = self.embedding.embedding_dim
         self.padding_idx = self.embedding.padding_idx
@@ -120,6 +122,10 @@ class MultiIndicesEmbedding(BaseInput):
         if self.fuse_fm and not self.flatten:
             out, fm, _ = F_.embed_fm(self.embedding.weight, idx, self.offsets, opt=self.fused_optimizer)
             out._trs_fused_fm = (fm, out._version)
+        elif (self.fuse_ipn and not self.flatten and self.padding_idx is None
+              and F_.embed_ipn_supported(self.embedding.weight, idx.shape[1])):
+            out, ipn = F_.embed_ipn(self.embedding.weight, idx, self.offsets, opt=self.fused_optimizer)
+            out._trs_fused_ipn = (ipn, out._version)
         else:
             out = F_.gather_rows(self.embedding.weight, idx, self.offsets, self.padding_idx, self.fused_optimizer)
         if self.flatten:

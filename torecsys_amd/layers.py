@@ -120,7 +120,11 @@ class InnerProductNetworkLayer(BaseLayer):
         x = _strip(emb_inputs)
         if x.dim() == 3 and x.shape[1] != self.num_fields:
             raise ValueError(f'expected {self.num_fields} fields, got {x.shape[1]}')
-        outputs = F_.pair_dot(x)
+        fused = getattr(emb_inputs, '_trs_fused_ipn', None)
+        if fused is not None and fused[1] == emb_inputs._version:
+            outputs = fused[0]            # produced by the lookup kernel in the same pass over the rows
+        else:
+            outputs = F_.pair_dot(x)
         outputs.names = ('B', 'O')
         return outputs
 
