@@ -377,7 +377,10 @@ int trs_cin_glue_bwd_apply(const void* y, const void* g_hidden, const void* g_po
                            trs_stream_t stream);
 /* The same two passes, also writing their output channels-first: hidden_cf (B, C-Hs, E), gy_cf (B, C, E) -- the
  * operand layout of trs_cin_dw, which otherwise costs one transposing copy of a 1-2 GB tensor per layer and step.
- * Shape limit: E == 8 * (256 / (C / 8)) (e.g. E = 64, C = 256); trs_cin_glue_cf_supported() tells.                 */
+ * Shape limit: E == 8 * (256 / (C / 8)) (e.g. E = 64, C = 256); trs_cin_glue_cf_supported() tells.
+ * colsum_partial (optional, may be NULL): [trs_cin_glue_blocks(B)][C] fp32 per-workgroup column sums of gy as stored
+ * -- the Conv1d bias gradient of the layer (compress_interaction_network.py:62), which otherwise costs one more pass
+ * over the 2 GB tensor.                                                                                             */
 int trs_cin_glue_cf_supported(int32_t E, int32_t C);
 int trs_cin_glue_fwd_cf(const void* y, const float* scale, const float* shift, int64_t B, int32_t E, int32_t C,
                         int32_t D, int32_t Hs, int32_t dtype, void* hidden, void* hidden_cf, void* pooled,
@@ -385,7 +388,7 @@ int trs_cin_glue_fwd_cf(const void* y, const float* scale, const float* shift, i
 int trs_cin_glue_bwd_apply_cf(const void* y, const void* g_hidden, const void* g_pooled, const float* scale,
                               const float* shift, const float* mean, const float* invstd, const float* c1,
                               const float* c2, int64_t B, int32_t E, int32_t C, int32_t D, int32_t Hs, int32_t dtype,
-                              void* gy, void* gy_cf, trs_stream_t stream);
+                              void* gy, void* gy_cf, float* colsum_partial, trs_stream_t stream);
 
 /* ---- OuterProductNetwork / BilinearInteraction on the (i<j) pair pattern -------
  * Pair p = (i_p, j_p), i<j, lexicographic (the order of inner_product_network.py:51-52); NC2 = N(N-1)/2.

@@ -37,7 +37,8 @@ SIGNATURES = {
     "trs_cin_glue_bwd_apply": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "trs_cin_glue_cf_supported": (c_int32, [_I32, _I32]),
     "trs_cin_glue_fwd_cf": (c_int32, [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P]),
-    "trs_cin_glue_bwd_apply_cf": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _P]),
+    "trs_cin_glue_bwd_apply_cf": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _P,
+                                            _P]),
     "trs_opn_vec_fwd": (c_int32, [_P, _P, _I32, _I64, _I32, _I32, _I32, _P, _P]),
     "trs_opn_vec_bwd_workspace_bytes": (_SZ, [_I64, _I32, _I32]),
     "trs_opn_vec_bwd": (c_int32, [_P, _P, _P, _I32, _I64, _I32, _I32, _I32, _P, _P, _P, _SZ, _P]),

@@ -277,9 +277,12 @@ __global__ __launch_bounds__(GLUE_THREADS) void glue_bwd_apply_cf_kernel(
     const bf16_t* __restrict__ y, const bf16_t* __restrict__ g_hidden, const bf16_t* __restrict__ g_pooled,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ c1, const float* __restrict__ c2, int64_t B, int E, int C,
-    int D, int Hs, bf16_t* __restrict__ gy, bf16_t* __restrict__ gy_cf) {
+    int D, int Hs, bf16_t* __restrict__ gy, bf16_t* __restrict__ gy_cf, float* __restrict__ colsum_partial) {
   const GlueIdx g = glue_idx(C);
   float a[8], sh[8], mu[8], is[8], k1[8], k2[8];
+  float cs[8];                       // column sums of gy (the conv-bias gradient), folded into this pass
+#pragma unroll
+  for (int k = 0; k < 8; ++k) cs[k] = 0.f;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     a[k] = scale[g.c0 + k]; sh[k] = shift[g.c0 + k]; mu[k] = mean[g.c0 + k]; is[k] = invstd[g.c0 + k];
@@ -313,7 +316,14 @@ __global__ __launch_bounds__(GLUE_THREADS) void glue_bwd_apply_cf_kernel(
         const float m = fmaf(x[k], a[k], sh[k]) > 0.f ? t[j][k] : 0.f;
         t[j][k] = a[k] * (m - k1[k] - (x[k] - mu[k]) * is[k] * k2[k]);
       }
-      out[(int64_t)(e0 + j) * g.vpr + g.v] = Vec16<bf16_t>::pack(t[j]);
+      const uint4 pk = Vec16<bf16_t>::pack(t[j]);
+      out[(int64_t)(e0 + j) * g.vpr + g.v] = pk;
+      if (colsum_partial != nullptr) {        // sums of the values as stored (bf16), like a pass over gy would see them
+        float rv[8];
+        Vec16<bf16_t>::unpack(pk, rv);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cs[k] += rv[k];
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -328,6 +338,13 @@ __global__ __launch_bounds__(GLUE_THREADS) void glue_bwd_apply_cf_kernel(
         dst[i] = *reinterpret_cast<const uint4*>(tile + ch * TS + ((ve ^ ((ch >> 3) & (vpe - 1))) << 3));
       }
     }
+  }
+  if (colsum_partial != nullptr) {
+    float o[8];
+    glue_block_reduce(lds, g, C, cs, o);     // begins with a barrier: every reader of the tile is done
+    if (g.rr == 0)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) colsum_partial[(size_t)blockIdx.x * C + g.c0 + k] = o[k];
   }
 }
 
@@ -426,7 +443,8 @@ extern "C" int trs_cin_glue_fwd_cf(const void* y, const float* scale, const floa
 extern "C" int trs_cin_glue_bwd_apply_cf(const void* y, const void* g_hidden, const void* g_pooled, const float* scale,
                                          const float* shift, const float* mean, const float* invstd, const float* c1,
                                          const float* c2, int64_t B, int32_t E, int32_t C, int32_t D, int32_t Hs,
-                                         int32_t dtype, void* gy, void* gy_cf, trs_stream_t stream) {
+                                         int32_t dtype, void* gy, void* gy_cf, float* colsum_partial,
+                                         trs_stream_t stream) {
   TRS_GLUE_COMMON("cin_glue_bwd_apply_cf");
   TRS_REQUIRE(glue_cf_ok(C, E), TRS_ESHAPE, "cin_glue_bwd_apply_cf: needs E == 8 * (256 / (C / 8)) (E = %d, C = %d)", E,
               C);
@@ -435,9 +453,10 @@ extern "C" int trs_cin_glue_bwd_apply_cf(const void* y, const void* g_hidden, co
               "cin_glue_bwd_apply_cf: NULL pointer");
   TRS_REQUIRE(aligned16(y) && aligned16(g_hidden) && aligned16(g_pooled) && aligned16(gy) && aligned16(gy_cf), TRS_EALIGN,
               "cin_glue_bwd_apply_cf: alignment");
-  hipLaunchKernelGGL(glue_bwd_apply_cf_kernel, dim3(glue_grid(B)), dim3(GLUE_THREADS), (size_t)C * (E + 8) * 2,
-                     (hipStream_t)stream,
+  // the LDS tile [C][E+8] bf16 is also the scratch of the final column-sum reduction ([rows per pass][C] fp32)
+  const size_t lds = std::max((size_t)C * (E + 8) * 2, (size_t)(GLUE_THREADS / (C / 8)) * C * 4);
+  hipLaunchKernelGGL(glue_bwd_apply_cf_kernel, dim3(glue_grid(B)), dim3(GLUE_THREADS), lds, (hipStream_t)stream,
                      (const bf16_t*)y, (const bf16_t*)g_hidden, (const bf16_t*)g_pooled, scale, shift, mean, invstd, c1, c2,
-                     B, E, C, D, Hs, (bf16_t*)gy, (bf16_t*)gy_cf);
+                     B, E, C, D, Hs, (bf16_t*)gy, (bf16_t*)gy_cf, colsum_partial);
   return check_launch("cin_glue_bwd_apply_cf");
 }

@@ -772,9 +772,11 @@ class _CINGlue(Function):
         gy = torch.empty_like(yT)
         if size_query("trs_cin_glue_cf_supported", E, C):
             gy_cf = torch.empty(B, C, E, dtype=yT.dtype, device=dev)      # (B,C,E) copy for trs_cin_dw, see forward
+            csum = torch.empty(nblk, C, dtype=torch.float32, device=dev)   # column sums of gy: the conv-bias gradient
             call("trs_cin_glue_bwd_apply_cf", ptr(yT), ptr(gh), ptr(gp), ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
-                 ptr(c1), ptr(c2), B, E, C, D, Hs, value_dtype_code(yT), ptr(gy), ptr(gy_cf), stream_ptr())
+                 ptr(c1), ptr(c2), B, E, C, D, Hs, value_dtype_code(yT), ptr(gy), ptr(gy_cf), ptr(csum), stream_ptr())
             gy._trs_cf = gy_cf
+            gy._trs_colsum = (csum, gy._version)
         else:
             call("trs_cin_glue_bwd_apply", ptr(yT), ptr(gh), ptr(gp), ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
                  ptr(c1), ptr(c2), B, E, C, D, Hs, value_dtype_code(yT), ptr(gy), stream_ptr())
@@ -1279,8 +1281,11 @@ class _CINContractCL(Function):
         dev = x0T.device
         ld0, ldk = x0T.shape[2], xkT.stride(1)
         db = None
+        pre = getattr(gyT, '_trs_colsum', None)    # column sums emitted by the glue backward that produced gyT
         if need_b and bdt is not None:
-            if cin_glue_supported(gyT, 0, 0):
+            if pre is not None and pre[1] == gyT._version:
+                db = pre[0].double().sum(0).to(bdt)
+            elif cin_glue_supported(gyT, 0, 0):
                 # column sums of the (B,E,C) gradient by the glue statistics kernel (one bf16 read, fp32 partials)
                 nblk = size_query("trs_cin_glue_blocks", B)
                 part = torch.empty(nblk, 2, C, dtype=torch.float32, device=gyT.device)
