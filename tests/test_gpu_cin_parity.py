@@ -77,7 +77,7 @@ def _device_f64(x0, xk, W, bias, gy, same, chunk=128):
 
 @pytest.mark.parametrize("B,N,H,C,E", [(4096, 39, 39, 256, 64), (4096, 39, 128, 256, 64), (1001, 10, 10, 64, 32),
                                        (1001, 10, 32, 128, 32), (515, 6, 6, 64, 16), (515, 6, 64, 32, 16),
-                                       (130, 40, 64, 32, 128), (262, 26, 256, 64, 32)],
+                                       (130, 40, 64, 32, 128), (262, 26, 256, 64, 32), (96, 64, 64, 64, 64)],
                          ids=lambda v: str(v))
 def test_cin_contraction_kernels_alone(dev, B, N, H, C, E):
     """BASELINE shapes plus the narrow ones (one or two 16-pixel tiles per wave, partial last step, short samples)."""
@@ -100,7 +100,8 @@ def test_cin_contraction_kernels_alone(dev, B, N, H, C, E):
     gd = torch.autograd.grad(yT, ins, gyT, retain_graph=True)
     dx0 = gd[0].detach()[:, :, :N].transpose(1, 2).float()                          # (B,N,E); x0 == xk: the sum of both
     dxk = None if same else gd[1].detach()[:, :, :H].transpose(1, 2).float()
-    assert float(gd[0][:, :, N:].float().abs().max()) == 0.0                        # padding columns get no gradient
+    if gd[0].shape[2] > N:
+        assert float(gd[0][:, :, N:].float().abs().max()) == 0.0                    # padding columns get no gradient
     dW, db = torch.autograd.grad(yT, (Wd, bd), gyT, retain_graph=True)
     torch.cuda.synchronize()
 

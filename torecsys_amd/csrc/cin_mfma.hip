@@ -571,7 +571,7 @@ int cin_cl_bwd_data(const void* x0T, int ld0, const void* xkT, int ldk, const vo
       ldk < 32 * KSH || ldo < 32 * KSH || ldo % 8 != 0 || workspace == nullptr)
     return 1;
   if (ws_bytes < cin_mfma_bwd_data_workspace_bytes(N, H, C)) return fail(TRS_EWORKSPACE, "cin_cl_bwd_data: workspace");
-  const int P = E % 64 == 0 ? 4 : (E % 32 == 0 ? 2 : 1);
+  int P = E % 64 == 0 ? 4 : (E % 32 == 0 ? 2 : 1);
   // C = 256: two passes of 128 channels (one pass with 512-register waves and four waves per workgroup measured 1.06 vs
   // 0.93 ms: the accumulators end up in AGPRs and are copied out for every VALU use)
   const int KC = KCT == 8 ? 4 : KCT;
@@ -583,6 +583,7 @@ int cin_cl_bwd_data(const void* x0T, int ld0, const void* xkT, int ldk, const vo
   };
   int NS = 1;
   const size_t cap = 156 * 1024;
+  while (P > 1 && lds_for(1) > cap) P >>= 1;     // many fields: the per-wave x0 / dx0 arrays (N x 16 P x 6 bytes) must fit
   if ((N + 2) / 3 * 3 <= (N + 1) / 2 * 2 && lds_for(3) <= cap && KC <= 4) NS = 3;
   else if (lds_for(2) <= cap) NS = 2;
   const size_t lds = lds_for(NS);
