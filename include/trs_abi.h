@@ -353,6 +353,10 @@ int trs_wgrad_finish(const float* part, int32_t S, int32_t R, int32_t Cc, int32_
  * gw[r, c] = sum_s part[s, c, r] for r < out_rows <= R, c < out_cols <= Cc.                                          */
 int trs_wgrad_finish_t(const float* part, int32_t S, int32_t Cc, int32_t R, int32_t out_rows, int32_t out_cols,
                        int32_t dtype, void* gw, const float* gb_f32, void* gb, trs_stream_t stream);
+/* n strided 2-D copies in one launch: desc (device, n x 6 int64) = {src address, dst address, rows, cols, src_ld,
+ * dst_ld} (sizes in elements of elem_size bytes); max_elems = the largest rows*cols (sizes the grid).  Refreshes the
+ * zero-padded copies of an MLP stack's nn.Linear parameters (multilayer_perceptron.py:55-61) before a forward.     */
+int trs_copy_padded_many(const int64_t* desc, int32_t n, int32_t elem_size, int64_t max_elems, trs_stream_t stream);
 
 /* ---- CIN layer glue on channels-last activations y (B,E,C) bf16 ---------------------------------
  * BatchNorm1d + ReLU + chunk(2) + sum over E of the direct half, compress_interaction_network.py:137-181:

@@ -457,3 +457,45 @@ extern "C" int trs_wgrad_finish_t(const float* part, int32_t S, int32_t Cc, int3
                        (bf16_t*)gw, gb_f32, (bf16_t*)gb);
   return check_launch("wgrad_finish_t");
 }
+
+// ------------------------------------------------------------------------------------------------
+// several strided 2-D copies in ONE launch: desc[k] = {src, dst, rows, cols, src_ld, dst_ld} (addresses as int64,
+// sizes in elements).  The padded copies of an MLP stack's weights and biases (8 tensors of 1 - 2 000 000 elements)
+// are refreshed before every training forward; as separate copies they were 8 launches of ~5 us each.
+namespace trs {
+__global__ __launch_bounds__(256) void copy_padded_many_kernel(const int64_t* __restrict__ desc, int elem_size) {
+  const int64_t* d = desc + (size_t)blockIdx.y * 6;
+  const char* src = reinterpret_cast<const char*>(d[0]);
+  char* dst = reinterpret_cast<char*>(d[1]);
+  const int64_t rows = d[2], cols = d[3], sld = d[4], dld = d[5];
+  const int64_t rb = cols * elem_size;                     // bytes per row
+  const bool vec = rb % 16 == 0 && (sld * elem_size) % 16 == 0 && (dld * elem_size) % 16 == 0 &&
+                   (d[0] & 15) == 0 && (d[1] & 15) == 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (vec) {
+    const int64_t vpr = rb / 16, total = rows * vpr;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+      const int64_t r = t / vpr, c = t - r * vpr;
+      *reinterpret_cast<uint4*>(dst + r * dld * elem_size + c * 16) =
+          *reinterpret_cast<const uint4*>(src + r * sld * elem_size + c * 16);
+    }
+  } else {
+    const int64_t total = rows * rb;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+      const int64_t r = t / rb, c = t - r * rb;
+      dst[r * dld * elem_size + c] = src[r * sld * elem_size + c];
+    }
+  }
+}
+}  // namespace trs
+
+extern "C" int trs_copy_padded_many(const int64_t* desc, int32_t n, int32_t elem_size, int64_t max_elems,
+                                    trs_stream_t stream) {
+  if (n <= 0) return TRS_OK;
+  TRS_REQUIRE(desc != nullptr, TRS_EINVAL, "copy_padded_many: NULL descriptor table");
+  TRS_REQUIRE(elem_size == 2 || elem_size == 4, TRS_EDTYPE, "copy_padded_many: element size %d", elem_size);
+  const int64_t work = std::max<int64_t>(1, max_elems * elem_size / 16);
+  const int gx = (int)std::min<int64_t>((work + 255) / 256, 256);
+  hipLaunchKernelGGL(trs::copy_padded_many_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, desc, elem_size);
+  return trs::check_launch("copy_padded_many");
+}

@@ -516,13 +516,15 @@ def _pad_width(width: int) -> int:
 
 
 class _PaddedLinear:
-    """Zero-padded copies of one nn.Linear's weight/bias, refreshed on every training forward (one small copy per
-    layer; parameters the user owns can change without any version bump) and on every hipGraph capture, where the
-    refresh must be part of the replayed work.  The parameters themselves keep the reference's shapes."""
+    """Zero-padded copies of one nn.Linear's weight/bias, refreshed on every training forward (parameters the user owns
+    can change without any version bump) and on every hipGraph capture, where the refresh must be part of the replayed
+    work.  The parameters themselves keep the reference's shapes.  ``get_many`` refreshes the copies of a whole stack
+    with ONE launch (trs_copy_padded_many) instead of two small copies per layer."""
     __slots__ = ("w", "b", "key")
+    _desc_cache = {}
 
     @staticmethod
-    def get(mod: nn.Linear, in_pad: int, out_pad: int):
+    def _state(mod: nn.Linear, in_pad: int, out_pad: int):
         w, b = mod.weight, mod.bias
         st = mod.__dict__.get('_trs_padded')
         if st is None or st.w.shape != (out_pad, in_pad) or st.w.dtype != w.dtype or st.w.device != w.device:
@@ -531,17 +533,59 @@ class _PaddedLinear:
             st.b = torch.zeros(out_pad, dtype=w.dtype, device=w.device) if b is not None else None
             st.key = None
             mod.__dict__['_trs_padded'] = st
+        return st
+
+    @staticmethod
+    def _stale(mod: nn.Linear, st) -> bool:
         # refreshed on EVERY forward that can be followed by a parameter update (grad mode): in-place writes through
         # ``p.data`` (p.data.add_(), clipping, EMA swap-in, dist.broadcast(p.data)) do not bump ``_version``, so a
         # version key would leave the padded copy stale.  Inference (no_grad) keeps the (ptr, version) key.
+        w, b = mod.weight, mod.bias
         key = (w.data_ptr(), w._version, None if b is None else (b.data_ptr(), b._version))
-        if st.key != key or torch.is_grad_enabled() or torch.cuda.is_current_stream_capturing():
+        stale = st.key != key or torch.is_grad_enabled() or torch.cuda.is_current_stream_capturing()
+        st.key = key
+        return stale
+
+    @staticmethod
+    def get(mod: nn.Linear, in_pad: int, out_pad: int):
+        st = _PaddedLinear._state(mod, in_pad, out_pad)
+        if _PaddedLinear._stale(mod, st):
+            w, b = mod.weight, mod.bias
             with torch.no_grad():
                 st.w[:w.shape[0], :w.shape[1]].copy_(w)
                 if b is not None:
                     st.b[:b.shape[0]].copy_(b)
-            st.key = key
         return st.w, st.b
+
+    @staticmethod
+    def get_many(items):
+        """items: [(nn.Linear, in_pad, out_pad)] -> [(w_pad, b_pad)], stale copies refreshed by one kernel."""
+        states = [_PaddedLinear._state(m, i, o) for m, i, o in items]
+        jobs = []
+        for (mod, _, _), st in zip(items, states):
+            if _PaddedLinear._stale(mod, st):
+                w, b = mod.weight, mod.bias
+                if not (w.is_cuda and w.is_contiguous() and (b is None or b.is_contiguous())):
+                    with torch.no_grad():
+                        st.w[:w.shape[0], :w.shape[1]].copy_(w)
+                        if b is not None:
+                            st.b[:b.shape[0]].copy_(b)
+                    continue
+                jobs.append((w.data_ptr(), st.w.data_ptr(), w.shape[0], w.shape[1], w.shape[1], st.w.shape[1]))
+                if b is not None:
+                    jobs.append((b.data_ptr(), st.b.data_ptr(), 1, b.shape[0], b.shape[0], st.b.shape[0]))
+        if jobs:
+            key = tuple(jobs)
+            w0 = items[0][0].weight
+            desc = _PaddedLinear._desc_cache.get(key)
+            if desc is None:      # a blocking 48-byte-per-copy upload, once per set of parameter storages
+                if len(_PaddedLinear._desc_cache) > 64:
+                    _PaddedLinear._desc_cache.clear()
+                desc = torch.tensor(jobs, dtype=torch.int64, device=w0.device)
+                _PaddedLinear._desc_cache[key] = desc
+            F_.call("trs_copy_padded_many", F_.ptr(desc), len(jobs), w0.element_size(), max(j[2] * j[3] for j in jobs),
+                    F_.stream_ptr())
+        return [(st.w, st.b) for st in states]
 
 
 def _split_count(rows: int, slice_rows: int, max_slices: int = 384) -> int:
@@ -768,7 +812,7 @@ class MultilayerPerceptionLayer(BaseLayer):
         """The whole stack through one autograd node (_MLPStack) when it is Linear -> ReLU ... -> Linear with biases
         (inactive Dropout modules are skipped); None when the stack has any other shape."""
         lin = [m for m in mods if not isinstance(m, nn.Dropout)]
-        spec, tensors = [], []
+        spec, tensors, padded, mods_used = [], [], [], []
         width = outputs.shape[-1]
         i = 0
         while i < len(lin):
@@ -783,19 +827,20 @@ class MultilayerPerceptionLayer(BaseLayer):
             row_bytes = out_pad * outputs.element_size()
             if fuse and (row_bytes % 16 != 0 or row_bytes > 4096):       # trs_relu_bwd_bias row limits
                 return None
-            if width != mod.in_features or out_pad != mod.out_features:
-                w_use, b_use = _PaddedLinear.get(mod, width, out_pad)
-            else:
-                w_use = b_use = None
+            padded.append((mod, width, out_pad) if (width != mod.in_features or out_pad != mod.out_features) else None)
             rowdot = (last and not fuse and mod.out_features == 1
                       and (width * outputs.element_size()) % 16 == 0
                       and F_.rowdot_width_supported(width, outputs.element_size()))
             spec.append((fuse, rowdot))
-            tensors += [mod.weight, mod.bias, w_use, b_use]
+            mods_used.append(mod)
             width = out_pad
             i += 2 if fuse else 1
         if not spec or not outputs.is_contiguous():
             return None
+        copies = iter(_PaddedLinear.get_many([p for p in padded if p is not None]))     # one launch for the whole stack
+        for mod, p in zip(mods_used, padded):
+            w_use, b_use = next(copies) if p is not None else (None, None)
+            tensors += [mod.weight, mod.bias, w_use, b_use]
         out = _MLPStack.apply(outputs, tuple(spec), *tensors)
         if out.dim() == 2:
             out.names = ('B', 'O',)
