@@ -24,8 +24,15 @@ namespace trs {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 mf_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float mf_f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned mf_u32x4;
 
-constexpr int MF_ROWS = 128;          // rows per workgroup pass
+#ifndef TRS_MF_ROWS
+#define TRS_MF_ROWS 128
+#endif
+#ifndef TRS_MF_GRID
+#define TRS_MF_GRID 256
+#endif
+constexpr int MF_ROWS = TRS_MF_ROWS;  // rows per workgroup pass
 constexpr int MF_MT = MF_ROWS / 16;   // 16-row tiles
 constexpr int MF_WAVES = 8;
 constexpr int MF_MAXP = 2;            // 32-column pairs per wave: widths up to 8 * 2 * 32 = 512
@@ -111,12 +118,12 @@ __device__ __forceinline__ MlpShare mlp_share(int N, int wave) {
     }
   } else {
     const int ng = npairs <= 1 ? 1 : (npairs == 2 ? 2 : 4);     // pair groups; MF_WAVES / ng row groups
-    const int mg = MF_WAVES / ng;
+    const int mg = MF_WAVES / ng < MF_MT ? MF_WAVES / ng : MF_MT;
     s.mcnt = MF_MT / mg;
     s.mt0 = (wave / ng) * s.mcnt;
     s.pair[0] = wave % ng;
     s.pair[1] = 0;
-    s.npw = s.pair[0] < npairs ? 1 : 0;
+    s.npw = (s.pair[0] < npairs && wave / ng < mg) ? 1 : 0;
   }
   return s;
 }
@@ -124,9 +131,9 @@ __device__ __forceinline__ MlpShare mlp_share(int N, int wave) {
 // acc[mi][2*pi + h] (+)= sum_k W-frag(pair pi, half h, ks) x act rows of tile mt0+mi, for MCNT row tiles and NPW column
 // pairs known at compile time (runtime bounds put a scalar branch in front of every MFMA).
 // The weight fragments come from L2: they are requested two k-steps before the MFMAs that consume them (an L2 round
-// trip under load outlasts one k-step of 16-32 MFMAs); PREFETCH_B (not used: registers) prefetches the LDS reads of the
-// activations one k-step ahead, otherwise they are read per k-step in two halves (16 registers of B operands instead of 64).
-template <int MCNT, int NPW, bool PREFETCH_B>
+// trip under load outlasts one k-step of 16-32 MFMAs); the activations are read from LDS per k-step in two halves (16
+// registers of B operands instead of 64).
+template <int MCNT, int NPW>
 __device__ __forceinline__ void mlp_gemm_t(const char* act, int act_str, const uint4* __restrict__ wf, int K,
                                            const MlpShare& sh, int lane, mf_f32x4 (&acc)[MF_MT][2 * MF_MAXP]) {
   const int KS = K >> 5;
@@ -135,40 +142,26 @@ __device__ __forceinline__ void mlp_gemm_t(const char* act, int act_str, const u
   const uint4* wbase[NPW];
 #pragma unroll
   for (int pi = 0; pi < NPW; ++pi) wbase[pi] = wf + ((size_t)(2 * sh.pair[pi]) * KS) * 64 + lane;
-  uint4 A[2 * NPW], An[2 * NPW];
-  auto loadA = [&](int ks, uint4 (&dst)[2 * NPW]) {
-#pragma unroll
-    for (int pi = 0; pi < NPW; ++pi) {
-      dst[2 * pi] = wbase[pi][(size_t)ks * 64];
-      dst[2 * pi + 1] = wbase[pi][(size_t)(KS + ks) * 64];
-    }
-  };
-  loadA(0, A);
-  if constexpr (PREFETCH_B) {
-    uint4 B[MCNT], Bn[MCNT];
-#pragma unroll
-    for (int mi = 0; mi < MCNT; ++mi) B[mi] = *reinterpret_cast<const uint4*>(arow + mi * 16 * act_str);
-    for (int ks = 0; ks < KS; ++ks) {
-      if (ks + 1 < KS) {
-        loadA(ks + 1, An);
-#pragma unroll
-        for (int mi = 0; mi < MCNT; ++mi) Bn[mi] = *reinterpret_cast<const uint4*>(arow + mi * 16 * act_str + (ks + 1) * 64);
-      }
-#pragma unroll
-      for (int t = 0; t < 2 * NPW; ++t)
-#pragma unroll
-        for (int mi = 0; mi < MCNT; ++mi)
-          acc[mi][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mf_bf16x8, A[t]),
-                                                               __builtin_bit_cast(mf_bf16x8, B[mi]), acc[mi][t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < 2 * NPW; ++t) A[t] = An[t];
-#pragma unroll
-      for (int mi = 0; mi < MCNT; ++mi) B[mi] = Bn[mi];
-    }
-  } else {
+  mf_u32x4 A[2 * NPW], An[2 * NPW];
+#define TRS_MF_FETCH(dst, ks_)                                                                                      \
+  _Pragma("unroll") for (int pi = 0; pi < NPW; ++pi) {                                                             \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[2 * pi]) : "v"(wbase[pi] + (size_t)(ks_) * 64));     \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst[2 * pi + 1]) : "v"(wbase[pi] + (size_t)(KS + (ks_)) * 64)); \
+  }
+#define TRS_MF_COMMIT(dst)                                \
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        \
+  _Pragma("unroll") for (int t = 0; t < 2 * NPW; ++t) asm volatile("" : "+v"(dst[t]));
+  TRS_MF_FETCH(A, 0)
+  TRS_MF_COMMIT(A)
+  {
     constexpr int HALF = MCNT >= 2 ? MCNT / 2 : 1;
-    if (1 < KS) loadA(1, An);                    // one k-step ahead (deeper costs 8 more register moves per k-step and the
-    for (int ks = 0; ks < KS; ++ks) {            // compiler drains the loads at the top of the loop body anyway)
+    // The fragment loads are issued by hand at the top of a k-step and waited for at its bottom: written as ordinary
+    // loads the compiler places them at the END of the previous k-step's body and waits vmcnt(0) at the top of the
+    // next one, i.e. every k-step starts with a full L2 round trip (ISA of the first version of this loop).
+    for (int ks = 0; ks < KS; ++ks) {
+      const int kn = ks + 1 < KS ? ks + 1 : ks;
+      TRS_MF_FETCH(An, kn)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int m0 = 0; m0 < MCNT; m0 += HALF) {
         uint4 Bh[HALF];
@@ -181,20 +174,23 @@ __device__ __forceinline__ void mlp_gemm_t(const char* act, int act_str, const u
             acc[m0 + mi][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                 __builtin_bit_cast(mf_bf16x8, A[t]), __builtin_bit_cast(mf_bf16x8, Bh[mi]), acc[m0 + mi][t], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      TRS_MF_COMMIT(An)
 #pragma unroll
       for (int t = 0; t < 2 * NPW; ++t) A[t] = An[t];
-      if (ks + 2 < KS) loadA(ks + 2, An);
     }
   }
+#undef TRS_MF_FETCH
+#undef TRS_MF_COMMIT
 }
 
 // run ``body.template operator()<MCNT, NPW>()`` for this wave's share (wave-uniform dispatch)
 template <typename F>
 __device__ __forceinline__ void mlp_dispatch(const MlpShare& sh, F&& body) {
   if (sh.npw == 0) return;
-  if (sh.mcnt == 8) {
-    if (sh.npw == 2) body.template operator()<8, 2>();
-    else body.template operator()<8, 1>();
+  if (sh.mcnt == MF_MT) {
+    if (sh.npw == 2) body.template operator()<MF_MT, 2>();
+    else body.template operator()<MF_MT, 1>();
   } else if (sh.mcnt == 4) {
     body.template operator()<4, 1>();
   } else if (sh.mcnt == 2) {
@@ -247,7 +243,7 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_fwd_kernel(MlpArgs
 #pragma unroll
           for (int mi = 0; mi < MF_MT; ++mi) acc[mi][2 * pi + h] = init;
         }
-      mlp_dispatch(sh, [&]<int MCNT, int NPW>() { mlp_gemm_t<MCNT, NPW, false>(act, a.act_str, st.wf, st.K, sh, lane, acc); });
+      mlp_dispatch(sh, [&]<int MCNT, int NPW>() { mlp_gemm_t<MCNT, NPW>(act, a.act_str, st.wf, st.K, sh, lane, acc); });
       const int out_cols = l + 1 < a.nsteps ? st.N : st.out_stride;
       __syncthreads();      // every wave is done reading the layer's input
       mlp_dispatch(sh, [&]<int MCNT, int NPW>() {
@@ -322,14 +318,14 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_bwd_kernel(MlpArgs
       // the ReLU mask this step's output needs: 16 bytes per thread, in flight during the GEMM
       uint4 mraw = make_uint4(0, 0, 0, 0);
       const int mrow = threadIdx.x >> 2, mc = threadIdx.x & 3;
-      if (st.mask != nullptr && row0 + mrow < a.rows)
+      if (st.mask != nullptr && mrow < MF_ROWS && row0 + mrow < a.rows)
         mraw = *(reinterpret_cast<const uint4*>(st.mask + (row0 + mrow) * MF_MASK_STR) + mc);
       mf_f32x4 acc[MF_MT][2 * MF_MAXP];
 #pragma unroll
       for (int mi = 0; mi < MF_MT; ++mi)
 #pragma unroll
         for (int t = 0; t < 2 * MF_MAXP; ++t) acc[mi][t] = mf_f32x4{0.f, 0.f, 0.f, 0.f};
-      mlp_dispatch(sh, [&]<int MCNT, int NPW>() { mlp_gemm_t<MCNT, NPW, false>(act, a.act_str, st.wf, st.K, sh, lane, acc); });
+      mlp_dispatch(sh, [&]<int MCNT, int NPW>() { mlp_gemm_t<MCNT, NPW>(act, a.act_str, st.wf, st.K, sh, lane, acc); });
       __builtin_amdgcn_sched_barrier(0);
       // column sums of the step's input (the bias gradient of its layer): 8 row slices x 16-byte column chunks
       if (st.colsum != nullptr) {
@@ -339,9 +335,9 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_bwd_kernel(MlpArgs
 #pragma unroll
           for (int j = 0; j < 8; ++j) sum[j] = 0.f;
 #pragma unroll 4
-          for (int rr = 0; rr < 16; ++rr) {
+          for (int rr = 0; rr < MF_ROWS / 8; ++rr) {
             float f[8];
-            Vec16<bf16_t>::unpack(*reinterpret_cast<const uint4*>(act + (sl * 16 + rr) * a.act_str + c * 16), f);
+            Vec16<bf16_t>::unpack(*reinterpret_cast<const uint4*>(act + (sl * (MF_ROWS / 8) + rr) * a.act_str + c * 16), f);
 #pragma unroll
             for (int j = 0; j < 8; ++j) sum[j] += f[j];
           }
@@ -349,7 +345,7 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_bwd_kernel(MlpArgs
           for (int j = 0; j < 8; ++j) scratch[sl * 512 + c * 8 + j] = sum[j];
         }
       }
-      if (st.mask != nullptr) *reinterpret_cast<uint4*>(mask + mrow * MF_MASK_STR + mc * 16) = mraw;
+      if (st.mask != nullptr && mrow < MF_ROWS) *reinterpret_cast<uint4*>(mask + mrow * MF_MASK_STR + mc * 16) = mraw;
       const int out_cols = s + 1 < a.nsteps ? st.N : st.out_stride;
       __syncthreads();
       if (st.colsum != nullptr && threadIdx.x < st.K) {
@@ -408,7 +404,7 @@ __global__ __launch_bounds__(256) void mlp_colsum_reduce_kernel(const float* __r
 }
 
 static inline int pad32(int v) { return (v + 31) / 32 * 32; }
-constexpr int MF_GRID = 256;
+constexpr int MF_GRID = TRS_MF_GRID;
 
 static bool mlp_fused_covers(int L, const int32_t* w) {
   if (L < 1 || L > MF_MAXL) return false;
