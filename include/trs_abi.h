@@ -293,14 +293,16 @@ int trs_relu_bwd_bias(const void* gy, const void* y, int64_t rows, int32_t C, in
  *   weights[l]: (widths[l+1], widths[l]) row-major = nn.Linear.weight; biases[l]: (widths[l+1]); host arrays of
  *   device pointers.  ReLU after every layer but the last.
  * fwd: hidden[l] (rows, pad32(widths[l+1])) for l < num_layers-1 = the ReLU outputs, zero in the padding columns
- *      (kept for the weight-gradient GEMMs); masks[l] (rows, 64) bytes: bit j of byte c = output column 8c+j > 0;
- *      y (rows, widths[num_layers]).
+ *      (kept for the weight-gradient GEMMs); masks[l]: trs_mlp_fused_mask_bytes(rows) bytes, the sign bits
+ *      [hidden > 0] in the kernel's own (pass, lane) order -- opaque, read only by trs_mlp_fused_bwd_data on the same
+ *      rows and widths; y (rows, widths[num_layers]).
  * bwd_data: gy (rows, widths[num_layers]) -> gz[l] (rows, pad32(widths[l+1])), l < num_layers-1 = gradient w.r.t. the
  *      pre-activation of layer l (that of the last layer is gy itself); gbias[l] (pad32(widths[l+1]) fp32, written) for
  *      every layer; gx (rows, widths[0]).  Weight gradients are left to the caller: dW_l = gz_l^T @ input_l.
  * trs_mlp_fused_supported: 1 when the widths fit the kernel (and its LDS budget).                              */
 int trs_mlp_fused_supported(int32_t num_layers, const int32_t* widths);
 size_t trs_mlp_fused_workspace_bytes(int32_t num_layers, const int32_t* widths);
+size_t trs_mlp_fused_mask_bytes(int64_t rows);
 int trs_mlp_fused_fwd(const void* x, int64_t rows, int32_t num_layers, const int32_t* widths,
                       const void* const* weights, const void* const* biases, void* const* hidden, void* const* masks,
                       void* y, int32_t dtype, void* workspace, size_t ws_bytes, trs_stream_t stream);

@@ -48,15 +48,16 @@ def test_fused_mlp_vs_oracle(dev, shape, widths):
     assert rel_err(y.float().cpu(), yo) <= TOL
     assert rel_err_rows(rows(y.float().cpu()), rows(yo), floor_frac=5e-2) <= 2 * TOL
     # gradients against the oracle UNDER THE KERNEL'S OWN ReLU MASKS (a hidden unit whose pre-activation bf16
-    # rounding moves across zero changes the gradient by a whole term -- see tests/test_gpu_cin_parity.py): the
-    # masks are the bit masks the forward kernel hands to the backward kernel
+    # rounding moves across zero changes the gradient by a whole term -- see tests/test_gpu_cin_parity.py).  The sign
+    # bits the forward kernel hands to the backward kernel are in the kernel's own order (opaque); they are the signs
+    # of the hidden activations it stores, which is what the oracle is masked with here -- wrong bits would show up as
+    # whole missing / extra terms in the gradients below
     _, hidden, masks = F_.fused_mlp_forward_raw(rows(x).to(dev), [w.to(dev) for w in Ws], [b.to(dev) for b in bs])
+    assert all(m.numel() == F_.size_query("trs_mlp_fused_mask_bytes", rows(x).shape[0]) for m in masks)
     unpacked = []
-    for l, m in enumerate(masks):
-        bits = ((m.cpu().unsqueeze(-1) >> torch.arange(8, dtype=torch.uint8)) & 1).reshape(m.shape[0], -1)
-        unpacked.append(bits[:, :widths[l + 1]].float().reshape(*shape, widths[l + 1]))
+    for l in range(len(masks)):
         h = hidden[l].float().cpu()
-        assert torch.equal(h[:, :widths[l + 1]] > 0, bits[:, :widths[l + 1]].bool())      # mask == sign of what was stored
+        unpacked.append((h[:, :widths[l + 1]] > 0).float().reshape(*shape, widths[l + 1]))
         assert float(h[:, widths[l + 1]:].abs().max() if h.shape[1] > widths[l + 1] else 0.0) == 0.0
     it = iter(unpacked)
     xr = x.float().requires_grad_()

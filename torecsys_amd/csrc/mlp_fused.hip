@@ -9,9 +9,9 @@
 // weights (0.74 MB for the DCN stack: they do not fit in LDS) are pre-packed once per call into MFMA fragment order
 // and streamed from L2 straight into registers: the output columns of a layer are split over the 8 waves, so every
 // weight byte is loaded once per workgroup and no weight passes through LDS.  HBM sees the rows once per tensor:
-//   forward : x read; every hidden activation written once (the weight-gradient GEMMs need them) + a 1-bit ReLU mask;
+//   forward : x read; every hidden activation written once (the weight-gradient GEMMs need them) + 1 ReLU sign bit each;
 //   backward: the output gradient read; d(pre-activation) of every layer written once (again for the weight
-//             gradients), the masks read (52 bytes per row and layer instead of a 832-byte activation row), column
+//             gradients), the sign bits read (64 bytes per row and layer instead of a 832-byte activation row), column
 //             sums (bias gradients) accumulated on chip, dx written.
 // The unfused pipeline (hipBLASLt GEMMs + trs_relu_bwd_bias) moves ~16 GB of hidden activations per step and pads the
 // 400-wide layers to 512 columns; here the widths are padded to 32 (416).  The weight gradients stay GEMMs with
@@ -37,7 +37,7 @@ constexpr int MF_MT = MF_ROWS / 16;   // 16-row tiles
 constexpr int MF_WAVES = 8;
 constexpr int MF_MAXP = 2;            // 32-column pairs per wave: widths up to 8 * 2 * 32 = 512
 constexpr int MF_MAXL = 8;
-constexpr int MF_MASK_STR = 64;       // mask bytes per row (512 columns / 8)
+constexpr int MF_MASK_TILE = 64 * MF_WAVES * 16;   // mask bytes per 128-row pass and layer: 16 per lane (see mlp_fused_fwd_kernel)
 
 // column of D-row slot m (= 4*q + i) of 16-column tile mt: the two tiles of a pair interleave 4-column groups, so that
 // a lane's (tile 2p, tile 2p+1) outputs are the 8 consecutive columns 32p + 8q .. +7 of its row
@@ -81,7 +81,7 @@ struct MlpStep {
   const uint4* wf;    // fragment-order weights of this step
   const float* bias;  // fp32, padded (forward) or null
   void* out;          // global output of the step (rows x out_stride elements), may be null
-  uint8_t* mask;      // forward: mask written for this step's output; backward: mask applied to this step's output
+  uint8_t* mask;      // forward: ReLU sign bits written for this step's output; backward: applied to this step's output
   float* colsum;      // backward: partial column sums of this step's INPUT, [gridDim.x][K] (may be null)
   int K, N;           // padded contraction / output widths (multiples of 32)
   int out_stride;     // elements per global output row
@@ -214,18 +214,20 @@ __device__ __forceinline__ void mlp_load_in(char* act, int act_str, const void* 
 }
 
 // ------------------------------------------------------------------------------------------------ forward
+// workgroup barrier for the LDS hand-offs inside a pass: __syncthreads() also waits vmcnt(0), i.e. for the global stores
+// in flight, which nothing here depends on
+#define MF_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_fwd_kernel(MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* act = smem;                                          // [MF_ROWS][act_str]
-  uint8_t* mask = reinterpret_cast<uint8_t*>(act + MF_ROWS * a.act_str);   // [MF_ROWS][MF_MASK_STR]
-  float* bias_s = reinterpret_cast<float*>(mask + MF_ROWS * MF_MASK_STR);   // all layers' padded biases, back to back
+  float* bias_s = reinterpret_cast<float*>(act + MF_ROWS * a.act_str);      // all layers' padded biases, back to back
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, r = lane & 15;
   for (int i = threadIdx.x; i < a.nbias; i += blockDim.x) bias_s[i] = a.step[0].bias[i];
   const int64_t ntiles = (a.rows + MF_ROWS - 1) / MF_ROWS;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t row0 = tile * MF_ROWS;
     mlp_load_in(act, a.act_str, a.in, a.in_stride, a.step[0].K, row0, a.rows);
-    __syncthreads();
+    MF_BAR();
     int boff = 0;
     for (int l = 0; l < a.nsteps; ++l) {
       const MlpStep st = a.step[l];
@@ -244,8 +246,14 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_fwd_kernel(MlpArgs
           for (int mi = 0; mi < MF_MT; ++mi) acc[mi][2 * pi + h] = init;
         }
       mlp_dispatch(sh, [&]<int MCNT, int NPW>() { mlp_gemm_t<MCNT, NPW>(act, a.act_str, st.wf, st.K, sh, lane, acc); });
-      const int out_cols = l + 1 < a.nsteps ? st.N : st.out_stride;
-      __syncthreads();      // every wave is done reading the layer's input
+      const bool last = l + 1 == a.nsteps;
+      const int out_cols = last ? st.out_stride : st.N;
+      MF_BAR();      // every wave is done reading the layer's input (after the last layer: LDS is free for the next pass)
+      // ReLU sign bits: a lane owns 8 columns of one row in each of its <= 16 (column pair, row tile) items, i.e. one
+      // byte per item and 16 bytes per layer.  They go to global memory as that one vector, in (pass, thread) order --
+      // the backward kernel gives the same lane the same items.  (Staging them through LDS in (row, column) order cost
+      // ~4 k LDS cycles of bank conflicts per layer and pass: byte writes 64 bytes apart.)
+      unsigned mbits[4] = {0u, 0u, 0u, 0u};
       mlp_dispatch(sh, [&]<int MCNT, int NPW>() {
 #pragma unroll
         for (int pi = 0; pi < NPW; ++pi) {
@@ -271,28 +279,23 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_fwd_kernel(MlpArgs
             const int row = (sh.mt0 + mi) * 16 + r;
             const int col = 32 * sh.pair[pi] + 8 * q;
             const uint4 pk = Vec16<bf16_t>::pack(v);
-            *reinterpret_cast<uint4*>(act + row * a.act_str + col * 2) = pk;
+            if (!last) *reinterpret_cast<uint4*>(act + row * a.act_str + col * 2) = pk;      // the next layer's input
             // the step's global output (hidden activations kept for the weight gradients / the result) leaves from the
-            // registers: 16 bytes per lane, 64 contiguous bytes per row and wave; the stores drain under the next
-            // layer's MFMAs (a separate LDS -> global pass cost 0.45 ms per 400-wide layer with the matrix pipe idle)
+            // registers: 16 bytes per lane, 64 contiguous bytes per row and wave.  (Global stores cost ~64 issue cycles
+            // per wave instruction wherever they are placed -- 0.9 of the kernel's 3.3 ms; spreading them over the next
+            // layer's k-steps from LDS, one per k-step with a counted vmcnt, measured the same.)
             if (st.out != nullptr && row0 + row < a.rows && col < out_cols)
               store_stream(reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(st.out) + (row0 + row) * st.out_stride + col), pk);
-            if (st.relu) mask[row * MF_MASK_STR + 4 * sh.pair[pi] + q] = (uint8_t)bits;
+            mbits[(pi * MCNT + mi) >> 2] |= bits << (8 * ((pi * MCNT + mi) & 3));
           }
         }
       });
-      __syncthreads();
-      if (st.mask != nullptr && st.relu) {
-        for (int t = threadIdx.x; t < MF_ROWS * (MF_MASK_STR / 16); t += blockDim.x) {
-          const int rr = t >> 2, c = t & 3;
-          if (row0 + rr < a.rows)
-            *(reinterpret_cast<uint4*>(st.mask + (row0 + rr) * MF_MASK_STR) + c) =
-                *reinterpret_cast<const uint4*>(mask + rr * MF_MASK_STR + c * 16);
-        }
-      }
+      if (!last) MF_BAR();
+      if (st.mask != nullptr && st.relu)
+        store_stream(reinterpret_cast<uint4*>(st.mask + tile * MF_MASK_TILE) + threadIdx.x,
+                     make_uint4(mbits[0], mbits[1], mbits[2], mbits[3]));
       boff += st.N;
     }
-    __syncthreads();        // the last copy-out has read LDS before the next tile's rows land in it
   }
 }
 
@@ -302,8 +305,7 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_fwd_kernel(MlpArgs
 __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_bwd_kernel(MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* act = smem;
-  uint8_t* mask = reinterpret_cast<uint8_t*>(act + MF_ROWS * a.act_str);            // [MF_ROWS][MF_MASK_STR]
-  float* scratch = reinterpret_cast<float*>(mask + MF_ROWS * MF_MASK_STR);           // [8 row slices][512]
+  float* scratch = reinterpret_cast<float*>(act + MF_ROWS * a.act_str);              // [8 row slices][512]
   float* csum = scratch + 8 * 512;                                                    // [nsteps][512] running column sums
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, r = lane & 15;
   for (int i = threadIdx.x; i < a.nsteps * 512; i += blockDim.x) csum[i] = 0.f;
@@ -311,15 +313,14 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_bwd_kernel(MlpArgs
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t row0 = tile * MF_ROWS;
     mlp_load_in(act, a.act_str, a.in, a.in_stride, a.step[0].K, row0, a.rows);
-    __syncthreads();
+    MF_BAR();
     for (int s = 0; s < a.nsteps; ++s) {
       const MlpStep st = a.step[s];
       const MlpShare sh = mlp_share(st.N, wave);
-      // the ReLU mask this step's output needs: 16 bytes per thread, in flight during the GEMM
+      // the ReLU sign bits of this lane's outputs (the forward's vector for this pass and thread), in flight during the GEMM
       uint4 mraw = make_uint4(0, 0, 0, 0);
-      const int mrow = threadIdx.x >> 2, mc = threadIdx.x & 3;
-      if (st.mask != nullptr && mrow < MF_ROWS && row0 + mrow < a.rows)
-        mraw = *(reinterpret_cast<const uint4*>(st.mask + (row0 + mrow) * MF_MASK_STR) + mc);
+      if (st.mask != nullptr) mraw = *(reinterpret_cast<const uint4*>(st.mask + tile * MF_MASK_TILE) + threadIdx.x);
+      const unsigned mword[4] = {mraw.x, mraw.y, mraw.z, mraw.w};
       mf_f32x4 acc[MF_MT][2 * MF_MAXP];
 #pragma unroll
       for (int mi = 0; mi < MF_MT; ++mi)
@@ -345,9 +346,9 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_bwd_kernel(MlpArgs
           for (int j = 0; j < 8; ++j) scratch[sl * 512 + c * 8 + j] = sum[j];
         }
       }
-      if (st.mask != nullptr && mrow < MF_ROWS) *reinterpret_cast<uint4*>(mask + mrow * MF_MASK_STR + mc * 16) = mraw;
-      const int out_cols = s + 1 < a.nsteps ? st.N : st.out_stride;
-      __syncthreads();
+      const bool last = s + 1 == a.nsteps;
+      const int out_cols = last ? st.out_stride : st.N;
+      MF_BAR();
       if (st.colsum != nullptr && threadIdx.x < st.K) {
         float t = 0.f;
 #pragma unroll
@@ -367,22 +368,21 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_bwd_kernel(MlpArgs
             }
             const int row = (sh.mt0 + mi) * 16 + r;
             if (st.mask != nullptr) {
-              const unsigned bits = mask[row * MF_MASK_STR + 4 * sh.pair[pi] + q];
+              const int word = (int)mword[(pi * MCNT + mi) >> 2];
 #pragma unroll
               for (int j = 0; j < 8; ++j)      // sign-extended 1-bit field (0 / all ones) ANDed onto the value: 2 instructions
-                v[j] = __int_as_float(__float_as_int(v[j]) & __builtin_amdgcn_sbfe((int)bits, j, 1));
+                v[j] = __int_as_float(__float_as_int(v[j]) & __builtin_amdgcn_sbfe(word, 8 * ((pi * MCNT + mi) & 3) + j, 1));
             }
             const int col = 32 * sh.pair[pi] + 8 * q;
             const uint4 pk = Vec16<bf16_t>::pack(v);
-            *reinterpret_cast<uint4*>(act + row * a.act_str + col * 2) = pk;
+            if (!last) *reinterpret_cast<uint4*>(act + row * a.act_str + col * 2) = pk;
             if (st.out != nullptr && row0 + row < a.rows && col < out_cols)      // as in the forward: from the registers
               store_stream(reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(st.out) + (row0 + row) * st.out_stride + col), pk);
           }
         }
       });
-      __syncthreads();
+      if (!last) MF_BAR();
     }
-    __syncthreads();
   }
   for (int s = 0; s < a.nsteps; ++s)
     if (a.step[s].colsum != nullptr && threadIdx.x < a.step[s].K)
@@ -437,9 +437,13 @@ extern "C" size_t trs_mlp_fused_workspace_bytes(int32_t num_layers, const int32_
   return mlp_frag_bytes(num_layers, widths) + (size_t)MF_GRID * sum * 4 + 4096;
 }
 
+extern "C" size_t trs_mlp_fused_mask_bytes(int64_t rows) {
+  return (size_t)((rows + MF_ROWS - 1) / MF_ROWS) * MF_MASK_TILE;
+}
+
 extern "C" int trs_mlp_fused_supported(int32_t num_layers, const int32_t* widths) {
   if (!mlp_fused_covers(num_layers, widths)) return 0;
-  const size_t lds = (size_t)MF_ROWS * mlp_act_str(num_layers, widths) + MF_ROWS * MF_MASK_STR + 8 * 512 * 4 +
+  const size_t lds = (size_t)MF_ROWS * mlp_act_str(num_layers, widths) + 8 * 512 * 4 +
                      (size_t)num_layers * 512 * 4;
   return lds <= 160 * 1024 ? 1 : 0;
 }
@@ -487,7 +491,7 @@ extern "C" int trs_mlp_fused_fwd(const void* x, int64_t rows, int32_t num_layers
     boff += N;
   }
   a.nbias = (int)boff;
-  const size_t lds = (size_t)MF_ROWS * a.act_str + MF_ROWS * MF_MASK_STR + boff * 4;
+  const size_t lds = (size_t)MF_ROWS * a.act_str + boff * 4;
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)mlp_fused_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
@@ -550,7 +554,7 @@ extern "C" int trs_mlp_fused_bwd_data(const void* gy, int64_t rows, int32_t num_
     woff += (size_t)K * N * 2;
     poff += (size_t)grid * K;
   }
-  const size_t lds = (size_t)MF_ROWS * a.act_str + MF_ROWS * MF_MASK_STR + 8 * 512 * 4 + (size_t)L * 512 * 4;
+  const size_t lds = (size_t)MF_ROWS * a.act_str + 8 * 512 * 4 + (size_t)L * 512 * 4;
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)mlp_fused_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=

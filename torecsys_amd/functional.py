@@ -1505,13 +1505,14 @@ def mlp_fused_supported(x: torch.Tensor, widths: Sequence[int]) -> bool:
 
 def fused_mlp_forward_raw(x2: torch.Tensor, Ws: Sequence[torch.Tensor], bs: Sequence[torch.Tensor]):
     """trs_mlp_fused_fwd on rows x2 (rows, widths[0]): returns (y (rows, widths[L]), hidden [(rows, pad32(w))] -- the
-    ReLU outputs of the hidden layers, zero in the padding columns --, masks [(rows, 64) uint8: bit j of byte c says
-    hidden column 8c+j is positive])."""
+    ReLU outputs of the hidden layers, zero in the padding columns --, masks [the sign bits of the hidden layers in the
+    kernel's own order: opaque bytes for trs_mlp_fused_bwd_data])."""
     L = len(Ws)
     widths = [Ws[0].shape[1]] + [w.shape[0] for w in Ws]
     rows, dev = x2.shape[0], x2.device
     hidden = [torch.empty(rows, _pad32(widths[l + 1]), dtype=torch.bfloat16, device=dev) for l in range(L - 1)]
-    masks = [torch.empty(rows, 64, dtype=torch.uint8, device=dev) for _ in range(L - 1)]
+    mask_bytes = size_query("trs_mlp_fused_mask_bytes", rows)
+    masks = [torch.empty(mask_bytes, dtype=torch.uint8, device=dev) for _ in range(L - 1)]
     y = torch.empty(rows, widths[L], dtype=torch.bfloat16, device=dev)
     wl = _i32_array(widths)
     ws_bytes = size_query("trs_mlp_fused_workspace_bytes", L, wl)
