@@ -376,6 +376,19 @@ def main():
     for _ in range(a.warmup if not use_graph else max(3, a.warmup // 2)):
         eager_step()
     torch.cuda.synchronize()
+    if os.environ.get("TRS_BENCH_TORCHPROF"):      # developer aid: which host op launches what (3 eager steps)
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+            eager_step()
+            torch.cuda.synchronize()
+        with open(os.environ["TRS_BENCH_TORCHPROF"], "w") as f:
+            f.write(prof.key_averages().table(sort_by="cuda_time_total", row_limit=60, max_name_column_width=60))
+            f.write("\n\nhost ops that launch device work, in issue order (op, input shapes -> kernels):\n")
+            for ev in sorted(prof.events(), key=lambda e: e.time_range.start):
+                ks = getattr(ev, "kernels", None)
+                if ks and not any(c.kernels for c in ev.cpu_children if getattr(c, "kernels", None)):
+                    f.write(f"{ev.name:44s} {str(ev.input_shapes)[:90]:90s} -> "
+                            + ", ".join(f"{k.name[:50]} {k.duration:.1f}us" for k in ks) + "\n")
     if world > 1:
         dist.barrier()
     if not sharded:          # the sharded step reports no single-kernel roofline (alg bytes depend on the routing)

@@ -79,14 +79,10 @@ class DeepAndCrossNetworkModel(nn.Module):
     def forward(self, emb_inputs: torch.Tensor) -> torch.Tensor:
         crossed = _plain(self.cross(emb_inputs))            # (B, N, E)
         per_field = _plain(self.deep(emb_inputs))           # (B, N, Od): the MLP runs on every field's row
-        # the head is Linear over the field-major [cross | deep] rows; its weight splits into the columns that meet the
-        # cross block and those that meet the MLP block, so the (B, N, E+Od) concatenation (0.65 GB written and read
-        # again at the bench size, and sliced apart again in the backward) is never built
-        B, N, E = crossed.shape
-        w = self.fc.weight.reshape(-1, N, E + per_field.shape[2])
-        w_cross = w[:, :, :E].reshape(w.shape[0], -1)
-        w_deep = w[:, :, E:].reshape(w.shape[0], -1)
-        return torch.addmm(self.fc.bias, crossed.reshape(B, -1), w_cross.t()) + per_field.reshape(B, -1) @ w_deep.t()
+        both = torch.cat((crossed, per_field), dim=2)       # field-major [cross | deep] rows, as the head expects
+        return self.fc(both.reshape(both.shape[0], -1))     # (a head split over the two blocks would save the 0.65 GB
+                                                            # concatenation -- 0.6 ms at the bench size -- but the callers
+                                                            # stay the reference's compositions)
 
 
 class XDeepFactorizationMachineModel(nn.Module):
