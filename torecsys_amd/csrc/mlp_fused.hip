@@ -254,38 +254,48 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_fwd_kernel(MlpArgs
       // the backward kernel gives the same lane the same items.  (Staging them through LDS in (row, column) order cost
       // ~4 k LDS cycles of bank conflicts per layer and pass: byte writes 64 bytes apart.)
       unsigned mbits[4] = {0u, 0u, 0u, 0u};
+      // addresses of the lane's items: one base per layer, wave-uniform offsets per item (a 64-bit row * stride product
+      // per item was a sixth of the epilogue's instructions); rows past the end of the tensor fail ``16 * mi < left``
+      const int lrow = sh.mt0 * 16 + r;
+      char* lds0 = act + lrow * a.act_str + 16 * q;
+      bf16_t* out0 = reinterpret_cast<bf16_t*>(st.out) + (row0 + lrow) * st.out_stride + 8 * q;
+      const int64_t left64 = a.rows - row0 - lrow;
+      const int left = st.out == nullptr ? 0 : (left64 > MF_ROWS ? MF_ROWS : (int)left64);
       mlp_dispatch(sh, [&]<int MCNT, int NPW>() {
 #pragma unroll
         for (int pi = 0; pi < NPW; ++pi) {
+          const bool colok = 32 * sh.pair[pi] + 8 * q < out_cols;
 #pragma unroll
           for (int mi = 0; mi < MCNT; ++mi) {
-            float v[8];
+            int iv[8];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              v[i] = acc[mi][2 * pi][i];
-              v[4 + i] = acc[mi][2 * pi + 1][i];
+              iv[i] = __float_as_int(acc[mi][2 * pi][i]);
+              iv[4 + i] = __float_as_int(acc[mi][2 * pi + 1][i]);
             }
             unsigned bits = 0;
             if (st.relu) {
-              // one compare per value feeds both the mask bit (bits = 2*bits + carry) and the select; fmaxf would add
-              // two v_max (it canonicalises NaNs first) -- a NaN reads as "not positive" either way
+              // on the bit patterns: max(int, 0) is ReLU (negative floats are negative ints, -0.0 included) and
+              // min(unsigned, 1) is [value > 0] -- 3 instructions per value with the shift-or, no NaN canonicalisation
 #pragma unroll
               for (int j = 7; j >= 0; --j) {
-                const bool pos = v[j] > 0.f;
-                bits = bits + bits + (pos ? 1u : 0u);
-                v[j] = pos ? v[j] : 0.f;
+                iv[j] = iv[j] > 0 ? iv[j] : 0;
+                unsigned one;      // written as a min the compiler turns it back into compare + select
+                asm("v_min_u32 %0, 1, %1" : "=v"(one) : "v"(iv[j]));
+                bits = (bits << 1) | one;
               }
             }
-            const int row = (sh.mt0 + mi) * 16 + r;
-            const int col = 32 * sh.pair[pi] + 8 * q;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = __int_as_float(iv[j]);
             const uint4 pk = Vec16<bf16_t>::pack(v);
-            if (!last) *reinterpret_cast<uint4*>(act + row * a.act_str + col * 2) = pk;      // the next layer's input
+            if (!last) *reinterpret_cast<uint4*>(lds0 + mi * 16 * a.act_str + sh.pair[pi] * 64) = pk;      // the next layer's input
             // the step's global output (hidden activations kept for the weight gradients / the result) leaves from the
             // registers: 16 bytes per lane, 64 contiguous bytes per row and wave.  (Global stores cost ~64 issue cycles
             // per wave instruction wherever they are placed -- 0.9 of the kernel's 3.3 ms; spreading them over the next
             // layer's k-steps from LDS, one per k-step with a counted vmcnt, measured the same.)
-            if (st.out != nullptr && row0 + row < a.rows && col < out_cols)
-              store_stream(reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(st.out) + (row0 + row) * st.out_stride + col), pk);
+            if (colok && 16 * mi < left)
+              store_stream(reinterpret_cast<uint4*>(out0 + (size_t)mi * 16 * st.out_stride + 32 * sh.pair[pi]), pk);
             mbits[(pi * MCNT + mi) >> 2] |= bits << (8 * ((pi * MCNT + mi) & 3));
           }
         }
@@ -355,9 +365,15 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_bwd_kernel(MlpArgs
         for (int sl = 0; sl < 8; ++sl) t += scratch[sl * 512 + threadIdx.x];
         csum[s * 512 + threadIdx.x] += t;
       }
+      const int lrow = sh.mt0 * 16 + r;          // item addresses as in the forward
+      char* lds0 = act + lrow * a.act_str + 16 * q;
+      bf16_t* out0 = reinterpret_cast<bf16_t*>(st.out) + (row0 + lrow) * st.out_stride + 8 * q;
+      const int64_t left64 = a.rows - row0 - lrow;
+      const int left = st.out == nullptr ? 0 : (left64 > MF_ROWS ? MF_ROWS : (int)left64);
       mlp_dispatch(sh, [&]<int MCNT, int NPW>() {
 #pragma unroll
         for (int pi = 0; pi < NPW; ++pi) {
+          const bool colok = 32 * sh.pair[pi] + 8 * q < out_cols;
 #pragma unroll
           for (int mi = 0; mi < MCNT; ++mi) {
             float v[8];
@@ -366,18 +382,16 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_bwd_kernel(MlpArgs
               v[i] = acc[mi][2 * pi][i];
               v[4 + i] = acc[mi][2 * pi + 1][i];
             }
-            const int row = (sh.mt0 + mi) * 16 + r;
             if (st.mask != nullptr) {
               const int word = (int)mword[(pi * MCNT + mi) >> 2];
 #pragma unroll
               for (int j = 0; j < 8; ++j)      // sign-extended 1-bit field (0 / all ones) ANDed onto the value: 2 instructions
                 v[j] = __int_as_float(__float_as_int(v[j]) & __builtin_amdgcn_sbfe(word, 8 * ((pi * MCNT + mi) & 3) + j, 1));
             }
-            const int col = 32 * sh.pair[pi] + 8 * q;
             const uint4 pk = Vec16<bf16_t>::pack(v);
-            if (!last) *reinterpret_cast<uint4*>(act + row * a.act_str + col * 2) = pk;
-            if (st.out != nullptr && row0 + row < a.rows && col < out_cols)      // as in the forward: from the registers
-              store_stream(reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(st.out) + (row0 + row) * st.out_stride + col), pk);
+            if (!last) *reinterpret_cast<uint4*>(lds0 + mi * 16 * a.act_str + sh.pair[pi] * 64) = pk;
+            if (colok && 16 * mi < left)      // as in the forward: from the registers
+              store_stream(reinterpret_cast<uint4*>(out0 + (size_t)mi * 16 * st.out_stride + 32 * sh.pair[pi]), pk);
           }
         }
       });
