@@ -93,14 +93,17 @@ int trs_csr_build(const void* idx, int32_t idx_dtype, const int64_t* offsets, in
  * NULL to disable) is the FM second-order backward dx = g*(S - x) of
  * layers/ctr/factorization_machine.py:62-73 fused into the same pass.  padding_row (-1: none)
  * gets a zero gradient (nn.Embedding padding_idx).  fp32 accumulation, one rounding on store.
+ * g_fm_cols = E: g_fm holds full (B x E) rows; g_fm_cols = 1 (with fm_sum): g_fm holds ONE value per sample, the
+ * gradient is constant along E (the backward of a sum over E -- what the reference's FM / DeepFM models feed back,
+ * models/ctr/deep_fm.py:55-110): the walk then reads 144 instead of 256 bytes of FM operands per lookup.
  * With fm_sum == NULL, g_fm is a plain per-sample gradient broadcast over the N fields (the
- * first-order sum's backward).  g_rows_batch_stride (rows; 0 = N) lets g_rows be a (B, N, E) slice
+ * first-order sum's backward; g_fm_cols = E).  g_rows_batch_stride (rows; 0 = N) lets g_rows be a (B, N, E) slice
  * of a larger (B, M, E) tensor: the row of position (b,n) is b*stride + n.
  * Rows with more than 256 lookups (Zipf-hot rows) are queued in `workspace`
  * (trs_scatter_workspace_bytes) and reduced by whole workgroups; the workspace also holds the
  * per-sample [g*S | g] rows the FM term is read from.                         */
 size_t trs_scatter_workspace_bytes(int64_t BN, int32_t N, int32_t E, int32_t dtype);
-int trs_scatter_rows(const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm,
+int trs_scatter_rows(const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm, int32_t g_fm_cols,
                      const float* fm_sum, const void* table, const int32_t* row_start,
                      const int32_t* perm, int64_t BN, int64_t V, int32_t E, int32_t N, int32_t dtype,
                      int64_t padding_row, void* grad_table, void* workspace, size_t ws_bytes,
@@ -111,7 +114,8 @@ int trs_scatter_rows(const void* g_rows, int64_t g_rows_batch_stride, const void
  * lookup; every row of grad_first is written).  Rows must be whole 16-byte vectors (E*sizeof(dtype) % 16 == 0).
  * Replaces the second embedding backward of the (B,N,1) first-order lookup (torch embedding_dense_backward of
  * multi_indices_emb.py:104-105 at embed_size = 1).                                                               */
-int trs_scatter_rows_first(const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm, const float* fm_sum,
+int trs_scatter_rows_first(const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm, int32_t g_fm_cols,
+                           const float* fm_sum,
                            const void* table, const int32_t* row_start, const int32_t* perm, int64_t BN, int64_t V,
                            int32_t E, int32_t N, int32_t dtype, int64_t padding_row, void* grad_table,
                            const void* g_first, void* grad_first, void* workspace, size_t ws_bytes,
@@ -122,7 +126,7 @@ int trs_scatter_rows_first(const void* g_rows, int64_t g_rows_batch_stride, cons
  * 2 = Adagrad  state += g*g, w -= lr*g/(sqrt(state)+eps)  (state: V x E fp32).  Exactly equivalent to the
  * dense torch.optim.SGD / Adagrad step (no momentum / weight decay): rows nobody looked up have zero gradient
  * and are not touched -- neither the dense V x E gradient nor a dense optimizer pass over the table exists.  */
-int trs_scatter_rows_update(const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm,
+int trs_scatter_rows_update(const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm, int32_t g_fm_cols,
                             const float* fm_sum, void* table, const int32_t* row_start, const int32_t* perm,
                             int64_t BN, int64_t V, int32_t E, int32_t N, int32_t dtype, int64_t padding_row,
                             int32_t optimizer, float lr, float eps, float* state, void* workspace,
@@ -132,7 +136,7 @@ int trs_scatter_rows_update(const void* g_rows, int64_t g_rows_batch_stride, con
  * the reference trains with dense Adam, trainer/torecsys_pipeline.py:562-578, which cannot exist at 1 B rows):
  *   m = m + (g - m)(1 - beta1);  v = v + (g*g - v)(1 - beta2);  w -= step_size * m / (sqrt(v) + eps)
  * with step_size = lr * sqrt(1 - beta2^t) / (1 - beta1^t) computed by the caller; exp_avg / exp_avg_sq: V x E fp32. */
-int trs_scatter_rows_update_adam(const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm,
+int trs_scatter_rows_update_adam(const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm, int32_t g_fm_cols,
                                  const float* fm_sum, void* table, const int32_t* row_start, const int32_t* perm,
                                  int64_t BN, int64_t V, int32_t E, int32_t N, int32_t dtype, int64_t padding_row,
                                  float step_size, float beta1, float beta2, float eps, float* exp_avg,

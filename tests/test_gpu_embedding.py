@@ -537,6 +537,40 @@ def test_very_hot_rows_are_chunked(dev, dtype, tol, fuse):
     assert rel_err(m.embedding.weight.grad.float().cpu(), wr.grad) <= tol
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("B,N,E,Vf,hot", [(1024, 10, 16, 100, False), (4096, 39, 64, 7, True), (300, 5, 10, 9, False)])
+def test_fm_gradient_constant_along_E(dev, dtype, tol, B, N, E, Vf, hot):
+    """The reference's FM / DeepFM models sum the FM output over E (models/ctr/deep_fm.py:55-110), so the gradient that
+    reaches the fused lookup+FM backward is an expanded (B,1) column.  trs_scatter_rows reads it as one value per sample
+    (g_fm_cols = 1): same table gradient as the oracle, and as the full-row path on the materialised gradient -- through
+    the bucket walk, the hot-row queue (``hot``), the any-E element path (E = 10) and the fused optimizer."""
+    from torecsys_amd import functional as F_
+    from torecsys_amd.optim import FusedSparseSGD
+    fs, idx, w, _, g = _rand_case(B, N, E, Vf, 321 + B + E, dtype, hot)
+    off = O.field_offsets(fs)
+    ge = torch.randn(B, N, E, generator=g).to(dtype)
+    g1 = torch.randn(B, 1, generator=g).to(dtype)
+    wr = w.float().clone().requires_grad_()
+    emb_r = O.multi_indices_embedding(wr, idx, off)
+    ((emb_r * ge.float()).sum() + (O.fm_layer(emb_r).sum(dim=1, keepdim=True) * g1.float()).sum()).backward()
+
+    def run(expand, opt=None):
+        wd = w.to(dev).clone().requires_grad_()
+        emb, fm, _ = F_.embed_fm(wd, idx.to(dev), off.to(dev), None, True, opt)
+        gfm = g1.to(dev).expand(B, E)
+        gfm = gfm if expand else gfm.contiguous()
+        torch.autograd.backward([emb, fm], [ge.to(dev), gfm])
+        return wd
+    assert F_._fm_grad_operand(g1.to(dev).expand(B, E)).shape == (B, 1)
+    got = run(True).grad.float().cpu()
+    assert rel_err(got, wr.grad) <= tol
+    full = run(False).grad.float().cpu()
+    assert rel_err(got, full) <= (1e-6 if dtype == torch.float32 else 8e-3)      # same sums, g*S rounded once either way
+    wd = run(True, FusedSparseSGD(0.5))                                           # applied in place by the fused optimizer
+    assert wd.grad is None
+    assert rel_err(wd.detach().float().cpu(), w.float() - 0.5 * wr.grad) <= tol
+
+
 def test_out_of_range_lookup_is_sanitised_and_reported_lazily(dev):
     """without TRS_CHECK_INDICES the kernels still range-check: an out-of-range lookup reads as a zero row, gets no
     gradient, and functional.index_errors_seen() reports it afterwards (no host read-back inside the lookup)"""

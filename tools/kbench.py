@@ -95,6 +95,9 @@ def main():
         report("scatter_rows (g_rows)", t, B * N * (E * s + 4) + V * E * s + V * 4)
         t = timeit(lambda: F_.scatter_rows(rb, w, g_rows=ge, g_bcast=gf, fm_sum=S))
         report("scatter_rows (g_rows + fm)", t, B * N * (E * s + 4) + V * E * s * 2 + V * 4)
+        g1 = gf[:, :1].contiguous()
+        t = timeit(lambda: F_.scatter_rows(rb, w, g_rows=ge, g_bcast=g1, fm_sum=S))
+        report("scatter_rows (g_rows + fm, g constant along E)", t, B * N * (E * s + 4) + V * E * s * 2 + V * 4)
         t = timeit(lambda: F_.scatter_rows(rb, w1, g_bcast=gf[:, :1].contiguous()))
         report("scatter_rows (first-order E=1)", t, B * N * (4) + V * s + V * 4)
     if want("cross"):

@@ -65,12 +65,12 @@ SIGNATURES = {
     "trs_csr_workspace_bytes": (_SZ, [_I64, _I64]),
     "trs_csr_build": (c_int32, [_P, _I32, _P, _I64, _I32, _I64, _P, _P, _P, _SZ, _P, _P]),
     "trs_scatter_workspace_bytes": (_SZ, [_I64, _I32, _I32, _I32]),
-    "trs_scatter_rows": (c_int32, [_P, _I64, _P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _I64, _P, _P, _SZ, _P]),
-    "trs_scatter_rows_first": (c_int32, [_P, _I64, _P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _I64, _P, _P, _P, _P,
+    "trs_scatter_rows": (c_int32, [_P, _I64, _P, _I32, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _I64, _P, _P, _SZ, _P]),
+    "trs_scatter_rows_first": (c_int32, [_P, _I64, _P, _I32, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _I64, _P, _P, _P, _P,
                                          _SZ, _P]),
-    "trs_scatter_rows_update": (c_int32, [_P, _I64, _P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _I64, _I32,
+    "trs_scatter_rows_update": (c_int32, [_P, _I64, _P, _I32, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _I64, _I32,
                                           ctypes.c_float, ctypes.c_float, _P, _P, _SZ, _P]),
-    "trs_scatter_rows_update_adam": (c_int32, [_P, _I64, _P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _I64,
+    "trs_scatter_rows_update_adam": (c_int32, [_P, _I64, _P, _I32, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _I64,
                                                ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P, _P,
                                                _P, _SZ, _P]),
     "trs_scatter_rows_update_mapped": (c_int32, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _I32, ctypes.c_float,

@@ -363,12 +363,23 @@ __device__ __forceinline__ void sink_elem(const RowSink& k, T* __restrict__ out,
 // to a queue and reduced by whole workgroups afterwards)
 // HAS_F1: a companion E = 1 table (the first-order term of the same lookups) rides in the same walk: g_first holds one
 // value per lookup (B*N), every lane of the group adds the same ones into *f1
+// Where the FM term of a lookup of sample b is read from (16-byte vectors, table dtype): t[b*tstr + lane] = g*S and
+// g[b*gstr + (gstr > 1 ? lane : 0)] = g.  Full g_fm rows: one [g*S | g] row of 2L vectors per sample (tstr = gstr = 2L,
+// g = t + L).  g_fm constant along E (the gradient of a sum over E, what the reference's FM / DeepFM models feed back):
+// g*S rows of L vectors and ONE vector per sample holding g in every element -- 144 instead of 256 bytes per lookup,
+// the g vectors (16 B x B) stay in L2.
+struct FmSrc {
+  const uint4* t;
+  const uint4* g;
+  int tstr, gstr;
+};
+
 template <typename T, int LOG2L, bool HAS_G, bool HAS_FM, int CH = 4, bool HAS_F1 = false>
 __device__ __forceinline__ void accumulate_bucket(float* acc, float* gsum, const uint4* __restrict__ g_rows,
                                                   const uint4* __restrict__ g_fm, const float* __restrict__ fm_sum,
                                                   const int32_t* __restrict__ perm, int beg, int end, int step,
-                                                  int N, int64_t gbs, int lane_v, const T* __restrict__ g_first = nullptr,
-                                                  float* f1 = nullptr) {
+                                                  int N, int64_t gbs, int lane_v, FmSrc fs,
+                                                  const T* __restrict__ g_first = nullptr, float* f1 = nullptr) {
   constexpr int L = 1 << LOG2L;
   constexpr int VE = Vec16<T>::VE;
   // CH lookups in flight per lane; the bucket positions of the NEXT round are fetched while this round's gradient rows
@@ -405,9 +416,9 @@ __device__ __forceinline__ void accumulate_bucket(float* acc, float* gsum, const
         }
         if (HAS_FM) {
           const int64_t b = (int64_t)((unsigned)p[c] / (unsigned)N);
-          if (fm_sum != nullptr) {  // FM mode: g_fm points at TG = [g*S | g] rows of 2*L vectors
-            tv[c] = g_fm[b * 2 * L + lane_v];
-            fv[c] = g_fm[b * 2 * L + L + lane_v];
+          if (fm_sum != nullptr) {  // FM mode: see FmSrc
+            tv[c] = fs.t[b * fs.tstr + lane_v];
+            fv[c] = fs.g[b * fs.gstr + (fs.gstr > 1 ? lane_v : 0)];
           } else {
             fv[c] = g_fm[b * L + lane_v];
           }
@@ -450,7 +461,7 @@ __global__ __launch_bounds__(256) void scatter_rows_group_kernel(
     const uint4* __restrict__ g_rows, const uint4* __restrict__ g_fm, const float* __restrict__ fm_sum,
     const uint4* __restrict__ table, const int32_t* __restrict__ row_start, const int32_t* __restrict__ perm,
     int64_t V, int N, int64_t gbs, int64_t padding_row, uint4* __restrict__ grad,
-    int32_t* __restrict__ long_rows /* [0]=count */, RowSink sink, const T* __restrict__ g_first = nullptr,
+    int32_t* __restrict__ long_rows /* [0]=count */, RowSink sink, FmSrc fs, const T* __restrict__ g_first = nullptr,
     T* __restrict__ grad_first = nullptr) {
   constexpr int L = 1 << LOG2L;
   constexpr int VE = Vec16<T>::VE;
@@ -483,7 +494,7 @@ __global__ __launch_bounds__(256) void scatter_rows_group_kernel(
     float f1 = 0.f;
     if (r != padding_row) {
       accumulate_bucket<T, LOG2L, HAS_G, HAS_FM, (HAS_FM ? 2 : 4), HAS_F1>(acc, gsum, g_rows, g_fm, fm_sum, perm, beg, end, 1, N,
-                                                                       gbs, lane_v, g_first, &f1);
+                                                                       gbs, lane_v, fs, g_first, &f1);
       if (HAS_FM && fm_sum != nullptr && end > beg) {
         float w[VE];
         Vec16<T>::unpack(wraw, w);
@@ -535,7 +546,7 @@ __global__ __launch_bounds__(256) void scatter_long_rows_kernel(
     const uint4* __restrict__ g_rows, const uint4* __restrict__ g_fm, const float* __restrict__ fm_sum,
     const uint4* __restrict__ table, const int32_t* __restrict__ row_start, const int32_t* __restrict__ perm, int N,
     int64_t gbs, uint4* __restrict__ grad, const int32_t* __restrict__ long_rows, float* __restrict__ scratch,
-    RowSink sink) {
+    RowSink sink, FmSrc fs) {
   constexpr int L = 1 << LOG2L;
   constexpr int VE = Vec16<T>::VE;
   constexpr int G = 256 / L;  // groups per workgroup
@@ -552,7 +563,7 @@ __global__ __launch_bounds__(256) void scatter_long_rows_kernel(
     float acc[VE], gsum[VE];
 #pragma unroll
     for (int k = 0; k < VE; ++k) { acc[k] = 0.f; gsum[k] = 0.f; }
-    accumulate_bucket<T, LOG2L, HAS_G, HAS_FM, 8>(acc, gsum, g_rows, g_fm, fm_sum, perm, beg + grp, end, G, N, gbs, lane_v);
+    accumulate_bucket<T, LOG2L, HAS_G, HAS_FM, 8>(acc, gsum, g_rows, g_fm, fm_sum, perm, beg + grp, end, G, N, gbs, lane_v, fs);
 #pragma unroll
     for (int k = 0; k < VE; ++k) { red[0][threadIdx.x][k] = acc[k]; red[1][threadIdx.x][k] = gsum[k]; }
     __syncthreads();
@@ -642,16 +653,34 @@ __global__ __launch_bounds__(256) void build_tg_kernel(const uint4* __restrict__
   }
 }
 
+// g_fm constant along E: T[b] = g[b] * fm_sum[b,:] (L vectors per sample) and gvec[b] = g[b] in every element of one vector
+template <typename T>
+__global__ __launch_bounds__(256) void build_tg1_kernel(const T* __restrict__ g1, const float* __restrict__ fm_sum,
+                                                        uint4* __restrict__ tg, uint4* __restrict__ gvec, int64_t B, int L) {
+  constexpr int VE = Vec16<T>::VE;
+  const int64_t total = B * L, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t b = t / L;
+    const float g = to_f32(g1[b]);
+    float o[VE], gg[VE];
+    const float* sp = fm_sum + t * VE;
+#pragma unroll
+    for (int k = 0; k < VE; ++k) { o[k] = g * sp[k]; gg[k] = g; }
+    tg[t] = Vec16<T>::pack(o);
+    if (t == b * L) gvec[b] = Vec16<T>::pack(gg);
+  }
+}
+
 // generic element path (any E): one thread per (row, e); hot rows are queued like in the group path
 template <typename T>
 __device__ __forceinline__ float elem_term(const T* __restrict__ g_rows, const T* __restrict__ g_fm,
                                            const float* __restrict__ fm_sum, int64_t p, int E, int N, int64_t gbs, int e,
-                                           float* gsum) {
+                                           float* gsum, int gcols) {
   const int64_t b = p / N;
   float acc = 0.f;
   if (g_rows != nullptr) acc += to_f32(g_rows[(b * gbs + (p - b * N)) * E + e]);
   if (g_fm != nullptr) {
-    const float gf = to_f32(g_fm[b * E + e]);
+    const float gf = to_f32(g_fm[gcols == 1 ? b : b * E + e]);
     if (fm_sum != nullptr) {
       acc = fmaf(gf, fm_sum[b * E + e], acc);
       *gsum += gf;
@@ -667,7 +696,7 @@ __global__ __launch_bounds__(256) void scatter_rows_elem_kernel(
     const T* __restrict__ g_rows, const T* __restrict__ g_fm, const float* __restrict__ fm_sum,
     const T* __restrict__ table, const int32_t* __restrict__ row_start, const int32_t* __restrict__ perm, int64_t V,
     int E, int N, int64_t gbs, int64_t padding_row, T* __restrict__ grad, int32_t* __restrict__ long_rows,
-    RowSink sink) {
+    RowSink sink, int gcols) {
   const int64_t total = V * E;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const bool f32 = total < ((int64_t)1 << 32);
@@ -686,7 +715,7 @@ __global__ __launch_bounds__(256) void scatter_rows_elem_kernel(
         }
         continue;
       }
-      for (int q = beg; q < end; ++q) acc += elem_term<T>(g_rows, g_fm, fm_sum, perm[q], E, N, gbs, e, &gsum);
+      for (int q = beg; q < end; ++q) acc += elem_term<T>(g_rows, g_fm, fm_sum, perm[q], E, N, gbs, e, &gsum, gcols);
       if (g_fm != nullptr && fm_sum != nullptr && end > beg) acc = fmaf(-to_f32(table[t]), gsum, acc);
     }
     sink_elem<T>(sink, grad, sink_row(sink, r) * E + e, acc, touched);
@@ -697,7 +726,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void scatter_long_rows_elem_kernel(
     const T* __restrict__ g_rows, const T* __restrict__ g_fm, const float* __restrict__ fm_sum,
     const T* __restrict__ table, const int32_t* __restrict__ row_start, const int32_t* __restrict__ perm, int E, int N,
-    int64_t gbs, T* __restrict__ grad, const int32_t* __restrict__ long_rows, RowSink sink) {
+    int64_t gbs, T* __restrict__ grad, const int32_t* __restrict__ long_rows, RowSink sink, int gcols) {
   // one wave per queued row: lanes stride the bucket, wavefront reduction, no workgroup barriers
   const int nlong = long_rows[0];
   const int lane = threadIdx.x & 63;
@@ -716,7 +745,7 @@ __global__ __launch_bounds__(256) void scatter_long_rows_elem_kernel(
         for (int u = 0; u < U; ++u) pp[u] = (q + 64 * u) < end ? perm[q + 64 * u] : -1;
 #pragma unroll
         for (int u = 0; u < U; ++u)
-          if (pp[u] >= 0) acc += elem_term<T>(g_rows, g_fm, fm_sum, pp[u], E, N, gbs, e, &gsum);
+          if (pp[u] >= 0) acc += elem_term<T>(g_rows, g_fm, fm_sum, pp[u], E, N, gbs, e, &gsum, gcols);
       }
 #pragma unroll
       for (int m = 32; m >= 1; m >>= 1) {
@@ -744,12 +773,21 @@ template <typename T, int LOG2L>
 static void scatter_group_launch(const void* g_rows, const void* g_fm, const float* fm_sum, const void* table,
                                  const int32_t* row_start, const int32_t* perm, int64_t V, int N, int64_t gbs,
                                  int64_t padding_row, void* grad, int32_t* long_rows, void* tg, float* scratch,
-                                 int64_t B, RowSink sink, hipStream_t s, const void* g_first = nullptr,
+                                 int64_t B, RowSink sink, hipStream_t s, int gcols, const void* g_first = nullptr,
                                  void* grad_first = nullptr) {
   const int L = 1 << LOG2L;
+  FmSrc fs{nullptr, nullptr, 0, 0};
   if (g_fm != nullptr && fm_sum != nullptr) {
-    hipLaunchKernelGGL((build_tg_kernel<T>), dim3(stream_grid(B * L, 256, 4096)), dim3(256), 0, s, (const uint4*)g_fm,
-                       fm_sum, (uint4*)tg, B, L);
+    if (gcols == 1 && L > 1) {
+      uint4* gvec = (uint4*)tg + B * L;
+      hipLaunchKernelGGL((build_tg1_kernel<T>), dim3(stream_grid(B * L, 256, 4096)), dim3(256), 0, s, (const T*)g_fm,
+                         fm_sum, (uint4*)tg, gvec, B, L);
+      fs = FmSrc{(const uint4*)tg, gvec, L, 1};
+    } else {
+      hipLaunchKernelGGL((build_tg_kernel<T>), dim3(stream_grid(B * L, 256, 4096)), dim3(256), 0, s, (const uint4*)g_fm,
+                         fm_sum, (uint4*)tg, B, L);
+      fs = FmSrc{(const uint4*)tg, (const uint4*)tg + L, 2 * L, 2 * L};
+    }
     g_fm = tg;
   }
   const int grid = stream_grid(V * L, 256, 256 * 32);
@@ -759,15 +797,15 @@ static void scatter_group_launch(const void* g_rows, const void* g_fm, const flo
     if (g_first != nullptr)                                                                                     \
       hipLaunchKernelGGL((scatter_rows_group_kernel<T, LOG2L, HG, HF, true>), dim3(grid), dim3(256), 0, s,       \
                          (const uint4*)g_rows, (const uint4*)g_fm, fm_sum, (const uint4*)table, row_start, perm, \
-                         V, N, gbs, padding_row, (uint4*)grad, long_rows, sink, (const T*)g_first,               \
+                         V, N, gbs, padding_row, (uint4*)grad, long_rows, sink, fs, (const T*)g_first,           \
                          (T*)grad_first);                                                                        \
     else                                                                                                        \
       hipLaunchKernelGGL((scatter_rows_group_kernel<T, LOG2L, HG, HF>), dim3(grid), dim3(256), 0, s,             \
                          (const uint4*)g_rows, (const uint4*)g_fm, fm_sum, (const uint4*)table, row_start, perm, \
-                         V, N, gbs, padding_row, (uint4*)grad, long_rows, sink);                                 \
+                         V, N, gbs, padding_row, (uint4*)grad, long_rows, sink, fs);                             \
     hipLaunchKernelGGL((scatter_long_rows_kernel<T, LOG2L, HG, HF>), dim3(1024), dim3(256), 0, s,                \
                        (const uint4*)g_rows, (const uint4*)g_fm, fm_sum, (const uint4*)table, row_start, perm, N, \
-                       gbs, (uint4*)grad, long_rows, scratch, sink);                                                  \
+                       gbs, (uint4*)grad, long_rows, scratch, sink, fs);                                              \
     hipLaunchKernelGGL((scatter_long_rows_finish_kernel<T, LOG2L, HF>), dim3(64), dim3(256), 0, s, fm_sum,           \
                        (const uint4*)table, row_start, (uint4*)grad, long_rows, scratch, sink);                       \
   } while (0)
@@ -784,26 +822,29 @@ template <typename T>
 static int scatter_launch(const void* g_rows, const void* g_fm, const float* fm_sum, const void* table,
                           const int32_t* row_start, const int32_t* perm, int64_t V, int E, int N, int64_t gbs,
                           int64_t padding_row, void* grad, int32_t* long_rows, void* tg, float* scratch, int64_t B,
-                          RowSink sink, hipStream_t s, const void* g_first = nullptr, void* grad_first = nullptr) {
+                          RowSink sink, hipStream_t s, int gcols, const void* g_first = nullptr,
+                          void* grad_first = nullptr) {
   const int lg = log2_lanes_sc(E * (int)sizeof(T));
-  const bool al = aligned16(g_rows) && aligned16(g_fm) && aligned16(table) && aligned16(grad) && aligned16(fm_sum);
+  const bool scal = gcols == 1 && E > 1 && fm_sum != nullptr;      // g_fm read as scalars: no alignment requirement
+  const bool al = aligned16(g_rows) && (scal || aligned16(g_fm)) && aligned16(table) && aligned16(grad) && aligned16(fm_sum);
   if (lg >= 0 && al) {
     switch (lg) {
-      case 0: scatter_group_launch<T, 0>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s, g_first, grad_first); break;
-      case 1: scatter_group_launch<T, 1>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s, g_first, grad_first); break;
-      case 2: scatter_group_launch<T, 2>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s, g_first, grad_first); break;
-      case 3: scatter_group_launch<T, 3>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s, g_first, grad_first); break;
-      case 4: scatter_group_launch<T, 4>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s, g_first, grad_first); break;
-      case 5: scatter_group_launch<T, 5>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s, g_first, grad_first); break;
-      default: scatter_group_launch<T, 6>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s, g_first, grad_first); break;
+      case 0: scatter_group_launch<T, 0>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s, gcols, g_first, grad_first); break;
+      case 1: scatter_group_launch<T, 1>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s, gcols, g_first, grad_first); break;
+      case 2: scatter_group_launch<T, 2>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s, gcols, g_first, grad_first); break;
+      case 3: scatter_group_launch<T, 3>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s, gcols, g_first, grad_first); break;
+      case 4: scatter_group_launch<T, 4>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s, gcols, g_first, grad_first); break;
+      case 5: scatter_group_launch<T, 5>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s, gcols, g_first, grad_first); break;
+      default: scatter_group_launch<T, 6>(g_rows, g_fm, fm_sum, table, row_start, perm, V, N, gbs, padding_row, grad, long_rows, tg, scratch, B, sink, s, gcols, g_first, grad_first); break;
     }
   } else {
     if (g_first != nullptr) return 1;   // the companion table rides only in the 16-byte-vector walk
     hipLaunchKernelGGL((scatter_rows_elem_kernel<T>), dim3(stream_grid(V * E, 256, 256 * 32)), dim3(256), 0, s,
                        (const T*)g_rows, (const T*)g_fm, fm_sum, (const T*)table, row_start, perm, V, E, N, gbs,
-                       padding_row, (T*)grad, long_rows, sink);
+                       padding_row, (T*)grad, long_rows, sink, gcols);
     hipLaunchKernelGGL((scatter_long_rows_elem_kernel<T>), dim3(2048), dim3(256), 0, s, (const T*)g_rows,
-                       (const T*)g_fm, fm_sum, (const T*)table, row_start, perm, E, N, gbs, (T*)grad, long_rows, sink);
+                       (const T*)g_fm, fm_sum, (const T*)table, row_start, perm, E, N, gbs, (T*)grad, long_rows, sink,
+                       gcols);
   }
   return check_launch("scatter_rows");
 }
@@ -912,13 +953,15 @@ extern "C" size_t trs_scatter_workspace_bytes(int64_t BN, int32_t N, int32_t E, 
 }
 
 static int scatter_rows_impl(RowSink sink, const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm,
-                                const float* fm_sum, const void* table, const int32_t* row_start,
+                                int32_t g_fm_cols, const float* fm_sum, const void* table, const int32_t* row_start,
                                 const int32_t* perm, int64_t BN, int64_t V, int32_t E, int32_t N, int32_t dtype,
                                 int64_t padding_row, void* grad_table, void* workspace, size_t ws_bytes,
                                 trs_stream_t stream, const void* g_first = nullptr, void* grad_first = nullptr) {
   TRS_REQUIRE(row_start && perm && grad_table && workspace, TRS_EINVAL, "scatter_rows: NULL pointer");
   TRS_REQUIRE(g_rows || g_fm, TRS_EINVAL, "scatter_rows: need g_rows and/or g_fm");
   TRS_REQUIRE((fm_sum == nullptr) || (g_fm && table), TRS_EINVAL, "scatter_rows: fm_sum needs g_fm and table");
+  TRS_REQUIRE(g_fm == nullptr || g_fm_cols == E || (g_fm_cols == 1 && fm_sum != nullptr), TRS_EINVAL,
+              "scatter_rows: g_fm_cols %d (E = %d full rows, or 1 = constant along E with fm_sum)", g_fm_cols, E);
   const int64_t gbs = g_rows_batch_stride > 0 ? g_rows_batch_stride : N;
   TRS_REQUIRE(gbs >= N, TRS_EINVAL, "scatter_rows: g_rows_batch_stride %lld < N", (long long)gbs);
   TRS_REQUIRE(V > 0 && E > 0 && N > 0 && BN >= 0, TRS_EINVAL, "scatter_rows: bad size");
@@ -935,35 +978,36 @@ static int scatter_rows_impl(RowSink sink, const void* g_rows, int64_t g_rows_ba
   int rc;
   if (dtype == TRS_F32)
     rc = scatter_launch<float>(g_rows, g_fm, fm_sum, table, row_start, perm, V, E, N, gbs, padding_row, grad_table,
-                               long_rows, tg, scratch, B, sink, s, g_first, grad_first);
+                               long_rows, tg, scratch, B, sink, s, g_fm_cols, g_first, grad_first);
   else
     rc = scatter_launch<bf16_t>(g_rows, g_fm, fm_sum, table, row_start, perm, V, E, N, gbs, padding_row, grad_table,
-                                long_rows, tg, scratch, B, sink, s, g_first, grad_first);
+                                long_rows, tg, scratch, B, sink, s, g_fm_cols, g_first, grad_first);
   if (rc == 1) return fail(TRS_ESHAPE, "scatter_rows_first: rows must be whole 16-byte vectors (E*sizeof %% 16 == 0)");
   return rc;
 }
 
 /* see include/trs_abi.h: the dense gradients of an embedding table AND of its first-order (E = 1) companion in one walk */
-extern "C" int trs_scatter_rows_first(const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm,
+extern "C" int trs_scatter_rows_first(const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm, int32_t g_fm_cols,
                                       const float* fm_sum, const void* table, const int32_t* row_start,
                                       const int32_t* perm, int64_t BN, int64_t V, int32_t E, int32_t N, int32_t dtype,
                                       int64_t padding_row, void* grad_table, const void* g_first, void* grad_first,
                                       void* workspace, size_t ws_bytes, trs_stream_t stream) {
   TRS_REQUIRE(g_first && grad_first, TRS_EINVAL, "scatter_rows_first: NULL first-order pointer");
-  return scatter_rows_impl(RowSink{0, 0.f, 0.f, nullptr}, g_rows, g_rows_batch_stride, g_fm, fm_sum, table, row_start,
+  return scatter_rows_impl(RowSink{0, 0.f, 0.f, nullptr}, g_rows, g_rows_batch_stride, g_fm, g_fm_cols, fm_sum, table, row_start,
                            perm, BN, V, E, N, dtype, padding_row, grad_table, workspace, ws_bytes, stream, g_first,
                            grad_first);
 }
 
-extern "C" int trs_scatter_rows(const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm, const float* fm_sum,
+extern "C" int trs_scatter_rows(const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm, int32_t g_fm_cols,
+                                const float* fm_sum,
                                 const void* table, const int32_t* row_start, const int32_t* perm, int64_t BN, int64_t V,
                                 int32_t E, int32_t N, int32_t dtype, int64_t padding_row, void* grad_table,
                                 void* workspace, size_t ws_bytes, trs_stream_t stream) {
-  return scatter_rows_impl(RowSink{0, 0.f, 0.f, nullptr}, g_rows, g_rows_batch_stride, g_fm, fm_sum, table, row_start,
+  return scatter_rows_impl(RowSink{0, 0.f, 0.f, nullptr}, g_rows, g_rows_batch_stride, g_fm, g_fm_cols, fm_sum, table, row_start,
                            perm, BN, V, E, N, dtype, padding_row, grad_table, workspace, ws_bytes, stream);
 }
 
-extern "C" int trs_scatter_rows_update(const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm,
+extern "C" int trs_scatter_rows_update(const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm, int32_t g_fm_cols,
                                        const float* fm_sum, void* table, const int32_t* row_start, const int32_t* perm,
                                        int64_t BN, int64_t V, int32_t E, int32_t N, int32_t dtype, int64_t padding_row,
                                        int32_t optimizer, float lr, float eps, float* state, void* workspace,
@@ -972,11 +1016,11 @@ extern "C" int trs_scatter_rows_update(const void* g_rows, int64_t g_rows_batch_
   TRS_REQUIRE(optimizer == 1 || optimizer == 2, TRS_EINVAL, "scatter_rows_update: optimizer %d (1 = SGD, 2 = Adagrad)",
               optimizer);
   TRS_REQUIRE(optimizer == 1 || state != nullptr, TRS_EINVAL, "scatter_rows_update: Adagrad needs the state buffer");
-  return scatter_rows_impl(RowSink{optimizer, lr, eps, state}, g_rows, g_rows_batch_stride, g_fm, fm_sum, table,
+  return scatter_rows_impl(RowSink{optimizer, lr, eps, state}, g_rows, g_rows_batch_stride, g_fm, g_fm_cols, fm_sum, table,
                            row_start, perm, BN, V, E, N, dtype, padding_row, table, workspace, ws_bytes, stream);
 }
 
-extern "C" int trs_scatter_rows_update_adam(const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm,
+extern "C" int trs_scatter_rows_update_adam(const void* g_rows, int64_t g_rows_batch_stride, const void* g_fm, int32_t g_fm_cols,
                                             const float* fm_sum, void* table, const int32_t* row_start,
                                             const int32_t* perm, int64_t BN, int64_t V, int32_t E, int32_t N,
                                             int32_t dtype, int64_t padding_row, float step_size, float beta1,
@@ -989,7 +1033,7 @@ extern "C" int trs_scatter_rows_update_adam(const void* g_rows, int64_t g_rows_b
   sink.beta1 = beta1;
   sink.beta2 = beta2;
   sink.state2 = exp_avg_sq;
-  return scatter_rows_impl(sink, g_rows, g_rows_batch_stride, g_fm, fm_sum, table, row_start, perm, BN, V, E, N, dtype,
+  return scatter_rows_impl(sink, g_rows, g_rows_batch_stride, g_fm, g_fm_cols, fm_sum, table, row_start, perm, BN, V, E, N, dtype,
                            padding_row, table, workspace, ws_bytes, stream);
 }
 
@@ -1009,6 +1053,6 @@ extern "C" int trs_scatter_rows_update_mapped(const void* g_rows, void* table, c
   sink.beta2 = beta2;
   sink.state2 = state2;
   sink.row_map = row_map;
-  return scatter_rows_impl(sink, g_rows, 0, nullptr, nullptr, table, row_start, perm, K, U, E, 1, dtype, -1, table,
+  return scatter_rows_impl(sink, g_rows, 0, nullptr, 0, nullptr, table, row_start, perm, K, U, E, 1, dtype, -1, table,
                            workspace, ws_bytes, stream);
 }

@@ -96,7 +96,7 @@ class HipOps:
         if g_fm is not None:
             # lookups per sample: the FM operands are indexed by sample = lookup // N
             rb = F_.RowBuckets(rb.row_start, rb.perm, rb.V, rb.BN, K // g_fm.shape[0])
-            return F_.scatter_rows(rb, rows, g_rows=gb, g_bcast=g_fm.contiguous(), fm_sum=fm_sum)
+            return F_.scatter_rows(rb, rows, g_rows=gb, g_bcast=F_._fm_grad_operand(g_fm), fm_sum=fm_sum)
         return F_.scatter_rows(rb, rows, g_rows=gb)
 
     def shard_update(self, weight: torch.Tensor, ids: torch.Tensor, grad_rows: torch.Tensor, opt, dense_index: bool):

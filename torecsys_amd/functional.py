@@ -246,6 +246,21 @@ def pack_columns(cols: Sequence[torch.Tensor], out_dtype: Optional[torch.dtype] 
     return out
 
 
+def _bcast_cols(g_bcast: Optional[torch.Tensor], E: int) -> int:
+    """trs_scatter_rows' g_fm_cols: E for full (B,E) rows, 1 for one value per sample ((B,) or (B,1) with E > 1)"""
+    if g_bcast is None:
+        return E
+    return 1 if (g_bcast.dim() == 1 or g_bcast.shape[-1] == 1) else E
+
+
+def _fm_grad_operand(g_fm: torch.Tensor) -> torch.Tensor:
+    """The FM gradient as trs_scatter_rows wants it: an expanded (B,1) -> (B,E) gradient (what a ``sum`` over E feeds
+    back) is passed as its (B,1) column -- the kernel then reads one value per sample instead of a row of E"""
+    if g_fm.dim() == 2 and g_fm.shape[1] > 1 and g_fm.stride(1) == 0:
+        return g_fm[:, :1].contiguous()
+    return g_fm.contiguous()
+
+
 def scatter_rows(rb: RowBuckets, like_table: torch.Tensor, g_rows: Optional[torch.Tensor] = None,
                  g_bcast: Optional[torch.Tensor] = None, fm_sum: Optional[torch.Tensor] = None,
                  padding_row: int = -1, g_rows_batch_stride: int = 0) -> torch.Tensor:
@@ -254,7 +269,7 @@ def scatter_rows(rb: RowBuckets, like_table: torch.Tensor, g_rows: Optional[torc
     grad = torch.empty_like(like_table)
     ws_bytes = size_query("trs_scatter_workspace_bytes", rb.BN, rb.N, E, value_dtype_code(like_table))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=like_table.device)
-    call("trs_scatter_rows", ptr(g_rows), g_rows_batch_stride, ptr(g_bcast), ptr(fm_sum),
+    call("trs_scatter_rows", ptr(g_rows), g_rows_batch_stride, ptr(g_bcast), _bcast_cols(g_bcast, E), ptr(fm_sum),
          ptr(like_table if fm_sum is not None else None), ptr(rb.row_start), ptr(rb.perm), rb.BN, V, E, rb.N,
          value_dtype_code(like_table), padding_row, ptr(grad), ptr(ws), ws_bytes, stream_ptr())
     return grad
@@ -271,7 +286,7 @@ def scatter_rows_first(rb: RowBuckets, like_table: torch.Tensor, like_first: tor
     gfirst = torch.empty_like(like_first)
     ws_bytes = size_query("trs_scatter_workspace_bytes", rb.BN, rb.N, E, value_dtype_code(like_table))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=like_table.device)
-    call("trs_scatter_rows_first", ptr(g_rows), 0, ptr(g_bcast), ptr(fm_sum),
+    call("trs_scatter_rows_first", ptr(g_rows), 0, ptr(g_bcast), _bcast_cols(g_bcast, E), ptr(fm_sum),
          ptr(like_table if fm_sum is not None else None), ptr(rb.row_start), ptr(rb.perm), rb.BN, V, E, rb.N,
          value_dtype_code(like_table), padding_row, ptr(grad), ptr(g_first), ptr(gfirst), ptr(ws), ws_bytes, stream_ptr())
     return grad, gfirst
@@ -295,12 +310,14 @@ def scatter_rows_update(rb: RowBuckets, table: torch.Tensor, opt, g_rows: Option
                                "correction is a host-side scalar); use FusedSparseSGD / FusedSparseAdagrad under "
                                "GraphedStep, or run the Adam step eagerly")
         m1, m2 = opt.state_for(table, key)
-        call("trs_scatter_rows_update_adam", ptr(g_rows), 0, ptr(g_bcast), ptr(fm_sum), ptr(table), ptr(rb.row_start),
+        call("trs_scatter_rows_update_adam", ptr(g_rows), 0, ptr(g_bcast), _bcast_cols(g_bcast, E), ptr(fm_sum), ptr(table),
+             ptr(rb.row_start),
              ptr(rb.perm), rb.BN, V, E, rb.N, value_dtype_code(table), padding_row, float(opt.next_step_size(table, key)),
              float(opt.beta1), float(opt.beta2), float(opt.eps), ptr(m1), ptr(m2), ptr(ws), ws_bytes, stream_ptr())
         return
     state = opt.state_for(table, key)
-    call("trs_scatter_rows_update", ptr(g_rows), 0, ptr(g_bcast), ptr(fm_sum), ptr(table), ptr(rb.row_start),
+    call("trs_scatter_rows_update", ptr(g_rows), 0, ptr(g_bcast), _bcast_cols(g_bcast, E), ptr(fm_sum), ptr(table),
+         ptr(rb.row_start),
          ptr(rb.perm), rb.BN, V, E, rb.N, value_dtype_code(table), padding_row, opt.kind, float(opt.lr), float(opt.eps),
          ptr(state), ptr(ws), ws_bytes, stream_ptr())
 
@@ -444,13 +461,13 @@ class _EmbedFM(Function):
                 and ctx.needs_input_grad[0] and ctx.needs_input_grad[3] and (E * weight.element_size()) % 16 == 0):
             gw, gfw = scatter_rows_first(rb, weight, first_weight, g_first.contiguous(),
                                          g_rows=g_emb.contiguous() if has_emb else None,
-                                         g_bcast=g_fm.contiguous() if has_fm else None,
+                                         g_bcast=_fm_grad_operand(g_fm) if has_fm else None,
                                          fm_sum=fm_sum if has_fm else None)
             return gw, None, None, gfw, None, None, None
         if ctx.needs_input_grad[0]:
             if has_emb or has_fm:
                 gw = _apply_or_grad(rb, weight, ctx.opt, g_rows=g_emb.contiguous() if has_emb else None,
-                                    g_bcast=g_fm.contiguous() if has_fm else None, fm_sum=fm_sum if has_fm else None)
+                                    g_bcast=_fm_grad_operand(g_fm) if has_fm else None, fm_sum=fm_sum if has_fm else None)
             elif ctx.opt is None:
                 gw = torch.zeros_like(weight)
         if first_weight is not None and ctx.needs_input_grad[3]:
