@@ -18,7 +18,10 @@ __global__ __launch_bounds__(512) void k(char* base, int iters, size_t region) {
       } else {                 // contiguous: store index s = j*8 + wave, 1 KB each
         off = ((size_t)(j * 8 + wave) * 64 + lane) * 16;
       }
-      if (NT) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(tile + off), "v"(v) : "memory");
+      if (NT == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(tile + off), "v"(v) : "memory");
+      else if (NT == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(tile + off), "v"(v) : "memory");
+      else if (NT == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(tile + off), "v"(v) : "memory");
+      else if (NT == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(tile + off), "v"(v) : "memory");
       else asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(tile + off), "v"(v) : "memory");
     }
     v.x += 1;
@@ -32,13 +35,12 @@ int main() {
   hipEventCreate(&e0); hipEventCreate(&e1);
   const int iters = 200;
   for (int pat = 0; pat < 2; ++pat)
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < 5; ++nt)
       for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0);
-        if (pat == 0 && nt == 0) k<0, 0><<<256, 512>>>(d, iters, region);
-        if (pat == 0 && nt == 1) k<0, 1><<<256, 512>>>(d, iters, region);
-        if (pat == 1 && nt == 0) k<1, 0><<<256, 512>>>(d, iters, region);
-        if (pat == 1 && nt == 1) k<1, 1><<<256, 512>>>(d, iters, region);
+#define LAUNCH(P, N) if (pat == P && nt == N) k<P, N><<<256, 512>>>(d, iters, region);
+        LAUNCH(0, 0) LAUNCH(0, 1) LAUNCH(0, 2) LAUNCH(0, 3) LAUNCH(0, 4)
+        LAUNCH(1, 0) LAUNCH(1, 1) LAUNCH(1, 2) LAUNCH(1, 3) LAUNCH(1, 4)
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
