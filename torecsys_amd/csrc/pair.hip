@@ -344,35 +344,66 @@ __global__ __launch_bounds__(256) void pair_dot_bwd_mfma_kernel(const bf16_t* __
   __syncthreads();   // lut complete (block-wide), zero fill visible
   const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  // A wave works through its samples one at a time, and a sample is a chain of dependent latencies (its gradient row
+  // and its x block from HBM, the LDS images, the fragments): the raw data of the NEXT sample is requested while this
+  // one is processed -- hand-written loads (the compiler moves ordinary ones to their first use), waited for after
+  // the MFMAs and before the stores of this sample, so that the wait covers the prefetch only (236 -> 164 us at the
+  // BASELINE shape).  Every lane issues every load (addresses clamped): a branch around an asm load makes the compiler
+  // copy its destination register while the load is still in flight.
+  constexpr int GR = (NP * (NP - 1) / 2 + 63) / 64;      // gradient values per lane (upper bound from the padded N)
+  constexpr int XR = (NP * (EC / 8) + 63) / 64;          // 16-byte x vectors per lane
+  typedef __attribute__((ext_vector_type(4))) unsigned pd_u32x4;
+  unsigned gcur[GR], gnxt[GR];
+  pd_u32x4 xcur[XR], xnxt[XR];
+  const int nxv = N * (EC / 8);
+#define TRS_PD_FETCH(gd, xd, bb)                                                                        \
+  _Pragma("unroll") for (int u = 0; u < GR; ++u) {                                                      \
+    const int pp = lane + 64 * u;                                                                       \
+    const bf16_t* a_ = g + (bb) * P + (pp < P ? pp : P - 1);                                            \
+    asm volatile("global_load_ushort %0, %1, off" : "=v"(gd[u]) : "v"(a_));                             \
+  }                                                                                                     \
+  _Pragma("unroll") for (int u = 0; u < XR; ++u) {                                                      \
+    const int v = lane + 64 * u;                                                                        \
+    const int vv = v < nxv ? v : nxv - 1;                                                               \
+    const bf16_t* a_ = x + ((bb) * N) * (int64_t)E + 8 * vv;       /* the sample's block is contiguous */ \
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xd[u]) : "v"(a_));                            \
+  }
+#define TRS_PD_COMMIT(gd, xd)                                                     \
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                \
+  _Pragma("unroll") for (int u = 0; u < GR; ++u) asm volatile("" : "+v"(gd[u]));  \
+  _Pragma("unroll") for (int u = 0; u < XR; ++u) asm volatile("" : "+v"(xd[u]));
+  if (wid < B) {
+    TRS_PD_FETCH(gcur, xcur, wid)
+    TRS_PD_COMMIT(gcur, xcur)
+  }
   for (int64_t b = wid; b < B; b += nwaves) {
+    const int64_t bn = b + nwaves < B ? b + nwaves : b;
+    TRS_PD_FETCH(gnxt, xnxt, bn)
+    __builtin_amdgcn_sched_barrier(0);
     {
-      const bf16_t* gb = g + b * P;
-      for (int p0 = lane; p0 < P; p0 += 256) {              // 4 independent coalesced loads in flight per lane
-        unsigned short v[4], ij[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int pp = p0 + 64 * u;
-          v[u] = pp < P ? gb[pp].v : (unsigned short)0;
-          ij[u] = pp < P ? lut[pp] : (unsigned short)0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (p0 + 64 * u < P) {
-            const int i = ij[u] >> 8, j = ij[u] & 255;
-            Gs[i * GS + j] = v[u];
-            Gs[j * GS + i] = v[u];
-          }
+      for (int u = 0; u < GR; ++u) {
+        const int pp = lane + 64 * u;
+        if (pp < P) {
+          const unsigned ij = lut[pp];
+          const int i = ij >> 8, j = ij & 255;
+          Gs[i * GS + j] = (unsigned short)gcur[u];
+          Gs[j * GS + i] = (unsigned short)gcur[u];
         }
       }
-      for (int v = lane; v < N * (EC / 8); v += 64) {
-        const int row = v / (EC / 8), c8 = v - row * (EC / 8);
-        const uint4 xv = *reinterpret_cast<const uint4*>(x + (b * N + row) * (int64_t)E + 8 * c8);
-        const unsigned w[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
-        for (int k = 0; k < 8; ++k) XT[(8 * c8 + k) * XTS + row] = (unsigned short)(w[k >> 1] >> (16 * (k & 1)));
+      for (int u = 0; u < XR; ++u) {
+        const int v = lane + 64 * u;
+        if (v < nxv) {
+          const int row = v / (EC / 8), c8 = v - row * (EC / 8);
+          const unsigned w[4] = {xcur[u][0], xcur[u][1], xcur[u][2], xcur[u][3]};
+#pragma unroll
+          for (int k = 0; k < 8; ++k) XT[(8 * c8 + k) * XTS + row] = (unsigned short)(w[k >> 1] >> (16 * (k & 1)));
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
+    uint4 res[KE / 2][NT];             // dx of the sample, held until the prefetch has been waited for
     {
       uint4 Bg[NT][KJ];                  // Gs fragments: field i = 16 ti + r, j run 32 kj + 8 q
 #pragma unroll
@@ -399,16 +430,28 @@ __global__ __launch_bounds__(256) void pair_dot_bwd_mfma_kernel(const bf16_t* __
               acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pd_bf16x8, Ax[h][kj]),
                                                                __builtin_bit_cast(pd_bf16x8, Bg[ti][kj]), acc[h], 0, 0, 0);
           }
-          const int i = 16 * ti + r;
-          if (i < N) {
-            const float run[8] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3], acc[1][0], acc[1][1], acc[1][2], acc[1][3]};
-            *reinterpret_cast<uint4*>(dx + (b * N + i) * (int64_t)E + 32 * u + 8 * q) = Vec16<bf16_t>::pack(run);
-          }
+          const float run[8] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3], acc[1][0], acc[1][1], acc[1][2], acc[1][3]};
+          res[u][ti] = Vec16<bf16_t>::pack(run);
         }
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    TRS_PD_COMMIT(gnxt, xnxt)
+#pragma unroll
+    for (int u = 0; u < GR; ++u) gcur[u] = gnxt[u];
+#pragma unroll
+    for (int u = 0; u < XR; ++u) xcur[u] = xnxt[u];
+#pragma unroll
+    for (int u = 0; u < KE / 2; ++u)
+#pragma unroll
+      for (int ti = 0; ti < NT; ++ti) {
+        const int i = 16 * ti + r;
+        if (i < N) *reinterpret_cast<uint4*>(dx + (b * N + i) * (int64_t)E + 32 * u + 8 * q) = res[u][ti];
+      }
     __builtin_amdgcn_wave_barrier();   // the next sample overwrites Gs / XT
   }
+#undef TRS_PD_FETCH
+#undef TRS_PD_COMMIT
 }
 
 static bool pair_mfma_ok(int N, int E) { return N >= 2 && N <= 64 && (E == 32 || E == 64 || E == 128); }
