@@ -142,6 +142,29 @@ __global__ __launch_bounds__(256) void cross_mfma_fwd_kernel(const uint4* __rest
   const int64_t ngroups = (rows + 16 * TP - 1) / (16 * TP);
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  // The rows of the NEXT group are requested while this one runs through its L layers: a group is one dependent chain
+  // (load -> L x (MFMAs -> epilogue) -> store) and only three waves share a SIMD (the resident W fragments take 48 KB of
+  // LDS per workgroup).  Hand-issued loads, addresses clamped into the tensor (every lane issues every load), waited
+  // for after the last layer and before this group's stores.
+  typedef __attribute__((ext_vector_type(4))) unsigned cx_u32x4;
+  cx_u32x4 nxt[TP][KS];
+#define TRS_CX_FETCH(g_)                                                                              \
+  _Pragma("unroll") for (int t = 0; t < TP; ++t) {                                                    \
+    int64_t rr_ = ((g_) * TP + t) * 16 + r;                                                           \
+    rr_ = rr_ < rows ? rr_ : rows - 1;                                                                \
+    _Pragma("unroll") for (int c = 0; c < KS; ++c) {                                                  \
+      const uint4* a_ = x + ((rr_ * E + 32 * c + 8 * q) >> 3);                                        \
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nxt[t][c]) : "v"(a_));                    \
+    }                                                                                                 \
+  }
+#define TRS_CX_COMMIT()                                                                               \
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                    \
+  _Pragma("unroll") for (int t = 0; t < TP; ++t)                                                      \
+    _Pragma("unroll") for (int c = 0; c < KS; ++c) asm volatile("" : "+v"(nxt[t][c]));
+  if (wave < ngroups) {
+    TRS_CX_FETCH(wave)
+    TRS_CX_COMMIT()
+  }
   for (int64_t grp = wave; grp < ngroups; grp += nwaves) {
     XTile<NT> x0[TP], cur[TP];
     uint4 B[TP][KS];
@@ -149,8 +172,25 @@ __global__ __launch_bounds__(256) void cross_mfma_fwd_kernel(const uint4* __rest
 #pragma unroll
     for (int t = 0; t < TP; ++t) {
       row[t] = (grp * TP + t) * 16 + r;
-      load_tile<NT>(x, row[t], rows, E, q, x0[t], B[t]);
+#pragma unroll
+      for (int c = 0; c < KS; ++c) {
+        uint4 u = make_uint4(nxt[t][c][0], nxt[t][c][1], nxt[t][c][2], nxt[t][c][3]);
+        if (row[t] >= rows) u = make_uint4(0, 0, 0, 0);
+        B[t][c] = u;
+        float f[8];
+        Vec16<bf16_t>::unpack(u, f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          x0[t].v[2 * c][i] = f[i];
+          x0[t].v[2 * c + 1][i] = f[4 + i];
+        }
+      }
     }
+    {
+      const int64_t gn = grp + nwaves < ngroups ? grp + nwaves : grp;
+      TRS_CX_FETCH(gn)
+    }
+    __builtin_amdgcn_sched_barrier(0);
     for (int l = 0; l < L; ++l) {
       f32x4 acc[TP][NT];
       layer_matmul<NT, TP>(Wl + (size_t)l * FRAG_PER_LAYER, bl + l * E, B, lane, q, acc);
@@ -163,6 +203,8 @@ __global__ __launch_bounds__(256) void cross_mfma_fwd_kernel(const uint4* __rest
         pack_tile<NT>(cur[t], B[t]);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    TRS_CX_COMMIT()
 #pragma unroll
     for (int t = 0; t < TP; ++t) {
       if (row[t] < rows) {
@@ -171,6 +213,8 @@ __global__ __launch_bounds__(256) void cross_mfma_fwd_kernel(const uint4* __rest
       }
     }
   }
+#undef TRS_CX_FETCH
+#undef TRS_CX_COMMIT
 }
 
 // ---------------------------------------------------------------------------------------------
