@@ -341,8 +341,7 @@ int trs_gather_by_pos(const void* rows, const int32_t* pos, int64_t K, int32_t E
 
 /* ---- Linear with one output unit (the logit layer of the DeepFM / xDeepFM MLP, multilayer_perceptron.py:51) -------
  * out[r] = h[r,:] . w + bias[0]: a row-wise dot product, not a GEMM.  h (rows, C), w (C); C * sizeof(T) / 16 must be
- * a power of two <= 64.  bwd: gh (rows, C) = g[r] * w (may be NULL); gw (C), gb (1) fp32 ACCUMULATED into (both or
- * neither).                                                                                                          */
+ * a power of two <= 64.  bwd: gh (rows, C) = g[r] * w (may be NULL); gw (C), gb (1) fp32, written (both or neither). */
 int trs_rowdot_fwd(const void* h, const void* w, const void* bias, int64_t rows, int32_t C, int32_t dtype, void* out,
                    trs_stream_t stream);
 size_t trs_rowdot_bwd_workspace_bytes(int64_t rows, int32_t C);

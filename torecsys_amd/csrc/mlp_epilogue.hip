@@ -232,11 +232,11 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const T* __restrict__ g
   }
 }
 
-__global__ void rowdot_accumulate_kernel(const float* __restrict__ tmp, int C, float* __restrict__ gw,
+__global__ void rowdot_finish_kernel(const float* __restrict__ tmp, int C, float* __restrict__ gw,
                                          float* __restrict__ gb) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < C) gw[c] += tmp[c];
-  else if (c == C) gb[0] += tmp[C];
+  if (c < C) gw[c] = tmp[c];
+  else if (c == C) gb[0] = tmp[C];
 }
 
 static int rowdot_fwd_blocks(int64_t rows, int lpr) {      // no partial buffer to bound the forward's grid
@@ -379,7 +379,7 @@ extern "C" int trs_rowdot_bwd(const void* g, const void* h, const void* w, int64
     float* tmp = part + (size_t)grid * (C + 1);          // C+1 floats behind the partials (inside the 1024-block budget)
     if (grid >= 1024) return fail(TRS_EWORKSPACE, "rowdot_bwd: internal workspace layout");
     hipLaunchKernelGGL(colsum_partials_kernel, dim3((C + 1 + 15) / 16), dim3(256), 0, s, part, grid, C + 1, tmp);
-    hipLaunchKernelGGL(rowdot_accumulate_kernel, dim3((C + 1 + 255) / 256), dim3(256), 0, s, tmp, C, gw, gb);
+    hipLaunchKernelGGL(rowdot_finish_kernel, dim3((C + 1 + 255) / 256), dim3(256), 0, s, tmp, C, gw, gb);
   }
   return check_launch("rowdot_bwd");
 }

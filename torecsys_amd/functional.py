@@ -1463,13 +1463,14 @@ class _RowDot(Function):
         g2 = g.reshape(-1).contiguous()
         need_h, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])
         gh = torch.empty_like(h2) if need_h else None
-        gw = torch.zeros(C + 1, dtype=torch.float32, device=h2.device) if need_w else None
+        gw = torch.empty(C + 1, dtype=torch.float32, device=h2.device) if need_w else None
         ws_bytes = size_query("trs_rowdot_bwd_workspace_bytes", rows, C)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=h2.device) if need_w else None
         call("trs_rowdot_bwd", ptr(g2), ptr(h2), ptr(W), rows, C, value_dtype_code(h2), ptr(gh),
              ptr(gw), ptr(gw[C:]) if need_w else ptr(None), ptr(ws), ws_bytes if need_w else 0, stream_ptr())
-        g_weight = gw[:wshape[1]].to(wdt).reshape(wshape) if (need_w and ctx.needs_input_grad[1]) else None
-        g_bias = gw[C:].to(wdt) if (need_w and has_bias and ctx.needs_input_grad[2]) else None
+        gq = gw.to(wdt) if need_w else None                      # one cast for weight row and bias
+        g_weight = gq[:wshape[1]].reshape(wshape) if (need_w and ctx.needs_input_grad[1]) else None
+        g_bias = gq[C:] if (need_w and has_bias and ctx.needs_input_grad[2]) else None
         return (gh.reshape(hshape) if need_h else None), g_weight, g_bias, None, None
 
 

@@ -727,16 +727,18 @@ class _MLPStack(torch.autograd.Function):
                 gwf = ws = None
                 ws_bytes = 0
                 if need_w or need_b:
-                    gwf = torch.zeros(C + 1, dtype=torch.float32, device=xin.device)
+                    gwf = torch.empty(C + 1, dtype=torch.float32, device=xin.device)
                     ws_bytes = F_.size_query("trs_rowdot_bwd_workspace_bytes", rows, C)
                     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=xin.device)
                 F_.call("trs_rowdot_bwd", F_.ptr(g2), F_.ptr(xin), F_.ptr(W), rows, C, F_.value_dtype_code(xin),
                         F_.ptr(gh), F_.ptr(gwf), F_.ptr(gwf[C:]) if gwf is not None else F_.ptr(None), F_.ptr(ws),
                         ws_bytes, F_.stream_ptr())
-                if need_w:
-                    grads[4 * l] = gwf[:in_f].to(wdt).reshape(out_f, in_f)
-                if need_b:
-                    grads[4 * l + 1] = gwf[C:].to(wdt)
+                if need_w or need_b:
+                    gq = gwf.to(wdt)                      # one cast for weight row and bias
+                    if need_w:
+                        grads[4 * l] = gq[:in_f].reshape(out_f, in_f)
+                    if need_b:
+                        grads[4 * l + 1] = gq[C:]
                 g2 = gh
                 continue
             gbf = None
