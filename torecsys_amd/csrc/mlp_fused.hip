@@ -130,9 +130,9 @@ __device__ __forceinline__ MlpShare mlp_share(int N, int wave) {
 
 // acc[mi][2*pi + h] (+)= sum_k W-frag(pair pi, half h, ks) x act rows of tile mt0+mi, for MCNT row tiles and NPW column
 // pairs known at compile time (runtime bounds put a scalar branch in front of every MFMA).
-// The weight fragments come from L2: they are requested two k-steps before the MFMAs that consume them (an L2 round
-// trip under load outlasts one k-step of 16-32 MFMAs); the activations are read from LDS per k-step in two halves (16
-// registers of B operands instead of 64).
+// The weight fragments come from L2: a k-step's fragments are requested at the top of the k-step before it and waited
+// for at that k-step's bottom; the activations are read from LDS per k-step in two halves (16 registers of B operands
+// instead of 64).
 template <int MCNT, int NPW>
 __device__ __forceinline__ void mlp_gemm_t(const char* act, int act_str, const uint4* __restrict__ wf, int K,
                                            const MlpShare& sh, int lane, mf_f32x4 (&acc)[MF_MT][2 * MF_MAXP]) {
