@@ -538,6 +538,37 @@ def test_very_hot_rows_are_chunked(dev, dtype, tol, fuse):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("E", [1, 10, 64])
+def test_gather_backward_of_a_field_constant_gradient(dev, dtype, tol, E):
+    """out.sum over the fields (the models' first-order term, models/ctr/deep_fm.py:55-110) feeds back the same row for
+    every field of a sample -- an expanded (B,1,E) gradient.  The gather backward reads it as one row per sample
+    (broadcast mode of trs_scatter_rows) instead of materialising (B,N,E): same gradient as index_add on the expanded
+    block, for the E = 1 element path, the any-E element path, the vector path and the padding row."""
+    from torecsys_amd import functional as F_
+    g = torch.Generator().manual_seed(99 + E)
+    B, fs = 3000, [40, 7, 300, 5]
+    N, V = len(fs), sum(fs)
+    off = O.field_offsets(fs)
+    idx = torch.stack([torch.randint(0, f, (B,), generator=g) for f in fs], 1)
+    idx[:2000, 1] = 2                                                # a hot row (long-row queue)
+    w = torch.randn(V, E, generator=g).to(dtype)
+    gs = torch.randn(B, 1, E, generator=g).to(dtype)
+    pad = int(off[2]) + 5
+    wd = w.to(dev).requires_grad_()
+    out = F_.gather_rows(wd, idx.to(dev), off.to(dev), padding_idx=pad)
+    gexp = gs.to(dev).expand(B, N, E)
+    assert gexp.stride(1) == 0
+    out.backward(gexp)
+    rows = (idx + off.view(1, -1)).reshape(-1)
+    ref = torch.zeros(V, E).index_add_(0, rows, gs.float().expand(B, N, E).reshape(-1, E))
+    ref[pad] = 0
+    assert rel_err(wd.grad.float().cpu(), ref) <= tol
+    wd2 = w.to(dev).requires_grad_()                                  # the materialised block takes the ordinary path
+    F_.gather_rows(wd2, idx.to(dev), off.to(dev), padding_idx=pad).backward(gexp.contiguous())
+    assert rel_err(wd.grad.float().cpu(), wd2.grad.float().cpu()) <= (1e-6 if dtype == torch.float32 else 8e-3)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
 @pytest.mark.parametrize("B,N,E,Vf,hot", [(1024, 10, 16, 100, False), (4096, 39, 64, 7, True), (300, 5, 10, 9, False)])
 def test_fm_gradient_constant_along_E(dev, dtype, tol, B, N, E, Vf, hot):
     """The reference's FM / DeepFM models sum the FM output over E (models/ctr/deep_fm.py:55-110), so the gradient that

@@ -385,7 +385,12 @@ class _GatherRows(Function):
     def backward(ctx, g):
         idx, offsets, weight = ctx.saved_tensors
         rb = row_buckets(idx, offsets, weight.shape[0])
-        grad = _apply_or_grad(rb, weight, ctx.opt, g_rows=g.contiguous(), padding_row=ctx.padding_idx)
+        if g.dim() == 3 and g.shape[1] > 1 and g.stride(1) == 0:
+            # the same gradient row for every field of a sample (the backward of a sum over the fields, e.g. the models'
+            # first-order term): read as one (B,E) row per sample instead of materialising the expanded (B,N,E) block
+            grad = _apply_or_grad(rb, weight, ctx.opt, g_bcast=g[:, 0, :].contiguous(), padding_row=ctx.padding_idx)
+        else:
+            grad = _apply_or_grad(rb, weight, ctx.opt, g_rows=g.contiguous(), padding_row=ctx.padding_idx)
         return grad, None, None, None, None
 
 
