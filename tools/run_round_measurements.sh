@@ -8,7 +8,7 @@ O=$R/gpurun_out/$tag
 mkdir -p "$O"
 run() { timeout 600 "$@"; }
 run python bench.py > $O/bench_deepfm.json 2> $O/bench_deepfm.err; tail -1 $O/bench_deepfm.json | cut -c1-300
-for m in fm dcn xdeepfm; do run python bench.py --no-cpu-baseline --no-large-table --model $m --steps 5 --warmup 2 2>/dev/null | tail -1 > $O/bench_$m.json; cut -c1-200 $O/bench_$m.json; done
+for m in fm dcn xdeepfm; do run python bench.py --no-cpu-baseline --no-large-table --model $m 2>/dev/null | tail -1 > $O/bench_$m.json; cut -c1-200 $O/bench_$m.json; done
 run python bench.py --no-cpu-baseline --no-large-table --eager 2>/dev/null | tail -1 > $O/bench_deepfm_eager.json
 run python bench.py --no-cpu-baseline --no-large-table --zipf 2>/dev/null | tail -1 > $O/bench_deepfm_zipf.json
 run python bench.py --no-cpu-baseline --no-large-table --optimizer adagrad 2>/dev/null | tail -1 > $O/bench_deepfm_adagrad.json
