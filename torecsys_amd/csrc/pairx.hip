@@ -196,6 +196,66 @@ __global__ __launch_bounds__(256) void pairw_dot_bwd_data_kernel(const T* __rest
   }
 }
 
+// data gradient, owner-computes (16-byte rows): a thread owns one 16-byte chunk v of one gradient row r and sums the N-1
+// pairs of its field in registers: gx[r, e] = sum_{o != r} g[p(r,o)] k[p(r,o), e] x[o, e].  No LDS accumulators, no
+// rounds (the kernel above runs N barriers per sample), two barriers per sample.  The per-pair scalars w[p] = g[b,p]
+// ('vec': k enters per element from L2) or g[b,p] k[p] ('num') are staged in LDS once per sample.
+template <typename T>
+__global__ __launch_bounds__(256) void pairw_dot_bwd_data_own_kernel(const T* __restrict__ g, const T* __restrict__ x,
+                                                                     const T* __restrict__ kern, int is_num, int64_t B,
+                                                                     int N, int E, T* __restrict__ gx) {
+  extern __shared__ float smem[];
+  float* xs = smem;                 // [N][E]
+  float* ws = smem + N * E;         // [P]
+  constexpr int VE = Vec16<T>::VE;
+  const int P = N * (N - 1) / 2;
+  const int vpr = E / VE;
+  const uint4* kv = reinterpret_cast<const uint4*>(kern);
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    stage_block(x + b * N * E, xs, N * E);
+    for (int p = threadIdx.x; p < P; p += blockDim.x)
+      ws[p] = to_f32(g[b * P + p]) * (is_num ? to_f32(kern[p]) : 1.f);
+    __syncthreads();
+    uint4* go = reinterpret_cast<uint4*>(gx + b * N * (int64_t)E);
+    for (int it = threadIdx.x; it < N * vpr; it += blockDim.x) {
+      const int r = it / vpr, v = it - r * vpr;
+      float acc[VE];
+#pragma unroll
+      for (int q = 0; q < VE; ++q) acc[q] = 0.f;
+      constexpr int U = 4;
+      for (int k0 = 0; k0 < N - 1; k0 += U) {
+        uint4 kk[U];
+        int o[U], pp[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int k = k0 + u < N - 1 ? k0 + u : N - 2;
+          o[u] = k < r ? k : k + 1;                                   // the other field
+          pp[u] = o[u] < r ? pair_index_of(o[u], r, N) : pair_index_of(r, o[u], N);
+          if (!is_num) kk[u] = kv[(int64_t)pp[u] * vpr + v];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (k0 + u < N - 1) {
+            const float w = ws[pp[u]];
+            const float* xo = xs + o[u] * E + v * VE;
+            if (is_num) {
+#pragma unroll
+              for (int q = 0; q < VE; ++q) acc[q] = fmaf(w, xo[q], acc[q]);
+            } else {
+              float kf[VE];
+              Vec16<T>::unpack(kk[u], kf);
+#pragma unroll
+              for (int q = 0; q < VE; ++q) acc[q] = fmaf(w * kf[q], xo[q], acc[q]);
+            }
+          }
+        }
+      }
+      go[it] = Vec16<T>::pack(acc);
+    }
+  }
+}
+
 // weight gradient: gk[p,e] = sum_b g[b,p] x_i[e] x_j[e].  A workgroup owns a range of samples and walks the pairs
 // in chunks of PC whose fp32 partial (PC x E) lives in LDS; every (pair, e) slot is owned by one fixed lane, so
 // the accumulation needs no atomics and is deterministic.  Partials per workgroup go to the workspace.
@@ -284,6 +344,40 @@ __global__ __launch_bounds__(256) void pair_mul_fwd_kernel(const T* __restrict__
 }
 
 // ga[b,i,:] = sum_{p: i_p = i} g[b,p,:] c[b,j_p,:],   gc[b,j,:] = sum_{p: j_p = j} g[b,p,:] a[b,i_p,:]
+// Owner-computes: a thread owns one 16-byte column chunk v of TWO output rows whose pair counts add up to N-1 (rows i
+// and N-2-i of ga, rows j and N-j of gc: every thread walks the same number of pairs) and sums its pairs in registers:
+// no LDS accumulators, no zero fill, two barriers per sample.  (The first version walked conflict-free rounds of
+// disjoint pairs with read-modify-writes on LDS accumulators -- N barriers per sample, 60 % of the threads busy.)
+// g is read twice per sample (94 KB at N = 39, E = 64: the second pass hits L2).
+template <typename T>
+__device__ __forceinline__ void pair_mul_row_sum(const uint4* __restrict__ grow, const float* __restrict__ other, int N, int E,
+                                                 int vpr, int v, int row, bool as_i, float (&acc)[Vec16<T>::VE]) {
+  constexpr int VE = Vec16<T>::VE;
+  // as_i: pairs (row, j), j = row+1 .. N-1, weights other[j];  else: pairs (i, row), i = 0 .. row-1, weights other[i]
+  const int cnt = as_i ? N - 1 - row : row;
+  constexpr int U = 4;
+  for (int k0 = 0; k0 < cnt; k0 += U) {
+    uint4 gv[U];
+    int o[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + u < cnt ? k0 + u : cnt - 1;
+      o[u] = as_i ? row + 1 + k : k;
+      const int pidx = as_i ? pair_index_of(row, o[u], N) : pair_index_of(o[u], row, N);
+      gv[u] = grow[(int64_t)pidx * vpr + v];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (k0 + u < cnt) {
+        float f[VE];
+        Vec16<T>::unpack(gv[u], f);
+#pragma unroll
+        for (int q = 0; q < VE; ++q) acc[q] = fmaf(f[q], other[o[u] * E + v * VE + q], acc[q]);
+      }
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void pair_mul_bwd_kernel(const T* __restrict__ g, const T* __restrict__ a,
                                                            const T* __restrict__ c, int64_t B, int N, int E,
@@ -291,71 +385,54 @@ __global__ __launch_bounds__(256) void pair_mul_bwd_kernel(const T* __restrict__
   extern __shared__ float smem[];
   float* as = smem;
   float* cs = smem + N * E;
-  float* gas = smem + 2 * N * E;
-  float* gcs = smem + 3 * N * E;
   constexpr int VE = Vec16<T>::VE;
   const int P = N * (N - 1) / 2;
-  const int R = sched_rounds(N), H = sched_width(N);
-  int* sched = reinterpret_cast<int*>(smem + 4 * N * E);
   const int vpr = E / VE;
-  const int groups = blockDim.x / vpr, grp = threadIdx.x / vpr, v = threadIdx.x % vpr;
-  const bool active = grp < groups;
-  build_round_schedule(sched, N);
+  // work items: (kind, row pair, v).  kind 0 = ga rows {r, N-2-r}, r < ceil((N-1)/2) (row N-1 of ga is zero);
+  // kind 1 = gc rows {r, N-r}, r = 1 .. ceil((N-1)/2)   (row 0 of gc is zero; r == N-r once when N is even)
+  const int half = N / 2;                     // number of row pairs of either kind
+  const int items = 2 * half * vpr;
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
     __syncthreads();
     stage_block(a + b * N * E, as, N * E);
     stage_block(c + b * N * E, cs, N * E);
-    for (int e = threadIdx.x; e < 2 * N * E; e += blockDim.x) gas[e] = 0.f;      // gas and gcs are adjacent
     __syncthreads();
     const uint4* grow = reinterpret_cast<const uint4*>(g + (b * P) * (int64_t)E);
-    // one pair per lane group and round when H <= groups (the usual case): the gradient row of the NEXT round is
-    // loaded before this round's barrier, so the global-load latency overlaps the LDS updates
-    const bool simple = H <= groups;
-    uint4 nxt = make_uint4(0, 0, 0, 0);
-    int nij = -1;
-    if (simple && active && grp < H) {
-      nij = sched[grp];
-      if (nij >= 0) nxt = grow[(int64_t)pair_index(nij >> 16, nij & 0xffff, N) * vpr + v];
-    }
-    for (int r = 0; r < R; ++r) {
-      if (active && simple) {
-        const int ij = nij;
-        const uint4 cur = nxt;
-        if (r + 1 < R && grp < H) {
-          nij = sched[(r + 1) * H + grp];
-          if (nij >= 0) nxt = grow[(int64_t)pair_index(nij >> 16, nij & 0xffff, N) * vpr + v];
-        }
-        if (grp < H && ij >= 0) {
-          const int i = ij >> 16, j = ij & 0xffff;
-          float gv[VE];
-          Vec16<T>::unpack(cur, gv);
+    uint4* gao = reinterpret_cast<uint4*>(ga + b * N * (int64_t)E);
+    uint4* gco = reinterpret_cast<uint4*>(gc + b * N * (int64_t)E);
+    for (int it = threadIdx.x; it < items; it += blockDim.x) {
+      const int v = it % vpr, rp = (it / vpr) % half, kind = it / (vpr * half);
+      float acc[VE];
+      if (kind == 0) {
+        const int r0 = rp, r1 = N - 2 - rp;
 #pragma unroll
-          for (int q = 0; q < VE; ++q) {
-            const int e = v * VE + q;
-            gas[i * E + e] = fmaf(gv[q], cs[j * E + e], gas[i * E + e]);
-            gcs[j * E + e] = fmaf(gv[q], as[i * E + e], gcs[j * E + e]);
-          }
-        }
-      } else if (active) {
-        for (int k = grp; k < H; k += groups) {
-          const int ij = sched[r * H + k];
-          if (ij < 0) continue;
-          const int i = ij >> 16, j = ij & 0xffff, p = pair_index(i, j, N);
-          float gv[VE];
-          Vec16<T>::unpack(grow[(int64_t)p * vpr + v], gv);
+        for (int q = 0; q < VE; ++q) acc[q] = 0.f;
+        pair_mul_row_sum<T>(grow, cs, N, E, vpr, v, r0, true, acc);
+        gao[r0 * vpr + v] = Vec16<T>::pack(acc);
+        if (r1 != r0) {
 #pragma unroll
-          for (int q = 0; q < VE; ++q) {
-            const int e = v * VE + q;
-            gas[i * E + e] = fmaf(gv[q], cs[j * E + e], gas[i * E + e]);
-            gcs[j * E + e] = fmaf(gv[q], as[i * E + e], gcs[j * E + e]);
-          }
+          for (int q = 0; q < VE; ++q) acc[q] = 0.f;
+          pair_mul_row_sum<T>(grow, cs, N, E, vpr, v, r1, true, acc);
+          gao[r1 * vpr + v] = Vec16<T>::pack(acc);
+        }
+      } else {
+        const int r0 = rp + 1, r1 = N - 1 - rp;
+#pragma unroll
+        for (int q = 0; q < VE; ++q) acc[q] = 0.f;
+        pair_mul_row_sum<T>(grow, as, N, E, vpr, v, r0, false, acc);
+        gco[r0 * vpr + v] = Vec16<T>::pack(acc);
+        if (r1 != r0) {
+#pragma unroll
+          for (int q = 0; q < VE; ++q) acc[q] = 0.f;
+          pair_mul_row_sum<T>(grow, as, N, E, vpr, v, r1, false, acc);
+          gco[r1 * vpr + v] = Vec16<T>::pack(acc);
         }
       }
-      __syncthreads();
     }
-    for (int e = threadIdx.x; e < N * E; e += blockDim.x) {
-      ga[b * N * E + e] = from_f32<T>(gas[e]);
-      gc[b * N * E + e] = from_f32<T>(gcs[e]);
+    // the rows without pairs
+    for (int v = threadIdx.x; v < vpr; v += blockDim.x) {
+      gao[(N - 1) * vpr + v] = make_uint4(0, 0, 0, 0);
+      gco[v] = make_uint4(0, 0, 0, 0);
     }
   }
 }
@@ -643,7 +720,18 @@ extern "C" int trs_opn_vec_bwd(const void* g, const void* x, const void* kern, i
               "opn_vec_bwd: N = %d, E = %d exceed the 64 KB LDS block", N, E);
   const int EL = pow2_lanes(E), kp = kern_is_num ? 1 : E, ke = kern_is_num ? 0 : 1;
   hipStream_t s = (hipStream_t)stream;
-  if (gx != nullptr) {
+  const int VEb = dtype == TRS_F32 ? 4 : 8;
+  if (gx != nullptr && E % VEb == 0 && aligned16(gx) && aligned16(x) && (kern_is_num || aligned16(kern)) &&
+      (size_t)(N * E + N * (N - 1) / 2) * 4 <= 64 * 1024) {
+    const size_t lds = (size_t)(N * E + N * (N - 1) / 2) * 4;
+    if (dtype == TRS_F32)
+      hipLaunchKernelGGL((pairw_dot_bwd_data_own_kernel<float>), dim3(sample_grid(B)), dim3(256), lds, s, (const float*)g,
+                         (const float*)x, (const float*)kern, kern_is_num ? 1 : 0, B, N, E, (float*)gx);
+    else
+      hipLaunchKernelGGL((pairw_dot_bwd_data_own_kernel<bf16_t>), dim3(sample_grid(B)), dim3(256), lds, s,
+                         (const bf16_t*)g, (const bf16_t*)x, (const bf16_t*)kern, kern_is_num ? 1 : 0, B, N, E,
+                         (bf16_t*)gx);
+  } else if (gx != nullptr) {
     const size_t lds = (size_t)N * E * 4 * 2 + sched_bytes;
     if (dtype == TRS_F32)
       hipLaunchKernelGGL((pairw_dot_bwd_data_kernel<float>), dim3(sample_grid(B)), dim3(256), lds, s, (const float*)g,
@@ -713,8 +801,8 @@ extern "C" int trs_pair_mul_bwd(const void* g, const void* a, const void* c, int
   const int VE = dtype == TRS_F32 ? 4 : 8;
   TRS_REQUIRE(E % VE == 0 && E / VE <= 256, TRS_ESHAPE, "pair_mul_bwd: E = %d must be a multiple of %d (16-byte rows)", E,
               VE);
-  TRS_REQUIRE(aligned16(g), TRS_EALIGN, "pair_mul_bwd: g must be 16-byte aligned");
-  const size_t lds = (size_t)N * E * 4 * 4 + (size_t)sched_rounds(N) * sched_width(N) * 4;
+  TRS_REQUIRE(aligned16(g) && aligned16(ga) && aligned16(gc), TRS_EALIGN, "pair_mul_bwd: g, ga, gc must be 16-byte aligned");
+  const size_t lds = (size_t)N * E * 4 * 2;
   TRS_REQUIRE(lds <= 64 * 1024, TRS_ESHAPE, "pair_mul_bwd: N = %d, E = %d exceed the 64 KB LDS block", N, E);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == TRS_F32)
