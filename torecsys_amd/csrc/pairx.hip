@@ -97,6 +97,62 @@ __global__ __launch_bounds__(256) void pairw_dot_fwd_kernel(const T* __restrict_
   }
 }
 
+// forward, 16-byte rows: a thread owns whole pairs and walks e in 16-byte chunks -- x_i / x_j chunks from the LDS copy of
+// the sample (kept in the table dtype, rows padded by 16 bytes: the lanes of a wave read one x_i row (broadcast) and
+// consecutive x_j rows, all on different banks), the k chunk of its pair from L2 -- and sums in registers: no cross-lane
+// reduction, 16-byte LDS reads instead of the 4-byte ones of the variant below (which is LDS-issue-bound: 229 us at
+// B = 8192, N = 39, E = 64).
+template <typename T>
+__global__ __launch_bounds__(256) void pairw_dot_fwd_own_kernel(const T* __restrict__ x, const T* __restrict__ kern,
+                                                                int is_num, int64_t B, int N, int E, T* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_c[];
+  constexpr int VE = Vec16<T>::VE;
+  const int P = N * (N - 1) / 2, vpr = E / VE;
+  const int RS = E * (int)sizeof(T) + 16;               // LDS row stride (bytes)
+  char* xs = smem_c;
+  int* lut = reinterpret_cast<int*>(smem_c + ((N * RS + 15) & ~15));
+  build_pair_lut(lut, N);
+  const uint4* kv = reinterpret_cast<const uint4*>(kern);
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    for (int v = threadIdx.x; v < N * vpr; v += blockDim.x) {
+      const int row = v / vpr, c = v - row * vpr;
+      *reinterpret_cast<uint4*>(xs + row * RS + c * 16) =
+          *(reinterpret_cast<const uint4*>(x + (b * N + row) * (int64_t)E) + c);
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < P; p += blockDim.x) {
+      const int ij = lut[p], i = ij >> 16, j = ij & 0xffff;
+      float acc = 0.f;
+      for (int c0 = 0; c0 < vpr; c0 += 4) {
+        uint4 kk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (!is_num && c0 + u < vpr) kk[u] = kv[(int64_t)p * vpr + c0 + u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (c0 + u < vpr) {
+            float xi[VE], xj[VE];
+            Vec16<T>::unpack(*reinterpret_cast<const uint4*>(xs + i * RS + (c0 + u) * 16), xi);
+            Vec16<T>::unpack(*reinterpret_cast<const uint4*>(xs + j * RS + (c0 + u) * 16), xj);
+            if (is_num) {
+#pragma unroll
+              for (int q = 0; q < VE; ++q) acc = fmaf(xi[q], xj[q], acc);
+            } else {
+              float kf[VE];
+              Vec16<T>::unpack(kk[u], kf);
+#pragma unroll
+              for (int q = 0; q < VE; ++q) acc = fmaf(xi[q] * xj[q], kf[q], acc);
+            }
+          }
+        }
+      }
+      if (is_num) acc *= to_f32(kern[p]);
+      out[b * P + p] = from_f32<T>(acc);
+    }
+  }
+}
+
 // Register-resident variant for the common case (E <= 64, NC2 <= 1024): a 1024-thread workgroup in which every LANE
 // owns one pair for every sample the workgroup processes.  The lane walks e itself, so there is no cross-lane
 // reduction at all; the x block sits in LDS with a row stride of E+1 floats, which spreads the lanes' different
@@ -677,6 +733,17 @@ extern "C" int trs_opn_vec_fwd(const void* x, const void* kern, int32_t kern_is_
   TRS_REQUIRE(lds <= 64 * 1024, TRS_ESHAPE, "opn_vec_fwd: N = %d, E = %d exceed the 64 KB LDS block", N, E);
   const int EL = pow2_lanes(E), kp = kern_is_num ? 1 : E, ke = kern_is_num ? 0 : 1;
   hipStream_t s = (hipStream_t)stream;
+  const int VEf = dtype == TRS_F32 ? 4 : 8;
+  const size_t own_lds = (size_t)((N * (E * (dtype == TRS_F32 ? 4 : 2) + 16) + 15) & ~15) + (size_t)N * (N - 1) / 2 * 4;
+  if (E % VEf == 0 && aligned16(x) && (kern_is_num || aligned16(kern)) && own_lds <= 64 * 1024) {
+    if (dtype == TRS_F32)
+      hipLaunchKernelGGL((pairw_dot_fwd_own_kernel<float>), dim3(sample_grid(B)), dim3(256), own_lds, s, (const float*)x,
+                         (const float*)kern, kern_is_num ? 1 : 0, B, N, E, (float*)out);
+    else
+      hipLaunchKernelGGL((pairw_dot_fwd_own_kernel<bf16_t>), dim3(sample_grid(B)), dim3(256), own_lds, s,
+                         (const bf16_t*)x, (const bf16_t*)kern, kern_is_num ? 1 : 0, B, N, E, (bf16_t*)out);
+    return check_launch("opn_vec_fwd(own)");
+  }
   if (pairw_reg_ok(N, E, kern_is_num != 0) && B >= 64) {
     const size_t rl = (size_t)N * (E + 1) * 4;
     if (dtype == TRS_F32)
