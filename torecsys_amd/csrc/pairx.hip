@@ -169,8 +169,11 @@ __global__ __launch_bounds__(1024) void pairw_reg_kernel(const T* __restrict__ x
                                                          T* __restrict__ out /* MODE 0 */,
                                                          float* __restrict__ partial /* MODE 1 */) {
   extern __shared__ float smem[];
-  float* xs = smem;                                   // [N][E+1]
-  const int P = N * (N - 1) / 2, RS = E + 1;
+  float* xs = smem;                                   // [N][RS]
+  // E % 4 == 0: rows padded to E+4 floats and read as float4 (rows of different fields start 4 banks apart: conflict
+  // free for 16-byte reads, one field's row is a broadcast) -- a quarter of the LDS instructions of the scalar form
+  const bool vec4 = (E & 3) == 0;
+  const int P = N * (N - 1) / 2, RS = vec4 ? E + 4 : E + 1;
   const int p = threadIdx.x;
   const bool own = p < P;
   int i = 0, j = 1;
@@ -194,6 +197,17 @@ __global__ __launch_bounds__(1024) void pairw_reg_kernel(const T* __restrict__ x
         for (int e = 0; e < PAIRW_EMAX; ++e)
           if (e < E) acc = fmaf(xi[e] * xj[e], reg[e], acc);
         out[b * P + p] = from_f32<T>(acc);
+      } else if (vec4) {
+        const float gp = to_f32(g[b * P + p]);
+#pragma unroll
+        for (int e = 0; e < PAIRW_EMAX; e += 4)
+          if (e < E) {
+            const float4 a = *reinterpret_cast<const float4*>(xi + e), c = *reinterpret_cast<const float4*>(xj + e);
+            reg[e] = fmaf(gp, a.x * c.x, reg[e]);
+            reg[e + 1] = fmaf(gp, a.y * c.y, reg[e + 1]);
+            reg[e + 2] = fmaf(gp, a.z * c.z, reg[e + 2]);
+            reg[e + 3] = fmaf(gp, a.w * c.w, reg[e + 3]);
+          }
       } else {
         const float gp = to_f32(g[b * P + p]);
 #pragma unroll
@@ -212,9 +226,9 @@ __global__ __launch_bounds__(1024) void pairw_reg_kernel(const T* __restrict__ x
 
 static bool pairw_reg_ok(int N, int E, bool is_num) {
   const int P = N * (N - 1) / 2;
-  return !is_num && E <= PAIRW_EMAX && P <= 1024 && (size_t)N * (E + 1) * 4 <= 64 * 1024;
+  return !is_num && E <= PAIRW_EMAX && P <= 1024 && (size_t)N * (E + 4) * 4 <= 64 * 1024;
 }
-static int pairw_reg_grid(int64_t B) { return (int)std::min<int64_t>(512, std::max<int64_t>(1, B / 4)); }
+static int pairw_reg_grid(int64_t B) { return (int)std::min<int64_t>(256, std::max<int64_t>(1, B / 4)); }
 
 // data gradient: gx_i[e] += g k x_j[e], gx_j[e] += g k x_i[e]   (per-sample LDS accumulators, conflict-free rounds)
 template <typename T>
@@ -745,7 +759,7 @@ extern "C" int trs_opn_vec_fwd(const void* x, const void* kern, int32_t kern_is_
     return check_launch("opn_vec_fwd(own)");
   }
   if (pairw_reg_ok(N, E, kern_is_num != 0) && B >= 64) {
-    const size_t rl = (size_t)N * (E + 1) * 4;
+    const size_t rl = (size_t)N * (E + 4) * 4;
     if (dtype == TRS_F32)
       hipLaunchKernelGGL((pairw_reg_kernel<float, 0>), dim3(pairw_reg_grid(B)), dim3(1024), rl, s, (const float*)x,
                          (const float*)kern, (const float*)nullptr, B, N, E, (float*)out, (float*)nullptr);
@@ -818,7 +832,7 @@ extern "C" int trs_opn_vec_bwd(const void* g, const void* x, const void* kern, i
     float* part = (float*)workspace;
     if (pairw_reg_ok(N, E, false) && B >= 64) {
       nblk = pairw_reg_grid(B);
-      const size_t rl = (size_t)N * (E + 1) * 4;
+      const size_t rl = (size_t)N * (E + 4) * 4;
       if (dtype == TRS_F32)
         hipLaunchKernelGGL((pairw_reg_kernel<float, 1>), dim3(nblk), dim3(1024), rl, s, (const float*)x,
                            (const float*)nullptr, (const float*)g, B, N, E, (float*)nullptr, part);
