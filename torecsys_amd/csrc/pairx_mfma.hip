@@ -59,19 +59,50 @@ __global__ __launch_bounds__(256) void pair_bil_fwd_mfma_kernel(const bf16_t* __
   const int64_t tiles = (B + 15) / 16;
   const int64_t per = (tiles + nsplit - 1) / nsplit;
   const int64_t t_lo = split * per, t_hi = std::min<int64_t>(t_lo + per, tiles);
+  // A wave walks its sample tiles one at a time: the x_i / x_j runs of the NEXT tile are requested (hand-issued loads,
+  // every lane issues every load, dead samples read sample 0) while this tile's MFMAs and epilogues run, and waited for
+  // at the end of the iteration -- otherwise every tile starts with a full HBM round trip for 24 MFMAs of work.
+  typedef __attribute__((ext_vector_type(4))) unsigned pb_u32x4;
+  pb_u32x4 nxi[KS], nxj[PB_PPT][KS];
+#define TRS_PB_FETCH(tt)                                                                                         \
+  {                                                                                                              \
+    const int64_t b_ = (tt) * 16 + n;                                                                            \
+    const bf16_t* xb_ = x + (b_ < B ? b_ : 0) * (int64_t)N * E;                                                  \
+    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                          \
+      const bf16_t* a_ = xb_ + fi * E + 32 * ks + 8 * q;                                                         \
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nxi[ks]) : "v"(a_));                                 \
+    }                                                                                                            \
+    _Pragma("unroll") for (int c = 0; c < PB_PPT; ++c)                                                           \
+      _Pragma("unroll") for (int u = 0; u < KS; ++u) {                                                           \
+        const bf16_t* a_ = xb_ + (j0 + (c < cnt ? c : 0)) * E + 32 * u + 8 * q;                                  \
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nxj[c][u]) : "v"(a_));                             \
+      }                                                                                                          \
+  }
+#define TRS_PB_COMMIT()                                                                                          \
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                               \
+  _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(nxi[ks]));                            \
+  _Pragma("unroll") for (int c = 0; c < PB_PPT; ++c)                                                             \
+    _Pragma("unroll") for (int u = 0; u < KS; ++u) asm volatile("" : "+v"(nxj[c][u]));
+  if (t_lo < t_hi) {
+    TRS_PB_FETCH(t_lo)
+    TRS_PB_COMMIT()
+  }
   for (int64_t t = t_lo; t < t_hi; ++t) {
     const int64_t b = t * 16 + n;
     const bool live = b < B;
-    const bf16_t* xb = x + (live ? b : 0) * (int64_t)N * E;
     uint4 xi[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) xi[ks] = *reinterpret_cast<const uint4*>(xb + fi * E + 32 * ks + 8 * q);
+    for (int ks = 0; ks < KS; ++ks) xi[ks] = make_uint4(nxi[ks][0], nxi[ks][1], nxi[ks][2], nxi[ks][3]);
     uint4 xj[PB_PPT][KS];
 #pragma unroll
     for (int c = 0; c < PB_PPT; ++c)
 #pragma unroll
-      for (int u = 0; u < KS; ++u)
-        xj[c][u] = *reinterpret_cast<const uint4*>(xb + (j0 + (c < cnt ? c : 0)) * E + 32 * u + 8 * q);
+      for (int u = 0; u < KS; ++u) xj[c][u] = make_uint4(nxj[c][u][0], nxj[c][u][1], nxj[c][u][2], nxj[c][u][3]);
+    {
+      const int64_t tn = t + 1 < t_hi ? t + 1 : t;
+      TRS_PB_FETCH(tn)
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < PB_PPT; ++c) {
       if (c >= cnt) break;
@@ -105,7 +136,11 @@ __global__ __launch_bounds__(256) void pair_bil_fwd_mfma_kernel(const bf16_t* __
         if (q == 0 && live) out[b * P + p0 + c] = from_f32<bf16_t>(part);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    TRS_PB_COMMIT()
   }
+#undef TRS_PB_FETCH
+#undef TRS_PB_COMMIT
 }
 
 }  // namespace trs
