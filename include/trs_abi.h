@@ -421,6 +421,15 @@ int trs_pair_mul_fwd(const void* a, const void* c, const void* bias, int32_t bia
 int trs_pair_mul_bwd(const void* g, const void* a, const void* c, int64_t B, int32_t N, int32_t E, int32_t dtype,
                      void* ga, void* gc, trs_stream_t stream);
 
+/* rows product with bias: the stand-alone forward of FieldAllTypeBilinear / FieldEachTypeBilinear
+ * (bilinear_interaction.py:72-76, 144-149), whose operands arrive already gathered per pair as (B,P,E):
+ *   out[r,:] = a[r,:] * c[r,:] + bias[(bias_per_pair ? r % P : 0), :]      r over rows = B*P   (bias may be NULL)
+ * bwd: ga = g * c, gc = g * a (either may be NULL).  Element-wise passes, any E.                     */
+int trs_rows_mul_bias_fwd(const void* a, const void* c, const void* bias, int32_t bias_per_pair, int64_t rows,
+                          int32_t P, int32_t E, int32_t dtype, void* out, trs_stream_t stream);
+int trs_rows_mul_bwd(const void* g, const void* a, const void* c, int64_t rows, int32_t E, int32_t dtype, void* ga,
+                     void* gc, trs_stream_t stream);
+
 /* per-pair bilinear form:  T[b,p,:] = x[b,i_p,:] @ W[(w_per_pair ? p : 0)]     W (NC2 | 1, E, E) row-major [e][h]
  *   mode 0 (OPN 'mat', outer_product_network.py:107-121 with W[p][e][h] = kernel[h,p,e]):
  *           out[b,p]   = sum_h T[b,p,h] * x[b,j_p,h]
@@ -479,6 +488,22 @@ int trs_afm_bwd(const void* g_out, const void* g_attn, const void* x, const void
                 const void* b1, const void* w2, int64_t B, int32_t N, int32_t E, int32_t A, int32_t dtype, void* gx,
                 float* gW1, float* gb1, float* gw2, float* gb2, void* workspace, size_t ws_bytes,
                 trs_stream_t stream);
+
+/* The same layer with the reference's dropout on the attention scores applied INSIDE the pass
+ * (attentional_factorization_machine.py:82, 105-113: nn.Dropout is the last module of ``self.attention``, so in training
+ * the weighted sum and the returned scores both see the dropped scores):
+ *   keep (B,NC2) uint8, nonzero = kept; multiplier m[b,p] = keep ? keep_scale : 0   (keep_scale = 1/(1-p))
+ *   attn      (B,NC2) = the softmax BEFORE dropout (what the backward needs)
+ *   attn_drop (B,NC2) = attn * m   (what the layer returns);   out[b,:] = sum_p attn_drop[b,p] prod[b,p,:]
+ * keep == NULL: no dropout, attn_drop is not written (== trs_afm_fwd / trs_afm_bwd).
+ * bwd: g_attn is the gradient of attn_drop; ``attn`` is the un-dropped softmax written by the forward.        */
+int trs_afm_fwd_dropout(const void* x, const void* W1, const void* b1, const void* w2, const void* b2,
+                        const uint8_t* keep, float keep_scale, int64_t B, int32_t N, int32_t E, int32_t A,
+                        int32_t dtype, void* out, void* attn, void* attn_drop, trs_stream_t stream);
+int trs_afm_bwd_dropout(const void* g_out, const void* g_attn, const void* x, const void* attn, const uint8_t* keep,
+                        float keep_scale, const void* W1, const void* b1, const void* w2, int64_t B, int32_t N, int32_t E,
+                        int32_t A, int32_t dtype, void* gx, float* gW1, float* gb1, float* gw2, float* gb2,
+                        void* workspace, size_t ws_bytes, trs_stream_t stream);
 
 /* ---- index staging: pack per-field columns into the (B,N) index matrix --------
  * out[b, c] = src_j[b * width_j + t]  for the c-th output column = column t of source j.

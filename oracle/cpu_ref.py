@@ -305,13 +305,19 @@ def outer_product_layer(x: torch.Tensor, kernel: torch.Tensor, kernel_type: str 
     raise ValueError('kernel_type only allows: ["mat", "num", "vec"].')
 
 
-def afm_layer(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor):
-    """(B,N,E) -> ((B,E), (B,NC2,1)).  attentional_factorization_machine.py:86-125 with both dropouts at p = 0:
-    prod[b,p,:] = x_i * x_j;  score = softmax_p(W2 relu(W1 prod + b1) + b2);  out[b,:] = sum_p score[b,p] prod[b,p,:]."""
+def afm_layer(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor,
+              score_keep: Optional[torch.Tensor] = None, keep_scale: float = 1.0):
+    """(B,N,E) -> ((B,E), (B,NC2,1)).  attentional_factorization_machine.py:86-125:
+    prod[b,p,:] = x_i * x_j;  score = Dropout(softmax_p(W2 relu(W1 prod + b1) + b2));  out[b,:] = sum_p score[b,p] prod[b,p,:].
+    ``score_keep`` (B,NC2) 0/1 + ``keep_scale`` = 1/(1-p) restate nn.Dropout GIVEN its mask (the last module of
+    ``self.attention``, :82: the returned scores and the weighted sum both see the dropped scores); None = eval / p = 0.
+    The output dropout (:84, :120) is left to the caller."""
     r, c = pair_indices(x.shape[1])
     prod = x[:, r] * x[:, c]
     h = torch.relu(torch.nn.functional.linear(prod, w1, b1))
     attn = torch.softmax(torch.nn.functional.linear(h, w2, b2), dim=1)
+    if score_keep is not None:
+        attn = attn * (score_keep.to(attn.dtype) * keep_scale).unsqueeze(-1)
     return (prod * attn).sum(dim=1), attn
 
 

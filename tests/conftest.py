@@ -54,6 +54,9 @@ CIN_CASES = ["a", "b", "c", "d", "e", "f"]
 PAIR_SHAPES = [(8, 4, 128), (16, 6, 64), (32, 12, 8), (32, 10, 16), (8, 12, 64), (4, 39, 64)]   # pairs.npz (8f N3 layers)
 
 
+AFM_DROP_SHAPES = [(8, 4, 128), (16, 6, 64), (32, 12, 8), (8, 12, 64), (4, 39, 64)]     # afm_drop.npz (training-mode AFM)
+
+
 def pair_heavy_ok(N, E):
     """make_golden_pairs.py skips the per-pair E x E parameter variants ('mat', 'each') above 300 k elements"""
     return N * (N - 1) // 2 * E * E <= 300_000

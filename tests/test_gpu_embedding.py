@@ -569,7 +569,8 @@ def test_gather_backward_of_a_field_constant_gradient(dev, dtype, tol, E):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
-@pytest.mark.parametrize("B,N,E,Vf,hot", [(1024, 10, 16, 100, False), (4096, 39, 64, 7, True), (300, 5, 10, 9, False)])
+@pytest.mark.parametrize("B,N,E,Vf,hot", [(1024, 10, 16, 100, False), (4096, 39, 64, 7, True), (300, 5, 10, 9, False),
+                                           (512, 6, 4, 50, False), (512, 6, 8, 50, True)])     # rows of ONE 16-byte vector
 def test_fm_gradient_constant_along_E(dev, dtype, tol, B, N, E, Vf, hot):
     """The reference's FM / DeepFM models sum the FM output over E (models/ctr/deep_fm.py:55-110), so the gradient that
     reaches the fused lookup+FM backward is an expanded (B,1) column.  trs_scatter_rows reads it as one value per sample
@@ -622,3 +623,92 @@ def test_out_of_range_lookup_is_sanitised_and_reported_lazily(dev):
     out_bad.sum().backward()
     assert torch.isfinite(emb.embedding.weight.grad).all()
     assert F_.index_errors_seen() and not F_.index_errors_seen()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("pad", [0, 7, -1])
+def test_fused_lookup_fm_respects_padding_idx(dev, dtype, tol, pad):
+    """multi_indices_emb.py:48 forwards ``padding_idx`` to nn.Embedding: that row is read like any other and gets NO
+    gradient.  The fused lookup + FM path (fuse_fm=True) must behave like F.embedding(padding_idx=) + FM: same block
+    (bit-exact), same FM term, same dense gradient with an exactly-zero padding row -- also through the fused optimizer."""
+    from torecsys_amd.inputs import MultiIndicesEmbedding
+    from torecsys_amd.layers import FactorizationMachineLayer
+    from torecsys_amd.optim import FusedSparseSGD
+    B, E, fs = 700, 16, [5, 9, 3, 11]
+    V = sum(fs)
+    g = torch.Generator().manual_seed(11 + (pad % V))
+    idx = torch.cat([torch.randint(0, f, (B, 1), generator=g) for f in fs], 1)
+    off = O.field_offsets(fs)
+    prow = pad % V
+    assert bool(((idx + off) == prow).any())                            # the padding row IS looked up
+    torch.manual_seed(5)
+    mod = MultiIndicesEmbedding(embed_size=E, field_sizes=fs, fuse_fm=True, padding_idx=pad).to(dev).to(dtype)
+    assert mod.padding_idx == prow
+    w0 = torch.randn(V, E, generator=g).to(dtype)
+    mod.embedding.weight.data.copy_(w0)
+    fm = FactorizationMachineLayer()
+    ge = torch.randn(B, len(fs), E, generator=g).to(dtype)
+    g1 = torch.randn(B, 1, generator=g).to(dtype)
+    # reference semantics on the CPU: F.embedding with padding_idx, dense gradient
+    wr = w0.float().clone().requires_grad_()
+    emb_r = torch.nn.functional.embedding(idx + off, wr, padding_idx=prow)
+    ((emb_r * ge.float()).sum() + (O.fm_layer(emb_r).sum(1, keepdim=True) * g1.float()).sum()).backward()
+    assert float(wr.grad[prow].abs().max()) == 0.0
+    out = mod(idx.to(dev))
+    assert hasattr(out, "_trs_fused_fm")
+    y = fm(out)
+    assert torch.equal(out.rename(None).float().cpu(), emb_r.detach())
+    ((out.rename(None) * ge.to(dev)).sum() + (y.rename(None).sum(1, keepdim=True) * g1.to(dev)).sum()).backward()
+    got = mod.embedding.weight.grad.float().cpu()
+    assert float(got[prow].abs().max()) == 0.0
+    assert rel_err(got, wr.grad) <= tol
+    # fused optimizer: the padding row keeps its value
+    mod.embedding.weight.grad = None
+    mod.set_fused_optimizer(FusedSparseSGD(0.25))
+    out = mod(idx.to(dev))
+    ((out.rename(None) * ge.to(dev)).sum() + (fm(out).rename(None).sum(1, keepdim=True) * g1.to(dev)).sum()).backward()
+    wn = mod.embedding.weight.detach().float().cpu()
+    assert torch.equal(wn[prow], w0[prow].float())
+    assert rel_err(wn, w0.float() - 0.25 * wr.grad) <= tol
+
+
+@pytest.mark.parametrize("kind", ["adagrad", "adam"])
+def test_fused_optimizer_state_of_first_order_table_persists(dev, kind):
+    """F_.embed_fm(first_weight=..., opt=...) steps the E = 1 first-order table through a reshaped VIEW of the parameter;
+    its optimizer state must be filed under the parameter (one entry, accumulating over the steps), not under the
+    per-call view: three steps against torch.optim on the dense gradients."""
+    from torecsys_amd import functional as F_
+    from torecsys_amd.optim import FusedSparseAdagrad, FusedSparseAdam
+    B, N, E, fs = 400, 4, 16, [6, 4, 9, 5]
+    V = sum(fs)
+    g = torch.Generator().manual_seed(3)
+    off = O.field_offsets(fs)
+    w0, f0 = torch.randn(V, E, generator=g), torch.randn(V, 1, generator=g)
+    wd, fd = w0.to(dev).requires_grad_(), f0.to(dev).requires_grad_()
+    wr, fr = w0.clone().requires_grad_(), f0.clone().requires_grad_()
+    if kind == "adagrad":
+        opt = FusedSparseAdagrad(lr=0.1, eps=1e-10)
+        ref = torch.optim.Adagrad([wr, fr], lr=0.1, eps=1e-10)
+    else:
+        opt = FusedSparseAdam(lr=0.05)
+        ref = torch.optim.SparseAdam([wr, fr], lr=0.05)
+    for step in range(3):
+        idx = torch.cat([torch.randint(0, f, (B, 1), generator=g) for f in fs], 1)
+        emb, fm, first = F_.embed_fm(wd, idx.to(dev), off.to(dev), fd, True, opt)
+        (fm.sum() + first.sum() * 0.5 + emb.sum() * 0.1).backward()
+        assert wd.grad is None and fd.grad is None
+        ref.zero_grad()
+        rows = idx + off
+        if kind == "adagrad":
+            emb_r = wr[rows]
+            (O.fm_layer(emb_r).sum() + fr[rows].sum() * 0.5 + emb_r.sum() * 0.1).backward()
+        else:       # SparseAdam wants sparse gradients: build them from the dense ones
+            emb_r = wr[rows]
+            (O.fm_layer(emb_r).sum() + fr[rows].sum() * 0.5 + emb_r.sum() * 0.1).backward()
+            touched = torch.unique(rows)
+            for p_ in (wr, fr):
+                p_.grad = torch.sparse_coo_tensor(touched.unsqueeze(0), p_.grad[touched], p_.shape).coalesce()
+        ref.step()
+        assert len(opt._state) == 2, "one state entry per table, not one per step"
+        assert rel_err(wd.detach().cpu(), wr.detach()) <= 2e-5, step
+        assert rel_err(fd.detach().cpu(), fr.detach()) <= 2e-5, step

@@ -218,3 +218,107 @@ def test_pair_bilinear_gemm_route_matches_oracle(dev, dtype, tol, N, E):
         assert rel_err(x.grad.float().cpu(), xr.grad) <= tol * 2, (fam, kind, "gx")
         for p, r in zip(params, pr):
             assert rel_err(p.grad.float().cpu(), r.grad) <= tol * 2, (fam, kind, "gparam")
+
+
+# ---- AFM in training mode at the reference's default configuration: dropout on the scores INSIDE the fused pass ----
+from conftest import AFM_DROP_SHAPES  # noqa: E402
+
+
+@pytest.mark.parametrize("shape", AFM_DROP_SHAPES)
+def test_afm_score_dropout_golden(golden, dev, shape):
+    """afm_drop.npz: the reference in train() with the masks its two nn.Dropout modules drew.  The kernel gets the score
+    mask (trs_afm_fwd_dropout / trs_afm_bwd_dropout); the output dropout stays the module the reference has."""
+    from torecsys_amd import functional as F_
+    G = golden("afm_drop")
+    B, N, E = shape
+    t = _tag(shape)
+    p = float(G(f"{t}/p")[0])
+    scale = 1.0 / (1.0 - p)
+    ps = [G(f"{t}/{n}").to(dev).requires_grad_() for n in ("W1", "b1", "W2", "b2")]
+    x = G(f"{t}/x").to(dev).requires_grad_()
+    keep = G(f"{t}/score_keep").to(dev)
+    y0, attn = F_.afm(x, *ps, keep, scale)
+    assert rel_err(y0.cpu(), G(f"{t}/out_before_dropout")) <= 1e-5
+    assert rel_err(attn.unsqueeze(-1).cpu(), G(f"{t}/attn")) <= 1e-5
+    assert bool((attn.detach().cpu()[G(f"{t}/score_keep") == 0] == 0).all())       # dropped scores are exactly 0
+    y = y0 * G(f"{t}/out_keep").to(dev).float() * scale
+    assert rel_err(y.cpu(), G(f"{t}/out")) <= 1e-5
+    ((y * G(f"{t}/gout").to(dev)).sum() + (attn.unsqueeze(-1) * G(f"{t}/gattn").to(dev)).sum()).backward()
+    assert rel_err(x.grad.cpu(), G(f"{t}/gx")) <= 2e-5
+    for p_, n in zip(ps[:3], ("gW1", "gb1", "gW2")):
+        assert rel_err(p_.grad.cpu(), G(f"{t}/{n}")) <= 5e-5, n
+    assert float((ps[3].grad.cpu() - G(f"{t}/gb2")).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-5), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("B,N,E,A,p", [(37, 39, 64, 64, 0.1), (130, 7, 24, 40, 0.3), (64, 10, 32, 32, 0.5),
+                                       (20, 39, 64, 128, 0.1), (9, 5, 128, 96, 0.2)])
+def test_afm_layer_training_dropout_vs_oracle(dev, dtype, tol, B, N, E, A, p):
+    """The LAYER in train() with p > 0 (the reference's default p = 0.1): no PyTorch recompute of the (B,NC2,E)
+    products -- the mask the layer draws is reproduced here from the same device generator state and handed to the
+    oracle.  MFMA path (bf16, E in {32,64,128}) and generic path (fp32 / E = 24)."""
+    from torecsys_amd.layers import AttentionalFactorizationMachineLayer
+    g = torch.Generator().manual_seed(B + N + E + A)
+    x0 = (torch.randn(B, N, E, generator=g) * 0.7).to(dtype)
+    ps = [(torch.randn(A, E, generator=g) / E ** 0.5).to(dtype), (torch.randn(A, generator=g) * 0.1).to(dtype),
+          (torch.randn(1, A, generator=g) / A ** 0.5).to(dtype), (torch.randn(1, generator=g) * 0.1).to(dtype)]
+    lay = _afm_layer(dev, E, N, A, *ps, dtype=dtype)
+    lay.attention.Dropout.p = p            # score dropout on, output dropout off: the output is compared directly
+    lay.train()
+    P = N * (N - 1) // 2
+    torch.manual_seed(1234)
+    keep = torch.empty(B, P, dtype=torch.uint8, device=dev).bernoulli_(1.0 - p).cpu()
+    torch.manual_seed(1234)
+    x = x0.to(dev).requires_grad_()
+    y, attn = lay(x)
+    assert 0 < int(keep.sum()) < keep.numel()
+    assert bool((attn.detach().float().cpu().squeeze(-1)[keep == 0] == 0).all()), "the layer drew a different mask"
+    xr = x0.float().clone().requires_grad_()
+    pr = [q.float().clone().requires_grad_() for q in ps]
+    yr, ar = O.afm_layer(xr, *pr, score_keep=keep, keep_scale=1.0 / (1.0 - p))
+    assert rel_err(y.rename(None).float().cpu(), yr) <= tol
+    assert rel_err(attn.float().cpu(), ar) <= tol
+    go, ga = torch.randn(B, E, generator=g), torch.randn(ar.shape, generator=g)
+    ((y.rename(None).float() * go.to(dev)).sum() + (attn.float() * ga.to(dev)).sum()).backward()
+    ((yr * go).sum() + (ar * ga).sum()).backward()
+    assert rel_err(x.grad.float().cpu(), xr.grad) <= tol * 3
+    a = lay.attention
+    for q, r in zip((a.Linear.weight, a.Linear.bias, a.OutProj.weight), pr):
+        err = float((q.grad.float().cpu() - r.grad).abs().max())
+        assert err <= tol * 3 * max(float(r.grad.abs().max()), 1e-2)
+    lay.eval()                              # eval: dropout is the identity, scores sum to one
+    _, attn_e = lay(x0.to(dev))
+    assert float((attn_e.float().sum(1) - 1).abs().max()) <= (1e-5 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("B,N,E", [(33, 6, 64), (8, 4, 24), (129, 12, 16)])
+def test_bilinear_submodules_stand_alone_forward(dev, dtype, tol, B, N, E):
+    """FieldAllTypeBilinear / FieldEachTypeBilinear called directly with gathered (B,P,E) operands, as the reference's
+    BilinearInteractionLayer.forward calls them (bilinear_interaction.py:72-76, 144-149): library GEMM + the HIP product /
+    bias pass, gradients for both operands and the parameters; off-GPU they raise like every module here."""
+    from torecsys_amd.layers import FieldAllTypeBilinear, FieldEachTypeBilinear
+    g = torch.Generator().manual_seed(B + N + E)
+    r, c = O.pair_indices(N)
+    P = len(r)
+    x0 = (torch.randn(B, N, E, generator=g) * 0.5).to(dtype)
+    for kind in ("all", "each"):
+        torch.manual_seed(3)
+        lay = (FieldAllTypeBilinear(E, E) if kind == "all" else FieldEachTypeBilinear(P, E, E))
+        with pytest.raises(RuntimeError, match="no CPU path"):
+            lay(x0[:, r].float(), x0[:, c].float())
+        lay = lay.to(dev).to(dtype)
+        a = x0[:, r].contiguous().to(dev).requires_grad_()
+        b = x0[:, c].contiguous().to(dev).requires_grad_()
+        y = lay(a, b)
+        ar, br = x0[:, r].float().clone().requires_grad_(), x0[:, c].float().clone().requires_grad_()
+        Wr = lay.weight.detach().float().cpu().requires_grad_()
+        br_ = lay.bias.detach().float().cpu().requires_grad_()
+        yr = (torch.matmul(ar, Wr) if kind == "all" else torch.einsum("bpe,peh->bph", ar, Wr)) * br + br_
+        assert rel_err(y.float().cpu(), yr) <= tol, kind
+        go = torch.randn(yr.shape, generator=g)
+        (y.float() * go.to(dev)).sum().backward()
+        (yr * go).sum().backward()
+        for got, ref, n in ((a.grad, ar.grad, "g1"), (b.grad, br.grad, "g2"), (lay.weight.grad, Wr.grad, "gW"),
+                            (lay.bias.grad, br_.grad, "gb")):
+            assert rel_err(got.float().cpu(), ref) <= tol * 3, (kind, n)

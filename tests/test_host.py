@@ -130,10 +130,10 @@ def test_patch_rebinds_reference_aliases():
     try:
         torecsys_amd.patch(pkg)
         assert lay.FMLayer is L.FMLayer and mdl.FMLayer is L.FMLayer and lay.CINLayer is L.CINLayer
-        assert lay.DNNLayer is Old          # out-of-path layers are left alone
+        assert lay.DNNLayer is L.MultilayerPerceptionLayer      # the models' deep branch
         assert inp.MultiIndicesEmbedding is torecsys_amd.inputs.MultiIndicesEmbedding
         torecsys_amd.unpatch()
-        assert lay.FMLayer is Old and mdl.FMLayer is Old and inp.MultiIndicesEmbedding is Old
+        assert lay.FMLayer is Old and mdl.FMLayer is Old and inp.MultiIndicesEmbedding is Old and lay.DNNLayer is Old
     finally:
         for m in (pkg, lay, mdl, inp):
             sys.modules.pop(m.__name__, None)
@@ -188,3 +188,102 @@ def test_fused_optimizer_state_dict_roundtrip():
     assert torch.equal(adam2.state_for(p2.data, p2)[0], adam.state_for(p.data, p)[0])
     with pytest.raises(KeyError):
         FusedSparseAdam().load_state_dict(sd, [("other", p2)])
+
+
+REFERENCE = "/root/reference"
+
+
+def _import_real_reference():
+    """The stub recipe of SURVEY 8c (tests/golden/make_golden.py): skip torecsys/__init__.py, stub torchvision."""
+    import importlib
+    saved = {k: sys.modules.get(k) for k in ("torecsys", "torchvision", "torchvision.transforms")}
+    pkg = types.ModuleType("torecsys")
+    pkg.__path__ = [REFERENCE + "/torecsys"]
+    sys.modules["torecsys"] = pkg
+    tv, tvt = types.ModuleType("torchvision"), types.ModuleType("torchvision.transforms")
+    tv.transforms = tvt
+    sys.modules["torchvision"], sys.modules["torchvision.transforms"] = tv, tvt
+    mods = [importlib.import_module("torecsys." + m) for m in ("inputs", "layers", "models")]
+    return pkg, mods, saved
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir(REFERENCE + "/torecsys"),
+                    reason="the reference never travels to the GPU box: build-container test")
+def test_patch_on_the_real_reference_models():
+    """patch() on the REAL reference: the four north-star models (models/ctr/factorization_machine.py:35,
+    deep_fm.py:46-53, deep_and_cross_network.py:43-56, xdeep_fm.py:60-79) and the Inputs router build on torecsys_amd
+    classes for every hot-path child -- interaction layer, deep MLP, embeddings, router -- with the reference's
+    state_dict keys, and a patched MultiIndicesEmbedding fuses the FM term by default."""
+    import warnings
+    import torecsys_amd
+    from torecsys_amd import inputs as I, layers as L
+    warnings.filterwarnings("ignore")
+    pkg, (ref_inputs, ref_layers, ref_models), saved = _import_real_reference()
+    try:
+        N, E = 5, 8
+        sizes = [7, 3, 11, 5, 9]
+
+        def build_all():
+            mods = {
+                "fm": ref_models.FactorizationMachineModel(use_bias=True, dropout_p=0.0),
+                "deepfm": ref_models.DeepFactorizationMachineModel(embed_size=E, num_fields=N, deep_layer_sizes=[16, 16],
+                                                                   fm_dropout_p=0.0),
+                "dcn": ref_models.DeepAndCrossNetworkModel(inputs_size=E, num_fields=N, deep_output_size=4,
+                                                           deep_layer_sizes=[16, 16], cross_num_layers=3),
+                "xdeepfm": ref_models.XDeepFactorizationMachineModel(embed_size=E, num_fields=N, cin_layer_sizes=[6, 6],
+                                                                     deep_layer_sizes=[16, 16]),
+            }
+            emb = ref_inputs.MultiIndicesEmbedding(embed_size=E, field_sizes=sizes)
+            feat = ref_inputs.MultiIndicesEmbedding(embed_size=1, field_sizes=sizes)
+            emb.set_schema(["c%d" % i for i in range(N)])
+            feat.set_schema(["c%d" % i for i in range(N)])
+            router = ref_inputs.Inputs(schema={"feat_inputs": feat, "emb_inputs": emb})
+            return mods, emb, router
+
+        ref_mods, ref_emb, ref_router = build_all()                       # the reference's own classes
+        ref_keys = {k: list(m.state_dict().keys()) for k, m in ref_mods.items()}
+        ref_router_keys = list(ref_router.state_dict().keys())
+        assert type(ref_mods["deepfm"].deep).__module__.startswith("torecsys.")
+
+        torecsys_amd.patch(pkg)
+        try:
+            mods, emb, router = build_all()
+            assert isinstance(mods["fm"].fm, L.FactorizationMachineLayer)
+            assert isinstance(mods["deepfm"].fm, L.FactorizationMachineLayer)
+            assert isinstance(mods["deepfm"].deep, L.MultilayerPerceptionLayer)
+            assert isinstance(mods["dcn"].cross, L.CrossNetworkLayer)
+            assert isinstance(mods["dcn"].deep, L.MultilayerPerceptionLayer)       # the per-field MLP (SURVEY 8f N4)
+            assert isinstance(mods["xdeepfm"].cin, L.CompressInteractionNetworkLayer)
+            assert isinstance(mods["xdeepfm"].deep, L.MultilayerPerceptionLayer)
+            assert isinstance(emb, I.MultiIndicesEmbedding) and emb.fuse_fm is True
+            assert isinstance(router, I.Inputs)
+            for alias in ("DNNLayer", "DenseLayer", "FullyConnectLayer", "FeedForwardLayer", "MultilayerPerceptionLayer"):
+                assert getattr(ref_layers, alias) is L.MultilayerPerceptionLayer, alias
+            for k, m in mods.items():
+                assert list(m.state_dict().keys()) == ref_keys[k], k
+                for c in m.modules():      # nothing of the reference's layer package is left inside the models
+                    assert not type(c).__module__.startswith("torecsys.layers"), (k, type(c))
+            assert list(router.state_dict().keys()) == ref_router_keys
+            # reference checkpoints load unchanged
+            for k, m in mods.items():
+                m.load_state_dict(ref_mods[k].state_dict())
+            # opt-outs
+            torecsys_amd.unpatch()
+            assert I.DEFAULT_FUSE_FM is False
+            torecsys_amd.patch(pkg, fuse_fm=False, mlp=False, router=False)
+            m2, e2, r2 = build_all()
+            assert e2.fuse_fm is False and not isinstance(r2, I.Inputs)
+            assert not isinstance(m2["deepfm"].deep, L.MultilayerPerceptionLayer)
+            assert isinstance(m2["deepfm"].fm, L.FactorizationMachineLayer)
+        finally:
+            torecsys_amd.unpatch()
+        m3, e3, _ = build_all()
+        assert type(m3["deepfm"].fm).__module__.startswith("torecsys.layers") and not isinstance(e3, I.MultiIndicesEmbedding)
+    finally:
+        for k in [k for k in sys.modules if k == "torecsys" or k.startswith("torecsys.")]:
+            del sys.modules[k]
+        for k, v in saved.items():
+            if v is not None:
+                sys.modules[k] = v
+            else:
+                sys.modules.pop(k, None)

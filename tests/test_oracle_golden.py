@@ -283,3 +283,29 @@ def test_pair_layer_quirks_in_reference(golden):
         O.outer_product_layer(torch.zeros(2, 3, 4), torch.zeros(1, 3, 4), "cube")
     with pytest.raises(ValueError):
         O.bilinear_layer(torch.zeros(2, 3, 4), torch.zeros(4, 4), torch.zeros(4), "interaction")
+
+
+# ---- AFM at the reference's default configuration: training mode, dropout on the scores and on the output
+# (tests/golden/make_golden_afm_drop.py records the masks the reference drew) ----
+from conftest import AFM_DROP_SHAPES  # noqa: E402
+
+
+@pytest.mark.parametrize("shape", AFM_DROP_SHAPES)
+def test_afm_training_mode_dropout(golden, shape):
+    G = golden("afm_drop")
+    t = _tag(shape)
+    p = float(G(f"{t}/p")[0])
+    scale = 1.0 / (1.0 - p)
+    xa = G(f"{t}/x").requires_grad_()
+    ps = [G(f"{t}/{n}").requires_grad_() for n in ("W1", "b1", "W2", "b2")]
+    keep = G(f"{t}/score_keep")
+    assert 0 < int(keep.sum()) < keep.numel()                       # the fixture really drops some scores
+    y0, attn = O.afm_layer(xa, *ps, score_keep=keep, keep_scale=scale)
+    assert rel_err(y0, G(f"{t}/out_before_dropout")) <= TOL * 2
+    assert rel_err(attn, G(f"{t}/attn")) <= TOL * 2
+    y = y0 * G(f"{t}/out_keep").to(y0.dtype) * scale                # the output nn.Dropout given its mask
+    assert rel_err(y, G(f"{t}/out")) <= TOL * 2
+    ((y * G(f"{t}/gout")).sum() + (attn * G(f"{t}/gattn")).sum()).backward()
+    assert rel_err(xa.grad, G(f"{t}/gx")) <= 5e-6
+    for p_, n in zip(ps, ("gW1", "gb1", "gW2", "gb2")):
+        assert rel_err(p_.grad, G(f"{t}/{n}")) <= 1e-5, n

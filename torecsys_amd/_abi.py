@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("TRS_LIB_PATH") or os.path.join(_HERE, "libtrs_hip.so"
 TRS_F32, TRS_BF16 = 0, 1
 TRS_I64, TRS_I32 = 0, 1
 
-_P, _I32, _I64, _SZ = c_void_p, c_int32, c_int64, c_size_t
+_P, _I32, _I64, _SZ, _F32 = c_void_p, c_int32, c_int64, c_size_t, ctypes.c_float
 
 # name -> (restype, argtypes); must list every symbol of include/trs_abi.h (tests/test_abi.py checks)
 SIGNATURES = {
@@ -44,6 +44,8 @@ SIGNATURES = {
     "trs_opn_vec_bwd_workspace_bytes": (_SZ, [_I64, _I32, _I32]),
     "trs_opn_vec_bwd": (c_int32, [_P, _P, _P, _I32, _I64, _I32, _I32, _I32, _P, _P, _P, _SZ, _P]),
     "trs_pair_mul_fwd": (c_int32, [_P, _P, _P, _I32, _I64, _I32, _I32, _I32, _P, _P]),
+    "trs_rows_mul_bias_fwd": (c_int32, [_P, _P, _P, _I32, _I64, _I32, _I32, _I32, _P, _P]),
+    "trs_rows_mul_bwd": (c_int32, [_P, _P, _P, _I64, _I32, _I32, _P, _P, _P]),
     "trs_pair_mul_bwd": (c_int32, [_P, _P, _P, _I64, _I32, _I32, _I32, _P, _P, _P]),
     "trs_pair_bilinear_fwd": (c_int32, [_P, _P, _I32, _P, _I32, _I32, _I64, _I32, _I32, _I32, _P, _P]),
     "trs_pair_bilinear_bwd_data": (c_int32, [_P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _P, _P, _P]),
@@ -55,6 +57,9 @@ SIGNATURES = {
     "trs_pair_epilogue_fwd": (c_int32, [_P, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32, _P, _P]),
     "trs_pair_epilogue_bwd": (c_int32, [_P, _P, _P, _I32, _I64, _I32, _I32, _I32, _P, _P]),
     "trs_afm_fwd": (c_int32, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _P, _P]),
+    "trs_afm_fwd_dropout": (c_int32, [_P, _P, _P, _P, _P, _P, _F32, _I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P]),
+    "trs_afm_bwd_dropout": (c_int32, [_P, _P, _P, _P, _P, _F32, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P,
+                                      _P, _P, _SZ, _P]),
     "trs_afm_bwd_workspace_bytes": (_SZ, [_I64, _I32, _I32, _I32]),
     "trs_afm_bwd": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "trs_pack_columns": (c_int32, [_P, _P, _I32, _I32, _I64, _P, _I32, _P]),

@@ -50,6 +50,7 @@ struct AfmLds {
   float* w2;    // [A]
   float* lg;    // [P]  logits -> scores
   float* aux;   // [P]  backward: d(score) -> d(logit)
+  float* msk;   // [P]  score-dropout multiplier of every pair (0 or keep_scale; 1 without dropout)
   float* vec;   // [E]  forward: output accumulator; backward: g_out
   float* dh;    // [4][A] per-wave d(hidden)
   float* red;   // [4]
@@ -65,13 +66,14 @@ __device__ __forceinline__ AfmLds afm_carve(float* smem, int N, int E, int A, in
   l.w2 = p; p += A;
   l.lg = p; p += P;
   l.aux = p; p += bwd ? P : 0;
+  l.msk = p; p += P;
   l.vec = p; p += E;
   l.dh = p; p += bwd ? 4 * A : 0;
   l.red = p;
   return l;
 }
 __host__ __device__ inline size_t afm_lds_floats(int N, int E, int A, int P, bool bwd) {
-  return (size_t)N * E + (size_t)E * A * (bwd ? 2 : 1) + 2 * A + (size_t)P * (bwd ? 2 : 1) + E + (bwd ? 4 * A : 0) + 8;
+  return (size_t)N * E + (size_t)E * A * (bwd ? 2 : 1) + 2 * A + (size_t)P * (bwd ? 3 : 2) + E + (bwd ? 4 * A : 0) + 8;
 }
 
 template <typename T>
@@ -107,7 +109,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void afm_fwd_kernel(const T* __restrict__ x, const T* __restrict__ W1,
                                                       const T* __restrict__ b1, const T* __restrict__ w2,
                                                       const T* __restrict__ b2, int64_t B, int N, int E, int A,
-                                                      T* __restrict__ out, T* __restrict__ attn) {
+                                                      T* __restrict__ out, T* __restrict__ attn,
+                                                      const uint8_t* __restrict__ keep, float keep_scale,
+                                                      T* __restrict__ attn_drop) {
   extern __shared__ float smem[];
   const int P = N * (N - 1) / 2;
   const AfmLds l = afm_carve(smem, N, E, A, P, false);
@@ -145,9 +149,13 @@ __global__ __launch_bounds__(256) void afm_fwd_kernel(const T* __restrict__ x, c
     s = block_sum(s, l.red);
     const float inv = 1.f / s;
     for (int p = threadIdx.x; p < P; p += 256) {
-      const float sc = l.lg[p] * inv;
-      l.lg[p] = sc;
+      float sc = l.lg[p] * inv;
       attn[b * P + p] = from_f32<T>(sc);
+      if (keep != nullptr) {      // dropout on the scores (attentional_factorization_machine.py:82): the sum uses the dropped ones
+        sc = keep[b * P + p] ? sc * keep_scale : 0.f;
+        attn_drop[b * P + p] = from_f32<T>(sc);
+      }
+      l.lg[p] = sc;
     }
     __syncthreads();
     // out[e] = sum_p score[p] x_i[e] x_j[e]: each wave takes every 4th pair, lanes along e
@@ -182,7 +190,9 @@ template <int AT /* A/16 */, int KS /* E/32 */>
 __global__ __launch_bounds__(256) void afm_fwd_mfma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ W1,
                                                            const bf16_t* __restrict__ b1, const bf16_t* __restrict__ w2,
                                                            const bf16_t* __restrict__ b2, int64_t B, int N,
-                                                           bf16_t* __restrict__ out, bf16_t* __restrict__ attn) {
+                                                           bf16_t* __restrict__ out, bf16_t* __restrict__ attn,
+                                                           const uint8_t* __restrict__ keep, float keep_scale,
+                                                           bf16_t* __restrict__ attn_drop) {
   constexpr int E = 32 * KS, A = 16 * AT, RS = E * 2 + 16;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int P = N * (N - 1) / 2, PT = (P + 15) / 16;
@@ -191,6 +201,7 @@ __global__ __launch_bounds__(256) void afm_fwd_mfma_kernel(const bf16_t* __restr
   int* lut = reinterpret_cast<int*>(lg + PT * 16);               // [PT*16]  (i << 16) | j, padded with pair 0
   float* vec = reinterpret_cast<float*>(lut + PT * 16);          // [E]
   float* red = vec + E;                                          // [8]
+  float* mk = red + 8;                                           // [PT*16] score-dropout multipliers (dropout only)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, n = lane & 15;
   for (int p = threadIdx.x; p < PT * 16; p += 256) {
     int i = 0, j = 1;
@@ -221,6 +232,8 @@ __global__ __launch_bounds__(256) void afm_fwd_mfma_kernel(const bf16_t* __restr
           *reinterpret_cast<const uint4*>(x + (b * N + row) * (int64_t)E + col * 8);
     }
     for (int k = threadIdx.x; k < E; k += 256) vec[k] = 0.f;
+    if (keep != nullptr)
+      for (int p = threadIdx.x; p < PT * 16; p += 256) mk[p] = (p < P && keep[b * P + p]) ? keep_scale : 0.f;
     __syncthreads();
     // online softmax (flash-attention style): running max / normaliser per wave, the weighted sum of the pair
     // products accumulates in registers (lane: pair column n, e runs 8q..8q+7 per k slab) while the logits are made
@@ -265,10 +278,12 @@ __global__ __launch_bounds__(256) void afm_fwd_mfma_kernel(const bf16_t* __restr
       const float w = valid ? __expf(lgv - new_m) : 0.f;
       run_l = run_l * scale + w;
       run_m = new_m;
+      // score dropout scales a pair's weight in the SUM only; the normaliser is the undropped softmax's
+      const float wd = keep != nullptr ? w * mk[pt * 16 + n] : w;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) ov[ks][k] = fmaf(w, pr[ks][k], ov[ks][k] * scale);
+        for (int k = 0; k < 8; ++k) ov[ks][k] = fmaf(wd, pr[ks][k], ov[ks][k] * scale);
     }
     // combine the 16 pair columns of each wave and the four waves
     float wm = run_m;
@@ -294,7 +309,11 @@ __global__ __launch_bounds__(256) void afm_fwd_mfma_kernel(const bf16_t* __restr
     __syncthreads();
     const float sum = red[4] + red[5] + red[6] + red[7];
     const float inv = 1.f / sum;
-    for (int p = threadIdx.x; p < P; p += 256) attn[b * P + p] = from_f32<bf16_t>(__expf(lg[p] - m) * inv);
+    for (int p = threadIdx.x; p < P; p += 256) {
+      const float sc = __expf(lg[p] - m) * inv;
+      attn[b * P + p] = from_f32<bf16_t>(sc);
+      if (keep != nullptr) attn_drop[b * P + p] = from_f32<bf16_t>(sc * mk[p]);
+    }
     __syncthreads();
     for (int k = threadIdx.x; k < E; k += 256) out[b * E + k] = from_f32<bf16_t>(vec[k] * inv);
   }
@@ -302,7 +321,7 @@ __global__ __launch_bounds__(256) void afm_fwd_mfma_kernel(const bf16_t* __restr
 
 static size_t afm_fwd_mfma_lds(int N, int E) {
   const int P = N * (N - 1) / 2, PT = (P + 15) / 16;
-  return (size_t)((N * (E * 2 + 16) + 15) & ~15) + (size_t)PT * 16 * 8 + (size_t)E * 4 + 64;
+  return (size_t)((N * (E * 2 + 16) + 15) & ~15) + (size_t)PT * 16 * 12 + (size_t)E * 4 + 64;
 }
 
 // Conflict-free pair schedule (trs_common.hpp): rounds of pairs that share no field, so the four waves can add into
@@ -323,7 +342,8 @@ __global__ __launch_bounds__(256) void afm_bwd_kernel(const T* __restrict__ g_ou
                                                       const T* __restrict__ x, const T* __restrict__ attn,
                                                       const T* __restrict__ W1, const T* __restrict__ b1,
                                                       const T* __restrict__ w2, int64_t B, int N, int E, int A,
-                                                      T* __restrict__ gx, float* __restrict__ partial) {
+                                                      T* __restrict__ gx, float* __restrict__ partial,
+                                                      const uint8_t* __restrict__ keep, float keep_scale) {
   extern __shared__ float smem[];
   const int P = N * (N - 1) / 2;
   const AfmLds l = afm_carve(smem, N, E, A, P, true);
@@ -349,9 +369,12 @@ __global__ __launch_bounds__(256) void afm_bwd_kernel(const T* __restrict__ g_ou
       gxs[k] = 0.f;
     }
     for (int k = threadIdx.x; k < E; k += 256) l.vec[k] = g_out != nullptr ? to_f32(g_out[b * E + k]) : 0.f;
-    for (int p = threadIdx.x; p < P; p += 256) l.lg[p] = to_f32(attn[b * P + p]);
+    for (int p = threadIdx.x; p < P; p += 256) {
+      l.lg[p] = to_f32(attn[b * P + p]);
+      l.msk[p] = keep == nullptr ? 1.f : (keep[b * P + p] ? keep_scale : 0.f);
+    }
     __syncthreads();
-    // d(score)
+    // d(score): with score dropout the sum and the returned scores see score * msk
     for (int p = wave; p < P; p += 4) {
       int i, j;
       pair_ij(p, N, &i, &j);
@@ -359,7 +382,7 @@ __global__ __launch_bounds__(256) void afm_bwd_kernel(const T* __restrict__ g_ou
       if (lane < E) d = l.vec[lane] * l.xs[i * E + lane] * l.xs[j * E + lane];
       if (64 + lane < E) d = fmaf(l.vec[64 + lane], l.xs[i * E + 64 + lane] * l.xs[j * E + 64 + lane], d);
       d = wave_sum(d);
-      if (lane == 0) l.aux[p] = d + (g_attn != nullptr ? to_f32(g_attn[b * P + p]) : 0.f);
+      if (lane == 0) l.aux[p] = (d + (g_attn != nullptr ? to_f32(g_attn[b * P + p]) : 0.f)) * l.msk[p];
     }
     __syncthreads();
     float s = 0.f;
@@ -372,7 +395,7 @@ __global__ __launch_bounds__(256) void afm_bwd_kernel(const T* __restrict__ g_ou
         const int ij = sched[r * H + k];
         if (ij < 0) continue;
         const int i = ij >> 16, j = ij & 0xffff, p = i * (2 * N - i - 1) / 2 + j - i - 1;
-        const float dl = l.aux[p], sc = l.lg[p];
+        const float dl = l.aux[p], sc = l.lg[p] * l.msk[p];
         float acc[2];
         afm_hidden(l, i, j, E, A, lane, acc);
         if (lane < A) {
@@ -454,7 +477,8 @@ __global__ __launch_bounds__(256) void afm_bwd_mfma_kernel(const bf16_t* __restr
                                                            const bf16_t* __restrict__ x, const bf16_t* __restrict__ attn,
                                                            const bf16_t* __restrict__ W1, const bf16_t* __restrict__ b1,
                                                            const bf16_t* __restrict__ w2, int64_t B, int N,
-                                                           bf16_t* __restrict__ gx, float* __restrict__ partial) {
+                                                           bf16_t* __restrict__ gx, float* __restrict__ partial,
+                                                           const uint8_t* __restrict__ keep, float keep_scale) {
   constexpr int E = 32 * KS, A = 16 * AT, ET = 2 * KS, AKS = AT / 2, RS = E * 2 + 16, TS = 80;
   constexpr int GS = E + 8;      // row stride (floats) of the per-wave gradient blocks: rows of different fields must not
                                  // start on the same LDS bank (E floats = a whole number of bank sweeps -> 16-way conflicts)
@@ -465,6 +489,7 @@ __global__ __launch_bounds__(256) void afm_bwd_mfma_kernel(const bf16_t* __restr
   char* xs = sp; sp += (N * RS + 15) & ~15;
   float* lg = reinterpret_cast<float*>(sp); sp += PP * 4;
   float* aux = reinterpret_cast<float*>(sp); sp += PP * 4;
+  float* msk = reinterpret_cast<float*>(sp); sp += PP * 4;       // score-dropout multipliers (1 without dropout)
   int* lutp = reinterpret_cast<int*>(sp); sp += PP * 4;
   float* go = reinterpret_cast<float*>(sp); sp += E * 4;
   float* red = reinterpret_cast<float*>(sp); sp += 64;
@@ -536,7 +561,10 @@ __global__ __launch_bounds__(256) void afm_bwd_mfma_kernel(const bf16_t* __restr
           *reinterpret_cast<const uint4*>(x + (b * N + row) * (int64_t)E + col * 8);
     }
     for (int k = threadIdx.x; k < E; k += 256) go[k] = g_out != nullptr ? to_f32(g_out[b * E + k]) : 0.f;
-    for (int p = threadIdx.x; p < P; p += 256) lg[p] = to_f32(attn[b * P + p]);
+    for (int p = threadIdx.x; p < P; p += 256) {
+      lg[p] = to_f32(attn[b * P + p]);
+      msk[p] = keep == nullptr ? 1.f : (keep[b * P + p] ? keep_scale : 0.f);
+    }
     for (int k = lane; k < N * GS; k += 64) gxs[k] = 0.f;
     __syncthreads();
     // d(score)_p = g_attn_p + g_out . prod_p      (one pair per thread, 16-byte row reads)
@@ -551,7 +579,7 @@ __global__ __launch_bounds__(256) void afm_bwd_mfma_kernel(const bf16_t* __restr
 #pragma unroll
         for (int k = 0; k < 8; ++k) d = fmaf(go[8 * c + k], xi[k] * xj[k], d);
       }
-      aux[p] = d + (g_attn != nullptr ? to_f32(g_attn[b * P + p]) : 0.f);
+      aux[p] = (d + (g_attn != nullptr ? to_f32(g_attn[b * P + p]) : 0.f)) * msk[p];
     }
     __syncthreads();
     float s = 0.f;
@@ -566,7 +594,7 @@ __global__ __launch_bounds__(256) void afm_bwd_mfma_kernel(const bf16_t* __restr
         const bool valid = ent >= 0;
         const int i = valid ? ent >> 16 : 0, j = valid ? ent & 0xffff : 1;
         const int p = i * (2 * N - i - 1) / 2 + j - i - 1;
-        const float dlv = valid ? aux[p] : 0.f, scv = valid ? lg[p] : 0.f;
+        const float dlv = valid ? aux[p] : 0.f, scv = valid ? lg[p] * msk[p] : 0.f;
         float xi[KS][8], xj[KS][8];
         afm_f32x4 acc1[AT];
 #pragma unroll
@@ -737,7 +765,7 @@ static size_t afm_bwd_mfma_lds(int N, int E, int A) {
   const int P = N * (N - 1) / 2, PP = (P + 15) & ~15;
   const int R = afm_rounds(N), H = afm_width(N), TPR = (H + 15) / 16;
   const size_t grad = std::max<size_t>((size_t)4 * N * (E + 8) * 4, ((size_t)A * E + 2 * A + 1) * 4);
-  return (size_t)((N * (E * 2 + 16) + 15) & ~15) + (size_t)PP * 12 + (size_t)E * 4 + 64 + (size_t)R * TPR * 64 + grad +
+  return (size_t)((N * (E * 2 + 16) + 15) & ~15) + (size_t)PP * 16 + (size_t)E * 4 + 64 + (size_t)R * TPR * 64 + grad +
          (size_t)4 * (A + E) * 80 + 64;
 }
 
@@ -768,10 +796,17 @@ using namespace trs;
 
 extern "C" int trs_afm_fwd(const void* x, const void* W1, const void* b1, const void* w2, const void* b2, int64_t B,
                            int32_t N, int32_t E, int32_t A, int32_t dtype, void* out, void* attn, trs_stream_t stream) {
+  return trs_afm_fwd_dropout(x, W1, b1, w2, b2, nullptr, 1.f, B, N, E, A, dtype, out, attn, nullptr, stream);
+}
+
+extern "C" int trs_afm_fwd_dropout(const void* x, const void* W1, const void* b1, const void* w2, const void* b2,
+                                   const uint8_t* keep, float keep_scale, int64_t B, int32_t N, int32_t E, int32_t A,
+                                   int32_t dtype, void* out, void* attn, void* attn_drop, trs_stream_t stream) {
   TRS_AFM_COMMON("afm_fwd");
   if (B == 0) return TRS_OK;
   TRS_REQUIRE(N >= 2, TRS_ESHAPE, "afm_fwd: needs at least two fields (N = %d)", N);
   TRS_REQUIRE(x && W1 && b1 && w2 && b2 && out && attn, TRS_EINVAL, "afm_fwd: NULL pointer");
+  TRS_REQUIRE(keep == nullptr || attn_drop != nullptr, TRS_EINVAL, "afm_fwd: a keep mask needs the attn_drop output");
   const int P = N * (N - 1) / 2;
   hipStream_t s = (hipStream_t)stream;
   static const bool no_mfma = getenv("TRS_AFM_GENERIC") != nullptr;      // tests pin the MFMA path to the generic one
@@ -782,7 +817,7 @@ extern "C" int trs_afm_fwd(const void* x, const void* W1, const void* b1, const 
 #define TRS_AFM_M(AT_, KS_)                                                                                       \
   hipLaunchKernelGGL((afm_fwd_mfma_kernel<AT_, KS_>), dim3(grid), dim3(256), lds, s, (const bf16_t*)x,            \
                      (const bf16_t*)W1, (const bf16_t*)b1, (const bf16_t*)w2, (const bf16_t*)b2, B, N, (bf16_t*)out, \
-                     (bf16_t*)attn)
+                     (bf16_t*)attn, keep, keep_scale, (bf16_t*)attn_drop)
 #define TRS_AFM_MK(AT_)                                 \
   do {                                                  \
     if (E == 32) TRS_AFM_M(AT_, 1);                     \
@@ -812,7 +847,8 @@ extern "C" int trs_afm_fwd(const void* x, const void* W1, const void* b1, const 
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)  \
       return check_launch("afm_fwd: LDS attribute");                                                                  \
     hipLaunchKernelGGL(kern, dim3(afm_grid(B)), dim3(256), lds, s, (const T_*)x, (const T_*)W1, (const T_*)b1,        \
-                       (const T_*)w2, (const T_*)b2, B, N, E, A, (T_*)out, (T_*)attn);                                \
+                       (const T_*)w2, (const T_*)b2, B, N, E, A, (T_*)out, (T_*)attn, keep, keep_scale,               \
+                       (T_*)attn_drop);                                                                               \
   } while (0)
   if (dtype == TRS_F32) TRS_AFM_F(float);
   else TRS_AFM_F(bf16_t);
@@ -829,6 +865,15 @@ extern "C" int trs_afm_bwd(const void* g_out, const void* g_attn, const void* x,
                            const void* b1, const void* w2, int64_t B, int32_t N, int32_t E, int32_t A, int32_t dtype,
                            void* gx, float* gW1, float* gb1, float* gw2, float* gb2, void* workspace, size_t ws_bytes,
                            trs_stream_t stream) {
+  return trs_afm_bwd_dropout(g_out, g_attn, x, attn, nullptr, 1.f, W1, b1, w2, B, N, E, A, dtype, gx, gW1, gb1, gw2, gb2,
+                             workspace, ws_bytes, stream);
+}
+
+extern "C" int trs_afm_bwd_dropout(const void* g_out, const void* g_attn, const void* x, const void* attn,
+                                   const uint8_t* keep, float keep_scale, const void* W1, const void* b1, const void* w2,
+                                   int64_t B, int32_t N, int32_t E, int32_t A, int32_t dtype, void* gx, float* gW1,
+                                   float* gb1, float* gw2, float* gb2, void* workspace, size_t ws_bytes,
+                                   trs_stream_t stream) {
   TRS_AFM_COMMON("afm_bwd");
   if (B == 0) return TRS_OK;
   TRS_REQUIRE(N >= 2, TRS_ESHAPE, "afm_bwd: needs at least two fields (N = %d)", N);
@@ -855,7 +900,7 @@ extern "C" int trs_afm_bwd(const void* g_out, const void* g_attn, const void* x,
       return check_launch("afm_bwd: LDS attribute");                                                                  \
     hipLaunchKernelGGL(kern, dim3(mgrid), dim3(256), mlds, s, (const bf16_t*)g_out, (const bf16_t*)g_attn,            \
                        (const bf16_t*)x, (const bf16_t*)attn, (const bf16_t*)W1, (const bf16_t*)b1, (const bf16_t*)w2, \
-                       B, N, (bf16_t*)gx, part);                                                                      \
+                       B, N, (bf16_t*)gx, part, keep, keep_scale);                                                    \
   } while (0)
 #define TRS_AFM_BMK(AT_)                                 \
   do {                                                   \
@@ -884,7 +929,8 @@ extern "C" int trs_afm_bwd(const void* g_out, const void* g_attn, const void* x,
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)  \
       return check_launch("afm_bwd: LDS attribute");                                                                  \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, (const T_*)g_out, (const T_*)g_attn, (const T_*)x,        \
-                       (const T_*)attn, (const T_*)W1, (const T_*)b1, (const T_*)w2, B, N, E, A, (T_*)gx, part);      \
+                       (const T_*)attn, (const T_*)W1, (const T_*)b1, (const T_*)w2, B, N, E, A, (T_*)gx, part, keep,  \
+                       keep_scale);                                                                                   \
   } while (0)
 #define TRS_AFM_BT(T_)                                   \
   do {                                                   \

@@ -372,6 +372,38 @@ __global__ __launch_bounds__(256) void pairx_reduce_partials_kernel(const float*
 }
 
 // ---------------------------------------------------------------------------------------------
+// rows product with bias (the stand-alone forward of FieldAllTypeBilinear / FieldEachTypeBilinear, which receive the two
+// pair operands ALREADY gathered as (B, P, E) tensors -- bilinear_interaction.py:72-76, 144-149):
+//   out[r, e] = a[r, e] * c[r, e] + bias[(bp ? r % P : 0), e]          r over B*P rows
+// and its data gradients ga = g * c, gc = g * a.  Plain element-wise streaming passes (any E).
+template <typename T>
+__global__ __launch_bounds__(256) void rows_mul_bias_fwd_kernel(const T* __restrict__ a, const T* __restrict__ c,
+                                                                const T* __restrict__ bias, int bp, int64_t rows, int P,
+                                                                int E, T* __restrict__ out) {
+  const int64_t total = rows * E, stride = (int64_t)gridDim.x * blockDim.x;
+  const bool f32 = total < ((int64_t)1 << 32);
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t r = udiv_fast(t, E, f32);
+    const int e = (int)(t - r * E);
+    float v = to_f32(a[t]) * to_f32(c[t]);
+    if (bias != nullptr) v += to_f32(bias[(bp ? (r % P) * E : 0) + e]);
+    out[t] = from_f32<T>(v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rows_mul_bwd_kernel(const T* __restrict__ g, const T* __restrict__ a,
+                                                           const T* __restrict__ c, int64_t total, T* __restrict__ ga,
+                                                           T* __restrict__ gc) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const float gv = to_f32(g[t]);
+    if (ga != nullptr) ga[t] = from_f32<T>(gv * to_f32(c[t]));
+    if (gc != nullptr) gc[t] = from_f32<T>(gv * to_f32(a[t]));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // pair product with optional bias:  out[b,p,:] = a[b,i,:] * c[b,j,:] + bias[p*bp, :]     (bp = 0 shared, 1 per pair)
 template <typename T>
 __global__ __launch_bounds__(256) void pair_mul_fwd_kernel(const T* __restrict__ a, const T* __restrict__ c,
@@ -850,6 +882,41 @@ extern "C" int trs_opn_vec_bwd(const void* g, const void* x, const void* kern, i
                        part, nblk, n, gkern_vec);
   }
   return check_launch("opn_vec_bwd");
+}
+
+extern "C" int trs_rows_mul_bias_fwd(const void* a, const void* c, const void* bias, int32_t bias_per_pair, int64_t rows,
+                                     int32_t P, int32_t E, int32_t dtype, void* out, trs_stream_t stream) {
+  TRS_REQUIRE(rows >= 0 && P > 0 && E > 0, TRS_EINVAL, "rows_mul_bias_fwd: bad size");
+  TRS_REQUIRE(dtype == TRS_F32 || dtype == TRS_BF16, TRS_EDTYPE, "rows_mul_bias_fwd: dtype %d", dtype);
+  if (rows == 0) return TRS_OK;
+  TRS_REQUIRE(a && c && out, TRS_EINVAL, "rows_mul_bias_fwd: NULL pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = stream_grid(rows * E, 256);
+  const int bp = bias_per_pair ? 1 : 0;
+  if (dtype == TRS_F32)
+    hipLaunchKernelGGL((rows_mul_bias_fwd_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)a, (const float*)c,
+                       (const float*)bias, bp, rows, P, E, (float*)out);
+  else
+    hipLaunchKernelGGL((rows_mul_bias_fwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)a,
+                       (const bf16_t*)c, (const bf16_t*)bias, bp, rows, P, E, (bf16_t*)out);
+  return check_launch("rows_mul_bias_fwd");
+}
+
+extern "C" int trs_rows_mul_bwd(const void* g, const void* a, const void* c, int64_t rows, int32_t E, int32_t dtype,
+                                void* ga, void* gc, trs_stream_t stream) {
+  TRS_REQUIRE(rows >= 0 && E > 0, TRS_EINVAL, "rows_mul_bwd: bad size");
+  TRS_REQUIRE(dtype == TRS_F32 || dtype == TRS_BF16, TRS_EDTYPE, "rows_mul_bwd: dtype %d", dtype);
+  if (rows == 0 || (ga == nullptr && gc == nullptr)) return TRS_OK;
+  TRS_REQUIRE(g && a && c, TRS_EINVAL, "rows_mul_bwd: NULL pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = stream_grid(rows * E, 256);
+  if (dtype == TRS_F32)
+    hipLaunchKernelGGL((rows_mul_bwd_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)g, (const float*)a,
+                       (const float*)c, rows * E, (float*)ga, (float*)gc);
+  else
+    hipLaunchKernelGGL((rows_mul_bwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)a,
+                       (const bf16_t*)c, rows * E, (bf16_t*)ga, (bf16_t*)gc);
+  return check_launch("rows_mul_bwd");
 }
 
 extern "C" int trs_pair_mul_fwd(const void* a, const void* c, const void* bias, int32_t bias_per_pair, int64_t B,

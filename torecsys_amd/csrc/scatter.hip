@@ -292,13 +292,20 @@ struct RowSink {
   // Optional: the bucketed rows are a COMPACT list of distinct table rows (row_map[r] = table row of bucket row r):
   // the owner side of a row-sharded table, whose 125 M-row shard cannot afford a V-sized bucket index per step.
   const int32_t* row_map = nullptr;
+  int64_t map_rows = 0;     // rows of the table row_map points into: an entry outside [0, map_rows) is skipped
 };
-__device__ __forceinline__ int64_t sink_row(const RowSink& k, int64_t r) { return k.row_map ? (int64_t)k.row_map[r] : r; }
+// table row a bucketed row lands on; -1 = a row_map entry outside the table (the sinks skip negative positions)
+__device__ __forceinline__ int64_t sink_row(const RowSink& k, int64_t r) {
+  if (k.row_map == nullptr) return r;
+  const int64_t m = (int64_t)k.row_map[r];
+  return (m >= 0 && m < k.map_rows) ? m : -1;
+}
 
 template <typename T>
 __device__ __forceinline__ void sink_vec(const RowSink& k, uint4* __restrict__ out, int64_t vec, const float* acc,
                                          bool touched) {
   constexpr int VE = Vec16<T>::VE;
+  if (vec < 0) return;
   if (k.mode == 0) {
     // dense gradient table: written once, read by the optimizer much later -- stream it past L2 (which the [g*S | g]
     // rows of the FM term want to keep)
@@ -336,6 +343,7 @@ __device__ __forceinline__ void sink_vec(const RowSink& k, uint4* __restrict__ o
 
 template <typename T>
 __device__ __forceinline__ void sink_elem(const RowSink& k, T* __restrict__ out, int64_t idx, float acc, bool touched) {
+  if (idx < 0) return;
   if (k.mode == 0) {
     out[idx] = from_f32<T>(acc);
     return;
@@ -778,7 +786,7 @@ static void scatter_group_launch(const void* g_rows, const void* g_fm, const flo
   const int L = 1 << LOG2L;
   FmSrc fs{nullptr, nullptr, 0, 0};
   if (g_fm != nullptr && fm_sum != nullptr) {
-    if (gcols == 1 && L > 1) {
+    if (gcols == 1) {      // (L == 1 too: a (B,1) buffer must never be read as B 16-byte rows)
       uint4* gvec = (uint4*)tg + B * L;
       hipLaunchKernelGGL((build_tg1_kernel<T>), dim3(stream_grid(B * L, 256, 4096)), dim3(256), 0, s, (const T*)g_fm,
                          fm_sum, (uint4*)tg, gvec, B, L);
@@ -1047,8 +1055,10 @@ extern "C" int trs_scatter_rows_update_mapped(const void* g_rows, void* table, c
   TRS_REQUIRE(optimizer >= 1 && optimizer <= 3, TRS_EINVAL, "scatter_rows_update_mapped: optimizer %d", optimizer);
   TRS_REQUIRE(optimizer == 1 || state != nullptr, TRS_EINVAL, "scatter_rows_update_mapped: missing optimizer state");
   TRS_REQUIRE(optimizer != 3 || state2 != nullptr, TRS_EINVAL, "scatter_rows_update_mapped: Adam needs both moments");
-  TRS_REQUIRE(U > 0 && U <= V, TRS_EINVAL, "scatter_rows_update_mapped: bad row counts");
+  TRS_REQUIRE(U >= 0 && V > 0 && K >= 0, TRS_EINVAL, "scatter_rows_update_mapped: bad row counts");
+  if (U == 0 || K == 0) return TRS_OK;      // a rank that received no lookups this step: nothing to update
   RowSink sink{optimizer, lr, eps, state};
+  sink.map_rows = V;
   sink.beta1 = beta1;
   sink.beta2 = beta2;
   sink.state2 = state2;

@@ -101,6 +101,8 @@ class HipOps:
 
     def shard_update(self, weight: torch.Tensor, ids: torch.Tensor, grad_rows: torch.Tensor, opt, dense_index: bool):
         """fused optimizer step on the owner: rows ``ids`` (with repeats) of ``weight`` receive ``grad_rows``"""
+        if ids.numel() == 0:          # this rank received no lookups this step
+            return
         with torch.no_grad():
             if dense_index:
                 rb = F_.row_buckets(ids.view(-1, 1), None, weight.shape[0])
@@ -108,6 +110,8 @@ class HipOps:
             else:
                 uniq, inv = torch.unique(ids, return_inverse=True)
                 rb = F_.row_buckets(inv.to(torch.int32).view(-1, 1), None, uniq.numel())
+                # ids outside the shard (the lookup read them as zero rows and raised the index flag) stay in ``uniq``:
+                # trs_scatter_rows_update_mapped skips row_map entries outside [0, V), so they update nothing
                 F_.scatter_rows_update_mapped(rb, weight.data, opt, grad_rows, uniq.to(torch.int32), key=weight)
 
     def unpermute(self, rows: torch.Tensor, inv_pos: torch.Tensor, B: int, N: int, want_fm: bool):

@@ -347,12 +347,14 @@ def scatter_rows_update_mapped(rb: RowBuckets, table: torch.Tensor, opt, g_rows:
          ptr(ws), ws_bytes, stream_ptr())
 
 
-def _apply_or_grad(rb, weight, opt, **kw):
-    """dense gradient (default) or in-place fused optimizer step (returns None)."""
+def _apply_or_grad(rb, weight, opt, key=None, **kw):
+    """dense gradient (default) or in-place fused optimizer step (returns None).  ``key``: the object the optimizer
+    state is filed under -- the parameter itself when ``weight`` is a reshaped view of it (a view is a new Python object
+    on every call: keyed by the view, the state would be re-created, and leaked, every step)."""
     if opt is None:
         return scatter_rows(rb, weight, **kw)
     with torch.no_grad():
-        scatter_rows_update(rb, weight.data, opt, key=weight, **kw)
+        scatter_rows_update(rb, weight.data, opt, key=weight if key is None else key, **kw)
     return None
 
 
@@ -416,7 +418,7 @@ class _EmbedFM(Function):
     one bucket walk (trs_scatter_rows_first)."""
 
     @staticmethod
-    def forward(ctx, weight, idx, offsets, first_weight, want_emb, opt=None, fields=False):
+    def forward(ctx, weight, idx, offsets, first_weight, want_emb, opt=None, fields=False, padding_idx=None):
         require_device(weight, idx, offsets, first_weight)
         B, N = idx.shape
         V, E = weight.shape
@@ -445,6 +447,7 @@ class _EmbedFM(Function):
         ctx.want_emb = want_emb
         ctx.opt = opt
         ctx.fields = bool(fields)
+        ctx.padding_idx = -1 if padding_idx is None else int(padding_idx)
         ctx.set_materialize_grads(False)   # unused outputs arrive as None, not as zero blocks
         outs = (emb if want_emb else fm.new_empty(0), fm, first if first is not None else fm.new_empty(0))
         if not want_emb:
@@ -462,40 +465,48 @@ class _EmbedFM(Function):
         gw = gfw = None
         has_emb = ctx.want_emb and g_emb is not None
         has_fm = g_fm is not None
-        if (ctx.fields and ctx.opt is None and g_first is not None and (has_emb or has_fm)
+        pad = ctx.padding_idx      # nn.Embedding(padding_idx=): that row of the E-wide table receives no gradient
+        if (ctx.fields and ctx.opt is None and g_first is not None and (has_emb or has_fm) and pad < 0
                 and ctx.needs_input_grad[0] and ctx.needs_input_grad[3] and (E * weight.element_size()) % 16 == 0):
             gw, gfw = scatter_rows_first(rb, weight, first_weight, g_first.contiguous(),
                                          g_rows=g_emb.contiguous() if has_emb else None,
                                          g_bcast=_fm_grad_operand(g_fm) if has_fm else None,
                                          fm_sum=fm_sum if has_fm else None)
-            return gw, None, None, gfw, None, None, None
+            return gw, None, None, gfw, None, None, None, None
         if ctx.needs_input_grad[0]:
             if has_emb or has_fm:
                 gw = _apply_or_grad(rb, weight, ctx.opt, g_rows=g_emb.contiguous() if has_emb else None,
-                                    g_bcast=_fm_grad_operand(g_fm) if has_fm else None, fm_sum=fm_sum if has_fm else None)
+                                    g_bcast=_fm_grad_operand(g_fm) if has_fm else None, fm_sum=fm_sum if has_fm else None,
+                                    padding_row=pad)
             elif ctx.opt is None:
                 gw = torch.zeros_like(weight)
         if first_weight is not None and ctx.needs_input_grad[3]:
             if g_first is not None:
                 if ctx.fields:       # one gradient value per lookup: the E = 1 table's own bucketed scatter
-                    gfw = _apply_or_grad(rb, first_weight.reshape(V, 1), ctx.opt, g_rows=g_first.contiguous())
+                    gfw = _apply_or_grad(rb, first_weight.reshape(V, 1), ctx.opt, key=first_weight,
+                                         g_rows=g_first.contiguous())
                 else:
-                    gfw = _apply_or_grad(rb, first_weight.reshape(V, 1), ctx.opt,
+                    gfw = _apply_or_grad(rb, first_weight.reshape(V, 1), ctx.opt, key=first_weight,
                                          g_bcast=g_first.contiguous().reshape(-1, 1))
                 gfw = None if gfw is None else gfw.reshape(first_weight.shape)
             elif ctx.opt is None:
                 gfw = torch.zeros_like(first_weight)
-        return gw, None, None, gfw, None, None, None
+        return gw, None, None, gfw, None, None, None, None
 
 
 def embed_fm(weight: torch.Tensor, idx: torch.Tensor, offsets: Optional[torch.Tensor] = None,
-             first_weight: Optional[torch.Tensor] = None, want_emb: bool = True, opt=None
+             first_weight: Optional[torch.Tensor] = None, want_emb: bool = True, opt=None,
+             padding_idx: Optional[int] = None
              ) -> Tuple[Optional[torch.Tensor], torch.Tensor, Optional[torch.Tensor]]:
-    """One pass over the looked-up rows: (emb (B,N,E) | None, fm (B,E), first (B,1) | None)."""
+    """One pass over the looked-up rows: (emb (B,N,E) | None, fm (B,E), first (B,1) | None).  ``padding_idx``: the
+    table row nn.Embedding(padding_idx=) keeps gradient-free (multi_indices_emb.py:48 forwards it); the forward reads
+    that row like any other, as F.embedding does."""
     idx = _as_index(idx)
     if idx.dim() != 2:
         raise ValueError(f"indices must be (B, N), got shape {tuple(idx.shape)}")
-    emb, fm, first = _EmbedFM.apply(weight, idx, offsets, first_weight, want_emb, opt, False)
+    if padding_idx is not None and padding_idx < 0:
+        padding_idx = weight.shape[0] + padding_idx
+    emb, fm, first = _EmbedFM.apply(weight, idx, offsets, first_weight, want_emb, opt, False, padding_idx)
     return (emb if want_emb else None), fm, (first if first_weight is not None else None)
 
 
@@ -928,6 +939,42 @@ def pair_mul(a: torch.Tensor, c: torch.Tensor, bias: Optional[torch.Tensor] = No
     return _PairMul.apply(a, c, bias, bias_per_pair)
 
 
+class _RowsMulBias(Function):
+    """out = a * c + bias on (B, P, E) operands that are already gathered per pair (trs_rows_mul_bias_fwd)."""
+
+    @staticmethod
+    def forward(ctx, a, c, bias, bias_per_pair):
+        require_device(a, c, bias)
+        B, P, E = a.shape
+        a, c = a.contiguous(), c.contiguous()
+        out = torch.empty_like(a)
+        bias_c = None if bias is None else bias.to(a.dtype).contiguous()
+        call("trs_rows_mul_bias_fwd", ptr(a), ptr(c), ptr(bias_c), int(bool(bias_per_pair)), B * P, P, E,
+             value_dtype_code(a), ptr(out), stream_ptr())
+        ctx.save_for_backward(a, c)
+        ctx.bias_per_pair = bool(bias_per_pair)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        a, c = ctx.saved_tensors
+        B, P, E = a.shape
+        g = g.contiguous()
+        ga = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        gc = torch.empty_like(c) if ctx.needs_input_grad[1] else None
+        call("trs_rows_mul_bwd", ptr(g), ptr(a), ptr(c), B * P, E, value_dtype_code(a), ptr(ga), ptr(gc), stream_ptr())
+        gb = _pair_bias_grad(g, ctx.bias_per_pair) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return ga, gc, gb, None
+
+
+def rows_mul_bias(a: torch.Tensor, c: torch.Tensor, bias: Optional[torch.Tensor] = None, bias_per_pair: bool = False):
+    if a.dim() != 3 or a.shape != c.shape:
+        raise ValueError(f"rows_mul_bias operands must both be (B, P, E), got {tuple(a.shape)} and {tuple(c.shape)}")
+    return _RowsMulBias.apply(a, c, bias, bias_per_pair)
+
+
 PAIR_GEMM_MIN_BATCH = 256      # below this the one-kernel path (weights streamed per sample group) is used
 
 
@@ -1083,30 +1130,40 @@ def pair_bilinear(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor]
 
 
 class _AFM(Function):
-    """(out (B,E), attn (B,NC2)) = attention-weighted sum of the pair products; see trs_afm_fwd."""
+    """(out (B,E), attn (B,NC2)) = attention-weighted sum of the pair products; see trs_afm_fwd_dropout.  With a ``keep``
+    mask (uint8 (B,NC2)) the reference's dropout on the scores (attentional_factorization_machine.py:82) happens inside
+    the pass: ``attn`` is then the dropped scores (what the reference returns) and the sum uses them."""
 
     @staticmethod
-    def forward(ctx, x, W1, b1, w2, b2):
-        require_device(x, W1, b1, w2, b2)
+    def forward(ctx, x, W1, b1, w2, b2, keep=None, keep_scale=1.0):
+        require_device(x, W1, b1, w2, b2, keep)
         x = x.contiguous()
         B, N, E = x.shape
         A = W1.shape[0]
+        P = N * (N - 1) // 2
         ps = [t.contiguous().to(x.dtype) for t in (W1, b1, w2.reshape(-1), b2.reshape(-1))]
         out = torch.empty(B, E, dtype=x.dtype, device=x.device)
-        attn = torch.empty(B, N * (N - 1) // 2, dtype=x.dtype, device=x.device)
-        call("trs_afm_fwd", ptr(x), ptr(ps[0]), ptr(ps[1]), ptr(ps[2]), ptr(ps[3]), B, N, E, A, value_dtype_code(x),
-             ptr(out), ptr(attn), stream_ptr())
-        ctx.save_for_backward(x, attn, *ps)
+        attn = torch.empty(B, P, dtype=x.dtype, device=x.device)
+        attn_drop = None
+        if keep is not None:
+            if keep.dtype != torch.uint8 or tuple(keep.shape) != (B, P):
+                raise ValueError(f"keep mask must be uint8 of shape {(B, P)}, got {keep.dtype} {tuple(keep.shape)}")
+            keep = keep.contiguous()
+            attn_drop = torch.empty_like(attn)
+        call("trs_afm_fwd_dropout", ptr(x), ptr(ps[0]), ptr(ps[1]), ptr(ps[2]), ptr(ps[3]), ptr(keep), float(keep_scale),
+             B, N, E, A, value_dtype_code(x), ptr(out), ptr(attn), ptr(attn_drop), stream_ptr())
+        ctx.save_for_backward(x, attn, keep, *ps)
+        ctx.keep_scale = float(keep_scale)
         ctx.set_materialize_grads(False)
         ctx.w2_shape, ctx.b2_shape = tuple(w2.shape), tuple(b2.shape)
-        return out, attn
+        return out, (attn if keep is None else attn_drop)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g_out, g_attn):
-        x, attn, W1, b1, w2, b2 = ctx.saved_tensors
+        x, attn, keep, W1, b1, w2, b2 = ctx.saved_tensors
         if g_out is None and g_attn is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None, None
         B, N, E = x.shape
         A = W1.shape[0]
         dev = x.device
@@ -1117,18 +1174,20 @@ class _AFM(Function):
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         go = None if g_out is None else g_out.contiguous()
         ga = None if g_attn is None else g_attn.contiguous()
-        call("trs_afm_bwd", ptr(go), ptr(ga), ptr(x), ptr(attn), ptr(W1), ptr(b1), ptr(w2), B, N, E, A,
-             value_dtype_code(x), ptr(gx), ptr(gW1), ptr(gv[:A]), ptr(gv[A:2 * A]), ptr(gv[2 * A:]), ptr(ws), ws_bytes,
-             stream_ptr())
+        call("trs_afm_bwd_dropout", ptr(go), ptr(ga), ptr(x), ptr(attn), ptr(keep), ctx.keep_scale, ptr(W1), ptr(b1),
+             ptr(w2), B, N, E, A, value_dtype_code(x), ptr(gx), ptr(gW1), ptr(gv[:A]), ptr(gv[A:2 * A]), ptr(gv[2 * A:]),
+             ptr(ws), ws_bytes, stream_ptr())
         dt = x.dtype
         return (gx, gW1.to(dt), gv[:A].to(dt), gv[A:2 * A].to(dt).reshape(ctx.w2_shape),
-                gv[2 * A:].to(dt).reshape(ctx.b2_shape))
+                gv[2 * A:].to(dt).reshape(ctx.b2_shape), None, None)
 
 
-def afm(x: torch.Tensor, W1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor):
+def afm(x: torch.Tensor, W1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor,
+        keep: Optional[torch.Tensor] = None, keep_scale: float = 1.0):
+    """``keep`` (uint8 (B,NC2), nonzero = kept) / ``keep_scale`` (1/(1-p)): dropout on the attention scores."""
     if x.dim() != 3:
         raise ValueError(f"AFM input must be (B, N, E), got {tuple(x.shape)}")
-    return _AFM.apply(x, W1, b1, w2, b2)
+    return _AFM.apply(x, W1, b1, w2, b2, keep, keep_scale)
 
 
 # --------------------------------------------------------------------------------------------
@@ -1574,7 +1633,7 @@ class _FusedMLP(Function):
         gy2 = gy.reshape(rows, widths[L]).contiguous()
         gz = [torch.empty(rows, _pad32(widths[l + 1]), dtype=torch.bfloat16, device=dev) for l in range(L - 1)]
         gb = [torch.empty(_pad32(widths[l + 1]), dtype=torch.float32, device=dev) for l in range(L)]
-        gx = torch.empty_like(x2) if ctx.needs_input_grad[0] else torch.empty_like(x2)
+        gx = torch.empty_like(x2)           # the kernel always writes dL/dx (the last GEMM of its chain)
         wl = _i32_array(widths)
         ws_bytes = size_query("trs_mlp_fused_workspace_bytes", L, wl)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)

@@ -38,6 +38,11 @@ def field_offsets(field_sizes: List[int]) -> torch.Tensor:
     return torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(sizes, 0)[:-1]])
 
 
+# What ``MultiIndicesEmbedding(fuse_fm=None)`` resolves to at construction.  ``torecsys_amd.patch(torecsys)`` switches it
+# on, so that models built from the reference's own classes run the fused lookup + FM kernel without naming it.
+DEFAULT_FUSE_FM = False
+
+
 class BaseInput(nn.Module):
     """inputs/base/__init__.py:11-45."""
 
@@ -87,14 +92,15 @@ class MultiIndicesEmbedding(BaseInput):
     (B,N) -> (B,N,E) (or (B,1,N*E) when ``flatten``).
 
     ``offsets`` is a non-persistent buffer (same ``state_dict`` as the reference -- only
-    ``embedding.weight`` -- but it follows ``.to()``).  With ``fuse_fm=True`` the lookup
+    ``embedding.weight`` -- but it follows ``.to()``).  With ``fuse_fm=True`` (``None`` = the package
+    default ``DEFAULT_FUSE_FM``, which ``torecsys_amd.patch()`` turns on) the lookup
     kernel also produces the FM second-order term of the same rows and leaves it on the returned tensor
     for ``FactorizationMachineLayer`` to pick up (one pass over the rows instead of two); ``fuse_ipn=True`` does the
     same for ``InnerProductNetworkLayer`` (bf16 tables the matrix-core pair kernel covers; plain lookup otherwise)."""
 
     def __init__(self, embed_size: Optional[int] = None, field_sizes: Optional[List[int]] = None,
                  nn_embedding: Optional[nn.Parameter] = None, device: str = 'cpu',
-                 flatten: Optional[bool] = False, fuse_fm: bool = False, fuse_ipn: bool = False, **kwargs):
+                 flatten: Optional[bool] = False, fuse_fm: Optional[bool] = None, fuse_ipn: bool = False, **kwargs):
         super().__init__()
         _check_embedding_kwargs(kwargs)
         if nn_embedding is not None:
@@ -107,7 +113,7 @@ class MultiIndicesEmbedding(BaseInput):
             raise ValueError('missing required arguments')
         self.register_buffer('offsets', field_offsets(field_sizes), persistent=False)
         self.flatten = flatten
-        self.fuse_fm = fuse_fm
+        self.fuse_fm = DEFAULT_FUSE_FM if fuse_fm is None else bool(fuse_fm)
         self.fuse_ipn = fuse_ipn
         self.field_size = self.embedding.num_embeddings
         self.embed_size = self.embedding.embedding_dim
@@ -120,7 +126,8 @@ class MultiIndicesEmbedding(BaseInput):
         if idx.dim() != 2 or idx.shape[1] != self.offsets.numel():
             raise ValueError(f'inputs must be (B, {self.offsets.numel()}), got {tuple(idx.shape)}')
         if self.fuse_fm and not self.flatten:
-            out, fm, _ = F_.embed_fm(self.embedding.weight, idx, self.offsets, opt=self.fused_optimizer)
+            out, fm, _ = F_.embed_fm(self.embedding.weight, idx, self.offsets, opt=self.fused_optimizer,
+                                     padding_idx=self.padding_idx)
             out._trs_fused_fm = (fm, out._version)
         elif (self.fuse_ipn and not self.flatten and self.padding_idx is None
               and F_.embed_ipn_supported(self.embedding.weight, idx.shape[1])):

@@ -219,10 +219,15 @@ class FieldAllTypeBilinear(BaseLayer):
         nn.init.uniform_(self.bias, -bound, bound)
 
     def forward(self, input1, input2):
-        return torch.mul(torch.matmul(input1, self.weight), input2) + self.bias
+        """(B,P,E) pair operands as ``BilinearInteractionLayer`` of the reference hands them over (:241-249; the drop-in
+        ``BilinearInteractionLayer`` above never materialises them and does not come through here): one library GEMM
+        with the shared matrix, then the product + bias pass on HIP.  Raises off-GPU like every module of this package."""
+        x1, x2 = _strip(input1), _strip(input2)
+        F_.require_device(x1, x2, self.weight)
+        return F_.rows_mul_bias(torch.matmul(x1, self.weight.to(x1.dtype)), x2, self.bias, False)
 
     def extra_repr(self):
-        return f'in1_features={self.in1_features}, in2_features={self.in2_features}, bias={self.bias is not None}'
+        return f'{self.in1_features} x {self.in2_features} shared by every pair, bias={self.bias is not None}'
 
 
 class FieldEachTypeBilinear(BaseLayer):
@@ -253,11 +258,16 @@ class FieldEachTypeBilinear(BaseLayer):
         nn.init.uniform_(self.bias, -bound, bound)
 
     def forward(self, input1, input2):
-        out = torch.matmul(input1.unsqueeze(-2), self.weight).squeeze(-2)
-        return torch.mul(out, input2) + self.bias
+        """(B,P,E) pair operands (see FieldAllTypeBilinear.forward): a batched library GEMM over the P matrices
+        ((P,B,E) @ (P,E,E)), then the product + per-pair bias pass on HIP."""
+        x1, x2 = _strip(input1), _strip(input2)
+        F_.require_device(x1, x2, self.weight)
+        T = torch.bmm(x1.transpose(0, 1), self.weight.to(x1.dtype)).transpose(0, 1)
+        return F_.rows_mul_bias(T, x2, self.bias, True)
 
     def extra_repr(self):
-        return f'in1_features={self.in1_features}, in2_features={self.in2_features}, bias={self.bias is not None}'
+        return (f'{self.weight.shape[0]} pair matrices of {self.in1_features} x {self.in2_features}, '
+                f'bias={self.bias is not None}')
 
 
 class BilinearInteractionLayer(BaseLayer):
@@ -315,9 +325,9 @@ class AttentionalFactorizationMachineLayer(BaseLayer):
     """Attentional FM, (B,N,E) -> ((B,E) named ('B','E'), (B,NC2,1) un-named attention scores).
     layers/ctr/attentional_factorization_machine.py:49-125.  Parameters as in the reference:
     ``attention.Linear.{weight (A,E), bias}``, ``attention.OutProj.{weight (1,A), bias}``; the Softmax / Dropout entries
-    of ``attention`` and the output ``dropout`` are kept as modules (dropout is applied to the scores and to the output
-    exactly where the reference applies it; the score dropout therefore acts after the fused weighted sum only in
-    eval / p = 0 -- with p > 0 in training the layer falls back to applying it before the sum in PyTorch)."""
+    of ``attention`` and the output ``dropout`` are kept as modules.  The score dropout (``attention.Dropout``, p = 0.1 by
+    default) acts BEFORE the weighted sum in the reference (:82, :105-113); in training the fused kernel takes a keep mask
+    drawn here and applies it to the scores it returns and to the sum (trs_afm_fwd_dropout / trs_afm_bwd_dropout)."""
 
     @property
     def inputs_size(self):
@@ -344,13 +354,15 @@ class AttentionalFactorizationMachineLayer(BaseLayer):
         if x.dim() != 3 or x.shape[1] != self.num_fields or x.shape[2] != self.embed_size:
             raise ValueError(f'expected (B, {self.num_fields}, {self.embed_size}), got {tuple(x.shape)}')
         lin, proj, drop = self.attention.Linear, self.attention.OutProj, self.attention.Dropout
-        outputs, attn = F_.afm(x, lin.weight, lin.bias, proj.weight, proj.bias)
-        attn_scores = attn.unsqueeze(-1)
+        keep, scale = None, 1.0
         if drop.training and drop.p > 0.0:
-            # dropout on the scores changes the weighted sum: redo it from the dropped scores (training-only path)
-            attn_scores = drop(attn_scores)
-            rows, cols = self.row_idx.to(x.device), self.col_idx.to(x.device)
-            outputs = (x[:, rows] * x[:, cols] * attn_scores).sum(dim=1)
+            # the dropout the reference applies to the scores inside ``self.attention`` (:82): only the random bits
+            # come from torch's generator (as nn.Dropout's do); masking, rescaling and the sum happen in the kernel
+            P = self.num_fields * (self.num_fields - 1) // 2
+            keep = torch.empty(x.shape[0], P, dtype=torch.uint8, device=x.device).bernoulli_(1.0 - drop.p)
+            scale = 1.0 / (1.0 - drop.p) if drop.p < 1.0 else 0.0
+        outputs, attn = F_.afm(x, lin.weight, lin.bias, proj.weight, proj.bias, keep, scale)
+        attn_scores = attn.unsqueeze(-1)
         outputs.names = ('B', 'E')
         outputs = self.dropout(outputs)
         return outputs, attn_scores
@@ -575,10 +587,14 @@ class _PaddedLinear:
                 if b is not None:
                     jobs.append((b.data_ptr(), st.b.data_ptr(), 1, b.shape[0], b.shape[0], st.b.shape[0]))
         if jobs:
-            key = tuple(jobs)
             w0 = items[0][0].weight
+            key = (str(w0.device), *jobs)     # addresses repeat across the GPUs of one process: the device is part of the key
             desc = _PaddedLinear._desc_cache.get(key)
             if desc is None:      # a blocking 48-byte-per-copy upload, once per set of parameter storages
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("torecsys_amd: the padded-weight copy descriptors of this MLP are not on the device "
+                                       "yet (a host-to-device upload cannot run inside a hipGraph capture); run one "
+                                       "eager step before capturing (graph.GraphedStep warms up by default)")
                 if len(_PaddedLinear._desc_cache) > 64:
                     _PaddedLinear._desc_cache.clear()
                 desc = torch.tensor(jobs, dtype=torch.int64, device=w0.device)

@@ -74,6 +74,9 @@ class _FusedSparse:
             st = self._state[id(p)] = {"step": int(entry.get("step", 0)), "ref": p}
             for b in self._buffers:
                 if b in entry:
+                    if tuple(entry[b].shape) != tuple(p.shape):
+                        raise ValueError(f"load_state_dict: state {b!r} of {name!r} has shape {tuple(entry[b].shape)}, "
+                                         f"the parameter has {tuple(p.shape)}")
                     st[b] = entry[b].to(device=p.device, dtype=torch.float32).clone()
 
 
