@@ -12,6 +12,10 @@
 // bias enters as the accumulator's initial value).  W_l fragments are pre-packed once per call into
 // fragment order (1 KiB per (layer, mt, ks), lane-linear -> conflict-free ds_read_b128) and kept in LDS.
 // HBM traffic: x read once, out written once (2*E*2 bytes per row); FLOPs 2*E*E*L per row on MFMA.
+#include <stdlib.h>
+
+#include <algorithm>
+
 #include "trs_common.hpp"
 
 namespace trs {
@@ -25,9 +29,12 @@ __host__ __device__ __forceinline__ int cross_row_of_slot(int mt, int m) {
 }
 
 // Pre-pack: Wp[(l*NT + mt)*KS + ks][lane][8] = W_l[row(mt, lane&15)][32*ks + 8*(lane>>4) + 0..7]
+// Wtp (optional, backward): the same fragment order for W_l^T, layers 1 .. L-1 (the gradient chain g_l = W_l^T du_l;
+// layer 0's is only needed without the detach quirk and is then read out of the forward fragments):
+//   Wtp[((l-1)*NT + mt)*KS + ks][lane][8] = W_l[32*ks + 8*(lane>>4) + 0..7][row(mt, lane&15)]
 __global__ __launch_bounds__(256) void cross_prepack_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ b,
                                                             bf16_t* __restrict__ Wp, float* __restrict__ bp, int E,
-                                                            int L) {
+                                                            int L, bf16_t* __restrict__ Wtp = nullptr) {
   const int NT = E / 16, KS = E / 32;
   const int total = L * NT * KS * 64;
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
@@ -43,6 +50,11 @@ __global__ __launch_bounds__(256) void cross_prepack_kernel(const bf16_t* __rest
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       Wp[(size_t)t * 8 + j] = Wl[(size_t)row * E + k0 + j];
+    if (Wtp != nullptr && l > 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        Wtp[((size_t)t - (size_t)NT * KS * 64) * 8 + j] = Wl[(size_t)(k0 + j) * E + row];
+    }
   }
   if (bp != nullptr)
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < L * E; t += gridDim.x * blockDim.x) bp[t] = to_f32(b[t]);
@@ -304,7 +316,7 @@ __device__ __forceinline__ void layer_matmul_pre(const uint4* Wl, const float* b
       A[mt][ks] = TRANSPOSED ? wt_frag<KS>(Wl, mt, ks, lane) : __builtin_bit_cast(bf16x8, Wl[(mt * KS + ks) * 64 + lane]);
 #pragma unroll
   for (int mt = 0; mt < NT; ++mt) {
-    if (!TRANSPOSED) {
+    if (!TRANSPOSED && bias != nullptr) {
       const float4 bv = *reinterpret_cast<const float4*>(bias + 32 * (mt >> 1) + 8 * q + 4 * (mt & 1));
       acc[mt] = f32x4{bv.x, bv.y, bv.z, bv.w};
     } else {
@@ -523,19 +535,350 @@ __global__ __launch_bounds__(64 * (B2_CHAIN + B2_DW), 2) void cross_mfma_bwd2_ke
   }
 }
 
-// out[i] += sum_p part[p][i]: 64 elements per workgroup, the partials split four ways over threadIdx.y (fixed order:
-// the sum does not depend on timing)
-__global__ __launch_bounds__(256) void cross_reduce_partials_kernel(const float* __restrict__ part, int nparts,
-                                                                    int n, float* __restrict__ out) {
-  __shared__ float red[4][64];
+// ---------------------------------------------------------------------------------------------
+// backward, round 3: gradient chain FIRST, forward recompute SECOND.
+//
+// The gradient chain needs no activation at all: du_l = g_{l+1} * x0, g_l = W_l^T du_l depends only on the incoming
+// gradient, x0 and the weights.  Only dx0 += g_{l+1} * (u_l + 1) and dW_l += du_l^T x_l need the forward values, and both
+// consume them in FORWARD order.  So a tile (16 rows, one chain wave) runs
+//   phase A  g_L -> g_{L-1} -> ... -> g_1 (-> g_0 without the detach quirk): L-1 matmuls with W_l^T, the g_l kept as
+//            packed bf16 registers (the role the u_l + 1 registers played in cross_mfma_bwd2); no slab traffic, no barrier;
+//   phase B  x_0 -> x_1 -> ... : per layer one forward matmul (u_l + 1), dx0 += g_{l+1} (u_l + 1), du_l = g_{l+1} x0 and
+//            x_l handed to the dW waves through double-buffered slabs, x_{l+1} = x0 (u_l + 1); one barrier per layer.
+// Against cross_mfma_bwd2 (forward first): no x store of all L layers in LDS (48 KiB -> two 12 KiB slab pairs), which
+// pays for (a) 96 rows per group with SIX chain waves beside two dW waves (two waves per SIMD, 256 registers: two SIMDs
+// host a pair of chain waves that overlap each other's MFMA and VALU phases, two host a chain wave beside a dW wave
+// that holds half of the E*E*L accumulators; six barriers per 96 rows instead of seven per 64.  Twelve waves -- eight
+// chain, four dW, three per SIMD on 168 registers -- was built first: hipcc spills ~100 registers of the chain waves
+// there and the kernel ran 2.4 ms) and (b) a second, TRANSPOSED set of W fragments for phase A: reading W^T out of the forward fragments with
+// ds_read_b64_tr_b16 is a 4-way bank conflict by construction (the four 256-byte quarters of a fragment a 16-lane group
+// gathers from map to the same banks; no swizzle that keeps the forward ds_read_b128 conflict-free gets below 2-way) --
+// counters of the first version of this kernel: half of all LDS cycles were conflict cycles, LDS 65 % busy.
+// Slab layout: [16-column panel][row][32 B], the two 16-byte halves of a row piece swapped for rows with bit 2 set (the
+// 8 lanes of a ds_write_b128 group then hit 8 different bank quads) and the dW waves' transpose reads take rows
+// k0..k0+3 first on even lane groups, k0+4..k0+7 first on odd ones (the two groups of a 32-lane half then cover all 64
+// banks; the permutation of k is the same for both MFMA operands).
+// LDS at E = 64, L = 6: W 48 KiB + W^T (layers 1..5) 40 KiB + biases 1.5 KiB + slabs 48 KiB = 137.5 KiB.
+constexpr int B3_CHAIN = 6;                         // chain waves per workgroup (one 16-row tile each)
+constexpr int B3_DW = 2;                            // weight-gradient waves
+constexpr int B3_ROWS = B3_CHAIN * 16;              // rows per workgroup step (96)
+constexpr int B3_PANEL = B3_ROWS * 32;              // bytes of one 16-column panel of a slab
+
+// 8 k-values (rows) x this lane's column of panel ``panel``: two transpose reads of a [4 rows][16 cols] block each
+__device__ __forceinline__ s16x8 rows_frag3(const char* tensor, int k0, int panel, int i, int q) {
+  typedef __attribute__((address_space(3))) s16x4* lds_p;
+  const int cq = i & 3, odd = q & 1;
+  const char* base = tensor + panel * B3_PANEL + (k0 + (i >> 2)) * 32 + (cq & 1) * 8;
+  const int h0 = (cq >> 1) * 16, h1 = 16 - h0;                 // rows with bit 2 clear / set: halves swapped
+  const char* p_lo = base + (odd ? 4 * 32 + h1 : h0);
+  const char* p_hi = base + (odd ? h0 : 4 * 32 + h1);
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p_lo));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p_hi));
+  return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <int NT>
+__device__ __forceinline__ void unpack_tile(const uint4* raw, XTile<NT>& t) {
+#pragma unroll
+  for (int c = 0; c < NT / 2; ++c) {
+    float f[8];
+    Vec16<bf16_t>::unpack(raw[c], f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      t.v[2 * c][i] = f[i];
+      t.v[2 * c + 1][i] = f[4 + i];
+    }
+  }
+}
+
+// acc[mt] = bias + sum_ks A[mt][ks] * B[ks], the fragments of ONE k-step in registers at a time (16 instead of 32 at
+// E = 64: the chain waves of cross_mfma_bwd3 live on 168 registers; the other chain wave of the SIMD covers the latency)
+template <int NT>
+__device__ __forceinline__ void layer_matmul_ks(const uint4* Wl, const float* bias, const uint4 (&B)[NT / 2], int lane,
+                                                int q, f32x4 (&acc)[NT]) {
+  constexpr int KS = NT / 2;
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt) {
+    if (bias != nullptr) {
+      const float4 bv = *reinterpret_cast<const float4*>(bias + 32 * (mt >> 1) + 8 * q + 4 * (mt & 1));
+      acc[mt] = f32x4{bv.x, bv.y, bv.z, bv.w};
+    } else {
+      acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    bf16x8 A[NT];
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) A[mt] = __builtin_bit_cast(bf16x8, Wl[(mt * KS + ks) * 64 + lane]);
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+      acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[mt], __builtin_bit_cast(bf16x8, B[ks]), acc[mt], 0, 0, 0);
+  }
+}
+
+#ifdef B3_TRACE      // developer build (tools/cross_trace.py): time stamps of workgroup 0's wave 0 (chain) and first dW wave
+__device__ long long b3_trace[2][1024];
+#define B3_STAMP(who, idx) \
+  do { if (blockIdx.x == 0 && lane == 0 && (idx) < 1024) b3_trace[who][idx] = (long long)wall_clock64(); } while (0)
+#else
+#define B3_STAMP(who, idx) do {} while (0)
+#endif
+
+template <int NT, int L, bool DETACH>
+__global__ __launch_bounds__(64 * (B3_CHAIN + B3_DW), 2) void cross_mfma_bwd3_kernel(
+    const uint4* __restrict__ x, const uint4* __restrict__ gout, const uint4* __restrict__ Wp,
+    const uint4* __restrict__ Wtp, const float* __restrict__ bp, int64_t rows, uint4* __restrict__ dx,
+    float* __restrict__ dWpart, float* __restrict__ dbpart) {
+  constexpr int detach_first = DETACH ? 1 : 0;
+  constexpr int KS = NT / 2;
+  constexpr int E = NT * 16;
+  constexpr int FRAG = NT * KS * 64;            // uint4 per layer
+  constexpr int TENSOR = NT * B3_PANEL;         // one (128-row x E) bf16 slab in the panel layout
+  constexpr int TPW = NT * NT / B3_DW;          // dW output tiles per dW wave
+  static_assert((NT * NT) % B3_DW == 0, "E must be a multiple of 32");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* Ws = reinterpret_cast<uint4*>(smem);                 // forward fragments, layers 0 .. L-1
+  uint4* Wts = Ws + L * FRAG;                                 // transposed fragments, layers 1 .. L-1
+  float* bs = reinterpret_cast<float*>(Wts + (L - 1) * FRAG);
+  char* duslab = reinterpret_cast<char*>(bs + L * E);         // [slot 2][panel NT][B3_ROWS][32 B]
+  char* xslab = duslab + 2 * TENSOR;                          // same
+  for (int i = threadIdx.x; i < L * FRAG; i += blockDim.x) Ws[i] = Wp[i];
+  for (int i = threadIdx.x; i < (L - 1) * FRAG; i += blockDim.x) Wts[i] = Wtp[i];
+  for (int i = threadIdx.x; i < L * E; i += blockDim.x) bs[i] = bp[i] + 1.f;      // the backward only ever needs u_l + 1
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, r = lane & 15;
+  const int64_t ngroups = (rows + B3_ROWS - 1) / B3_ROWS;
+  int step = 0;                                  // global step counter (slab slot = step & 1)
+
+  if (wave < B3_CHAIN) {
+    // ------------------------------------------------------------------ chain waves
+    uint4 nx_raw[KS], ng_raw[KS];
+    // Prefetch of the next group's rows: UNCONDITIONAL loads (row index clamped into the tensor, out-of-range rows zeroed
+    // when consumed) -- loads under a branch make hipcc's wait-count insertion wait for them wherever an older load is
+    // consumed.  Issued in the middle of phase B, when the first two g_l registers of the group are dead (the wave lives
+    // on a tight register budget), consumed after the group's last step.
+    auto fetch = [&](int64_t grp_) {
+      int64_t row_ = grp_ * B3_ROWS + wave * 16 + r;
+      row_ = row_ < rows ? row_ : rows - 1;
+#pragma unroll
+      for (int c = 0; c < KS; ++c) {
+        nx_raw[c] = x[(row_ * E + 32 * c + 8 * q) >> 3];
+        ng_raw[c] = gout[(row_ * E + 32 * c + 8 * q) >> 3];
+      }
+    };
+    constexpr int FETCH_AT = L >= 3 ? 2 : L - 1;
+    uint4 x0raw[KS], Gp[L + 1][KS];    // packed bf16: x0 (the layer-0 B operand); g_l of every layer (g_L = the input)
+    auto take = [&](int64_t grp_) {
+      const bool live = grp_ * B3_ROWS + wave * 16 + r < rows;
+#pragma unroll
+      for (int c = 0; c < KS; ++c) {
+        x0raw[c] = live ? nx_raw[c] : make_uint4(0, 0, 0, 0);
+        Gp[L][c] = live ? ng_raw[c] : make_uint4(0, 0, 0, 0);
+      }
+    };
+    fetch(blockIdx.x);
+    take(blockIdx.x);
+    // this lane's 16-byte pieces of a slab: piece c covers columns 32c+8q .. +7 -> panel 2c + (q>>1), half q&1 (swapped
+    // for rows with bit 2 set)
+    const int piece0 = (q >> 1) * B3_PANEL + (wave * 16 + r) * 32 + (((q & 1) ^ ((r >> 2) & 1)) * 16);
+    int gi = 0;
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x, ++gi) {
+      if (wave == 0) B3_STAMP(0, gi * 8);
+      // LDS addresses are re-derived from two laundered lane offsets in every group: left alone, LICM keeps ~40
+      // loop-invariant per-fragment / per-slot addresses in registers for the whole kernel (LDS offsets beyond 64 KiB
+      // do not fit the DS immediate) and the wave, which lives on 168 registers, spills its g_l to scratch
+      int lane16 = lane * 16, pc0 = piece0;
+      asm volatile("" : "+v"(lane16), "+v"(pc0));
+      const uint4* Wsl = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Ws) + lane16);
+      const uint4* Wtsl = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Wts) + lane16);
+      XTile<NT> x0f;                   // fp32 copy of this tile's x0 rows
+      unpack_tile<NT>(x0raw, x0f);
+      // ---- phase A: the gradient chain, layers L-1 .. 1 (.. 0 without the detach quirk)
+      {
+        XTile<NT> g;
+        unpack_tile<NT>(Gp[L], g);
+#pragma unroll
+        for (int l = L - 1; l >= 0; --l) {
+          if (l > 0 || detach_first == 0) {
+            XTile<NT> du;
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) du.v[mt][i] = g.v[mt][i] * x0f.v[mt][i];
+            uint4 Bdu[KS];
+            pack_tile<NT>(du, Bdu);
+            f32x4 ga[NT];
+            if (l > 0) layer_matmul_ks<NT>(Wtsl + (l > 0 ? l - 1 : 0) * FRAG, nullptr, Bdu, 0, q, ga);
+            else layer_matmul_pre<NT, true>(Ws, nullptr, Bdu, lane, q, ga);      // W_0^T out of the forward fragments
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) g.v[mt][i] = ga[mt][i];
+            pack_tile<NT>(g, Gp[l]);
+          }
+        }
+      }
+      if (wave == 0) B3_STAMP(0, gi * 8 + 1);
+      // ---- phase B: forward recompute; dx0, and du_l / x_l for the dW waves
+      XTile<NT> dx0;
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dx0.v[mt][i] = 0.f;
+      // (Issuing x_{l+1} and the MFMAs of layer l+1 before the rest of layer l -- a software pipeline inside the wave --
+      // was built and measured: +16 accumulator registers push the wave into scratch and the kernel ran 727 vs ~650 us.)
+      uint4 Bx[KS];
+#pragma unroll
+      for (int c = 0; c < KS; ++c) Bx[c] = x0raw[c];
+#pragma unroll
+      for (int l = 0; l < L; ++l, ++step) {
+        if (l == FETCH_AT) fetch(grp + gridDim.x);
+        f32x4 up[NT];                                   // u_l + 1 (the +1 rides in the bias)
+        layer_matmul_ks<NT>(Wsl + l * FRAG, bs + l * E, Bx, 0, q, up);
+        XTile<NT> du;
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float gv = frag_value<KS>(Gp[l + 1], mt, i);
+            dx0.v[mt][i] = fmaf(gv, up[mt][i], dx0.v[mt][i]);
+            du.v[mt][i] = gv * x0f.v[mt][i];
+          }
+        uint4 Bdu[KS];
+        pack_tile<NT>(du, Bdu);
+        char* dslot = duslab + ((step & 1) ? TENSOR : 0) + pc0;
+        char* xslot = xslab + ((step & 1) ? TENSOR : 0) + pc0;
+#pragma unroll
+        for (int c = 0; c < KS; ++c) {
+          *reinterpret_cast<uint4*>(dslot + 2 * c * B3_PANEL) = Bdu[c];
+          *reinterpret_cast<uint4*>(xslot + 2 * c * B3_PANEL) = Bx[c];
+        }
+        if (l + 1 < L) {
+          XTile<NT> nx;
+#pragma unroll
+          for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) nx.v[mt][i] = x0f.v[mt][i] * up[mt][i];
+          pack_tile<NT>(nx, Bx);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (wave == 0 && l < 3) B3_STAMP(0, gi * 8 + 2 + 2 * l);      // before / after the barrier of steps 0..2
+        __builtin_amdgcn_s_barrier();
+        if (wave == 0 && l < 3) B3_STAMP(0, gi * 8 + 3 + 2 * l);
+      }
+      if (detach_first == 0) {
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dx0.v[mt][i] += frag_value<KS>(Gp[0], mt, i);
+      }
+      const int64_t row = grp * B3_ROWS + wave * 16 + r;
+      if (row < rows) {
+        uint4 raw[KS];
+        pack_tile<NT>(dx0, raw);
+#pragma unroll
+        for (int c = 0; c < KS; ++c) dx[(row * E + 32 * c + 8 * q) >> 3] = raw[c];
+      }
+      take(grp + gridDim.x);
+    }
+  } else {
+    // ------------------------------------------------------------------ dW waves
+    // wave wq owns output tiles t = wq*TPW .. +TPW-1, t -> (row tile mo = t / NT, column tile no = t % NT): whole row
+    // tiles (TPW is a multiple of NT), so it also owns db of its MO row tiles.  db_l = du_l^T 1 rides on the matrix pipe:
+    // one more MFMA per A fragment whose B operand is the one-hot column l (ones in column l, zeros elsewhere), so ONE
+    // accumulator tile per row tile collects the sums of all L <= 16 layers, layer l in column l.  (Summing the A
+    // fragments on the VALU, as cross_mfma_bwd2 does, made these waves the critical path: 5.9 -> 9.9 us per 96 rows.)
+    const int wq = wave - B3_CHAIN;
+    constexpr int MO = TPW / NT;
+    static_assert(TPW % NT == 0 && MO >= 1 && L <= 16, "a dW wave owns whole row tiles; db columns = layers");
+    f32x4 dWacc[L][TPW], dbacc[MO];
+#pragma unroll
+    for (int m = 0; m < MO; ++m) dbacc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+#pragma unroll
+      for (int k = 0; k < TPW; ++k) dWacc[l][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    int gi = 0;
+    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x, ++gi) {
+#pragma unroll
+      for (int l = 0; l < L; ++l, ++step) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (wq == 0 && l < 4) B3_STAMP(1, gi * 8 + 2 * l);             // arrival at / release from the barrier
+        __builtin_amdgcn_s_barrier();                   // the chain waves have written slot step & 1 (layer l)
+        if (wq == 0 && l < 4) B3_STAMP(1, gi * 8 + 2 * l + 1);
+        const char* du_t = duslab + ((step & 1) ? TENSOR : 0);
+        const char* x_t = xslab + ((step & 1) ? TENSOR : 0);
+        const unsigned hot = (r == l) ? 0x3f803f80u : 0u;               // bf16 1.0 pairs in column l
+        const uint4 onehot = make_uint4(hot, hot, hot, hot);
+#ifndef B3_NO_DW        // (ablation switch of tools/cross_trace.py)
+#pragma unroll
+        for (int ks = 0; ks < B3_ROWS / 32; ++ks) {
+          s16x8 Bf[NT];
+#pragma unroll
+          for (int no = 0; no < NT; ++no) Bf[no] = rows_frag3(x_t, 32 * ks + 8 * q, no, r, q);
+#pragma unroll
+          for (int m = 0; m < MO; ++m) {
+            const s16x8 A = rows_frag3(du_t, 32 * ks + 8 * q, wq * MO + m, r, q);
+#pragma unroll
+            for (int no = 0; no < NT; ++no)
+              dWacc[l][m * NT + no] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                  __builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, Bf[no]), dWacc[l][m * NT + no], 0, 0, 0);
+            dbacc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A),
+                                                               __builtin_bit_cast(bf16x8, onehot), dbacc[m], 0, 0, 0);
+          }
+        }
+#endif
+      }
+    }
+    // partial results of this workgroup: D layout -> (row m = 4q+i -> e_out, col n = r -> e_in)
+    float* myW = dWpart + (size_t)blockIdx.x * L * E * E;
+    float* myb = dbpart + (size_t)blockIdx.x * L * E;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+#pragma unroll
+      for (int k = 0; k < TPW; ++k) {
+        const int mo = wq * MO + k / NT, no = k % NT;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) myW[(size_t)l * E * E + (16 * mo + 4 * q + i) * E + 16 * no + r] = dWacc[l][k][i];
+      }
+    }
+    if (r < L) {                           // column r of the db tiles = layer r
+#pragma unroll
+      for (int m = 0; m < MO; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) myb[r * E + 16 * (wq * MO + m) + 4 * q + i] = dbacc[m][i];
+    }
+  }
+}
+
+// out[i] += sum_p part[p][i]: 64 elements per workgroup, the partials split sixteen ways over the waves (fixed order:
+// the sum does not depend on timing), four loads in flight per thread
+__global__ __launch_bounds__(1024) void cross_reduce_partials_kernel(const float* __restrict__ part, int nparts,
+                                                                     int n, float* __restrict__ out) {
+  __shared__ float red[16][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + tx;
-  float s = 0.f;
-  if (i < n)
-    for (int p = ty; p < nparts; p += 4) s += part[(size_t)p * n + i];
-  red[ty][tx] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n) {
+    int p = ty;
+    for (; p + 48 < nparts; p += 64) {
+      s0 += part[(size_t)p * n + i];
+      s1 += part[(size_t)(p + 16) * n + i];
+      s2 += part[(size_t)(p + 32) * n + i];
+      s3 += part[(size_t)(p + 48) * n + i];
+    }
+    for (; p < nparts; p += 16) s0 += part[(size_t)p * n + i];
+  }
+  red[ty][tx] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (ty == 0 && i < n) out[i] += (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+  if (ty == 0 && i < n) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k][tx];
+    out[i] += s;
+  }
 }
 
 constexpr int BW_MAX_BLOCKS = 256;      // one persistent workgroup per CU
@@ -543,10 +886,10 @@ constexpr int BW_MAX_BLOCKS = 256;      // one persistent workgroup per CU
 static size_t cross_pack_bytes(int E, int L) { return (size_t)L * E * E * 2; }
 
 size_t cross_mfma_workspace_bytes(int E, int L) {
-  // [W fragments][bias fp32][per-workgroup dW partials][db partials], each 256-byte aligned
+  // [W fragments][bias fp32][per-workgroup dW partials][db partials][W^T fragments (backward)], each 256-byte aligned
   auto al = [](size_t v) { return (v + 255) / 256 * 256; };
   return al(cross_pack_bytes(E, L)) + al((size_t)L * E * 4) + al((size_t)BW_MAX_BLOCKS * L * E * E * 4) +
-         al((size_t)BW_MAX_BLOCKS * L * E * 4);
+         al((size_t)BW_MAX_BLOCKS * L * E * 4) + al(cross_pack_bytes(E, L));
 }
 
 static bool cross_mfma_covers(int E, int L) { return E % 32 == 0 && E >= 32 && E <= 128 && L >= 1; }
@@ -584,27 +927,50 @@ int cross_mfma_fwd(const void* x, const void* W, const void* b, int64_t rows, in
 }
 
 template <int NT, int L>
-static int cross_bwd_launch(const void* x, const void* g, const uint4* Wp, const float* bp, int64_t rows,
-                            void* dx, float* dWpart, float* dbpart, float* dW, float* db, int detach_first,
-                            hipStream_t s) {
+static int cross_bwd_launch(const void* x, const void* g, const uint4* Wp, const uint4* Wtp, const float* bp,
+                            int64_t rows, void* dx, float* dWpart, float* dbpart, float* dW, float* db,
+                            int detach_first, hipStream_t s) {
   constexpr int E = NT * 16;
-  const size_t lds = (size_t)L * E * E * 2 + (size_t)L * E * 4 + (size_t)(L + 2) * NT * B2_PANEL;
-  auto kern = cross_mfma_bwd2_kernel<NT, L>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return check_launch("cross_bwd(mfma): LDS attribute");
-    attr_set = true;
+  static const bool use_bwd2 = getenv("TRS_CROSS_BWD2") != nullptr;      // developer A/B switch: the round-2 kernel
+  int grid;
+  if (use_bwd2) {
+    const size_t lds = (size_t)L * E * E * 2 + (size_t)L * E * 4 + (size_t)(L + 2) * NT * B2_PANEL;
+    auto kern = cross_mfma_bwd2_kernel<NT, L>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return check_launch("cross_bwd(mfma): LDS attribute");
+      attr_set = true;
+    }
+    const int64_t ngroups = (rows + B2_ROWS - 1) / B2_ROWS;
+    grid = (int)std::min<int64_t>(ngroups, BW_MAX_BLOCKS);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (B2_CHAIN + B2_DW)), lds, s, (const uint4*)x, (const uint4*)g, Wp, bp,
+                       rows, (uint4*)dx, dWpart, dbpart, detach_first);
+  } else {
+    const size_t lds = (size_t)(2 * L - 1) * E * E * 2 + (size_t)L * E * 4 + (size_t)4 * NT * B3_PANEL;
+    auto kern = detach_first ? cross_mfma_bwd3_kernel<NT, L, true> : cross_mfma_bwd3_kernel<NT, L, false>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[detach_first ? 1 : 0]) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return check_launch("cross_bwd(mfma): LDS attribute");
+      attr_set[detach_first ? 1 : 0] = true;
+    }
+    const int64_t ngroups = (rows + B3_ROWS - 1) / B3_ROWS;
+    grid = (int)std::min<int64_t>(ngroups, BW_MAX_BLOCKS);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (B3_CHAIN + B3_DW)), lds, s, (const uint4*)x, (const uint4*)g, Wp, Wtp,
+                       bp, rows, (uint4*)dx, dWpart, dbpart);
   }
-  const int64_t ngroups = (rows + B2_ROWS - 1) / B2_ROWS;
-  const int grid = (int)std::min<int64_t>(ngroups, BW_MAX_BLOCKS);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (B2_CHAIN + B2_DW)), lds, s, (const uint4*)x, (const uint4*)g, Wp, bp, rows,
-                     (uint4*)dx, dWpart, dbpart, detach_first);
-  hipLaunchKernelGGL(cross_reduce_partials_kernel, dim3((L * E * E + 63) / 64), dim3(256), 0, s, dWpart, grid,
+  hipLaunchKernelGGL(cross_reduce_partials_kernel, dim3((L * E * E + 63) / 64), dim3(1024), 0, s, dWpart, grid,
                      L * E * E, dW);
-  hipLaunchKernelGGL(cross_reduce_partials_kernel, dim3((L * E + 63) / 64), dim3(256), 0, s, dbpart, grid, L * E, db);
+  hipLaunchKernelGGL(cross_reduce_partials_kernel, dim3((L * E + 63) / 64), dim3(1024), 0, s, dbpart, grid, L * E, db);
   return check_launch("cross_bwd(mfma)");
 }
+
+#ifdef B3_TRACE
+extern "C" int trs_debug_b3_trace(long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(b3_trace), sizeof(long long) * 2 * 1024, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 int cross_mfma_bwd(const void* x, const void* W, const void* b, const void* g, int64_t rows, int E, int L, void* dx,
                    float* dW, float* db, int detach_first, void* workspace, size_t ws_bytes, hipStream_t s) {
@@ -618,11 +984,13 @@ int cross_mfma_bwd(const void* x, const void* W, const void* b, const void* g, i
   float* bp = (float*)(ws + al(cross_pack_bytes(E, L)));
   float* dWpart = (float*)((char*)bp + al((size_t)L * E * 4));
   float* dbpart = (float*)((char*)dWpart + al((size_t)BW_MAX_BLOCKS * L * E * E * 4));
+  bf16_t* Wtp = (bf16_t*)((char*)dbpart + al((size_t)BW_MAX_BLOCKS * L * E * 4));
   const int pgrid = std::min(64, (L * E * E / 8 + 255) / 256);
   hipLaunchKernelGGL((cross_prepack_kernel), dim3(pgrid), dim3(256), 0, s, (const bf16_t*)W, (const bf16_t*)b, Wp, bp, E,
-                     L);
+                     L, Wtp);
 #define TRS_CB(NT_, L_)                                                                                              \
-  return cross_bwd_launch<NT_, L_>(x, g, (const uint4*)Wp, bp, rows, dx, dWpart, dbpart, dW, db, detach_first, s)
+  return cross_bwd_launch<NT_, L_>(x, g, (const uint4*)Wp, (const uint4*)Wtp, bp, rows, dx, dWpart, dbpart, dW, db, \
+                                   detach_first, s)
   if (E == 32) {
     switch (L) {
       case 1: TRS_CB(2, 1);
