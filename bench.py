@@ -167,6 +167,31 @@ def cpu_baseline(a, sizes):
                       f"dim {E}, MLP [400,400,400]); {listing}"}
 
 
+def self_check(a, inputs, model, idx, sizes, rows=4096):
+    """End-to-end parity AT the benchmark's size and parameters: the logits of the first ``rows`` samples of a timed batch
+    from the product path (bf16 kernels) against the fp32 oracle evaluated on the same (bf16-rounded) parameters.
+    Checker use of the oracle, part of the cpu_baseline leg."""
+    from oracle import cpu_ref as O
+    sl = idx[:rows]
+    with torch.no_grad():
+        d = inputs({"c0": sl})
+        got = model(**d).float().cpu()
+    sd = {k: v.detach().float().cpu() for k, v in list(inputs.state_dict().items()) + list(model.state_dict().items())}
+    off = O.field_offsets(sizes)
+    ic = sl.cpu()
+    emb = O.multi_indices_embedding(sd["emb_inputs.embedding.weight"], ic, off)
+    feat = O.multi_indices_embedding(sd["feat_inputs.embedding.weight"], ic, off)
+    if a.model == "deepfm":
+        names = [k[:-len(".weight")] for k in sd if k.startswith("deep.model.") and k.endswith(".weight")]
+        ref = O.deepfm_model(feat, emb, [sd[n + ".weight"] for n in names], [sd[n + ".bias"] for n in names])
+    else:
+        ref = O.fm_model(feat, emb, sd.get("bias"))
+    err = float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+    return {"rows": rows, "max_rel_err_logits": round(err, 6), "tolerance": 1e-2 if a.dtype == "bf16" else 1e-5,
+            "ok": bool(err <= (1e-2 if a.dtype == "bf16" else 1e-5)),
+            "what": "product-path logits of the first rows of timed batch 0 vs the fp32 oracle on the same parameters"}
+
+
 WORKLOADS = {
     "deepfm": "BASELINE.json configs[1]: DeepFM 39 Criteo-shaped fields, MLP [400,400,400]",
     "fm": "FactorizationMachine (BASELINE.json configs[0] shape class) on the configs[1] inputs",
@@ -175,9 +200,11 @@ WORKLOADS = {
 }
 
 
-def large_table_roofline(a, dev, dt, esz):
+def large_table_roofline(a, dev, dt, esz, fm_only=False):
     """The roofline kernel again, stand-alone, on a table that cannot sit in the 256 MiB Infinity Cache (default 32 M
-    rows x 64 x bf16 = 4 GiB): same batch shape, HIP events on the launch stream, median of the timed launches."""
+    rows x 64 x bf16 = 4 GiB): same batch shape, HIP events on the launch stream, median of the timed launches.
+    ``fm_only``: the (B,N,E) block is not written (want_emb=False) -- north_star's literal "fused embedding + FM forward"
+    READ roofline (idx + rows read, FM out written; target <= 73.5 us at the BASELINE shape)."""
     from torecsys_amd import _abi
     from torecsys_amd import functional as F_
     B, N, E = a.batch, a.fields, a.embed
@@ -188,7 +215,8 @@ def large_table_roofline(a, dev, dt, esz):
     off = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(torch.tensor(sizes), 0)[:-1]]).to(dev)
     w = torch.empty(Vb, E, dtype=dt, device=dev).normal_()
     name = "trs_embed_fm" if not a.no_fuse else "trs_gather_rows"
-    fn = (lambda: F_._EmbedFM.apply(w, idx, off, None, True)) if not a.no_fuse else (lambda: F_._GatherRows.apply(w, idx, off, None))
+    fn = ((lambda: F_._EmbedFM.apply(w, idx, off, None, not fm_only)) if not a.no_fuse
+          else (lambda: F_._GatherRows.apply(w, idx, off, None)))
     for _ in range(3):
         fn()
     _abi.time_kernel(name, True, expect=12, every=1)
@@ -200,9 +228,10 @@ def large_table_roofline(a, dev, dt, esz):
     if not ts:
         return None
     med = ts[len(ts) // 2] * 1e-3
-    alg = B * N * (8 + E * esz) + B * N * E * esz + (B * E * esz if not a.no_fuse else 0)
+    alg = B * N * (8 + E * esz) + (0 if fm_only else B * N * E * esz) + (B * E * esz if not a.no_fuse else 0)
     ach = alg / med / 1e9
-    return {"bound": "hbm", "kernel": name.replace("trs_", ""), "table_rows": Vb, "table_bytes": Vb * E * esz,
+    return {"bound": "hbm", "kernel": name.replace("trs_", "") + (" (no block written)" if fm_only else ""),
+            "table_rows": Vb, "table_bytes": Vb * E * esz,
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
             "alg_bytes_per_launch": alg, "median_launch_us": round(med * 1e6, 2), "launches_timed": len(ts)}
 
@@ -365,6 +394,10 @@ def main():
         return loss
 
     roof_kernel = "trs_embed_fm" if not a.no_fuse else "trs_gather_rows"
+    # dcn / xdeepfm: the dominant kernel of THEIR step is a matrix-core kernel (cross = MFMA-bound, CIN =
+    # MFMA-bound): its FLOPs / time against the dense bf16 MFMA peak, next to the fused lookup launch
+    model_kernel = {"dcn": "trs_cross_bwd", "xdeepfm": "trs_cin_cl_bwd_data"}.get(a.model) if dt == torch.bfloat16 else None
+    first_kernel = "trs_gather_rows" if (not a.no_fuse and a.model in ("deepfm", "fm", "xdeepfm")) else None
     from torecsys_amd import inputs as _inputs_mod
     if (_inputs_mod.PAIR_FIRST_ORDER and not a.no_fuse and not sharded and a.optimizer == "none"
             and a.model in ("deepfm", "fm")):
@@ -396,6 +429,10 @@ def main():
         # host wait on the runtime's profiling signals and more than doubles the step (see _abi.time_kernel)
         every = max(1, min(a.time_every, a.steps))
         _abi.time_kernel(roof_kernel, True, expect=a.steps // every + 2, every=every)
+        if model_kernel:
+            _abi.time_kernel(model_kernel, True, expect=3 * a.steps + 8, every=1)
+        if first_kernel:       # the E = 1 first-order lookup of the same indices: the other half of SURVEY 8d's unit
+            _abi.time_kernel(first_kernel, True, expect=a.steps // every + 2, every=every)
     if use_graph:
         from torecsys_amd.graph import GraphedStep
 
@@ -419,6 +456,8 @@ def main():
             for _ in range(a.warmup):
                 step()
             _abi.kernel_times_ms(roof_kernel)      # drop the warm-up samples
+            if first_kernel:
+                _abi.kernel_times_ms(first_kernel)
         except Exception as exc:                   # capture refused on this box / runtime: the eager step is the same work
             if a.graph:
                 raise
@@ -500,6 +539,11 @@ def main():
     device_span_ms = span0.elapsed_time(span1)
     ktimes = _abi.kernel_times_ms(roof_kernel)
     _abi.time_kernel(roof_kernel, False)
+    mtimes = _abi.kernel_times_ms(model_kernel) if (model_kernel and not sharded) else []
+    ftimes = _abi.kernel_times_ms(first_kernel) if (first_kernel and not sharded) else []
+    for kn in (model_kernel, first_kernel):
+        if kn:
+            _abi.time_kernel(kn, False)
     if world > 1:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -538,9 +582,45 @@ def main():
                     "launches_timed": len(ktimes),
                     "note": f"the {V * E * esz >> 20} MiB table of this configuration fits the 256 MiB Infinity Cache; "
                             "roofline_large_table repeats the same launch on a table that does not"}
-        big = None
+        big = big_fm = None
         if roof is not None and not a.no_large_table and world == 1:
             big = large_table_roofline(a, dev, dt, esz)
+            if not a.no_fuse:
+                big_fm = large_table_roofline(a, dev, dt, esz, fm_only=True)
+        # SURVEY 8d's FULL unit: fused lookup + FM of the E-wide table AND the first-order rows of the same indices
+        # (B*N*s more bytes read) -- two launches in this step (folding the E = 1 lookup into the wide kernel was built
+        # and measured slower): bytes of both / time of both
+        full_unit = None
+        if roof is not None and ftimes and kt:
+            ft = sum(ftimes) / len(ftimes) * 1e-3
+            alg_full = alg + B * N * esz + B * N * esz            # first-order rows read (+ the (B,N,1) values written)
+            full_unit = {"bound": "hbm", "kernels": [roof_kernel.replace("trs_", ""), "gather_rows (E=1 first-order table)"],
+                         "achieved": round(alg_full / (kt + ft) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg_full / (kt + ft) / 1e9 / HBM_PEAK_GBS, 4), "alg_bytes": alg_full,
+                         "avg_launch_us": [round(kt * 1e6, 2), round(ft * 1e6, 2)]}
+        model_roof = None
+        if mtimes:
+            rows_ = B * N
+            if a.model == "dcn":
+                Lc = 6
+                flops = 2.0 * rows_ * E * E * (3 * Lc - 1)          # recompute L + gradient chain L-1 + weight gradient L
+                per_step = 1
+                what = ("cross_mfma_bwd3 (+ prepack and the two partial-sum reductions of the same entry point): "
+                        "2*rows*E^2*(3L-1) FLOP, detached first layer")
+                hbm_alg = 3 * rows_ * E * esz
+            else:
+                Hs = [N, 128, 128]
+                flops = sum(2.0 * B * E * 256 * N * h for h in Hs)   # S_n = W_n^T gy over the three layers of a step
+                per_step = 3
+                what = "cin_cl_bwd_data, the three layers of a step together: sum_k 2*B*E*C*N*H_k FLOP (C = 256)"
+                hbm_alg = None
+            tsum = sum(mtimes) / len(mtimes) * per_step * 1e-3       # seconds per step in this kernel
+            model_roof = {"bound": "mfma", "kernel": model_kernel.replace("trs_", ""), "what": what,
+                          "achieved": round(flops / tsum / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                          "frac": round(flops / tsum / 1e12 / 2500.0, 4), "flops_per_step": flops,
+                          "us_per_step": round(tsum * 1e6, 1), "launches_timed": len(mtimes)}
+            if hbm_alg:
+                model_roof["hbm_frac"] = round(hbm_alg / tsum / 1e9 / HBM_PEAK_GBS, 4)
         res = {
             "metric": "CTR samples/sec fwd+bwd (DeepFM, 39 fields x dim 64)" if a.model == "deepfm" else
                       f"CTR samples/sec fwd+bwd ({a.model}, 39 fields x dim 64)",
@@ -560,8 +640,16 @@ def main():
         }
         if big is not None:
             res["roofline_large_table"] = big
+        if big_fm is not None:
+            res["roofline_fm_only_large_table"] = big_fm
+        if full_unit is not None:
+            res["roofline_full_unit"] = full_unit
+        if model_roof is not None:
+            res["roofline_model_kernel"] = model_roof
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a, field_sizes(1_000_000, N))
+            if not sharded and a.optimizer == "none" and a.model in ("deepfm", "fm"):
+                res["self_check"] = self_check(a, inputs, model, idx_ring[0], sizes)
     else:
         res = None
     if sharded:
