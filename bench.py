@@ -633,7 +633,7 @@ def main():
                         f"global batch {B * world}"),
                        "global_batch": B * world, "rows": V, "parallelism": parallelism,
                        "microbatches": MB, "optimizer": a.optimizer, "hipgraph": bool(use_graph), "indices_from_host": bool(host_idx),
-                       "fused_lookup_fm": not a.no_fuse, "loss": float(loss),
+                       "fused_lookup_fm": not a.no_fuse, "loss": float(loss.detach()),
                        "host_enqueue_ms_per_step": round(enqueue_s / a.steps * 1e3, 4),
                        "device_span_ms_per_step": round(device_span_ms / a.steps, 4)},
             "roofline": roof,

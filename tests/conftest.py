@@ -62,20 +62,31 @@ def pair_heavy_ok(N, E):
     return N * (N - 1) // 2 * E * E <= 300_000
 
 
+def _report(kind, val):
+    """TRS_TOL_REPORT=<file>: append (norm, value, calling test line) -- how the tolerances in tests/ were calibrated"""
+    path = os.environ.get("TRS_TOL_REPORT")
+    if path:
+        import inspect
+        fr = inspect.stack()[2]
+        with open(path, "a") as f:
+            f.write(f"{os.path.basename(fr.filename)}:{fr.lineno}\t{kind}\t{val:.3e}\n")
+    return val
+
+
 def rel_err(a, b):
-    a = a.double()
-    b = b.double()
-    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+    a = a.detach().double()
+    b = b.detach().double()
+    return _report("rel_err", float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)))
 
 
 def rel_err_rows(a, b, floor_frac=1e-2):
     """Worst PER-ROW relative error: every leading-index row is normalised by its OWN largest reference magnitude
     (floored at ``floor_frac`` of the global one, so an all-zero row does not divide by zero), so a row of small
     values that is wrong cannot hide behind a large value elsewhere in the tensor, as it can in ``rel_err``."""
-    a = a.double().reshape(a.shape[0], -1)
-    b = b.double().reshape(b.shape[0], -1)
+    a = a.detach().double().reshape(a.shape[0], -1)
+    b = b.detach().double().reshape(b.shape[0], -1)
     scale = b.abs().amax(dim=1).clamp_min(floor_frac * float(b.abs().max().clamp_min(1e-30)))
-    return float(((a - b).abs().amax(dim=1) / scale).max())
+    return _report("rel_err_rows", float(((a - b).abs().amax(dim=1) / scale).max()))
 
 
 def sum_err(a, b, terms_abs):

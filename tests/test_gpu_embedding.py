@@ -404,7 +404,7 @@ def test_fused_sparse_optimizer_equals_dense_step(dev, kind, dtype, E):
             else:
                 assert m.embedding.weight.grad is None
         mods.append(m.embedding.weight.detach().float().cpu())
-    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    tol = 1e-5 if dtype == torch.float32 else 1e-2          # north_star's bounds (measured: 4e-7 / 4.4e-3)
     assert rel_err(mods[1], mods[0]) <= tol
     assert not torch.equal(mods[0], w.float())
 
@@ -444,7 +444,7 @@ def test_fused_sparse_adam_equals_torch_sparse_adam(dev, dtype, E):
         master.grad = torch.sparse_coo_tensor(rows.unsqueeze(0), G[rows], size=G.shape)
         ref_opt.step()
         plain.embedding.weight.data.copy_(master.data)      # keep the forward of the reference path in step
-    tol = 5e-5 if dtype == torch.float32 else 2e-2
+    tol = 1e-5 if dtype == torch.float32 else 1e-2          # north_star's bounds (measured: 5e-7 / 5.4e-3)
     assert rel_err(fused.embedding.weight.detach().float().cpu(), master.detach().cpu()) <= tol
     assert not torch.equal(master.detach().cpu(), w.float())
 
@@ -508,7 +508,7 @@ def test_row_buckets_partitioned_and_fallback(dev, case):
     assert rel_err(w.grad.cpu(), ref.cpu()) <= 1e-5
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
 @pytest.mark.parametrize("fuse", [False, True])
 def test_very_hot_rows_are_chunked(dev, dtype, tol, fuse):
     """A row that collects thousands of lookups is cut into 1024-lookup chunks reduced by different workgroups and
@@ -537,7 +537,7 @@ def test_very_hot_rows_are_chunked(dev, dtype, tol, fuse):
     assert rel_err(m.embedding.weight.grad.float().cpu(), wr.grad) <= tol
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
 @pytest.mark.parametrize("E", [1, 10, 64])
 def test_gather_backward_of_a_field_constant_gradient(dev, dtype, tol, E):
     """out.sum over the fields (the models' first-order term, models/ctr/deep_fm.py:55-110) feeds back the same row for
@@ -568,7 +568,7 @@ def test_gather_backward_of_a_field_constant_gradient(dev, dtype, tol, E):
     assert rel_err(wd.grad.float().cpu(), wd2.grad.float().cpu()) <= (1e-6 if dtype == torch.float32 else 8e-3)
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
 @pytest.mark.parametrize("B,N,E,Vf,hot", [(1024, 10, 16, 100, False), (4096, 39, 64, 7, True), (300, 5, 10, 9, False),
                                            (512, 6, 4, 50, False), (512, 6, 8, 50, True)])     # rows of ONE 16-byte vector
 def test_fm_gradient_constant_along_E(dev, dtype, tol, B, N, E, Vf, hot):
@@ -710,5 +710,5 @@ def test_fused_optimizer_state_of_first_order_table_persists(dev, kind):
                 p_.grad = torch.sparse_coo_tensor(touched.unsqueeze(0), p_.grad[touched], p_.shape).coalesce()
         ref.step()
         assert len(opt._state) == 2, "one state entry per table, not one per step"
-        assert rel_err(wd.detach().cpu(), wr.detach()) <= 2e-5, step
-        assert rel_err(fd.detach().cpu(), fr.detach()) <= 2e-5, step
+        assert rel_err(wd.detach().cpu(), wr.detach()) <= 1e-5, step
+        assert rel_err(fd.detach().cpu(), fr.detach()) <= 1e-5, step

@@ -50,14 +50,14 @@ def test_lookup_fm_scatter(dev, dtype, shape):
     scale = float(fr.detach().abs().max().clamp_min(1.0))
     assert float((fm.float().cpu() - fr.detach()).abs().max()) <= tol * scale * 4
     ((emb.float() * ge.to(dev).float()).sum() + (fm.float() * gf.to(dev).float()).sum()).backward()
-    assert rel_err(wd.grad.float().cpu(), wr.grad) <= tol * 2
+    assert rel_err(wd.grad.float().cpu(), wr.grad) <= tol
     # plain gather + separate FM layer
     wd2 = w.to(dev).requires_grad_()
     e2 = F_.gather_rows(wd2, idx.to(dev), off.to(dev))
     f2 = F_.fm_layer(e2)
     assert torch.equal(e2.detach().cpu(), er.detach().to(dtype))
     ((e2.float() * ge.to(dev).float()).sum() + (f2.float() * gf.to(dev).float()).sum()).backward()
-    assert rel_err(wd2.grad.float().cpu(), wr.grad) <= tol * 2
+    assert rel_err(wd2.grad.float().cpu(), wr.grad) <= tol
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -75,10 +75,10 @@ def test_pair_layers(dev, dtype, shape):
     if P:
         yr = O.inner_product_layer(xr)
         go = torch.randn(B, P, generator=g).to(dtype)
-        assert rel_err(y.float().cpu(), yr.detach()) <= tol * 2
+        assert rel_err(y.float().cpu(), yr.detach()) <= tol
         (y.float() * go.to(dev).float()).sum().backward()
         (yr * go.float()).sum().backward()
-        assert rel_err(xd.grad.float().cpu(), xr.grad) <= tol * 2
+        assert rel_err(xd.grad.float().cpu(), xr.grad) <= tol
     # FFM on a materialised block and fused from the tables
     if N <= 17:
         xf = (0.7 * torch.randn(B, N * N, E, generator=g)).to(dtype)
@@ -91,7 +91,7 @@ def test_pair_layers(dev, dtype, shape):
             gf = torch.randn(B, P, E, generator=g).to(dtype)
             (yf.float() * gf.to(dev).float()).sum().backward()
             (yfr * gf.float()).sum().backward()
-            assert rel_err(xfd.grad.float().cpu(), xfr.grad) <= tol * 2
+            assert rel_err(xfd.grad.float().cpu(), xfr.grad) <= tol
             ws = [torch.randn(sum(fs), E, generator=g).to(dtype) for _ in range(N)]
             wsd = [t.to(dev).requires_grad_() for t in ws]
             wsr = [t.float().clone().requires_grad_() for t in ws]
@@ -111,7 +111,7 @@ def test_cross_and_cin_contract(dev, dtype, shape):
     from torecsys_amd import functional as F_
     B, N, E = shape
     g, fs, idx, w, x = _mk(B, N, E, dtype, 201 + B + 3 * N + 7 * E)
-    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    tol = 1e-5 if dtype == torch.float32 else 1e-2          # north_star's bounds, no multipliers (measured max 7.3e-3)
     L = 1 + (B + N) % 4
     W = (torch.randn(L, E, E, generator=g) / max(1.0, E ** 0.5)).to(dtype)
     b = (0.1 * torch.randn(L, E, generator=g)).to(dtype)
@@ -124,9 +124,9 @@ def test_cross_and_cin_contract(dev, dtype, shape):
     go = torch.randn(B, N, E, generator=g).to(dtype)
     (y.float() * go.to(dev).float()).sum().backward()
     (yr * go.float()).sum().backward()
-    assert rel_err(xd.grad.float().cpu(), xr.grad) <= tol * 2
-    assert rel_err(Wd.grad.float().cpu(), Wr.grad) <= tol * 2
-    assert rel_err(bd.grad.float().cpu(), br.grad) <= tol * 2
+    assert rel_err(xd.grad.float().cpu(), xr.grad) <= tol
+    assert rel_err(Wd.grad.float().cpu(), Wr.grad) <= tol
+    assert rel_err(bd.grad.float().cpu(), br.grad) <= tol
     # CIN contraction (channels-first generic kernels)
     H, C = 1 + (B * 3) % 5, 2 + N % 4
     xk = (0.7 * torch.randn(B, H, E, generator=g)).to(dtype)
@@ -142,4 +142,4 @@ def test_cross_and_cin_contract(dev, dtype, shape):
     assert rel_err(yc.float().cpu(), yc_r.detach()) <= tol
     (yc.float() * gy.to(dev).float()).sum().backward()
     for a, r in zip(td, ts):
-        assert rel_err(a.grad.float().cpu(), r.grad) <= tol * 3
+        assert rel_err(a.grad.float().cpu(), r.grad) <= tol

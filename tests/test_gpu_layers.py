@@ -103,25 +103,27 @@ def test_cin_golden(golden, dev, name):
     x = G(pre + "/x").to(dev).requires_grad_()
     y = lay(x.refine_names("B", "N", "E"))
     assert y.names == ("B", "O")
-    assert rel_err(y.rename(None).cpu(), G(pre + "/train_out")) <= 2e-5
+    assert rel_err(y.rename(None).cpu(), G(pre + "/train_out")) <= 1e-5
     (y.rename(None) * G(pre + "/gout").to(dev)).sum().backward()
-    assert rel_err(x.grad.cpu(), G(pre + "/train_gx")) <= 1e-4
+    assert rel_err(x.grad.cpu(), G(pre + "/train_gx")) <= 1e-5
     for i, seq in enumerate(lay.model):
-        assert rel_err(seq.Conv1d.weight.grad.cpu(), G(f"{pre}/train_gconv_w{i}")) <= 1e-4
+        assert rel_err(seq.Conv1d.weight.grad.cpu(), G(f"{pre}/train_gconv_w{i}")) <= 1e-5
         if use_bias:
             gb = G(f"{pre}/train_gconv_b{i}")
-            assert float((seq.Conv1d.bias.grad.cpu() - gb).abs().max()) <= 1e-4 * max(1.0, float(gb.abs().max()))
+            # with BatchNorm behind the convolution d/d(conv bias) is analytically ZERO (the batch mean absorbs it): both
+            # sides hold fp32 summation noise of sums whose terms are O(1), compared on the absolute scale of the terms
+            assert float((seq.Conv1d.bias.grad.cpu() - gb).abs().max()) <= (1e-4 if use_bn else 1e-5) * max(1.0, float(gb.abs().max()))
         if use_bn:
-            assert rel_err(seq.Batchnorm.weight.grad.cpu(), G(f"{pre}/train_gbn_w{i}")) <= 1e-4
+            assert rel_err(seq.Batchnorm.weight.grad.cpu(), G(f"{pre}/train_gbn_w{i}")) <= 1e-5
             assert rel_err(seq.Batchnorm.running_mean.cpu(), G(f"{pre}/run_mean{i}")) <= 1e-5
             assert rel_err(seq.Batchnorm.running_var.cpu(), G(f"{pre}/run_var{i}")) <= 1e-5
-    assert rel_err(lay.fc.weight.grad.cpu(), G(pre + "/train_gfc_w")) <= 1e-4
+    assert rel_err(lay.fc.weight.grad.cpu(), G(pre + "/train_gfc_w")) <= 1e-5
     lay.eval()
     x2 = G(pre + "/x").to(dev).requires_grad_()
     y2 = lay(x2)
-    assert rel_err(y2.rename(None).cpu(), G(pre + "/eval_out")) <= 2e-5
+    assert rel_err(y2.rename(None).cpu(), G(pre + "/eval_out")) <= 1e-5
     (y2.rename(None) * G(pre + "/gout").to(dev)).sum().backward()
-    assert rel_err(x2.grad.cpu(), G(pre + "/eval_gx")) <= 1e-4
+    assert rel_err(x2.grad.cpu(), G(pre + "/eval_gx")) <= 1e-5
 
 
 @pytest.mark.parametrize("B,N,E", [(512, 39, 64), (300, 10, 16), (64, 7, 128), (33, 5, 10)])
@@ -296,23 +298,23 @@ def test_cin_glue_matches_aten_sequence(dev, mode, B, E, C):
     z = torch.relu(z).reshape(B, E, C)
     ref_hidden, ref_pooled = z[:, :, Hs:], z[:, :, :D].sum(dim=1)
     assert hidden.shape == ref_hidden.shape and pooled.shape == ref_pooled.shape
-    assert rel_err(hidden.float().cpu(), ref_hidden.float().cpu()) <= 2e-2
-    assert rel_err(pooled.float().cpu(), ref_pooled.float().cpu()) <= 2e-2
+    assert rel_err(hidden.float().cpu(), ref_hidden.float().cpu()) <= 1e-2
+    assert rel_err(pooled.float().cpu(), ref_pooled.float().cpu()) <= 1e-2
     gh = torch.randn(hidden.shape, generator=g).bfloat16().to(dev)
     gp = torch.randn(pooled.shape, generator=g).bfloat16().to(dev)
     ((hidden.float() * gh.float()).sum() + (pooled.float() * gp.float()).sum()).backward()
     ((ref_hidden.float() * gh.float()).sum() + (ref_pooled.float() * gp.float()).sum()).backward()
-    assert rel_err(ya.grad.float().cpu(), yb.grad.float().cpu()) <= 3e-2
+    assert rel_err(ya.grad.float().cpu(), yb.grad.float().cpu()) <= 1e-2
     if cf:
         gy_seen, gy_cf = seen_cf[0]
         assert gy_cf is not None, "the channels-first gradient copy did not ride on the gradient tensor"
         assert torch.equal(gy_cf, gy_seen.transpose(1, 2).contiguous())
     if bn is not None:
         if bn.affine:
-            assert rel_err(bn.weight.grad.float().cpu(), ref_bn.weight.grad.float().cpu()) <= 3e-2
-            assert rel_err(bn.bias.grad.float().cpu(), ref_bn.bias.grad.float().cpu()) <= 3e-2
-        assert rel_err(bn.running_mean.float().cpu(), ref_bn.running_mean.float().cpu()) <= 2e-2
-        assert rel_err(bn.running_var.float().cpu(), ref_bn.running_var.float().cpu()) <= 2e-2
+            assert rel_err(bn.weight.grad.float().cpu(), ref_bn.weight.grad.float().cpu()) <= 1e-2
+            assert rel_err(bn.bias.grad.float().cpu(), ref_bn.bias.grad.float().cpu()) <= 1e-2
+        assert rel_err(bn.running_mean.float().cpu(), ref_bn.running_mean.float().cpu()) <= 1e-2
+        assert rel_err(bn.running_var.float().cpu(), ref_bn.running_var.float().cpu()) <= 1e-2
         assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked)
     # only one of the two outputs used downstream
     yc = y0.clone().requires_grad_()

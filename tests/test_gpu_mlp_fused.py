@@ -106,7 +106,9 @@ def test_mlp_layer_takes_fused_path_and_matches_gemm_path(dev):
     finally:
         F_.FUSED_MLP = saved
     yb.rename(None).backward(go)
-    assert rel_err(ya.rename(None).float(), yb.rename(None).float()) <= 2e-2
+    # two bf16 paths against EACH OTHER: each is within north_star's 1e-2 of the fp32 oracle (asserted above and in
+    # test_gpu_mlp.py), so they may be up to 2e-2 apart (measured: 2.4e-3 forward, 9.7e-3 on the input gradient)
+    assert rel_err(ya.rename(None).float(), yb.rename(None).float()) <= 1e-2
     assert rel_err(xa.grad.float(), xb.grad.float()) <= 2e-2
     for a, p in zip(ga, lay.parameters()):
-        assert rel_err(a.float(), p.grad.float()) <= 2e-2
+        assert rel_err(a.float(), p.grad.float()) <= 1e-2

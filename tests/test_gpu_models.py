@@ -47,7 +47,7 @@ def test_models_golden(golden, dev, shape, fuse):
     batch = {f"f{i}": idx[:, i] for i in range(N)}          # dict of 1-D columns, routed like inputs.py:69-87
     gout = G(t + "/gout").to(dev)
 
-    def run(model, two, key, tol_out=1e-5, tol_g=5e-5):
+    def run(model, two, key, tol_out=1e-5, tol_g=1e-5):
         inputs.zero_grad()
         model.zero_grad()
         d = inputs(batch)
@@ -76,7 +76,7 @@ def test_models_golden(golden, dev, shape, fuse):
     m3.fc.weight.data.copy_(G(t + "/dcn_fc_w"))
     m3.fc.bias.data.copy_(G(t + "/dcn_fc_b"))
     run(m3.to(dev), False, "dcn")
-    assert rel_err(torch.stack([l.weight.grad for l in m3.cross.model]).cpu(), G(t + "/dcn_gcross_W")) <= 5e-5
+    assert rel_err(torch.stack([l.weight.grad for l in m3.cross.model]).cpu(), G(t + "/dcn_gcross_W")) <= 1e-5
 
     m4 = M.XDeepFactorizationMachineModel(embed_size=E, num_fields=N, cin_layer_sizes=[8, 8], deep_layer_sizes=[16, 8])
     _set_mlp(m4.deep, G, t + "/xdfm")
@@ -89,4 +89,4 @@ def test_models_golden(golden, dev, shape, fuse):
     m4.cin.fc.bias.data.copy_(G(t + "/xdfm_fc_b"))
     m4.bias.data.copy_(G(t + "/xdfm_bias"))
     m4.train()
-    run(m4.to(dev), True, "xdfm", tol_out=2e-5, tol_g=2e-4)
+    run(m4.to(dev), True, "xdfm")

@@ -4,7 +4,7 @@ CPU oracle on the same inputs."""
 import pytest
 import torch
 
-from conftest import PAIR_SHAPES, pair_heavy_ok, rel_err
+from conftest import PAIR_SHAPES, pair_heavy_ok, rel_err, rel_err_rows
 from oracle import cpu_ref as O
 
 pytestmark = pytest.mark.gpu
@@ -82,7 +82,7 @@ def test_pair_layer_constructor_errors(dev):
         OuterProductNetworkLayer(8, 4, "vec")(torch.zeros(2, 4, 8))       # CPU tensors: no CPU path
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
 @pytest.mark.parametrize("B,N,E", [(37, 39, 64), (5, 2, 16), (130, 7, 24), (64, 5, 128), (1, 3, 8), (96, 39, 64),
                                    (70, 12, 16), (257, 2, 64)])
 def test_pair_layers_vs_oracle(dev, dtype, tol, B, N, E):
@@ -108,12 +108,14 @@ def test_pair_layers_vs_oracle(dev, dtype, tol, B, N, E):
         yr = O.outer_product_layer(xr, pr[0], kind) if fam == "opn" else O.bilinear_layer(xr, pr[0], pr[1], kind)
         assert y.shape == yr.shape
         assert rel_err(y.float().cpu(), yr) <= tol, (fam, kind)
+        assert rel_err_rows(y.float().cpu(), yr.detach(), floor_frac=5e-2) <= 2 * tol, (fam, kind, "per sample")
         go = torch.randn(yr.shape, generator=g)
         (y.float() * go.to(dev)).sum().backward()
         (yr * go).sum().backward()
-        assert rel_err(x.grad.float().cpu(), xr.grad) <= tol * 2, (fam, kind, "gx")
+        assert rel_err(x.grad.float().cpu(), xr.grad) <= tol, (fam, kind, "gx")
+        assert rel_err_rows(x.grad.float().cpu(), xr.grad, floor_frac=5e-2) <= 2 * tol, (fam, kind, "gx per sample")
         for p, r in zip(params, pr):
-            assert rel_err(p.grad.float().cpu(), r.grad) <= tol * 2, (fam, kind, "gparam")
+            assert rel_err(p.grad.float().cpu(), r.grad) <= tol, (fam, kind, "gparam")
 
 
 def _afm_layer(dev, E, N, A, W1, b1, W2, b2, dtype=torch.float32):
@@ -140,10 +142,10 @@ def test_afm_golden(golden, dev, shape):
     assert rel_err(y.rename(None).cpu(), G(f"afm/{t}/out")) <= 1e-5
     assert rel_err(attn.cpu(), G(f"afm/{t}/attn")) <= 1e-5
     ((y.rename(None) * G(f"afm/{t}/gout").to(dev)).sum() + (attn * G(f"afm/{t}/gattn").to(dev)).sum()).backward()
-    assert rel_err(x.grad.cpu(), G(f"afm/{t}/gx")) <= 2e-5
+    assert rel_err(x.grad.cpu(), G(f"afm/{t}/gx")) <= 1e-5
     a = lay.attention
     for p, n in ((a.Linear.weight, "gW1"), (a.Linear.bias, "gb1"), (a.OutProj.weight, "gW2")):
-        assert rel_err(p.grad.cpu(), G(f"afm/{t}/{n}")) <= 5e-5, n
+        assert rel_err(p.grad.cpu(), G(f"afm/{t}/{n}")) <= 1e-5, n
     # d/d(b2) of a softmax over the logits is identically zero (a shift of every logit): the reference's value is
     # summation noise, so it is compared on an absolute scale
     assert float((a.OutProj.bias.grad.cpu() - G(f"afm/{t}/gb2")).abs().max()) <= 1e-5
@@ -151,7 +153,7 @@ def test_afm_golden(golden, dev, shape):
                                                "attention.OutProj.bias", "attention.OutProj.weight"]
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-5), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
 @pytest.mark.parametrize("B,N,E,A", [(37, 39, 64, 64), (5, 2, 16, 8), (130, 7, 24, 40), (9, 5, 128, 100), (1, 3, 8, 1),
                                      (64, 10, 32, 16), (33, 12, 128, 32), (20, 39, 64, 128), (3, 2, 64, 48),
                                      (40, 9, 32, 64), (17, 6, 64, 96), (9, 4, 32, 128), (300, 2, 64, 32), (70, 34, 64, 32)])
@@ -171,13 +173,14 @@ def test_afm_vs_oracle(dev, dtype, tol, B, N, E, A):
     go, ga = torch.randn(B, E, generator=g), torch.randn(ar.shape, generator=g)
     ((y.rename(None).float() * go.to(dev)).sum() + (attn.float() * ga.to(dev)).sum()).backward()
     ((yr * go).sum() + (ar * ga).sum()).backward()
-    assert rel_err(x.grad.float().cpu(), xr.grad) <= tol * 3
+    assert rel_err(x.grad.float().cpu(), xr.grad) <= tol
     a = lay.attention
     for p, r in zip((a.Linear.weight, a.Linear.bias, a.OutProj.weight), pr):
         # gradients that cancel analytically (one attention unit: d/d(b1) is a multiple of sum_p d(logit) = 0) are
-        # pure summation noise: scale the error by at least 1e-2
+        # pure summation noise (the oracle's value is 0 or ~1e-8): such a gradient is compared on the absolute scale of
+        # the terms it sums (|d(logit)_p * w2| ~ 0.1 with these inputs); every other gradient at north_star's relative bound
         err = float((p.grad.float().cpu() - r.grad).abs().max())
-        assert err <= tol * 3 * max(float(r.grad.abs().max()), 1e-2)
+        assert err <= tol * max(float(r.grad.abs().max()), 0.1)
     assert float(a.OutProj.bias.grad.float().abs().max()) <= tol * float(ga.abs().max()) * B    # analytically zero
     # only the output is used downstream: the attention gradient input is None
     x2 = x0.to(dev).requires_grad_()
@@ -185,10 +188,10 @@ def test_afm_vs_oracle(dev, dtype, tol, B, N, E, A):
     (y2.rename(None).float() * go.to(dev)).sum().backward()
     xr2 = x0.float().clone().requires_grad_()
     (O.afm_layer(xr2, *[p.detach() for p in pr])[0] * go).sum().backward()
-    assert rel_err(x2.grad.float().cpu(), xr2.grad) <= tol * 3
+    assert rel_err(x2.grad.float().cpu(), xr2.grad) <= tol
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-5), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
 @pytest.mark.parametrize("N,E", [(39, 64), (7, 32), (12, 16)])
 def test_pair_bilinear_gemm_route_matches_oracle(dev, dtype, tol, N, E):
     """B >= 256 takes the per-field GEMM route (trs_pair_epilogue_*); same checks as the one-kernel route."""
@@ -212,12 +215,14 @@ def test_pair_bilinear_gemm_route_matches_oracle(dev, dtype, tol, N, E):
         pr = [p.detach().float().cpu().requires_grad_() for p in params]
         yr = O.outer_product_layer(xr, pr[0], kind) if fam == "opn" else O.bilinear_layer(xr, pr[0], pr[1], kind)
         assert rel_err(y.float().cpu(), yr) <= tol, (fam, kind)
+        assert rel_err_rows(y.float().cpu(), yr.detach(), floor_frac=5e-2) <= 2 * tol, (fam, kind, "per sample")
         go = torch.randn(yr.shape, generator=g)
         (y.float() * go.to(dev)).sum().backward()
         (yr * go).sum().backward()
-        assert rel_err(x.grad.float().cpu(), xr.grad) <= tol * 2, (fam, kind, "gx")
+        assert rel_err(x.grad.float().cpu(), xr.grad) <= tol, (fam, kind, "gx")
+        assert rel_err_rows(x.grad.float().cpu(), xr.grad, floor_frac=5e-2) <= 2 * tol, (fam, kind, "gx per sample")
         for p, r in zip(params, pr):
-            assert rel_err(p.grad.float().cpu(), r.grad) <= tol * 2, (fam, kind, "gparam")
+            assert rel_err(p.grad.float().cpu(), r.grad) <= tol, (fam, kind, "gparam")
 
 
 # ---- AFM in training mode at the reference's default configuration: dropout on the scores INSIDE the fused pass ----
@@ -244,13 +249,13 @@ def test_afm_score_dropout_golden(golden, dev, shape):
     y = y0 * G(f"{t}/out_keep").to(dev).float() * scale
     assert rel_err(y.cpu(), G(f"{t}/out")) <= 1e-5
     ((y * G(f"{t}/gout").to(dev)).sum() + (attn.unsqueeze(-1) * G(f"{t}/gattn").to(dev)).sum()).backward()
-    assert rel_err(x.grad.cpu(), G(f"{t}/gx")) <= 2e-5
+    assert rel_err(x.grad.cpu(), G(f"{t}/gx")) <= 1e-5
     for p_, n in zip(ps[:3], ("gW1", "gb1", "gW2")):
-        assert rel_err(p_.grad.cpu(), G(f"{t}/{n}")) <= 5e-5, n
+        assert rel_err(p_.grad.cpu(), G(f"{t}/{n}")) <= 1e-5, n
     assert float((ps[3].grad.cpu() - G(f"{t}/gb2")).abs().max()) <= 1e-5
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-5), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
 @pytest.mark.parametrize("B,N,E,A,p", [(37, 39, 64, 64, 0.1), (130, 7, 24, 40, 0.3), (64, 10, 32, 32, 0.5),
                                        (20, 39, 64, 128, 0.1), (9, 5, 128, 96, 0.2)])
 def test_afm_layer_training_dropout_vs_oracle(dev, dtype, tol, B, N, E, A, p):
@@ -281,11 +286,11 @@ def test_afm_layer_training_dropout_vs_oracle(dev, dtype, tol, B, N, E, A, p):
     go, ga = torch.randn(B, E, generator=g), torch.randn(ar.shape, generator=g)
     ((y.rename(None).float() * go.to(dev)).sum() + (attn.float() * ga.to(dev)).sum()).backward()
     ((yr * go).sum() + (ar * ga).sum()).backward()
-    assert rel_err(x.grad.float().cpu(), xr.grad) <= tol * 3
+    assert rel_err(x.grad.float().cpu(), xr.grad) <= tol
     a = lay.attention
     for q, r in zip((a.Linear.weight, a.Linear.bias, a.OutProj.weight), pr):
         err = float((q.grad.float().cpu() - r.grad).abs().max())
-        assert err <= tol * 3 * max(float(r.grad.abs().max()), 1e-2)
+        assert err <= tol * max(float(r.grad.abs().max()), 1e-2)
     lay.eval()                              # eval: dropout is the identity, scores sum to one
     _, attn_e = lay(x0.to(dev))
     assert float((attn_e.float().sum(1) - 1).abs().max()) <= (1e-5 if dtype == torch.float32 else 1e-2)
@@ -321,4 +326,4 @@ def test_bilinear_submodules_stand_alone_forward(dev, dtype, tol, B, N, E):
         (yr * go).sum().backward()
         for got, ref, n in ((a.grad, ar.grad, "g1"), (b.grad, br.grad, "g2"), (lay.weight.grad, Wr.grad, "gW"),
                             (lay.bias.grad, br_.grad, "gb")):
-            assert rel_err(got.float().cpu(), ref) <= tol * 3, (kind, n)
+            assert rel_err(got.float().cpu(), ref) <= tol, (kind, n)
