@@ -8,6 +8,10 @@
 // no float atomics; the FM second-order backward dx = g*(S - x) is folded into the same walk:
 //   sum_p g_fm[b_p]*(S[b_p] - W[r]) = sum_p g_fm[b_p]*S[b_p]  -  W[r] * sum_p g_fm[b_p].
 // HBM-bound: reads B*N*(E*s + 4) (+ 2*B*E*s L2-resident FM operands), writes V*E*s.
+#include <stdlib.h>
+
+#include <algorithm>
+
 #include "trs_common.hpp"
 
 namespace trs {
@@ -380,9 +384,12 @@ struct FmSrc {
   const uint4* t;
   const uint4* g;
   int tstr, gstr;
+  const void* g1 = nullptr;   // SCAL kernels: the per-sample gradient scalars themselves (B values of the table dtype)
 };
 
-template <typename T, int LOG2L, bool HAS_G, bool HAS_FM, int CH = 4, bool HAS_F1 = false>
+// SCAL: the FM gradient is one scalar per sample (g constant along E): it is read as that scalar (2-4 bytes, L2-resident)
+// instead of a 16-byte vector of copies, and its sum over the bucket is ONE register (gsum[0]) instead of VE
+template <typename T, int LOG2L, bool HAS_G, bool HAS_FM, int CH = 4, bool HAS_F1 = false, bool SCAL = false>
 __device__ __forceinline__ void accumulate_bucket(float* acc, float* gsum, const uint4* __restrict__ g_rows,
                                                   const uint4* __restrict__ g_fm, const float* __restrict__ fm_sum,
                                                   const int32_t* __restrict__ perm, int beg, int end, int step,
@@ -398,7 +405,7 @@ __device__ __forceinline__ void accumulate_bucket(float* acc, float* gsum, const
   for (int q = beg; q < end; q += CH * step) {
     int p[CH];
     uint4 gv[CH], fv[CH], tv[CH];
-    float fr[CH];
+    float fr[CH], gs[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) p[c] = pn[c];
 #pragma unroll
@@ -412,6 +419,7 @@ __device__ __forceinline__ void accumulate_bucket(float* acc, float* gsum, const
       fv[c] = make_uint4(0, 0, 0, 0);
       tv[c] = make_uint4(0, 0, 0, 0);
       fr[c] = 0.f;
+      gs[c] = 0.f;
       if (p[c] >= 0) {
         if (HAS_F1) fr[c] = to_f32(g_first[p[c]]);
         if (HAS_G) {
@@ -426,7 +434,8 @@ __device__ __forceinline__ void accumulate_bucket(float* acc, float* gsum, const
           const int64_t b = (int64_t)((unsigned)p[c] / (unsigned)N);
           if (fm_sum != nullptr) {  // FM mode: see FmSrc
             tv[c] = fs.t[b * fs.tstr + lane_v];
-            fv[c] = fs.g[b * fs.gstr + (fs.gstr > 1 ? lane_v : 0)];
+            if (SCAL) gs[c] = to_f32(static_cast<const T*>(fs.g1)[b]);
+            else fv[c] = fs.g[b * fs.gstr + (fs.gstr > 1 ? lane_v : 0)];
           } else {
             fv[c] = g_fm[b * L + lane_v];
           }
@@ -445,14 +454,17 @@ __device__ __forceinline__ void accumulate_bucket(float* acc, float* gsum, const
         }
         if (HAS_FM) {
           float gf[VE];
-          Vec16<T>::unpack(fv[c], gf);
+          if (!SCAL) Vec16<T>::unpack(fv[c], gf);
           if (fm_sum != nullptr) {
             float tg[VE];
             Vec16<T>::unpack(tv[c], tg);
 #pragma unroll
-            for (int k = 0; k < VE; ++k) {
-              acc[k] += tg[k];
-              gsum[k] += gf[k];
+            for (int k = 0; k < VE; ++k) acc[k] += tg[k];
+            if (SCAL) {
+              gsum[0] += gs[c];
+            } else {
+#pragma unroll
+              for (int k = 0; k < VE; ++k) gsum[k] += gf[k];
             }
           } else {  // plain per-sample broadcast gradient (first-order sum): no FM weighting
 #pragma unroll
@@ -464,7 +476,7 @@ __device__ __forceinline__ void accumulate_bucket(float* acc, float* gsum, const
   }
 }
 
-template <typename T, int LOG2L, bool HAS_G, bool HAS_FM, bool HAS_F1 = false>
+template <typename T, int LOG2L, bool HAS_G, bool HAS_FM, bool HAS_F1 = false, bool SCAL = false, int CHF = 2>
 __global__ __launch_bounds__(256) void scatter_rows_group_kernel(
     const uint4* __restrict__ g_rows, const uint4* __restrict__ g_fm, const float* __restrict__ fm_sum,
     const uint4* __restrict__ table, const int32_t* __restrict__ row_start, const int32_t* __restrict__ perm,
@@ -501,17 +513,101 @@ __global__ __launch_bounds__(256) void scatter_rows_group_kernel(
     }
     float f1 = 0.f;
     if (r != padding_row) {
-      accumulate_bucket<T, LOG2L, HAS_G, HAS_FM, (HAS_FM ? 2 : 4), HAS_F1>(acc, gsum, g_rows, g_fm, fm_sum, perm, beg, end, 1, N,
-                                                                       gbs, lane_v, fs, g_first, &f1);
+      accumulate_bucket<T, LOG2L, HAS_G, HAS_FM, (HAS_FM ? CHF : 4), HAS_F1, SCAL>(acc, gsum, g_rows, g_fm, fm_sum, perm, beg,
+                                                                                end, 1, N, gbs, lane_v, fs, g_first, &f1);
       if (HAS_FM && fm_sum != nullptr && end > beg) {
         float w[VE];
         Vec16<T>::unpack(wraw, w);
 #pragma unroll
-        for (int k = 0; k < VE; ++k) acc[k] = fmaf(-w[k], gsum[k], acc[k]);
+        for (int k = 0; k < VE; ++k) acc[k] = fmaf(-w[k], gsum[SCAL ? 0 : k], acc[k]);
       }
     }
     sink_vec<T>(sink, grad, sink_row(sink, r) * L + lane_v, acc, end > beg && r != padding_row);
     if (HAS_F1 && lane_v == 0) grad_first[r] = from_f32<T>(f1);      // dense companion gradient: every row written
+  }
+}
+
+// The models' case, lean: FM gradient constant along E (one scalar per sample), rows of whole 16-byte vectors, no
+// companion table.  Same walk as scatter_rows_group_kernel, written for 64 registers (8 waves per SIMD: the walk is a
+// chain of dependent latencies -- bucket bounds -> bucket positions -> gradient rows -- and its throughput is the number
+// of rows in flight; the generic FM kernel needs 92 registers = 5 waves per SIMD and ran 193 us where the plain walk,
+// at 8 waves, takes 105): 32-bit element offsets from uniform bases (BN * L < 2^31 is checked by the host), the sample
+// index by a multiply-shift with a host-computed reciprocal, the table row fetched with the bucket bounds.
+template <typename T, int LOG2L, bool HAS_G>
+__global__ __launch_bounds__(256, 8) void scatter_rows_fm1_kernel(
+    const uint4* __restrict__ g_rows, const uint4* __restrict__ tg, const T* __restrict__ g1,
+    const uint4* __restrict__ table, const int32_t* __restrict__ row_start, const int32_t* __restrict__ perm, int V,
+    unsigned N, unsigned rcpN /* ceil(2^32 / N) */, int padding_row, uint4* __restrict__ grad,
+    int32_t* __restrict__ long_rows /* [0]=count */, RowSink sink) {
+  constexpr int L = 1 << LOG2L;
+  constexpr int VE = Vec16<T>::VE;
+  constexpr int CH = 2;      // 3 / 4 lookups in flight per lane cost 8 / 16 registers = 7 / 5 waves per SIMD: 171 / 191 us vs 163
+  const unsigned lane_v = threadIdx.x & (L - 1);
+  const int groups = (int)(((int64_t)gridDim.x * blockDim.x) >> LOG2L);
+  int r = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> LOG2L);
+  int nbeg = 0, nend = 0;
+  if (r < V) { nbeg = row_start[r]; nend = row_start[r + 1]; }
+  for (; r < V; r += groups) {
+    const int beg = nbeg, end = nend;
+    if (r + groups < V) { nbeg = row_start[r + groups]; nend = row_start[r + groups + 1]; }
+    const uint4 wraw = table[(unsigned)r * L + lane_v];
+    float acc[VE], gsum = 0.f;
+#pragma unroll
+    for (int k = 0; k < VE; ++k) acc[k] = 0.f;
+    const bool live = r != padding_row;
+    if (end - beg > LONG_ROW && live) {
+      if (lane_v == 0) {
+        const int nch = (end - beg + LONG_CHUNK - 1) / LONG_CHUNK;
+        const int slot = atomicAdd(&long_rows[0], nch);
+        for (int c = 0; c < nch; ++c) {
+          long_rows[1 + 2 * (slot + c)] = r;
+          long_rows[2 + 2 * (slot + c)] = c;
+        }
+      }
+      continue;
+    }
+    if (live) {
+      int pn[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) pn[c] = (beg + c) < end ? perm[beg + c] : -1;
+      for (int q = beg; q < end; q += CH) {
+        int p[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) p[c] = pn[c];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) pn[c] = (q + CH + c) < end ? perm[q + CH + c] : -1;
+        uint4 gv[CH], tv[CH];
+        float gs[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          gv[c] = make_uint4(0, 0, 0, 0);
+          tv[c] = make_uint4(0, 0, 0, 0);
+          gs[c] = 0.f;
+          if (p[c] >= 0) {
+            const unsigned b = __umulhi((unsigned)p[c], rcpN);      // p / N for p < 2^31, N < 2^16 (host-checked)
+            if (HAS_G) gv[c] = g_rows[(unsigned)p[c] * L + lane_v];
+            tv[c] = tg[b * L + lane_v];
+            gs[c] = to_f32(g1[b]);
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          float x[VE], t[VE];
+          if (HAS_G) Vec16<T>::unpack(gv[c], x);
+          Vec16<T>::unpack(tv[c], t);
+#pragma unroll
+          for (int k = 0; k < VE; ++k) acc[k] += HAS_G ? x[k] + t[k] : t[k];
+          gsum += gs[c];
+        }
+      }
+      if (end > beg) {
+        float w[VE];
+        Vec16<T>::unpack(wraw, w);
+#pragma unroll
+        for (int k = 0; k < VE; ++k) acc[k] = fmaf(-w[k], gsum, acc[k]);
+      }
+    }
+    sink_vec<T>(sink, grad, sink_row(sink, r) * L + lane_v, acc, end > beg && live);
   }
 }
 
@@ -549,7 +645,7 @@ __global__ __launch_bounds__(256) void scatter_first_long_kernel(const T* __rest
 // hot rows: one 256-thread workgroup per (row, chunk) queue entry, groups stride over the chunk, LDS tree reduction.
 // Rows of a single chunk are finished here; otherwise the chunk's partial sums go to scratch[entry][2][E] (fp32)
 // and scatter_long_rows_finish_kernel adds the chunks of the row.
-template <typename T, int LOG2L, bool HAS_G, bool HAS_FM>
+template <typename T, int LOG2L, bool HAS_G, bool HAS_FM, bool SCAL = false>
 __global__ __launch_bounds__(256) void scatter_long_rows_kernel(
     const uint4* __restrict__ g_rows, const uint4* __restrict__ g_fm, const float* __restrict__ fm_sum,
     const uint4* __restrict__ table, const int32_t* __restrict__ row_start, const int32_t* __restrict__ perm, int N,
@@ -571,9 +667,10 @@ __global__ __launch_bounds__(256) void scatter_long_rows_kernel(
     float acc[VE], gsum[VE];
 #pragma unroll
     for (int k = 0; k < VE; ++k) { acc[k] = 0.f; gsum[k] = 0.f; }
-    accumulate_bucket<T, LOG2L, HAS_G, HAS_FM, 8>(acc, gsum, g_rows, g_fm, fm_sum, perm, beg + grp, end, G, N, gbs, lane_v, fs);
+    accumulate_bucket<T, LOG2L, HAS_G, HAS_FM, 8, false, SCAL>(acc, gsum, g_rows, g_fm, fm_sum, perm, beg + grp, end, G, N, gbs,
+                                                               lane_v, fs);
 #pragma unroll
-    for (int k = 0; k < VE; ++k) { red[0][threadIdx.x][k] = acc[k]; red[1][threadIdx.x][k] = gsum[k]; }
+    for (int k = 0; k < VE; ++k) { red[0][threadIdx.x][k] = acc[k]; red[1][threadIdx.x][k] = gsum[SCAL ? 0 : k]; }
     __syncthreads();
     for (int h = G >> 1; h >= 1; h >>= 1) {
       if (grp < h) {
@@ -785,12 +882,16 @@ static void scatter_group_launch(const void* g_rows, const void* g_fm, const flo
                                  void* grad_first = nullptr) {
   const int L = 1 << LOG2L;
   FmSrc fs{nullptr, nullptr, 0, 0};
+  bool scal = false;
+  static const int variant = getenv("TRS_SCATTER_VARIANT") ? atoi(getenv("TRS_SCATTER_VARIANT")) : 1;   // 0: the generic FM walk (A/B)
   if (g_fm != nullptr && fm_sum != nullptr) {
     if (gcols == 1) {      // (L == 1 too: a (B,1) buffer must never be read as B 16-byte rows)
       uint4* gvec = (uint4*)tg + B * L;
       hipLaunchKernelGGL((build_tg1_kernel<T>), dim3(stream_grid(B * L, 256, 4096)), dim3(256), 0, s, (const T*)g_fm,
                          fm_sum, (uint4*)tg, gvec, B, L);
       fs = FmSrc{(const uint4*)tg, gvec, L, 1};
+      fs.g1 = g_fm;
+      scal = variant != 0 && g_first == nullptr;
     } else {
       hipLaunchKernelGGL((build_tg_kernel<T>), dim3(stream_grid(B * L, 256, 4096)), dim3(256), 0, s, (const uint4*)g_fm,
                          fm_sum, (uint4*)tg, B, L);
@@ -800,6 +901,14 @@ static void scatter_group_launch(const void* g_rows, const void* g_fm, const flo
   }
   const int grid = stream_grid(V * L, 256, 256 * 32);
   const bool hg = g_rows != nullptr, hf = g_fm != nullptr;
+#define TRS_SC_TAIL(HG, HF, SC)                                                                                 \
+  do {                                                                                                          \
+    hipLaunchKernelGGL((scatter_long_rows_kernel<T, LOG2L, HG, HF, SC>), dim3(1024), dim3(256), 0, s,            \
+                       (const uint4*)g_rows, (const uint4*)g_fm, fm_sum, (const uint4*)table, row_start, perm, N, \
+                       gbs, (uint4*)grad, long_rows, scratch, sink, fs);                                              \
+    hipLaunchKernelGGL((scatter_long_rows_finish_kernel<T, LOG2L, HF>), dim3(64), dim3(256), 0, s, fm_sum,           \
+                       (const uint4*)table, row_start, (uint4*)grad, long_rows, scratch, sink);                       \
+  } while (0)
 #define TRS_SC(HG, HF)                                                                                          \
   do {                                                                                                          \
     if (g_first != nullptr)                                                                                     \
@@ -811,16 +920,38 @@ static void scatter_group_launch(const void* g_rows, const void* g_fm, const flo
       hipLaunchKernelGGL((scatter_rows_group_kernel<T, LOG2L, HG, HF>), dim3(grid), dim3(256), 0, s,             \
                          (const uint4*)g_rows, (const uint4*)g_fm, fm_sum, (const uint4*)table, row_start, perm, \
                          V, N, gbs, padding_row, (uint4*)grad, long_rows, sink, fs);                             \
-    hipLaunchKernelGGL((scatter_long_rows_kernel<T, LOG2L, HG, HF>), dim3(1024), dim3(256), 0, s,                \
-                       (const uint4*)g_rows, (const uint4*)g_fm, fm_sum, (const uint4*)table, row_start, perm, N, \
-                       gbs, (uint4*)grad, long_rows, scratch, sink, fs);                                              \
-    hipLaunchKernelGGL((scatter_long_rows_finish_kernel<T, LOG2L, HF>), dim3(64), dim3(256), 0, s, fm_sum,           \
-                       (const uint4*)table, row_start, (uint4*)grad, long_rows, scratch, sink);                       \
+    TRS_SC_TAIL(HG, HF, false);                                                                                 \
   } while (0)
-  if (hg && hf) TRS_SC(true, true);
+#define TRS_SCS(HG, CHF_)                                                                                       \
+  do {                                                                                                          \
+    hipLaunchKernelGGL((scatter_rows_group_kernel<T, LOG2L, HG, true, false, true, CHF_>), dim3(grid), dim3(256), 0, s, \
+                       (const uint4*)g_rows, (const uint4*)g_fm, fm_sum, (const uint4*)table, row_start, perm,   \
+                       V, N, gbs, padding_row, (uint4*)grad, long_rows, sink, fs);                               \
+    TRS_SC_TAIL(HG, true, true);                                                                                \
+  } while (0)
+  const bool lean = scal && variant == 1 && (B * N) * (int64_t)L < ((int64_t)1 << 31) && V * (int64_t)L < ((int64_t)1 << 31) &&
+                    N >= 2 && (B * N) * (int64_t)N < ((int64_t)1 << 32) && gbs == N;   // (mulhi by ceil(2^32/N) is exact)
+  if (lean) {
+    const unsigned rcpN = (unsigned)((((uint64_t)1 << 32) + (unsigned)N - 1) / (unsigned)N);
+    if (hg)
+      hipLaunchKernelGGL((scatter_rows_fm1_kernel<T, LOG2L, true>), dim3(grid), dim3(256), 0, s, (const uint4*)g_rows,
+                         (const uint4*)tg, (const T*)fs.g1, (const uint4*)table, row_start, perm, (int)V, (unsigned)N,
+                         rcpN, (int)padding_row, (uint4*)grad, long_rows, sink);
+    else
+      hipLaunchKernelGGL((scatter_rows_fm1_kernel<T, LOG2L, false>), dim3(grid), dim3(256), 0, s, (const uint4*)g_rows,
+                         (const uint4*)tg, (const T*)fs.g1, (const uint4*)table, row_start, perm, (int)V, (unsigned)N,
+                         rcpN, (int)padding_row, (uint4*)grad, long_rows, sink);
+    if (hg) TRS_SC_TAIL(true, true, true);
+    else TRS_SC_TAIL(false, true, true);
+  } else if (scal) {
+    if (hg) TRS_SCS(true, 2);
+    else TRS_SCS(false, 2);
+  } else if (hg && hf) TRS_SC(true, true);
   else if (hg) TRS_SC(true, false);
   else TRS_SC(false, true);
 #undef TRS_SC
+#undef TRS_SCS
+#undef TRS_SC_TAIL
   if (g_first != nullptr)
     hipLaunchKernelGGL((scatter_first_long_kernel<T>), dim3(64), dim3(256), 0, s, (const T*)g_first, row_start, perm,
                        long_rows, (T*)grad_first);
