@@ -87,6 +87,9 @@ def parse():
                          "one GPU -- per-micro-batch host syncs and sparse-gradient accumulation outweigh the overlap)")
     ap.add_argument("--dedup", action="store_true",
                     help="sharded path: send every distinct row id of the local batch once (pays on skewed indices)")
+    ap.add_argument("--capacity", type=float, default=0.0,
+                    help="sharded path: fixed-capacity all-to-all slots (factor on the even share B*N/world, e.g. 1.1): equal "
+                         "splits, no split size read on the host (dist.RowShardedMultiIndicesEmbedding(capacity=...))")
     ap.add_argument("--cpu-batch", type=int, default=65536)
     ap.add_argument("--host-indices", action="store_true",
                     help="index batches start in host memory: packed into pinned int32 buffers and copied over PCIe "
@@ -279,9 +282,11 @@ def main():
         parallelism = "single"
     else:
         from torecsys_amd.dist import RowShardedMultiIndicesEmbedding
+        cap = a.capacity if a.capacity >= 1.0 else None
         emb = RowShardedMultiIndicesEmbedding(embed_size=E, field_sizes=sizes, fuse_fm=not a.no_fuse,
-                                              dtype=dt, device=dev, dedup=a.dedup)
-        feat = RowShardedMultiIndicesEmbedding(embed_size=1, field_sizes=sizes, dtype=dt, device=dev, dedup=a.dedup)
+                                              dtype=dt, device=dev, dedup=a.dedup, capacity=cap)
+        feat = RowShardedMultiIndicesEmbedding(embed_size=1, field_sizes=sizes, dtype=dt, device=dev, dedup=a.dedup,
+                                               capacity=cap)
         parallelism = f"row-sharded table x{world} (all-to-all lookup), data-parallel MLP"
     emb.set_schema(["c0"])       # the whole (B,N) index block travels as one named column
     feat.set_schema(["c0"])

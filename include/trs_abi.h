@@ -331,7 +331,8 @@ int trs_scatter_by_pos(const void* rows, const int32_t* pos, int64_t K, int32_t 
                        void* out, trs_stream_t stream);
 /* out[k,:] = g_block[pos[k],:] + g_fm[b,:]*(fm_sum[b,:] - x[pos[k],:]), b = pos[k]/N: the block gradient (and
  * the FM second-order backward when the FM term was fused into the sharded lookup) in exchange order, one pass.
- * g_block or the (g_fm, fm_sum, x) triple may be NULL.                                                       */
+ * g_block or the (g_fm, fm_sum, x) triple may be NULL.  pos[k] < 0 marks a padding slot of a fixed-capacity
+ * exchange: its row is written as zeros.                                                                      */
 int trs_permute_grad(const void* g_block, const void* g_fm, const float* fm_sum, const void* x,
                      const int32_t* pos, int64_t K, int32_t N, int32_t E, int32_t dtype, void* out,
                      trs_stream_t stream);

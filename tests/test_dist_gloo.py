@@ -30,7 +30,7 @@ class CpuOps:
         inv[order] = torch.arange(order.numel(), dtype=torch.int32)
         return counts, send_ids, send_pos, inv
 
-    def gather_local(self, weight, ids, n_valid=None):
+    def gather_local(self, weight, ids, n_valid=None, padded=False):
         out = weight.detach()[ids.long().clamp(0, weight.shape[0] - 1)]
         if n_valid is not None:
             out = out * ((ids >= 0) & (ids < n_valid)).unsqueeze(-1).to(out.dtype)
@@ -55,7 +55,10 @@ class CpuOps:
         out.index_add_(0, inv.long(), g)
         return out.to(rows.dtype)
 
-    def shard_update(self, weight, ids, grad_rows, opt, dense_index):
+    def shard_update(self, weight, ids, grad_rows, opt, dense_index, padded=False):
+        if padded:                       # -1 = padding slot of a fixed-capacity exchange: updates nothing
+            keep = ids >= 0
+            ids, grad_rows = ids[keep], grad_rows[keep]
         with torch.no_grad():
             g = torch.zeros_like(weight, dtype=torch.float32)
             g.index_add_(0, ids.long(), grad_rows.float())
@@ -83,9 +86,13 @@ class CpuOps:
             dx = g_fm.unsqueeze(1).float() * (fm_sum.unsqueeze(1) - block.float())
             g_block = dx.to(block.dtype) if g_block is None else g_block + dx.to(block.dtype)
         E = g_block.shape[-1]
-        return g_block.reshape(-1, E)[send_pos.long()]
+        out = g_block.reshape(-1, E)[send_pos.long().clamp_min(0)]
+        return out * (send_pos >= 0).unsqueeze(-1).to(out.dtype)          # padding slots: zero rows
 
-    def shard_grad_dense(self, weight, ids, grad_rows):
+    def shard_grad_dense(self, weight, ids, grad_rows, padded=False):
+        if padded:
+            keep = ids >= 0
+            ids, grad_rows = ids[keep], grad_rows[keep]
         g = torch.zeros_like(weight)
         g.index_add_(0, ids.long(), grad_rows)
         return g
@@ -99,7 +106,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, fuse, sparse, ret, dedup=False, optimizer=None):
+def _worker(rank, world, port, fuse, sparse, ret, dedup=False, optimizer=None, capacity=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -108,18 +115,20 @@ def _worker(rank, world, port, fuse, sparse, ret, dedup=False, optimizer=None):
         from torecsys_amd.dist import RowShardedMultiIndicesEmbedding, shard_ranges
         torch.manual_seed(0)
         fs = [7, 3, 11, 5, 9]
-        N, E, B = len(fs), 8, 13 + rank          # ragged local batches
+        ragged = capacity is None                # fixed-capacity slots need the same batch size on every rank
+        N, E = len(fs), 8
         V = sum(fs)
         g = torch.Generator().manual_seed(99)
         W = torch.randn(V, E, generator=g)
-        idx_all = [torch.cat([torch.randint(0, f, (13 + r, 1), generator=g) for f in fs], 1) for r in range(world)]
+        idx_all = [torch.cat([torch.randint(0, f, (13 + (r if ragged else 0), 1), generator=g) for f in fs], 1) for r in range(world)]
         if dedup:                        # plenty of duplicate lookups inside every local batch
             for t in idx_all:
                 t[1::2] = t[0::2][: t[1::2].shape[0]]
-        gb_all = [torch.randn(13 + r, N, E, generator=g) for r in range(world)]
-        gf_all = [torch.randn(13 + r, E, generator=g) for r in range(world)]
+        gb_all = [torch.randn(13 + (r if ragged else 0), N, E, generator=g) for r in range(world)]
+        gf_all = [torch.randn(13 + (r if ragged else 0), E, generator=g) for r in range(world)]
         m = RowShardedMultiIndicesEmbedding(embed_size=E, field_sizes=fs, fuse_fm=fuse, ops=CpuOps(),
-                                            dense_grad_max_rows=0 if sparse else 10 ** 9, dedup=dedup)
+                                            dense_grad_max_rows=0 if sparse else 10 ** 9, dedup=dedup,
+                                            capacity=None if capacity is None else abs(capacity))
         opt = None
         if optimizer is not None:
             from torecsys_amd.optim import FusedSparseAdagrad, FusedSparseSGD
@@ -132,6 +141,14 @@ def _worker(rank, world, port, fuse, sparse, ret, dedup=False, optimizer=None):
         assert torch.equal(m.full_weight(), W)
         if fuse:                         # exercise the routed-ahead path (input-pipeline hint) on half the cases
             m.prefetch_route(idx_all[rank])
+        if capacity is not None and capacity < 0:
+            # too few slots on purpose: the lookups that do not fit read as zero rows and the device-side flag is raised
+            from torecsys_amd import functional as F_
+            F_.index_errors_seen()
+            out = m(idx_all[rank])
+            assert F_.index_errors_seen(), "slot overflow must raise the index flag"
+            ret[rank] = "ok"
+            return
         out = m(idx_all[rank])
         assert out.names == ("B", "N", "E")
         off = O.field_offsets(fs)
@@ -205,6 +222,31 @@ def test_row_sharded_fused_optimizer_gloo(world, fuse, sparse, dedup, optimizer)
     """set_fused_optimizer on the sharded module: the owner steps its rows inside the backward pass (no gradient
     tensor), equal to a dense torch.optim step on the full table"""
     _run(world, fuse, sparse, dedup, optimizer)
+
+
+@pytest.mark.parametrize("world,fuse,sparse,optimizer", [(2, False, False, None), (2, True, False, None), (3, True, True, None),
+                                                         (2, True, False, "adagrad"), (3, False, False, "sgd")])
+def test_row_sharded_fixed_capacity_gloo(world, fuse, sparse, optimizer):
+    """capacity=...: equal-split all-to-alls over padded slots, no split size read on the host; block bit-exact, gradients /
+    owner-side optimizer steps equal the unsharded reference (padding slots carry zero rows and update nothing)"""
+    _run(world, fuse, sparse, False, optimizer, 2.0)
+
+
+def test_row_sharded_fixed_capacity_overflow_is_flagged():
+    """13 x 5 = 65 lookups over 2 ranks at factor 1.0 = 64 slots per peer rounded up: a skewed split overflows them"""
+    from torecsys_amd.dist import pad_slots
+    counts = torch.tensor([100, 28])
+    ids = torch.arange(128, dtype=torch.int32)
+    pos = torch.arange(128, dtype=torch.int32)
+    ids_pad, pos_pad, inv_pad, bad = pad_slots(counts, ids, pos, pos.clone(), 64, 2)
+    assert bool(bad) and ids_pad.shape == (128,)
+    assert torch.equal(ids_pad[:64], ids[:64]) and torch.equal(ids_pad[64:92], ids[100:128])
+    assert bool((ids_pad[92:] == -1).all()) and bool((pos_pad[92:] == -1).all())
+    assert bool((inv_pad[64:100] == 128).all())                     # the 36 lookups that did not fit -> the zero row
+    assert torch.equal(inv_pad[100:], torch.arange(64, 92, dtype=torch.int32))
+    counts = torch.tensor([60, 64])
+    _, _, inv_pad, bad = pad_slots(counts, ids[:124], pos[:124], pos[:124].clone(), 64, 2)
+    assert not bool(bad) and torch.equal(inv_pad[60:], torch.arange(64, 128, dtype=torch.int32))
 
 
 def test_default_ops_refuse_cpu():

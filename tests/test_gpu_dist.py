@@ -128,3 +128,57 @@ def test_sharded_fused_optimizer_matches_unsharded(pg, kind, big_shard):
             assert m.embedding.weight.grad is None
         outs.append(m.embedding.weight.detach().clone())
     assert rel_err(outs[1], outs[0]) <= 1e-5
+
+
+def test_sharded_step_is_capturable(pg):
+    """The row-sharded lookup + FM + owner-side fused optimizer inside a hipGraph (world 1: no collective, and -- as in
+    fixed-capacity mode at any world size -- no split size read on the host): a capture fails on the first host read, so
+    replaying it IS the check.  Replays on fresh index batches must leave the table exactly where the eager steps leave it
+    (the table after step k depends on every kernel of the forward and the backward of steps 1..k).  Other device work
+    is allocated and freed between the replays on purpose: the first version of this test faulted there -- the
+    global-atomic bucket build zeroed its counters with hipMemsetAsync, which as a captured memset NODE did not hold in
+    replays (counters incremented on top of the previous replay's sums -> writes past the end of perm).  The scalar loss
+    is not compared: it is an ATen two-stage reduction, whose replayed value was seen to go stale under the same
+    allocator churn while the gradients computed beside it stayed exact."""
+    from torecsys_amd.dist import RowShardedMultiIndicesEmbedding
+    from torecsys_amd.graph import GraphedStep
+    from torecsys_amd.layers import FMLayer
+    from torecsys_amd.optim import FusedSparseSGD
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    fs = [60 + 7 * i for i in range(12)]
+    B, N, E = 2048, 12, 64
+    W = torch.randn(sum(fs), E, generator=g)
+    batches = [torch.cat([torch.randint(0, f, (B, 1), generator=g) for f in fs], 1).to(dev) for _ in range(4)]
+    gb = torch.randn(B, N, E, generator=g).to(dev)
+
+    def make():
+        m = RowShardedMultiIndicesEmbedding(embed_size=E, field_sizes=fs, fuse_fm=True, dtype=torch.float32, device=dev,
+                                            capacity=1.25)
+        m.load_full_weight(W.to(dev))
+        m.set_fused_optimizer(FusedSparseSGD(1e-4))
+        fm = FMLayer()
+
+        def fn(ix):
+            out = m(ix)
+            loss = (out.rename(None) * gb).sum() + (fm(out).rename(None) ** 2).sum() * 1e-3
+            loss.backward()
+            return loss
+        return m, fn
+
+    m_e, fn_e = make()
+    eager = []
+    for ix in batches:
+        fn_e(ix)
+        eager.append(m_e.embedding.weight.detach().clone())
+    m_g, fn_g = make()
+    step = GraphedStep(fn_g, (batches[0],), params=[], warmup=1)
+    m_g.load_full_weight(W.to(dev))          # the warm-up stepped the table: start over
+    for ix, w0 in zip(batches, eager):
+        step(ix)
+        torch.cuda.synchronize()
+        assert rel_err(m_g.embedding.weight.detach(), w0) <= 1e-5
+        churn = [torch.full((B * N,), 2 ** 31 - 5, dtype=torch.int32, device=dev) for _ in range(4)]
+        churn += [torch.randn(sum(fs), E, device=dev).double() * 1e30 for _ in range(4)]
+        torch.cuda.synchronize()
+        del churn

@@ -249,6 +249,10 @@ __global__ __launch_bounds__(256) void permute_grad_vec_kernel(const uint4* __re
     float o[VE];
 #pragma unroll
     for (int i = 0; i < VE; ++i) o[i] = 0.f;
+    if (p < 0) {      // a padding slot of a fixed-capacity exchange: a zero gradient row
+      store_stream(&out[t], Vec16<T>::pack(o));
+      continue;
+    }
     if (g_block != nullptr) Vec16<T>::unpack(g_block[p * vpr + lv], o);
     if (g_fm != nullptr) {
       const int64_t b = (int64_t)((unsigned)p / (unsigned)N);       // pos is int32
@@ -272,6 +276,10 @@ __global__ __launch_bounds__(256) void permute_grad_elem_kernel(const T* __restr
     const int64_t k = t / E;
     const int e = (int)(t - k * E);
     const int64_t p = pos[k];
+    if (p < 0) {      // padding slot
+      out[t] = from_f32<T>(0.f);
+      continue;
+    }
     float o = g_block ? to_f32(g_block[p * E + e]) : 0.f;
     if (g_fm != nullptr) {
       const int64_t b = p / N;

@@ -990,6 +990,18 @@ static int scatter_launch(const void* g_rows, const void* g_fm, const float* fm_
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Zero-fill by a kernel, not hipMemsetAsync: a memset captured into a hipGraph becomes a memset NODE, and on this runtime
+// the global-atomic bucket build replayed from a graph faulted (counters incremented on top of the previous replay's
+// prefix sums -> positions past the end of perm) until the fills in front of atomically-updated counters were kernels.
+__global__ __launch_bounds__(256) void zero_i32_kernel(int32_t* __restrict__ p, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0;
+}
+static int zero_i32(int32_t* p, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(zero_i32_kernel, dim3(stream_grid(n, 256, 1024)), dim3(256), 0, s, p, n);
+  return 0;
+}
+
 }  // namespace trs
 
 using namespace trs;
@@ -1031,10 +1043,10 @@ extern "C" int trs_csr_build(const void* idx, int32_t idx_dtype, const int64_t* 
   const int64_t max_items = (int64_t)N + (V + chunk - 1) / chunk;
   const bool part = offsets != nullptr && N <= CSR2_MAX_FIELDS && B >= 2048 && max_items <= 16 * (int64_t)N + 256 &&
                     max_items <= 16384;
-  if (hipMemsetAsync(row_start, 0, (size_t)n * 4, s) != hipSuccess) return check_launch("csr_build(memset)");
+  zero_i32(row_start, n, s);
   const int32_t* gate = nullptr;
   if (part) {
-    if (hipMemsetAsync(flags, 0, 256, s) != hipSuccess) return check_launch("csr_build(memset)");
+    zero_i32(flags, 64, s);
     const int tiles = (int)((B + CSR2_TB - 1) / CSR2_TB);
     const size_t lds = (size_t)N * (CSR2_TB + 1) * 4;
     if (idx_dtype == TRS_I64)
@@ -1113,7 +1125,7 @@ static int scatter_rows_impl(RowSink sink, const void* g_rows, int64_t g_rows_ba
   float* scratch = (float*)((char*)tg + align_up((size_t)B * 2 * E * dtype_size(dtype), 256));
   hipStream_t s = (hipStream_t)stream;
   int32_t* long_rows = (int32_t*)workspace;
-  if (hipMemsetAsync(long_rows, 0, 4, s) != hipSuccess) return check_launch("scatter_rows(memset)");
+  zero_i32(long_rows, 1, s);
   int rc;
   if (dtype == TRS_F32)
     rc = scatter_launch<float>(g_rows, g_fm, fm_sum, table, row_start, perm, V, E, N, gbs, padding_row, grad_table,

@@ -66,6 +66,12 @@ __global__ __launch_bounds__(256) void bucket_fill_kernel(const IdxT* __restrict
   }
 }
 
+// counts / cursor start at zero.  A kernel, not hipMemsetAsync: inside a captured hipGraph the 8-byte memset nodes were
+// seen racing with the kernels behind them (the fill pass then computes slots from garbage and writes out of bounds)
+__global__ void bucket_zero_kernel(unsigned long long* __restrict__ a, unsigned long long* __restrict__ b, int W) {
+  for (int w = threadIdx.x; w < W; w += blockDim.x) { a[w] = 0ull; b[w] = 0ull; }
+}
+
 static size_t align_up_s(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 }  // namespace trs
@@ -90,9 +96,9 @@ extern "C" int trs_bucket_by_owner(const void* idx, int32_t idx_dtype, const int
   hipStream_t s = (hipStream_t)stream;
   const int64_t BN = B * N;
   TRS_REQUIRE(BN < (int64_t)0x7fffffff, TRS_ESHAPE, "bucket_by_owner: B*N must fit int32");
-  if (hipMemsetAsync(counts, 0, (size_t)world * 8, s) != hipSuccess) return check_launch("bucket(memset)");
-  if (hipMemsetAsync(workspace, 0, (size_t)world * 8, s) != hipSuccess) return check_launch("bucket(memset)");
-  if (BN == 0) return TRS_OK;
+  hipLaunchKernelGGL(bucket_zero_kernel, dim3(1), dim3(64), 0, s, (unsigned long long*)counts,
+                     (unsigned long long*)workspace, world);
+  if (BN == 0) return check_launch("bucket_by_owner");
   TRS_REQUIRE(idx && send_ids && send_pos, TRS_EINVAL, "bucket_by_owner: NULL pointer");
   unsigned long long* cnt = (unsigned long long*)counts;
   unsigned long long* cursor = (unsigned long long*)workspace;

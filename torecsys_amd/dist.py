@@ -24,6 +24,13 @@ rebuilt from the distinct rows and the gradients of duplicate lookups are summed
 (Zipf) data, costs a sort on uniform data, default off.  A process group of one rank takes no collective and no host
 read at all (the step is then capturable into a hipGraph).
 
+``capacity=<factor>`` switches the exchange to FIXED-CAPACITY slots: every peer gets ``ceil(B*N/world * factor)`` lookup
+slots per step (padded with -1), so all three all-to-alls have equal, compile-time splits and NO split size is ever read on
+the host -- the host can run ahead of the device and the whole step (collectives included) has a static launch sequence,
+which is what a hipGraph capture needs.  A peer whose share exceeds its slots raises the device-side index flag
+(``functional.index_errors_seen()``) and the lookups that did not fit read as zero rows; with uniform ids a factor of
+1.1 is ~100 standard deviations of the per-peer count at the BASELINE shape.
+
 ``backend='nccl'`` is RCCL on ROCm (xGMI links); the same code runs on ``gloo`` with CPU tensors when a
 CPU ``ops`` object is injected (tests only -- the default ops are the HIP kernels and refuse CPU tensors).
 """
@@ -62,10 +69,15 @@ class HipOps:
              ptr(counts), ptr(send_ids), ptr(send_pos), ptr(inv_pos), ptr(ws), ws_bytes, stream_ptr())
         return counts, send_ids, send_pos, inv_pos
 
-    def gather_local(self, weight: torch.Tensor, ids: torch.Tensor, n_valid: Optional[int] = None) -> torch.Tensor:
+    def gather_local(self, weight: torch.Tensor, ids: torch.Tensor, n_valid: Optional[int] = None,
+                     padded: bool = False) -> torch.Tensor:
         """rows ``ids`` of this rank's shard.  Ids outside [0, n_valid) -- a global id past the table, a negative id,
         the short last shard -- read as zero rows and raise the device-side index flag
-        (functional.index_errors_seen() / TRS_CHECK_INDICES=1) instead of touching foreign memory."""
+        (functional.index_errors_seen() / TRS_CHECK_INDICES=1) instead of touching foreign memory.
+        ``padded``: -1 entries are the padding of a fixed-capacity exchange (their rows are never used): they read row 0
+        and raise nothing (negative REAL ids were flagged by the sender, ``pad_slots``)."""
+        if padded:
+            ids = ids.clamp_min(0)
         K = ids.numel()
         V, E = weight.shape
         out = torch.empty(K, E, dtype=weight.dtype, device=weight.device)
@@ -99,13 +111,15 @@ class HipOps:
             return F_.scatter_rows(rb, rows, g_rows=gb, g_bcast=F_._fm_grad_operand(g_fm), fm_sum=fm_sum)
         return F_.scatter_rows(rb, rows, g_rows=gb)
 
-    def shard_update(self, weight: torch.Tensor, ids: torch.Tensor, grad_rows: torch.Tensor, opt, dense_index: bool):
-        """fused optimizer step on the owner: rows ``ids`` (with repeats) of ``weight`` receive ``grad_rows``"""
+    def shard_update(self, weight: torch.Tensor, ids: torch.Tensor, grad_rows: torch.Tensor, opt, dense_index: bool,
+                     padded: bool = False):
+        """fused optimizer step on the owner: rows ``ids`` (with repeats) of ``weight`` receive ``grad_rows``
+        (``padded``: -1 entries are padding slots and update nothing)"""
         if ids.numel() == 0:          # this rank received no lookups this step
             return
         with torch.no_grad():
             if dense_index:
-                rb = F_.row_buckets(ids.view(-1, 1), None, weight.shape[0])
+                rb = F_.row_buckets(ids.view(-1, 1), None, weight.shape[0], check=not padded)
                 F_.scatter_rows_update(rb, weight.data, opt, g_rows=grad_rows.contiguous(), key=weight)
             else:
                 uniq, inv = torch.unique(ids, return_inverse=True)
@@ -141,8 +155,9 @@ class HipOps:
                  stream_ptr())
         return out
 
-    def shard_grad_dense(self, weight: torch.Tensor, ids: torch.Tensor, grad_rows: torch.Tensor) -> torch.Tensor:
-        rb = F_.row_buckets(ids.view(-1, 1), None, weight.shape[0])
+    def shard_grad_dense(self, weight: torch.Tensor, ids: torch.Tensor, grad_rows: torch.Tensor,
+                         padded: bool = False) -> torch.Tensor:
+        rb = F_.row_buckets(ids.view(-1, 1), None, weight.shape[0], check=not padded)
         return F_.scatter_rows(rb, weight, g_rows=grad_rows.contiguous())
 
 
@@ -155,12 +170,38 @@ def _all_to_all(out: torch.Tensor, inp: torch.Tensor, out_splits: List[int], in_
     dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
 
 
+PAD = -1        # id / position of a padding slot
+
+
+def pad_slots(counts: torch.Tensor, send_ids: torch.Tensor, send_pos: torch.Tensor, inv_pos: torch.Tensor, cap: int,
+              world: int):
+    """Compact per-owner lists -> ``world`` slots of ``cap`` entries each, on the device, with no host read.
+    Returns (send_ids_pad (W*cap) int32, PAD-filled; pos_pad (W*cap) int32: the lookup that sits in each slot or PAD;
+    inv_pad (B*N) int32: the slot of every lookup -- W*cap, one past the last slot, for a lookup that did not fit;
+    bad (0-d bool): some owner's share exceeded ``cap`` or a row id was negative).  Index plumbing only: cumsum /
+    bucketize / scatter on B*N int32 values."""
+    K = send_ids.numel()
+    dev = send_ids.device
+    ends = counts.cumsum(0)
+    starts = ends - counts
+    k = torch.arange(K, device=dev)
+    owner = torch.bucketize(k, ends, right=True).clamp_max(world - 1)
+    within = k - starts[owner]
+    total = world * cap
+    slot = torch.where(within < cap, owner * cap + within, torch.full_like(k, total))     # `total` = the trash slot
+    ids_pad = torch.full((total + 1,), PAD, dtype=torch.int32, device=dev).scatter_(0, slot, send_ids)
+    pos_pad = torch.full((total + 1,), PAD, dtype=torch.int32, device=dev).scatter_(0, slot, send_pos)
+    inv_pad = slot.to(torch.int32)[inv_pos.long()]
+    bad = (counts.max() > cap) | (send_ids.min() < 0) if K else torch.zeros((), dtype=torch.bool, device=dev)
+    return ids_pad[:total], pos_pad[:total], inv_pad, bad
+
+
 class RoutePlan:
     """Everything about one batch of indices that does not depend on the table: who owns each lookup, the
     per-peer split sizes (host ints) and the local row ids every peer asked this rank for.  Tables looked up
     with the same index tensor (the E=64 embeddings and the E=1 first-order weights of one model) share it,
     so the bucketing, the count exchange (one host sync) and the id all-to-all happen once per batch."""
-    __slots__ = ("send_pos", "inv_pos", "send_splits", "recv_splits", "recv_ids")
+    __slots__ = ("send_pos", "inv_pos", "send_splits", "recv_splits", "recv_ids", "cap")
 
 
 _route_cache: List[tuple] = []      # [(key, idx kept alive, RoutePlan)]
@@ -182,6 +223,14 @@ MAX_PENDING_ROUTES = 4               # batches routed ahead of their forward pas
 route_stats = {"prefetched": 0, "cached": 0, "cold": 0}     # how forward passes obtained their route plan
 
 
+def clear_route_caches():
+    _route_cache.clear()
+    _pending_routes.clear()
+
+
+F_._clear_hooks.append(clear_route_caches)      # F_.clear_caches() (GraphedStep) drops the route plans too
+
+
 def _start_route(idx: torch.Tensor, mod) -> "_PendingRoute":
     ops, group, world = mod.ops, mod.group, mod.world
     pr = _PendingRoute()
@@ -193,6 +242,14 @@ def _start_route(idx: torch.Tensor, mod) -> "_PendingRoute":
         pr.send_ids, pr.send_pos, pr.inv_pos = send_ids, send_pos, inv_pos
     if world == 1:
         pr.host_counts, pr.ready = None, None        # one rank: everything stays local, nothing to read back
+        return pr
+    if mod.capacity is not None and not mod.dedup:
+        cap = mod.slot_capacity(idx.numel())
+        pr.send_ids, pr.send_pos, pr.inv_pos, bad = pad_slots(counts, send_ids, send_pos, inv_pos, cap, world)
+        flag = F_._ErrFlag(idx.device)
+        flag.t.copy_(torch.maximum(flag.t, bad.to(torch.int32).reshape(1)))
+        flag.check("sharded lookup (fixed-capacity slots)")
+        pr.host_counts, pr.ready = None, None        # equal splits: no count exchange, no host read
         return pr
     recv_counts = torch.empty_like(counts)
     dist.all_to_all_single(recv_counts, counts, group=group)
@@ -238,8 +295,14 @@ def _route_plan(idx: torch.Tensor, mod) -> "RoutePlan":
         route_stats["cold"] += 1
         pr = _start_route(idx, mod)
     p = RoutePlan()
-    p.send_pos, p.inv_pos = pr.send_pos, pr.inv_pos
-    if mod.world == 1:
+    p.send_pos, p.inv_pos, p.cap = pr.send_pos, pr.inv_pos, 0
+    if pr.host_counts is None and mod.world > 1:
+        # fixed-capacity slots: equal splits, nothing to read on the host
+        p.cap = mod.slot_capacity(idx.numel())
+        p.send_splits = p.recv_splits = None
+        p.recv_ids = torch.empty_like(pr.send_ids)
+        dist.all_to_all_single(p.recv_ids, pr.send_ids, group=mod.group)
+    elif mod.world == 1:
         n = int(pr.send_ids.numel())                 # a shape, not a device value: no synchronisation
         p.send_splits, p.recv_splits, p.recv_ids = [n], [n], pr.send_ids
     else:
@@ -259,6 +322,11 @@ def _exchange(out_rows: int, inp: torch.Tensor, out_splits, in_splits, mod) -> t
     """all-to-all of row blocks; a one-rank group hands the tensor through"""
     if mod.world == 1:
         return inp
+    if out_splits is None:            # fixed-capacity slots: one more (zero) row behind the received ones for lookups
+        buf = torch.empty(out_rows + 1, inp.shape[1], dtype=inp.dtype, device=inp.device)      # that did not fit
+        buf[out_rows:].zero_()
+        dist.all_to_all_single(buf[:out_rows], inp, group=mod.group)
+        return buf
     out = torch.empty(out_rows, inp.shape[1], dtype=inp.dtype, device=inp.device)
     _all_to_all(out, inp, out_splits, in_splits, mod.group)
     return out
@@ -272,10 +340,17 @@ class _ShardedLookup(Function):
         ops = mod.ops
         B, N = idx.shape
         plan = _route_plan(idx, mod)
-        rows = ops.gather_local(weight, plan.recv_ids, mod.row_range[1] - mod.row_range[0])     # rows of my shard
-        back = _exchange(sum(plan.send_splits), rows, plan.send_splits, plan.recv_splits, mod)
+        padded = plan.cap > 0
+        n_valid = mod.row_range[1] - mod.row_range[0]
+        if padded:
+            rows = ops.gather_local(weight, plan.recv_ids, n_valid, padded=True)                # rows of my shard
+            back = _exchange(plan.recv_ids.numel(), rows, None, None, mod)
+        else:
+            rows = ops.gather_local(weight, plan.recv_ids, n_valid)
+            back = _exchange(sum(plan.send_splits), rows, plan.send_splits, plan.recv_splits, mod)
         block, fm, fm_sum = ops.unpermute(back, plan.inv_pos, B, N, mod.fuse_fm)
         ctx.mod = mod
+        ctx.padded = padded
         ctx.splits = (plan.send_splits, plan.recv_splits)
         ctx.save_for_backward(weight, plan.recv_ids, plan.send_pos if plan.send_pos is not None else plan.inv_pos,
                               block if mod.fuse_fm else None, fm_sum, back if mod.dedup else None)
@@ -301,16 +376,21 @@ class _ShardedLookup(Function):
             if block is None:
                 block = g_block     # shape carrier only
             g_rows = ops.permute_grad(g_block, pos, g_fm if mod.fuse_fm else None, fm_sum, block)
-        recv_g = _exchange(sum(recv_splits), g_rows, recv_splits, send_splits, mod)              # reverse exchange
+        if ctx.padded:      # equal splits; padding slots carry zero rows (pos = PAD) and update nothing on the owner
+            recv_g = _exchange(g_rows.shape[0], g_rows, None, None, mod)[: g_rows.shape[0]]
+        else:
+            recv_g = _exchange(sum(recv_splits), g_rows, recv_splits, send_splits, mod)          # reverse exchange
         dense_index = weight.shape[0] <= mod.dense_grad_max_rows
+        pad_kw = {"padded": True} if ctx.padded else {}
         if mod.fused_optimizer is not None:
             # the owner steps its rows right here: no gradient tensor of any kind (weight.grad stays None)
-            ops.shard_update(weight, recv_ids, recv_g, mod.fused_optimizer, dense_index)
+            ops.shard_update(weight, recv_ids, recv_g, mod.fused_optimizer, dense_index, **pad_kw)
             return None, None, None
         if dense_index:
-            gw = ops.shard_grad_dense(weight, recv_ids, recv_g)
+            gw = ops.shard_grad_dense(weight, recv_ids, recv_g, **pad_kw)
         else:
-            gw = torch.sparse_coo_tensor(recv_ids.long().unsqueeze(0), recv_g, size=weight.shape)
+            ids = recv_ids.clamp_min(0) if ctx.padded else recv_ids      # padding: zero rows added to row 0
+            gw = torch.sparse_coo_tensor(ids.long().unsqueeze(0), recv_g, size=weight.shape)
         return gw, None, None
 
 
@@ -323,7 +403,8 @@ class RowShardedMultiIndicesEmbedding(BaseInput):
 
     def __init__(self, embed_size: int, field_sizes: List[int], flatten: bool = False, fuse_fm: bool = False,
                  dtype: torch.dtype = torch.float32, device='cpu', process_group=None, ops=None,
-                 dense_grad_max_rows: int = DENSE_GRAD_MAX_ROWS, dedup: bool = False):
+                 dense_grad_max_rows: int = DENSE_GRAD_MAX_ROWS, dedup: bool = False,
+                 capacity: Optional[float] = None):
         super().__init__()
         if not dist.is_initialized():
             raise RuntimeError("RowShardedMultiIndicesEmbedding needs torch.distributed to be initialised")
@@ -344,8 +425,30 @@ class RowShardedMultiIndicesEmbedding(BaseInput):
         self.padding_idx = None
         self.dense_grad_max_rows = dense_grad_max_rows
         self.dedup = bool(dedup)
-        self.route_key = (tuple(int(f) for f in field_sizes), self.world, id(process_group), self.dedup)
+        if capacity is not None and capacity < 1.0:
+            raise ValueError("capacity is a factor on the even share B*N/world: it must be >= 1")
+        if capacity is not None and dedup:
+            raise ValueError("fixed-capacity slots and dedup (a data-dependent number of rows) exclude each other")
+        self.capacity = None if capacity is None else float(capacity)
+        self._caps = {}
+        self.route_key = (tuple(int(f) for f in field_sizes), self.world, id(process_group), self.dedup, self.capacity)
         self.length = embed_size * len(field_sizes) if flatten else embed_size
+
+    def slot_capacity(self, lookups: int) -> int:
+        """slots per peer of a fixed-capacity exchange of ``lookups`` = B*N row ids (a multiple of 64).  Equal splits
+        need the same slot size on every rank, i.e. the same local batch size: checked ONCE per distinct size (one
+        small all-reduce the first time a size is seen), never per step."""
+        cap = self._caps.get(lookups)
+        if cap is None:
+            t = torch.tensor([lookups, -lookups], dtype=torch.int64, device=self.embedding.weight.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            hi, lo = int(t[0]), -int(t[1])
+            if hi != lo:
+                raise RuntimeError(f"fixed-capacity exchange: every rank must look up the same number of ids per step "
+                                   f"(this step: between {lo} and {hi})")
+            even = -(-lookups // self.world)
+            cap = self._caps[lookups] = max(64, -(-int(even * self.capacity) // 64) * 64)
+        return cap
 
     def forward(self, inputs: torch.Tensor) -> torch.Tensor:
         idx = inputs.rename(None) if inputs.has_names() else inputs

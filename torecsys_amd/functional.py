@@ -114,7 +114,9 @@ def _bucket_key(idx, offsets, V):
     return (idx.data_ptr(), idx._version, tuple(idx.shape), idx.dtype, _offsets_key(offsets), V)
 
 
-def _build_buckets(idx, offsets, V) -> RowBuckets:
+def _build_buckets(idx, offsets, V, check: bool = True) -> RowBuckets:
+    """``check=False``: ids outside [0, V) are skipped WITHOUT raising the index flag (the padding slots of a
+    fixed-capacity exchange carry -1; real ids were range-checked when they were looked up)."""
     B, N = idx.shape
     BN = B * N
     dev = idx.device
@@ -122,14 +124,15 @@ def _build_buckets(idx, offsets, V) -> RowBuckets:
     perm = torch.empty(max(BN, 1), dtype=torch.int32, device=dev)
     ws_bytes = size_query("trs_csr_workspace_bytes", V, BN)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    flag = _ErrFlag(dev)
+    flag = _ErrFlag(dev) if check else None
     call("trs_csr_build", ptr(idx), index_dtype_code(idx), ptr(offsets), B, N, V, ptr(row_start), ptr(perm),
-         ptr(ws), ws_bytes, ptr(flag.t), stream_ptr())
-    flag.check("row_buckets")
+         ptr(ws), ws_bytes, ptr(flag.t if check else None), stream_ptr())
+    if check:
+        flag.check("row_buckets")
     return RowBuckets(row_start, perm, V, BN, N)
 
 
-def row_buckets(idx: torch.Tensor, offsets: Optional[torch.Tensor], V: int) -> RowBuckets:
+def row_buckets(idx: torch.Tensor, offsets: Optional[torch.Tensor], V: int, check: bool = True) -> RowBuckets:
     """Build (or fetch) the CSR for ``idx`` (B,N).  The cache keeps a reference to the index tensor,
     so its storage cannot be recycled for another batch while the entry is live; in-place edits bump
     ``_version`` and miss."""
@@ -138,7 +141,7 @@ def row_buckets(idx: torch.Tensor, offsets: Optional[torch.Tensor], V: int) -> R
         if k == key:
             rb.wait()
             return rb
-    rb = _build_buckets(idx, offsets, V)
+    rb = _build_buckets(idx, offsets, V, check)
     _bucket_cache.append((key, idx, rb))
     if len(_bucket_cache) > _BUCKET_CACHE_SIZE:
         _bucket_cache.pop(0)
@@ -202,8 +205,13 @@ def prefetch_row_buckets(idx: torch.Tensor, offsets: Optional[torch.Tensor], V: 
         _bucket_cache.pop(0)
 
 
+_clear_hooks: List = []        # other per-batch caches keyed by index-tensor identity (dist.py's route plans)
+
+
 def clear_caches():
     _bucket_cache.clear()
+    for hook in _clear_hooks:
+        hook()
 
 
 # --------------------------------------------------------------------------------------------

@@ -14,7 +14,8 @@ The callable must be shape-static and must not branch on tensor values.  Scalars
 learning rate of a fused sparse optimizer) are frozen at capture time; call ``recapture()`` after changing them.
 ``FusedSparseAdam`` refuses to be captured: its bias-corrected step size changes every step and is a host scalar
 (FusedSparseSGD / FusedSparseAdagrad have no per-step host state and capture fine).
-The row-sharded multi-GPU lookup reads its all-to-all split sizes on the host and therefore stays eager.
+The row-sharded multi-GPU lookup is capturable where it reads nothing on the host: one rank, or fixed-capacity slots
+(``RowShardedMultiIndicesEmbedding(capacity=...)``: equal all-to-all splits); with exact split sizes it stays eager.
 """
 from typing import Callable, Iterable, Optional, Sequence
 
@@ -72,7 +73,10 @@ class GraphedStep:
         # construction (and the event they wait on) OUT of the graph and replay stale buckets for every later batch
         F_.clear_caches()
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        # "thread_local": only THIS thread's calls are policed during the capture.  In the default "global" mode an
+        # event query from any other thread -- the watchdog of an initialised RCCL process group polls its events all
+        # the time -- invalidates the capture and the runtime aborts the process
+        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
             self.output = self._fn(*self._static)
         torch.cuda.synchronize()
         F_.clear_caches()          # entries made during the capture point into the graph's private pool
