@@ -49,6 +49,11 @@ from ._abi import call, index_dtype_code, ptr, require_device, size_query, strea
 from .inputs import BaseInput, field_offsets
 
 DENSE_GRAD_MAX_ROWS = 8_000_000      # shards up to this many rows get a dense gradient
+# TRS_SHARD_PREFETCH=1: build the owner-side row buckets at forward time on the side stream.  Off by default: measured on
+# the one-rank DeepFM step (same box, alternating runs) 1.968-1.971 ms with it against 1.933-1.936 ms without -- the
+# global-atomic build (no per-field ranges on the owner side) slows the bandwidth-bound lookup kernels it runs beside by
+# more than the ~160 us it takes off the backward
+OWNER_PREFETCH = __import__("os").environ.get("TRS_SHARD_PREFETCH", "0") == "1"
 
 
 class HipOps:
@@ -127,6 +132,13 @@ class HipOps:
                 # ids outside the shard (the lookup read them as zero rows and raised the index flag) stay in ``uniq``:
                 # trs_scatter_rows_update_mapped skips row_map entries outside [0, V), so they update nothing
                 F_.scatter_rows_update_mapped(rb, weight.data, opt, grad_rows, uniq.to(torch.int32), key=weight)
+
+    def prefetch_owner_buckets(self, weight: torch.Tensor, ids: torch.Tensor, padded: bool = False) -> None:
+        """The owner-side row buckets of this step (the CSR over the ids this rank RECEIVED) depend only on the route: start
+        building them on the side stream at forward time, as the unsharded lookup does, so the backward's reduction
+        finds them ready instead of running a ~160 us global-atomic build on the critical path."""
+        if ids.numel() and weight.requires_grad and OWNER_PREFETCH:
+            F_.prefetch_row_buckets(ids.view(-1, 1), None, weight.shape[0], check=not padded)
 
     def unpermute(self, rows: torch.Tensor, inv_pos: torch.Tensor, B: int, N: int, want_fm: bool):
         """block[p] = rows[inv_pos[p]]; with ``want_fm`` also FM second order + the fp32 field sum."""
@@ -349,6 +361,8 @@ class _ShardedLookup(Function):
             rows = ops.gather_local(weight, plan.recv_ids, n_valid)
             back = _exchange(sum(plan.send_splits), rows, plan.send_splits, plan.recv_splits, mod)
         block, fm, fm_sum = ops.unpermute(back, plan.inv_pos, B, N, mod.fuse_fm)
+        if weight.shape[0] <= mod.dense_grad_max_rows and hasattr(ops, "prefetch_owner_buckets"):
+            ops.prefetch_owner_buckets(weight, plan.recv_ids, padded)
         ctx.mod = mod
         ctx.padded = padded
         ctx.splits = (plan.send_splits, plan.recv_splits)

@@ -166,19 +166,19 @@ class defer_prefetch:
         if _defer_depth[0] == 0:
             reqs = list(_pending_prefetch)
             _pending_prefetch.clear()
-            for idx, offsets, V in reqs:
-                prefetch_row_buckets(idx, offsets, V)
+            for idx, offsets, V, check in reqs:
+                prefetch_row_buckets(idx, offsets, V, check)
         return False
 
 
-def prefetch_row_buckets(idx: torch.Tensor, offsets: Optional[torch.Tensor], V: int) -> None:
+def prefetch_row_buckets(idx: torch.Tensor, offsets: Optional[torch.Tensor], V: int, check: bool = True) -> None:
     """Start building the CSR of this batch on a side stream at FORWARD time: it depends only on the
     indices, is latency-bound (int32 atomics), and hides behind the forward/backward of the dense part
     of the model; the backward's scatter then just waits on an event."""
     if not PREFETCH_BUCKETS:
         return
     if _defer_depth[0] > 0:
-        _pending_prefetch.append((idx, offsets, V))
+        _pending_prefetch.append((idx, offsets, V, check))
         return
     key = _bucket_key(idx, offsets, V)
     for k, _, _rb in _bucket_cache:
@@ -192,7 +192,7 @@ def prefetch_row_buckets(idx: torch.Tensor, offsets: Optional[torch.Tensor], V: 
     side.wait_stream(main)
     torch.cuda.set_stream(side)          # not `with torch.cuda.stream(side)`: its constructor and __enter__ each resolve
     try:                                 # the current device through hipGetDeviceCount (~0.1 ms apiece)
-        rb = _build_buckets(idx, offsets, V)
+        rb = _build_buckets(idx, offsets, V, check)
         rb.ready = torch.cuda.Event()
         rb.ready.record(side)
     finally:
