@@ -133,6 +133,55 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(int32_t* __res
   }
 }
 
+// Exclusive scan of data[0..n) in ONE pass (decoupled look-back): workgroup t scans its tile, publishes its aggregate in
+// status[t] (bit 30 = aggregate only, bit 31 = inclusive prefix; the counts are < 2^30), and finds its exclusive prefix
+// by walking back over its predecessors' status words until it meets an inclusive one.  Replaces tile-sums -> one-workgroup
+// scan of the sums -> apply (three launches, the middle one a single workgroup).  Workgroups are dispatched in index order
+// and the grid (V / 4096 tiles) is far smaller than what the chip keeps resident, so a predecessor is always running.
+// status[] must be zero on entry.
+__global__ __launch_bounds__(SCAN_THREADS) void scan_onepass_kernel(int32_t* __restrict__ data, int64_t n,
+                                                                    unsigned* __restrict__ status) {
+  __shared__ int lds[8];
+  __shared__ int s_prefix;
+  const int tile = blockIdx.x;
+  const int64_t base = (int64_t)tile * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  int v[SCAN_ITEMS];
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    v[i] = base + i < n ? data[base + i] : 0;
+    s += v[i];
+  }
+  int tot;
+  const int ex = block_exclusive_scan(s, &tot, lds);
+  if (threadIdx.x == 0) {
+    volatile unsigned* st = status;
+    if (tile == 0) {
+      st[0] = 0x80000000u | (unsigned)tot;
+      s_prefix = 0;
+    } else {
+      st[tile] = 0x40000000u | (unsigned)tot;
+      __threadfence();
+      int run = 0;
+      for (int p = tile - 1; p >= 0; --p) {
+        unsigned w;
+        do { w = st[p]; } while ((w & 0xc0000000u) == 0u);
+        run += (int)(w & 0x3fffffffu);
+        if (w & 0x80000000u) break;
+      }
+      s_prefix = run;
+      st[tile] = 0x80000000u | (unsigned)(run + tot);
+    }
+  }
+  __syncthreads();
+  int run = s_prefix + ex;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    if (base + i < n) data[base + i] = run;
+    run += v[i];
+  }
+}
+
 template <typename IdxT>
 __global__ __launch_bounds__(256) void csr_fill_kernel(const IdxT* __restrict__ idx,
                                                        const int64_t* __restrict__ offsets, int64_t BN, int N,
@@ -1001,6 +1050,14 @@ static int zero_i32(int32_t* p, int64_t n, hipStream_t s) {
   hipLaunchKernelGGL(zero_i32_kernel, dim3(stream_grid(n, 256, 1024)), dim3(256), 0, s, p, n);
   return 0;
 }
+__global__ __launch_bounds__(256) void zero2_i32_kernel(int32_t* __restrict__ p, int64_t n, int32_t* __restrict__ p2,
+                                                        int64_t n2) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n + n2; i += stride) {
+    if (i < n) p[i] = 0;
+    else p2[i - n] = 0;
+  }
+}
 
 }  // namespace trs
 
@@ -1043,7 +1100,9 @@ extern "C" int trs_csr_build(const void* idx, int32_t idx_dtype, const int64_t* 
   const int64_t max_items = (int64_t)N + (V + chunk - 1) / chunk;
   const bool part = offsets != nullptr && N <= CSR2_MAX_FIELDS && B >= 2048 && max_items <= 16 * (int64_t)N + 256 &&
                     max_items <= 16384;
-  zero_i32(row_start, n, s);
+  const bool onepass = (n + SCAN_TILE - 1) / SCAN_TILE <= 2048;   // (the scan's status words are zeroed with the counters)
+  hipLaunchKernelGGL(zero2_i32_kernel, dim3(stream_grid(n, 256, 1024)), dim3(256), 0, s, row_start, n, tile_sums,
+                     (int64_t)(onepass ? ntiles : 0));
   const int32_t* gate = nullptr;
   if (part) {
     zero_i32(flags, 64, s);
@@ -1070,9 +1129,13 @@ extern "C" int trs_csr_build(const void* idx, int32_t idx_dtype, const int64_t* 
       hipLaunchKernelGGL((csr_count_kernel<int32_t>), dim3(grid), dim3(256), 0, s, (const int32_t*)idx, offsets, BN, N,
                          V, row_start, slot, err_flag, gate);
   }
-  hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(ntiles), dim3(SCAN_THREADS), 0, s, row_start, n, tile_sums);
-  hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, tile_sums, ntiles);
-  hipLaunchKernelGGL(scan_apply_kernel, dim3(ntiles), dim3(SCAN_THREADS), 0, s, row_start, n, tile_sums);
+  if (onepass) {             // every tile's workgroup resident at once: one pass
+    hipLaunchKernelGGL(scan_onepass_kernel, dim3(ntiles), dim3(SCAN_THREADS), 0, s, row_start, n, (unsigned*)tile_sums);
+  } else {
+    hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(ntiles), dim3(SCAN_THREADS), 0, s, row_start, n, tile_sums);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, tile_sums, ntiles);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(ntiles), dim3(SCAN_THREADS), 0, s, row_start, n, tile_sums);
+  }
   if (part)
     hipLaunchKernelGGL((csr2_pass_kernel<true>), dim3((int)max_items), dim3(CSR2_THREADS), 0, s, rowT, offsets, B, N, V,
                        row_start, perm, flags, (int)chunk);
