@@ -260,27 +260,36 @@ int trs_cin_bwd(const void* x0, const void* xk, const void* Wc, const void* gy, 
  *   yT  (B,E,C): yT[b,e,c] = y[b,c,e]
  * Requirements: C % 32 == 0, E % 16 == 0, H <= 256.  workspace: trs_cin_cl_workspace_bytes.
  * The x0[n] factor multiplies the MFMA result, so the outer product never exists even in registers.
+ * tri != 0 (needs xkT == x0T, ldk == ld0, N == H): the caller states that Wc[c, n*H + h] == 0 for every h > n -- the form the first
+ * layer's weights take once W[n,h] + W[h,n] is folded onto h <= n, which is exact there because xk IS x0 and
+ * the products x0[n]*x0[h] are symmetric -- and the k-steps that only hold such zeros are skipped.
  * layers/ctr/compress_interaction_network.py:125-137.                                          */
 size_t trs_cin_cl_workspace_bytes(int32_t N, int32_t H, int32_t C);
 int trs_cin_cl_fwd(const void* x0T, int32_t ld0, const void* xkT, int32_t ldk, const void* Wc,
                    const void* bias, int64_t B, int32_t N, int32_t H, int32_t C, int32_t E, int32_t dtype,
-                   void* yT, void* workspace, size_t ws_bytes, trs_stream_t stream);
+                   int32_t tri, void* yT, void* workspace, size_t ws_bytes, trs_stream_t stream);
 /* data gradients of the same contraction, channels-last: given gyT (B,E,C)
  *   dx0T (B,E,ld0)  : dx0T[b,e,n] = sum_{c,h} gy*Wc*xk   (zeros past N)
  *   dxkT rows of stride ldo (>= 32*ceil(H/32)): dxkT[b*E+e,h] = sum_{c,n} gy*Wc*x0
- * Requirements: C in {32,64,128,256}, E % 16 == 0.  bias gradient = sum of gy over (b,e) (caller).  */
+ * Requirements: C in {32,64,128,256}, E % 16 == 0.  bias gradient = sum of gy over (b,e) (caller).
+ * tri: as in trs_cin_cl_fwd; xkT is x0T there, so the two gradients belong to the same values: dx0T receives
+ * their SUM (added in fp32, rounded once) and dxkT is not written (may be NULL).                        */
 size_t trs_cin_cl_bwd_data_workspace_bytes(int32_t N, int32_t H, int32_t C);
 int trs_cin_cl_bwd_data(const void* x0T, int32_t ld0, const void* xkT, int32_t ldk, const void* gyT,
                         const void* Wc, int64_t B, int32_t N, int32_t H, int32_t C, int32_t E,
-                        int32_t dtype, void* dx0T, void* dxkT, int32_t ldo, void* workspace,
+                        int32_t dtype, int32_t tri, void* dx0T, void* dxkT, int32_t ldo, void* workspace,
                         size_t ws_bytes, trs_stream_t stream);
 
 /* weight gradient of the same contraction on the matrix cores; CHANNELS-FIRST operands (the sum runs over
  * pixels, which must be the contiguous axis): gy (B,C,E), x0 (B,N,E), xk (B,H,E) bf16;
- * dW (C, N*H) fp32 is ACCUMULATED into (zero it first).  C in {64,128,256}, E in {32,64,128}.       */
+ * dW (C, N*H) fp32 is ACCUMULATED into (zero it first).  C in {64,128,256}, E in {32,64,128}.
+ * tri != 0 (needs xk == x0, N == H): the first layer, where dW[c,n,h] is symmetric in (n,h) -- only the
+ * 16-h blocks at or below the diagonal are computed and the rest is mirrored; the result is the same full
+ * (C, N*H) gradient of the UNFOLDED weights.                                                          */
 size_t trs_cin_dw_workspace_bytes(int64_t B, int32_t N, int32_t H, int32_t C);
 int trs_cin_dw(const void* gy, const void* x0, const void* xk, int64_t B, int32_t N, int32_t H, int32_t C,
-               int32_t E, int32_t dtype, float* dW, void* workspace, size_t ws_bytes, trs_stream_t stream);
+               int32_t E, int32_t dtype, int32_t tri, float* dW, void* workspace, size_t ws_bytes,
+               trs_stream_t stream);
 
 /* ---- MLP backward epilogue (the GEMMs stay on hipBLASLt) -----------------------------------------------
  * y = relu(linear(x)):  gz = gy * (y > 0) and gb[c] = sum_r gz[r,c] (fp32) in ONE pass over (rows, C) instead of

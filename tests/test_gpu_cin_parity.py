@@ -77,7 +77,10 @@ def _device_f64(x0, xk, W, bias, gy, same, chunk=128):
 
 @pytest.mark.parametrize("B,N,H,C,E", [(4096, 39, 39, 256, 64), (4096, 39, 128, 256, 64), (1001, 10, 10, 64, 32),
                                        (1001, 10, 32, 128, 32), (515, 6, 6, 64, 16), (515, 6, 64, 32, 16),
-                                       (130, 40, 64, 32, 128), (262, 26, 256, 64, 32), (96, 64, 64, 64, 64)],
+                                       (130, 40, 64, 32, 128), (262, 26, 256, 64, 32), (96, 64, 64, 64, 64),
+                                       # first-layer form (xk is x0, N > 32: folded weights, diagonal-and-below blocks)
+                                       (300, 48, 48, 128, 64), (200, 33, 33, 256, 32), (64, 100, 100, 128, 64),
+                                       (50, 36, 36, 128, 32)],
                          ids=lambda v: str(v))
 def test_cin_contraction_kernels_alone(dev, B, N, H, C, E):
     """BASELINE shapes plus the narrow ones (one or two 16-pixel tiles per wave, partial last step, short samples)."""

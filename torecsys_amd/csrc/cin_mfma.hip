@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void cin_prepack_fwd_kernel(const bf16_t* __re
 // leaning on the other wave of its SIMD.  The fragment stream is continuous over the items a workgroup walks (the
 // step after an item's last is the next item's first), fetched one step ahead with unconditional, clamped loads.
 // Fields past N in the last step have zero fragments and zero x0 rows.
-template <int KS, int P, int NS>
+template <int KS, int P, int NS, bool TRI>
 __global__ __launch_bounds__(256, 2) void cin_cl_fwd_kernel(const bf16_t* __restrict__ x0T, int ld0,
                                                             const bf16_t* __restrict__ xkT, int ldk,
                                                             const uint4* __restrict__ Wp, const float* __restrict__ bias,
@@ -178,14 +178,18 @@ __global__ __launch_bounds__(256, 2) void cin_cl_fwd_kernel(const bf16_t* __rest
       for (int g = 0; g < G; ++g) {
         if (g + 1 < G) loadA(g + 1);
         loadX(g);
+        // lower-triangular weights (tri): field n has no weight on h > n, so its k-steps past n / 32 are all zero
+        const int ks_end = TRI ? (n0 + (g >> 1)) / 32 + 1 : KS;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
+          if (!TRI || ks == 0 || ks < ks_end) {
 #pragma unroll
-          for (int t = 0; t < P; ++t)
-            T[g & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                __builtin_bit_cast(bf16x8, Af[g & 1][ks]), __builtin_bit_cast(bf16x8, Bf[t][ks]),
-                ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : T[g & 1][t], 0, 0, 0);
+            for (int t = 0; t < P; ++t)
+              T[g & 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                  __builtin_bit_cast(bf16x8, Af[g & 1][ks]), __builtin_bit_cast(bf16x8, Bf[t][ks]),
+                  ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : T[g & 1][t], 0, 0, 0);
+          }
           if (g > 0) {
 #pragma unroll
             for (int t = 0; t < P; ++t)
@@ -235,7 +239,7 @@ static bool cin_cl_covers(int N, int H, int C, int E) {
 
 // x0T: (B,E,ld0) with ld0 % 8 == 0 and zeros past N; xkT: rows (B*E) of stride ldk >= 32*ceil(H/32), zeros past H.
 int cin_cl_fwd(const void* x0T, int ld0, const void* xkT, int ldk, const void* Wc, const void* bias, int64_t B, int N,
-               int H, int C, int E, void* yT, void* workspace, size_t ws_bytes, hipStream_t s) {
+               int H, int C, int E, int tri, void* yT, void* workspace, size_t ws_bytes, hipStream_t s) {
   if (!cin_cl_covers(N, H, C, E)) return 1;
   const int KS = (H + 31) / 32;
   if (ld0 % 8 != 0 || ld0 < ((N + 7) / 8) * 8 || ldk % 8 != 0 || ldk < 32 * KS || !aligned16(x0T) || !aligned16(xkT) ||
@@ -250,6 +254,7 @@ int cin_cl_fwd(const void* x0T, int ld0, const void* xkT, int ldk, const void* W
     return (size_t)2 * NS_ * 2 * KS * 64 * 16 + (size_t)C * 4 + (size_t)4 * np * 16 * P * 2;
   };
   int NS = 2;
+  while (P > 1 && lds_for(2) > 78 * 1024) P >>= 1;     // many fields: the per-wave x0 array (N x 16 P x 2 bytes) must fit
   if (KS <= 4 && (N + 2) / 3 * 3 <= (N + 1) / 2 * 2 && lds_for(3) <= 78 * 1024) NS = 3;
   const size_t lds = lds_for(NS);
   if (lds > 78 * 1024) return 1;                       // two workgroups per CU
@@ -262,9 +267,14 @@ int cin_cl_fwd(const void* x0T, int ld0, const void* xkT, int ldk, const void* W
   if (bias) hipLaunchKernelGGL(cin_bias_to_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const bf16_t*)bias, bf, C);
   const int64_t nitems = B * (E / (16 * P));
   const int grid = (int)std::min<int64_t>((nitems + 3) / 4, 256 * 2);
-#define TRS_CINF(KS_, P_, NS_)                                                                                      \
+#define TRS_CINF(KS_, P_, NS_) \
+  do {                         \
+    if (tri && KS_ > 1) TRS_CINF_T(KS_, P_, NS_, (KS_ > 1)); \
+    else TRS_CINF_T(KS_, P_, NS_, false);                    \
+  } while (0)
+#define TRS_CINF_T(KS_, P_, NS_, TRI_)                                                                              \
   do {                                                                                                              \
-    auto kern = cin_cl_fwd_kernel<KS_, P_, NS_>;                                                                    \
+    auto kern = cin_cl_fwd_kernel<KS_, P_, NS_, TRI_>;                                                              \
     static size_t attr_lds = 0;                                                                                     \
     if (lds > 64 * 1024 && lds > attr_lds) {                                                                        \
       if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
@@ -297,6 +307,7 @@ int cin_cl_fwd(const void* x0T, int ld0, const void* xkT, int ldk, const void* W
 #undef TRS_CINF_P
 #undef TRS_CINF_NS
 #undef TRS_CINF
+#undef TRS_CINF_T
   return check_launch("cin_cl_fwd");
 }
 
@@ -364,7 +375,7 @@ template <int KC, int P, int NS, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void cin_cl_bwd_data_kernel(
     const bf16_t* __restrict__ x0T, int ld0, const bf16_t* __restrict__ xkT, int ldk, const bf16_t* __restrict__ gyT,
     const uint4* __restrict__ WpT, bf16_t* __restrict__ dx0T, bf16_t* __restrict__ dxkT, int ldo, int64_t B, int N, int H,
-    int C, int E, int npass) {
+    int C, int E, int npass, int tri) {
   constexpr int NT = 64 * WAVES;
   constexpr int PIX = 16 * P;
   constexpr int G = 2 * NS;
@@ -379,7 +390,6 @@ __global__ __launch_bounds__(64 * WAVES) void cin_cl_bwd_data_kernel(
   const int KSH = (H + 31) / 32;
   const int npairs = (N + NS - 1) / NS;
   const int NP = npairs * NS;
-  const int nsteps = KSH * npass * npairs;
   float* dx0s = reinterpret_cast<float*>(smem + 2 * FR * 16) + (size_t)wave * NP * PIX;                // [NP][PIX] fp32
   unsigned short* x0w = reinterpret_cast<unsigned short*>(smem + 2 * FR * 16 + (size_t)WAVES * NP * PIX * 4) +
                         (size_t)wave * NP * PIX;                                                       // [NP][16][P]
@@ -422,7 +432,9 @@ __global__ __launch_bounds__(64 * WAVES) void cin_cl_bwd_data_kernel(
       }
     }
     uint4 Bg[P][KC];
-    int step = 0;
+    // lower-triangular weights (tri): the 32-h tile jh only gets contributions from the fields n >= 32 jh, so the steps
+    // below the one that holds field 32 jh are left out of the walk (and of the fragment stream)
+    auto first_n0 = [&](int jh_) { return tri ? (32 * jh_ / NS) * NS : 0; };
     for (int jh = 0; jh < KSH; ++jh) {
       f32x4 acc[P][2];
       float xkd[P][2][4];
@@ -454,10 +466,17 @@ __global__ __launch_bounds__(64 * WAVES) void cin_cl_bwd_data_kernel(
 #pragma unroll
           for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(xkd[t][0][i]), "v"(xkd[t][1][i]));
         }
-        for (int n0 = 0; n0 < NP; n0 += NS) {      // one basic block per step
+        for (int n0 = first_n0(jh); n0 < NP; n0 += NS) {      // one basic block per step
           const uint4* A = Abuf + par * FR;
           u32x4 nxt[NPF];
-          step = step + 1 < nsteps ? step + 1 : 0;
+          int step;                                  // the step after this one (the next item's first after the last)
+          if (n0 + NS < NP) {
+            step = (jh * npass + pass) * npairs + (n0 + NS) / NS;
+          } else {
+            const int jn = pass + 1 < npass ? jh : (jh + 1 < KSH ? jh + 1 : 0);
+            const int pn = pass + 1 < npass ? pass + 1 : 0;
+            step = (jn * npass + pn) * npairs + first_n0(jn) / NS;
+          }
           TRS_CIN_FETCH(nxt, step)
           __builtin_amdgcn_sched_barrier(0);
           uint4 Af[2][KC];
@@ -529,7 +548,17 @@ __global__ __launch_bounds__(64 * WAVES) void cin_cl_bwd_data_kernel(
           __syncthreads();
         }
       }
-      if (live) {
+      if (tri) {
+        // xk IS x0: dxk[h] and dx0[h] are gradients of the same values -- summed here in fp32 (the wave's own array)
+        // and rounded once, instead of two bf16 tensors that the caller adds
+#pragma unroll
+        for (int t = 0; t < P; ++t)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int h = 32 * jh + 8 * q + k;
+            if (h < N) dx0s[h * PIX + 16 * t + r] += acc[t][k >> 2][k & 3];
+          }
+      } else if (live) {
 #pragma unroll
         for (int t = 0; t < P; ++t) {
           float f[8];
@@ -564,7 +593,7 @@ size_t cin_mfma_bwd_data_workspace_bytes(int N, int H, int C) {
 }
 
 int cin_cl_bwd_data(const void* x0T, int ld0, const void* xkT, int ldk, const void* gyT, const void* Wc, int64_t B, int N,
-                    int H, int C, int E, void* dx0T, void* dxkT, int ldo, void* workspace, size_t ws_bytes,
+                    int H, int C, int E, int tri, void* dx0T, void* dxkT, int ldo, void* workspace, size_t ws_bytes,
                     hipStream_t s) {
   const int KSH = (H + 31) / 32, KCT = C / 32;
   if (C % 32 != 0 || E % 16 != 0 || !(KCT == 1 || KCT == 2 || KCT == 4 || KCT == 8) || ld0 % 8 != 0 || ldk % 8 != 0 ||
@@ -606,7 +635,7 @@ int cin_cl_bwd_data(const void* x0T, int ld0, const void* xkT, int ldk, const vo
     }                                                                                                               \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * W_), lds, s, (const bf16_t*)x0T, ld0, (const bf16_t*)xkT, ldk,   \
                        (const bf16_t*)gyT, (const uint4*)WpT, (bf16_t*)dx0T, (bf16_t*)dxkT, ldo, B, N, H, C, E,     \
-                       npass);                                                                                      \
+                       npass, tri);                                                                                 \
   } while (0)
 #define TRS_CINB_NS(KC_, P_)              \
   do {                                    \
@@ -799,18 +828,213 @@ __global__ __launch_bounds__(256) void cin_reduce_partials_kernel(const float* _
   }
 }
 
+// First layer (xk IS x0, weights folded onto h <= n): G[c,n,h] = sum_pix gy[c,pix] * x0[n,pix] * x0[h,pix] is
+// symmetric in (n,h), so only the 16-h blocks hb <= n/16 of every field are computed and the reduce kernel mirrors
+// them.  The roles of the operands are swapped relative to cin_dw_kernel: the A operand is gy itself (no VALU work,
+// read from LDS once per k-step for all the fields of the wave) and the B operand is the product row
+// Z[(n,h),pix] = x0[n,pix] * x0[h,pix] (8 multiplies + 4 packs per fragment, one fragment per field), so a fragment's
+// VALU cost is spread over the CT = 8 channel tiles it is multiplied with: (8 + 20 PT) / (PT CT) = 2.8 VALU
+// instructions per MFMA where the general kernel needs 6 at three h tiles.
+// Wave = task (h block hb, PT = 3 consecutive fields >= 16 hb) x 128 channels; workgroup = 8 tasks of one channel
+// block, sharing the staged gy tile and x0 rows of a sample.
+template <int KE, int NV>
+__global__ __launch_bounds__(512) void cin_dw_tri_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x0,
+                                                         float* __restrict__ dWpart, int64_t B, int N, int C, int nsplit,
+                                                         int wg_per_cb) {
+  constexpr int PT = 3, CT = 8, CB = 16 * CT;
+  constexpr int E = 32 * KE;
+  constexpr int RS = E * 2 + 16;
+  constexpr int VPR = E / 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, r = lane & 15;
+  const int NB = (N + 15) / 16;
+  const int XR = 16 * NB + 1;                         // x0 rows staged: N real ones, zero rows up to 16 NB, one more zero row
+  const int ROWS = CB + XR;
+  const int BUF = ROWS * RS;
+  const int TOTV = ROWS * VPR;
+  int bid = blockIdx.x;
+  const int part = bid % wg_per_cb; bid /= wg_per_cb;
+  const int cbc = C / CB;
+  const int cb = bid % cbc; bid /= cbc;
+  const int split = bid;
+  int task = part * 8 + wave, hb = 0, n_first = -1;
+  for (; hb < NB; ++hb) {
+    const int cnt = (N - 16 * hb + PT - 1) / PT;
+    if (task < cnt) { n_first = 16 * hb + PT * task; break; }
+    task -= cnt;
+  }
+  const bool active = n_first >= 0;
+  if (!active) { hb = 0; n_first = 0; }
+  const int64_t per = (B + nsplit - 1) / nsplit;
+  const int64_t b_lo = split * per, b_hi = b_lo + per < B ? b_lo + per : B;
+  f32x4 acc[PT][CT];
+#pragma unroll
+  for (int i = 0; i < PT; ++i)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[i][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bf16_t* src[NV];
+  int sstride[NV];
+  int doff[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int v = threadIdx.x + 512 * k;
+    src[k] = nullptr; sstride[k] = 0; doff[k] = 0;
+    if (v < TOTV) {
+      const int row = v / VPR, col = v - row * VPR;
+      doff[k] = row * RS + col * 16;
+      if (row < CB) {
+        sstride[k] = C * E;
+        src[k] = gy + b_lo * sstride[k] + (int64_t)(CB * cb + row) * E + col * 8;
+      } else if (row - CB < N) {
+        sstride[k] = N * E;
+        src[k] = x0 + b_lo * sstride[k] + (int64_t)(row - CB) * E + col * 8;
+      }
+    }
+  }
+  uint4 stage[NV];
+  auto fetch = [&](int64_t b) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      stage[k] = make_uint4(0, 0, 0, 0);
+      if (src[k] != nullptr && b < b_hi) {
+        stage[k] = *reinterpret_cast<const uint4*>(src[k]);
+        src[k] += sstride[k];
+      }
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+      if (threadIdx.x + 512 * k < TOTV) *reinterpret_cast<uint4*>(smem + (size_t)buf * BUF + doff[k]) = stage[k];
+  };
+  if (b_lo < b_hi) {
+    fetch(b_lo);
+    commit(0);
+  }
+  __syncthreads();
+  int nrow[PT];
+#pragma unroll
+  for (int i = 0; i < PT; ++i) nrow[i] = n_first + i < N ? n_first + i : XR - 1;     // past N: the zero row
+  int cur = 0;
+  for (int64_t b = b_lo; b < b_hi; ++b) {
+    fetch(b + 1);
+    const char* gy_s = smem + (size_t)cur * BUF;
+    const char* x0_s = gy_s + CB * RS;
+    if (active) {
+#pragma unroll
+      for (int ke = 0; ke < KE; ++ke) {
+        const int eoff = (32 * ke + 8 * q) * 2;
+        float hf[8];
+        Vec16<bf16_t>::unpack(*reinterpret_cast<const uint4*>(x0_s + (16 * hb + r) * RS + eoff), hf);
+        uint4 Bz[PT];
+#pragma unroll
+        for (int i = 0; i < PT; ++i) {
+          float nf[8];
+          Vec16<bf16_t>::unpack(*reinterpret_cast<const uint4*>(x0_s + nrow[i] * RS + eoff), nf);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) nf[k] *= hf[k];
+          Bz[i] = Vec16<bf16_t>::pack(nf);
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const uint4 a = *reinterpret_cast<const uint4*>(gy_s + (16 * ct + r) * RS + eoff);
+#pragma unroll
+          for (int i = 0; i < PT; ++i)
+            acc[i][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                                 __builtin_bit_cast(bf16x8, Bz[i]), acc[i][ct], 0, 0, 0);
+        }
+      }
+    }
+    commit(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (!active) return;
+  float* out = dWpart + (size_t)split * C * N * N;
+  const int h = 16 * hb + r;
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    const int n = n_first + i;
+    if (n >= N || h >= N) continue;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = CB * cb + 16 * ct + 4 * q + j;
+        out[(size_t)c * N * N + (size_t)n * N + h] = acc[i][ct][j];
+      }
+  }
+}
+
+// out[c,n,h] += sum_p part[p][c][max(n,h)][min(n,h)]: every such entry lies in a computed block (min/16 <= max/16)
+__global__ __launch_bounds__(256) void cin_reduce_partials_tri_kernel(const float* __restrict__ part, int nparts, int C,
+                                                                      int N, float* __restrict__ out) {
+  const int64_t n_all = (int64_t)C * N * N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_all; i += (int64_t)gridDim.x * blockDim.x) {
+    const int h = (int)(i % N), n = (int)((i / N) % N);
+    const int64_t c = i / ((int64_t)N * N);
+    const int64_t j = (c * N + (n > h ? n : h)) * N + (n > h ? h : n);
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * n_all + j];
+    out[i] += s;
+  }
+}
+
 size_t cin_dw_workspace_bytes(int64_t B, int N, int H, int C) {
-  return (size_t)32 * C * N * H * 4 + 256;
+  return (size_t)64 * C * N * H * 4 + 256;     // up to 32 sample splits (64: the first-layer kernel)
+}
+
+static int cin_dw_tri(const void* gy, const void* x0, int64_t B, int N, int C, int E, float* dW, float* part, int NV,
+                      hipStream_t s) {
+  const int KE = E / 32;
+  const int NB = (N + 15) / 16;
+  int ntasks = 0;
+  for (int hb = 0; hb < NB; ++hb) ntasks += (N - 16 * hb + 2) / 3;
+  const int wg_per_cb = (ntasks + 7) / 8, cbc = C / 128;
+  int nsplit = (int)std::max<int64_t>(1, 256 / (wg_per_cb * cbc));              // one workgroup per CU
+  nsplit = (int)std::min<int64_t>(std::min(nsplit, 64), std::max<int64_t>(1, B / 8));
+  const size_t lds = (size_t)2 * (128 + 16 * NB + 1) * (E * 2 + 16);
+#define TRS_DWT(KE_, NV_)                                                                                        \
+  do {                                                                                                           \
+    auto kern = cin_dw_tri_kernel<KE_, NV_>;                                                                     \
+    static size_t attr_lds = 0;                                                                                  \
+    if (lds > 64 * 1024 && lds > attr_lds) {                                                                     \
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+        return check_launch("cin_dw: LDS attribute");                                                            \
+      attr_lds = lds;                                                                                            \
+    }                                                                                                            \
+    hipLaunchKernelGGL(kern, dim3(wg_per_cb * cbc * nsplit), dim3(512), lds, s, (const bf16_t*)gy,               \
+                       (const bf16_t*)x0, part, B, N, C, nsplit, wg_per_cb);                                     \
+  } while (0)
+#define TRS_DWT_NV(KE_)               \
+  do {                                \
+    if (NV == 2) TRS_DWT(KE_, 2);     \
+    else if (NV == 3) TRS_DWT(KE_, 3); \
+    else TRS_DWT(KE_, 4);             \
+  } while (0)
+  if (KE == 1) TRS_DWT_NV(1);
+  else TRS_DWT_NV(2);
+#undef TRS_DWT_NV
+#undef TRS_DWT
+  const int64_t n = (int64_t)C * N * N;
+  hipLaunchKernelGGL(cin_reduce_partials_tri_kernel, dim3((int)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, s,
+                     part, nsplit, C, N, dW);
+  return check_launch("cin_dw (first layer)");
 }
 
 // gy (B,C,E), x0 (B,N,E), xk (B,H,E) contiguous bf16; dW (C, N*H) fp32 accumulated into.
-int cin_dw(const void* gy, const void* x0, const void* xk, int64_t B, int N, int H, int C, int E, float* dW,
+// tri: xk is x0 (same pointer, H == N): the symmetric first-layer form, cin_dw_tri_kernel where it covers the shape
+int cin_dw(const void* gy, const void* x0, const void* xk, int64_t B, int N, int H, int C, int E, int tri, float* dW,
            void* workspace, size_t ws_bytes, hipStream_t s) {
   if (!(C == 64 || C == 128 || C == 256) || !(E == 32 || E == 64 || E == 128) || workspace == nullptr ||
       !aligned16(gy) || !aligned16(x0) || !aligned16(xk))
     return 1;
   if (ws_bytes < cin_dw_workspace_bytes(B, N, H, C)) return fail(TRS_EWORKSPACE, "cin_dw: workspace too small");
   const int KE = E / 32;
+  if (tri && xk == x0 && H == N && C % 128 == 0 && KE <= 2) {
+    const int nv = ((128 + 16 * ((N + 15) / 16) + 1) * (E / 8) + 511) / 512;
+    if (nv <= 4) return cin_dw_tri(gy, x0, B, N, C, E, dW, (float*)workspace, std::max(nv, 2), s);
+  }
   const int tiles = (H + 15) / 16;
   // wide H (5..8 tiles per 128-h block): two fields x 32 channels x 8 h-tiles per wave; narrow H: four fields per wave,
   // all waves share the h range and split 128 channels; otherwise two wave groups split h
@@ -848,11 +1072,12 @@ int cin_dw(const void* gy, const void* x0, const void* xk, int64_t B, int N, int
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, (const bf16_t*)gy, (const bf16_t*)x0, (const bf16_t*)xk, \
                        part, B, N, H, C, nsplit);                                                                \
   } while (0)
-#define TRS_DW_KE(WH_, HW_)                    \
-  do {                                         \
-    if (KE == 1) TRS_DW(4, WH_, HW_, 1);       \
-    else if (KE == 2) TRS_DW(4, WH_, HW_, 2);  \
-    else TRS_DW(4, WH_, HW_, 4);               \
+#define TRS_DW_KE(WH_, HW_)                                                              \
+  do {                                                                                   \
+    if (KE == 1) TRS_DW(4, WH_, HW_, 1);                                                 \
+    else if (KE == 2) TRS_DW(4, WH_, HW_, 2);                                            \
+    else if constexpr (HW_ <= 2) TRS_DW(4, WH_, HW_, 4);      /* E = 128: hw_cap = 2 */  \
+    else return fail(TRS_ESHAPE, "cin_dw: E = 128 runs at most 2 h tiles per wave");     \
   } while (0)
 #define TRS_DW_HW(WH_)                         \
   do {                                         \
@@ -892,12 +1117,15 @@ extern "C" size_t trs_cin_cl_workspace_bytes(int32_t N, int32_t H, int32_t C) {
 
 extern "C" int trs_cin_cl_fwd(const void* x0T, int32_t ld0, const void* xkT, int32_t ldk, const void* Wc,
                               const void* bias, int64_t B, int32_t N, int32_t H, int32_t C, int32_t E, int32_t dtype,
-                              void* yT, void* workspace, size_t ws_bytes, trs_stream_t stream) {
+                              int32_t tri, void* yT, void* workspace, size_t ws_bytes, trs_stream_t stream) {
   if (B == 0) return TRS_OK;
   TRS_REQUIRE(x0T && xkT && Wc && yT, TRS_EINVAL, "cin_cl_fwd: NULL pointer");
   TRS_REQUIRE(B > 0 && N > 0 && H > 0 && C > 0 && E > 0, TRS_EINVAL, "cin_cl_fwd: bad size");
   TRS_REQUIRE(dtype == TRS_BF16, TRS_EDTYPE, "cin_cl_fwd: bf16 only (dtype %d)", dtype);
-  const int rc = cin_cl_fwd(x0T, ld0, xkT, ldk, Wc, bias, B, N, H, C, E, yT, workspace, ws_bytes, (hipStream_t)stream);
+  TRS_REQUIRE(!tri || (N == H && x0T == xkT && ld0 == ldk), TRS_EINVAL, "cin_cl_fwd: tri needs xkT to be x0T (N %d, H %d)",
+              N, H);
+  const int rc = cin_cl_fwd(x0T, ld0, xkT, ldk, Wc, bias, B, N, H, C, E, tri != 0, yT, workspace, ws_bytes,
+                            (hipStream_t)stream);
   if (rc == 1) return fail(TRS_ESHAPE, "cin_cl_fwd: shape not covered (need C%%32==0, E%%16==0, H<=256, padded rows)");
   return rc;
 }
@@ -909,14 +1137,16 @@ extern "C" size_t trs_cin_cl_bwd_data_workspace_bytes(int32_t N, int32_t H, int3
 
 extern "C" int trs_cin_cl_bwd_data(const void* x0T, int32_t ld0, const void* xkT, int32_t ldk, const void* gyT,
                                    const void* Wc, int64_t B, int32_t N, int32_t H, int32_t C, int32_t E,
-                                   int32_t dtype, void* dx0T, void* dxkT, int32_t ldo, void* workspace,
+                                   int32_t dtype, int32_t tri, void* dx0T, void* dxkT, int32_t ldo, void* workspace,
                                    size_t ws_bytes, trs_stream_t stream) {
   if (B == 0) return TRS_OK;
-  TRS_REQUIRE(x0T && xkT && gyT && Wc && dx0T && dxkT, TRS_EINVAL, "cin_cl_bwd_data: NULL pointer");
+  TRS_REQUIRE(x0T && xkT && gyT && Wc && dx0T && (dxkT || tri), TRS_EINVAL, "cin_cl_bwd_data: NULL pointer");
   TRS_REQUIRE(B > 0 && N > 0 && H > 0 && C > 0 && E > 0, TRS_EINVAL, "cin_cl_bwd_data: bad size");
   TRS_REQUIRE(dtype == TRS_BF16, TRS_EDTYPE, "cin_cl_bwd_data: bf16 only (dtype %d)", dtype);
-  const int rc = cin_cl_bwd_data(x0T, ld0, xkT, ldk, gyT, Wc, B, N, H, C, E, dx0T, dxkT, ldo, workspace, ws_bytes,
-                                 (hipStream_t)stream);
+  TRS_REQUIRE(!tri || (N == H && x0T == xkT && ld0 == ldk), TRS_EINVAL,
+              "cin_cl_bwd_data: tri needs xkT to be x0T (N %d, H %d)", N, H);
+  const int rc = cin_cl_bwd_data(x0T, ld0, xkT, ldk, gyT, Wc, B, N, H, C, E, tri != 0, dx0T, dxkT, ldo, workspace,
+                                 ws_bytes, (hipStream_t)stream);
   if (rc == 1) return fail(TRS_ESHAPE, "cin_cl_bwd_data: shape not covered (C in {32,64,128,256}, E%%16==0)");
   return rc;
 }
@@ -927,12 +1157,14 @@ extern "C" size_t trs_cin_dw_workspace_bytes(int64_t B, int32_t N, int32_t H, in
 }
 
 extern "C" int trs_cin_dw(const void* gy, const void* x0, const void* xk, int64_t B, int32_t N, int32_t H, int32_t C,
-                          int32_t E, int32_t dtype, float* dW, void* workspace, size_t ws_bytes, trs_stream_t stream) {
+                          int32_t E, int32_t dtype, int32_t tri, float* dW, void* workspace, size_t ws_bytes,
+                          trs_stream_t stream) {
   if (B == 0) return TRS_OK;
   TRS_REQUIRE(gy && x0 && xk && dW, TRS_EINVAL, "cin_dw: NULL pointer");
   TRS_REQUIRE(B > 0 && N > 0 && H > 0 && C > 0 && E > 0, TRS_EINVAL, "cin_dw: bad size");
   TRS_REQUIRE(dtype == TRS_BF16, TRS_EDTYPE, "cin_dw: bf16 only (dtype %d)", dtype);
-  const int rc = cin_dw(gy, x0, xk, B, N, H, C, E, dW, workspace, ws_bytes, (hipStream_t)stream);
+  TRS_REQUIRE(!tri || (xk == x0 && N == H), TRS_EINVAL, "cin_dw: tri needs xk to be x0 (N %d, H %d)", N, H);
+  const int rc = cin_dw(gy, x0, xk, B, N, H, C, E, tri != 0, dW, workspace, ws_bytes, (hipStream_t)stream);
   if (rc == 1) return fail(TRS_ESHAPE, "cin_dw: shape not covered (C in {64,128,256}, E in {32,64,128})");
   return rc;
 }

@@ -1335,6 +1335,9 @@ def cin_cl_supported(x: torch.Tensor, out_channels: Sequence[int], hidden_sizes:
     return all(h in (32, 64, 128, 256) for h in hidden_sizes)
 
 
+CIN_FOLD_SYMMETRIC = os.environ.get("TRS_CIN_FOLD", "1") != "0"
+
+
 class _CINContractCL(Function):
     @staticmethod
     def forward(ctx, x0T, xkT, Wc, bias, N, H, x0_cf=None, xk_cf=None):
@@ -1344,13 +1347,22 @@ class _CINContractCL(Function):
         C = Wc.shape[0]
         if xkT.stride(2) != 1 or xkT.stride(0) != E * ldk or x0T.stride() != (E * ld0, ld0, 1):
             raise ValueError("cin_contract_cl: x0T must be contiguous and xkT a (B,E,>=H) view with unit inner stride")
-        w = Wc.to(torch.bfloat16).contiguous()
+        # First layer (xk IS x0): the products x0[n]*x0[h] are symmetric in (n,h), so W[n,h] + W[h,n] folded onto h <= n
+        # (one fp32 add, one bf16 rounding) gives the same sums from half the weights; the kernels skip the k-steps /
+        # h tiles that then hold only zeros.  Pays once a field needs more than one 32-wide k-step.
+        tri = int(xkT.data_ptr() == x0T.data_ptr() and ldk == ld0 and H == N and N > 32 and CIN_FOLD_SYMMETRIC)
+        if tri:
+            W3 = Wc.detach().float().view(C, N, N)
+            w = (torch.tril(W3) + torch.triu(W3, 1).transpose(1, 2)).to(torch.bfloat16).view(C, N * N)
+        else:
+            w = Wc.to(torch.bfloat16).contiguous()
         bb = None if bias is None else bias.to(torch.bfloat16).contiguous()
         yT = torch.empty(B, E, C, dtype=torch.bfloat16, device=x0T.device)
         ws_bytes = size_query("trs_cin_cl_workspace_bytes", N, H, C)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x0T.device)
-        call("trs_cin_cl_fwd", ptr(x0T), ld0, ptr(xkT), ldk, ptr(w), ptr(bb), B, N, H, C, E, _abi.TRS_BF16, ptr(yT),
+        call("trs_cin_cl_fwd", ptr(x0T), ld0, ptr(xkT), ldk, ptr(w), ptr(bb), B, N, H, C, E, _abi.TRS_BF16, tri, ptr(yT),
              ptr(ws), ws_bytes, stream_ptr())
+        ctx.tri = tri
         ctx.save_for_backward(x0T, xkT, w)
         ctx.x0_cf = x0_cf        # the caller's channels-first (B,N,E) input, if it has one (saves a transpose per layer)
         ctx.xk_cf = xk_cf        # likewise the hidden state (B,H,E), emitted by the glue pass of the previous layer
@@ -1389,12 +1401,16 @@ class _CINContractCL(Function):
             if mfma_data:
                 ldo = ((H + 31) // 32) * 32
                 dx0T = torch.empty_like(x0T)
-                dxk_pad = torch.empty(B, E, ldo, dtype=torch.bfloat16, device=dev)
+                # tri: xkT is x0T, the kernel returns the sum of the two gradients (= the gradient of the quadratic form
+                # under the folded weights = under the original ones) in dx0T and xkT's slot of this function stays None
+                dxk_pad = None if ctx.tri else torch.empty(B, E, ldo, dtype=torch.bfloat16, device=dev)
                 ws_bytes = size_query("trs_cin_cl_bwd_data_workspace_bytes", N, H, C)
                 ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
                 call("trs_cin_cl_bwd_data", ptr(x0T), ld0, ptr(xkT), ldk, ptr(gyT), ptr(w), B, N, H, C, E, _abi.TRS_BF16,
-                     ptr(dx0T), ptr(dxk_pad), ldo, ptr(ws), ws_bytes, stream_ptr())
-                if tuple(dxk_pad.shape) == tuple(xkT.shape):     # already zero past H (zero weight fragments)
+                     ctx.tri, ptr(dx0T), ptr(dxk_pad), ldo, ptr(ws), ws_bytes, stream_ptr())
+                if ctx.tri:
+                    dxkT = None
+                elif tuple(dxk_pad.shape) == tuple(xkT.shape):     # already zero past H (zero weight fragments)
                     dxkT = dxk_pad
                 else:
                     dxkT = torch.zeros(xkT.shape, dtype=xkT.dtype, device=dev)
@@ -1436,9 +1452,10 @@ class _CINContractCL(Function):
             dW = torch.zeros(C, N * H, dtype=torch.float32, device=dev)
             ws_bytes = size_query("trs_cin_dw_workspace_bytes", B, N, H, C)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-            call("trs_cin_dw", ptr(gy), ptr(x0), ptr(xk), B, N, H, C, E, _abi.TRS_BF16, ptr(dW), ptr(ws), ws_bytes,
-                 stream_ptr())
-        return (dx0T if need_x0 else None, dxkT if need_xk else None, (dW.to(wdt) if need_w else None), db, None, None,
+            call("trs_cin_dw", ptr(gy), ptr(x0), ptr(xk), B, N, H, C, E, _abi.TRS_BF16, int(ctx.tri and xk is x0), ptr(dW),
+                 ptr(ws), ws_bytes, stream_ptr())
+        return (dx0T if need_x0 else None, dxkT if (need_xk and dxkT is not None) else None,
+                (dW.to(wdt) if need_w else None), db, None, None,
                 None, None)
 
 
