@@ -12,6 +12,10 @@
 #include <algorithm>
 
 #include "trs_common.hpp"
+#include <map>
+#include <mutex>
+#include <utility>
+#include <vector>
 
 namespace trs {
 
@@ -462,6 +466,60 @@ __global__ __launch_bounds__(256) void afm_bwd_kernel(const T* __restrict__ g_ou
   for (int k = threadIdx.x; k < 2 * A + 1; k += 256) mine[A * E + k] = dw1[k];
 }
 
+// Tiles of the backward pass: 16 pairs that share no field (so a wave adds dprod * x into its per-field gradient rows
+// with plain read-modify-writes).  The round-robin rounds of trs_common.hpp give such sets, but a round of N = 39 fields
+// has 19 pairs = one full tile + one with 3 pairs: 78 tiles for 741 pairs.  A greedy pass over the pairs in round order
+// (take a pair when both of its fields are still free in the tile being filled) packs them into ceil(P / 16) = 47 tiles
+// for N = 39 (and reaches that bound for every N > 32 tried: 33, 40, 48, 64); for N <= 32 a tile cannot hold more
+// disjoint pairs than a round has and the rounds are used as they are.  The table is built once per N on the host and
+// travels in the kernel arguments (by value: nothing to upload or keep alive, and a captured launch carries its copy).
+constexpr int AFM_TILE_MAX = 112;                       // 3.5 KB of the 4 KB kernel-argument block
+struct AfmTiles {
+  uint16_t e[AFM_TILE_MAX * 16];                        // (i << 8) | j, 0xffff = empty slot
+};
+
+static const AfmTiles* afm_packed_tiles(int N, int* ntiles) {
+  struct Entry { AfmTiles t; int n; };
+  static std::mutex mu;
+  static std::map<int, Entry*> cache;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(N);
+  if (it == cache.end()) {
+    const int M = (N & 1) ? N : N - 1;                  // players of the circle method
+    std::vector<std::pair<int, int>> rem;
+    for (int r = 0; r < M; ++r) {
+      for (int d = 1; d <= M / 2; ++d) {
+        const int a = ((r - d) % M + M) % M, b = (r + d) % M;
+        rem.emplace_back(std::min(a, b), std::max(a, b));
+      }
+      if (!(N & 1)) rem.emplace_back(r, N - 1);
+    }
+    Entry* en = new Entry;
+    for (auto& v : en->t.e) v = 0xffff;
+    int nt = 0;
+    while (!rem.empty() && nt < AFM_TILE_MAX) {
+      uint64_t used = 0;
+      int cnt = 0;
+      std::vector<std::pair<int, int>> keep;
+      for (auto& pr : rem) {
+        const uint64_t m = (1ull << pr.first) | (1ull << pr.second);
+        if (cnt < 16 && !(used & m)) {
+          en->t.e[nt * 16 + cnt++] = (uint16_t)((pr.first << 8) | pr.second);
+          used |= m;
+        } else {
+          keep.push_back(pr);
+        }
+      }
+      rem.swap(keep);
+      ++nt;
+    }
+    en->n = rem.empty() ? nt : 0;                       // 0: does not fit the argument block -> rounds
+    it = cache.emplace(N, en).first;
+  }
+  *ntiles = it->second->n;
+  return &it->second->t;
+}
+
 // ---------------------------------------------------------------------------------------------
 // bf16 fast path, backward: three chained GEMMs per tile of 16 pairs, all on MFMA 16x16x32 bf16.
 //   (1) hidden^T[a][p]  = W1 . prod^T              rows of W1 fed in a permuted order so that a lane's outputs are
@@ -471,20 +529,24 @@ __global__ __launch_bounds__(256) void afm_bwd_kernel(const T* __restrict__ g_ou
 //                                                   LDS transpose (2-byte stores, 16-byte fragment loads), 32 pairs a step
 // Tiles are taken from the conflict-free round schedule (16 field-disjoint pairs), every wave owns whole rounds and
 // a private fp32 copy of the (N x E) input-gradient block, so dx_i += dprod * x_j needs no atomics at all.
-template <int AT /* A/16, even */, int KS /* E/32 */>
-__global__ __launch_bounds__(256) void afm_bwd_mfma_kernel(const bf16_t* __restrict__ g_out,
+template <int AT /* A/16, even */, int KS /* E/32 */, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void afm_bwd_mfma_kernel(const bf16_t* __restrict__ g_out,
                                                            const bf16_t* __restrict__ g_attn,
                                                            const bf16_t* __restrict__ x, const bf16_t* __restrict__ attn,
                                                            const bf16_t* __restrict__ W1, const bf16_t* __restrict__ b1,
                                                            const bf16_t* __restrict__ w2, int64_t B, int N,
                                                            bf16_t* __restrict__ gx, float* __restrict__ partial,
-                                                           const uint8_t* __restrict__ keep, float keep_scale) {
-  constexpr int E = 32 * KS, A = 16 * AT, ET = 2 * KS, AKS = AT / 2, RS = E * 2 + 16, TS = 80;
-  constexpr int GS = E + 8;      // row stride (floats) of the per-wave gradient blocks: rows of different fields must not
-                                 // start on the same LDS bank (E floats = a whole number of bank sweeps -> 16-way conflicts)
+                                                           const uint8_t* __restrict__ keep, float keep_scale,
+                                                           int T /* packed tiles, 0 = the rounds */, AfmTiles packed) {
+  constexpr int E = 32 * KS, A = 16 * AT, ET = 2 * KS, AKS = AT / 2, RS = E * 2 + 16, TS = 80, NTHR = 64 * WAVES;
+  constexpr int GS = E + 4;      // row stride (floats) of the per-wave gradient blocks.  The 16 lanes of a tile update 16
+                                 // different field rows with float4 accesses: with E + 4 floats a row starts at bank
+                                 // 4 (i mod 16), so only fields 16 apart collide (E: every row on the same banks; E + 8:
+                                 // 8 (i mod 8), half the slots -- 1253 vs 1091 us for the whole backward at B = 8192)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int P = N * (N - 1) / 2, PP = (P + 15) & ~15;
   const int R = afm_rounds(N), H = afm_width(N), TPR = (H + 15) / 16;
+  const int NT = T > 0 ? T : R * TPR;            // tiles of a sample
   char* sp = smem_raw;
   char* xs = sp; sp += (N * RS + 15) & ~15;
   float* lg = reinterpret_cast<float*>(sp); sp += PP * 4;
@@ -493,22 +555,27 @@ __global__ __launch_bounds__(256) void afm_bwd_mfma_kernel(const bf16_t* __restr
   int* lutp = reinterpret_cast<int*>(sp); sp += PP * 4;
   float* go = reinterpret_cast<float*>(sp); sp += E * 4;
   float* red = reinterpret_cast<float*>(sp); sp += 64;
-  int* sched = reinterpret_cast<int*>(sp); sp += R * TPR * 16 * 4;
-  float* gxs_all = reinterpret_cast<float*>(sp); sp += 4 * N * GS * 4;
-  char* dhT_all = sp; sp += 4 * A * TS;
+  int* sched = reinterpret_cast<int*>(sp); sp += NT * 16 * 4;
+  float* gxs_all = reinterpret_cast<float*>(sp); sp += WAVES * N * GS * 4;
+  char* dhT_all = sp; sp += WAVES * A * TS;
   char* prT_all = sp;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, n = lane & 15;
   float* gxs = gxs_all + wave * N * GS;
   char* dhT = dhT_all + wave * A * TS;
   char* prT = prT_all + wave * E * TS;
-  for (int p = threadIdx.x; p < PP; p += 256) {
+  for (int p = threadIdx.x; p < PP; p += NTHR) {
     int i = 0, j = 1;
     if (p < P) pair_ij(p, N, &i, &j);
     lutp[p] = (i << 16) | j;
   }
-  for (int t = threadIdx.x; t < R * TPR * 16; t += 256) {
-    const int r = t / (TPR * 16), k = t - r * (TPR * 16);
-    sched[t] = k < H ? sched_entry(r, k, N) : -1;
+  for (int t = threadIdx.x; t < NT * 16; t += NTHR) {
+    if (T > 0) {
+      const int e = packed.e[t];
+      sched[t] = e == 0xffff ? -1 : ((e >> 8) << 16) | (e & 0xff);
+    } else {
+      const int r = t / (TPR * 16), k = t - r * (TPR * 16);
+      sched[t] = k < H ? sched_entry(r, k, N) : -1;
+    }
   }
   // resident operands.  amap(t, m): row m of tile t <-> unit 32 (t>>1) + 8 (m>>2) + 4 (t&1) + (m&3)
   uint4 Wf[AT][KS], Vf[ET][AKS];
@@ -555,20 +622,20 @@ __global__ __launch_bounds__(256) void afm_bwd_mfma_kernel(const bf16_t* __restr
 
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
     __syncthreads();
-    for (int v = threadIdx.x; v < N * VPR; v += 256) {
+    for (int v = threadIdx.x; v < N * VPR; v += NTHR) {
       const int row = v / VPR, col = v - row * VPR;
       *reinterpret_cast<uint4*>(xs + row * RS + col * 16) =
           *reinterpret_cast<const uint4*>(x + (b * N + row) * (int64_t)E + col * 8);
     }
-    for (int k = threadIdx.x; k < E; k += 256) go[k] = g_out != nullptr ? to_f32(g_out[b * E + k]) : 0.f;
-    for (int p = threadIdx.x; p < P; p += 256) {
+    for (int k = threadIdx.x; k < E; k += NTHR) go[k] = g_out != nullptr ? to_f32(g_out[b * E + k]) : 0.f;
+    for (int p = threadIdx.x; p < P; p += NTHR) {
       lg[p] = to_f32(attn[b * P + p]);
       msk[p] = keep == nullptr ? 1.f : (keep[b * P + p] ? keep_scale : 0.f);
     }
     for (int k = lane; k < N * GS; k += 64) gxs[k] = 0.f;
     __syncthreads();
     // d(score)_p = g_attn_p + g_out . prod_p      (one pair per thread, 16-byte row reads)
-    for (int p = threadIdx.x; p < P; p += 256) {
+    for (int p = threadIdx.x; p < P; p += NTHR) {
       const int ij = lutp[p], i = ij >> 16, j = ij & 0xffff;
       float d = 0.f;
 #pragma unroll
@@ -583,14 +650,19 @@ __global__ __launch_bounds__(256) void afm_bwd_mfma_kernel(const bf16_t* __restr
     }
     __syncthreads();
     float s = 0.f;
-    for (int p = threadIdx.x; p < P; p += 256) s += lg[p] * aux[p];
-    s = block_sum(s, red);
-    for (int p = threadIdx.x; p < P; p += 256) aux[p] = lg[p] * (aux[p] - s);       // d(logit)
+    for (int p = threadIdx.x; p < P; p += NTHR) s += lg[p] * aux[p];
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    s = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) s += red[w];
+    for (int p = threadIdx.x; p < P; p += NTHR) aux[p] = lg[p] * (aux[p] - s);       // d(logit)
     __syncthreads();
     int tiles_done = 0;
-    for (int r = wave; r < R; r += 4) {
-      for (int t = 0; t < TPR; ++t) {
-        const int ent = sched[(r * TPR + t) * 16 + n];
+    {
+      for (int tile = wave; tile < NT; tile += WAVES) {
+        const int ent = sched[tile * 16 + n];
         const bool valid = ent >= 0;
         const int i = valid ? ent >> 16 : 0, j = valid ? ent & 0xffff : 1;
         const int p = i * (2 * N - i - 1) / 2 + j - i - 1;
@@ -616,13 +688,15 @@ __global__ __launch_bounds__(256) void afm_bwd_mfma_kernel(const bf16_t* __restr
 #pragma unroll
           for (int k = 0; k < 8; ++k) hi[k] = pr[k] - hi[k];
           const uint4 bl = Vec16<bf16_t>::pack(hi);
+          // (all tiles with the rounded product, then all with the residual: no MFMA waits for the one before it)
 #pragma unroll
-          for (int mt = 0; mt < AT; ++mt) {
+          for (int mt = 0; mt < AT; ++mt)
             acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(afm_bf16x8, Wf[mt][ks]),
                                                                __builtin_bit_cast(afm_bf16x8, bf), acc1[mt], 0, 0, 0);
+#pragma unroll
+          for (int mt = 0; mt < AT; ++mt)
             acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(afm_bf16x8, Wf[mt][ks]),
                                                                __builtin_bit_cast(afm_bf16x8, bl), acc1[mt], 0, 0, 0);
-          }
           // prod^T for GEMM (3): element (e = 32 ks + 8 q + k, pair column col)
           const uint32_t words[4] = {bf.x, bf.y, bf.z, bf.w};
 #pragma unroll
@@ -658,13 +732,13 @@ __global__ __launch_bounds__(256) void afm_bwd_mfma_kernel(const bf16_t* __restr
         // GEMM (2): dprod^T = W1^T . dh
         afm_f32x4 acc2[ET];
 #pragma unroll
-        for (int et = 0; et < ET; ++et) {
-          acc2[et] = afm_f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int et = 0; et < ET; ++et) acc2[et] = afm_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int u = 0; u < AKS; ++u)
+        for (int u = 0; u < AKS; ++u)
+#pragma unroll
+          for (int et = 0; et < ET; ++et)
             acc2[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(afm_bf16x8, Vf[et][u]),
                                                                __builtin_bit_cast(afm_bf16x8, Bdh[u]), acc2[et], 0, 0, 0);
-        }
         if (valid) {
 #pragma unroll
           for (int v = 0; v < KS; ++v) {
@@ -690,7 +764,7 @@ __global__ __launch_bounds__(256) void afm_bwd_mfma_kernel(const bf16_t* __restr
           }
         }
         ++tiles_done;
-        const bool last = (r + 4 >= R) && (t == TPR - 1);
+        const bool last = tile + WAVES >= NT;
         if ((tiles_done & 1) == 0 || last) {
           if (tiles_done & 1) {
             // odd tile count: the second half of the 32-pair step is empty
@@ -725,15 +799,18 @@ __global__ __launch_bounds__(256) void afm_bwd_mfma_kernel(const bf16_t* __restr
       }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < N * E; k += 256) {
+    for (int k = threadIdx.x; k < N * E; k += NTHR) {
       const int row = k / E, o = row * GS + (k - row * E);
-      gx[b * N * E + k] = from_f32<bf16_t>(gxs_all[o] + gxs_all[N * GS + o] + gxs_all[2 * N * GS + o] + gxs_all[3 * N * GS + o]);
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) t += gxs_all[w * N * GS + o];
+      gx[b * N * E + k] = from_f32<bf16_t>(t);
     }
   }
   // ---- parameter gradients of this workgroup -> partial[A*E + 2A + 1]
   __syncthreads();
   float* dw1 = gxs_all;                         // [A][E] + [2A+1], reuses the gradient blocks
-  for (int k = threadIdx.x; k < A * E + 2 * A + 1; k += 256) dw1[k] = 0.f;
+  for (int k = threadIdx.x; k < A * E + 2 * A + 1; k += NTHR) dw1[k] = 0.f;
   __syncthreads();
 #pragma unroll
   for (int mt = 0; mt < AT; ++mt)
@@ -758,15 +835,16 @@ __global__ __launch_bounds__(256) void afm_bwd_mfma_kernel(const bf16_t* __restr
   if (lane == 0) atomicAdd(&dw1[A * E + 2 * A], db2r);
   __syncthreads();
   float* mine = partial + (size_t)blockIdx.x * (A * E + 2 * A + 1);
-  for (int k = threadIdx.x; k < A * E + 2 * A + 1; k += 256) mine[k] = dw1[k];
+  for (int k = threadIdx.x; k < A * E + 2 * A + 1; k += NTHR) mine[k] = dw1[k];
 }
 
-static size_t afm_bwd_mfma_lds(int N, int E, int A) {
+static size_t afm_bwd_mfma_lds(int N, int E, int A, int T = 0, int waves = 4) {
   const int P = N * (N - 1) / 2, PP = (P + 15) & ~15;
   const int R = afm_rounds(N), H = afm_width(N), TPR = (H + 15) / 16;
-  const size_t grad = std::max<size_t>((size_t)4 * N * (E + 8) * 4, ((size_t)A * E + 2 * A + 1) * 4);
-  return (size_t)((N * (E * 2 + 16) + 15) & ~15) + (size_t)PP * 16 + (size_t)E * 4 + 64 + (size_t)R * TPR * 64 + grad +
-         (size_t)4 * (A + E) * 80 + 64;
+  const int NT = T > 0 ? T : R * TPR;
+  const size_t grad = std::max<size_t>((size_t)waves * N * (E + 4) * 4, ((size_t)A * E + 2 * A + 1) * 4);
+  return (size_t)((N * (E * 2 + 16) + 15) & ~15) + (size_t)PP * 16 + (size_t)E * 4 + 64 + (size_t)NT * 64 + grad +
+         (size_t)waves * (A + E) * 80 + 64;
 }
 
 __global__ __launch_bounds__(256) void afm_reduce_partials_kernel(const float* __restrict__ part, int nparts, int n,
@@ -890,17 +968,28 @@ extern "C" int trs_afm_bwd_dropout(const void* g_out, const void* g_attn, const 
   if (!no_mfma && dtype == TRS_BF16 && (E == 32 || E == 64 || E == 128) && A % 32 == 0 && A <= 128 &&
       (A / 16) * (E / 32) <= 12 &&
       afm_bwd_mfma_lds(N, E, A) <= 160 * 1024 && aligned16(x) && aligned16(W1)) {
-    const size_t mlds = afm_bwd_mfma_lds(N, E, A);
+    int T = 0;
+    static const bool rounds_only = getenv("TRS_AFM_ROUNDS") != nullptr;
+    const AfmTiles* packed = afm_packed_tiles(N, &T);
+    if (N <= 32 || rounds_only) T = 0;               // a round IS a maximal tile there
+    // (four waves = one per SIMD: A = 64, E = 64 already holds 388 registers per wave -- W1 / W1^T fragments, the dW1
+    // accumulators, both x rows of the tile -- so a second wave per SIMD would spill; measured with six: 536 B of scratch)
+    const int waves = 4;
+    const size_t mlds = afm_bwd_mfma_lds(N, E, A, T, waves);
     const int mgrid = (int)std::min<int64_t>(B, 256);
-#define TRS_AFM_BM(AT_, KS_)                                                                                          \
+#define TRS_AFM_BM(AT_, KS_)                        \
+  do {                                              \
+    TRS_AFM_BMW(AT_, KS_, 4);                       \
+  } while (0)
+#define TRS_AFM_BMW(AT_, KS_, W_)                                                                                     \
   do {                                                                                                                \
-    auto kern = afm_bwd_mfma_kernel<AT_, KS_>;                                                                        \
+    auto kern = afm_bwd_mfma_kernel<AT_, KS_, W_>;                                                                    \
     if (mlds > 64 * 1024 &&                                                                                           \
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds) != hipSuccess) \
       return check_launch("afm_bwd: LDS attribute");                                                                  \
-    hipLaunchKernelGGL(kern, dim3(mgrid), dim3(256), mlds, s, (const bf16_t*)g_out, (const bf16_t*)g_attn,            \
+    hipLaunchKernelGGL(kern, dim3(mgrid), dim3(64 * W_), mlds, s, (const bf16_t*)g_out, (const bf16_t*)g_attn,        \
                        (const bf16_t*)x, (const bf16_t*)attn, (const bf16_t*)W1, (const bf16_t*)b1, (const bf16_t*)w2, \
-                       B, N, (bf16_t*)gx, part, keep, keep_scale);                                                    \
+                       B, N, (bf16_t*)gx, part, keep, keep_scale, T, *packed);                                        \
   } while (0)
 #define TRS_AFM_BMK(AT_)                                 \
   do {                                                   \
@@ -916,6 +1005,7 @@ extern "C" int trs_afm_bwd_dropout(const void* g_out, const void* g_attn, const 
     }
 #undef TRS_AFM_BMK
 #undef TRS_AFM_BM
+#undef TRS_AFM_BMW
     const int n = A * E + 2 * A + 1;
     hipLaunchKernelGGL(afm_reduce_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, s, part, mgrid, n, A, E, gW1,
                        gb1, gw2, gb2);
