@@ -19,6 +19,22 @@ typedef __attribute__((ext_vector_type(4))) float pb_f32x4;
 
 constexpr int PB_PPT = 3;        // pairs per task
 
+// Waves of 256-thread workgroups of `kernel` that the device holds at once.  The sample splits of these kernels are
+// sized from it: a wave owns one (task, split) for the whole launch, so ntasks * nsplit just ABOVE this number (260 tasks
+// x 8 splits = 2080 on 2048 slots at two waves per SIMD) leaves a second, nearly empty round that doubles the time.
+static int64_t pbm_wave_slots(const void* kernel, size_t dyn_lds) {
+  int dev = 0, cus = 256, blocks = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 2048;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, 256, dyn_lds) != hipSuccess || blocks < 1) blocks = 2;
+  return (int64_t)cus * blocks * 4;
+}
+// sample splits: as many as fill the slots in ONE round, each with at least min_per units
+static int pbm_splits(int64_t units, int ntasks, int64_t min_per, int64_t slots) {
+  const int64_t by_slots = std::max<int64_t>(1, slots / ntasks);
+  return (int)std::max<int64_t>(1, std::min<int64_t>(std::max<int64_t>(1, units / min_per), by_slots));
+}
+
 template <int KS /* E/32 */, int MODE /* 0: sum over h, 1: per-h output + bias */>
 __global__ __launch_bounds__(256) void pair_bil_fwd_mfma_kernel(const bf16_t* __restrict__ x,
                                                                 const bf16_t* __restrict__ Wt /* (P,H,E) */,
@@ -59,53 +75,50 @@ __global__ __launch_bounds__(256) void pair_bil_fwd_mfma_kernel(const bf16_t* __
   const int64_t tiles = (B + 15) / 16;
   const int64_t per = (tiles + nsplit - 1) / nsplit;
   const int64_t t_lo = split * per, t_hi = std::min<int64_t>(t_lo + per, tiles);
-  // A wave walks its sample tiles one at a time: the x_i / x_j runs of the NEXT tile are requested (hand-issued loads,
-  // every lane issues every load, dead samples read sample 0) while this tile's MFMAs and epilogues run, and waited for
-  // at the end of the iteration -- otherwise every tile starts with a full HBM round trip for 24 MFMAs of work.
+  // A wave walks its sample tiles one at a time.  All the tasks of a sample split reach the same 16 samples at about the
+  // same time, so for its XCD's L2 nearly every tile is a first touch: the x_i / x_j runs arrive with Infinity-Cache
+  // latency (2-3 us per tile iteration measured, against ~0.35 us of MFMAs and epilogue).  Two register sets hold the runs
+  // of this tile and the next; a set is consumed IN PLACE and each of its registers is re-loaded for the tile after next
+  // right behind its last use (x_j of a pair after that pair's epilogue, x_i after the last pair's MFMAs), so a load has
+  // between one and two tile times to land and no copy of a register with a load in flight can exist.  Loads are issued
+  // by hand (hipcc sinks ordinary loads of read-only memory to their use and puts an s_waitcnt vmcnt(0) behind volatile
+  // ones); every lane issues every load -- dead samples and the tiles past the end read valid addresses -- so the counted
+  // wait at the top of a tile (all but the 8 youngest loads done = the other set may still be in flight) is exact.
   typedef __attribute__((ext_vector_type(4))) unsigned pb_u32x4;
-  pb_u32x4 nxi[KS], nxj[PB_PPT][KS];
-#define TRS_PB_FETCH(tt)                                                                                         \
-  {                                                                                                              \
-    const int64_t b_ = (tt) * 16 + n;                                                                            \
-    const bf16_t* xb_ = x + (b_ < B ? b_ : 0) * (int64_t)N * E;                                                  \
-    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                          \
-      const bf16_t* a_ = xb_ + fi * E + 32 * ks + 8 * q;                                                         \
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nxi[ks]) : "v"(a_));                                 \
-    }                                                                                                            \
-    _Pragma("unroll") for (int c = 0; c < PB_PPT; ++c)                                                           \
-      _Pragma("unroll") for (int u = 0; u < KS; ++u) {                                                           \
-        const bf16_t* a_ = xb_ + (j0 + (c < cnt ? c : 0)) * E + 32 * u + 8 * q;                                  \
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nxj[c][u]) : "v"(a_));                             \
-      }                                                                                                          \
-  }
-#define TRS_PB_COMMIT()                                                                                          \
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                               \
-  _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(nxi[ks]));                            \
-  _Pragma("unroll") for (int c = 0; c < PB_PPT; ++c)                                                             \
-    _Pragma("unroll") for (int u = 0; u < KS; ++u) asm volatile("" : "+v"(nxj[c][u]));
-  if (t_lo < t_hi) {
-    TRS_PB_FETCH(t_lo)
-    TRS_PB_COMMIT()
-  }
-  for (int64_t t = t_lo; t < t_hi; ++t) {
-    const int64_t b = t * 16 + n;
-    const bool live = b < B;
-    uint4 xi[KS];
+  constexpr int NLD = KS * (1 + PB_PPT);                 // loads per tile
+  pb_u32x4 nxi[2][KS] = {}, nxj[2][PB_PPT][KS] = {};
+  auto row_of = [&](int64_t tt) {
+    const int64_t tc = tt < t_hi ? tt : t_hi - 1;
+    const int64_t b_ = tc * 16 + n;
+    return x + (b_ < B ? b_ : 0) * (int64_t)N * E;
+  };
+  auto load_xi = [&](pb_u32x4 (&xi)[KS], const bf16_t* xb) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) xi[ks] = make_uint4(nxi[ks][0], nxi[ks][1], nxi[ks][2], nxi[ks][3]);
-    uint4 xj[PB_PPT][KS];
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16_t* a_ = xb + fi * E + 32 * ks + 8 * q;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(xi[ks]) : "v"(a_));
+    }
+  };
+  auto load_xj = [&](pb_u32x4 (&xj)[KS], int c, const bf16_t* xb) {
+#pragma unroll
+    for (int u = 0; u < KS; ++u) {
+      const bf16_t* a_ = xb + (j0 + (c < cnt ? c : 0)) * E + 32 * u + 8 * q;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(xj[u]) : "v"(a_));
+    }
+  };
+  auto tile = [&](int64_t t, pb_u32x4 (&xi)[KS], pb_u32x4 (&xj)[PB_PPT][KS]) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(xi[ks]));
 #pragma unroll
     for (int c = 0; c < PB_PPT; ++c)
 #pragma unroll
-      for (int u = 0; u < KS; ++u) xj[c][u] = make_uint4(nxj[c][u][0], nxj[c][u][1], nxj[c][u][2], nxj[c][u][3]);
-    {
-      const int64_t tn = t + 1 < t_hi ? t + 1 : t;
-      TRS_PB_FETCH(tn)
-    }
-    __builtin_amdgcn_sched_barrier(0);
+      for (int u = 0; u < KS; ++u) asm volatile("" : "+v"(xj[c][u]));
+    const int64_t b = t * 16 + n;
+    const bool live = b < B;
+    const bf16_t* xb2 = row_of(t + 2);
 #pragma unroll
     for (int c = 0; c < PB_PPT; ++c) {
-      if (c >= cnt) break;
       pb_f32x4 acc[MT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
@@ -115,11 +128,15 @@ __global__ __launch_bounds__(256) void pair_bil_fwd_mfma_kernel(const bf16_t* __
           acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pb_bf16x8, Wf[c][mt][ks]),
                                                             __builtin_bit_cast(pb_bf16x8, xi[ks]), acc[mt], 0, 0, 0);
       }
+      if (c == PB_PPT - 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        load_xi(xi, xb2);                                  // the tile's last MFMAs are issued: x_i is free
+      }
       float part = 0.f;
 #pragma unroll
       for (int u = 0; u < KS; ++u) {
         float xv[8];
-        Vec16<bf16_t>::unpack(xj[c][u], xv);
+        Vec16<bf16_t>::unpack(__builtin_bit_cast(uint4, xj[c][u]), xv);
         float r8[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -127,20 +144,44 @@ __global__ __launch_bounds__(256) void pair_bil_fwd_mfma_kernel(const bf16_t* __
           if (MODE == 0) part = fmaf(tv, xv[k], part);
           else r8[k] = fmaf(tv, xv[k], bv[c][u][k]);
         }
-        if (MODE == 1 && live)
+        if (MODE == 1 && live && c < cnt)
           *reinterpret_cast<uint4*>(out + ((b * P + p0 + c) * (int64_t)E) + 32 * u + 8 * q) = Vec16<bf16_t>::pack(r8);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      load_xj(xj[c], c, xb2);
       if (MODE == 0) {
         part += __shfl_xor(part, 16, 64);
         part += __shfl_xor(part, 32, 64);
-        if (q == 0 && live) out[b * P + p0 + c] = from_f32<bf16_t>(part);
+        if (q == 0 && live && c < cnt) out[b * P + p0 + c] = from_f32<bf16_t>(part);
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    TRS_PB_COMMIT()
+  };
+  if (t_lo < t_hi) {
+    load_xi(nxi[0], row_of(t_lo));
+#pragma unroll
+    for (int c = 0; c < PB_PPT; ++c) load_xj(nxj[0][c], c, row_of(t_lo));
+    load_xi(nxi[1], row_of(t_lo + 1));
+#pragma unroll
+    for (int c = 0; c < PB_PPT; ++c) load_xj(nxj[1][c], c, row_of(t_lo + 1));
+    int64_t t = t_lo;
+    for (; t + 1 < t_hi; t += 2) {
+      tile(t, nxi[0], nxj[0]);
+      tile(t + 1, nxi[1], nxj[1]);
+    }
+    if (t < t_hi) tile(t, nxi[0], nxj[0]);
+    // the clamped loads behind the last tiles are still landing: both sets stay allocated until they have (registers
+    // the compiler considers dead are handed to the next address computation, and a late load would overwrite it)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(nxi[s2][ks]));
+#pragma unroll
+      for (int c = 0; c < PB_PPT; ++c)
+#pragma unroll
+        for (int u = 0; u < KS; ++u) asm volatile("" ::"v"(nxj[s2][c][u]));
+    }
   }
-#undef TRS_PB_FETCH
-#undef TRS_PB_COMMIT
 }
 
 }  // namespace trs
@@ -160,14 +201,16 @@ extern "C" int trs_pair_bilinear_fwd_mfma(const void* x, const void* Wt, const v
   TRS_REQUIRE(aligned16(x) && aligned16(Wt) && aligned16(bias) && aligned16(out), TRS_EALIGN,
               "pair_bilinear_fwd_mfma: 16-byte alignment");
   const int64_t tiles = (B + 15) / 16;
-  // enough waves for ~2 per SIMD, each with at least a few tiles
-  int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(tiles / 4, (2048 + ntasks - 1) / ntasks));
-  const int64_t waves = (int64_t)ntasks * nsplit;
-  const int grid = (int)((waves + 3) / 4);
   hipStream_t s = (hipStream_t)stream;
 #define TRS_PBM(KS_, MODE_)                                                                                         \
-  hipLaunchKernelGGL((pair_bil_fwd_mfma_kernel<KS_, MODE_>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x,          \
-                     (const bf16_t*)Wt, (const bf16_t*)bias, tasks, ntasks, nsplit, B, N, (bf16_t*)out)
+  do {                                                                                                              \
+    auto kern = pair_bil_fwd_mfma_kernel<KS_, MODE_>;                                                               \
+    static const int64_t slots = pbm_wave_slots((const void*)kern, 0);                                              \
+    const int nsplit = pbm_splits(tiles, ntasks, 4, slots);                                                         \
+    const int grid = (int)(((int64_t)ntasks * nsplit + 3) / 4);                                                     \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)Wt, (const bf16_t*)bias,  \
+                       tasks, ntasks, nsplit, B, N, (bf16_t*)out);                                                  \
+  } while (0)
   if (E == 32) { if (mode == 0) TRS_PBM(1, 0); else TRS_PBM(1, 1); }
   else { if (mode == 0) TRS_PBM(2, 0); else TRS_PBM(2, 1); }
 #undef TRS_PBM
@@ -459,10 +502,6 @@ __global__ __launch_bounds__(256) void pair_w_reduce_kernel(const float* __restr
   }
 }
 
-static int pbm_splits(int64_t units, int ntasks, int64_t min_per) {
-  return (int)std::max<int64_t>(1, std::min<int64_t>(std::max<int64_t>(1, units / min_per), (2048 + ntasks - 1) / ntasks));
-}
-
 }  // namespace trs
 
 using namespace trs;
@@ -487,14 +526,17 @@ extern "C" int trs_pair_bilinear_bwd_data_mfma(const void* g, const void* x, con
               TRS_EALIGN, "pair_bilinear_bwd_data_mfma: 16-byte alignment");
   hipStream_t s = (hipStream_t)stream;
   const int64_t tiles = (B + 15) / 16;
-  const int nsi = pbm_splits(tiles, nti, 4), nsj = pbm_splits(tiles, ntj, 4);
-  const int gi = (int)(((int64_t)nti * nsi + 3) / 4), gj = (int)(((int64_t)ntj * nsj + 3) / 4);
 #define TRS_PBI(KS_, M_)                                                                                            \
   do {                                                                                                              \
-    hipLaunchKernelGGL((pair_bil_bwd_xi_mfma_kernel<KS_, M_>), dim3(gi), dim3(256), 0, s, (const bf16_t*)g,          \
-                       (const bf16_t*)x, (const bf16_t*)W, tasks_i, nti, nsi, B, N, (bf16_t*)contrib_i);             \
-    hipLaunchKernelGGL((pair_bil_bwd_xj_mfma_kernel<KS_, M_>), dim3(gj), dim3(256), 0, s, (const bf16_t*)g,          \
-                       (const bf16_t*)x, (const bf16_t*)Wt, tasks_j, ntj, nsj, B, N, (bf16_t*)contrib_j);            \
+    auto ki = pair_bil_bwd_xi_mfma_kernel<KS_, M_>;                                                                 \
+    auto kj = pair_bil_bwd_xj_mfma_kernel<KS_, M_>;                                                                 \
+    static const int64_t slots_i = pbm_wave_slots((const void*)ki, 0), slots_j = pbm_wave_slots((const void*)kj, 0); \
+    const int nsi = pbm_splits(tiles, nti, 4, slots_i), nsj = pbm_splits(tiles, ntj, 4, slots_j);                   \
+    const int gi = (int)(((int64_t)nti * nsi + 3) / 4), gj = (int)(((int64_t)ntj * nsj + 3) / 4);                   \
+    hipLaunchKernelGGL(ki, dim3(gi), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)x, (const bf16_t*)W, tasks_i, \
+                       nti, nsi, B, N, (bf16_t*)contrib_i);                                                         \
+    hipLaunchKernelGGL(kj, dim3(gj), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)x, (const bf16_t*)Wt,         \
+                       tasks_j, ntj, nsj, B, N, (bf16_t*)contrib_j);                                                \
   } while (0)
   if (E == 32) { if (mode == 0) TRS_PBI(1, 0); else TRS_PBI(1, 1); }
   else { if (mode == 0) TRS_PBI(2, 0); else TRS_PBI(2, 1); }
@@ -508,7 +550,7 @@ extern "C" int trs_pair_bilinear_bwd_data_mfma(const void* g, const void* x, con
 extern "C" size_t trs_pair_bilinear_bwd_w_mfma_workspace_bytes(int64_t B, int32_t N, int32_t E) {
   if (B <= 0 || N < 2 || E <= 0) return 256;
   const int P = N * (N - 1) / 2;
-  const int ns = pbm_splits((B + 31) / 32, P, 8);
+  const int ns = pbm_splits((B + 31) / 32, P, 8, 8192);        // upper bound of what the launch picks (8 waves per SIMD)
   return (size_t)ns * P * E * E * 4 + 256;
 }
 
@@ -530,13 +572,17 @@ extern "C" int trs_pair_bilinear_bwd_w_mfma(const void* g, const void* x, int32_
     if (hipMemsetAsync(gW, 0, (size_t)n * 2, s) != hipSuccess) return check_launch("pair_bilinear_bwd_w_mfma(memset)");
     return TRS_OK;
   }
-  const int ns = pbm_splits((B + 31) / 32, P, 8);
-  const int grid = (int)(((int64_t)P * ns + 3) / 4);
   const size_t lds = (size_t)4 * 2 * E * 80;
   float* part = (float*)workspace;
+  int ns = 1;
 #define TRS_PBW(KS_, M_)                                                                                            \
-  hipLaunchKernelGGL((pair_bil_bwd_w_mfma_kernel<KS_, M_>), dim3(grid), dim3(256), lds, s, (const bf16_t*)g,         \
-                     (const bf16_t*)x, ns, B, N, part)
+  do {                                                                                                              \
+    auto kern = pair_bil_bwd_w_mfma_kernel<KS_, M_>;                                                                \
+    static const int64_t slots = std::min<int64_t>(8192, pbm_wave_slots((const void*)kern, lds));                   \
+    ns = pbm_splits((B + 31) / 32, P, 8, slots);                                                                    \
+    hipLaunchKernelGGL(kern, dim3((int)(((int64_t)P * ns + 3) / 4)), dim3(256), lds, s, (const bf16_t*)g,            \
+                       (const bf16_t*)x, ns, B, N, part);                                                           \
+  } while (0)
   if (E == 32) { if (mode == 0) TRS_PBW(1, 0); else TRS_PBW(1, 1); }
   else { if (mode == 0) TRS_PBW(2, 0); else TRS_PBW(2, 1); }
 #undef TRS_PBW
