@@ -891,11 +891,19 @@ extern "C" int trs_afm_fwd_dropout(const void* x, const void* W1, const void* b1
   if (!no_mfma && dtype == TRS_BF16 && (E == 32 || E == 64 || E == 128) && A % 16 == 0 && A <= 128 &&
       afm_fwd_mfma_lds(N, E) <= 64 * 1024 && aligned16(x) && aligned16(W1)) {
     const size_t lds = afm_fwd_mfma_lds(N, E);
-    const int grid = (int)std::min<int64_t>(B, 256 * 4);
+    // one round of workgroups, each walking its share of the samples (A = E = 64: 162 registers = 3 workgroups per CU;
+    // the fixed 1024 this replaces ran as a round of 768 and one of 256)
 #define TRS_AFM_M(AT_, KS_)                                                                                       \
-  hipLaunchKernelGGL((afm_fwd_mfma_kernel<AT_, KS_>), dim3(grid), dim3(256), lds, s, (const bf16_t*)x,            \
-                     (const bf16_t*)W1, (const bf16_t*)b1, (const bf16_t*)w2, (const bf16_t*)b2, B, N, (bf16_t*)out, \
-                     (bf16_t*)attn, keep, keep_scale, (bf16_t*)attn_drop)
+  do {                                                                                                            \
+    auto kern = afm_fwd_mfma_kernel<AT_, KS_>;                                                                    \
+    static size_t cap_lds = ~(size_t)0;                                                                           \
+    static int cap = 0;                                                                                           \
+    if (cap_lds != lds) { cap = resident_blocks((const void*)kern, 256, lds); cap_lds = lds; }                    \
+    const int grid = (int)std::min<int64_t>(B, cap);                                                              \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)W1, (const bf16_t*)b1, \
+                       (const bf16_t*)w2, (const bf16_t*)b2, B, N, (bf16_t*)out, (bf16_t*)attn, keep, keep_scale,  \
+                       (bf16_t*)attn_drop);                                                                       \
+  } while (0)
 #define TRS_AFM_MK(AT_)                                 \
   do {                                                  \
     if (E == 32) TRS_AFM_M(AT_, 1);                     \

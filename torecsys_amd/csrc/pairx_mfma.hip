@@ -21,14 +21,8 @@ constexpr int PB_PPT = 3;        // pairs per task
 
 // Waves of 256-thread workgroups of `kernel` that the device holds at once.  The sample splits of these kernels are
 // sized from it: a wave owns one (task, split) for the whole launch, so ntasks * nsplit just ABOVE this number (260 tasks
-// x 8 splits = 2080 on 2048 slots at two waves per SIMD) leaves a second, nearly empty round that doubles the time.
-static int64_t pbm_wave_slots(const void* kernel, size_t dyn_lds) {
-  int dev = 0, cus = 256, blocks = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return 2048;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, 256, dyn_lds) != hipSuccess || blocks < 1) blocks = 2;
-  return (int64_t)cus * blocks * 4;
-}
+// x 8 splits = 2080 on 2048 slots at two waves per SIMD) leaves a second, nearly empty round.
+static int64_t pbm_wave_slots(const void* kernel, size_t dyn_lds) { return (int64_t)resident_blocks(kernel, 256, dyn_lds) * 4; }
 // sample splits: as many as fill the slots in ONE round, each with at least min_per units
 static int pbm_splits(int64_t units, int ntasks, int64_t min_per, int64_t slots) {
   const int64_t by_slots = std::max<int64_t>(1, slots / ntasks);

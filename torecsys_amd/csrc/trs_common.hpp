@@ -138,6 +138,19 @@ inline int stream_grid(int64_t work_items, int block, int max_blocks = 256 * 16)
   return (int)g;
 }
 
+// Workgroups of `kernel` (threads per block, dynamic LDS bytes) that are resident on the device at once.  Kernels whose
+// blocks walk equal shares of the work (a wave or block owns its share for the whole launch) size their grid from this:
+// a grid a little above it runs as a full round plus a nearly empty one -- 1024 blocks on 768 slots take two rounds for
+// 1.33 rounds of work.
+inline int resident_blocks(const void* kernel, int threads, size_t dyn_lds) {
+  int dev = 0, cus = 256, blocks = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, kernel, threads, dyn_lds) != hipSuccess || blocks < 1)
+    blocks = 1;
+  return cus * blocks;
+}
+
 // Flat element counters are int64 in the kernels' loops, but almost always fit 32 bits: a runtime-divisor 64-bit
 // division is ~80 emulated instructions per element, the 32-bit one a float reciprocal + fix-up.  ``fits32`` is uniform
 // over the launch (total element count < 2^32).
