@@ -1677,6 +1677,58 @@ class _FusedMLP(Function):
         return (gx.reshape(xshape) if ctx.needs_input_grad[0] else None, *grads)
 
 
+class _FusedMLPTail(Function):
+    """The layers BEHIND a wide first layer (DeepFM / xDeepFM deep branch: 2496 -> 400 | -> 400 -> 400 -> 1) as one HIP
+    kernel per direction: x2 is the first layer's ReLU output at its zero-padded GEMM width, the tail's first weight is
+    padded on the input side to match and its last on the output side to the kernel's minimum width (8 columns; only the
+    first ``out_f`` are returned).  ``tensors`` per layer: weight, bias (the parameters: they receive the gradients),
+    w_use, b_use (what the kernel reads: the parameter itself when None)."""
+
+    @staticmethod
+    def forward(ctx, x2, *tensors):
+        require_device(x2, *[t for t in tensors if t is not None])
+        L = len(tensors) // 4
+        Ws = [(tensors[4 * l] if tensors[4 * l + 2] is None else tensors[4 * l + 2]).contiguous() for l in range(L)]
+        bs = [(tensors[4 * l + 1] if tensors[4 * l + 3] is None else tensors[4 * l + 3]).contiguous() for l in range(L)]
+        y, hidden, masks = fused_mlp_forward_raw(x2, Ws, bs)
+        out_f = tensors[4 * (L - 1)].shape[0]
+        ctx.save_for_backward(x2, *Ws, *hidden, *masks)
+        ctx.meta = (L, [x2.shape[1]] + [w.shape[0] for w in Ws], [tuple(tensors[4 * l].shape) for l in range(L)],
+                    [tensors[4 * l].dtype for l in range(L)])
+        return y[:, :out_f].contiguous() if out_f != y.shape[1] else y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        L, widths, wshapes, wdt = ctx.meta
+        saved = ctx.saved_tensors
+        x2, Ws = saved[0], saved[1:1 + L]
+        hidden, masks = saved[1 + L:L + L], saved[L + L:]
+        rows, dev = x2.shape[0], x2.device
+        if gy.shape[1] != widths[L]:
+            gy2 = torch.zeros(rows, widths[L], dtype=torch.bfloat16, device=dev)
+            gy2[:, :gy.shape[1]] = gy
+        else:
+            gy2 = gy.contiguous()
+        gz = [torch.empty(rows, _pad32(widths[l + 1]), dtype=torch.bfloat16, device=dev) for l in range(L - 1)]
+        gb = [torch.empty(_pad32(widths[l + 1]), dtype=torch.float32, device=dev) for l in range(L)]
+        gx = torch.empty_like(x2)
+        wl = _i32_array(widths)
+        ws_bytes = size_query("trs_mlp_fused_workspace_bytes", L, wl)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        call("trs_mlp_fused_bwd_data", ptr(gy2), rows, L, wl, _ptr_array(Ws), _ptr_array(masks), _ptr_array(gz),
+             _ptr_array(gb), ptr(gx), _abi.TRS_BF16, ptr(ws), ws_bytes, stream_ptr())
+        grads = []
+        for l in range(L):
+            inp = x2 if l == 0 else hidden[l - 1]
+            g = gy2 if l == L - 1 else gz[l]
+            out_f, in_f = wshapes[l]
+            gw = _wgrad_rows(g, inp, out_f, in_f, wdt[l]) if ctx.needs_input_grad[1 + 4 * l] else None
+            gbias = gb[l][:out_f].to(wdt[l]) if ctx.needs_input_grad[2 + 4 * l] else None
+            grads += [gw, gbias, None, None]
+        return (gx if ctx.needs_input_grad[0] else None, *grads)
+
+
 def _wgrad_rows(g: torch.Tensor, inp: torch.Tensor, out_f: int, in_f: int, dtype) -> torch.Tensor:
     """dW = g^T @ inp over the rows (K = rows): split-K batched GEMM with fp32 partials, folded / sliced / cast by
     trs_wgrad_finish (the padding columns of g / inp are dropped there)."""

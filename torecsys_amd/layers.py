@@ -11,6 +11,7 @@ from abc import ABC, abstractmethod
 from typing import Dict, List, Optional, Tuple
 
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -517,6 +518,7 @@ class CompressInteractionNetworkLayer(BaseLayer):
 PAD_MULTIPLE = 128        # hidden widths are zero-padded to a multiple of this inside the GEMMs
 PAD_MIN_WIDTH = 192
 PAD_MIN_ROWS = 4096
+HYBRID_MLP = os.environ.get("TRS_HYBRID_MLP", "1") not in ("", "0")   # fused tail behind a wide first layer
 
 
 def _pad_width(width: int) -> int:
@@ -866,6 +868,54 @@ class MultilayerPerceptionLayer(BaseLayer):
             out.names = ('B', 'N', 'O',)
         return out
 
+    def _forward_hybrid(self, outputs: torch.Tensor, mods) -> Optional[torch.Tensor]:
+        """A first layer too wide for the fused kernel (the 2496-wide input of the DeepFM / xDeepFM deep branch) on
+        hipBLASLt, every layer behind it -- ReLU hidden layers and the output Linear -- as ONE kernel per direction
+        (F_._FusedMLPTail): 65 536 x 400 x 400 GEMMs are too small for the library's 256-wide macro tiles (300-450
+        TFLOP/s each, plus a ReLU-backward pass per layer).  None when the stack does not have that shape."""
+        lin = [m for m in mods if not isinstance(m, nn.Dropout)]
+        layers = []
+        i = 0
+        while i < len(lin):
+            mod = lin[i]
+            if not isinstance(mod, nn.Linear) or mod.bias is None or mod.weight.dtype != outputs.dtype:
+                return None
+            relu = i + 1 < len(lin) and type(lin[i + 1]) is nn.ReLU
+            last = i + (2 if relu else 1) >= len(lin)
+            if relu == last:
+                return None
+            layers.append(mod)
+            i += 2 if relu else 1
+        if len(layers) < 3 or not HYBRID_MLP or not outputs.is_contiguous() or outputs.dim() != 2:
+            return None
+        first, tail = layers[0], layers[1:]
+        h_pad = _pad_width(first.out_features)
+        if (h_pad * outputs.element_size()) % 16 != 0 or h_pad * outputs.element_size() > 4096:
+            return None
+        out_pad = max(8, (tail[-1].out_features + 7) // 8 * 8)
+        widths = [h_pad] + [m.out_features for m in tail[:-1]] + [out_pad]
+        if any(a.in_features != b.out_features for a, b in zip(tail, layers[:-1])):
+            return None
+        if first.in_features <= 512 or not F_.mlp_fused_supported(outputs.new_empty(outputs.shape[0], h_pad), widths):
+            return None
+        padded = [(first, outputs.shape[-1], h_pad) if (outputs.shape[-1] != first.in_features
+                                                         or h_pad != first.out_features) else None,
+                  (tail[0], h_pad, tail[0].out_features) if h_pad != tail[0].in_features else None]
+        if len(tail) > 1:
+            padded += [None] * (len(tail) - 2)
+            padded.append((tail[-1], tail[-1].in_features, out_pad) if out_pad != tail[-1].out_features else None)
+        elif out_pad != tail[0].out_features:
+            padded[1] = (tail[0], h_pad, out_pad)
+        copies = iter(_PaddedLinear.get_many([p for p in padded if p is not None]))
+        use = [next(copies) if p is not None else (None, None) for p in padded]
+        h1 = _MLPStack.apply(outputs, ((True, False),), first.weight, first.bias, use[0][0], use[0][1])
+        tensors = []
+        for mod, (w_use, b_use) in zip(tail, use[1:]):
+            tensors += [mod.weight, mod.bias, w_use, b_use]
+        out = F_._FusedMLPTail.apply(h1, *tensors)
+        out.names = ('B', 'O',)
+        return out
+
     def _forward_fused(self, outputs: torch.Tensor, mods) -> Optional[torch.Tensor]:
         """Narrow stacks (every width <= 512: the per-field MLP of DeepAndCrossNetwork, 64 -> 400 -> 400 -> 400 -> 64 on
         B*N rows) as ONE kernel per direction with the activations of a row tile kept in LDS (trs_mlp_fused_*,
@@ -913,6 +963,9 @@ class MultilayerPerceptionLayer(BaseLayer):
             fused = self._forward_fused(outputs, mods)
             if fused is not None:
                 return fused
+            hybrid = self._forward_hybrid(outputs, mods)
+            if hybrid is not None:
+                return hybrid
             stacked = self._forward_stacked(outputs, mods)
             if stacked is not None:
                 return stacked
