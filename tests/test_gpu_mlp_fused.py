@@ -112,3 +112,44 @@ def test_mlp_layer_takes_fused_path_and_matches_gemm_path(dev):
     assert rel_err(xa.grad.float(), xb.grad.float()) <= 2e-2
     for a, p in zip(ga, lay.parameters()):
         assert rel_err(a.float(), p.grad.float()) <= 1e-2
+
+
+def test_mlp_layer_with_wide_first_layer_takes_hybrid_path(dev):
+    """DeepFM's deep branch (2496 -> 400 -> 400 -> 400 -> 1 on B rows): first layer on hipBLASLt, everything behind it
+    in the fused kernels (F_._FusedMLPTail).  Checked against the fp32 oracle on the forward, and against the all-GEMM
+    arrangement it replaces on every gradient (two bf16 paths, each within 1e-2 of the oracle: up to 2e-2 apart)."""
+    from torecsys_amd import functional as F_
+    from torecsys_amd import layers as L
+    torch.manual_seed(7)
+    lay = L.DNNLayer(inputs_size=2496, output_size=1, layer_sizes=[400, 400, 400]).to(dev).bfloat16()
+    x = (0.5 * torch.randn(8192 + 37, 2496, device=dev)).bfloat16()          # ragged last row tile
+    calls = []
+    orig = F_._FusedMLPTail.apply
+    F_._FusedMLPTail.apply = lambda *a: (calls.append(1), orig(*a))[1]
+    try:
+        xa = x.clone().requires_grad_()
+        ya = lay(xa)
+    finally:
+        F_._FusedMLPTail.apply = orig
+    assert calls, "the layer did not take the hybrid path"
+    assert ya.names == ("B", "O") and ya.shape == (x.shape[0], 1)
+    lin = [m for m in lay.model if isinstance(m, torch.nn.Linear)]
+    yo = O.mlp(x.float().cpu(), [m.weight.detach().float().cpu() for m in lin], [m.bias.detach().float().cpu() for m in lin])
+    assert rel_err(ya.rename(None).float().cpu(), yo) <= TOL
+    go = torch.randn_like(ya.rename(None))
+    ya.rename(None).backward(go)
+    ga = [p.grad.clone() for p in lay.parameters()]
+    lay.zero_grad()
+    saved = L.HYBRID_MLP
+    L.HYBRID_MLP = False
+    try:
+        xb = x.clone().requires_grad_()
+        yb = lay(xb)
+    finally:
+        L.HYBRID_MLP = saved
+    yb.rename(None).backward(go)
+    assert rel_err(ya.rename(None).float(), yb.rename(None).float()) <= 2 * TOL
+    assert rel_err(xa.grad.float(), xb.grad.float()) <= 2 * TOL
+    for (n, p), g in zip(lay.named_parameters(), ga):
+        assert g.shape == p.grad.shape
+        assert rel_err(g.float(), p.grad.float()) <= 2 * TOL, n
