@@ -115,18 +115,18 @@ __global__ __launch_bounds__(256) void pair_bil_fwd_mfma_kernel(const bf16_t* __
     for (int c = 0; c < PB_PPT; ++c) {
       pb_f32x4 acc[MT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        acc[mt] = pb_f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = pb_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
+      for (int ks = 0; ks < KS; ++ks)          // k-steps outermost: consecutive MFMAs never wait for one another
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
           acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pb_bf16x8, Wf[c][mt][ks]),
                                                             __builtin_bit_cast(pb_bf16x8, xi[ks]), acc[mt], 0, 0, 0);
-      }
       if (c == PB_PPT - 1) {
         __builtin_amdgcn_sched_barrier(0);
         load_xi(xi, xb2);                                  // the tile's last MFMAs are issued: x_i is free
       }
-      float part = 0.f;
+      float part = 0.f, part2 = 0.f;           // two chains: the 16 FMAs of a lane are not one dependent string
 #pragma unroll
       for (int u = 0; u < KS; ++u) {
         float xv[8];
@@ -135,8 +135,12 @@ __global__ __launch_bounds__(256) void pair_bil_fwd_mfma_kernel(const bf16_t* __
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const float tv = k < 4 ? acc[2 * u][k & 3] : acc[2 * u + 1][k & 3];
-          if (MODE == 0) part = fmaf(tv, xv[k], part);
-          else r8[k] = fmaf(tv, xv[k], bv[c][u][k]);
+          if (MODE == 0) {
+            if (k & 1) part2 = fmaf(tv, xv[k], part2);
+            else part = fmaf(tv, xv[k], part);
+          } else {
+            r8[k] = fmaf(tv, xv[k], bv[c][u][k]);
+          }
         }
         if (MODE == 1 && live && c < cnt)
           *reinterpret_cast<uint4*>(out + ((b * P + p0 + c) * (int64_t)E) + 32 * u + 8 * q) = Vec16<bf16_t>::pack(r8);
@@ -144,8 +148,13 @@ __global__ __launch_bounds__(256) void pair_bil_fwd_mfma_kernel(const bf16_t* __
       __builtin_amdgcn_sched_barrier(0);
       load_xj(xj[c], c, xb2);
       if (MODE == 0) {
-        part += __shfl_xor(part, 16, 64);
-        part += __shfl_xor(part, 32, 64);
+        // sum over the four 16-lane rows (the h quarters of the sample in lane n) with two lane-permute instructions;
+        // __shfl_xor goes through ds_bpermute and an lgkmcnt wait -- two LDS round trips per pair
+        part += part2;
+        const auto a2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(part), __float_as_uint(part), false, false);
+        const float h2 = __uint_as_float(a2[0]) + __uint_as_float(a2[1]);
+        const auto c2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(h2), __float_as_uint(h2), false, false);
+        part = __uint_as_float(c2[0]) + __uint_as_float(c2[1]);
         if (q == 0 && live && c < cnt) out[b * P + p0 + c] = from_f32<bf16_t>(part);
       }
     }
