@@ -34,14 +34,22 @@ __global__ __launch_bounds__(256) void pair_bil_fwd_mfma_kernel(const bf16_t* __
                                                                 const bf16_t* __restrict__ Wt /* (P,H,E) */,
                                                                 const bf16_t* __restrict__ bias /* (P,E) | null */,
                                                                 const int32_t* __restrict__ tasks /* (T,3): i, j0, cnt */,
-                                                                int ntasks, int nsplit, int64_t B, int N,
+                                                                int ntasks, int64_t per_wave, int64_t B, int N,
                                                                 bf16_t* __restrict__ out) {
   constexpr int E = 32 * KS, MT = 2 * KS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, n = lane & 15;
   const int P = N * (N - 1) / 2;
-  const int gw = blockIdx.x * 4 + wave;                 // global wave id: task fastest within a sample split
-  const int task = gw % ntasks, split = gw / ntasks;
-  if (split >= nsplit) return;
+  // Work = (task, 16-sample tile) pairs, task-major; every wave takes the same number of consecutive pairs (its range
+  // may straddle two tasks: the weights are then loaded again).  The kernel is bound by VALU / MFMA issue, not by
+  // memory: with whole (task, sample split) units per wave, 1820 waves on 2048 slots left CUs with one workgroup done
+  // after 84-115 us and the ones with two after 164.
+  const int64_t tiles = (B + 15) / 16;
+  const int64_t flat_lo = (int64_t)(blockIdx.x * 4 + wave) * per_wave;
+  const int64_t flat_hi = std::min<int64_t>(flat_lo + per_wave, (int64_t)ntasks * tiles);
+  for (int64_t flat = flat_lo; flat < flat_hi;) {
+  const int task = (int)(flat / tiles);
+  const int64_t t_lo = flat - (int64_t)task * tiles, t_hi = std::min<int64_t>(tiles, t_lo + (flat_hi - flat));
+  flat += t_hi - t_lo;
   const int fi = tasks[3 * task], j0 = tasks[3 * task + 1], cnt = tasks[3 * task + 2];
   const int p0 = pair_index_of(fi, j0, N);
   // resident A fragments: row m of tile mt <-> h = 32 (mt>>1) + 8 (m>>2) + 4 (mt&1) + (m&3)
@@ -66,9 +74,6 @@ __global__ __launch_bounds__(256) void pair_bil_fwd_mfma_kernel(const bf16_t* __
         for (int k = 0; k < 8; ++k) bv[c][u][k] = 0.f;
     }
   }
-  const int64_t tiles = (B + 15) / 16;
-  const int64_t per = (tiles + nsplit - 1) / nsplit;
-  const int64_t t_lo = split * per, t_hi = std::min<int64_t>(t_lo + per, tiles);
   // A wave walks its sample tiles one at a time.  All the tasks of a sample split reach the same 16 samples at about the
   // same time, so for its XCD's L2 nearly every tile is a first touch: the x_i / x_j runs arrive with Infinity-Cache
   // latency (2-3 us per tile iteration measured, against ~0.35 us of MFMAs and epilogue).  Two register sets hold the runs
@@ -185,6 +190,7 @@ __global__ __launch_bounds__(256) void pair_bil_fwd_mfma_kernel(const bf16_t* __
         for (int u = 0; u < KS; ++u) asm volatile("" ::"v"(nxj[s2][c][u]));
     }
   }
+  }   // (task, tile range) segments of this wave
 }
 
 }  // namespace trs
@@ -209,10 +215,12 @@ extern "C" int trs_pair_bilinear_fwd_mfma(const void* x, const void* Wt, const v
   do {                                                                                                              \
     auto kern = pair_bil_fwd_mfma_kernel<KS_, MODE_>;                                                               \
     static const int64_t slots = pbm_wave_slots((const void*)kern, 0);                                              \
-    const int nsplit = pbm_splits(tiles, ntasks, 4, slots);                                                         \
-    const int grid = (int)(((int64_t)ntasks * nsplit + 3) / 4);                                                     \
+    const int64_t units = (int64_t)ntasks * tiles;                                                                  \
+    const int64_t waves = std::max<int64_t>(4, std::min<int64_t>(slots, (units + 3) / 4) / 4 * 4);   /* >= 4 tiles each */ \
+    const int64_t per_wave = (units + waves - 1) / waves;                                                           \
+    const int grid = (int)((units + per_wave * 4 - 1) / (per_wave * 4));                                            \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)Wt, (const bf16_t*)bias,  \
-                       tasks, ntasks, nsplit, B, N, (bf16_t*)out);                                                  \
+                       tasks, ntasks, per_wave, B, N, (bf16_t*)out);                                                \
   } while (0)
   if (E == 32) { if (mode == 0) TRS_PBM(1, 0); else TRS_PBM(1, 1); }
   else { if (mode == 0) TRS_PBM(2, 0); else TRS_PBM(2, 1); }
