@@ -23,6 +23,13 @@ constexpr int PB_PPT = 3;        // pairs per task
 // sized from it: a wave owns one (task, split) for the whole launch, so ntasks * nsplit just ABOVE this number (260 tasks
 // x 8 splits = 2080 on 2048 slots at two waves per SIMD) leaves a second, nearly empty round.
 static int64_t pbm_wave_slots(const void* kernel, size_t dyn_lds) { return (int64_t)resident_blocks(kernel, 256, dyn_lds) * 4; }
+// units per wave when `units` are dealt evenly to at most `slots` waves (at least 4 units each); *grid = workgroups of 4
+static int64_t pbm_even_share(int64_t units, int64_t slots, int* grid) {
+  const int64_t waves = std::max<int64_t>(4, std::min<int64_t>(slots, (units + 3) / 4) / 4 * 4);
+  const int64_t per_wave = (units + waves - 1) / waves;
+  *grid = (int)((units + per_wave * 4 - 1) / (per_wave * 4));
+  return per_wave;
+}
 // sample splits: as many as fill the slots in ONE round, each with at least min_per units
 static int pbm_splits(int64_t units, int ntasks, int64_t min_per, int64_t slots) {
   const int64_t by_slots = std::max<int64_t>(1, slots / ntasks);
@@ -215,10 +222,8 @@ extern "C" int trs_pair_bilinear_fwd_mfma(const void* x, const void* Wt, const v
   do {                                                                                                              \
     auto kern = pair_bil_fwd_mfma_kernel<KS_, MODE_>;                                                               \
     static const int64_t slots = pbm_wave_slots((const void*)kern, 0);                                              \
-    const int64_t units = (int64_t)ntasks * tiles;                                                                  \
-    const int64_t waves = std::max<int64_t>(4, std::min<int64_t>(slots, (units + 3) / 4) / 4 * 4);   /* >= 4 tiles each */ \
-    const int64_t per_wave = (units + waves - 1) / waves;                                                           \
-    const int grid = (int)((units + per_wave * 4 - 1) / (per_wave * 4));                                            \
+    int grid;                                                                                                       \
+    const int64_t per_wave = pbm_even_share((int64_t)ntasks * tiles, slots, &grid);                                 \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)Wt, (const bf16_t*)bias,  \
                        tasks, ntasks, per_wave, B, N, (bf16_t*)out);                                                \
   } while (0)
@@ -246,14 +251,19 @@ template <int KS, int MODE>
 __global__ __launch_bounds__(256) void pair_bil_bwd_xi_mfma_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ x,
                                                                    const bf16_t* __restrict__ W /* (P,E,H) */,
                                                                    const int32_t* __restrict__ tasks, int ntasks,
-                                                                   int nsplit, int64_t B, int N,
+                                                                   int64_t per_wave, int64_t B, int N,
                                                                    bf16_t* __restrict__ contrib /* (B,ntasks,E) */) {
   constexpr int E = 32 * KS, ET = 2 * KS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, n = lane & 15;
   const int P = N * (N - 1) / 2;
-  const int gw = blockIdx.x * 4 + wave;
-  const int task = gw % ntasks, split = gw / ntasks;
-  if (split >= nsplit) return;
+  // equal shares of the (task, sample tile) units, task-major (see pair_bil_fwd_mfma_kernel)
+  const int64_t tiles = (B + 15) / 16;
+  const int64_t flat_lo = (int64_t)(blockIdx.x * 4 + wave) * per_wave;
+  const int64_t flat_hi = std::min<int64_t>(flat_lo + per_wave, (int64_t)ntasks * tiles);
+  for (int64_t flat = flat_lo; flat < flat_hi;) {
+  const int task = (int)(flat / tiles);
+  const int64_t t_lo = flat - (int64_t)task * tiles, t_hi = std::min<int64_t>(tiles, t_lo + (flat_hi - flat));
+  flat += t_hi - t_lo;
   const int fi = tasks[3 * task], j0 = tasks[3 * task + 1], cnt = tasks[3 * task + 2];
   const int p0 = pair_index_of(fi, j0, N);
   uint4 Wf[PB_PPT][ET][KS];           // A: row m of tile et <-> e = 32 (et>>1) + 8 (m>>2) + 4 (et&1) + (m&3); k = h
@@ -268,9 +278,6 @@ __global__ __launch_bounds__(256) void pair_bil_bwd_xi_mfma_kernel(const bf16_t*
         Wf[c][et][ks] = *reinterpret_cast<const uint4*>(W + ((size_t)pc * E + e) * E + 32 * ks + 8 * q);
     }
   }
-  const int64_t tiles = (B + 15) / 16;
-  const int64_t per = (tiles + nsplit - 1) / nsplit;
-  const int64_t t_lo = split * per, t_hi = std::min<int64_t>(t_lo + per, tiles);
   for (int64_t t = t_lo; t < t_hi; ++t) {
     const int64_t b = t * 16 + n;
     const bool live = b < B;
@@ -307,6 +314,7 @@ __global__ __launch_bounds__(256) void pair_bil_bwd_xi_mfma_kernel(const bf16_t*
       }
     }
   }
+  }   // segments
 }
 
 // tasks here are (j, i0, count): pairs (i0 .. i0+count-1, j)
@@ -314,14 +322,18 @@ template <int KS, int MODE>
 __global__ __launch_bounds__(256) void pair_bil_bwd_xj_mfma_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ x,
                                                                    const bf16_t* __restrict__ Wt /* (P,H,E) */,
                                                                    const int32_t* __restrict__ tasks, int ntasks,
-                                                                   int nsplit, int64_t B, int N,
+                                                                   int64_t per_wave, int64_t B, int N,
                                                                    bf16_t* __restrict__ contrib /* (B,ntasks,E) */) {
   constexpr int E = 32 * KS, MT = 2 * KS;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, n = lane & 15;
   const int P = N * (N - 1) / 2;
-  const int gw = blockIdx.x * 4 + wave;
-  const int task = gw % ntasks, split = gw / ntasks;
-  if (split >= nsplit) return;
+  const int64_t tiles = (B + 15) / 16;
+  const int64_t flat_lo = (int64_t)(blockIdx.x * 4 + wave) * per_wave;
+  const int64_t flat_hi = std::min<int64_t>(flat_lo + per_wave, (int64_t)ntasks * tiles);
+  for (int64_t flat = flat_lo; flat < flat_hi;) {
+  const int task = (int)(flat / tiles);
+  const int64_t t_lo = flat - (int64_t)task * tiles, t_hi = std::min<int64_t>(tiles, t_lo + (flat_hi - flat));
+  flat += t_hi - t_lo;
   const int fj = tasks[3 * task], i0 = tasks[3 * task + 1], cnt = tasks[3 * task + 2];
   uint4 Wf[PB_PPT][MT][KS];
   int pidx[PB_PPT];
@@ -336,9 +348,6 @@ __global__ __launch_bounds__(256) void pair_bil_bwd_xj_mfma_kernel(const bf16_t*
         Wf[c][mt][ks] = *reinterpret_cast<const uint4*>(Wt + ((size_t)pidx[c] * E + h) * E + 32 * ks + 8 * q);
     }
   }
-  const int64_t tiles = (B + 15) / 16;
-  const int64_t per = (tiles + nsplit - 1) / nsplit;
-  const int64_t t_lo = split * per, t_hi = std::min<int64_t>(t_lo + per, tiles);
   for (int64_t t = t_lo; t < t_hi; ++t) {
     const int64_t b = t * 16 + n;
     const bool live = b < B;
@@ -396,6 +405,7 @@ __global__ __launch_bounds__(256) void pair_bil_bwd_xj_mfma_kernel(const bf16_t*
       }
     }
   }
+  }   // segments
 }
 
 // gx[b][f][:] = sum of the XI contributions of field f's tasks + the XJ contributions of field f's tasks
@@ -542,12 +552,13 @@ extern "C" int trs_pair_bilinear_bwd_data_mfma(const void* g, const void* x, con
     auto ki = pair_bil_bwd_xi_mfma_kernel<KS_, M_>;                                                                 \
     auto kj = pair_bil_bwd_xj_mfma_kernel<KS_, M_>;                                                                 \
     static const int64_t slots_i = pbm_wave_slots((const void*)ki, 0), slots_j = pbm_wave_slots((const void*)kj, 0); \
-    const int nsi = pbm_splits(tiles, nti, 4, slots_i), nsj = pbm_splits(tiles, ntj, 4, slots_j);                   \
-    const int gi = (int)(((int64_t)nti * nsi + 3) / 4), gj = (int)(((int64_t)ntj * nsj + 3) / 4);                   \
+    int gi, gj;                                                                                                     \
+    const int64_t pwi = pbm_even_share((int64_t)nti * tiles, slots_i, &gi);                                         \
+    const int64_t pwj = pbm_even_share((int64_t)ntj * tiles, slots_j, &gj);                                         \
     hipLaunchKernelGGL(ki, dim3(gi), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)x, (const bf16_t*)W, tasks_i, \
-                       nti, nsi, B, N, (bf16_t*)contrib_i);                                                         \
+                       nti, pwi, B, N, (bf16_t*)contrib_i);                                                         \
     hipLaunchKernelGGL(kj, dim3(gj), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)x, (const bf16_t*)Wt,         \
-                       tasks_j, ntj, nsj, B, N, (bf16_t*)contrib_j);                                                \
+                       tasks_j, ntj, pwj, B, N, (bf16_t*)contrib_j);                                                \
   } while (0)
   if (E == 32) { if (mode == 0) TRS_PBI(1, 0); else TRS_PBI(1, 1); }
   else { if (mode == 0) TRS_PBI(2, 0); else TRS_PBI(2, 1); }
