@@ -196,9 +196,11 @@ __device__ __forceinline__ void mlp_gemm_t(const char* act, int act_str, const u
     // The fragment loads are issued by hand at the top of a k-step and waited for at its bottom: written as ordinary
     // loads the compiler places them at the END of the previous k-step's body and waits vmcnt(0) at the top of the
     // next one, i.e. every k-step starts with a full L2 round trip (ISA of the first version of this loop).
-    for (int ks = 0; ks < KS; ++ks) {
+    // two k-steps per iteration with the two fragment sets trading places: no register copies between the steps
+    // (16 v_mov per k-step beside 32 MFMAs: the matrix pipe and the VALU share the SIMD's issue port)
+    auto kstep = [&](int ks, mf_u32x4 (&cur)[2 * NPW], mf_u32x4 (&nxt)[2 * NPW]) {
       const int kn = ks + 1 < KS ? ks + 1 : ks;
-      TRS_MF_FETCH(An, kn)
+      TRS_MF_FETCH(nxt, kn)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int m0 = 0; m0 < MCNT; m0 += HALF) {
@@ -210,13 +212,17 @@ __device__ __forceinline__ void mlp_gemm_t(const char* act, int act_str, const u
 #pragma unroll
           for (int mi = 0; mi < HALF; ++mi)
             acc[m0 + mi][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                __builtin_bit_cast(mf_bf16x8, A[t]), __builtin_bit_cast(mf_bf16x8, Bh[mi]), acc[m0 + mi][t], 0, 0, 0);
+                __builtin_bit_cast(mf_bf16x8, cur[t]), __builtin_bit_cast(mf_bf16x8, Bh[mi]), acc[m0 + mi][t], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
-      TRS_MF_COMMIT(An)
-#pragma unroll
-      for (int t = 0; t < 2 * NPW; ++t) A[t] = An[t];
+      TRS_MF_COMMIT(nxt)
+    };
+    int ks = 0;
+    for (; ks + 1 < KS; ks += 2) {
+      kstep(ks, A, An);
+      kstep(ks + 1, An, A);
     }
+    if (ks < KS) kstep(ks, A, An);
   }
 #undef TRS_MF_FETCH
 #undef TRS_MF_COMMIT
