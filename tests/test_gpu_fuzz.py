@@ -143,3 +143,36 @@ def test_cross_and_cin_contract(dev, dtype, shape):
     (yc.float() * gy.to(dev).float()).sum().backward()
     for a, r in zip(td, ts):
         assert rel_err(a.grad.float().cpu(), r.grad) <= tol
+
+
+@pytest.mark.parametrize("E", [32, 64])
+@pytest.mark.parametrize("N", [2, 5, 39])
+def test_pair_bilinear_mfma_batch_tails(dev, N, E):
+    """The matrix-core per-pair bilinear kernels walk 16-sample tiles with loads two tiles ahead and every wave takes an
+    equal share of (task, tile) units: batch sizes around every boundary of that scheme (one tile, an odd number of
+    tiles, a ragged last tile, fewer units than waves, a wave range that straddles two tasks), OPN 'mat' and Bilinear
+    'each', forward and gradients against the same sums in fp32 torch ops on the bf16-rounded operands."""
+    from torecsys_amd import functional as F_
+    P = N * (N - 1) // 2
+    i_idx, j_idx = torch.triu_indices(N, N, 1)
+    for B in (16, 17, 31, 32, 33, 47, 48, 49, 65, 100, 257, 1000):
+        g = torch.Generator().manual_seed(B * 131 + N * 7 + E)
+        x = (0.5 * torch.randn(B, N, E, generator=g)).bfloat16()
+        W = (torch.randn(P, E, E, generator=g) / E ** 0.5).bfloat16()
+        bias = (0.1 * torch.randn(P, E, generator=g)).bfloat16()
+        for mode in (0, 1):
+            xd = x.to(dev).requires_grad_()
+            Wd = W.to(dev).requires_grad_()
+            bd = bias.to(dev).requires_grad_() if mode == 1 else None
+            assert F_._pair_mfma_fwd_ok(xd)
+            y = F_._PairBilinear.apply(xd, Wd, bd, mode)
+            xr = x.float().requires_grad_()
+            Wr = W.float().requires_grad_()
+            T = torch.einsum("bpe,peh->bph", xr[:, i_idx], Wr)
+            yr = (T * xr[:, j_idx]).sum(-1) if mode == 0 else T * xr[:, j_idx] + bias.float()
+            assert rel_err(y.float().cpu(), yr) <= 1e-2, (B, mode, "forward")
+            go = torch.randn(yr.shape, generator=g)
+            (y.float() * go.to(dev)).sum().backward()
+            (yr * go).sum().backward()
+            assert rel_err(xd.grad.float().cpu(), xr.grad) <= 1e-2, (B, mode, "gx")
+            assert rel_err(Wd.grad.float().cpu(), Wr.grad) <= 1e-2, (B, mode, "gW")
