@@ -493,6 +493,12 @@ int trs_pair_epilogue_bwd(const void* g, const void* x, void* T, int32_t mode, i
  * ACCUMULATED into.  E, A <= 128.                                                                   */
 int trs_afm_fwd(const void* x, const void* W1, const void* b1, const void* w2, const void* b2, int64_t B, int32_t N,
                 int32_t E, int32_t A, int32_t dtype, void* out, void* attn, trs_stream_t stream);
+/* Host-side helper (no device work): the backward kernel's schedule of 16-pair tiles for N fields -- every pair (i < j)
+ * exactly once, the pairs of a tile sharing no field (what lets a wave add into per-field gradient rows without
+ * atomics), packed greedily from the round-robin rounds.  tiles[16 t + k] = (i << 8) | j, 0xffff = empty slot;
+ * *ntiles = 0 when the table does not fit the kernel-argument block (the kernel then walks the rounds themselves).
+ * attentional_factorization_machine.py:86-120 (the pair enumeration the attention runs over).                   */
+int trs_afm_pair_tiles(int32_t N, uint16_t* tiles, int32_t capacity, int32_t* ntiles);
 size_t trs_afm_bwd_workspace_bytes(int64_t B, int32_t N, int32_t E, int32_t A);
 int trs_afm_bwd(const void* g_out, const void* g_attn, const void* x, const void* attn, const void* W1,
                 const void* b1, const void* w2, int64_t B, int32_t N, int32_t E, int32_t A, int32_t dtype, void* gx,

@@ -287,3 +287,35 @@ def test_patch_on_the_real_reference_models():
                 sys.modules[k] = v
             else:
                 sys.modules.pop(k, None)
+
+
+@pytest.mark.parametrize("N", [2, 3, 7, 16, 32, 33, 39, 40, 48])
+def test_afm_pair_tiles_cover_every_pair_once_and_are_field_disjoint(N):
+    """the host-built tile schedule of the AFM backward kernel (afm_packed_tiles): each of the N(N-1)/2 pairs exactly once,
+    no field twice inside a tile, and no more tiles than the round-robin rounds would take"""
+    import ctypes
+    import numpy as np
+    from torecsys_amd import _abi
+    lib = _abi.load()
+    buf = np.full(112 * 16, 0xffff, dtype=np.uint16)
+    nt = ctypes.c_int32(0)
+    rc = lib.trs_afm_pair_tiles(N, buf.ctypes.data_as(ctypes.c_void_p), buf.size, ctypes.byref(nt))
+    assert rc == 0 and nt.value > 0
+    seen = set()
+    for t in range(nt.value):
+        fields = set()
+        for e in buf[16 * t:16 * t + 16]:
+            if e == 0xffff:
+                continue
+            i, j = int(e) >> 8, int(e) & 0xff
+            assert 0 <= i < j < N
+            assert (i, j) not in seen
+            seen.add((i, j))
+            assert i not in fields and j not in fields
+            fields.update((i, j))
+    assert len(seen) == N * (N - 1) // 2
+    assert np.all(buf[16 * nt.value:] == 0xffff)
+    rounds = N if N % 2 else N - 1
+    assert nt.value <= rounds * ((N // 2 + 15) // 16)
+    if N > 32:
+        assert nt.value == -(-len(seen) // 16)          # the greedy pass reaches the lower bound for these N

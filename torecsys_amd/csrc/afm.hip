@@ -942,6 +942,16 @@ extern "C" int trs_afm_fwd_dropout(const void* x, const void* W1, const void* b1
   return check_launch("afm_fwd");
 }
 
+extern "C" int trs_afm_pair_tiles(int32_t N, uint16_t* tiles, int32_t capacity, int32_t* ntiles) {
+  TRS_REQUIRE(N >= 2 && N <= 64 && tiles && ntiles && capacity >= 0, TRS_EINVAL, "afm_pair_tiles: bad argument");
+  int T = 0;
+  const AfmTiles* t = afm_packed_tiles(N, &T);
+  *ntiles = T;
+  TRS_REQUIRE(T * 16 <= capacity, TRS_EWORKSPACE, "afm_pair_tiles: %d entries needed, room for %d", T * 16, capacity);
+  for (int i = 0; i < T * 16; ++i) tiles[i] = t->e[i];
+  return TRS_OK;
+}
+
 extern "C" size_t trs_afm_bwd_workspace_bytes(int64_t B, int32_t N, int32_t E, int32_t A) {
   if (B <= 0 || E <= 0 || A <= 0) return 256;
   return (size_t)afm_grid(B) * ((size_t)A * E + 2 * A + 1) * 4 + 256;
