@@ -319,3 +319,28 @@ def test_afm_pair_tiles_cover_every_pair_once_and_are_field_disjoint(N):
     assert nt.value <= rounds * ((N // 2 + 15) // 16)
     if N > 32:
         assert nt.value == -(-len(seen) // 16)          # the greedy pass reaches the lower bound for these N
+
+
+@pytest.mark.parametrize("N,C,E", [(5, 4, 3), (33, 8, 4), (39, 6, 2)])
+def test_cin_symmetric_fold_keeps_the_first_layer_contraction(N, C, E):
+    """functional.cin_fold_symmetric: with xk = x0 the oracle's contraction gives the same (B,C,E) for the folded weights
+    (and their gradient w.r.t. x0, which is what the data-gradient kernel returns as dx0 + dxk), in float64"""
+    from torecsys_amd import functional as F_
+    from oracle import cpu_ref as O
+    g = torch.Generator().manual_seed(N)
+    x = torch.randn(3, E, N, generator=g, dtype=torch.float64)
+    W = torch.randn(C, N * N, generator=g, dtype=torch.float64)
+    Wf = F_.cin_fold_symmetric(W.float(), N).double()
+    # exactness of the fold itself is a property of real arithmetic: redo it in float64 for the comparison
+    W3 = W.view(C, N, N)
+    Wf64 = (torch.tril(W3) + torch.triu(W3, 1).transpose(1, 2)).reshape(C, N * N)
+    assert float((Wf - Wf64).abs().max()) <= 1e-6 * float(W.abs().max()) * 2
+    assert float(torch.triu(Wf64.view(C, N, N), 1).abs().max()) == 0.0
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    ya = O.cin_contraction(xa, xa, W.unsqueeze(-1), None)
+    yb = O.cin_contraction(xb, xb, Wf64.unsqueeze(-1), None)
+    assert float((ya - yb).abs().max()) <= 1e-10 * float(ya.abs().max())
+    go = torch.randn(ya.shape, generator=g, dtype=torch.float64)
+    (ya * go).sum().backward()
+    (yb * go).sum().backward()
+    assert float((xa.grad - xb.grad).abs().max()) <= 1e-10 * float(xa.grad.abs().max())

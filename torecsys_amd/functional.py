@@ -1338,6 +1338,15 @@ def cin_cl_supported(x: torch.Tensor, out_channels: Sequence[int], hidden_sizes:
 CIN_FOLD_SYMMETRIC = os.environ.get("TRS_CIN_FOLD", "1") != "0"
 
 
+def cin_fold_symmetric(Wc: torch.Tensor, N: int) -> torch.Tensor:
+    """First CIN layer (xk IS x0, compress_interaction_network.py:125-132 with H_0 = N): the products x0[n]*x0[h] are
+    symmetric in (n, h), so the weight of the pair lives on h <= n as W[n,h] + W[h,n] (fp32 sum) and is 0 above the
+    diagonal.  Wc (C, N*N) -> (C, N*N) fp32; sum_{n,h} W x0[n] x0[h] is unchanged."""
+    C = Wc.shape[0]
+    W3 = Wc.float().view(C, N, N)
+    return (torch.tril(W3) + torch.triu(W3, 1).transpose(1, 2)).reshape(C, N * N)
+
+
 class _CINContractCL(Function):
     @staticmethod
     def forward(ctx, x0T, xkT, Wc, bias, N, H, x0_cf=None, xk_cf=None):
@@ -1352,8 +1361,7 @@ class _CINContractCL(Function):
         # h tiles that then hold only zeros.  Pays once a field needs more than one 32-wide k-step.
         tri = int(xkT.data_ptr() == x0T.data_ptr() and ldk == ld0 and H == N and N > 32 and CIN_FOLD_SYMMETRIC)
         if tri:
-            W3 = Wc.detach().float().view(C, N, N)
-            w = (torch.tril(W3) + torch.triu(W3, 1).transpose(1, 2)).to(torch.bfloat16).view(C, N * N)
+            w = cin_fold_symmetric(Wc.detach(), N).to(torch.bfloat16)
         else:
             w = Wc.to(torch.bfloat16).contiguous()
         bb = None if bias is None else bias.to(torch.bfloat16).contiguous()
