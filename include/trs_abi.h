@@ -323,6 +323,16 @@ int trs_mlp_fused_bwd_data(const void* gy, int64_t rows, int32_t num_layers, con
                            const void* const* weights, const void* const* masks, void* const* gz, float* const* gbias,
                            void* gx, int32_t dtype, void* workspace, size_t ws_bytes, trs_stream_t stream);
 
+/* ---- one wide layer with a short contraction: the input gradient of a deep branch's first Linear ----------------
+ * y (rows, in_f) = x[:, :out_f] @ W, x (rows, x_stride) and W (out_f, in_f) = nn.Linear(in_f, out_f).weight, bf16:
+ * dL/d(input) of that layer from dL/d(pre-activation) (multilayer_perceptron.py:53-61 under autograd).  out_f <= 512
+ * (a 128-row tile of x stays in LDS), in_f % 8 == 0, x_stride % 8 == 0 and >= out_f rounded up to 32 (the columns
+ * past out_f meet zero weight rows).  workspace: trs_rows_gemm_workspace_bytes (fragment-order copy of W).           */
+size_t trs_rows_gemm_workspace_bytes(int32_t out_f, int32_t in_f);
+int trs_rows_gemm_supported(int32_t out_f, int32_t in_f, int32_t x_stride);
+int trs_rows_gemm(const void* x, int64_t rows, int32_t x_stride, const void* W, int32_t out_f, int32_t in_f,
+                  int32_t dtype, void* y, void* workspace, size_t ws_bytes, trs_stream_t stream);
+
 /* ---- row-sharded tables (multi-GPU lookup) -----------------------------
  * Bucket the B*N global row ids of the local batch by owner rank (owner = id / rows_per_rank):
  *   counts[w]  = number of ids owned by rank w                                  (W int64)

@@ -153,3 +153,20 @@ def test_mlp_layer_with_wide_first_layer_takes_hybrid_path(dev):
     for (n, p), g in zip(lay.named_parameters(), ga):
         assert g.shape == p.grad.shape
         assert rel_err(g.float(), p.grad.float()) <= 2 * TOL, n
+
+
+@pytest.mark.parametrize("rows,out_f,in_f,x_stride", [(65536, 400, 2496, 512), (1000, 400, 2496, 512), (129, 72, 200, 96),
+                                                      (4133, 512, 1024, 512), (257, 8, 40, 32), (128, 33 * 8, 2504, 288)])
+def test_rows_gemm_is_the_input_gradient_of_a_linear(dev, rows, out_f, in_f, x_stride):
+    """trs_rows_gemm: y = x[:, :out_f] @ W for short K / wide N (ragged last row tile, widths that are not multiples of 32,
+    columns of x past out_f that must not leak in) against the same product in fp32 on the bf16-rounded operands"""
+    from torecsys_amd import functional as F_
+    g = torch.Generator().manual_seed(rows + out_f)
+    x = torch.randn(rows, x_stride, generator=g).bfloat16()          # garbage past out_f: only zero weight rows may meet it
+    x[:, out_f:(out_f + 31) // 32 * 32] = 0          # the contract: readable, and multiplied by zero rows of W's padding
+    W = (torch.randn(out_f, in_f, generator=g) / out_f ** 0.5).bfloat16()
+    y = F_.rows_gemm(x.to(dev), W.to(dev), out_f, in_f)
+    ref = x[:, :out_f].float() @ W.float()
+    assert y.shape == (rows, in_f) and y.dtype == torch.bfloat16
+    assert rel_err(y.float().cpu(), ref) <= TOL
+    assert rel_err_rows(y.float().cpu(), ref, floor_frac=5e-2) <= 2 * TOL

@@ -61,6 +61,9 @@ SIGNATURES = {
     "trs_afm_bwd_dropout": (c_int32, [_P, _P, _P, _P, _P, _F32, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P,
                                       _P, _P, _SZ, _P]),
     "trs_afm_pair_tiles": (c_int32, [_I32, _P, _I32, _P]),
+    "trs_rows_gemm_workspace_bytes": (_SZ, [_I32, _I32]),
+    "trs_rows_gemm_supported": (c_int32, [_I32, _I32, _I32]),
+    "trs_rows_gemm": (c_int32, [_P, _I64, _I32, _P, _I32, _I32, _I32, _P, _P, _SZ, _P]),
     "trs_afm_bwd_workspace_bytes": (_SZ, [_I64, _I32, _I32, _I32]),
     "trs_afm_bwd": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "trs_pack_columns": (c_int32, [_P, _P, _I32, _I32, _I64, _P, _I32, _P]),

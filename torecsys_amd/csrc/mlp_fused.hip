@@ -353,6 +353,70 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_fwd_kernel(MlpArgs
   }
 }
 
+// ------------------------------------------------------------------------------------------------ one wide layer
+// y[rows, N] = x[rows, :K] @ W[K, N] for a short K (<= 512: a 128-row tile of x stays in LDS) and a wide N -- the input
+// gradient of the first layer of a deep branch (K = 400 hidden units, N = 2496 embedding columns), where the library's
+// 256-wide macro tiles pad K to 512 and run at 0.6 PFLOP/s useful.  The same k-loop as the fused kernels (fragments of
+// W from L2 one k-step ahead, activation rows from LDS), a wave walks column pairs wave, wave + 8, ... two at a time;
+// x is read once, nothing but the bf16 result is written, and there is no barrier between a wave's rounds.
+struct RowsGemmArgs {
+  const void* in;      // (rows x in_stride) bf16
+  const uint4* wf;     // fragment-order W (mlp_prepack_many_kernel, transpose = 1)
+  void* out;           // (rows x out_stride) bf16
+  int64_t rows;
+  int in_stride, K, N, out_cols, out_stride, act_str;
+};
+__global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_rows_gemm_kernel(RowsGemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* act = smem;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, r = lane & 15;
+  const int npairs = a.N >> 5;
+  const int64_t ntiles = (a.rows + MF_ROWS - 1) / MF_ROWS;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t row0 = tile * MF_ROWS;
+    MF_BAR();                                            // the previous tile's rows are no longer read
+    mlp_load_in(act, a.act_str, a.in, a.in_stride, a.K, row0, a.rows);
+    MF_BAR();
+    bf16_t* out0 = reinterpret_cast<bf16_t*>(a.out) + (row0 + r) * a.out_stride + 8 * q;
+    const int64_t left64 = a.rows - row0 - r;
+    const int left = left64 > MF_ROWS ? MF_ROWS : (int)left64;
+    for (int p0 = wave; p0 < npairs; p0 += 2 * MF_WAVES) {
+      MlpShare sh;
+      sh.mt0 = 0;
+      sh.mcnt = MF_MT;
+      sh.pair[0] = p0;
+      sh.pair[1] = p0 + MF_WAVES;
+      sh.npw = sh.pair[1] < npairs ? 2 : 1;
+      mf_f32x4 acc[MF_MT][2 * MF_MAXP];
+#pragma unroll
+      for (int mi = 0; mi < MF_MT; ++mi)
+#pragma unroll
+        for (int t = 0; t < 2 * MF_MAXP; ++t) acc[mi][t] = mf_f32x4{0.f, 0.f, 0.f, 0.f};
+      auto body = [&]<int NPW>() {
+        mlp_gemm_t<MF_MT, NPW>(act, a.act_str, a.wf, a.K, sh, lane, acc);
+#pragma unroll
+        for (int pi = 0; pi < NPW; ++pi) {
+          const bool colok = 32 * sh.pair[pi] + 8 * q < a.out_cols;
+#pragma unroll
+          for (int mi = 0; mi < MF_MT; ++mi) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              v[i] = acc[mi][2 * pi][i];
+              v[4 + i] = acc[mi][2 * pi + 1][i];
+            }
+            if (colok && 16 * mi < left)
+              store_stream(reinterpret_cast<uint4*>(out0 + (size_t)mi * 16 * a.out_stride + 32 * sh.pair[pi]),
+                           Vec16<bf16_t>::pack(v));
+          }
+        }
+      };
+      if (sh.npw == 2) body.template operator()<2>();
+      else body.template operator()<1>();
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ backward (data)
 // step s works on layer l = L-1-s: input = d(pre-activation of layer l) (rows x N_l) in LDS, output = d(input of layer l)
 // = d(output of layer l-1), masked by layer l-1's ReLU mask into d(pre-activation of layer l-1).
@@ -666,4 +730,56 @@ extern "C" int trs_mlp_fused_bwd_data(const void* gy, int64_t rows, int32_t num_
   }
   hipLaunchKernelGGL(mlp_colsum_reduce_many_kernel, dim3((kmax + 63) / 64, L), dim3(1024), 0, s, cs);
   return check_launch("mlp_fused_bwd_data");
+}
+
+/* y (rows x in_f) = x[:, :out_f] (rows x x_stride) @ W (out_f x in_f, row stride in_f), bf16 -- the input gradient of an
+ * nn.Linear(in_f, out_f) whose weight is W.  out_f <= 512, in_f % 8 == 0, x_stride % 8 == 0; the columns of x between
+ * out_f and pad32(out_f) must be readable (they meet zero weight rows).  workspace: trs_rows_gemm_workspace_bytes. */
+extern "C" size_t trs_rows_gemm_workspace_bytes(int32_t out_f, int32_t in_f) {
+  if (out_f <= 0 || in_f <= 0) return 256;
+  return (size_t)pad32(out_f) * pad32(in_f) * 2 + 256;
+}
+
+extern "C" int trs_rows_gemm_supported(int32_t out_f, int32_t in_f, int32_t x_stride) {
+  if (out_f < 8 || out_f > 512 || in_f < 32 || in_f % 8 != 0 || x_stride % 8 != 0 || x_stride < pad32(out_f)) return 0;
+  const size_t lds = (size_t)MF_ROWS * (pad32(out_f) * 2 + 16);
+  return lds <= 160 * 1024 ? 1 : 0;
+}
+
+extern "C" int trs_rows_gemm(const void* x, int64_t rows, int32_t x_stride, const void* W, int32_t out_f, int32_t in_f,
+                             int32_t dtype, void* y, void* workspace, size_t ws_bytes, trs_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  TRS_REQUIRE(dtype == TRS_BF16, TRS_EDTYPE, "rows_gemm: bf16 only");
+  TRS_REQUIRE(trs_rows_gemm_supported(out_f, in_f, x_stride), TRS_ESHAPE, "rows_gemm: unsupported shape (K %d, N %d)", out_f, in_f);
+  TRS_REQUIRE(x && W && y && workspace, TRS_EINVAL, "rows_gemm: NULL pointer");
+  TRS_REQUIRE(ws_bytes >= trs_rows_gemm_workspace_bytes(out_f, in_f), TRS_EWORKSPACE, "rows_gemm: workspace too small");
+  TRS_REQUIRE(aligned16(x) && aligned16(y) && aligned16(workspace), TRS_EALIGN, "rows_gemm: 16-byte alignment");
+  if (rows == 0) return TRS_OK;
+  const int K = pad32(out_f), N = pad32(in_f);
+  MlpPackArgs pk;
+  pk.transpose = 1;
+  pk.job[0] = MlpPackJob{(const bf16_t*)W, nullptr, (bf16_t*)workspace, nullptr, out_f, in_f, N / 16, K / 32, 0};
+  hipLaunchKernelGGL(mlp_prepack_many_kernel, dim3(std::min(256, (N / 16 * (K / 32) * 64 + 255) / 256), 1), dim3(256), 0, s, pk);
+  RowsGemmArgs a;
+  a.in = x;
+  a.wf = (const uint4*)workspace;
+  a.out = y;
+  a.rows = rows;
+  a.in_stride = x_stride;
+  a.K = K;
+  a.N = N;
+  a.out_cols = in_f;
+  a.out_stride = in_f;
+  a.act_str = K * 2 + 16;
+  const size_t lds = (size_t)MF_ROWS * a.act_str;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)mlp_rows_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+        hipSuccess)
+      return check_launch("rows_gemm: LDS attribute");
+    attr = true;
+  }
+  const int64_t ntiles = (rows + MF_ROWS - 1) / MF_ROWS;
+  hipLaunchKernelGGL(mlp_rows_gemm_kernel, dim3((int)std::min<int64_t>(ntiles, MF_GRID)), dim3(64 * MF_WAVES), lds, s, a);
+  return check_launch("rows_gemm");
 }

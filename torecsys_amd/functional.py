@@ -1685,6 +1685,29 @@ class _FusedMLP(Function):
         return (gx.reshape(xshape) if ctx.needs_input_grad[0] else None, *grads)
 
 
+ROWS_GEMM = os.environ.get("TRS_ROWS_GEMM", "1") not in ("", "0")
+ROWS_GEMM_MIN_COLS = 1024       # narrower outputs: the library GEMM is as fast
+
+
+def rows_gemm_supported(g: torch.Tensor, W: torch.Tensor, out_f: int, in_f: int) -> bool:
+    """dL/dx = g[:, :out_f] @ W[:out_f] by trs_rows_gemm: bf16 on the device, a short contraction (out_f <= 512) and a
+    wide result (the 2496 embedding columns in front of a deep branch), enough rows to fill the chip"""
+    if not (ROWS_GEMM and g.is_cuda and g.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and g.dim() == 2
+            and g.is_contiguous() and W.is_contiguous() and g.shape[0] >= 4096 and in_f >= ROWS_GEMM_MIN_COLS
+            and W.shape[1] == in_f and W.shape[0] >= out_f):
+        return False
+    return bool(_abi.load().trs_rows_gemm_supported(int(out_f), int(in_f), int(g.shape[1])))
+
+
+def rows_gemm(g: torch.Tensor, W: torch.Tensor, out_f: int, in_f: int) -> torch.Tensor:
+    y = torch.empty(g.shape[0], in_f, dtype=torch.bfloat16, device=g.device)
+    ws_bytes = size_query("trs_rows_gemm_workspace_bytes", out_f, in_f)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=g.device)
+    call("trs_rows_gemm", ptr(g), g.shape[0], g.shape[1], ptr(W), out_f, in_f, _abi.TRS_BF16, ptr(y), ptr(ws), ws_bytes,
+         stream_ptr())
+    return y
+
+
 class _FusedMLPTail(Function):
     """The layers BEHIND a wide first layer (DeepFM / xDeepFM deep branch: 2496 -> 400 | -> 400 -> 400 -> 1) as one HIP
     kernel per direction: x2 is the first layer's ReLU output at its zero-padded GEMM width, the tail's first weight is

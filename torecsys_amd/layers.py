@@ -762,7 +762,11 @@ class _MLPStack(torch.autograd.Function):
             gbf = None
             if fuse:
                 g2, gbf = F_.relu_bwd_bias(g2, y)
-            gx = (g2 @ W) if need_x else None
+            if need_x and F_.rows_gemm_supported(g2, W, out_f, xin.shape[1]) and W.shape[1] == xin.shape[1]:
+                # wide input, short contraction (2496 <- 400): our own kernel, K not padded to the library's tile
+                gx = F_.rows_gemm(g2, W, out_f, xin.shape[1])
+            else:
+                gx = (g2 @ W) if need_x else None
             S = _split_count(rows, _LinearSplitK.SPLIT_ROWS)
             if need_w or (need_b and gbf is not None):
                 if need_w and S >= 4 and rows % S == 0 and 32 <= g2.shape[1] <= 1024 and 32 <= xin.shape[1] <= 4096 \
