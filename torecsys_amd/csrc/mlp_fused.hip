@@ -228,6 +228,53 @@ __device__ __forceinline__ void mlp_gemm_t(const char* act, int act_str, const u
 #undef TRS_MF_COMMIT
 }
 
+// The same k-loop with the number of k-steps known at compile time: everything is unrolled, so every fragment set is its
+// own value (no loop-carried register roles, nothing for the compiler to copy while a load is in flight) and the loads
+// can run TWO k-steps ahead -- a k-step (32 MFMAs of this wave, 64 with its SIMD neighbour) is about one L2 round trip,
+// one step of distance leaves the wave waiting at most steps.  Only fragments that will be multiplied are requested.
+template <int MCNT, int NPW, int KS>
+__device__ __forceinline__ void mlp_gemm_static(const char* act, int act_str, const uint4* __restrict__ wf,
+                                                const MlpShare& sh, int lane, mf_f32x4 (&acc)[MF_MT][2 * MF_MAXP]) {
+  const int r = lane & 15, q = lane >> 4;
+  const char* arow = act + (sh.mt0 * 16 + r) * act_str + q * 16;
+  const uint4* wbase[NPW];
+#pragma unroll
+  for (int pi = 0; pi < NPW; ++pi) wbase[pi] = wf + ((size_t)(2 * sh.pair[pi]) * KS) * 64 + lane;
+  mf_u32x4 F[KS][2 * NPW];
+  auto fetch = [&](int ks) {
+#pragma unroll
+    for (int pi = 0; pi < NPW; ++pi) {
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(F[ks][2 * pi]) : "v"(wbase[pi] + (size_t)ks * 64));
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(F[ks][2 * pi + 1]) : "v"(wbase[pi] + (size_t)(KS + ks) * 64));
+    }
+  };
+  constexpr int HALF = MCNT >= 2 ? MCNT / 2 : 1;
+  fetch(0);
+  if (KS > 1) fetch(1);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    if (ks + 1 < KS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory");      // the next step's set may stay in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < 2 * NPW; ++t) asm volatile("" : "+v"(F[ks][t]));
+    if (ks + 2 < KS) fetch(ks + 2);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m0 = 0; m0 < MCNT; m0 += HALF) {
+      uint4 Bh[HALF];
+#pragma unroll
+      for (int mi = 0; mi < HALF; ++mi) Bh[mi] = *reinterpret_cast<const uint4*>(arow + (m0 + mi) * 16 * act_str + ks * 64);
+#pragma unroll
+      for (int t = 0; t < 2 * NPW; ++t)
+#pragma unroll
+        for (int mi = 0; mi < HALF; ++mi)
+          acc[m0 + mi][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              __builtin_bit_cast(mf_bf16x8, F[ks][t]), __builtin_bit_cast(mf_bf16x8, Bh[mi]), acc[m0 + mi][t], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // run ``body.template operator()<MCNT, NPW>()`` for this wave's share (wave-uniform dispatch)
 template <typename F>
 __device__ __forceinline__ void mlp_dispatch(const MlpShare& sh, F&& body) {
@@ -393,7 +440,9 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_rows_gemm_kernel(RowsGem
 #pragma unroll
         for (int t = 0; t < 2 * MF_MAXP; ++t) acc[mi][t] = mf_f32x4{0.f, 0.f, 0.f, 0.f};
       auto body = [&]<int NPW>() {
-        mlp_gemm_t<MF_MT, NPW>(act, a.act_str, a.wf, a.K, sh, lane, acc);
+        if (a.K == 416) mlp_gemm_static<MF_MT, NPW, 13>(act, a.act_str, a.wf, sh, lane, acc);      // 400 hidden units
+        else if (a.K == 512) mlp_gemm_static<MF_MT, NPW, 16>(act, a.act_str, a.wf, sh, lane, acc);
+        else mlp_gemm_t<MF_MT, NPW>(act, a.act_str, a.wf, a.K, sh, lane, acc);
 #pragma unroll
         for (int pi = 0; pi < NPW; ++pi) {
           const bool colok = 32 * sh.pair[pi] + 8 * q < a.out_cols;
