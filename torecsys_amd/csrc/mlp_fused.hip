@@ -248,9 +248,19 @@ __device__ __forceinline__ void mlp_gemm_static(const char* act, int act_str, co
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(F[ks][2 * pi + 1]) : "v"(wbase[pi] + (size_t)(KS + ks) * 64));
     }
   };
-  constexpr int HALF = MCNT >= 2 ? MCNT / 2 : 1;
+  // the activation fragments are read two row tiles at a time, the NEXT two (of this k-step or of the next one) while the
+  // current two are multiplied: the rows-GEMM's counters showed half the wave cycles waiting for an issuable instruction
+  constexpr int RT = MCNT >= 2 ? 2 : 1;               // row tiles per read group
+  constexpr int NG = MCNT / RT;                        // groups per k-step
+  uint4 B[KS * NG][RT];
+  auto read_group = [&](int g) {                       // g = ks * NG + group
+#pragma unroll
+    for (int mi = 0; mi < RT; ++mi)
+      B[g][mi] = *reinterpret_cast<const uint4*>(arow + ((g % NG) * RT + mi) * 16 * act_str + (g / NG) * 64);
+  };
   fetch(0);
   if (KS > 1) fetch(1);
+  read_group(0);
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     if (ks + 1 < KS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory");      // the next step's set may stay in flight
@@ -258,20 +268,19 @@ __device__ __forceinline__ void mlp_gemm_static(const char* act, int act_str, co
 #pragma unroll
     for (int t = 0; t < 2 * NPW; ++t) asm volatile("" : "+v"(F[ks][t]));
     if (ks + 2 < KS) fetch(ks + 2);
-    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int m0 = 0; m0 < MCNT; m0 += HALF) {
-      uint4 Bh[HALF];
-#pragma unroll
-      for (int mi = 0; mi < HALF; ++mi) Bh[mi] = *reinterpret_cast<const uint4*>(arow + (m0 + mi) * 16 * act_str + ks * 64);
+    for (int gi = 0; gi < NG; ++gi) {
+      const int g = ks * NG + gi;
+      if (g + 1 < KS * NG) read_group(g + 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < 2 * NPW; ++t)
 #pragma unroll
-        for (int mi = 0; mi < HALF; ++mi)
-          acc[m0 + mi][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-              __builtin_bit_cast(mf_bf16x8, F[ks][t]), __builtin_bit_cast(mf_bf16x8, Bh[mi]), acc[m0 + mi][t], 0, 0, 0);
+        for (int mi = 0; mi < RT; ++mi)
+          acc[gi * RT + mi][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              __builtin_bit_cast(mf_bf16x8, F[ks][t]), __builtin_bit_cast(mf_bf16x8, B[g][mi]), acc[gi * RT + mi][t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
