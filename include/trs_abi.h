@@ -378,6 +378,13 @@ int trs_wgrad_finish(const float* part, int32_t S, int32_t R, int32_t Cc, int32_
  * gw[r, c] = sum_s part[s, c, r] for r < out_rows <= R, c < out_cols <= Cc.                                          */
 int trs_wgrad_finish_t(const float* part, int32_t S, int32_t Cc, int32_t R, int32_t out_rows, int32_t out_cols,
                        int32_t dtype, void* gw, const float* gb_f32, void* gb, trs_stream_t stream);
+/* dW partials by a hand-written kernel instead of a batched library GEMM: part (S, M, N) fp32, slice s = g[rows_s, :M]^T
+ * x[rows_s, :N] over the s-th of S contiguous row ranges (bf16 operands, row strides ldg / ldx, M and N multiples of
+ * 8); trs_wgrad_finish then folds the slices.  S comes from trs_wgrad_rows_splits (0: shape not handled -- more than
+ * 32 blocks of 224 x 224, or fewer than 256 rows).                                                                   */
+int32_t trs_wgrad_rows_splits(int32_t M, int32_t N, int64_t rows);
+int trs_wgrad_rows(const void* g, int32_t ldg, const void* x, int32_t ldx, int64_t rows, int32_t M, int32_t N,
+                   int32_t dtype, int32_t S, float* part, trs_stream_t stream);
 /* n strided 2-D copies in one launch: desc (device, n x 6 int64) = {src address, dst address, rows, cols, src_ld,
  * dst_ld} (sizes in elements of elem_size bytes); max_elems = the largest rows*cols (sizes the grid).  Refreshes the
  * zero-padded copies of an MLP stack's nn.Linear parameters (multilayer_perceptron.py:55-61) before a forward.     */

@@ -170,3 +170,59 @@ def test_rows_gemm_is_the_input_gradient_of_a_linear(dev, rows, out_f, in_f, x_s
     assert y.shape == (rows, in_f) and y.dtype == torch.bfloat16
     assert rel_err(y.float().cpu(), ref) <= TOL
     assert rel_err_rows(y.float().cpu(), ref, floor_frac=5e-2) <= 2 * TOL
+
+
+@pytest.mark.parametrize("rows,M,N", [
+    (8192, 416, 416),        # 2 x 2 blocks of 13 x 13 tiles, waves 7|6 x 7|6
+    (4096 + 40, 416, 416),   # rows not a multiple of 128: the checked loads, zero rows past the end
+    (16384, 416, 64),        # narrow x: one workgroup owns all 26 x 4 tiles (waves 4 x 1)
+    (16384, 64, 416),        # narrow g (waves 1 x 4)
+    (16384, 8, 416),         # the last layer of a stack (one output, padded to 8 columns): half a tile of g
+    (9000, 232, 136),        # 15 x 9 tiles: blocks of 7|8 x 9 tiles, waves with 3 and 4 rows
+    (5000, 48, 72),
+    (4096, 416, 2496),       # 2 x 16 blocks
+])
+def test_wgrad_rows_kernel_against_fp32_product(dev, rows, M, N):
+    """trs_wgrad_rows + trs_wgrad_finish: dW = g^T x summed over the rows, against the fp32 product of the bf16-rounded
+    operands (transpose-detecting: M != N in most cases, random operands).  fp32 accumulation in a different order
+    than the reference: 1e-5 of the largest entry."""
+    from torecsys_amd import functional as F_
+    gen = torch.Generator().manual_seed(rows + M)
+    g = torch.randn(rows, M, generator=gen).bfloat16()
+    x = torch.randn(rows, N, generator=gen).bfloat16()
+    S = int(F_._abi.load().trs_wgrad_rows_splits(M, N, rows))
+    assert S > 0 and S % 8 == 0
+    gw = F_._wgrad_rows(g.to(dev), x.to(dev), M, N, torch.float32)
+    ref = g.double().t() @ x.double()
+    assert gw.shape == (M, N)
+    assert float((gw.double().cpu() - ref).abs().max() / ref.abs().max()) <= 1e-5
+
+
+def test_wgrad_rows_kernel_honours_row_strides_and_corner(dev):
+    """operands that are column slices of wider tensors (ld > M, N) and an output corner smaller than the padded widths
+    (what the MLP stack asks for: 400 x 400 out of 416 x 416)"""
+    from torecsys_amd import functional as F_
+    from torecsys_amd.functional import call, ptr, stream_ptr, _abi
+    rows, ld = 4096, 416
+    gen = torch.Generator().manual_seed(5)
+    g = torch.randn(rows, ld, generator=gen).bfloat16().to(dev)
+    x = torch.randn(rows, ld, generator=gen).bfloat16().to(dev)
+    M, N = 208, 96
+    S = int(_abi.load().trs_wgrad_rows_splits(M, N, rows))
+    part = torch.empty(S, M, N, dtype=torch.float32, device=dev)
+    call("trs_wgrad_rows", ptr(g), ld, ptr(x), ld, rows, M, N, _abi.TRS_BF16, S, ptr(part), stream_ptr())
+    ref = g[:, :M].double().t() @ x[:, :N].double()
+    assert float((part.sum(0).double() - ref).abs().max() / ref.abs().max()) <= 1e-5
+    gw = F_._wgrad_rows(g, x, 400, 400, torch.bfloat16)
+    ref2 = (g.double().t() @ x.double())[:400, :400]
+    assert gw.shape == (400, 400) and rel_err(gw.float().cpu(), ref2.float().cpu()) <= TOL
+
+
+def test_wgrad_rows_falls_back_to_the_library_gemm_below_256_rows(dev):
+    from torecsys_amd import functional as F_
+    assert int(F_._abi.load().trs_wgrad_rows_splits(416, 416, 200)) == 0
+    g = torch.randn(200, 48).bfloat16().to(dev)
+    x = torch.randn(200, 72).bfloat16().to(dev)
+    gw = F_._wgrad_rows(g, x, 40, 70, torch.float32)
+    ref = (g.double().t() @ x.double())[:40, :70]
+    assert float((gw.double() - ref).abs().max() / ref.abs().max()) <= 1e-2

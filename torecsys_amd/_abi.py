@@ -30,6 +30,8 @@ SIGNATURES = {
     "trs_rowdot_bwd": (c_int32, [_P, _P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _SZ, _P]),
     "trs_wgrad_finish": (c_int32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P]),
     "trs_wgrad_finish_t": (c_int32, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P, _P]),
+    "trs_wgrad_rows_splits": (c_int32, [_I32, _I32, _I64]),
+    "trs_wgrad_rows": (c_int32, [_P, _I32, _P, _I32, _I64, _I32, _I32, _I32, _I32, _P, _P]),
     "trs_copy_padded_many": (c_int32, [_P, _I32, _I32, _I64, _P]),
     "trs_cin_glue_blocks": (c_int32, [_I64]),
     "trs_cin_glue_stats": (c_int32, [_P, _I64, _I32, _I32, _I32, _P, _P]),

@@ -1,0 +1,319 @@
+// Weight gradient of a dense layer over the rows of a batch:  dW (M x N) = g^T x,  g (rows, M) = dL/d(pre-activation),
+// x (rows, N) = the layer's input, both bf16 row-major -- the contraction runs over the SLOW dimension of both operands
+// (multilayer_perceptron.py:53-61 under autograd; rows = B for the deep branch of DeepFM / xDeepFM, B*N for the per-field
+// stacks of DCN).  At 416 x 416 one row carries 1664 bytes and 346 kFLOP: 208 FLOP per byte, under the chip's ~310, so
+// the kernel is bound by HBM as long as every operand byte is fetched once -- which is what the layout is built for.
+//
+// One workgroup (4 waves, one per SIMD, 512 registers each) owns a block of at most 14 x 14 output tiles of 16 x 16 (waves as
+// 2 x 2; 28 x 7 / 7 x 28 with the waves as 4 x 1 / 1 x 4 for narrow operands) and a contiguous range of rows; it keeps the
+// whole block in MFMA accumulators (<= 49 tiles per wave) and writes ONE fp32 partial at the end (summed over the row
+// ranges and cast by trs_wgrad_finish).  The workgroups that share a row range (2 x 2 blocks at 416 x 416) sit on the
+// same XCD (blockIdx % 8) so that the second reader of a g / x piece finds it in that XCD's L2.
+//
+// Rows arrive 32 at a time (one MFMA k-step) through registers into a ring of four LDS slots, each
+// [16-column panel][row][32 B]: both MFMA operands want the row index along K, which is what ds_read_b64_tr_b16 delivers
+// from that image (lane i of a 16-lane group gets column i of a [4 rows][16 columns] block).  Odd lane groups take rows
+// +4..7 first, so the two groups of a 32-lane half cover all 64 banks (the permutation of k is the same for both
+// operands); 16 consecutive lanes load 256 contiguous bytes of a row and the 8 lanes of a ds_write_b128 group land on
+// 4 panels x 32 B, which the panel stride (32 mod 128) spreads over the 32 banks.  The pipeline never drains: the
+// fragments of step k+1 are fetched during the last rows of step k, step k+2 is written and step k+6 requested behind
+// the second row of step k, one barrier per step.
+//
+// Measured (2.55 M rows, 416 x 416): 1.22 ms against 1.37 ms for the batched hipBLASLt GEMM it replaces; the loads alone
+// (MFMAs removed) take 0.90-0.96 ms = 4.7 TB/s of distinct bytes, the MFMAs alone 0.64 ms -- the two overlap badly while
+// the chip, throttled to ~2.0 GHz by the matrix pipe, also slows its own L2.  416 x 64: 0.43 ms = 5.7 TB/s (0.52 ms).
+#include "trs_common.hpp"
+
+namespace trs {
+
+typedef __attribute__((ext_vector_type(4))) short wg_s16x4;
+typedef __attribute__((ext_vector_type(8))) short wg_s16x8;
+typedef __attribute__((ext_vector_type(8))) __bf16 wg_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float wg_f32x4;
+
+constexpr int WG_KR = 64;                  // rows per stage (two MFMA k-steps)
+constexpr int WG_KS = 32;                  // rows per step
+constexpr int WG_PANEL = WG_KS * 32 + 32;  // bytes from one 16-column panel of a step to the next (32 mod 128, below)
+constexpr int WG_TC = 7;                   // output tiles per wave and direction, at most
+constexpr int WG_MAXP = 28;                // panels of a stage (g + x), at most
+constexpr int WG_NLD = 16;                 // 16-byte loads per thread and stage, at most
+
+struct WgradArgs {
+  const uint16_t* g;
+  const uint16_t* x;
+  float* part;               // (S, M, N) fp32
+  int64_t rows;
+  int ldg, ldx;              // row strides (elements)
+  int M, N;                  // columns of g / x that count (multiples of 8)
+  int MB, NB;                // output blocks along M / N
+  int slots_per_xcd;         // row ranges per XCD (S = 8 * slots_per_xcd)
+};
+
+__device__ __forceinline__ int split_start(int total, int parts, int k) { return (int)(((int64_t)total * k) / parts); }
+
+// 8 k-values x this lane's column: two transpose reads (``lo`` / ``hi``: the lane's addresses of rows +0..3 / +4..7 -- swapped
+// on odd lane groups --, ``off`` a compile-time byte offset that lands in the instruction's offset field)
+__device__ __forceinline__ wg_bf16x8 tr_frag(const char* lo_p, const char* hi_p, int off) {
+  typedef __attribute__((address_space(3))) wg_s16x4* lds_p;
+  const wg_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lo_p + off));
+  const wg_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(hi_p + off));
+  const wg_s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(wg_bf16x8, v);
+}
+
+// acc += A B, accumulator pinned to the accumulation registers and updated in place.  Written as an asm statement because
+// with 49 tiles per wave hipcc otherwise gives the result a different register from the addend and moves 196 values
+// back every iteration (3.7 register moves per MFMA).  The compiler still tracks the operands (it waits for the LDS reads
+// that feed A and B); what it cannot know is that the statement is an MFMA: the accumulators are read only after the
+// loop, behind explicit wait states.
+__device__ __forceinline__ void wg_mfma(wg_f32x4& acc, const wg_bf16x8& A, const wg_bf16x8& B) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(A), "v"(B));
+}
+
+template <int WM, int WN, int MC, int NC, bool CHECK>
+__global__ __launch_bounds__(256, 1) void wgrad_rows_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char wg_lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, i = lane & 15;
+  const bool odd = q & 1;
+
+  // ---- which block, which rows
+  const int TB = a.MB * a.NB;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int slot = xcd * a.slots_per_xcd + j / TB;
+  const int S = 8 * a.slots_per_xcd;
+  const int tile = j % TB;
+  const int mb = tile / a.NB, nb = tile % a.NB;
+  const int Mt = (a.M + 15) >> 4, Nt = (a.N + 15) >> 4;
+  const int bm0 = split_start(Mt, a.MB, mb), bm1 = split_start(Mt, a.MB, mb + 1);      // block's tiles along M
+  const int bn0 = split_start(Nt, a.NB, nb), bn1 = split_start(Nt, a.NB, nb + 1);
+  const int PM = bm1 - bm0, PN = bn1 - bn0, P = PM + PN;
+  const int wm = wave / WN, wn = wave % WN;
+  const int am0 = split_start(PM, WM, wm), mc = split_start(PM, WM, wm + 1) - am0;     // wave's tiles inside the block
+  const int an0 = split_start(PN, WN, wn), nc = split_start(PN, WN, wn + 1) - an0;
+  // the rows, in steps of 32 (one MFMA k-step); a row range is a multiple of four steps (the loop below has one exit:
+  // a second one in the middle costs 200 spilled registers)
+  const int64_t quads_total = (a.rows + 4 * WG_KS - 1) / (4 * WG_KS);
+  const int64_t h0 = 4 * (quads_total * slot / S), h1 = 4 * (quads_total * (slot + 1) / S);
+  const int64_t n_h = h1 - h0;
+
+  // ---- staging: wave w stages panels 8w .. 8w+7 (256 bytes of a row), four rows per instruction, 16 consecutive lanes
+  // reading 256 contiguous bytes; the 8 lanes of a ds_write_b128 group land on 4 panels x 32 B of one row, which the
+  // panel stride (32 mod 128) spreads over all 32 banks
+  const int panel = wave * 8 + ((lane & 15) >> 1);
+  const int rlow = lane >> 4, half = lane & 1;
+  const bool is_g = panel < PM;
+  const int col = is_g ? 16 * (bm0 + panel) + 8 * half : 16 * (bn0 + panel - PM) + 8 * half;
+  const bool col_ok = panel < P && col + 8 <= (is_g ? a.M : a.N);
+  const int ld = is_g ? a.ldg : a.ldx;
+  const uint16_t* src = (is_g ? a.g : a.x) + col;
+  const int lds_off = panel * WG_PANEL + rlow * 32 + half * 16;
+  const int slot_bytes = P * WG_PANEL;                           // one 32-row step in LDS; four of them form a ring
+
+  // four sets of 8 staging registers per thread, named one by one (an array here ends up in scratch memory): the rows
+  // of steps h+3 .. h+6 are on their way while step h is multiplied -- ~100 KB per CU in flight
+  const int64_t rstep = (int64_t)4 * ld * 2;                    // bytes between this lane's rows of one step
+  uint4 sa0, sa1, sa2, sa3, sa4, sa5, sa6, sa7, sb0, sb1, sb2, sb3, sb4, sb5, sb6, sb7;
+  uint4 sc0, sc1, sc2, sc3, sc4, sc5, sc6, sc7, sd0, sd1, sd2, sd3, sd4, sd5, sd6, sd7;
+#define WG_EACH(X, R) X(R, 0) X(R, 1) X(R, 2) X(R, 3) X(R, 4) X(R, 5) X(R, 6) X(R, 7)
+#define WG_LD(R, t) R##t = *reinterpret_cast<const uint4*>(p + t * rstep);
+#define WG_LDC(R, t) \
+  R##t = (h_ * WG_KS + rlow + 4 * t < a.rows) ? *reinterpret_cast<const uint4*>(p + t * rstep) : make_uint4(0, 0, 0, 0);
+#define WG_WR(R, t) *reinterpret_cast<uint4*>(dst + 4 * t * 32) = R##t;
+#define WG_WR0(R, t) *reinterpret_cast<uint4*>(dst + 4 * t * 32) = make_uint4(0, 0, 0, 0);
+  // no branches around the loads (they would turn the staging registers into merge points the allocator handles
+  // badly): a lane whose columns lie outside its operand reads the operand's first columns instead and never writes
+  // them -- its LDS pieces are zeroed once, here.  CHECK (rows not a multiple of 128): rows past the end read as zero.
+  const char* src_b = reinterpret_cast<const char*>(col_ok ? src : (is_g ? a.g : a.x));
+  const bool writer = panel < P && col_ok;
+  if (panel < P && !col_ok) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      char* dst = wg_lds + b * slot_bytes + lds_off;
+      WG_EACH(WG_WR0, z)
+    }
+  }
+  // the k-th step this workgroup works on (past the end: the last one again -- loaded, never used)
+  auto step_of = [&](int64_t k) { return h0 + (k < n_h ? k : n_h - 1); };
+#define WG_LOAD(R, k)                                                 \
+  {                                                                   \
+    const int64_t h_ = step_of(k);                                    \
+    const char* p = src_b + (h_ * WG_KS + rlow) * ld * 2;             \
+    if (CHECK) {                                                      \
+      WG_EACH(WG_LDC, R)                                              \
+    } else {                                                          \
+      WG_EACH(WG_LD, R)                                               \
+    }                                                                 \
+  }
+#define WG_WRITE(R, b)                                 \
+  {                                                    \
+    char* dst = wg_lds + (b) * slot_bytes + lds_off;   \
+    if (writer) {                                      \
+      WG_EACH(WG_WR, R)                                \
+    }                                                  \
+  }
+
+  wg_f32x4 acc[MC][NC];
+#pragma unroll
+  for (int m = 0; m < MC; ++m)
+#pragma unroll
+    for (int n = 0; n < NC; ++n) acc[m][n] = wg_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // per-lane fragment addresses.  Every wave multiplies MC x NC tiles; a wave that owns fewer runs on into the panels
+  // behind its own (same cost for the workgroup -- the SIMD with the full share sets the pace --, no branches in the
+  // loop, and every read is one base register plus an immediate; the results are dropped at the end)
+  const int frag_lane = (8 * q + (i >> 2)) * 32 + (i & 3) * 8;
+  const int a_lo = am0 * WG_PANEL + frag_lane + (odd ? 128 : 0), a_hi = am0 * WG_PANEL + frag_lane + (odd ? 0 : 128);
+  const int b_lo = (PM + an0) * WG_PANEL + frag_lane + (odd ? 128 : 0);
+  const int b_hi = (PM + an0) * WG_PANEL + frag_lane + (odd ? 0 : 128);
+
+  // One 32-row step out of ring slot ``c`` with the fragments of the NEXT step (ring slot ``nx``) fetched on the way:
+  // the A fragment of row m+2 (of this step or the next) before the MFMAs of row m, the B fragments in place behind
+  // the last row -- so a step starts with its operands in registers.  ``mid`` runs behind the second row: the LDS
+  // writes and global loads of the steps further ahead.
+  constexpr int PD = MC >= 2 ? 2 : 1;
+  wg_bf16x8 Ar[4], Bf[NC];                         // A: a ring of four, row m of step c in slot (MC * c + m) % 4
+#define WG_STEP(c, nx, MID)                                                                                       \
+  {                                                                                                               \
+    const char* cb = wg_lds + (c) * slot_bytes;                                                                   \
+    const char* nb_ = wg_lds + (nx) * slot_bytes;                                                                 \
+    constexpr int RO = (MC * (c)) % 4;                                                                            \
+    _Pragma("unroll") for (int m = 0; m < MC; ++m) {                                                              \
+      const int t = (m + PD) % MC;                                                                                \
+      const char* fb = (m + PD < MC) ? cb : nb_;                                                                  \
+      Ar[(RO + m + PD) % 4] = tr_frag(fb + a_lo, fb + a_hi, t * WG_PANEL);                                        \
+      _Pragma("unroll") for (int n = 0; n < NC; ++n) {                                                            \
+        wg_mfma(acc[m][n], Ar[(RO + m) % 4], Bf[n]);                                                              \
+        if (m == MC - 1) Bf[n] = tr_frag(nb_ + b_lo, nb_ + b_hi, n * WG_PANEL);                                   \
+      }                                                                                                           \
+      if (m == (MC > 2 ? 1 : 0)) { MID }                                                                          \
+    }                                                                                                             \
+  }
+
+  if (n_h > 0) {
+    WG_LOAD(sa, 0)
+    WG_LOAD(sb, 1)
+    WG_WRITE(sa, 0)
+    WG_WRITE(sb, 1)
+    WG_LOAD(sc, 2)
+    WG_LOAD(sd, 3)
+    WG_LOAD(sa, 4)
+    WG_LOAD(sb, 5)
+    __syncthreads();
+    {
+      const char* cb = wg_lds;
+#pragma unroll
+      for (int n = 0; n < NC; ++n) Bf[n] = tr_frag(cb + b_lo, cb + b_hi, n * WG_PANEL);
+#pragma unroll
+      for (int m = 0; m < PD; ++m) Ar[m] = tr_frag(cb + a_lo, cb + a_hi, m * WG_PANEL);
+    }
+    // ring slot k % 4 holds step k, register set j % 4 the rows of step j on their way.  At step k: step k+2 is written
+    // (loaded four steps ago) and the loads of step k+6 leave into the same registers; one barrier per step: slot k+2
+    // complete, slot k free.  (Requesting before the wait, into the set written out a step earlier, measured the same at
+    // 416 x 416 and 15 % slower at 416 x 2496.)
+    for (int64_t k = 0; k < n_h; k += 4) {
+      WG_STEP(0, 1, WG_WRITE(sc, 2) WG_LOAD(sc, k + 6))
+      __syncthreads();
+      WG_STEP(1, 2, WG_WRITE(sd, 3) WG_LOAD(sd, k + 7))
+      __syncthreads();
+      WG_STEP(2, 3, WG_WRITE(sa, 0) WG_LOAD(sa, k + 8))
+      __syncthreads();
+      WG_STEP(3, 0, WG_WRITE(sb, 1) WG_LOAD(sb, k + 9))
+      __syncthreads();
+    }
+  }
+
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs' results are not visible before this
+  // ---- the block's partial: D[m = 4q + e][n = i]
+  float* out = a.part + (int64_t)slot * a.M * a.N;
+#pragma unroll
+  for (int m = 0; m < MC; ++m)
+#pragma unroll
+    for (int n = 0; n < NC; ++n)
+      if (m < mc && n < nc) {
+        const int row = 16 * (bm0 + am0 + m) + 4 * q, c = 16 * (bn0 + an0 + n) + i;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (row + e < a.M && c < a.N) out[(int64_t)(row + e) * a.N + c] = acc[m][n][e];
+      }
+}
+
+struct WgradPlan {
+  int wm, wn, mc, nc, MB, NB, slots_per_xcd;
+};
+
+static inline int tile_class(int t) { return t <= 1 ? 1 : (t <= 4 ? 4 : WG_TC); }
+
+// slots_per_xcd == 0: not handled
+static WgradPlan wgrad_plan(int M, int N, int64_t rows) {
+  WgradPlan p{0, 0, 0, 0, 0, 0, 0};
+  if (M < 8 || N < 8 || (M & 7) || (N & 7) || rows < 4 * WG_KR) return p;
+  const int Mt = (M + 15) / 16, Nt = (N + 15) / 16;
+  if (Mt <= 4 * WG_TC && Nt <= WG_TC && Mt + Nt <= 32 && Mt >= Nt) {
+    p = WgradPlan{4, 1, WG_TC, Nt <= 4 ? 4 : WG_TC, 1, 1, 0};
+  } else if (Mt <= WG_TC && Nt <= 4 * WG_TC && Mt + Nt <= 32) {
+    p = WgradPlan{1, 4, tile_class(Mt), WG_TC, 1, 1, 0};
+  } else {
+    p = WgradPlan{2, 2, WG_TC, WG_TC, (Mt + 2 * WG_TC - 1) / (2 * WG_TC), (Nt + 2 * WG_TC - 1) / (2 * WG_TC), 0};
+    while (!is_pow2(p.MB)) ++p.MB;
+    while (!is_pow2(p.NB)) ++p.NB;
+    if (p.MB * p.NB > 32) return WgradPlan{0, 0, 0, 0, 0, 0, 0};
+  }
+  int slots = 32 / (p.MB * p.NB);
+  // every row range at least 4 stages long
+  const int64_t stages = (rows + WG_KR - 1) / WG_KR;
+  while (slots > 1 && stages / (8 * slots) < 4) slots >>= 1;
+  p.slots_per_xcd = slots;
+  return p;
+}
+
+template <int WM, int WN, int MC, int NC, bool CHECK>
+int wgrad_launch_c(const WgradArgs& a, int grid, size_t lds, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)wgrad_rows_kernel<WM, WN, MC, NC, CHECK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return check_launch("wgrad_rows: LDS attribute");
+    attr = true;
+  }
+  hipLaunchKernelGGL((wgrad_rows_kernel<WM, WN, MC, NC, CHECK>), dim3(grid), dim3(256), lds, s, a);
+  return check_launch("wgrad_rows");
+}
+
+}  // namespace trs
+
+using namespace trs;
+
+template <int WM, int WN, int MC, int NC>
+static int wgrad_launch(const WgradArgs& a, int grid, size_t lds, hipStream_t s) {
+  return (a.rows % (4 * WG_KS)) ? wgrad_launch_c<WM, WN, MC, NC, true>(a, grid, lds, s)
+                          : wgrad_launch_c<WM, WN, MC, NC, false>(a, grid, lds, s);
+}
+
+extern "C" int32_t trs_wgrad_rows_splits(int32_t M, int32_t N, int64_t rows) {
+  const WgradPlan p = wgrad_plan(M, N, rows);
+  return 8 * p.slots_per_xcd;
+}
+
+extern "C" int trs_wgrad_rows(const void* g, int32_t ldg, const void* x, int32_t ldx, int64_t rows, int32_t M, int32_t N,
+                              int32_t dtype, int32_t S, float* part, trs_stream_t stream) {
+  TRS_REQUIRE(dtype == TRS_BF16, TRS_EDTYPE, "wgrad_rows: bf16 operands only");
+  const WgradPlan p = wgrad_plan(M, N, rows);
+  TRS_REQUIRE(p.slots_per_xcd > 0 && S == 8 * p.slots_per_xcd, TRS_ESHAPE,
+              "wgrad_rows: (M=%d, N=%d, rows=%lld) takes %d row ranges, caller passed %d", M, N, (long long)rows,
+              8 * p.slots_per_xcd, S);
+  TRS_REQUIRE(ldg >= M && ldx >= N && (ldg & 7) == 0 && (ldx & 7) == 0 && aligned16(g) && aligned16(x), TRS_ESHAPE,
+              "wgrad_rows: row strides must be multiples of 8 elements and cover M / N, operands 16-byte aligned");
+  if (!g || !x || !part) return fail(TRS_EINVAL, "wgrad_rows: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  WgradArgs a{(const uint16_t*)g, (const uint16_t*)x, part, rows, ldg, ldx, M, N, p.MB, p.NB, p.slots_per_xcd};
+  const int Mt = (M + 15) / 16, Nt = (N + 15) / 16;
+  const int PM = (Mt + p.MB - 1) / p.MB, PN = (Nt + p.NB - 1) / p.NB;
+  const size_t lds = (size_t)(4 * (PM + PN) + WG_TC) * WG_PANEL;      // + the panels a short wave runs on into
+  const int grid = 8 * p.slots_per_xcd * p.MB * p.NB;
+  if (p.wm == 2) return wgrad_launch<2, 2, WG_TC, WG_TC>(a, grid, lds, s);
+  if (p.wm == 4) return p.nc == 4 ? wgrad_launch<4, 1, WG_TC, 4>(a, grid, lds, s) : wgrad_launch<4, 1, WG_TC, WG_TC>(a, grid, lds, s);
+  if (p.mc == 1) return wgrad_launch<1, 4, 1, WG_TC>(a, grid, lds, s);
+  if (p.mc == 4) return wgrad_launch<1, 4, 4, WG_TC>(a, grid, lds, s);
+  return wgrad_launch<1, 4, WG_TC, WG_TC>(a, grid, lds, s);
+}

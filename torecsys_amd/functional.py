@@ -1760,10 +1760,24 @@ class _FusedMLPTail(Function):
         return (gx if ctx.needs_input_grad[0] else None, *grads)
 
 
+WGRAD_ROWS = os.environ.get("TRS_WGRAD_ROWS", "1") not in ("", "0")
+
+
 def _wgrad_rows(g: torch.Tensor, inp: torch.Tensor, out_f: int, in_f: int, dtype) -> torch.Tensor:
     """dW = g^T @ inp over the rows (K = rows): split-K batched GEMM with fp32 partials, folded / sliced / cast by
     trs_wgrad_finish (the padding columns of g / inp are dropped there)."""
     rows = g.shape[0]
+    if (WGRAD_ROWS and g.is_cuda and g.dtype == torch.bfloat16 and inp.dtype == torch.bfloat16 and g.is_contiguous()
+            and inp.is_contiguous()):
+        S = int(_abi.load().trs_wgrad_rows_splits(int(g.shape[1]), int(inp.shape[1]), int(rows)))
+        if S > 0:
+            part = torch.empty(S, g.shape[1], inp.shape[1], dtype=torch.float32, device=g.device)
+            call("trs_wgrad_rows", ptr(g), g.shape[1], ptr(inp), inp.shape[1], rows, g.shape[1], inp.shape[1],
+                 _abi.TRS_BF16, S, ptr(part), stream_ptr())
+            gw = torch.empty(out_f, in_f, dtype=dtype, device=g.device)
+            call("trs_wgrad_finish", ptr(part), S, part.shape[1], part.shape[2], out_f, in_f, value_dtype_code(gw),
+                 ptr(gw), ptr(None), ptr(None), stream_ptr())
+            return gw
     S = 0
     # 192 batches measured best at 2.5 M rows (416 x 416: 1.33 ms against 1.48 at 384 and 1.53 at 96; 416 x 64: 0.49 against
     # 0.57 / 0.54): enough workgroups for the chip, partials still small against the operands
