@@ -258,6 +258,8 @@ static WgradPlan wgrad_plan(int M, int N, int64_t rows) {
     while (!is_pow2(p.MB)) ++p.MB;
     while (!is_pow2(p.NB)) ++p.NB;
     if (p.MB * p.NB > 32) return WgradPlan{0, 0, 0, 0, 0, 0, 0};
+    // tiles per wave along N once the blocks are cut (2496 columns in 16 blocks: 9 | 10 tiles, 5 per wave)
+    if (((Nt + p.NB - 1) / p.NB + 1) / 2 <= 5) p.nc = 5;
   }
   int slots = 32 / (p.MB * p.NB);
   // every row range at least 4 stages long
@@ -311,7 +313,8 @@ extern "C" int trs_wgrad_rows(const void* g, int32_t ldg, const void* x, int32_t
   const int PM = (Mt + p.MB - 1) / p.MB, PN = (Nt + p.NB - 1) / p.NB;
   const size_t lds = (size_t)(4 * (PM + PN) + WG_TC) * WG_PANEL;      // + the panels a short wave runs on into
   const int grid = 8 * p.slots_per_xcd * p.MB * p.NB;
-  if (p.wm == 2) return wgrad_launch<2, 2, WG_TC, WG_TC>(a, grid, lds, s);
+  if (p.wm == 2)
+    return p.nc == 5 ? wgrad_launch<2, 2, WG_TC, 5>(a, grid, lds, s) : wgrad_launch<2, 2, WG_TC, WG_TC>(a, grid, lds, s);
   if (p.wm == 4) return p.nc == 4 ? wgrad_launch<4, 1, WG_TC, 4>(a, grid, lds, s) : wgrad_launch<4, 1, WG_TC, WG_TC>(a, grid, lds, s);
   if (p.mc == 1) return wgrad_launch<1, 4, 1, WG_TC>(a, grid, lds, s);
   if (p.mc == 4) return wgrad_launch<1, 4, 4, WG_TC>(a, grid, lds, s);
