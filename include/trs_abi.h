@@ -312,16 +312,21 @@ int trs_relu_bwd_bias(const void* gy, const void* y, int64_t rows, int32_t C, in
  * bwd_data: gy (rows, widths[num_layers]) -> gz[l] (rows, pad32(widths[l+1])), l < num_layers-1 = gradient w.r.t. the
  *      pre-activation of layer l (that of the last layer is gy itself); gbias[l] (pad32(widths[l+1]) fp32, written) for
  *      every layer; gx (rows, widths[0]).  Weight gradients are left to the caller: dW_l = gz_l^T @ input_l.
+ * A stack fed by the ReLU output of a layer in front of it (the hipBLASLt first layer of a deep branch): mask_in
+ *      (trs_mlp_fused_mask_bytes(rows) bytes, may be NULL) receives the sign bits [x > 0] in the forward; given to the
+ *      backward together with gbias_in (pad32(widths[0]) fp32, written), gx becomes the gradient w.r.t. that layer's
+ *      pre-activation, gx * [x > 0], and gbias_in its column sums = that layer's bias gradient (needs num_layers <= 7).
  * trs_mlp_fused_supported: 1 when the widths fit the kernel (and its LDS budget).                              */
 int trs_mlp_fused_supported(int32_t num_layers, const int32_t* widths);
 size_t trs_mlp_fused_workspace_bytes(int32_t num_layers, const int32_t* widths);
 size_t trs_mlp_fused_mask_bytes(int64_t rows);
 int trs_mlp_fused_fwd(const void* x, int64_t rows, int32_t num_layers, const int32_t* widths,
                       const void* const* weights, const void* const* biases, void* const* hidden, void* const* masks,
-                      void* y, int32_t dtype, void* workspace, size_t ws_bytes, trs_stream_t stream);
+                      void* mask_in, void* y, int32_t dtype, void* workspace, size_t ws_bytes, trs_stream_t stream);
 int trs_mlp_fused_bwd_data(const void* gy, int64_t rows, int32_t num_layers, const int32_t* widths,
                            const void* const* weights, const void* const* masks, void* const* gz, float* const* gbias,
-                           void* gx, int32_t dtype, void* workspace, size_t ws_bytes, trs_stream_t stream);
+                           void* gx, const void* mask_in, float* gbias_in, int32_t dtype, void* workspace,
+                           size_t ws_bytes, trs_stream_t stream);
 
 /* ---- one wide layer with a short contraction: the input gradient of a deep branch's first Linear ----------------
  * y (rows, in_f) = x[:, :out_f] @ W, x (rows, x_stride) and W (out_f, in_f) = nn.Linear(in_f, out_f).weight, bf16:

@@ -116,7 +116,8 @@ def test_mlp_layer_takes_fused_path_and_matches_gemm_path(dev):
 
 def test_mlp_layer_with_wide_first_layer_takes_hybrid_path(dev):
     """DeepFM's deep branch (2496 -> 400 -> 400 -> 400 -> 1 on B rows): first layer on hipBLASLt, everything behind it
-    in the fused kernels (F_._FusedMLPTail).  Checked against the fp32 oracle on the forward, and against the all-GEMM
+    in the fused kernels, one autograd node (layers._HybridMLP: the first layer's ReLU-backward and bias gradient come out
+    of the fused backward kernel).  Checked against the fp32 oracle on the forward, and against the all-GEMM
     arrangement it replaces on every gradient (two bf16 paths, each within 1e-2 of the oracle: up to 2e-2 apart)."""
     from torecsys_amd import functional as F_
     from torecsys_amd import layers as L
@@ -124,13 +125,13 @@ def test_mlp_layer_with_wide_first_layer_takes_hybrid_path(dev):
     lay = L.DNNLayer(inputs_size=2496, output_size=1, layer_sizes=[400, 400, 400]).to(dev).bfloat16()
     x = (0.5 * torch.randn(8192 + 37, 2496, device=dev)).bfloat16()          # ragged last row tile
     calls = []
-    orig = F_._FusedMLPTail.apply
-    F_._FusedMLPTail.apply = lambda *a: (calls.append(1), orig(*a))[1]
+    orig = L._HybridMLP.apply
+    L._HybridMLP.apply = lambda *a: (calls.append(1), orig(*a))[1]
     try:
         xa = x.clone().requires_grad_()
         ya = lay(xa)
     finally:
-        F_._FusedMLPTail.apply = orig
+        L._HybridMLP.apply = orig
     assert calls, "the layer did not take the hybrid path"
     assert ya.names == ("B", "O") and ya.shape == (x.shape[0], 1)
     lin = [m for m in lay.model if isinstance(m, torch.nn.Linear)]
@@ -226,3 +227,27 @@ def test_wgrad_rows_falls_back_to_the_library_gemm_below_256_rows(dev):
     gw = F_._wgrad_rows(g, x, 40, 70, torch.float32)
     ref = (g.double().t() @ x.double())[:40, :70]
     assert float((gw.double() - ref).abs().max() / ref.abs().max()) <= 1e-2
+
+
+def test_fused_backward_masks_its_input_gradient_with_the_upstream_relu(dev):
+    """mask_in / gbias_in of trs_mlp_fused_*: for a stack fed by relu(z), gx must be dL/dz = dL/dx * [x > 0] and gbias_in
+    its column sums -- against the unmasked gradient of the same call, masked and summed here (ragged last row tile,
+    input columns that are exactly zero in some rows)"""
+    from torecsys_amd import functional as F_
+    gen = torch.Generator().manual_seed(11)
+    rows, widths = 1000 + 19, [416, 400, 400, 8]
+    x = torch.relu(torch.randn(rows, widths[0], generator=gen)).bfloat16().to(dev)
+    Ws = [(torch.randn(widths[l + 1], widths[l], generator=gen) / widths[l] ** 0.5).bfloat16().to(dev) for l in range(3)]
+    bs = [(0.1 * torch.randn(widths[l + 1], generator=gen)).bfloat16().to(dev) for l in range(3)]
+    y, hidden, masks, mask_in = F_.fused_mlp_forward_raw(x, Ws, bs, input_mask=True)
+    y0, _, _ = F_.fused_mlp_forward_raw(x, Ws, bs)
+    assert torch.equal(y, y0)
+    gy = torch.randn(rows, widths[-1], generator=gen).bfloat16().to(dev)
+    gx0, gz0, gb0, none = F_.fused_mlp_backward_raw(gy, widths, Ws, masks)
+    gx1, gz1, gb1, gb_in = F_.fused_mlp_backward_raw(gy, widths, Ws, masks, mask_in)
+    assert none is None
+    assert all(torch.equal(a, b) for a, b in zip(gz0, gz1)) and all(torch.equal(a, b) for a, b in zip(gb0, gb1))
+    want = torch.where(x > 0, gx0, torch.zeros_like(gx0))
+    assert torch.equal(gx1, want)
+    ref = want.double().sum(0)
+    assert float((gb_in[:widths[0]].double() - ref).abs().max() / ref.abs().max()) <= 1e-5

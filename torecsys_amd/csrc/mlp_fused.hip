@@ -133,6 +133,9 @@ struct MlpArgs {
   int nbias;          // forward: total padded bias entries (copied to LDS)
   int64_t rows;
   int act_str;        // bytes per LDS activation row
+  uint8_t* mask_in;   // sign bits [input > 0] of the stack's INPUT rows (an upstream ReLU's output), in the item order of
+                      // the backward's last step: written by the forward, applied by the backward; may be null
+  float* colsum_in;   // backward, with mask_in: partial column sums of the masked input gradient, [gridDim.x][step N]
 };
 
 // tiles of the step owned by this wave: wide outputs split the 32-column pairs over the 8 waves (all 8 row tiles
@@ -328,6 +331,31 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_fwd_kernel(MlpArgs
     const int64_t row0 = tile * MF_ROWS;
     mlp_load_in(act, a.act_str, a.in, a.in_stride, a.step[0].K, row0, a.rows);
     MF_BAR();
+    if (a.mask_in != nullptr) {
+      // the input rows are the output of a ReLU in front of this stack: their sign bits, taken from LDS in the item order
+      // in which the backward's last step (output width = this input width) hands the same lane its 8 columns
+      const MlpShare shi = mlp_share(a.step[0].K, wave);
+      unsigned mb[4] = {0u, 0u, 0u, 0u};
+      const char* li0 = act + (shi.mt0 * 16 + r) * a.act_str + 16 * q;
+      mlp_dispatch(shi, [&]<int MCNT, int NPW>() {
+#pragma unroll
+        for (int pi = 0; pi < NPW; ++pi)
+#pragma unroll
+          for (int mi = 0; mi < MCNT; ++mi) {
+            const uint4 u = *reinterpret_cast<const uint4*>(li0 + mi * 16 * a.act_str + shi.pair[pi] * 64);
+            const unsigned w[4] = {u.x, u.y, u.z, u.w};
+            unsigned bits = 0;
+#pragma unroll
+            for (int j = 7; j >= 0; --j) {
+              const int v = (j & 1) ? (int)(w[j >> 1] & 0xffff0000u) : (int)(w[j >> 1] << 16);
+              bits = (bits << 1) | (v > 0 ? 1u : 0u);
+            }
+            mb[(pi * MCNT + mi) >> 2] |= bits << (8 * ((pi * MCNT + mi) & 3));
+          }
+      });
+      store_stream(reinterpret_cast<uint4*>(a.mask_in + tile * MF_MASK_TILE) + threadIdx.x,
+                   make_uint4(mb[0], mb[1], mb[2], mb[3]));
+    }
     int boff = 0;
     for (int l = 0; l < a.nsteps; ++l) {
       const MlpStep st = a.step[l];
@@ -482,9 +510,9 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_bwd_kernel(MlpArgs
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* act = smem;
   float* scratch = reinterpret_cast<float*>(act + MF_ROWS * a.act_str);              // [8 row slices][512]
-  float* csum = scratch + 8 * 512;                                                    // [nsteps][512] running column sums
+  float* csum = scratch + 8 * 512;                                                    // [nsteps + 1][512] running column sums
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, r = lane & 15;
-  for (int i = threadIdx.x; i < a.nsteps * 512; i += blockDim.x) csum[i] = 0.f;
+  for (int i = threadIdx.x; i < (a.nsteps + 1) * 512; i += blockDim.x) csum[i] = 0.f;
   const int64_t ntiles = (a.rows + MF_ROWS - 1) / MF_ROWS;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t row0 = tile * MF_ROWS;
@@ -555,7 +583,7 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_bwd_kernel(MlpArgs
                 v[j] = __int_as_float(__float_as_int(v[j]) & __builtin_amdgcn_sbfe(word, 8 * ((pi * MCNT + mi) & 3) + j, 1));
             }
             const uint4 pk = Vec16<bf16_t>::pack(v);
-            if (!last) *reinterpret_cast<uint4*>(lds0 + mi * 16 * a.act_str + sh.pair[pi] * 64) = pk;
+            if (!last || a.colsum_in != nullptr) *reinterpret_cast<uint4*>(lds0 + mi * 16 * a.act_str + sh.pair[pi] * 64) = pk;
             if (colok && 16 * mi < left)      // as in the forward: from the registers
               store_stream(reinterpret_cast<uint4*>(out0 + (size_t)mi * 16 * st.out_stride + 32 * sh.pair[pi]), pk);
           }
@@ -563,10 +591,40 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_bwd_kernel(MlpArgs
       });
       if (!last) MF_BAR();
     }
+    if (a.colsum_in != nullptr) {
+      // the stack's input came out of a ReLU (mask_in): the masked input gradient is the gradient of that layer's
+      // pre-activation, and its column sums are that layer's bias gradient -- one more pass over the rows in LDS
+      const int Kin = a.step[a.nsteps - 1].N;
+      MF_BAR();
+      const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
+      if (c < (Kin >> 3)) {
+        float sum[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum[j] = 0.f;
+#pragma unroll 4
+        for (int rr = 0; rr < MF_ROWS / 8; ++rr) {
+          float f[8];
+          Vec16<bf16_t>::unpack(*reinterpret_cast<const uint4*>(act + (sl * (MF_ROWS / 8) + rr) * a.act_str + c * 16), f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) sum[j] += f[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) scratch[sl * 512 + c * 8 + j] = sum[j];
+      }
+      MF_BAR();
+      if (threadIdx.x < Kin) {
+        float t = 0.f;
+#pragma unroll
+        for (int sl2 = 0; sl2 < 8; ++sl2) t += scratch[sl2 * 512 + threadIdx.x];
+        csum[a.nsteps * 512 + threadIdx.x] += t;
+      }
+    }
   }
   for (int s = 0; s < a.nsteps; ++s)
     if (a.step[s].colsum != nullptr && threadIdx.x < a.step[s].K)
       a.step[s].colsum[(size_t)blockIdx.x * a.step[s].K + threadIdx.x] = csum[s * 512 + threadIdx.x];
+  if (a.colsum_in != nullptr && threadIdx.x < a.step[a.nsteps - 1].N)
+    a.colsum_in[(size_t)blockIdx.x * a.step[a.nsteps - 1].N + threadIdx.x] = csum[a.nsteps * 512 + threadIdx.x];
 }
 
 // out[i] = sum_p part[p][i]
@@ -650,14 +708,14 @@ extern "C" size_t trs_mlp_fused_mask_bytes(int64_t rows) {
 extern "C" int trs_mlp_fused_supported(int32_t num_layers, const int32_t* widths) {
   if (!mlp_fused_covers(num_layers, widths)) return 0;
   const size_t lds = (size_t)MF_ROWS * mlp_act_str(num_layers, widths) + 8 * 512 * 4 +
-                     (size_t)num_layers * 512 * 4;
+                     (size_t)(num_layers + 1) * 512 * 4;
   return lds <= 160 * 1024 ? 1 : 0;
 }
 
 extern "C" int trs_mlp_fused_fwd(const void* x, int64_t rows, int32_t num_layers, const int32_t* widths,
                                  const void* const* weights, const void* const* biases, void* const* hidden,
-                                 void* const* masks, void* y, int32_t dtype, void* workspace, size_t ws_bytes,
-                                 trs_stream_t stream) {
+                                 void* const* masks, void* mask_in, void* y, int32_t dtype, void* workspace,
+                                 size_t ws_bytes, trs_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   TRS_REQUIRE(dtype == TRS_BF16, TRS_EDTYPE, "mlp_fused_fwd: bf16 only");
   TRS_REQUIRE(trs_mlp_fused_supported(num_layers, widths), TRS_ESHAPE, "mlp_fused_fwd: unsupported layer widths");
@@ -673,6 +731,8 @@ extern "C" int trs_mlp_fused_fwd(const void* x, int64_t rows, int32_t num_layers
   a.rows = rows;
   a.nbias = 0;
   a.act_str = mlp_act_str(L, widths);
+  a.mask_in = (uint8_t*)mask_in;
+  a.colsum_in = nullptr;
   char* wsp = (char*)workspace;
   float* bias_base = (float*)(wsp + mlp_frag_bytes(L, widths));
   size_t woff = 0, boff = 0;
@@ -718,8 +778,8 @@ extern "C" int trs_mlp_fused_fwd(const void* x, int64_t rows, int32_t num_layers
  * layer is gy itself.  gbias[l] (l = 0..L-1): pad32(widths[l+1]) fp32 each, written.  gx: (rows x widths[0]). */
 extern "C" int trs_mlp_fused_bwd_data(const void* gy, int64_t rows, int32_t num_layers, const int32_t* widths,
                                       const void* const* weights, const void* const* masks, void* const* gz,
-                                      float* const* gbias, void* gx, int32_t dtype, void* workspace, size_t ws_bytes,
-                                      trs_stream_t stream) {
+                                      float* const* gbias, void* gx, const void* mask_in, float* gbias_in, int32_t dtype,
+                                      void* workspace, size_t ws_bytes, trs_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   TRS_REQUIRE(dtype == TRS_BF16, TRS_EDTYPE, "mlp_fused_bwd_data: bf16 only");
   TRS_REQUIRE(trs_mlp_fused_supported(num_layers, widths), TRS_ESHAPE, "mlp_fused_bwd_data: unsupported layer widths");
@@ -727,9 +787,12 @@ extern "C" int trs_mlp_fused_bwd_data(const void* gy, int64_t rows, int32_t num_
   TRS_REQUIRE(ws_bytes >= trs_mlp_fused_workspace_bytes(num_layers, widths), TRS_EWORKSPACE,
               "mlp_fused_bwd_data: workspace too small");
   const int L = num_layers;
+  TRS_REQUIRE((mask_in == nullptr) == (gbias_in == nullptr) && (mask_in == nullptr || (L + 1 <= MF_MAXL && gx != nullptr)),
+              TRS_EINVAL, "mlp_fused_bwd_data: mask_in and gbias_in come together (and with gx, at most %d layers)", MF_MAXL - 1);
   if (rows == 0) {
     for (int l = 0; l < L; ++l)
       if (hipMemsetAsync(gbias[l], 0, (size_t)pad32(widths[l + 1]) * 4, s) != hipSuccess) return check_launch("mlp_fused_bwd_data");
+    if (gbias_in && hipMemsetAsync(gbias_in, 0, (size_t)pad32(widths[0]) * 4, s) != hipSuccess) return check_launch("mlp_fused_bwd_data");
     return TRS_OK;
   }
   MlpArgs a;
@@ -761,12 +824,14 @@ extern "C" int trs_mlp_fused_bwd_data(const void* gy, int64_t rows, int32_t num_
     st.relu = 0;
     st.out = l > 0 ? gz[l - 1] : gx;
     st.out_stride = l > 0 ? N : widths[0];
-    st.mask = l > 0 ? (uint8_t*)masks[l - 1] : nullptr;
+    st.mask = l > 0 ? (uint8_t*)masks[l - 1] : (uint8_t*)mask_in;
     st.colsum = part_base + poff;
     woff += (size_t)K * N * 2;
     poff += (size_t)grid * K;
   }
-  const size_t lds = (size_t)MF_ROWS * a.act_str + 8 * 512 * 4 + (size_t)L * 512 * 4;
+  a.mask_in = nullptr;
+  a.colsum_in = mask_in != nullptr ? part_base + poff : nullptr;      // (the workspace counts widths[0] as well)
+  const size_t lds = (size_t)MF_ROWS * a.act_str + 8 * 512 * 4 + (size_t)(L + 1) * 512 * 4;
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)mlp_fused_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
@@ -786,7 +851,15 @@ extern "C" int trs_mlp_fused_bwd_data(const void* gy, int64_t rows, int32_t num_
     cs.n[sidx] = a.step[sidx].K;
     kmax = std::max(kmax, a.step[sidx].K);
   }
-  hipLaunchKernelGGL(mlp_colsum_reduce_many_kernel, dim3((kmax + 63) / 64, L), dim3(1024), 0, s, cs);
+  int nsum = L;
+  if (a.colsum_in != nullptr) {
+    cs.part[L] = a.colsum_in;
+    cs.out[L] = gbias_in;
+    cs.n[L] = pad32(widths[0]);
+    kmax = std::max(kmax, cs.n[L]);
+    nsum = L + 1;
+  }
+  hipLaunchKernelGGL(mlp_colsum_reduce_many_kernel, dim3((kmax + 63) / 64, nsum), dim3(1024), 0, s, cs);
   return check_launch("mlp_fused_bwd_data");
 }
 

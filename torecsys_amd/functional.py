@@ -1618,23 +1618,46 @@ def mlp_fused_supported(x: torch.Tensor, widths: Sequence[int]) -> bool:
     return bool(_abi.load().trs_mlp_fused_supported(len(widths) - 1, _i32_array(widths)))
 
 
-def fused_mlp_forward_raw(x2: torch.Tensor, Ws: Sequence[torch.Tensor], bs: Sequence[torch.Tensor]):
+def fused_mlp_forward_raw(x2: torch.Tensor, Ws: Sequence[torch.Tensor], bs: Sequence[torch.Tensor],
+                          input_mask: bool = False):
     """trs_mlp_fused_fwd on rows x2 (rows, widths[0]): returns (y (rows, widths[L]), hidden [(rows, pad32(w))] -- the
     ReLU outputs of the hidden layers, zero in the padding columns --, masks [the sign bits of the hidden layers in the
-    kernel's own order: opaque bytes for trs_mlp_fused_bwd_data])."""
+    kernel's own order: opaque bytes for trs_mlp_fused_bwd_data]) and, with ``input_mask`` (x2 is itself a ReLU output),
+    the sign bits of x2 in the same form as a fourth value."""
     L = len(Ws)
     widths = [Ws[0].shape[1]] + [w.shape[0] for w in Ws]
     rows, dev = x2.shape[0], x2.device
     hidden = [torch.empty(rows, _pad32(widths[l + 1]), dtype=torch.bfloat16, device=dev) for l in range(L - 1)]
     mask_bytes = size_query("trs_mlp_fused_mask_bytes", rows)
     masks = [torch.empty(mask_bytes, dtype=torch.uint8, device=dev) for _ in range(L - 1)]
+    mask_in = torch.empty(mask_bytes, dtype=torch.uint8, device=dev) if input_mask else None
     y = torch.empty(rows, widths[L], dtype=torch.bfloat16, device=dev)
     wl = _i32_array(widths)
     ws_bytes = size_query("trs_mlp_fused_workspace_bytes", L, wl)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     call("trs_mlp_fused_fwd", ptr(x2), rows, L, wl, _ptr_array(Ws), _ptr_array(bs), _ptr_array(hidden),
-         _ptr_array(masks), ptr(y), _abi.TRS_BF16, ptr(ws), ws_bytes, stream_ptr())
+         _ptr_array(masks), ptr(mask_in), ptr(y), _abi.TRS_BF16, ptr(ws), ws_bytes, stream_ptr())
+    if input_mask:
+        return y, hidden, masks, mask_in
     return y, hidden, masks
+
+
+def fused_mlp_backward_raw(gy2: torch.Tensor, widths: Sequence[int], Ws: Sequence[torch.Tensor],
+                           masks: Sequence[torch.Tensor], mask_in: Optional[torch.Tensor] = None):
+    """trs_mlp_fused_bwd_data: (gx, gz [d(pre-activation) of the hidden layers], gb [fp32 bias gradients, padded]) and,
+    with ``mask_in``, gb_in: gx is then masked by the upstream ReLU and gb_in holds its column sums."""
+    L = len(Ws)
+    rows, dev = gy2.shape[0], gy2.device
+    gz = [torch.empty(rows, _pad32(widths[l + 1]), dtype=torch.bfloat16, device=dev) for l in range(L - 1)]
+    gb = [torch.empty(_pad32(widths[l + 1]), dtype=torch.float32, device=dev) for l in range(L)]
+    gx = torch.empty(rows, widths[0], dtype=torch.bfloat16, device=dev)   # the kernel always writes dL/dx (its last GEMM)
+    gb_in = torch.empty(_pad32(widths[0]), dtype=torch.float32, device=dev) if mask_in is not None else None
+    wl = _i32_array(widths)
+    ws_bytes = size_query("trs_mlp_fused_workspace_bytes", L, wl)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    call("trs_mlp_fused_bwd_data", ptr(gy2), rows, L, wl, _ptr_array(Ws), _ptr_array(masks), _ptr_array(gz),
+         _ptr_array(gb), ptr(gx), ptr(mask_in), ptr(gb_in), _abi.TRS_BF16, ptr(ws), ws_bytes, stream_ptr())
+    return gx, gz, gb, gb_in
 
 
 class _FusedMLP(Function):
@@ -1664,14 +1687,7 @@ class _FusedMLP(Function):
         hidden, masks = saved[1 + L:L + L], saved[L + L:]
         rows, dev = x2.shape[0], x2.device
         gy2 = gy.reshape(rows, widths[L]).contiguous()
-        gz = [torch.empty(rows, _pad32(widths[l + 1]), dtype=torch.bfloat16, device=dev) for l in range(L - 1)]
-        gb = [torch.empty(_pad32(widths[l + 1]), dtype=torch.float32, device=dev) for l in range(L)]
-        gx = torch.empty_like(x2)           # the kernel always writes dL/dx (the last GEMM of its chain)
-        wl = _i32_array(widths)
-        ws_bytes = size_query("trs_mlp_fused_workspace_bytes", L, wl)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        call("trs_mlp_fused_bwd_data", ptr(gy2), rows, L, wl, _ptr_array(Ws), _ptr_array(masks), _ptr_array(gz),
-             _ptr_array(gb), ptr(gx), _abi.TRS_BF16, ptr(ws), ws_bytes, stream_ptr())
+        gx, gz, gb, _ = fused_mlp_backward_raw(gy2, widths, Ws, masks)
         grads = []
         for l in range(L):
             inp = x2 if l == 0 else hidden[l - 1]               # (rows, widths[l] | pad32)
@@ -1741,14 +1757,7 @@ class _FusedMLPTail(Function):
             gy2[:, :gy.shape[1]] = gy
         else:
             gy2 = gy.contiguous()
-        gz = [torch.empty(rows, _pad32(widths[l + 1]), dtype=torch.bfloat16, device=dev) for l in range(L - 1)]
-        gb = [torch.empty(_pad32(widths[l + 1]), dtype=torch.float32, device=dev) for l in range(L)]
-        gx = torch.empty_like(x2)
-        wl = _i32_array(widths)
-        ws_bytes = size_query("trs_mlp_fused_workspace_bytes", L, wl)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        call("trs_mlp_fused_bwd_data", ptr(gy2), rows, L, wl, _ptr_array(Ws), _ptr_array(masks), _ptr_array(gz),
-             _ptr_array(gb), ptr(gx), _abi.TRS_BF16, ptr(ws), ws_bytes, stream_ptr())
+        gx, gz, gb, _ = fused_mlp_backward_raw(gy2, widths, Ws, masks)
         grads = []
         for l in range(L):
             inp = x2 if l == 0 else hidden[l - 1]

@@ -518,6 +518,7 @@ class CompressInteractionNetworkLayer(BaseLayer):
 PAD_MULTIPLE = 128        # hidden widths are zero-padded to a multiple of this inside the GEMMs
 PAD_MIN_WIDTH = 192
 PAD_MIN_ROWS = 4096
+HYBRID_ONE_NODE = os.environ.get("TRS_HYBRID_ONE_NODE", "1") not in ("", "0")
 HYBRID_MLP = os.environ.get("TRS_HYBRID_MLP", "1") not in ("", "0")   # fused tail behind a wide first layer
 
 
@@ -686,6 +687,108 @@ class _LinearSplitK(torch.autograd.Function):
         return gx, gw, gb, None, None, None
 
 
+def _dense_layer_grads(g2, gbf, xin, W, out_f, in_f, wdt, need_x, need_w, need_b):
+    """Gradients of y = xin @ W^T + b from g2 = dL/dy (rows, padded width; ``gbf``: its fp32 column sums when a fused
+    ReLU-backward already produced them): (dL/dxin, dL/dW, dL/db), None where not needed."""
+    rows = xin.shape[0]
+    gw_out = gb_out = None
+    if need_x and F_.rows_gemm_supported(g2, W, out_f, xin.shape[1]) and W.shape[1] == xin.shape[1]:
+        # wide input, short contraction (2496 <- 400): our own kernel, K not padded to the library's tile
+        gx = F_.rows_gemm(g2, W, out_f, xin.shape[1])
+    else:
+        gx = (g2 @ W) if need_x else None
+    S = _split_count(rows, _LinearSplitK.SPLIT_ROWS)
+    if need_w or (need_b and gbf is not None):
+        if need_w and S >= 4 and rows % S == 0 and 32 <= g2.shape[1] <= 1024 and 32 <= xin.shape[1] <= 4096 \
+                and xin.is_contiguous():
+            gw = torch.empty(out_f, in_f, dtype=wdt, device=xin.device)
+            St = _split_count(rows, _MLPStack.SPLIT_ROWS_WIDE)
+            if xin.shape[1] >= 2 * g2.shape[1] and St >= 4:
+                # wide input (the 2496-wide first layer): slices of x^T g, 16 of them at 65 536 rows -- hipBLASLt
+                # runs that orientation in 190 us against 282 us for 32 slices of g^T x (tools/wgrad_probe3.py)
+                part = torch.bmm(xin.view(St, rows // St, -1).transpose(1, 2), g2.view(St, rows // St, -1),
+                                 out_dtype=torch.float32)
+                with_b = need_b and gbf is not None
+                gb = torch.empty(out_f, dtype=wdt, device=xin.device) if with_b else None
+                F_.call("trs_wgrad_finish_t", F_.ptr(part), St, part.shape[1], part.shape[2], out_f, in_f,
+                        F_.value_dtype_code(gw), F_.ptr(gw), F_.ptr(gbf) if with_b else F_.ptr(None), F_.ptr(gb),
+                        F_.stream_ptr())
+            else:
+                part = torch.bmm(g2.view(S, rows // S, -1).transpose(1, 2), xin.view(S, rows // S, -1),
+                                 out_dtype=torch.float32)
+                with_b = need_b and gbf is not None and out_f <= (in_f + 255) // 256 * 256
+                gb = torch.empty(out_f, dtype=wdt, device=xin.device) if with_b else None
+                F_.call("trs_wgrad_finish", F_.ptr(part), S, part.shape[1], part.shape[2], out_f, in_f,
+                        F_.value_dtype_code(gw), F_.ptr(gw), F_.ptr(gbf) if with_b else F_.ptr(None), F_.ptr(gb),
+                        F_.stream_ptr())
+            gw_out = gw
+            if with_b:
+                gb_out = gb
+        elif need_w:
+            gw = (g2.t() @ xin)[:out_f, :in_f]
+            gw_out = gw if gw.is_contiguous() else gw.contiguous()
+    if need_b and gb_out is None:
+        gb_out = gbf[:out_f].to(wdt) if gbf is not None else g2.sum(0)[:out_f]
+    return gx, gw_out, gb_out
+
+
+class _HybridMLP(torch.autograd.Function):
+    """A deep branch whose first layer is too wide for the fused kernel, as ONE autograd node: first Linear + ReLU on
+    hipBLASLt, every layer behind it in trs_mlp_fused_fwd / _bwd_data (F_._FusedMLPTail's arrangement).  One node instead
+    of two so that the first layer's ReLU-backward and bias gradient come out of the fused backward kernel (it masks its
+    input gradient with the sign bits of h1 the forward kernel took while loading h1, and sums the columns) instead of a
+    pass of their own over the (rows, 400) gradient: trs_relu_bwd_bias, 32 us of a 1.4 ms DeepFM step.
+    ``tensors``: weight, bias, w_use, b_use of the first layer, then of every tail layer (w_use / b_use: the zero-padded
+    copies the kernels read, or None)."""
+
+    @staticmethod
+    def forward(ctx, x, *tensors):
+        cur = x.reshape(-1, x.shape[-1])
+        w1, b1, w1u, b1u = tensors[:4]
+        tail = tensors[4:]
+        W1 = w1 if w1u is None else w1u
+        B1 = b1 if w1u is None else b1u
+        h1 = torch._addmm_activation(B1, cur, W1.t(), use_gelu=False)
+        L = len(tail) // 4
+        Ws = [(tail[4 * l] if tail[4 * l + 2] is None else tail[4 * l + 2]).contiguous() for l in range(L)]
+        bs = [(tail[4 * l + 1] if tail[4 * l + 3] is None else tail[4 * l + 3]).contiguous() for l in range(L)]
+        y, hidden, masks, mask_in = F_.fused_mlp_forward_raw(h1, Ws, bs, input_mask=True)
+        out_f = tail[4 * (L - 1)].shape[0]
+        ctx.save_for_backward(cur, W1, h1, mask_in, *Ws, *hidden, *masks)
+        ctx.meta = (L, [h1.shape[1]] + [w.shape[0] for w in Ws], [tuple(tail[4 * l].shape) for l in range(L)],
+                    [tail[4 * l].dtype for l in range(L)], tuple(w1.shape), w1.dtype, tuple(x.shape))
+        y = y[:, :out_f].contiguous() if out_f != y.shape[1] else y
+        return y.reshape(*x.shape[:-1], out_f)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        L, widths, wshapes, wdt, w1shape, w1dt, xshape = ctx.meta
+        saved = ctx.saved_tensors
+        cur, W1, h1, mask_in = saved[:4]
+        Ws = saved[4:4 + L]
+        hidden, masks = saved[4 + L:3 + L + L], saved[3 + L + L:]
+        needs = ctx.needs_input_grad
+        rows, dev = h1.shape[0], h1.device
+        gy = gy.reshape(rows, -1)
+        if gy.shape[1] != widths[L]:
+            gy2 = torch.zeros(rows, widths[L], dtype=torch.bfloat16, device=dev)
+            gy2[:, :gy.shape[1]] = gy
+        else:
+            gy2 = gy.contiguous()
+        g1, gz, gb, gb1 = F_.fused_mlp_backward_raw(gy2, widths, Ws, masks, mask_in)
+        grads = []
+        for l in range(L):
+            inp = h1 if l == 0 else hidden[l - 1]
+            g = gy2 if l == L - 1 else gz[l]
+            out_f, in_f = wshapes[l]
+            gw = F_._wgrad_rows(g, inp, out_f, in_f, wdt[l]) if needs[5 + 4 * l] else None
+            gbias = gb[l][:out_f].to(wdt[l]) if needs[6 + 4 * l] else None
+            grads += [gw, gbias, None, None]
+        gx, gw1, gbias1 = _dense_layer_grads(g1, gb1, cur, W1, w1shape[0], w1shape[1], w1dt, needs[0], needs[1], needs[2])
+        return (gx.reshape(xshape) if needs[0] else None, gw1, gbias1, None, None, *grads)
+
+
 class _MLPStack(torch.autograd.Function):
     """A whole bf16 Linear+ReLU stack (hidden layers Linear -> ReLU, then an output Linear) as ONE autograd node: the
     same GEMM arrangement as ``_LinearSplitK`` (bias+ReLU epilogue, zero-padded widths, split-K weight gradient,
@@ -762,43 +865,8 @@ class _MLPStack(torch.autograd.Function):
             gbf = None
             if fuse:
                 g2, gbf = F_.relu_bwd_bias(g2, y)
-            if need_x and F_.rows_gemm_supported(g2, W, out_f, xin.shape[1]) and W.shape[1] == xin.shape[1]:
-                # wide input, short contraction (2496 <- 400): our own kernel, K not padded to the library's tile
-                gx = F_.rows_gemm(g2, W, out_f, xin.shape[1])
-            else:
-                gx = (g2 @ W) if need_x else None
-            S = _split_count(rows, _LinearSplitK.SPLIT_ROWS)
-            if need_w or (need_b and gbf is not None):
-                if need_w and S >= 4 and rows % S == 0 and 32 <= g2.shape[1] <= 1024 and 32 <= xin.shape[1] <= 4096 \
-                        and xin.is_contiguous():
-                    gw = torch.empty(out_f, in_f, dtype=wdt, device=xin.device)
-                    St = _split_count(rows, _MLPStack.SPLIT_ROWS_WIDE)
-                    if xin.shape[1] >= 2 * g2.shape[1] and St >= 4:
-                        # wide input (the 2496-wide first layer): slices of x^T g, 16 of them at 65 536 rows -- hipBLASLt
-                        # runs that orientation in 190 us against 282 us for 32 slices of g^T x (tools/wgrad_probe3.py)
-                        part = torch.bmm(xin.view(St, rows // St, -1).transpose(1, 2), g2.view(St, rows // St, -1),
-                                         out_dtype=torch.float32)
-                        with_b = need_b and gbf is not None
-                        gb = torch.empty(out_f, dtype=wdt, device=xin.device) if with_b else None
-                        F_.call("trs_wgrad_finish_t", F_.ptr(part), St, part.shape[1], part.shape[2], out_f, in_f,
-                                F_.value_dtype_code(gw), F_.ptr(gw), F_.ptr(gbf) if with_b else F_.ptr(None), F_.ptr(gb),
-                                F_.stream_ptr())
-                    else:
-                        part = torch.bmm(g2.view(S, rows // S, -1).transpose(1, 2), xin.view(S, rows // S, -1),
-                                         out_dtype=torch.float32)
-                        with_b = need_b and gbf is not None and out_f <= (in_f + 255) // 256 * 256
-                        gb = torch.empty(out_f, dtype=wdt, device=xin.device) if with_b else None
-                        F_.call("trs_wgrad_finish", F_.ptr(part), S, part.shape[1], part.shape[2], out_f, in_f,
-                                F_.value_dtype_code(gw), F_.ptr(gw), F_.ptr(gbf) if with_b else F_.ptr(None), F_.ptr(gb),
-                                F_.stream_ptr())
-                    grads[4 * l] = gw
-                    if with_b:
-                        grads[4 * l + 1] = gb
-                elif need_w:
-                    gw = (g2.t() @ xin)[:out_f, :in_f]
-                    grads[4 * l] = gw if gw.is_contiguous() else gw.contiguous()
-            if need_b and grads[4 * l + 1] is None:
-                grads[4 * l + 1] = gbf[:out_f].to(wdt) if gbf is not None else g2.sum(0)[:out_f]
+            gx, grads[4 * l], grads[4 * l + 1] = _dense_layer_grads(g2, gbf, xin, W, out_f, in_f, wdt, need_x, need_w,
+                                                                    need_b)
             g2 = gx
         return (g2.reshape(ctx.xshape) if needs[0] else None, None, *grads)
 
@@ -912,11 +980,14 @@ class MultilayerPerceptionLayer(BaseLayer):
             padded[1] = (tail[0], h_pad, out_pad)
         copies = iter(_PaddedLinear.get_many([p for p in padded if p is not None]))
         use = [next(copies) if p is not None else (None, None) for p in padded]
-        h1 = _MLPStack.apply(outputs, ((True, False),), first.weight, first.bias, use[0][0], use[0][1])
-        tensors = []
+        tensors = [first.weight, first.bias, use[0][0], use[0][1]]
         for mod, (w_use, b_use) in zip(tail, use[1:]):
             tensors += [mod.weight, mod.bias, w_use, b_use]
-        out = F_._FusedMLPTail.apply(h1, *tensors)
+        if len(tail) + 1 <= 8 and HYBRID_ONE_NODE:
+            out = _HybridMLP.apply(outputs, *tensors)
+        else:
+            h1 = _MLPStack.apply(outputs, ((True, False),), *tensors[:4])
+            out = F_._FusedMLPTail.apply(h1, *tensors[4:])
         out.names = ('B', 'O',)
         return out
 
