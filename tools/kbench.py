@@ -210,6 +210,20 @@ def main():
         print(f"fused MLP bwd (data only): med {t[0]*1e3:.3f} ms  {fl/t[0]/1e12:.1f} TFLOP/s", flush=True)
         t = timeit(lambda: torch.autograd.grad(y, (xx, *Ws, *bs), gy, retain_graph=True), iters=3, warm=1)
         print(f"fused MLP bwd (data + weight gradients): med {t[0]*1e3:.3f} ms  {2*fl/t[0]/1e12:.1f} TFLOP/s", flush=True)
+    if want("mlpf") or want("wgrad"):
+        # dW = g^T x over the rows: the hand-written kernel against the batched library GEMM it replaces
+        for rows_, M_, N_ in [(B * N, 416, 416), (B * N, 416, 64), (B * N, 64, 416), (B, 416, 416), (B, 416, 2496)]:
+            gg = torch.randn(rows_, M_, generator=g).to(dt).to(dev)
+            xx2 = torch.randn(rows_, N_, generator=g).to(dt).to(dev)
+            fl = 2.0 * rows_ * M_ * N_
+            by = (M_ + N_) * 2.0 * rows_
+            for on in (True, False):
+                F_.WGRAD_ROWS = on
+                t = timeit(lambda: F_._wgrad_rows(gg, xx2, M_, N_, dt), iters=5, warm=2)
+                print(f"wgrad {'trs_wgrad_rows' if on else 'bmm split-K  '} rows={rows_} {M_}x{N_}: med {t[0]*1e6:8.1f} us  "
+                      f"{fl/t[0]/1e12:6.1f} TFLOP/s  {by/t[0]/1e9:7.1f} GB/s (operands once)", flush=True)
+            F_.WGRAD_ROWS = True
+            del gg, xx2
     if want("copy"):
         x = torch.empty(512 * 1024 * 1024 // 4, dtype=torch.float32, device=dev)
         y = torch.empty_like(x)
