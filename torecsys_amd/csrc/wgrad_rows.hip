@@ -19,9 +19,13 @@
 // fragments of step k+1 are fetched during the last rows of step k, step k+2 is written and step k+6 requested behind
 // the second row of step k, one barrier per step.
 //
-// Measured (2.55 M rows, 416 x 416): 1.22 ms against 1.37 ms for the batched hipBLASLt GEMM it replaces; the loads alone
-// (MFMAs removed) take 0.90-0.96 ms = 4.7 TB/s of distinct bytes, the MFMAs alone 0.64 ms -- the two overlap badly while
-// the chip, throttled to ~2.0 GHz by the matrix pipe, also slows its own L2.  416 x 64: 0.43 ms = 5.7 TB/s (0.52 ms).
+// Measured (2.55 M rows, 416 x 416): 1.16 ms in the eight-wave form (1.28 ms with four waves of 49 tiles) against
+// 1.37-1.42 ms for the batched hipBLASLt GEMM it replaces; the loads alone (MFMAs removed) take 0.90-0.96 ms = 4.7 TB/s of
+// distinct bytes, the MFMAs alone 0.64 ms -- with one wave per SIMD the two overlap badly (every wait of the wave is a
+// wait of the matrix pipe), and 13 % fewer MFMAs bought 13 % of the time at 384 columns; hence the second form.
+// 416 x 64: 0.43 ms = 5.7 TB/s (0.52 ms).
+#include <stdlib.h>
+
 #include "trs_common.hpp"
 
 namespace trs {
@@ -70,8 +74,15 @@ __device__ __forceinline__ void wg_mfma(wg_f32x4& acc, const wg_bf16x8& A, const
   asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(A), "v"(B));
 }
 
+// WM x WN waves: 4 (one per SIMD, every wave MC x NC tiles -- short shares run on into the neighbour's panels) or, for the
+// 2 x 2 blocking of wide outputs, 8 as 2 x 4 (two per SIMD, 256 registers each: one wave's waits -- rows not there yet,
+// LDS writes, the barrier -- sit under the other's MFMAs) with EXACT shares: a wave owns MC or MC-1 by NC or NC-1 tiles
+// and runs the copy of the loop compiled for its share, so no MFMA is issued for nothing (13 x 13 tiles: 7|6 x 4|3|3|3,
+// paired on the SIMDs as 28+18, 21+24, 21+18, 21+18).
 template <int WM, int WN, int MC, int NC, bool CHECK>
-__global__ __launch_bounds__(256, 1) void wgrad_rows_kernel(WgradArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, 1) void wgrad_rows_kernel(WgradArgs a) {
+  constexpr int NWAVES = WM * WN;
+  constexpr bool EXACT = NWAVES == 8;
   extern __shared__ __attribute__((aligned(16))) char wg_lds[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, i = lane & 15;
@@ -88,7 +99,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_rows_kernel(WgradArgs a) {
   const int bm0 = split_start(Mt, a.MB, mb), bm1 = split_start(Mt, a.MB, mb + 1);      // block's tiles along M
   const int bn0 = split_start(Nt, a.NB, nb), bn1 = split_start(Nt, a.NB, nb + 1);
   const int PM = bm1 - bm0, PN = bn1 - bn0, P = PM + PN;
-  const int wm = wave / WN, wn = wave % WN;
+  // (8 waves: waves w and w+4 share a SIMD; 4..7 take the column shares 1, 0, 2, 3 so that the large shares meet small ones)
+  const int wm = wave / WN, wn = (EXACT && wave >= 4) ? ((wave & 3) < 2 ? 1 - (wave & 3) : (wave & 3)) : wave % WN;
   const int am0 = split_start(PM, WM, wm), mc = split_start(PM, WM, wm + 1) - am0;     // wave's tiles inside the block
   const int an0 = split_start(PN, WN, wn), nc = split_start(PN, WN, wn + 1) - an0;
   // the rows, in steps of 32 (one MFMA k-step); a row range is a multiple of four steps (the loop below has one exit:
@@ -100,8 +112,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_rows_kernel(WgradArgs a) {
   // ---- staging: wave w stages panels 8w .. 8w+7 (256 bytes of a row), four rows per instruction, 16 consecutive lanes
   // reading 256 contiguous bytes; the 8 lanes of a ds_write_b128 group land on 4 panels x 32 B of one row, which the
   // panel stride (32 mod 128) spreads over all 32 banks
-  const int panel = wave * 8 + ((lane & 15) >> 1);
-  const int rlow = lane >> 4, half = lane & 1;
+  constexpr int NLD = 32 / NWAVES;                               // 16-byte loads per thread and step: 8 (4 waves) or 4
+  const int panel = (wave & 3) * 8 + ((lane & 15) >> 1);
+  const int rlow = (wave >> 2) * 16 + (lane >> 4), half = lane & 1;   // 8 waves: waves 4..7 stage rows 16..31 of the step
   const bool is_g = panel < PM;
   const int col = is_g ? 16 * (bm0 + panel) + 8 * half : 16 * (bn0 + panel - PM) + 8 * half;
   const bool col_ok = panel < P && col + 8 <= (is_g ? a.M : a.N);
@@ -116,11 +129,15 @@ __global__ __launch_bounds__(256, 1) void wgrad_rows_kernel(WgradArgs a) {
   uint4 sa0, sa1, sa2, sa3, sa4, sa5, sa6, sa7, sb0, sb1, sb2, sb3, sb4, sb5, sb6, sb7;
   uint4 sc0, sc1, sc2, sc3, sc4, sc5, sc6, sc7, sd0, sd1, sd2, sd3, sd4, sd5, sd6, sd7;
 #define WG_EACH(X, R) X(R, 0) X(R, 1) X(R, 2) X(R, 3) X(R, 4) X(R, 5) X(R, 6) X(R, 7)
-#define WG_LD(R, t) R##t = *reinterpret_cast<const uint4*>(p + t * rstep);
-#define WG_LDC(R, t) \
-  R##t = (h_ * WG_KS + rlow + 4 * t < a.rows) ? *reinterpret_cast<const uint4*>(p + t * rstep) : make_uint4(0, 0, 0, 0);
-#define WG_WR(R, t) *reinterpret_cast<uint4*>(dst + 4 * t * 32) = R##t;
-#define WG_WR0(R, t) *reinterpret_cast<uint4*>(dst + 4 * t * 32) = make_uint4(0, 0, 0, 0);
+#define WG_LD(R, t) \
+  if (t < NLD) R##t = *reinterpret_cast<const uint4*>(p + t * rstep);
+#define WG_LDC(R, t)  \
+  if (t < NLD)        \
+    R##t = (h_ * WG_KS + rlow + 4 * t < a.rows) ? *reinterpret_cast<const uint4*>(p + t * rstep) : make_uint4(0, 0, 0, 0);
+#define WG_WR(R, t) \
+  if (t < NLD) *reinterpret_cast<uint4*>(dst + 4 * t * 32) = R##t;
+#define WG_WR0(R, t) \
+  if (t < NLD) *reinterpret_cast<uint4*>(dst + 4 * t * 32) = make_uint4(0, 0, 0, 0);
   // no branches around the loads (they would turn the staging registers into merge points the allocator handles
   // badly): a lane whose columns lie outside its operand reads the operand's first columns instead and never writes
   // them -- its LDS pieces are zeroed once, here.  CHECK (rows not a multiple of 128): rows past the end read as zero.
@@ -153,90 +170,108 @@ __global__ __launch_bounds__(256, 1) void wgrad_rows_kernel(WgradArgs a) {
     }                                                  \
   }
 
-  wg_f32x4 acc[MC][NC];
-#pragma unroll
-  for (int m = 0; m < MC; ++m)
-#pragma unroll
-    for (int n = 0; n < NC; ++n) acc[m][n] = wg_f32x4{0.f, 0.f, 0.f, 0.f};
+  // everything from here on is compiled once per share (MCx x NCx tiles): once for the 4-wave form, four times for EXACT
+  auto run = [&]<int MCx, int NCx>() __attribute__((always_inline)) {
+    wg_f32x4 acc[MCx][NCx];
+  #pragma unroll
+    for (int m = 0; m < MCx; ++m)
+  #pragma unroll
+      for (int n = 0; n < NCx; ++n) acc[m][n] = wg_f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // per-lane fragment addresses.  Every wave multiplies MC x NC tiles; a wave that owns fewer runs on into the panels
-  // behind its own (same cost for the workgroup -- the SIMD with the full share sets the pace --, no branches in the
-  // loop, and every read is one base register plus an immediate; the results are dropped at the end)
-  const int frag_lane = (8 * q + (i >> 2)) * 32 + (i & 3) * 8;
-  const int a_lo = am0 * WG_PANEL + frag_lane + (odd ? 128 : 0), a_hi = am0 * WG_PANEL + frag_lane + (odd ? 0 : 128);
-  const int b_lo = (PM + an0) * WG_PANEL + frag_lane + (odd ? 128 : 0);
-  const int b_hi = (PM + an0) * WG_PANEL + frag_lane + (odd ? 0 : 128);
+    // per-lane fragment addresses.  Every wave multiplies MCx x NCx tiles; a wave that owns fewer runs on into the panels
+    // behind its own (same cost for the workgroup -- the SIMD with the full share sets the pace --, no branches in the
+    // loop, and every read is one base register plus an immediate; the results are dropped at the end)
+    const int frag_lane = (8 * q + (i >> 2)) * 32 + (i & 3) * 8;
+    const int a_lo = am0 * WG_PANEL + frag_lane + (odd ? 128 : 0), a_hi = am0 * WG_PANEL + frag_lane + (odd ? 0 : 128);
+    const int b_lo = (PM + an0) * WG_PANEL + frag_lane + (odd ? 128 : 0);
+    const int b_hi = (PM + an0) * WG_PANEL + frag_lane + (odd ? 0 : 128);
 
-  // One 32-row step out of ring slot ``c`` with the fragments of the NEXT step (ring slot ``nx``) fetched on the way:
-  // the A fragment of row m+2 (of this step or the next) before the MFMAs of row m, the B fragments in place behind
-  // the last row -- so a step starts with its operands in registers.  ``mid`` runs behind the second row: the LDS
-  // writes and global loads of the steps further ahead.
-  constexpr int PD = MC >= 2 ? 2 : 1;
-  wg_bf16x8 Ar[4], Bf[NC];                         // A: a ring of four, row m of step c in slot (MC * c + m) % 4
-#define WG_STEP(c, nx, MID)                                                                                       \
-  {                                                                                                               \
-    const char* cb = wg_lds + (c) * slot_bytes;                                                                   \
-    const char* nb_ = wg_lds + (nx) * slot_bytes;                                                                 \
-    constexpr int RO = (MC * (c)) % 4;                                                                            \
-    _Pragma("unroll") for (int m = 0; m < MC; ++m) {                                                              \
-      const int t = (m + PD) % MC;                                                                                \
-      const char* fb = (m + PD < MC) ? cb : nb_;                                                                  \
-      Ar[(RO + m + PD) % 4] = tr_frag(fb + a_lo, fb + a_hi, t * WG_PANEL);                                        \
-      _Pragma("unroll") for (int n = 0; n < NC; ++n) {                                                            \
-        wg_mfma(acc[m][n], Ar[(RO + m) % 4], Bf[n]);                                                              \
-        if (m == MC - 1) Bf[n] = tr_frag(nb_ + b_lo, nb_ + b_hi, n * WG_PANEL);                                   \
-      }                                                                                                           \
-      if (m == (MC > 2 ? 1 : 0)) { MID }                                                                          \
-    }                                                                                                             \
-  }
-
-  if (n_h > 0) {
-    WG_LOAD(sa, 0)
-    WG_LOAD(sb, 1)
-    WG_WRITE(sa, 0)
-    WG_WRITE(sb, 1)
-    WG_LOAD(sc, 2)
-    WG_LOAD(sd, 3)
-    WG_LOAD(sa, 4)
-    WG_LOAD(sb, 5)
-    __syncthreads();
-    {
-      const char* cb = wg_lds;
-#pragma unroll
-      for (int n = 0; n < NC; ++n) Bf[n] = tr_frag(cb + b_lo, cb + b_hi, n * WG_PANEL);
-#pragma unroll
-      for (int m = 0; m < PD; ++m) Ar[m] = tr_frag(cb + a_lo, cb + a_hi, m * WG_PANEL);
+    // One 32-row step out of ring slot ``c`` with the fragments of the NEXT step (ring slot ``nx``) fetched on the way:
+    // the A fragment of row m+2 (of this step or the next) before the MFMAs of row m, the B fragments in place behind
+    // the last row -- so a step starts with its operands in registers.  ``mid`` runs behind the second row: the LDS
+    // writes and global loads of the steps further ahead.
+    constexpr int PD = MCx >= 2 ? 2 : 1;
+    wg_bf16x8 Ar[4], Bf[NCx];                         // A: a ring of four, row m of step c in slot (MCx * c + m) % 4
+  #define WG_STEP(c, nx, MID)                                                                                       \
+    {                                                                                                               \
+      const char* cb = wg_lds + (c) * slot_bytes;                                                                   \
+      const char* nb_ = wg_lds + (nx) * slot_bytes;                                                                 \
+      constexpr int RO = (MCx * (c)) % 4;                                                                            \
+      _Pragma("unroll") for (int m = 0; m < MCx; ++m) {                                                              \
+        const int t = (m + PD) % MCx;                                                                                \
+        const char* fb = (m + PD < MCx) ? cb : nb_;                                                                  \
+        Ar[(RO + m + PD) % 4] = tr_frag(fb + a_lo, fb + a_hi, t * WG_PANEL);                                        \
+        _Pragma("unroll") for (int n = 0; n < NCx; ++n) {                                                            \
+          wg_mfma(acc[m][n], Ar[(RO + m) % 4], Bf[n]);                                                              \
+          if (m == MCx - 1) Bf[n] = tr_frag(nb_ + b_lo, nb_ + b_hi, n * WG_PANEL);                                   \
+        }                                                                                                           \
+        if (m == (MCx > 2 ? 1 : 0)) { MID }                                                                          \
+      }                                                                                                             \
     }
-    // ring slot k % 4 holds step k, register set j % 4 the rows of step j on their way.  At step k: step k+2 is written
-    // (loaded four steps ago) and the loads of step k+6 leave into the same registers; one barrier per step: slot k+2
-    // complete, slot k free.  (Requesting before the wait, into the set written out a step earlier, measured the same at
-    // 416 x 416 and 15 % slower at 416 x 2496.)
-    for (int64_t k = 0; k < n_h; k += 4) {
-      WG_STEP(0, 1, WG_WRITE(sc, 2) WG_LOAD(sc, k + 6))
-      __syncthreads();
-      WG_STEP(1, 2, WG_WRITE(sd, 3) WG_LOAD(sd, k + 7))
-      __syncthreads();
-      WG_STEP(2, 3, WG_WRITE(sa, 0) WG_LOAD(sa, k + 8))
-      __syncthreads();
-      WG_STEP(3, 0, WG_WRITE(sb, 1) WG_LOAD(sb, k + 9))
-      __syncthreads();
-    }
-  }
 
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs' results are not visible before this
-  // ---- the block's partial: D[m = 4q + e][n = i]
-  float* out = a.part + (int64_t)slot * a.M * a.N;
-#pragma unroll
-  for (int m = 0; m < MC; ++m)
-#pragma unroll
-    for (int n = 0; n < NC; ++n)
-      if (m < mc && n < nc) {
-        const int row = 16 * (bm0 + am0 + m) + 4 * q, c = 16 * (bn0 + an0 + n) + i;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (row + e < a.M && c < a.N) out[(int64_t)(row + e) * a.N + c] = acc[m][n][e];
+    if (n_h > 0) {
+      WG_LOAD(sa, 0)
+      WG_LOAD(sb, 1)
+      WG_WRITE(sa, 0)
+      WG_WRITE(sb, 1)
+      WG_LOAD(sc, 2)
+      WG_LOAD(sd, 3)
+      WG_LOAD(sa, 4)
+      WG_LOAD(sb, 5)
+      __syncthreads();
+      {
+        const char* cb = wg_lds;
+  #pragma unroll
+        for (int n = 0; n < NCx; ++n) Bf[n] = tr_frag(cb + b_lo, cb + b_hi, n * WG_PANEL);
+  #pragma unroll
+        for (int m = 0; m < PD; ++m) Ar[m] = tr_frag(cb + a_lo, cb + a_hi, m * WG_PANEL);
       }
+      // ring slot k % 4 holds step k, register set j % 4 the rows of step j on their way.  At step k: step k+2 is written
+      // (loaded four steps ago) and the loads of step k+6 leave into the same registers; one barrier per step: slot k+2
+      // complete, slot k free.  (Requesting before the wait, into the set written out a step earlier, measured the same at
+      // 416 x 416 and 15 % slower at 416 x 2496.)
+      for (int64_t k = 0; k < n_h; k += 4) {
+        WG_STEP(0, 1, WG_WRITE(sc, 2) WG_LOAD(sc, k + 6))
+        __syncthreads();
+        WG_STEP(1, 2, WG_WRITE(sd, 3) WG_LOAD(sd, k + 7))
+        __syncthreads();
+        WG_STEP(2, 3, WG_WRITE(sa, 0) WG_LOAD(sa, k + 8))
+        __syncthreads();
+        WG_STEP(3, 0, WG_WRITE(sb, 1) WG_LOAD(sb, k + 9))
+        __syncthreads();
+      }
+    }
+
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs' results are not visible before this
+    // ---- the block's partial: D[m = 4q + e][n = i]
+    float* out = a.part + (int64_t)slot * a.M * a.N;
+  #pragma unroll
+    for (int m = 0; m < MCx; ++m)
+  #pragma unroll
+      for (int n = 0; n < NCx; ++n)
+        if (m < mc && n < nc) {
+          const int row = 16 * (bm0 + am0 + m) + 4 * q, c = 16 * (bn0 + an0 + n) + i;
+  #pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (row + e < a.M && c < a.N) out[(int64_t)(row + e) * a.N + c] = acc[m][n][e];
+        }
+
+  };
+  if constexpr (!EXACT) {
+    run.template operator()<MC, NC>();
+  } else {
+    // the four shares of the 2 x 4 form; every copy holds the same number of barriers
+    if (mc == MC && nc == NC) run.template operator()<MC, NC>();
+    else if (mc == MC) run.template operator()<MC, NC - 1>();
+    else if (nc == NC) run.template operator()<MC - 1, NC>();
+    else run.template operator()<MC - 1, NC - 1>();
+  }
 }
+
+static const bool WGRAD_EIGHT = [] {
+  const char* e = getenv("TRS_WGRAD_EIGHT");
+  return !(e && e[0] == '0');
+}();
 
 struct WgradPlan {
   int wm, wn, mc, nc, MB, NB, slots_per_xcd;
@@ -260,6 +295,13 @@ static WgradPlan wgrad_plan(int M, int N, int64_t rows) {
     if (p.MB * p.NB > 32) return WgradPlan{0, 0, 0, 0, 0, 0, 0};
     // tiles per wave along N once the blocks are cut (2496 columns in 16 blocks: 9 | 10 tiles, 5 per wave)
     if (((Nt + p.NB - 1) / p.NB + 1) / 2 <= 5) p.nc = 5;
+    // blocks of 12..14 x 12..16 tiles (416 x 416: 13 x 13): eight waves with exact shares of 7|6 x 4|3 tiles
+    const int pm_lo = Mt / p.MB, pm_hi = (Mt + p.MB - 1) / p.MB, pn_lo = Nt / p.NB, pn_hi = (Nt + p.NB - 1) / p.NB;
+    if (WGRAD_EIGHT && pm_lo >= 12 && pm_hi <= 14 && pn_lo >= 12 && pn_hi <= 16) {
+      p.wn = 4;
+      p.mc = 7;
+      p.nc = 4;
+    }
   }
   int slots = 32 / (p.MB * p.NB);
   // every row range at least 4 stages long
@@ -278,7 +320,7 @@ int wgrad_launch_c(const WgradArgs& a, int grid, size_t lds, hipStream_t s) {
       return check_launch("wgrad_rows: LDS attribute");
     attr = true;
   }
-  hipLaunchKernelGGL((wgrad_rows_kernel<WM, WN, MC, NC, CHECK>), dim3(grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((wgrad_rows_kernel<WM, WN, MC, NC, CHECK>), dim3(grid), dim3(64 * WM * WN), lds, s, a);
   return check_launch("wgrad_rows");
 }
 
@@ -313,6 +355,7 @@ extern "C" int trs_wgrad_rows(const void* g, int32_t ldg, const void* x, int32_t
   const int PM = (Mt + p.MB - 1) / p.MB, PN = (Nt + p.NB - 1) / p.NB;
   const size_t lds = (size_t)(4 * (PM + PN) + WG_TC) * WG_PANEL;      // + the panels a short wave runs on into
   const int grid = 8 * p.slots_per_xcd * p.MB * p.NB;
+  if (p.wm == 2 && p.wn == 4) return wgrad_launch<2, 4, 7, 4>(a, grid, lds, s);
   if (p.wm == 2)
     return p.nc == 5 ? wgrad_launch<2, 2, WG_TC, 5>(a, grid, lds, s) : wgrad_launch<2, 2, WG_TC, WG_TC>(a, grid, lds, s);
   if (p.wm == 4) return p.nc == 4 ? wgrad_launch<4, 1, WG_TC, 4>(a, grid, lds, s) : wgrad_launch<4, 1, WG_TC, WG_TC>(a, grid, lds, s);
