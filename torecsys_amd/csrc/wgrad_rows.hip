@@ -301,6 +301,10 @@ static WgradPlan wgrad_plan(int M, int N, int64_t rows) {
       p.wn = 4;
       p.mc = 7;
       p.nc = 4;
+    } else if (WGRAD_EIGHT && pm_lo >= 12 && pm_hi <= 14 && pn_lo >= 8 && pn_hi <= 12) {
+      p.wn = 4;      // 2496 columns in 16 blocks of 9 | 10 tiles: shares of 3 | 2
+      p.mc = 7;
+      p.nc = 3;
     }
   }
   int slots = 32 / (p.MB * p.NB);
@@ -355,7 +359,8 @@ extern "C" int trs_wgrad_rows(const void* g, int32_t ldg, const void* x, int32_t
   const int PM = (Mt + p.MB - 1) / p.MB, PN = (Nt + p.NB - 1) / p.NB;
   const size_t lds = (size_t)(4 * (PM + PN) + WG_TC) * WG_PANEL;      // + the panels a short wave runs on into
   const int grid = 8 * p.slots_per_xcd * p.MB * p.NB;
-  if (p.wm == 2 && p.wn == 4) return wgrad_launch<2, 4, 7, 4>(a, grid, lds, s);
+  if (p.wm == 2 && p.wn == 4)
+    return p.nc == 4 ? wgrad_launch<2, 4, 7, 4>(a, grid, lds, s) : wgrad_launch<2, 4, 7, 3>(a, grid, lds, s);
   if (p.wm == 2)
     return p.nc == 5 ? wgrad_launch<2, 2, WG_TC, 5>(a, grid, lds, s) : wgrad_launch<2, 2, WG_TC, WG_TC>(a, grid, lds, s);
   if (p.wm == 4) return p.nc == 4 ? wgrad_launch<4, 1, WG_TC, 4>(a, grid, lds, s) : wgrad_launch<4, 1, WG_TC, WG_TC>(a, grid, lds, s);
