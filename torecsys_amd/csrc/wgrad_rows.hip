@@ -78,7 +78,7 @@ __device__ __forceinline__ void wg_mfma(wg_f32x4& acc, const wg_bf16x8& A, const
 // 2 x 2 blocking of wide outputs, 8 as 2 x 4 (two per SIMD, 256 registers each: one wave's waits -- rows not there yet,
 // LDS writes, the barrier -- sit under the other's MFMAs) with EXACT shares: a wave owns MC or MC-1 by NC or NC-1 tiles
 // and runs the copy of the loop compiled for its share, so no MFMA is issued for nothing (13 x 13 tiles: 7|6 x 4|3|3|3,
-// paired on the SIMDs as 28+18, 21+24, 21+18, 21+18).
+// paired on the SIMDs as 21+18, 21+18, 21+24, 28+18).
 template <int WM, int WN, int MC, int NC, bool CHECK>
 __global__ __launch_bounds__(64 * WM * WN, 1) void wgrad_rows_kernel(WgradArgs a) {
   constexpr int NWAVES = WM * WN;
@@ -99,8 +99,9 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void wgrad_rows_kernel(WgradArgs a
   const int bm0 = split_start(Mt, a.MB, mb), bm1 = split_start(Mt, a.MB, mb + 1);      // block's tiles along M
   const int bn0 = split_start(Nt, a.NB, nb), bn1 = split_start(Nt, a.NB, nb + 1);
   const int PM = bm1 - bm0, PN = bn1 - bn0, P = PM + PN;
-  // (8 waves: waves w and w+4 share a SIMD; 4..7 take the column shares 1, 0, 2, 3 so that the large shares meet small ones)
-  const int wm = wave / WN, wn = (EXACT && wave >= 4) ? ((wave & 3) < 2 ? 1 - (wave & 3) : (wave & 3)) : wave % WN;
+  // (8 waves: waves w and w+4 share a SIMD; 4..7 take the column shares rotated by one, so that the one or two large
+  // shares of 13 or 14 columns -- 3,3,3,4 / 3,4,3,4 -- meet a small one: 28 + 18 MFMAs per step instead of 28 + 24)
+  const int wm = wave / WN, wn = (EXACT && wave >= 4) ? ((wave + 1) & 3) : wave % WN;
   const int am0 = split_start(PM, WM, wm), mc = split_start(PM, WM, wm + 1) - am0;     // wave's tiles inside the block
   const int an0 = split_start(PN, WN, wn), nc = split_start(PN, WN, wn + 1) - an0;
   // the rows, in steps of 32 (one MFMA k-step); a row range is a multiple of four steps (the loop below has one exit:
