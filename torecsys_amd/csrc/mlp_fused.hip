@@ -92,23 +92,32 @@ struct MlpPackArgs {
 __global__ __launch_bounds__(256) void mlp_prepack_many_kernel(MlpPackArgs a) {
   const MlpPackJob& j = a.job[blockIdx.y];
   const int total = j.NTt * j.KS * 64;
+  const bool vec = !a.transpose && (j.in_f & 7) == 0 && (reinterpret_cast<uintptr_t>(j.W) & 15u) == 0;
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
     const int lane = t & 63;
     const int f = t >> 6;
     const int ks = f % j.KS, mt = f / j.KS;
     const int oc = mf_col_of_slot(mt, lane & 15);
     const int k0 = 32 * ks + 8 * (lane >> 4);
+    uint4* dst = reinterpret_cast<uint4*>(j.Wf + (size_t)t * 8);
+    if (vec) {       // 8 consecutive k of one weight row: one 16-byte load, one 16-byte store
+      *dst = (oc < j.out_f && k0 + 8 <= j.in_f) ? *reinterpret_cast<const uint4*>(j.W + (size_t)oc * j.in_f + k0)
+                                                 : make_uint4(0, 0, 0, 0);
+      continue;
+    }
+    uint16_t v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int k = k0 + e;
-      bf16_t v{0};
+      v[e] = 0;
       if (!a.transpose) {
-        if (oc < j.out_f && k < j.in_f) v = j.W[(size_t)oc * j.in_f + k];
+        if (oc < j.out_f && k < j.in_f) v[e] = j.W[(size_t)oc * j.in_f + k].v;
       } else {
-        if (oc < j.in_f && k < j.out_f) v = j.W[(size_t)k * j.in_f + oc];
+        if (oc < j.in_f && k < j.out_f) v[e] = j.W[(size_t)k * j.in_f + oc].v;
       }
-      j.Wf[(size_t)t * 8 + e] = v;
     }
+    *dst = make_uint4(v[0] | ((uint32_t)v[1] << 16), v[2] | ((uint32_t)v[3] << 16), v[4] | ((uint32_t)v[5] << 16),
+                      v[6] | ((uint32_t)v[7] << 16));
   }
   if (j.bf != nullptr)
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < j.bias_n; t += gridDim.x * blockDim.x)
