@@ -4,11 +4,12 @@
 // stacks of DCN).  At 416 x 416 one row carries 1664 bytes and 346 kFLOP: 208 FLOP per byte, under the chip's ~310, so
 // the kernel is bound by HBM as long as every operand byte is fetched once -- which is what the layout is built for.
 //
-// One workgroup (4 waves, one per SIMD, 512 registers each) owns a block of at most 14 x 14 output tiles of 16 x 16 (waves as
-// 2 x 2; 28 x 7 / 7 x 28 with the waves as 4 x 1 / 1 x 4 for narrow operands) and a contiguous range of rows; it keeps the
-// whole block in MFMA accumulators (<= 49 tiles per wave) and writes ONE fp32 partial at the end (summed over the row
-// ranges and cast by trs_wgrad_finish).  The workgroups that share a row range (2 x 2 blocks at 416 x 416) sit on the
-// same XCD (blockIdx % 8) so that the second reader of a g / x piece finds it in that XCD's L2.
+// One workgroup owns a block of at most 14 x 16 output tiles of 16 x 16 (28 x 7 / 7 x 28 for narrow operands) and a
+// contiguous range of rows; it keeps the whole block in MFMA accumulators and writes ONE fp32 partial at the end (summed
+// over the row ranges and cast by trs_wgrad_finish).  Two forms of the same loop: four waves, one per SIMD on up to 512
+// registers, 49 tiles each (waves as 2 x 2, 4 x 1 or 1 x 4), and eight waves, two per SIMD, as 2 x 4 with exact shares
+// (see the kernel).  The workgroups that share a row range (2 x 2 blocks at 416 x 416) sit on the same XCD
+// (blockIdx % 8) so that the second reader of a g / x piece finds it in that XCD's L2.
 //
 // Rows arrive 32 at a time (one MFMA k-step) through registers into a ring of four LDS slots, each
 // [16-column panel][row][32 B]: both MFMA operands want the row index along K, which is what ds_read_b64_tr_b16 delivers
@@ -35,12 +36,10 @@ typedef __attribute__((ext_vector_type(8))) short wg_s16x8;
 typedef __attribute__((ext_vector_type(8))) __bf16 wg_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float wg_f32x4;
 
-constexpr int WG_KR = 64;                  // rows per stage (two MFMA k-steps)
+constexpr int WG_KR = 64;                  // row ranges are cut in units of two of these (four steps)
 constexpr int WG_KS = 32;                  // rows per step
 constexpr int WG_PANEL = WG_KS * 32 + 32;  // bytes from one 16-column panel of a step to the next (32 mod 128, below)
 constexpr int WG_TC = 7;                   // output tiles per wave and direction, at most
-constexpr int WG_MAXP = 28;                // panels of a stage (g + x), at most
-constexpr int WG_NLD = 16;                 // 16-byte loads per thread and stage, at most
 
 struct WgradArgs {
   const uint16_t* g;
