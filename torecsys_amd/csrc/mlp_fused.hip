@@ -153,9 +153,12 @@ struct MlpShare {
   int npw;              // pairs of this wave (0..MF_MAXP)
   int pair[MF_MAXP];
   int mt0, mcnt;        // row tiles mt0 .. mt0+mcnt-1
+  int mt1, mc1;         // mc1 > 0: the wave's LAST pair covers only row tiles mt1 .. mt1+mc1-1 (a pair shared by 4 or 2 waves)
 };
 __device__ __forceinline__ MlpShare mlp_share(int N, int wave) {
   MlpShare s;
+  s.mt1 = 0;
+  s.mc1 = 0;
   const int npairs = N >> 5;
   if (npairs > 4) {
     s.mt0 = 0;
@@ -165,6 +168,18 @@ __device__ __forceinline__ MlpShare mlp_share(int N, int wave) {
     for (int i = 0; i < MF_MAXP; ++i) {
       s.pair[i] = wave + MF_WAVES * i;
       if (s.pair[i] < npairs) s.npw = i + 1;
+    }
+    // Waves w and w+4 share a SIMD: pairs 8, 9, ... given whole to waves 0, 1, ... load the SIMDs evenly only in groups of
+    // four.  One or two pairs left over (13 pairs = 416 columns: pair 12) would sit on one or two SIMDs -- 4 pairs against
+    // 3 on the others, the wave at the barrier for a third of the GEMM -- so the four waves of that group share them by
+    // row tiles instead: 2 of the 8 row tiles each (one pair left over) or 4 each (two).
+    const int extra = npairs - MF_WAVES, left = extra & 3, g0 = extra & ~3;
+    if (MF_MT == 8 && extra > 0 && extra < MF_WAVES && (left == 1 || left == 2) && wave >= g0 && wave < g0 + 4) {
+      const int c = wave - g0;
+      s.npw = 2;
+      s.pair[1] = MF_WAVES + g0 + (left == 1 ? 0 : (c >> 1));
+      s.mc1 = left == 1 ? 2 : 4;
+      s.mt1 = left == 1 ? 2 * c : 4 * (c & 1);
     }
   } else {
     const int ng = npairs <= 1 ? 1 : (npairs == 2 ? 2 : 4);     // pair groups; MF_WAVES / ng row groups
@@ -183,12 +198,15 @@ __device__ __forceinline__ MlpShare mlp_share(int N, int wave) {
 // The weight fragments come from L2: a k-step's fragments are requested at the top of the k-step before it and waited
 // for at that k-step's bottom; the activations are read from LDS per k-step in two halves (16 registers of B operands
 // instead of 64).
-template <int MCNT, int NPW>
+// MC1 > 0: the last pair covers MC1 row tiles from sh.mt1 (its accumulators are acc[0 .. MC1-1][2 * (NPW-1) + h]).
+template <int MCNT, int NPW, int MC1 = 0>
 __device__ __forceinline__ void mlp_gemm_t(const char* act, int act_str, const uint4* __restrict__ wf, int K,
                                            const MlpShare& sh, int lane, mf_f32x4 (&acc)[MF_MT][2 * MF_MAXP]) {
   const int KS = K >> 5;
   const int r = lane & 15, q = lane >> 4;
   const char* arow = act + (sh.mt0 * 16 + r) * act_str + q * 16;
+  const char* arow1 = act + (sh.mt1 * 16 + r) * act_str + q * 16;
+  constexpr int TF = 2 * (NPW - (MC1 > 0 ? 1 : 0));      // fragments of the pairs that cover all MCNT row tiles
   const uint4* wbase[NPW];
 #pragma unroll
   for (int pi = 0; pi < NPW; ++pi) wbase[pi] = wf + ((size_t)(2 * sh.pair[pi]) * KS) * 64 + lane;
@@ -220,11 +238,22 @@ __device__ __forceinline__ void mlp_gemm_t(const char* act, int act_str, const u
 #pragma unroll
         for (int mi = 0; mi < HALF; ++mi) Bh[mi] = *reinterpret_cast<const uint4*>(arow + (m0 + mi) * 16 * act_str + ks * 64);
 #pragma unroll
-        for (int t = 0; t < 2 * NPW; ++t)
+        for (int t = 0; t < TF; ++t)
 #pragma unroll
           for (int mi = 0; mi < HALF; ++mi)
             acc[m0 + mi][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                 __builtin_bit_cast(mf_bf16x8, cur[t]), __builtin_bit_cast(mf_bf16x8, Bh[mi]), acc[m0 + mi][t], 0, 0, 0);
+      }
+      if constexpr (MC1 > 0) {
+        uint4 Bx[MC1];
+#pragma unroll
+        for (int mi = 0; mi < MC1; ++mi) Bx[mi] = *reinterpret_cast<const uint4*>(arow1 + mi * 16 * act_str + ks * 64);
+#pragma unroll
+        for (int t = TF; t < TF + 2; ++t)
+#pragma unroll
+          for (int mi = 0; mi < MC1; ++mi)
+            acc[mi][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(mf_bf16x8, cur[t]), __builtin_bit_cast(mf_bf16x8, Bx[mi]), acc[mi][t], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       TRS_MF_COMMIT(nxt)
@@ -301,14 +330,19 @@ template <typename F>
 __device__ __forceinline__ void mlp_dispatch(const MlpShare& sh, F&& body) {
   if (sh.npw == 0) return;
   if (sh.mcnt == MF_MT) {
-    if (sh.npw == 2) body.template operator()<MF_MT, 2>();
-    else body.template operator()<MF_MT, 1>();
+    if (sh.npw == 2) {
+      if (sh.mc1 == 0) body.template operator()<MF_MT, 2, 0>();
+      else if (sh.mc1 == 2) body.template operator()<MF_MT, 2, 2>();
+      else body.template operator()<MF_MT, 2, 4>();
+    } else {
+      body.template operator()<MF_MT, 1, 0>();
+    }
   } else if (sh.mcnt == 4) {
-    body.template operator()<4, 1>();
+    body.template operator()<4, 1, 0>();
   } else if (sh.mcnt == 2) {
-    body.template operator()<2, 1>();
+    body.template operator()<2, 1, 0>();
   } else {
-    body.template operator()<1, 1>();
+    body.template operator()<1, 1, 0>();
   }
 }
 
@@ -328,6 +362,10 @@ __device__ __forceinline__ void mlp_load_in(char* act, int act_str, const void* 
 // ------------------------------------------------------------------------------------------------ forward
 // workgroup barrier for the LDS hand-offs inside a pass: __syncthreads() also waits vmcnt(0), i.e. for the global stores
 // in flight, which nothing here depends on
+// Sign bits of the 8 values of an item as one byte: value j sits at bit (j >> 1) + 4 * (j & 1) -- the order in which the
+// packed [x > 0] words of the forward (bit 0 / bit 16 of word k = values 2k / 2k+1, shifted left by k and ORed) fold into it.
+__device__ __forceinline__ unsigned mf_mask_byte(unsigned m) { return (m & 0xFu) | ((m >> 12) & 0xF0u); }
+__device__ __forceinline__ int mf_mask_bit(int j) { return (j >> 1) + 4 * (j & 1); }
 #define MF_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_fwd_kernel(MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -346,19 +384,25 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_fwd_kernel(MlpArgs
       const MlpShare shi = mlp_share(a.step[0].K, wave);
       unsigned mb[4] = {0u, 0u, 0u, 0u};
       const char* li0 = act + (shi.mt0 * 16 + r) * a.act_str + 16 * q;
-      mlp_dispatch(shi, [&]<int MCNT, int NPW>() {
+      mlp_dispatch(shi, [&]<int MCNT, int NPW, int MC1>() {
 #pragma unroll
         for (int pi = 0; pi < NPW; ++pi)
 #pragma unroll
           for (int mi = 0; mi < MCNT; ++mi) {
-            const uint4 u = *reinterpret_cast<const uint4*>(li0 + mi * 16 * a.act_str + shi.pair[pi] * 64);
+            const bool part = MC1 > 0 && pi == NPW - 1;      // the pair this wave shares by row tiles (mlp_share)
+            if (part && mi >= MC1) continue;
+            const int rt = part ? shi.mt1 - shi.mt0 + mi : mi;
+            const uint4 u = *reinterpret_cast<const uint4*>(li0 + rt * 16 * a.act_str + shi.pair[pi] * 64);
             const unsigned w[4] = {u.x, u.y, u.z, u.w};
-            unsigned bits = 0;
+            unsigned m = 0;
 #pragma unroll
-            for (int j = 7; j >= 0; --j) {
-              const int v = (j & 1) ? (int)(w[j >> 1] & 0xffff0000u) : (int)(w[j >> 1] << 16);
-              bits = (bits << 1) | (v > 0 ? 1u : 0u);
+            for (int k2 = 0; k2 < 4; ++k2) {
+              unsigned x, t;
+              asm("v_pk_max_i16 %0, %1, 0" : "=v"(x) : "v"(w[k2]));
+              asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "v"(x), "s"(0x00010001u));
+              m |= t << k2;
             }
+            const unsigned bits = mf_mask_byte(m);
             mb[(pi * MCNT + mi) >> 2] |= bits << (8 * ((pi * MCNT + mi) & 3));
           }
       });
@@ -382,7 +426,7 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_fwd_kernel(MlpArgs
 #pragma unroll
           for (int mi = 0; mi < MF_MT; ++mi) acc[mi][2 * pi + h] = init;
         }
-      mlp_dispatch(sh, [&]<int MCNT, int NPW>() { mlp_gemm_t<MCNT, NPW>(act, a.act_str, st.wf, st.K, sh, lane, acc); });
+      mlp_dispatch(sh, [&]<int MCNT, int NPW, int MC1>() { mlp_gemm_t<MCNT, NPW, MC1>(act, a.act_str, st.wf, st.K, sh, lane, acc); });
       const bool last = l + 1 == a.nsteps;
       const int out_cols = last ? st.out_stride : st.N;
       MF_BAR();      // every wave is done reading the layer's input (after the last layer: LDS is free for the next pass)
@@ -398,41 +442,42 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_fwd_kernel(MlpArgs
       bf16_t* out0 = reinterpret_cast<bf16_t*>(st.out) + (row0 + lrow) * st.out_stride + 8 * q;
       const int64_t left64 = a.rows - row0 - lrow;
       const int left = st.out == nullptr ? 0 : (left64 > MF_ROWS ? MF_ROWS : (int)left64);
-      mlp_dispatch(sh, [&]<int MCNT, int NPW>() {
+      mlp_dispatch(sh, [&]<int MCNT, int NPW, int MC1>() {
 #pragma unroll
         for (int pi = 0; pi < NPW; ++pi) {
           const bool colok = 32 * sh.pair[pi] + 8 * q < out_cols;
 #pragma unroll
           for (int mi = 0; mi < MCNT; ++mi) {
-            int iv[8];
+            const bool part = MC1 > 0 && pi == NPW - 1;      // the pair this wave shares by row tiles (mlp_share)
+            if (part && mi >= MC1) continue;
+            const int rt = part ? sh.mt1 - sh.mt0 + mi : mi;
+            // round to bf16 first (one convert per two values), then ReLU and the sign bits on the PACKED words: as 16-bit
+            // integers negative floats (and -0.0) are negative, so max(x, 0) is ReLU and min(x, 1) is [x > 0], two values per
+            // instruction (on the fp32 values it took three instructions per value: 48 VALU per item, now 36)
+            unsigned w[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              iv[i] = __float_as_int(acc[mi][2 * pi][i]);
-              iv[4 + i] = __float_as_int(acc[mi][2 * pi + 1][i]);
-            }
+            for (int k2 = 0; k2 < 4; ++k2)
+              w[k2] = f32x2_to_bf16x2_bits(acc[mi][2 * pi + (k2 >> 1)][2 * (k2 & 1)], acc[mi][2 * pi + (k2 >> 1)][2 * (k2 & 1) + 1]);
             unsigned bits = 0;
             if (st.relu) {
-              // on the bit patterns: max(int, 0) is ReLU (negative floats are negative ints, -0.0 included) and
-              // min(unsigned, 1) is [value > 0] -- 3 instructions per value with the shift-or, no NaN canonicalisation
+              unsigned m = 0;
 #pragma unroll
-              for (int j = 7; j >= 0; --j) {
-                iv[j] = iv[j] > 0 ? iv[j] : 0;
-                unsigned one;      // written as a min the compiler turns it back into compare + select
-                asm("v_min_u32 %0, 1, %1" : "=v"(one) : "v"(iv[j]));
-                bits = (bits << 1) | one;
+              for (int k2 = 0; k2 < 4; ++k2) {
+                unsigned t;
+                asm("v_pk_max_i16 %0, %1, 0" : "=v"(w[k2]) : "v"(w[k2]));
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "v"(w[k2]), "s"(0x00010001u));
+                m |= t << k2;
               }
+              bits = mf_mask_byte(m);
             }
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = __int_as_float(iv[j]);
-            const uint4 pk = Vec16<bf16_t>::pack(v);
-            if (!last) *reinterpret_cast<uint4*>(lds0 + mi * 16 * a.act_str + sh.pair[pi] * 64) = pk;      // the next layer's input
+            const uint4 pk = make_uint4(w[0], w[1], w[2], w[3]);
+            if (!last) *reinterpret_cast<uint4*>(lds0 + rt * 16 * a.act_str + sh.pair[pi] * 64) = pk;      // the next layer's input
             // the step's global output (hidden activations kept for the weight gradients / the result) leaves from the
             // registers: 16 bytes per lane, 64 contiguous bytes per row and wave.  (Global stores cost ~64 issue cycles
             // per wave instruction wherever they are placed -- 0.9 of the kernel's 3.3 ms; spreading them over the next
             // layer's k-steps from LDS, one per k-step with a counted vmcnt, measured the same.)
-            if (colok && 16 * mi < left)
-              store_stream(reinterpret_cast<uint4*>(out0 + (size_t)mi * 16 * st.out_stride + 32 * sh.pair[pi]), pk);
+            if (colok && 16 * rt < left)
+              store_stream(reinterpret_cast<uint4*>(out0 + (size_t)rt * 16 * st.out_stride + 32 * sh.pair[pi]), pk);
             mbits[(pi * MCNT + mi) >> 2] |= bits << (8 * ((pi * MCNT + mi) & 3));
           }
         }
@@ -480,6 +525,8 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_rows_gemm_kernel(RowsGem
       sh.pair[0] = p0;
       sh.pair[1] = p0 + MF_WAVES;
       sh.npw = sh.pair[1] < npairs ? 2 : 1;
+      sh.mt1 = 0;
+      sh.mc1 = 0;
       mf_f32x4 acc[MF_MT][2 * MF_MAXP];
 #pragma unroll
       for (int mi = 0; mi < MF_MT; ++mi)
@@ -539,7 +586,7 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_bwd_kernel(MlpArgs
       for (int mi = 0; mi < MF_MT; ++mi)
 #pragma unroll
         for (int t = 0; t < 2 * MF_MAXP; ++t) acc[mi][t] = mf_f32x4{0.f, 0.f, 0.f, 0.f};
-      mlp_dispatch(sh, [&]<int MCNT, int NPW>() { mlp_gemm_t<MCNT, NPW>(act, a.act_str, st.wf, st.K, sh, lane, acc); });
+      mlp_dispatch(sh, [&]<int MCNT, int NPW, int MC1>() { mlp_gemm_t<MCNT, NPW, MC1>(act, a.act_str, st.wf, st.K, sh, lane, acc); });
       __builtin_amdgcn_sched_barrier(0);
       // column sums of the step's input (the bias gradient of its layer): 8 row slices x 16-byte column chunks
       if (st.colsum != nullptr) {
@@ -573,12 +620,15 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_bwd_kernel(MlpArgs
       bf16_t* out0 = reinterpret_cast<bf16_t*>(st.out) + (row0 + lrow) * st.out_stride + 8 * q;
       const int64_t left64 = a.rows - row0 - lrow;
       const int left = st.out == nullptr ? 0 : (left64 > MF_ROWS ? MF_ROWS : (int)left64);
-      mlp_dispatch(sh, [&]<int MCNT, int NPW>() {
+      mlp_dispatch(sh, [&]<int MCNT, int NPW, int MC1>() {
 #pragma unroll
         for (int pi = 0; pi < NPW; ++pi) {
           const bool colok = 32 * sh.pair[pi] + 8 * q < out_cols;
 #pragma unroll
           for (int mi = 0; mi < MCNT; ++mi) {
+            const bool part = MC1 > 0 && pi == NPW - 1;      // the pair this wave shares by row tiles (mlp_share)
+            if (part && mi >= MC1) continue;
+            const int rt = part ? sh.mt1 - sh.mt0 + mi : mi;
             float v[8];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -589,12 +639,12 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_bwd_kernel(MlpArgs
               const int word = (int)mword[(pi * MCNT + mi) >> 2];
 #pragma unroll
               for (int j = 0; j < 8; ++j)      // sign-extended 1-bit field (0 / all ones) ANDed onto the value: 2 instructions
-                v[j] = __int_as_float(__float_as_int(v[j]) & __builtin_amdgcn_sbfe(word, 8 * ((pi * MCNT + mi) & 3) + j, 1));
+                v[j] = __int_as_float(__float_as_int(v[j]) & __builtin_amdgcn_sbfe(word, 8 * ((pi * MCNT + mi) & 3) + mf_mask_bit(j), 1));
             }
             const uint4 pk = Vec16<bf16_t>::pack(v);
-            if (!last || a.colsum_in != nullptr) *reinterpret_cast<uint4*>(lds0 + mi * 16 * a.act_str + sh.pair[pi] * 64) = pk;
-            if (colok && 16 * mi < left)      // as in the forward: from the registers
-              store_stream(reinterpret_cast<uint4*>(out0 + (size_t)mi * 16 * st.out_stride + 32 * sh.pair[pi]), pk);
+            if (!last || a.colsum_in != nullptr) *reinterpret_cast<uint4*>(lds0 + rt * 16 * a.act_str + sh.pair[pi] * 64) = pk;
+            if (colok && 16 * rt < left)      // as in the forward: from the registers
+              store_stream(reinterpret_cast<uint4*>(out0 + (size_t)rt * 16 * st.out_stride + 32 * sh.pair[pi]), pk);
           }
         }
       });
