@@ -273,11 +273,13 @@ __device__ __forceinline__ void mlp_gemm_t(const char* act, int act_str, const u
 // own value (no loop-carried register roles, nothing for the compiler to copy while a load is in flight) and the loads
 // can run TWO k-steps ahead -- a k-step (32 MFMAs of this wave, 64 with its SIMD neighbour) is about one L2 round trip,
 // one step of distance leaves the wave waiting at most steps.  Only fragments that will be multiplied are requested.
-template <int MCNT, int NPW, int KS>
+template <int MCNT, int NPW, int KS, int MC1 = 0>
 __device__ __forceinline__ void mlp_gemm_static(const char* act, int act_str, const uint4* __restrict__ wf,
                                                 const MlpShare& sh, int lane, mf_f32x4 (&acc)[MF_MT][2 * MF_MAXP]) {
   const int r = lane & 15, q = lane >> 4;
   const char* arow = act + (sh.mt0 * 16 + r) * act_str + q * 16;
+  const char* arow1 = act + (sh.mt1 * 16 + r) * act_str + q * 16;
+  constexpr int TF = 2 * (NPW - (MC1 > 0 ? 1 : 0));      // fragments of the pairs that cover all MCNT row tiles
   const uint4* wbase[NPW];
 #pragma unroll
   for (int pi = 0; pi < NPW; ++pi) wbase[pi] = wf + ((size_t)(2 * sh.pair[pi]) * KS) * 64 + lane;
@@ -315,12 +317,23 @@ __device__ __forceinline__ void mlp_gemm_static(const char* act, int act_str, co
       if (g + 1 < KS * NG) read_group(g + 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < 2 * NPW; ++t)
+      for (int t = 0; t < TF; ++t)
 #pragma unroll
         for (int mi = 0; mi < RT; ++mi)
           acc[gi * RT + mi][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
               __builtin_bit_cast(mf_bf16x8, F[ks][t]), __builtin_bit_cast(mf_bf16x8, B[g][mi]), acc[gi * RT + mi][t], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (MC1 > 0) {      // the pair shared by row tiles: MC1 row tiles from sh.mt1
+      uint4 Bx[MC1];
+#pragma unroll
+      for (int mi = 0; mi < MC1; ++mi) Bx[mi] = *reinterpret_cast<const uint4*>(arow1 + mi * 16 * act_str + ks * 64);
+#pragma unroll
+      for (int t = TF; t < TF + 2; ++t)
+#pragma unroll
+        for (int mi = 0; mi < MC1; ++mi)
+          acc[mi][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              __builtin_bit_cast(mf_bf16x8, F[ks][t]), __builtin_bit_cast(mf_bf16x8, Bx[mi]), acc[mi][t], 0, 0, 0);
     }
   }
 }
@@ -426,7 +439,10 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_fwd_kernel(MlpArgs
 #pragma unroll
           for (int mi = 0; mi < MF_MT; ++mi) acc[mi][2 * pi + h] = init;
         }
-      mlp_dispatch(sh, [&]<int MCNT, int NPW, int MC1>() { mlp_gemm_t<MCNT, NPW, MC1>(act, a.act_str, st.wf, st.K, sh, lane, acc); });
+      mlp_dispatch(sh, [&]<int MCNT, int NPW, int MC1>() {
+        if (MCNT == MF_MT && st.K == 416) mlp_gemm_static<MCNT, NPW, 13, MC1>(act, a.act_str, st.wf, sh, lane, acc);
+        else mlp_gemm_t<MCNT, NPW, MC1>(act, a.act_str, st.wf, st.K, sh, lane, acc);
+      });
       const bool last = l + 1 == a.nsteps;
       const int out_cols = last ? st.out_stride : st.N;
       MF_BAR();      // every wave is done reading the layer's input (after the last layer: LDS is free for the next pass)
@@ -586,7 +602,10 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_bwd_kernel(MlpArgs
       for (int mi = 0; mi < MF_MT; ++mi)
 #pragma unroll
         for (int t = 0; t < 2 * MF_MAXP; ++t) acc[mi][t] = mf_f32x4{0.f, 0.f, 0.f, 0.f};
-      mlp_dispatch(sh, [&]<int MCNT, int NPW, int MC1>() { mlp_gemm_t<MCNT, NPW, MC1>(act, a.act_str, st.wf, st.K, sh, lane, acc); });
+      mlp_dispatch(sh, [&]<int MCNT, int NPW, int MC1>() {
+        if (MCNT == MF_MT && st.K == 416) mlp_gemm_static<MCNT, NPW, 13, MC1>(act, a.act_str, st.wf, sh, lane, acc);
+        else mlp_gemm_t<MCNT, NPW, MC1>(act, a.act_str, st.wf, st.K, sh, lane, acc);
+      });
       __builtin_amdgcn_sched_barrier(0);
       // column sums of the step's input (the bias gradient of its layer): 8 row slices x 16-byte column chunks
       if (st.colsum != nullptr) {
