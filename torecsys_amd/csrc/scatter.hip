@@ -133,17 +133,23 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(int32_t* __res
   }
 }
 
-// Exclusive scan of data[0..n) in ONE pass (decoupled look-back): workgroup t scans its tile, publishes its aggregate in
-// status[t] (bit 30 = aggregate only, bit 31 = inclusive prefix; the counts are < 2^30), and finds its exclusive prefix
-// by walking back over its predecessors' status words until it meets an inclusive one.  Replaces tile-sums -> one-workgroup
-// scan of the sums -> apply (three launches, the middle one a single workgroup).  Workgroups are dispatched in index order
-// and the grid (V / 4096 tiles) is far smaller than what the chip keeps resident, so a predecessor is always running.
-// status[] must be zero on entry.
+// Exclusive scan of data[0..n) in ONE pass (decoupled look-back): a workgroup draws its tile from a ticket counter
+// (status[ntiles]; progress therefore never depends on the order blockIdx values are dispatched in: whoever holds tile t
+// started after the holders of tiles < t drew theirs), scans the tile, publishes its aggregate in status[t] (bit 30 =
+// aggregate only, bit 31 = inclusive prefix; the caller guarantees counts < 2^30) and finds its exclusive prefix by
+// walking back over its predecessors' status words until it meets an inclusive one.  The status words are written and
+// polled with relaxed agent-scope atomics (sc1: served by L2, never by a CU's own L1, and visible across XCDs); the
+// words carry their own payload, so no other memory has to be ordered with them.  Replaces tile-sums -> one-workgroup
+// scan of the sums -> apply (three launches, the middle one a single workgroup).  status[0..ntiles] must be zero on entry.
 __global__ __launch_bounds__(SCAN_THREADS) void scan_onepass_kernel(int32_t* __restrict__ data, int64_t n,
-                                                                    unsigned* __restrict__ status) {
+                                                                    unsigned* __restrict__ status, int ntiles) {
   __shared__ int lds[8];
   __shared__ int s_prefix;
-  const int tile = blockIdx.x;
+  __shared__ int s_tile;
+  if (threadIdx.x == 0)
+    s_tile = (int)__hip_atomic_fetch_add(&status[ntiles], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int tile = s_tile;
   const int64_t base = (int64_t)tile * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
   int v[SCAN_ITEMS];
   int s = 0;
@@ -155,22 +161,23 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_onepass_kernel(int32_t* __r
   int tot;
   const int ex = block_exclusive_scan(s, &tot, lds);
   if (threadIdx.x == 0) {
-    volatile unsigned* st = status;
     if (tile == 0) {
-      st[0] = 0x80000000u | (unsigned)tot;
+      __hip_atomic_store(&status[0], 0x80000000u | (unsigned)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_prefix = 0;
     } else {
-      st[tile] = 0x40000000u | (unsigned)tot;
-      __threadfence();
+      __hip_atomic_store(&status[tile], 0x40000000u | (unsigned)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       int run = 0;
       for (int p = tile - 1; p >= 0; --p) {
         unsigned w;
-        do { w = st[p]; } while ((w & 0xc0000000u) == 0u);
+        do {
+          w = __hip_atomic_load(&status[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((w & 0xc0000000u) == 0u) __builtin_amdgcn_s_sleep(1);
+        } while ((w & 0xc0000000u) == 0u);
         run += (int)(w & 0x3fffffffu);
         if (w & 0x80000000u) break;
       }
       s_prefix = run;
-      st[tile] = 0x80000000u | (unsigned)(run + tot);
+      __hip_atomic_store(&status[tile], 0x80000000u | (unsigned)(run + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   __syncthreads();
@@ -1066,7 +1073,7 @@ using namespace trs;
 // workspace layout for csr_build: [slot: BN int32][tile_sums: ntiles int32][rowT: BN int32][flags: 256 B]
 extern "C" size_t trs_csr_workspace_bytes(int64_t V, int64_t BN) {
   const size_t ntiles = (size_t)((V + 1 + SCAN_TILE - 1) / SCAN_TILE);
-  return 2 * align_up((size_t)BN * 4, 256) + align_up(ntiles * 4, 256) + 512;
+  return 2 * align_up((size_t)BN * 4, 256) + align_up((ntiles + 1) * 4, 256) + 512;   // + the scan's ticket word
 }
 
 extern "C" int trs_csr_build(const void* idx, int32_t idx_dtype, const int64_t* offsets, int64_t B, int32_t N,
@@ -1087,7 +1094,7 @@ extern "C" int trs_csr_build(const void* idx, int32_t idx_dtype, const int64_t* 
   const int64_t n = V + 1;
   const int ntiles = (int)((n + SCAN_TILE - 1) / SCAN_TILE);
   int32_t* tile_sums = (int32_t*)wsp;
-  wsp += align_up((size_t)ntiles * 4, 256);
+  wsp += align_up((size_t)(ntiles + 1) * 4, 256);
   int32_t* rowT = (int32_t*)wsp;
   wsp += align_up((size_t)BN * 4, 256);
   int32_t* flags = (int32_t*)wsp;
@@ -1100,9 +1107,10 @@ extern "C" int trs_csr_build(const void* idx, int32_t idx_dtype, const int64_t* 
   const int64_t max_items = (int64_t)N + (V + chunk - 1) / chunk;
   const bool part = offsets != nullptr && N <= CSR2_MAX_FIELDS && B >= 2048 && max_items <= 16 * (int64_t)N + 256 &&
                     max_items <= 16384;
-  const bool onepass = (n + SCAN_TILE - 1) / SCAN_TILE <= 2048;   // (the scan's status words are zeroed with the counters)
+  // one-pass scan: the status words hold 30-bit sums (B*N lookups in total) and are zeroed with the counters
+  const bool onepass = (n + SCAN_TILE - 1) / SCAN_TILE <= 2048 && BN < ((int64_t)1 << 30);
   hipLaunchKernelGGL(zero2_i32_kernel, dim3(stream_grid(n, 256, 1024)), dim3(256), 0, s, row_start, n, tile_sums,
-                     (int64_t)(onepass ? ntiles : 0));
+                     (int64_t)(onepass ? ntiles + 1 : 0));
   const int32_t* gate = nullptr;
   if (part) {
     zero_i32(flags, 64, s);
@@ -1130,7 +1138,8 @@ extern "C" int trs_csr_build(const void* idx, int32_t idx_dtype, const int64_t* 
                          V, row_start, slot, err_flag, gate);
   }
   if (onepass) {             // every tile's workgroup resident at once: one pass
-    hipLaunchKernelGGL(scan_onepass_kernel, dim3(ntiles), dim3(SCAN_THREADS), 0, s, row_start, n, (unsigned*)tile_sums);
+    hipLaunchKernelGGL(scan_onepass_kernel, dim3(ntiles), dim3(SCAN_THREADS), 0, s, row_start, n, (unsigned*)tile_sums,
+                       ntiles);
   } else {
     hipLaunchKernelGGL(scan_tile_sums_kernel, dim3(ntiles), dim3(SCAN_THREADS), 0, s, row_start, n, tile_sums);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, tile_sums, ntiles);

@@ -110,8 +110,10 @@ def _offsets_key(offsets):
     return v
 
 
-def _bucket_key(idx, offsets, V):
-    return (idx.data_ptr(), idx._version, tuple(idx.shape), idx.dtype, _offsets_key(offsets), V)
+def _bucket_key(idx, offsets, V, check=True):
+    # ``check`` is part of the key: a build that skipped out-of-range ids silently (fixed-capacity padding) must not be
+    # handed to a caller that expects the index flag to have been raised for them, nor the other way round
+    return (idx.data_ptr(), idx._version, tuple(idx.shape), idx.dtype, _offsets_key(offsets), V, bool(check))
 
 
 def _build_buckets(idx, offsets, V, check: bool = True) -> RowBuckets:
@@ -136,7 +138,7 @@ def row_buckets(idx: torch.Tensor, offsets: Optional[torch.Tensor], V: int, chec
     """Build (or fetch) the CSR for ``idx`` (B,N).  The cache keeps a reference to the index tensor,
     so its storage cannot be recycled for another batch while the entry is live; in-place edits bump
     ``_version`` and miss."""
-    key = _bucket_key(idx, offsets, V)
+    key = _bucket_key(idx, offsets, V, check)
     for k, _, rb in _bucket_cache:
         if k == key:
             rb.wait()
@@ -180,7 +182,7 @@ def prefetch_row_buckets(idx: torch.Tensor, offsets: Optional[torch.Tensor], V: 
     if _defer_depth[0] > 0:
         _pending_prefetch.append((idx, offsets, V, check))
         return
-    key = _bucket_key(idx, offsets, V)
+    key = _bucket_key(idx, offsets, V, check)
     for k, _, _rb in _bucket_cache:
         if k == key:
             return
@@ -978,9 +980,22 @@ class _RowsMulBias(Function):
 
 
 def rows_mul_bias(a: torch.Tensor, c: torch.Tensor, bias: Optional[torch.Tensor] = None, bias_per_pair: bool = False):
-    if a.dim() != 3 or a.shape != c.shape:
-        raise ValueError(f"rows_mul_bias operands must both be (B, P, E), got {tuple(a.shape)} and {tuple(c.shape)}")
-    return _RowsMulBias.apply(a, c, bias, bias_per_pair)
+    """out = a * c + bias.  Operands (*, P, E) of equal shape -- any number of leading dimensions, as the reference's
+    (N, *, H) contract allows (bilinear_interaction.py:11-79); they are folded into one batch axis for the kernel.
+    bias: (E,) shared by every pair, or (P, E) with ``bias_per_pair``; its shape is checked here because the kernel
+    indexes it without one."""
+    if a.dim() < 2 or a.shape != c.shape:
+        raise ValueError(f"rows_mul_bias operands must both be (*, P, E), got {tuple(a.shape)} and {tuple(c.shape)}")
+    P, E = a.shape[-2], a.shape[-1]
+    if bias is not None:
+        want = (P, E) if bias_per_pair else (E,)
+        if tuple(bias.shape) != want:
+            raise ValueError(f"rows_mul_bias: bias must be {want} for operands {tuple(a.shape)}, got {tuple(bias.shape)}")
+    if a.dim() == 3:
+        return _RowsMulBias.apply(a, c, bias, bias_per_pair)
+    lead = a.shape[:-2]
+    out = _RowsMulBias.apply(a.reshape(-1, P, E), c.reshape(-1, P, E), bias, bias_per_pair)
+    return out.reshape(*lead, P, E)
 
 
 PAIR_GEMM_MIN_BATCH = 256      # below this the one-kernel path (weights streamed per sample group) is used
@@ -1609,13 +1624,26 @@ def _ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[0 if t is None else t.data_ptr() for t in tensors])
 
 
-def mlp_fused_supported(x: torch.Tensor, widths: Sequence[int]) -> bool:
-    """bf16 rows on the HIP device, every width a multiple of 8 and at most 512, enough rows to fill the chip"""
-    if not (FUSED_MLP and x.is_cuda and x.dtype == torch.bfloat16 and x.numel() // max(1, x.shape[-1]) >= FUSED_MLP_MIN_ROWS):
+_mlp_fused_verdicts = {}
+
+
+def mlp_fused_supported_for(rows: int, dtype: torch.dtype, is_cuda: bool, widths: Sequence[int]) -> bool:
+    """bf16 rows on the HIP device, every width a multiple of 8 and at most 512, enough rows to fill the chip.  Takes the
+    row count / dtype / placement instead of a tensor (no throwaway allocation) and remembers the library's verdict per
+    width list."""
+    if not (FUSED_MLP and is_cuda and dtype == torch.bfloat16 and rows >= FUSED_MLP_MIN_ROWS):
         return False
     if len(widths) < 2 or len(widths) > 9 or any(w % 8 or w > 512 for w in widths):
         return False
-    return bool(_abi.load().trs_mlp_fused_supported(len(widths) - 1, _i32_array(widths)))
+    key = tuple(int(w) for w in widths)
+    ok = _mlp_fused_verdicts.get(key)
+    if ok is None:
+        ok = _mlp_fused_verdicts[key] = bool(_abi.load().trs_mlp_fused_supported(len(widths) - 1, _i32_array(widths)))
+    return ok
+
+
+def mlp_fused_supported(x: torch.Tensor, widths: Sequence[int]) -> bool:
+    return mlp_fused_supported_for(x.numel() // max(1, x.shape[-1]), x.dtype, x.is_cuda, widths)
 
 
 def fused_mlp_forward_raw(x2: torch.Tensor, Ws: Sequence[torch.Tensor], bs: Sequence[torch.Tensor],

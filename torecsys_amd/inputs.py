@@ -113,7 +113,8 @@ class MultiIndicesEmbedding(BaseInput):
             raise ValueError('missing required arguments')
         self.register_buffer('offsets', field_offsets(field_sizes), persistent=False)
         self.flatten = flatten
-        self.fuse_fm = DEFAULT_FUSE_FM if fuse_fm is None else bool(fuse_fm)
+        # the package default never overrides an explicit request for the fused inner-product lookup
+        self.fuse_fm = (DEFAULT_FUSE_FM and not fuse_ipn) if fuse_fm is None else bool(fuse_fm)
         self.fuse_ipn = fuse_ipn
         self.field_size = self.embedding.num_embeddings
         self.embed_size = self.embedding.embedding_dim

@@ -263,8 +263,14 @@ class FieldEachTypeBilinear(BaseLayer):
         ((P,B,E) @ (P,E,E)), then the product + per-pair bias pass on HIP."""
         x1, x2 = _strip(input1), _strip(input2)
         F_.require_device(x1, x2, self.weight)
-        T = torch.bmm(x1.transpose(0, 1), self.weight.to(x1.dtype)).transpose(0, 1)
-        return F_.rows_mul_bias(T, x2, self.bias, True)
+        if x1.dim() < 2 or x1.shape != x2.shape:
+            raise ValueError(f'FieldEachTypeBilinear operands must both be (*, P, E), got {tuple(x1.shape)} and '
+                             f'{tuple(x2.shape)}')
+        P, E = x1.shape[-2], x1.shape[-1]
+        lead = x1.shape[:-2]
+        a3, c3 = x1.reshape(-1, P, E), x2.reshape(-1, P, E)           # leading dimensions folded into the batch axis
+        T = torch.bmm(a3.transpose(0, 1), self.weight.to(x1.dtype)).transpose(0, 1)
+        return F_.rows_mul_bias(T, c3, self.bias, True).reshape(*lead, P, self.in2_features)
 
     def extra_repr(self):
         return (f'{self.weight.shape[0]} pair matrices of {self.in1_features} x {self.in2_features}, '
@@ -968,7 +974,8 @@ class MultilayerPerceptionLayer(BaseLayer):
         widths = [h_pad] + [m.out_features for m in tail[:-1]] + [out_pad]
         if any(a.in_features != b.out_features for a, b in zip(tail, layers[:-1])):
             return None
-        if first.in_features <= 512 or not F_.mlp_fused_supported(outputs.new_empty(outputs.shape[0], h_pad), widths):
+        if first.in_features <= 512 or not F_.mlp_fused_supported_for(outputs.shape[0], outputs.dtype, outputs.is_cuda,
+                                                                       widths):
             return None
         padded = [(first, outputs.shape[-1], h_pad) if (outputs.shape[-1] != first.in_features
                                                          or h_pad != first.out_features) else None,
