@@ -67,6 +67,12 @@ def parse():
     ap.add_argument("--rows-per-gpu", type=int, default=0, help="0 = 1M (N=1) / 125M (N>1)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--zipf", action="store_true", help="Zipf(1.05)-like skewed indices instead of uniform")
+    ap.add_argument("--field-layout", default="uniform", choices=["uniform", "skewed"],
+                    help="SURVEY 8d's two field-size layouts: uniform (38 x 25 641 + 25 642 at 1 M rows) or criteo-skewed "
+                         "(log-spaced sizes from 4 to ~300 k rows summing to the same total: tiny fields = very hot rows)")
+    ap.add_argument("--no-other-models", action="store_true",
+                    help="skip the short DCN / xDeepFM legs (BASELINE configs[2], [3]) the default one-GPU run appends")
+    ap.add_argument("--other-steps", type=int, default=5, help="timed steps of each of those legs")
     ap.add_argument("--no-fuse", action="store_true", help="separate lookup and FM kernels (drop-in unfused path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large-table", action="store_true",
@@ -102,7 +108,17 @@ def parse():
     return ap.parse_args()
 
 
-def field_sizes(total_rows, n_fields):
+def field_sizes(total_rows, n_fields, layout="uniform"):
+    if layout == "skewed" and n_fields > 1:
+        # log-spaced from 4 rows to 0.3 x total (300 k at 1 M rows), rescaled to the requested total
+        import math
+        lo, hi = math.log(4.0), math.log(0.3 * total_rows)
+        raw = [math.exp(lo + (hi - lo) * i / (n_fields - 1)) for i in range(n_fields)]
+        scale = total_rows / sum(raw)
+        sizes = [max(4, int(round(x * scale))) for x in raw]
+        sizes[-1] += total_rows - sum(sizes)
+        assert sizes[-1] >= 4 and sum(sizes) == total_rows
+        return sizes
     per = total_rows // n_fields
     return [per] * (n_fields - 1) + [total_rows - per * (n_fields - 1)]
 
@@ -203,6 +219,91 @@ WORKLOADS = {
 }
 
 
+MODEL_KERNELS = {"dcn": ["trs_cross_bwd"], "xdeepfm": ["trs_cin16_bwd_data", "trs_cin_cl_bwd_data"]}
+
+
+def model_kernel_roofline(model, kernel, mtimes, B, N, E, esz):
+    """dcn / xdeepfm: the dominant kernel of THEIR step is a matrix-core kernel (cross = MFMA-bound, CIN =
+    MFMA-bound): its FLOPs / HIP-event time against the dense bf16 MFMA peak."""
+    rows_ = B * N
+    if model == "dcn":
+        Lc = 6
+        flops = 2.0 * rows_ * E * E * (3 * Lc - 1)          # recompute L + gradient chain L-1 + weight gradient L
+        per_step = 1
+        what = ("cross_mfma_bwd3 (+ prepack and the two partial-sum reductions of the same entry point): "
+                "2*rows*E^2*(3L-1) FLOP, detached first layer")
+        hbm_alg = 3 * rows_ * E * esz
+    else:
+        Hs = [N, 128, 128]
+        flops = sum(2.0 * B * E * 256 * N * h for h in Hs)   # S_n = W_n^T gy over the three layers of a step
+        per_step = 3
+        what = (kernel.replace("trs_", "") + ", the three layers of a step together: sum_k 2*B*E*C*N*H_k FLOP (C = 256; "
+                "the first layer runs the symmetric fold and does about half of its share)")
+        hbm_alg = None
+    tsum = sum(mtimes) / len(mtimes) * per_step * 1e-3       # seconds per step in this kernel
+    out = {"bound": "mfma", "kernel": kernel.replace("trs_", ""), "what": what,
+           "achieved": round(flops / tsum / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
+           "frac": round(flops / tsum / 1e12 / 2500.0, 4), "flops_per_step": flops,
+           "us_per_step": round(tsum * 1e6, 1), "launches_timed": len(mtimes)}
+    if hbm_alg:
+        out["hbm_frac"] = round(hbm_alg / tsum / 1e9 / HBM_PEAK_GBS, 4)
+    return out
+
+
+def other_model_leg(name, a, dev, dt, inputs, idx_ring, label_ring, esz):
+    """BASELINE configs[2] / [3] in the default run: a few eager fwd+bwd steps of DCN / xDeepFM on the same inputs,
+    same batch ring and same definition of a step as the headline leg (dense table gradients, no optimizer), timed by a
+    HIP event pair around the steps; the dominant matrix-core kernel by events around each of its launches."""
+    from harness import ctr_models as M
+    from torecsys_amd import _abi
+    B, N, E = a.batch, a.fields, a.embed
+    torch.manual_seed(11)
+    if name == "dcn":
+        model = M.DeepAndCrossNetworkModel(inputs_size=E, num_fields=N, deep_output_size=64,
+                                           deep_layer_sizes=[400, 400, 400], cross_num_layers=6)
+    else:
+        model = M.XDeepFactorizationMachineModel(embed_size=E, num_fields=N, cin_layer_sizes=[128, 128, 128],
+                                                 deep_layer_sizes=[400, 400, 400])
+    model = model.to(dev).to(dt)
+    crit = nn.BCEWithLogitsLoss()
+    params = [p for p in list(inputs.parameters()) + list(model.parameters()) if p.requires_grad]
+    ring = len(idx_ring)
+
+    def one(k):
+        for p in params:
+            p.grad = None
+        d = inputs({"c0": idx_ring[k % ring]})
+        out = model(**d) if name != "dcn" else model(emb_inputs=d["emb_inputs"])
+        loss = crit(out.float(), label_ring[k % ring])
+        loss.backward()
+        return loss
+
+    for k in range(2):
+        one(k)
+    torch.cuda.synchronize()
+    kernels = MODEL_KERNELS[name] if dt == torch.bfloat16 else []
+    for kn in kernels:
+        _abi.time_kernel(kn, True, expect=3 * a.other_steps + 4, every=1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for k in range(a.other_steps):
+        loss = one(k)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / a.other_steps
+    leg = {"workload": WORKLOADS[name], "steps": a.other_steps, "ms_per_step": round(ms, 4),
+           "value": round(B / ms * 1e3, 1), "unit": "samples/s", "loss": float(loss.detach()), "hipgraph": False}
+    for kn in kernels:
+        ts = _abi.kernel_times_ms(kn)
+        _abi.time_kernel(kn, False)
+        if ts and "roofline_model_kernel" not in leg:
+            leg["roofline_model_kernel"] = model_kernel_roofline(name, kn, ts, B, N, E, esz)
+    for p in params:
+        p.grad = None
+    del model
+    return leg
+
+
 def large_table_roofline(a, dev, dt, esz, fm_only=False):
     """The roofline kernel again, stand-alone, on a table that cannot sit in the 256 MiB Infinity Cache (default 32 M
     rows x 64 x bf16 = 4 GiB): same batch shape, HIP events on the launch stream, median of the timed launches.
@@ -212,7 +313,7 @@ def large_table_roofline(a, dev, dt, esz, fm_only=False):
     from torecsys_amd import functional as F_
     B, N, E = a.batch, a.fields, a.embed
     Vb = a.large_table_rows
-    sizes = field_sizes(Vb, N)
+    sizes = field_sizes(Vb, N, a.field_layout)
     gen = torch.Generator().manual_seed(99)
     idx = synth_indices(B, sizes, gen, a.zipf).to(dev)
     off = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(torch.tensor(sizes), 0)[:-1]]).to(dev)
@@ -267,7 +368,7 @@ def main():
     B, N, E = a.batch, a.fields, a.embed
     rows_local = a.rows_per_gpu or (1_000_000 if world == 1 else 125_000_000)
     V = rows_local * world
-    sizes = field_sizes(V, N)
+    sizes = field_sizes(V, N, a.field_layout)
     gen = torch.Generator().manual_seed(1234 + rank)
     # a ring of distinct batches resident in HBM: every step sees new indices, so nothing derived from
     # them (row buckets for the backward) can be reused across steps
@@ -401,7 +502,11 @@ def main():
     roof_kernel = "trs_embed_fm" if not a.no_fuse else "trs_gather_rows"
     # dcn / xdeepfm: the dominant kernel of THEIR step is a matrix-core kernel (cross = MFMA-bound, CIN =
     # MFMA-bound): its FLOPs / time against the dense bf16 MFMA peak, next to the fused lookup launch
-    model_kernel = {"dcn": "trs_cross_bwd", "xdeepfm": "trs_cin_cl_bwd_data"}.get(a.model) if dt == torch.bfloat16 else None
+    model_kernel = MODEL_KERNELS.get(a.model, [None])[-1] if dt == torch.bfloat16 else None
+    if a.model == "xdeepfm" and dt == torch.bfloat16:
+        from torecsys_amd import layers as _layers_mod
+        if getattr(_layers_mod, "CIN_F16", False):
+            model_kernel = MODEL_KERNELS["xdeepfm"][0]
     first_kernel = "trs_gather_rows" if (not a.no_fuse and a.model in ("deepfm", "fm", "xdeepfm")) else None
     from torecsys_amd import inputs as _inputs_mod
     if (_inputs_mod.PAIR_FIRST_ORDER and not a.no_fuse and not sharded and a.optimizer == "none"
@@ -429,15 +534,22 @@ def main():
                             + ", ".join(f"{k.name[:50]} {k.duration:.1f}us" for k in ks) + "\n")
     if world > 1:
         dist.barrier()
-    if not sharded:          # the sharded step reports no single-kernel roofline (alg bytes depend on the routing)
-        # HIP events around every `--time-every`-th launch inside the timed region: bracketing all of them makes the
-        # host wait on the runtime's profiling signals and more than doubles the step (see _abi.time_kernel)
-        every = max(1, min(a.time_every, a.steps))
+    every = max(1, min(a.time_every, a.steps))
+
+    def enable_kernel_timing():
+        """eager steps: HIP events around every `--time-every`-th launch inside the timed region (bracketing all of them
+        makes the host wait on the runtime's profiling signals and more than doubles the step, see _abi.time_kernel).
+        Replayed steps: the timed graph carries NO timing launches at all; the roofline kernel is sampled after the
+        timed region from a second capture of the same step whose launches are bracketed by device timestamp marks."""
         _abi.time_kernel(roof_kernel, True, expect=a.steps // every + 2, every=every)
         if model_kernel:
             _abi.time_kernel(model_kernel, True, expect=3 * a.steps + 8, every=1)
         if first_kernel:       # the E = 1 first-order lookup of the same indices: the other half of SURVEY 8d's unit
             _abi.time_kernel(first_kernel, True, expect=a.steps // every + 2, every=every)
+
+    if not sharded and not use_graph:   # the sharded step reports no single-kernel roofline (alg bytes depend on the routing)
+        enable_kernel_timing()
+    graph_fn = None
     if use_graph:
         from torecsys_amd.graph import GraphedStep
 
@@ -449,7 +561,6 @@ def main():
             return l_
 
         try:
-            # the roofline kernel is bracketed by two captured device-timestamp marks (one sample per replay)
             gstep = GraphedStep(graph_fn, (idx_ring[0].int() if host_idx else idx_ring[0], label_ring[0]), params=params,
                                 warmup=1)      # staged batches arrive as int32
 
@@ -460,9 +571,6 @@ def main():
 
             for _ in range(a.warmup):
                 step()
-            _abi.kernel_times_ms(roof_kernel)      # drop the warm-up samples
-            if first_kernel:
-                _abi.kernel_times_ms(first_kernel)
         except Exception as exc:                   # capture refused on this box / runtime: the eager step is the same work
             if a.graph:
                 raise
@@ -470,9 +578,12 @@ def main():
             use_graph = False
             step = eager_step
             torch.cuda.synchronize()
+            enable_kernel_timing()
             for _ in range(a.warmup):
                 step()
             _abi.kernel_times_ms(roof_kernel)
+            if first_kernel:
+                _abi.kernel_times_ms(first_kernel)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -505,6 +616,7 @@ def main():
     gc.enable()
     torch.cuda.synchronize()
     span1.synchronize()      # belt and braces: the region's last event has completed
+    final_loss = float(loss.detach())
     if world > 1:
         dist.barrier()
     el = time.perf_counter() - t0
@@ -542,6 +654,19 @@ def main():
               (20 * 2 * 8192 ** 3 / (e0.elapsed_time(e1) * 1e-3) / 1e12,
                20 * 2 * (1 << 28) / (e1.elapsed_time(e2) * 1e-3) / 1e9), file=sys.stderr)
     device_span_ms = span0.elapsed_time(span1)
+    sampled_replays = 0
+    if use_graph and not sharded:
+        # the roofline kernel inside the step, sampled AFTER the timed region: a second capture of the same step with its
+        # launches of the roofline kernel (and of the first-order lookup) bracketed by two device timestamp marks each;
+        # every replay adds one sample per kernel.  The timed replays above carried none of these launches.
+        enable_kernel_timing()
+        torch.cuda.synchronize()
+        gstep_t = GraphedStep(graph_fn, (idx_ring[0].int() if host_idx else idx_ring[0], label_ring[0]), params=params,
+                              warmup=1)
+        sampled_replays = max(8, min(32, a.steps))
+        for j in range(sampled_replays):
+            gstep_t(idx_ring[j % RING].int() if host_idx else idx_ring[j % RING], label_ring[j % RING])
+        torch.cuda.synchronize()
     ktimes = _abi.kernel_times_ms(roof_kernel)
     _abi.time_kernel(roof_kernel, False)
     mtimes = _abi.kernel_times_ms(model_kernel) if (model_kernel and not sharded) else []
@@ -585,6 +710,9 @@ def main():
                                       "command, corrected per MI355X_MICROARCH.md; not collected in this run",
                     "alg_bytes_per_launch": alg, "side_output_bytes": side, "avg_launch_us": round(kt * 1e6, 2),
                     "launches_timed": len(ktimes),
+                    "timed_how": ("device timestamp marks around the launch in %d replays of a second capture of the step, "
+                                  "taken after the timed region (the timed replays carry no timing launches)" % sampled_replays)
+                                 if sampled_replays else "HIP events around every %d-th launch inside the timed region" % every,
                     "note": f"the {V * E * esz >> 20} MiB table of this configuration fits the 256 MiB Infinity Cache; "
                             "roofline_large_table repeats the same launch on a table that does not"}
         big = big_fm = None
@@ -603,29 +731,7 @@ def main():
                          "achieved": round(alg_full / (kt + ft) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(alg_full / (kt + ft) / 1e9 / HBM_PEAK_GBS, 4), "alg_bytes": alg_full,
                          "avg_launch_us": [round(kt * 1e6, 2), round(ft * 1e6, 2)]}
-        model_roof = None
-        if mtimes:
-            rows_ = B * N
-            if a.model == "dcn":
-                Lc = 6
-                flops = 2.0 * rows_ * E * E * (3 * Lc - 1)          # recompute L + gradient chain L-1 + weight gradient L
-                per_step = 1
-                what = ("cross_mfma_bwd3 (+ prepack and the two partial-sum reductions of the same entry point): "
-                        "2*rows*E^2*(3L-1) FLOP, detached first layer")
-                hbm_alg = 3 * rows_ * E * esz
-            else:
-                Hs = [N, 128, 128]
-                flops = sum(2.0 * B * E * 256 * N * h for h in Hs)   # S_n = W_n^T gy over the three layers of a step
-                per_step = 3
-                what = "cin_cl_bwd_data, the three layers of a step together: sum_k 2*B*E*C*N*H_k FLOP (C = 256)"
-                hbm_alg = None
-            tsum = sum(mtimes) / len(mtimes) * per_step * 1e-3       # seconds per step in this kernel
-            model_roof = {"bound": "mfma", "kernel": model_kernel.replace("trs_", ""), "what": what,
-                          "achieved": round(flops / tsum / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
-                          "frac": round(flops / tsum / 1e12 / 2500.0, 4), "flops_per_step": flops,
-                          "us_per_step": round(tsum * 1e6, 1), "launches_timed": len(mtimes)}
-            if hbm_alg:
-                model_roof["hbm_frac"] = round(hbm_alg / tsum / 1e9 / HBM_PEAK_GBS, 4)
+        model_roof = model_kernel_roofline(a.model, model_kernel, mtimes, B, N, E, esz) if mtimes else None
         res = {
             "metric": "CTR samples/sec fwd+bwd (DeepFM, 39 fields x dim 64)" if a.model == "deepfm" else
                       f"CTR samples/sec fwd+bwd ({a.model}, 39 fields x dim 64)",
@@ -633,12 +739,12 @@ def main():
             "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": (WORKLOADS[a.model] + f", {V} total rows, embed_dim {E}, batch {B}, "
-                                    + ("zipf" if a.zipf else "uniform") + " indices") if world == 1 else
+                                    + ("zipf" if a.zipf else "uniform") + f" indices, {a.field_layout} field sizes") if world == 1 else
                        ("BASELINE.json configs[4] (weak-scaled): DeepFM, " f"{V} rows row-sharded over {world} GPUs, "
                         f"global batch {B * world}"),
                        "global_batch": B * world, "rows": V, "parallelism": parallelism,
                        "microbatches": MB, "optimizer": a.optimizer, "hipgraph": bool(use_graph), "indices_from_host": bool(host_idx),
-                       "fused_lookup_fm": not a.no_fuse, "loss": float(loss.detach()),
+                       "fused_lookup_fm": not a.no_fuse, "loss": final_loss,
                        "host_enqueue_ms_per_step": round(enqueue_s / a.steps * 1e3, 4),
                        "device_span_ms_per_step": round(device_span_ms / a.steps, 4)},
             "roofline": roof,
@@ -652,9 +758,14 @@ def main():
         if model_roof is not None:
             res["roofline_model_kernel"] = model_roof
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(a, field_sizes(1_000_000, N))
+            res["cpu_baseline"] = cpu_baseline(a, field_sizes(1_000_000, N, a.field_layout))
             if not sharded and a.optimizer == "none" and a.model in ("deepfm", "fm"):
                 res["self_check"] = self_check(a, inputs, model, idx_ring[0], sizes)
+        if (world == 1 and not sharded and a.model == "deepfm" and not a.no_other_models and a.optimizer == "none"
+                and not a.no_fuse):
+            # BASELINE configs[2] and [3] ride along: a few steps each, reported beside the headline (never as `value`)
+            res["other_models"] = {m: other_model_leg(m, a, dev, dt, inputs, idx_ring, label_ring, esz)
+                                   for m in ("dcn", "xdeepfm")}
     else:
         res = None
     if sharded:

@@ -291,33 +291,6 @@ int trs_cin_dw(const void* gy, const void* x0, const void* xk, int64_t B, int32_
                int32_t E, int32_t dtype, int32_t tri, float* dW, void* workspace, size_t ws_bytes,
                trs_stream_t stream);
 
-/* ---- K5 on the matrix cores, packed-fp16 operand form (round 4; csrc/cin_f16.hip) -----------------------
- * The same contraction with the CIN layer's INTERNAL tensors in fp16: the outer product x0[p,n]*xk[p,h] is formed as
- * the MFMA operand by v_pk_mul_f16 (gfx950 has no packed bf16 arithmetic) and v_mfma_f32_32x32x16_f16 accumulates over
- * K = N*H in place.  fp16 has 3 more mantissa bits than bf16 and less range: the caller keeps |x0|*|xk| < 6e4 (and
- * hands power-of-two scales back in through the *_mul device scalars, which multiply the fp32 results).
- *   x0h (B,N,E) fp16 channels-first (the embedding block); xkT rows = B*E pixels of stride ldk (multiple of 8,
- *   >= 16*ceil(H/16), zeros past H) fp16; W (C, N*H) fp32 (Conv1d(k=1).weight squeezed; for tri the folded form of
- *   trs_cin_cl_fwd); bias (C) fp32 or NULL; out_mul: device float or NULL (1.0);  yT (B,E,C) bf16 = out_mul*acc + bias.
- * Requirements: E % 64 == 0, C in {128,256}, H <= 128, N <= 64 (trs_cin16_supported).
- * layers/ctr/compress_interaction_network.py:125-137.                                                       */
-int trs_cin16_supported(int32_t N, int32_t H, int32_t C, int32_t E);
-size_t trs_cin16_fwd_workspace_bytes(int32_t N, int32_t H, int32_t C);
-int trs_cin16_fwd(const void* x0h, const void* xkT, int32_t ldk, const float* W, const float* bias,
-                  const float* out_mul, int64_t B, int32_t N, int32_t H, int32_t C, int32_t E, int32_t tri,
-                  void* yT, void* workspace, size_t ws_bytes, trs_stream_t stream);
-
-/* data gradients of the same contraction (fp16 operands): given gyT rows (B*E) of C fp16 -- the gradient of yT times
- * whatever power of two keeps it inside fp16's range, undone by out_mul --
- *   dx0  (B,N,E) bf16 channels-first: dx0[b,n,e] = out_mul * sum_{c,h} gy*W*xk
- *   dxkT rows of stride ldo (>= 32*ceil(H/32)) bf16: dxkT[b*E+e,h] = out_mul * sum_{c,n} gy*W*x0   (zeros past H)
- * xkT rows need ldk >= 32*ceil(H/32) here.  tri (first layer, xkT = the transposed x0h, folded W): both tensors are
- * written; the caller adds dxkT[:, :, :N] transposed into dx0.                                               */
-size_t trs_cin16_bwd_data_workspace_bytes(int32_t N, int32_t H, int32_t C);
-int trs_cin16_bwd_data(const void* x0h, const void* xkT, int32_t ldk, const void* gyT, const float* W,
-                       const float* out_mul, int64_t B, int32_t N, int32_t H, int32_t C, int32_t E, int32_t tri,
-                       void* dx0, void* dxkT, int32_t ldo, void* workspace, size_t ws_bytes, trs_stream_t stream);
-
 /* ---- MLP backward epilogue (the GEMMs stay on hipBLASLt) -----------------------------------------------
  * y = relu(linear(x)):  gz = gy * (y > 0) and gb[c] = sum_r gz[r,c] (fp32) in ONE pass over (rows, C) instead of
  * ATen's threshold_backward + column sum.  C*sizeof(T) must be a multiple of 16 and <= 4096.

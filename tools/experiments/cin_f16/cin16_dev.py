@@ -1,7 +1,10 @@
-"""Developer harness for csrc/cin_f16.hip: parity of each kernel against a float64 contraction on the device and
-timings at the xDeepFM shape next to the bf16 kernels of cin_mfma.hip.
+"""Harness of the packed-fp16 CIN experiment (tools/experiments/cin_f16/cin_f16.hip, built by build.sh next to it; NOT
+part of the product library): parity of each kernel against a float64 contraction on the device and timings at the
+xDeepFM shape next to the shipped bf16 kernels of csrc/cin_mfma.hip.  Results: profiles/r04_cin_f16.md.
 
-    python tools/cin16_dev.py [fwd] [bwd] [dw] [--B 65536] [--check-B 512]
+    bash tools/experiments/cin_f16/build.sh && python tools/experiments/cin_f16/cin16_dev.py [fwd] [bwd] [--B 65536]
+    CIN16_LIB=<variant .so>: an ablation / staging variant built with build.sh -D... -o <name>
+    CIN16_DATA=abs|relu|zeros: contents of the hidden-state operand (power-dependent clocks)
 """
 import argparse
 import os
@@ -9,10 +12,39 @@ import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes  # noqa: E402
+from ctypes import c_int32, c_int64, c_size_t, c_void_p  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(HERE))))
 from torecsys_amd import _abi  # noqa: E402
-from torecsys_amd._abi import call, ptr, size_query, stream_ptr  # noqa: E402
+from torecsys_amd._abi import ptr, stream_ptr  # noqa: E402
 from torecsys_amd import functional as F_  # noqa: E402
+
+_abi.load()                                       # libtrs_hip.so first: the experiment library resolves its helpers there
+_P, _I32, _I64, _SZ = c_void_p, c_int32, c_int64, c_size_t
+_SIG = {
+    "trs_cin16_supported": (c_int32, [_I32, _I32, _I32, _I32]),
+    "trs_cin16_fwd_workspace_bytes": (_SZ, [_I32, _I32, _I32]),
+    "trs_cin16_fwd": (c_int32, [_P, _P, _I32, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _SZ, _P]),
+    "trs_cin16_bwd_data_workspace_bytes": (_SZ, [_I32, _I32, _I32]),
+    "trs_cin16_bwd_data": (c_int32, [_P, _P, _I32, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _I32, _P, _SZ, _P]),
+}
+_x = ctypes.CDLL(os.environ.get("CIN16_LIB") or os.path.join(HERE, "libcin16.so"))
+for _n, (_r, _a) in _SIG.items():
+    getattr(_x, _n).restype, getattr(_x, _n).argtypes = _r, _a
+
+
+def size_query(name, *args):
+    return int(getattr(_x, name)(*args)) if name in _SIG else _abi.size_query(name, *args)
+
+
+def call(name, *args):
+    if name not in _SIG:
+        return _abi.call(name, *args)
+    rc = getattr(_x, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {_abi.last_error()}")
 
 dev = torch.device("cuda:0")
 

@@ -18,7 +18,7 @@
 // All three: wave = one sample's 64 pixels (E = 64) as two 32-pixel tiles of v_mfma_f32_32x32x16_f16, one wave per SIMD
 // (512 registers), weights streamed L2 -> LDS by LDS-DMA one step ahead (lane-linear fragment images, conflict-free
 // ds_read_b128).
-#include "trs_common.hpp"
+#include "../../../torecsys_amd/csrc/trs_common.hpp"   // error helpers are resolved from libtrs_hip.so at link time
 
 namespace trs {
 
@@ -46,17 +46,60 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
   return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
 }
 
-// Staging of one step's weight image, L2 -> registers -> LDS.  A wave moves PP pieces of 1 KiB (one 16-byte vector per
-// lane) in groups of <= 4; group Q is requested at sub-step Q into register set Q & 1 and written to LDS two sub-steps
-// later (tail(): the groups the step has no sub-step left for).  Why not LDS-DMA (global_load_lds_dwordx4, which needs no
-// registers and was the first version of these kernels): its ISSUE costs the wave ~100 cycles per piece beside MFMAs
-// (MI355X_MICROARCH.md, price list), 16 pieces per 4096-cycle step -- the forward sat at 70 % matrix-pipe busy with it,
-// exactly that much short (profiles/r04_pmc_cin.md).  The loads are hand-issued (the compiler would sink ordinary loads
-// to their use and drain vmcnt(0) in front of it) and counted by hand: inside a step NO other vector-memory operation of
-// the wave is in flight, so `vmcnt` = the pieces of the younger groups.  Destinations are consumed right behind the
-// matching s_waitcnt (the rule of DESIGN.md section 8 for hand-issued loads).
+// Staging of one step's weight image from L2 into LDS.  A wave moves PP pieces of 1 KiB (one 16-byte vector per lane)
+// in groups of <= 4, group Q at sub-step Q of the step.  Two implementations with one interface:
+//  * Cin16StageDma (shipped): LDS-DMA (global_load_lds_dwordx4), no registers, no LDS-write instructions; the pieces
+//    are waited for with one vmcnt(0) in tail() -- inside a step no other vector-memory operation of the wave is in flight.
+//    M0 belongs to the compiler: saved and restored inside the statement.  No "memory" clobber on purpose: the
+//    destination is the buffer nobody reads before the next barrier, ordering comes from tail() + the barrier.
+//  * Cin16StageReg (-DTRS_CIN16_STAGE_REG, measured and not kept): hand-issued global_load_dwordx4 into a two-set register
+//    ring, written to LDS two sub-steps later.  The idea was that an LDS-DMA's issue costs the wave ~100 cycles per piece
+//    beside MFMAs (MI355X_MICROARCH.md price list); measured the other way round: forward 8.32 -> 8.87 ms, data gradient
+//    9.4 -> 13.7 ms at B = 65 536 (the counted waits in front of the LDS writes park the wave).
+template <int NP>
+__device__ __forceinline__ void cin16_dma(const char* src_lane, unsigned lds_dst_uniform) {
+  static_assert(NP >= 1 && NP <= 4, "pieces per statement");
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst_uniform);
+  if constexpr (NP == 4)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:2048\n\tglobal_load_lds_dwordx4 %1, off offset:3072\n\t"
+                 "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(src_lane), "s"(dst));
+  else if constexpr (NP == 3)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:2048\n\t"
+                 "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(src_lane), "s"(dst));
+  else if constexpr (NP == 2)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:1024\n\t"
+                 "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(src_lane), "s"(dst));
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\t"
+                 "s_mov_b32 m0, %0" : "=&s"(keep) : "v"(src_lane), "s"(dst));
+}
+
 template <int PP>
-struct Cin16Stage {
+struct Cin16StageDma {
+  static constexpr int NG = (PP + 3) / 4;
+  __host__ __device__ static constexpr int pieces(int q) { return q < PP / 4 ? 4 : (q == PP / 4 ? PP % 4 : 0); }
+  // src_wave_lane: the wave's share of the image + lane * 16; lds_wave: the wave's share of the target buffer
+  template <int SS>
+  __device__ __forceinline__ void substep(const char* src_wave_lane, u32x4* lds_wave, int) {
+    if constexpr (SS < NG) cin16_dma<pieces(SS)>(src_wave_lane + SS * 4096, lds_addr_of(lds_wave) + SS * 4096);
+  }
+  template <int NSS>
+  __device__ __forceinline__ void tail(u32x4*, int) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  __device__ __forceinline__ void all(const char* src_wave_lane, u32x4* lds_wave, int lane) {
+    static_for<0, NG>([&](auto q) { substep<decltype(q)::value>(src_wave_lane, lds_wave, lane); });
+    tail<NG>(lds_wave, lane);
+  }
+};
+
+template <int PP>
+struct Cin16StageReg {
   static constexpr int NG = (PP + 3) / 4;
   __host__ __device__ static constexpr int pieces(int q) { return q < PP / 4 ? 4 : (q == PP / 4 ? PP % 4 : 0); }
   u32x4 R[2][4];
@@ -73,42 +116,46 @@ struct Cin16Stage {
   }
   // LEFT = pieces of the groups requested after Q that may still be on their way
   template <int Q, int LEFT>
-  __device__ __forceinline__ void store(u32x4* lds_wave_lane) {
+  __device__ __forceinline__ void store(u32x4* lds_wave, int lane) {
     if constexpr (Q >= 0 && Q < NG) {
       constexpr int NPC = pieces(Q);
       asm volatile("s_waitcnt vmcnt(%0)" ::"i"(LEFT) : "memory");
       asm volatile("" : "+v"(R[Q & 1][0]), "+v"(R[Q & 1][1]), "+v"(R[Q & 1][2]), "+v"(R[Q & 1][3]));
 #pragma unroll
-      for (int j = 0; j < NPC; ++j) lds_wave_lane[(Q * 4 + j) * 64] = R[Q & 1][j];
+      for (int j = 0; j < NPC; ++j) lds_wave[(Q * 4 + j) * 64 + lane] = R[Q & 1][j];
     }
   }
-  // sub-step SS of a step with NSS sub-steps: write group SS - 2, request group SS
   template <int SS>
-  __device__ __forceinline__ void substep(const char* src_wave_lane, u32x4* lds_wave_lane) {
-    store<SS - 2, pieces(SS - 1)>(lds_wave_lane);
+  __device__ __forceinline__ void substep(const char* src_wave_lane, u32x4* lds_wave, int lane) {
+    store<SS - 2, pieces(SS - 1)>(lds_wave, lane);
     load<SS>(src_wave_lane);
   }
   template <int Q, int NSS>
-  __device__ __forceinline__ void tail_from(u32x4* lds_wave_lane) {
+  __device__ __forceinline__ void tail_from(u32x4* lds_wave, int lane) {
     if constexpr (Q < NG) {
       constexpr int left = [] { int t = 0; for (int q = Q + 1; q < NG; ++q) t += pieces(q); return t; }();
-      store<Q, left>(lds_wave_lane);
-      tail_from<Q + 1, NSS>(lds_wave_lane);
+      store<Q, left>(lds_wave, lane);
+      tail_from<Q + 1, NSS>(lds_wave, lane);
     }
   }
   template <int NSS>
-  __device__ __forceinline__ void tail(u32x4* lds_wave_lane) { tail_from<(NSS >= 2 ? NSS - 2 : 0), NSS>(lds_wave_lane); }
-  // the whole image at once (kernel prologue)
-  __device__ __forceinline__ void all(const char* src_wave_lane, u32x4* lds_wave_lane) { all_from<0>(src_wave_lane, lds_wave_lane); }
+  __device__ __forceinline__ void tail(u32x4* lds_wave, int lane) { tail_from<(NSS >= 2 ? NSS - 2 : 0), NSS>(lds_wave, lane); }
   template <int Q>
-  __device__ __forceinline__ void all_from(const char* src_wave_lane, u32x4* lds_wave_lane) {
+  __device__ __forceinline__ void all_from(const char* src_wave_lane, u32x4* lds_wave, int lane) {
     if constexpr (Q < NG) {
       load<Q>(src_wave_lane);
-      store<Q, 0>(lds_wave_lane);
-      all_from<Q + 1>(src_wave_lane, lds_wave_lane);
+      store<Q, 0>(lds_wave, lane);
+      all_from<Q + 1>(src_wave_lane, lds_wave, lane);
     }
   }
+  __device__ __forceinline__ void all(const char* src_wave_lane, u32x4* lds_wave, int lane) { all_from<0>(src_wave_lane, lds_wave, lane); }
 };
+
+#ifdef TRS_CIN16_STAGE_REG
+template <int PP> using Cin16Stage = Cin16StageReg<PP>;
+#else
+template <int PP> using Cin16Stage = Cin16StageDma<PP>;
+#endif
 
 __device__ __forceinline__ h16x8 cin16_scale(const uint4& f, h16x2 s) {
   const h16x2 a = __builtin_bit_cast(h16x2, f.x) * s, b = __builtin_bit_cast(h16x2, f.y) * s,
@@ -142,6 +189,11 @@ __global__ __launch_bounds__(256) void cin16_prepack_fwd_kernel(const float* __r
 // A step = one field n: its C x (16 KS) weight image (KS*CT KiB) is in LDS buffer `par`, the next field's is on its way
 // into the other one.  The image stream is cyclic in n and does not depend on the item, so it runs continuously over
 // the items a workgroup walks.
+// developer ablations of the forward kernel (wrong results, timing only): -DTRS_CIN16_ABL=<bits>
+//   1 no staging of the next image   2 no barrier   4 no LDS fragment reads   8 no operand scaling
+#ifndef TRS_CIN16_ABL
+#define TRS_CIN16_ABL 0
+#endif
 template <int KS, int CT, bool TRI>
 __global__ __launch_bounds__(256) void cin16_fwd_kernel(const h16* __restrict__ x0h, const h16* __restrict__ xkT, int ldk,
                                                         const char* __restrict__ Wp, const float* __restrict__ bias,
@@ -157,12 +209,12 @@ __global__ __launch_bounds__(256) void cin16_fwd_kernel(const h16* __restrict__ 
   const uint4* Wb = reinterpret_cast<const uint4*>(smem);
   unsigned* x0w = reinterpret_cast<unsigned*>(smem + 2 * FRB) + (size_t)wave * N * 32;      // [N][32] (tile 0 | tile 1 << 16)
   float* bs = reinterpret_cast<float*>(smem + 2 * FRB + (size_t)4 * N * 32 * 4);            // [C]
-  u32x4* wdst = reinterpret_cast<u32x4*>(smem + wave * (PP * 1024)) + lane;     // this wave's share of buffer 0
+  u32x4* wdst = reinterpret_cast<u32x4*>(smem + wave * (PP * 1024));            // this wave's share of buffer 0
   const char* wsrc = Wp + wave * (PP * 1024) + lane * 16;
   const int epb = E / 64;
   for (int i = threadIdx.x; i < C; i += 256) bs[i] = bias ? bias[i] : 0.f;
   Cin16Stage<PP> stg;
-  stg.all(wsrc, wdst);
+  stg.all(wsrc, wdst, lane);
   __syncthreads();
   const float mul = out_mul ? *out_mul : 1.f;
   int par = 0;
@@ -229,7 +281,7 @@ __global__ __launch_bounds__(256) void cin16_fwd_kernel(const h16* __restrict__ 
         loadA(0, A, 0);
         static_for<0, KS>([&](auto ksc) {
           constexpr int ks = decltype(ksc)::value;
-          stg.template substep<ks>(wsrc + (size_t)nn * FRB, wdst + (par ^ 1) * (FRB / 16));
+          stg.template substep<ks>(wsrc + (size_t)nn * FRB, wdst + (par ^ 1) * (FRB / 16), lane);
           if (ks < ks_end) {
             if (ks + 1 < KS && ks + 1 < ks_end) loadA((ks + 1) & 1, A, ks + 1);
             const h16x8 s0 = cin16_scale(Bf[0][ks], xlo), s1 = cin16_scale(Bf[1][ks], xhi);
@@ -238,25 +290,26 @@ __global__ __launch_bounds__(256) void cin16_fwd_kernel(const h16* __restrict__ 
             __builtin_amdgcn_sched_barrier(0);
           }
         });
-        stg.template tail<KS>(wdst + (par ^ 1) * (FRB / 16));
+        stg.template tail<KS>(wdst + (par ^ 1) * (FRB / 16), lane);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
       } else {
         static_for<0, KS>([&](auto ksc) {
           constexpr int ks = decltype(ksc)::value;
-          stg.template substep<ks>(wsrc + (size_t)nn * FRB, wdst + (par ^ 1) * (FRB / 16));
+          if constexpr (!(TRS_CIN16_ABL & 1)) stg.template substep<ks>(wsrc + (size_t)nn * FRB, wdst + (par ^ 1) * (FRB / 16), lane);
           if constexpr (ks + 1 < KS) {
-            loadA(aset(ks + 1), A, ks + 1);
+            if constexpr (!(TRS_CIN16_ABL & 4)) loadA(aset(ks + 1), A, ks + 1);
           } else {
             // the step's last k-step: its fragments are in registers, so the hand-over to the next image (image written,
             // own reads done, barrier, first fragments of the next step) happens BEFORE its MFMAs -- the matrix pipe has
             // 16 of them to chew on while the first LDS reads of the next step are in flight
-            stg.template tail<KS>(wdst + (par ^ 1) * (FRB / 16));
+            if constexpr (!(TRS_CIN16_ABL & 1)) stg.template tail<KS>(wdst + (par ^ 1) * (FRB / 16), lane);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            loadA(aset(0), Anext, 0);
+            if constexpr (!(TRS_CIN16_ABL & 2)) __builtin_amdgcn_s_barrier();
+            if constexpr (!(TRS_CIN16_ABL & 4)) loadA(aset(0), Anext, 0);
           }
-          const h16x8 s0 = cin16_scale(Bf[0][ks], xlo), s1 = cin16_scale(Bf[1][ks], xhi);
+          const h16x8 s0 = (TRS_CIN16_ABL & 8) ? __builtin_bit_cast(h16x8, Bf[0][ks]) : cin16_scale(Bf[0][ks], xlo);
+          const h16x8 s1 = (TRS_CIN16_ABL & 8) ? __builtin_bit_cast(h16x8, Bf[1][ks]) : cin16_scale(Bf[1][ks], xhi);
           __builtin_amdgcn_sched_barrier(0);
           mfmas(aset(ks), s0, s1);
           __builtin_amdgcn_sched_barrier(0);
@@ -327,11 +380,11 @@ __global__ __launch_bounds__(512) void cin16_bwd_data_kernel(const h16* __restri
   const int r = lane & 31, g = lane >> 5;
   const uint4* Wb = reinterpret_cast<const uint4*>(smem);
   unsigned short* x0w = reinterpret_cast<unsigned short*>(smem + 2 * FRB) + (size_t)wave * N * 32;     // [N][32]
-  u32x4* wdst = reinterpret_cast<u32x4*>(smem + wave * (PP * 1024)) + lane;
+  u32x4* wdst = reinterpret_cast<u32x4*>(smem + wave * (PP * 1024));
   const char* wsrc = WpT + wave * (PP * 1024) + lane * 16;
   const int epb = E / 32;
   Cin16Stage<PP> stg;
-  stg.all(wsrc, wdst);
+  stg.all(wsrc, wdst, lane);
   __syncthreads();
   const float mul = out_mul ? *out_mul : 1.f;
   int par = 0;
@@ -371,7 +424,7 @@ __global__ __launch_bounds__(512) void cin16_bwd_data_kernel(const h16* __restri
       float d0 = 0.f;
       static_for<0, HT>([&](auto htc) {
         constexpr int ht = decltype(htc)::value;
-        stg.template substep<ht>(wsrc + (size_t)nn * FRB, wdst + (par ^ 1) * (FRB / 16));
+        stg.template substep<ht>(wsrc + (size_t)nn * FRB, wdst + (par ^ 1) * (FRB / 16), lane);
         if (!TRI || ht < ht_end) {
           f32x16 S;
 #pragma unroll
@@ -396,7 +449,7 @@ __global__ __launch_bounds__(512) void cin16_bwd_data_kernel(const h16* __restri
           __builtin_amdgcn_sched_barrier(0);
         }
       });
-      stg.template tail<HT>(wdst + (par ^ 1) * (FRB / 16));
+      stg.template tail<HT>(wdst + (par ^ 1) * (FRB / 16), lane);
       {
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(d0), __float_as_uint(d0), false, false);
         const float tot = (__uint_as_float(sw[0]) + __uint_as_float(sw[1])) * mul;

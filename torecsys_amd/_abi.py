@@ -109,11 +109,6 @@ SIGNATURES = {
                                       _P, _SZ, _P]),
     "trs_cin_dw_workspace_bytes": (_SZ, [_I64, _I32, _I32, _I32]),
     "trs_cin_dw": (c_int32, [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _SZ, _P]),
-    "trs_cin16_supported": (c_int32, [_I32, _I32, _I32, _I32]),
-    "trs_cin16_fwd_workspace_bytes": (_SZ, [_I32, _I32, _I32]),
-    "trs_cin16_fwd": (c_int32, [_P, _P, _I32, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _SZ, _P]),
-    "trs_cin16_bwd_data_workspace_bytes": (_SZ, [_I32, _I32, _I32]),
-    "trs_cin16_bwd_data": (c_int32, [_P, _P, _I32, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _I32, _P, _SZ, _P]),
     "trs_relu_bwd_bias_workspace_bytes": (_SZ, [_I64, _I32]),
     "trs_relu_bwd_bias": (c_int32, [_P, _P, _I64, _I32, _I32, _P, _P, _P, _SZ, _P]),
     "trs_mlp_fused_supported": (c_int32, [_I32, _P]),

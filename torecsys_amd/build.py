@@ -23,7 +23,7 @@ FLAGS = ["-O3", "-std=c++20", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=
 # cost more issue time beside the matrix pipe than the two single ones they replace (CIN forward 1.58 vs 1.18 ms, cross
 # backward 1.15 vs 1.04 ms)
 FILE_FLAGS = {"cin_mfma.hip": ["-fno-slp-vectorize"], "cross_mfma.hip": ["-fno-slp-vectorize"],
-              "mlp_fused.hip": ["-fno-slp-vectorize"], "cin_f16.hip": ["-fno-slp-vectorize"]}
+              "mlp_fused.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():
