@@ -93,6 +93,10 @@ def parse():
                          "one GPU -- per-micro-batch host syncs and sparse-gradient accumulation outweigh the overlap)")
     ap.add_argument("--dedup", action="store_true",
                     help="sharded path: send every distinct row id of the local batch once (pays on skewed indices)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="sharded path: issue every exchange where the step needs it (default: the lookup exchange of batch "
+                         "k+1 and the gradient exchange of batch k run on a communication stream under the dense compute, "
+                         "dist.prefetch_lookup / overlap_grad_exchange)")
     ap.add_argument("--capacity", type=float, default=0.0,
                     help="sharded path: fixed-capacity all-to-all slots (factor on the even share B*N/world, e.g. 1.1): equal "
                          "splits, no split size read on the host (dist.RowShardedMultiIndicesEmbedding(capacity=...))")
@@ -377,6 +381,7 @@ def main():
     label_ring = [(torch.rand(B, 1, generator=gen) < 0.25).float().to(dev) for _ in range(RING)]
 
     torch.manual_seed(7)
+    pipelined = False
     if not sharded:
         emb = MultiIndicesEmbedding(embed_size=E, field_sizes=sizes, fuse_fm=not a.no_fuse)
         feat = MultiIndicesEmbedding(embed_size=1, field_sizes=sizes)
@@ -384,10 +389,12 @@ def main():
     else:
         from torecsys_amd.dist import RowShardedMultiIndicesEmbedding
         cap = a.capacity if a.capacity >= 1.0 else None
+        pipelined = not a.no_pipeline and a.optimizer == "none" and (a.microbatches or 1) == 1
         emb = RowShardedMultiIndicesEmbedding(embed_size=E, field_sizes=sizes, fuse_fm=not a.no_fuse,
-                                              dtype=dt, device=dev, dedup=a.dedup, capacity=cap)
+                                              dtype=dt, device=dev, dedup=a.dedup, capacity=cap,
+                                              overlap_grad_exchange=pipelined)
         feat = RowShardedMultiIndicesEmbedding(embed_size=1, field_sizes=sizes, dtype=dt, device=dev, dedup=a.dedup,
-                                               capacity=cap)
+                                               capacity=cap, overlap_grad_exchange=pipelined)
         parallelism = f"row-sharded table x{world} (all-to-all lookup), data-parallel MLP"
     emb.set_schema(["c0"])       # the whole (B,N) index block travels as one named column
     feat.set_schema(["c0"])
@@ -459,7 +466,16 @@ def main():
             t0 = time.perf_counter()
             loss = fwd_loss(next_indices(k), label_ring[k], 1.0)
             t1 = time.perf_counter()
-            if sharded:      # input-pipeline style hint: start routing the batch after the next one before this backward
+            if sharded and pipelined:
+                # the NEXT batch's lookup exchange (route, id all-to-all, owner gather, row all-to-all) goes onto the
+                # communication stream now and runs under this batch's backward; the gradient exchange of this batch
+                # runs under the next forward (overlap_grad_exchange).  fwd+bwd metric: the shards do not change, so the
+                # early lookup is bit-identical (tests/test_dist_gloo.py::test_row_sharded_pipelined_step_is_bit_equal)
+                emb.prefetch_lookup(idx_ring[(k + 1) % RING])
+                feat.prefetch_lookup(idx_ring[(k + 1) % RING])
+                if not cap:
+                    emb.prefetch_route(idx_ring[(k + 3) % RING])      # split sizes read on the host: routed further ahead
+            elif sharded:    # input-pipeline style hint: start routing the batch after the next one before this backward
                 emb.prefetch_route(idx_ring[(k + 2) % RING])
             t2 = time.perf_counter()
             loss.backward()
@@ -654,6 +670,25 @@ def main():
               (20 * 2 * 8192 ** 3 / (e0.elapsed_time(e1) * 1e-3) / 1e12,
                20 * 2 * (1 << 28) / (e1.elapsed_time(e2) * 1e-3) / 1e9), file=sys.stderr)
     device_span_ms = span0.elapsed_time(span1)
+    shard_diag = None
+    if sharded:
+        # diagnostic leg, outside the timed region: a few more steps with a HIP event pair around every phase of the
+        # sharded lookup (on the stream it runs on) and the bytes each rank puts on the wire
+        from torecsys_amd import dist as _d
+        _d.PROFILE = True
+        _d.phase_events.clear()
+        for kk in _d.wire_bytes:
+            _d.wire_bytes[kk] = 0
+        for _ in range(6):
+            step()
+        torch.cuda.synchronize()
+        ph = _d.phase_times_ms()
+        _d.PROFILE = False
+        nst = max(1, _d.wire_bytes["steps"] // 2)          # two sharded tables (E = 64 and E = 1) per step
+        shard_diag = {"phase_ms_per_call": {k_: round(v_, 4) for k_, v_ in ph.items()},
+                      "wire_bytes_sent_per_step": {k_: int(v_ / nst) for k_, v_ in _d.wire_bytes.items() if k_ != "steps"},
+                      "pipelined": bool(pipelined), "lookups": dict(_d.lookup_stats), "routes": dict(_d.route_stats),
+                      "note": "device ms per call of each phase (two tables per step share the route); rank 0 only"}
     sampled_replays = 0
     if use_graph and not sharded:
         # the roofline kernel inside the step, sampled AFTER the timed region: a second capture of the same step with its
@@ -661,6 +696,8 @@ def main():
         # every replay adds one sample per kernel.  The timed replays above carried none of these launches.
         enable_kernel_timing()
         torch.cuda.synchronize()
+        loss = None
+        gstep.output = None       # the first capture's autograd graph must be gone before the parameters are captured again
         gstep_t = GraphedStep(graph_fn, (idx_ring[0].int() if host_idx else idx_ring[0], label_ring[0]), params=params,
                               warmup=1)
         sampled_replays = max(8, min(32, a.steps))
@@ -746,7 +783,8 @@ def main():
                        "microbatches": MB, "optimizer": a.optimizer, "hipgraph": bool(use_graph), "indices_from_host": bool(host_idx),
                        "fused_lookup_fm": not a.no_fuse, "loss": final_loss,
                        "host_enqueue_ms_per_step": round(enqueue_s / a.steps * 1e3, 4),
-                       "device_span_ms_per_step": round(device_span_ms / a.steps, 4)},
+                       "device_span_ms_per_step": round(device_span_ms / a.steps, 4),
+                       **({"sharded": shard_diag} if shard_diag is not None else {})},
             "roofline": roof,
         }
         if big is not None:

@@ -249,6 +249,98 @@ def test_row_sharded_fixed_capacity_overflow_is_flagged():
     assert not bool(bad) and torch.equal(inv_pad[60:], torch.arange(64, 128, dtype=torch.int32))
 
 
+def _pipeline_worker(rank, world, port, fuse, capacity, ret):
+    """>= 4 training-shaped steps with the cross-step pipeline (prefetch_lookup of batch k+1 issued before the backward of
+    batch k; overlap_grad_exchange) against the same steps without it: blocks, FM terms and shard gradients bit-equal."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from torecsys_amd import dist as D
+        from torecsys_amd.dist import RowShardedMultiIndicesEmbedding
+        fs = [7, 3, 11, 5, 9]
+        N, E, B, STEPS = len(fs), 8, 12, 5
+        g = torch.Generator().manual_seed(17)
+        W = torch.randn(sum(fs), E, generator=g)
+        batches = [[torch.cat([torch.randint(0, f, (B, 1), generator=g) for f in fs], 1) for _ in range(world)]
+                   for _ in range(STEPS)]
+        gbs = [[torch.randn(B, N, E, generator=g) for _ in range(world)] for _ in range(STEPS)]
+        gfs = [[torch.randn(B, E, generator=g) for _ in range(world)] for _ in range(STEPS)]
+
+        def run(pipelined):
+            D.clear_route_caches()
+            D._lookup_cache.clear()
+            m = RowShardedMultiIndicesEmbedding(embed_size=E, field_sizes=fs, fuse_fm=fuse, ops=CpuOps(), capacity=capacity,
+                                                overlap_grad_exchange=pipelined)
+            m.load_full_weight(W)
+            outs = []
+            if pipelined:
+                m.prefetch_lookup(batches[0][rank])
+            for k in range(STEPS):
+                m.embedding.weight.grad = None
+                out = m(batches[k][rank])
+                loss = (out.rename(None) * gbs[k][rank]).sum()
+                fm = None
+                if fuse:
+                    fm = out._trs_fused_fm[0]
+                    loss = loss + (fm * gfs[k][rank]).sum()
+                if pipelined and k + 1 < STEPS:
+                    m.prefetch_lookup(batches[k + 1][rank])        # the next batch's exchange, ahead of this backward
+                loss.backward()
+                m.wait_grad()
+                outs.append((out.rename(None).detach().clone(), None if fm is None else fm.detach().clone(),
+                             m.embedding.weight.grad.detach().clone()))
+            return outs
+
+        D.lookup_stats.update(prefetched=0, inline=0)
+        a = run(False)
+        assert D.lookup_stats["prefetched"] == 0 and D.lookup_stats["inline"] == STEPS
+        D.lookup_stats.update(prefetched=0, inline=0)
+        b = run(True)
+        assert D.lookup_stats["prefetched"] == STEPS and D.lookup_stats["inline"] == 0, D.lookup_stats
+        for k, (x, y) in enumerate(zip(a, b)):
+            assert torch.equal(x[0], y[0]), f"block differs at step {k}"
+            assert (x[1] is None and y[1] is None) or torch.equal(x[1], y[1]), f"FM differs at step {k}"
+            assert torch.equal(x[2], y[2]), f"shard gradient differs at step {k}"
+        # a fused optimizer makes an early lookup stale: refused unless asked for
+        from torecsys_amd.optim import FusedSparseSGD
+        m = RowShardedMultiIndicesEmbedding(embed_size=E, field_sizes=fs, fuse_fm=fuse, ops=CpuOps(), capacity=capacity)
+        m.load_full_weight(W)
+        m.set_fused_optimizer(FusedSparseSGD(0.1))
+        try:
+            m.prefetch_lookup(batches[0][rank])
+            raise AssertionError("prefetch_lookup must refuse a fused optimizer without stale_ok")
+        except RuntimeError as e:
+            assert "stale_ok" in str(e)
+        # stale_ok: step k+1 sees the rows as they were BEFORE step k's update (one update behind), nothing else changes
+        m.prefetch_lookup(batches[0][rank], stale_ok=True)
+        out0 = m(batches[0][rank])
+        m.prefetch_lookup(batches[1][rank], stale_ok=True)
+        (out0.rename(None) * gbs[0][rank]).sum().backward()          # updates the shards
+        out1 = m(batches[1][rank])
+        from oracle import cpu_ref as O
+        ref1 = O.multi_indices_embedding(W, batches[1][rank], O.field_offsets(fs))
+        assert torch.equal(out1.rename(None), ref1), "the early lookup reads the rows of before the update"
+        ret[rank] = "ok"
+    except Exception:  # noqa: BLE001
+        import traceback
+        ret[rank] = "FAIL: " + traceback.format_exc()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,fuse,capacity", [(2, True, None), (3, False, None), (2, True, 2.0), (1, True, None)])
+def test_row_sharded_pipelined_step_is_bit_equal(world, fuse, capacity):
+    """dist.prefetch_lookup + overlap_grad_exchange (the cross-step pipeline of DESIGN.md section 6) change WHEN the
+    exchanges are issued, never what they compute"""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    mp.spawn(_pipeline_worker, args=(world, port, fuse, capacity, ret), nprocs=world, join=True)
+    for r in range(world):
+        assert ret.get(r) == "ok", ret.get(r)
+
+
 def test_default_ops_refuse_cpu():
     from torecsys_amd.dist import HipOps
     with pytest.raises(RuntimeError, match="no CPU path"):

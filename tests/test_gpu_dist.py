@@ -182,3 +182,59 @@ def test_sharded_step_is_capturable(pg):
         churn += [torch.randn(sum(fs), E, device=dev).double() * 1e30 for _ in range(4)]
         torch.cuda.synchronize()
         del churn
+
+
+@pytest.mark.parametrize("fuse,sparse", [(True, False), (False, True)])
+def test_sharded_pipelined_step_is_bit_equal_on_the_device(pg, fuse, sparse):
+    """The cross-step pipeline with the real ops and real streams (world 1: RCCL hands the tensors through): the lookup
+    exchange of batch k+1 issued on the communication stream before the backward of batch k, the gradient exchange /
+    owner-side reduction of batch k on that stream under the next forward -- blocks, FM terms and shard gradients bit-equal
+    to the same steps issued in program order, with dense compute in between to give the streams something to race with."""
+    from torecsys_amd import dist as D
+    from torecsys_amd.dist import RowShardedMultiIndicesEmbedding
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(8)
+    fs = [500 + 31 * i for i in range(39)]
+    B, N, E, STEPS = 4096, 39, 64, 5
+    W = torch.randn(sum(fs), E, generator=g).to(torch.bfloat16).to(dev)
+    batches = [torch.cat([torch.randint(0, f, (B, 1), generator=g) for f in fs], 1).to(dev) for _ in range(STEPS)]
+    gbs = [torch.randn(B, N, E, generator=g).to(torch.bfloat16).to(dev) for _ in range(STEPS)]
+    dense = torch.randn(N * E, N * E, generator=g).to(torch.bfloat16).to(dev)
+
+    def run(pipelined):
+        D.clear_route_caches()
+        D._lookup_cache.clear()
+        m = RowShardedMultiIndicesEmbedding(embed_size=E, field_sizes=fs, fuse_fm=fuse, dtype=torch.bfloat16, device=dev,
+                                            dense_grad_max_rows=0 if sparse else 10 ** 9, overlap_grad_exchange=pipelined)
+        m.load_full_weight(W)
+        outs = []
+        if pipelined:
+            m.prefetch_lookup(batches[0])
+        for k in range(STEPS):
+            m.embedding.weight.grad = None
+            out = m(batches[k])
+            x = out.rename(None)
+            h = (x.reshape(B, N * E) @ dense).reshape(B, N, E)            # compute-stream work the exchanges overlap with
+            loss = (h.float() * gbs[k].float()).sum()
+            fm = None
+            if fuse:
+                fm = out._trs_fused_fm[0]
+                loss = loss + (fm.float() ** 2).sum()
+            if pipelined and k + 1 < STEPS:
+                m.prefetch_lookup(batches[k + 1])
+            loss.backward()
+            m.wait_grad()
+            gw = m.embedding.weight.grad
+            gw = gw.to_dense() if gw.is_sparse else gw
+            outs.append((x.detach().clone(), None if fm is None else fm.detach().clone(), gw.detach().clone()))
+        torch.cuda.synchronize()
+        return outs
+
+    D.lookup_stats.update(prefetched=0, inline=0)
+    a = run(False)
+    b = run(True)
+    assert D.lookup_stats["prefetched"] == STEPS and D.lookup_stats["inline"] == STEPS, D.lookup_stats
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert torch.equal(x[0], y[0]), f"block differs at step {k}"
+        assert (x[1] is None and y[1] is None) or torch.equal(x[1], y[1]), f"FM differs at step {k}"
+        assert torch.equal(x[2], y[2]), f"shard gradient differs at step {k}"

@@ -11,6 +11,8 @@
 
 #include <algorithm>
 
+#include <type_traits>
+
 #include "trs_common.hpp"
 #include <map>
 #include <mutex>
@@ -995,35 +997,35 @@ extern "C" int trs_afm_bwd_dropout(const void* g_out, const void* g_attn, const 
     const int waves = 4;
     const size_t mlds = afm_bwd_mfma_lds(N, E, A, T, waves);
     const int mgrid = (int)std::min<int64_t>(B, 256);
-#define TRS_AFM_BM(AT_, KS_)                        \
-  do {                                              \
-    TRS_AFM_BMW(AT_, KS_, 4);                       \
-  } while (0)
-#define TRS_AFM_BMW(AT_, KS_, W_)                                                                                     \
-  do {                                                                                                                \
-    auto kern = afm_bwd_mfma_kernel<AT_, KS_, W_>;                                                                    \
-    if (mlds > 64 * 1024 &&                                                                                           \
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds) != hipSuccess) \
-      return check_launch("afm_bwd: LDS attribute");                                                                  \
-    hipLaunchKernelGGL(kern, dim3(mgrid), dim3(64 * W_), mlds, s, (const bf16_t*)g_out, (const bf16_t*)g_attn,        \
-                       (const bf16_t*)x, (const bf16_t*)attn, (const bf16_t*)W1, (const bf16_t*)b1, (const bf16_t*)w2, \
-                       B, N, (bf16_t*)gx, part, keep, keep_scale, T, *packed);                                        \
-  } while (0)
-#define TRS_AFM_BMK(AT_)                                 \
-  do {                                                   \
-    if (E == 32) TRS_AFM_BM(AT_, 1);                     \
-    else if (E == 64) TRS_AFM_BM(AT_, 2);                \
-    else TRS_AFM_BM(AT_, 4);                             \
-  } while (0)
+    // only the (A / 16, E / 32) combinations the test above admits are instantiated: the others need more than 512
+    // registers per wave (125-589 spilled) and were never dispatched
+    int rc_launch = 0;
+    auto launch = [&](auto at_c, auto ks_c) {
+      constexpr int AT_ = decltype(at_c)::value, KS_ = decltype(ks_c)::value;
+      if constexpr (AT_ * KS_ <= 12) {
+        auto kern = afm_bwd_mfma_kernel<AT_, KS_, 4>;
+        if (mlds > 64 * 1024 &&
+            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds) != hipSuccess) {
+          rc_launch = check_launch("afm_bwd: LDS attribute");
+          return;
+        }
+        hipLaunchKernelGGL(kern, dim3(mgrid), dim3(64 * waves), mlds, s, (const bf16_t*)g_out, (const bf16_t*)g_attn,
+                           (const bf16_t*)x, (const bf16_t*)attn, (const bf16_t*)W1, (const bf16_t*)b1, (const bf16_t*)w2,
+                           B, N, (bf16_t*)gx, part, keep, keep_scale, T, *packed);
+      }
+    };
+    auto launch_at = [&](auto at_c) {
+      if (E == 32) launch(at_c, std::integral_constant<int, 1>{});
+      else if (E == 64) launch(at_c, std::integral_constant<int, 2>{});
+      else launch(at_c, std::integral_constant<int, 4>{});
+    };
     switch (A / 32) {
-      case 1: TRS_AFM_BMK(2); break;
-      case 2: TRS_AFM_BMK(4); break;
-      case 3: TRS_AFM_BMK(6); break;
-      default: TRS_AFM_BMK(8); break;
+      case 1: launch_at(std::integral_constant<int, 2>{}); break;
+      case 2: launch_at(std::integral_constant<int, 4>{}); break;
+      case 3: launch_at(std::integral_constant<int, 6>{}); break;
+      default: launch_at(std::integral_constant<int, 8>{}); break;
     }
-#undef TRS_AFM_BMK
-#undef TRS_AFM_BM
-#undef TRS_AFM_BMW
+    if (rc_launch != 0) return rc_launch;
     const int n = A * E + 2 * A + 1;
     hipLaunchKernelGGL(afm_reduce_partials_kernel, dim3((n + 255) / 256), dim3(256), 0, s, part, mgrid, n, A, E, gW1,
                        gb1, gw2, gb2);

@@ -15,6 +15,8 @@
 // Work decomposition: wave = P pixel tiles (16*P pixels of one sample; E = 64 -> P = 4 = the whole sample),
 // workgroup = 4 waves; the W fragments of one (channel-pair-tile j, field n) step (2*KS KiB) are staged in LDS
 // (double buffered, one barrier per step) and shared by the 4 waves; every fragment read from LDS feeds P MFMAs.
+#include <type_traits>
+
 #include "trs_common.hpp"
 
 namespace trs {
@@ -269,8 +271,8 @@ int cin_cl_fwd(const void* x0T, int ld0, const void* xkT, int ldk, const void* W
   const int grid = (int)std::min<int64_t>((nitems + 3) / 4, 256 * 2);
 #define TRS_CINF(KS_, P_, NS_) \
   do {                         \
-    if (tri && KS_ > 1) TRS_CINF_T(KS_, P_, NS_, (KS_ > 1)); \
-    else TRS_CINF_T(KS_, P_, NS_, false);                    \
+    if (tri && KS_ == 2) TRS_CINF_T(KS_, P_, NS_, (KS_ == 2)); /* KS = 4 (97..128 fields): the skipping form spills, */ \
+    else TRS_CINF_T(KS_, P_, NS_, false);                      /* the plain kernel multiplies the zero k-steps too    */ \
   } while (0)
 #define TRS_CINF_T(KS_, P_, NS_, TRI_)                                                                              \
   do {                                                                                                              \
@@ -613,7 +615,8 @@ int cin_cl_bwd_data(const void* x0T, int ld0, const void* xkT, int ldk, const vo
   int NS = 1;
   const size_t cap = 156 * 1024;
   while (P > 1 && lds_for(1) > cap) P >>= 1;     // many fields: the per-wave x0 / dx0 arrays (N x 16 P x 6 bytes) must fit
-  if ((N + 2) / 3 * 3 <= (N + 1) / 2 * 2 && lds_for(3) <= cap && KC <= 4) NS = 3;
+  // (three fields per step at 64 channels per pass, P = 4 needs 17 registers more than a wave has)
+  if ((N + 2) / 3 * 3 <= (N + 1) / 2 * 2 && lds_for(3) <= cap && KC <= 4 && !(KC == 2 && P == 4)) NS = 3;
   else if (lds_for(2) <= cap) NS = 2;
   const size_t lds = lds_for(NS);
   if (lds > cap) return 1;
@@ -624,39 +627,40 @@ int cin_cl_bwd_data(const void* x0T, int ld0, const void* xkT, int ldk, const vo
                      (const bf16_t*)Wc, WpT, C, N, NP, H, KSH, KC, npass);
   const int64_t nitems = B * (E / (16 * P));
   const int grid = (int)std::min<int64_t>((nitems + WAVES - 1) / WAVES, 256);
-#define TRS_CINB(KC_, P_, NS_, W_)                                                                                  \
-  do {                                                                                                              \
-    auto kern = cin_cl_bwd_data_kernel<KC_, P_, NS_, W_>;                                                           \
-    static size_t attr_lds = 0;                                                                                     \
-    if (lds > 64 * 1024 && lds > attr_lds) {                                                                        \
-      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
-        return check_launch("cin_cl_bwd_data: LDS attribute");                                                      \
-      attr_lds = lds;                                                                                               \
-    }                                                                                                               \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * W_), lds, s, (const bf16_t*)x0T, ld0, (const bf16_t*)xkT, ldk,   \
-                       (const bf16_t*)gyT, (const uint4*)WpT, (bf16_t*)dx0T, (bf16_t*)dxkT, ldo, B, N, H, C, E,     \
-                       npass, tri);                                                                                 \
-  } while (0)
-#define TRS_CINB_NS(KC_, P_)              \
-  do {                                    \
-    if (NS == 3) TRS_CINB(KC_, P_, 3, 8); \
-    else if (NS == 2) TRS_CINB(KC_, P_, 2, 8); \
-    else TRS_CINB(KC_, P_, 1, 8);         \
-  } while (0)
-#define TRS_CINB_P(KC_)                   \
-  do {                                    \
-    if (P == 4) TRS_CINB_NS(KC_, 4);      \
-    else if (P == 2) TRS_CINB_NS(KC_, 2); \
-    else TRS_CINB_NS(KC_, 1);             \
-  } while (0)
+  // (generic lambda: only the combinations the choice of NS above can produce are instantiated)
+  int rc_launch = 0;
+  auto launch = [&](auto kc_c, auto p_c, auto ns_c) {
+    constexpr int KC_ = decltype(kc_c)::value, P_ = decltype(p_c)::value, NS_ = decltype(ns_c)::value;
+    if constexpr (!(NS_ == 3 && KC_ == 2 && P_ == 4)) {
+      auto kern = cin_cl_bwd_data_kernel<KC_, P_, NS_, 8>;
+      static size_t attr_lds = 0;
+      if (lds > 64 * 1024 && lds > attr_lds) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+          rc_launch = check_launch("cin_cl_bwd_data: LDS attribute");
+          return;
+        }
+        attr_lds = lds;
+      }
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * 8), lds, s, (const bf16_t*)x0T, ld0, (const bf16_t*)xkT, ldk,
+                         (const bf16_t*)gyT, (const uint4*)WpT, (bf16_t*)dx0T, (bf16_t*)dxkT, ldo, B, N, H, C, E, npass, tri);
+    }
+  };
+  auto launch_ns = [&](auto kc_c, auto p_c) {
+    if (NS == 3) launch(kc_c, p_c, std::integral_constant<int, 3>{});
+    else if (NS == 2) launch(kc_c, p_c, std::integral_constant<int, 2>{});
+    else launch(kc_c, p_c, std::integral_constant<int, 1>{});
+  };
+  auto launch_p = [&](auto kc_c) {
+    if (P == 4) launch_ns(kc_c, std::integral_constant<int, 4>{});
+    else if (P == 2) launch_ns(kc_c, std::integral_constant<int, 2>{});
+    else launch_ns(kc_c, std::integral_constant<int, 1>{});
+  };
   switch (KC) {
-    case 1: TRS_CINB_P(1); break;
-    case 2: TRS_CINB_P(2); break;
-    default: TRS_CINB_P(4); break;
+    case 1: launch_p(std::integral_constant<int, 1>{}); break;
+    case 2: launch_p(std::integral_constant<int, 2>{}); break;
+    default: launch_p(std::integral_constant<int, 4>{}); break;
   }
-#undef TRS_CINB_P
-#undef TRS_CINB_NS
-#undef TRS_CINB
+  if (rc_launch != 0) return rc_launch;
   return check_launch("cin_cl_bwd_data");
 }
 

@@ -230,51 +230,13 @@ __global__ __launch_bounds__(256) void cross_mfma_fwd_kernel(const uint4* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward, role-specialised workgroup (the shipped path).
-//
-// The weight gradient dW_l = du_l^T x_l contracts over ROWS for every layer; its fp32 accumulators (E*E*L values:
-// 384 registers per lane at E = 64, L = 6) are what forced one wave per SIMD, and in a symmetric design -- every
-// wave owning a row tile AND a share of the accumulators -- du^T / x^T of all waves must be exchanged through LDS
-// with two barriers per layer in the middle of every wave's dependent chain (the first version of this kernel: 2.1 ms
-// at 2.5 M rows, half of its wave cycles spent waiting).  Here the two kinds of work get their own waves, 8 waves
-// (two per SIMD, 256 registers each) per workgroup, 64 rows per group, L+1 steps per group, one barrier per step:
-//   * waves 0..3 ("chain"): one 16-row tile each, never touching dW.  Step 0 recomputes x_1 .. x_{L-1} and leaves
-//     them in LDS as plain bf16 rows (the "x store"; 16-byte stores of the registers the wave already holds -- no
-//     shuffles, no transposing VALU work) and keeps u_l + 1 of every layer as packed bf16 registers; steps 1..L run
-//     the gradient chain of layers L-1 .. 0 (du = g*x0, dx0 += g*(u_l+1), g <- W_l^T du: ONE matmul per step) and
-//     hand du_l over as rows in a double-buffered slab.  Keeping x_l in LDS instead of registers is what leaves
-//     the wave room to have its W fragments in flight ahead of the MFMAs that consume them;
-//   * waves 4..7 ("dW"): each owns a quarter of the E*E*L accumulators (96 registers at E = 64, L = 6) and nothing
-//     else; one step behind, they read du_l and x_l with ds_read_b64_tr_b16 -- the LDS transpose read delivers
-//     [row][e] data with rows along K, i.e. directly as the A (du^T) and B (x) operands -- and issue independent MFMAs.
-// Waves w and w+4 of a workgroup land on the same SIMD, so every SIMD hosts one chain wave (MFMA + VALU epilogues)
-// beside one dW wave (MFMA only).  db_l = column sums of du_l is taken by the dW waves from the A operands they
-// already hold (VALU adds beside the MFMAs) and reduced across lanes once at the end.
-//
-// Row layout in LDS (x store and du slab): [16-column panel][row][16 columns] bf16, i.e. 32-byte row pieces, rows
-// contiguous inside a panel -- a transpose read of a 16-lane group then covers 128 contiguous bytes (bank-conflict
-// free; a row-major slab with padded rows costs a 4-way conflict on every transpose read).
-// Only ONE copy of the W fragments lives in LDS: the A operand of g <- W_l^T du (W_l^T in the same permuted slot
-// order) is fetched from the forward fragments with the transpose read as well (wt_frag below).
-// LDS at E = 64, L = 6: W fragments 48 KiB + biases 1.5 KiB + x store 48 KiB + du slab 16 KiB = 113.5 KiB.
-constexpr int B2_CHAIN = 4;                         // chain waves per workgroup (one 16-row tile each)
-constexpr int B2_DW = 4;                            // weight-gradient waves
-constexpr int B2_ROWS = B2_CHAIN * 16;              // rows per workgroup step (64)
-constexpr int B2_PANEL = B2_ROWS * 32;              // bytes of one 16-column panel
-
+// backward: helpers shared by the role-specialised kernel below (chain waves own row tiles, dW waves own the E*E*L
+// weight-gradient accumulators; du / x rows are handed over through LDS slabs laid out [16-column panel][row][16 columns]
+// so that ds_read_b64_tr_b16 delivers [row][e] data with rows along K -- directly the A (du^T) and B (x) operands).
+// Round 2's forward-first kernel (cross_mfma_bwd2_kernel: x store of all L layers in LDS, 1.0-1.08 ms at 2.5 M rows) was
+// superseded by cross_mfma_bwd3_kernel in round 3 and removed in round 4.
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
-
-// 8 k-values (rows k0 .. k0+7) x this lane's column of panel ``panel``: two transpose reads of a [4 rows][16 cols]
-// block.  Lane i of a 16-lane group supplies the address of 4 contiguous bf16 of row (i>>2), columns 4*(i&3)..+3, and
-// receives column i of the block (element j = row j).
-__device__ __forceinline__ s16x8 rows_frag(const char* tensor, int k0, int panel, int i) {
-  typedef __attribute__((address_space(3))) s16x4* lds_p;
-  const char* p = tensor + panel * B2_PANEL + (k0 + (i >> 2)) * 32 + (i & 3) * 8;
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p + 4 * 32));
-  return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-}
 
 // fp32 value (mt, i) of a row held as bf16 B fragments (the D-layout slot order of XTile)
 template <int KS>
@@ -328,211 +290,6 @@ __device__ __forceinline__ void layer_matmul_pre(const uint4* Wl, const float* b
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt)
       acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[mt][ks], __builtin_bit_cast(bf16x8, B[ks]), acc[mt], 0, 0, 0);
-}
-
-template <int NT, int L>
-__global__ __launch_bounds__(64 * (B2_CHAIN + B2_DW), 2) void cross_mfma_bwd2_kernel(
-    const uint4* __restrict__ x, const uint4* __restrict__ gout, const uint4* __restrict__ Wp,
-    const float* __restrict__ bp, int64_t rows, uint4* __restrict__ dx, float* __restrict__ dWpart,
-    float* __restrict__ dbpart, int detach_first) {
-  constexpr int KS = NT / 2;
-  constexpr int E = NT * 16;
-  constexpr int FRAG = NT * KS * 64;            // uint4 per layer
-  constexpr int TENSOR = NT * B2_PANEL;         // one (64-row x E) bf16 tensor in the panel layout
-  constexpr int TPW = NT * NT / B2_DW;          // dW output tiles per dW wave: tiles t = w'*TPW + k -> (t / NT, t % NT)
-  static_assert((NT * NT) % B2_DW == 0, "E must be a multiple of 32");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint4* Ws = reinterpret_cast<uint4*>(smem);
-  float* bs = reinterpret_cast<float*>(Ws + L * FRAG);
-  char* xstore = reinterpret_cast<char*>(bs + L * E);         // [layer L][panel NT][B2_ROWS][32 B]
-  char* duslab = xstore + L * TENSOR;                         // [buffer 2][panel NT][B2_ROWS][32 B]
-  for (int i = threadIdx.x; i < L * FRAG; i += blockDim.x) Ws[i] = Wp[i];
-  for (int i = threadIdx.x; i < L * E; i += blockDim.x) bs[i] = bp[i] + 1.f;      // the backward only ever needs u_l + 1
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, r = lane & 15;
-  const int64_t ngroups = (rows + B2_ROWS - 1) / B2_ROWS;
-  int step0 = 0;                                 // global step counter at the start of the group (buffer parity)
-
-  if (wave < B2_CHAIN) {
-    // ------------------------------------------------------------------ chain waves
-    uint4 nx_raw[KS], ng_raw[KS];
-    // Prefetch of a later group's rows.  The loads are UNCONDITIONAL (row index clamped into the tensor, out-of-range
-    // rows zeroed when consumed): loads under a branch make hipcc's wait-count insertion pessimistic -- it then waits
-    // for these just-issued loads wherever an older load is consumed, i.e. one exposed HBM round trip per group.
-    auto fetch = [&](int64_t grp_) {
-      int64_t row_ = grp_ * B2_ROWS + wave * 16 + r;
-      row_ = row_ < rows ? row_ : rows - 1;
-#pragma unroll
-      for (int c = 0; c < KS; ++c) {
-        nx_raw[c] = x[(row_ * E + 32 * c + 8 * q) >> 3];
-        ng_raw[c] = gout[(row_ * E + 32 * c + 8 * q) >> 3];
-      }
-    };
-    fetch(blockIdx.x);
-    // this lane's 16-byte pieces of a row tensor: piece c covers columns 32c+8q .. +7 -> panel 2c + (q>>1), half q&1
-    const int piece0 = (q >> 1) * B2_PANEL + (wave * 16 + r) * 32 + (q & 1) * 16;
-    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x, step0 += L + 1) {
-      XTile<NT> g, dx0;
-      uint4 B0[1][KS];
-      const bool live = grp * B2_ROWS + wave * 16 + r < rows;
-#pragma unroll
-      for (int c = 0; c < KS; ++c) {
-        B0[0][c] = live ? nx_raw[c] : make_uint4(0, 0, 0, 0);
-        float f[8];
-        Vec16<bf16_t>::unpack(live ? ng_raw[c] : make_uint4(0, 0, 0, 0), f);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          g.v[2 * c][i] = f[i];
-          g.v[2 * c + 1][i] = f[4 + i];
-        }
-      }
-#pragma unroll
-      for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dx0.v[mt][i] = 0.f;
-      fetch(grp + gridDim.x);
-      // step 0: forward recompute; x_1 .. x_{L-1} go to the x store (x_0 follows in step 1, see below); u_l + 1 of every
-      // layer stays in registers as packed bf16 (the backward needs it once, in dx0 += g_{l+1} * (u_l + 1))
-      uint4 U1[L][KS];
-      {
-        uint4 Bl[1][KS];
-#pragma unroll
-        for (int c = 0; c < KS; ++c) Bl[0][c] = B0[0][c];
-#pragma unroll
-        for (int l = 0; l < L; ++l) {
-          f32x4 acc[1][NT];
-          layer_matmul_pre<NT, false>(Ws + l * FRAG, bs + l * E, Bl[0], lane, q, acc[0]);
-          XTile<NT> up;                    // u_l + 1 (the +1 rides in the bias)
-#pragma unroll
-          for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) up.v[mt][i] = acc[0][mt][i];
-          pack_tile<NT>(up, U1[l]);
-          if (l + 1 < L) {
-            XTile<NT> nx;
-#pragma unroll
-            for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-              for (int i = 0; i < 4; ++i) nx.v[mt][i] = frag_value<KS>(B0[0], mt, i) * up.v[mt][i];
-            pack_tile<NT>(nx, Bl[0]);
-#pragma unroll
-            for (int c = 0; c < KS; ++c)
-              *reinterpret_cast<uint4*>(xstore + (l + 1) * TENSOR + piece0 + 2 * c * B2_PANEL) = Bl[0][c];
-          }
-        }
-      }
-      __syncthreads();
-      // steps 1..L: layers L-1 .. 0
-#pragma unroll
-      for (int l = L - 1; l >= 0; --l) {
-        char* slab = duslab + (((step0 + (L - l)) & 1) ? TENSOR : 0);
-        if (l == L - 1) {
-          // x_0 of THIS group: only now, the dW waves read the previous group's x_0 during step 0
-#pragma unroll
-          for (int c = 0; c < KS; ++c) *reinterpret_cast<uint4*>(xstore + piece0 + 2 * c * B2_PANEL) = B0[0][c];
-        }
-        XTile<NT> du;
-#pragma unroll
-        for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            du.v[mt][i] = g.v[mt][i] * frag_value<KS>(B0[0], mt, i);
-            dx0.v[mt][i] = fmaf(g.v[mt][i], frag_value<KS>(U1[l], mt, i), dx0.v[mt][i]);
-          }
-        uint4 Bdu[1][KS];
-        pack_tile<NT>(du, Bdu[0]);
-#pragma unroll
-        for (int c = 0; c < KS; ++c) *reinterpret_cast<uint4*>(slab + piece0 + 2 * c * B2_PANEL) = Bdu[0][c];
-        const bool need_g = (l > 0) || (detach_first == 0);
-        if (need_g) {
-          f32x4 ga[1][NT];
-          layer_matmul_pre<NT, true>(Ws + l * FRAG, nullptr, Bdu[0], lane, q, ga[0]);
-#pragma unroll
-          for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) g.v[mt][i] = ga[0][mt][i];
-        }
-        __syncthreads();
-      }
-      const int64_t row = grp * B2_ROWS + wave * 16 + r;
-      if (row < rows) {
-        XTile<NT> o;
-#pragma unroll
-        for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) o.v[mt][i] = dx0.v[mt][i] + (detach_first ? 0.f : g.v[mt][i]);
-        uint4 raw[KS];
-        pack_tile<NT>(o, raw);
-#pragma unroll
-        for (int c = 0; c < KS; ++c) dx[(row * E + 32 * c + 8 * q) >> 3] = raw[c];
-      }
-    }
-  } else {
-    // ------------------------------------------------------------------ dW waves
-    const int wq = wave - B2_CHAIN;
-    f32x4 dWacc[L][TPW];
-    float dbacc[L];
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-      dbacc[l] = 0.f;
-#pragma unroll
-      for (int k = 0; k < TPW; ++k) dWacc[l][k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    auto consume = [&](const char* du_t, const char* x_t, f32x4 (&acc)[TPW], float& db) {
-#pragma unroll
-      for (int ks = 0; ks < B2_ROWS / 32; ++ks) {
-#pragma unroll
-        for (int k = 0; k < TPW; ++k) {
-          const int t = wq * TPW + k, mo = t / NT, no = t % NT;      // NT = 4: one output row tile, all four column tiles
-          const s16x8 A = rows_frag(du_t, 32 * ks + 8 * q, mo, r);
-          const s16x8 Bf = rows_frag(x_t, 32 * ks + 8 * q, no, r);
-          acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, Bf),
-                                                           acc[k], 0, 0, 0);
-          if (k == 0) {
-            // db: this lane's 8 rows of column e_out = 16*mo + r; the wave whose first tile has no == 0 owns row tile mo
-            float sum = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) sum += bf16_bits_to_f32((uint32_t)(uint16_t)A[j]);
-            db += (no == 0) ? sum : 0.f;
-          }
-        }
-      }
-    };
-    bool first = true;
-    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x, step0 += L + 1) {
-      // step 0: layer 0 of the previous group (its du was written in that group's last step)
-      if (!first) consume(duslab + (((step0 - 1) & 1) ? TENSOR : 0), xstore, dWacc[0], dbacc[0]);
-      first = false;
-      __syncthreads();
-#pragma unroll
-      for (int l = L - 1; l >= 0; --l) {
-        // step L-l: the chain waves are on layer l; these waves take layer l+1, whose du was written one step earlier
-        if (l + 1 < L)
-          consume(duslab + (((step0 + (L - l) - 1) & 1) ? TENSOR : 0), xstore + (l + 1 < L ? l + 1 : 0) * TENSOR,
-                  dWacc[l + 1 < L ? l + 1 : 0], dbacc[l + 1 < L ? l + 1 : 0]);
-        __syncthreads();
-      }
-    }
-    if (!first) consume(duslab + (((step0 - 1) & 1) ? TENSOR : 0), xstore, dWacc[0], dbacc[0]);
-    // partial results of this workgroup: D layout -> (row m = 4q+i -> e_out, col n = r -> e_in)
-    float* myW = dWpart + (size_t)blockIdx.x * L * E * E;
-    float* myb = dbpart + (size_t)blockIdx.x * L * E;
-#pragma unroll
-    for (int l = 0; l < L; ++l) {
-#pragma unroll
-      for (int k = 0; k < TPW; ++k) {
-        const int t = wq * TPW + k, mo = t / NT, no = t % NT;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) myW[(size_t)l * E * E + (16 * mo + 4 * q + i) * E + 16 * no + r] = dWacc[l][k][i];
-        if (k == 0 && no == 0) {
-          float v = dbacc[l];            // the four q-groups hold different rows of the same column
-          v += __shfl_xor(v, 16, 64);
-          v += __shfl_xor(v, 32, 64);
-          if (q == 0) myb[l * E + 16 * mo + r] = v;
-        }
-      }
-    }
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -931,22 +688,8 @@ static int cross_bwd_launch(const void* x, const void* g, const uint4* Wp, const
                             int64_t rows, void* dx, float* dWpart, float* dbpart, float* dW, float* db,
                             int detach_first, hipStream_t s) {
   constexpr int E = NT * 16;
-  static const bool use_bwd2 = getenv("TRS_CROSS_BWD2") != nullptr;      // developer A/B switch: the round-2 kernel
   int grid;
-  if (use_bwd2) {
-    const size_t lds = (size_t)L * E * E * 2 + (size_t)L * E * 4 + (size_t)(L + 2) * NT * B2_PANEL;
-    auto kern = cross_mfma_bwd2_kernel<NT, L>;
-    static bool attr_set = false;
-    if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return check_launch("cross_bwd(mfma): LDS attribute");
-      attr_set = true;
-    }
-    const int64_t ngroups = (rows + B2_ROWS - 1) / B2_ROWS;
-    grid = (int)std::min<int64_t>(ngroups, BW_MAX_BLOCKS);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (B2_CHAIN + B2_DW)), lds, s, (const uint4*)x, (const uint4*)g, Wp, bp,
-                       rows, (uint4*)dx, dWpart, dbpart, detach_first);
-  } else {
+  {
     const size_t lds = (size_t)(2 * L - 1) * E * E * 2 + (size_t)L * E * 4 + (size_t)4 * NT * B3_PANEL;
     auto kern = detach_first ? cross_mfma_bwd3_kernel<NT, L, true> : cross_mfma_bwd3_kernel<NT, L, false>;
     static bool attr_set[2] = {false, false};

@@ -31,6 +31,16 @@ which is what a hipGraph capture needs.  A peer whose share exceeds its slots ra
 (``functional.index_errors_seen()``) and the lookups that did not fit read as zero rows; with uniform ids a factor of
 1.1 is ~100 standard deviations of the per-peer count at the BASELINE shape.
 
+Cross-step pipeline (round 4; the 8-GPU step is link-bound, so the exchanges have to hide behind the dense part):
+``prefetch_lookup(next_inputs)`` runs steps 1-4 of the NEXT batch -- route, id all-to-all, owner-side gather, row
+all-to-all -- on a communication stream while the current batch's MLP forward / backward occupies the compute stream; the
+next ``forward`` finds the received rows ready and only un-permutes them.  ``overlap_grad_exchange=True`` moves the reverse
+all-to-all and the owner-side reduction of a batch onto the same stream, where they run under the NEXT batch's forward
+(``wait_grad()`` makes the current stream wait for them; ``weight.grad`` must not be READ before).  With gradients only
+(the fwd+bwd metric) nothing is stale: the shard does not change between the early lookup and the forward that uses it.
+With a fused optimizer on the owner an early lookup reads rows that are one update behind (asynchronous-SGD semantics):
+refused unless ``prefetch_lookup(..., stale_ok=True)``.
+
 ``backend='nccl'`` is RCCL on ROCm (xGMI links); the same code runs on ``gloo`` with CPU tensors when a
 CPU ``ops`` object is injected (tests only -- the default ops are the HIP kernels and refuse CPU tensors).
 """
@@ -184,6 +194,85 @@ def _all_to_all(out: torch.Tensor, inp: torch.Tensor, out_splits: List[int], in_
 
 PAD = -1        # id / position of a padding slot
 
+# ---- communication stream and per-phase device times --------------------------------------------------------------------
+_comm_streams = {}
+
+
+def comm_stream(dev: torch.device):
+    """The stream the exchanges of the pipelined step run on (one per device); None for CPU tensors (gloo tests: the same
+    code path runs inline, in program order)."""
+    if dev.type != "cuda":
+        return None
+    s_ = _comm_streams.get(dev)
+    if s_ is None:
+        s_ = _comm_streams[dev] = torch.cuda.Stream(device=dev)
+    return s_
+
+
+class _on_stream:
+    """``with _on_stream(s):`` -- make ``s`` current (set_stream pairs: torch.cuda.stream()'s constructor and __enter__ each
+    resolve the device through hipGetDeviceCount, ~0.1 ms apiece); a no-op for ``s is None``."""
+
+    def __init__(self, s_):
+        self.s = s_
+
+    def __enter__(self):
+        if self.s is not None:
+            self.prev = torch.cuda.current_stream(self.s.device)
+            torch.cuda.set_stream(self.s)
+        return self
+
+    def __exit__(self, *exc):
+        if self.s is not None:
+            torch.cuda.set_stream(self.prev)
+        return False
+
+
+PROFILE = __import__("os").environ.get("TRS_DIST_PROFILE", "0") == "1"
+phase_events = {}       # phase -> [(start event, end event)]   (TRS_DIST_PROFILE=1; read by phase_times_ms())
+wire_bytes = {"ids": 0, "rows_fwd": 0, "rows_bwd": 0, "steps": 0}      # bytes this rank SENT to other ranks
+
+
+class _phase:
+    """``with _phase("row a2a"):`` brackets the enqueued work with a HIP event pair on the current stream when profiling"""
+
+    def __init__(self, name, dev):
+        self.on = PROFILE and dev.type == "cuda"
+        self.name = name
+
+    def __enter__(self):
+        if self.on:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            phase_events.setdefault(self.name, []).append((self.a, b))
+        return False
+
+
+def phase_times_ms(reset: bool = True):
+    """mean device milliseconds per recorded phase (synchronises)"""
+    if not phase_events:
+        return {}
+    torch.cuda.synchronize()
+    out = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in phase_events.items()}
+    if reset:
+        phase_events.clear()
+    return out
+
+
+def _count_wire(kind: str, splits, rank: int, row_bytes: int, total_rows: int, world: int):
+    if world == 1:
+        return
+    if splits is None:                   # equal splits: everything but this rank's own slots travels
+        wire_bytes[kind] += (total_rows - total_rows // world) * row_bytes
+    else:
+        wire_bytes[kind] += (sum(splits) - splits[rank]) * row_bytes
+
 
 def pad_slots(counts: torch.Tensor, send_ids: torch.Tensor, send_pos: torch.Tensor, inv_pos: torch.Tensor, cap: int,
               world: int):
@@ -305,7 +394,8 @@ def _route_plan(idx: torch.Tensor, mod) -> "RoutePlan":
             break
     if pr is None:
         route_stats["cold"] += 1
-        pr = _start_route(idx, mod)
+        with _phase("route (bucket by owner)", idx.device):
+            pr = _start_route(idx, mod)
     p = RoutePlan()
     p.send_pos, p.inv_pos, p.cap = pr.send_pos, pr.inv_pos, 0
     if pr.host_counts is None and mod.world > 1:
@@ -313,7 +403,9 @@ def _route_plan(idx: torch.Tensor, mod) -> "RoutePlan":
         p.cap = mod.slot_capacity(idx.numel())
         p.send_splits = p.recv_splits = None
         p.recv_ids = torch.empty_like(pr.send_ids)
-        dist.all_to_all_single(p.recv_ids, pr.send_ids, group=mod.group)
+        with _phase("id all-to-all", idx.device):
+            dist.all_to_all_single(p.recv_ids, pr.send_ids, group=mod.group)
+        _count_wire("ids", None, mod.rank, 4, pr.send_ids.numel(), mod.world)
     elif mod.world == 1:
         n = int(pr.send_ids.numel())                 # a shape, not a device value: no synchronisation
         p.send_splits, p.recv_splits, p.recv_ids = [n], [n], pr.send_ids
@@ -323,7 +415,9 @@ def _route_plan(idx: torch.Tensor, mod) -> "RoutePlan":
         p.send_splits = pr.host_counts[0].tolist()
         p.recv_splits = pr.host_counts[1].tolist()
         p.recv_ids = torch.empty(sum(p.recv_splits), dtype=torch.int32, device=idx.device)
-        _all_to_all(p.recv_ids, pr.send_ids, p.recv_splits, p.send_splits, mod.group)
+        with _phase("id all-to-all", idx.device):
+            _all_to_all(p.recv_ids, pr.send_ids, p.recv_splits, p.send_splits, mod.group)
+        _count_wire("ids", p.send_splits, mod.rank, 4, 0, mod.world)
     _route_cache.append((key, idx, p))
     if len(_route_cache) > 2:
         _route_cache.pop(0)
@@ -344,6 +438,76 @@ def _exchange(out_rows: int, inp: torch.Tensor, out_splits, in_splits, mod) -> t
     return out
 
 
+def _fetch_rows(weight: torch.Tensor, idx: torch.Tensor, mod):
+    """Steps 1-4 of the forward: route plan, owner-side gather, rows back.  -> (plan, rows in exchange order)"""
+    ops = mod.ops
+    plan = _route_plan(idx, mod)
+    padded = plan.cap > 0
+    n_valid = mod.row_range[1] - mod.row_range[0]
+    row_bytes = weight.shape[1] * weight.element_size()
+    with _phase("owner gather", idx.device):
+        rows = ops.gather_local(weight, plan.recv_ids, n_valid, padded=True) if padded else \
+            ops.gather_local(weight, plan.recv_ids, n_valid)                                    # rows of my shard
+    with _phase("row all-to-all (forward)", idx.device):
+        if padded:
+            back = _exchange(plan.recv_ids.numel(), rows, None, None, mod)
+        else:
+            back = _exchange(sum(plan.send_splits), rows, plan.send_splits, plan.recv_splits, mod)
+    _count_wire("rows_fwd", None if padded else plan.recv_splits, mod.rank, row_bytes, plan.recv_ids.numel(), mod.world)
+    return plan, back
+
+
+class _PrefetchedLookup:
+    """rows of a batch fetched ahead of its forward (prefetch_lookup): the plan, the received rows, the event on the
+    communication stream after which they are complete"""
+    __slots__ = ("plan", "back", "event")
+
+
+_lookup_cache: List[tuple] = []      # [(key, idx kept alive, weight id, _PrefetchedLookup)]
+MAX_PREFETCHED_LOOKUPS = 4
+lookup_stats = {"prefetched": 0, "inline": 0}
+F_._clear_hooks.append(_lookup_cache.clear)
+
+
+def prefetch_lookup(idx: torch.Tensor, mod, stale_ok: bool = False) -> None:
+    """Run the exchange half of the lookup of ``idx`` (a batch whose forward comes NEXT) now, on the communication stream,
+    so that it overlaps whatever the compute stream is busy with; the matching ``forward`` waits for its event and only
+    un-permutes the rows.  See the module docstring for the staleness rule with a fused optimizer."""
+    if mod.fused_optimizer is not None and not stale_ok:
+        raise RuntimeError("prefetch_lookup: with a fused optimizer on the owner an early lookup reads rows that are one "
+                           "update behind; pass stale_ok=True to accept that, or look up at forward time")
+    idx = idx.rename(None) if idx.has_names() else idx
+    if idx.dtype not in (torch.int64, torch.int32):
+        idx = idx.long()
+    idx = idx.contiguous()
+    key = _route_key(idx, mod)
+    weight = mod.embedding.weight
+    if any(k == key and w == id(weight) for k, _, w, _ in _lookup_cache):
+        return
+    cs = comm_stream(idx.device)
+    if cs is not None:
+        cs.wait_stream(torch.cuda.current_stream(idx.device))     # the indices (and any update of the shard) come first
+    with _on_stream(cs), torch.no_grad():
+        pl = _PrefetchedLookup()
+        pl.plan, pl.back = _fetch_rows(weight.detach(), idx, mod)
+        pl.event = None
+        if cs is not None:
+            pl.event = torch.cuda.Event()
+            pl.event.record(cs)
+    _lookup_cache.append((key, idx, id(weight), pl))
+    if len(_lookup_cache) > MAX_PREFETCHED_LOOKUPS:
+        _lookup_cache.pop(0)
+
+
+def _take_prefetched(idx: torch.Tensor, weight: torch.Tensor, mod):
+    key = _route_key(idx, mod)
+    for i, (k, _, w, pl) in enumerate(_lookup_cache):
+        if k == key and w == id(weight):
+            _lookup_cache.pop(i)
+            return pl
+    return None
+
+
 class _ShardedLookup(Function):
     """(local shard, local batch of indices) -> (B,N,E) block [+ FM]; gradient flows back to the shard owners."""
 
@@ -351,16 +515,22 @@ class _ShardedLookup(Function):
     def forward(ctx, weight, idx, mod):
         ops = mod.ops
         B, N = idx.shape
-        plan = _route_plan(idx, mod)
-        padded = plan.cap > 0
-        n_valid = mod.row_range[1] - mod.row_range[0]
-        if padded:
-            rows = ops.gather_local(weight, plan.recv_ids, n_valid, padded=True)                # rows of my shard
-            back = _exchange(plan.recv_ids.numel(), rows, None, None, mod)
+        pl = _take_prefetched(idx, weight, mod)
+        if pl is not None:
+            lookup_stats["prefetched"] += 1
+            plan, back = pl.plan, pl.back
+            if pl.event is not None:
+                cur = torch.cuda.current_stream(idx.device)
+                cur.wait_event(pl.event)
+                for t in (back, plan.inv_pos, plan.send_pos, plan.recv_ids):      # made on the communication stream, used here
+                    if t is not None:
+                        t.record_stream(cur)
         else:
-            rows = ops.gather_local(weight, plan.recv_ids, n_valid)
-            back = _exchange(sum(plan.send_splits), rows, plan.send_splits, plan.recv_splits, mod)
-        block, fm, fm_sum = ops.unpermute(back, plan.inv_pos, B, N, mod.fuse_fm)
+            lookup_stats["inline"] += 1
+            plan, back = _fetch_rows(weight, idx, mod)
+        padded = plan.cap > 0
+        with _phase("un-permute (+FM)", idx.device):
+            block, fm, fm_sum = ops.unpermute(back, plan.inv_pos, B, N, mod.fuse_fm)
         if weight.shape[0] <= mod.dense_grad_max_rows and hasattr(ops, "prefetch_owner_buckets"):
             ops.prefetch_owner_buckets(weight, plan.recv_ids, padded)
         ctx.mod = mod
@@ -383,28 +553,49 @@ class _ShardedLookup(Function):
         send_splits, recv_splits = ctx.splits
         if g_block is None and g_fm is None:
             return None, None, None
-        if mod.dedup:
-            # one gradient row per DISTINCT row of the local batch (duplicates summed before they travel)
-            g_rows = ops.reduce_grad_unique(g_block, pos, back, g_fm if mod.fuse_fm else None, fm_sum)
-        else:
-            if block is None:
-                block = g_block     # shape carrier only
-            g_rows = ops.permute_grad(g_block, pos, g_fm if mod.fuse_fm else None, fm_sum, block)
-        if ctx.padded:      # equal splits; padding slots carry zero rows (pos = PAD) and update nothing on the owner
-            recv_g = _exchange(g_rows.shape[0], g_rows, None, None, mod)[: g_rows.shape[0]]
-        else:
-            recv_g = _exchange(sum(recv_splits), g_rows, recv_splits, send_splits, mod)          # reverse exchange
-        dense_index = weight.shape[0] <= mod.dense_grad_max_rows
-        pad_kw = {"padded": True} if ctx.padded else {}
-        if mod.fused_optimizer is not None:
-            # the owner steps its rows right here: no gradient tensor of any kind (weight.grad stays None)
-            ops.shard_update(weight, recv_ids, recv_g, mod.fused_optimizer, dense_index, **pad_kw)
-            return None, None, None
-        if dense_index:
-            gw = ops.shard_grad_dense(weight, recv_ids, recv_g, **pad_kw)
-        else:
-            ids = recv_ids.clamp_min(0) if ctx.padded else recv_ids      # padding: zero rows added to row 0
-            gw = torch.sparse_coo_tensor(ids.long().unsqueeze(0), recv_g, size=weight.shape)
+        dev = weight.device
+        with _phase("permute gradient", dev):
+            if mod.dedup:
+                # one gradient row per DISTINCT row of the local batch (duplicates summed before they travel)
+                g_rows = ops.reduce_grad_unique(g_block, pos, back, g_fm if mod.fuse_fm else None, fm_sum)
+            else:
+                if block is None:
+                    block = g_block     # shape carrier only
+                g_rows = ops.permute_grad(g_block, pos, g_fm if mod.fuse_fm else None, fm_sum, block)
+        # The reverse exchange and the owner-side reduction run on the communication stream when asked to overlap with
+        # the next batch's forward; never when a gradient is being ACCUMULATED (autograd would add into .grad on the
+        # compute stream right away).
+        cs = comm_stream(dev) if (mod.overlap_grad_exchange and weight.grad is None) else None
+        if cs is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            cs.wait_event(ev)
+            for t in (g_rows, recv_ids):
+                t.record_stream(cs)
+        row_bytes = g_rows.shape[1] * g_rows.element_size()
+        with _on_stream(cs):
+            with _phase("row all-to-all (gradient)", dev):
+                if ctx.padded:  # equal splits; padding slots carry zero rows (pos = PAD) and update nothing on the owner
+                    recv_g = _exchange(g_rows.shape[0], g_rows, None, None, mod)[: g_rows.shape[0]]
+                else:
+                    recv_g = _exchange(sum(recv_splits), g_rows, recv_splits, send_splits, mod)      # reverse exchange
+            _count_wire("rows_bwd", None if ctx.padded else send_splits, mod.rank, row_bytes, g_rows.shape[0], mod.world)
+            wire_bytes["steps"] += 1
+            dense_index = weight.shape[0] <= mod.dense_grad_max_rows
+            pad_kw = {"padded": True} if ctx.padded else {}
+            gw = None
+            with _phase("owner reduce / update", dev):
+                if mod.fused_optimizer is not None:
+                    # the owner steps its rows right here: no gradient tensor of any kind (weight.grad stays None)
+                    ops.shard_update(weight, recv_ids, recv_g, mod.fused_optimizer, dense_index, **pad_kw)
+                elif dense_index:
+                    gw = ops.shard_grad_dense(weight, recv_ids, recv_g, **pad_kw)
+                else:
+                    ids = recv_ids.clamp_min(0) if ctx.padded else recv_ids      # padding: zero rows added to row 0
+                    gw = torch.sparse_coo_tensor(ids.long().unsqueeze(0), recv_g, size=weight.shape)
+            if cs is not None:
+                mod._grad_event = torch.cuda.Event()
+                mod._grad_event.record(cs)
         return gw, None, None
 
 
@@ -418,7 +609,7 @@ class RowShardedMultiIndicesEmbedding(BaseInput):
     def __init__(self, embed_size: int, field_sizes: List[int], flatten: bool = False, fuse_fm: bool = False,
                  dtype: torch.dtype = torch.float32, device='cpu', process_group=None, ops=None,
                  dense_grad_max_rows: int = DENSE_GRAD_MAX_ROWS, dedup: bool = False,
-                 capacity: Optional[float] = None):
+                 capacity: Optional[float] = None, overlap_grad_exchange: bool = False):
         super().__init__()
         if not dist.is_initialized():
             raise RuntimeError("RowShardedMultiIndicesEmbedding needs torch.distributed to be initialised")
@@ -444,6 +635,8 @@ class RowShardedMultiIndicesEmbedding(BaseInput):
         if capacity is not None and dedup:
             raise ValueError("fixed-capacity slots and dedup (a data-dependent number of rows) exclude each other")
         self.capacity = None if capacity is None else float(capacity)
+        self.overlap_grad_exchange = bool(overlap_grad_exchange)
+        self._grad_event = None
         self._caps = {}
         self.route_key = (tuple(int(f) for f in field_sizes), self.world, id(process_group), self.dedup, self.capacity)
         self.length = embed_size * len(field_sizes) if flatten else embed_size
@@ -485,6 +678,20 @@ class RowShardedMultiIndicesEmbedding(BaseInput):
         behind the current forward, and a host that waits for it falls into lock-step with the GPU (measured on the
         world-size-1 run: 2.9 ms/step when the host stays ahead, 4.6 ms when it does not -- bistable)."""
         prefetch_route(next_inputs, self)
+
+    def prefetch_lookup(self, next_inputs: torch.Tensor, stale_ok: bool = False) -> None:
+        """Hint: ``next_inputs`` is the index batch of the NEXT forward.  Its route, id exchange, owner-side gather and
+        row exchange start now on the communication stream (``dist.prefetch_lookup``) and overlap the current batch's
+        dense compute.  Without a fused optimizer the result is bit-identical to the lookup at forward time."""
+        prefetch_lookup(next_inputs, self, stale_ok)
+
+    def wait_grad(self) -> None:
+        """With ``overlap_grad_exchange``: make the current stream wait for the last backward's gradient exchange and
+        owner-side reduction (``embedding.weight.grad`` / the fused update).  Call before reading ``.grad`` (an optimizer
+        step, clipping, a checkpoint); the next forward's lookup is ordered behind it by the communication stream itself."""
+        ev, self._grad_event = self._grad_event, None
+        if ev is not None:
+            torch.cuda.current_stream(self.embedding.weight.device).wait_event(ev)
 
     @torch.no_grad()
     def load_full_weight(self, full: torch.Tensor):

@@ -91,6 +91,11 @@ _bucket_cache: List[tuple] = []   # [(key, idx_tensor_kept_alive, RowBuckets)]
 _BUCKET_CACHE_SIZE = 2
 _side_streams = {}
 PREFETCH_BUCKETS = os.environ.get("TRS_PREFETCH_BUCKETS", "1") not in ("", "0")
+# priority of the side stream the row buckets are built on (HIP: larger number = lower priority)
+SIDE_STREAM_PRIORITY = int(os.environ.get("TRS_SIDE_STREAM_PRIORITY", "0"))
+# TRS_PREFETCH_EARLY=1: start the bucket build BEFORE the fused lookup launch (beside the HBM-bound lookup instead of beside
+# the first MLP GEMM)
+PREFETCH_EARLY = os.environ.get("TRS_PREFETCH_EARLY", "0") not in ("", "0")
 
 
 _offsets_content = {}     # offsets tensor (ptr, version) -> tuple of its values (read back once)
@@ -173,13 +178,14 @@ class defer_prefetch:
         return False
 
 
-def prefetch_row_buckets(idx: torch.Tensor, offsets: Optional[torch.Tensor], V: int, check: bool = True) -> None:
+def prefetch_row_buckets(idx: torch.Tensor, offsets: Optional[torch.Tensor], V: int, check: bool = True,
+                         now: bool = False) -> None:
     """Start building the CSR of this batch on a side stream at FORWARD time: it depends only on the
     indices, is latency-bound (int32 atomics), and hides behind the forward/backward of the dense part
     of the model; the backward's scatter then just waits on an event."""
     if not PREFETCH_BUCKETS:
         return
-    if _defer_depth[0] > 0:
+    if _defer_depth[0] > 0 and not now:
         _pending_prefetch.append((idx, offsets, V, check))
         return
     key = _bucket_key(idx, offsets, V, check)
@@ -189,7 +195,7 @@ def prefetch_row_buckets(idx: torch.Tensor, offsets: Optional[torch.Tensor], V: 
     dev = idx.device
     side = _side_streams.get(dev)
     if side is None:
-        side = _side_streams[dev] = torch.cuda.Stream(device=dev)
+        side = _side_streams[dev] = torch.cuda.Stream(device=dev, priority=SIDE_STREAM_PRIORITY)
     main = _abi.current_stream_of(dev)
     side.wait_stream(main)
     torch.cuda.set_stream(side)          # not `with torch.cuda.stream(side)`: its constructor and __enter__ each resolve
@@ -447,6 +453,8 @@ class _EmbedFM(Function):
         elif fields:
             raise ValueError("fields=True needs the first-order table")
         flag = _ErrFlag(dev)
+        if PREFETCH_EARLY and (ctx.needs_input_grad[0] or ctx.needs_input_grad[3]):
+            prefetch_row_buckets(idx, offsets, V, now=True)
         call("trs_embed_fm_fields" if fields else "trs_embed_fm", ptr(w), V, E, value_dtype_code(w), ptr(idx),
              index_dtype_code(idx), ptr(offsets), B, N, ptr(emb), ptr(fm), ptr(fm_sum), ptr(fw), ptr(first), ptr(flag.t),
              stream_ptr())

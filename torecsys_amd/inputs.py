@@ -113,8 +113,10 @@ class MultiIndicesEmbedding(BaseInput):
             raise ValueError('missing required arguments')
         self.register_buffer('offsets', field_offsets(field_sizes), persistent=False)
         self.flatten = flatten
-        # the package default never overrides an explicit request for the fused inner-product lookup
-        self.fuse_fm = (DEFAULT_FUSE_FM and not fuse_ipn) if fuse_fm is None else bool(fuse_fm)
+        # the package default never overrides an explicit request for the fused inner-product lookup, and skips one-wide
+        # tables (the first-order ``feat_inputs`` of the CTR models: nobody consumes an FM term of theirs)
+        self.fuse_fm = ((DEFAULT_FUSE_FM and not fuse_ipn and self.embedding.embedding_dim > 1) if fuse_fm is None
+                        else bool(fuse_fm))
         self.fuse_ipn = fuse_ipn
         self.field_size = self.embedding.num_embeddings
         self.embed_size = self.embedding.embedding_dim
