@@ -538,6 +538,39 @@ def test_very_hot_rows_are_chunked(dev, dtype, tol, fuse):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("E,bcast", [(1, True), (1, False), (10, False)])
+def test_element_path_splits_very_hot_rows_over_waves(dev, dtype, tol, E, bcast):
+    """criteo-skewed fields (4, 5, 6 ... rows): a row of the E = 1 first-order table (or of any table whose rows are not
+    whole 16-byte vectors) collects thousands of lookups; above 2048 it is cut into chunks reduced by different waves
+    whose partial sums meet in fp32 accumulators (round 4: one wave per row took 115 us of the skewed DeepFM step).  Also
+    the row-bucket build on fields of <= 32 rows (wave-aggregated LDS atomics).  Same gradient as index_add."""
+    from torecsys_amd import functional as F_
+    g = torch.Generator().manual_seed(31 + E)
+    B, fs = 20000, [4, 5, 2, 33, 700, 9]
+    N, V = len(fs), sum(fs)
+    off = O.field_offsets(fs)
+    idx = torch.stack([torch.randint(0, f, (B,), generator=g) for f in fs], 1)
+    idx[:, 2] = 1                                                     # 20 000 lookups of one row: 10 chunks
+    idx[:2100, 4] = 77                                                # just above one chunk
+    idx[:2048, 5] = 3                                                 # exactly the limit: stays on the one-wave path
+    w = torch.randn(V, E, generator=g).to(dtype)
+    wd = w.to(dev).requires_grad_()
+    out = F_.gather_rows(wd, idx.to(dev), off.to(dev))
+    rows = (idx + off.view(1, -1)).reshape(-1)
+    assert torch.equal(out.detach().cpu(), w[rows].reshape(B, N, E))
+    if bcast:                         # the models' first-order term: one gradient row per sample, shared by its fields
+        gs = torch.randn(B, 1, E, generator=g).to(dtype)
+        out.backward(gs.to(dev).expand(B, N, E))
+        gfull = gs.float().expand(B, N, E)
+    else:
+        gfull = torch.randn(B, N, E, generator=g).to(dtype)
+        out.backward(gfull.to(dev))
+        gfull = gfull.float()
+    ref = torch.zeros(V, E, dtype=torch.float64).index_add_(0, rows, gfull.reshape(-1, E).double())
+    assert rel_err(wd.grad.double().cpu(), ref) <= tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
 @pytest.mark.parametrize("E", [1, 10, 64])
 def test_gather_backward_of_a_field_constant_gradient(dev, dtype, tol, E):
     """out.sum over the fields (the models' first-order term, models/ctr/deep_fm.py:55-110) feeds back the same row for

@@ -8,8 +8,15 @@
 // in flight; HBM latency ~1 us on a random row): 60 VGPRs, 8 waves per SIMD, so the 2048 workgroups of the
 // B = 65 536 launch are all resident at once.  CH = 8 needed 83 VGPRs (5 waves per SIMD: the grid then ran as one
 // full round plus a 60 % one) and was 8 % slower inside the training step (142 -> 130 us) although each wave had
-// twice the loads in flight.
+// twice the loads in flight.  Round 4, for the HBM-resident case (32 M rows = 4 GiB, where every row is a DRAM page miss):
+// the row ids of the NEXT chunk requested beside the current chunk's rows (a chunk is otherwise two dependent round
+// trips) with 4 or 8 rows in flight -- 137.4 / 136.9 us against 137.1 with the block, 77.1 / 78.3 against 75.4 without:
+// no gain, removed again.  The walk is not short of loads in flight (128 KB per CU); 4.7-5.0 TB/s is what random 128-byte
+// rows get out of the memory system here (the device-to-device copy ceiling is 6.3 TB/s).
 // HBM-bound: algorithmic bytes per sample = N*(idx 8 + E*s) read, E*s (+N*E*s with the block) written.
+#include <algorithm>
+#include <cstdlib>
+
 #include "trs_common.hpp"
 
 namespace trs {

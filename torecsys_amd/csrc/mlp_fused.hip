@@ -32,6 +32,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned mf_u32x4;
 #ifndef TRS_MF_GRID
 #define TRS_MF_GRID 256
 #endif
+#ifndef TRS_MF_MINW
+#define TRS_MF_MINW 2      // waves per SIMD the kernels are compiled for (2 = one 8-wave workgroup per CU)
+#endif
 constexpr int MF_ROWS = TRS_MF_ROWS;  // rows per workgroup pass
 constexpr int MF_MT = MF_ROWS / 16;   // 16-row tiles
 constexpr int MF_WAVES = 8;
@@ -380,7 +383,7 @@ __device__ __forceinline__ void mlp_load_in(char* act, int act_str, const void* 
 __device__ __forceinline__ unsigned mf_mask_byte(unsigned m) { return (m & 0xFu) | ((m >> 12) & 0xF0u); }
 __device__ __forceinline__ int mf_mask_bit(int j) { return (j >> 1) + 4 * (j & 1); }
 #define MF_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-__global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_fwd_kernel(MlpArgs a) {
+__global__ __launch_bounds__(64 * MF_WAVES, TRS_MF_MINW) void mlp_fused_fwd_kernel(MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* act = smem;                                          // [MF_ROWS][act_str]
   float* bias_s = reinterpret_cast<float*>(act + MF_ROWS * a.act_str);      // all layers' padded biases, back to back
@@ -520,7 +523,7 @@ struct RowsGemmArgs {
   int64_t rows;
   int in_stride, K, N, out_cols, out_stride, act_str;
 };
-__global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_rows_gemm_kernel(RowsGemmArgs a) {
+__global__ __launch_bounds__(64 * MF_WAVES, TRS_MF_MINW) void mlp_rows_gemm_kernel(RowsGemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* act = smem;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, r = lane & 15;
@@ -578,7 +581,7 @@ __global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_rows_gemm_kernel(RowsGem
 // ------------------------------------------------------------------------------------------------ backward (data)
 // step s works on layer l = L-1-s: input = d(pre-activation of layer l) (rows x N_l) in LDS, output = d(input of layer l)
 // = d(output of layer l-1), masked by layer l-1's ReLU mask into d(pre-activation of layer l-1).
-__global__ __launch_bounds__(64 * MF_WAVES, 2) void mlp_fused_bwd_kernel(MlpArgs a) {
+__global__ __launch_bounds__(64 * MF_WAVES, TRS_MF_MINW) void mlp_fused_bwd_kernel(MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* act = smem;
   float* scratch = reinterpret_cast<float*>(act + MF_ROWS * a.act_str);              // [8 row slices][512]

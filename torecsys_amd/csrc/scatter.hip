@@ -27,6 +27,12 @@ constexpr int LONG_ROW_ELEM = 32;
 // very hot rows (a Zipf head row collects thousands of lookups) are cut into chunks of LONG_CHUNK lookups that
 // different workgroups reduce; a second pass adds the chunk partials of a row.  Queue entries are (row, chunk).
 constexpr int LONG_CHUNK = 1024;
+// element path (rows that are not whole 16-byte vectors, e.g. the E = 1 first-order table): a queued row is reduced by ONE
+// wave; rows with more than ELEM_SPLIT lookups (a 4-row field collects 16 384 of a 65 536-sample batch) are cut into
+// chunks of ELEM_SPLIT lookups, one wave each, whose partial sums meet in fp32 scratch (atomics) and are finished by a
+// third small kernel.  Round 4: with one wave per row the criteo-skewed layout spent 115 us here (64 rounds of two
+// dependent latencies on a single wave).
+constexpr int ELEM_SPLIT = 2048;
 
 // 4 independent lookups per thread per iteration: 4 index loads, then 4 returning atomics in flight
 template <typename IdxT>
@@ -228,6 +234,8 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const IdxT* __restrict__ 
 // partitioned kernels then exit and the gated global-atomic kernels run instead -- no host round trip.
 constexpr int CSR2_CHUNK = 15360;      // 60 KB of int32 counters
 constexpr int CSR2_THREADS = 1024;
+constexpr int CSR2_TINY = 32;          // chunks of at most this many rows use privatised counters
+constexpr int CSR2_COPIES = 16;
 constexpr int CSR2_TB = 128;           // samples per transpose tile
 constexpr int CSR2_MAX_FIELDS = 120;   // transpose tile (N x 129 int32) stays under 64 KB
 
@@ -313,6 +321,67 @@ __global__ __launch_bounds__(CSR2_THREADS) void csr2_pass_kernel(const int32_t* 
   const int32_t* col = rowT + (int64_t)n * B;
   const int32_t ibase = (int32_t)base;
   constexpr int U = 8;
+  if (len <= CSR2_TINY) {
+    // A field of a handful of rows (criteo's bucketised numeric fields: 4, 5, 6, 8 ... rows): all 64 lanes of every wave
+    // hit the same few counters, and an LDS atomic on one address retires about one lane per clock (csr2_pass_kernel<true>
+    // 150 -> 204 us on the skewed layout).  The counters are PRIVATISED here: CSR2_COPIES copies of the chunk's counters,
+    // a lane uses copy (lane & 15), so the 64 lanes of a wave spread over 16 x len addresses.  Count pass: add up the
+    // copies.  Fill pass: count into the copies first, turn them into start positions (copy c of row v starts behind
+    // copies 0..c-1), then walk the column again with returning atomics on the lane's own copy.  (A ballot per row value
+    // instead of atomics was tried first: 8 x len dependent ballot rounds per wave iteration, 341 us.)
+    __shared__ int32_t ctrp[CSR2_COPIES][CSR2_TINY];
+    const int copy = threadIdx.x & (CSR2_COPIES - 1);
+    for (int i = threadIdx.x; i < CSR2_COPIES * CSR2_TINY; i += CSR2_THREADS) (&ctrp[0][0])[i] = 0;
+    __syncthreads();
+    for (int64_t b0 = threadIdx.x; b0 < B; b0 += (int64_t)CSR2_THREADS * U) {
+      int32_t r[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t b = b0 + (int64_t)u * CSR2_THREADS;
+        r[u] = b < B ? col[b] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const unsigned d = (unsigned)(r[u] - ibase);
+        if (r[u] >= 0 && d < (unsigned)len) atomicAdd(&ctrp[copy][d], 1);
+      }
+    }
+    __syncthreads();
+    if (!FILL) {
+      for (int v = threadIdx.x; v < len; v += CSR2_THREADS) {
+        int t = 0;
+        for (int c = 0; c < CSR2_COPIES; ++c) t += ctrp[c][v];
+        row_start[base + v] = t;
+      }
+      return;
+    }
+    for (int v = threadIdx.x; v < len; v += CSR2_THREADS) {      // counts -> start positions, per row over the copies
+      int run = ctr[v];                                         // = row_start[base + v]
+      for (int c = 0; c < CSR2_COPIES; ++c) {
+        const int t = ctrp[c][v];
+        ctrp[c][v] = run;
+        run += t;
+      }
+    }
+    __syncthreads();
+    for (int64_t b0 = threadIdx.x; b0 < B; b0 += (int64_t)CSR2_THREADS * U) {
+      int32_t r[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t b = b0 + (int64_t)u * CSR2_THREADS;
+        r[u] = b < B ? col[b] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const unsigned d = (unsigned)(r[u] - ibase);
+        if (r[u] >= 0 && d < (unsigned)len) {
+          const int pos = atomicAdd(&ctrp[copy][d], 1);
+          perm[pos] = (int32_t)((b0 + (int64_t)u * CSR2_THREADS) * N + n);
+        }
+      }
+    }
+    return;
+  }
   for (int64_t b0 = threadIdx.x; b0 < B; b0 += (int64_t)CSR2_THREADS * U) {
     int32_t r[U];
 #pragma unroll
@@ -857,7 +926,8 @@ __global__ __launch_bounds__(256) void scatter_rows_elem_kernel(
     const T* __restrict__ g_rows, const T* __restrict__ g_fm, const float* __restrict__ fm_sum,
     const T* __restrict__ table, const int32_t* __restrict__ row_start, const int32_t* __restrict__ perm, int64_t V,
     int E, int N, int64_t gbs, int64_t padding_row, T* __restrict__ grad, int32_t* __restrict__ long_rows,
-    RowSink sink, int gcols) {
+    RowSink sink, int gcols, int32_t* __restrict__ split_rows /* [0] = count, then (row, chunk) pairs */,
+    float* __restrict__ split_acc /* [entry][2][E] */) {
   const int64_t total = V * E;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const bool f32 = total < ((int64_t)1 << 32);
@@ -869,6 +939,18 @@ __global__ __launch_bounds__(256) void scatter_rows_elem_kernel(
     if (r != padding_row) {
       const int beg = row_start[r], end = row_start[r + 1];
       touched = end > beg;
+      if (end - beg > ELEM_SPLIT) {
+        if (e == 0) {
+          const int nch = (end - beg + ELEM_SPLIT - 1) / ELEM_SPLIT;
+          const int slot = atomicAdd(&split_rows[0], nch);      // the chunks of a row are adjacent in the queue
+          for (int c = 0; c < nch; ++c) {
+            split_rows[1 + 2 * (slot + c)] = (int32_t)r;
+            split_rows[2 + 2 * (slot + c)] = c;
+          }
+          for (int k = 0; k < 2 * E; ++k) split_acc[(size_t)slot * 2 * E + k] = 0.f;      // the row's accumulators
+        }
+        continue;
+      }
       if (end - beg > LONG_ROW_ELEM) {
         if (e == 0) {
           const int slot = atomicAdd(&long_rows[0], 1);
@@ -918,6 +1000,62 @@ __global__ __launch_bounds__(256) void scatter_long_rows_elem_kernel(
         sink_elem<T>(sink, grad, sink_row(sink, r) * E + e, acc, true);
       }
     }
+  }
+}
+
+// very hot rows of the element path: one wave per (row, chunk of ELEM_SPLIT lookups) entry, partial sums added into the
+// row's fp32 accumulators (the first entry of the row owns them)
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_split_rows_elem_kernel(
+    const T* __restrict__ g_rows, const T* __restrict__ g_fm, const float* __restrict__ fm_sum,
+    const int32_t* __restrict__ row_start, const int32_t* __restrict__ perm, int E, int N, int64_t gbs,
+    const int32_t* __restrict__ split_rows, float* __restrict__ split_acc, int gcols) {
+  const int nent = split_rows[0];
+  const int lane = threadIdx.x & 63;
+  const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int i = wid; i < nent; i += nwaves) {
+    const int64_t r = split_rows[1 + 2 * i];
+    const int c = split_rows[2 + 2 * i];
+    const int rbeg = row_start[r], rend = row_start[r + 1];
+    const int beg = rbeg + c * ELEM_SPLIT, end = rend < beg + ELEM_SPLIT ? rend : beg + ELEM_SPLIT;
+    float* racc = split_acc + (size_t)(i - c) * 2 * E;
+    for (int e = 0; e < E; ++e) {
+      float acc = 0.f, gsum = 0.f;
+      constexpr int U = 4;
+      for (int q = beg + lane; q < end; q += 64 * U) {
+        int pp[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) pp[u] = (q + 64 * u) < end ? perm[q + 64 * u] : -1;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (pp[u] >= 0) acc += elem_term<T>(g_rows, g_fm, fm_sum, pp[u], E, N, gbs, e, &gsum, gcols);
+      }
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) {
+        acc += __shfl_xor(acc, m, 64);
+        gsum += __shfl_xor(gsum, m, 64);
+      }
+      if (lane == 0) {
+        atomicAdd(&racc[e], acc);
+        atomicAdd(&racc[E + e], gsum);
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_split_rows_finish_elem_kernel(
+    const T* __restrict__ g_fm, const float* __restrict__ fm_sum, const T* __restrict__ table, int E,
+    T* __restrict__ grad, const int32_t* __restrict__ split_rows, const float* __restrict__ split_acc, RowSink sink) {
+  const int nent = split_rows[0];
+  const int64_t total = (int64_t)nent * E;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(t / E), e = (int)(t - (int64_t)i * E);
+    if (split_rows[2 + 2 * i] != 0) continue;                 // the first chunk of a row finishes it
+    const int64_t r = split_rows[1 + 2 * i];
+    float acc = split_acc[(size_t)i * 2 * E + e];
+    if (g_fm != nullptr && fm_sum != nullptr) acc = fmaf(-to_f32(table[r * E + e]), split_acc[(size_t)i * 2 * E + E + e], acc);
+    sink_elem<T>(sink, grad, sink_row(sink, r) * E + e, acc, true);
   }
 }
 
@@ -1034,12 +1172,19 @@ static int scatter_launch(const void* g_rows, const void* g_fm, const float* fm_
     }
   } else {
     if (g_first != nullptr) return 1;   // the companion table rides only in the 16-byte-vector walk
+    // queue of the split rows: behind the plain queue of long rows (long_row_queue_bytes); its counter was zeroed with
+    // the other one (scatter_rows_impl)
+    int32_t* split_rows = long_rows + 1 + (B * N / LONG_ROW_ELEM + 2);
     hipLaunchKernelGGL((scatter_rows_elem_kernel<T>), dim3(stream_grid(V * E, 256, 256 * 32)), dim3(256), 0, s,
                        (const T*)g_rows, (const T*)g_fm, fm_sum, (const T*)table, row_start, perm, V, E, N, gbs,
-                       padding_row, (T*)grad, long_rows, sink, gcols);
+                       padding_row, (T*)grad, long_rows, sink, gcols, split_rows, scratch);
     hipLaunchKernelGGL((scatter_long_rows_elem_kernel<T>), dim3(2048), dim3(256), 0, s, (const T*)g_rows,
                        (const T*)g_fm, fm_sum, (const T*)table, row_start, perm, E, N, gbs, (T*)grad, long_rows, sink,
                        gcols);
+    hipLaunchKernelGGL((scatter_split_rows_elem_kernel<T>), dim3(512), dim3(256), 0, s, (const T*)g_rows,
+                       (const T*)g_fm, fm_sum, row_start, perm, E, N, gbs, split_rows, scratch, gcols);
+    hipLaunchKernelGGL((scatter_split_rows_finish_elem_kernel<T>), dim3(16), dim3(256), 0, s, (const T*)g_fm, fm_sum,
+                       (const T*)table, E, (T*)grad, split_rows, scratch, sink);
   }
   return check_launch("scatter_rows");
 }
@@ -1052,6 +1197,9 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 __global__ __launch_bounds__(256) void zero_i32_kernel(int32_t* __restrict__ p, int64_t n) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0;
+}
+__global__ void zero_two_i32_kernel(int32_t* __restrict__ a, int32_t* __restrict__ b) {
+  if (threadIdx.x == 0) { *a = 0; *b = 0; }
 }
 static int zero_i32(int32_t* p, int64_t n, hipStream_t s) {
   hipLaunchKernelGGL(zero_i32_kernel, dim3(stream_grid(n, 256, 1024)), dim3(256), 0, s, p, n);
@@ -1165,7 +1313,10 @@ extern "C" int trs_csr_build(const void* idx, int32_t idx_dtype, const int64_t* 
 static size_t long_row_entries(int64_t BN) { return (size_t)(BN / LONG_ROW + BN / LONG_CHUNK + 2); }
 static size_t long_row_queue_bytes(int64_t BN) {
   // (row, chunk) pairs on the vector path, single row ids on the element path: room for the larger of the two
-  return align_up(std::max(long_row_entries(BN) * 8 + 8, (size_t)(BN / LONG_ROW_ELEM + 2) * 4), 256);
+  // (+ on the element path the queue of (row, chunk) pairs of the rows split over several waves, behind the plain one)
+  return align_up(std::max(long_row_entries(BN) * 8 + 8,
+                           (size_t)(BN / LONG_ROW_ELEM + 3) * 4 + (size_t)(BN / ELEM_SPLIT + BN / LONG_ROW_ELEM / 64 + 2) * 8 + 8),
+                  256);
 }
 
 extern "C" size_t trs_scatter_workspace_bytes(int64_t BN, int32_t N, int32_t E, int32_t dtype) {
@@ -1197,7 +1348,8 @@ static int scatter_rows_impl(RowSink sink, const void* g_rows, int64_t g_rows_ba
   float* scratch = (float*)((char*)tg + align_up((size_t)B * 2 * E * dtype_size(dtype), 256));
   hipStream_t s = (hipStream_t)stream;
   int32_t* long_rows = (int32_t*)workspace;
-  zero_i32(long_rows, 1, s);
+  // the counters of the hot-row queue and (element path) of the split-row queue behind it
+  hipLaunchKernelGGL(zero_two_i32_kernel, dim3(1), dim3(64), 0, s, long_rows, long_rows + 1 + (BN / LONG_ROW_ELEM + 2));
   int rc;
   if (dtype == TRS_F32)
     rc = scatter_launch<float>(g_rows, g_fm, fm_sum, table, row_start, perm, V, E, N, gbs, padding_row, grad_table,
