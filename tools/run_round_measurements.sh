@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): bash tools/run_round_measurements.sh r02
+# usage (on the GPU box, from the repo root): bash tools/run_round_measurements.sh r04
 # writes gpurun_out/<tag>/*: the bench lines of the three models and their variants, stand-alone kernel timings and the
 # rocprofv3 kernel traces that profiles/<tag>_* are copied from
 tag=${1:-r02}
@@ -9,14 +9,17 @@ mkdir -p "$O"
 run() { timeout 600 "$@"; }
 run python bench.py > $O/bench_deepfm.json 2> $O/bench_deepfm.err; tail -1 $O/bench_deepfm.json | cut -c1-300
 for m in fm dcn xdeepfm; do run python bench.py --no-cpu-baseline --no-large-table --model $m 2>/dev/null | tail -1 > $O/bench_$m.json; cut -c1-200 $O/bench_$m.json; done
-run python bench.py --no-cpu-baseline --no-large-table --eager 2>/dev/null | tail -1 > $O/bench_deepfm_eager.json
-run python bench.py --no-cpu-baseline --no-large-table --zipf 2>/dev/null | tail -1 > $O/bench_deepfm_zipf.json
-run python bench.py --no-cpu-baseline --no-large-table --optimizer adagrad 2>/dev/null | tail -1 > $O/bench_deepfm_adagrad.json
+run python bench.py --no-cpu-baseline --no-large-table --no-other-models --eager 2>/dev/null | tail -1 > $O/bench_deepfm_eager.json
+run python bench.py --no-cpu-baseline --no-large-table --no-other-models --zipf 2>/dev/null | tail -1 > $O/bench_deepfm_zipf.json
+run python bench.py --no-cpu-baseline --no-large-table --no-other-models --field-layout skewed 2>/dev/null | tail -1 > $O/bench_deepfm_skewed.json
+run python bench.py --no-cpu-baseline --no-large-table --no-other-models --field-layout skewed --zipf 2>/dev/null | tail -1 > $O/bench_deepfm_skewed_zipf.json
+run python bench.py --no-cpu-baseline --no-large-table --no-other-models --optimizer adagrad 2>/dev/null | tail -1 > $O/bench_deepfm_adagrad.json
 run python bench.py --no-cpu-baseline --no-large-table --force-sharded 2>/dev/null | tail -1 > $O/bench_deepfm_sharded1.json
+run python bench.py --no-cpu-baseline --no-large-table --force-sharded --no-pipeline 2>/dev/null | tail -1 > $O/bench_deepfm_sharded1_nopipe.json
 run python bench.py --no-cpu-baseline --no-large-table --force-sharded --optimizer adagrad 2>/dev/null | tail -1 > $O/bench_deepfm_sharded1_adagrad.json
 run python tools/kbench.py 2>&1 | grep -v Warn > $O/kbench.txt
 run python tools/kbench.py --what pairx,mlpf 2>&1 | grep -v Warn > $O/kbench_pairx_mlpf.txt
-run bash tools/trace_run.sh $O/bench_deepfm_kernel_trace.md "$tag -- rocprofv3 --kernel-trace --stats: bench.py (DeepFM, BASELINE configs[1])" -- python $R/bench.py --no-cpu-baseline --no-large-table --steps 20 --warmup 5
+run bash tools/trace_run.sh $O/bench_deepfm_kernel_trace.md "$tag -- rocprofv3 --kernel-trace --stats: bench.py (DeepFM, BASELINE configs[1])" -- python $R/bench.py --no-cpu-baseline --no-large-table --no-other-models --steps 20 --warmup 5
 TRS_TRACE_CALLS="cin_|glue" run bash tools/trace_run.sh $O/bench_xdeepfm_kernel_trace.md "$tag -- rocprofv3 --kernel-trace --stats: bench.py --model xdeepfm" -- python $R/bench.py --no-cpu-baseline --no-large-table --model xdeepfm --steps 3 --warmup 2
 run bash tools/trace_run.sh $O/bench_dcn_kernel_trace.md "$tag -- rocprofv3 --kernel-trace --stats: bench.py --model dcn" -- python $R/bench.py --no-cpu-baseline --no-large-table --model dcn --steps 3 --warmup 2
 ls -la $O

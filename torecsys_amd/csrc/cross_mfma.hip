@@ -316,16 +316,28 @@ __device__ __forceinline__ void layer_matmul_pre(const uint4* Wl, const float* b
 // k0..k0+3 first on even lane groups, k0+4..k0+7 first on odd ones (the two groups of a 32-lane half then cover all 64
 // banks; the permutation of k is the same for both MFMA operands).
 // LDS at E = 64, L = 6: W 48 KiB + W^T (layers 1..5) 40 KiB + biases 1.5 KiB + slabs 48 KiB = 137.5 KiB.
-constexpr int B3_CHAIN = 6;                         // chain waves per workgroup (one 16-row tile each)
-constexpr int B3_DW = 2;                            // weight-gradient waves
-constexpr int B3_ROWS = B3_CHAIN * 16;              // rows per workgroup step (96)
-constexpr int B3_PANEL = B3_ROWS * 32;              // bytes of one 16-column panel of a slab
+// wave roles per workgroup by E (NT = E / 16): E = 64 may trade chain waves for dW waves (TRS_B3_CHAIN64 / TRS_B3_DW64);
+// E = 32 has only NT * NT = 4 dW tiles per layer, i.e. at most two dW waves that own whole row tiles
+#ifndef TRS_B3_CHAIN64
+#define TRS_B3_CHAIN64 6
+#endif
+#ifndef TRS_B3_DW64
+#define TRS_B3_DW64 2
+#endif
+template <int NT>
+struct B3 {
+  static constexpr int CHAIN = NT >= 4 ? TRS_B3_CHAIN64 : 6;      // chain waves per workgroup (one 16-row tile each)
+  static constexpr int DW = NT >= 4 ? TRS_B3_DW64 : 2;            // weight-gradient waves
+  static constexpr int ROWS = CHAIN * 16;                         // rows per workgroup step
+  static constexpr int PANEL = ROWS * 32;                         // bytes of one 16-column panel of a slab
+};
 
 // 8 k-values (rows) x this lane's column of panel ``panel``: two transpose reads of a [4 rows][16 cols] block each
+template <int PANEL_BYTES>
 __device__ __forceinline__ s16x8 rows_frag3(const char* tensor, int k0, int panel, int i, int q) {
   typedef __attribute__((address_space(3))) s16x4* lds_p;
   const int cq = i & 3, odd = q & 1;
-  const char* base = tensor + panel * B3_PANEL + (k0 + (i >> 2)) * 32 + (cq & 1) * 8;
+  const char* base = tensor + panel * PANEL_BYTES + (k0 + (i >> 2)) * 32 + (cq & 1) * 8;
   const int h0 = (cq >> 1) * 16, h1 = 16 - h0;                 // rows with bit 2 clear / set: halves swapped
   const char* p_lo = base + (odd ? 4 * 32 + h1 : h0);
   const char* p_hi = base + (odd ? h0 : 4 * 32 + h1);
@@ -383,11 +395,12 @@ __device__ long long b3_trace[2][1024];
 #endif
 
 template <int NT, int L, bool DETACH>
-__global__ __launch_bounds__(64 * (B3_CHAIN + B3_DW), 2) void cross_mfma_bwd3_kernel(
+__global__ __launch_bounds__(64 * (B3<NT>::CHAIN + B3<NT>::DW), 2) void cross_mfma_bwd3_kernel(
     const uint4* __restrict__ x, const uint4* __restrict__ gout, const uint4* __restrict__ Wp,
     const uint4* __restrict__ Wtp, const float* __restrict__ bp, int64_t rows, uint4* __restrict__ dx,
     float* __restrict__ dWpart, float* __restrict__ dbpart) {
   constexpr int detach_first = DETACH ? 1 : 0;
+  constexpr int B3_CHAIN = B3<NT>::CHAIN, B3_DW = B3<NT>::DW, B3_ROWS = B3<NT>::ROWS, B3_PANEL = B3<NT>::PANEL;
   constexpr int KS = NT / 2;
   constexpr int E = NT * 16;
   constexpr int FRAG = NT * KS * 64;            // uint4 per layer
@@ -574,10 +587,10 @@ __global__ __launch_bounds__(64 * (B3_CHAIN + B3_DW), 2) void cross_mfma_bwd3_ke
         for (int ks = 0; ks < B3_ROWS / 32; ++ks) {
           s16x8 Bf[NT];
 #pragma unroll
-          for (int no = 0; no < NT; ++no) Bf[no] = rows_frag3(x_t, 32 * ks + 8 * q, no, r, q);
+          for (int no = 0; no < NT; ++no) Bf[no] = rows_frag3<B3_PANEL>(x_t, 32 * ks + 8 * q, no, r, q);
 #pragma unroll
           for (int m = 0; m < MO; ++m) {
-            const s16x8 A = rows_frag3(du_t, 32 * ks + 8 * q, wq * MO + m, r, q);
+            const s16x8 A = rows_frag3<B3_PANEL>(du_t, 32 * ks + 8 * q, wq * MO + m, r, q);
 #pragma unroll
             for (int no = 0; no < NT; ++no)
               dWacc[l][m * NT + no] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
@@ -690,6 +703,7 @@ static int cross_bwd_launch(const void* x, const void* g, const uint4* Wp, const
   constexpr int E = NT * 16;
   int grid;
   {
+    constexpr int B3_CHAIN = B3<NT>::CHAIN, B3_DW = B3<NT>::DW, B3_ROWS = B3<NT>::ROWS, B3_PANEL = B3<NT>::PANEL;
     const size_t lds = (size_t)(2 * L - 1) * E * E * 2 + (size_t)L * E * 4 + (size_t)4 * NT * B3_PANEL;
     auto kern = detach_first ? cross_mfma_bwd3_kernel<NT, L, true> : cross_mfma_bwd3_kernel<NT, L, false>;
     static bool attr_set[2] = {false, false};
