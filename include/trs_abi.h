@@ -318,6 +318,12 @@ int trs_relu_bwd_bias(const void* gy, const void* y, int64_t rows, int32_t C, in
  *      pre-activation, gx * [x > 0], and gbias_in its column sums = that layer's bias gradient (needs num_layers <= 7).
  * trs_mlp_fused_supported: 1 when the widths fit the kernel (and its LDS budget).                              */
 int trs_mlp_fused_supported(int32_t num_layers, const int32_t* widths);
+/* The two stack shapes of the models (64-400-400-400-64 on B*N rows; 416-400-400-8 behind a wide first layer) have a
+ * second pair of kernels (csrc/mlp_ro.hpp: a wave owns 64 / 32 rows for the whole stack) behind the same two entry
+ * points.  mode 0: never; 1 (default; TRS_MLP_RO in the environment): from 131 072 rows on; 2: at any size.  Returns
+ * the previous mode; any other argument only queries.  fwd and bwd_data of one stack must run under the same mode
+ * (the sign-bit layouts differ). */
+int32_t trs_mlp_ro_mode(int32_t mode);
 size_t trs_mlp_fused_workspace_bytes(int32_t num_layers, const int32_t* widths);
 size_t trs_mlp_fused_mask_bytes(int64_t rows);
 int trs_mlp_fused_fwd(const void* x, int64_t rows, int32_t num_layers, const int32_t* widths,

@@ -18,6 +18,16 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(params=[0, 2], ids=["tile-in-LDS kernels", "row-owner kernels"])
+def ro_mode(request):
+    """trs_mlp_ro_mode: the two stack shapes of the models have a second pair of kernels (csrc/mlp_ro.hpp), chosen from
+    131 072 rows on; 2 forces them at any size, 0 switches them off -- every test that takes this fixture runs on both."""
+    from torecsys_amd import _abi
+    prev = _abi.load().trs_mlp_ro_mode(request.param)
+    yield request.param
+    _abi.load().trs_mlp_ro_mode(prev)
+
+
 def _params(widths, g):
     Ws = [(torch.randn(o, i, generator=g) / i ** 0.5).bfloat16() for i, o in zip(widths[:-1], widths[1:])]
     bs = [(0.1 * torch.randn(o, generator=g)).bfloat16() for o in widths[1:]]
@@ -25,11 +35,13 @@ def _params(widths, g):
 
 
 @pytest.mark.parametrize("shape,widths", [((700, 7), [64, 400, 400, 400, 64]),      # the DCN stack, ragged last tile
+                                          ((70019,), [64, 400, 400, 400, 64]),     # ... more passes than workgroups
+                                          ((66003,), [416, 400, 400, 8]),          # the tail of a 400-400-400 deep branch
                                           ((4096,), [16, 72, 8]),                  # widths that are not multiples of 32
                                           ((33, 130), [64, 512, 64]),              # the widest supported layer
                                           ((5000,), [32, 104, 200, 40]),
                                           ((4224,), [128, 96, 96, 96, 96, 96, 24])])
-def test_fused_mlp_vs_oracle(dev, shape, widths):
+def test_fused_mlp_vs_oracle(dev, shape, widths, ro_mode):
     from torecsys_amd import functional as F_
     g = torch.Generator().manual_seed(sum(widths) + shape[0])
     Ws, bs = _params(widths, g)
@@ -46,7 +58,9 @@ def test_fused_mlp_vs_oracle(dev, shape, widths):
     # forward against the oracle as it is
     yo = O.mlp(x.float(), [w.float() for w in Ws], [b.float() for b in bs])
     assert rel_err(y.float().cpu(), yo) <= TOL
-    assert rel_err_rows(rows(y.float().cpu()), rows(yo), floor_frac=5e-2) <= 2 * TOL
+    # (the worst single row: over 66 000 rows of an 8-wide output the tail of the bf16 rounding noise reaches 2.3e-2)
+    row_tol = (2 if y.numel() // y.shape[-1] < 50000 else 3) * TOL
+    assert rel_err_rows(rows(y.float().cpu()), rows(yo), floor_frac=5e-2) <= row_tol
     # gradients against the oracle UNDER THE KERNEL'S OWN ReLU MASKS (a hidden unit whose pre-activation bf16
     # rounding moves across zero changes the gradient by a whole term -- see tests/test_gpu_cin_parity.py).  The sign
     # bits the forward kernel hands to the backward kernel are in the kernel's own order (opaque); they are the signs
@@ -69,7 +83,7 @@ def test_fused_mlp_vs_oracle(dev, shape, widths):
         [torch.relu(torch.nn.functional.linear(x.float(), Ws[0].float(), bs[0].float()))], unpacked[:1]))
     assert flips <= 2e-2
     assert rel_err(xd.grad.float().cpu(), xr.grad) <= TOL
-    assert rel_err_rows(rows(xd.grad.float().cpu()), rows(xr.grad), floor_frac=5e-2) <= 2 * TOL
+    assert rel_err_rows(rows(xd.grad.float().cpu()), rows(xr.grad), floor_frac=5e-2) <= row_tol
     for l, (a, b) in enumerate(zip(Wd, Wr)):
         assert rel_err(a.grad.float().cpu(), b.grad) <= TOL, ("dW", l)
     for l, (a, b) in enumerate(zip(bd, br)):
@@ -229,13 +243,14 @@ def test_wgrad_rows_falls_back_to_the_library_gemm_below_256_rows(dev):
     assert float((gw.double() - ref).abs().max() / ref.abs().max()) <= 1e-2
 
 
-def test_fused_backward_masks_its_input_gradient_with_the_upstream_relu(dev):
+@pytest.mark.parametrize("rows", [1000 + 19, 66000 + 7])
+def test_fused_backward_masks_its_input_gradient_with_the_upstream_relu(dev, rows, ro_mode):
     """mask_in / gbias_in of trs_mlp_fused_*: for a stack fed by relu(z), gx must be dL/dz = dL/dx * [x > 0] and gbias_in
     its column sums -- against the unmasked gradient of the same call, masked and summed here (ragged last row tile,
     input columns that are exactly zero in some rows)"""
     from torecsys_amd import functional as F_
     gen = torch.Generator().manual_seed(11)
-    rows, widths = 1000 + 19, [416, 400, 400, 8]
+    widths = [416, 400, 400, 8]
     x = torch.relu(torch.randn(rows, widths[0], generator=gen)).bfloat16().to(dev)
     Ws = [(torch.randn(widths[l + 1], widths[l], generator=gen) / widths[l] ** 0.5).bfloat16().to(dev) for l in range(3)]
     bs = [(0.1 * torch.randn(widths[l + 1], generator=gen)).bfloat16().to(dev) for l in range(3)]

@@ -23,7 +23,8 @@ FLAGS = ["-O3", "-std=c++20", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=
 # cost more issue time beside the matrix pipe than the two single ones they replace (CIN forward 1.58 vs 1.18 ms, cross
 # backward 1.15 vs 1.04 ms)
 FILE_FLAGS = {"cin_mfma.hip": ["-fno-slp-vectorize"], "cross_mfma.hip": ["-fno-slp-vectorize"],
-              "mlp_fused.hip": ["-fno-slp-vectorize"]}
+              "mlp_fused.hip": ["-fno-slp-vectorize"], "mlp_ro.hip": ["-fno-slp-vectorize"],
+              **{f"mlp_ro_{k}.hip": ["-fno-slp-vectorize"] for k in ("dcn_fwd", "dcn_bwd", "tail_fwd", "tail_bwd")}}
 
 
 def sources():

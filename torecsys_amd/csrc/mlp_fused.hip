@@ -758,6 +758,23 @@ static bool mlp_fused_covers(int L, const int32_t* w) {
   return true;
 }
 
+// mlp_ro.hip: the row-owner kernels for the stack shapes they are instantiated for
+bool mlp_ro_covers(int L, const int32_t* widths, int64_t rows);
+int mlp_ro_set_mode(int mode);
+size_t mlp_ro_mask_bytes(int64_t rows);
+int mlp_ro_fwd(const void* x, int64_t rows, int L, const int32_t* widths, const void* const* weights,
+               const void* const* biases, void* const* hidden, void* const* masks, void* mask_in, void* y, void* workspace,
+               hipStream_t s);
+struct RoColsum {
+  const float* part[9];
+  float* out[9];
+  int n[9];
+  int count, nparts;
+};
+int mlp_ro_bwd(const void* gy, int64_t rows, int L, const int32_t* widths, const void* const* weights,
+               const void* const* masks, void* const* gz, float* const* gbias, void* gx, const void* mask_in,
+               float* gbias_in, void* workspace, hipStream_t s, RoColsum* cs);
+
 static int mlp_act_str(int L, const int32_t* w) {
   int mx = 0;
   for (int i = 0; i <= L; ++i) mx = std::max(mx, pad32(w[i]));
@@ -779,11 +796,13 @@ extern "C" size_t trs_mlp_fused_workspace_bytes(int32_t num_layers, const int32_
   if (!mlp_fused_covers(num_layers, widths)) return 0;
   size_t sum = 0;
   for (int l = 0; l <= num_layers; ++l) sum += (size_t)pad32(widths[l]);
-  return mlp_frag_bytes(num_layers, widths) + (size_t)MF_GRID * sum * 4 + 4096;
+  return mlp_frag_bytes(num_layers, widths) + (size_t)MF_GRID * 8 * sum * 4 + 4096;      // (8: per-wave slices of the row-owner kernels)
 }
 
-extern "C" size_t trs_mlp_fused_mask_bytes(int64_t rows) {
-  return (size_t)((rows + MF_ROWS - 1) / MF_ROWS) * MF_MASK_TILE;
+extern "C" int32_t trs_mlp_ro_mode(int32_t mode) { return mlp_ro_set_mode(mode); }
+
+extern "C" size_t trs_mlp_fused_mask_bytes(int64_t rows) {      // either kernel family's layout
+  return std::max((size_t)((rows + MF_ROWS - 1) / MF_ROWS) * MF_MASK_TILE, mlp_ro_mask_bytes(rows));
 }
 
 extern "C" int trs_mlp_fused_supported(int32_t num_layers, const int32_t* widths) {
@@ -805,6 +824,8 @@ extern "C" int trs_mlp_fused_fwd(const void* x, int64_t rows, int32_t num_layers
               "mlp_fused_fwd: workspace too small");
   if (rows == 0) return TRS_OK;
   const int L = num_layers;
+  if (mlp_ro_covers(L, widths, rows))
+    return mlp_ro_fwd(x, rows, L, widths, weights, biases, hidden, masks, mask_in, y, workspace, s);
   MlpArgs a;
   a.nsteps = L;
   a.in = x;
@@ -875,6 +896,22 @@ extern "C" int trs_mlp_fused_bwd_data(const void* gy, int64_t rows, int32_t num_
       if (hipMemsetAsync(gbias[l], 0, (size_t)pad32(widths[l + 1]) * 4, s) != hipSuccess) return check_launch("mlp_fused_bwd_data");
     if (gbias_in && hipMemsetAsync(gbias_in, 0, (size_t)pad32(widths[0]) * 4, s) != hipSuccess) return check_launch("mlp_fused_bwd_data");
     return TRS_OK;
+  }
+  if (mlp_ro_covers(L, widths, rows)) {
+    RoColsum rc;
+    const int rcode = mlp_ro_bwd(gy, rows, L, widths, weights, masks, gz, gbias, gx, mask_in, gbias_in, workspace, s, &rc);
+    if (rcode != TRS_OK) return rcode;
+    MlpColsumArgs cs;
+    cs.nparts = rc.nparts;
+    int kmax = 0;
+    for (int i = 0; i < rc.count; ++i) {
+      cs.part[i] = rc.part[i];
+      cs.out[i] = rc.out[i];
+      cs.n[i] = rc.n[i];
+      kmax = std::max(kmax, rc.n[i]);
+    }
+    hipLaunchKernelGGL(mlp_colsum_reduce_many_kernel, dim3((kmax + 63) / 64, rc.count), dim3(1024), 0, s, cs);
+    return check_launch("mlp_fused_bwd_data");
   }
   MlpArgs a;
   a.nsteps = L;
