@@ -1,31 +1,45 @@
 // SURVEY.md 8f N4, second form of the fused Linear+ReLU stack (layers/ctr/multilayer_perceptron.py:63-84 applied to the
 // (B*N, E) rows of DeepAndCrossNetwork, models/ctr/deep_and_cross_network.py:71-87, and the tail of the deep branches of
 // DeepFM / xDeepFM): "row owner" kernels.  mlp_fused.hip keeps a 128-row tile of activations in LDS and splits the OUTPUT
-// columns over 8 waves, so every layer ends with two workgroup barriers and an LDS round trip of the whole tile, and the
-// weight fragments come from L2 per wave; it reaches 0.7 PFLOP/s.  Here a wave OWNS 64 rows for the whole stack:
+// columns over 8 waves: every layer ends with two workgroup barriers and an LDS round trip of the whole tile, and the
+// weight fragments come from L2 once per wave and 128 rows.  Here a wave OWNS its rows for the whole stack:
 //
 //   * D (32 output columns x 32 rows) = A (weights, 32 x 16 per k-step) x B (the rows' activations, 16 x 32 per k-step)
 //     with v_mfma_f32_32x32x16_bf16; the weight rows are fed in a permuted order (ro_col_of_row) so that a lane's 16
 //     results are columns 32 ct + 16 h + 8 g + (0..7), h = 0, 1 of ITS row: after bias / ReLU / rounding they are, as
 //     they stand, the B operands 2 ct + h of the next layer.  A layer's activations never leave the wave.
-//   * the 208 registers a 64 x 416 bf16 input takes leave no room for a second such block, and none is needed: the hidden
-//     activations go to global memory anyway (the weight-gradient GEMMs read them), so the next layer's input is read back
-//     from there (L2) into the registers the current layer's input dies out of during the layer's last column chunk;
-//     only the last two chunks' results travel in registers.
+//   * a 400-wide input is 100 registers per 32 rows; the next layer's input, as it is produced chunk by chunk (32
+//     columns), waits in registers (the last NREG chunks) and in LDS (the chunks before: 64 bytes per row and chunk,
+//     written and read back by the same lane, no barrier), and takes over the input's registers at the end of the layer.
+//     (Reading it back from the global copy the weight-gradient GEMMs need anyway cost 1.0 of 3.6 ms: 6.8 MB per XCD
+//     in flight between store and reload do not stay in a 4 MB L2.)
 //   * the weights pass through LDS: a chunk (32 output columns x K, <= 26 KB in MFMA fragment order) is copied by LDS-DMA
-//     three chunks ahead into a ring of four slots, one workgroup barrier per chunk, and every wave reads each fragment
-//     once per two MFMAs (its two 32-row tiles): 25 % of the LDS read rate, one L2 read per workgroup.
-//   * the epilogue of chunk c (bias is the accumulators' initial value; ReLU and the sign bits on the packed words; the
-//     16-byte stores) is issued in the second half of chunk c+1, between its MFMAs.
-// One workgroup = 4 waves (one per SIMD, up to 512 registers) = 256 rows per pass; grid = one workgroup per CU.
-// Everything is unrolled per stack shape (RoCfg): the shapes the models use are instantiated at the bottom, any other
-// stack runs on mlp_fused.hip.
+//     two chunks ahead into a ring of three slots, one workgroup barrier per chunk (in the middle of the chunk, so that
+//     the next chunk's first fragments can be read ahead of its first MFMA), one L2 read per workgroup and 256 rows.
+//   * the epilogue of chunk c (bias is the accumulators' initial value; ReLU and the sign bits on the packed words;
+//     16-byte stores) is spread word by word over the first half of chunk c+1, its stores follow the barrier.
+//   * backward: the same walk over the transposed weights; the epilogue multiplies the packed words with the forward's
+//     sign bits, and the bias gradients (column sums of every step's input) run on the matrix cores too: a 32 x 16
+//     piece goes through 1 KB of LDS, comes back transposed (ds_read_b64_tr_b16) and meets a one-hot B operand, so that
+//     one 16 x 16 accumulator tile collects 16 pieces' sums; waves add their tiles to private slices in global memory.
+//
+// Forward: 8 waves of 32 rows (two per SIMD, 240 registers); backward: 4 waves of 64 rows (464 registers; with 32 rows
+// it needs 18 registers more than a wave of 8 has).  256 rows per pass, one workgroup per CU, persistent.  Everything is
+// unrolled per stack shape (RoCfg); the shapes the models use are instantiated in mlp_ro_*.hip, one kernel per file,
+// any other stack runs on mlp_fused.hip.
+//
+// What bounds them (profiles/r04_mlp_ro.md): not the matrix pipe (MFMAs + epilogue alone: 1.2 ms of the forward's 2.4 at
+// 2.56 M rows) and not HBM (7.2 GB written, exactly the algorithmic bytes, at 3 TB/s against 6.9 measured for a fill) but
+// the CU's vector-memory path: a 16-byte-per-lane store touching 32 rows costs ~52 cycles of it, a 1 KB LDS-DMA piece
+// ~15, and a pass issues 43 KB of them per 1664-cycle chunk.  Things that looked free and were not: nt stores (5.2 vs
+// 2.5 ms: partial lines written through), a value used right behind its load (the compiler's wait counts the weight
+// copies it cannot see), loop-invariant address arithmetic (hoisted out of the pass loop by the hundred, then spilled).
+#pragma once
 #include <stdlib.h>
 
 #include <algorithm>
 #include <type_traits>
 
-#pragma once
 #include "trs_common.hpp"
 
 namespace trs {
@@ -35,14 +49,13 @@ typedef __attribute__((ext_vector_type(16))) float ro_f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned ro_u32x4;
 typedef __attribute__((ext_vector_type(4))) float ro_f32x4;
 
-constexpr int RO_ROWS = 256;                    // rows per workgroup pass: 4 waves x 2 tiles of 32
+constexpr int RO_ROWS = 256;                    // rows per workgroup pass: 8 waves x 32 or 4 waves x 64
 constexpr int RO_MAXL = 8;
 constexpr int RO_MAXKS = 26;                    // widths up to 416
 constexpr int RO_MAXCT = RO_MAXKS / 2;
 constexpr int RO_SLOTS = 3;                     // weight ring
 constexpr int RO_AHEAD = 2;                     // chunks between a copy's issue and its first use
-constexpr int RO_SLOT_BYTES = RO_MAXKS * 1024;
-constexpr int RO_MASK_WORDS = 16 * 256;         // sign-bit words per pass and layer: [chunk][thread], 16 KB
+constexpr int RO_MASK_WORDS = 16 * 256;         // sign-bit words per pass and layer: [chunk][row pair], 16 KB
 #ifndef TRS_RO_PF
 #define TRS_RO_PF 3
 #endif
@@ -60,8 +73,8 @@ __host__ __device__ constexpr int ro_nreg(bool bwd, int rt) { return bwd && rt =
 #define TRS_RO_NT 0      // cache policy of the output stores (2 = nt: measured 2x SLOWER, 5.2 vs 2.5 ms -- partial lines written through)
 #endif
 #ifndef TRS_RO_ABL
-#define TRS_RO_ABL 0      // timing experiments (wrong results): 1 no weight copies, 2 no stores, 4 no mid wait + barrier,
-#endif                    // 16 no fragment reads
+#define TRS_RO_ABL 0      // timing experiments (wrong results): 1 no weight copies, 2 no stores, 4 no wait + barrier,
+#endif                    // 16 no fragment reads, 32 no column sums, 64 no sign bits (backward)
 
 template <int V>
 using ro_ic = std::integral_constant<int, V>;
@@ -285,9 +298,11 @@ __global__ __launch_bounds__(512 / RT, 1) void mlp_ro_kernel(RoArgs a) {
   }
   bool have_prev = false;
   unsigned mtile_prev = 0;
-  unsigned off_out[L][RT], off_last_prev[RT];
+  // offsets of this lane's two stores per row tile (see epi_store): rows (n % 16) and (n % 16) + 16 of the tile, column
+  // half n / 16
+  unsigned off_out[L][RT][2], off_last_prev[RT][2];
 #pragma unroll
-  for (int r = 0; r < RT; ++r) off_last_prev[r] = 0;
+  for (int r = 0; r < RT; ++r) off_last_prev[r][0] = off_last_prev[r][1] = 0;
 
   // ---- backward: the sign bits for the pending epilogue, and the column sums (= bias gradients) of what the steps
   // write.  A quarter (32 rows x 16 columns: this lane's 16 bytes and its partner's) goes through 1 KB of LDS and comes
@@ -383,19 +398,35 @@ __global__ __launch_bounds__(512 / RT, 1) void mlp_ro_kernel(RoArgs a) {
       }
     }
   };
-  auto epi_store = [&](auto pc_, auto t_, const unsigned (&off)[RT], unsigned& mw, bool on) __attribute__((always_inline)) {
+  // The stores of a row tile's 32 x 32 results.  As they come out of the MFMA a lane holds 2 x 16 bytes of ONE row, so a
+  // 16-byte-per-lane store touches 32 rows with 32 bytes each -- and the vector-memory path pays per cache line touched
+  // (~52 cycles for such a store against ~15 for 1 KB in one piece).  v_permlane16_swap trades the second column half of
+  // lanes n < 16 for the first of lanes n + 16: then one store writes rows 0..15 of the tile, 64 bytes each, the other
+  // rows 16..31.
+  auto epi_store = [&](auto pc_, auto t_, const unsigned (&off)[RT][2], unsigned& mw, bool on) __attribute__((always_inline)) {
     constexpr int pc = decltype(pc_)::value, t = decltype(t_)::value, r = t >> 1, h = t & 1;
     constexpr int pl = Cfg::layer_of(pc), pct = Cfg::ct_of(pc);
     constexpr bool hidden = pl + 1 < L;
     const RoLayer& ly = a.layer[pl];
     if constexpr (!BWD && hidden) mw |= (mq[t] & 0xfu) << ro_flag_bit(t, 0) | (mq[t] >> 16) << (ro_flag_bit(t, 0) + 8);
-    const ro_u32x4 pk = {pw[t][0], pw[t][1], pw[t][2], pw[t][3]};
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ly.out, 0, (unsigned)(a.rows * ly.out_stride * 2), 0x00020000);
-    unsigned o = off[r] + (32 * pct + 16 * h) * 2;
-    if constexpr (!hidden) o = 32 * pct + 16 * h + 8 * g < ly.out_cols ? o : 0xfffffff0u;
-    if constexpr (TRS_RO_ABL & 2) o = pk[0] == 0x12345678u ? o : 0xfffffff0u;
-    o = on ? o : 0xfffffff0u;      // past the end of every tensor: dropped
-    __builtin_amdgcn_raw_buffer_store_b128(pk, rs, o, 0, TRS_RO_NT);
+    if constexpr (h == 1) {
+      ro_u32x4 lo, hi;      // after the swap: rows n % 16 / n % 16 + 16, column half n / 16
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(pw[t - 1][k2], pw[t][k2], false, false);
+        lo[k2] = sw[0];
+        hi[k2] = sw[1];
+      }
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(ly.out, 0, (unsigned)(a.rows * ly.out_stride * 2), 0x00020000);
+#pragma unroll
+      for (int sidx = 0; sidx < 2; ++sidx) {
+        unsigned o = off[r][sidx] + 32 * pct * 2;
+        if constexpr (!hidden) o = 32 * pct + 16 * ((lane >> 4) & 1) + 8 * g < ly.out_cols ? o : 0xfffffff0u;
+        if constexpr (TRS_RO_ABL & 2) o = lo[0] == 0x12345678u ? o : 0xfffffff0u;
+        o = on ? o : 0xfffffff0u;      // past the end of every tensor: dropped
+        __builtin_amdgcn_raw_buffer_store_b128(sidx == 0 ? lo : hi, rs, o, 0, TRS_RO_NT);
+      }
+    }
   };
   auto mask_store = [&](auto pc_, unsigned mtile, unsigned mw, bool on) __attribute__((always_inline)) {
     constexpr int pc = decltype(pc_)::value, pl = Cfg::layer_of(pc), pct = Cfg::ct_of(pc);
@@ -461,7 +492,10 @@ __global__ __launch_bounds__(512 / RT, 1) void mlp_ro_kernel(RoArgs a) {
 
       if constexpr (ct == 0) {      // this lane's offsets into the layer's output (first needed by the next chunk's stores)
 #pragma unroll
-        for (int r = 0; r < RT; ++r) off_out[l][r] = ((row_here + 32 * r) * a.layer[l].out_stride + 8 * g) * 2u;
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+          for (int sidx = 0; sidx < 2; ++sidx)
+            off_out[l][r][sidx] = ((row_here - (lane & 16) + 32 * r + 16 * sidx) * a.layer[l].out_stride + 8 * g + (lane & 16)) * 2u;
       }
       ro_u32x4 af[KS];
       ro_for<0, PF>([&](auto i) __attribute__((always_inline)) { af[i] = afn[i]; });
@@ -625,7 +659,7 @@ __global__ __launch_bounds__(512 / RT, 1) void mlp_ro_kernel(RoArgs a) {
     have_prev = true;
     mtile_prev = mtile;
 #pragma unroll
-    for (int r = 0; r < RT; ++r) off_last_prev[r] = off_out[L - 1][r];
+    for (int r = 0; r < RT; ++r) off_last_prev[r][0] = off_out[L - 1][r][0], off_last_prev[r][1] = off_out[L - 1][r][1];
   }
   // the last chunk's epilogue
   {
