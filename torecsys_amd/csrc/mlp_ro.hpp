@@ -67,8 +67,8 @@ constexpr int RO_PF = TRS_RO_PF;                // weight fragments read ahead o
 #define TRS_RO_NREG 9
 #endif
 // chunks of a layer's output that wait for the next layer in registers; the ones before them wait in LDS (64 bytes per
-// chunk and row).  The backward kernels need the registers elsewhere and have the LDS (no bias, narrower weight slots).
-__host__ __device__ constexpr int ro_nreg(bool bwd, int rt) { return bwd && rt == 2 ? TRS_RO_NREG - 1 : TRS_RO_NREG; }
+// chunk and row)
+__host__ __device__ constexpr int ro_nreg(bool bwd, int rt) { return TRS_RO_NREG; }
 #ifndef TRS_RO_NT
 #define TRS_RO_NT 0      // cache policy of the output stores (2 = nt: measured 2x SLOWER, 5.2 vs 2.5 ms -- partial lines written through)
 #endif
@@ -163,6 +163,14 @@ __device__ __forceinline__ void ro_dma1(const char* src, unsigned voff, unsigned
   const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(dst), "s"(src) : "memory");
+}
+
+// the same for 4 bytes per lane (256 bytes per wave), as a buffer operation: offsets past the end read nothing
+__device__ __forceinline__ void ro_dma1_dword(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(dst), "s"(rs) : "memory");
 }
 
 template <int N>
@@ -310,8 +318,8 @@ __global__ __launch_bounds__(512 / RT, 1) void mlp_ro_kernel(RoArgs a) {
   // and 0 elsewhere: a 16 x 16 accumulator tile collects the sums of 16 units x 16 columns, a 416-wide output takes two.
   // At the end of a step a wave adds its tiles to ITS slice of the partial sums in global memory (fixed order: the
   // bias gradients are reproducible bit for bit).
-  unsigned mcur = 0xffffffffu, mnone = 0;
-  unsigned mraw = 0;
+  unsigned mcur = 0xffffffffu;
+  const unsigned mstage = RING + NW * STASH_WAVE + NW * 1024 + wave * 768;      // this wave's three 256-byte stages for sign-bit words
   ro_f32x4 cs = {0.f, 0.f, 0.f, 0.f};       // sums of the running step's input ...
   ro_f32x4 cso = {0.f, 0.f, 0.f, 0.f};      // ... and, in the last step, of its output: both are under way at once
   unsigned scr_wr = RING + NW * STASH_WAVE + wave * 1024 + (2 * (lane & 31) + g) * 16;
@@ -362,8 +370,9 @@ __global__ __launch_bounds__(512 / RT, 1) void mlp_ro_kernel(RoArgs a) {
       const unsigned f = ro_pk_flag(w);
       mq[t] = k2 == 0 ? f : (mq[t] | (f << k2));
     }
-    if constexpr (BWD && !(TRS_RO_ABL & 64)) {      // times [forward activation > 0], two columns per instruction (all ones when the step has no mask)
-      const unsigned e = ((mcur >> ro_flag_bit(t, k2)) & 1u) | (((mcur >> (ro_flag_bit(t, k2) + 8)) & 1u) << 16);
+    if constexpr (BWD && !(TRS_RO_ABL & (64 | 128))) {      // times [forward activation > 0], two columns per instruction (all ones when the step has no mask)
+      // (the word's middle bytes were exchanged when it was taken over: the two flags are 16 bits apart)
+      const unsigned e = (mcur >> (8 * r + 4 * h + k2)) & 0x00010001u;
       w = ro_pk_mul_u16(w, e);
     }
     pw[t][k2] = w;
@@ -438,6 +447,21 @@ __global__ __launch_bounds__(512 / RT, 1) void mlp_ro_kernel(RoArgs a) {
     }
   };
 
+  // backward: the sign bits of chunk (l, ct) of the pass whose first mask element is ``mt``, into stage ``st`` of this
+  // wave's LDS staging area (LDS-DMA, 4 bytes per lane): requested at the chunk's first k-step, landed at the barrier's
+  // wait, read at the end of the chunk for the epilogue that runs in the next one.  Through LDS and not into a register:
+  // a register written by a hand-issued load must not be touched before the wait, and nothing keeps the compiler from
+  // moving a value it believes defined (to an AGPR, say) while the load is in flight; as a compiler-visible load its
+  // wait in front of the first use counts the weight copies the compiler cannot see and parks the wave for them
+  // (1.2 of 4.4 ms).  (Requested a chunk ahead, right behind the barrier, where the stores and the weight copies are
+  // issued: 3.18 instead of 2.98 ms.)
+  static_assert(!BWD || RT == 2, "backward: 64 rows per wave (one 32-bit word of sign bits per lane and chunk)");
+  auto mask_has = [&](auto l_) __attribute__((always_inline)) { return decltype(l_)::value + 1 < L || a.layer[decltype(l_)::value].mask != nullptr; };
+  auto mask_load = [&](auto l_, auto ct_, unsigned mt, int st) __attribute__((always_inline)) {
+    constexpr int l = decltype(l_)::value, ct = decltype(ct_)::value;
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(a.layer[l].mask, 0, (unsigned)(ntiles * RO_MASK_WORDS * 4), 0x00020000);
+    if (mask_has(l_)) ro_dma1_dword(rm, (mt + ct * MSTR) * 4, ring + mstage + st * 256);
+  };
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     asm volatile("s_mov_b32 %0, 0" : "=s"(pass_zero));
 #pragma unroll
@@ -544,19 +568,7 @@ __global__ __launch_bounds__(512 / RT, 1) void mlp_ro_kernel(RoArgs a) {
 
       ro_for<0, KS>([&](auto ks_) __attribute__((always_inline)) {
         constexpr int ks = decltype(ks_)::value;
-        if constexpr (BWD && ks == 0 && !(TRS_RO_ABL & 64)) {
-          // this chunk's sign bits: requested now, complete at the barrier (its wait), used by the epilogue in the next chunk
-          // (buffer operation: a 32-bit offset; as a pointer + index the compiler forms 41 64-bit addresses per pass early)
-          const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(a.layer[l].mask, 0, (unsigned)(ntiles * RO_MASK_WORDS * 4), 0x00020000);
-          const bool has = l + 1 < L || a.layer[l].mask != nullptr;      // (no mask: an offset past the end reads nothing)
-          // (the value is not touched before the end of the chunk: any use, even the zero extension, parks the wave here)
-          // (issued by hand: it is complete at the barrier's wait, which the compiler does not know -- its own wait, in
-          // front of the first use, counts the weight copies it cannot see and would park the wave for them)
-          const unsigned mo = has ? (mtile + ct * MSTR) * (RT == 2 ? 4 : 2) : 0xfffffff0u;
-          if constexpr (RT == 2) asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(mraw) : "v"(mo), "s"(rm));
-          else asm volatile("buffer_load_ushort %0, %1, %2, 0 offen" : "=v"(mraw) : "v"(mo), "s"(rm));
-          mnone = has ? 0u : 0xffffffffu;
-        }
+        if constexpr (BWD && ks == 0 && !(TRS_RO_ABL & 64)) mask_load(ro_ic<l>{}, ro_ic<ct>{}, mtile, c % 3);
         words(ks_, ro_ic<1>{});
         if constexpr (ks + PF < KS) af[ks + PF] = lds_frag(rd_at, ks + PF);
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ro_bf16x8, af[ks]), __builtin_bit_cast(ro_bf16x8, B[0][ks]), acc[0], 0, 0, 0);
@@ -645,7 +657,10 @@ __global__ __launch_bounds__(512 / RT, 1) void mlp_ro_kernel(RoArgs a) {
       else mask_store(ro_ic<pc>{}, mtile_prev, mw, have_prev);
 #pragma unroll
       for (int r = 0; r < RT; ++r) accp[r] = acc[r];
-      if constexpr (BWD) mcur = (unsigned)mraw | mnone;
+      if constexpr (BWD) {      // this chunk's word (requested a chunk ago) for its epilogue in the next chunk
+        const unsigned mv = *reinterpret_cast<const unsigned*>(smem + mstage + (c % 3) * 256 + lane * 4);      // (three stages: c's is read while c+1's lands; % 2 would do within a pass, not across passes of an odd chunk count)
+        mcur = mask_has(ro_ic<l>{}) ? __builtin_amdgcn_perm(mv, mv, 0x03010200u) : 0xffffffffu;      // middle bytes exchanged: see epi_word
+      }
       rd_at = rd_next;
       dma_at = slot_inc(dma_at, ring);
       if constexpr (last_of_layer) {
@@ -700,8 +715,8 @@ struct RoPackArgs {
 template <class Cfg, bool BWD, int IN_COLS, int RT>
 inline int ro_launch(const RoArgs& a, hipStream_t s) {
   static bool attr = false;
-  const size_t lds = (size_t)RO_SLOTS * Cfg::max_ks() * 1024 + 8 * (RO_MAXCT - ro_nreg(BWD, RT)) * 2048 + (BWD ? (8 / RT) * 1024 : Cfg::NB * 4);
-  static_assert(RO_SLOTS * Cfg::max_ks() * 1024 + 8 * (RO_MAXCT - ro_nreg(BWD, RT)) * 2048 + (BWD ? (8 / RT) * 1024 : Cfg::NB * 4) <= 160 * 1024, "LDS");
+  const size_t lds = (size_t)RO_SLOTS * Cfg::max_ks() * 1024 + 8 * (RO_MAXCT - ro_nreg(BWD, RT)) * 2048 + (BWD ? (8 / RT) * (1024 + 768) : Cfg::NB * 4);
+  static_assert(RO_SLOTS * Cfg::max_ks() * 1024 + 8 * (RO_MAXCT - ro_nreg(BWD, RT)) * 2048 + (BWD ? (8 / RT) * (1024 + 768) : Cfg::NB * 4) <= 160 * 1024, "LDS");
   if (!attr) {
     if (hipFuncSetAttribute((const void*)mlp_ro_kernel<Cfg, BWD, IN_COLS, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
         hipSuccess)
