@@ -510,6 +510,9 @@ SPILL_ALLOWLIST = {
     "void trs::pairw_reg_kernel<float, 1>": (13, "OPN 'vec' weight gradient: 64 accumulators per lane at the 128-register "
                                                  "cap of a 1024-thread workgroup (one pair per lane needs the 1024 threads)"),
     "void trs::pairw_reg_kernel<trs::bf16_t, 1>": (12, "as above"),
+    "void trs::mlp_ro_kernel<trs::RoCfg<416, 400, 400, 8>, false, 416, 1>": (1, "one per-pass value saved at the start of a "
+                                                                               "pass and re-read once at its end (the 416-wide "
+                                                                               "input takes 104 of the 256 registers)"),
 }
 
 

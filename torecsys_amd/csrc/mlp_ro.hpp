@@ -57,7 +57,7 @@ constexpr int RO_SLOTS = 3;                     // weight ring
 constexpr int RO_AHEAD = 2;                     // chunks between a copy's issue and its first use
 constexpr int RO_MASK_WORDS = 16 * 256;         // sign-bit words per pass and layer: [chunk][row pair], 16 KB
 #ifndef TRS_RO_PF
-#define TRS_RO_PF 3
+#define TRS_RO_PF 2
 #endif
 constexpr int RO_PF = TRS_RO_PF;                // weight fragments read ahead of the MFMAs
 #ifndef TRS_RO_PFB
@@ -165,11 +165,11 @@ __device__ __forceinline__ void ro_dma1(const char* src, unsigned voff, unsigned
                : "=&s"(keep) : "v"(voff), "s"(dst), "s"(src) : "memory");
 }
 
-// the same for 4 bytes per lane (256 bytes per wave), as a buffer operation: offsets past the end read nothing
-__device__ __forceinline__ void ro_dma1_dword(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned lds_dst) {
+// the same as a buffer operation (offsets past the end read nothing)
+__device__ __forceinline__ void ro_dma1_buf(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned lds_dst) {
   unsigned keep;
   const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(dst), "s"(rs) : "memory");
 }
 
@@ -199,10 +199,14 @@ __device__ __forceinline__ unsigned ro_pk_mul_u16(unsigned a, unsigned b) {
   return x;
 }
 
-// Sign bits of a pass (256 rows) and layer: one 32-bit word per chunk and "row pair" p = 64 (row / 64) + row % 32 --
-// [pass][chunk][p]; half r = (row / 32) % 2 of the word belongs to row p + 32 r: bit 16 r + 4 h + k2 is the flag of
-// column 32 chunk + 16 h + 8 g + 2 k2 (g: the lane group, = which of the row's two lanes), bit 16 r + 8 + 4 h + k2 of
-// the column after it.  A wave with 64 rows (RT = 2) owns whole words, a wave with 32 rows (RT = 1) one half of each.
+// Sign bits of a pass (256 rows) and layer: 16 bits per lane, 32-row tile and chunk -- bit 4 h + k2 is the flag of column
+// 32 chunk + 16 h + 8 g + 2 k2 (g: the lane group, = which of the row's two lanes), bit 8 + 4 h + k2 of the column after
+// it -- in groups of four chunks: [pass][chunk / 4][slot = 2 (64 (row / 64) + lane) + (row / 32) % 2][chunk % 4], 8 bytes
+// per slot and group.  A vector-memory instruction costs what it costs whether it moves 2 or 16 bytes per lane (one
+// 256-byte load per chunk was 0.3 of the backward's 3.0 ms), and what it costs grows with the number of separate
+// segments it touches (32-byte records per lane, two 16-byte stores each: forward 2.39 -> 2.54 ms): the forward (32 rows
+// per wave: one slot per lane) writes 512 contiguous bytes per wave and group, the backward (64 rows per wave: two
+// adjacent slots per lane) fetches 1 KB per wave and group by LDS-DMA and picks the chunks' bits out of LDS.
 __host__ __device__ constexpr int ro_flag_bit(int t, int k2) { return 16 * (t >> 1) + 4 * (t & 1) + k2; }      // t = 2 r + h
 
 // RT: 32-row tiles per wave -- 2: four waves (one per SIMD, 512 registers) of 64 rows, every weight fragment read from LDS
@@ -218,7 +222,6 @@ __global__ __launch_bounds__(512 / RT, 1) void mlp_ro_kernel(RoArgs a) {
   constexpr int NREGK = ro_nreg(BWD, RT), NLDSK = RO_MAXCT - NREGK;
   constexpr int STASH_WAVE = NLDSK * 2048 * RT;
   constexpr int SLOT = Cfg::max_ks() * 1024;          // bytes per ring slot
-  constexpr int MSTR = 512 / RT;                       // mask elements per chunk
   constexpr unsigned RING = RO_SLOTS * SLOT;
   extern __shared__ __attribute__((aligned(16))) char smem[];      // [weight ring][the waves' stash][bias]
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(512 / RT, 1) void mlp_ro_kernel(RoArgs a) {
   // At the end of a step a wave adds its tiles to ITS slice of the partial sums in global memory (fixed order: the
   // bias gradients are reproducible bit for bit).
   unsigned mcur = 0xffffffffu;
-  const unsigned mstage = RING + NW * STASH_WAVE + NW * 1024 + wave * 768;      // this wave's three 256-byte stages for sign-bit words
+  const unsigned mstage = RING + NW * STASH_WAVE + NW * 1024 + wave * 4096;      // this wave's stage for a layer's sign-bit records
   ro_f32x4 cs = {0.f, 0.f, 0.f, 0.f};       // sums of the running step's input ...
   ro_f32x4 cso = {0.f, 0.f, 0.f, 0.f};      // ... and, in the last step, of its output: both are under way at once
   unsigned scr_wr = RING + NW * STASH_WAVE + wave * 1024 + (2 * (lane & 31) + g) * 16;
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(512 / RT, 1) void mlp_ro_kernel(RoArgs a) {
       mq[t] = k2 == 0 ? f : (mq[t] | (f << k2));
     }
     if constexpr (BWD && !(TRS_RO_ABL & (64 | 128))) {      // times [forward activation > 0], two columns per instruction (all ones when the step has no mask)
-      // (the word's middle bytes were exchanged when it was taken over: the two flags are 16 bits apart)
+      // (mcur: see the end of the chunk body -- a word's two flags are 16 bits apart)
       const unsigned e = (mcur >> (8 * r + 4 * h + k2)) & 0x00010001u;
       w = ro_pk_mul_u16(w, e);
     }
@@ -437,31 +440,44 @@ __global__ __launch_bounds__(512 / RT, 1) void mlp_ro_kernel(RoArgs a) {
       }
     }
   };
-  auto mask_store = [&](auto pc_, unsigned mtile, unsigned mw, bool on) __attribute__((always_inline)) {
-    constexpr int pc = decltype(pc_)::value, pl = Cfg::layer_of(pc), pct = Cfg::ct_of(pc);
+  static_assert(BWD ? RT == 2 : RT == 1, "sign-bit records: written by 32-row waves, read by 64-row waves");
+  // forward: chunk pct's 16 flags of this lane join the record under construction; 4 chunks (or the layer's last ones)
+  // leave as one 8-byte store.  ``mrec``: this lane's slot of the pass's first group (byte offset into the layer's mask)
+  unsigned mreg[2];
+  auto mask_store = [&](auto pc_, unsigned mrec, unsigned mw, bool on) __attribute__((always_inline)) {
+    constexpr int pc = decltype(pc_)::value, pl = Cfg::layer_of(pc), pct = Cfg::ct_of(pc), CTp = Cfg::ct(pl);
     if constexpr (!BWD && pl + 1 < L) {
-      const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(a.layer[pl].mask, 0, (unsigned)(ntiles * RO_MASK_WORDS * 4), 0x00020000);
-      const unsigned o = (on && (!(TRS_RO_ABL & 2) || mw == 0x13572468u)) ? (mtile + pct * MSTR) * (RT == 2 ? 4 : 2) : 0xfffffff0u;
-      if constexpr (RT == 2) __builtin_amdgcn_raw_buffer_store_b32(mw, rm, o, 0, 0);
-      else __builtin_amdgcn_raw_buffer_store_b16((unsigned short)mw, rm, o, 0, 0);
+      constexpr int sl = pct & 3;
+      if constexpr ((sl & 1) == 0) mreg[sl >> 1] = mw & 0xffffu;
+      else mreg[sl >> 1] |= mw << 16;
+      if constexpr (sl == 3 || pct == CTp - 1) {
+        if constexpr (sl < 2) mreg[1] = 0;
+        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(a.layer[pl].mask, 0, (unsigned)(ntiles * RO_MASK_WORDS * 4), 0x00020000);
+        const unsigned o = (on && (!(TRS_RO_ABL & 2) || mw == 0x13572468u)) ? mrec + (pct >> 2) * 4096 : 0xfffffff0u;
+        typedef __attribute__((ext_vector_type(2))) unsigned ro_u32x2;
+        __builtin_amdgcn_raw_buffer_store_b64(ro_u32x2{mreg[0], mreg[1]}, rm, o, 0, 0);
+      }
     }
   };
 
-  // backward: the sign bits of chunk (l, ct) of the pass whose first mask element is ``mt``, into stage ``st`` of this
-  // wave's LDS staging area (LDS-DMA, 4 bytes per lane): requested at the chunk's first k-step, landed at the barrier's
-  // wait, read at the end of the chunk for the epilogue that runs in the next one.  Through LDS and not into a register:
+  // backward: a layer's sign bits of this wave (4 groups of 1 KB) by LDS-DMA into the wave's 4 KB stage --
+  // requested at the first k-step of the layer's first chunk, landed at that chunk's barrier (its wait), and read chunk
+  // by chunk at the end of every chunk for the epilogue that runs in the next one.  Through LDS and not into registers:
   // a register written by a hand-issued load must not be touched before the wait, and nothing keeps the compiler from
-  // moving a value it believes defined (to an AGPR, say) while the load is in flight; as a compiler-visible load its
+  // moving a value it believes defined (to an AGPR, say) while the load is in flight; as compiler-visible loads their
   // wait in front of the first use counts the weight copies the compiler cannot see and parks the wave for them
-  // (1.2 of 4.4 ms).  (Requested a chunk ahead, right behind the barrier, where the stores and the weight copies are
-  // issued: 3.18 instead of 2.98 ms.)
-  static_assert(!BWD || RT == 2, "backward: 64 rows per wave (one 32-bit word of sign bits per lane and chunk)");
+  // (1.2 of 4.4 ms).
   auto mask_has = [&](auto l_) __attribute__((always_inline)) { return decltype(l_)::value + 1 < L || a.layer[decltype(l_)::value].mask != nullptr; };
-  auto mask_load = [&](auto l_, auto ct_, unsigned mt, int st) __attribute__((always_inline)) {
-    constexpr int l = decltype(l_)::value, ct = decltype(ct_)::value;
+  auto mask_load = [&](auto l_, unsigned mrec) __attribute__((always_inline)) {
+    constexpr int l = decltype(l_)::value;
     const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(a.layer[l].mask, 0, (unsigned)(ntiles * RO_MASK_WORDS * 4), 0x00020000);
-    if (mask_has(l_)) ro_dma1_dword(rm, (mt + ct * MSTR) * 4, ring + mstage + st * 256);
+    if (mask_has(l_)) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)      // piece q: chunks 4 q .. 4 q + 3, this lane's two slots (16 bytes)
+        if (4 * q < Cfg::ct(l)) ro_dma1_buf(rm, mrec + q * 4096, ring + mstage + q * 1024);
+    }
   };
+
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     asm volatile("s_mov_b32 %0, 0" : "=s"(pass_zero));
 #pragma unroll
@@ -470,15 +486,16 @@ __global__ __launch_bounds__(512 / RT, 1) void mlp_ro_kernel(RoArgs a) {
       asm volatile("" : "+s"(wfl[l]));
     }
     const int64_t row0 = tile * RO_ROWS;
-    // this lane's mask element of chunk 0 (RT = 2: words; RT = 1: halves of words), MSTR from chunk to chunk
-    const unsigned mtile = (unsigned)tile * (RO_MASK_WORDS * 2 / RT) + (RT == 2 ? threadIdx.x : 2 * (64 * (wave >> 1) + lane) + (wave & 1));
+    // this lane's (first) sign-bit slot of the pass's first group: byte offset into a layer's mask
+    const unsigned mtile = ((unsigned)tile * 2048 + (RT == 2 ? 2 * threadIdx.x : 2 * (64 * (wave >> 1) + lane) + (wave & 1))) * 8;
     const unsigned row_here = (unsigned)row0 + rowl;
     unsigned off_in_next[RT];
 #pragma unroll
     for (int r = 0; r < RT; ++r) off_in_next[r] = in_off(row0 + (int64_t)gridDim.x * RO_ROWS, r);
 
     if (!BWD && a.mask_in != nullptr) {
-      // the input rows are a ReLU's output: their sign bits in the layout of a layer output of the same width
+      // the input rows are a ReLU's output: their sign bits, in the layout of a layer output of the same width
+      unsigned mi[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
       ro_for<0, (Cfg::ks(0) + 1) / 2>([&](auto ct_) __attribute__((always_inline)) {
         constexpr int ct = decltype(ct_)::value;
         unsigned mw = 0;
@@ -491,9 +508,13 @@ __global__ __launch_bounds__(512 / RT, 1) void mlp_ro_kernel(RoArgs a) {
           for (int k2 = 0; k2 < 4; ++k2) m |= ro_pk_flag(ro_pk_max0(v[k2])) << k2;
           mw |= (m & 0xfu) << ro_flag_bit(t, 0) | (m >> 16) << (ro_flag_bit(t, 0) + 8);
         }
-        if constexpr (RT == 2) a.mask_in[mtile + ct * MSTR] = mw;
-        else reinterpret_cast<uint16_t*>(a.mask_in)[mtile + ct * MSTR] = (uint16_t)mw;
+        mi[ct >> 1] |= (mw & 0xffffu) << (16 * (ct & 1));
       });
+      const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(a.mask_in, 0, (unsigned)(ntiles * RO_MASK_WORDS * 4), 0x00020000);
+      typedef __attribute__((ext_vector_type(2))) unsigned ro_u32x2;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (8 * q < Cfg::ks(0)) __builtin_amdgcn_raw_buffer_store_b64(ro_u32x2{mi[2 * q], mi[2 * q + 1]}, rm, mtile + q * 4096, 0, 0);
     }
 
     ro_for<0, NC>([&](auto c_) __attribute__((always_inline)) {
@@ -568,7 +589,7 @@ __global__ __launch_bounds__(512 / RT, 1) void mlp_ro_kernel(RoArgs a) {
 
       ro_for<0, KS>([&](auto ks_) __attribute__((always_inline)) {
         constexpr int ks = decltype(ks_)::value;
-        if constexpr (BWD && ks == 0 && !(TRS_RO_ABL & 64)) mask_load(ro_ic<l>{}, ro_ic<ct>{}, mtile, c % 3);
+        if constexpr (BWD && ks == 0 && ct == 0 && !(TRS_RO_ABL & 64)) mask_load(ro_ic<l>{}, mtile);
         words(ks_, ro_ic<1>{});
         if constexpr (ks + PF < KS) af[ks + PF] = lds_frag(rd_at, ks + PF);
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ro_bf16x8, af[ks]), __builtin_bit_cast(ro_bf16x8, B[0][ks]), acc[0], 0, 0, 0);
@@ -657,9 +678,11 @@ __global__ __launch_bounds__(512 / RT, 1) void mlp_ro_kernel(RoArgs a) {
       else mask_store(ro_ic<pc>{}, mtile_prev, mw, have_prev);
 #pragma unroll
       for (int r = 0; r < RT; ++r) accp[r] = acc[r];
-      if constexpr (BWD) {      // this chunk's word (requested a chunk ago) for its epilogue in the next chunk
-        const unsigned mv = *reinterpret_cast<const unsigned*>(smem + mstage + (c % 3) * 256 + lane * 4);      // (three stages: c's is read while c+1's lands; % 2 would do within a pass, not across passes of an odd chunk count)
-        mcur = mask_has(ro_ic<l>{}) ? __builtin_amdgcn_perm(mv, mv, 0x03010200u) : 0xffffffffu;      // middle bytes exchanged: see epi_word
+      if constexpr (BWD) {      // this chunk's flags (the two row tiles' 16 bits) for its epilogue in the next chunk
+        const unsigned m0 = *reinterpret_cast<const unsigned short*>(smem + mstage + (ct >> 2) * 1024 + lane * 16 + (ct & 3) * 2);
+        const unsigned m1 = *reinterpret_cast<const unsigned short*>(smem + mstage + (ct >> 2) * 1024 + lane * 16 + 8 + (ct & 3) * 2);
+        // bytes [r0 low flags, r1 low flags, r0 high flags, r1 high flags]: a word's two flags 16 bits apart (epi_word)
+        mcur = mask_has(ro_ic<l>{}) ? __builtin_amdgcn_perm(m1, m0, 0x05010400u) : 0xffffffffu;
       }
       rd_at = rd_next;
       dma_at = slot_inc(dma_at, ring);
@@ -715,8 +738,8 @@ struct RoPackArgs {
 template <class Cfg, bool BWD, int IN_COLS, int RT>
 inline int ro_launch(const RoArgs& a, hipStream_t s) {
   static bool attr = false;
-  const size_t lds = (size_t)RO_SLOTS * Cfg::max_ks() * 1024 + 8 * (RO_MAXCT - ro_nreg(BWD, RT)) * 2048 + (BWD ? (8 / RT) * (1024 + 768) : Cfg::NB * 4);
-  static_assert(RO_SLOTS * Cfg::max_ks() * 1024 + 8 * (RO_MAXCT - ro_nreg(BWD, RT)) * 2048 + (BWD ? (8 / RT) * (1024 + 768) : Cfg::NB * 4) <= 160 * 1024, "LDS");
+  const size_t lds = (size_t)RO_SLOTS * Cfg::max_ks() * 1024 + 8 * (RO_MAXCT - ro_nreg(BWD, RT)) * 2048 + (BWD ? (8 / RT) * (1024 + 4096) : Cfg::NB * 4);
+  static_assert(RO_SLOTS * Cfg::max_ks() * 1024 + 8 * (RO_MAXCT - ro_nreg(BWD, RT)) * 2048 + (BWD ? (8 / RT) * (1024 + 4096) : Cfg::NB * 4) <= 160 * 1024, "LDS");
   if (!attr) {
     if (hipFuncSetAttribute((const void*)mlp_ro_kernel<Cfg, BWD, IN_COLS, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
         hipSuccess)
