@@ -57,18 +57,18 @@ constexpr int RO_SLOTS = 3;                     // weight ring
 constexpr int RO_AHEAD = 2;                     // chunks between a copy's issue and its first use
 constexpr int RO_MASK_WORDS = 16 * 256;         // sign-bit words per pass and layer: [chunk][row pair], 16 KB
 #ifndef TRS_RO_PF
-#define TRS_RO_PF 2
+#define TRS_RO_PF 2      // weight fragments read ahead of the MFMAs (3: six registers more, and they are not there)
 #endif
-constexpr int RO_PF = TRS_RO_PF;                // weight fragments read ahead of the MFMAs
+constexpr int RO_PF = TRS_RO_PF;
 #ifndef TRS_RO_PFB
-#define TRS_RO_PFB 2      // the same in the backward kernels (they need the registers elsewhere)
+#define TRS_RO_PFB 2      // the same in the backward kernels
 #endif
 #ifndef TRS_RO_NREG
 #define TRS_RO_NREG 9
 #endif
 // chunks of a layer's output that wait for the next layer in registers; the ones before them wait in LDS (64 bytes per
 // chunk and row)
-__host__ __device__ constexpr int ro_nreg(bool bwd, int rt) { return TRS_RO_NREG; }
+__host__ __device__ constexpr int ro_nreg(bool, int) { return TRS_RO_NREG; }
 #ifndef TRS_RO_NT
 #define TRS_RO_NT 0      // cache policy of the output stores (2 = nt: measured 2x SLOWER, 5.2 vs 2.5 ms -- partial lines written through)
 #endif
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(512 / RT, 1) void mlp_ro_kernel(RoArgs a) {
       constexpr int c = decltype(c_)::value;
       constexpr int l = Cfg::layer_of(c), ct = Cfg::ct_of(c), KS = Cfg::ks(l), CT = Cfg::ct(l);
       constexpr int MID = KS / 2;
-      constexpr int PFD = BWD ? TRS_RO_PFB : RO_PF;      // (backward: the registers are needed elsewhere)
+      constexpr int PFD = BWD ? TRS_RO_PFB : RO_PF;
       constexpr int PF = KS < PFD ? KS : PFD;
       constexpr int cn = (c + 1) % NC, ln = Cfg::layer_of(cn), ctn = Cfg::ct_of(cn), KSn = Cfg::ks(ln);
       constexpr int PFn = KSn < PFD ? KSn : PFD;
