@@ -1814,13 +1814,16 @@ def _wgrad_rows(g: torch.Tensor, inp: torch.Tensor, out_f: int, in_f: int, dtype
     rows = g.shape[0]
     if (WGRAD_ROWS and g.is_cuda and g.dtype == torch.bfloat16 and inp.dtype == torch.bfloat16 and g.is_contiguous()
             and inp.is_contiguous()):
-        S = int(_abi.load().trs_wgrad_rows_splits(int(g.shape[1]), int(inp.shape[1]), int(rows)))
+        # only the columns that exist in the weight (rounded up to the kernel's 8): a 400-wide layer kept in 416-column
+        # tensors is 25 x 25 output tiles instead of 26 x 26, and its 16 zero columns are not fetched
+        M, N = min(g.shape[1], (out_f + 7) // 8 * 8), min(inp.shape[1], (in_f + 7) // 8 * 8)
+        S = int(_abi.load().trs_wgrad_rows_splits(M, N, int(rows)))
         if S > 0:
-            part = torch.empty(S, g.shape[1], inp.shape[1], dtype=torch.float32, device=g.device)
-            call("trs_wgrad_rows", ptr(g), g.shape[1], ptr(inp), inp.shape[1], rows, g.shape[1], inp.shape[1],
+            part = torch.empty(S, M, N, dtype=torch.float32, device=g.device)
+            call("trs_wgrad_rows", ptr(g), g.shape[1], ptr(inp), inp.shape[1], rows, M, N,
                  _abi.TRS_BF16, S, ptr(part), stream_ptr())
             gw = torch.empty(out_f, in_f, dtype=dtype, device=g.device)
-            call("trs_wgrad_finish", ptr(part), S, part.shape[1], part.shape[2], out_f, in_f, value_dtype_code(gw),
+            call("trs_wgrad_finish", ptr(part), S, M, N, out_f, in_f, value_dtype_code(gw),
                  ptr(gw), ptr(None), ptr(None), stream_ptr())
             return gw
     S = 0
