@@ -36,13 +36,16 @@ def _params(widths, g):
 
 @pytest.mark.parametrize("shape,widths", [((700, 7), [64, 400, 400, 400, 64]),      # the DCN stack, ragged last tile
                                           ((70019,), [64, 400, 400, 400, 64]),     # ... more passes than workgroups
+                                          ((257,), [64, 400, 400, 400, 64]),       # ... one row into the second pass
+                                          ((1,), [64, 400, 400, 400, 64]),
                                           ((66003,), [416, 400, 400, 8]),          # the tail of a 400-400-400 deep branch
                                           ((4096,), [16, 72, 8]),                  # widths that are not multiples of 32
                                           ((33, 130), [64, 512, 64]),              # the widest supported layer
                                           ((5000,), [32, 104, 200, 40]),
                                           ((4224,), [128, 96, 96, 96, 96, 96, 24])])
-def test_fused_mlp_vs_oracle(dev, shape, widths, ro_mode):
+def test_fused_mlp_vs_oracle(dev, shape, widths, ro_mode, monkeypatch):
     from torecsys_amd import functional as F_
+    monkeypatch.setattr(F_, "FUSED_MLP_MIN_ROWS", 1)      # (the layers take the GEMM path below 4096 rows; the kernels do not care)
     g = torch.Generator().manual_seed(sum(widths) + shape[0])
     Ws, bs = _params(widths, g)
     x = torch.randn(*shape, widths[0], generator=g).bfloat16()
