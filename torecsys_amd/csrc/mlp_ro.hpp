@@ -23,7 +23,7 @@
 //     piece goes through 1 KB of LDS, comes back transposed (ds_read_b64_tr_b16) and meets a one-hot B operand, so that
 //     one 16 x 16 accumulator tile collects 16 pieces' sums; waves add their tiles to private slices in global memory.
 //
-// Forward: 8 waves of 32 rows (two per SIMD, 240 registers); backward: 4 waves of 64 rows (464 registers; with 32 rows
+// Forward: 8 waves of 32 rows (two per SIMD, 240 registers; the two waves of a SIMD store at different k-steps); backward: 4 waves of 64 rows (464 registers; with 32 rows
 // it needs 18 registers more than a wave of 8 has).  256 rows per pass, one workgroup per CU, persistent.  Everything is
 // unrolled per stack shape (RoCfg); the shapes the models use are instantiated in mlp_ro_*.hip, one kernel per file,
 // any other stack runs on mlp_fused.hip.
@@ -62,6 +62,9 @@ constexpr int RO_MASK_WORDS = 16 * 256;         // sign-bit words per pass and l
 constexpr int RO_PF = TRS_RO_PF;
 #ifndef TRS_RO_PFB
 #define TRS_RO_PFB 2      // the same in the backward kernels
+#endif
+#ifndef TRS_RO_STAGGER
+#define TRS_RO_STAGGER 2      // groups of waves that store at different k-steps (forward; 1: 2.35 ms, 2: 2.24, 4: 2.26)
 #endif
 #ifndef TRS_RO_NREG
 #define TRS_RO_NREG 9
@@ -608,15 +611,34 @@ __global__ __launch_bounds__(512 / RT, 1) void mlp_ro_kernel(RoArgs a) {
           constexpr int NP = (Cfg::ks(Cfg::layer_of((c + RO_AHEAD) % NC)) + NW - 1) / NW;
           constexpr int per = (NP + (KS - MID + 1) - 1) / (KS - MID + 1);
 #pragma unroll
-          for (int i = per * (ks - (MID - 1)); i < per * (ks - (MID - 1) + 1) && i < NP; ++i) dma_piece(ro_ic<c + RO_AHEAD>{}, i);
+          for (int i = per * (ks - (MID - 1)); i < per * (ks - (MID - 1) + 1) && i < NP; ++i) dma_piece(ro_ic<c + RO_AHEAD>{}, i);      // (staggering these between the waves: no change)
         }
         if constexpr (ks >= MID) {
+#if TRS_RO_STAGGER > 1
+          // the waves do not store at the same k-step: group gq (of TRS_RO_STAGGER; the two waves of a SIMD are in different
+          // groups) a share of the half chunk later, so that they are not parked on the memory path together
+          // (one wave per SIMD, the backward: 2 or 4 groups measured no different from none)
+          constexpr int NG = (RT == 1 && KS - MID >= 8) ? TRS_RO_STAGGER : 1;
+          const int gq = NG == 1 ? 0 : (NG == 2 ? wave >> 2 : 2 * (wave >> 2) + (wave & 1));
+          ro_for<0, NQ>([&](auto t_) __attribute__((always_inline)) {
+            ro_for<0, NG>([&](auto g_) __attribute__((always_inline)) {
+              constexpr int gg = decltype(g_)::value;
+              if constexpr (store_step(decltype(t_)::value) + (gg * (KS - MID - 2)) / NG == ks) {
+                if (gq == gg) {
+                  if constexpr (c > 0) epi_store(ro_ic<pc>{}, t_, off_out[pl], mw, true);
+                  else epi_store(ro_ic<pc>{}, t_, off_last_prev, mw, have_prev);
+                }
+              }
+            });
+          });
+#else
           ro_for<0, NQ>([&](auto t_) __attribute__((always_inline)) {
             if constexpr (store_step(decltype(t_)::value) == ks) {
               if constexpr (c > 0) epi_store(ro_ic<pc>{}, t_, off_out[pl], mw, true);
               else epi_store(ro_ic<pc>{}, t_, off_last_prev, mw, have_prev);
             }
           });
+#endif
           // backward: column sums of this step's input, a few 16-column units per chunk while the registers are not yet
           // full of the next step's input; units in ascending order (the last two arrive with chunk 0's first half)
           if constexpr (BWD && !(TRS_RO_ABL & 32)) {
