@@ -55,7 +55,7 @@ constexpr int RO_MAXKS = 26;                    // widths up to 416
 constexpr int RO_MAXCT = RO_MAXKS / 2;
 constexpr int RO_SLOTS = 3;                     // weight ring
 constexpr int RO_AHEAD = 2;                     // chunks between a copy's issue and its first use
-constexpr int RO_MASK_WORDS = 16 * 256;         // sign-bit words per pass and layer: [chunk][row pair], 16 KB
+constexpr int RO_MASK_WORDS = 16 * 256;         // 32-bit words of sign bits per pass and layer (16 KB; layout below)
 #ifndef TRS_RO_PF
 #define TRS_RO_PF 2      // weight fragments read ahead of the MFMAs (3: six registers more, and they are not there)
 #endif
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(512 / RT, 1) void mlp_ro_kernel(RoArgs a) {
   // At the end of a step a wave adds its tiles to ITS slice of the partial sums in global memory (fixed order: the
   // bias gradients are reproducible bit for bit).
   unsigned mcur = 0xffffffffu;
-  const unsigned mstage = RING + NW * STASH_WAVE + NW * 1024 + wave * 4096;      // this wave's stage for a layer's sign-bit records
+  const unsigned mstage = RING + NW * STASH_WAVE + NW * 1024 + wave * 4096;      // this wave's stage for a layer's sign bits
   ro_f32x4 cs = {0.f, 0.f, 0.f, 0.f};       // sums of the running step's input ...
   ro_f32x4 cso = {0.f, 0.f, 0.f, 0.f};      // ... and, in the last step, of its output: both are under way at once
   unsigned scr_wr = RING + NW * STASH_WAVE + wave * 1024 + (2 * (lane & 31) + g) * 16;
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(512 / RT, 1) void mlp_ro_kernel(RoArgs a) {
       }
     }
   };
-  static_assert(BWD ? RT == 2 : RT == 1, "sign-bit records: written by 32-row waves, read by 64-row waves");
+  static_assert(BWD ? RT == 2 : RT == 1, "sign bits: written by 32-row waves (one slot per lane), read by 64-row waves (two)");
   // forward: chunk pct's 16 flags of this lane join the record under construction; 4 chunks (or the layer's last ones)
   // leave as one 8-byte store.  ``mrec``: this lane's slot of the pass's first group (byte offset into the layer's mask)
   unsigned mreg[2];
