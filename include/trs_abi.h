@@ -318,21 +318,30 @@ int trs_relu_bwd_bias(const void* gy, const void* y, int64_t rows, int32_t C, in
  *      pre-activation, gx * [x > 0], and gbias_in its column sums = that layer's bias gradient (needs num_layers <= 7).
  * trs_mlp_fused_supported: 1 when the widths fit the kernel (and its LDS budget).                              */
 int trs_mlp_fused_supported(int32_t num_layers, const int32_t* widths);
-/* The two stack shapes of the models (64-400-400-400-64 on B*N rows; 416-400-400-8 behind a wide first layer) have a
- * second pair of kernels (csrc/mlp_ro.hpp: a wave owns 64 / 32 rows for the whole stack) behind the same two entry
- * points.  mode 0: never; 1 (default; TRS_MLP_RO in the environment): from 131 072 rows on; 2: at any size.  Returns
- * the previous mode; any other argument only queries.  fwd and bwd_data of one stack must run under the same mode
- * (the sign-bit layouts differ). */
-int32_t trs_mlp_ro_mode(int32_t mode);
+/* Kernel families.  The two stack shapes of the models (64-400-400-400-64 on B*N rows; 416-400-400-8 behind a wide first
+ * layer) have a second pair of kernels (csrc/mlp_ro.hpp: a wave owns 64 / 32 rows for the whole stack) behind the same
+ * two entry points, and the two families lay the sign bits out differently.  Which family runs is a PER-CALL argument --
+ * the library keeps no mode:
+ *   trs_mlp_fused_fwd(family = AUTO | TILE | ROW_OWNER); AUTO = ROW_OWNER for the covered shapes from 131 072 rows on
+ *   (the start-up environment may set TRS_MLP_RO=0: never / 2: at any size -- read once when the library is loaded);
+ *   trs_mlp_fused_family(num_layers, widths, rows, request) -> the family (TILE or ROW_OWNER) that request runs, 0 when it
+ *   cannot be met (ROW_OWNER on an uncovered shape; the forward then returns TRS_EINVAL).  A pure function.
+ *   trs_mlp_fused_bwd_data(family) must be given THAT value (TILE or ROW_OWNER; AUTO is TRS_EINVAL): the caller records
+ *   what its forward ran, so a policy or size threshold cannot come between a forward and its backward.              */
+#define TRS_MLP_FAMILY_AUTO 0
+#define TRS_MLP_FAMILY_TILE 1
+#define TRS_MLP_FAMILY_ROW_OWNER 2
+int32_t trs_mlp_fused_family(int32_t num_layers, const int32_t* widths, int64_t rows, int32_t request);
 size_t trs_mlp_fused_workspace_bytes(int32_t num_layers, const int32_t* widths);
 size_t trs_mlp_fused_mask_bytes(int64_t rows);
 int trs_mlp_fused_fwd(const void* x, int64_t rows, int32_t num_layers, const int32_t* widths,
                       const void* const* weights, const void* const* biases, void* const* hidden, void* const* masks,
-                      void* mask_in, void* y, int32_t dtype, void* workspace, size_t ws_bytes, trs_stream_t stream);
+                      void* mask_in, void* y, int32_t dtype, int32_t family, void* workspace, size_t ws_bytes,
+                      trs_stream_t stream);
 int trs_mlp_fused_bwd_data(const void* gy, int64_t rows, int32_t num_layers, const int32_t* widths,
                            const void* const* weights, const void* const* masks, void* const* gz, float* const* gbias,
-                           void* gx, const void* mask_in, float* gbias_in, int32_t dtype, void* workspace,
-                           size_t ws_bytes, trs_stream_t stream);
+                           void* gx, const void* mask_in, float* gbias_in, int32_t dtype, int32_t family,
+                           void* workspace, size_t ws_bytes, trs_stream_t stream);
 
 /* ---- one wide layer with a short contraction: the input gradient of a deep branch's first Linear ----------------
  * y (rows, in_f) = x[:, :out_f] @ W, x (rows, x_stride) and W (out_f, in_f) = nn.Linear(in_f, out_f).weight, bf16:

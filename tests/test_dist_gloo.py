@@ -321,6 +321,17 @@ def _pipeline_worker(rank, world, port, fuse, capacity, ret):
         from oracle import cpu_ref as O
         ref1 = O.multi_indices_embedding(W, batches[1][rank], O.field_offsets(fs))
         assert torch.equal(out1.rename(None), ref1), "the early lookup reads the rows of before the update"
+        # an ORDINARY in-place update of the shard (torch.optim's step) between the hint and the forward: the early rows
+        # are dropped and the forward looks up again (round-4 advisor finding: it silently used the old rows)
+        m2 = RowShardedMultiIndicesEmbedding(embed_size=E, field_sizes=fs, fuse_fm=fuse, ops=CpuOps(), capacity=capacity)
+        m2.load_full_weight(W)
+        m2.prefetch_lookup(batches[2][rank])
+        with torch.no_grad():
+            m2.embedding.weight.mul_(2.0)
+        D.lookup_stats.update(prefetched=0, inline=0, stale_dropped=0)
+        out2 = m2(batches[2][rank])
+        assert D.lookup_stats["stale_dropped"] == 1 and D.lookup_stats["inline"] == 1, D.lookup_stats
+        assert torch.equal(out2.rename(None), O.multi_indices_embedding(2.0 * W, batches[2][rank], O.field_offsets(fs)))
         ret[rank] = "ok"
     except Exception:  # noqa: BLE001
         import traceback

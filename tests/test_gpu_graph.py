@@ -98,3 +98,44 @@ def test_timestamp_marks_agree_with_events(dev):
     a, b = sorted(ev)[2], sorted(mk)[2]
     assert 0.4 * a <= b <= 2.0 * a + 0.02, (ev, mk)
     assert out[0].shape == (B, N, E)
+
+
+def test_graphed_dcn_mlp_stack_row_owner_replays_match_eager(dev):
+    """The per-field MLP of DeepAndCrossNetwork at >= 131 072 rows (the row-owner kernels: their backward accumulates the
+    bias gradients' column-sum partials with atomics on a buffer zeroed IN the captured work -- by a kernel, never a
+    memset node): 5 replays of one captured forward + backward give the eager step's bias gradients bit for bit."""
+    from torecsys_amd import functional as F_
+    from torecsys_amd.graph import GraphedStep
+    from torecsys_amd.layers import DNNLayer
+    torch.manual_seed(9)
+    B, N, E = 3400, 39, 64                     # 132 600 rows: AUTO picks the row-owner family
+    lay = DNNLayer(inputs_size=E, output_size=E, layer_sizes=[400, 400, 400]).to(dev).bfloat16()
+    assert F_.mlp_fused_family([E, 400, 400, 400, E], B * N) == F_.MLP_FAMILY_ROW_OWNER
+    params = list(lay.parameters())
+    g = torch.Generator().manual_seed(1)
+    xs = [torch.randn(B, N, E, generator=g).bfloat16().to(dev) for _ in range(2)]
+    gy = torch.randn(B, N, E, generator=g).bfloat16().to(dev)
+
+    def fn(x):
+        y = lay(x).rename(None)
+        y.backward(gy)
+        return y
+
+    eager = []
+    for x in xs:
+        for p in params:
+            p.grad = None
+        y = fn(x)
+        eager.append([y.detach().clone()] + [p.grad.clone() for p in params])
+    del y
+    step = GraphedStep(fn, (xs[0],), params=params, warmup=1)
+    for rep in range(5):
+        x, want = xs[rep % 2], eager[rep % 2]
+        y = step(x)
+        torch.cuda.synchronize()
+        assert torch.equal(y.detach(), want[0]), rep
+        for (name, p), w in zip(lay.named_parameters(), want[1:]):
+            if name.endswith("bias"):
+                assert torch.equal(p.grad, w), (rep, name)
+            else:
+                assert rel_err(p.grad.float().cpu(), w.float().cpu()) <= 1e-2, (rep, name)

@@ -18,14 +18,15 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(params=[0, 2], ids=["tile-in-LDS kernels", "row-owner kernels"])
+@pytest.fixture(params=[1, 2], ids=["tile-in-LDS kernels", "row-owner kernels"])
 def ro_mode(request):
-    """trs_mlp_ro_mode: the two stack shapes of the models have a second pair of kernels (csrc/mlp_ro.hpp), chosen from
-    131 072 rows on; 2 forces them at any size, 0 switches them off -- every test that takes this fixture runs on both."""
-    from torecsys_amd import _abi
-    prev = _abi.load().trs_mlp_ro_mode(request.param)
-    yield request.param
-    _abi.load().trs_mlp_ro_mode(prev)
+    """The two stack shapes of the models have a second pair of kernels (csrc/mlp_ro.hpp), chosen by AUTO from 131 072
+    rows on.  Which family runs is a per-call request (functional.mlp_family; trs_mlp_fused_family in the ABI): every test
+    that takes this fixture issues its forwards under TILE and under ROW_OWNER (stacks the row-owner kernels do not cover
+    fall back to the tile kernels)."""
+    from torecsys_amd import functional as F_
+    with F_.mlp_family(request.param):
+        yield request.param
 
 
 def _params(widths, g):
@@ -69,7 +70,9 @@ def test_fused_mlp_vs_oracle(dev, shape, widths, ro_mode, monkeypatch):
     # bits the forward kernel hands to the backward kernel are in the kernel's own order (opaque); they are the signs
     # of the hidden activations it stores, which is what the oracle is masked with here -- wrong bits would show up as
     # whole missing / extra terms in the gradients below
-    _, hidden, masks = F_.fused_mlp_forward_raw(rows(x).to(dev), [w.to(dev) for w in Ws], [b.to(dev) for b in bs])
+    _, hidden, masks, fam = F_.fused_mlp_forward_raw(rows(x).to(dev), [w.to(dev) for w in Ws], [b.to(dev) for b in bs])
+    covered = widths in ([64, 400, 400, 400, 64], [416, 400, 400, 8])
+    assert fam == (ro_mode if covered else F_.MLP_FAMILY_TILE)
     assert all(m.numel() == F_.size_query("trs_mlp_fused_mask_bytes", rows(x).shape[0]) for m in masks)
     unpacked = []
     for l in range(len(masks)):
@@ -257,15 +260,73 @@ def test_fused_backward_masks_its_input_gradient_with_the_upstream_relu(dev, row
     x = torch.relu(torch.randn(rows, widths[0], generator=gen)).bfloat16().to(dev)
     Ws = [(torch.randn(widths[l + 1], widths[l], generator=gen) / widths[l] ** 0.5).bfloat16().to(dev) for l in range(3)]
     bs = [(0.1 * torch.randn(widths[l + 1], generator=gen)).bfloat16().to(dev) for l in range(3)]
-    y, hidden, masks, mask_in = F_.fused_mlp_forward_raw(x, Ws, bs, input_mask=True)
-    y0, _, _ = F_.fused_mlp_forward_raw(x, Ws, bs)
-    assert torch.equal(y, y0)
+    y, hidden, masks, mask_in, fam = F_.fused_mlp_forward_raw(x, Ws, bs, input_mask=True)
+    y0, _, _, fam0 = F_.fused_mlp_forward_raw(x, Ws, bs)
+    assert torch.equal(y, y0) and fam == fam0 == ro_mode
     gy = torch.randn(rows, widths[-1], generator=gen).bfloat16().to(dev)
-    gx0, gz0, gb0, none = F_.fused_mlp_backward_raw(gy, widths, Ws, masks)
-    gx1, gz1, gb1, gb_in = F_.fused_mlp_backward_raw(gy, widths, Ws, masks, mask_in)
+    gx0, gz0, gb0, none = F_.fused_mlp_backward_raw(gy, widths, Ws, masks, family=fam)
+    gx1, gz1, gb1, gb_in = F_.fused_mlp_backward_raw(gy, widths, Ws, masks, mask_in, family=fam)
     assert none is None
     assert all(torch.equal(a, b) for a, b in zip(gz0, gz1)) and all(torch.equal(a, b) for a, b in zip(gb0, gb1))
     want = torch.where(x > 0, gx0, torch.zeros_like(gx0))
     assert torch.equal(gx1, want)
     ref = want.double().sum(0)
     assert float((gb_in[:widths[0]].double() - ref).abs().max() / ref.abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("fwd_req,bwd_req", [(2, 1), (1, 2), (2, 0), (0, 2)])
+def test_backward_runs_the_family_its_forward_ran_whatever_is_requested_later(dev, fwd_req, bwd_req, monkeypatch):
+    """The kernel family is per call and the autograd node records it: a request (or a size policy) that changes between
+    a stack's forward and its backward must not change which backward kernels read the forward's sign bits.  Forward under
+    one request, backward under another: gradients equal the ones of a run that never switched, bit for bit.  (Round 4
+    had a process-global mode here; flipping it between the two calls gave wrong gradients with return code 0.)"""
+    from torecsys_amd import functional as F_
+    monkeypatch.setattr(F_, "FUSED_MLP_MIN_ROWS", 1)
+    g = torch.Generator().manual_seed(77)
+    widths = [64, 400, 400, 400, 64]
+    Ws, bs = _params(widths, g)
+    x = torch.randn(3000, 64, generator=g).bfloat16().to(dev)
+    gy = torch.randn(3000, 64, generator=g).bfloat16().to(dev)
+
+    def run(req_f, req_b):
+        xd = x.clone().requires_grad_()
+        Wd = [w.to(dev).requires_grad_() for w in Ws]
+        bd = [b.to(dev).requires_grad_() for b in bs]
+        with F_.mlp_family(req_f):
+            y = F_.fused_mlp(xd, Wd, bd)
+        with F_.mlp_family(req_b):
+            y.backward(gy)
+        return [y.detach(), xd.grad] + [w.grad for w in Wd] + [b.grad for b in bd]
+
+    same = run(fwd_req, fwd_req)
+    switched = run(fwd_req, bwd_req)
+    assert all(torch.equal(a, b) for a, b in zip(same, switched))
+
+
+def test_backward_refuses_a_family_the_forward_did_not_report(dev):
+    """C ABI: trs_mlp_fused_bwd_data takes the family as an argument -- AUTO (a policy, not a record) and values outside
+    {TILE, ROW_OWNER} are TRS_EINVAL, and so is ROW_OWNER for a stack those kernels do not cover; the Python wrapper
+    raises before the call."""
+    from torecsys_amd import functional as F_
+    g = torch.Generator().manual_seed(3)
+    widths = [32, 104, 200, 40]              # not a row-owner shape
+    Ws, bs = _params(widths, g)
+    Ws, bs = [w.to(dev) for w in Ws], [b.to(dev) for b in bs]
+    x = torch.randn(512, 32, generator=g).bfloat16().to(dev)
+    y, hidden, masks, fam = F_.fused_mlp_forward_raw(x, Ws, bs, family=F_.MLP_FAMILY_ROW_OWNER)   # falls back: uncovered
+    assert fam == F_.MLP_FAMILY_TILE
+    assert int(F_._abi.load().trs_mlp_fused_family(3, F_._i32_array(widths), 512, F_.MLP_FAMILY_ROW_OWNER)) == 0
+    gy = torch.randn(512, 40, generator=g).bfloat16().to(dev)
+    with pytest.raises(ValueError):
+        F_.fused_mlp_backward_raw(gy, widths, Ws, masks, family=F_.MLP_FAMILY_AUTO)
+    gz = [torch.empty(512, F_._pad32(w), dtype=torch.bfloat16, device=dev) for w in widths[1:-1]]
+    gb = [torch.empty(F_._pad32(w), dtype=torch.float32, device=dev) for w in widths[1:]]
+    gx = torch.empty(512, 32, dtype=torch.bfloat16, device=dev)
+    wl = F_._i32_array(widths)
+    ws_bytes = F_.size_query("trs_mlp_fused_workspace_bytes", 3, wl)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    for bad in (F_.MLP_FAMILY_AUTO, F_.MLP_FAMILY_ROW_OWNER, 7):
+        with pytest.raises(RuntimeError, match="family"):
+            F_.call("trs_mlp_fused_bwd_data", F_.ptr(gy), 512, 3, wl, F_._ptr_array(Ws), F_._ptr_array(masks),
+                    F_._ptr_array(gz), F_._ptr_array(gb), F_.ptr(gx), F_.ptr(None), F_.ptr(None), F_._abi.TRS_BF16, bad,
+                    F_.ptr(ws), ws_bytes, F_.stream_ptr())

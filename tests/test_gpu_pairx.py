@@ -327,3 +327,28 @@ def test_bilinear_submodules_stand_alone_forward(dev, dtype, tol, B, N, E):
         for got, ref, n in ((a.grad, ar.grad, "g1"), (b.grad, br.grad, "g2"), (lay.weight.grad, Wr.grad, "gW"),
                             (lay.bias.grad, br_.grad, "gb")):
             assert rel_err(got.float().cpu(), ref) <= tol, (kind, n)
+
+
+def test_field_each_type_bilinear_rectangular(dev):
+    """in1_features != in2_features (bilinear_interaction.py:143-148: input1 (..., P, in1), input2 (..., P, in2), weight
+    (P, in1, in2)) -- round 4 rejected it with a shape check the reference does not have."""
+    from torecsys_amd.layers import FieldEachTypeBilinear
+    g = torch.Generator().manual_seed(12)
+    B, P, E1, E2 = 17, 6, 24, 40
+    torch.manual_seed(4)
+    lay = FieldEachTypeBilinear(P, E1, E2).to(dev)
+    a = torch.randn(B, P, E1, generator=g).to(dev).requires_grad_()
+    b = torch.randn(B, P, E2, generator=g).to(dev).requires_grad_()
+    y = lay(a, b)
+    assert y.shape == (B, P, E2)
+    ar, br = a.detach().cpu().clone().requires_grad_(), b.detach().cpu().clone().requires_grad_()
+    Wr, cr = lay.weight.detach().cpu().requires_grad_(), lay.bias.detach().cpu().requires_grad_()
+    yr = torch.einsum("bpe,peh->bph", ar, Wr) * br + cr
+    assert rel_err(y.detach().cpu(), yr.detach()) <= 1e-5
+    go = torch.randn(yr.shape, generator=g)
+    (y * go.to(dev)).sum().backward()
+    (yr * go).sum().backward()
+    for got, ref in ((a.grad, ar.grad), (b.grad, br.grad), (lay.weight.grad, Wr.grad), (lay.bias.grad, cr.grad)):
+        assert rel_err(got.cpu(), ref) <= 1e-5
+    with pytest.raises(ValueError):
+        lay(a, b[:, :5])

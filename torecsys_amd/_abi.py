@@ -112,11 +112,11 @@ SIGNATURES = {
     "trs_relu_bwd_bias_workspace_bytes": (_SZ, [_I64, _I32]),
     "trs_relu_bwd_bias": (c_int32, [_P, _P, _I64, _I32, _I32, _P, _P, _P, _SZ, _P]),
     "trs_mlp_fused_supported": (c_int32, [_I32, _P]),
-    "trs_mlp_ro_mode": (c_int32, [_I32]),
+    "trs_mlp_fused_family": (c_int32, [_I32, _P, _I64, _I32]),
     "trs_mlp_fused_workspace_bytes": (_SZ, [_I32, _P]),
     "trs_mlp_fused_mask_bytes": (_SZ, [_I64]),
-    "trs_mlp_fused_fwd": (c_int32, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _SZ, _P]),
-    "trs_mlp_fused_bwd_data": (c_int32, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _SZ, _P]),
+    "trs_mlp_fused_fwd": (c_int32, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _SZ, _P]),
+    "trs_mlp_fused_bwd_data": (c_int32, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _SZ, _P]),
     "trs_bucket_workspace_bytes": (_SZ, [_I64, _I32]),
     "trs_bucket_by_owner": (c_int32, [_P, _I32, _P, _I64, _I32, _I64, _I32, _P, _P, _P, _P, _P, _SZ, _P]),
     "trs_permute_grad": (c_int32, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _P]),

@@ -1,6 +1,8 @@
 // K1: embedding row gather (bit-exact copy), field-aware gather (I3), permute helpers.
 // HBM-bound: every lane moves one 16-byte vector of a table row; a 128-byte bf16 row (E=64) is
 // fetched by 8 adjacent lanes = one full cache line per row, one wave instruction = 8 rows.
+#include <algorithm>
+
 #include "trs_common.hpp"
 
 namespace trs {
@@ -18,6 +20,27 @@ int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(TRS_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
   return TRS_OK;
+}
+
+// Zero-fill by a KERNEL (never hipMemsetAsync): captured into a hipGraph a memset becomes a memset NODE, and on this
+// runtime such nodes did not reliably re-zero their target in replays (scatter.hip, shard.hip found it the hard way).
+// Every fill the library enqueues goes through here.  ``bytes`` is a multiple of 2; 16-byte stores where p allows.
+__global__ __launch_bounds__(256) void zero_bytes_kernel(char* __restrict__ p, size_t head, size_t nvec, size_t tail) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint4* v = reinterpret_cast<uint4*>(p + head);
+  for (size_t i = t0; i < nvec; i += stride) v[i] = make_uint4(0, 0, 0, 0);
+  for (size_t i = t0; i < head; i += stride) p[i] = 0;
+  for (size_t i = t0; i < tail; i += stride) p[head + nvec * 16 + i] = 0;
+}
+int zero_bytes(void* p, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return TRS_OK;
+  const size_t mis = (size_t)(reinterpret_cast<uintptr_t>(p) & 15u);
+  const size_t head = std::min(bytes, mis ? 16 - mis : (size_t)0);
+  const size_t nvec = (bytes - head) / 16, tail = bytes - head - nvec * 16;
+  hipLaunchKernelGGL(zero_bytes_kernel, dim3(stream_grid((int64_t)std::max<size_t>(nvec, 16), 256, 2048)), dim3(256), 0, s,
+                     (char*)p, head, nvec, tail);
+  return check_launch("zero_bytes");
 }
 
 // rows = B*N flat positions; vpr = 16-byte vectors per row (E*sizeof(T)/16).

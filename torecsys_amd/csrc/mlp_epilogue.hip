@@ -399,8 +399,7 @@ extern "C" int trs_relu_bwd_bias(const void* gy, const void* y, int64_t rows, in
   TRS_REQUIRE(row_bytes % 16 == 0 && row_bytes / 16 <= RB_THREADS, TRS_ESHAPE,
               "relu_bwd_bias: row bytes %d must be a multiple of 16 and at most %d", row_bytes, RB_THREADS * 16);
   if (rows == 0) {
-    if (hipMemsetAsync(gb, 0, (size_t)C * 4, s) != hipSuccess) return check_launch("relu_bwd_bias(memset)");
-    return TRS_OK;
+    return zero_bytes(gb, (size_t)C * 4, s);
   }
   TRS_REQUIRE(gy && y && gz, TRS_EINVAL, "relu_bwd_bias: NULL pointer");
   TRS_REQUIRE(aligned16(gy) && aligned16(y) && aligned16(gz), TRS_EALIGN, "relu_bwd_bias: 16-byte alignment");

@@ -759,8 +759,7 @@ static bool mlp_fused_covers(int L, const int32_t* w) {
 }
 
 // mlp_ro.hip: the row-owner kernels for the stack shapes they are instantiated for
-bool mlp_ro_covers(int L, const int32_t* widths, int64_t rows);
-int mlp_ro_set_mode(int mode);
+int mlp_resolve_family(int L, const int32_t* widths, int64_t rows, int request);
 size_t mlp_ro_mask_bytes(int64_t rows);
 int mlp_ro_fwd(const void* x, int64_t rows, int L, const int32_t* widths, const void* const* weights,
                const void* const* biases, void* const* hidden, void* const* masks, void* mask_in, void* y, void* workspace,
@@ -799,7 +798,10 @@ extern "C" size_t trs_mlp_fused_workspace_bytes(int32_t num_layers, const int32_
   return mlp_frag_bytes(num_layers, widths) + (size_t)MF_GRID * 8 * sum * 4 + 4096;      // (8: per-wave slices of the row-owner kernels)
 }
 
-extern "C" int32_t trs_mlp_ro_mode(int32_t mode) { return mlp_ro_set_mode(mode); }
+extern "C" int32_t trs_mlp_fused_family(int32_t num_layers, const int32_t* widths, int64_t rows, int32_t request) {
+  if (!mlp_fused_covers(num_layers, widths)) return 0;
+  return mlp_resolve_family(num_layers, widths, rows, request);
+}
 
 extern "C" size_t trs_mlp_fused_mask_bytes(int64_t rows) {      // either kernel family's layout
   return std::max((size_t)((rows + MF_ROWS - 1) / MF_ROWS) * MF_MASK_TILE, mlp_ro_mask_bytes(rows));
@@ -814,17 +816,19 @@ extern "C" int trs_mlp_fused_supported(int32_t num_layers, const int32_t* widths
 
 extern "C" int trs_mlp_fused_fwd(const void* x, int64_t rows, int32_t num_layers, const int32_t* widths,
                                  const void* const* weights, const void* const* biases, void* const* hidden,
-                                 void* const* masks, void* mask_in, void* y, int32_t dtype, void* workspace,
-                                 size_t ws_bytes, trs_stream_t stream) {
+                                 void* const* masks, void* mask_in, void* y, int32_t dtype, int32_t family,
+                                 void* workspace, size_t ws_bytes, trs_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   TRS_REQUIRE(dtype == TRS_BF16, TRS_EDTYPE, "mlp_fused_fwd: bf16 only");
   TRS_REQUIRE(trs_mlp_fused_supported(num_layers, widths), TRS_ESHAPE, "mlp_fused_fwd: unsupported layer widths");
   TRS_REQUIRE(x && y && weights && biases && hidden && masks && workspace, TRS_EINVAL, "mlp_fused_fwd: NULL pointer");
   TRS_REQUIRE(ws_bytes >= trs_mlp_fused_workspace_bytes(num_layers, widths), TRS_EWORKSPACE,
               "mlp_fused_fwd: workspace too small");
-  if (rows == 0) return TRS_OK;
   const int L = num_layers;
-  if (mlp_ro_covers(L, widths, rows))
+  const int fam = mlp_resolve_family(L, widths, rows, family);
+  TRS_REQUIRE(fam != 0, TRS_EINVAL, "mlp_fused_fwd: kernel family %d is not available for this stack (trs_mlp_fused_family)", family);
+  if (rows == 0) return TRS_OK;
+  if (fam == TRS_MLP_FAMILY_ROW_OWNER)
     return mlp_ro_fwd(x, rows, L, widths, weights, biases, hidden, masks, mask_in, y, workspace, s);
   MlpArgs a;
   a.nsteps = L;
@@ -881,7 +885,7 @@ extern "C" int trs_mlp_fused_fwd(const void* x, int64_t rows, int32_t num_layers
 extern "C" int trs_mlp_fused_bwd_data(const void* gy, int64_t rows, int32_t num_layers, const int32_t* widths,
                                       const void* const* weights, const void* const* masks, void* const* gz,
                                       float* const* gbias, void* gx, const void* mask_in, float* gbias_in, int32_t dtype,
-                                      void* workspace, size_t ws_bytes, trs_stream_t stream) {
+                                      int32_t family, void* workspace, size_t ws_bytes, trs_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   TRS_REQUIRE(dtype == TRS_BF16, TRS_EDTYPE, "mlp_fused_bwd_data: bf16 only");
   TRS_REQUIRE(trs_mlp_fused_supported(num_layers, widths), TRS_ESHAPE, "mlp_fused_bwd_data: unsupported layer widths");
@@ -889,15 +893,21 @@ extern "C" int trs_mlp_fused_bwd_data(const void* gy, int64_t rows, int32_t num_
   TRS_REQUIRE(ws_bytes >= trs_mlp_fused_workspace_bytes(num_layers, widths), TRS_EWORKSPACE,
               "mlp_fused_bwd_data: workspace too small");
   const int L = num_layers;
+  // the family is what the forward of these masks ran (trs_mlp_fused_family): AUTO is refused here because the policy
+  // behind it is not the caller's record of what happened
+  TRS_REQUIRE((family == TRS_MLP_FAMILY_TILE || family == TRS_MLP_FAMILY_ROW_OWNER) &&
+                  mlp_resolve_family(L, widths, rows, family) == family,
+              TRS_EINVAL, "mlp_fused_bwd_data: family must be the TILE / ROW_OWNER value the forward ran under (got %d)", family);
+  TRS_REQUIRE(family != TRS_MLP_FAMILY_ROW_OWNER || gx != nullptr, TRS_EINVAL, "mlp_fused_bwd_data: the row-owner kernels need gx");
   TRS_REQUIRE((mask_in == nullptr) == (gbias_in == nullptr) && (mask_in == nullptr || (L + 1 <= MF_MAXL && gx != nullptr)),
               TRS_EINVAL, "mlp_fused_bwd_data: mask_in and gbias_in come together (and with gx, at most %d layers)", MF_MAXL - 1);
   if (rows == 0) {
     for (int l = 0; l < L; ++l)
-      if (hipMemsetAsync(gbias[l], 0, (size_t)pad32(widths[l + 1]) * 4, s) != hipSuccess) return check_launch("mlp_fused_bwd_data");
-    if (gbias_in && hipMemsetAsync(gbias_in, 0, (size_t)pad32(widths[0]) * 4, s) != hipSuccess) return check_launch("mlp_fused_bwd_data");
+      if (int rc = zero_bytes(gbias[l], (size_t)pad32(widths[l + 1]) * 4, s)) return rc;
+    if (gbias_in) return zero_bytes(gbias_in, (size_t)pad32(widths[0]) * 4, s);
     return TRS_OK;
   }
-  if (mlp_ro_covers(L, widths, rows)) {
+  if (family == TRS_MLP_FAMILY_ROW_OWNER) {
     RoColsum rc;
     const int rcode = mlp_ro_bwd(gy, rows, L, widths, weights, masks, gz, gbias, gx, mask_in, gbias_in, workspace, s, &rc);
     if (rcode != TRS_OK) return rcode;

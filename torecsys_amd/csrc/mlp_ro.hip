@@ -49,25 +49,35 @@ static bool ro_matches(int L, const int32_t* w, bool reversed) {
 }
 static inline int ro_ks(int w) { return w <= 16 ? 2 : (w + 15) / 16; }
 
-// 0: every stack on the kernels of mlp_fused.hip; 1: the row-owner kernels for the shapes they are built for, from
-// RO_MIN_ROWS rows on (below that a workgroup sees one or two passes and the pipeline between passes -- next input,
-// previous epilogue -- has nothing to run against: DeepFM's tail at B = 65 536, one pass per CU, forward 74 vs 101 us but
-// backward 125 vs 92 us); 2: for those shapes at any size (tests).  Start value from TRS_MLP_RO, changed by trs_mlp_ro_mode.
-static int RO_MODE = [] {
+// Which kernel family runs a stack is a PER-CALL argument of the two entry points (trs_mlp_fused_family resolves a
+// request; the backward is told the family its forward ran -- the sign-bit layouts differ).  There is no mutable state:
+// the only process-wide input is the policy of TRS_MLP_FAMILY_AUTO, read once from the environment when the library is
+// loaded -- TRS_MLP_RO = 0: never the row-owner kernels; 1 (default): for the shapes they are built for from RO_MIN_ROWS
+// rows on (below that a workgroup sees one or two passes and the pipeline between passes -- next input, previous
+// epilogue -- has nothing to run against: DeepFM's tail at B = 65 536, one pass per CU, forward 74 vs 101 us but
+// backward 125 vs 92 us); 2: for those shapes at any size.
+static const int RO_AUTO_POLICY = [] {
   const char* e = getenv("TRS_MLP_RO");
   return e != nullptr && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1;
 }();
 constexpr int64_t RO_MIN_ROWS = 131072;
 
-int mlp_ro_set_mode(int mode) {
-  const int prev = RO_MODE;
-  if (mode >= 0 && mode <= 2) RO_MODE = mode;
-  return prev;
+bool mlp_ro_shape_ok(int L, const int32_t* widths, int64_t rows) {
+  if (rows * 1024 >= ((int64_t)1 << 32)) return false;
+  return ro_matches<RoDcn>(L, widths, false) || ro_matches<RoTail>(L, widths, false);
 }
 
-bool mlp_ro_covers(int L, const int32_t* widths, int64_t rows) {
-  if (RO_MODE == 0 || (RO_MODE == 1 && rows < RO_MIN_ROWS) || rows * 1024 >= ((int64_t)1 << 32)) return false;
-  return ro_matches<RoDcn>(L, widths, false) || ro_matches<RoTail>(L, widths, false);
+// request (TRS_MLP_FAMILY_*) -> the family that runs (TILE / ROW_OWNER), 0 when the request cannot be met
+int mlp_resolve_family(int L, const int32_t* widths, int64_t rows, int request) {
+  const bool ok = mlp_ro_shape_ok(L, widths, rows);
+  switch (request) {
+    case TRS_MLP_FAMILY_TILE: return TRS_MLP_FAMILY_TILE;
+    case TRS_MLP_FAMILY_ROW_OWNER: return ok ? TRS_MLP_FAMILY_ROW_OWNER : 0;
+    case TRS_MLP_FAMILY_AUTO:
+      if (ok && (RO_AUTO_POLICY == 2 || (RO_AUTO_POLICY == 1 && rows >= RO_MIN_ROWS))) return TRS_MLP_FAMILY_ROW_OWNER;
+      return TRS_MLP_FAMILY_TILE;
+    default: return 0;
+  }
 }
 
 size_t mlp_ro_mask_bytes(int64_t rows) { return (size_t)((rows + RO_ROWS - 1) / RO_ROWS) * RO_MASK_WORDS * 4; }
@@ -164,7 +174,7 @@ int mlp_ro_bwd(const void* gy, int64_t rows, int L, const int32_t* widths, const
     }
     woff += (size_t)(N / 32) * KS * 1024;
   }
-  if (hipMemsetAsync(part_base, 0, poff * 4, s) != hipSuccess) return check_launch("mlp_ro_bwd: memset");
+  if (int rc = zero_bytes(part_base, poff * 4, s)) return rc;
   hipLaunchKernelGGL(mlp_ro_prepack_kernel, dim3(pk_blocks, L), dim3(256), 0, s, pk);
   return ro_matches<RoDcn>(L, widths, false) ? ro_launch_dcn_bwd(a, s) : ro_launch_tail_bwd(a, s);
 }

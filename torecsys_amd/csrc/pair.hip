@@ -791,9 +791,7 @@ extern "C" int trs_pair_dot_bwd(const void* x, const void* g, int64_t B, int32_t
   TRS_REQUIRE(x && dx && (g || N < 2), TRS_EINVAL, "pair_dot_bwd: NULL pointer");
   TRS_CHECK_BNE("pair_dot_bwd");
   if (N < 2) {
-    if (hipMemsetAsync(dx, 0, (size_t)B * N * E * dtype_size(dtype), (hipStream_t)stream) != hipSuccess)
-      return check_launch("pair_dot_bwd(memset)");
-    return TRS_OK;
+    return zero_bytes(dx, (size_t)B * N * E * dtype_size(dtype), (hipStream_t)stream);
   }
   if (dtype == TRS_F32) return pair_dot_bwd_launch<float>(x, g, dx, B, N, E, (hipStream_t)stream);
   if (pair_mfma_ok(N, E) && aligned16(x)) return pair_dot_bwd_mfma(x, g, dx, B, N, E, (hipStream_t)stream);

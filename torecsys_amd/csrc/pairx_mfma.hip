@@ -591,8 +591,7 @@ extern "C" int trs_pair_bilinear_bwd_w_mfma(const void* g, const void* x, int32_
   hipStream_t s = (hipStream_t)stream;
   const int64_t n = (int64_t)P * E * E;
   if (B == 0) {
-    if (hipMemsetAsync(gW, 0, (size_t)n * 2, s) != hipSuccess) return check_launch("pair_bilinear_bwd_w_mfma(memset)");
-    return TRS_OK;
+    return zero_bytes(gW, (size_t)n * 2, s);
   }
   const size_t lds = (size_t)4 * 2 * E * 80;
   float* part = (float*)workspace;

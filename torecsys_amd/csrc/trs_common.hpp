@@ -13,6 +13,8 @@ namespace trs {
 char* err_buf();
 int fail(int code, const char* fmt, ...);
 int check_launch(const char* what);
+// zero-fill by a kernel (gather.hip): hipMemsetAsync is not used anywhere in the library (memset nodes in hipGraph replays)
+int zero_bytes(void* p, size_t bytes, hipStream_t s);
 
 #define TRS_REQUIRE(cond, code, ...) \
   do {                               \

@@ -302,7 +302,19 @@ class RoutePlan:
     per-peer split sizes (host ints) and the local row ids every peer asked this rank for.  Tables looked up
     with the same index tensor (the E=64 embeddings and the E=1 first-order weights of one model) share it,
     so the bucketing, the count exchange (one host sync) and the id all-to-all happen once per batch."""
-    __slots__ = ("send_pos", "inv_pos", "send_splits", "recv_splits", "recv_ids", "cap")
+    __slots__ = ("send_pos", "inv_pos", "send_splits", "recv_splits", "recv_ids", "cap", "event", "stream")
+
+    def use_on(self, cur) -> None:
+        """A plan built on the communication stream (prefetch_lookup) sits in the shared route cache: a later hit from
+        another stream -- a second table looked up with the same indices, or an inline forward after the prefetched rows
+        were evicted -- must wait for the producing stream and tell the allocator about its use of the plan's tensors."""
+        ev = getattr(self, "event", None)
+        if ev is None or cur is None or cur == self.stream:
+            return
+        cur.wait_event(ev)
+        for t in (self.send_pos, self.inv_pos, self.recv_ids):
+            if t is not None and t.is_cuda:
+                t.record_stream(cur)
 
 
 _route_cache: List[tuple] = []      # [(key, idx kept alive, RoutePlan)]
@@ -384,6 +396,7 @@ def _route_plan(idx: torch.Tensor, mod) -> "RoutePlan":
     for k, _, p in _route_cache:
         if k == key:
             route_stats["cached"] += 1
+            p.use_on(torch.cuda.current_stream(idx.device) if idx.is_cuda else None)
             return p
     pr = None
     for i, (k, _, cand) in enumerate(_pending_routes):
@@ -398,6 +411,7 @@ def _route_plan(idx: torch.Tensor, mod) -> "RoutePlan":
             pr = _start_route(idx, mod)
     p = RoutePlan()
     p.send_pos, p.inv_pos, p.cap = pr.send_pos, pr.inv_pos, 0
+    p.event, p.stream = None, (torch.cuda.current_stream(idx.device) if idx.is_cuda else None)
     if pr.host_counts is None and mod.world > 1:
         # fixed-capacity slots: equal splits, nothing to read on the host
         p.cap = mod.slot_capacity(idx.numel())
@@ -460,12 +474,12 @@ def _fetch_rows(weight: torch.Tensor, idx: torch.Tensor, mod):
 class _PrefetchedLookup:
     """rows of a batch fetched ahead of its forward (prefetch_lookup): the plan, the received rows, the event on the
     communication stream after which they are complete"""
-    __slots__ = ("plan", "back", "event")
+    __slots__ = ("plan", "back", "event", "version", "stale_ok")
 
 
 _lookup_cache: List[tuple] = []      # [(key, idx kept alive, weight id, _PrefetchedLookup)]
 MAX_PREFETCHED_LOOKUPS = 4
-lookup_stats = {"prefetched": 0, "inline": 0}
+lookup_stats = {"prefetched": 0, "inline": 0, "stale_dropped": 0}
 F_._clear_hooks.append(_lookup_cache.clear)
 
 
@@ -494,6 +508,12 @@ def prefetch_lookup(idx: torch.Tensor, mod, stale_ok: bool = False) -> None:
         if cs is not None:
             pl.event = torch.cuda.Event()
             pl.event.record(cs)
+            if pl.plan.stream == cs and pl.plan.event is None:
+                pl.plan.event = pl.event      # the plan was built here: other streams that hit it in the route cache wait
+    # what the rows were read from: an in-place update of the shard between this prefetch and the forward (optimizer.step()
+    # bumps the version; the fused owner-side optimizer writes through .data and is covered by ``stale_ok`` above) makes the
+    # forward drop these rows and look up again, unless staleness was accepted
+    pl.version, pl.stale_ok = weight._version, bool(stale_ok)
     _lookup_cache.append((key, idx, id(weight), pl))
     if len(_lookup_cache) > MAX_PREFETCHED_LOOKUPS:
         _lookup_cache.pop(0)
@@ -504,6 +524,9 @@ def _take_prefetched(idx: torch.Tensor, weight: torch.Tensor, mod):
     for i, (k, _, w, pl) in enumerate(_lookup_cache):
         if k == key and w == id(weight):
             _lookup_cache.pop(i)
+            if pl.version != weight._version and not pl.stale_ok:
+                lookup_stats["stale_dropped"] += 1
+                return None
             return pl
     return None
 
@@ -527,6 +550,7 @@ class _ShardedLookup(Function):
                         t.record_stream(cur)
         else:
             lookup_stats["inline"] += 1
+            mod.order_after_grad()      # an owner-side update / reduction still running on the communication stream
             plan, back = _fetch_rows(weight, idx, mod)
         padded = plan.cap > 0
         with _phase("un-permute (+FM)", idx.device):
@@ -682,25 +706,43 @@ class RowShardedMultiIndicesEmbedding(BaseInput):
     def prefetch_lookup(self, next_inputs: torch.Tensor, stale_ok: bool = False) -> None:
         """Hint: ``next_inputs`` is the index batch of the NEXT forward.  Its route, id exchange, owner-side gather and
         row exchange start now on the communication stream (``dist.prefetch_lookup``) and overlap the current batch's
-        dense compute.  Without a fused optimizer the result is bit-identical to the lookup at forward time."""
+        dense compute.  Bit-identical to the lookup at forward time as long as the shard is not updated in between: an
+        ``optimizer.step()`` on the shard between this call and the forward makes the forward drop the early rows and look
+        up again (``lookup_stats['stale_dropped']``) -- hint AFTER the step, or pass ``stale_ok=True`` to keep rows that
+        are one update behind."""
         prefetch_lookup(next_inputs, self, stale_ok)
 
     def wait_grad(self) -> None:
         """With ``overlap_grad_exchange``: make the current stream wait for the last backward's gradient exchange and
         owner-side reduction (``embedding.weight.grad`` / the fused update).  Call before reading ``.grad`` (an optimizer
-        step, clipping, a checkpoint); the next forward's lookup is ordered behind it by the communication stream itself."""
+        step, clipping, a checkpoint).  Lookups order themselves: a prefetched one runs on the communication stream behind
+        the update, an inline one (forward without a matching prefetch) waits for the same event -- ``order_after_grad``."""
         ev, self._grad_event = self._grad_event, None
         if ev is not None:
             torch.cuda.current_stream(self.embedding.weight.device).wait_event(ev)
 
+    def order_after_grad(self) -> None:
+        """Every reader / writer of the shard on the CURRENT stream (an inline lookup, load_full_weight, full_weight,
+        state_dict) comes behind the last overlapped gradient exchange: with a fused optimizer on the owner that exchange
+        ends in an in-place update of the shard on the communication stream.  Does not consume the event (wait_grad does)."""
+        ev = self._grad_event
+        if ev is not None:
+            torch.cuda.current_stream(self.embedding.weight.device).wait_event(ev)
+
+    def state_dict(self, *args, **kwargs):
+        self.order_after_grad()
+        return super().state_dict(*args, **kwargs)
+
     @torch.no_grad()
     def load_full_weight(self, full: torch.Tensor):
         lo, hi = self.row_range
+        self.order_after_grad()
         self.embedding.weight[: hi - lo].copy_(full[lo:hi])
 
     @torch.no_grad()
     def full_weight(self) -> torch.Tensor:
         lo, hi = self.row_range
+        self.order_after_grad()
         parts = [torch.empty(self.rows_per_rank, self.embed_size, dtype=self.embedding.weight.dtype,
                              device=self.embedding.weight.device) for _ in range(self.world)]
         mine = torch.zeros_like(parts[0])

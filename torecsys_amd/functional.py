@@ -1654,15 +1654,53 @@ def mlp_fused_supported(x: torch.Tensor, widths: Sequence[int]) -> bool:
     return mlp_fused_supported_for(x.numel() // max(1, x.shape[-1]), x.dtype, x.is_cuda, widths)
 
 
+MLP_FAMILY_AUTO, MLP_FAMILY_TILE, MLP_FAMILY_ROW_OWNER = 0, 1, 2
+_mlp_family_request = MLP_FAMILY_AUTO
+
+
+class mlp_family:
+    """``with mlp_family(MLP_FAMILY_TILE | MLP_FAMILY_ROW_OWNER | MLP_FAMILY_AUTO):`` -- the kernel family the fused-MLP
+    FORWARDS issued inside the block ask for (a request the library resolves per call, trs_mlp_fused_family; a family
+    that does not cover a stack falls back to AUTO for it).  Backwards never look at this: every autograd node records the
+    family its forward ran and hands that to trs_mlp_fused_bwd_data."""
+
+    def __init__(self, request: int):
+        self.request = int(request)
+
+    def __enter__(self):
+        global _mlp_family_request
+        self.prev, _mlp_family_request = _mlp_family_request, self.request
+        return self
+
+    def __exit__(self, *exc):
+        global _mlp_family_request
+        _mlp_family_request = self.prev
+        return False
+
+
+def mlp_fused_family(widths: Sequence[int], rows: int, request: Optional[int] = None) -> int:
+    """The kernel family (MLP_FAMILY_TILE / MLP_FAMILY_ROW_OWNER) a forward of this stack runs"""
+    req = _mlp_family_request if request is None else int(request)
+    wl = _i32_array(widths)
+    fam = int(_abi.load().trs_mlp_fused_family(len(widths) - 1, wl, int(rows), req))
+    if fam == 0 and req != MLP_FAMILY_AUTO:
+        fam = int(_abi.load().trs_mlp_fused_family(len(widths) - 1, wl, int(rows), MLP_FAMILY_AUTO))
+    if fam == 0:
+        raise RuntimeError(f"torecsys_amd: no fused-MLP kernel family for widths {list(widths)}")
+    return fam
+
+
 def fused_mlp_forward_raw(x2: torch.Tensor, Ws: Sequence[torch.Tensor], bs: Sequence[torch.Tensor],
-                          input_mask: bool = False):
+                          input_mask: bool = False, family: Optional[int] = None):
     """trs_mlp_fused_fwd on rows x2 (rows, widths[0]): returns (y (rows, widths[L]), hidden [(rows, pad32(w))] -- the
     ReLU outputs of the hidden layers, zero in the padding columns --, masks [the sign bits of the hidden layers in the
-    kernel's own order: opaque bytes for trs_mlp_fused_bwd_data]) and, with ``input_mask`` (x2 is itself a ReLU output),
-    the sign bits of x2 in the same form as a fourth value."""
+    kernel's own order: opaque bytes for trs_mlp_fused_bwd_data], [with ``input_mask`` (x2 is itself a ReLU output): the
+    sign bits of x2 in the same form,] family -- the kernel family that ran, which the backward of THESE masks must be
+    given (the two families lay the sign bits out differently)."""
     L = len(Ws)
     widths = [Ws[0].shape[1]] + [w.shape[0] for w in Ws]
     rows, dev = x2.shape[0], x2.device
+    fam = mlp_fused_family(widths, rows, family)
     hidden = [torch.empty(rows, _pad32(widths[l + 1]), dtype=torch.bfloat16, device=dev) for l in range(L - 1)]
     mask_bytes = size_query("trs_mlp_fused_mask_bytes", rows)
     masks = [torch.empty(mask_bytes, dtype=torch.uint8, device=dev) for _ in range(L - 1)]
@@ -1672,16 +1710,19 @@ def fused_mlp_forward_raw(x2: torch.Tensor, Ws: Sequence[torch.Tensor], bs: Sequ
     ws_bytes = size_query("trs_mlp_fused_workspace_bytes", L, wl)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     call("trs_mlp_fused_fwd", ptr(x2), rows, L, wl, _ptr_array(Ws), _ptr_array(bs), _ptr_array(hidden),
-         _ptr_array(masks), ptr(mask_in), ptr(y), _abi.TRS_BF16, ptr(ws), ws_bytes, stream_ptr())
+         _ptr_array(masks), ptr(mask_in), ptr(y), _abi.TRS_BF16, fam, ptr(ws), ws_bytes, stream_ptr())
     if input_mask:
-        return y, hidden, masks, mask_in
-    return y, hidden, masks
+        return y, hidden, masks, mask_in, fam
+    return y, hidden, masks, fam
 
 
 def fused_mlp_backward_raw(gy2: torch.Tensor, widths: Sequence[int], Ws: Sequence[torch.Tensor],
-                           masks: Sequence[torch.Tensor], mask_in: Optional[torch.Tensor] = None):
+                           masks: Sequence[torch.Tensor], mask_in: Optional[torch.Tensor] = None, *, family: int):
     """trs_mlp_fused_bwd_data: (gx, gz [d(pre-activation) of the hidden layers], gb [fp32 bias gradients, padded]) and,
-    with ``mask_in``, gb_in: gx is then masked by the upstream ReLU and gb_in holds its column sums."""
+    with ``mask_in``, gb_in: gx is then masked by the upstream ReLU and gb_in holds its column sums.  ``family``: what
+    fused_mlp_forward_raw returned with these masks."""
+    if family not in (MLP_FAMILY_TILE, MLP_FAMILY_ROW_OWNER):
+        raise ValueError("fused_mlp_backward_raw: family must be the value the forward returned with these masks")
     L = len(Ws)
     rows, dev = gy2.shape[0], gy2.device
     gz = [torch.empty(rows, _pad32(widths[l + 1]), dtype=torch.bfloat16, device=dev) for l in range(L - 1)]
@@ -1692,7 +1733,7 @@ def fused_mlp_backward_raw(gy2: torch.Tensor, widths: Sequence[int], Ws: Sequenc
     ws_bytes = size_query("trs_mlp_fused_workspace_bytes", L, wl)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     call("trs_mlp_fused_bwd_data", ptr(gy2), rows, L, wl, _ptr_array(Ws), _ptr_array(masks), _ptr_array(gz),
-         _ptr_array(gb), ptr(gx), ptr(mask_in), ptr(gb_in), _abi.TRS_BF16, ptr(ws), ws_bytes, stream_ptr())
+         _ptr_array(gb), ptr(gx), ptr(mask_in), ptr(gb_in), _abi.TRS_BF16, int(family), ptr(ws), ws_bytes, stream_ptr())
     return gx, gz, gb, gb_in
 
 
@@ -1709,21 +1750,21 @@ class _FusedMLP(Function):
         bs = [params[2 * l + 1].contiguous() for l in range(L)]
         widths = [Ws[0].shape[1]] + [w.shape[0] for w in Ws]
         x2 = x.reshape(-1, widths[0]).contiguous()
-        y, hidden, masks = fused_mlp_forward_raw(x2, Ws, bs)
+        y, hidden, masks, fam = fused_mlp_forward_raw(x2, Ws, bs)
         ctx.save_for_backward(x2, *Ws, *hidden, *masks)
-        ctx.meta = (L, widths, tuple(x.shape), [p.dtype for p in params])
+        ctx.meta = (L, widths, tuple(x.shape), [p.dtype for p in params], fam)
         return y.reshape(*x.shape[:-1], widths[L])
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        L, widths, xshape, pdt = ctx.meta
+        L, widths, xshape, pdt, fam = ctx.meta
         saved = ctx.saved_tensors
         x2, Ws = saved[0], saved[1:1 + L]
         hidden, masks = saved[1 + L:L + L], saved[L + L:]
         rows, dev = x2.shape[0], x2.device
         gy2 = gy.reshape(rows, widths[L]).contiguous()
-        gx, gz, gb, _ = fused_mlp_backward_raw(gy2, widths, Ws, masks)
+        gx, gz, gb, _ = fused_mlp_backward_raw(gy2, widths, Ws, masks, family=fam)
         grads = []
         for l in range(L):
             inp = x2 if l == 0 else hidden[l - 1]               # (rows, widths[l] | pad32)
@@ -1773,17 +1814,17 @@ class _FusedMLPTail(Function):
         L = len(tensors) // 4
         Ws = [(tensors[4 * l] if tensors[4 * l + 2] is None else tensors[4 * l + 2]).contiguous() for l in range(L)]
         bs = [(tensors[4 * l + 1] if tensors[4 * l + 3] is None else tensors[4 * l + 3]).contiguous() for l in range(L)]
-        y, hidden, masks = fused_mlp_forward_raw(x2, Ws, bs)
+        y, hidden, masks, fam = fused_mlp_forward_raw(x2, Ws, bs)
         out_f = tensors[4 * (L - 1)].shape[0]
         ctx.save_for_backward(x2, *Ws, *hidden, *masks)
         ctx.meta = (L, [x2.shape[1]] + [w.shape[0] for w in Ws], [tuple(tensors[4 * l].shape) for l in range(L)],
-                    [tensors[4 * l].dtype for l in range(L)])
+                    [tensors[4 * l].dtype for l in range(L)], fam)
         return y[:, :out_f].contiguous() if out_f != y.shape[1] else y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        L, widths, wshapes, wdt = ctx.meta
+        L, widths, wshapes, wdt, fam = ctx.meta
         saved = ctx.saved_tensors
         x2, Ws = saved[0], saved[1:1 + L]
         hidden, masks = saved[1 + L:L + L], saved[L + L:]
@@ -1793,7 +1834,7 @@ class _FusedMLPTail(Function):
             gy2[:, :gy.shape[1]] = gy
         else:
             gy2 = gy.contiguous()
-        gx, gz, gb, _ = fused_mlp_backward_raw(gy2, widths, Ws, masks)
+        gx, gz, gb, _ = fused_mlp_backward_raw(gy2, widths, Ws, masks, family=fam)
         grads = []
         for l in range(L):
             inp = x2 if l == 0 else hidden[l - 1]

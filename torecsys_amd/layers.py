@@ -263,12 +263,14 @@ class FieldEachTypeBilinear(BaseLayer):
         ((P,B,E) @ (P,E,E)), then the product + per-pair bias pass on HIP."""
         x1, x2 = _strip(input1), _strip(input2)
         F_.require_device(x1, x2, self.weight)
-        if x1.dim() < 2 or x1.shape != x2.shape:
-            raise ValueError(f'FieldEachTypeBilinear operands must both be (*, P, E), got {tuple(x1.shape)} and '
-                             f'{tuple(x2.shape)}')
-        P, E = x1.shape[-2], x1.shape[-1]
+        if x1.dim() < 2 or x1.shape[:-1] != x2.shape[:-1]:
+            raise ValueError(f'FieldEachTypeBilinear operands must be (*, P, in1) and (*, P, in2), got '
+                             f'{tuple(x1.shape)} and {tuple(x2.shape)}')
+        P = x1.shape[-2]
         lead = x1.shape[:-2]
-        a3, c3 = x1.reshape(-1, P, E), x2.reshape(-1, P, E)           # leading dimensions folded into the batch axis
+        # leading dimensions folded into the batch axis; in1 != in2 is allowed as in the reference (:143-148): the
+        # product pass compares T (.., P, in2) with x2
+        a3, c3 = x1.reshape(-1, P, x1.shape[-1]), x2.reshape(-1, P, x2.shape[-1])
         T = torch.bmm(a3.transpose(0, 1), self.weight.to(x1.dtype)).transpose(0, 1)
         return F_.rows_mul_bias(T, c3, self.bias, True).reshape(*lead, P, self.in2_features)
 
@@ -758,18 +760,18 @@ class _HybridMLP(torch.autograd.Function):
         L = len(tail) // 4
         Ws = [(tail[4 * l] if tail[4 * l + 2] is None else tail[4 * l + 2]).contiguous() for l in range(L)]
         bs = [(tail[4 * l + 1] if tail[4 * l + 3] is None else tail[4 * l + 3]).contiguous() for l in range(L)]
-        y, hidden, masks, mask_in = F_.fused_mlp_forward_raw(h1, Ws, bs, input_mask=True)
+        y, hidden, masks, mask_in, fam = F_.fused_mlp_forward_raw(h1, Ws, bs, input_mask=True)
         out_f = tail[4 * (L - 1)].shape[0]
         ctx.save_for_backward(cur, W1, h1, mask_in, *Ws, *hidden, *masks)
         ctx.meta = (L, [h1.shape[1]] + [w.shape[0] for w in Ws], [tuple(tail[4 * l].shape) for l in range(L)],
-                    [tail[4 * l].dtype for l in range(L)], tuple(w1.shape), w1.dtype, tuple(x.shape))
+                    [tail[4 * l].dtype for l in range(L)], tuple(w1.shape), w1.dtype, tuple(x.shape), fam)
         y = y[:, :out_f].contiguous() if out_f != y.shape[1] else y
         return y.reshape(*x.shape[:-1], out_f)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, gy):
-        L, widths, wshapes, wdt, w1shape, w1dt, xshape = ctx.meta
+        L, widths, wshapes, wdt, w1shape, w1dt, xshape, fam = ctx.meta
         saved = ctx.saved_tensors
         cur, W1, h1, mask_in = saved[:4]
         Ws = saved[4:4 + L]
@@ -782,7 +784,7 @@ class _HybridMLP(torch.autograd.Function):
             gy2[:, :gy.shape[1]] = gy
         else:
             gy2 = gy.contiguous()
-        g1, gz, gb, gb1 = F_.fused_mlp_backward_raw(gy2, widths, Ws, masks, mask_in)
+        g1, gz, gb, gb1 = F_.fused_mlp_backward_raw(gy2, widths, Ws, masks, mask_in, family=fam)
         grads = []
         for l in range(L):
             inp = h1 if l == 0 else hidden[l - 1]
