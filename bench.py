@@ -109,6 +109,9 @@ def parse():
                          "(the default for the deepfm / fm workloads on one GPU: the eager step spends 1.3-1.45 ms of "
                          "host time per 1.56 ms step, so its rate depends on the host the driver happens to get)")
     ap.add_argument("--eager", action="store_true", help="never capture: launch every step from Python")
+    ap.add_argument("--aten-head", action="store_true",
+                    help="A/B: the models' scalar head and BCEWithLogitsLoss as ATen ops (~35 launches) instead of "
+                         "functional.ctr_logit / fused.BCEWithLogitsLoss (csrc/head.hip)")
     return ap.parse_args()
 
 
@@ -254,6 +257,19 @@ def model_kernel_roofline(model, kernel, mtimes, B, N, E, esz):
     return out
 
 
+def _criterion(a):
+    """BCEWithLogitsLoss (SURVEY 8d's loss): the HIP one by default (bf16 logits read as they are, 3 launches fwd+bwd),
+    ATen's with --aten-head"""
+    if a.aten_head:
+        return nn.BCEWithLogitsLoss()
+    from torecsys_amd.fused import BCEWithLogitsLoss
+    return BCEWithLogitsLoss()
+
+
+def _loss(crit, out, lab):
+    return crit(out.float(), lab) if isinstance(crit, nn.BCEWithLogitsLoss) else crit(out, lab)
+
+
 def other_model_leg(name, a, dev, dt, inputs, idx_ring, label_ring, esz):
     """BASELINE configs[2] / [3] in the default run: a few eager fwd+bwd steps of DCN / xDeepFM on the same inputs,
     same batch ring and same definition of a step as the headline leg (dense table gradients, no optimizer), timed by a
@@ -269,7 +285,7 @@ def other_model_leg(name, a, dev, dt, inputs, idx_ring, label_ring, esz):
         model = M.XDeepFactorizationMachineModel(embed_size=E, num_fields=N, cin_layer_sizes=[128, 128, 128],
                                                  deep_layer_sizes=[400, 400, 400])
     model = model.to(dev).to(dt)
-    crit = nn.BCEWithLogitsLoss()
+    crit = _criterion(a)
     params = [p for p in list(inputs.parameters()) + list(model.parameters()) if p.requires_grad]
     ring = len(idx_ring)
 
@@ -278,7 +294,7 @@ def other_model_leg(name, a, dev, dt, inputs, idx_ring, label_ring, esz):
             p.grad = None
         d = inputs({"c0": idx_ring[k % ring]})
         out = model(**d) if name != "dcn" else model(emb_inputs=d["emb_inputs"])
-        loss = crit(out.float(), label_ring[k % ring])
+        loss = _loss(crit, out, label_ring[k % ring])
         loss.backward()
         return loss
 
@@ -366,6 +382,8 @@ def main():
     from torecsys_amd import _abi
     from harness import ctr_models as M
     from torecsys_amd.inputs import Inputs, MultiIndicesEmbedding
+    if a.aten_head:
+        M.FUSED_HEAD = False
 
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     esz = 2 if dt == torch.bfloat16 else 4
@@ -415,7 +433,7 @@ def main():
         for p in model.parameters():
             dist.broadcast(p.data, 0)
     counter = [0]
-    crit = nn.BCEWithLogitsLoss()
+    crit = _criterion(a)
     params = [p for p in list(inputs.parameters()) + list(model.parameters()) if p.requires_grad]
     dense_opt = None
     if a.optimizer != "none":
@@ -437,7 +455,7 @@ def main():
     def fwd_loss(ix, lab, scale):
         d = inputs({"c0": ix})
         out = model(**d) if a.model != "dcn" else model(emb_inputs=d["emb_inputs"])
-        loss = crit(out.float(), lab)
+        loss = _loss(crit, out, lab)
         return loss if scale == 1.0 else loss * scale
 
     host_idx = a.host_indices and not sharded and MB == 1

@@ -15,11 +15,13 @@ Outputs are (B, 1) un-named tensors, pinned to the reference by ``tests/golden/m
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
 import torch.nn as nn
 
+from torecsys_amd import functional as F_
 from torecsys_amd.layers import CINLayer, CrossNetworkLayer, DNNLayer, FMLayer
 
 
@@ -31,6 +33,15 @@ def _first_order(feat: torch.Tensor) -> torch.Tensor:
     """(B, N, 1) first-order weights of the looked-up rows -> (B, 1)"""
     f = _plain(feat)
     return f.reshape(f.shape[0], -1).sum(dim=1, keepdim=True)
+
+
+FUSED_HEAD = os.environ.get("TRS_FUSED_HEAD", "1") not in ("", "0")
+
+
+def _fused_head(t: torch.Tensor) -> bool:
+    """the models' scalar head (row sums + adds) as one kernel, F_.ctr_logit -- what ``torecsys_amd.patch(pkg, heads=True)``
+    puts under the reference's own model classes"""
+    return FUSED_HEAD and t.is_cuda and t.dtype in (torch.float32, torch.bfloat16)
 
 
 def _rows(emb: torch.Tensor) -> torch.Tensor:
@@ -48,7 +59,10 @@ class FactorizationMachineModel(nn.Module):
             self.bias = nn.Parameter(torch.empty(1, 1).uniform_())
 
     def forward(self, feat_inputs: torch.Tensor, emb_inputs: torch.Tensor) -> torch.Tensor:
-        logit = _plain(self.fm(emb_inputs)).sum(dim=1, keepdim=True) + _first_order(feat_inputs)
+        fm = self.fm(emb_inputs)
+        if _fused_head(fm):
+            return F_.ctr_logit(fm, feat_inputs, bias=self.bias)
+        logit = _plain(fm).sum(dim=1, keepdim=True) + _first_order(feat_inputs)
         return logit if self.bias is None else logit + self.bias
 
 
@@ -62,8 +76,12 @@ class DeepFactorizationMachineModel(nn.Module):
                              dropout_p=deep_dropout_p, activation=deep_activation)
 
     def forward(self, feat_inputs: torch.Tensor, emb_inputs: torch.Tensor) -> torch.Tensor:
-        shallow = _plain(self.fm(emb_inputs)).sum(dim=1, keepdim=True) + _first_order(feat_inputs)
-        return _plain(self.deep(_rows(emb_inputs))) + shallow
+        fm = self.fm(emb_inputs)
+        deep = self.deep(_rows(emb_inputs))
+        if _fused_head(fm):
+            return F_.ctr_logit(fm, feat_inputs, [deep])
+        shallow = _plain(fm).sum(dim=1, keepdim=True) + _first_order(feat_inputs)
+        return _plain(deep) + shallow
 
 
 class DeepAndCrossNetworkModel(nn.Module):
@@ -99,5 +117,8 @@ class XDeepFactorizationMachineModel(nn.Module):
         self.bias = nn.Parameter(torch.empty(1).uniform_())
 
     def forward(self, feat_inputs: torch.Tensor, emb_inputs: torch.Tensor) -> torch.Tensor:
+        cin, deep = self.cin(emb_inputs), self.deep(_rows(emb_inputs))
+        if _fused_head(cin):
+            return F_.ctr_logit(None, feat_inputs, [cin, deep], bias=self.bias)
         wide = _first_order(feat_inputs) + self.bias
-        return _plain(self.cin(emb_inputs)) + _plain(self.deep(_rows(emb_inputs))) + wide
+        return _plain(cin) + _plain(deep) + wide

@@ -343,6 +343,11 @@ int trs_mlp_fused_bwd_data(const void* gy, int64_t rows, int32_t num_layers, con
                            void* gx, const void* mask_in, float* gbias_in, int32_t dtype, int32_t family,
                            void* workspace, size_t ws_bytes, trs_stream_t stream);
 
+/* dst (rows, c_out) = [src (rows, c_in) | zeros], bf16: the gradient of the first c_in columns of a padded output (the
+ * logit column of a deep branch whose last layer runs at 8 columns) in one launch.                                   */
+int trs_pad_cols(const void* src, int32_t c_in, void* dst, int32_t c_out, int64_t rows, int32_t dtype,
+                 trs_stream_t stream);
+
 /* ---- one wide layer with a short contraction: the input gradient of a deep branch's first Linear ----------------
  * y (rows, in_f) = x[:, :out_f] @ W, x (rows, x_stride) and W (out_f, in_f) = nn.Linear(in_f, out_f).weight, bf16:
  * dL/d(input) of that layer from dL/d(pre-activation) (multilayer_perceptron.py:53-61 under autograd).  out_f <= 512
@@ -565,6 +570,28 @@ int trs_afm_bwd_dropout(const void* g_out, const void* g_attn, const void* x, co
  * src_dtype / out_dtype: TRS_I64 | TRS_I32 (narrowing to int32 is the caller's responsibility).   */
 int trs_pack_columns(const void* const* srcs, const int32_t* widths, int32_t nsrc, int32_t src_dtype,
                      int64_t B, void* out, int32_t out_dtype, trs_stream_t stream);
+
+/* ---- the scalar head of the CTR models and its loss (callers M1 / M2 / M4 of section 8a) ----------
+ * logit[b] = sum_e fm[b,e] + sum_n feat[b,n] + sum_k extras[k][b * extra_strides[k]] + bias[0]          -> out (B,1)
+ *   models/ctr/factorization_machine.py:55-66 (fm_second.sum('O') + feat_inputs.sum('N') + bias),
+ *   models/ctr/deep_fm.py:75-104 (cat([fm_second, fm_first]).sum('O') + deep_out),
+ *   models/ctr/xdeep_fm.py:117-121 (feat.sum('N') + cin_out + deep_out + bias).
+ * fm (B,E) / feat (B,N) contiguous, either may be NULL (E / N = 0); extras: HOST array of n_extras <= 4 device pointers to
+ * one value per sample with element stride extra_strides[k] (a (B,1) column, or column 0 of a wider padded output);
+ * bias: one device value or NULL.  fp32 accumulation, one rounding on store.  The gradient of every operand is the
+ * incoming (B,1) column itself (broadcast): there is no backward entry point.                                        */
+int trs_ctr_logit_fwd(const void* fm, int32_t E, const void* feat, int32_t N, const void* const* extras,
+                      const int64_t* extra_strides, int32_t n_extras, const void* bias, int64_t B, int32_t dtype,
+                      void* out, trs_stream_t stream);
+/* BCEWithLogitsLoss, reduction = mean (the loss the fwd+bwd metric is defined on):
+ *   loss = mean_b( max(x,0) - x*y + log1p(exp(-|x|)) )   -> *loss (fp32, device);  logits (B) f32|bf16, labels (B) f32|bf16
+ *   bwd: glogits[b] = (sigmoid(x) - y) * gout[0] / B     (gout: fp32 device scalar, NULL = 1)
+ * Two launches forward (per-workgroup partial sums in a fixed order: reproducible), one backward.                    */
+size_t trs_bce_logits_workspace_bytes(int64_t B);
+int trs_bce_logits_fwd(const void* logits, int32_t dtype, const void* labels, int32_t label_dtype, int64_t B, float* loss,
+                       void* workspace, size_t ws_bytes, trs_stream_t stream);
+int trs_bce_logits_bwd(const void* logits, int32_t dtype, const void* labels, int32_t label_dtype, const float* gout,
+                       int64_t B, void* glogits, trs_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -271,6 +271,13 @@ def xdeepfm_model(feat: torch.Tensor, emb: torch.Tensor, cin_kwargs: dict,
     return feat.sum(dim=1) + cin_out + deep_out + bias
 
 
+def bce_with_logits(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """The loss SURVEY.md 8d defines the fwd+bwd metric on: ``nn.BCEWithLogitsLoss()`` (mean reduction) = ATen's
+    binary_cross_entropy_with_logits, on fp32 logits.  The reference's trainer takes the criterion from the user
+    (trainer/torecsys_pipeline.py:440-470); this is the one the benchmark fixes."""
+    return F.binary_cross_entropy_with_logits(logits.float(), labels.float())
+
+
 # --------------------------------------------------------------------------
 # Row-sharded lookup (the build's multi-GPU design, SURVEY §8e) -- single-process
 # statement of what the all-to-all path must reproduce.

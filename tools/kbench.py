@@ -224,6 +224,32 @@ def main():
                       f"{fl/t[0]/1e12:6.1f} TFLOP/s  {by/t[0]/1e9:7.1f} GB/s (operands once)", flush=True)
             F_.WGRAD_ROWS = True
             del gg, xx2
+    if "ffm" in what:         # (not part of "all": 5 GB of tables + 12.8 GB + 6.2 GB tensors at the BASELINE shape)
+        # the fused field-aware lookup + FFM reads B*N*8 + B*N*N*E*s (12.8 GB at S) and writes B*NC2*E*s (6.2 GB)
+        P = N * (N - 1) // 2
+        tabs = [(torch.rand(V, E, generator=g) - 0.5).to(dt).to(dev) for _ in range(N)]
+        rd_fa = B * N * 8 + B * N * N * E * s
+        with torch.no_grad():
+            t = timeit(lambda: F_.fa_gather_rows(tabs, idx, off), iters=5, warm=1)
+            report("fa_gather_rows (B,N*N,E)", t, rd_fa + B * N * N * E * s)
+            xfa = F_.fa_gather_rows(tabs, idx, off)
+            t = timeit(lambda: F_.ffm_layer(xfa, N), iters=5, warm=1)
+            report("ffm_fwd on the materialised block", t, 2 * B * P * E * s + B * P * E * s)
+            t = timeit(lambda: F_.ffm_fused(tabs, idx, off), iters=5, warm=1)
+            report("ffm_fused_fwd (lookup + FFM)", t, rd_fa + B * P * E * s)
+            print(f"    -> SURVEY 8d bytes {(rd_fa + B * P * E * s) / 1e9:.2f} GB; 8 TB/s floor "
+                  f"{(rd_fa + B * P * E * s) / 8e12 * 1e3:.2f} ms", flush=True)
+        xr = xfa.detach().requires_grad_()
+        y = F_.ffm_layer(xr, N)
+        gy = torch.randn(B, P, E, dtype=dt, device=dev)
+        t = timeit(lambda: torch.autograd.grad(y, xr, gy, retain_graph=True), iters=3, warm=1)
+        report("ffm_bwd on the materialised block", t, 3 * B * P * E * s + B * N * N * E * s)
+        del y, xr, xfa
+        tr = [w_.requires_grad_() for w_ in tabs]
+        y = F_.ffm_fused(tr, idx, off)
+        t = timeit(lambda: torch.autograd.grad(y, tr, gy, retain_graph=True), iters=3, warm=1)
+        report("ffm_fused_bwd (all N table grads)", t, 2 * B * N * N * E * s // 1 + N * V * E * s)
+        del y, gy, tr, tabs
     if want("copy"):
         x = torch.empty(512 * 1024 * 1024 // 4, dtype=torch.float32, device=dev)
         y = torch.empty_like(x)

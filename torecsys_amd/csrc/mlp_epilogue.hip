@@ -488,6 +488,32 @@ __global__ __launch_bounds__(256) void copy_padded_many_kernel(const int64_t* __
 }
 }  // namespace trs
 
+// dst (rows, c_out) = [src (rows, c_in) | 0]: the (B,1) logit gradient widened to the 8 columns the fused MLP tail's last
+// layer runs at -- one launch instead of a fill and a strided copy (2-byte elements)
+namespace trs {
+__global__ __launch_bounds__(256) void pad_cols_kernel(const uint16_t* __restrict__ src, int c_in, uint16_t* __restrict__ dst,
+                                                       int c_out, int64_t total) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t r = t / c_out;
+    const int c = (int)(t - r * c_out);
+    dst[t] = c < c_in ? src[r * c_in + c] : (uint16_t)0;
+  }
+}
+}  // namespace trs
+
+extern "C" int trs_pad_cols(const void* src, int32_t c_in, void* dst, int32_t c_out, int64_t rows, int32_t dtype,
+                            trs_stream_t stream) {
+  TRS_REQUIRE(dtype == TRS_BF16, TRS_EDTYPE, "pad_cols: bf16 only");
+  TRS_REQUIRE(c_in > 0 && c_out >= c_in && rows >= 0, TRS_ESHAPE, "pad_cols: %d -> %d columns", c_in, c_out);
+  if (rows == 0) return TRS_OK;
+  TRS_REQUIRE(src && dst, TRS_EINVAL, "pad_cols: NULL pointer");
+  const int64_t total = rows * c_out;
+  hipLaunchKernelGGL(trs::pad_cols_kernel, dim3(trs::stream_grid(total, 256, 2048)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)src, c_in, (uint16_t*)dst, c_out, total);
+  return trs::check_launch("pad_cols");
+}
+
 extern "C" int trs_copy_padded_many(const int64_t* desc, int32_t n, int32_t elem_size, int64_t max_elems,
                                     trs_stream_t stream) {
   if (n <= 0) return TRS_OK;

@@ -1770,10 +1770,14 @@ class _FusedMLP(Function):
             inp = x2 if l == 0 else hidden[l - 1]               # (rows, widths[l] | pad32)
             g = gy2 if l == L - 1 else gz[l]                    # (rows, widths[l+1] | pad32)
             gw = gbias = None
-            if ctx.needs_input_grad[1 + 2 * l]:
-                gw = _wgrad_rows(g, inp, widths[l + 1], widths[l], pdt[2 * l])
-            if ctx.needs_input_grad[2 + 2 * l]:
-                gbias = gb[l][:widths[l + 1]].to(pdt[2 * l + 1])
+            need_w, need_b = ctx.needs_input_grad[1 + 2 * l], ctx.needs_input_grad[2 + 2 * l]
+            if need_w and need_b and pdt[2 * l] == pdt[2 * l + 1]:
+                gw, gbias = _wgrad_rows(g, inp, widths[l + 1], widths[l], pdt[2 * l], gb[l])
+            else:
+                if need_w:
+                    gw = _wgrad_rows(g, inp, widths[l + 1], widths[l], pdt[2 * l])
+                if need_b:
+                    gbias = gb[l][:widths[l + 1]].to(pdt[2 * l + 1])
             grads += [gw, gbias]
         return (gx.reshape(xshape) if ctx.needs_input_grad[0] else None, *grads)
 
@@ -1801,6 +1805,14 @@ def rows_gemm(g: torch.Tensor, W: torch.Tensor, out_f: int, in_f: int) -> torch.
     return y
 
 
+def _tail_layer_grads(g, inp, out_f, in_f, dtype, gb_f32, need_w, need_b):
+    """(dW, db) of one layer behind the fused kernels: the bias cast rides in the weight gradient's finish launch"""
+    if need_w and need_b:
+        return _wgrad_rows(g, inp, out_f, in_f, dtype, gb_f32)
+    gw = _wgrad_rows(g, inp, out_f, in_f, dtype) if need_w else None
+    return gw, (gb_f32[:out_f].to(dtype) if need_b else None)
+
+
 class _FusedMLPTail(Function):
     """The layers BEHIND a wide first layer (DeepFM / xDeepFM deep branch: 2496 -> 400 | -> 400 -> 400 -> 1) as one HIP
     kernel per direction: x2 is the first layer's ReLU output at its zero-padded GEMM width, the tail's first weight is
@@ -1819,7 +1831,7 @@ class _FusedMLPTail(Function):
         ctx.save_for_backward(x2, *Ws, *hidden, *masks)
         ctx.meta = (L, [x2.shape[1]] + [w.shape[0] for w in Ws], [tuple(tensors[4 * l].shape) for l in range(L)],
                     [tensors[4 * l].dtype for l in range(L)], fam)
-        return y[:, :out_f].contiguous() if out_f != y.shape[1] else y
+        return y[:, :out_f] if out_f != y.shape[1] else y      # (a view of the padded output: consumers read it strided)
 
     @staticmethod
     @once_differentiable
@@ -1829,19 +1841,15 @@ class _FusedMLPTail(Function):
         x2, Ws = saved[0], saved[1:1 + L]
         hidden, masks = saved[1 + L:L + L], saved[L + L:]
         rows, dev = x2.shape[0], x2.device
-        if gy.shape[1] != widths[L]:
-            gy2 = torch.zeros(rows, widths[L], dtype=torch.bfloat16, device=dev)
-            gy2[:, :gy.shape[1]] = gy
-        else:
-            gy2 = gy.contiguous()
+        gy2 = pad_cols(gy, widths[L]) if gy.shape[1] != widths[L] else gy.contiguous()
         gx, gz, gb, _ = fused_mlp_backward_raw(gy2, widths, Ws, masks, family=fam)
         grads = []
         for l in range(L):
             inp = x2 if l == 0 else hidden[l - 1]
             g = gy2 if l == L - 1 else gz[l]
             out_f, in_f = wshapes[l]
-            gw = _wgrad_rows(g, inp, out_f, in_f, wdt[l]) if ctx.needs_input_grad[1 + 4 * l] else None
-            gbias = gb[l][:out_f].to(wdt[l]) if ctx.needs_input_grad[2 + 4 * l] else None
+            gw, gbias = _tail_layer_grads(g, inp, out_f, in_f, wdt[l], gb[l], ctx.needs_input_grad[1 + 4 * l],
+                                          ctx.needs_input_grad[2 + 4 * l])
             grads += [gw, gbias, None, None]
         return (gx if ctx.needs_input_grad[0] else None, *grads)
 
@@ -1849,9 +1857,28 @@ class _FusedMLPTail(Function):
 WGRAD_ROWS = os.environ.get("TRS_WGRAD_ROWS", "1") not in ("", "0")
 
 
-def _wgrad_rows(g: torch.Tensor, inp: torch.Tensor, out_f: int, in_f: int, dtype) -> torch.Tensor:
+def pad_cols(g: torch.Tensor, width: int) -> torch.Tensor:
+    """(rows, c) bf16 -> (rows, width) with zeros behind the c columns, one launch (trs_pad_cols)"""
+    g = g.contiguous()
+    out = torch.empty(g.shape[0], width, dtype=g.dtype, device=g.device)
+    call("trs_pad_cols", ptr(g), g.shape[1], ptr(out), width, g.shape[0], value_dtype_code(g), stream_ptr())
+    return out
+
+
+def _wgrad_rows(g: torch.Tensor, inp: torch.Tensor, out_f: int, in_f: int, dtype, gb_f32: Optional[torch.Tensor] = None):
     """dW = g^T @ inp over the rows (K = rows): split-K batched GEMM with fp32 partials, folded / sliced / cast by
-    trs_wgrad_finish (the padding columns of g / inp are dropped there)."""
+    trs_wgrad_finish (the padding columns of g / inp are dropped there).  With ``gb_f32`` (the layer's fp32 bias
+    gradient, at least out_f entries) returns (dW, db): the cast of the bias gradient rides in the same finish launch."""
+    if gb_f32 is not None:
+        gb = torch.empty(out_f, dtype=dtype, device=g.device)
+        if out_f <= (in_f + 255) // 256 * 256:
+            return _wgrad_rows_impl(g, inp, out_f, in_f, dtype, gb_f32, gb), gb
+        gb.copy_(gb_f32[:out_f])
+        return _wgrad_rows_impl(g, inp, out_f, in_f, dtype, None, None), gb
+    return _wgrad_rows_impl(g, inp, out_f, in_f, dtype, None, None)
+
+
+def _wgrad_rows_impl(g, inp, out_f, in_f, dtype, gb_f32, gb):
     rows = g.shape[0]
     if (WGRAD_ROWS and g.is_cuda and g.dtype == torch.bfloat16 and inp.dtype == torch.bfloat16 and g.is_contiguous()
             and inp.is_contiguous()):
@@ -1865,7 +1892,7 @@ def _wgrad_rows(g: torch.Tensor, inp: torch.Tensor, out_f: int, in_f: int, dtype
                  _abi.TRS_BF16, S, ptr(part), stream_ptr())
             gw = torch.empty(out_f, in_f, dtype=dtype, device=g.device)
             call("trs_wgrad_finish", ptr(part), S, M, N, out_f, in_f, value_dtype_code(gw),
-                 ptr(gw), ptr(None), ptr(None), stream_ptr())
+                 ptr(gw), ptr(gb_f32), ptr(gb), stream_ptr())
             return gw
     S = 0
     # 192 batches measured best at 2.5 M rows (416 x 416: 1.33 ms against 1.48 at 384 and 1.53 at 96; 416 x 64: 0.49 against
@@ -1875,11 +1902,13 @@ def _wgrad_rows(g: torch.Tensor, inp: torch.Tensor, out_f: int, in_f: int, dtype
             S = cand
             break
     if S == 0:
+        if gb is not None:
+            gb.copy_(gb_f32[:out_f])
         return (g.t() @ inp)[:out_f, :in_f].contiguous().to(dtype)
     part = torch.bmm(g.view(S, rows // S, -1).transpose(1, 2), inp.view(S, rows // S, -1), out_dtype=torch.float32)
     gw = torch.empty(out_f, in_f, dtype=dtype, device=g.device)
     call("trs_wgrad_finish", ptr(part), S, part.shape[1], part.shape[2], out_f, in_f, value_dtype_code(gw), ptr(gw),
-         ptr(None), ptr(None), stream_ptr())
+         ptr(gb_f32), ptr(gb), stream_ptr())
     return gw
 
 
@@ -1888,3 +1917,98 @@ def fused_mlp(x: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequence
     for w, b in zip(weights, biases):
         params += [w, b]
     return _FusedMLP.apply(x, *params)
+
+
+# --------------------------------------------------------------------------------------------
+# K8: the scalar head of the CTR models and its loss (csrc/head.hip)
+# --------------------------------------------------------------------------------------------
+class _CTRLogit(Function):
+    """logit (B,1) = sum_e fm + sum_n feat + sum_k extra_k + bias in one pass; the gradient of every operand is the
+    incoming column broadcast, returned as VIEWS (the lookups' backwards read a broadcast gradient as one value per
+    sample: _fm_grad_operand, _GatherRows.backward) -- no kernel in the backward except the bias' batch sum."""
+
+    @staticmethod
+    def forward(ctx, fm, feat, bias, *extras):
+        ref = fm if fm is not None else (feat if feat is not None else extras[0])
+        require_device(ref, *[t for t in (fm, feat, bias, *extras) if t is not None])
+        B = ref.shape[0]
+        dt = ref.dtype
+        for t in (fm, feat, bias, *extras):
+            if t is not None and t.dtype != dt:
+                raise ValueError("ctr_logit: every operand must have the same dtype")
+        fmc = None if fm is None else fm.contiguous()
+        ftc = None if feat is None else feat.reshape(B, -1).contiguous()
+        E = 0 if fmc is None else fmc.shape[1]
+        N = 0 if ftc is None else ftc.shape[1]
+        cols, strides = [], []
+        for t in extras:
+            if t.dim() != 2 or t.shape[0] != B or t.shape[1] != 1:
+                raise ValueError(f"ctr_logit: extra terms must be (B,1), got {tuple(t.shape)}")
+            cols.append(t)
+            strides.append(t.stride(0))          # a (B,1) slice of a wider row (the padded logit column of the fused MLP tail)
+        out = torch.empty(B, 1, dtype=dt, device=ref.device)
+        call("trs_ctr_logit_fwd", ptr(fmc), E, ptr(ftc), N, _ptr_array(cols), (ctypes.c_int64 * max(1, len(cols)))(*strides),
+             len(cols), ptr(bias), B, value_dtype_code(out), ptr(out), stream_ptr())
+        ctx.shapes = (None if fm is None else tuple(fm.shape), None if feat is None else tuple(feat.shape),
+                      None if bias is None else tuple(bias.shape), len(extras))
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        fm_shape, feat_shape, bias_shape, n_extras = ctx.shapes
+        needs = ctx.needs_input_grad
+        B = g.shape[0]
+        g_fm = g.expand(fm_shape) if fm_shape is not None and needs[0] else None
+        g_feat = None
+        if feat_shape is not None and needs[1]:
+            g_feat = g.reshape(B, *([1] * (len(feat_shape) - 1))).expand(feat_shape)
+        g_bias = g.sum().reshape(bias_shape) if bias_shape is not None and needs[2] else None
+        return (g_fm, g_feat, g_bias, *[g if needs[3 + k] else None for k in range(n_extras)])
+
+
+def ctr_logit(fm: Optional[torch.Tensor] = None, feat: Optional[torch.Tensor] = None,
+              extras: Sequence[torch.Tensor] = (), bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The scalar head the reference's CTR models end in, as one kernel: ``fm`` (B,E) second-order FM term (summed over
+    E), ``feat`` (B,N,1) | (B,N) first-order weights of the looked-up rows (summed over N), ``extras`` up to four (B,1)
+    columns (deep / CIN outputs), ``bias`` one value -> (B,1).  models/ctr/factorization_machine.py:55-66,
+    deep_fm.py:75-104, xdeep_fm.py:117-121."""
+    if fm is None and feat is None and not extras:
+        raise ValueError("ctr_logit: nothing to sum")
+    strip = lambda t: None if t is None else (t.rename(None) if t.has_names() else t)
+    return _CTRLogit.apply(strip(fm), strip(feat), bias, *[strip(t) for t in extras])
+
+
+class _BCEWithLogits(Function):
+    @staticmethod
+    def forward(ctx, logits, labels):
+        require_device(logits, labels)
+        x = logits.reshape(-1).contiguous()
+        y = labels.reshape(-1).contiguous()
+        if x.numel() != y.numel():
+            raise ValueError(f"bce_with_logits: {tuple(logits.shape)} logits against {tuple(labels.shape)} labels")
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        ws_bytes = size_query("trs_bce_logits_workspace_bytes", x.numel())
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+        call("trs_bce_logits_fwd", ptr(x), value_dtype_code(x), ptr(y), value_dtype_code(y), x.numel(), ptr(loss), ptr(ws),
+             ws_bytes, stream_ptr())
+        ctx.save_for_backward(x, y)
+        ctx.shape = tuple(logits.shape)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        gx = torch.empty_like(x)
+        gf = g.float().contiguous()
+        call("trs_bce_logits_bwd", ptr(x), value_dtype_code(x), ptr(y), value_dtype_code(y), ptr(gf), x.numel(), ptr(gx),
+             stream_ptr())
+        return gx.reshape(ctx.shape), None
+
+
+def bce_with_logits(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """mean binary cross entropy of ``logits`` (fp32 / bf16, any shape) against ``labels`` (fp32 / bf16, same number of
+    elements): an fp32 scalar.  ``F.binary_cross_entropy_with_logits(logits.float(), labels)`` in three launches
+    (forward 2, backward 1) instead of ATen's cast + log-sigmoid chain + mean and their backwards."""
+    return _BCEWithLogits.apply(logits, labels)

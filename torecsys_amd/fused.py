@@ -58,3 +58,20 @@ class EmbeddingFM(nn.Module):
             emb.names = ('B', 'N', 'E',)
         fm.names = ('B', 'O',)
         return emb, fm, first
+
+
+class BCEWithLogitsLoss(nn.Module):
+    """``nn.BCEWithLogitsLoss()`` (mean reduction, no weights) on the HIP device: ``loss(logits, labels)`` with logits in
+    fp32 or bf16 -- no ``.float()`` cast needed in front -- and 0/1 (or soft) labels in fp32 / bf16; an fp32 scalar.
+    Forward two launches, backward one (functional.bce_with_logits) instead of ATen's ~16.  The loss SURVEY.md 8d defines
+    the fwd+bwd metric on; configurations this module does not cover raise at construction."""
+
+    def __init__(self, weight=None, size_average=None, reduce=None, reduction: str = 'mean', pos_weight=None):
+        super().__init__()
+        if weight is not None or pos_weight is not None or reduction != 'mean' or size_average is not None \
+                or reduce is not None:
+            raise NotImplementedError("torecsys_amd.fused.BCEWithLogitsLoss covers reduction='mean' without weights; use "
+                                      "torch.nn.BCEWithLogitsLoss for anything else")
+
+    def forward(self, input: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        return F_.bce_with_logits(input, target)

@@ -765,7 +765,7 @@ class _HybridMLP(torch.autograd.Function):
         ctx.save_for_backward(cur, W1, h1, mask_in, *Ws, *hidden, *masks)
         ctx.meta = (L, [h1.shape[1]] + [w.shape[0] for w in Ws], [tuple(tail[4 * l].shape) for l in range(L)],
                     [tail[4 * l].dtype for l in range(L)], tuple(w1.shape), w1.dtype, tuple(x.shape), fam)
-        y = y[:, :out_f].contiguous() if out_f != y.shape[1] else y
+        y = y[:, :out_f] if out_f != y.shape[1] else y      # a view of the padded output (the head reads it strided)
         return y.reshape(*x.shape[:-1], out_f)
 
     @staticmethod
@@ -779,19 +779,14 @@ class _HybridMLP(torch.autograd.Function):
         needs = ctx.needs_input_grad
         rows, dev = h1.shape[0], h1.device
         gy = gy.reshape(rows, -1)
-        if gy.shape[1] != widths[L]:
-            gy2 = torch.zeros(rows, widths[L], dtype=torch.bfloat16, device=dev)
-            gy2[:, :gy.shape[1]] = gy
-        else:
-            gy2 = gy.contiguous()
+        gy2 = F_.pad_cols(gy, widths[L]) if gy.shape[1] != widths[L] else gy.contiguous()
         g1, gz, gb, gb1 = F_.fused_mlp_backward_raw(gy2, widths, Ws, masks, mask_in, family=fam)
         grads = []
         for l in range(L):
             inp = h1 if l == 0 else hidden[l - 1]
             g = gy2 if l == L - 1 else gz[l]
             out_f, in_f = wshapes[l]
-            gw = F_._wgrad_rows(g, inp, out_f, in_f, wdt[l]) if needs[5 + 4 * l] else None
-            gbias = gb[l][:out_f].to(wdt[l]) if needs[6 + 4 * l] else None
+            gw, gbias = F_._tail_layer_grads(g, inp, out_f, in_f, wdt[l], gb[l], needs[5 + 4 * l], needs[6 + 4 * l])
             grads += [gw, gbias, None, None]
         gx, gw1, gbias1 = _dense_layer_grads(g1, gb1, cur, W1, w1shape[0], w1shape[1], w1dt, needs[0], needs[1], needs[2])
         return (gx.reshape(xshape) if needs[0] else None, gw1, gbias1, None, None, *grads)
