@@ -400,19 +400,27 @@ def main():
 
     torch.manual_seed(7)
     pipelined = False
+    dense_graph = False
     if not sharded:
         emb = MultiIndicesEmbedding(embed_size=E, field_sizes=sizes, fuse_fm=not a.no_fuse)
         feat = MultiIndicesEmbedding(embed_size=1, field_sizes=sizes)
         parallelism = "single"
     else:
         from torecsys_amd.dist import RowShardedMultiIndicesEmbedding
-        cap = a.capacity if a.capacity >= 1.0 else None
+        if a.capacity == 0.0 and world > 1 and not a.dedup:
+            a.capacity = 1.1       # default at N > 1: fixed-capacity slots -- equal all-to-all splits, no split size read on
+        cap = a.capacity if a.capacity >= 1.0 else None        # the host (--capacity -1: exact, data-dependent splits)
         pipelined = not a.no_pipeline and a.optimizer == "none" and (a.microbatches or 1) == 1
+        # the dense part of the step (deep branch, head, loss and their backward) replayed from a hipGraph while the
+        # lookups and their exchanges stay eager on the compute / communication streams (graph.GraphedRegion)
+        dense_graph = (not a.eager and a.optimizer == "none" and (a.microbatches or 1) == 1 and not a.no_fuse
+                       and a.model in ("deepfm", "fm") and not a.dedup)
         emb = RowShardedMultiIndicesEmbedding(embed_size=E, field_sizes=sizes, fuse_fm=not a.no_fuse,
                                               dtype=dt, device=dev, dedup=a.dedup, capacity=cap,
-                                              overlap_grad_exchange=pipelined)
+                                              overlap_grad_exchange=pipelined, persistent_outputs=dense_graph)
         feat = RowShardedMultiIndicesEmbedding(embed_size=1, field_sizes=sizes, dtype=dt, device=dev, dedup=a.dedup,
-                                               capacity=cap, overlap_grad_exchange=pipelined)
+                                               capacity=cap, overlap_grad_exchange=pipelined,
+                                               persistent_outputs=dense_graph)
         parallelism = f"row-sharded table x{world} (all-to-all lookup), data-parallel MLP"
     emb.set_schema(["c0"])       # the whole (B,N) index block travels as one named column
     feat.set_schema(["c0"])
@@ -474,27 +482,72 @@ def main():
         return cur
 
     phases = [0.0, 0.0, 0.0, 0]          # host seconds in forward / route prefetch / backward, steps (TRS_BENCH_PHASES=1)
+    bucket = None
+    if world > 1:          # data-parallel dense parameters: one flat bf16 bucket, all-reduced on the communication stream
+        from torecsys_amd.dist import DenseGradBucket
+        bucket = DenseGradBucket(model.parameters())
+    region = [None]        # graph.GraphedRegion of the dense part (sharded runs), built after the eager warm-up
+    lab_static = label_ring[0].clone()
+    table_params = [p for p in inputs.parameters() if p.requires_grad]
+
+    def hint_next(k):
+        if sharded and pipelined:
+            # the NEXT batch's lookup exchange (route, id all-to-all, owner gather, row all-to-all) goes onto the
+            # communication stream now and runs under this batch's backward; the gradient exchange of this batch
+            # runs under the next forward (overlap_grad_exchange).  fwd+bwd metric: the shards do not change, so the
+            # early lookup is bit-identical (tests/test_dist_gloo.py::test_row_sharded_pipelined_step_is_bit_equal)
+            emb.prefetch_lookup(idx_ring[(k + 1) % RING])
+            feat.prefetch_lookup(idx_ring[(k + 1) % RING])
+            if not cap:
+                emb.prefetch_route(idx_ring[(k + 3) % RING])      # split sizes read on the host: routed further ahead
+        elif sharded:    # input-pipeline style hint: start routing the batch after the next one before this backward
+            emb.prefetch_route(idx_ring[(k + 2) % RING])
+
+    def dense_fn(xb, fm_t, ft, lab):
+        """the dense part on detached leaves aliasing the lookups' persistent output buffers"""
+        xb._trs_fused_fm = (fm_t, xb._version)
+        return _loss(crit, model(feat_inputs=ft, emb_inputs=xb), lab)
+
+    def graphed_dense_step(k):
+        """lookups eager -> one replay (dense forward + backward) -> gradients back into the lookups, eager"""
+        for p in table_params:
+            p.grad = None
+        d = inputs({"c0": next_indices(k)})
+        eo, fo = d["emb_inputs"].rename(None), d["feat_inputs"].rename(None)
+        fm_o = d["emb_inputs"]._trs_fused_fm[0]
+        if region[0] is None:
+            from torecsys_amd.graph import GraphedRegion
+            lab_static.copy_(label_ring[k])
+            region[0] = GraphedRegion(dense_fn, (eo.detach(), fm_o.detach(), fo.detach(), lab_static),
+                                      (True, True, True, False), params=list(model.parameters()), warmup=2)
+        lab_static.copy_(label_ring[k], non_blocking=True)
+        loss, (g_e, g_fm, g_f, _) = region[0]()
+        hint_next(k)
+        outs, grads = [], []
+        for o_, g_ in ((eo, g_e), (fm_o, g_fm), (fo, g_f)):
+            if g_ is not None:
+                outs.append(o_)
+                grads.append(g_)
+        torch.autograd.backward(outs, grads)
+        return loss
+
+    dense_ready = [False]      # flipped after the eager warm-up steps (lazy initialisation must not happen in a capture)
 
     def step():
         k = counter[0] % RING
         counter[0] += 1
-        for p in params:
-            p.grad = None
-        if MB == 1:
+        if bucket is not None:
+            bucket.wait()       # the previous step's all-reduce still reads / writes the gradients this step replaces
+        if not (dense_graph and dense_ready[0]):
+            for p in params:
+                p.grad = None
+        if MB == 1 and dense_graph and dense_ready[0]:
+            loss = graphed_dense_step(k)
+        elif MB == 1:
             t0 = time.perf_counter()
             loss = fwd_loss(next_indices(k), label_ring[k], 1.0)
             t1 = time.perf_counter()
-            if sharded and pipelined:
-                # the NEXT batch's lookup exchange (route, id all-to-all, owner gather, row all-to-all) goes onto the
-                # communication stream now and runs under this batch's backward; the gradient exchange of this batch
-                # runs under the next forward (overlap_grad_exchange).  fwd+bwd metric: the shards do not change, so the
-                # early lookup is bit-identical (tests/test_dist_gloo.py::test_row_sharded_pipelined_step_is_bit_equal)
-                emb.prefetch_lookup(idx_ring[(k + 1) % RING])
-                feat.prefetch_lookup(idx_ring[(k + 1) % RING])
-                if not cap:
-                    emb.prefetch_route(idx_ring[(k + 3) % RING])      # split sizes read on the host: routed further ahead
-            elif sharded:    # input-pipeline style hint: start routing the batch after the next one before this backward
-                emb.prefetch_route(idx_ring[(k + 2) % RING])
+            hint_next(k)
             t2 = time.perf_counter()
             loss.backward()
             phases[0] += t1 - t0; phases[1] += t2 - t1; phases[2] += time.perf_counter() - t2; phases[3] += 1
@@ -522,15 +575,8 @@ def main():
             for st in streams:
                 main.wait_stream(st)
             loss = total
-        if world > 1:      # data-parallel dense parameters: average their gradients (one flat bucket)
-            ps = [p for p in model.parameters() if p.grad is not None]
-            flat = torch.cat([p.grad.reshape(-1).float() for p in ps])
-            dist.all_reduce(flat)
-            flat.div_(world)
-            o = 0
-            for p in ps:
-                p.grad.copy_(flat[o:o + p.numel()].view_as(p.grad))
-                o += p.numel()
+        if bucket is not None:      # averaged on the communication stream (dist.DenseGradBucket), under the next forward
+            bucket.reduce()
         return loss
 
     roof_kernel = "trs_embed_fm" if not a.no_fuse else "trs_gather_rows"
@@ -553,6 +599,19 @@ def main():
     for _ in range(a.warmup if not use_graph else max(3, a.warmup // 2)):
         eager_step()
     torch.cuda.synchronize()
+    if dense_graph:
+        try:
+            dense_ready[0] = True
+            for _ in range(3):
+                step()              # the first of these captures the region
+            torch.cuda.synchronize()
+        except Exception as exc:    # noqa: BLE001 -- capture refused: the eager step is the same work
+            print(f"bench.py: hipGraph capture of the dense region failed ({type(exc).__name__}: {exc}); running eager",
+                  file=sys.stderr)
+            dense_ready[0] = False
+            dense_graph = False
+            region[0] = None
+            torch.cuda.synchronize()
     if os.environ.get("TRS_BENCH_TORCHPROF"):      # developer aid: which host op launches what (3 eager steps)
         from torch.profiler import ProfilerActivity, profile
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
@@ -651,6 +710,8 @@ def main():
     torch.cuda.synchronize()
     span1.synchronize()      # belt and braces: the region's last event has completed
     final_loss = float(loss.detach())
+    if bucket is not None:
+        bucket.wait()
     if world > 1:
         dist.barrier()
     el = time.perf_counter() - t0
@@ -798,7 +859,11 @@ def main():
                        ("BASELINE.json configs[4] (weak-scaled): DeepFM, " f"{V} rows row-sharded over {world} GPUs, "
                         f"global batch {B * world}"),
                        "global_batch": B * world, "rows": V, "parallelism": parallelism,
-                       "microbatches": MB, "optimizer": a.optimizer, "hipgraph": bool(use_graph), "indices_from_host": bool(host_idx),
+                       "microbatches": MB, "optimizer": a.optimizer, "hipgraph": bool(use_graph or (dense_graph and dense_ready[0])),
+                       **({"hipgraph_scope": "dense region (deep branch, head, loss, their backward) replayed; lookups, "
+                                             "exchanges and the dense all-reduce eager on the compute / communication streams"}
+                          if (dense_graph and dense_ready[0]) else {}),
+                       "indices_from_host": bool(host_idx),
                        "fused_lookup_fm": not a.no_fuse, "loss": final_loss,
                        "host_enqueue_ms_per_step": round(enqueue_s / a.steps * 1e3, 4),
                        "device_span_ms_per_step": round(device_span_ms / a.steps, 4),

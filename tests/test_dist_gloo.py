@@ -356,3 +356,55 @@ def test_default_ops_refuse_cpu():
     from torecsys_amd.dist import HipOps
     with pytest.raises(RuntimeError, match="no CPU path"):
         HipOps().bucket_by_owner(torch.zeros(2, 2, dtype=torch.long), torch.zeros(2, dtype=torch.long), 4, 2)
+
+
+def _bucket_worker(rank, world, port, dtype, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from torecsys_amd.dist import DenseGradBucket
+        torch.manual_seed(0)
+        shapes = [(400, 2496), (400,), (400, 400), (1, 400), (1,)]
+        params = [torch.nn.Parameter(torch.zeros(*s, dtype=dtype)) for s in shapes]
+        frozen = torch.nn.Parameter(torch.zeros(3), requires_grad=False)
+        bucket = DenseGradBucket(params + [frozen])
+        assert bucket.flat.dtype == dtype and bucket.flat.numel() == sum(p.numel() for p in params)
+        assert bucket.bytes_per_step == (0 if world == 1 else bucket.flat.numel() * bucket.flat.element_size())
+        for step in range(3):                                   # the same bucket, step after step
+            g = torch.Generator().manual_seed(100 * step)
+            all_grads = [[torch.randn(*s, generator=g).to(dtype) for s in shapes] for _ in range(world)]
+            for p, gr in zip(params, all_grads[rank]):
+                p.grad = gr.clone()
+            bucket.reduce()
+            bucket.wait()
+            for i, p in enumerate(params):
+                want = sum(all_grads[r][i].float() for r in range(world)) / world
+                err = float((p.grad.float() - want).abs().max())
+                tol = 1e-6 if dtype == torch.float32 else 2e-2 * float(want.abs().max()) + 1e-3
+                assert err <= tol, (step, i, err)
+        params[1].grad = None
+        if world > 1:
+            try:
+                bucket.reduce()
+                raise AssertionError("a missing gradient must be refused")
+            except RuntimeError as e:
+                assert "no gradient" in str(e)
+        ret[rank] = "ok"
+    except Exception:  # noqa: BLE001
+        import traceback
+        ret[rank] = "FAIL: " + traceback.format_exc()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dtype", [(2, torch.float32), (2, torch.bfloat16), (3, torch.bfloat16), (1, torch.bfloat16)])
+def test_dense_grad_bucket_averages_over_ranks(world, dtype):
+    """dist.DenseGradBucket: one flat persistent bucket, the parameters' own dtype on the wire (bf16 for a bf16 model),
+    gradients averaged in place; world 1 is a no-op"""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    mp.spawn(_bucket_worker, args=(world, port, dtype, ret), nprocs=world, join=True)
+    for r in range(world):
+        assert ret.get(r) == "ok", ret.get(r)

@@ -249,3 +249,70 @@ def test_sharded_pipelined_step_is_bit_equal_on_the_device(pg, fuse, sparse):
             # the dense shard gradient is a bucket walk whose bucket order comes out of LDS atomics: the fp32 sums of two
             # runs of the SAME code differ in their last bits, so this one is compared at bf16 resolution
             assert rel_err(y[2].float(), x[2].float()) <= 2.0 ** -7, f"shard gradient differs at step {k}"
+
+
+def test_graphed_dense_region_behind_eager_sharded_lookups(pg):
+    """graph.GraphedRegion: the dense part of a DeepFM step (deep branch, head, loss and their backward) replayed from a
+    hipGraph behind EAGER row-sharded lookups that write persistent output buffers (the arrangement bench.py --gpus N
+    runs: the exchanges stay on their streams, RCCL stays out of the capture).  Four different batches: loss, the dense
+    parameters' gradients and both tables' gradients equal the all-eager step on the same modules."""
+    from harness import ctr_models as M
+    from torecsys_amd.dist import RowShardedMultiIndicesEmbedding
+    from torecsys_amd.fused import BCEWithLogitsLoss
+    from torecsys_amd.graph import GraphedRegion
+    dev = torch.device("cuda:0")
+    B, N, E = 4096, 7, 32
+    sizes = [50, 3, 1000, 17, 400, 9, 121]
+    torch.manual_seed(3)
+    emb = RowShardedMultiIndicesEmbedding(embed_size=E, field_sizes=sizes, fuse_fm=True, dtype=torch.bfloat16, device=dev,
+                                          persistent_outputs=True)
+    feat = RowShardedMultiIndicesEmbedding(embed_size=1, field_sizes=sizes, dtype=torch.bfloat16, device=dev,
+                                           persistent_outputs=True)
+    model = M.DeepFactorizationMachineModel(E, N, [64, 32], fm_dropout_p=0.0).to(dev).bfloat16()
+    crit = BCEWithLogitsLoss()
+    g = torch.Generator().manual_seed(0)
+    batches = [(torch.stack([torch.randint(0, s, (B,), generator=g) for s in sizes], 1).to(dev),
+                (torch.rand(B, 1, generator=g) < 0.3).float().to(dev)) for _ in range(4)]
+    tables = [emb.embedding.weight, feat.embedding.weight]
+    dense = list(model.parameters())
+
+    def lookups(ix):
+        eo = emb(ix)
+        return eo.rename(None), eo._trs_fused_fm[0], feat(ix).rename(None)
+
+    def head(xb, fm_t, ft, lab):
+        xb._trs_fused_fm = (fm_t, xb._version)
+        return crit(model(feat_inputs=ft, emb_inputs=xb), lab)
+
+    eager = []
+    for ix, lab in batches:
+        for p in tables + dense:
+            p.grad = None
+        eo, fm_o, fo = lookups(ix)
+        xb = eo.detach().requires_grad_(); fm_t = fm_o.detach().requires_grad_(); ft = fo.detach().requires_grad_()
+        loss = head(xb, fm_t, ft, lab)
+        loss.backward()
+        torch.autograd.backward([eo, fm_o, fo], [xb.grad, fm_t.grad, ft.grad])
+        eager.append((float(loss), [p.grad.clone() for p in tables + dense]))
+    # the same buffers every step
+    eo1, _, _ = lookups(batches[0][0])
+    eo2, _, _ = lookups(batches[1][0])
+    assert eo1.data_ptr() == eo2.data_ptr()
+    lab_static = batches[0][1].clone()
+    eo, fm_o, fo = lookups(batches[0][0])
+    for p in dense:
+        p.grad = None
+    region = GraphedRegion(head, (eo.detach(), fm_o.detach(), fo.detach(), lab_static), (True, True, True, False),
+                           params=dense, warmup=2)
+    for (ix, lab), (l0, g0) in zip(batches, eager):
+        for p in tables:
+            p.grad = None
+        eo, fm_o, fo = lookups(ix)
+        lab_static.copy_(lab)
+        loss, (g_e, g_fm, g_f, g_lab) = region()
+        assert g_lab is None
+        torch.autograd.backward([eo, fm_o, fo], [g_e, g_fm, g_f])
+        torch.cuda.synchronize()
+        assert abs(float(loss) - l0) <= 1e-6 * abs(l0)
+        for p, want in zip(tables + dense, g0):
+            assert rel_err(p.grad.float().cpu(), want.float().cpu()) <= 1e-2

@@ -273,3 +273,42 @@ def test_pair_layers_full_size(dev, block):
     assert rel_err(x.grad[rd].float().cpu(), xr.grad) <= TOL
     assert rel_err(a.Linear.weight.grad.float().cpu(), ps[0].grad) <= TOL
     assert rel_err(a.OutProj.weight.grad.float().cpu(), ps[2].grad) <= TOL
+
+
+def test_ffm_full_size(dev):
+    """F2 / I3 at the BASELINE shape (12.8 GB of field-aware rows in, 6.2 GB of pair products out; 5 GB of
+    tables): the fused lookup + FFM (trs_ffm_fused_fwd -- (B, N*N, E) is never formed) on the whole batch against the
+    oracle's field-aware lookup + FFM on 48 sampled rows.  The products are single bf16 multiplications of table rows:
+    BIT-EXACT (field_aware_factorization_machine.py:69-87, multi_indices_field_aware_emb.py:102-105).  Element counts
+    pass 2^32 here (B*N*N*E = 6.4e9), which is what the small-shape tests cannot reach.  Backward: a loss that weights
+    only the sampled rows must reproduce the oracle's table gradients on the rows those samples touch and leave every
+    other row exactly zero (checked on two of the 39 tables)."""
+    from torecsys_amd import functional as F_
+    V = 1_000_000
+    per = V // N
+    fs = [per] * (N - 1) + [V - per * (N - 1)]
+    off = O.field_offsets(fs)
+    g = torch.Generator().manual_seed(99)
+    idx = torch.cat([torch.randint(0, f, (B, 1), generator=g) for f in fs], 1)
+    rows = torch.randperm(B, generator=g)[:S].sort().values
+    gd = torch.Generator(device=dev).manual_seed(5)
+    tabs = [((torch.rand(V, E, generator=gd, device=dev) - 0.5)).bfloat16().requires_grad_() for _ in range(N)]
+    y = F_.ffm_fused(tabs, idx.to(dev), off.to(dev))
+    P = N * (N - 1) // 2
+    assert y.shape == (B, P, E)
+    # oracle on the sampled rows: only the table rows those samples read are needed on the host
+    gsel = (idx[rows] + off.view(1, -1)).reshape(-1)                      # global row ids, (S*N)
+    uniq, inv = torch.unique(gsel, return_inverse=True)
+    small = [t.detach()[uniq.to(dev)].float().cpu().requires_grad_() for t in tabs]
+    xr = O.multi_indices_field_aware_embedding(small, inv.view(S, N), torch.zeros(N, dtype=torch.int64))
+    yr = O.ffm_layer(xr, N)
+    got = y[rows.to(dev)].float().cpu()
+    assert torch.equal(got, yr.detach().bfloat16().float())
+    gs = torch.randn(S, P, E, generator=g)
+    _sampled_loss(y, rows, gs.bfloat16().float()).backward()
+    (yr * gs.bfloat16().float()).sum().backward()
+    for i in (0, N - 1):
+        gi = tabs[i].grad
+        assert rel_err(gi[uniq.to(dev)].float().cpu(), small[i].grad) <= TOL
+        mask = torch.ones(V, dtype=torch.bool); mask[uniq] = False
+        assert float(gi[mask.to(dev)].float().abs().max()) == 0.0

@@ -150,14 +150,18 @@ class HipOps:
         if ids.numel() and weight.requires_grad and OWNER_PREFETCH:
             F_.prefetch_row_buckets(ids.view(-1, 1), None, weight.shape[0], check=not padded)
 
-    def unpermute(self, rows: torch.Tensor, inv_pos: torch.Tensor, B: int, N: int, want_fm: bool):
-        """block[p] = rows[inv_pos[p]]; with ``want_fm`` also FM second order + the fp32 field sum."""
+    def unpermute(self, rows: torch.Tensor, inv_pos: torch.Tensor, B: int, N: int, want_fm: bool, out=None):
+        """block[p] = rows[inv_pos[p]]; with ``want_fm`` also FM second order + the fp32 field sum.  ``out``: (block, fm,
+        fm_sum) buffers to write into (the module's persistent output buffers) instead of fresh allocations."""
         K, E = rows.shape
-        block = torch.empty(B, N, E, dtype=rows.dtype, device=rows.device)
         fm = fm_sum = None
-        if want_fm:
-            fm = torch.empty(B, E, dtype=rows.dtype, device=rows.device)
-            fm_sum = torch.empty(B, E, dtype=torch.float32, device=rows.device)
+        if out is not None:
+            block, fm, fm_sum = out
+        else:
+            block = torch.empty(B, N, E, dtype=rows.dtype, device=rows.device)
+            if want_fm:
+                fm = torch.empty(B, E, dtype=rows.dtype, device=rows.device)
+                fm_sum = torch.empty(B, E, dtype=torch.float32, device=rows.device)
         if B:
             call("trs_embed_fm", ptr(rows), max(K, 1), E, value_dtype_code(rows), ptr(inv_pos), index_dtype_code(inv_pos),
                  ptr(None), B, N, ptr(block), ptr(fm), ptr(fm_sum), ptr(None), ptr(None), ptr(None), stream_ptr())
@@ -554,7 +558,11 @@ class _ShardedLookup(Function):
             plan, back = _fetch_rows(weight, idx, mod)
         padded = plan.cap > 0
         with _phase("un-permute (+FM)", idx.device):
-            block, fm, fm_sum = ops.unpermute(back, plan.inv_pos, B, N, mod.fuse_fm)
+            if mod.persistent_outputs:
+                block, fm, fm_sum = ops.unpermute(back, plan.inv_pos, B, N, mod.fuse_fm,
+                                                  out=mod.output_buffers(B, N, weight))
+            else:
+                block, fm, fm_sum = ops.unpermute(back, plan.inv_pos, B, N, mod.fuse_fm)
         if weight.shape[0] <= mod.dense_grad_max_rows and hasattr(ops, "prefetch_owner_buckets"):
             ops.prefetch_owner_buckets(weight, plan.recv_ids, padded)
         ctx.mod = mod
@@ -633,7 +641,8 @@ class RowShardedMultiIndicesEmbedding(BaseInput):
     def __init__(self, embed_size: int, field_sizes: List[int], flatten: bool = False, fuse_fm: bool = False,
                  dtype: torch.dtype = torch.float32, device='cpu', process_group=None, ops=None,
                  dense_grad_max_rows: int = DENSE_GRAD_MAX_ROWS, dedup: bool = False,
-                 capacity: Optional[float] = None, overlap_grad_exchange: bool = False):
+                 capacity: Optional[float] = None, overlap_grad_exchange: bool = False,
+                 persistent_outputs: bool = False):
         super().__init__()
         if not dist.is_initialized():
             raise RuntimeError("RowShardedMultiIndicesEmbedding needs torch.distributed to be initialised")
@@ -660,10 +669,29 @@ class RowShardedMultiIndicesEmbedding(BaseInput):
             raise ValueError("fixed-capacity slots and dedup (a data-dependent number of rows) exclude each other")
         self.capacity = None if capacity is None else float(capacity)
         self.overlap_grad_exchange = bool(overlap_grad_exchange)
+        # persistent_outputs: every forward writes its (B,N,E) block (and FM term) into the SAME buffers -- what lets the
+        # dense part of the step behind the lookup be replayed from a hipGraph (graph.GraphedRegion reads fixed addresses)
+        # while the exchanges stay eager on their own stream.  The caller must be done with step k's outputs before step
+        # k+1's forward (true for a training loop: backward(k) precedes forward(k+1) on the compute stream).
+        self.persistent_outputs = bool(persistent_outputs)
+        self._out_bufs = {}
         self._grad_event = None
         self._caps = {}
         self.route_key = (tuple(int(f) for f in field_sizes), self.world, id(process_group), self.dedup, self.capacity)
         self.length = embed_size * len(field_sizes) if flatten else embed_size
+
+    def output_buffers(self, B: int, N: int, weight: torch.Tensor):
+        key = (B, N, weight.dtype)
+        bufs = self._out_bufs.get(key)
+        if bufs is None:
+            E, dev = weight.shape[1], weight.device
+            block = torch.empty(B, N, E, dtype=weight.dtype, device=dev)
+            fm = torch.empty(B, E, dtype=weight.dtype, device=dev) if self.fuse_fm else None
+            fm_sum = torch.empty(B, E, dtype=torch.float32, device=dev) if self.fuse_fm else None
+            if len(self._out_bufs) >= 4:
+                self._out_bufs.clear()
+            bufs = self._out_bufs[key] = (block, fm, fm_sum)
+        return bufs
 
     def slot_capacity(self, lookups: int) -> int:
         """slots per peer of a fixed-capacity exchange of ``lookups`` = B*N row ids (a multiple of 64).  Equal splits
@@ -752,3 +780,62 @@ class RowShardedMultiIndicesEmbedding(BaseInput):
 
     def full_state_dict(self):
         return {'embedding.weight': self.full_weight()}
+
+
+class DenseGradBucket:
+    """Data-parallel dense parameters (the MLP / cross / CIN weights, a few MB): their gradients averaged over the ranks
+    by ONE all-reduce of a flat, persistent bucket -- bf16 on the wire when every gradient is bf16 (fp32 otherwise) --
+    issued on the communication stream, where it queues with the embedding exchanges and overlaps the owner-side reduction
+    of the sparse gradient instead of sitting on the compute stream behind a ``torch.cat`` and a copy-back loop.
+
+        bucket = DenseGradBucket(model.parameters(), group)        # once
+        loss.backward(); bucket.reduce()                            # every step: pack -> all-reduce -> unpack (averaged)
+        bucket.wait()                                               # before the gradients are read (optimizer step)
+
+    Pack and unpack are one multi-tensor launch each (torch._foreach_copy_); the bucket and its per-parameter views are
+    allocated once, so the step has a static launch sequence.  A process group of one rank does nothing at all."""
+
+    def __init__(self, params, group=None, wire_dtype: Optional[torch.dtype] = None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        self.world = dist.get_world_size(group)
+        if not self.params:
+            raise ValueError("DenseGradBucket: no parameters")
+        dev = self.params[0].device
+        if wire_dtype is None:
+            wire_dtype = torch.bfloat16 if all(p.dtype == torch.bfloat16 for p in self.params) else torch.float32
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=wire_dtype, device=dev)
+        self.views, o = [], 0
+        for p in self.params:
+            self.views.append(self.flat[o:o + p.numel()].view(p.shape))
+            o += p.numel()
+        self._event = None
+        self.bytes_per_step = 0 if self.world == 1 else self.flat.numel() * self.flat.element_size()
+
+    def reduce(self) -> None:
+        """average ``p.grad`` over the ranks in place (every parameter must have a gradient)"""
+        if self.world == 1:
+            return
+        grads = [p.grad for p in self.params]
+        if any(g is None for g in grads):
+            raise RuntimeError("DenseGradBucket.reduce: a parameter has no gradient (run backward first)")
+        dev = self.flat.device
+        cs = comm_stream(dev)
+        if cs is not None:
+            cs.wait_stream(torch.cuda.current_stream(dev))        # the gradients come first
+        with _on_stream(cs), torch.no_grad():
+            with _phase("dense all-reduce", dev):
+                torch._foreach_copy_(self.views, grads)                 # pack (one launch; casts to the wire dtype)
+                dist.all_reduce(self.flat, group=self.group)
+                self.flat.mul_(1.0 / self.world)
+                torch._foreach_copy_(grads, self.views)                 # unpack
+            if cs is not None:
+                for g in grads:
+                    g.record_stream(cs)
+                self._event = torch.cuda.Event()
+                self._event.record(cs)
+
+    def wait(self) -> None:
+        ev, self._event = self._event, None
+        if ev is not None:
+            torch.cuda.current_stream(self.flat.device).wait_event(ev)

@@ -25,7 +25,7 @@ import torch
 
 from . import functional as F_
 
-__all__ = ["GraphedStep"]
+__all__ = ["GraphedStep", "GraphedRegion"]
 
 
 class GraphedStep:
@@ -91,3 +91,73 @@ class GraphedStep:
             dst.copy_(src, non_blocking=True)
         self._graph.replay()
         return self.output
+
+
+class GraphedRegion:
+    """hipGraph capture of the DENSE part of a step -- everything between the lookups' outputs and the gradients that
+    go back into the lookups -- for steps whose lookups must stay eager (the row-sharded multi-GPU step: its exchanges
+    are pipelined across steps on a communication stream, which a whole-step capture would serialise, and RCCL stays out
+    of the capture altogether).  The region reads its inputs at FIXED addresses (``RowShardedMultiIndicesEmbedding(
+    persistent_outputs=True)`` writes every batch's block / FM term into the same buffers), runs forward + backward and
+    leaves
+
+        loss, the gradients w.r.t. the differentiable inputs, and ``p.grad`` of every parameter
+
+    in static tensors.  One replay replaces the ~45 launches of a DeepFM deep branch + head + loss; the host is left with
+    the lookups' ~20.
+
+        region = GraphedRegion(lambda block, fm, first, label: crit(model_head(block, fm, first), label),
+                               inputs=(block_buf, fm_buf, first_buf, label_buf), diff=(True, True, True, False),
+                               params=model.parameters())
+        loss, (g_block, g_fm, g_first, _) = region()              # after the eager lookups wrote the buffers
+        torch.autograd.backward([block_out, fm_out, first_out], [g_block, g_fm, g_first])    # eager: back to the owners
+
+    ``fn`` receives detached leaves aliasing ``inputs``.  Parameter gradients are OVERWRITTEN by every replay (never
+    accumulated): do not set them to None between steps."""
+
+    def __init__(self, fn: Callable[..., torch.Tensor], inputs: Sequence[torch.Tensor], diff: Sequence[bool],
+                 params: Optional[Iterable[torch.nn.Parameter]] = None, warmup: int = 2):
+        if not all(t.is_cuda for t in inputs):
+            raise RuntimeError("GraphedRegion: inputs must live on the HIP device (no CPU path)")
+        if len(diff) != len(inputs):
+            raise ValueError("GraphedRegion: one ``diff`` flag per input")
+        self._fn = fn
+        self._inputs = list(inputs)
+        self._diff = [bool(d) for d in diff]
+        self._params = [p for p in (params or []) if p.requires_grad]
+        self._warmup = int(warmup)
+        self.loss = None
+        self.input_grads = None
+        self.recapture()
+
+    def _run(self):
+        leaves = [t.detach().requires_grad_() if d else t.detach() for t, d in zip(self._inputs, self._diff)]
+        loss = self._fn(*leaves)
+        wrt = [t for t, d in zip(leaves, self._diff) if d] + self._params
+        grads = list(torch.autograd.grad(loss, wrt, allow_unused=True))
+        gin, k = [], 0
+        for d in self._diff:
+            gin.append(grads[k] if d else None)
+            k += 1 if d else 0
+        return loss.detach(), gin, grads[k:]
+
+    def recapture(self):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(max(1, self._warmup)):
+                self._run()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        F_.clear_caches()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
+            self.loss, self.input_grads, pgrads = self._run()
+        torch.cuda.synchronize()
+        F_.clear_caches()
+        for p, g in zip(self._params, pgrads):
+            p.grad = g                     # static tensors of the graph's pool: refreshed in place by every replay
+
+    def __call__(self):
+        self._graph.replay()
+        return self.loss, self.input_grads
