@@ -331,16 +331,28 @@ int trs_mlp_fused_supported(int32_t num_layers, const int32_t* widths);
 #define TRS_MLP_FAMILY_AUTO 0
 #define TRS_MLP_FAMILY_TILE 1
 #define TRS_MLP_FAMILY_ROW_OWNER 2
+/* Phases.  Both entry points (and trs_rows_gemm) first copy the weights into MFMA fragment order in the workspace, then run.
+ * The copy depends on the parameters only, so a caller may take it off the critical path of its step:
+ *   phase = ALL : copy, then run (one call does everything);
+ *   phase = PACK: only the copy (+ zeroing of the workspace's partial sums) -- enqueue it on ANY stream as soon as the
+ *                 parameters are final, e.g. on a side stream at the start of the step; pointers to rows / outputs /
+ *                 masks may be NULL, `rows`, `widths`, `weights`, `biases`, `family` and the workspace must be the ones
+ *                 of the RUN call;
+ *   phase = RUN : the workspace holds what a PACK call with the same arguments left (the caller orders the two calls:
+ *                 same stream, or an event); nothing is copied.                                                       */
+#define TRS_MLP_PHASE_ALL 0
+#define TRS_MLP_PHASE_PACK 1
+#define TRS_MLP_PHASE_RUN 2
 int32_t trs_mlp_fused_family(int32_t num_layers, const int32_t* widths, int64_t rows, int32_t request);
 size_t trs_mlp_fused_workspace_bytes(int32_t num_layers, const int32_t* widths);
 size_t trs_mlp_fused_mask_bytes(int64_t rows);
 int trs_mlp_fused_fwd(const void* x, int64_t rows, int32_t num_layers, const int32_t* widths,
                       const void* const* weights, const void* const* biases, void* const* hidden, void* const* masks,
-                      void* mask_in, void* y, int32_t dtype, int32_t family, void* workspace, size_t ws_bytes,
-                      trs_stream_t stream);
+                      void* mask_in, void* y, int32_t dtype, int32_t family, int32_t phase, void* workspace,
+                      size_t ws_bytes, trs_stream_t stream);
 int trs_mlp_fused_bwd_data(const void* gy, int64_t rows, int32_t num_layers, const int32_t* widths,
                            const void* const* weights, const void* const* masks, void* const* gz, float* const* gbias,
-                           void* gx, const void* mask_in, float* gbias_in, int32_t dtype, int32_t family,
+                           void* gx, const void* mask_in, float* gbias_in, int32_t dtype, int32_t family, int32_t phase,
                            void* workspace, size_t ws_bytes, trs_stream_t stream);
 
 /* dst (rows, c_out) = [src (rows, c_in) | zeros], bf16: the gradient of the first c_in columns of a padded output (the
@@ -352,11 +364,12 @@ int trs_pad_cols(const void* src, int32_t c_in, void* dst, int32_t c_out, int64_
  * y (rows, in_f) = x[:, :out_f] @ W, x (rows, x_stride) and W (out_f, in_f) = nn.Linear(in_f, out_f).weight, bf16:
  * dL/d(input) of that layer from dL/d(pre-activation) (multilayer_perceptron.py:53-61 under autograd).  out_f <= 512
  * (a 128-row tile of x stays in LDS), in_f % 8 == 0, x_stride % 8 == 0 and >= out_f rounded up to 32 (the columns
- * past out_f meet zero weight rows).  workspace: trs_rows_gemm_workspace_bytes (fragment-order copy of W).           */
+ * past out_f meet zero weight rows).  workspace: trs_rows_gemm_workspace_bytes (fragment-order copy of W); phase:
+ * TRS_MLP_PHASE_* as above (PACK: x and y may be NULL).                                                              */
 size_t trs_rows_gemm_workspace_bytes(int32_t out_f, int32_t in_f);
 int trs_rows_gemm_supported(int32_t out_f, int32_t in_f, int32_t x_stride);
 int trs_rows_gemm(const void* x, int64_t rows, int32_t x_stride, const void* W, int32_t out_f, int32_t in_f,
-                  int32_t dtype, void* y, void* workspace, size_t ws_bytes, trs_stream_t stream);
+                  int32_t dtype, int32_t phase, void* y, void* workspace, size_t ws_bytes, trs_stream_t stream);
 
 /* ---- row-sharded tables (multi-GPU lookup) -----------------------------
  * Bucket the B*N global row ids of the local batch by owner rank (owner = id / rows_per_rank):

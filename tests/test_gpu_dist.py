@@ -293,7 +293,10 @@ def test_graphed_dense_region_behind_eager_sharded_lookups(pg):
         loss = head(xb, fm_t, ft, lab)
         loss.backward()
         torch.autograd.backward([eo, fm_o, fo], [xb.grad, fm_t.grad, ft.grad])
-        eager.append((float(loss), [p.grad.clone() for p in tables + dense]))
+        eager.append((float(loss.detach()), [p.grad.clone() for p in tables + dense]))
+    # no autograd graph of the eager steps may stay alive: the dense parameters' AccumulateGrad nodes would stay bound to
+    # this (legacy default) stream and the capture below would pull it in (GraphedRegion refuses that with an error)
+    del loss, xb, fm_t, ft, eo, fm_o, fo
     # the same buffers every step
     eo1, _, _ = lookups(batches[0][0])
     eo2, _, _ = lookups(batches[1][0])

@@ -329,4 +329,37 @@ def test_backward_refuses_a_family_the_forward_did_not_report(dev):
         with pytest.raises(RuntimeError, match="family"):
             F_.call("trs_mlp_fused_bwd_data", F_.ptr(gy), 512, 3, wl, F_._ptr_array(Ws), F_._ptr_array(masks),
                     F_._ptr_array(gz), F_._ptr_array(gb), F_.ptr(gx), F_.ptr(None), F_.ptr(None), F_._abi.TRS_BF16, bad,
-                    F_.ptr(ws), ws_bytes, F_.stream_ptr())
+                    F_.MLP_PHASE_ALL, F_.ptr(ws), ws_bytes, F_.stream_ptr())
+
+
+@pytest.mark.parametrize("widths,rows", [([32, 104, 200, 40], 700), ([416, 400, 400, 8], 3000)])
+@pytest.mark.parametrize("fam_req", [1, 2])
+def test_pack_and_run_phases_equal_the_one_call_form(dev, widths, rows, fam_req):
+    """C ABI phases: a PACK call (weights into fragment order, on a SIDE stream) followed by a RUN call on the packed
+    workspace gives bit for bit what the one-call form gives -- forward, data gradient, bias gradients, and trs_rows_gemm."""
+    from torecsys_amd import functional as F_
+    g = torch.Generator().manual_seed(5)
+    Ws, bs = _params(widths, g)
+    Ws, bs = [w.to(dev) for w in Ws], [b.to(dev) for b in bs]
+    x = torch.randn(rows, widths[0], generator=g).relu().bfloat16().to(dev)
+    gy = torch.randn(rows, widths[-1], generator=g).bfloat16().to(dev)
+    fam = F_.mlp_fused_family(widths, rows, fam_req)
+    y0, h0, m0, mi0, _ = F_.fused_mlp_forward_raw(x, Ws, bs, input_mask=True, family=fam)
+    ref_b = F_.fused_mlp_backward_raw(gy, widths, Ws, m0, mi0, family=fam)
+    (wsf, wsb), ev, side = F_.run_on_side(dev, "pack", lambda: (F_.fused_mlp_pack(Ws, bs, widths, rows, fam, False),
+                                                                F_.fused_mlp_pack(Ws, None, widths, rows, fam, True)))
+    torch.cuda.current_stream().wait_event(ev)
+    y1, h1, m1, mi1, _ = F_.fused_mlp_forward_raw(x, Ws, bs, input_mask=True, family=fam, packed_ws=wsf)
+    got_b = F_.fused_mlp_backward_raw(gy, widths, Ws, m1, mi1, family=fam, packed_ws=wsb)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1) and all(torch.equal(a, b) for a, b in zip(h0, h1))
+    assert torch.equal(ref_b[0], got_b[0]) and all(torch.equal(a, b) for a, b in zip(ref_b[1], got_b[1]))
+    for a, b in zip(list(ref_b[2]) + [ref_b[3]], list(got_b[2]) + [got_b[3]]):
+        assert torch.equal(a, b)
+    # the wide input gradient in front of such a stack
+    out_f, in_f = widths[0] - (16 if widths[0] == 416 else 0), 1024
+    W1 = (torch.randn(out_f, in_f, generator=g) * 0.05).bfloat16().to(dev)
+    gz = torch.randn(4096, widths[0], generator=g).bfloat16().to(dev)
+    if F_.rows_gemm_supported(gz, W1, out_f, in_f):
+        ws = F_.rows_gemm_pack(W1, 4096, widths[0], out_f, in_f)
+        assert torch.equal(F_.rows_gemm(gz, W1, out_f, in_f), F_.rows_gemm(gz, W1, out_f, in_f, packed_ws=ws))

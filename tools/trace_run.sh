@@ -8,3 +8,5 @@ cd /tmp && rm -rf /tmp/trc && rocprofv3 --kernel-trace --stats -d /tmp/trc -o t 
 cd "$R"
 db=$(find /tmp/trc -name "*.db" | head -1)
 python tools/prof_summary.py "$db" --out "$out" --title "$title" --cmd "rocprofv3 --kernel-trace --stats -- $*" ${TRS_TRACE_CALLS:+--calls "$TRS_TRACE_CALLS"}
+# TRS_TIMELINE=<file.md> [TRS_TIMELINE_ANCHOR=<kernel substring>]: one step of the same trace, launch by launch
+if [ -n "$TRS_TIMELINE" ]; then python tools/step_timeline.py "$db" --out "$TRS_TIMELINE" --title "$title -- one step" ${TRS_TIMELINE_ANCHOR:+--anchor "$TRS_TIMELINE_ANCHOR"}; fi

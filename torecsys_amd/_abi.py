@@ -66,7 +66,7 @@ SIGNATURES = {
     "trs_pad_cols": (c_int32, [_P, _I32, _P, _I32, _I64, _I32, _P]),
     "trs_rows_gemm_workspace_bytes": (_SZ, [_I32, _I32]),
     "trs_rows_gemm_supported": (c_int32, [_I32, _I32, _I32]),
-    "trs_rows_gemm": (c_int32, [_P, _I64, _I32, _P, _I32, _I32, _I32, _P, _P, _SZ, _P]),
+    "trs_rows_gemm": (c_int32, [_P, _I64, _I32, _P, _I32, _I32, _I32, _I32, _P, _P, _SZ, _P]),
     "trs_afm_bwd_workspace_bytes": (_SZ, [_I64, _I32, _I32, _I32]),
     "trs_afm_bwd": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _SZ, _P]),
     "trs_pack_columns": (c_int32, [_P, _P, _I32, _I32, _I64, _P, _I32, _P]),
@@ -116,8 +116,8 @@ SIGNATURES = {
     "trs_mlp_fused_family": (c_int32, [_I32, _P, _I64, _I32]),
     "trs_mlp_fused_workspace_bytes": (_SZ, [_I32, _P]),
     "trs_mlp_fused_mask_bytes": (_SZ, [_I64]),
-    "trs_mlp_fused_fwd": (c_int32, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _SZ, _P]),
-    "trs_mlp_fused_bwd_data": (c_int32, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _SZ, _P]),
+    "trs_mlp_fused_fwd": (c_int32, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _SZ, _P]),
+    "trs_mlp_fused_bwd_data": (c_int32, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _SZ, _P]),
     "trs_ctr_logit_fwd": (c_int32, [_P, _I32, _P, _I32, _P, _P, _I32, _P, _I64, _I32, _P, _P]),
     "trs_bce_logits_workspace_bytes": (_SZ, [_I64]),
     "trs_bce_logits_fwd": (c_int32, [_P, _I32, _P, _I32, _I64, _P, _P, _SZ, _P]),

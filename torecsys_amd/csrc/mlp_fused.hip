@@ -763,7 +763,7 @@ int mlp_resolve_family(int L, const int32_t* widths, int64_t rows, int request);
 size_t mlp_ro_mask_bytes(int64_t rows);
 int mlp_ro_fwd(const void* x, int64_t rows, int L, const int32_t* widths, const void* const* weights,
                const void* const* biases, void* const* hidden, void* const* masks, void* mask_in, void* y, void* workspace,
-               hipStream_t s);
+               hipStream_t s, int phase);
 struct RoColsum {
   const float* part[9];
   float* out[9];
@@ -772,7 +772,7 @@ struct RoColsum {
 };
 int mlp_ro_bwd(const void* gy, int64_t rows, int L, const int32_t* widths, const void* const* weights,
                const void* const* masks, void* const* gz, float* const* gbias, void* gx, const void* mask_in,
-               float* gbias_in, void* workspace, hipStream_t s, RoColsum* cs);
+               float* gbias_in, void* workspace, hipStream_t s, RoColsum* cs, int phase);
 
 static int mlp_act_str(int L, const int32_t* w) {
   int mx = 0;
@@ -817,11 +817,15 @@ extern "C" int trs_mlp_fused_supported(int32_t num_layers, const int32_t* widths
 extern "C" int trs_mlp_fused_fwd(const void* x, int64_t rows, int32_t num_layers, const int32_t* widths,
                                  const void* const* weights, const void* const* biases, void* const* hidden,
                                  void* const* masks, void* mask_in, void* y, int32_t dtype, int32_t family,
-                                 void* workspace, size_t ws_bytes, trs_stream_t stream) {
+                                 int32_t phase, void* workspace, size_t ws_bytes, trs_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   TRS_REQUIRE(dtype == TRS_BF16, TRS_EDTYPE, "mlp_fused_fwd: bf16 only");
   TRS_REQUIRE(trs_mlp_fused_supported(num_layers, widths), TRS_ESHAPE, "mlp_fused_fwd: unsupported layer widths");
-  TRS_REQUIRE(x && y && weights && biases && hidden && masks && workspace, TRS_EINVAL, "mlp_fused_fwd: NULL pointer");
+  TRS_REQUIRE(phase == TRS_MLP_PHASE_ALL || phase == TRS_MLP_PHASE_PACK || phase == TRS_MLP_PHASE_RUN, TRS_EINVAL,
+              "mlp_fused_fwd: phase %d", phase);
+  // (a PACK call reads the parameters only: the input rows may not exist yet)
+  TRS_REQUIRE(weights && biases && workspace && (phase == TRS_MLP_PHASE_PACK || (x && y && hidden && masks)), TRS_EINVAL,
+              "mlp_fused_fwd: NULL pointer");
   TRS_REQUIRE(ws_bytes >= trs_mlp_fused_workspace_bytes(num_layers, widths), TRS_EWORKSPACE,
               "mlp_fused_fwd: workspace too small");
   const int L = num_layers;
@@ -829,7 +833,7 @@ extern "C" int trs_mlp_fused_fwd(const void* x, int64_t rows, int32_t num_layers
   TRS_REQUIRE(fam != 0, TRS_EINVAL, "mlp_fused_fwd: kernel family %d is not available for this stack (trs_mlp_fused_family)", family);
   if (rows == 0) return TRS_OK;
   if (fam == TRS_MLP_FAMILY_ROW_OWNER)
-    return mlp_ro_fwd(x, rows, L, widths, weights, biases, hidden, masks, mask_in, y, workspace, s);
+    return mlp_ro_fwd(x, rows, L, widths, weights, biases, hidden, masks, mask_in, y, workspace, s, phase);
   MlpArgs a;
   a.nsteps = L;
   a.in = x;
@@ -858,14 +862,15 @@ extern "C" int trs_mlp_fused_fwd(const void* x, int64_t rows, int32_t num_layers
     st.K = K;
     st.N = N;
     st.relu = l + 1 < L ? 1 : 0;
-    st.out = l + 1 < L ? hidden[l] : y;
+    st.out = phase == TRS_MLP_PHASE_PACK ? nullptr : (l + 1 < L ? hidden[l] : y);
     st.out_stride = l + 1 < L ? N : widths[L];
-    st.mask = l + 1 < L ? (uint8_t*)masks[l] : nullptr;
+    st.mask = (l + 1 < L && phase != TRS_MLP_PHASE_PACK) ? (uint8_t*)masks[l] : nullptr;
     st.colsum = nullptr;
     woff += (size_t)K * N * 2;
     boff += N;
   }
-  hipLaunchKernelGGL(mlp_prepack_many_kernel, dim3(pk_blocks, L), dim3(256), 0, s, pk);
+  if (phase != TRS_MLP_PHASE_RUN) hipLaunchKernelGGL(mlp_prepack_many_kernel, dim3(pk_blocks, L), dim3(256), 0, s, pk);
+  if (phase == TRS_MLP_PHASE_PACK) return check_launch("mlp_fused_fwd(pack)");
   a.nbias = (int)boff;
   const size_t lds = (size_t)MF_ROWS * a.act_str + boff * 4;
   static bool attr = false;
@@ -885,11 +890,15 @@ extern "C" int trs_mlp_fused_fwd(const void* x, int64_t rows, int32_t num_layers
 extern "C" int trs_mlp_fused_bwd_data(const void* gy, int64_t rows, int32_t num_layers, const int32_t* widths,
                                       const void* const* weights, const void* const* masks, void* const* gz,
                                       float* const* gbias, void* gx, const void* mask_in, float* gbias_in, int32_t dtype,
-                                      int32_t family, void* workspace, size_t ws_bytes, trs_stream_t stream) {
+                                      int32_t family, int32_t phase, void* workspace, size_t ws_bytes,
+                                      trs_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   TRS_REQUIRE(dtype == TRS_BF16, TRS_EDTYPE, "mlp_fused_bwd_data: bf16 only");
   TRS_REQUIRE(trs_mlp_fused_supported(num_layers, widths), TRS_ESHAPE, "mlp_fused_bwd_data: unsupported layer widths");
-  TRS_REQUIRE(gy && weights && masks && gz && gbias && workspace, TRS_EINVAL, "mlp_fused_bwd_data: NULL pointer");
+  TRS_REQUIRE(phase == TRS_MLP_PHASE_ALL || phase == TRS_MLP_PHASE_PACK || phase == TRS_MLP_PHASE_RUN, TRS_EINVAL,
+              "mlp_fused_bwd_data: phase %d", phase);
+  const bool pack_only = phase == TRS_MLP_PHASE_PACK;      // reads the parameters only: no gradient exists yet
+  TRS_REQUIRE(weights && workspace && (pack_only || (gy && masks && gz && gbias)), TRS_EINVAL, "mlp_fused_bwd_data: NULL pointer");
   TRS_REQUIRE(ws_bytes >= trs_mlp_fused_workspace_bytes(num_layers, widths), TRS_EWORKSPACE,
               "mlp_fused_bwd_data: workspace too small");
   const int L = num_layers;
@@ -898,10 +907,10 @@ extern "C" int trs_mlp_fused_bwd_data(const void* gy, int64_t rows, int32_t num_
   TRS_REQUIRE((family == TRS_MLP_FAMILY_TILE || family == TRS_MLP_FAMILY_ROW_OWNER) &&
                   mlp_resolve_family(L, widths, rows, family) == family,
               TRS_EINVAL, "mlp_fused_bwd_data: family must be the TILE / ROW_OWNER value the forward ran under (got %d)", family);
-  TRS_REQUIRE(family != TRS_MLP_FAMILY_ROW_OWNER || gx != nullptr, TRS_EINVAL, "mlp_fused_bwd_data: the row-owner kernels need gx");
-  TRS_REQUIRE((mask_in == nullptr) == (gbias_in == nullptr) && (mask_in == nullptr || (L + 1 <= MF_MAXL && gx != nullptr)),
+  TRS_REQUIRE(pack_only || family != TRS_MLP_FAMILY_ROW_OWNER || gx != nullptr, TRS_EINVAL, "mlp_fused_bwd_data: the row-owner kernels need gx");
+  TRS_REQUIRE(pack_only || ((mask_in == nullptr) == (gbias_in == nullptr) && (mask_in == nullptr || (L + 1 <= MF_MAXL && gx != nullptr))),
               TRS_EINVAL, "mlp_fused_bwd_data: mask_in and gbias_in come together (and with gx, at most %d layers)", MF_MAXL - 1);
-  if (rows == 0) {
+  if (rows == 0 && !pack_only) {
     for (int l = 0; l < L; ++l)
       if (int rc = zero_bytes(gbias[l], (size_t)pad32(widths[l + 1]) * 4, s)) return rc;
     if (gbias_in) return zero_bytes(gbias_in, (size_t)pad32(widths[0]) * 4, s);
@@ -909,8 +918,8 @@ extern "C" int trs_mlp_fused_bwd_data(const void* gy, int64_t rows, int32_t num_
   }
   if (family == TRS_MLP_FAMILY_ROW_OWNER) {
     RoColsum rc;
-    const int rcode = mlp_ro_bwd(gy, rows, L, widths, weights, masks, gz, gbias, gx, mask_in, gbias_in, workspace, s, &rc);
-    if (rcode != TRS_OK) return rcode;
+    const int rcode = mlp_ro_bwd(gy, rows, L, widths, weights, masks, gz, gbias, gx, mask_in, gbias_in, workspace, s, &rc, phase);
+    if (rcode != TRS_OK || pack_only) return rcode;
     MlpColsumArgs cs;
     cs.nparts = rc.nparts;
     int kmax = 0;
@@ -950,9 +959,9 @@ extern "C" int trs_mlp_fused_bwd_data(const void* gy, int64_t rows, int32_t num_
     st.K = K;
     st.N = N;
     st.relu = 0;
-    st.out = l > 0 ? gz[l - 1] : gx;
+    st.out = pack_only ? nullptr : (l > 0 ? gz[l - 1] : gx);
     st.out_stride = l > 0 ? N : widths[0];
-    st.mask = l > 0 ? (uint8_t*)masks[l - 1] : (uint8_t*)mask_in;
+    st.mask = pack_only ? nullptr : (l > 0 ? (uint8_t*)masks[l - 1] : (uint8_t*)mask_in);
     st.colsum = part_base + poff;
     woff += (size_t)K * N * 2;
     poff += (size_t)grid * K;
@@ -967,7 +976,8 @@ extern "C" int trs_mlp_fused_bwd_data(const void* gy, int64_t rows, int32_t num_
       return check_launch("mlp_fused_bwd_data: LDS attribute");
     attr = true;
   }
-  hipLaunchKernelGGL(mlp_prepack_many_kernel, dim3(pk_blocks, L), dim3(256), 0, s, pk);
+  if (phase != TRS_MLP_PHASE_RUN) hipLaunchKernelGGL(mlp_prepack_many_kernel, dim3(pk_blocks, L), dim3(256), 0, s, pk);
+  if (pack_only) return check_launch("mlp_fused_bwd_data(pack)");
   hipLaunchKernelGGL(mlp_fused_bwd_kernel, dim3(grid), dim3(64 * MF_WAVES), lds, s, a);
   MlpColsumArgs cs;
   cs.nparts = grid;
@@ -1006,19 +1016,23 @@ extern "C" int trs_rows_gemm_supported(int32_t out_f, int32_t in_f, int32_t x_st
 }
 
 extern "C" int trs_rows_gemm(const void* x, int64_t rows, int32_t x_stride, const void* W, int32_t out_f, int32_t in_f,
-                             int32_t dtype, void* y, void* workspace, size_t ws_bytes, trs_stream_t stream) {
+                             int32_t dtype, int32_t phase, void* y, void* workspace, size_t ws_bytes, trs_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   TRS_REQUIRE(dtype == TRS_BF16, TRS_EDTYPE, "rows_gemm: bf16 only");
   TRS_REQUIRE(trs_rows_gemm_supported(out_f, in_f, x_stride), TRS_ESHAPE, "rows_gemm: unsupported shape (K %d, N %d)", out_f, in_f);
-  TRS_REQUIRE(x && W && y && workspace, TRS_EINVAL, "rows_gemm: NULL pointer");
+  TRS_REQUIRE(phase == TRS_MLP_PHASE_ALL || phase == TRS_MLP_PHASE_PACK || phase == TRS_MLP_PHASE_RUN, TRS_EINVAL, "rows_gemm: phase %d", phase);
+  const bool pack_only = phase == TRS_MLP_PHASE_PACK;
+  TRS_REQUIRE(W && workspace && (pack_only || (x && y)), TRS_EINVAL, "rows_gemm: NULL pointer");
   TRS_REQUIRE(ws_bytes >= trs_rows_gemm_workspace_bytes(out_f, in_f), TRS_EWORKSPACE, "rows_gemm: workspace too small");
   TRS_REQUIRE(aligned16(x) && aligned16(y) && aligned16(workspace), TRS_EALIGN, "rows_gemm: 16-byte alignment");
-  if (rows == 0) return TRS_OK;
+  if (rows == 0 && !pack_only) return TRS_OK;
   const int K = pad32(out_f), N = pad32(in_f);
   MlpPackArgs pk;
   pk.transpose = 1;
   pk.job[0] = MlpPackJob{(const bf16_t*)W, nullptr, (bf16_t*)workspace, nullptr, out_f, in_f, N / 16, K / 32, 0};
-  hipLaunchKernelGGL(mlp_prepack_many_kernel, dim3(std::min(256, (N / 16 * (K / 32) * 64 + 255) / 256), 1), dim3(256), 0, s, pk);
+  if (phase != TRS_MLP_PHASE_RUN)
+    hipLaunchKernelGGL(mlp_prepack_many_kernel, dim3(std::min(256, (N / 16 * (K / 32) * 64 + 255) / 256), 1), dim3(256), 0, s, pk);
+  if (pack_only) return check_launch("rows_gemm(pack)");
   RowsGemmArgs a;
   a.in = x;
   a.wf = (const uint4*)workspace;

@@ -85,7 +85,8 @@ size_t mlp_ro_mask_bytes(int64_t rows) { return (size_t)((rows + RO_ROWS - 1) / 
 // same contract as trs_mlp_fused_fwd (mlp_fused.hip), which hands over after its argument checks
 int mlp_ro_fwd(const void* x, int64_t rows, int L, const int32_t* widths, const void* const* weights,
                const void* const* biases, void* const* hidden, void* const* masks, void* mask_in, void* y, void* workspace,
-               hipStream_t s) {
+               hipStream_t s, int phase) {
+  const bool pack_only = phase == TRS_MLP_PHASE_PACK;
   RoArgs a;
   a.in = (const char*)x;
   a.in_stride = widths[0];
@@ -109,15 +110,16 @@ int mlp_ro_fwd(const void* x, int64_t rows, int L, const int32_t* widths, const 
     pk_blocks = std::max(pk_blocks, std::min(256, (N / 32 * KS * 64 + 255) / 256));
     RoLayer& ly = a.layer[l];
     ly.wf = wsp + woff;
-    ly.out = (char*)(l + 1 < L ? hidden[l] : y);
+    ly.out = pack_only ? nullptr : (char*)(l + 1 < L ? hidden[l] : y);
     ly.out_stride = l + 1 < L ? N : widths[L];
     ly.out_cols = l + 1 < L ? N : widths[L];
-    ly.mask = l + 1 < L ? (uint32_t*)masks[l] : nullptr;
+    ly.mask = (l + 1 < L && !pack_only) ? (uint32_t*)masks[l] : nullptr;
     ly.colsum = nullptr;
     woff += (size_t)(N / 32) * KS * 1024;
     boff += N;
   }
-  hipLaunchKernelGGL(mlp_ro_prepack_kernel, dim3(pk_blocks, L), dim3(256), 0, s, pk);
+  if (phase != TRS_MLP_PHASE_RUN) hipLaunchKernelGGL(mlp_ro_prepack_kernel, dim3(pk_blocks, L), dim3(256), 0, s, pk);
+  if (pack_only) return check_launch("mlp_ro_fwd(pack)");
   return ro_matches<RoDcn>(L, widths, false) ? ro_launch_dcn_fwd(a, s) : ro_launch_tail_fwd(a, s);
 }
 
@@ -126,7 +128,8 @@ int mlp_ro_fwd(const void* x, int64_t rows, int L, const int32_t* widths, const 
 // partial column sums listed in ``cs`` afterwards (its reduction kernel)
 int mlp_ro_bwd(const void* gy, int64_t rows, int L, const int32_t* widths, const void* const* weights,
                const void* const* masks, void* const* gz, float* const* gbias, void* gx, const void* mask_in,
-               float* gbias_in, void* workspace, hipStream_t s, RoColsum* cs) {
+               float* gbias_in, void* workspace, hipStream_t s, RoColsum* cs, int phase) {
+  const bool pack_only = phase == TRS_MLP_PHASE_PACK;
   RoArgs a;
   a.in = (const char*)gy;
   a.in_stride = widths[L];
@@ -150,7 +153,7 @@ int mlp_ro_bwd(const void* gy, int64_t rows, int L, const int32_t* widths, const
   // the input rows' column sums: the last layer's bias gradient
   a.colsum_in = part_base + poff;
   cs->part[cs->count] = a.colsum_in;
-  cs->out[cs->count] = gbias[L - 1];
+  cs->out[cs->count] = pack_only ? nullptr : gbias[L - 1];
   cs->n[cs->count++] = ro_pad32(widths[L]);
   poff += (size_t)nparts * ro_pad32(widths[L]);
   for (int sidx = 0; sidx < L; ++sidx) {
@@ -160,22 +163,26 @@ int mlp_ro_bwd(const void* gy, int64_t rows, int L, const int32_t* widths, const
     pk_blocks = std::max(pk_blocks, std::min(256, (N / 32 * KS * 64 + 255) / 256));
     RoLayer& ly = a.layer[sidx];
     ly.wf = wsp + woff;
-    ly.out = (char*)(l > 0 ? gz[l - 1] : gx);
+    ly.out = pack_only ? nullptr : (char*)(l > 0 ? gz[l - 1] : gx);
     ly.out_stride = l > 0 ? N : widths[0];
     ly.out_cols = l > 0 ? N : widths[0];
-    ly.mask = (uint32_t*)(l > 0 ? masks[l - 1] : mask_in);
+    ly.mask = pack_only ? nullptr : (uint32_t*)(l > 0 ? masks[l - 1] : mask_in);
     ly.colsum = nullptr;
-    if (l > 0 || mask_in != nullptr) {
+    if (l > 0 || mask_in != nullptr || pack_only) {      // (a PACK call zeroes the input sums' slice whether or not it will be used)
       ly.colsum = part_base + poff;
       cs->part[cs->count] = ly.colsum;
-      cs->out[cs->count] = l > 0 ? gbias[l - 1] : gbias_in;
+      cs->out[cs->count] = pack_only ? nullptr : (l > 0 ? gbias[l - 1] : gbias_in);
       cs->n[cs->count++] = N;
       poff += (size_t)nparts * N;
     }
     woff += (size_t)(N / 32) * KS * 1024;
   }
-  if (int rc = zero_bytes(part_base, poff * 4, s)) return rc;
-  hipLaunchKernelGGL(mlp_ro_prepack_kernel, dim3(pk_blocks, L), dim3(256), 0, s, pk);
+  // (the partial column sums are accumulated by atomics: zeroed with the weights, i.e. in a PACK call when there is one)
+  if (phase != TRS_MLP_PHASE_RUN) {
+    if (int rc = zero_bytes(part_base, poff * 4, s)) return rc;
+    hipLaunchKernelGGL(mlp_ro_prepack_kernel, dim3(pk_blocks, L), dim3(256), 0, s, pk);
+  }
+  if (pack_only) return check_launch("mlp_ro_bwd(pack)");
   return ro_matches<RoDcn>(L, widths, false) ? ro_launch_dcn_bwd(a, s) : ro_launch_tail_bwd(a, s);
 }
 

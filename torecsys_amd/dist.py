@@ -572,7 +572,7 @@ class _ShardedLookup(Function):
                               block if mod.fuse_fm else None, fm_sum, back if mod.dedup else None)
         ctx.set_materialize_grads(False)
         if fm is None:
-            fm = block.new_empty(0)
+            fm = torch.empty(0, dtype=block.dtype, device=block.device)
             ctx.mark_non_differentiable(fm)
         return block, fm
 
@@ -691,7 +691,9 @@ class RowShardedMultiIndicesEmbedding(BaseInput):
             if len(self._out_bufs) >= 4:
                 self._out_bufs.clear()
             bufs = self._out_bufs[key] = (block, fm, fm_sum)
-        return bufs
+        # fresh aliases every call: the caller's tensor objects receive names / a grad_fn (forward sets ``out.names``), the
+        # buffers themselves must stay plain
+        return tuple(None if t is None else t.view(t.shape) for t in bufs)
 
     def slot_capacity(self, lookups: int) -> int:
         """slots per peer of a fixed-capacity exchange of ``lookups`` = B*N row ids (a multiple of 64).  Equal splits

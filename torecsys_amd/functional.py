@@ -98,6 +98,46 @@ SIDE_STREAM_PRIORITY = int(os.environ.get("TRS_SIDE_STREAM_PRIORITY", "0"))
 PREFETCH_EARLY = os.environ.get("TRS_PREFETCH_EARLY", "0") not in ("", "0")
 
 
+def side_stream(dev: torch.device, role: str) -> torch.cuda.Stream:
+    """The per-device side stream of a ROLE: "buckets" (row-bucket builds, beside the dense forward), "lookup" (the
+    lookups of a batch beyond the first, beside it -- and, because autograd runs a node's backward on its forward's stream,
+    their bucket walks beside the first one's), "pack" (weight copies into MFMA fragment order, beside the first GEMM of
+    a deep branch).  One stream per role: work of one role must never queue behind another's (a weight copy behind a
+    bucket build would stall the main stream for the whole build)."""
+    side = _side_streams.get((dev, role))
+    if side is None:
+        side = _side_streams[(dev, role)] = torch.cuda.Stream(device=dev, priority=SIDE_STREAM_PRIORITY)
+    return side
+
+
+def run_on_side(dev: torch.device, role: str, fn):
+    """Enqueue ``fn()`` on the role's side stream behind everything the current stream holds so far; returns (result,
+    event recorded behind it, the side stream).  The caller makes the consumer's stream wait for the event and tells the
+    allocator about tensors that cross (record_stream).  Capture-safe: the side stream forks from the current stream and
+    the event wait joins it again."""
+    side = side_stream(dev, role)
+    main = _abi.current_stream_of(dev)
+    side.wait_stream(main)
+    torch.cuda.set_stream(side)      # (not ``with torch.cuda.stream``: see prefetch_row_buckets)
+    try:
+        out = fn()
+    finally:
+        torch.cuda.set_stream(main)
+    ev = torch.cuda.Event()
+    ev.record(side)
+    return out, ev, side
+
+
+def _adopt_grads(*grads):
+    """A lookup's backward runs on the stream of its forward -- the "lookup" side stream for every lookup of a batch but the
+    first -- while the gradients it receives were allocated (and will be freed) under the producer's stream: tell the
+    allocator.  No-op until a side lookup has happened."""
+    for g in grads:
+        if g is not None and g.is_cuda and (g.device, "lookup") in _side_streams:
+            cur = _abi.current_stream_of(g.device)
+            (g.rename(None) if g.has_names() else g).record_stream(cur)
+
+
 _offsets_content = {}     # offsets tensor (ptr, version) -> tuple of its values (read back once)
 
 
@@ -193,9 +233,7 @@ def prefetch_row_buckets(idx: torch.Tensor, offsets: Optional[torch.Tensor], V: 
         if k == key:
             return
     dev = idx.device
-    side = _side_streams.get(dev)
-    if side is None:
-        side = _side_streams[dev] = torch.cuda.Stream(device=dev, priority=SIDE_STREAM_PRIORITY)
+    side = side_stream(dev, "buckets")
     main = _abi.current_stream_of(dev)
     side.wait_stream(main)
     torch.cuda.set_stream(side)          # not `with torch.cuda.stream(side)`: its constructor and __enter__ each resolve
@@ -402,6 +440,7 @@ class _GatherRows(Function):
     @once_differentiable
     def backward(ctx, g):
         idx, offsets, weight = ctx.saved_tensors
+        _adopt_grads(g)
         rb = row_buckets(idx, offsets, weight.shape[0])
         if g.dim() == 3 and g.shape[1] > 1 and g.stride(1) == 0:
             # the same gradient row for every field of a sample (the backward of a sum over the fields, e.g. the models'
@@ -478,6 +517,7 @@ class _EmbedFM(Function):
     @once_differentiable
     def backward(ctx, g_emb, g_fm, g_first):
         idx, offsets, weight, first_weight, fm_sum = ctx.saved_tensors
+        _adopt_grads(g_emb, g_fm, g_first)
         V, E = weight.shape
         rb = row_buckets(idx, offsets, V)
         gw = gfw = None
@@ -615,6 +655,7 @@ class _FAGather(Function):
     @once_differentiable
     def backward(ctx, g):
         idx, offsets, *weights = ctx.saved_tensors
+        _adopt_grads(g)
         B, N = idx.shape
         V, E = weights[0].shape
         g = g.contiguous()
@@ -703,6 +744,7 @@ class _EmbedIPN(Function):
     @once_differentiable
     def backward(ctx, g_emb, g_out):
         idx, offsets, weight, emb = ctx.saved_tensors
+        _adopt_grads(g_emb, g_out)
         V, E = weight.shape
         B, N = idx.shape
         g_rows = None
@@ -1690,8 +1732,30 @@ def mlp_fused_family(widths: Sequence[int], rows: int, request: Optional[int] = 
     return fam
 
 
+MLP_PHASE_ALL, MLP_PHASE_PACK, MLP_PHASE_RUN = 0, 1, 2
+
+
+def fused_mlp_pack(Ws: Sequence[torch.Tensor], bs: Optional[Sequence[torch.Tensor]], widths: Sequence[int], rows: int,
+                   family: int, backward: bool) -> torch.Tensor:
+    """The PACK phase of trs_mlp_fused_fwd / _bwd_data on the current stream: the weights in MFMA fragment order (and the
+    zeroed partial sums) in a fresh workspace, which the matching ``fused_mlp_*_raw(packed_ws=...)`` call then runs on.
+    Depends on the parameters only -- callers enqueue it on a side stream while the layer in front of the stack runs."""
+    L = len(Ws)
+    wl = _i32_array(widths)
+    ws_bytes = size_query("trs_mlp_fused_workspace_bytes", L, wl)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=Ws[0].device)
+    if backward:
+        call("trs_mlp_fused_bwd_data", ptr(None), rows, L, wl, _ptr_array(Ws), ptr(None), ptr(None), ptr(None), ptr(None),
+             ptr(None), ptr(None), _abi.TRS_BF16, int(family), MLP_PHASE_PACK, ptr(ws), ws_bytes, stream_ptr())
+    else:
+        call("trs_mlp_fused_fwd", ptr(None), rows, L, wl, _ptr_array(Ws), _ptr_array(bs), ptr(None), ptr(None), ptr(None),
+             ptr(None), _abi.TRS_BF16, int(family), MLP_PHASE_PACK, ptr(ws), ws_bytes, stream_ptr())
+    return ws
+
+
 def fused_mlp_forward_raw(x2: torch.Tensor, Ws: Sequence[torch.Tensor], bs: Sequence[torch.Tensor],
-                          input_mask: bool = False, family: Optional[int] = None):
+                          input_mask: bool = False, family: Optional[int] = None,
+                          packed_ws: Optional[torch.Tensor] = None):
     """trs_mlp_fused_fwd on rows x2 (rows, widths[0]): returns (y (rows, widths[L]), hidden [(rows, pad32(w))] -- the
     ReLU outputs of the hidden layers, zero in the padding columns --, masks [the sign bits of the hidden layers in the
     kernel's own order: opaque bytes for trs_mlp_fused_bwd_data], [with ``input_mask`` (x2 is itself a ReLU output): the
@@ -1707,17 +1771,21 @@ def fused_mlp_forward_raw(x2: torch.Tensor, Ws: Sequence[torch.Tensor], bs: Sequ
     mask_in = torch.empty(mask_bytes, dtype=torch.uint8, device=dev) if input_mask else None
     y = torch.empty(rows, widths[L], dtype=torch.bfloat16, device=dev)
     wl = _i32_array(widths)
-    ws_bytes = size_query("trs_mlp_fused_workspace_bytes", L, wl)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    if packed_ws is not None:      # fused_mlp_pack(..., family=fam) ran before (the caller ordered the two)
+        ws, ws_bytes, phase = packed_ws, packed_ws.numel(), MLP_PHASE_RUN
+    else:
+        ws_bytes = size_query("trs_mlp_fused_workspace_bytes", L, wl)
+        ws, phase = torch.empty(ws_bytes, dtype=torch.uint8, device=dev), MLP_PHASE_ALL
     call("trs_mlp_fused_fwd", ptr(x2), rows, L, wl, _ptr_array(Ws), _ptr_array(bs), _ptr_array(hidden),
-         _ptr_array(masks), ptr(mask_in), ptr(y), _abi.TRS_BF16, fam, ptr(ws), ws_bytes, stream_ptr())
+         _ptr_array(masks), ptr(mask_in), ptr(y), _abi.TRS_BF16, fam, phase, ptr(ws), ws_bytes, stream_ptr())
     if input_mask:
         return y, hidden, masks, mask_in, fam
     return y, hidden, masks, fam
 
 
 def fused_mlp_backward_raw(gy2: torch.Tensor, widths: Sequence[int], Ws: Sequence[torch.Tensor],
-                           masks: Sequence[torch.Tensor], mask_in: Optional[torch.Tensor] = None, *, family: int):
+                           masks: Sequence[torch.Tensor], mask_in: Optional[torch.Tensor] = None, *, family: int,
+                           packed_ws: Optional[torch.Tensor] = None):
     """trs_mlp_fused_bwd_data: (gx, gz [d(pre-activation) of the hidden layers], gb [fp32 bias gradients, padded]) and,
     with ``mask_in``, gb_in: gx is then masked by the upstream ReLU and gb_in holds its column sums.  ``family``: what
     fused_mlp_forward_raw returned with these masks."""
@@ -1730,10 +1798,14 @@ def fused_mlp_backward_raw(gy2: torch.Tensor, widths: Sequence[int], Ws: Sequenc
     gx = torch.empty(rows, widths[0], dtype=torch.bfloat16, device=dev)   # the kernel always writes dL/dx (its last GEMM)
     gb_in = torch.empty(_pad32(widths[0]), dtype=torch.float32, device=dev) if mask_in is not None else None
     wl = _i32_array(widths)
-    ws_bytes = size_query("trs_mlp_fused_workspace_bytes", L, wl)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    if packed_ws is not None:
+        ws, ws_bytes, phase = packed_ws, packed_ws.numel(), MLP_PHASE_RUN
+    else:
+        ws_bytes = size_query("trs_mlp_fused_workspace_bytes", L, wl)
+        ws, phase = torch.empty(ws_bytes, dtype=torch.uint8, device=dev), MLP_PHASE_ALL
     call("trs_mlp_fused_bwd_data", ptr(gy2), rows, L, wl, _ptr_array(Ws), _ptr_array(masks), _ptr_array(gz),
-         _ptr_array(gb), ptr(gx), ptr(mask_in), ptr(gb_in), _abi.TRS_BF16, int(family), ptr(ws), ws_bytes, stream_ptr())
+         _ptr_array(gb), ptr(gx), ptr(mask_in), ptr(gb_in), _abi.TRS_BF16, int(family), phase, ptr(ws), ws_bytes,
+         stream_ptr())
     return gx, gz, gb, gb_in
 
 
@@ -1786,22 +1858,42 @@ ROWS_GEMM = os.environ.get("TRS_ROWS_GEMM", "1") not in ("", "0")
 ROWS_GEMM_MIN_COLS = 1024       # narrower outputs: the library GEMM is as fast
 
 
+def rows_gemm_supported_for(rows: int, x_stride: int, W: torch.Tensor, out_f: int, in_f: int) -> bool:
+    """rows_gemm_supported for a contiguous bf16 (rows, x_stride) gradient that does not exist yet"""
+    if not (ROWS_GEMM and W.is_cuda and W.dtype == torch.bfloat16 and W.is_contiguous() and rows >= 4096
+            and in_f >= ROWS_GEMM_MIN_COLS and W.shape[1] == in_f and W.shape[0] >= out_f):
+        return False
+    return bool(_abi.load().trs_rows_gemm_supported(int(out_f), int(in_f), int(x_stride)))
+
+
 def rows_gemm_supported(g: torch.Tensor, W: torch.Tensor, out_f: int, in_f: int) -> bool:
     """dL/dx = g[:, :out_f] @ W[:out_f] by trs_rows_gemm: bf16 on the device, a short contraction (out_f <= 512) and a
     wide result (the 2496 embedding columns in front of a deep branch), enough rows to fill the chip"""
-    if not (ROWS_GEMM and g.is_cuda and g.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and g.dim() == 2
-            and g.is_contiguous() and W.is_contiguous() and g.shape[0] >= 4096 and in_f >= ROWS_GEMM_MIN_COLS
-            and W.shape[1] == in_f and W.shape[0] >= out_f):
+    if not (g.is_cuda and g.dtype == torch.bfloat16 and g.dim() == 2 and g.is_contiguous()):
         return False
-    return bool(_abi.load().trs_rows_gemm_supported(int(out_f), int(in_f), int(g.shape[1])))
+    return rows_gemm_supported_for(g.shape[0], g.shape[1], W, out_f, in_f)
 
 
-def rows_gemm(g: torch.Tensor, W: torch.Tensor, out_f: int, in_f: int) -> torch.Tensor:
-    y = torch.empty(g.shape[0], in_f, dtype=torch.bfloat16, device=g.device)
+def rows_gemm_pack(W: torch.Tensor, rows: int, x_stride: int, out_f: int, in_f: int) -> torch.Tensor:
+    """The PACK phase of trs_rows_gemm on the current stream (see fused_mlp_pack): W in fragment order in a fresh
+    workspace for ``rows_gemm(..., packed_ws=...)``"""
     ws_bytes = size_query("trs_rows_gemm_workspace_bytes", out_f, in_f)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=g.device)
-    call("trs_rows_gemm", ptr(g), g.shape[0], g.shape[1], ptr(W), out_f, in_f, _abi.TRS_BF16, ptr(y), ptr(ws), ws_bytes,
-         stream_ptr())
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=W.device)
+    call("trs_rows_gemm", ptr(None), rows, x_stride, ptr(W), out_f, in_f, _abi.TRS_BF16, MLP_PHASE_PACK, ptr(None), ptr(ws),
+         ws_bytes, stream_ptr())
+    return ws
+
+
+def rows_gemm(g: torch.Tensor, W: torch.Tensor, out_f: int, in_f: int,
+              packed_ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+    y = torch.empty(g.shape[0], in_f, dtype=torch.bfloat16, device=g.device)
+    if packed_ws is not None:
+        ws, ws_bytes, phase = packed_ws, packed_ws.numel(), MLP_PHASE_RUN
+    else:
+        ws_bytes = size_query("trs_rows_gemm_workspace_bytes", out_f, in_f)
+        ws, phase = torch.empty(ws_bytes, dtype=torch.uint8, device=g.device), MLP_PHASE_ALL
+    call("trs_rows_gemm", ptr(g), g.shape[0], g.shape[1], ptr(W), out_f, in_f, _abi.TRS_BF16, phase, ptr(y), ptr(ws),
+         ws_bytes, stream_ptr())
     return y
 
 

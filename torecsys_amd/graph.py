@@ -144,11 +144,21 @@ class GraphedRegion:
     def recapture(self):
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(max(1, self._warmup)):
-                self._run()
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            with torch.cuda.stream(s):
+                for _ in range(max(1, self._warmup)):
+                    self._run()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        for w in caught:
+            if "AccumulateGrad node's stream does not match" in str(w.message):
+                # (same hazard as GraphedStep: hipStreamEndCapture crashes when the legacy default stream is pulled in)
+                raise RuntimeError(
+                    "GraphedRegion: an autograd graph of an earlier eager step is still alive (a loss or output tensor "
+                    "is still referenced), so the parameters' AccumulateGrad nodes are bound to that step's stream. "
+                    "Drop those references (del loss) before capturing.")
+            warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
         F_.clear_caches()
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):

@@ -200,6 +200,10 @@ class ValueInput(BaseInput):
 PAIR_FIRST_ORDER = os.environ.get("TRS_PAIR_FIRST_ORDER", "0") == "1"
 
 
+LOOKUP_STREAMS = os.environ.get("TRS_LOOKUP_STREAMS", "1") not in ("", "0")
+_SIDE_LOOKUPS = (SingleIndexEmbedding, MultiIndicesEmbedding, MultiIndicesFieldAwareEmbedding)
+
+
 class Inputs(BaseInput):
     """Dictionary router, inputs/inputs.py:56-89: for every schema entry gather its named columns,
     ``unsqueeze`` 1-D ones, ``cat`` on dim 1 and call the embedding module.  Integer columns on the HIP device are
@@ -257,6 +261,8 @@ class Inputs(BaseInput):
             p = self._first_order_partner(k)
             if p is not None and p not in partner:
                 partner[p] = k
+        joins = []                     # (event, output) of lookups enqueued on the "lookup" side stream
+        first_lookup = True
         with F_.defer_prefetch():      # row-bucket builds start once every lookup of the batch is enqueued
             for k, emb_fn in self.schema.items():
                 if k in outputs:       # a first-order table already served by its partner's pass
@@ -291,8 +297,28 @@ class Inputs(BaseInput):
                     first.names = ('B', 'N', 'E',)
                     outputs[k] = out
                     outputs[feat_key] = first
+                elif (LOOKUP_STREAMS and not first_lookup and type(emb_fn) in _SIDE_LOOKUPS
+                      and isinstance(inp_args[0], torch.Tensor) and inp_args[0].is_cuda):
+                    # The lookups of a batch are independent of each other: every one after the first goes onto the
+                    # "lookup" side stream and runs beside it (the E = 1 first-order table of an FM-family model beside
+                    # the E = 64 lookup: 17 us off the critical path).  Autograd runs a node's backward on the stream of
+                    # its forward, so the bucket walk of that table (one walk and four small launches, ~45 us) also runs
+                    # beside the wide table's walk instead of behind it.  TRS_LOOKUP_STREAMS=0: everything in order.
+                    idx_t = inp_args[0]
+                    out, ev, side = F_.run_on_side(idx_t.device, "lookup", lambda: emb_fn(*inp_args))
+                    idx_t.record_stream(side)
+                    joins.append((ev, out))
+                    outputs[k] = out
                 else:
                     outputs[k] = emb_fn(*inp_args)
+                    first_lookup = first_lookup and type(emb_fn) not in _SIDE_LOOKUPS
+        if joins:
+            main = F_._abi.current_stream_of(joins[0][1].device)
+            for ev, out in joins:      # consumers are enqueued on the caller's stream: it waits for the side lookups here
+                main.wait_event(ev)
+                extra = [t[0] for t in (getattr(out, a, None) for a in ('_trs_fused_fm', '_trs_fused_ipn')) if t is not None]
+                for t in [out] + extra:
+                    (t.rename(None) if t.has_names() else t).record_stream(main)
         return {k: outputs[k] for k in self.schema}      # schema order, as the reference returns it
 
     def add_inputs(self, name: Optional[str] = None, model: Optional[nn.Module] = None,

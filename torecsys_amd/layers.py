@@ -528,6 +528,7 @@ PAD_MIN_WIDTH = 192
 PAD_MIN_ROWS = 4096
 HYBRID_ONE_NODE = os.environ.get("TRS_HYBRID_ONE_NODE", "1") not in ("", "0")
 HYBRID_MLP = os.environ.get("TRS_HYBRID_MLP", "1") not in ("", "0")   # fused tail behind a wide first layer
+HOIST_PACK = os.environ.get("TRS_HOIST_PACK", "1") not in ("", "0")   # _HybridMLP: weight copies on a side stream beside the first GEMM
 
 
 def _pad_width(width: int) -> int:
@@ -695,14 +696,15 @@ class _LinearSplitK(torch.autograd.Function):
         return gx, gw, gb, None, None, None
 
 
-def _dense_layer_grads(g2, gbf, xin, W, out_f, in_f, wdt, need_x, need_w, need_b):
+def _dense_layer_grads(g2, gbf, xin, W, out_f, in_f, wdt, need_x, need_w, need_b, rows_gemm_ws=None):
     """Gradients of y = xin @ W^T + b from g2 = dL/dy (rows, padded width; ``gbf``: its fp32 column sums when a fused
-    ReLU-backward already produced them): (dL/dxin, dL/dW, dL/db), None where not needed."""
+    ReLU-backward already produced them): (dL/dxin, dL/dW, dL/db), None where not needed.  ``rows_gemm_ws``: W already in
+    fragment order for trs_rows_gemm (F_.rows_gemm_pack at forward time)."""
     rows = xin.shape[0]
     gw_out = gb_out = None
     if need_x and F_.rows_gemm_supported(g2, W, out_f, xin.shape[1]) and W.shape[1] == xin.shape[1]:
         # wide input, short contraction (2496 <- 400): our own kernel, K not padded to the library's tile
-        gx = F_.rows_gemm(g2, W, out_f, xin.shape[1])
+        gx = F_.rows_gemm(g2, W, out_f, xin.shape[1], packed_ws=rows_gemm_ws)
     else:
         gx = (g2 @ W) if need_x else None
     S = _split_count(rows, _LinearSplitK.SPLIT_ROWS)
@@ -756,11 +758,39 @@ class _HybridMLP(torch.autograd.Function):
         tail = tensors[4:]
         W1 = w1 if w1u is None else w1u
         B1 = b1 if w1u is None else b1u
-        h1 = torch._addmm_activation(B1, cur, W1.t(), use_gelu=False)
         L = len(tail) // 4
         Ws = [(tail[4 * l] if tail[4 * l + 2] is None else tail[4 * l + 2]).contiguous() for l in range(L)]
         bs = [(tail[4 * l + 1] if tail[4 * l + 3] is None else tail[4 * l + 3]).contiguous() for l in range(L)]
-        y, hidden, masks, mask_in, fam = F_.fused_mlp_forward_raw(h1, Ws, bs, input_mask=True)
+        # Every copy of weights into MFMA fragment order this node needs -- the tail's forward and backward kernels, the
+        # first layer's input-gradient kernel -- depends on the parameters only: all of them go onto the "pack" side
+        # stream now and run beside the first layer's GEMM (three launches of ~9 us each that used to sit on the step's
+        # critical path: in front of the tail's forward, of its backward and of trs_rows_gemm).  TRS_HOIST_PACK=0: each
+        # kernel packs in front of itself again.
+        rows, wpack = cur.shape[0], None
+        widths_t = [W1.shape[0]] + [w.shape[0] for w in Ws]
+        if HOIST_PACK and rows >= PAD_MIN_ROWS:
+            fam_t = F_.mlp_fused_family(widths_t, rows)
+            need_bwd = any(ctx.needs_input_grad)
+            gx_ws = need_bwd and ctx.needs_input_grad[0] and W1.is_contiguous() and W1.shape[1] == cur.shape[1] and \
+                F_.rows_gemm_supported_for(rows, W1.shape[0], W1, w1.shape[0], cur.shape[1])
+
+            def pack():
+                return (F_.fused_mlp_pack(Ws, bs, widths_t, rows, fam_t, False),
+                        F_.fused_mlp_pack(Ws, None, widths_t, rows, fam_t, True) if need_bwd else None,
+                        F_.rows_gemm_pack(W1, rows, W1.shape[0], w1.shape[0], cur.shape[1]) if gx_ws else None)
+            wpack, ev, side = F_.run_on_side(cur.device, "pack", pack)
+        h1 = torch._addmm_activation(B1, cur, W1.t(), use_gelu=False)
+        if wpack is not None:
+            main = F_._abi.current_stream_of(cur.device)
+            main.wait_event(ev)
+            for t in wpack:
+                if t is not None:
+                    t.record_stream(main)      # allocated under the side stream, read (and freed) under this one
+            y, hidden, masks, mask_in, fam = F_.fused_mlp_forward_raw(h1, Ws, bs, input_mask=True, family=fam_t,
+                                                                      packed_ws=wpack[0])
+        else:
+            y, hidden, masks, mask_in, fam = F_.fused_mlp_forward_raw(h1, Ws, bs, input_mask=True)
+        ctx.wpack = wpack
         out_f = tail[4 * (L - 1)].shape[0]
         ctx.save_for_backward(cur, W1, h1, mask_in, *Ws, *hidden, *masks)
         ctx.meta = (L, [h1.shape[1]] + [w.shape[0] for w in Ws], [tuple(tail[4 * l].shape) for l in range(L)],
@@ -780,7 +810,8 @@ class _HybridMLP(torch.autograd.Function):
         rows, dev = h1.shape[0], h1.device
         gy = gy.reshape(rows, -1)
         gy2 = F_.pad_cols(gy, widths[L]) if gy.shape[1] != widths[L] else gy.contiguous()
-        g1, gz, gb, gb1 = F_.fused_mlp_backward_raw(gy2, widths, Ws, masks, mask_in, family=fam)
+        wpack = ctx.wpack if ctx.wpack is not None else (None, None, None)
+        g1, gz, gb, gb1 = F_.fused_mlp_backward_raw(gy2, widths, Ws, masks, mask_in, family=fam, packed_ws=wpack[1])
         grads = []
         for l in range(L):
             inp = h1 if l == 0 else hidden[l - 1]
@@ -788,7 +819,8 @@ class _HybridMLP(torch.autograd.Function):
             out_f, in_f = wshapes[l]
             gw, gbias = F_._tail_layer_grads(g, inp, out_f, in_f, wdt[l], gb[l], needs[5 + 4 * l], needs[6 + 4 * l])
             grads += [gw, gbias, None, None]
-        gx, gw1, gbias1 = _dense_layer_grads(g1, gb1, cur, W1, w1shape[0], w1shape[1], w1dt, needs[0], needs[1], needs[2])
+        gx, gw1, gbias1 = _dense_layer_grads(g1, gb1, cur, W1, w1shape[0], w1shape[1], w1dt, needs[0], needs[1], needs[2],
+                                             rows_gemm_ws=wpack[2])
         return (gx.reshape(xshape) if needs[0] else None, gw1, gbias1, None, None, *grads)
 
 
