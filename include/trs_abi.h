@@ -355,6 +355,17 @@ int trs_mlp_fused_bwd_data(const void* gy, int64_t rows, int32_t num_layers, con
                            void* gx, const void* mask_in, float* gbias_in, int32_t dtype, int32_t family, int32_t phase,
                            void* workspace, size_t ws_bytes, trs_stream_t stream);
 
+/* Every weight copy a deep branch needs, in ONE launch: the PACK phases of trs_mlp_fused_fwd (into ws_fwd), of
+ * trs_mlp_fused_bwd_data (into ws_bwd, same size; NULL: none) and of the trs_rows_gemm of the Linear in front of the stack
+ * (gemm_W (gemm_out_f, gemm_in_f) into ws_gemm; NULL: none); the three RUN-phase calls then find what their own PACK call
+ * would have left.  For stacks that `family` resolves to the tile kernels (TRS_ESHAPE otherwise: use the PACK phases).
+ * multilayer_perceptron.py:53-61 -- three 6-9 us launches with 5 us gaps in front of a 65 536-row deep branch's kernels
+ * become one that runs beside the first layer's GEMM.                                                                */
+int trs_mlp_pack_branch(int64_t rows, int32_t num_layers, const int32_t* widths, const void* const* weights,
+                        const void* const* biases, int32_t family, void* ws_fwd, void* ws_bwd, size_t ws_bytes,
+                        const void* gemm_W, int32_t gemm_out_f, int32_t gemm_in_f, void* ws_gemm, size_t ws_gemm_bytes,
+                        trs_stream_t stream);
+
 /* dst (rows, c_out) = [src (rows, c_in) | zeros], bf16: the gradient of the first c_in columns of a padded output (the
  * logit column of a deep branch whose last layer runs at 8 columns) in one launch.                                   */
 int trs_pad_cols(const void* src, int32_t c_in, void* dst, int32_t c_out, int64_t rows, int32_t dtype,

@@ -87,15 +87,17 @@ struct MlpPackJob {
   bf16_t* Wf;
   float* bf;
   int out_f, in_f, NTt, KS, bias_n;
-};
-struct MlpPackArgs {
-  MlpPackJob job[MF_MAXL];
   int transpose;
+};
+constexpr int MF_MAXJOBS = 2 * MF_MAXL + 1;      // a stack's forward and backward copies + the layer in front of it (trs_mlp_pack_branch)
+struct MlpPackArgs {
+  MlpPackJob job[MF_MAXJOBS];
 };
 __global__ __launch_bounds__(256) void mlp_prepack_many_kernel(MlpPackArgs a) {
   const MlpPackJob& j = a.job[blockIdx.y];
   const int total = j.NTt * j.KS * 64;
-  const bool vec = !a.transpose && (j.in_f & 7) == 0 && (reinterpret_cast<uintptr_t>(j.W) & 15u) == 0;
+  const int transpose = j.transpose;
+  const bool vec = !transpose && (j.in_f & 7) == 0 && (reinterpret_cast<uintptr_t>(j.W) & 15u) == 0;
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
     const int lane = t & 63;
     const int f = t >> 6;
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256) void mlp_prepack_many_kernel(MlpPackArgs a) {
     for (int e = 0; e < 8; ++e) {
       const int k = k0 + e;
       v[e] = 0;
-      if (!a.transpose) {
+      if (!transpose) {
         if (oc < j.out_f && k < j.in_f) v[e] = j.W[(size_t)oc * j.in_f + k].v;
       } else {
         if (oc < j.in_f && k < j.out_f) v[e] = j.W[(size_t)k * j.in_f + oc].v;
@@ -786,6 +788,42 @@ static size_t mlp_frag_bytes(int L, const int32_t* w) {
   return (b + 255) / 256 * 256;
 }
 
+// The weight copies of the tile kernels as job lists (the entry points below and trs_mlp_pack_branch build the SAME jobs:
+// what a PACK call leaves is what a RUN call reads).  Return the grid width the jobs want.
+static int mlp_fwd_pack_jobs(int L, const int32_t* widths, const void* const* weights, const void* const* biases, char* wsp,
+                             MlpPackJob* job) {
+  float* bias_base = (float*)(wsp + mlp_frag_bytes(L, widths));
+  size_t woff = 0, boff = 0;
+  int blocks = 1;
+  for (int l = 0; l < L; ++l) {
+    const int K = pad32(widths[l]), N = pad32(widths[l + 1]);
+    job[l] = MlpPackJob{(const bf16_t*)weights[l], (const bf16_t*)biases[l], (bf16_t*)(wsp + woff), bias_base + boff,
+                        widths[l + 1], widths[l], N / 16, K / 32, N, 0};
+    blocks = std::max(blocks, std::min(256, (N / 16 * (K / 32) * 64 + 255) / 256));
+    woff += (size_t)K * N * 2;
+    boff += N;
+  }
+  return blocks;
+}
+static int mlp_bwd_pack_jobs(int L, const int32_t* widths, const void* const* weights, char* wsp, MlpPackJob* job) {
+  size_t woff = 0;
+  int blocks = 1;
+  for (int sidx = 0; sidx < L; ++sidx) {
+    const int l = L - 1 - sidx;
+    const int K = pad32(widths[l + 1]), N = pad32(widths[l]);      // contraction over layer l's outputs, output = its inputs
+    job[sidx] = MlpPackJob{(const bf16_t*)weights[l], nullptr, (bf16_t*)(wsp + woff), nullptr, widths[l + 1], widths[l],
+                           N / 16, K / 32, 0, 1};
+    blocks = std::max(blocks, std::min(256, (N / 16 * (K / 32) * 64 + 255) / 256));
+    woff += (size_t)K * N * 2;
+  }
+  return blocks;
+}
+static int mlp_gemm_pack_job(const void* W, int out_f, int in_f, void* workspace, MlpPackJob* job) {
+  const int K = pad32(out_f), N = pad32(in_f);
+  job[0] = MlpPackJob{(const bf16_t*)W, nullptr, (bf16_t*)workspace, nullptr, out_f, in_f, N / 16, K / 32, 0, 1};
+  return std::min(256, (N / 16 * (K / 32) * 64 + 255) / 256);
+}
+
 }  // namespace trs
 
 using namespace trs;
@@ -847,15 +885,11 @@ extern "C" int trs_mlp_fused_fwd(const void* x, int64_t rows, int32_t num_layers
   float* bias_base = (float*)(wsp + mlp_frag_bytes(L, widths));
   size_t woff = 0, boff = 0;
   MlpPackArgs pk;
-  pk.transpose = 0;
-  int pk_blocks = 1;
+  const int pk_blocks = mlp_fwd_pack_jobs(L, widths, weights, biases, wsp, pk.job);
   for (int l = 0; l < L; ++l) {
     const int K = pad32(widths[l]), N = pad32(widths[l + 1]);
     bf16_t* wf = (bf16_t*)(wsp + woff);
     float* bf = bias_base + boff;
-    pk.job[l] = MlpPackJob{(const bf16_t*)weights[l], (const bf16_t*)biases[l], wf, bf, widths[l + 1], widths[l], N / 16,
-                           K / 32, N};
-    pk_blocks = std::max(pk_blocks, std::min(256, (N / 16 * (K / 32) * 64 + 255) / 256));
     MlpStep& st = a.step[l];
     st.wf = (const uint4*)wf;
     st.bias = bf;
@@ -945,14 +979,11 @@ extern "C" int trs_mlp_fused_bwd_data(const void* gy, int64_t rows, int32_t num_
   float* part_base = (float*)(wsp + mlp_frag_bytes(L, widths));
   size_t woff = 0, poff = 0;
   MlpPackArgs pk;
-  pk.transpose = 1;
-  int pk_blocks = 1;
+  const int pk_blocks = mlp_bwd_pack_jobs(L, widths, weights, wsp, pk.job);
   for (int sidx = 0; sidx < L; ++sidx) {
     const int l = L - 1 - sidx;
     const int K = pad32(widths[l + 1]), N = pad32(widths[l]);      // contraction over layer l's outputs, output = its inputs
     bf16_t* wf = (bf16_t*)(wsp + woff);
-    pk.job[sidx] = MlpPackJob{(const bf16_t*)weights[l], nullptr, wf, nullptr, widths[l + 1], widths[l], N / 16, K / 32, 0};
-    pk_blocks = std::max(pk_blocks, std::min(256, (N / 16 * (K / 32) * 64 + 255) / 256));
     MlpStep& st = a.step[sidx];
     st.wf = (const uint4*)wf;
     st.bias = nullptr;
@@ -1028,10 +1059,8 @@ extern "C" int trs_rows_gemm(const void* x, int64_t rows, int32_t x_stride, cons
   if (rows == 0 && !pack_only) return TRS_OK;
   const int K = pad32(out_f), N = pad32(in_f);
   MlpPackArgs pk;
-  pk.transpose = 1;
-  pk.job[0] = MlpPackJob{(const bf16_t*)W, nullptr, (bf16_t*)workspace, nullptr, out_f, in_f, N / 16, K / 32, 0};
-  if (phase != TRS_MLP_PHASE_RUN)
-    hipLaunchKernelGGL(mlp_prepack_many_kernel, dim3(std::min(256, (N / 16 * (K / 32) * 64 + 255) / 256), 1), dim3(256), 0, s, pk);
+  const int pk_blocks = mlp_gemm_pack_job(W, out_f, in_f, workspace, pk.job);
+  if (phase != TRS_MLP_PHASE_RUN) hipLaunchKernelGGL(mlp_prepack_many_kernel, dim3(pk_blocks, 1), dim3(256), 0, s, pk);
   if (pack_only) return check_launch("rows_gemm(pack)");
   RowsGemmArgs a;
   a.in = x;
@@ -1055,4 +1084,38 @@ extern "C" int trs_rows_gemm(const void* x, int64_t rows, int32_t x_stride, cons
   const int64_t ntiles = (rows + MF_ROWS - 1) / MF_ROWS;
   hipLaunchKernelGGL(mlp_rows_gemm_kernel, dim3((int)std::min<int64_t>(ntiles, MF_GRID)), dim3(64 * MF_WAVES), lds, s, a);
   return check_launch("rows_gemm");
+}
+
+/* Every weight copy of a deep branch in ONE launch: the PACK phases of trs_mlp_fused_fwd (into ws_fwd), of
+ * trs_mlp_fused_bwd_data (into ws_bwd; NULL: none) and of the trs_rows_gemm of the layer in front of the stack (gemm_W
+ * (gemm_out_f x gemm_in_f) into ws_gemm; NULL: none).  The three RUN calls then find what their own PACK call would have
+ * left.  Tile family only (TRS_ESHAPE for a stack that `family` resolves to the row-owner kernels: use the PACK phases). */
+extern "C" int trs_mlp_pack_branch(int64_t rows, int32_t num_layers, const int32_t* widths, const void* const* weights,
+                                   const void* const* biases, int32_t family, void* ws_fwd, void* ws_bwd, size_t ws_bytes,
+                                   const void* gemm_W, int32_t gemm_out_f, int32_t gemm_in_f, void* ws_gemm,
+                                   size_t ws_gemm_bytes, trs_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  TRS_REQUIRE(trs_mlp_fused_supported(num_layers, widths), TRS_ESHAPE, "mlp_pack_branch: unsupported layer widths");
+  TRS_REQUIRE(weights && biases && ws_fwd, TRS_EINVAL, "mlp_pack_branch: NULL pointer");
+  TRS_REQUIRE(ws_bytes >= trs_mlp_fused_workspace_bytes(num_layers, widths), TRS_EWORKSPACE, "mlp_pack_branch: workspace too small");
+  TRS_REQUIRE(mlp_resolve_family(num_layers, widths, rows, family) == TRS_MLP_FAMILY_TILE, TRS_ESHAPE,
+              "mlp_pack_branch: the tile kernels only (family %d resolves to another one for this stack)", family);
+  const int L = num_layers;
+  MlpPackArgs pk;
+  int njobs = L;
+  int blocks = mlp_fwd_pack_jobs(L, widths, weights, biases, (char*)ws_fwd, pk.job);
+  if (ws_bwd != nullptr) {
+    blocks = std::max(blocks, mlp_bwd_pack_jobs(L, widths, weights, (char*)ws_bwd, pk.job + njobs));
+    njobs += L;
+  }
+  if (gemm_W != nullptr) {
+    TRS_REQUIRE(ws_gemm != nullptr && trs_rows_gemm_supported(gemm_out_f, gemm_in_f, pad32(gemm_out_f)), TRS_ESHAPE,
+                "mlp_pack_branch: rows_gemm shape (K %d, N %d)", gemm_out_f, gemm_in_f);
+    TRS_REQUIRE(ws_gemm_bytes >= trs_rows_gemm_workspace_bytes(gemm_out_f, gemm_in_f), TRS_EWORKSPACE,
+                "mlp_pack_branch: rows_gemm workspace too small");
+    blocks = std::max(blocks, mlp_gemm_pack_job(gemm_W, gemm_out_f, gemm_in_f, ws_gemm, pk.job + njobs));
+    njobs += 1;
+  }
+  hipLaunchKernelGGL(mlp_prepack_many_kernel, dim3(blocks, njobs), dim3(256), 0, s, pk);
+  return check_launch("mlp_pack_branch");
 }

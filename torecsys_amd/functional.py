@@ -1753,6 +1753,30 @@ def fused_mlp_pack(Ws: Sequence[torch.Tensor], bs: Optional[Sequence[torch.Tenso
     return ws
 
 
+def fused_mlp_pack_branch(Ws: Sequence[torch.Tensor], bs: Sequence[torch.Tensor], widths: Sequence[int], rows: int,
+                          family: int, backward: bool, gemm: Optional[tuple] = None):
+    """(ws_fwd, ws_bwd | None, ws_gemm | None): what fused_mlp_pack(forward), fused_mlp_pack(backward) and
+    rows_gemm_pack(*gemm) -- gemm = (W, x_stride, out_f, in_f) -- leave, on the current stream.  The tile family does it
+    in ONE launch (trs_mlp_pack_branch), the row-owner family in one per workspace."""
+    if family != MLP_FAMILY_TILE:
+        return (fused_mlp_pack(Ws, bs, widths, rows, family, False),
+                fused_mlp_pack(Ws, None, widths, rows, family, True) if backward else None,
+                rows_gemm_pack(gemm[0], rows, gemm[1], gemm[2], gemm[3]) if gemm is not None else None)
+    L, dev = len(Ws), Ws[0].device
+    wl = _i32_array(widths)
+    ws_bytes = size_query("trs_mlp_fused_workspace_bytes", L, wl)
+    ws_f = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    ws_b = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if backward else None
+    ws_g, g_bytes, gW, g_out, g_in = None, 0, None, 0, 0
+    if gemm is not None:
+        gW, _, g_out, g_in = gemm
+        g_bytes = size_query("trs_rows_gemm_workspace_bytes", g_out, g_in)
+        ws_g = torch.empty(g_bytes, dtype=torch.uint8, device=dev)
+    call("trs_mlp_pack_branch", rows, L, wl, _ptr_array(Ws), _ptr_array(bs), int(family), ptr(ws_f), ptr(ws_b), ws_bytes,
+         ptr(gW), g_out, g_in, ptr(ws_g), g_bytes, stream_ptr())
+    return ws_f, ws_b, ws_g
+
+
 def fused_mlp_forward_raw(x2: torch.Tensor, Ws: Sequence[torch.Tensor], bs: Sequence[torch.Tensor],
                           input_mask: bool = False, family: Optional[int] = None,
                           packed_ws: Optional[torch.Tensor] = None):

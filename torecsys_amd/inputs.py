@@ -200,7 +200,9 @@ class ValueInput(BaseInput):
 PAIR_FIRST_ORDER = os.environ.get("TRS_PAIR_FIRST_ORDER", "0") == "1"
 
 
-LOOKUP_STREAMS = os.environ.get("TRS_LOOKUP_STREAMS", "1") not in ("", "0")
+# 0: every lookup on the caller's stream; 1: lookups beyond the first on the "lookup" side stream, enqueued BEHIND the first
+# (the forward stays serial, the backward's bucket walks run side by side); 2: enqueued in FRONT of it (parallel forward)
+LOOKUP_STREAMS = int(os.environ.get("TRS_LOOKUP_STREAMS", "1") or 0)
 _SIDE_LOOKUPS = (SingleIndexEmbedding, MultiIndicesEmbedding, MultiIndicesFieldAwareEmbedding)
 
 
@@ -261,28 +263,56 @@ class Inputs(BaseInput):
             p = self._first_order_partner(k)
             if p is not None and p not in partner:
                 partner[p] = k
-        joins = []                     # (event, output) of lookups enqueued on the "lookup" side stream
-        first_lookup = True
-        with F_.defer_prefetch():      # row-bucket builds start once every lookup of the batch is enqueued
-            for k, emb_fn in self.schema.items():
-                if k in outputs:       # a first-order table already served by its partner's pass
-                    continue
-                if k in partner and partner[k] not in outputs:
-                    continue           # served when its partner runs (below, or later in this loop)
-                if emb_fn.__class__.__name__ in ['ConcatInput', 'StackedInput']:
-                    inp_args = [{i: inputs[i] for i in emb_fn.schema.inputs}]
+        # pass 1: every entry's index tensor (column packing runs on the caller's stream, once per column set)
+        args = {}
+        for k, emb_fn in self.schema.items():
+            if k in partner and partner[k] in self.schema:
+                continue               # a first-order table served by its partner's pass
+            if emb_fn.__class__.__name__ in ['ConcatInput', 'StackedInput']:
+                args[k] = [{i: inputs[i] for i in emb_fn.schema.inputs}]
+                continue
+            names = tuple(emb_fn.schema.inputs)
+            inp = packed.get(names)
+            if inp is None:
+                raw = [inputs[emb_k] for emb_k in names]
+                if F_.pack_columns_supported(raw):
+                    inp = F_.pack_columns(raw)
                 else:
-                    names = tuple(emb_fn.schema.inputs)
-                    inp = packed.get(names)
-                    if inp is None:
-                        raw = [inputs[emb_k] for emb_k in names]
-                        if F_.pack_columns_supported(raw):
-                            inp = F_.pack_columns(raw)
-                        else:
-                            cols = [v.unsqueeze(-1) if v.dim() == 1 else v for v in raw]
-                            inp = cols[0] if len(cols) == 1 else torch.cat(cols, dim=1)
-                        packed[names] = inp
-                    inp_args = [inp]
+                    cols = [v.unsqueeze(-1) if v.dim() == 1 else v for v in raw]
+                    inp = cols[0] if len(cols) == 1 else torch.cat(cols, dim=1)
+                packed[names] = inp
+            args[k] = [inp]
+        # The lookups of a batch are independent of each other: every plain lookup after the first goes onto the "lookup"
+        # side stream.  What pays is the BACKWARD: autograd runs a node's backward on the stream of its forward, so the
+        # bucket walk of the E = 1 first-order table of an FM-family model (one walk and four small launches, ~45 us at the
+        # end of the step) runs beside the dense backward instead.  In the forward the side lookup is enqueued BEHIND the
+        # first one (mode 1): beside it (mode 2) the two gathers share the memory pipe and the wide lookup goes from 131 to
+        # 157 us for the 17 us it hides.  Measured alternately on one box, DeepFM step: 0: 1.287 ms, 1: 1.259 ms,
+        # 2: 1.304 ms (gpurun_out/r05e, r05f).
+        side_keys, first_lookup = [], True
+        for k in args:
+            emb_fn = self.schema[k]
+            plain = (type(emb_fn) in _SIDE_LOOKUPS and k not in partner.values()
+                     and isinstance(args[k][0], torch.Tensor) and args[k][0].is_cuda)
+            if plain and not first_lookup and LOOKUP_STREAMS:
+                side_keys.append(k)
+            first_lookup = first_lookup and not plain
+        joins = []                     # (event, output) of lookups enqueued on the side stream
+        def side_lookups():
+            for k in side_keys:
+                emb_fn, idx_t = self.schema[k], args[k][0]
+                out, ev, side = F_.run_on_side(idx_t.device, "lookup", lambda: emb_fn(idx_t))
+                idx_t.record_stream(side)
+                joins.append((ev, out))
+                outputs[k] = out
+
+        with F_.defer_prefetch():      # row-bucket builds start once every lookup of the batch is enqueued
+            if LOOKUP_STREAMS == 2:
+                side_lookups()
+            for k in args:
+                if k in outputs or k in side_keys:
+                    continue
+                emb_fn, inp_args = self.schema[k], args[k]
                 feat_key = next((f for f, w in partner.items() if w == k), None)
                 if feat_key is not None:
                     # one lookup pass and one bucket walk for the wide table and its first-order companion
@@ -297,21 +327,10 @@ class Inputs(BaseInput):
                     first.names = ('B', 'N', 'E',)
                     outputs[k] = out
                     outputs[feat_key] = first
-                elif (LOOKUP_STREAMS and not first_lookup and type(emb_fn) in _SIDE_LOOKUPS
-                      and isinstance(inp_args[0], torch.Tensor) and inp_args[0].is_cuda):
-                    # The lookups of a batch are independent of each other: every one after the first goes onto the
-                    # "lookup" side stream and runs beside it (the E = 1 first-order table of an FM-family model beside
-                    # the E = 64 lookup: 17 us off the critical path).  Autograd runs a node's backward on the stream of
-                    # its forward, so the bucket walk of that table (one walk and four small launches, ~45 us) also runs
-                    # beside the wide table's walk instead of behind it.  TRS_LOOKUP_STREAMS=0: everything in order.
-                    idx_t = inp_args[0]
-                    out, ev, side = F_.run_on_side(idx_t.device, "lookup", lambda: emb_fn(*inp_args))
-                    idx_t.record_stream(side)
-                    joins.append((ev, out))
-                    outputs[k] = out
                 else:
                     outputs[k] = emb_fn(*inp_args)
-                    first_lookup = first_lookup and type(emb_fn) not in _SIDE_LOOKUPS
+            if LOOKUP_STREAMS != 2:
+                side_lookups()
         if joins:
             main = F_._abi.current_stream_of(joins[0][1].device)
             for ev, out in joins:      # consumers are enqueued on the caller's stream: it waits for the side lookups here

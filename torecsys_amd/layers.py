@@ -528,7 +528,12 @@ PAD_MIN_WIDTH = 192
 PAD_MIN_ROWS = 4096
 HYBRID_ONE_NODE = os.environ.get("TRS_HYBRID_ONE_NODE", "1") not in ("", "0")
 HYBRID_MLP = os.environ.get("TRS_HYBRID_MLP", "1") not in ("", "0")   # fused tail behind a wide first layer
-HOIST_PACK = os.environ.get("TRS_HOIST_PACK", "1") not in ("", "0")   # _HybridMLP: weight copies on a side stream beside the first GEMM
+# _HybridMLP's weight copies into fragment order: 0 (default) in front of each kernel; 1 one launch on the "pack" side stream
+# beside the first GEMM; 2 one launch on the caller's stream in front of the first GEMM.  Measured alternately on one box
+# (gpurun_out/r05e, r05f; DeepFM step replayed from a hipGraph): 0: 1.259 ms, 2: 1.279 ms, 1: 1.277 ms -- three launches
+# fewer on the critical path and still 20 us slower (what the graph's branches overlap with moves: the bucket build no
+# longer runs beside the first GEMM).  Kept as a switch and as the ABI's PACK / RUN phases; off.
+HOIST_PACK = int(os.environ.get("TRS_HOIST_PACK", "0") or 0)
 
 
 def _pad_width(width: int) -> int:
@@ -761,11 +766,9 @@ class _HybridMLP(torch.autograd.Function):
         L = len(tail) // 4
         Ws = [(tail[4 * l] if tail[4 * l + 2] is None else tail[4 * l + 2]).contiguous() for l in range(L)]
         bs = [(tail[4 * l + 1] if tail[4 * l + 3] is None else tail[4 * l + 3]).contiguous() for l in range(L)]
-        # Every copy of weights into MFMA fragment order this node needs -- the tail's forward and backward kernels, the
-        # first layer's input-gradient kernel -- depends on the parameters only: all of them go onto the "pack" side
-        # stream now and run beside the first layer's GEMM (three launches of ~9 us each that used to sit on the step's
-        # critical path: in front of the tail's forward, of its backward and of trs_rows_gemm).  TRS_HOIST_PACK=0: each
-        # kernel packs in front of itself again.
+        # TRS_HOIST_PACK (off by default, see HOIST_PACK): every copy of weights into MFMA fragment order this node needs --
+        # the tail's forward and backward kernels, the first layer's input-gradient kernel -- depends on the parameters
+        # only and can be ONE launch in front of (or, on the "pack" side stream, beside) the first layer's GEMM.
         rows, wpack = cur.shape[0], None
         widths_t = [W1.shape[0]] + [w.shape[0] for w in Ws]
         if HOIST_PACK and rows >= PAD_MIN_ROWS:
@@ -774,18 +777,20 @@ class _HybridMLP(torch.autograd.Function):
             gx_ws = need_bwd and ctx.needs_input_grad[0] and W1.is_contiguous() and W1.shape[1] == cur.shape[1] and \
                 F_.rows_gemm_supported_for(rows, W1.shape[0], W1, w1.shape[0], cur.shape[1])
 
-            def pack():
-                return (F_.fused_mlp_pack(Ws, bs, widths_t, rows, fam_t, False),
-                        F_.fused_mlp_pack(Ws, None, widths_t, rows, fam_t, True) if need_bwd else None,
-                        F_.rows_gemm_pack(W1, rows, W1.shape[0], w1.shape[0], cur.shape[1]) if gx_ws else None)
-            wpack, ev, side = F_.run_on_side(cur.device, "pack", pack)
+            gemm = (W1, W1.shape[0], w1.shape[0], cur.shape[1]) if gx_ws else None
+            if HOIST_PACK == 2:
+                wpack, ev = F_.fused_mlp_pack_branch(Ws, bs, widths_t, rows, fam_t, need_bwd, gemm), None
+            else:
+                wpack, ev, side = F_.run_on_side(cur.device, "pack", lambda: F_.fused_mlp_pack_branch(
+                    Ws, bs, widths_t, rows, fam_t, need_bwd, gemm))
         h1 = torch._addmm_activation(B1, cur, W1.t(), use_gelu=False)
         if wpack is not None:
-            main = F_._abi.current_stream_of(cur.device)
-            main.wait_event(ev)
-            for t in wpack:
-                if t is not None:
-                    t.record_stream(main)      # allocated under the side stream, read (and freed) under this one
+            if ev is not None:
+                main = F_._abi.current_stream_of(cur.device)
+                main.wait_event(ev)
+                for t in wpack:
+                    if t is not None:
+                        t.record_stream(main)      # allocated under the side stream, read (and freed) under this one
             y, hidden, masks, mask_in, fam = F_.fused_mlp_forward_raw(h1, Ws, bs, input_mask=True, family=fam_t,
                                                                       packed_ws=wpack[0])
         else:
