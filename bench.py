@@ -813,11 +813,17 @@ def main():
         if sharded:
             alg = None
         kt = sum(ktimes) / max(1, len(ktimes)) * 1e-3 if ktimes else None
-        traffic = None
+        traffic = traffic_round = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(roof_kernel + ("_zipf" if a.zipf else ""))
+                tj = json.load(open(tpath))
+                import hashlib
+                src = os.path.join(ROOT, "torecsys_amd", "csrc", "fm.hip")
+                # a figure taken from another build of the kernel is not this kernel's traffic: refused
+                if tj.get("kernel_source_sha16") == hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]:
+                    traffic = tj.get(roof_kernel + ("_zipf" if a.zipf else ""))
+                    traffic_round = tj.get("round")
             except Exception:  # noqa: BLE001
                 traffic = None
         roof = None
@@ -825,9 +831,12 @@ def main():
             ach = alg / kt / 1e9
             roof = {"bound": "hbm", "kernel": roof_kernel.replace("trs_", ""), "achieved": round(ach, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": None, "traffic_profiled": traffic,
-                    "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                      "command, corrected per MI355X_MICROARCH.md; not collected in this run",
+                    "traffic": traffic, "traffic_round": traffic_round,
+                    "traffic_source": "profiles/traffic.json: HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / "
+                                      "WRITE_SIZE passes of this command (tools/pmc_traffic.sh), corrected per "
+                                      "MI355X_MICROARCH.md (1 KiB units, FETCH_SIZE x 2 on gfx950); counters cannot be read "
+                                      "inside a timed run, so the figure is the committed one of the same kernel source "
+                                      "(hash-checked: null when fm.hip differs from the profiled build)",
                     "alg_bytes_per_launch": alg, "side_output_bytes": side, "avg_launch_us": round(kt * 1e6, 2),
                     "launches_timed": len(ktimes),
                     "timed_how": ("device timestamp marks around the launch in %d replays of a second capture of the step, "

@@ -19,7 +19,11 @@ run python bench.py --no-cpu-baseline --no-large-table --force-sharded --no-pipe
 run python bench.py --no-cpu-baseline --no-large-table --force-sharded --optimizer adagrad 2>/dev/null | tail -1 > $O/bench_deepfm_sharded1_adagrad.json
 run python tools/kbench.py 2>&1 | grep -v Warn > $O/kbench.txt
 run python tools/kbench.py --what pairx,mlpf 2>&1 | grep -v Warn > $O/kbench_pairx_mlpf.txt
-run bash tools/trace_run.sh $O/bench_deepfm_kernel_trace.md "$tag -- rocprofv3 --kernel-trace --stats: bench.py (DeepFM, BASELINE configs[1])" -- python $R/bench.py --no-cpu-baseline --no-large-table --no-other-models --steps 20 --warmup 5
+run python tools/kbench.py --what ffm 2>&1 | grep -v Warn > $O/kbench_ffm.txt
+# HBM traffic of the roofline kernel from the PMC counters (separate passes, counters only) -> profiles/traffic.json
+run bash tools/pmc_traffic.sh $O/pmc_traffic "embed_fm_group scatter_rows_fm1" -- python $R/bench.py --no-cpu-baseline --no-large-table --no-other-models --steps 10 --warmup 3 --eager > /dev/null 2>&1
+python tools/make_traffic_json.py $O/pmc_traffic ${tag#r} --md $O/pmc_embed_fm.md; cp profiles/traffic.json $O/traffic.json
+TRS_TIMELINE=$O/bench_deepfm_step_timeline.md run bash tools/trace_run.sh $O/bench_deepfm_kernel_trace.md "$tag -- rocprofv3 --kernel-trace --stats: bench.py (DeepFM, BASELINE configs[1])" -- python $R/bench.py --no-cpu-baseline --no-large-table --no-other-models --steps 20 --warmup 5
 TRS_TRACE_CALLS="cin_|glue" run bash tools/trace_run.sh $O/bench_xdeepfm_kernel_trace.md "$tag -- rocprofv3 --kernel-trace --stats: bench.py --model xdeepfm" -- python $R/bench.py --no-cpu-baseline --no-large-table --model xdeepfm --steps 3 --warmup 2
 run bash tools/trace_run.sh $O/bench_dcn_kernel_trace.md "$tag -- rocprofv3 --kernel-trace --stats: bench.py --model dcn" -- python $R/bench.py --no-cpu-baseline --no-large-table --model dcn --steps 3 --warmup 2
 ls -la $O
