@@ -66,6 +66,16 @@ int trs_gather_rows(const void* table, int64_t V, int32_t E, int32_t dtype,
                     const void* idx, int32_t idx_dtype, const int64_t* offsets,
                     int64_t B, int32_t N, void* out, int32_t* err_flag, trs_stream_t stream);
 
+/* ---- N separate tables, one index column each: a StackedInput of SingleIndexEmbeddings in one launch -------------
+ * inputs/base/stacked_inp.py:94-134 calls N SingleIndexEmbeddings (single_index_emb.py:48-59: nn.Embedding on a (B,1)
+ * column) and concatenates along N.  out[b,n,:] = tables[n][idx[b,n],:], bit-exact.  tables: DEVICE array of N base
+ * pointers (rows of E elements, 16-byte aligned when E*sizeof(T) is a multiple of 16); table_rows: DEVICE array of N row
+ * counts; idx (B,N) int64/int32 RAW per-table indices (no offsets).  An index outside its table reads as a zero row and
+ * raises *err_flag.  Backward: the caller buckets idx over the concatenated row space (trs_csr_build with offsets =
+ * cumulative row counts) and scatters into one (sum rows, E) gradient whose slices are the tables' gradients.          */
+int trs_gather_rows_tables(const void* const* tables, const int64_t* table_rows, int32_t E, int32_t dtype, const void* idx,
+                           int32_t idx_dtype, int64_t B, int32_t N, void* out, int32_t* err_flag, trs_stream_t stream);
+
 /* ---- I3: field-aware gather ---------------------------------------------------------------
  * out[b, i*N+j, :] = tables[i][idx[b,j] + offsets[j], :]   for i,j in [0,N)
  * `tables` = device array of N table base pointers (each V x E).

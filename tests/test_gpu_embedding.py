@@ -745,3 +745,78 @@ def test_fused_optimizer_state_of_first_order_table_persists(dev, kind):
         assert len(opt._state) == 2, "one state entry per table, not one per step"
         assert rel_err(wd.detach().cpu(), wr.detach()) <= 1e-5, step
         assert rel_err(fd.detach().cpu(), fr.detach()) <= 1e-5, step
+
+
+def test_stacked_single_index_embeddings_take_one_launch(monkeypatch):
+    """A StackedInput of SingleIndexEmbeddings (reference inputs/base/stacked_inp.py:94-134: N nn.Embedding lookups + a cat;
+    how the reference's own tests and most user code build their inputs) routed by ``Inputs`` onto ONE lookup launch over
+    the N separate tables (trs_gather_rows_tables) and one bucket walk: output bit-exact against the oracle's
+    single_index_embedding per table, every table's gradient against the oracle's, and equal to the child-by-child path."""
+    from oracle import cpu_ref as O
+    from torecsys_amd import functional as F_
+    from torecsys_amd import inputs as I
+    dev = torch.device("cuda:0")
+
+    class StackedInput(I.BaseInput):      # stand-in for the reference's class (Inputs dispatches on the class NAME)
+        def __init__(self, inputs):
+            super().__init__()
+            self.inputs = inputs
+            self.length = len(inputs[0])
+            for i, inp in enumerate(inputs):
+                self.add_module(f"Input_{i}", inp)
+            self.set_schema([c for inp in inputs for c in inp.schema.inputs])
+
+        def forward(self, d):
+            outs = []
+            for inp in self.inputs:
+                v = d[inp.schema.inputs[0]]
+                outs.append(inp(v.unsqueeze(-1) if v.dim() == 1 else v).rename(None))
+            out = torch.cat(outs, dim=1)
+            out.names = ("B", "N", "E")
+            return out
+
+    g = torch.Generator().manual_seed(11)
+    for dt, E, B, sizes, idt in ((torch.float32, 16, 300, [7, 1, 50, 3, 1000], torch.int64),
+                                 (torch.bfloat16, 64, 4096, [40 + 13 * i for i in range(39)], torch.int32),
+                                 (torch.float32, 10, 257, [5, 9, 2], torch.int64)):      # rows that are not 16-byte multiples
+        children = []
+        for i, V in enumerate(sizes):
+            c = I.SingleIndexEmbedding(E, V)
+            c.set_schema([f"c{i}"])
+            children.append(c)
+        router = I.Inputs({"emb_inputs": StackedInput(children)}).to(dev).to(dt)
+        cols = {f"c{i}": torch.randint(0, V, (B,), generator=g).to(idt).to(dev) for i, V in enumerate(sizes)}
+        gout = torch.randn(B, len(sizes), E, generator=g).to(dt).to(dev)
+        calls = {"tables": 0, "rows": 0}
+        real_t, real_r = F_.gather_rows_tables, F_.gather_rows
+        monkeypatch.setattr(F_, "gather_rows_tables", lambda *a, **k: (calls.__setitem__("tables", calls["tables"] + 1), real_t(*a, **k))[1])
+        monkeypatch.setattr(F_, "gather_rows", lambda *a, **k: (calls.__setitem__("rows", calls["rows"] + 1), real_r(*a, **k))[1])
+        out = router(cols)["emb_inputs"]
+        assert calls == {"tables": 1, "rows": 0}, calls
+        assert out.names == ("B", "N", "E") and tuple(out.shape) == (B, len(sizes), E)
+        out.rename(None).backward(gout)
+        torch.cuda.synchronize()
+        got = [c.embedding.weight.grad.clone() for c in children]
+        # oracle: one single_index_embedding per table on the CPU
+        ws = [c.embedding.weight.detach().cpu().float().requires_grad_() for c in children]      # (exact images of the bf16 rows)
+        ref = torch.cat([O.single_index_embedding(w, cols[f"c{i}"].cpu().long().unsqueeze(-1), None) for i, w in enumerate(ws)], 1)
+        assert torch.equal(out.rename(None).detach().float().cpu(), ref.detach()), "lookup not bit-exact"
+        ref.backward(gout.float().cpu())
+        tol = 1e-5 if dt == torch.float32 else 1e-2
+        for i, (a, w) in enumerate(zip(got, ws)):
+            assert rel_err(a.float().cpu(), w.grad.float()) <= tol, i
+        # ... and the child-by-child path gives the same
+        for c in children:
+            c.embedding.weight.grad = None
+        monkeypatch.setattr(I, "STACKED_ONE_LAUNCH", False)
+        out2 = router(cols)["emb_inputs"]
+        assert calls["tables"] == 1 and calls["rows"] == len(sizes)
+        assert torch.equal(out2.rename(None), out.rename(None))
+        monkeypatch.setattr(I, "STACKED_ONE_LAUNCH", True)
+        monkeypatch.setattr(F_, "gather_rows_tables", real_t)
+        monkeypatch.setattr(F_, "gather_rows", real_r)
+    # an index outside its table raises the device-side flag
+    bad = dict(cols)
+    bad["c1"] = torch.full_like(cols["c1"], sizes[1])
+    router(bad)
+    assert F_.index_errors_seen(dev)

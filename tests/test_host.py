@@ -442,6 +442,86 @@ def test_reference_model_forwards_run_over_the_dropins(monkeypatch):
                 sys.modules.pop(k, None)
 
 
+@pytest.mark.skipif(not __import__("os").path.isdir(REFERENCE + "/torecsys"),
+                    reason="the reference never travels to the GPU box: build-container test")
+def test_reference_stacked_input_of_single_index_embeddings_is_one_lookup(monkeypatch):
+    """The REAL reference's ``StackedInput`` (inputs/base/stacked_inp.py:94-134) over patched ``SingleIndexEmbedding``s
+    inside the patched ``Inputs`` router: the router recognises the schema and issues ONE table-list lookup
+    (F_.gather_rows_tables; replaced here by an oracle-backed CPU stand-in, as the other entry points are) instead of N
+    lookups + a cat; output names / shape / values and every table's gradient equal the un-patched reference."""
+    import warnings
+    import torecsys_amd
+    from oracle import cpu_ref as O
+    from torecsys_amd import functional as F_
+    from torecsys_amd import inputs as I
+    warnings.filterwarnings("ignore")
+    pkg, (ref_inputs, ref_layers, ref_models), saved = _import_real_reference()
+    try:
+        B, E = 9, 8
+        sizes = [7, 3, 11, 5]
+        g = torch.Generator().manual_seed(4)
+        cols = {"c%d" % i: torch.randint(0, v, (B,), generator=g) for i, v in enumerate(sizes)}
+
+        def build():
+            torch.manual_seed(2)
+            children = []
+            for i, v in enumerate(sizes):
+                c = ref_inputs.SingleIndexEmbedding(E, v)
+                c.set_schema(["c%d" % i])
+                children.append(c)
+            return ref_inputs.Inputs(schema={"emb_inputs": ref_inputs.StackedInput(children)})
+
+        def run(router):
+            out = router({k: v.clone() for k, v in cols.items()})["emb_inputs"]
+            (out.rename(None) * torch.arange(1, E + 1).float()).sum().backward()
+            return out, {n: p.grad.clone() for n, p in router.named_parameters()}
+
+        ref_router = build()
+        y0, g0 = run(ref_router)
+        torecsys_amd.patch(pkg)
+        try:
+            calls = {"tables": 0, "rows": 0}
+
+            def gather_rows_tables(weights, idx):
+                calls["tables"] += 1
+                idx = idx.rename(None) if idx.has_names() else idx
+                return torch.cat([O.single_index_embedding(w, idx[:, i:i + 1], None) for i, w in enumerate(weights)], 1)
+
+            def gather_rows(weight, idx, offsets=None, padding_idx=None, opt=None):
+                calls["rows"] += 1
+                return O.single_index_embedding(weight, idx.rename(None) if idx.has_names() else idx, padding_idx)
+
+            monkeypatch.setattr(F_, "gather_rows_tables", gather_rows_tables)
+            monkeypatch.setattr(F_, "gather_rows", gather_rows)
+            monkeypatch.setattr(F_, "pack_columns_supported", lambda cols: False)
+            monkeypatch.setattr(I, "_on_hip", lambda t: True)
+            router = build()
+            assert isinstance(router, I.Inputs) and router.schema["emb_inputs"].__class__.__name__ == "StackedInput"
+            assert all(type(c) is I.SingleIndexEmbedding for c in router.schema["emb_inputs"].inputs)
+            router.load_state_dict(ref_router.state_dict())
+            y, gr = run(router)
+            assert calls == {"tables": 1, "rows": 0}, calls
+            assert y.names == y0.names and tuple(y.shape) == tuple(y0.shape) == (B, len(sizes), E)
+            assert torch.equal(y.rename(None), y0.rename(None))
+            assert set(gr) == set(g0)
+            for n in gr:
+                assert torch.allclose(gr[n], g0[n], rtol=1e-6, atol=0), n
+            # a child with a padding row is outside the one-launch form: the StackedInput's own forward runs
+            monkeypatch.setattr(I, "STACKED_ONE_LAUNCH", False)
+            run(router)
+            assert calls["tables"] == 1 and calls["rows"] == len(sizes), calls
+        finally:
+            torecsys_amd.unpatch()
+    finally:
+        for k in [k for k in sys.modules if k == "torecsys" or k.startswith("torecsys.")]:
+            del sys.modules[k]
+        for k, v in saved.items():
+            if v is not None:
+                sys.modules[k] = v
+            else:
+                sys.modules.pop(k, None)
+
+
 @pytest.mark.parametrize("N", [2, 3, 7, 16, 32, 33, 39, 40, 48])
 def test_afm_pair_tiles_cover_every_pair_once_and_are_field_disjoint(N):
     """the host-built tile schedule of the AFM backward kernel (afm_packed_tiles): each of the N(N-1)/2 pairs exactly once,

@@ -55,7 +55,7 @@ out += ["", f"Default line extras: `roofline_large_table.frac` = {lt.get('frac')
         "", "The default line as printed:", "", "```", json.dumps(d), "```", "",
         "## stand-alone kernels (`tools/kbench.py`, HIP events on the launch stream; B = 65 536, N = 39, E = 64, bf16 unless noted)",
         "", "```"]
-for name in ("kbench.txt", "kbench_pairx_mlpf.txt"):
+for name in ("kbench.txt", "kbench_pairx_mlpf.txt", "kbench_ffm.txt"):
     with open(os.path.join(src, name)) as f:
         out += [ln.rstrip() for ln in f if ln.strip() and "amdgpu.ids" not in ln]
 out += ["```", ""]

@@ -73,6 +73,7 @@ SIGNATURES = {
     "trs_mark_timestamp": (c_int32, [_P, _I32, _P]),
     "trs_wall_clock_khz": (_I64, []),
     "trs_gather_rows": (c_int32, [_P, _I64, _I32, _I32, _P, _I32, _P, _I64, _I32, _P, _P, _P]),
+    "trs_gather_rows_tables": (c_int32, [_P, _P, _I32, _I32, _P, _I32, _I64, _I32, _P, _P, _P]),
     "trs_fa_gather_rows": (c_int32, [_P, _I64, _I32, _I32, _P, _I32, _P, _I64, _I32, _P, _P, _P]),
     "trs_csr_workspace_bytes": (_SZ, [_I64, _I64]),
     "trs_csr_build": (c_int32, [_P, _I32, _P, _I64, _I32, _I64, _P, _P, _P, _SZ, _P, _P]),

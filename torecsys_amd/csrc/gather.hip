@@ -355,6 +355,106 @@ extern "C" int64_t trs_wall_clock_khz(void) {
 extern "C" int trs_version(void) { return TRS_ABI_VERSION; }
 extern "C" const char* trs_last_error_string(void) { return trs::err_buf(); }
 
+// ---- N separate tables, one column of the index block each (a StackedInput of SingleIndexEmbeddings, reference
+// inputs/base/stacked_inp.py:94-134: N nn.Embedding lookups + a cat): out[b, n, :] = tables[n][idx[b, n], :].  The tables
+// stay the caller's separate allocations (N parameters); the kernel takes their base pointers and row counts.  Same lane
+// layout as gather_rows_vec_kernel: one lane = one 16-byte vector of a row, UNROLL independent rows in flight.
+template <typename IdxT, int UNROLL>
+__global__ __launch_bounds__(256) void gather_tables_vec_kernel(const uint4* const* __restrict__ tables,
+                                                                const int64_t* __restrict__ table_rows,
+                                                                const IdxT* __restrict__ idx, uint4* __restrict__ out,
+                                                                int64_t total_vecs, int vpr, int N,
+                                                                int32_t* __restrict__ err_flag) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; t0 < total_vecs; t0 += stride * UNROLL) {
+    uint4 v[UNROLL];
+    bool ok[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t t = t0 + u * stride;
+      ok[u] = t < total_vecs;
+      v[u] = make_uint4(0, 0, 0, 0);
+      if (ok[u]) {
+        const unsigned p = (unsigned)(t / vpr);      // flat positions fit 32 bits (checked by the entry point)
+        const int lane_v = (int)(t - (int64_t)p * vpr);
+        const int n = (int)(p % (unsigned)N);
+        const int64_t r = (int64_t)idx[p];
+        if (r < 0 || r >= table_rows[n]) {
+          if (err_flag != nullptr) *err_flag = 1;      // reads as a zero row
+        } else {
+          v[u] = tables[n][r * vpr + lane_v];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int64_t t = t0 + u * stride;
+      if (ok[u]) {
+        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+        const u32x4 w = {v[u].x, v[u].y, v[u].z, v[u].w};
+        __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(&out[t]));
+      }
+    }
+  }
+}
+
+template <typename T, typename IdxT>
+__global__ __launch_bounds__(256) void gather_tables_elem_kernel(const T* const* __restrict__ tables,
+                                                                 const int64_t* __restrict__ table_rows,
+                                                                 const IdxT* __restrict__ idx, T* __restrict__ out,
+                                                                 int64_t total, int E, int N, int32_t* __restrict__ err_flag) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t p = t / E;
+    const int e = (int)(t - p * E);
+    const int n = (int)(p % N);
+    const int64_t r = (int64_t)idx[p];
+    if (r < 0 || r >= table_rows[n]) {
+      if (err_flag != nullptr) *err_flag = 1;
+      out[t] = T{};
+    } else {
+      out[t] = tables[n][r * E + e];
+    }
+  }
+}
+
+template <typename IdxT>
+static int gather_tables_dispatch(const void* const* tables, const int64_t* table_rows, int E, int dtype, const IdxT* idx,
+                                  int64_t rows, int N, void* out, int32_t* err_flag, hipStream_t s) {
+  const int row_bytes = E * dtype_size(dtype);
+  if (row_bytes % 16 == 0 && aligned16(out)) {      // (the tables' own alignment: the host checks every base pointer)
+    const int vpr = row_bytes / 16;
+    const int64_t total = rows * vpr;
+    constexpr int UNROLL = 4;
+    hipLaunchKernelGGL((gather_tables_vec_kernel<IdxT, UNROLL>), dim3(stream_grid((total + UNROLL - 1) / UNROLL, 256, 256 * 32)),
+                       dim3(256), 0, s, (const uint4* const*)tables, table_rows, idx, (uint4*)out, total, vpr, N, err_flag);
+  } else if (dtype == TRS_F32) {
+    hipLaunchKernelGGL((gather_tables_elem_kernel<float, IdxT>), dim3(stream_grid(rows * E, 256, 256 * 32)), dim3(256), 0, s,
+                       (const float* const*)tables, table_rows, idx, (float*)out, rows * E, E, N, err_flag);
+  } else {
+    hipLaunchKernelGGL((gather_tables_elem_kernel<bf16_t, IdxT>), dim3(stream_grid(rows * E, 256, 256 * 32)), dim3(256), 0, s,
+                       (const bf16_t* const*)tables, table_rows, idx, (bf16_t*)out, rows * E, E, N, err_flag);
+  }
+  return check_launch("gather_rows_tables");
+}
+
+extern "C" int trs_gather_rows_tables(const void* const* tables, const int64_t* table_rows, int32_t E, int32_t dtype,
+                                      const void* idx, int32_t idx_dtype, int64_t B, int32_t N, void* out,
+                                      int32_t* err_flag, trs_stream_t stream) {
+  if (B == 0) return TRS_OK;  // empty batch: nothing to do (pointers may be NULL)
+  TRS_REQUIRE(tables && table_rows && idx && out, TRS_EINVAL, "gather_rows_tables: NULL pointer");
+  TRS_REQUIRE(E > 0 && B >= 0 && N > 0, TRS_EINVAL, "gather_rows_tables: bad size E=%d B=%lld N=%d", E, (long long)B, N);
+  TRS_REQUIRE(dtype == TRS_F32 || dtype == TRS_BF16, TRS_EDTYPE, "gather_rows_tables: dtype %d", dtype);
+  TRS_REQUIRE(idx_dtype == TRS_I64 || idx_dtype == TRS_I32, TRS_EDTYPE, "gather_rows_tables: idx dtype %d", idx_dtype);
+  TRS_REQUIRE(B * (int64_t)N < ((int64_t)1 << 32), TRS_ESHAPE, "gather_rows_tables: B*N = %lld lookups must fit 32 bits",
+              (long long)(B * (int64_t)N));
+  hipStream_t s = (hipStream_t)stream;
+  if (idx_dtype == TRS_I64)
+    return gather_tables_dispatch<int64_t>(tables, table_rows, E, dtype, (const int64_t*)idx, B * N, N, out, err_flag, s);
+  return gather_tables_dispatch<int32_t>(tables, table_rows, E, dtype, (const int32_t*)idx, B * N, N, out, err_flag, s);
+}
+
 extern "C" int trs_gather_rows(const void* table, int64_t V, int32_t E, int32_t dtype, const void* idx,
                                int32_t idx_dtype, const int64_t* offsets, int64_t B, int32_t N, void* out,
                                int32_t* err_flag, trs_stream_t stream) {

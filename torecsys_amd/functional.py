@@ -320,7 +320,7 @@ def scatter_rows(rb: RowBuckets, like_table: torch.Tensor, g_rows: Optional[torc
                  padding_row: int = -1, g_rows_batch_stride: int = 0) -> torch.Tensor:
     """Dense gradient of a (V,E) table: see trs_scatter_rows in include/trs_abi.h."""
     V, E = like_table.shape
-    grad = torch.empty_like(like_table)
+    grad = torch.empty(V, E, dtype=like_table.dtype, device=like_table.device)
     ws_bytes = size_query("trs_scatter_workspace_bytes", rb.BN, rb.N, E, value_dtype_code(like_table))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=like_table.device)
     call("trs_scatter_rows", ptr(g_rows), g_rows_batch_stride, ptr(g_bcast), _bcast_cols(g_bcast, E), ptr(fm_sum),
@@ -667,6 +667,89 @@ class _FAGather(Function):
             else:
                 grads.append(None)
         return (None, None, *grads)
+
+
+_table_rows_cache = {}
+
+
+def _tables_meta(weights: Sequence[torch.Tensor]):
+    """(row counts, cumulative row offsets) of N tables as device int64 tensors, cached per shape tuple and device"""
+    key = (tuple(int(w.shape[0]) for w in weights), weights[0].device)
+    m = _table_rows_cache.get(key)
+    if m is None:
+        if len(_table_rows_cache) > 64:
+            _table_rows_cache.clear()
+        rows = torch.tensor(key[0], dtype=torch.int64)
+        off = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(rows, 0)[:-1]])
+        m = _table_rows_cache[key] = (rows.to(key[1]), off.to(key[1]))
+    return m
+
+
+class _GatherRowsTables(Function):
+    """out[b,n,:] = weights[n][idx[b,n],:] for N SEPARATE tables of one width (a StackedInput of SingleIndexEmbeddings,
+    stacked_inp.py:94-134) in one launch (trs_gather_rows_tables).  Backward: one row-bucket build over the concatenated
+    row space and one bucket walk into a (sum V_n, E) gradient; every table's gradient is its slice of that tensor."""
+
+    @staticmethod
+    def forward(ctx, idx, *weights):
+        require_device(idx, *weights)
+        B, N = idx.shape
+        E = weights[0].shape[1]
+        if len(weights) != N:
+            raise ValueError(f"gather_rows_tables: {len(weights)} tables for {N} index columns")
+        ws = [w.contiguous() for w in weights]
+        for w in ws:
+            if w.dim() != 2 or w.shape[1] != E or w.dtype != ws[0].dtype:
+                raise ValueError("gather_rows_tables: the tables must share embed size and dtype")
+            if (E * w.element_size()) % 16 == 0 and w.data_ptr() % 16 != 0:
+                raise ValueError("gather_rows_tables: every table must be 16-byte aligned")
+        rows, offsets = _tables_meta(ws)
+        out = torch.empty(B, N, E, dtype=ws[0].dtype, device=ws[0].device)
+        flag = _ErrFlag(out.device)
+        call("trs_gather_rows_tables", ptr(_pointer_table(ws)), ptr(rows), E, value_dtype_code(ws[0]), ptr(idx),
+             index_dtype_code(idx), B, N, ptr(out), ptr(flag.t), stream_ptr())
+        flag.check("gather_rows_tables")
+        if any(ctx.needs_input_grad[1:]):
+            prefetch_row_buckets(idx, offsets, int(sum(w.shape[0] for w in ws)))
+        ctx.save_for_backward(idx, offsets)
+        ctx.shapes = [tuple(w.shape) for w in ws]
+        ctx.like = ws[0]
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        idx, offsets = ctx.saved_tensors
+        _adopt_grads(g)
+        Vs = [s[0] for s in ctx.shapes]
+        Vtot, E = sum(Vs), ctx.shapes[0][1]
+        rb = row_buckets(idx, offsets, Vtot)
+        gcat = scatter_rows(rb, _ShapeOnly(Vtot, E, ctx.like), g_rows=g.contiguous())
+        grads, o = [], 0
+        for i, v in enumerate(Vs):
+            grads.append(gcat[o:o + v] if ctx.needs_input_grad[1 + i] else None)
+            o += v
+        return (None, *grads)
+
+
+class _ShapeOnly:
+    """what scatter_rows needs of its ``like_table`` when no (V,E) table exists: shape, dtype, device"""
+
+    def __init__(self, V, E, like):
+        self.shape, self.dtype, self.device, self._like = (V, E), like.dtype, like.device, like
+
+    def element_size(self):
+        return self._like.element_size()
+
+
+def gather_rows_tables(weights: Sequence[torch.Tensor], idx: torch.Tensor) -> torch.Tensor:
+    """(B,N) raw per-table indices -> (B,N,E) from N separate (V_n,E) tables; dense per-table gradients"""
+    idx = _as_index(idx)
+    if idx.dim() == 1:
+        idx = idx.unsqueeze(-1)
+    if idx.dim() != 2:
+        raise ValueError(f"indices must be (B, N), got shape {tuple(idx.shape)}")
+    return _GatherRowsTables.apply(idx, *weights)
 
 
 def fa_gather_rows(weights: Sequence[torch.Tensor], idx: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:

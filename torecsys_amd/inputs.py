@@ -202,6 +202,12 @@ PAIR_FIRST_ORDER = os.environ.get("TRS_PAIR_FIRST_ORDER", "0") == "1"
 
 # 0: every lookup on the caller's stream; 1: lookups beyond the first on the "lookup" side stream, enqueued BEHIND the first
 # (the forward stays serial, the backward's bucket walks run side by side); 2: enqueued in FRONT of it (parallel forward)
+def _on_hip(t: torch.Tensor) -> bool:
+    return t.is_cuda
+
+
+# a StackedInput of SingleIndexEmbeddings as ONE lookup launch over the separate tables (TRS_STACKED_ONE_LAUNCH=0: its own forward)
+STACKED_ONE_LAUNCH = os.environ.get("TRS_STACKED_ONE_LAUNCH", "1") not in ("", "0")
 LOOKUP_STREAMS = int(os.environ.get("TRS_LOOKUP_STREAMS", "1") or 0)
 _SIDE_LOOKUPS = (SingleIndexEmbedding, MultiIndicesEmbedding, MultiIndicesFieldAwareEmbedding)
 
@@ -253,6 +259,34 @@ class Inputs(BaseInput):
                 return k
         return None
 
+    @staticmethod
+    def _stacked_single_index_tables(stacked, inputs):
+        """(children, their index columns) when ``stacked`` is a StackedInput whose inputs are all plain
+        SingleIndexEmbeddings of this package -- one column each, one embed size / dtype / HIP device, no padding row, no
+        fused optimizer -- i.e. when F_.gather_rows_tables computes exactly what its forward computes; else None."""
+        children = getattr(stacked, 'inputs', None)
+        if stacked.__class__.__name__ != 'StackedInput' or not isinstance(children, (list, tuple)) or len(children) < 2:
+            return None
+        w0 = getattr(getattr(children[0], 'embedding', None), 'weight', None)
+        if w0 is None or not _on_hip(w0):
+            return None
+        raw = []
+        for c in children:
+            if type(c) is not SingleIndexEmbedding or c.schema is None or len(c.schema.inputs) != 1:
+                return None
+            w = c.embedding.weight
+            if (c.embedding.padding_idx is not None or c.fused_optimizer is not None or w.shape[1] != w0.shape[1]
+                    or w.dtype != w0.dtype or w.device != w0.device or not w.is_contiguous()):
+                return None
+            v = inputs[c.schema.inputs[0]]
+            v = v.rename(None) if v.has_names() else v
+            if v.is_floating_point() or v.device != w0.device or not (v.dim() == 1 or (v.dim() == 2 and v.shape[1] == 1)):
+                return None
+            raw.append(v)
+        if len({v.shape[0] for v in raw}) != 1 or len({v.dtype for v in raw}) != 1 or raw[0].dtype not in (torch.int64, torch.int32):
+            return None
+        return list(children), raw
+
     def forward(self, inputs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         outputs = {}
         packed = {}                    # tuple of column names -> packed tensor (shared between schema entries)
@@ -269,6 +303,23 @@ class Inputs(BaseInput):
             if k in partner and partner[k] in self.schema:
                 continue               # a first-order table served by its partner's pass
             if emb_fn.__class__.__name__ in ['ConcatInput', 'StackedInput']:
+                stacked = self._stacked_single_index_tables(emb_fn, inputs) if STACKED_ONE_LAUNCH else None
+                if stacked is not None:
+                    # N SingleIndexEmbeddings under a StackedInput (stacked_inp.py:94-134: N lookups + a cat, and N
+                    # bucket builds + walks in the backward): one lookup launch over the N separate tables, one walk
+                    children, raw = stacked
+                    names = tuple(c.schema.inputs[0] for c in children)
+                    idx = packed.get(names)
+                    if idx is None:
+                        if F_.pack_columns_supported(raw):
+                            idx = F_.pack_columns(raw)
+                        else:
+                            idx = torch.cat([v.unsqueeze(-1) if v.dim() == 1 else v for v in raw], dim=1)
+                        packed[names] = idx
+                    out = F_.gather_rows_tables([c.embedding.weight for c in children], idx)
+                    out.names = ('B', 'N', 'E',)
+                    outputs[k] = out
+                    continue
                 args[k] = [{i: inputs[i] for i in emb_fn.schema.inputs}]
                 continue
             names = tuple(emb_fn.schema.inputs)
