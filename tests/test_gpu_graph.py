@@ -65,6 +65,51 @@ def test_graphed_step_matches_eager(dev, dt):
         step(batches[0][0][:10], batches[0][1][:10])
 
 
+def test_graphed_step_input_sets_replay_without_copies(dev):
+    """GraphedStep(input_sets=K): one captured graph per set of static input buffers in one memory pool.  ``load(k, batch)``
+    once, then ``replay(k)`` in any order and repeatedly: loss and gradients of the batch that set holds equal the eager
+    step's, and ``p.grad`` is the tensor the replay has just refreshed."""
+    from torecsys_amd.graph import GraphedStep
+    dt = torch.bfloat16
+    B, N, E = 512, 7, 32
+    sizes = [50, 3, 1000, 17, 400, 9, 121]
+    inputs, model, emb, feat = _deepfm(dev, dt, N, E, sizes)
+    params = list(inputs.parameters()) + list(model.parameters())
+    g = torch.Generator().manual_seed(1)
+    batches = [(torch.stack([torch.randint(0, s, (B,), generator=g) for s in sizes], 1).to(dev),
+                (torch.rand(B, 1, generator=g) < 0.3).float().to(dev)) for _ in range(3)]
+    crit = torch.nn.BCEWithLogitsLoss()
+
+    def fn(ix, lab):
+        loss = crit(model(**inputs({"c0": ix})).float(), lab)
+        loss.backward()
+        return loss
+
+    eager = []
+    for ix, lab in batches:
+        for p in params:
+            p.grad = None
+        loss = fn(ix, lab)
+        eager.append((loss.detach().clone(), emb.embedding.weight.grad.clone(), model.deep.model.Linear_0.weight.grad.clone()))
+    del loss
+    step = GraphedStep(fn, batches[0], params=params, warmup=1, input_sets=3)
+    assert step.input_sets == 3
+    for k, (ix, lab) in enumerate(batches):
+        step.load(k, ix, lab)
+    for k in (2, 0, 1, 1, 2, 0):
+        loss = step.replay(k)
+        torch.cuda.synchronize()
+        l0, ge, gw = eager[k]
+        assert torch.equal(loss.detach(), l0), k
+        assert rel_err(emb.embedding.weight.grad.float().cpu(), ge.float().cpu()) <= 1e-2, k
+        assert rel_err(model.deep.model.Linear_0.weight.grad.float().cpu(), gw.float().cpu()) <= 1e-2, k
+    # the copying form still works (set 0)
+    loss = step(*batches[1])
+    torch.cuda.synchronize()
+    assert torch.equal(loss.detach(), eager[1][0])
+    step.release_outputs()
+
+
 def test_timestamp_marks_agree_with_events(dev):
     """_abi.time_kernel: HIP events in eager mode, trs_mark_timestamp pairs inside a capture."""
     from torecsys_amd import _abi

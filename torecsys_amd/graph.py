@@ -30,20 +30,70 @@ __all__ = ["GraphedStep", "GraphedRegion"]
 
 class GraphedStep:
     def __init__(self, fn: Callable[..., torch.Tensor], example_inputs: Sequence[torch.Tensor],
-                 params: Optional[Iterable[torch.nn.Parameter]] = None, warmup: int = 3):
+                 params: Optional[Iterable[torch.nn.Parameter]] = None, warmup: int = 3, input_sets: int = 1):
         """``fn(*static_inputs) -> loss`` runs forward AND backward (and optimizer.step() if wanted).
         ``params``: parameters whose ``.grad`` must be dropped before capture so that the captured backward
         allocates them from the graph's private pool (they then stay valid, updated in place, after every replay).
-        At least one eager warm-up iteration always runs (on a side stream) before the capture."""
+        At least one eager warm-up iteration always runs (on a side stream) before the capture.
+
+        ``input_sets`` = K > 1: K sets of static input buffers, one captured graph per set (all in one memory pool: the
+        step's intermediates exist once).  A captured step reads its inputs at fixed addresses, so ``step(*batch)`` has
+        to COPY every batch into them first (20 MB of indices at the BASELINE shape: 16 us + a launch gap per 1.25 ms
+        step); with K sets the input pipeline writes batch k+1 straight into ``static_inputs((k+1) % K)`` while step k
+        runs (its host-to-device copy lands there) and ``replay(k % K)`` copies nothing.  Parameter gradients: every set's
+        graph writes its own gradient tensors; ``replay(k)`` rebinds ``p.grad`` to the ones it has just refreshed."""
         if not all(t.is_cuda for t in example_inputs):
             raise RuntimeError("GraphedStep: inputs must live on the HIP device (no CPU path)")
+        if int(input_sets) < 1:
+            raise ValueError("GraphedStep: input_sets must be >= 1")
         self._fn = fn
         self._params = list(params) if params is not None else []
         self._static = [t.clone() for t in example_inputs]
+        self._extra_static = [[t.clone() for t in example_inputs] for _ in range(int(input_sets) - 1)]
         self._warmup = int(warmup)
         self._graph = None
+        self._extra = []            # (graph, output, [grad per param]) of input sets 1 .. K-1
+        self._grads0 = None
         self.output = None
         self.recapture()
+
+    @property
+    def input_sets(self) -> int:
+        return 1 + len(self._extra_static)
+
+    def static_inputs(self, k: int = 0):
+        """the static input tensors of set ``k``: write the next batch into them (in stream order), then ``replay(k)``"""
+        return list(self._static if k == 0 else self._extra_static[k - 1])
+
+    def load(self, k: int, *inputs: torch.Tensor) -> None:
+        """copy a batch into input set ``k`` (what an input pipeline does instead: produce the batch there)"""
+        dsts = self.static_inputs(k)
+        if len(inputs) != len(dsts):
+            raise ValueError(f"GraphedStep: expected {len(dsts)} inputs, got {len(inputs)}")
+        for dst, src in zip(dsts, inputs):
+            if dst.shape != src.shape or dst.dtype != src.dtype:
+                raise ValueError(f"GraphedStep: input {tuple(src.shape)}/{src.dtype} does not match the captured "
+                                 f"{tuple(dst.shape)}/{dst.dtype}")
+            dst.copy_(src, non_blocking=True)
+
+    def release_outputs(self) -> None:
+        """drop the captured outputs (losses with their autograd graphs): needed before ANOTHER capture of the same
+        parameters -- a live graph keeps the parameters' AccumulateGrad nodes bound to this capture's stream"""
+        self.output = None
+        self._extra = [(g, None, grads) for g, _, grads in self._extra]
+
+    def replay(self, k: int = 0) -> torch.Tensor:
+        """run the step on whatever input set ``k`` holds: no copy"""
+        if k == 0:
+            self._graph.replay()
+            grads, out = self._grads0, self.output
+        else:
+            g, out, grads = self._extra[k - 1]
+            g.replay()
+        if self._extra:
+            for p, gr in zip(self._params, grads):
+                p.grad = gr
+        return out
 
     def recapture(self):
         # eager warm-up on a side stream: lazy initialisation (hipBLASLt workspaces, TunableOp tuning, kernel
@@ -80,6 +130,20 @@ class GraphedStep:
             self.output = self._fn(*self._static)
         torch.cuda.synchronize()
         F_.clear_caches()          # entries made during the capture point into the graph's private pool
+        self._grads0 = [p.grad for p in self._params]
+        self._extra = []
+        for st in self._extra_static:      # further input sets: the same step captured on other buffers, same pool
+            for p in self._params:
+                p.grad = None
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self._graph.pool(), capture_error_mode="thread_local"):
+                out = self._fn(*st)
+            torch.cuda.synchronize()
+            F_.clear_caches()
+            self._extra.append((g, out, [p.grad for p in self._params]))
+        if self._extra:
+            for p, gr in zip(self._params, self._grads0):
+                p.grad = gr
 
     def __call__(self, *inputs: torch.Tensor) -> torch.Tensor:
         if len(inputs) != len(self._static):
@@ -89,8 +153,7 @@ class GraphedStep:
                 raise ValueError(f"GraphedStep: input {tuple(src.shape)}/{src.dtype} does not match the captured "
                                  f"{tuple(dst.shape)}/{dst.dtype}")
             dst.copy_(src, non_blocking=True)
-        self._graph.replay()
-        return self.output
+        return self.replay(0)
 
 
 class GraphedRegion:
