@@ -336,11 +336,13 @@ int trs_mlp_fused_supported(int32_t num_layers, const int32_t* widths);
  *   (the start-up environment may set TRS_MLP_RO=0: never / 2: at any size -- read once when the library is loaded);
  *   trs_mlp_fused_family(num_layers, widths, rows, request) -> the family (TILE or ROW_OWNER) that request runs, 0 when it
  *   cannot be met (ROW_OWNER on an uncovered shape; the forward then returns TRS_EINVAL).  A pure function.
- *   trs_mlp_fused_bwd_data(family) must be given THAT value (TILE or ROW_OWNER; AUTO is TRS_EINVAL): the caller records
+ *   trs_mlp_fused_bwd_data(family) must be given THAT value (TILE, ROW_OWNER or MIXED; AUTO is TRS_EINVAL): the caller records
  *   what its forward ran, so a policy or size threshold cannot come between a forward and its backward.              */
 #define TRS_MLP_FAMILY_AUTO 0
 #define TRS_MLP_FAMILY_TILE 1
 #define TRS_MLP_FAMILY_ROW_OWNER 2
+#define TRS_MLP_FAMILY_MIXED 3      /* row-owner forward, tile backward reading the row-owner sign-bit layout (covered
+                                       shapes below 131 072 rows: each direction on the family that is faster there) */
 /* Phases.  Both entry points (and trs_rows_gemm) first copy the weights into MFMA fragment order in the workspace, then run.
  * The copy depends on the parameters only, so a caller may take it off the critical path of its step:
  *   phase = ALL : copy, then run (one call does everything);

@@ -18,7 +18,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(params=[1, 2], ids=["tile-in-LDS kernels", "row-owner kernels"])
+@pytest.fixture(params=[1, 2, 3], ids=["tile-in-LDS kernels", "row-owner kernels", "row-owner forward + tile backward"])
 def ro_mode(request):
     """The two stack shapes of the models have a second pair of kernels (csrc/mlp_ro.hpp), chosen by AUTO from 131 072
     rows on.  Which family runs is a per-call request (functional.mlp_family; trs_mlp_fused_family in the ABI): every test
@@ -333,7 +333,7 @@ def test_backward_refuses_a_family_the_forward_did_not_report(dev):
 
 
 @pytest.mark.parametrize("widths,rows", [([32, 104, 200, 40], 700), ([416, 400, 400, 8], 3000)])
-@pytest.mark.parametrize("fam_req", [1, 2])
+@pytest.mark.parametrize("fam_req", [1, 2, 3])
 def test_pack_and_run_phases_equal_the_one_call_form(dev, widths, rows, fam_req):
     """C ABI phases: a PACK call (weights into fragment order, on a SIDE stream) followed by a RUN call on the packed
     workspace gives bit for bit what the one-call form gives -- forward, data gradient, bias gradients, and trs_rows_gemm."""

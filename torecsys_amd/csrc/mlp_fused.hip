@@ -150,6 +150,7 @@ struct MlpArgs {
   uint8_t* mask_in;   // sign bits [input > 0] of the stack's INPUT rows (an upstream ReLU's output), in the item order of
                       // the backward's last step: written by the forward, applied by the backward; may be null
   float* colsum_in;   // backward, with mask_in: partial column sums of the masked input gradient, [gridDim.x][step N]
+  int ro_masks;       // backward: the sign bits are in the ROW-OWNER kernels' layout (mlp_ro.hpp), see mlp_fused_bwd_kernel
 };
 
 // tiles of the step owned by this wave: wide outputs split the 32-column pairs over the 8 waves (all 8 row tiles
@@ -583,11 +584,19 @@ __global__ __launch_bounds__(64 * MF_WAVES, TRS_MF_MINW) void mlp_rows_gemm_kern
 // ------------------------------------------------------------------------------------------------ backward (data)
 // step s works on layer l = L-1-s: input = d(pre-activation of layer l) (rows x N_l) in LDS, output = d(input of layer l)
 // = d(output of layer l-1), masked by layer l-1's ReLU mask into d(pre-activation of layer l-1).
+template <bool RO_MASKS>
 __global__ __launch_bounds__(64 * MF_WAVES, TRS_MF_MINW) void mlp_fused_bwd_kernel(MlpArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* act = smem;
   float* scratch = reinterpret_cast<float*>(act + MF_ROWS * a.act_str);              // [8 row slices][512]
   float* csum = scratch + 8 * 512;                                                    // [nsteps + 1][512] running column sums
+  // sign bits written by the row-owner forward (TRS_MLP_FAMILY_MIXED): a 128-row tile's share of a layer is four 2 KB
+  // pieces (one per group of four 32-column chunks) -- one 16-byte load per thread into this 8 KB stage, picked apart per
+  // item in the epilogue.  Layout (mlp_ro.hpp): [pass of 256 rows][chunk / 4][slot = 2 (64 (row / 64) + (row % 32) + 32 g)
+  // + (row / 32) % 2][chunk % 4] 16-bit words; bit 4 h + k2 = column 32 chunk + 16 h + 8 g + 2 k2, bit 8 + 4 h + k2 the one
+  // after it.  This kernel's byte for (row, pair, q) -- bit j/2 + 4 (j & 1) = column 32 pair + 8 q + j -- is the two
+  // nibbles h = q / 2 of the word of (row, chunk = pair, g = q & 1).
+  unsigned short* mstage = reinterpret_cast<unsigned short*>(csum + (a.nsteps + 1) * 512);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, r = lane & 15;
   for (int i = threadIdx.x; i < (a.nsteps + 1) * 512; i += blockDim.x) csum[i] = 0.f;
   const int64_t ntiles = (a.rows + MF_ROWS - 1) / MF_ROWS;
@@ -600,7 +609,13 @@ __global__ __launch_bounds__(64 * MF_WAVES, TRS_MF_MINW) void mlp_fused_bwd_kern
       const MlpShare sh = mlp_share(st.N, wave);
       // the ReLU sign bits of this lane's outputs (the forward's vector for this pass and thread), in flight during the GEMM
       uint4 mraw = make_uint4(0, 0, 0, 0);
-      if (st.mask != nullptr) mraw = *(reinterpret_cast<const uint4*>(st.mask + tile * MF_MASK_TILE) + threadIdx.x);
+      if (st.mask != nullptr) {
+        if constexpr (RO_MASKS)      // piece threadIdx.x / 128 (= chunk group), 16 bytes of this tile's 2 KB of it
+          mraw = *reinterpret_cast<const uint4*>(st.mask + (tile >> 1) * 16384 + (threadIdx.x >> 7) * 4096 + (tile & 1) * 2048 +
+                                                 (threadIdx.x & 127) * 16);
+        else
+          mraw = *(reinterpret_cast<const uint4*>(st.mask + tile * MF_MASK_TILE) + threadIdx.x);
+      }
       const unsigned mword[4] = {mraw.x, mraw.y, mraw.z, mraw.w};
       mf_f32x4 acc[MF_MT][2 * MF_MAXP];
 #pragma unroll
@@ -632,6 +647,7 @@ __global__ __launch_bounds__(64 * MF_WAVES, TRS_MF_MINW) void mlp_fused_bwd_kern
       }
       const bool last = s + 1 == a.nsteps;
       const int out_cols = last ? st.out_stride : st.N;
+      if (RO_MASKS && st.mask != nullptr) reinterpret_cast<uint4*>(mstage)[threadIdx.x] = mraw;      // (read behind the barrier)
       MF_BAR();
       if (st.colsum != nullptr && threadIdx.x < st.K) {
         float t = 0.f;
@@ -660,10 +676,19 @@ __global__ __launch_bounds__(64 * MF_WAVES, TRS_MF_MINW) void mlp_fused_bwd_kern
               v[4 + i] = acc[mi][2 * pi + 1][i];
             }
             if (st.mask != nullptr) {
-              const int word = (int)mword[(pi * MCNT + mi) >> 2];
+              int word = (int)mword[(pi * MCNT + mi) >> 2];
+              int sh8 = 8 * ((pi * MCNT + mi) & 3);
+              if constexpr (RO_MASKS) {
+                const int rt_ = lrow + 16 * rt;                              // row inside the 128-row tile
+                const int slot = 2 * (64 * (rt_ >> 6) + (rt_ & 31) + 32 * (q & 1)) + ((rt_ >> 5) & 1);
+                const unsigned w16 = mstage[(sh.pair[pi] >> 2) * 1024 + slot * 4 + (sh.pair[pi] & 3)];
+                const unsigned nib = w16 >> (4 * (q >> 1));
+                word = (int)((nib & 0xFu) | ((nib >> 4) & 0xF0u));
+                sh8 = 0;
+              }
 #pragma unroll
               for (int j = 0; j < 8; ++j)      // sign-extended 1-bit field (0 / all ones) ANDed onto the value: 2 instructions
-                v[j] = __int_as_float(__float_as_int(v[j]) & __builtin_amdgcn_sbfe(word, 8 * ((pi * MCNT + mi) & 3) + mf_mask_bit(j), 1));
+                v[j] = __int_as_float(__float_as_int(v[j]) & __builtin_amdgcn_sbfe(word, sh8 + mf_mask_bit(j), 1));
             }
             const uint4 pk = Vec16<bf16_t>::pack(v);
             if (!last || a.colsum_in != nullptr) *reinterpret_cast<uint4*>(lds0 + rt * 16 * a.act_str + sh.pair[pi] * 64) = pk;
@@ -870,7 +895,7 @@ extern "C" int trs_mlp_fused_fwd(const void* x, int64_t rows, int32_t num_layers
   const int fam = mlp_resolve_family(L, widths, rows, family);
   TRS_REQUIRE(fam != 0, TRS_EINVAL, "mlp_fused_fwd: kernel family %d is not available for this stack (trs_mlp_fused_family)", family);
   if (rows == 0) return TRS_OK;
-  if (fam == TRS_MLP_FAMILY_ROW_OWNER)
+  if (fam == TRS_MLP_FAMILY_ROW_OWNER || fam == TRS_MLP_FAMILY_MIXED)
     return mlp_ro_fwd(x, rows, L, widths, weights, biases, hidden, masks, mask_in, y, workspace, s, phase);
   MlpArgs a;
   a.nsteps = L;
@@ -938,9 +963,9 @@ extern "C" int trs_mlp_fused_bwd_data(const void* gy, int64_t rows, int32_t num_
   const int L = num_layers;
   // the family is what the forward of these masks ran (trs_mlp_fused_family): AUTO is refused here because the policy
   // behind it is not the caller's record of what happened
-  TRS_REQUIRE((family == TRS_MLP_FAMILY_TILE || family == TRS_MLP_FAMILY_ROW_OWNER) &&
+  TRS_REQUIRE((family == TRS_MLP_FAMILY_TILE || family == TRS_MLP_FAMILY_ROW_OWNER || family == TRS_MLP_FAMILY_MIXED) &&
                   mlp_resolve_family(L, widths, rows, family) == family,
-              TRS_EINVAL, "mlp_fused_bwd_data: family must be the TILE / ROW_OWNER value the forward ran under (got %d)", family);
+              TRS_EINVAL, "mlp_fused_bwd_data: family must be the TILE / ROW_OWNER / MIXED value the forward ran under (got %d)", family);
   TRS_REQUIRE(pack_only || family != TRS_MLP_FAMILY_ROW_OWNER || gx != nullptr, TRS_EINVAL, "mlp_fused_bwd_data: the row-owner kernels need gx");
   TRS_REQUIRE(pack_only || ((mask_in == nullptr) == (gbias_in == nullptr) && (mask_in == nullptr || (L + 1 <= MF_MAXL && gx != nullptr))),
               TRS_EINVAL, "mlp_fused_bwd_data: mask_in and gbias_in come together (and with gx, at most %d layers)", MF_MAXL - 1);
@@ -999,17 +1024,21 @@ extern "C" int trs_mlp_fused_bwd_data(const void* gy, int64_t rows, int32_t num_
   }
   a.mask_in = nullptr;
   a.colsum_in = mask_in != nullptr ? part_base + poff : nullptr;      // (the workspace counts widths[0] as well)
-  const size_t lds = (size_t)MF_ROWS * a.act_str + 8 * 512 * 4 + (size_t)(L + 1) * 512 * 4;
+  a.ro_masks = family == TRS_MLP_FAMILY_MIXED ? 1 : 0;
+  const size_t lds = (size_t)MF_ROWS * a.act_str + 8 * 512 * 4 + (size_t)(L + 1) * 512 * 4 + (a.ro_masks ? 8192 : 0);
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute((const void*)mlp_fused_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
-        hipSuccess)
+    if (hipFuncSetAttribute((const void*)mlp_fused_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+            hipSuccess ||
+        hipFuncSetAttribute((const void*)mlp_fused_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+            hipSuccess)
       return check_launch("mlp_fused_bwd_data: LDS attribute");
     attr = true;
   }
   if (phase != TRS_MLP_PHASE_RUN) hipLaunchKernelGGL(mlp_prepack_many_kernel, dim3(pk_blocks, L), dim3(256), 0, s, pk);
   if (pack_only) return check_launch("mlp_fused_bwd_data(pack)");
-  hipLaunchKernelGGL(mlp_fused_bwd_kernel, dim3(grid), dim3(64 * MF_WAVES), lds, s, a);
+  if (a.ro_masks) hipLaunchKernelGGL(mlp_fused_bwd_kernel<true>, dim3(grid), dim3(64 * MF_WAVES), lds, s, a);
+  else hipLaunchKernelGGL(mlp_fused_bwd_kernel<false>, dim3(grid), dim3(64 * MF_WAVES), lds, s, a);
   MlpColsumArgs cs;
   cs.nparts = grid;
   int kmax = 0;

@@ -61,6 +61,11 @@ static const int RO_AUTO_POLICY = [] {
   return e != nullptr && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1;
 }();
 constexpr int64_t RO_MIN_ROWS = 131072;
+constexpr int64_t RO_MIXED_MIN_ROWS = 32768;
+static const bool RO_MIXED = [] {      // TRS_MLP_MIXED=0: AUTO never picks the mixed family
+  const char* e = getenv("TRS_MLP_MIXED");
+  return !(e != nullptr && e[0] == '0');
+}();
 
 bool mlp_ro_shape_ok(int L, const int32_t* widths, int64_t rows) {
   if (rows * 1024 >= ((int64_t)1 << 32)) return false;
@@ -73,8 +78,13 @@ int mlp_resolve_family(int L, const int32_t* widths, int64_t rows, int request) 
   switch (request) {
     case TRS_MLP_FAMILY_TILE: return TRS_MLP_FAMILY_TILE;
     case TRS_MLP_FAMILY_ROW_OWNER: return ok ? TRS_MLP_FAMILY_ROW_OWNER : 0;
+    case TRS_MLP_FAMILY_MIXED: return ok ? TRS_MLP_FAMILY_MIXED : 0;
     case TRS_MLP_FAMILY_AUTO:
       if (ok && (RO_AUTO_POLICY == 2 || (RO_AUTO_POLICY == 1 && rows >= RO_MIN_ROWS))) return TRS_MLP_FAMILY_ROW_OWNER;
+      // below that: the row-owner FORWARD (one pass per CU at 65 536 rows: 74 us against the tile kernel's 94-101) with the
+      // tile BACKWARD (92 against 119-125), which reads the row-owner sign-bit layout -- from RO_MIXED_MIN_ROWS rows on
+      // (fewer rows do not fill the 256-row passes of 256 workgroups)
+      if (ok && RO_AUTO_POLICY == 1 && RO_MIXED && rows >= RO_MIXED_MIN_ROWS) return TRS_MLP_FAMILY_MIXED;
       return TRS_MLP_FAMILY_TILE;
     default: return 0;
   }

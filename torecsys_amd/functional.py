@@ -1779,7 +1779,7 @@ def mlp_fused_supported(x: torch.Tensor, widths: Sequence[int]) -> bool:
     return mlp_fused_supported_for(x.numel() // max(1, x.shape[-1]), x.dtype, x.is_cuda, widths)
 
 
-MLP_FAMILY_AUTO, MLP_FAMILY_TILE, MLP_FAMILY_ROW_OWNER = 0, 1, 2
+MLP_FAMILY_AUTO, MLP_FAMILY_TILE, MLP_FAMILY_ROW_OWNER, MLP_FAMILY_MIXED = 0, 1, 2, 3
 _mlp_family_request = MLP_FAMILY_AUTO
 
 
@@ -1896,7 +1896,7 @@ def fused_mlp_backward_raw(gy2: torch.Tensor, widths: Sequence[int], Ws: Sequenc
     """trs_mlp_fused_bwd_data: (gx, gz [d(pre-activation) of the hidden layers], gb [fp32 bias gradients, padded]) and,
     with ``mask_in``, gb_in: gx is then masked by the upstream ReLU and gb_in holds its column sums.  ``family``: what
     fused_mlp_forward_raw returned with these masks."""
-    if family not in (MLP_FAMILY_TILE, MLP_FAMILY_ROW_OWNER):
+    if family not in (MLP_FAMILY_TILE, MLP_FAMILY_ROW_OWNER, MLP_FAMILY_MIXED):
         raise ValueError("fused_mlp_backward_raw: family must be the value the forward returned with these masks")
     L = len(Ws)
     rows, dev = gy2.shape[0], gy2.device

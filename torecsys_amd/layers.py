@@ -523,7 +523,7 @@ class CompressInteractionNetworkLayer(BaseLayer):
         return outputs
 
 
-PAD_MULTIPLE = 128        # hidden widths are zero-padded to a multiple of this inside the GEMMs
+PAD_MULTIPLE = int(os.environ.get("TRS_PAD_MULTIPLE", "128"))        # hidden widths are zero-padded to a multiple of this inside the GEMMs
 PAD_MIN_WIDTH = 192
 PAD_MIN_ROWS = 4096
 HYBRID_ONE_NODE = os.environ.get("TRS_HYBRID_ONE_NODE", "1") not in ("", "0")
