@@ -352,6 +352,11 @@ int trs_mlp_fused_supported(int32_t num_layers, const int32_t* widths);
  *                 of the RUN call;
  *   phase = RUN : the workspace holds what a PACK call with the same arguments left (the caller orders the two calls:
  *                 same stream, or an event); nothing is copied.                                                       */
+/* x_stride (trs_mlp_fused_fwd): elements between consecutive rows of x; 0 = widths[0].  A larger stride (a multiple of 8)
+ * makes the stack read the first widths[0] columns of wider rows -- the 416-wide tail of a deep branch on the 512-wide
+ * output of the library GEMM in front of it; row-owner and mixed family only (TRS_ESHAPE otherwise).  The matching
+ * backward may then be called with widths[0] = that stride under TRS_MLP_FAMILY_MIXED: it computes the gradient of all
+ * x_stride columns (those past the forward's width meet zero weights and come out as zeros).                       */
 #define TRS_MLP_PHASE_ALL 0
 #define TRS_MLP_PHASE_PACK 1
 #define TRS_MLP_PHASE_RUN 2
@@ -360,8 +365,8 @@ size_t trs_mlp_fused_workspace_bytes(int32_t num_layers, const int32_t* widths);
 size_t trs_mlp_fused_mask_bytes(int64_t rows);
 int trs_mlp_fused_fwd(const void* x, int64_t rows, int32_t num_layers, const int32_t* widths,
                       const void* const* weights, const void* const* biases, void* const* hidden, void* const* masks,
-                      void* mask_in, void* y, int32_t dtype, int32_t family, int32_t phase, void* workspace,
-                      size_t ws_bytes, trs_stream_t stream);
+                      void* mask_in, void* y, int32_t dtype, int32_t family, int32_t phase, int32_t x_stride,
+                      void* workspace, size_t ws_bytes, trs_stream_t stream);
 int trs_mlp_fused_bwd_data(const void* gy, int64_t rows, int32_t num_layers, const int32_t* widths,
                            const void* const* weights, const void* const* masks, void* const* gz, float* const* gbias,
                            void* gx, const void* mask_in, float* gbias_in, int32_t dtype, int32_t family, int32_t phase,

@@ -363,3 +363,41 @@ def test_pack_and_run_phases_equal_the_one_call_form(dev, widths, rows, fam_req)
     if F_.rows_gemm_supported(gz, W1, out_f, in_f):
         ws = F_.rows_gemm_pack(W1, 4096, widths[0], out_f, in_f)
         assert torch.equal(F_.rows_gemm(gz, W1, out_f, in_f), F_.rows_gemm(gz, W1, out_f, in_f, packed_ws=ws))
+
+
+def test_mixed_family_reads_the_first_columns_of_wider_rows(dev):
+    """The deep branch's arrangement: the library GEMM in front of the fused tail leaves 512-wide rows (zero beyond the 400
+    real columns), the tail's FORWARD reads their first 416 columns (x_stride) with the row-owner kernel, its BACKWARD runs
+    the tile kernels at the full 512 columns on the row-owner sign bits.  Equal to the 416-wide stack on the 416-wide copy
+    of the rows: output, hidden activations, input gradient (zeros in columns 416..511), inner gradients, bias gradients."""
+    from torecsys_amd import functional as F_
+    g = torch.Generator().manual_seed(9)
+    rows, wn, ww = 40000, 416, 512
+    widths = [wn, 400, 400, 8]
+    Ws, bs = _params([400, 400, 400, 8], g)
+    W0n = torch.zeros(400, wn, dtype=torch.bfloat16); W0n[:, :400] = Ws[0]
+    W0w = torch.zeros(400, ww, dtype=torch.bfloat16); W0w[:, :400] = Ws[0]
+    Wn = [W0n.to(dev)] + [w.to(dev) for w in Ws[1:]]
+    Ww = [W0w.to(dev)] + [w.to(dev) for w in Ws[1:]]
+    bd = [b.to(dev) for b in bs]
+    xw = torch.zeros(rows, ww, dtype=torch.bfloat16)
+    xw[:, :400] = torch.randn(rows, 400, generator=g).relu().bfloat16()
+    xw = xw.to(dev)
+    xn = xw[:, :wn].contiguous()
+    gy = torch.randn(rows, 8, generator=g).bfloat16().to(dev)
+    assert F_.mlp_fused_family(widths, rows, F_.MLP_FAMILY_MIXED) == F_.MLP_FAMILY_MIXED
+    y0, h0, m0, mi0, fam0 = F_.fused_mlp_forward_raw(xn, Wn, bd, input_mask=True, family=F_.MLP_FAMILY_MIXED)
+    y1, h1, m1, mi1, fam1 = F_.fused_mlp_forward_raw(xw, Wn, bd, input_mask=True, family=F_.MLP_FAMILY_MIXED, x_stride=ww)
+    assert fam0 == fam1 == F_.MLP_FAMILY_MIXED
+    assert torch.equal(y0, y1) and all(torch.equal(a, b) for a, b in zip(h0, h1))
+    gx0, gz0, gb0, gbi0 = F_.fused_mlp_backward_raw(gy, widths, Wn, m0, mi0, family=fam0)
+    gx1, gz1, gb1, gbi1 = F_.fused_mlp_backward_raw(gy, [ww] + widths[1:], Ww, m1, mi1, family=fam1)
+    torch.cuda.synchronize()
+    assert gx1.shape == (rows, ww) and torch.equal(gx1[:, :wn], gx0) and not gx1[:, wn:].any()
+    assert all(torch.equal(a, b) for a, b in zip(gz0, gz1))
+    for a, b in zip(gb0, gb1):
+        assert rel_err(b.cpu(), a.cpu()) <= 1e-6
+    assert rel_err(gbi1[:wn].cpu(), gbi0.cpu()) <= 1e-6 and not gbi1[wn:].any()
+    # the tile kernels do not read wider rows
+    with pytest.raises(RuntimeError, match="x_stride"):
+        F_.fused_mlp_forward_raw(xw, Wn, bd, family=F_.MLP_FAMILY_TILE, x_stride=ww)

@@ -587,6 +587,9 @@ SPILL_ALLOWLIST = {
                                                           "packed gradient tile; the default variant <4, 6, true> has none"),
     "trs::mlp_fused_fwd_kernel": (10, "kernel-invariant addresses saved at entry and re-read once per tile / layer "
                                       "(profiles/r04_kernels.md); none inside a k-loop"),
+    "void trs::mlp_fused_bwd_kernel<true>": (5, "the variant that reads the row-owner sign bits: five kernel-invariant values "
+                                                "stored once at entry, six single reloads per tile between the GEMM variants, "
+                                                "none inside a k-loop (11 scratch instructions in 11.7 k lines of ISA)"),
     "void trs::pairw_reg_kernel<float, 1>": (13, "OPN 'vec' weight gradient: 64 accumulators per lane at the 128-register "
                                                  "cap of a 1024-thread workgroup (one pair per lane needs the 1024 threads)"),
     "void trs::pairw_reg_kernel<trs::bf16_t, 1>": (12, "as above"),

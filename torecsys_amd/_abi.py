@@ -118,7 +118,7 @@ SIGNATURES = {
     "trs_mlp_fused_workspace_bytes": (_SZ, [_I32, _P]),
     "trs_mlp_fused_mask_bytes": (_SZ, [_I64]),
     "trs_mlp_pack_branch": (c_int32, [_I64, _I32, _P, _P, _P, _I32, _P, _P, _SZ, _P, _I32, _I32, _P, _SZ, _P]),
-    "trs_mlp_fused_fwd": (c_int32, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _SZ, _P]),
+    "trs_mlp_fused_fwd": (c_int32, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _SZ, _P]),
     "trs_mlp_fused_bwd_data": (c_int32, [_P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _SZ, _P]),
     "trs_ctr_logit_fwd": (c_int32, [_P, _I32, _P, _I32, _P, _P, _I32, _P, _I64, _I32, _P, _P]),
     "trs_bce_logits_workspace_bytes": (_SZ, [_I64]),

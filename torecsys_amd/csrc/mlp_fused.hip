@@ -596,7 +596,9 @@ __global__ __launch_bounds__(64 * MF_WAVES, TRS_MF_MINW) void mlp_fused_bwd_kern
   // + (row / 32) % 2][chunk % 4] 16-bit words; bit 4 h + k2 = column 32 chunk + 16 h + 8 g + 2 k2, bit 8 + 4 h + k2 the one
   // after it.  This kernel's byte for (row, pair, q) -- bit j/2 + 4 (j & 1) = column 32 pair + 8 q + j -- is the two
   // nibbles h = q / 2 of the word of (row, chunk = pair, g = q & 1).
-  unsigned short* mstage = reinterpret_cast<unsigned short*>(csum + (a.nsteps + 1) * 512);
+  // The stage ALIASES the column-sum scratch (a 512-wide stack leaves no 8 KB of LDS free): written once the step's partial
+  // sums have been folded, between two extra barriers.
+  unsigned short* mstage = reinterpret_cast<unsigned short*>(scratch);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, r = lane & 15;
   for (int i = threadIdx.x; i < (a.nsteps + 1) * 512; i += blockDim.x) csum[i] = 0.f;
   const int64_t ntiles = (a.rows + MF_ROWS - 1) / MF_ROWS;
@@ -647,13 +649,17 @@ __global__ __launch_bounds__(64 * MF_WAVES, TRS_MF_MINW) void mlp_fused_bwd_kern
       }
       const bool last = s + 1 == a.nsteps;
       const int out_cols = last ? st.out_stride : st.N;
-      if (RO_MASKS && st.mask != nullptr) reinterpret_cast<uint4*>(mstage)[threadIdx.x] = mraw;      // (read behind the barrier)
       MF_BAR();
       if (st.colsum != nullptr && threadIdx.x < st.K) {
         float t = 0.f;
 #pragma unroll
         for (int sl = 0; sl < 8; ++sl) t += scratch[sl * 512 + threadIdx.x];
         csum[s * 512 + threadIdx.x] += t;
+      }
+      if (RO_MASKS && st.mask != nullptr) {
+        MF_BAR();                                                        // the partial sums have been read
+        reinterpret_cast<uint4*>(mstage)[threadIdx.x] = mraw;
+        MF_BAR();
       }
       const int lrow = sh.mt0 * 16 + r;          // item addresses as in the forward
       char* lds0 = act + lrow * a.act_str + 16 * q;
@@ -790,7 +796,7 @@ int mlp_resolve_family(int L, const int32_t* widths, int64_t rows, int request);
 size_t mlp_ro_mask_bytes(int64_t rows);
 int mlp_ro_fwd(const void* x, int64_t rows, int L, const int32_t* widths, const void* const* weights,
                const void* const* biases, void* const* hidden, void* const* masks, void* mask_in, void* y, void* workspace,
-               hipStream_t s, int phase);
+               hipStream_t s, int phase, int x_stride);
 struct RoColsum {
   const float* part[9];
   float* out[9];
@@ -880,7 +886,7 @@ extern "C" int trs_mlp_fused_supported(int32_t num_layers, const int32_t* widths
 extern "C" int trs_mlp_fused_fwd(const void* x, int64_t rows, int32_t num_layers, const int32_t* widths,
                                  const void* const* weights, const void* const* biases, void* const* hidden,
                                  void* const* masks, void* mask_in, void* y, int32_t dtype, int32_t family,
-                                 int32_t phase, void* workspace, size_t ws_bytes, trs_stream_t stream) {
+                                 int32_t phase, int32_t x_stride, void* workspace, size_t ws_bytes, trs_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   TRS_REQUIRE(dtype == TRS_BF16, TRS_EDTYPE, "mlp_fused_fwd: bf16 only");
   TRS_REQUIRE(trs_mlp_fused_supported(num_layers, widths), TRS_ESHAPE, "mlp_fused_fwd: unsupported layer widths");
@@ -895,8 +901,12 @@ extern "C" int trs_mlp_fused_fwd(const void* x, int64_t rows, int32_t num_layers
   const int fam = mlp_resolve_family(L, widths, rows, family);
   TRS_REQUIRE(fam != 0, TRS_EINVAL, "mlp_fused_fwd: kernel family %d is not available for this stack (trs_mlp_fused_family)", family);
   if (rows == 0) return TRS_OK;
+  TRS_REQUIRE(x_stride == 0 || (x_stride >= widths[0] && x_stride % 8 == 0), TRS_ESHAPE, "mlp_fused_fwd: x_stride %d", x_stride);
+  TRS_REQUIRE(x_stride == 0 || x_stride == widths[0] || fam != TRS_MLP_FAMILY_TILE, TRS_ESHAPE,
+              "mlp_fused_fwd: rows wider than the stack's input (x_stride %d > %d) are read by the row-owner kernels only", x_stride, widths[0]);
   if (fam == TRS_MLP_FAMILY_ROW_OWNER || fam == TRS_MLP_FAMILY_MIXED)
-    return mlp_ro_fwd(x, rows, L, widths, weights, biases, hidden, masks, mask_in, y, workspace, s, phase);
+    return mlp_ro_fwd(x, rows, L, widths, weights, biases, hidden, masks, mask_in, y, workspace, s, phase,
+                      x_stride ? x_stride : widths[0]);
   MlpArgs a;
   a.nsteps = L;
   a.in = x;
@@ -963,9 +973,19 @@ extern "C" int trs_mlp_fused_bwd_data(const void* gy, int64_t rows, int32_t num_
   const int L = num_layers;
   // the family is what the forward of these masks ran (trs_mlp_fused_family): AUTO is refused here because the policy
   // behind it is not the caller's record of what happened
-  TRS_REQUIRE((family == TRS_MLP_FAMILY_TILE || family == TRS_MLP_FAMILY_ROW_OWNER || family == TRS_MLP_FAMILY_MIXED) &&
-                  mlp_resolve_family(L, widths, rows, family) == family,
-              TRS_EINVAL, "mlp_fused_bwd_data: family must be the TILE / ROW_OWNER / MIXED value the forward ran under (got %d)", family);
+  bool fam_ok = (family == TRS_MLP_FAMILY_TILE || family == TRS_MLP_FAMILY_ROW_OWNER || family == TRS_MLP_FAMILY_MIXED) &&
+                mlp_resolve_family(L, widths, rows, family) == family;
+  if (!fam_ok && family == TRS_MLP_FAMILY_MIXED && L <= MF_MAXL) {
+    // a mixed forward that read the first columns of wider rows (x_stride): this call sees the full row width
+    int32_t wn[MF_MAXL + 1];
+    for (int l = 0; l <= L; ++l) wn[l] = widths[l];
+    for (int w0 = pad32(widths[0]) - 32; w0 >= 32 && !fam_ok; w0 -= 32) {
+      wn[0] = w0;
+      fam_ok = mlp_resolve_family(L, wn, rows, family) == family;
+    }
+  }
+  TRS_REQUIRE(fam_ok, TRS_EINVAL,
+              "mlp_fused_bwd_data: family must be the TILE / ROW_OWNER / MIXED value the forward ran under (got %d)", family);
   TRS_REQUIRE(pack_only || family != TRS_MLP_FAMILY_ROW_OWNER || gx != nullptr, TRS_EINVAL, "mlp_fused_bwd_data: the row-owner kernels need gx");
   TRS_REQUIRE(pack_only || ((mask_in == nullptr) == (gbias_in == nullptr) && (mask_in == nullptr || (L + 1 <= MF_MAXL && gx != nullptr))),
               TRS_EINVAL, "mlp_fused_bwd_data: mask_in and gbias_in come together (and with gx, at most %d layers)", MF_MAXL - 1);
@@ -1025,7 +1045,7 @@ extern "C" int trs_mlp_fused_bwd_data(const void* gy, int64_t rows, int32_t num_
   a.mask_in = nullptr;
   a.colsum_in = mask_in != nullptr ? part_base + poff : nullptr;      // (the workspace counts widths[0] as well)
   a.ro_masks = family == TRS_MLP_FAMILY_MIXED ? 1 : 0;
-  const size_t lds = (size_t)MF_ROWS * a.act_str + 8 * 512 * 4 + (size_t)(L + 1) * 512 * 4 + (a.ro_masks ? 8192 : 0);
+  const size_t lds = (size_t)MF_ROWS * a.act_str + 8 * 512 * 4 + (size_t)(L + 1) * 512 * 4;
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)mlp_fused_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=

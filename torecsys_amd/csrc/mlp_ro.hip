@@ -95,11 +95,11 @@ size_t mlp_ro_mask_bytes(int64_t rows) { return (size_t)((rows + RO_ROWS - 1) / 
 // same contract as trs_mlp_fused_fwd (mlp_fused.hip), which hands over after its argument checks
 int mlp_ro_fwd(const void* x, int64_t rows, int L, const int32_t* widths, const void* const* weights,
                const void* const* biases, void* const* hidden, void* const* masks, void* mask_in, void* y, void* workspace,
-               hipStream_t s, int phase) {
+               hipStream_t s, int phase, int x_stride) {
   const bool pack_only = phase == TRS_MLP_PHASE_PACK;
   RoArgs a;
   a.in = (const char*)x;
-  a.in_stride = widths[0];
+  a.in_stride = x_stride;      // (both instantiated stacks read every column of their input width: the stride is only a pitch)
   a.rows = rows;
   a.mask_in = (uint32_t*)mask_in;
   a.colsum_in = nullptr;

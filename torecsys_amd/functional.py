@@ -1832,7 +1832,7 @@ def fused_mlp_pack(Ws: Sequence[torch.Tensor], bs: Optional[Sequence[torch.Tenso
              ptr(None), ptr(None), _abi.TRS_BF16, int(family), MLP_PHASE_PACK, ptr(ws), ws_bytes, stream_ptr())
     else:
         call("trs_mlp_fused_fwd", ptr(None), rows, L, wl, _ptr_array(Ws), _ptr_array(bs), ptr(None), ptr(None), ptr(None),
-             ptr(None), _abi.TRS_BF16, int(family), MLP_PHASE_PACK, ptr(ws), ws_bytes, stream_ptr())
+             ptr(None), _abi.TRS_BF16, int(family), MLP_PHASE_PACK, 0, ptr(ws), ws_bytes, stream_ptr())
     return ws
 
 
@@ -1862,7 +1862,7 @@ def fused_mlp_pack_branch(Ws: Sequence[torch.Tensor], bs: Sequence[torch.Tensor]
 
 def fused_mlp_forward_raw(x2: torch.Tensor, Ws: Sequence[torch.Tensor], bs: Sequence[torch.Tensor],
                           input_mask: bool = False, family: Optional[int] = None,
-                          packed_ws: Optional[torch.Tensor] = None):
+                          packed_ws: Optional[torch.Tensor] = None, x_stride: int = 0):
     """trs_mlp_fused_fwd on rows x2 (rows, widths[0]): returns (y (rows, widths[L]), hidden [(rows, pad32(w))] -- the
     ReLU outputs of the hidden layers, zero in the padding columns --, masks [the sign bits of the hidden layers in the
     kernel's own order: opaque bytes for trs_mlp_fused_bwd_data], [with ``input_mask`` (x2 is itself a ReLU output): the
@@ -1871,6 +1871,10 @@ def fused_mlp_forward_raw(x2: torch.Tensor, Ws: Sequence[torch.Tensor], bs: Sequ
     L = len(Ws)
     widths = [Ws[0].shape[1]] + [w.shape[0] for w in Ws]
     rows, dev = x2.shape[0], x2.device
+    # ``x_stride`` (row-owner / mixed family): x2's rows are wider than the stack's input -- the first widths[0] columns
+    # of every row are read
+    if x_stride and (x_stride < widths[0] or x2.shape[1] != x_stride or not x2.is_contiguous()):
+        raise ValueError(f"fused_mlp_forward_raw: x_stride {x_stride} does not describe x2 {tuple(x2.shape)}")
     fam = mlp_fused_family(widths, rows, family)
     hidden = [torch.empty(rows, _pad32(widths[l + 1]), dtype=torch.bfloat16, device=dev) for l in range(L - 1)]
     mask_bytes = size_query("trs_mlp_fused_mask_bytes", rows)
@@ -1884,7 +1888,7 @@ def fused_mlp_forward_raw(x2: torch.Tensor, Ws: Sequence[torch.Tensor], bs: Sequ
         ws_bytes = size_query("trs_mlp_fused_workspace_bytes", L, wl)
         ws, phase = torch.empty(ws_bytes, dtype=torch.uint8, device=dev), MLP_PHASE_ALL
     call("trs_mlp_fused_fwd", ptr(x2), rows, L, wl, _ptr_array(Ws), _ptr_array(bs), _ptr_array(hidden),
-         _ptr_array(masks), ptr(mask_in), ptr(y), _abi.TRS_BF16, fam, phase, ptr(ws), ws_bytes, stream_ptr())
+         _ptr_array(masks), ptr(mask_in), ptr(y), _abi.TRS_BF16, fam, phase, int(x_stride), ptr(ws), ws_bytes, stream_ptr())
     if input_mask:
         return y, hidden, masks, mask_in, fam
     return y, hidden, masks, fam

@@ -534,6 +534,8 @@ HYBRID_MLP = os.environ.get("TRS_HYBRID_MLP", "1") not in ("", "0")   # fused ta
 # fewer on the critical path and still 20 us slower (what the graph's branches overlap with moves: the bucket build no
 # longer runs beside the first GEMM).  Kept as a switch and as the ABI's PACK / RUN phases; off.
 HOIST_PACK = int(os.environ.get("TRS_HOIST_PACK", "0") or 0)
+# the fused tail's forward on the first 416 columns of the 512-wide first-layer output, by the row-owner kernel (mixed family)
+MIXED_TAIL = os.environ.get("TRS_MIXED_TAIL", "1") not in ("", "0")
 
 
 def _pad_width(width: int) -> int:
@@ -555,13 +557,18 @@ class _PaddedLinear:
     @staticmethod
     def _state(mod: nn.Linear, in_pad: int, out_pad: int):
         w, b = mod.weight, mod.bias
-        st = mod.__dict__.get('_trs_padded')
-        if st is None or st.w.shape != (out_pad, in_pad) or st.w.dtype != w.dtype or st.w.device != w.device:
+        slots = mod.__dict__.get('_trs_padded')      # (out_pad, in_pad) -> copy: a layer can be wanted at two widths (the
+        if slots is None:                            # library GEMM behind it at 512, the fused tail's forward at 416)
+            slots = mod.__dict__['_trs_padded'] = {}
+        st = slots.get((out_pad, in_pad))
+        if st is None or st.w.dtype != w.dtype or st.w.device != w.device:
+            if len(slots) >= 4:
+                slots.clear()
             st = _PaddedLinear()
             st.w = torch.zeros(out_pad, in_pad, dtype=w.dtype, device=w.device)
             st.b = torch.zeros(out_pad, dtype=w.dtype, device=w.device) if b is not None else None
             st.key = None
-            mod.__dict__['_trs_padded'] = st
+            slots[(out_pad, in_pad)] = st
         return st
 
     @staticmethod
@@ -757,7 +764,7 @@ class _HybridMLP(torch.autograd.Function):
     copies the kernels read, or None)."""
 
     @staticmethod
-    def forward(ctx, x, *tensors):
+    def forward(ctx, x, w_narrow, *tensors):
         cur = x.reshape(-1, x.shape[-1])
         w1, b1, w1u, b1u = tensors[:4]
         tail = tensors[4:]
@@ -793,6 +800,10 @@ class _HybridMLP(torch.autograd.Function):
                         t.record_stream(main)      # allocated under the side stream, read (and freed) under this one
             y, hidden, masks, mask_in, fam = F_.fused_mlp_forward_raw(h1, Ws, bs, input_mask=True, family=fam_t,
                                                                       packed_ws=wpack[0])
+        elif w_narrow is not None:
+            # mixed family on the first h_n columns of the 512-wide rows (see _forward_hybrid)
+            y, hidden, masks, mask_in, fam = F_.fused_mlp_forward_raw(h1, [w_narrow] + Ws[1:], bs, input_mask=True,
+                                                                      family=F_.MLP_FAMILY_MIXED, x_stride=h1.shape[1])
         else:
             y, hidden, masks, mask_in, fam = F_.fused_mlp_forward_raw(h1, Ws, bs, input_mask=True)
         ctx.wpack = wpack
@@ -822,11 +833,11 @@ class _HybridMLP(torch.autograd.Function):
             inp = h1 if l == 0 else hidden[l - 1]
             g = gy2 if l == L - 1 else gz[l]
             out_f, in_f = wshapes[l]
-            gw, gbias = F_._tail_layer_grads(g, inp, out_f, in_f, wdt[l], gb[l], needs[5 + 4 * l], needs[6 + 4 * l])
+            gw, gbias = F_._tail_layer_grads(g, inp, out_f, in_f, wdt[l], gb[l], needs[6 + 4 * l], needs[7 + 4 * l])
             grads += [gw, gbias, None, None]
-        gx, gw1, gbias1 = _dense_layer_grads(g1, gb1, cur, W1, w1shape[0], w1shape[1], w1dt, needs[0], needs[1], needs[2],
+        gx, gw1, gbias1 = _dense_layer_grads(g1, gb1, cur, W1, w1shape[0], w1shape[1], w1dt, needs[0], needs[2], needs[3],
                                              rows_gemm_ws=wpack[2])
-        return (gx.reshape(xshape) if needs[0] else None, gw1, gbias1, None, None, *grads)
+        return (gx.reshape(xshape) if needs[0] else None, None, gw1, gbias1, None, None, *grads)
 
 
 class _MLPStack(torch.autograd.Function):
@@ -1019,13 +1030,24 @@ class MultilayerPerceptionLayer(BaseLayer):
             padded.append((tail[-1], tail[-1].in_features, out_pad) if out_pad != tail[-1].out_features else None)
         elif out_pad != tail[0].out_features:
             padded[1] = (tail[0], h_pad, out_pad)
-        copies = iter(_PaddedLinear.get_many([p for p in padded if p is not None]))
+        # The library GEMMs of the first layer want its output 512 wide (PAD_MULTIPLE), the fused tail wants 416 (13 chunks
+        # of 32: 19 % fewer MFMAs in its first layer, and the shape the row-owner forward is built for).  Both: the tail's
+        # FORWARD reads the first 416 columns of the 512-wide rows (x_stride) against a 416-wide copy of its first weight
+        # when the library resolves that stack to the mixed family; the backward keeps the 512-wide form, whose extra
+        # columns meet zero weights (the gradient the first layer's weight-gradient GEMM reads stays 512 wide).
+        narrow = None
+        h_n = (first.out_features + 31) // 32 * 32
+        if (MIXED_TAIL and len(tail) >= 2 and h_n < h_pad and len(tail) + 1 <= 8 and HYBRID_ONE_NODE
+                and F_.mlp_fused_family([h_n] + widths[1:], outputs.shape[0]) == F_.MLP_FAMILY_MIXED):
+            narrow = (tail[0], h_n, tail[0].out_features)
+        copies = iter(_PaddedLinear.get_many([p for p in padded if p is not None] + ([narrow] if narrow else [])))
         use = [next(copies) if p is not None else (None, None) for p in padded]
+        w_narrow = next(copies)[0] if narrow else None
         tensors = [first.weight, first.bias, use[0][0], use[0][1]]
         for mod, (w_use, b_use) in zip(tail, use[1:]):
             tensors += [mod.weight, mod.bias, w_use, b_use]
         if len(tail) + 1 <= 8 and HYBRID_ONE_NODE:
-            out = _HybridMLP.apply(outputs, *tensors)
+            out = _HybridMLP.apply(outputs, w_narrow, *tensors)
         else:
             h1 = _MLPStack.apply(outputs, ((True, False),), *tensors[:4])
             out = F_._FusedMLPTail.apply(h1, *tensors[4:])
