@@ -401,3 +401,23 @@ def test_mixed_family_reads_the_first_columns_of_wider_rows(dev):
     # the tile kernels do not read wider rows
     with pytest.raises(RuntimeError, match="x_stride"):
         F_.fused_mlp_forward_raw(xw, Wn, bd, family=F_.MLP_FAMILY_TILE, x_stride=ww)
+
+
+@pytest.mark.parametrize("M,N", [(416, 416), (400, 400)])
+def test_wgrad_rows_long_row_ranges_take_the_four_wave_dma_kernel(dev, M, N):
+    """From 2^20 rows on a 13|12 x 26|25-tile weight gradient runs four waves on 13 x 26-tile blocks fed by LDS-DMA
+    (wgrad_dma2_kernel: twice the row ranges of the eight-wave form); against the float64 product on the device."""
+    from torecsys_amd import functional as F_
+    rows, ld = (1 << 20) + 128 * 3, 416
+    gen = torch.Generator(device=dev).manual_seed(M)
+    g = torch.randn(rows, ld, generator=gen, device=dev).bfloat16()
+    x = torch.randn(rows, ld, generator=gen, device=dev).bfloat16()
+    S8 = int(F_._abi.load().trs_wgrad_rows_splits(M, N, 131072))      # the eight-wave form
+    S = int(F_._abi.load().trs_wgrad_rows_splits(M, N, rows))
+    assert S == 2 * S8, (S, S8)
+    gw = F_._wgrad_rows(g, x, M, N, torch.float32)
+    ref = torch.zeros(M, N, dtype=torch.float64, device=dev)
+    for r0 in range(0, rows, 1 << 17):
+        ref += g[r0:r0 + (1 << 17), :M].double().t() @ x[r0:r0 + (1 << 17), :N].double()
+    assert gw.shape == (M, N)
+    assert float((gw.double() - ref).abs().max() / ref.abs().max()) <= 1e-5

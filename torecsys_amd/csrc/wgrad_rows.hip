@@ -27,6 +27,8 @@
 // 416 x 64: 0.43 ms = 5.7 TB/s (0.52 ms).
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "trs_common.hpp"
 
 namespace trs {
@@ -52,7 +54,7 @@ struct WgradArgs {
   int slots_per_xcd;         // row ranges per XCD (S = 8 * slots_per_xcd)
 };
 
-__device__ __forceinline__ int split_start(int total, int parts, int k) { return (int)(((int64_t)total * k) / parts); }
+__host__ __device__ __forceinline__ int split_start(int total, int parts, int k) { return (int)(((int64_t)total * k) / parts); }
 
 // 8 k-values x this lane's column: two transpose reads (``lo`` / ``hi``: the lane's addresses of rows +0..3 / +4..7 -- swapped
 // on odd lane groups --, ``off`` a compile-time byte offset that lands in the instruction's offset field)
@@ -268,6 +270,300 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void wgrad_rows_kernel(WgradArgs a
   }
 }
 
+// ------------------------------------------------------------------------------------------------ LDS-DMA staging (round 5)
+// The same 13 x 13-tile blocks, eight waves with exact shares and pinned accumulators, but the rows reach LDS by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, no ds_write) and the ring is six steps deep.  The image of a step is
+// ROW-MAJOR per operand block -- [32 rows][208 columns] = 13 312 bytes, i.e. 13 pieces of 1 KB that a DMA instruction
+// fills contiguously (lane l of piece j brings bytes 1024 j + 16 l of the image: 2.5 rows of 416 contiguous bytes each)
+// -- and the transposing fragment reads work on it as they stand: a row pitch of 416 bytes is 32 mod 128, which spreads
+// the four rows of a 16-lane group and, with the odd groups' +4-row rotation, the two groups of a half wave over all 64
+// banks, exactly as the panel layout above does.  Step k lives in ring slot k % 6; its copy is issued five steps ahead
+// (during step k-5, behind the barrier that freed the slot), every wave waits for ITS pieces of step k+1 before the
+// barrier that ends step k-1 (three later steps' pieces may still be in flight: s_waitcnt vmcnt(9 | 12)), so four steps
+// = ~100 KB per CU are under way at any time -- what the register-staged form keeps in flight with 64 VGPRs per thread.
+// Used when both operands cover whole 13-tile blocks in memory (ld >= 208 columns behind every block start) and the rows
+// are a multiple of 128; TRS_WGRAD_DMA=0 keeps the register-staged kernel.
+constexpr int WD_S = 416;                 // bytes per image row (208 columns)
+constexpr int WD_IMG = WG_KS * WD_S;      // one operand block of one step
+constexpr int WD_SLOT = 2 * WD_IMG;
+constexpr int WD_NSLOT = 6;
+constexpr int WD_AHEAD = 5;
+
+__device__ __forceinline__ void wd_dma(const char* src, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(dst), "s"(src) : "memory");
+}
+
+template <int MC, int NC>
+__global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char wg_lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, i = lane & 15;
+  const bool odd = q & 1;
+  const int TB = a.MB * a.NB;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int slot = xcd * a.slots_per_xcd + j / TB;
+  const int S = 8 * a.slots_per_xcd;
+  const int tile = j % TB;
+  const int mb = tile / a.NB, nb = tile % a.NB;
+  const int Mt = (a.M + 15) >> 4, Nt = (a.N + 15) >> 4;
+  const int bm0 = split_start(Mt, a.MB, mb), bm1 = split_start(Mt, a.MB, mb + 1);
+  const int bn0 = split_start(Nt, a.NB, nb), bn1 = split_start(Nt, a.NB, nb + 1);
+  const int PM = bm1 - bm0, PN = bn1 - bn0;
+  const int wm = wave >> 2, wn = wave >= 4 ? ((wave + 1) & 3) : (wave & 3);
+  const int am0 = split_start(PM, 2, wm), mc = split_start(PM, 2, wm + 1) - am0;
+  const int an0 = split_start(PN, 4, wn), nc = split_start(PN, 4, wn + 1) - an0;
+  const int64_t quads_total = a.rows / (4 * WG_KS);      // (rows % 128 == 0: checked by the host)
+  const int64_t h0 = 4 * (quads_total * slot / S), h1 = 4 * (quads_total * (slot + 1) / S);
+  const int64_t n_h = h1 - h0;
+
+  // ---- this wave's pieces of a step: p = wave + 8 t (t = 0..3, p < 26); pieces 0..12 the g block, 13..25 the x block
+  const char* gcol = reinterpret_cast<const char*>(a.g + 16 * bm0);
+  const char* xcol = reinterpret_cast<const char*>(a.x + 16 * bn0);
+  unsigned voff[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int p = wave + 8 * t, op = p >= 13, jj = op ? p - 13 : p;
+    const int o = jj * 1024 + 16 * lane, row = o / WD_S, cb = o - row * WD_S;
+    voff[t] = (unsigned)(row * (op ? a.ldx : a.ldg) * 2 + cb);
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)wg_lds;
+  auto issue = [&](int64_t k, unsigned ring_slot) __attribute__((always_inline)) {      // the copy of step k into ring slot ``ring_slot``
+    const int64_t h = h0 + (k < n_h ? k : n_h - 1);      // (past the end: the last step again -- landed, never read)
+    const char* gs = gcol + h * WG_KS * a.ldg * 2;
+    const char* xs = xcol + h * WG_KS * a.ldx * 2;
+    const unsigned base = lds0 + ring_slot * WD_SLOT;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int p = wave + 8 * t;
+      if (p < 26) wd_dma(p >= 13 ? xs : gs, voff[t], base + (p >= 13 ? WD_IMG + (p - 13) * 1024 : p * 1024));
+    }
+  };
+  // this wave's pieces of all steps but the three youngest have landed (then: barrier -> visible to every wave)
+  auto landed = [&]() __attribute__((always_inline)) {
+    if (wave < 2) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+
+  auto run = [&]<int MCx, int NCx>() __attribute__((always_inline)) {
+    wg_f32x4 acc[MCx][NCx];
+#pragma unroll
+    for (int m = 0; m < MCx; ++m)
+#pragma unroll
+      for (int n = 0; n < NCx; ++n) acc[m][n] = wg_f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frag_lane = (8 * q + (i >> 2)) * WD_S + (i & 3) * 8;
+    const int a_lo = am0 * 32 + frag_lane + (odd ? 4 * WD_S : 0), a_hi = am0 * 32 + frag_lane + (odd ? 0 : 4 * WD_S);
+    const int b_lo = WD_IMG + an0 * 32 + frag_lane + (odd ? 4 * WD_S : 0);
+    const int b_hi = WD_IMG + an0 * 32 + frag_lane + (odd ? 0 : 4 * WD_S);
+    constexpr int PD = MCx >= 2 ? 2 : 1;
+    wg_bf16x8 Ar[4], Bf[NCx];
+    unsigned cur = 0;      // ring slot of the step being multiplied
+    auto nxt_of = [](unsigned c) { return c + 1 == WD_NSLOT ? 0u : c + 1; };
+#define WD_STEP(c4, KEXPR)                                                                                          \
+    {                                                                                                               \
+      const unsigned nx = nxt_of(cur);                                                                              \
+      const char* cb = wg_lds + cur * WD_SLOT;                                                                      \
+      const char* nb_ = wg_lds + nx * WD_SLOT;                                                                      \
+      constexpr int RO = (MCx * (c4)) % 4;                                                                          \
+      _Pragma("unroll") for (int m = 0; m < MCx; ++m) {                                                              \
+        const int t = (m + PD) % MCx;                                                                                \
+        const char* fb = (m + PD < MCx) ? cb : nb_;                                                                  \
+        Ar[(RO + m + PD) % 4] = tr_frag(fb + a_lo, fb + a_hi, t * 32);                                              \
+        _Pragma("unroll") for (int n = 0; n < NCx; ++n) {                                                            \
+          wg_mfma(acc[m][n], Ar[(RO + m) % 4], Bf[n]);                                                              \
+          if (m == MCx - 1) Bf[n] = tr_frag(nb_ + b_lo, nb_ + b_hi, n * 32);                                         \
+        }                                                                                                           \
+        if (m == (MCx > 2 ? 1 : 0)) {                                                                                \
+          /* slot (cur + 5) % 6 = (cur - 1) % 6 was freed by the barrier that ended the previous step */           \
+          issue((KEXPR) + WD_AHEAD, cur == 0 ? WD_NSLOT - 1 : cur - 1);                                              \
+        }                                                                                                           \
+      }                                                                                                             \
+      landed();                                                                                                     \
+      cur = nx;                                                                                                     \
+    }
+    if (n_h > 0) {
+#pragma unroll
+      for (int k = 0; k < WD_AHEAD; ++k) issue(k, k);
+      landed();      // steps 0 and 1 are in LDS (2, 3, 4 may still be on their way)
+      {
+        const char* cb = wg_lds;
+#pragma unroll
+        for (int n = 0; n < NCx; ++n) Bf[n] = tr_frag(cb + b_lo, cb + b_hi, n * 32);
+#pragma unroll
+        for (int m = 0; m < PD; ++m) Ar[m] = tr_frag(cb + a_lo, cb + a_hi, m * 32);
+      }
+      for (int64_t k = 0; k < n_h; k += 4) {
+        WD_STEP(0, k)
+        WD_STEP(1, k + 1)
+        WD_STEP(2, k + 2)
+        WD_STEP(3, k + 3)
+      }
+    }
+#undef WD_STEP
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");      // copies still landing; the last MFMAs' results
+    float* out = a.part + (int64_t)slot * a.M * a.N;
+#pragma unroll
+    for (int m = 0; m < MCx; ++m)
+#pragma unroll
+      for (int n = 0; n < NCx; ++n)
+        if (m < mc && n < nc) {
+          const int row = 16 * (bm0 + am0 + m) + 4 * q, c = 16 * (bn0 + an0 + n) + i;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (row + e < a.M && c < a.N) out[(int64_t)(row + e) * a.N + c] = acc[m][n][e];
+        }
+  };
+  if (mc == MC && nc == NC) run.template operator()<MC, NC>();
+  else if (mc == MC) run.template operator()<MC, NC - 1>();
+  else if (nc == NC) run.template operator()<MC - 1, NC>();
+  else run.template operator()<MC - 1, NC - 1>();
+}
+
+// ---- the same, FOUR waves on a 13 x 26-tile block (one g block against both x blocks of a 400..416-wide x): a wave owns
+// all 13 (12) tile rows and 7 | 6 tile columns -- 91 accumulator tiles on 364 of its 512 registers -- so a fragment read
+// from LDS feeds 7 or 13 MFMAs instead of 4 or 7: the eight-wave form above reads 88 KB of fragments per 169-tile step,
+// which is as many LDS cycles (256 B per clock) as the step has MFMA cycles per SIMD, and the two do not overlap
+// perfectly; here it is 80 KB per 338-tile step.  The g block is also fetched once instead of twice.  Three images per
+// step (g, x block 0, x block 1: 39 pieces), ring of four slots, copies three steps ahead.  For long row ranges
+// (rows >= WD2_MIN_ROWS: twice as many fp32 partials as the eight-wave form for the same number of workgroups).
+constexpr int WD2_SLOT = 3 * WD_IMG;
+constexpr int WD2_NSLOT = 4;
+constexpr int WD2_AHEAD = 3;
+constexpr int64_t WD2_MIN_ROWS = 1 << 20;
+
+template <bool AG>
+__device__ __forceinline__ void wd_mfma(wg_f32x4& acc, const wg_bf16x8& A, const wg_bf16x8& B) {
+  if constexpr (AG) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(A), "v"(B));
+  else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(A), "v"(B));
+}
+
+__global__ __launch_bounds__(256, 1) void wgrad_dma2_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char wg_lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q = lane >> 4, i = lane & 15;
+  const bool odd = q & 1;
+  const int TB = a.MB;                                   // (a.NB == 2: both x blocks belong to the workgroup)
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int slot = xcd * a.slots_per_xcd + j / TB;
+  const int S = 8 * a.slots_per_xcd;
+  const int mb = j % TB;
+  const int Mt = (a.M + 15) >> 4, Nt = (a.N + 15) >> 4;
+  const int bm0 = split_start(Mt, a.MB, mb), PM = split_start(Mt, a.MB, mb + 1) - bm0;
+  const int xb = wave >> 1;                              // this wave's x block
+  const int bn0 = split_start(Nt, 2, xb), PN = split_start(Nt, 2, xb + 1) - bn0;
+  const int an0 = split_start(PN, 2, wave & 1), nc = split_start(PN, 2, (wave & 1) + 1) - an0;
+  const int xc0 = 16 * split_start(Nt, 2, 0), xc1 = 16 * split_start(Nt, 2, 1);
+  const int64_t quads_total = a.rows / (4 * WG_KS);
+  const int64_t h0 = 4 * (quads_total * slot / S), h1 = 4 * (quads_total * (slot + 1) / S);
+  const int64_t n_h = h1 - h0;
+
+  // pieces p = wave + 4 t (t = 0..9, p < 39): image p / 13 (g, x block 0, x block 1), KB p % 13 of it
+  const char* gcol = reinterpret_cast<const char*>(a.g + 16 * bm0);
+  const char* x0col = reinterpret_cast<const char*>(a.x + xc0);
+  const char* x1col = reinterpret_cast<const char*>(a.x + xc1);
+  unsigned voff[10];
+#pragma unroll
+  for (int t = 0; t < 10; ++t) {
+    const int p = wave + 4 * t, img = p / 13, jj = p - 13 * img;
+    const int o = jj * 1024 + 16 * lane, row = o / WD_S, cb = o - row * WD_S;
+    voff[t] = (unsigned)(row * (img ? a.ldx : a.ldg) * 2 + cb);
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)wg_lds;
+  auto issue = [&](int64_t k, unsigned ring_slot) __attribute__((always_inline)) {
+    const int64_t h = h0 + (k < n_h ? k : n_h - 1);
+    const char* gs = gcol + h * WG_KS * a.ldg * 2;
+    const char* x0s = x0col + h * WG_KS * a.ldx * 2;
+    const char* x1s = x1col + h * WG_KS * a.ldx * 2;
+    const unsigned base = lds0 + ring_slot * WD2_SLOT;
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+      const int p = wave + 4 * t;
+      if (p < 39) wd_dma(p < 13 ? gs : (p < 26 ? x0s : x1s), voff[t], base + p * 1024);
+    }
+  };
+  auto landed = [&]() __attribute__((always_inline)) {      // all but the youngest step's pieces of this wave
+    if (wave < 3) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+
+  auto run = [&]<int MCx, int NCx>() __attribute__((always_inline)) {
+    wg_f32x4 acc[MCx][NCx];
+#pragma unroll
+    for (int m = 0; m < MCx; ++m)
+#pragma unroll
+      for (int n = 0; n < NCx; ++n) acc[m][n] = wg_f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frag_lane = (8 * q + (i >> 2)) * WD_S + (i & 3) * 8;
+    const int a_lo = frag_lane + (odd ? 4 * WD_S : 0), a_hi = frag_lane + (odd ? 0 : 4 * WD_S);
+    const int b_lo = WD_IMG * (1 + xb) + an0 * 32 + frag_lane + (odd ? 4 * WD_S : 0);
+    const int b_hi = WD_IMG * (1 + xb) + an0 * 32 + frag_lane + (odd ? 0 : 4 * WD_S);
+    constexpr int PD = 2;
+    wg_bf16x8 Ar[4], Bf[NCx];
+#define WD2_STEP(c4, KEXPR)                                                                                         \
+    {                                                                                                               \
+      const char* cb = wg_lds + (c4) * WD2_SLOT;                                                                    \
+      const char* nb_ = wg_lds + (((c4) + 1) % WD2_NSLOT) * WD2_SLOT;                                               \
+      constexpr int RO = (MCx * (c4)) % 4;                                                                          \
+      _Pragma("unroll") for (int m = 0; m < MCx; ++m) {                                                              \
+        const int t = (m + PD) % MCx;                                                                                \
+        const char* fb = (m + PD < MCx) ? cb : nb_;                                                                  \
+        Ar[(RO + m + PD) % 4] = tr_frag(fb + a_lo, fb + a_hi, t * 32);                                              \
+        _Pragma("unroll") for (int n = 0; n < NCx; ++n) {                                                            \
+          if (m * NCx + n < 64) wd_mfma<true>(acc[m][n], Ar[(RO + m) % 4], Bf[n]);                                   \
+          else wd_mfma<false>(acc[m][n], Ar[(RO + m) % 4], Bf[n]);                                                   \
+          if (m == MCx - 1) Bf[n] = tr_frag(nb_ + b_lo, nb_ + b_hi, n * 32);                                         \
+        }                                                                                                           \
+        if (m == 1) issue((KEXPR) + WD2_AHEAD, ((c4) + WD2_AHEAD) % WD2_NSLOT);      /* the slot the last barrier freed */ \
+      }                                                                                                             \
+      landed();                                                                                                     \
+    }
+    if (n_h > 0) {
+#pragma unroll
+      for (int k = 0; k < WD2_AHEAD; ++k) issue(k, k);
+      landed();
+      {
+        const char* cb = wg_lds;
+#pragma unroll
+        for (int n = 0; n < NCx; ++n) Bf[n] = tr_frag(cb + b_lo, cb + b_hi, n * 32);
+#pragma unroll
+        for (int m = 0; m < PD; ++m) Ar[m] = tr_frag(cb + a_lo, cb + a_hi, m * 32);
+      }
+      for (int64_t k = 0; k < n_h; k += 4) {
+        WD2_STEP(0, k)
+        WD2_STEP(1, k + 1)
+        WD2_STEP(2, k + 2)
+        WD2_STEP(3, k + 3)
+      }
+    }
+#undef WD2_STEP
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    float* out = a.part + (int64_t)slot * a.M * a.N;
+#pragma unroll
+    for (int m = 0; m < MCx; ++m)
+#pragma unroll
+      for (int n = 0; n < NCx; ++n)
+        if (m < PM && n < nc) {
+          const int row = 16 * (bm0 + m) + 4 * q, c = 16 * (bn0 + an0 + n) + i;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (row + e < a.M && c < a.N) out[(int64_t)(row + e) * a.N + c] = acc[m][n][e];
+        }
+  };
+  // (a 12-tile g block runs the 13-row copy on one tile of whatever follows the block in memory: results dropped)
+  if (nc == 7) run.template operator()<13, 7>();
+  else run.template operator()<13, 6>();
+}
+
+static const bool WGRAD_DMA = [] {
+  const char* e = getenv("TRS_WGRAD_DMA");
+  return !(e && e[0] == '0');
+}();
+static const bool WGRAD_DMA2 = [] {
+  const char* e = getenv("TRS_WGRAD_DMA2");
+  return !(e && e[0] == '0');
+}();
+
 static const bool WGRAD_EIGHT = [] {
   const char* e = getenv("TRS_WGRAD_EIGHT");
   return !(e && e[0] == '0');
@@ -275,6 +571,7 @@ static const bool WGRAD_EIGHT = [] {
 
 struct WgradPlan {
   int wm, wn, mc, nc, MB, NB, slots_per_xcd;
+  int dma = 0;      // 0: register-staged kernel; 1: wgrad_dma_kernel (eight waves, 13 x 13 tiles); 2: wgrad_dma2_kernel (four waves, 13 x 26)
 };
 
 static inline int tile_class(int t) { return t <= 1 ? 1 : (t <= 4 ? 4 : WG_TC); }
@@ -307,7 +604,19 @@ static WgradPlan wgrad_plan(int M, int N, int64_t rows) {
       p.nc = 3;
     }
   }
-  int slots = 32 / (p.MB * p.NB);
+  // the LDS-DMA forms: 2 x 4 waves on 13 x 13-tile blocks whose 208-column images exist inside the M / N columns the caller
+  // vouches for, rows a multiple of 128; the four-wave 13 x 26 form for long row ranges against a two-block x
+  auto blocks_ok = [](int T, int B, int cols) {
+    for (int b = 0; b < B; ++b) {
+      const int t0 = split_start(T, B, b), t1 = split_start(T, B, b + 1);
+      if (t1 - t0 < 12 || t1 - t0 > 13 || 16 * t0 + 208 > cols) return false;
+    }
+    return true;
+  };
+  if (WGRAD_DMA && p.wm == 2 && p.wn == 4 && p.nc == 4 && rows % (4 * WG_KS) == 0 && blocks_ok(Mt, p.MB, M) &&
+      blocks_ok(Nt, p.NB, N))
+    p.dma = (WGRAD_DMA2 && p.NB == 2 && rows >= WD2_MIN_ROWS) ? 2 : 1;
+  int slots = 32 / (p.dma == 2 ? p.MB : p.MB * p.NB);
   // every row range at least 4 stages long
   const int64_t stages = (rows + WG_KR - 1) / WG_KR;
   while (slots > 1 && stages / (8 * slots) < 4) slots >>= 1;
@@ -359,6 +668,27 @@ extern "C" int trs_wgrad_rows(const void* g, int32_t ldg, const void* x, int32_t
   const int PM = (Mt + p.MB - 1) / p.MB, PN = (Nt + p.NB - 1) / p.NB;
   const size_t lds = (size_t)(4 * (PM + PN) + WG_TC) * WG_PANEL;      // + the panels a short wave runs on into
   const int grid = 8 * p.slots_per_xcd * p.MB * p.NB;
+  TRS_REQUIRE(p.dma == 0 || (int64_t)WG_KS * std::max(ldg, ldx) * 2 < ((int64_t)1 << 31), TRS_ESHAPE, "wgrad_rows: row stride too large");
+  if (p.dma == 2) {
+    static bool attr2 = false;
+    if (!attr2) {
+      if (hipFuncSetAttribute((const void*)wgrad_dma2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return check_launch("wgrad_rows(dma2): LDS attribute");
+      attr2 = true;
+    }
+    hipLaunchKernelGGL(wgrad_dma2_kernel, dim3(8 * p.slots_per_xcd * p.MB), dim3(256), (size_t)WD2_NSLOT * WD2_SLOT, s, a);
+    return check_launch("wgrad_rows(dma2)");
+  }
+  if (p.dma == 1) {
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute((const void*)wgrad_dma_kernel<7, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return check_launch("wgrad_rows(dma): LDS attribute");
+      attr = true;
+    }
+    hipLaunchKernelGGL((wgrad_dma_kernel<7, 4>), dim3(grid), dim3(512), (size_t)WD_NSLOT * WD_SLOT, s, a);
+    return check_launch("wgrad_rows(dma)");
+  }
   if (p.wm == 2 && p.wn == 4)
     return p.nc == 4 ? wgrad_launch<2, 4, 7, 4>(a, grid, lds, s) : wgrad_launch<2, 4, 7, 3>(a, grid, lds, s);
   if (p.wm == 2)
