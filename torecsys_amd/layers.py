@@ -534,6 +534,10 @@ HYBRID_MLP = os.environ.get("TRS_HYBRID_MLP", "1") not in ("", "0")   # fused ta
 # fewer on the critical path and still 20 us slower (what the graph's branches overlap with moves: the bucket build no
 # longer runs beside the first GEMM).  Kept as a switch and as the ABI's PACK / RUN phases; off.
 HOIST_PACK = int(os.environ.get("TRS_HOIST_PACK", "0") or 0)
+# _HybridMLP.backward: the tail's weight-gradient launches on a side stream beside the first layer's gradient GEMMs.
+# Measured alternately on one box (gpurun_out/r05p): 1.1956 ms off, 1.1975 ms on -- matrix-core kernels beside matrix-core
+# kernels only move time.  Off.
+WGRAD_STREAM = os.environ.get("TRS_WGRAD_STREAM", "0") not in ("", "0")
 # the fused tail's forward on the first 416 columns of the 512-wide first-layer output, by the row-owner kernel (mixed family)
 MIXED_TAIL = os.environ.get("TRS_MIXED_TAIL", "1") not in ("", "0")
 
@@ -828,15 +832,32 @@ class _HybridMLP(torch.autograd.Function):
         gy2 = F_.pad_cols(gy, widths[L]) if gy.shape[1] != widths[L] else gy.contiguous()
         wpack = ctx.wpack if ctx.wpack is not None else (None, None, None)
         g1, gz, gb, gb1 = F_.fused_mlp_backward_raw(gy2, widths, Ws, masks, mask_in, family=fam, packed_ws=wpack[1])
-        grads = []
-        for l in range(L):
-            inp = h1 if l == 0 else hidden[l - 1]
-            g = gy2 if l == L - 1 else gz[l]
-            out_f, in_f = wshapes[l]
-            gw, gbias = F_._tail_layer_grads(g, inp, out_f, in_f, wdt[l], gb[l], needs[6 + 4 * l], needs[7 + 4 * l])
-            grads += [gw, gbias, None, None]
+        def tail_grads():
+            grads = []
+            for l in range(L):
+                inp = h1 if l == 0 else hidden[l - 1]
+                g = gy2 if l == L - 1 else gz[l]
+                out_f, in_f = wshapes[l]
+                gw, gbias = F_._tail_layer_grads(g, inp, out_f, in_f, wdt[l], gb[l], needs[6 + 4 * l], needs[7 + 4 * l])
+                grads += [gw, gbias, None, None]
+            return grads
+
+        # The tail's weight gradients (three GEMMs over the rows + their finish passes: six launches nobody waits for
+        # until the step ends) on the "wgrad" side stream, beside the first layer's input- and weight-gradient GEMMs;
+        # this node's stream waits for them before it returns (the gradients go to AccumulateGrad on this stream).
+        ev = None
+        if WGRAD_STREAM and rows >= PAD_MIN_ROWS:
+            grads, ev, side = F_.run_on_side(dev, "wgrad", tail_grads)
+        else:
+            grads = tail_grads()
         gx, gw1, gbias1 = _dense_layer_grads(g1, gb1, cur, W1, w1shape[0], w1shape[1], w1dt, needs[0], needs[2], needs[3],
                                              rows_gemm_ws=wpack[2])
+        if ev is not None:
+            main = F_._abi.current_stream_of(dev)
+            main.wait_event(ev)
+            for t in grads:
+                if t is not None:
+                    t.record_stream(main)
         return (gx.reshape(xshape) if needs[0] else None, None, gw1, gbias1, None, None, *grads)
 
 
