@@ -842,7 +842,9 @@ def main():
                 import hashlib
                 src = os.path.join(ROOT, "torecsys_amd", "csrc", "fm.hip")
                 # a figure taken from another build of the kernel is not this kernel's traffic: refused
-                if tj.get("kernel_source_sha16") == hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]:
+                # (and the figure belongs to the configuration it was profiled on: BASELINE configs[1], uniform field sizes)
+                if (tj.get("kernel_source_sha16") == hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+                        and a.field_layout == "uniform" and a.model == "deepfm" and B == 65536):
                     traffic = tj.get(roof_kernel + ("_zipf" if a.zipf else ""))
                     traffic_round = tj.get("round")
             except Exception:  # noqa: BLE001
