@@ -104,6 +104,10 @@ def parse():
     ap.add_argument("--host-indices", action="store_true",
                     help="index batches start in host memory: packed into pinned int32 buffers and copied over PCIe "
                          "inside the timed region (IndexStager), overlapped with the previous step; single-GPU path")
+    ap.add_argument("--graph-steps-per-replay", type=int, default=4,
+                    help="consecutive steps (each on its own resident batch of the ring) captured into ONE hipGraph; the "
+                         "device idles ~25 us between two replays, a K-step graph pays that once per K steps; 1 = one "
+                         "step per replay")
     ap.add_argument("--graph-input-sets", type=int, default=1,
                     help="static input sets of the replayed step (torecsys_amd.graph.GraphedStep(input_sets=)): one per "
                          "resident batch of the ring, so a replay copies nothing; 1 = one set, every batch copied into it")
@@ -672,20 +676,47 @@ def main():
             # per step; --graph-input-sets 1 restores that).  Batches staged from the host keep the single set: their copy
             # into the static buffer IS the transfer being measured.
             nsets = 1 if host_idx else max(1, min(a.graph_input_sets, RING))
-            gstep = GraphedStep(graph_fn, (idx_ring[0].int() if host_idx else idx_ring[0], label_ring[0]), params=params,
-                                warmup=1, input_sets=nsets)      # staged batches arrive as int32
-            if nsets > 1:
-                assert RING % nsets == 0
-                for k in range(nsets):
-                    gstep.load(k, idx_ring[k], label_ring[k])
-                torch.cuda.synchronize()
+            # --graph-steps-per-replay K (default: the ring length): ONE graph holds K consecutive steps, each on its own
+            # resident batch of the ring -- K full forward + backward passes per launch.  Between two replays the device
+            # idles for ~25 us (graph-to-graph hand-over: `profiles/r05_bench_deepfm_step_timeline.md`, the gap in front of
+            # the next lookup); a K-step graph pays it once per K steps.  Same steps, same order, same final loss.
+            ksteps = a.graph_steps_per_replay if (not host_idx and RING % max(1, a.graph_steps_per_replay) == 0
+                                                  and a.steps % max(1, a.graph_steps_per_replay) == 0) else 1
+            if ksteps > 1:
+                def graph_fn_multi(*flat):
+                    for j in range(ksteps):
+                        if j:
+                            for p in params:
+                                p.grad = None          # (host-side: every step of the graph writes fresh gradient tensors)
+                        l_ = graph_fn(flat[2 * j], flat[2 * j + 1])
+                    return l_
 
-            def step():
-                k = counter[0] % RING
-                counter[0] += 1
-                if nsets > 1 and k < nsets and nsets == RING:
-                    return gstep.replay(k)                        # the batch is already where the graph reads it
-                return gstep(next_indices(k), label_ring[k])      # copies the batch into the static buffers, replays
+                flat = []
+                for j in range(ksteps):
+                    flat += [idx_ring[j], label_ring[j]]
+                gstep = GraphedStep(graph_fn_multi, tuple(flat), params=params, warmup=1)      # static copies of the ring
+
+                def step():
+                    k = counter[0]
+                    counter[0] += 1
+                    if k % ksteps == 0:
+                        return gstep.replay(0)          # steps k .. k + ksteps - 1 (ring slots (k + j) % RING)
+                    return gstep.output
+            else:
+                gstep = GraphedStep(graph_fn, (idx_ring[0].int() if host_idx else idx_ring[0], label_ring[0]), params=params,
+                                    warmup=1, input_sets=nsets)      # staged batches arrive as int32
+                if nsets > 1:
+                    assert RING % nsets == 0
+                    for k in range(nsets):
+                        gstep.load(k, idx_ring[k], label_ring[k])
+                    torch.cuda.synchronize()
+
+                def step():
+                    k = counter[0] % RING
+                    counter[0] += 1
+                    if nsets > 1 and k < nsets and nsets == RING:
+                        return gstep.replay(k)                        # the batch is already where the graph reads it
+                    return gstep(next_indices(k), label_ring[k])      # copies the batch into the static buffers, replays
 
             for _ in range(a.warmup):
                 step()
@@ -897,6 +928,7 @@ def main():
                        "global_batch": B * world, "rows": V, "parallelism": parallelism,
                        "microbatches": MB, "optimizer": a.optimizer, "hipgraph": bool(use_graph or (dense_graph and dense_ready[0])),
                        "hipgraph_input_sets": (nsets if use_graph else None),
+                       "hipgraph_steps_per_replay": (ksteps if use_graph else None),
                        **({"hipgraph_scope": "dense region (deep branch, head, loss, their backward) replayed; lookups, "
                                              "exchanges and the dense all-reduce eager on the compute / communication streams"}
                           if (dense_graph and dense_ready[0]) else {}),
