@@ -662,9 +662,12 @@ def main():
     if use_graph:
         from torecsys_amd.graph import GraphedStep
 
+        one = torch.ones((), dtype=torch.float32, device=dev)      # dL/dL, made once: loss.backward() would fill a fresh one
+                                                                   # (a 4.5 us launch) in every step of the graph
+
         def graph_fn(ix, lab):
             l_ = fwd_loss(ix, lab, 1.0)
-            l_.backward()
+            l_.backward(one if l_.dtype == torch.float32 and l_.dim() == 0 else None)
             if dense_opt is not None:
                 dense_opt.step()
             return l_

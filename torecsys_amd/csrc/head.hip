@@ -28,13 +28,27 @@ __global__ __launch_bounds__(256) void ctr_logit_kernel(const T* __restrict__ fm
                                                         HeadExtras ex, const T* __restrict__ bias, int64_t B,
                                                         T* __restrict__ out) {
   const int lane = threadIdx.x & 15;
+  const bool fm_vec = fm != nullptr && (E * (int)sizeof(T)) % 8 == 0 && (reinterpret_cast<uintptr_t>(fm) & 7u) == 0;
   const int64_t groups = (int64_t)gridDim.x * (blockDim.x >> 4);
   const float b0 = bias != nullptr ? to_f32(bias[0]) : 0.f;
   for (int64_t b = (int64_t)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4); b < B; b += groups) {
     float acc = 0.f;
     if (fm != nullptr) {
       const T* r = fm + b * E;
-      for (int e = lane; e < E; e += 16) acc += to_f32(r[e]);
+      if (fm_vec) {      // 8 bytes per lane and load: a 64-wide bf16 row is one load per lane instead of four
+        constexpr int VE = 8 / (int)sizeof(T);
+        for (int e = lane * VE; e < E; e += 16 * VE) {
+          const uint2 u = *reinterpret_cast<const uint2*>(r + e);
+          if constexpr (sizeof(T) == 2) {
+            acc += __uint_as_float(u.x << 16) + __uint_as_float(u.x & 0xffff0000u) + __uint_as_float(u.y << 16) +
+                   __uint_as_float(u.y & 0xffff0000u);
+          } else {
+            acc += __uint_as_float(u.x) + __uint_as_float(u.y);
+          }
+        }
+      } else {
+        for (int e = lane; e < E; e += 16) acc += to_f32(r[e]);
+      }
     }
     if (feat != nullptr) {
       const T* r = feat + b * N;
