@@ -14,6 +14,10 @@
 
 #include "trs_common.hpp"
 
+#ifndef TRS_SCATTER_NT_LOADS
+#define TRS_SCATTER_NT_LOADS 1      // nontemporal loads of the block gradient in the bucket walks (0: plain loads)
+#endif
+
 namespace trs {
 
 constexpr int SCAN_THREADS = 256;
@@ -553,7 +557,11 @@ __device__ __forceinline__ void accumulate_bucket(float* acc, float* gsum, const
             const unsigned b = (unsigned)p[c] / (unsigned)N;
             row = (int64_t)b * gbs + ((unsigned)p[c] - b * (unsigned)N);
           }
+#if TRS_SCATTER_NT_LOADS
+          gv[c] = load_stream(&g_rows[row * L + lane_v]);
+#else
           gv[c] = g_rows[row * L + lane_v];
+#endif
         }
         if (HAS_FM) {
           const int64_t b = (int64_t)((unsigned)p[c] / (unsigned)N);
@@ -710,7 +718,11 @@ __global__ __launch_bounds__(256, 8) void scatter_rows_fm1_kernel(
           gs[c] = 0.f;
           if (p[c] >= 0) {
             const unsigned b = __umulhi((unsigned)p[c], rcpN);      // p / N for p < 2^31, N < 2^16 (host-checked)
+#if TRS_SCATTER_NT_LOADS
+            if (HAS_G) gv[c] = load_stream(&g_rows[(unsigned)p[c] * L + lane_v]);      // read once: see load_stream
+#else
             if (HAS_G) gv[c] = g_rows[(unsigned)p[c] * L + lane_v];
+#endif
             tv[c] = tg[b * L + lane_v];
             gs[c] = to_f32(g1[b]);
           }

@@ -159,6 +159,15 @@ inline int resident_blocks(const void* kernel, int threads, size_t dyn_lds) {
 __device__ __forceinline__ int64_t udiv_fast(int64_t a, int d, bool fits32) {
   return fits32 ? (int64_t)((unsigned)a / (unsigned)d) : a / d;
 }
+// 16-byte streaming load: data that is read exactly once (the (B,N,E) block gradient in the bucket walk) should not
+// displace what IS re-read -- the embedding table in the 256 MiB Infinity Cache: with plain loads of the 327 MB gradient the
+// next step's lookup found the table evicted (134 us in the DeepFM step), with these it runs at 112-116 us
+// (profiles/r05_logs/ab_scatter_nt_loads.txt)
+__device__ __forceinline__ uint4 load_stream(const uint4* src) {
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  const u32x4 w = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
+  return make_uint4(w.x, w.y, w.z, w.w);
+}
 // 16-byte streaming store: the destination is consumed by a later kernel, keep L2 for data that is re-read
 __device__ __forceinline__ void store_stream(uint4* dst, const uint4& v) {
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
