@@ -29,6 +29,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned mf_u32x4;
 #ifndef TRS_MF_ROWS
 #define TRS_MF_ROWS 128
 #endif
+#ifndef TRS_ROWS_GEMM_PLAIN_STORES
+#define TRS_ROWS_GEMM_PLAIN_STORES 0      // 1: the wide input gradient written with cache-allocating stores (experiment)
+#endif
 #ifndef TRS_MF_GRID
 #define TRS_MF_GRID 256
 #endif
@@ -569,9 +572,14 @@ __global__ __launch_bounds__(64 * MF_WAVES, TRS_MF_MINW) void mlp_rows_gemm_kern
               v[i] = acc[mi][2 * pi][i];
               v[4 + i] = acc[mi][2 * pi + 1][i];
             }
-            if (colok && 16 * mi < left)
+            if (colok && 16 * mi < left) {
+#if TRS_ROWS_GEMM_PLAIN_STORES
+              *reinterpret_cast<uint4*>(out0 + (size_t)mi * 16 * a.out_stride + 32 * sh.pair[pi]) = Vec16<bf16_t>::pack(v);
+#else
               store_stream(reinterpret_cast<uint4*>(out0 + (size_t)mi * 16 * a.out_stride + 32 * sh.pair[pi]),
                            Vec16<bf16_t>::pack(v));
+#endif
+            }
           }
         }
       };

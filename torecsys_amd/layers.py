@@ -538,6 +538,8 @@ HOIST_PACK = int(os.environ.get("TRS_HOIST_PACK", "0") or 0)
 # Measured alternately on one box (gpurun_out/r05p): 1.1956 ms off, 1.1975 ms on -- matrix-core kernels beside matrix-core
 # kernels only move time.  Off.
 WGRAD_STREAM = os.environ.get("TRS_WGRAD_STREAM", "0") not in ("", "0")
+# _dense_layer_grads: the input gradient behind the weight gradient (see there)
+GX_LAST = os.environ.get("TRS_GX_LAST", "1") not in ("", "0")
 # the fused tail's forward on the first 416 columns of the 512-wide first-layer output, by the row-owner kernel (mixed family)
 MIXED_TAIL = os.environ.get("TRS_MIXED_TAIL", "1") not in ("", "0")
 
@@ -718,11 +720,17 @@ def _dense_layer_grads(g2, gbf, xin, W, out_f, in_f, wdt, need_x, need_w, need_b
     fragment order for trs_rows_gemm (F_.rows_gemm_pack at forward time)."""
     rows = xin.shape[0]
     gw_out = gb_out = None
-    if need_x and F_.rows_gemm_supported(g2, W, out_f, xin.shape[1]) and W.shape[1] == xin.shape[1]:
-        # wide input, short contraction (2496 <- 400): our own kernel, K not padded to the library's tile
-        gx = F_.rows_gemm(g2, W, out_f, xin.shape[1], packed_ws=rows_gemm_ws)
-    else:
-        gx = (g2 @ W) if need_x else None
+
+    def input_grad():
+        if need_x and F_.rows_gemm_supported(g2, W, out_f, xin.shape[1]) and W.shape[1] == xin.shape[1]:
+            # wide input, short contraction (2496 <- 400): our own kernel, K not padded to the library's tile
+            return F_.rows_gemm(g2, W, out_f, xin.shape[1], packed_ws=rows_gemm_ws)
+        return (g2 @ W) if need_x else None
+
+    # GX_LAST: the input gradient is enqueued BEHIND the weight gradient, i.e. right in front of its consumer (the bucket
+    # walk of the embedding backward reads the (B,N,E) gradient next): what of it is still in the Infinity Cache then
+    # does not come from HBM
+    gx = None if GX_LAST else input_grad()
     S = _split_count(rows, _LinearSplitK.SPLIT_ROWS)
     if need_w or (need_b and gbf is not None):
         if need_w and S >= 4 and rows % S == 0 and 32 <= g2.shape[1] <= 1024 and 32 <= xin.shape[1] <= 4096 \
@@ -755,6 +763,8 @@ def _dense_layer_grads(g2, gbf, xin, W, out_f, in_f, wdt, need_x, need_w, need_b
             gw_out = gw if gw.is_contiguous() else gw.contiguous()
     if need_b and gb_out is None:
         gb_out = gbf[:out_f].to(wdt) if gbf is not None else g2.sum(0)[:out_f]
+    if GX_LAST:
+        gx = input_grad()
     return gx, gw_out, gb_out
 
 
