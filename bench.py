@@ -683,8 +683,8 @@ def main():
             # resident batch of the ring -- K full forward + backward passes per launch.  Between two replays the device
             # idles for ~25 us (graph-to-graph hand-over: `profiles/r05_bench_deepfm_step_timeline.md`, the gap in front of
             # the next lookup); a K-step graph pays it once per K steps.  Same steps, same order, same final loss.
-            ksteps = a.graph_steps_per_replay if (not host_idx and RING % max(1, a.graph_steps_per_replay) == 0
-                                                  and a.steps % max(1, a.graph_steps_per_replay) == 0) else 1
+            kreq = max(1, a.graph_steps_per_replay)
+            ksteps = kreq if (not host_idx and (RING % kreq == 0 or kreq % RING == 0) and a.steps % kreq == 0) else 1
             if ksteps > 1:
                 def graph_fn_multi(*flat):
                     for j in range(ksteps):
@@ -696,7 +696,7 @@ def main():
 
                 flat = []
                 for j in range(ksteps):
-                    flat += [idx_ring[j], label_ring[j]]
+                    flat += [idx_ring[j % RING], label_ring[j % RING]]
                 gstep = GraphedStep(graph_fn_multi, tuple(flat), params=params, warmup=1)      # static copies of the ring
 
                 def step():
