@@ -820,3 +820,24 @@ def test_stacked_single_index_embeddings_take_one_launch(monkeypatch):
     bad["c1"] = torch.full_like(cols["c1"], sizes[1])
     router(bad)
     assert F_.index_errors_seen(dev)
+
+
+def test_fused_lookup_fm_on_a_table_beyond_the_caches_streams_its_rows():
+    """A table larger than 512 MiB takes the kernel instantiation that fetches rows with streaming loads: same results --
+    block bit-exact against index_select, FM term against the fp32 formula on the same rows."""
+    from torecsys_amd import functional as F_
+    dev = torch.device("cuda:0")
+    V, E, N, B = 5_000_000, 64, 13, 4096
+    assert V * E * 2 > (512 << 20)
+    g = torch.Generator(device=dev).manual_seed(3)
+    w = torch.randn(V, E, generator=g, device=dev).bfloat16()
+    per = V // N
+    sizes = [per] * (N - 1) + [V - per * (N - 1)]
+    off = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(torch.tensor(sizes), 0)[:-1]]).to(dev)
+    idx = torch.stack([torch.randint(0, s_, (B,), generator=g, device=dev) for s_ in sizes], 1)
+    emb, fm, _ = F_.embed_fm(w, idx, off)
+    rows = w.index_select(0, (idx + off).reshape(-1)).reshape(B, N, E)
+    assert torch.equal(emb, rows)
+    x = rows.float()
+    ref = 0.5 * (x.sum(1) ** 2 - (x * x).sum(1))
+    assert rel_err(fm.float().cpu(), ref.cpu()) <= 1e-2

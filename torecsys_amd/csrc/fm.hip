@@ -21,7 +21,10 @@
 
 namespace trs {
 
-template <typename T, typename IdxT, int LOG2L, bool GATHER>
+// STREAM: the table is far larger than the caches (EMBED_STREAM_BYTES): its rows are fetched with streaming loads -- a row
+// that will not be looked up again before it is evicted anyway should not displace the index / output traffic in L2 (4 GiB
+// table, FM only: 72.1-74.8 -> 70.6-71.5 us; on a cache-resident table the same loads cost 115 -> 128 us: rows ARE reused)
+template <typename T, typename IdxT, int LOG2L, bool GATHER, bool STREAM = false>
 __global__ __launch_bounds__(256) void embed_fm_group_kernel(
     const uint4* __restrict__ src,  // GATHER: table (V x E); else x (B x N x E)
     const IdxT* __restrict__ idx, const int64_t* __restrict__ offsets, int64_t B, int N, int64_t V,
@@ -57,7 +60,7 @@ __global__ __launch_bounds__(256) void embed_fm_group_kernel(
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
         v[c] = make_uint4(0, 0, 0, 0);
-        if (r[c] >= 0) v[c] = src[r[c] * L + lane_v];
+        if (r[c] >= 0) v[c] = STREAM ? load_stream(&src[r[c] * L + lane_v]) : src[r[c] * L + lane_v];
       }
       if (GATHER && first_table != nullptr) {
 #pragma unroll
@@ -144,6 +147,8 @@ __global__ __launch_bounds__(256) void embed_fm_elem_kernel(
   }
 }
 
+constexpr size_t EMBED_STREAM_BYTES = (size_t)512 << 20;      // twice the Infinity Cache
+
 static int log2_lanes(int row_bytes) {
   if (row_bytes % 16 != 0) return -1;
   const int L = row_bytes / 16;
@@ -162,10 +167,17 @@ static int embed_fm_launch(const void* src, const IdxT* idx, const int64_t* offs
   if (lg >= 0 && al) {
     const int L = 1 << lg;
     const int grid = stream_grid(B * L, 256, 256 * 16);
-#define TRS_EF(LG)                                                                                        \
-  hipLaunchKernelGGL((embed_fm_group_kernel<T, IdxT, LG, GATHER>), dim3(grid), dim3(256), 0, s,            \
+    const bool stream = GATHER && (size_t)V * E * sizeof(T) > EMBED_STREAM_BYTES;
+#define TRS_EF2(LG, ST)                                                                                   \
+  hipLaunchKernelGGL((embed_fm_group_kernel<T, IdxT, LG, GATHER, ST>), dim3(grid), dim3(256), 0, s,        \
                      (const uint4*)src, idx, offsets, B, N, V, (uint4*)emb, (uint4*)fm, fm_sum,            \
                      (const T*)first_table, (T*)first, err_flag, (T*)first_vals)
+#define TRS_EF(LG)                 \
+  if (GATHER && stream) {          \
+    TRS_EF2(LG, GATHER);           \
+  } else {                         \
+    TRS_EF2(LG, false);            \
+  }
     switch (lg) {
       case 0: TRS_EF(0); break;
       case 1: TRS_EF(1); break;
@@ -176,6 +188,7 @@ static int embed_fm_launch(const void* src, const IdxT* idx, const int64_t* offs
       default: TRS_EF(6); break;
     }
 #undef TRS_EF
+#undef TRS_EF2
   } else {
     const int grid = stream_grid(B * E, 256, 256 * 16);
     hipLaunchKernelGGL((embed_fm_elem_kernel<T, IdxT, GATHER>), dim3(grid), dim3(256), 0, s, (const T*)src, idx,
