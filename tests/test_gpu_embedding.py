@@ -838,6 +838,7 @@ def test_fused_lookup_fm_on_a_table_beyond_the_caches_streams_its_rows():
     emb, fm, _ = F_.embed_fm(w, idx, off)
     rows = w.index_select(0, (idx + off).reshape(-1)).reshape(B, N, E)
     assert torch.equal(emb, rows)
+    assert torch.equal(F_.gather_rows(w, idx, off), rows)      # the plain lookup streams such a table's rows as well
     x = rows.float()
     ref = 0.5 * (x.sum(1) ** 2 - (x * x).sum(1))
     assert rel_err(fm.float().cpu(), ref.cpu()) <= 1e-2

@@ -45,10 +45,12 @@ int zero_bytes(void* p, size_t bytes, hipStream_t s) {
 
 // rows = B*N flat positions; vpr = 16-byte vectors per row (E*sizeof(T)/16).
 // SHIFT >= 0: vpr == 1<<SHIFT (no integer division); SHIFT < 0: generic.
+// ``stream`` (uniform): the table is far larger than the caches (> 512 MiB, e.g. a 16 GB shard of a row-sharded table):
+// rows are fetched with streaming loads, as embed_fm does (fm.hip)
 template <typename IdxT, int SHIFT, int UNROLL>
 __global__ __launch_bounds__(256) void gather_rows_vec_kernel(
     const uint4* __restrict__ table, const IdxT* __restrict__ idx, const int64_t* __restrict__ offsets,
-    uint4* __restrict__ out, int64_t total_vecs, int vpr, int N, int64_t V, int32_t* __restrict__ err_flag) {
+    uint4* __restrict__ out, int64_t total_vecs, int vpr, int N, int64_t V, int32_t* __restrict__ err_flag, bool stream) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (; t0 < total_vecs; t0 += stride * UNROLL) {
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256) void gather_rows_vec_kernel(
         if (err_flag != nullptr && (r < 0 || r >= V)) {
           *err_flag = 1;
         } else {
-          v[u] = table[r * vpr + lane_v];
+          v[u] = stream ? load_stream(&table[r * vpr + lane_v]) : table[r * vpr + lane_v];
         }
       }
     }
@@ -121,7 +123,8 @@ static int launch_gather_vec(const void* table, const IdxT* idx, const int64_t* 
   const int grid = stream_grid((total + UNROLL - 1) / UNROLL, 256, 256 * 32);
 #define TRS_GV(SH)                                                                                  \
   hipLaunchKernelGGL((gather_rows_vec_kernel<IdxT, SH, UNROLL>), dim3(grid), dim3(256), 0, s,       \
-                     (const uint4*)table, idx, offsets, (uint4*)out, total, vpr, N, V, err_flag)
+                     (const uint4*)table, idx, offsets, (uint4*)out, total, vpr, N, V, err_flag,  \
+                     (size_t)V * vpr * 16 > ((size_t)512 << 20))
   switch (vpr) {
     case 1: TRS_GV(0); break;
     case 2: TRS_GV(1); break;
