@@ -6,6 +6,8 @@
 // stored as one contiguous N(N-1)/2 run per sample.  Backward is (G_sym * X) with G_sym the
 // symmetric zero-diagonal matrix of the incoming pair gradients, same tiling.
 // FFM: pure element-wise, HBM-bound: one lane = one 16-byte vector of an output row.
+#include <algorithm>
+
 #include "trs_common.hpp"
 
 namespace trs {
@@ -696,6 +698,64 @@ __global__ __launch_bounds__(256) void ffm_fused_fwd_kernel(const UNIT* const* _
   }
 }
 
+// The same, round 5 (rows of whole 16-byte units): a workgroup takes a SAMPLE at a time -- its N row ids are read once into
+// LDS (the element kernel above re-reads two of them per 16 bytes of output and divides a 64-bit item index three times)
+// -- and its lane groups (UPR lanes = one row) walk the P pairs, PIPE of them in flight per group: 2 PIPE independent row
+// loads, then PIPE products and streaming stores.  Consecutive groups take consecutive pairs: a wave writes whole
+// contiguous KBs of the output.  Rows come from N tables of V rows each (5 GB at the BASELINE shape: nothing is reused
+// before it is evicted), so they are fetched with streaming loads when the tables are larger than the caches, and the
+// 6.2 GB product is written past them.  The (i, j) of every pair comes from a table in LDS built once per workgroup.
+template <typename T, typename IdxT, int LOG2U, bool STREAM>
+__global__ __launch_bounds__(256) void ffm_fused_fwd_rows_kernel(const uint4* const* __restrict__ tables,
+                                                                 const IdxT* __restrict__ idx,
+                                                                 const int64_t* __restrict__ offsets,
+                                                                 uint4* __restrict__ out, int64_t B, int N, int64_t V,
+                                                                 int32_t* __restrict__ err_flag) {
+  constexpr int U = 1 << LOG2U, G = 256 >> LOG2U, PIPE = 4;
+  extern __shared__ __attribute__((aligned(16))) char ffm_lds[];
+  const int P = N * (N - 1) / 2;
+  unsigned short* pij = reinterpret_cast<unsigned short*>(ffm_lds);                       // [P]: i << 8 | j
+  int64_t* rid = reinterpret_cast<int64_t*>(ffm_lds + ((2 * P + 15) / 16) * 16);          // [N] row ids of the sample
+  for (int i = threadIdx.x; i < N; i += 256)
+    for (int j = i + 1; j < N; ++j) pij[pair_index(i, j, N)] = (unsigned short)(i << 8 | j);
+  const int lv = threadIdx.x & (U - 1), grp = threadIdx.x >> LOG2U;
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();                                      // the previous sample's ids are no longer read
+    for (int n = threadIdx.x; n < N; n += 256) {
+      int64_t r = load_row_id(idx, offsets, b * N + n, n);
+      if (r < 0 || r >= V) {
+        if (err_flag != nullptr) *err_flag = 1;
+        r = -1;
+      }
+      rid[n] = r;
+    }
+    __syncthreads();
+    uint4* ob = out + b * P * U;
+    for (int p0 = grp; p0 < P; p0 += G * PIPE) {
+      uint4 a[PIPE], c[PIPE];
+#pragma unroll
+      for (int k = 0; k < PIPE; ++k) {
+        const int p = p0 + k * G;
+        a[k] = make_uint4(0, 0, 0, 0);
+        c[k] = make_uint4(0, 0, 0, 0);
+        if (p < P) {
+          const int i = pij[p] >> 8, j = pij[p] & 255;
+          const int64_t ri = rid[i], rj = rid[j];
+          if (ri >= 0 && rj >= 0) {
+            a[k] = STREAM ? load_stream(&tables[i][rj * U + lv]) : tables[i][rj * U + lv];
+            c[k] = STREAM ? load_stream(&tables[j][ri * U + lv]) : tables[j][ri * U + lv];
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < PIPE; ++k) {
+        const int p = p0 + k * G;
+        if (p < P) store_stream(&ob[p * U + lv], mul_unit<T, uint4>(a[k], c[k]));
+      }
+    }
+  }
+}
+
 // fused FFM backward: for table i and row r,
 //   grad_i[r,:] = sum over lookups p=(b,j) of row r with j != i of  gout[b, pair(i,j), :] * tables[j][g(b,i), :]
 // one UNIT-lane group per (table, row) walks the row's bucket of the shared CSR; every gradient row is
@@ -848,6 +908,39 @@ static int ffm_fused_dispatch(const void* const* tables, int64_t V, int E, int d
   const int rb = E * dtype_size(dtype);
   const bool vec = rb % 16 == 0 && aligned16(out);
   const int upr = vec ? rb / 16 : E;
+  if (vec && is_pow2(upr) && upr <= 64 && N <= 255) {      // whole 16-byte units, a power of two of them per row: the sample-wise kernel
+    int lg = 0;
+    while ((1 << lg) < upr) ++lg;
+    const int P = N * (N - 1) / 2;
+    const size_t lds = (size_t)((2 * P + 15) / 16) * 16 + (size_t)N * 8;
+    const bool stream = (size_t)N * V * rb > ((size_t)512 << 20);
+    const int grid = (int)std::min<int64_t>(B, 256 * 8);
+#define TRS_FFM_ROWS(TT, LG)                                                                                              \
+  if (stream)                                                                                                             \
+    hipLaunchKernelGGL((ffm_fused_fwd_rows_kernel<TT, IdxT, LG, true>), dim3(grid), dim3(256), lds, s,                     \
+                       (const uint4* const*)tables, idx, offsets, (uint4*)out, B, N, V, err_flag);                        \
+  else                                                                                                                    \
+    hipLaunchKernelGGL((ffm_fused_fwd_rows_kernel<TT, IdxT, LG, false>), dim3(grid), dim3(256), lds, s,                    \
+                       (const uint4* const*)tables, idx, offsets, (uint4*)out, B, N, V, err_flag)
+#define TRS_FFM_ROWS_T(TT)                    \
+  switch (lg) {                               \
+    case 0: TRS_FFM_ROWS(TT, 0); break;       \
+    case 1: TRS_FFM_ROWS(TT, 1); break;       \
+    case 2: TRS_FFM_ROWS(TT, 2); break;       \
+    case 3: TRS_FFM_ROWS(TT, 3); break;       \
+    case 4: TRS_FFM_ROWS(TT, 4); break;       \
+    case 5: TRS_FFM_ROWS(TT, 5); break;       \
+    default: TRS_FFM_ROWS(TT, 6); break;      \
+  }
+    if (dtype == TRS_F32) {
+      TRS_FFM_ROWS_T(float)
+    } else {
+      TRS_FFM_ROWS_T(bf16_t)
+    }
+#undef TRS_FFM_ROWS_T
+#undef TRS_FFM_ROWS
+    return check_launch("ffm_fused_fwd");
+  }
   const int grid = stream_grid(B * N * N * upr, 256, 256 * 32);
   if (vec && dtype == TRS_F32)
     hipLaunchKernelGGL((ffm_fused_fwd_kernel<float, uint4, IdxT>), dim3(grid), dim3(256), 0, s, (const uint4* const*)tables, idx, offsets, (uint4*)out, B, N, upr, V, err_flag);
