@@ -98,7 +98,7 @@ SIGNATURES = {
     "trs_ffm_fwd": (c_int32, [_P, _I64, _I32, _I32, _I32, _P, _P]),
     "trs_ffm_bwd": (c_int32, [_P, _P, _I64, _I32, _I32, _I32, _P, _P]),
     "trs_ffm_fused_fwd": (c_int32, [_P, _I64, _I32, _I32, _P, _I32, _P, _I64, _I32, _P, _P, _P]),
-    "trs_ffm_fused_bwd": (c_int32, [_P, _I64, _I32, _I32, _P, _I32, _P, _P, _P, _P, _I64, _I32, _P, _P]),
+    "trs_ffm_fused_bwd": (c_int32, [_P, _I64, _I32, _I32, _P, _I32, _P, _P, _P, _P, _I64, _I32, _P, _P, _P]),
     "trs_cross_workspace_bytes": (_SZ, [_I64, _I32, _I32, _I32]),
     "trs_cross_fwd": (c_int32, [_P, _P, _P, _I64, _I32, _I32, _I32, _P, _P, _SZ, _P]),
     "trs_cross_bwd": (c_int32, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _SZ, _P]),

@@ -809,6 +809,82 @@ __global__ __launch_bounds__(256) void ffm_fused_bwd_kernel(const UNIT* const* _
   }
 }
 
+// The same walk for rows of whole 16-byte units, round 5: blockIdx.y = table, one UPR-lane group per row, CH bucket
+// entries in flight (their positions, then their row ids, then 2 CH independent row loads: the element kernel above
+// serialises three dependent loads per entry), 32-bit arithmetic with a reciprocal for p / N, the next row's bucket bounds
+// fetched beside the current walk; the output gradient (6.2 GB, each row read by two tables' walks) and -- when the
+// tables are larger than the caches -- the table rows come in by streaming loads, the gradient rows leave by streaming
+// stores.
+template <typename T, typename IdxT, int LOG2U, bool STREAM>
+__global__ __launch_bounds__(256) void ffm_fused_bwd_rows_kernel(const uint4* const* __restrict__ tables,
+                                                                 const IdxT* __restrict__ idx,
+                                                                 const int64_t* __restrict__ offsets,
+                                                                 const uint4* __restrict__ gout,
+                                                                 const int32_t* __restrict__ row_start,
+                                                                 const int32_t* __restrict__ perm, unsigned N,
+                                                                 unsigned rcpN, int64_t V, uint4* const* __restrict__ grads,
+                                                                 const int32_t* __restrict__ rid_t, int64_t B) {
+  constexpr int U = 1 << LOG2U, VE = Vec16<T>::VE, CH = 4;
+  const int i = blockIdx.y;
+  const int P = (int)(N * (N - 1) / 2);
+  const int lv = threadIdx.x & (U - 1);
+  const int64_t groups = ((int64_t)gridDim.x * 256) >> LOG2U;
+  int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> LOG2U;
+  const int64_t off_i = offsets != nullptr ? offsets[i] : 0;
+  uint4* gi = grads[i];
+  int nbeg = 0, nend = 0;
+  if (r < V) { nbeg = row_start[r]; nend = row_start[r + 1]; }
+  for (; r < V; r += groups) {
+    const int beg = nbeg, end = nend;
+    if (r + groups < V) { nbeg = row_start[r + groups]; nend = row_start[r + groups + 1]; }
+    float acc[VE];
+#pragma unroll
+    for (int k = 0; k < VE; ++k) acc[k] = 0.f;
+    for (int q = beg; q < end; q += CH) {
+      int p[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) p[c] = q + c < end ? perm[q + c] : -1;
+      int64_t ri[CH];
+      unsigned bb[CH], jj[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        ri[c] = -1;
+        bb[c] = jj[c] = 0;
+        if (p[c] >= 0) {
+          bb[c] = __umulhi((unsigned)p[c], rcpN);      // p / N for p < 2^31, N < 2^16 (host-checked)
+          jj[c] = (unsigned)p[c] - bb[c] * N;
+          if (jj[c] != (unsigned)i) {
+            const int64_t v = rid_t != nullptr ? (int64_t)rid_t[(int64_t)i * B + bb[c]]
+                                               : (int64_t)idx[(int64_t)bb[c] * N + i] + off_i;
+            ri[c] = (v >= 0 && v < V) ? v : -1;
+          }
+        }
+      }
+      uint4 gv[CH], tv[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        gv[c] = make_uint4(0, 0, 0, 0);
+        tv[c] = make_uint4(0, 0, 0, 0);
+        if (ri[c] >= 0) {
+          const int j = (int)jj[c];
+          const int pidx = i < j ? pair_index(i, j, (int)N) : pair_index(j, i, (int)N);
+          gv[c] = load_stream(&gout[((int64_t)bb[c] * P + pidx) * U + lv]);
+          tv[c] = STREAM ? load_stream(&tables[j][ri[c] * U + lv]) : tables[j][ri[c] * U + lv];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        float gf[VE], tf[VE];
+        Vec16<T>::unpack(gv[c], gf);
+        Vec16<T>::unpack(tv[c], tf);
+#pragma unroll
+        for (int k = 0; k < VE; ++k) acc[k] = fmaf(gf[k], tf[k], acc[k]);
+      }
+    }
+    store_stream(&gi[r * U + lv], Vec16<T>::pack(acc));
+  }
+}
+
 }  // namespace trs
 
 using namespace trs;
@@ -970,10 +1046,45 @@ extern "C" int trs_ffm_fused_fwd(const void* const* tables, int64_t V, int32_t E
 template <typename IdxT>
 static int ffm_fused_bwd_dispatch(const void* const* tables, int64_t V, int E, int dtype, const IdxT* idx,
                                   const int64_t* offsets, const void* gout, const int32_t* row_start,
-                                  const int32_t* perm, int N, void* const* grads, hipStream_t s) {
+                                  const int32_t* perm, int N, void* const* grads, hipStream_t s, int64_t BN,
+                                  const int32_t* rid_t) {
   const int rb = E * dtype_size(dtype);
   const bool vec = rb % 16 == 0 && aligned16(gout);
   const int upr = vec ? rb / 16 : E;
+  if (vec && is_pow2(upr) && upr <= 64 && N < 65536 && BN < ((int64_t)1 << 31)) {
+    int lg = 0;
+    while ((1 << lg) < upr) ++lg;
+    const bool stream = (size_t)N * V * rb > ((size_t)512 << 20);
+    const unsigned rcpN = (unsigned)((((uint64_t)1 << 32) + N - 1) / N);
+    const dim3 grid((unsigned)stream_grid(V * upr, 256, 256 * 4), (unsigned)N);
+#define TRS_FFMB(TT, LG)                                                                                                 \
+  if (stream)                                                                                                           \
+    hipLaunchKernelGGL((ffm_fused_bwd_rows_kernel<TT, IdxT, LG, true>), grid, dim3(256), 0, s, (const uint4* const*)tables, \
+                       idx, offsets, (const uint4*)gout, row_start, perm, (unsigned)N, rcpN, V, (uint4* const*)grads,    \
+                       rid_t, BN / N);                                                                                  \
+  else                                                                                                                  \
+    hipLaunchKernelGGL((ffm_fused_bwd_rows_kernel<TT, IdxT, LG, false>), grid, dim3(256), 0, s, (const uint4* const*)tables, \
+                       idx, offsets, (const uint4*)gout, row_start, perm, (unsigned)N, rcpN, V, (uint4* const*)grads,    \
+                       rid_t, BN / N)
+#define TRS_FFMB_T(TT)                   \
+  switch (lg) {                          \
+    case 0: TRS_FFMB(TT, 0); break;      \
+    case 1: TRS_FFMB(TT, 1); break;      \
+    case 2: TRS_FFMB(TT, 2); break;      \
+    case 3: TRS_FFMB(TT, 3); break;      \
+    case 4: TRS_FFMB(TT, 4); break;      \
+    case 5: TRS_FFMB(TT, 5); break;      \
+    default: TRS_FFMB(TT, 6); break;     \
+  }
+    if (dtype == TRS_F32) {
+      TRS_FFMB_T(float)
+    } else {
+      TRS_FFMB_T(bf16_t)
+    }
+#undef TRS_FFMB_T
+#undef TRS_FFMB
+    return check_launch("ffm_fused_bwd");
+  }
   const int grid = stream_grid((int64_t)N * V * upr, 256, 256 * 32);
   if (vec && dtype == TRS_F32)
     hipLaunchKernelGGL((ffm_fused_bwd_kernel<float, uint4, IdxT>), dim3(grid), dim3(256), 0, s, (const uint4* const*)tables, idx, offsets, (const uint4*)gout, row_start, perm, N, upr, V, (uint4* const*)grads);
@@ -989,13 +1100,13 @@ static int ffm_fused_bwd_dispatch(const void* const* tables, int64_t V, int E, i
 extern "C" int trs_ffm_fused_bwd(const void* const* tables, int64_t V, int32_t E, int32_t dtype, const void* idx,
                                  int32_t idx_dtype, const int64_t* offsets, const void* gout,
                                  const int32_t* row_start, const int32_t* perm, int64_t B, int32_t N,
-                                 void* const* grad_tables, trs_stream_t stream) {
+                                 void* const* grad_tables, const int32_t* row_ids_t, trs_stream_t stream) {
   TRS_REQUIRE(tables && grad_tables && row_start, TRS_EINVAL, "ffm_fused_bwd: NULL pointer");
   TRS_REQUIRE(V > 0, TRS_EINVAL, "ffm_fused_bwd: bad V");
   TRS_CHECK_BNE("ffm_fused_bwd");
   TRS_REQUIRE(idx_dtype == TRS_I64 || idx_dtype == TRS_I32, TRS_EDTYPE, "ffm_fused_bwd: idx dtype %d", idx_dtype);
   TRS_REQUIRE(B == 0 || (idx && gout && perm), TRS_EINVAL, "ffm_fused_bwd: NULL pointer");
   if (idx_dtype == TRS_I64)
-    return ffm_fused_bwd_dispatch<int64_t>(tables, V, E, dtype, (const int64_t*)idx, offsets, gout, row_start, perm, N, grad_tables, (hipStream_t)stream);
-  return ffm_fused_bwd_dispatch<int32_t>(tables, V, E, dtype, (const int32_t*)idx, offsets, gout, row_start, perm, N, grad_tables, (hipStream_t)stream);
+    return ffm_fused_bwd_dispatch<int64_t>(tables, V, E, dtype, (const int64_t*)idx, offsets, gout, row_start, perm, N, grad_tables, (hipStream_t)stream, B * (int64_t)N, row_ids_t);
+  return ffm_fused_bwd_dispatch<int32_t>(tables, V, E, dtype, (const int32_t*)idx, offsets, gout, row_start, perm, N, grad_tables, (hipStream_t)stream, B * (int64_t)N, row_ids_t);
 }

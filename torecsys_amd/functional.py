@@ -1654,9 +1654,15 @@ class _FFMFused(Function):
         ws = [w.contiguous() for w in weights]
         rb = row_buckets(idx, offsets, V)
         grads = [torch.empty_like(w) for w in ws]
+        # the global row ids transposed to (N, B) int32: table i's walk reads ONE 4 B-per-sample column (cache-resident)
+        # instead of a random 8-byte load per lookup (9.5 -> see profiles/r05_kernels.md)
+        rid_t = None
+        if V < 2 ** 31 and B > 0:
+            rid = idx if offsets is None else idx + offsets
+            rid_t = rid.t().contiguous().to(torch.int32)
         call("trs_ffm_fused_bwd", ptr(_pointer_table(ws)), V, E, value_dtype_code(ws[0]), ptr(idx), index_dtype_code(idx),
              ptr(offsets), ptr(g.contiguous()), ptr(rb.row_start), ptr(rb.perm), B, N, ptr(_pointer_table(grads)),
-             stream_ptr())
+             ptr(rid_t), stream_ptr())
         return (None, None, *grads)
 
 
