@@ -189,6 +189,52 @@ __global__ __launch_bounds__(256) void fa_gather_vec_kernel(
   }
 }
 
+// The same for rows of a power of two of 16-byte units, round 5: a workgroup takes a sample at a time (its N row ids once
+// into LDS), lane groups of one row walk the N x N (table, field) items four in flight; rows of tables larger than the
+// caches (N tables of V rows: 5 GB at the BASELINE shape) come in by streaming loads.
+template <typename IdxT, int LOG2U, bool STREAM>
+__global__ __launch_bounds__(256) void fa_gather_rows_kernel(const uint4* const* __restrict__ tables,
+                                                             const IdxT* __restrict__ idx,
+                                                             const int64_t* __restrict__ offsets, uint4* __restrict__ out,
+                                                             int64_t B, int N, int64_t V, int32_t* __restrict__ err_flag) {
+  constexpr int U = 1 << LOG2U, G = 256 >> LOG2U, PIPE = 4;
+  extern __shared__ __attribute__((aligned(16))) char fa_lds[];
+  int64_t* rid = reinterpret_cast<int64_t*>(fa_lds);
+  const int lv = threadIdx.x & (U - 1), grp = threadIdx.x >> LOG2U;
+  const int NN = N * N;
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    __syncthreads();
+    for (int n = threadIdx.x; n < N; n += 256) {
+      int64_t r = load_row_id(idx, offsets, b * N + n, n);
+      if (r < 0 || r >= V) {
+        if (err_flag != nullptr) *err_flag = 1;
+        r = -1;
+      }
+      rid[n] = r;
+    }
+    __syncthreads();
+    uint4* ob = out + b * NN * U;
+    for (int t0 = grp; t0 < NN; t0 += G * PIPE) {
+      uint4 v[PIPE];
+#pragma unroll
+      for (int k = 0; k < PIPE; ++k) {
+        const int t = t0 + k * G;
+        v[k] = make_uint4(0, 0, 0, 0);
+        if (t < NN) {
+          const int i = t / N, j = t - i * N;
+          const int64_t r = rid[j];
+          if (r >= 0) v[k] = STREAM ? load_stream(&tables[i][r * U + lv]) : tables[i][r * U + lv];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < PIPE; ++k) {
+        const int t = t0 + k * G;
+        if (t < NN) store_stream(&ob[t * U + lv], v[k]);
+      }
+    }
+  }
+}
+
 template <typename T, typename IdxT>
 __global__ __launch_bounds__(256) void fa_gather_elem_kernel(
     const T* const* __restrict__ tables, const IdxT* __restrict__ idx, const int64_t* __restrict__ offsets,
@@ -482,6 +528,31 @@ static int fa_dispatch(const void* const* tables, int64_t V, int E, int dtype, c
   if (row_bytes % 16 == 0 && aligned16(out)) {
     const int vpr = row_bytes / 16;
     const int64_t total = B * N * N * vpr;
+    if (is_pow2(vpr) && vpr <= 64 && N <= 4096) {
+      int lg = 0;
+      while ((1 << lg) < vpr) ++lg;
+      const bool stream = (size_t)N * V * row_bytes > ((size_t)512 << 20);
+      const int grid = (int)std::min<int64_t>(B, 256 * 8);
+      const size_t lds = (size_t)N * 8;
+#define TRS_FAG(LG)                                                                                                     \
+  if (stream)                                                                                                           \
+    hipLaunchKernelGGL((fa_gather_rows_kernel<IdxT, LG, true>), dim3(grid), dim3(256), lds, s,                           \
+                       (const uint4* const*)tables, idx, offsets, (uint4*)out, B, N, V, err_flag);                      \
+  else                                                                                                                  \
+    hipLaunchKernelGGL((fa_gather_rows_kernel<IdxT, LG, false>), dim3(grid), dim3(256), lds, s,                          \
+                       (const uint4* const*)tables, idx, offsets, (uint4*)out, B, N, V, err_flag)
+      switch (lg) {
+        case 0: TRS_FAG(0); break;
+        case 1: TRS_FAG(1); break;
+        case 2: TRS_FAG(2); break;
+        case 3: TRS_FAG(3); break;
+        case 4: TRS_FAG(4); break;
+        case 5: TRS_FAG(5); break;
+        default: TRS_FAG(6); break;
+      }
+#undef TRS_FAG
+      return check_launch("fa_gather_rows");
+    }
     hipLaunchKernelGGL((fa_gather_vec_kernel<IdxT>), dim3(stream_grid(total, 256, 256 * 32)), dim3(256), 0, s,
                        (const uint4* const*)tables, idx, offsets, (uint4*)out, B, N, vpr, V, err_flag);
   } else if (dtype == TRS_F32) {
