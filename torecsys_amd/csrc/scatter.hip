@@ -23,14 +23,16 @@ namespace trs {
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 16;
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
-// rows with more than LONG_ROW lookups are reduced by a whole workgroup (Zipf-hot rows)
+// rows with more than LONG_ROW lookups go to a queue and are reduced by whole waves (Zipf-hot rows)
 constexpr int LONG_ROW = 64;
 // element path (rows that are not 16-byte multiples, e.g. the E = 1 first-order table): one THREAD walks a row's bucket,
 // so already moderately hot rows stall their wave; rows above this go to the queue and are reduced by whole waves
 constexpr int LONG_ROW_ELEM = 32;
 // very hot rows (a Zipf head row collects thousands of lookups) are cut into chunks of LONG_CHUNK lookups that
-// different workgroups reduce; a second pass adds the chunk partials of a row.  Queue entries are (row, chunk).
-constexpr int LONG_CHUNK = 1024;
+// different waves reduce; a second pass adds the chunk partials of a row.  Queue entries are (row, chunk).
+// 256 = four rounds of a wave at E = 64 bf16 (8 lane groups x 8 lookups in flight); measured on the Zipf(1.05) DeepFM
+// step, same box alternately: 1024 per workgroup 1.292 ms, 1024 per wave 1.294, 256 per wave 1.267, 128 per wave 1.276
+constexpr int LONG_CHUNK = 256;
 // element path (rows that are not whole 16-byte vectors, e.g. the E = 1 first-order table): a queued row is reduced by ONE
 // wave; rows with more than ELEM_SPLIT lookups (a 4-row field collects 16 384 of a 65 536-sample batch) are cut into
 // chunks of ELEM_SPLIT lookups, one wave each, whose partial sums meet in fp32 scratch (atomics) and are finished by a
@@ -501,7 +503,7 @@ __device__ __forceinline__ void sink_elem(const RowSink& k, T* __restrict__ out,
 
 // ---------------------------------------------------------------------------------------------
 // segmented reduction: one L-lane group per table row (rows with > LONG_ROW lookups are deferred
-// to a queue and reduced by whole workgroups afterwards)
+// to a queue and reduced by whole waves afterwards)
 // HAS_F1: a companion E = 1 table (the first-order term of the same lookups) rides in the same walk: g_first holds one
 // value per lookup (B*N), every lane of the group adds the same ones into *f1
 // Where the FM term of a lookup of sample b is read from (16-byte vectors, table dtype): t[b*tstr + lane] = g*S and
@@ -779,7 +781,10 @@ __global__ __launch_bounds__(256) void scatter_first_long_kernel(const T* __rest
   }
 }
 
-// hot rows: one 256-thread workgroup per (row, chunk) queue entry, groups stride over the chunk, LDS tree reduction.
+// hot rows: one WAVE per (row, chunk) queue entry -- its 64 / L lane groups stride over the chunk with eight lookups in
+// flight each, then the groups' partial sums are folded by shuffles: no LDS, no barrier.  (Round 5: the entry used to
+// belong to a whole 256-thread workgroup with an LDS tree and six barriers; on Zipf(1.05) indices most queue entries are
+// rows of 65 ... 300 lookups, for which 7 of its 8 lane-group rounds had nothing to do -- 92 us at the end of the step.)
 // Rows of a single chunk are finished here; otherwise the chunk's partial sums go to scratch[entry][2][E] (fp32)
 // and scatter_long_rows_finish_kernel adds the chunks of the row.
 template <typename T, int LOG2L, bool HAS_G, bool HAS_FM, bool SCAL = false>
@@ -790,12 +795,13 @@ __global__ __launch_bounds__(256) void scatter_long_rows_kernel(
     RowSink sink, FmSrc fs) {
   constexpr int L = 1 << LOG2L;
   constexpr int VE = Vec16<T>::VE;
-  constexpr int G = 256 / L;  // groups per workgroup
-  __shared__ float red[2][256][VE];
-  const int lane_v = threadIdx.x & (L - 1);
-  const int grp = threadIdx.x >> LOG2L;
+  constexpr int G = 64 / L;  // lane groups per wave
+  const int lane = threadIdx.x & 63;
+  const int lane_v = lane & (L - 1);
+  const int grp = lane >> LOG2L;
   const int nlong = long_rows[0];
-  for (int i = blockIdx.x; i < nlong; i += gridDim.x) {
+  const int waves = gridDim.x * (blockDim.x >> 6);
+  for (int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < nlong; i += waves) {
     const int64_t r = long_rows[1 + 2 * i];
     const int c = long_rows[2 + 2 * i];
     const int rbeg = row_start[r], rend = row_start[r + 1];
@@ -807,21 +813,17 @@ __global__ __launch_bounds__(256) void scatter_long_rows_kernel(
     accumulate_bucket<T, LOG2L, HAS_G, HAS_FM, 8, false, SCAL>(acc, gsum, g_rows, g_fm, fm_sum, perm, beg + grp, end, G, N, gbs,
                                                                lane_v, fs);
 #pragma unroll
-    for (int k = 0; k < VE; ++k) { red[0][threadIdx.x][k] = acc[k]; red[1][threadIdx.x][k] = gsum[SCAL ? 0 : k]; }
-    __syncthreads();
-    for (int h = G >> 1; h >= 1; h >>= 1) {
-      if (grp < h) {
+    for (int m = L; m < 64; m <<= 1) {
 #pragma unroll
-        for (int k = 0; k < VE; ++k) {
-          red[0][threadIdx.x][k] += red[0][threadIdx.x + h * L][k];
-          red[1][threadIdx.x][k] += red[1][threadIdx.x + h * L][k];
-        }
-      }
-      __syncthreads();
+      for (int k = 0; k < VE; ++k) acc[k] += __shfl_xor(acc[k], m, 64);
+#pragma unroll
+      for (int k = 0; k < (SCAL ? 1 : VE); ++k) gsum[k] += __shfl_xor(gsum[k], m, 64);
+    }
+    if (SCAL) {
+#pragma unroll
+      for (int k = 1; k < VE; ++k) gsum[k] = gsum[0];
     }
     if (grp == 0) {
-#pragma unroll
-      for (int k = 0; k < VE; ++k) { acc[k] = red[0][threadIdx.x][k]; gsum[k] = red[1][threadIdx.x][k]; }
       if (single) {
         if (HAS_FM && fm_sum != nullptr) {
           float w[VE];
@@ -836,7 +838,6 @@ __global__ __launch_bounds__(256) void scatter_long_rows_kernel(
         for (int k = 0; k < VE; ++k) { sa[k] = acc[k]; sa[L * VE + k] = gsum[k]; }
       }
     }
-    __syncthreads();
   }
 }
 
@@ -1109,7 +1110,7 @@ static void scatter_group_launch(const void* g_rows, const void* g_fm, const flo
   const bool hg = g_rows != nullptr, hf = g_fm != nullptr;
 #define TRS_SC_TAIL(HG, HF, SC)                                                                                 \
   do {                                                                                                          \
-    hipLaunchKernelGGL((scatter_long_rows_kernel<T, LOG2L, HG, HF, SC>), dim3(1024), dim3(256), 0, s,            \
+    hipLaunchKernelGGL((scatter_long_rows_kernel<T, LOG2L, HG, HF, SC>), dim3(2048), dim3(256), 0, s,            \
                        (const uint4*)g_rows, (const uint4*)g_fm, fm_sum, (const uint4*)table, row_start, perm, N, \
                        gbs, (uint4*)grad, long_rows, scratch, sink, fs);                                              \
     hipLaunchKernelGGL((scatter_long_rows_finish_kernel<T, LOG2L, HF>), dim3(64), dim3(256), 0, s, fm_sum,           \
