@@ -134,7 +134,9 @@ def test_mlp_logit_layer_uses_rowdot(dev):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("S,R,Cc,out_rows,out_cols,with_bias", [
     (32, 512, 2496, 400, 2496, True), (8, 512, 512, 400, 400, True), (4, 64, 96, 64, 96, False),
-    (5, 128, 40, 100, 33, True), (1, 16, 300, 16, 300, True)])
+    (5, 128, 40, 100, 33, True), (1, 16, 300, 16, 300, True),
+    # few rows, many splits (the 400 -> 1 head at 65 536 rows): the kernel with 16 threads per column
+    (256, 8, 400, 1, 400, True), (70, 8, 33, 3, 33, True), (64, 8, 1000, 8, 999, False)])
 def test_wgrad_finish_matches_torch(dev, dtype, S, R, Cc, out_rows, out_cols, with_bias):
     """trs_wgrad_finish = part.sum(0)[:out_rows, :out_cols].to(dtype) (+ the bias-gradient cast) in one launch"""
     from torecsys_amd import _abi

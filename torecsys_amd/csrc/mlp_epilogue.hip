@@ -281,6 +281,48 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restri
   gw[(size_t)r * out_cols + c] = from_f32<T>((a0 + a1) + (a2 + a3));
 }
 
+// The finish of a layer with FEW output rows and MANY splits (the 400 -> 1 head at 65 536 rows: 256 partial products of
+// 8 x 400): one thread per column would walk the 256 partials in 64 dependent rounds inside two workgroups (20.8 us
+// for 3.3 MB).  Here a column belongs to 16 threads, each adds every 16th partial, the 16 sums meet in LDS.  Bias row as
+// above.  The sum of a column is taken in another order than wgrad_finish_kernel's (fp32, then one rounding to T).
+constexpr int WF_SL = 16;            // threads per column
+constexpr int WF_COLS = 256 / WF_SL; // columns per workgroup
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_finish_few_rows_kernel(const float* __restrict__ part, int S, int R, int Cc,
+                                                                   int out_rows, int out_cols, T* __restrict__ gw,
+                                                                   const float* __restrict__ gbf, T* __restrict__ gb) {
+  __shared__ float red[WF_SL][WF_COLS + 1];
+  if ((int)blockIdx.y == out_rows) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (gb != nullptr && c < out_rows) gb[c] = from_f32<T>(gbf[c]);
+    return;
+  }
+  const int cl = threadIdx.x % WF_COLS, sl = threadIdx.x / WF_COLS;
+  const int c = blockIdx.x * WF_COLS + cl;
+  const int r = blockIdx.y;
+  const size_t stride = (size_t)R * Cc;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < out_cols) {
+    const float* p = part + (size_t)r * Cc + c;
+    int s = sl;
+    for (; s + 3 * WF_SL < S; s += 4 * WF_SL) {
+      a0 += p[(size_t)s * stride];
+      a1 += p[(size_t)(s + WF_SL) * stride];
+      a2 += p[(size_t)(s + 2 * WF_SL) * stride];
+      a3 += p[(size_t)(s + 3 * WF_SL) * stride];
+    }
+    for (; s < S; s += WF_SL) a0 += p[(size_t)s * stride];
+  }
+  red[sl][cl] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (sl == 0 && c < out_cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < WF_SL; ++k) t += red[k][cl];
+    gw[(size_t)r * out_cols + c] = from_f32<T>(t);
+  }
+}
+
 // The same finish for partial products stored TRANSPOSED, part (S, Cc, R) = slices of x^T g: for a wide input layer
 // (2496 x 512) hipBLASLt runs that orientation 1.5x faster than g^T x.  32 x 32 tiles through LDS so that both the
 // reads (along r) and the writes (along c) are coalesced.
@@ -430,6 +472,16 @@ extern "C" int trs_wgrad_finish(const float* part, int32_t S, int32_t R, int32_t
               "wgrad_finish: out_rows %d exceeds the bias row of workgroups", out_rows);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((out_cols + 255) / 256, out_rows + 1);
+  if (S >= 4 * WF_SL && (int64_t)grid.x * out_rows < 64) {      // few rows, many splits: 16 threads per column
+    dim3 gridf((out_cols + WF_COLS - 1) / WF_COLS, out_rows + 1);
+    if (dtype == TRS_F32)
+      hipLaunchKernelGGL((wgrad_finish_few_rows_kernel<float>), gridf, dim3(256), 0, s, part, S, R, Cc, out_rows, out_cols,
+                         (float*)gw, gb_f32, (float*)gb);
+    else
+      hipLaunchKernelGGL((wgrad_finish_few_rows_kernel<bf16_t>), gridf, dim3(256), 0, s, part, S, R, Cc, out_rows, out_cols,
+                         (bf16_t*)gw, gb_f32, (bf16_t*)gb);
+    return check_launch("wgrad_finish");
+  }
   if (dtype == TRS_F32)
     hipLaunchKernelGGL((wgrad_finish_kernel<float>), grid, dim3(256), 0, s, part, S, R, Cc, out_rows, out_cols,
                        (float*)gw, gb_f32, (float*)gb);
