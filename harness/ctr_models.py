@@ -97,10 +97,12 @@ class DeepAndCrossNetworkModel(nn.Module):
     def forward(self, emb_inputs: torch.Tensor) -> torch.Tensor:
         crossed = _plain(self.cross(emb_inputs))            # (B, N, E)
         per_field = _plain(self.deep(emb_inputs))           # (B, N, Od): the MLP runs on every field's row
+        if _fused_head(crossed) and self.fc.out_features == 1 and F_.cat_head_supported(crossed, per_field, self.fc.weight):
+            # the one-output Linear read from the two blocks where they lie: no 0.65 GB concatenation, no slice copies of
+            # its gradient (F_.cat_head; TRS_FUSED_HEAD=0 restores the composition below)
+            return F_.cat_head(crossed, per_field, self.fc.weight, self.fc.bias)
         both = torch.cat((crossed, per_field), dim=2)       # field-major [cross | deep] rows, as the head expects
-        return self.fc(both.reshape(both.shape[0], -1))     # (a head split over the two blocks would save the 0.65 GB
-                                                            # concatenation -- 0.6 ms at the bench size -- but the callers
-                                                            # stay the reference's compositions)
+        return self.fc(both.reshape(both.shape[0], -1))
 
 
 class XDeepFactorizationMachineModel(nn.Module):

@@ -437,6 +437,20 @@ size_t trs_rowdot_bwd_workspace_bytes(int64_t rows, int32_t C);
 int trs_rowdot_bwd(const void* g, const void* h, const void* w, int64_t rows, int32_t C, int32_t dtype, void* gh,
                    float* gw, float* gb, void* workspace, size_t ws_bytes, trs_stream_t stream);
 
+/* ---- one-output Linear over the concatenation of two blocks, without the concatenation -----------------------------
+ * The head of deep_and_cross_network.py:82-92: torch.cat([cross_out, deep_out], dim='O') -> flatten(('N','O'),'O') ->
+ * nn.Linear(cat_size, 1).  a (rows, N, Ea), d (rows, N, Eb) contiguous, w (N * (Ea + Eb)) in the Linear's own order
+ * (field-major [a_f | d_f]), bias (1) or NULL:
+ *   out[r] = sum_f  a[r,f,:] . w[f*(Ea+Eb) : +Ea]  +  d[r,f,:] . w[f*(Ea+Eb)+Ea : +Eb]  + bias[0]
+ * bwd: ga = g[r] * (a's part of w), gd = g[r] * (d's part) (either may be NULL); gw (N*(Ea+Eb)) and gb (1) fp32,
+ * written (both or neither).  Ea, Eb whole 16-byte vectors; N * (Ea + Eb) * sizeof(T) / 16 <= 1024.               */
+int trs_cat_head_fwd(const void* a, const void* d, const void* w, const void* bias, int64_t rows, int32_t N, int32_t Ea,
+                     int32_t Eb, int32_t dtype, void* out, trs_stream_t stream);
+size_t trs_cat_head_bwd_workspace_bytes(int64_t rows, int32_t N, int32_t Ea, int32_t Eb);
+int trs_cat_head_bwd(const void* g, const void* a, const void* d, const void* w, int64_t rows, int32_t N, int32_t Ea,
+                     int32_t Eb, int32_t dtype, void* ga, void* gd, float* gw, float* gb, void* workspace,
+                     size_t ws_bytes, trs_stream_t stream);
+
 /* ---- finish of a split-K weight gradient (the K = batch GEMM of multilayer_perceptron.py's nn.Linear backward) -----
  * part (S, R, Cc) fp32 partial products  ->  gw (out_rows, out_cols) = sum_s part[s, :out_rows, :out_cols] cast to
  * dtype (the un-padded corner when the GEMMs ran on zero-padded weights); gb (out_rows) = cast(gb_f32) (both or

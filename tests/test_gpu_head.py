@@ -142,3 +142,66 @@ def test_deepfm_step_with_fused_head_and_loss_matches_unfused(dev, monkeypatch):
     assert abs(res[0][0] - res[1][0]) <= 1e-5 * abs(res[0][0])
     for a, b in zip(res[0][1], res[1][1]):
         assert rel_err(b.cpu(), a.cpu()) <= 1e-5
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 1e-2)])
+@pytest.mark.parametrize("B,N,Ea,Eb", [(257, 39, 64, 64), (1, 1, 8, 8), (1000, 10, 16, 64), (33, 5, 24, 8), (4096, 39, 64, 64),
+                                       (70000, 3, 128, 32), (5, 16, 256, 256)])
+def test_cat_head_vs_the_concatenated_linear(dev, dtype, tol, B, N, Ea, Eb):
+    """F_.cat_head = nn.Linear(N*(Ea+Eb), 1) on cat((a, d), dim=2).flatten(1) (deep_and_cross_network.py:82-92): output
+    and the gradients of both blocks, the weight row and the bias, against the composition in fp32 on the same (rounded)
+    operands.  The block gradients are g[r] * w rounded once: equal to the composition's bit for bit in fp32."""
+    from torecsys_amd import functional as F_
+    g = torch.Generator().manual_seed(B + N + Ea + Eb)
+    C = N * (Ea + Eb)
+    a = torch.randn(B, N, Ea, generator=g).to(dtype)
+    d = torch.randn(B, N, Eb, generator=g).to(dtype)
+    w = (torch.randn(1, C, generator=g) / C ** 0.5).to(dtype)
+    b = torch.randn(1, generator=g).to(dtype)
+    go = torch.randn(B, 1, generator=g).to(dtype)
+    da, dd, dw, db = (t.to(dev).clone().requires_grad_() for t in (a, d, w, b))
+    if C * a.element_size() // 16 > 1024:       # more 16-byte vectors per sample than a wave's lanes hold (fp32, 39 x 128)
+        assert not F_.cat_head_supported(da, dd, dw)
+        with pytest.raises(RuntimeError):
+            F_.cat_head(da, dd, dw, db)
+        return
+    assert F_.cat_head_supported(da, dd, dw)
+    out = F_.cat_head(da, dd, dw, db)
+    out.backward(go.to(dev))
+    ra, rd, rw, rb = (t.float().clone().requires_grad_() for t in (a, d, w, b))
+    ref = torch.nn.functional.linear(torch.cat((ra, rd), dim=2).reshape(B, -1), rw, rb)
+    ref.backward(go.float())
+    assert out.shape == (B, 1) and out.dtype == dtype
+    assert rel_err(out.float().cpu(), ref.detach()) <= tol
+    assert rel_err(da.grad.float().cpu(), ra.grad) <= tol
+    assert rel_err(dd.grad.float().cpu(), rd.grad) <= tol
+    assert rel_err(dw.grad.float().cpu(), rw.grad) <= tol
+    assert rel_err(db.grad.float().cpu(), rb.grad) <= tol
+    if dtype == torch.float32:
+        assert torch.equal(da.grad.cpu(), ra.grad) and torch.equal(dd.grad.cpu(), rd.grad)
+
+
+def test_cat_head_partial_gradients_and_rejections(dev):
+    """only the blocks' gradients (frozen head), only the head's (detached blocks); shapes the kernel does not take are
+    reported by cat_head_supported and refused by the C entry point"""
+    from torecsys_amd import _abi, functional as F_
+    torch.manual_seed(3)
+    a = torch.randn(64, 7, 16, device=dev)
+    d = torch.randn(64, 7, 8, device=dev)
+    w = torch.randn(1, 7 * 24, device=dev)
+    b = torch.randn(1, device=dev)
+    go = torch.randn(64, 1, device=dev)
+    a1, d1 = a.clone().requires_grad_(), d.clone().requires_grad_()
+    F_.cat_head(a1, d1, w, b).backward(go)
+    wa = w.view(7, 24)[:, :16].reshape(1, 7, 16)
+    assert torch.equal(a1.grad, go.view(64, 1, 1) * wa)
+    w2, b2 = w.clone().requires_grad_(), b.clone().requires_grad_()
+    F_.cat_head(a, d, w2, b2).backward(go)
+    ref_w = (go.view(64, 1) * torch.cat((a, d), 2).reshape(64, -1)).sum(0, keepdim=True)
+    assert rel_err(w2.grad.cpu(), ref_w.cpu()) <= 1e-5 and rel_err(b2.grad.cpu(), go.sum().view(1).cpu()) <= 1e-5
+    assert not F_.cat_head_supported(a[:, :, :6], d, w)                      # 24-byte rows
+    assert not F_.cat_head_supported(a, d, w[:, :-1])
+    out = torch.empty(64, 1, device=dev)
+    with pytest.raises(RuntimeError):
+        _abi.call("trs_cat_head_fwd", _abi.ptr(a), _abi.ptr(d), _abi.ptr(w), _abi.ptr(b), 64, 7, 6, 8, 0, _abi.ptr(out),
+                  _abi.stream_ptr())

@@ -426,6 +426,247 @@ extern "C" int trs_rowdot_bwd(const void* g, const void* h, const void* w, int64
   return check_launch("rowdot_bwd");
 }
 
+// ------------------------------------------------------------------------------------------------
+// One-output Linear over the concatenation of two blocks, without the concatenation (the head of
+// deep_and_cross_network.py:82-92: torch.cat([cross_out, deep_out], dim='O') -> flatten(('N','O')) -> nn.Linear(cat, 1)).
+// A row of the virtual concatenation is VA + VD 16-byte vectors (a's N*Ea values, then d's N*Eb); lane l of a wave owns
+// the vectors l, l + 64, ... of every row its wave walks, so the weights it needs (w is field-major [a_f | d_f]) are
+// per-lane constants and stay in registers, packed.  One wave per row: 10 loads of 16 B in flight per lane at
+// 39 x (64 + 64) bf16.  HBM-bound: 2 x 327 MB read (forward), the same read plus 2 x 327 MB written (backward) at
+// 65 536 rows -- against cat (654 MB read + written), a 4992-wide GEMV, its two backward GEMMs (654 MB written, 654 MB
+// read), two slice copies and the add of the block gradient in the composition.
+namespace trs {
+struct CatHeadShape {
+  int VA, VD;            // vectors per row of a / d
+  int va_pf, vd_pf;      // vectors per field
+  int wstride, Ea;       // elements: Ea + Eb, Ea
+};
+// element offset into w of virtual vector j (j < VA + VD)
+__device__ __forceinline__ int cat_head_woff(const CatHeadShape& sh, int j, int VE) {
+  if (j < sh.VA) {
+    const int f = j / sh.va_pf;
+    return f * sh.wstride + (j - f * sh.va_pf) * VE;
+  }
+  const int jj = j - sh.VA;
+  const int f = jj / sh.vd_pf;
+  return f * sh.wstride + sh.Ea + (jj - f * sh.vd_pf) * VE;
+}
+
+template <typename T, int ITERS>
+__global__ __launch_bounds__(256) void cat_head_fwd_kernel(const uint4* __restrict__ a, const uint4* __restrict__ d,
+                                                           const T* __restrict__ w, const T* __restrict__ bias,
+                                                           int64_t rows, CatHeadShape sh, T* __restrict__ out) {
+  constexpr int VE = Vec16<T>::VE;
+  const int lane = threadIdx.x & 63;
+  const int VT = sh.VA + sh.VD;
+  uint4 wp[ITERS];
+#pragma unroll
+  for (int i = 0; i < ITERS; ++i) {
+    const int j = lane + 64 * i;
+    wp[i] = j < VT ? *reinterpret_cast<const uint4*>(w + cat_head_woff(sh, j, VE)) : make_uint4(0, 0, 0, 0);
+  }
+  const float b0 = bias != nullptr ? to_f32(bias[0]) : 0.f;
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += nw) {
+    uint4 raw[ITERS];
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+      const int j = lane + 64 * i;
+      raw[i] = make_uint4(0, 0, 0, 0);
+      if (j < sh.VA) raw[i] = load_stream(&a[r * sh.VA + j]);
+      else if (j < VT) raw[i] = load_stream(&d[r * sh.VD + (j - sh.VA)]);
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+      float x[VE], wv[VE];
+      Vec16<T>::unpack(raw[i], x);
+      Vec16<T>::unpack(wp[i], wv);
+#pragma unroll
+      for (int k = 0; k < VE; ++k) acc = fmaf(x[k], wv[k], acc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) out[r] = from_f32<T>(acc + b0);
+  }
+}
+
+// ga[r,:] = g[r] * w_a, gd[r,:] = g[r] * w_d;  partial[blk][c] = sum over the workgroup's rows of g[r] * cat[r,c] in w's
+// order, partial[blk][C] = sum g[r]
+template <typename T, int ITERS>
+__global__ __launch_bounds__(256) void cat_head_bwd_kernel(const T* __restrict__ g, const uint4* __restrict__ a,
+                                                           const uint4* __restrict__ d, const T* __restrict__ w,
+                                                           int64_t rows, CatHeadShape sh, uint4* __restrict__ ga,
+                                                           uint4* __restrict__ gd, float* __restrict__ partial) {
+  constexpr int VE = Vec16<T>::VE;
+  __shared__ float red[ITERS * 64 * VE + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int VT = sh.VA + sh.VD;
+  const int C = VT * VE;
+  uint4 wp[ITERS];
+  float acc[ITERS][VE];
+  float gsum = 0.f;
+#pragma unroll
+  for (int i = 0; i < ITERS; ++i) {
+    const int j = lane + 64 * i;
+    wp[i] = j < VT ? *reinterpret_cast<const uint4*>(w + cat_head_woff(sh, j, VE)) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < VE; ++k) acc[i][k] = 0.f;
+  }
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < rows; r += nw) {
+    const float gr = to_f32(g[r]);
+    gsum += gr;
+    uint4 raw[ITERS];
+    if (partial != nullptr) {
+#pragma unroll
+      for (int i = 0; i < ITERS; ++i) {
+        const int j = lane + 64 * i;
+        raw[i] = make_uint4(0, 0, 0, 0);
+        if (j < sh.VA) raw[i] = load_stream(&a[r * sh.VA + j]);
+        else if (j < VT) raw[i] = load_stream(&d[r * sh.VD + (j - sh.VA)]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+      const int j = lane + 64 * i;
+      float wv[VE], o[VE];
+      Vec16<T>::unpack(wp[i], wv);
+#pragma unroll
+      for (int k = 0; k < VE; ++k) o[k] = gr * wv[k];
+      if (j < sh.VA) {
+        if (ga != nullptr) ga[r * sh.VA + j] = Vec16<T>::pack(o);
+      } else if (j < VT) {
+        if (gd != nullptr) gd[r * sh.VD + (j - sh.VA)] = Vec16<T>::pack(o);
+      }
+      if (partial != nullptr) {
+        float x[VE];
+        Vec16<T>::unpack(raw[i], x);
+#pragma unroll
+        for (int k = 0; k < VE; ++k) acc[i][k] = fmaf(gr, x[k], acc[i][k]);
+      }
+    }
+  }
+  if (partial == nullptr) return;
+  // the four waves add their sums into LDS one after the other (20 KB instead of four images)
+  for (int wv_ = 0; wv_ < 4; ++wv_) {
+    if (wave == wv_) {
+#pragma unroll
+      for (int i = 0; i < ITERS; ++i) {
+#pragma unroll
+        for (int k = 0; k < VE; ++k) {
+          float* p = &red[((i * 64 + lane) * VE) + k];
+          *p = wv_ == 0 ? acc[i][k] : *p + acc[i][k];
+        }
+      }
+      if (lane == 0) red[ITERS * 64 * VE] = wv_ == 0 ? gsum : red[ITERS * 64 * VE] + gsum;
+    }
+    __syncthreads();
+  }
+  float* mine = partial + (size_t)blockIdx.x * (C + 1);
+  for (int e = threadIdx.x; e < C; e += 256) {
+    const int j = e / VE, k = e - j * VE;
+    mine[cat_head_woff(sh, j, VE) + k] = red[e];        // red is indexed by (virtual vector j, k): j = lane + 64 i
+  }
+  if (threadIdx.x == 0) mine[C] = red[ITERS * 64 * VE];
+}
+
+static bool cat_head_shape(int N, int Ea, int Eb, int dtype, CatHeadShape* sh) {
+  const int ve = dtype == TRS_F32 ? 4 : 8;
+  if (N <= 0 || Ea <= 0 || Eb <= 0 || Ea % ve != 0 || Eb % ve != 0) return false;
+  sh->va_pf = Ea / ve;
+  sh->vd_pf = Eb / ve;
+  sh->VA = N * sh->va_pf;
+  sh->VD = N * sh->vd_pf;
+  sh->wstride = Ea + Eb;
+  sh->Ea = Ea;
+  return sh->VA + sh->VD <= 64 * 16;
+}
+static int cat_head_blocks(int64_t rows) { return (int)std::min<int64_t>((rows + 3) / 4, 512); }
+
+template <typename T, int ITERS>
+static void cat_head_launch_fwd(const void* a, const void* d, const void* w, const void* bias, int64_t rows,
+                                const CatHeadShape& sh, void* out, hipStream_t s) {
+  hipLaunchKernelGGL((cat_head_fwd_kernel<T, ITERS>), dim3((int)std::min<int64_t>((rows + 3) / 4, 4096)), dim3(256), 0, s,
+                     (const uint4*)a, (const uint4*)d, (const T*)w, (const T*)bias, rows, sh, (T*)out);
+}
+template <typename T, int ITERS>
+static void cat_head_launch_bwd(const void* g, const void* a, const void* d, const void* w, int64_t rows,
+                                const CatHeadShape& sh, void* ga, void* gd, float* part, hipStream_t s) {
+  hipLaunchKernelGGL((cat_head_bwd_kernel<T, ITERS>), dim3(cat_head_blocks(rows)), dim3(256), 0, s, (const T*)g,
+                     (const uint4*)a, (const uint4*)d, (const T*)w, rows, sh, (uint4*)ga, (uint4*)gd, part);
+}
+}  // namespace trs
+
+// ITERS = vectors per lane: 2 / 4 / 6 / 8 / 10 / 12 / 16 cover up to 1024 vectors per row (10: 39 x (64 + 64) bf16)
+#define TRS_CAT_HEAD_DISPATCH(T, FN, ...)                                            \
+  do {                                                                               \
+    const int it = (sh.VA + sh.VD + 63) / 64;                                        \
+    if (it <= 2) FN<T, 2>(__VA_ARGS__);                                              \
+    else if (it <= 4) FN<T, 4>(__VA_ARGS__);                                         \
+    else if (it <= 6) FN<T, 6>(__VA_ARGS__);                                         \
+    else if (it <= 8) FN<T, 8>(__VA_ARGS__);                                         \
+    else if (it <= 10) FN<T, 10>(__VA_ARGS__);                                       \
+    else if (it <= 12) FN<T, 12>(__VA_ARGS__);                                       \
+    else FN<T, 16>(__VA_ARGS__);                                                     \
+  } while (0)
+
+extern "C" int trs_cat_head_fwd(const void* a, const void* d, const void* w, const void* bias, int64_t rows, int32_t N,
+                                int32_t Ea, int32_t Eb, int32_t dtype, void* out, trs_stream_t stream) {
+  TRS_REQUIRE(rows >= 0, TRS_EINVAL, "cat_head_fwd: bad size");
+  TRS_REQUIRE(dtype == TRS_F32 || dtype == TRS_BF16, TRS_EDTYPE, "cat_head_fwd: dtype %d", dtype);
+  CatHeadShape sh;
+  TRS_REQUIRE(cat_head_shape(N, Ea, Eb, dtype, &sh), TRS_ESHAPE,
+              "cat_head_fwd: N = %d, Ea = %d, Eb = %d (rows of whole 16-byte vectors, at most 1024 per sample)", N, Ea, Eb);
+  if (rows == 0) return TRS_OK;
+  TRS_REQUIRE(a && d && w && out, TRS_EINVAL, "cat_head_fwd: NULL pointer");
+  TRS_REQUIRE(aligned16(a) && aligned16(d) && aligned16(w), TRS_EALIGN, "cat_head_fwd: 16-byte alignment");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == TRS_F32) TRS_CAT_HEAD_DISPATCH(float, cat_head_launch_fwd, a, d, w, bias, rows, sh, out, s);
+  else TRS_CAT_HEAD_DISPATCH(bf16_t, cat_head_launch_fwd, a, d, w, bias, rows, sh, out, s);
+  return check_launch("cat_head_fwd");
+}
+
+extern "C" size_t trs_cat_head_bwd_workspace_bytes(int64_t rows, int32_t N, int32_t Ea, int32_t Eb) {
+  (void)rows;
+  return (size_t)513 * ((size_t)N * (Ea + Eb) + 1) * 4 + 256;
+}
+
+extern "C" int trs_cat_head_bwd(const void* g, const void* a, const void* d, const void* w, int64_t rows, int32_t N,
+                                int32_t Ea, int32_t Eb, int32_t dtype, void* ga, void* gd, float* gw, float* gb,
+                                void* workspace, size_t ws_bytes, trs_stream_t stream) {
+  TRS_REQUIRE(rows >= 0, TRS_EINVAL, "cat_head_bwd: bad size");
+  TRS_REQUIRE(dtype == TRS_F32 || dtype == TRS_BF16, TRS_EDTYPE, "cat_head_bwd: dtype %d", dtype);
+  TRS_REQUIRE((gw == nullptr) == (gb == nullptr), TRS_EINVAL, "cat_head_bwd: gw and gb go together");
+  CatHeadShape sh;
+  TRS_REQUIRE(cat_head_shape(N, Ea, Eb, dtype, &sh), TRS_ESHAPE,
+              "cat_head_bwd: N = %d, Ea = %d, Eb = %d (rows of whole 16-byte vectors, at most 1024 per sample)", N, Ea, Eb);
+  const int C = N * (Ea + Eb);
+  hipStream_t s = (hipStream_t)stream;
+  if (rows == 0) {
+    if (gw != nullptr) {
+      if (int rc = zero_bytes(gw, (size_t)C * 4, s)) return rc;
+      return zero_bytes(gb, 4, s);
+    }
+    return TRS_OK;
+  }
+  TRS_REQUIRE(g && w && (gw == nullptr || (a && d)), TRS_EINVAL, "cat_head_bwd: NULL pointer");
+  TRS_REQUIRE(aligned16(a) && aligned16(d) && aligned16(w) && aligned16(ga) && aligned16(gd), TRS_EALIGN,
+              "cat_head_bwd: 16-byte alignment");
+  TRS_REQUIRE(gw == nullptr || (workspace != nullptr && ws_bytes >= trs_cat_head_bwd_workspace_bytes(rows, N, Ea, Eb)),
+              TRS_EWORKSPACE, "cat_head_bwd: workspace too small");
+  float* part = gw != nullptr ? (float*)workspace : nullptr;
+  if (dtype == TRS_F32) TRS_CAT_HEAD_DISPATCH(float, cat_head_launch_bwd, g, a, d, w, rows, sh, ga, gd, part, s);
+  else TRS_CAT_HEAD_DISPATCH(bf16_t, cat_head_launch_bwd, g, a, d, w, rows, sh, ga, gd, part, s);
+  if (gw != nullptr) {
+    const int grid = cat_head_blocks(rows);
+    float* tmp = part + (size_t)grid * (C + 1);
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3((C + 1 + 15) / 16), dim3(256), 0, s, part, grid, C + 1, tmp);
+    hipLaunchKernelGGL(rowdot_finish_kernel, dim3((C + 1 + 255) / 256), dim3(256), 0, s, tmp, C, gw, gb);
+  }
+  return check_launch("cat_head_bwd");
+}
+
 extern "C" size_t trs_relu_bwd_bias_workspace_bytes(int64_t rows, int32_t C) {
   (void)rows;
   return (size_t)2048 * C * 4 + 256;

@@ -1725,6 +1725,66 @@ class _RowDot(Function):
         return (gh.reshape(hshape) if need_h else None), g_weight, g_bias, None, None
 
 
+def cat_head_supported(a: torch.Tensor, d: torch.Tensor, weight: torch.Tensor) -> bool:
+    """one-output Linear over cat((a, d), dim=2).flatten(1) as one pass over the two blocks (trs_cat_head_fwd / _bwd):
+    (B, N, Ea) and (B, N, Eb) HIP tensors of one dtype (bf16 / fp32) with rows of whole 16-byte vectors, at most 1024
+    vectors per sample, weight (1, N * (Ea + Eb))"""
+    if not (a.is_cuda and d.is_cuda and a.dim() == 3 and d.dim() == 3 and a.shape[:2] == d.shape[:2]
+            and a.dtype == d.dtype == weight.dtype and a.dtype in (torch.float32, torch.bfloat16)):
+        return False
+    N, Ea, Eb = a.shape[1], a.shape[2], d.shape[2]
+    ve = 16 // a.element_size()
+    return (Ea % ve == 0 and Eb % ve == 0 and N * (Ea + Eb) // ve <= 1024
+            and tuple(weight.shape) == (1, N * (Ea + Eb)))
+
+
+class _CatHead(Function):
+    """out (B, 1) = cat((a, d), dim=2).flatten(1) @ weight (1, N*(Ea+Eb))^T + bias: the head of the reference's
+    DeepAndCrossNetworkModel (deep_and_cross_network.py:82-92) without the (B, N, Ea+Eb) concatenation, its slice
+    copies in the backward and the 4992-wide GEMV / GEMMs around them."""
+
+    @staticmethod
+    def forward(ctx, a, d, weight, bias):
+        a, d = a.contiguous(), d.contiguous()
+        W = weight.reshape(-1).contiguous()
+        B, N, Ea = a.shape
+        Eb = d.shape[2]
+        out = torch.empty(B, 1, dtype=a.dtype, device=a.device)
+        call("trs_cat_head_fwd", ptr(a), ptr(d), ptr(W), ptr(bias), B, N, Ea, Eb, value_dtype_code(a), ptr(out),
+             stream_ptr())
+        ctx.save_for_backward(a, d, W)
+        ctx.meta = (tuple(weight.shape), bias is not None)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        a, d, W = ctx.saved_tensors
+        wshape, has_bias = ctx.meta
+        B, N, Ea = a.shape
+        Eb = d.shape[2]
+        C = N * (Ea + Eb)
+        g2 = g.reshape(-1).contiguous()
+        need_a, need_d = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_w = ctx.needs_input_grad[2] or (has_bias and ctx.needs_input_grad[3])
+        ga = torch.empty_like(a) if need_a else None
+        gd = torch.empty_like(d) if need_d else None
+        gw = torch.empty(C + 1, dtype=torch.float32, device=a.device) if need_w else None
+        ws_bytes = size_query("trs_cat_head_bwd_workspace_bytes", B, N, Ea, Eb) if need_w else 0
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device) if need_w else None
+        call("trs_cat_head_bwd", ptr(g2), ptr(a), ptr(d), ptr(W), B, N, Ea, Eb, value_dtype_code(a), ptr(ga), ptr(gd),
+             ptr(gw), ptr(gw[C:]) if need_w else ptr(None), ptr(ws), ws_bytes, stream_ptr())
+        gq = gw.to(W.dtype) if need_w else None                  # one cast for the weight row and the bias
+        g_weight = gq[:C].reshape(wshape) if (need_w and ctx.needs_input_grad[2]) else None
+        g_bias = gq[C:] if (need_w and has_bias and ctx.needs_input_grad[3]) else None
+        return ga, gd, g_weight, g_bias
+
+
+def cat_head(a: torch.Tensor, d: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """``F.linear(torch.cat((a, d), dim=2).flatten(1), weight, bias)`` for a one-output Linear; see cat_head_supported"""
+    return _CatHead.apply(a, d, weight, bias)
+
+
 def relu_bwd_bias_supported(y: torch.Tensor) -> bool:
     row_bytes = y.shape[-1] * y.element_size()
     return (y.is_cuda and y.dtype in (torch.float32, torch.bfloat16) and y.is_contiguous()

@@ -13,7 +13,9 @@ inputs and the ``Inputs`` router (inputs/inputs.py:56-89).  ``patch(pkg, mlp=Fal
 ``heads`` (default on): the scalar heads of ``FactorizationMachineModel``, ``DeepFactorizationMachineModel`` and
 ``XDeepFactorizationMachineModel`` (models/ctr/factorization_machine.py:55-66, deep_fm.py:75-104, xdeep_fm.py:117-121:
 ``cat`` / ``sum('O')`` / ``sum('N')`` / adds on (B, <= 64) tensors, ~20 small ATen launches with their backwards) run as
-one kernel, ``functional.ctr_logit``: the classes keep their constructors, parameters and ``state_dict``; only ``forward``
+one kernel, ``functional.ctr_logit``, and the one-output ``fc`` of ``DeepAndCrossNetworkModel``
+(deep_and_cross_network.py:82-92: ``cat`` of the cross and deep blocks -> flatten -> Linear) reads the two blocks where
+they lie, ``functional.cat_head`` (no 0.65 GB concatenation at the bench size): the classes keep their constructors, parameters and ``state_dict``; only ``forward``
 is wrapped, and the wrapper hands anything it does not cover (CPU tensors, dtypes other than fp32 / bf16, models whose
 layers are not the drop-ins) to the reference's own ``forward``."""
 from __future__ import annotations
@@ -101,8 +103,24 @@ def _xdeepfm_forward(orig):
     return forward
 
 
+def _dcn_forward(orig):
+    def forward(self, emb_inputs):
+        fc = getattr(self, "fc", None)
+        if not (torch.is_tensor(emb_inputs) and emb_inputs.is_cuda and emb_inputs.dim() == 3
+                and isinstance(self.cross, _layers.CrossNetworkLayer) and isinstance(self.deep, _layers.MultilayerPerceptionLayer)
+                and isinstance(fc, torch.nn.Linear) and fc.out_features == 1):
+            return orig(self, emb_inputs)
+        crossed, per_field = _plain(self.cross(emb_inputs)), _plain(self.deep(emb_inputs))      # (B,N,E), (B,N,Od)
+        if not (crossed.dim() == 3 and per_field.dim() == 3 and _F.cat_head_supported(crossed, per_field, fc.weight)):
+            both = torch.cat((crossed, per_field), dim=2)          # deep_and_cross_network.py:82-92, un-named
+            return fc(both.reshape(both.shape[0], -1))
+        return _F.cat_head(crossed, per_field, fc.weight, fc.bias)
+    forward._trs_head = True
+    return forward
+
+
 _HEADS = {"FactorizationMachineModel": _fm_forward, "DeepFactorizationMachineModel": _deepfm_forward,
-          "XDeepFactorizationMachineModel": _xdeepfm_forward}
+          "XDeepFactorizationMachineModel": _xdeepfm_forward, "DeepAndCrossNetworkModel": _dcn_forward}
 _saved_forwards = {}
 
 
