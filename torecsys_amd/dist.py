@@ -59,11 +59,13 @@ from ._abi import call, index_dtype_code, ptr, require_device, size_query, strea
 from .inputs import BaseInput, field_offsets
 
 DENSE_GRAD_MAX_ROWS = 8_000_000      # shards up to this many rows get a dense gradient
-# TRS_SHARD_PREFETCH=1: build the owner-side row buckets at forward time on the side stream.  Off by default: measured on
-# the one-rank DeepFM step (same box, alternating runs) 1.968-1.971 ms with it against 1.933-1.936 ms without -- the
-# global-atomic build (no per-field ranges on the owner side) slows the bandwidth-bound lookup kernels it runs beside by
-# more than the ~160 us it takes off the backward
-OWNER_PREFETCH = __import__("os").environ.get("TRS_SHARD_PREFETCH", "0") == "1"
+# TRS_SHARD_PREFETCH: build the owner-side row buckets at forward time on the side stream (1), never (0), or -- default --
+# only in the pipelined step (overlap_grad_exchange), where the backward's owner reduction runs on the communication stream
+# under the next forward and finds them ready.  Measured on the one-rank DeepFM step, same box, alternating runs (round 5,
+# profiles/r05_logs/ab_shard_prefetch.txt): pipelined 1.787 -> 1.725 ms with it; un-pipelined 1.712 -> 1.758 ms (there the
+# global-atomic build -- no per-field ranges on the owner side -- slows the bandwidth-bound lookup kernels it runs beside by
+# more than the ~170 us it takes off the backward).
+OWNER_PREFETCH = __import__("os").environ.get("TRS_SHARD_PREFETCH", "auto")
 
 
 class HipOps:
@@ -143,11 +145,13 @@ class HipOps:
                 # trs_scatter_rows_update_mapped skips row_map entries outside [0, V), so they update nothing
                 F_.scatter_rows_update_mapped(rb, weight.data, opt, grad_rows, uniq.to(torch.int32), key=weight)
 
-    def prefetch_owner_buckets(self, weight: torch.Tensor, ids: torch.Tensor, padded: bool = False) -> None:
+    def prefetch_owner_buckets(self, weight: torch.Tensor, ids: torch.Tensor, padded: bool = False,
+                               pipelined: bool = False) -> None:
         """The owner-side row buckets of this step (the CSR over the ids this rank RECEIVED) depend only on the route: start
         building them on the side stream at forward time, as the unsharded lookup does, so the backward's reduction
         finds them ready instead of running a ~160 us global-atomic build on the critical path."""
-        if ids.numel() and weight.requires_grad and OWNER_PREFETCH:
+        on = OWNER_PREFETCH == "1" or (OWNER_PREFETCH == "auto" and pipelined)
+        if ids.numel() and weight.requires_grad and on:
             F_.prefetch_row_buckets(ids.view(-1, 1), None, weight.shape[0], check=not padded)
 
     def unpermute(self, rows: torch.Tensor, inv_pos: torch.Tensor, B: int, N: int, want_fm: bool, out=None):
@@ -564,7 +568,7 @@ class _ShardedLookup(Function):
             else:
                 block, fm, fm_sum = ops.unpermute(back, plan.inv_pos, B, N, mod.fuse_fm)
         if weight.shape[0] <= mod.dense_grad_max_rows and hasattr(ops, "prefetch_owner_buckets"):
-            ops.prefetch_owner_buckets(weight, plan.recv_ids, padded)
+            ops.prefetch_owner_buckets(weight, plan.recv_ids, padded, pipelined=bool(mod.overlap_grad_exchange))
         ctx.mod = mod
         ctx.padded = padded
         ctx.splits = (plan.send_splits, plan.recv_splits)
