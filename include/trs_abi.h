@@ -437,6 +437,13 @@ size_t trs_rowdot_bwd_workspace_bytes(int64_t rows, int32_t C);
 int trs_rowdot_bwd(const void* g, const void* h, const void* w, int64_t rows, int32_t C, int32_t dtype, void* gh,
                    float* gw, float* gb, void* workspace, size_t ws_bytes, trs_stream_t stream);
 
+/* ---- batched 2-D transposition with zero padding (the channels-last entry of the CIN layer) --------------------------
+ * out[b][c][r] = in[b][r][c] (r < R, c < Cc), 0 for R <= r < ld_out.  in (B, R, ld_in), out (B, Cc, ld_out), bf16;
+ * R, Cc, ld_in <= 64; ld_in, ld_out multiples of 8.  compress_interaction_network.py:105 (align_to('B','E','N')):
+ * x0 (B,N,E) -> x0T (B,E,ld0) with the field axis padded to the matrix-core k-step, and its gradient back.          */
+int trs_transpose_pad(const void* in, int64_t B, int32_t R, int32_t Cc, int32_t ld_in, void* out, int32_t ld_out,
+                      int32_t dtype, trs_stream_t stream);
+
 /* ---- one-output Linear over the concatenation of two blocks, without the concatenation -----------------------------
  * The head of deep_and_cross_network.py:82-92: torch.cat([cross_out, deep_out], dim='O') -> flatten(('N','O'),'O') ->
  * nn.Linear(cat_size, 1).  a (rows, N, Ea), d (rows, N, Eb) contiguous, w (N * (Ea + Eb)) in the Linear's own order

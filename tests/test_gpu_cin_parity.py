@@ -267,3 +267,23 @@ def test_cin_layer_mfma_vs_oracle_under_kernel_masks(dev, B, N, E, sizes, direct
     assert rel_err(f32(lay.fc.weight.grad), P["fc_weight"].grad) <= TOL
     # fc.bias.grad = sum_b of the bf16-rounded output gradient (nn.Linear's own backward, no kernel of this path)
     assert batch_sum_err(f32(lay.fc.bias.grad), P["fc_bias"].grad, (go ** 2).sum(dim=0), TOL) <= 1.0
+
+
+@pytest.mark.parametrize("B,N,E,ld", [(65, 39, 64, 64), (1, 1, 8, 8), (300, 10, 16, 32), (4100, 33, 64, 64), (7, 64, 64, 64),
+                                      (129, 5, 40, 8)])
+def test_transpose_pad_is_the_padded_transposition_bit_for_bit(dev, B, N, E, ld):
+    """F_.transpose_pad = new_zeros(B,E,ld)[:, :, :N] = x.transpose(1,2) (the CIN layer's channels-last entry,
+    compress_interaction_network.py:105) and its gradient = the un-padded transposition back: moves only, so equal bit
+    for bit; more samples than workgroups on the (4100, ...) case"""
+    from torecsys_amd import functional as F_
+    g = torch.Generator().manual_seed(B * N + E)
+    x = torch.randn(B, N, E, generator=g).to(torch.bfloat16).to(dev).requires_grad_()
+    assert F_.transpose_pad_supported(x, ld)
+    y = F_.transpose_pad(x, ld)
+    ref = x.detach().new_zeros(B, E, ld)
+    ref[:, :, :N] = x.detach().transpose(1, 2)
+    assert y.shape == (B, E, ld) and torch.equal(y, ref)
+    go = torch.randn(B, E, ld, generator=g).to(torch.bfloat16).to(dev)
+    y.backward(go)
+    assert torch.equal(x.grad, go[:, :, :N].transpose(1, 2).contiguous())
+    assert not F_.transpose_pad_supported(x, 128) and not F_.transpose_pad_supported(x.float(), ld)

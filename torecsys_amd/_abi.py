@@ -28,6 +28,7 @@ SIGNATURES = {
     "trs_rowdot_fwd": (c_int32, [_P, _P, _P, _I64, _I32, _I32, _P, _P]),
     "trs_rowdot_bwd_workspace_bytes": (_SZ, [_I64, _I32]),
     "trs_rowdot_bwd": (c_int32, [_P, _P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _SZ, _P]),
+    "trs_transpose_pad": (c_int32, [_P, _I64, _I32, _I32, _I32, _P, _I32, _I32, _P]),
     "trs_cat_head_fwd": (c_int32, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _P]),
     "trs_cat_head_bwd_workspace_bytes": (_SZ, [_I64, _I32, _I32, _I32]),
     "trs_cat_head_bwd": (c_int32, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _SZ, _P]),

@@ -1725,6 +1725,40 @@ class _RowDot(Function):
         return (gh.reshape(hshape) if need_h else None), g_weight, g_bias, None, None
 
 
+def transpose_pad_supported(x: torch.Tensor, ld: int) -> bool:
+    """(B, N, E) bf16 HIP tensor -> (B, E, ld) with zeros behind the N fields in one pass (trs_transpose_pad)"""
+    return (x.is_cuda and x.dim() == 3 and x.dtype == torch.bfloat16 and x.shape[1] <= ld <= 64 and ld % 8 == 0
+            and x.shape[2] <= 64 and x.shape[2] % 8 == 0)
+
+
+class _TransposePad(Function):
+    """x (B,N,E) -> (B,E,ld): out[b,e,n] = x[b,n,e], zeros for n >= N; the gradient is the transposition back.  What
+    ``x.new_zeros(B,E,ld)[:, :, :N] = x.transpose(1,2)`` does in a fill + a strided copy forward and a clone + a slice
+    clone backward (compress_interaction_network.py:105 keeps the activations as ('B','E','N'))."""
+
+    @staticmethod
+    def forward(ctx, x, ld):
+        x = x.contiguous()
+        B, N, E = x.shape
+        out = torch.empty(B, E, ld, dtype=x.dtype, device=x.device)
+        call("trs_transpose_pad", ptr(x), B, N, E, E, ptr(out), ld, value_dtype_code(x), stream_ptr())
+        ctx.dims = (N, E, ld)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        N, E, ld = ctx.dims
+        g = g.contiguous()
+        gx = torch.empty(g.shape[0], N, E, dtype=g.dtype, device=g.device)
+        call("trs_transpose_pad", ptr(g), g.shape[0], E, N, ld, ptr(gx), E, value_dtype_code(g), stream_ptr())
+        return gx, None
+
+
+def transpose_pad(x: torch.Tensor, ld: int) -> torch.Tensor:
+    return _TransposePad.apply(x, ld)
+
+
 def cat_head_supported(a: torch.Tensor, d: torch.Tensor, weight: torch.Tensor) -> bool:
     """one-output Linear over cat((a, d), dim=2).flatten(1) as one pass over the two blocks (trs_cat_head_fwd / _bwd):
     (B, N, Ea) and (B, N, Eb) HIP tensors of one dtype (bf16 / fp32) with rows of whole 16-byte vectors, at most 1024

@@ -487,8 +487,11 @@ class CompressInteractionNetworkLayer(BaseLayer):
         matrix-core operand; BatchNorm1d sees the (B*E, C) view (same per-channel statistics over (B,E))."""
         B, N, E = x0.shape
         ld0 = ((N + 31) // 32) * 32
-        x0T = x0.new_zeros(B, E, ld0)
-        x0T[:, :, :N] = x0.transpose(1, 2)
+        if TRANSPOSE_PAD and F_.transpose_pad_supported(x0, ld0):
+            x0T = F_.transpose_pad(x0, ld0)              # one pass; its backward is the transposition back
+        else:
+            x0T = x0.new_zeros(B, E, ld0)
+            x0T[:, :, :N] = x0.transpose(1, 2)
         hiddenT, H = x0T, N
         pooled = []
         for seq in self.model:
@@ -523,6 +526,7 @@ class CompressInteractionNetworkLayer(BaseLayer):
         return outputs
 
 
+TRANSPOSE_PAD = os.environ.get("TRS_TRANSPOSE_PAD", "1") not in ("", "0")   # CIN entry: (B,N,E) -> (B,E,ld0) in one pass
 PAD_MULTIPLE = int(os.environ.get("TRS_PAD_MULTIPLE", "128"))        # hidden widths are zero-padded to a multiple of this inside the GEMMs
 PAD_MIN_WIDTH = 192
 PAD_MIN_ROWS = 4096
