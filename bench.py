@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--no-other-models", action="store_true",
                     help="skip the short DCN / xDeepFM legs (BASELINE configs[2], [3]) the default one-GPU run appends")
     ap.add_argument("--other-steps", type=int, default=5, help="timed steps of each of those legs")
+    ap.add_argument("--other-warmup", type=int, default=2, help="untimed steps in front of them")
     ap.add_argument("--no-fuse", action="store_true", help="separate lookup and FM kernels (drop-in unfused path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large-table", action="store_true",
@@ -305,7 +306,7 @@ def other_model_leg(name, a, dev, dt, inputs, idx_ring, label_ring, esz):
         loss.backward()
         return loss
 
-    for k in range(2):
+    for k in range(max(1, a.other_warmup)):
         one(k)
     torch.cuda.synchronize()
     kernels = MODEL_KERNELS[name] if dt == torch.bfloat16 else []
@@ -313,6 +314,8 @@ def other_model_leg(name, a, dev, dt, inputs, idx_ring, label_ring, esz):
     import gc
     gc.collect()          # as in the headline leg: a generation-2 pass (~65 ms on the host) inside five 10 ms steps lets the
     gc.disable()          # device run dry -- seen as 19.2 instead of 10.3 ms per DCN step
+    one(0)                # one more untimed step behind that pause: the device idled through it and comes back at a lower
+    torch.cuda.synchronize()      # clock (five DCN steps: 9.6 ms each against 9.2 in a 20-step run on the same box)
     e0.record()
     for k in range(a.other_steps):
         loss = one(k)
