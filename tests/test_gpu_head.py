@@ -81,7 +81,7 @@ def test_ctr_logit_takes_a_strided_column_and_named_tensors(dev):
 
 @pytest.mark.parametrize("ldtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1e-2)])
-@pytest.mark.parametrize("B", [1, 255, 65536, 300001])
+@pytest.mark.parametrize("B", [1, 255, 8192, 8193, 65536, 300001])   # 8192: the last one-workgroup batch
 def test_bce_with_logits_vs_aten(dev, dtype, tol, ldtype, B):
     from torecsys_amd import functional as F_
     from torecsys_amd.fused import BCEWithLogitsLoss

@@ -103,9 +103,11 @@ __global__ __launch_bounds__(64) void bce_finish_kernel(const float* __restrict_
   if (threadIdx.x == 0) *loss = acc * inv_B;
 }
 
-// batches up to BCE_ONE_MAX logits: ONE workgroup of 1024 threads does the whole mean (65 536 logits: 64 per thread) --
-// one launch instead of two on a path where a launch is ~5 us and the work under 1 us.  Fixed order: reproducible.
-constexpr int64_t BCE_ONE_MAX = 1 << 18;
+// batches up to BCE_ONE_MAX logits: ONE workgroup of 1024 threads does the whole mean (8 per thread) -- one launch
+// instead of two where a launch is ~5 us and the work under 1 us.  Fixed order: reproducible.  NOT beyond that: at
+// 65 536 logits the one workgroup ran 63 us (64 dependent load + exp + log1p rounds per thread on one CU) against
+// 5 + 5 us for partial + finish (profiles/r05_bench_deepfm_step_timeline.md of a8457d2 against the one of fdf8b4f).
+constexpr int64_t BCE_ONE_MAX = 1 << 13;
 template <typename T, typename L>
 __global__ __launch_bounds__(1024) void bce_one_kernel(const T* __restrict__ x, const L* __restrict__ y, int64_t B,
                                                        float inv_B, float* __restrict__ loss) {
