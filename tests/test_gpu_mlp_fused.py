@@ -421,62 +421,3 @@ def test_wgrad_rows_long_row_ranges_take_the_four_wave_dma_kernel(dev, M, N):
         ref += g[r0:r0 + (1 << 17), :M].double().t() @ x[r0:r0 + (1 << 17), :N].double()
     assert gw.shape == (M, N)
     assert float((gw.double() - ref).abs().max() / ref.abs().max()) <= 1e-5
-
-
-@pytest.mark.parametrize("mode", [1, 2, 3])
-def test_hybrid_branch_weight_gradients_on_the_deferred_side_stream(dev, mode):
-    """layers.WGRAD_DEFER: the deep branch's weight gradients on the "wgrad" side stream, joined at the END of the backward
-    pass (functional.join_at_backward_end) instead of inside the node.  Same kernels on the same operands: every gradient
-    bit-equal to the in-node arrangement, eagerly and replayed from a hipGraph; a parameter that already holds a
-    gradient (accumulation on the caller's stream) must fall back to the in-node arrangement."""
-    from torecsys_amd import layers as L
-    from torecsys_amd.graph import GraphedStep
-    torch.manual_seed(11)
-    lay = L.DNNLayer(inputs_size=2496, output_size=1, layer_sizes=[400, 400, 400]).to(dev).bfloat16()
-    params = list(lay.parameters())
-    x = (0.5 * torch.randn(8192, 2496, device=dev)).bfloat16()
-    go = torch.randn(8192, 1, device=dev).bfloat16()
-
-    def run(xin):
-        xa = xin.clone().requires_grad_()
-        (lay(xa).rename(None) * go).sum().backward()
-        return xa.grad
-
-    def fresh():
-        for p in params:
-            p.grad = None
-
-    fresh()
-    gx0 = run(x)
-    g0 = [p.grad.clone() for p in params]
-    saved = L.WGRAD_DEFER
-    L.WGRAD_DEFER = mode
-    try:
-        fresh()
-        gx1 = run(x)
-        torch.cuda.synchronize()
-        assert torch.equal(gx0, gx1)
-        for a, p in zip(g0, params):
-            assert torch.equal(a, p.grad)
-        # a second pass WITHOUT clearing: accumulation -> the in-node path, twice the gradient
-        run(x)
-        torch.cuda.synchronize()
-        for a, p in zip(g0, params):
-            assert rel_err((2 * a.float()), p.grad.float()) <= 1e-2
-        # replayed from a hipGraph: the side stream forks and joins inside the capture
-        fresh()
-        xs = x.clone()
-        holder = {}
-
-        def fn(xin):
-            holder["gx"] = run(xin)
-            return holder["gx"].float().sum()
-
-        step = GraphedStep(fn, (xs,), params=params, warmup=2)
-        for _ in range(3):
-            step(xs)
-        torch.cuda.synchronize()
-        for a, p in zip(g0, params):
-            assert torch.equal(a, p.grad)
-    finally:
-        L.WGRAD_DEFER = saved

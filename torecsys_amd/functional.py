@@ -128,27 +128,6 @@ def run_on_side(dev: torch.device, role: str, fn):
     return out, ev, side
 
 
-def join_at_backward_end(dev: torch.device, ev: "torch.cuda.Event", results) -> None:
-    """Called INSIDE an autograd backward: the stream the backward pass was called from waits for ``ev`` when the pass
-    ends (the engine's final callbacks run on the caller's streams, after it has joined the leaf streams) instead of the
-    node that forked the side work waiting before it returns -- so the nodes behind it (the embedding lookups' bucket walks)
-    run BESIDE the side work.  Only for results nobody on the main stream reads before the pass ends: gradients that go
-    into an EMPTY ``.grad`` of a parameter without hooks.  Capture-safe: the wait joins the forked stream again."""
-    def _join():
-        cur = _abi.current_stream_of(dev)
-        cur.wait_event(ev)
-        for t in results:
-            if t is not None:
-                t.record_stream(cur)
-    torch.autograd.Variable._execution_engine.queue_callback(_join)
-
-
-def grad_goes_into_empty_slot(p) -> bool:
-    """A leaf whose gradient of this pass is only STORED (no accumulation kernel, no hook reads it on the main stream)"""
-    return (isinstance(p, torch.Tensor) and p.is_leaf and p.grad is None and not p._backward_hooks
-            and not getattr(p, "_post_accumulate_grad_hooks", None))
-
-
 def _adopt_grads(*grads):
     """A lookup's backward runs on the stream of its forward -- the "lookup" side stream for every lookup of a batch but the
     first -- while the gradients it receives were allocated (and will be freed) under the producer's stream: tell the
@@ -2057,7 +2036,6 @@ class _FusedMLP(Function):
         y, hidden, masks, fam = fused_mlp_forward_raw(x2, Ws, bs)
         ctx.save_for_backward(x2, *Ws, *hidden, *masks)
         ctx.meta = (L, widths, tuple(x.shape), [p.dtype for p in params], fam)
-        ctx.leaves = tuple(params)
         return y.reshape(*x.shape[:-1], widths[L])
 
     @staticmethod
@@ -2070,40 +2048,23 @@ class _FusedMLP(Function):
         rows, dev = x2.shape[0], x2.device
         gy2 = gy.reshape(rows, widths[L]).contiguous()
         gx, gz, gb, _ = fused_mlp_backward_raw(gy2, widths, Ws, masks, family=fam)
-
-        def weight_grads():
-            grads = []
-            for l in range(L):
-                inp = x2 if l == 0 else hidden[l - 1]               # (rows, widths[l] | pad32)
-                g = gy2 if l == L - 1 else gz[l]                    # (rows, widths[l+1] | pad32)
-                gw = gbias = None
-                need_w, need_b = ctx.needs_input_grad[1 + 2 * l], ctx.needs_input_grad[2 + 2 * l]
-                if need_w and need_b and pdt[2 * l] == pdt[2 * l + 1]:
-                    gw, gbias = _wgrad_rows(g, inp, widths[l + 1], widths[l], pdt[2 * l], gb[l])
-                else:
-                    if need_w:
-                        gw = _wgrad_rows(g, inp, widths[l + 1], widths[l], pdt[2 * l])
-                    if need_b:
-                        gbias = gb[l][:widths[l + 1]].to(pdt[2 * l + 1])
-                grads += [gw, gbias]
-            return grads
-
-        # WGRAD_DEFER_STACK: the stack's weight gradients on the "wgrad" side stream, joined when the backward pass ENDS
-        # (join_at_backward_end): whatever autograd runs behind this node -- the other branch of the model, the
-        # embedding tables' bucket walks -- runs beside them.  Only into empty .grad slots of hook-free leaves.
-        if WGRAD_DEFER_STACK and ctx.needs_input_grad[0] and rows >= WGRAD_DEFER_MIN_ROWS and all(
-                grad_goes_into_empty_slot(p) for p in ctx.leaves if p.requires_grad):
-            grads, ev, side = run_on_side(dev, "wgrad", weight_grads)
-            for t in (x2, gy2, *hidden, *gz, *gb):
-                t.record_stream(side)          # allocated (and freed) under this stream, read under the side stream
-            join_at_backward_end(dev, ev, grads)
-        else:
-            grads = weight_grads()
+        grads = []
+        for l in range(L):
+            inp = x2 if l == 0 else hidden[l - 1]               # (rows, widths[l] | pad32)
+            g = gy2 if l == L - 1 else gz[l]                    # (rows, widths[l+1] | pad32)
+            gw = gbias = None
+            need_w, need_b = ctx.needs_input_grad[1 + 2 * l], ctx.needs_input_grad[2 + 2 * l]
+            if need_w and need_b and pdt[2 * l] == pdt[2 * l + 1]:
+                gw, gbias = _wgrad_rows(g, inp, widths[l + 1], widths[l], pdt[2 * l], gb[l])
+            else:
+                if need_w:
+                    gw = _wgrad_rows(g, inp, widths[l + 1], widths[l], pdt[2 * l])
+                if need_b:
+                    gbias = gb[l][:widths[l + 1]].to(pdt[2 * l + 1])
+            grads += [gw, gbias]
         return (gx.reshape(xshape) if ctx.needs_input_grad[0] else None, *grads)
 
 
-WGRAD_DEFER_STACK = os.environ.get("TRS_WGRAD_DEFER_STACK", "0") not in ("", "0")
-WGRAD_DEFER_MIN_ROWS = 4096
 ROWS_GEMM = os.environ.get("TRS_ROWS_GEMM", "1") not in ("", "0")
 ROWS_GEMM_MIN_COLS = 1024       # narrower outputs: the library GEMM is as fast
 

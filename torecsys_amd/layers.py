@@ -542,13 +542,6 @@ HOIST_PACK = int(os.environ.get("TRS_HOIST_PACK", "0") or 0)
 # Measured alternately on one box (gpurun_out/r05p): 1.1956 ms off, 1.1975 ms on -- matrix-core kernels beside matrix-core
 # kernels only move time.  Off.
 WGRAD_STREAM = os.environ.get("TRS_WGRAD_STREAM", "0") not in ("", "0")
-# _HybridMLP.backward: EVERY weight gradient of the branch on the "wgrad" side stream with the join deferred to the end of
-# the backward pass (F_.join_at_backward_end), the input gradient on the caller's stream right behind the fused backward
-# kernel -- so the embedding tables' bucket walks (HBM-bound) run beside the weight-gradient GEMMs (matrix-core-bound)
-# instead of behind them.  1: tail layers first, then the first layer; 2: first layer first; 3: only the first layer's
-# (the tail's stay on the caller's stream in front of the input gradient).  Taken only when every weight / bias of the
-# branch has an empty .grad and no hooks (nothing on the caller's stream reads the gradients before the pass ends).
-WGRAD_DEFER = int(os.environ.get("TRS_WGRAD_DEFER", "0") or 0)
 # _dense_layer_grads: the input gradient behind the weight gradient (see there)
 GX_LAST = os.environ.get("TRS_GX_LAST", "1") not in ("", "0")
 # the fused tail's forward on the first 416 columns of the 512-wide first-layer output, by the row-owner kernel (mixed family)
@@ -832,7 +825,6 @@ class _HybridMLP(torch.autograd.Function):
         else:
             y, hidden, masks, mask_in, fam = F_.fused_mlp_forward_raw(h1, Ws, bs, input_mask=True)
         ctx.wpack = wpack
-        ctx.leaves = (w1, b1) + tuple(t for l in range(L) for t in tail[4 * l:4 * l + 2])
         out_f = tail[4 * (L - 1)].shape[0]
         ctx.save_for_backward(cur, W1, h1, mask_in, *Ws, *hidden, *masks)
         ctx.meta = (L, [h1.shape[1]] + [w.shape[0] for w in Ws], [tuple(tail[4 * l].shape) for l in range(L)],
@@ -868,28 +860,6 @@ class _HybridMLP(torch.autograd.Function):
         # until the step ends) on the "wgrad" side stream, beside the first layer's input- and weight-gradient GEMMs;
         # this node's stream waits for them before it returns (the gradients go to AccumulateGrad on this stream).
         ev = None
-        if WGRAD_DEFER and rows >= PAD_MIN_ROWS and needs[0] and all(
-                F_.grad_goes_into_empty_slot(p) for p in ctx.leaves if p is not None and p.requires_grad):
-            def first_grads():
-                return _dense_layer_grads(g1, gb1, cur, W1, w1shape[0], w1shape[1], w1dt, False, needs[2], needs[3])[1:]
-
-            def all_grads():
-                if WGRAD_DEFER == 2:
-                    f = first_grads()
-                    return tail_grads(), f
-                t = tail_grads() if WGRAD_DEFER != 3 else None
-                return t, first_grads()
-            grads = tail_grads() if WGRAD_DEFER == 3 else None
-            (tg, (gw1, gbias1)), ev, side = F_.run_on_side(dev, "wgrad", all_grads)
-            if grads is None:
-                grads = tg
-            for t in (g1, gb1, cur, h1, gy2, *hidden, *gz, *[b for b in gb if b is not None]):
-                if t is not None:
-                    t.record_stream(side)      # allocated (and freed) under this stream, read under the side stream
-            F_.join_at_backward_end(dev, ev, [gw1, gbias1, *grads])
-            gx = _dense_layer_grads(g1, None, cur, W1, w1shape[0], w1shape[1], w1dt, True, False, False,
-                                    rows_gemm_ws=wpack[2])[0]
-            return (gx.reshape(xshape), None, gw1, gbias1, None, None, *grads)
         if WGRAD_STREAM and rows >= PAD_MIN_ROWS:
             grads, ev, side = F_.run_on_side(dev, "wgrad", tail_grads)
         else:
