@@ -471,7 +471,8 @@ int trs_wgrad_finish_t(const float* part, int32_t S, int32_t Cc, int32_t R, int3
 /* dW partials by a hand-written kernel instead of a batched library GEMM: part (S, M, N) fp32, slice s = g[rows_s, :M]^T
  * x[rows_s, :N] over the s-th of S contiguous row ranges (bf16 operands, row strides ldg / ldx, M and N multiples of
  * 8); trs_wgrad_finish then folds the slices.  S comes from trs_wgrad_rows_splits (0: shape not handled -- more than
- * 32 blocks of 224 x 224, or fewer than 256 rows).                                                                   */
+ * 32 blocks of 224 x 224, or fewer than 256 rows); that number halved any number of times down to 8 is accepted too
+ * (longer row ranges on fewer workgroups, for two weight gradients that share the chip on two streams).              */
 int32_t trs_wgrad_rows_splits(int32_t M, int32_t N, int64_t rows);
 int trs_wgrad_rows(const void* g, int32_t ldg, const void* x, int32_t ldx, int64_t rows, int32_t M, int32_t N,
                    int32_t dtype, int32_t S, float* part, trs_stream_t stream);

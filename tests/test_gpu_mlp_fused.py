@@ -421,3 +421,70 @@ def test_wgrad_rows_long_row_ranges_take_the_four_wave_dma_kernel(dev, M, N):
         ref += g[r0:r0 + (1 << 17), :M].double().t() @ x[r0:r0 + (1 << 17), :N].double()
     assert gw.shape == (M, N)
     assert float((gw.double() - ref).abs().max() / ref.abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("div", [2, 4, 64])
+def test_wgrad_rows_with_fewer_row_ranges_than_planned(dev, div):
+    """trs_wgrad_rows accepts the planned number of row ranges halved down to 8 (longer ranges on fewer workgroups:
+    layers.WGRAD_PAIR runs two such launches side by side); any other count is refused"""
+    from torecsys_amd import functional as F_
+    from torecsys_amd.functional import call, ptr, stream_ptr, _abi
+    rows, M, N = 65536, 400, 400
+    gen = torch.Generator().manual_seed(div)
+    g = torch.randn(rows, 416, generator=gen).bfloat16().to(dev)
+    x = torch.randn(rows, 416, generator=gen).bfloat16().to(dev)
+    S0 = int(_abi.load().trs_wgrad_rows_splits(M, N, rows))
+    assert S0 >= 16
+    gw = F_._wgrad_rows(g, x, M, N, torch.float32, splits_div=div)
+    ref = (g.double().t() @ x.double())[:M, :N]
+    assert float((gw.double() - ref).abs().max() / ref.abs().max()) <= 1e-5
+    part = torch.empty(S0, M, N, dtype=torch.float32, device=dev)
+    with pytest.raises(RuntimeError):
+        call("trs_wgrad_rows", ptr(g), 416, ptr(x), 416, rows, M, N, _abi.TRS_BF16, 24, ptr(part), stream_ptr())
+    with pytest.raises(RuntimeError):
+        call("trs_wgrad_rows", ptr(g), 416, ptr(x), 416, rows, M, N, _abi.TRS_BF16, 2 * S0, ptr(part), stream_ptr())
+
+
+def test_hybrid_branch_with_paired_tail_weight_gradients(dev):
+    """layers.WGRAD_PAIR: the two square tail layers' weight gradients as half-size launches on two streams -- the same
+    gradients up to the fp32 summation order of the row ranges, eagerly and replayed from a hipGraph"""
+    from torecsys_amd import layers as L
+    from torecsys_amd.graph import GraphedStep
+    torch.manual_seed(11)
+    lay = L.DNNLayer(inputs_size=2496, output_size=1, layer_sizes=[400, 400, 400]).to(dev).bfloat16()
+    params = list(lay.parameters())
+    x = (0.5 * torch.randn(16384, 2496, device=dev)).bfloat16()
+    go = torch.randn(16384, 1, device=dev).bfloat16()
+
+    def run(xin):
+        xa = xin.clone().requires_grad_()
+        (lay(xa).rename(None) * go).sum().backward()
+        return xa.grad
+
+    def fresh():
+        for p in params:
+            p.grad = None
+
+    fresh()
+    gx0 = run(x)
+    g0 = [p.grad.clone() for p in params]
+    saved = L.WGRAD_PAIR
+    L.WGRAD_PAIR = True
+    try:
+        fresh()
+        gx1 = run(x)
+        torch.cuda.synchronize()
+        assert torch.equal(gx0, gx1)
+        for a, p in zip(g0, params):
+            assert rel_err(a.float(), p.grad.float()) <= 1e-3
+        g1 = [p.grad.clone() for p in params]
+        fresh()
+        xs = x.clone()
+        step = GraphedStep(lambda xin: run(xin).float().sum(), (xs,), params=params, warmup=2)
+        for _ in range(3):
+            step(xs)
+        torch.cuda.synchronize()
+        for a, p in zip(g1, params):
+            assert torch.equal(a, p.grad)
+    finally:
+        L.WGRAD_PAIR = saved

@@ -655,10 +655,13 @@ extern "C" int32_t trs_wgrad_rows_splits(int32_t M, int32_t N, int64_t rows) {
 extern "C" int trs_wgrad_rows(const void* g, int32_t ldg, const void* x, int32_t ldx, int64_t rows, int32_t M, int32_t N,
                               int32_t dtype, int32_t S, float* part, trs_stream_t stream) {
   TRS_REQUIRE(dtype == TRS_BF16, TRS_EDTYPE, "wgrad_rows: bf16 operands only");
-  const WgradPlan p = wgrad_plan(M, N, rows);
-  TRS_REQUIRE(p.slots_per_xcd > 0 && S == 8 * p.slots_per_xcd, TRS_ESHAPE,
-              "wgrad_rows: (M=%d, N=%d, rows=%lld) takes %d row ranges, caller passed %d", M, N, (long long)rows,
-              8 * p.slots_per_xcd, S);
+  WgradPlan p = wgrad_plan(M, N, rows);
+  // S = what trs_wgrad_rows_splits returned, or that number halved any number of times down to 8 (longer row ranges on
+  // fewer workgroups: two weight gradients enqueued on two streams then share the chip, see layers._HybridMLP)
+  TRS_REQUIRE(p.slots_per_xcd > 0 && S >= 8 && S <= 8 * p.slots_per_xcd && (8 * p.slots_per_xcd) % S == 0 && is_pow2(S / 8),
+              TRS_ESHAPE, "wgrad_rows: (M=%d, N=%d, rows=%lld) takes %d row ranges (or that halved down to 8), caller passed %d",
+              M, N, (long long)rows, 8 * p.slots_per_xcd, S);
+  p.slots_per_xcd = S / 8;
   TRS_REQUIRE(ldg >= M && ldx >= N && (ldg & 7) == 0 && (ldx & 7) == 0 && aligned16(g) && aligned16(x), TRS_ESHAPE,
               "wgrad_rows: row strides must be multiples of 8 elements and cover M / N, operands 16-byte aligned");
   if (!g || !x || !part) return fail(TRS_EINVAL, "wgrad_rows: null pointer");

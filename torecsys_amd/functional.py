@@ -2108,11 +2108,11 @@ def rows_gemm(g: torch.Tensor, W: torch.Tensor, out_f: int, in_f: int,
     return y
 
 
-def _tail_layer_grads(g, inp, out_f, in_f, dtype, gb_f32, need_w, need_b):
+def _tail_layer_grads(g, inp, out_f, in_f, dtype, gb_f32, need_w, need_b, splits_div=1):
     """(dW, db) of one layer behind the fused kernels: the bias cast rides in the weight gradient's finish launch"""
     if need_w and need_b:
-        return _wgrad_rows(g, inp, out_f, in_f, dtype, gb_f32)
-    gw = _wgrad_rows(g, inp, out_f, in_f, dtype) if need_w else None
+        return _wgrad_rows(g, inp, out_f, in_f, dtype, gb_f32, splits_div=splits_div)
+    gw = _wgrad_rows(g, inp, out_f, in_f, dtype, splits_div=splits_div) if need_w else None
     return gw, (gb_f32[:out_f].to(dtype) if need_b else None)
 
 
@@ -2168,20 +2168,30 @@ def pad_cols(g: torch.Tensor, width: int) -> torch.Tensor:
     return out
 
 
-def _wgrad_rows(g: torch.Tensor, inp: torch.Tensor, out_f: int, in_f: int, dtype, gb_f32: Optional[torch.Tensor] = None):
+def _wgrad_rows(g: torch.Tensor, inp: torch.Tensor, out_f: int, in_f: int, dtype, gb_f32: Optional[torch.Tensor] = None,
+                splits_div: int = 1):
     """dW = g^T @ inp over the rows (K = rows): split-K batched GEMM with fp32 partials, folded / sliced / cast by
     trs_wgrad_finish (the padding columns of g / inp are dropped there).  With ``gb_f32`` (the layer's fp32 bias
     gradient, at least out_f entries) returns (dW, db): the cast of the bias gradient rides in the same finish launch."""
     if gb_f32 is not None:
         gb = torch.empty(out_f, dtype=dtype, device=g.device)
         if out_f <= (in_f + 255) // 256 * 256:
-            return _wgrad_rows_impl(g, inp, out_f, in_f, dtype, gb_f32, gb), gb
+            return _wgrad_rows_impl(g, inp, out_f, in_f, dtype, gb_f32, gb, splits_div), gb
         gb.copy_(gb_f32[:out_f])
-        return _wgrad_rows_impl(g, inp, out_f, in_f, dtype, None, None), gb
-    return _wgrad_rows_impl(g, inp, out_f, in_f, dtype, None, None)
+        return _wgrad_rows_impl(g, inp, out_f, in_f, dtype, None, None, splits_div), gb
+    return _wgrad_rows_impl(g, inp, out_f, in_f, dtype, None, None, splits_div)
 
 
-def _wgrad_rows_impl(g, inp, out_f, in_f, dtype, gb_f32, gb):
+def wgrad_rows_splits(g: torch.Tensor, inp: torch.Tensor, out_f: int, in_f: int) -> int:
+    """row ranges trs_wgrad_rows cuts this layer's weight gradient into (0: the kernel does not take the shape)"""
+    if not (WGRAD_ROWS and g.is_cuda and g.dtype == torch.bfloat16 and inp.dtype == torch.bfloat16 and g.is_contiguous()
+            and inp.is_contiguous()):
+        return 0
+    M, N = min(g.shape[1], (out_f + 7) // 8 * 8), min(inp.shape[1], (in_f + 7) // 8 * 8)
+    return int(_abi.load().trs_wgrad_rows_splits(M, N, int(g.shape[0])))
+
+
+def _wgrad_rows_impl(g, inp, out_f, in_f, dtype, gb_f32, gb, splits_div=1):
     rows = g.shape[0]
     if (WGRAD_ROWS and g.is_cuda and g.dtype == torch.bfloat16 and inp.dtype == torch.bfloat16 and g.is_contiguous()
             and inp.is_contiguous()):
@@ -2190,6 +2200,9 @@ def _wgrad_rows_impl(g, inp, out_f, in_f, dtype, gb_f32, gb):
         M, N = min(g.shape[1], (out_f + 7) // 8 * 8), min(inp.shape[1], (in_f + 7) // 8 * 8)
         S = int(_abi.load().trs_wgrad_rows_splits(M, N, int(rows)))
         if S > 0:
+            while splits_div > 1 and S % 2 == 0 and S // 2 >= 8:      # (S is 8 x a power of two)
+                S //= 2
+                splits_div //= 2
             part = torch.empty(S, M, N, dtype=torch.float32, device=g.device)
             call("trs_wgrad_rows", ptr(g), g.shape[1], ptr(inp), inp.shape[1], rows, M, N,
                  _abi.TRS_BF16, S, ptr(part), stream_ptr())

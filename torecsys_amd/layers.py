@@ -542,6 +542,8 @@ HOIST_PACK = int(os.environ.get("TRS_HOIST_PACK", "0") or 0)
 # Measured alternately on one box (gpurun_out/r05p): 1.1956 ms off, 1.1975 ms on -- matrix-core kernels beside matrix-core
 # kernels only move time.  Off.
 WGRAD_STREAM = os.environ.get("TRS_WGRAD_STREAM", "0") not in ("", "0")
+# _HybridMLP.backward: the two square tail layers' weight gradients as half-size launches on two streams (see tail_grads)
+WGRAD_PAIR = os.environ.get("TRS_WGRAD_PAIR", "0") not in ("", "0")
 # _dense_layer_grads: the input gradient behind the weight gradient (see there)
 GX_LAST = os.environ.get("TRS_GX_LAST", "1") not in ("", "0")
 # the fused tail's forward on the first 416 columns of the 512-wide first-layer output, by the row-owner kernel (mixed family)
@@ -846,15 +848,32 @@ class _HybridMLP(torch.autograd.Function):
         gy2 = F_.pad_cols(gy, widths[L]) if gy.shape[1] != widths[L] else gy.contiguous()
         wpack = ctx.wpack if ctx.wpack is not None else (None, None, None)
         g1, gz, gb, gb1 = F_.fused_mlp_backward_raw(gy2, widths, Ws, masks, mask_in, family=fam, packed_ws=wpack[1])
+        def layer_grads(l, splits_div=1):
+            inp = h1 if l == 0 else hidden[l - 1]
+            g = gy2 if l == L - 1 else gz[l]
+            out_f, in_f = wshapes[l]
+            return F_._tail_layer_grads(g, inp, out_f, in_f, wdt[l], gb[l], needs[6 + 4 * l], needs[7 + 4 * l], splits_div)
+
         def tail_grads():
-            grads = []
-            for l in range(L):
-                inp = h1 if l == 0 else hidden[l - 1]
-                g = gy2 if l == L - 1 else gz[l]
-                out_f, in_f = wshapes[l]
-                gw, gbias = F_._tail_layer_grads(g, inp, out_f, in_f, wdt[l], gb[l], needs[6 + 4 * l], needs[7 + 4 * l])
-                grads += [gw, gbias, None, None]
-            return grads
+            # WGRAD_PAIR: the first two tail layers' weight gradients (400 x 400 from 65 536 rows each: 256 workgroups of
+            # 1024 rows, where start-up and the fp32 partial cost as much as the loop) as two launches of HALF as many
+            # workgroups over twice the rows, one on the "wgrad" side stream, sharing the chip
+            pair = (WGRAD_PAIR and L >= 3 and rows >= PAD_MIN_ROWS and wshapes[0] == wshapes[1]
+                    and all(needs[6 + 4 * l] for l in (0, 1))
+                    and F_.wgrad_rows_splits(gz[0], h1, *wshapes[0]) >= 16
+                    and F_.wgrad_rows_splits(gz[1], hidden[0], *wshapes[1]) >= 16)
+            if not pair:
+                return [t for l in range(L) for t in (*layer_grads(l), None, None)]
+            (gw1_, gb1_), ev1, side1 = F_.run_on_side(dev, "wgrad", lambda: layer_grads(1, 2))
+            for t in (gz[1], hidden[0], gb[1]):
+                t.record_stream(side1)
+            per_layer = [layer_grads(0, 2), (gw1_, gb1_)] + [layer_grads(l) for l in range(2, L)]
+            main_ = F_._abi.current_stream_of(dev)
+            main_.wait_event(ev1)
+            for t in (gw1_, gb1_):
+                if t is not None:
+                    t.record_stream(main_)
+            return [t for pr in per_layer for t in (*pr, None, None)]
 
         # The tail's weight gradients (three GEMMs over the rows + their finish passes: six launches nobody waits for
         # until the step ends) on the "wgrad" side stream, beside the first layer's input- and weight-gradient GEMMs;
