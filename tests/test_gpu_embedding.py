@@ -465,7 +465,8 @@ def _check_csr(rb, rows_flat, V):
     assert torch.equal(torch.bincount(got_rows, minlength=V), counts)
 
 
-@pytest.mark.parametrize("case", ["criteo", "tiny_fields", "spill", "unsorted_offsets", "int32", "huge_field", "zipf"])
+@pytest.mark.parametrize("case", ["criteo", "tiny_fields", "spill", "unsorted_offsets", "int32", "huge_field", "zipf",
+                                  "tiny_tail", "ragged_batch"])
 def test_row_buckets_partitioned_and_fallback(dev, case):
     """trs_csr_build: the partitioned LDS-counter build (B >= 2048, per-field ranges) and its device-side fall-back
     to the global-atomic build must produce the same CSR as a bincount/sort restatement."""
@@ -476,6 +477,10 @@ def test_row_buckets_partitioned_and_fallback(dev, case):
         sizes = [1, 2, 3, 1, 7, 40000, 5]
     elif case == "huge_field":
         sizes = [100, 70000, 9]          # 5 chunks in one field
+    elif case == "tiny_tail":
+        sizes = [2053, 1029, 3]          # chunks of 1024 rows: both long fields end in a 5-row chunk (privatised counters)
+    elif case == "ragged_batch":
+        sizes, B = [2564] * 5 + [17, 1, 333, 20000], 5000 + 37          # batch not a multiple of any kernel's stride
     else:
         sizes = [2564] * 13 + [20000, 17, 1, 333, 15361, 15360, 15359]
     N = len(sizes)
