@@ -259,6 +259,7 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const IdxT* __restrict__ 
 constexpr int CSR2_CHUNK = 15360;      // 60 KB of int32 counters
 constexpr int CSR2_THREADS = 1024;
 constexpr int CSR2_TINY = 32;          // chunks of at most this many rows use privatised counters
+constexpr int CSR2_STAGE = 24576;      // positions of perm a fill workgroup can stage in LDS (96 KB)
 constexpr int CSR2_COPIES = 16;
 constexpr int CSR2_TB = 128;           // samples per transpose tile
 constexpr int CSR2_MAX_FIELDS = 120;   // transpose tile (N x 129 int32) stays under 64 KB
@@ -325,7 +326,8 @@ __global__ __launch_bounds__(CSR2_THREADS) void csr2_pass_kernel(const int32_t* 
                                                                  const int64_t* __restrict__ offsets, int64_t B, int N,
                                                                  int64_t V, int32_t* __restrict__ row_start,
                                                                  int32_t* __restrict__ perm,
-                                                                 const int32_t* __restrict__ flags, int chunk) {
+                                                                 const int32_t* __restrict__ flags, int chunk,
+                                                                 int stage_cap) {
   __shared__ int32_t ctr[CSR2_CHUNK];
   __shared__ int s_field, s_len, s_ok;
   __shared__ int64_t s_base;
@@ -341,6 +343,16 @@ __global__ __launch_bounds__(CSR2_THREADS) void csr2_pass_kernel(const int32_t* 
   const int n = s_field, len = s_len;
   const int64_t base = s_base;
   for (int i = threadIdx.x; i < len; i += CSR2_THREADS) ctr[i] = FILL ? row_start[base + i] : 0;
+  // fill pass: the chunk's rows own ONE contiguous piece of perm, [row_start[base], row_start[base + len]).  When it fits
+  // the stage (dynamic LDS behind the counters) the positions are scattered into LDS and the piece leaves as contiguous
+  // stores -- the pass is bound by its scattered 4-byte global stores otherwise (profiles/r05_logs/ab_csr_rank_fill.txt)
+  extern __shared__ int32_t stage[];
+  int seg0 = 0, seg_len = 0;
+  if (FILL && stage_cap > 0 && len > CSR2_TINY) {
+    seg0 = row_start[base];
+    seg_len = row_start[base + len] - seg0;
+  }
+  const bool staged = FILL && stage_cap > 0 && len > CSR2_TINY && seg_len <= stage_cap;
   __syncthreads();
   const int32_t* col = rowT + (int64_t)n * B;
   const int32_t ibase = (int32_t)base;
@@ -419,12 +431,18 @@ __global__ __launch_bounds__(CSR2_THREADS) void csr2_pass_kernel(const int32_t* 
       if (r[u] >= 0 && d < (unsigned)len) {
         if (FILL) {
           const int pos = atomicAdd(&ctr[d], 1);
-          perm[pos] = (int32_t)((b0 + (int64_t)u * CSR2_THREADS) * N + n);
+          const int32_t p = (int32_t)((b0 + (int64_t)u * CSR2_THREADS) * N + n);
+          if (staged) stage[pos - seg0] = p;
+          else perm[pos] = p;
         } else {
           atomicAdd(&ctr[d], 1);
         }
       }
     }
+  }
+  if (staged) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < seg_len; i += CSR2_THREADS) perm[seg0 + i] = stage[i];
   }
   if (!FILL) {
     __syncthreads();
@@ -1302,7 +1320,7 @@ extern "C" int trs_csr_build(const void* idx, int32_t idx_dtype, const int64_t* 
       hipLaunchKernelGGL((csr2_rowid_kernel<int32_t>), dim3(tiles), dim3(256), lds, s, (const int32_t*)idx, offsets, B,
                          N, V, rowT, flags, err_flag, (int)max_items, (int)chunk);
     hipLaunchKernelGGL((csr2_pass_kernel<false>), dim3((int)max_items), dim3(CSR2_THREADS), 0, s, rowT, offsets, B, N, V,
-                       row_start, perm, flags, (int)chunk);
+                       row_start, perm, flags, (int)chunk, 0);
     gate = flags;
   }
   if (BN > 0) {
@@ -1324,9 +1342,17 @@ extern "C" int trs_csr_build(const void* idx, int32_t idx_dtype, const int64_t* 
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, tile_sums, ntiles);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(ntiles), dim3(SCAN_THREADS), 0, s, row_start, n, tile_sums);
   }
-  if (part)
-    hipLaunchKernelGGL((csr2_pass_kernel<true>), dim3((int)max_items), dim3(CSR2_THREADS), 0, s, rowT, offsets, B, N, V,
-                       row_start, perm, flags, (int)chunk);
+  if (part) {
+    // stage for a chunk's piece of perm: what the LDS holds behind the 60 KB of counters (24 576 positions = 96 KB)
+    static const int stage_cap = [] {
+      const char* e = getenv("TRS_CSR_STAGE");
+      if (e && e[0] == '0') return 0;
+      return hipFuncSetAttribute((const void*)csr2_pass_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 CSR2_STAGE * 4) == hipSuccess ? CSR2_STAGE : 0;
+    }();
+    hipLaunchKernelGGL((csr2_pass_kernel<true>), dim3((int)max_items), dim3(CSR2_THREADS), (size_t)stage_cap * 4, s, rowT,
+                       offsets, B, N, V, row_start, perm, flags, (int)chunk, stage_cap);
+  }
   if (BN > 0) {
     // behind the partitioned build these kernels normally exit at once: a small grid keeps them off the CUs (the
     // grid-stride loops still cover every lookup when the fall-back flag is set)
