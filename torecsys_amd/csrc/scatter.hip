@@ -1298,7 +1298,8 @@ extern "C" int trs_csr_build(const void* idx, int32_t idx_dtype, const int64_t* 
   // partitioned (LDS-counter) build when the per-field ranges are few chunks each; otherwise global atomics
   // chunk size: enough (field, chunk) workgroups to cover the chip (each rescans its field's column of the batch,
   // so no more than ~16 per field on average), at most CSR2_CHUNK counters
-  const int64_t target = std::max<int64_t>(256, 4 * (int64_t)N);
+  static const int64_t target_env = getenv("TRS_CSR_TARGET") ? atoll(getenv("TRS_CSR_TARGET")) : 0;      // (tuning: workgroups aimed at)
+  const int64_t target = target_env > N ? target_env : std::max<int64_t>(256, 4 * (int64_t)N);
   int64_t chunk = (V + (target - N) - 1) / std::max<int64_t>(1, target - N);
   chunk = std::min<int64_t>(CSR2_CHUNK, std::max<int64_t>(1024, (chunk + 255) / 256 * 256));
   const int64_t max_items = (int64_t)N + (V + chunk - 1) / chunk;
