@@ -904,7 +904,8 @@ class _MLPStack(torch.autograd.Function):
     ``spec``: per layer (fuse_relu, rowdot); ``tensors``: per layer weight, bias, w_use, b_use (the last two: the
     zero-padded copies the GEMMs read, or None)."""
 
-    SPLIT_ROWS_WIDE = 4096      # rows per split-K slice of a wide-input layer's weight gradient
+    # rows per split-K slice of a wide-input layer's weight gradient (TRS_SPLIT_ROWS_WIDE: tuning)
+    SPLIT_ROWS_WIDE = int(os.environ.get("TRS_SPLIT_ROWS_WIDE", "4096"))
 
     @staticmethod
     def forward(ctx, x, spec, *tensors):
