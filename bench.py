@@ -379,14 +379,32 @@ def large_table_roofline(a, dev, dt, esz, fm_only=False):
             "alg_bytes_per_launch": alg, "median_launch_us": round(med * 1e6, 2), "launches_timed": len(ts)}
 
 
+def self_launch_argv(gpus, argv, env):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: the command this process replaces itself with --
+    one rank per GPU under torch.distributed.run on 127.0.0.1 (the container hostname may not resolve), a free port
+    unless MASTER_PORT names one.  None when a launcher already set WORLD_SIZE or N = 1."""
+    if gpus <= 1 or "WORLD_SIZE" in env or "RANK" in env:
+        return None
+    port = env.get("MASTER_PORT")
+    if not port:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(argv[0]), *argv[1:]]
+
+
 def main():
     a = parse()
+    relaunch = self_launch_argv(a.gpus, sys.argv, os.environ)
+    if relaunch is not None:
+        sys.stdout.flush()
+        os.execv(relaunch[0], relaunch)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         a.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     torch.cuda.set_device(local_rank)

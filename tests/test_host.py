@@ -613,3 +613,40 @@ def test_no_unexpected_register_spills():
         if lim is None or vs > lim[0]:
             unexpected.append((src, name, vs))
     assert not unexpected, f"kernels with VGPR spills: {unexpected}"
+
+
+def test_bench_self_launches_for_more_than_one_gpu(monkeypatch):
+    """`python bench.py --gpus N` (the driver's BENCH command form, no launcher around it) must start N ranks by itself:
+    the process replaces itself with torch.distributed.run on 127.0.0.1; under a launcher (WORLD_SIZE set) or at N = 1
+    it does not."""
+    import importlib.util
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--no-tunableop"])       # module import must not touch TunableOp files
+    spec = importlib.util.spec_from_file_location("trs_bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    argv = ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"]
+    cmd = bench.self_launch_argv(8, argv, {})
+    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    i = cmd.index(os.path.join(ROOT, "bench.py")) if os.path.join(ROOT, "bench.py") in cmd else cmd.index(os.path.abspath("bench.py"))
+    assert cmd[i + 1:] == argv[1:]
+    assert bench.self_launch_argv(8, argv, {"MASTER_PORT": "29777"})[cmd.index("--master-port") + 1] == "29777"
+    assert bench.self_launch_argv(8, argv, {"WORLD_SIZE": "8", "RANK": "0"}) is None
+    assert bench.self_launch_argv(1, argv, {}) is None
+    # main() execs exactly that command
+    seen = {}
+
+    def fake_execv(path, args):
+        seen["path"], seen["args"] = path, list(args)
+        raise SystemExit(0)
+
+    monkeypatch.setattr(os, "execv", fake_execv)
+    monkeypatch.setattr(sys, "argv", [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--no-tunableop"])
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(SystemExit):
+        bench.main()
+    assert seen["path"] == sys.executable and seen["args"][seen["args"].index("--nproc-per-node") + 1] == "2"
+    assert seen["args"][-5:] == ["--gpus", "2", "--steps", "4", "--no-tunableop"]
