@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from torecsys_amd import functional as F_
-from torecsys_amd.layers import CINLayer, CrossNetworkLayer, DNNLayer, FMLayer
+from torecsys_amd.layers import CINLayer, CrossNetworkLayer, DNNLayer, FMLayer, strided_outputs
 
 
 def _plain(t: torch.Tensor) -> torch.Tensor:
@@ -77,7 +77,11 @@ class DeepFactorizationMachineModel(nn.Module):
 
     def forward(self, feat_inputs: torch.Tensor, emb_inputs: torch.Tensor) -> torch.Tensor:
         fm = self.fm(emb_inputs)
-        deep = self.deep(_rows(emb_inputs))
+        if _fused_head(fm):
+            with strided_outputs():          # ctr_logit reads the logit column of the padded output where it lies
+                deep = self.deep(_rows(emb_inputs))
+        else:
+            deep = self.deep(_rows(emb_inputs))
         if _fused_head(fm):
             return F_.ctr_logit(fm, feat_inputs, [deep])
         shallow = _plain(fm).sum(dim=1, keepdim=True) + _first_order(feat_inputs)
@@ -119,7 +123,12 @@ class XDeepFactorizationMachineModel(nn.Module):
         self.bias = nn.Parameter(torch.empty(1).uniform_())
 
     def forward(self, feat_inputs: torch.Tensor, emb_inputs: torch.Tensor) -> torch.Tensor:
-        cin, deep = self.cin(emb_inputs), self.deep(_rows(emb_inputs))
+        cin = self.cin(emb_inputs)
+        if _fused_head(cin):
+            with strided_outputs():
+                deep = self.deep(_rows(emb_inputs))
+        else:
+            deep = self.deep(_rows(emb_inputs))
         if _fused_head(cin):
             return F_.ctr_logit(None, feat_inputs, [cin, deep], bias=self.bias)
         wide = _first_order(feat_inputs) + self.bias

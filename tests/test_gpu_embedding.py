@@ -847,3 +847,47 @@ def test_fused_lookup_fm_on_a_table_beyond_the_caches_streams_its_rows():
     x = rows.float()
     ref = 0.5 * (x.sum(1) ** 2 - (x * x).sum(1))
     assert rel_err(fm.float().cpu(), ref.cpu()) <= 1e-2
+
+
+@pytest.mark.parametrize("prefetch", [False, True])
+def test_shared_row_buckets_across_streams_inline_builds_and_three_index_sets(dev, monkeypatch, prefetch):
+    """A row-bucket entry is shared by every table looked up with the same indices (DeepFM's wide table and its E = 1
+    first-order table), and those lookups' backwards can run on two streams (Inputs puts lookups beyond the first on
+    the "lookup" stream).  With prefetching off -- or a prefetched entry evicted from the two-entry cache by a third
+    index set -- the build happens INLINE in whichever backward comes first: the entry must carry its event so the walk
+    on the other stream waits for it.  Three index sets alive at once, gradients against autograd over the oracle."""
+    from torecsys_amd import functional as F_
+    from torecsys_amd import inputs as I_
+    from torecsys_amd.inputs import Inputs, MultiIndicesEmbedding
+    monkeypatch.setattr(F_, "PREFETCH_BUCKETS", prefetch)
+    monkeypatch.setattr(I_, "LOOKUP_STREAMS", 1)
+    F_.clear_caches()
+    B, N, E = 8192, 39, 64
+    fs, _, w, w1, g = _rand_case(B, N, E, 300, 5, torch.float32)
+    off = O.field_offsets(fs)
+    emb = MultiIndicesEmbedding(embed_size=E, field_sizes=fs).to(dev)
+    feat = MultiIndicesEmbedding(embed_size=1, field_sizes=fs).to(dev)
+    emb.embedding.weight.data.copy_(w)
+    feat.embedding.weight.data.copy_(w1)
+    emb.set_schema(["c0"])
+    feat.set_schema(["c0"])
+    inp = Inputs(schema={"emb_inputs": emb, "feat_inputs": feat})
+    sets = [torch.cat([torch.randint(0, f, (B, 1), generator=g) for f in fs], 1) for _ in range(3)]
+    dsets = [s.to(dev) for s in sets]
+    ge = torch.randn(B, N, E, generator=g)
+    gf = torch.randn(B, N, 1, generator=g)
+    for rnd in range(3):
+        # three forwards first (three index sets: the two-entry cache evicts the first one), then their backwards
+        outs = [inp({"c0": d}) for d in dsets]
+        for k, d in enumerate(outs):
+            for p in (emb.embedding.weight, feat.embedding.weight):
+                p.grad = None
+            loss = ((d["emb_inputs"].rename(None) * ge.to(dev)).sum() + (d["feat_inputs"].rename(None) * gf.to(dev)).sum())
+            loss.backward()
+            torch.cuda.synchronize()
+            wr, w1r = w.clone().requires_grad_(), w1.clone().requires_grad_()
+            ((O.multi_indices_embedding(wr, sets[k], off) * ge).sum()
+             + (O.multi_indices_embedding(w1r, sets[k], off) * gf).sum()).backward()
+            assert rel_err(emb.embedding.weight.grad.cpu(), wr.grad) <= TOL32, (rnd, k)
+            assert rel_err(feat.embedding.weight.grad.cpu(), w1r.grad) <= TOL32, (rnd, k)
+    F_.clear_caches()

@@ -205,3 +205,62 @@ def test_cat_head_partial_gradients_and_rejections(dev):
     with pytest.raises(RuntimeError):
         _abi.call("trs_cat_head_fwd", _abi.ptr(a), _abi.ptr(d), _abi.ptr(w), _abi.ptr(b), 64, 7, 6, 8, 0, _abi.ptr(out),
                   _abi.stream_ptr())
+
+
+def test_patched_heads_accept_an_fp32_bias_under_bf16_activations(dev):
+    """patch(heads=True) wraps the reference's model forwards.  The reference's `outputs += self.bias` promotes in place,
+    so bf16 tables / activations with the default fp32 bias parameter work there: the wrapped forwards must take that
+    case too (bias cast to the activation dtype, gradient back in the parameter's own dtype) instead of raising from
+    ctr_logit's same-dtype check.  Stand-in classes shaped like models/ctr/factorization_machine.py:42-71 and
+    xdeep_fm.py:82-124 (the reference package is absent on the GPU box)."""
+    import torch.nn as nn
+    from torecsys_amd import layers as L
+    from torecsys_amd import patching as P
+    B, N, E = 512, 10, 16
+    g = torch.Generator().manual_seed(3)
+    emb = torch.randn(B, N, E, generator=g).to(torch.bfloat16)
+    feat = torch.randn(B, N, 1, generator=g).to(torch.bfloat16)
+
+    class FactorizationMachineModel(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.use_bias = True
+            self.fm = L.FactorizationMachineLayer(0.0)
+            self.bias = nn.Parameter(torch.full((1, 1), 0.37))          # fp32, as nn.Parameter(torch.zeros) leaves it
+
+        def forward(self, feat_inputs, emb_inputs):
+            raise AssertionError("the reference forward must not be needed for this case")
+
+    FactorizationMachineModel.forward = P._fm_forward(FactorizationMachineModel.forward)
+    m = FactorizationMachineModel().to(dev)
+    e, f = emb.to(dev).requires_grad_(), feat.to(dev).requires_grad_()
+    out = m(f, e)
+    assert out.dtype == torch.bfloat16 and tuple(out.shape) == (B, 1)
+    ref = O.fm_model(feat.float(), emb.float(), torch.full((1, 1), 0.37))
+    assert rel_err(out.float().cpu(), ref) <= 1e-2
+    out.float().sum().backward()
+    assert m.bias.grad is not None and m.bias.grad.dtype == torch.float32
+    assert abs(float(m.bias.grad) - B) <= 1e-2 * B
+
+    class XDeepFactorizationMachineModel(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.cin = L.CompressInteractionNetworkLayer(embed_size=E, num_fields=N, output_size=1, layer_sizes=[8, 8])
+            self.deep = L.MultilayerPerceptionLayer(inputs_size=N * E, output_size=1, layer_sizes=[32])
+            self.bias = nn.Parameter(torch.full((1,), -0.25))
+
+        def forward(self, feat_inputs, emb_inputs):
+            raise AssertionError("the reference forward must not be needed for this case")
+
+    XDeepFactorizationMachineModel.forward = P._xdeepfm_forward(XDeepFactorizationMachineModel.forward)
+    torch.manual_seed(5)
+    x = XDeepFactorizationMachineModel().to(dev)
+    x.cin.to(torch.bfloat16)
+    x.deep.to(torch.bfloat16)          # the bias stays fp32
+    x.eval()
+    with torch.no_grad():
+        got = x(feat.to(dev), emb.to(dev))
+        parts = (P._plain(x.cin(emb.to(dev))).float() + P._plain(x.deep(emb.to(dev).reshape(B, -1))).float()
+                 + feat.to(dev).float().sum(1) - 0.25)
+    assert got.dtype == torch.bfloat16
+    assert rel_err(got.float().cpu(), parts.cpu()) <= 1e-2

@@ -208,3 +208,25 @@ def test_mlp_wide_first_layer_uses_transposed_split(dev):
     for (n, pa), (_, pb) in zip(mlp.model.named_parameters(), ref.named_parameters()):
         assert pa.grad.shape == pb.grad.shape
         assert rel_err(pa.grad.float().cpu(), pb.grad.float().cpu()) <= 1e-2, n
+
+
+@pytest.mark.parametrize("out_f", [1, 3, 10])
+@pytest.mark.parametrize("rows,K,sizes", [(65536, 2496, [400, 400, 400]), (8192, 96, [400, 400]), (8192, 64, [400, 400, 400])])
+def test_mlp_public_output_is_contiguous(dev, out_f, rows, K, sizes):
+    """A user-facing MLP layer returns a contiguous (rows, out_f) tensor like the reference's DNNLayer (`.view` works for
+    every out_f, no padded buffer behind it); only inside layers.strided_outputs() -- the fused head's own call -- may it
+    hand back the strided view of its padded output."""
+    from torecsys_amd.layers import MultilayerPerceptionLayer, strided_outputs
+    torch.manual_seed(2)
+    mlp = MultilayerPerceptionLayer(K, out_f, sizes).to(dev).bfloat16()
+    x = torch.randn(rows, K, device=dev, dtype=torch.bfloat16, requires_grad=True)
+    y = mlp(x)
+    assert y.names == ('B', 'O') and tuple(y.shape) == (rows, out_f)
+    p = y.rename(None)
+    assert p.is_contiguous()
+    assert p.view(-1).shape[0] == rows * out_f
+    with strided_outputs():
+        ys = mlp(x).rename(None)
+    assert torch.equal(ys.float().cpu(), p.float().cpu())
+    p.float().sum().backward()
+    assert x.grad is not None and mlp.model[0].weight.grad is not None

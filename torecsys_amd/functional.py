@@ -72,19 +72,30 @@ def index_errors_seen(device=None, reset: bool = True) -> bool:
 # with the same index tensor (E=64 embeddings and the E=1 first-order weights).
 # --------------------------------------------------------------------------------------------
 class RowBuckets:
-    __slots__ = ("row_start", "perm", "V", "BN", "N", "ready")
+    __slots__ = ("row_start", "perm", "V", "BN", "N", "ready", "stream")
 
     def __init__(self, row_start, perm, V, BN, N):
         self.row_start, self.perm, self.V, self.BN, self.N = row_start, perm, V, BN, N
-        self.ready = None        # event recorded on the build stream (side-stream prefetch)
+        self.ready = None        # event recorded behind the build on the stream it ran on
+        self.stream = None       # that stream (side-stream prefetch or the consumer's own stream for an inline build)
+
+    def built_on(self, stream):
+        """Record where the build was enqueued: every consumer on ANOTHER stream (the E = 1 table's walk on the "lookup"
+        stream sharing the wide table's entry, or the other way round) waits for the event first."""
+        self.stream = stream
+        self.ready = torch.cuda.Event()
+        self.ready.record(stream)
 
     def wait(self):
         """Make the current stream wait for the build (no-op when built on this stream)."""
-        if self.ready is not None:
-            cur = _abi.current_stream_of(self.row_start.device)
-            cur.wait_event(self.ready)
-            self.row_start.record_stream(cur)
-            self.perm.record_stream(cur)
+        if self.ready is None:
+            return
+        cur = _abi.current_stream_of(self.row_start.device)
+        if self.stream is not None and cur == self.stream:
+            return
+        cur.wait_event(self.ready)
+        self.row_start.record_stream(cur)
+        self.perm.record_stream(cur)
 
 
 _bucket_cache: List[tuple] = []   # [(key, idx_tensor_kept_alive, RowBuckets)]
@@ -189,6 +200,9 @@ def row_buckets(idx: torch.Tensor, offsets: Optional[torch.Tensor], V: int, chec
             rb.wait()
             return rb
     rb = _build_buckets(idx, offsets, V, check)
+    # an inline build is shared like a prefetched one (two tables looked up with the same indices, possibly on two
+    # streams): it carries its event and stream too
+    rb.built_on(_abi.current_stream_of(idx.device))
     _bucket_cache.append((key, idx, rb))
     if len(_bucket_cache) > _BUCKET_CACHE_SIZE:
         _bucket_cache.pop(0)
@@ -239,8 +253,7 @@ def prefetch_row_buckets(idx: torch.Tensor, offsets: Optional[torch.Tensor], V: 
     torch.cuda.set_stream(side)          # not `with torch.cuda.stream(side)`: its constructor and __enter__ each resolve
     try:                                 # the current device through hipGetDeviceCount (~0.1 ms apiece)
         rb = _build_buckets(idx, offsets, V, check)
-        rb.ready = torch.cuda.Event()
-        rb.ready.record(side)
+        rb.built_on(side)
     finally:
         torch.cuda.set_stream(main)
     idx.record_stream(side)

@@ -977,6 +977,34 @@ class _MLPStack(torch.autograd.Function):
         return (g2.reshape(ctx.xshape) if needs[0] else None, None, *grads)
 
 
+_strided_ok = [0]
+
+
+class strided_outputs:
+    """Inside this context a ``MultilayerPerceptionLayer`` may return a strided VIEW of its padded output (an (B,1)
+    logit column with row stride 8): the consumer is ``functional.ctr_logit``, which reads it where it lies.  Everywhere
+    else the layer returns a contiguous tensor like the reference's DNNLayer (``.view`` works, the padded buffer is
+    released)."""
+
+    def __enter__(self):
+        _strided_ok[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _strided_ok[0] -= 1
+        return False
+
+
+def _public_out(t: torch.Tensor) -> torch.Tensor:
+    if _strided_ok[0] or t.is_contiguous():
+        return t
+    names = t.names if t.has_names() else None
+    c = (t.rename(None) if names else t).contiguous()
+    if names:
+        c.names = names
+    return c
+
+
 class MultilayerPerceptionLayer(BaseLayer):
     """Linear/activation/dropout stack + output Linear.  layers/ctr/multilayer_perceptron.py:24-84.
     Plain GEMMs: stays on nn.Linear parameters and hipBLASLt kernels (outside the hand-written path, inside the timed
@@ -1155,13 +1183,13 @@ class MultilayerPerceptionLayer(BaseLayer):
         if pad and outputs.dtype == torch.bfloat16:
             fused = self._forward_fused(outputs, mods)
             if fused is not None:
-                return fused
+                return _public_out(fused)
             hybrid = self._forward_hybrid(outputs, mods)
             if hybrid is not None:
-                return hybrid
+                return _public_out(hybrid)
             stacked = self._forward_stacked(outputs, mods)
             if stacked is not None:
-                return stacked
+                return _public_out(stacked)
         i = 0
         while i < len(mods):
             mod = mods[i]

@@ -67,6 +67,14 @@ def _head_ok(self, feat_inputs, emb_inputs) -> bool:
             and emb_inputs.dim() == 3 and feat_inputs.dim() == 3 and feat_inputs.shape[-1] == 1)
 
 
+def _bias_like(bias, ref):
+    """The model's bias (an fp32 nn.Parameter unless the user cast it) in the dtype of the activations: the reference's
+    ``outputs += self.bias`` promotes in place, so a bf16 model with an fp32 bias is a working configuration there and
+    must stay one here (the cast is differentiable: the gradient arrives in the parameter's own dtype)."""
+    b = _plain(bias)
+    return b if b.dtype == ref.dtype else b.to(ref.dtype)
+
+
 def _rows(emb):
     e = _plain(emb)
     return e.reshape(e.shape[0], -1)
@@ -76,7 +84,7 @@ def _fm_forward(orig):
     def forward(self, feat_inputs, emb_inputs):
         if not (_head_ok(self, feat_inputs, emb_inputs) and isinstance(self.fm, _layers.FactorizationMachineLayer)):
             return orig(self, feat_inputs, emb_inputs)
-        bias = _plain(self.bias) if getattr(self, "use_bias", False) else None
+        bias = _bias_like(self.bias, emb_inputs) if getattr(self, "use_bias", False) else None
         return _F.ctr_logit(self.fm(emb_inputs), feat_inputs, bias=bias)
     forward._trs_head = True
     return forward
@@ -87,7 +95,11 @@ def _deepfm_forward(orig):
         if not (_head_ok(self, feat_inputs, emb_inputs) and isinstance(self.fm, _layers.FactorizationMachineLayer)
                 and isinstance(self.deep, _layers.MultilayerPerceptionLayer)):
             return orig(self, feat_inputs, emb_inputs)
-        return _F.ctr_logit(self.fm(emb_inputs), feat_inputs, [_plain(self.deep(_rows(emb_inputs)))])
+        with _layers.strided_outputs():          # the logit column is read where it lies by ctr_logit
+            deep = _plain(self.deep(_rows(emb_inputs)))
+        if deep.dtype != emb_inputs.dtype:          # a deep branch kept in another precision: the reference's own arithmetic
+            return orig(self, feat_inputs, emb_inputs)
+        return _F.ctr_logit(self.fm(emb_inputs), feat_inputs, [deep])
     forward._trs_head = True
     return forward
 
@@ -97,8 +109,11 @@ def _xdeepfm_forward(orig):
         if not (_head_ok(self, feat_inputs, emb_inputs) and isinstance(self.cin, _layers.CompressInteractionNetworkLayer)
                 and isinstance(self.deep, _layers.MultilayerPerceptionLayer)):
             return orig(self, feat_inputs, emb_inputs)
-        cin, deep = _plain(self.cin(emb_inputs)), _plain(self.deep(_rows(emb_inputs)))      # both (B,1): xdeep_fm.py:60-78
-        return _F.ctr_logit(None, feat_inputs, [cin, deep], bias=_plain(self.bias))
+        with _layers.strided_outputs():
+            cin, deep = _plain(self.cin(emb_inputs)), _plain(self.deep(_rows(emb_inputs)))  # both (B,1): xdeep_fm.py:60-78
+        if cin.dtype != emb_inputs.dtype or deep.dtype != emb_inputs.dtype:
+            return orig(self, feat_inputs, emb_inputs)
+        return _F.ctr_logit(None, feat_inputs, [cin, deep], bias=_bias_like(self.bias, emb_inputs))
     forward._trs_head = True
     return forward
 
