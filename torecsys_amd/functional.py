@@ -637,7 +637,9 @@ def _pointer_table(tensors: Sequence[torch.Tensor]) -> torch.Tensor:
     if tab is None:
         if len(_ptr_table_cache) > 64:
             _ptr_table_cache.clear()
-        tab = torch.tensor(key, dtype=torch.int64, device=tensors[0].device)
+        # a pageable host -> device copy with non_blocking=False: PyTorch synchronises the copy's stream before returning,
+        # so the entry is complete for every stream that reads it afterwards (lookups run on several streams)
+        tab = torch.tensor(key, dtype=torch.int64).to(tensors[0].device, non_blocking=False)
         _ptr_table_cache[key] = tab
     return tab
 
@@ -694,7 +696,7 @@ def _tables_meta(weights: Sequence[torch.Tensor]):
             _table_rows_cache.clear()
         rows = torch.tensor(key[0], dtype=torch.int64)
         off = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(rows, 0)[:-1]])
-        m = _table_rows_cache[key] = (rows.to(key[1]), off.to(key[1]))
+        m = _table_rows_cache[key] = (rows.to(key[1], non_blocking=False), off.to(key[1], non_blocking=False))  # blocking: see _pointer_table
     return m
 
 
@@ -1671,7 +1673,10 @@ class _FFMFused(Function):
         # instead of a random 8-byte load per lookup (9.5 -> see profiles/r05_kernels.md)
         rid_t = None
         if V < 2 ** 31 and B > 0:
-            rid = idx if offsets is None else idx + offsets
+            # range check BEFORE narrowing: an id such as 2^32 + 5 must stay out of range (-1: contributes nothing, as in
+            # the forward), not wrap onto a foreign row
+            rid = idx.long() if offsets is None else idx.long() + offsets
+            rid = torch.where((rid >= 0) & (rid < V), rid, rid.new_full((), -1))
             rid_t = rid.t().contiguous().to(torch.int32)
         call("trs_ffm_fused_bwd", ptr(_pointer_table(ws)), V, E, value_dtype_code(ws[0]), ptr(idx), index_dtype_code(idx),
              ptr(offsets), ptr(g.contiguous()), ptr(rb.row_start), ptr(rb.perm), B, N, ptr(_pointer_table(grads)),

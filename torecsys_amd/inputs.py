@@ -276,8 +276,9 @@ class Inputs(BaseInput):
                 return None
             w = c.embedding.weight
             if (c.embedding.padding_idx is not None or c.fused_optimizer is not None or w.shape[1] != w0.shape[1]
-                    or w.dtype != w0.dtype or w.device != w0.device or not w.is_contiguous()):
-                return None
+                    or w.dtype != w0.dtype or w.device != w0.device or not w.is_contiguous()
+                    or ((w.shape[1] * w.element_size()) % 16 == 0 and w.data_ptr() % 16 != 0)):
+                return None            # (a 16-byte-misaligned table, e.g. a view into a larger buffer: per-child lookups)
             v = inputs[c.schema.inputs[0]]
             v = v.rename(None) if v.has_names() else v
             if v.is_floating_point() or v.device != w0.device or not (v.dim() == 1 or (v.dim() == 2 and v.shape[1] == 1)):
