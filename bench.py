@@ -72,6 +72,9 @@ def parse():
                          "(log-spaced sizes from 4 to ~300 k rows summing to the same total: tiny fields = very hot rows)")
     ap.add_argument("--no-other-models", action="store_true",
                     help="skip the short DCN / xDeepFM legs (BASELINE configs[2], [3]) the default one-GPU run appends")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the zipf / skewed / skewed_zipf legs of the headline step the default one-GPU run appends")
+    ap.add_argument("--variant-steps", type=int, default=12, help="timed steps of each of those legs")
     ap.add_argument("--other-steps", type=int, default=5, help="timed steps of each of those legs")
     ap.add_argument("--other-warmup", type=int, default=2, help="untimed steps in front of them")
     ap.add_argument("--no-fuse", action="store_true", help="separate lookup and FM kernels (drop-in unfused path)")
@@ -226,6 +229,57 @@ def self_check(a, inputs, model, idx, sizes, rows=4096):
             "what": "product-path logits of the first rows of timed batch 0 vs the fp32 oracle on the same parameters"}
 
 
+def _mlp_params(sd, prefix):
+    names = [k[:-len(".weight")] for k in sd if k.startswith(prefix) and k.endswith(".weight")]
+    return [sd[n + ".weight"] for n in names], [sd[n + ".bias"] for n in names]
+
+
+def other_model_self_check(name, a, inputs, model, idx, sizes):
+    """configs[2] / [3] at the benchmark's size and parameters: product-path logits of the first rows of timed batch 0
+    against the fp32 oracle on the same (bf16-rounded) parameters.  DCN: 2048 rows.  xDeepFM: 512 rows (the oracle forms
+    the (B, N*H, E) outer product like the reference: 0.65 GB at 512 rows) with BatchNorm in EVAL mode on the running
+    statistics the timed training steps left behind -- rows are independent there; the train-mode statistics are pinned
+    at this batch size in tests/test_gpu_fullsize.py.  Checker use of the oracle."""
+    from oracle import cpu_ref as O
+    rows = 2048 if name == "dcn" else 512
+    sl = idx[:rows]
+    was_training = model.training
+    model.eval()
+    try:
+        with torch.no_grad():
+            d = inputs({"c0": sl})
+            got = (model(**d) if name != "dcn" else model(emb_inputs=d["emb_inputs"])).float().cpu()
+    finally:
+        model.train(was_training)
+    sd = {k: v.detach().float().cpu() for k, v in list(inputs.state_dict().items()) + list(model.state_dict().items())}
+    off = O.field_offsets(sizes)
+    ic = sl.cpu()
+    emb = O.multi_indices_embedding(sd["emb_inputs.embedding.weight"], ic, off)
+    dw, db = _mlp_params(sd, "deep.model.")
+    if name == "dcn":
+        L = len([k for k in sd if k.startswith("cross.model.") and k.endswith(".weight")])
+        ref = O.dcn_model(emb, [sd[f"cross.model.{l}.weight"] for l in range(L)], [sd[f"cross.model.{l}.bias"] for l in range(L)],
+                          dw, db, sd["fc.weight"], sd["fc.bias"])
+        terms = None
+    else:
+        feat = O.multi_indices_embedding(sd["feat_inputs.embedding.weight"], ic, off)
+        K = len([k for k in sd if k.startswith("cin.model.") and k.endswith(".Conv1d.weight")])
+        kw = dict(conv_weights=[sd[f"cin.model.{k}.Conv1d.weight"] for k in range(K)],
+                  conv_biases=[sd[f"cin.model.{k}.Conv1d.bias"] for k in range(K)],
+                  fc_weight=sd["cin.fc.weight"], fc_bias=sd["cin.fc.bias"],
+                  bn_weights=[sd[f"cin.model.{k}.Batchnorm.weight"] for k in range(K)],
+                  bn_biases=[sd[f"cin.model.{k}.Batchnorm.bias"] for k in range(K)],
+                  bn_running_means=[sd[f"cin.model.{k}.Batchnorm.running_mean"].clone() for k in range(K)],
+                  bn_running_vars=[sd[f"cin.model.{k}.Batchnorm.running_var"].clone() for k in range(K)],
+                  training=False)
+        ref = O.xdeepfm_model(feat, emb, kw, dw, db, sd["bias"])
+    err = float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+    tol = 1e-2 if a.dtype == "bf16" else 1e-5
+    return {"rows": rows, "max_rel_err_logits": round(err, 6), "tolerance": tol, "ok": bool(err <= tol),
+            "what": "product-path logits of the first rows of timed batch 0 vs the fp32 oracle on the same parameters"
+                    + ("" if name == "dcn" else " (BatchNorm in eval mode on the running statistics of the timed steps)")}
+
+
 WORKLOADS = {
     "deepfm": "BASELINE.json configs[1]: DeepFM 39 Criteo-shaped fields, MLP [400,400,400]",
     "fm": "FactorizationMachine (BASELINE.json configs[0] shape class) on the configs[1] inputs",
@@ -278,7 +332,7 @@ def _loss(crit, out, lab):
     return crit(out.float(), lab) if isinstance(crit, nn.BCEWithLogitsLoss) else crit(out, lab)
 
 
-def other_model_leg(name, a, dev, dt, inputs, idx_ring, label_ring, esz):
+def other_model_leg(name, a, dev, dt, inputs, idx_ring, label_ring, esz, sizes=None):
     """BASELINE configs[2] / [3] in the default run: a few eager fwd+bwd steps of DCN / xDeepFM on the same inputs,
     same batch ring and same definition of a step as the headline leg (dense table gradients, no optimizer), timed by a
     HIP event pair around the steps; the dominant matrix-core kernel by events around each of its launches."""
@@ -339,6 +393,11 @@ def other_model_leg(name, a, dev, dt, inputs, idx_ring, label_ring, esz):
             leg["roofline_model_kernel"] = model_kernel_roofline(name, kn, ts, B, N, E, esz)
     for p in params:
         p.grad = None
+    if sizes is not None and not a.no_cpu_baseline:
+        try:
+            leg["self_check"] = other_model_self_check(name, a, inputs, model, idx_ring[0], sizes)
+        except Exception as exc:          # noqa: BLE001 -- the checker must not cost the line
+            leg["self_check"] = {"ok": False, "error": f"{type(exc).__name__}: {exc}"}
     del model
     return leg
 
@@ -395,12 +454,55 @@ def self_launch_argv(gpus, argv, env):
             "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(argv[0]), *argv[1:]]
 
 
+VARIANTS = {"zipf": dict(zipf=True, field_layout="uniform"), "skewed": dict(zipf=False, field_layout="skewed"),
+            "skewed_zipf": dict(zipf=True, field_layout="skewed")}
+
+
+def variant_legs(a):
+    """"report both" -- the headline line is quoted on uniform field sizes and uniform indices (the friendliest
+    case for the bucket walk's atomics-free reduction and for the caches); these legs time the SAME step (same code path,
+    hipGraph replay, resident batches) on Zipf(1.05) indices, on criteo-skewed field sizes (log-spaced, 4 .. ~300 k rows)
+    and on both, a few steps each, and report ms per step and the roofline kernel's fraction inside that step."""
+    import copy
+    out = {}
+    for name, kw in VARIANTS.items():
+        b = copy.copy(a)
+        for k, v in kw.items():
+            setattr(b, k, v)
+        b.steps, b.warmup = a.variant_steps, max(2, a.variant_steps // 4)
+        b.no_cpu_baseline = b.no_large_table = b.no_other_models = b.no_variants = True
+        try:
+            r = run(b)
+            rf = r.get("roofline") or {}
+            out[name] = {"workload": r["config"]["workload"], "steps": r["steps"], "ms_per_step": r["ms_per_step"],
+                         "value": r["value"], "unit": r["unit"], "loss": r["config"]["loss"],
+                         "hipgraph": r["config"]["hipgraph"],
+                         "roofline": {k: rf.get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_us",
+                                                             "launches_timed")} if rf else None}
+        except Exception as exc:      # noqa: BLE001 -- a failed variant must not cost the headline line
+            out[name] = {"error": f"{type(exc).__name__}: {exc}"}
+        torch.cuda.synchronize()
+        from torecsys_amd import functional as _F
+        _F.clear_caches()
+    return out
+
+
 def main():
     a = parse()
     relaunch = self_launch_argv(a.gpus, sys.argv, os.environ)
     if relaunch is not None:
         sys.stdout.flush()
         os.execv(relaunch[0], relaunch)
+    res = run(a)
+    if res is not None:
+        # RCCL writes a version banner through C stdio; flush it first so the JSON line is the LAST line
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(res), flush=True)
+
+
+def run(a):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -996,18 +1098,17 @@ def main():
         if (world == 1 and not sharded and a.model == "deepfm" and not a.no_other_models and a.optimizer == "none"
                 and not a.no_fuse):
             # BASELINE configs[2] and [3] ride along: a few steps each, reported beside the headline (never as `value`)
-            res["other_models"] = {m: other_model_leg(m, a, dev, dt, inputs, idx_ring, label_ring, esz)
+            res["other_models"] = {m: other_model_leg(m, a, dev, dt, inputs, idx_ring, label_ring, esz, sizes)
                                    for m in ("dcn", "xdeepfm")}
+        if (world == 1 and not sharded and a.model == "deepfm" and not getattr(a, "no_variants", False)
+                and not a.no_other_models and a.optimizer == "none" and not a.no_fuse and not a.zipf and a.field_layout == "uniform"
+                and not a.host_indices):
+            res["variants"] = variant_legs(a)
     else:
         res = None
     if sharded:
         dist.destroy_process_group()
-    if res is not None:
-        # RCCL writes a version banner through C stdio; flush it first so the JSON line is the LAST line
-        import ctypes
-        sys.stdout.flush()
-        ctypes.CDLL(None).fflush(None)
-        print(json.dumps(res), flush=True)
+    return res
 
 
 if __name__ == "__main__":

@@ -319,3 +319,81 @@ def test_graphed_dense_region_behind_eager_sharded_lookups(pg):
         assert abs(float(loss) - l0) <= 1e-6 * abs(l0)
         for p, want in zip(tables + dense, g0):
             assert rel_err(p.grad.float().cpu(), want.float().cpu()) <= 1e-2
+
+
+def test_cfg5_real_shard_one_rank(pg):
+    """BASELINE configs[4] at its REAL per-GPU size on the one test GPU: a 125 M-row x 64 bf16 shard (16 GB), B = 65 536
+    x N = 39, and global row ids of the 1 B-row table (up to ~1e9, int64 arithmetic: idx + offsets computed in-kernel;
+    the reference's own offsets go through float32 and are wrong above 2^24 rows, multi_indices_emb.py:54).
+
+    (a) the sharded MODULE on a one-rank group over a 125 M-row table: block bit-exact against index_select on the same
+        table, the compact-row path of the fused owner-side optimizer (no dense 16 GB gradient, no gradient tensor at all)
+        against index_add_ in fp32 on the touched rows;
+    (b) the 8-rank ROUTE of a 1 B-row table, evaluated on this rank as owner 7: bucket_by_owner over global ids in
+        [0, 1e9) -- per-owner counts against a host bincount, every owner's local ids in [0, 125 M), send / inverse
+        positions a permutation -- and the owner-side gather of owner 7's ids from the real 16 GB shard, bit-exact."""
+    from oracle import cpu_ref as O
+    from torecsys_amd.dist import HipOps, RowShardedMultiIndicesEmbedding, shard_ranges
+    from torecsys_amd.optim import FusedSparseSGD
+    dev = torch.device("cuda:0")
+    B, N, E = 65536, 39, 64
+    ROWS = 125_000_000
+    g = torch.Generator().manual_seed(55)
+    # ---- (a) one-rank module on a 125 M-row table
+    per = ROWS // N
+    fs = [per] * (N - 1) + [ROWS - per * (N - 1)]
+    m = RowShardedMultiIndicesEmbedding(embed_size=E, field_sizes=fs, fuse_fm=True, dtype=torch.bfloat16, device=dev)
+    assert m.embedding.weight.shape == (ROWS, E) and m.embedding.weight.shape[0] > m.dense_grad_max_rows
+    with torch.no_grad():
+        m.embedding.weight.uniform_(-0.5, 0.5)
+    idx = torch.cat([torch.randint(0, f, (B, 1), generator=g) for f in fs], 1)
+    off = O.field_offsets(fs)
+    gid = (idx + off.view(1, N)).to(dev)
+    assert int(gid.max()) > 2 ** 26
+    opt = FusedSparseSGD(0.5)
+    m.set_fused_optimizer(opt)
+    w_before = m.embedding.weight.detach()[gid.reshape(-1)].float()          # rows the step touches (with repeats)
+    out = m(idx.to(dev))
+    block = out.rename(None)
+    assert torch.equal(block.detach().reshape(B * N, E), m.embedding.weight.detach().index_select(0, gid.reshape(-1)))
+    gb = (torch.randn(B, N, E, generator=g) * 0.1).bfloat16().to(dev)
+    (block.float() * gb.float()).sum().backward()
+    torch.cuda.synchronize()
+    assert m.embedding.weight.grad is None
+    uniq, inv = torch.unique(gid.reshape(-1), return_inverse=True)
+    acc = torch.zeros(uniq.numel(), E, dtype=torch.float32, device=dev).index_add_(0, inv, gb.float().reshape(-1, E))
+    first = torch.zeros(uniq.numel(), dtype=torch.int64, device=dev).scatter_(0, inv, torch.arange(B * N, device=dev))
+    want = w_before[first] - 0.5 * acc
+    got = m.embedding.weight.detach()[uniq].float()
+    assert rel_err(got, want) <= 1e-2
+    del m, out, block, w_before, acc, want, got, opt
+    torch.cuda.empty_cache()
+    # ---- (b) the 8-rank route of the 1 B-row table, this GPU as owner 7
+    V, W = 1_000_000_000, 8
+    per = V // N
+    fs = [per] * (N - 1) + [V - per * (N - 1)]
+    off = O.field_offsets(fs)
+    assert int(off[-1]) > 2 ** 24 and off.dtype == torch.int64
+    idx = torch.cat([torch.randint(0, f, (B, 1), generator=g) for f in fs], 1)
+    rpr, ranges = shard_ranges(V, W)
+    assert rpr == ROWS
+    ops = HipOps()
+    counts, send_ids, send_pos, inv_pos = ops.bucket_by_owner(idx.to(dev), off.to(dev), rpr, W)
+    gidh = (idx + off.view(1, N)).reshape(-1)
+    owner = gidh // rpr
+    assert torch.equal(counts.cpu(), torch.bincount(owner, minlength=W))
+    assert int(send_ids.min()) >= 0 and int(send_ids.max()) < rpr
+    sp = send_pos.long().cpu()
+    assert torch.equal(sp.sort().values, torch.arange(B * N))                # every lookup sits in exactly one slot
+    assert torch.equal(sp[inv_pos.long().cpu()], torch.arange(B * N))        # and inv_pos finds it again
+    ends = counts.cumsum(0).cpu()
+    seg_owner = torch.bucketize(torch.arange(B * N), ends, right=True)
+    assert torch.equal(seg_owner, owner[sp])                                 # slots grouped by owner, in rank order
+    assert torch.equal(send_ids.long().cpu(), gidh[sp] - owner[sp] * rpr)    # local ids = global - owner * rows_per_rank
+    shard = torch.empty(ROWS, E, dtype=torch.bfloat16, device=dev).uniform_(-0.5, 0.5)      # owner 7's 16 GB
+    lo, hi = int(ends[6]), int(ends[7])
+    mine = send_ids[lo:hi].contiguous()
+    rows = ops.gather_local(shard, mine, ranges[7][1] - ranges[7][0])
+    assert torch.equal(rows, shard.index_select(0, mine.long()))
+    del shard, rows
+    torch.cuda.empty_cache()

@@ -126,7 +126,8 @@ def _rand_case(B, N, E, V_per_field, seed, dtype, zipf=False):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,N,E,Vf,zipf", [(1024, 10, 16, 100, False), (512, 39, 64, 50, False),
-                                           (4096, 39, 64, 7, True), (300, 5, 10, 9, False), (64, 3, 128, 4, False)])
+                                           (4096, 39, 64, 7, True), (300, 5, 10, 9, False), (64, 3, 128, 4, False),
+                                           (1024, 10, 16, 10000, False)])      # the last: BASELINE configs[0]'s shape
 def test_fused_embed_fm_vs_oracle(dev, dtype, B, N, E, Vf, zipf):
     """embed_fm (lookup + FM + first-order sum in one kernel) and its backward (FM term folded into the
     segmented scatter; hot rows through the long-row path) against autograd over the oracle."""

@@ -312,3 +312,225 @@ def test_ffm_full_size(dev):
         assert rel_err(gi[uniq.to(dev)].float().cpu(), small[i].grad) <= TOL
         mask = torch.ones(V, dtype=torch.bool); mask[uniq] = False
         assert float(gi[mask.to(dev)].float().abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# The three timed models, the step exactly as bench.py arranges it (Inputs router over the fused lookup + FM table and the
+# E = 1 first-order table, the harness model, the fused head, the HIP BCE-with-logits loss, full backward with dense table
+# gradients; DeepFM replayed from a hipGraph, DCN / xDeepFM eager), at B = 65 536 on a 1 M-row table.
+#
+# How a sum over 65 536 samples is checked against an oracle that can only afford a few dozen of them: the S sampled
+# samples look up RESERVED table rows (sample j reads row j of every field; every other sample draws from rows >= S), so
+# the gradient rows of those reserved ids receive exactly one contribution each -- (1/B) dl_j / d emb[j, n] -- and the
+# oracle evaluated on the S samples alone, with its loss divided by B, must reproduce them.
+# ------------------------------------------------------------------------------------------------------------------------
+V_STEP = 1_000_000
+
+
+def _step_case(dev, seed):
+    per = V_STEP // N
+    sizes = [per] * (N - 1) + [V_STEP - per * (N - 1)]
+    off = O.field_offsets(sizes)
+    g = torch.Generator().manual_seed(seed)
+    idx = torch.cat([torch.randint(S, f, (B, 1), generator=g) for f in sizes], 1)
+    rows = torch.randperm(B, generator=g)[:S].sort().values
+    idx[rows] = torch.arange(S).view(S, 1).expand(S, N)
+    labels = (torch.rand(B, 1, generator=g) < 0.25).float()
+    return sizes, off, idx, rows, labels
+
+
+def _step_inputs(dev, sizes):
+    from torecsys_amd.inputs import Inputs, MultiIndicesEmbedding
+    emb = MultiIndicesEmbedding(embed_size=E, field_sizes=sizes, fuse_fm=True)
+    feat = MultiIndicesEmbedding(embed_size=1, field_sizes=sizes)
+    emb.set_schema(["c0"])
+    feat.set_schema(["c0"])
+    return Inputs(schema={"emb_inputs": emb, "feat_inputs": feat}).to(dev).to(torch.bfloat16), emb, feat
+
+
+def _reserved(emb, feat, off, dev):
+    """fp32 host copies of the reserved rows of both tables as (S*N, .) leaf tensors + the (S, N) local index block"""
+    gid = (torch.arange(S).view(S, 1) + off.view(1, N)).reshape(-1)
+    w = emb.embedding.weight.detach()[gid.to(dev)].float().cpu().requires_grad_()
+    w1 = feat.embedding.weight.detach()[gid.to(dev)].float().cpu().requires_grad_()
+    return gid, w, w1, torch.arange(S * N).view(S, N)
+
+
+def _mlp_of(dnn):
+    lin = [m for m in dnn.model if isinstance(m, torch.nn.Linear)]
+    return [l.weight.detach().float().cpu() for l in lin], [l.bias.detach().float().cpu() for l in lin]
+
+
+def _check_step(tag, logits, ref_logits, terms, gw, gw_ref, gw1, gw1_ref, loss, loss_ref):
+    le = sum_err(logits, ref_logits, terms)
+    ge, gr = rel_err(gw, gw_ref), rel_err_rows(gw.view(S, -1), gw_ref.view(S, -1))
+    g1 = rel_err(gw1, gw1_ref)
+    print(f"{tag}: logits sum_err {le:.2e}  table-grad rel {ge:.2e} per-sample-row {gr:.2e}  first-order grad {g1:.2e}"
+          + (f"  loss {loss:.6f} vs {loss_ref:.6f}" if loss_ref is not None else ""))
+    return le, ge, gr, g1
+
+
+def test_deepfm_step_full_size(dev):
+    """DeepFM (deep_fm.py:73-108) as benchmarked: graph replay, mixed-family fused tail, fused head, BCE.  Sampled-row
+    logits, the reserved rows of BOTH table gradients, and -- the oracle affords the whole batch for this model -- the
+    loss itself over all 65 536 samples."""
+    from harness import ctr_models as M
+    from torecsys_amd.fused import BCEWithLogitsLoss
+    from torecsys_amd.graph import GraphedStep
+    sizes, off, idx, rows, labels = _step_case(dev, 2024)
+    torch.manual_seed(7)
+    inputs, emb, feat = _step_inputs(dev, sizes)
+    model = M.DeepFactorizationMachineModel(embed_size=E, num_fields=N, deep_layer_sizes=[400, 400, 400],
+                                            fm_dropout_p=0.0).to(dev).to(torch.bfloat16)
+    crit = BCEWithLogitsLoss()
+    params = [p for p in list(inputs.parameters()) + list(model.parameters()) if p.requires_grad]
+    held = {}
+
+    def fn(ix, lab):
+        d = inputs({"c0": ix})
+        out = model(**d)
+        held["out"] = out.detach()
+        l_ = crit(out, lab)
+        l_.backward()
+        return l_
+
+    step = GraphedStep(fn, (idx.to(dev), labels.to(dev)), params=params, warmup=1)
+    other = torch.cat([torch.randint(S, f, (B, 1), generator=torch.Generator().manual_seed(1)) for f in sizes], 1)
+    step(other.to(dev), labels.to(dev))          # another batch through the same graph first: nothing may be stale
+    loss = step(idx.to(dev), labels.to(dev))
+    torch.cuda.synchronize()
+    logits = held["out"].float().cpu()
+    ws, bs = _mlp_of(model.deep)
+    # the whole batch on the oracle (fp32 on the bf16-rounded parameters): loss and every logit
+    W = emb.embedding.weight.detach().float().cpu()
+    W1 = feat.embedding.weight.detach().float().cpu()
+    e_all = O.multi_indices_embedding(W, idx, off)
+    f_all = O.multi_indices_embedding(W1, idx, off)
+    ref_all = O.deepfm_model(f_all, e_all, ws, bs)
+    loss_ref = float(O.bce_with_logits(ref_all, labels))
+    assert abs(float(loss) - loss_ref) <= 1e-3 * abs(loss_ref)
+    assert rel_err(logits, ref_all) <= TOL
+    gid, w, w1, loc = _reserved(emb, feat, off, dev)
+    er = O.multi_indices_embedding(w, loc, torch.zeros(N, dtype=torch.int64))
+    fr = O.multi_indices_embedding(w1, loc, torch.zeros(N, dtype=torch.int64))
+    ref = O.deepfm_model(fr, er, ws, bs)
+    (torch.nn.functional.binary_cross_entropy_with_logits(ref, labels[rows], reduction="sum") / B).backward()
+    with torch.no_grad():       # the logit is sum_e FM_e + sum_n first_n + deep: bounded relative to its terms
+        terms = (O.fm_layer(er).abs().sum(dim=1, keepdim=True) + fr.abs().sum(dim=1)
+                 + O.mlp(er.reshape(S, -1), ws, bs).abs())
+    le, ge, gr, g1 = _check_step("deepfm", logits[rows], ref.detach(), terms,
+                                 emb.embedding.weight.grad[gid.to(dev)].float().cpu(), w.grad,
+                                 feat.embedding.weight.grad[gid.to(dev)].float().cpu(), w1.grad, float(loss), loss_ref)
+    assert le <= TOL and ge <= TOL and gr <= TOL and g1 <= TOL
+
+
+def test_dcn_step_full_size(dev):
+    """DeepAndCrossNetwork (deep_and_cross_network.py:71-96) as benchmarked: cross network (6 layers, detached first
+    input) + row-owner per-field MLP at 2.56 M rows + the cat-free head + BCE, eager."""
+    from harness import ctr_models as M
+    from torecsys_amd.fused import BCEWithLogitsLoss
+    sizes, off, idx, rows, labels = _step_case(dev, 2025)
+    torch.manual_seed(11)
+    inputs, emb, feat = _step_inputs(dev, sizes)
+    model = M.DeepAndCrossNetworkModel(inputs_size=E, num_fields=N, deep_output_size=64, deep_layer_sizes=[400, 400, 400],
+                                       cross_num_layers=6).to(dev).to(torch.bfloat16)
+    crit = BCEWithLogitsLoss()
+    for _ in range(2):
+        for p in list(inputs.parameters()) + list(model.parameters()):
+            p.grad = None
+        d = inputs({"c0": idx.to(dev)})
+        out = model(emb_inputs=d["emb_inputs"])
+        loss = crit(out, labels.to(dev))
+        loss.backward()
+    torch.cuda.synchronize()
+    logits = out.detach().float().cpu()
+    gid, w, _, loc = _reserved(emb, feat, off, dev)
+    er = O.multi_indices_embedding(w, loc, torch.zeros(N, dtype=torch.int64))
+    f32 = lambda t: t.detach().float().cpu()
+    cw, cb = [f32(l.weight) for l in model.cross.model], [f32(l.bias) for l in model.cross.model]
+    ws, bs = _mlp_of(model.deep)
+    ref = O.dcn_model(er, cw, cb, ws, bs, f32(model.fc.weight), f32(model.fc.bias))
+    (torch.nn.functional.binary_cross_entropy_with_logits(ref, labels[rows], reduction="sum") / B).backward()
+    # the logit is one 4 992-term dot product of [cross | deep] with the head's weights: bounded relative to its terms
+    with torch.no_grad():
+        cat = torch.cat([O.cross_network(er, cw, cb), O.mlp(er, ws, bs)], dim=2).reshape(S, -1)
+        terms = cat.abs() @ f32(model.fc.weight).abs().t() + f32(model.fc.bias).abs()
+    gw = emb.embedding.weight.grad[gid.to(dev)].float().cpu()
+    le = sum_err(logits[rows], ref.detach(), terms)
+    ge, gr = rel_err(gw, w.grad), rel_err_rows(gw.view(S, -1), w.grad.view(S, -1))
+    print(f"dcn: logits sum_err {le:.2e}  table-grad rel {ge:.2e} per-sample-row {gr:.2e}  loss {float(loss):.6f}")
+    assert le <= TOL and ge <= TOL and gr <= TOL
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_xdeepfm_step_full_size(dev, mode):
+    """xDeepFM (xdeep_fm.py:100-122) as benchmarked: CIN [128,128,128] + DNN + first-order sum + bias, fused head, BCE.
+    train: BatchNorm on batch statistics -- reduced in float64 on the device from each layer's own contraction output and
+    handed to the oracle -- sampled-row LOGITS (the train-mode backward couples every sample through the statistics; its
+    kernels are pinned at this batch size in test_cin_pieces_full_size).  eval: running statistics, samples independent:
+    logits and the reserved table-gradient rows, the oracle's CIN under the kernel's own ReLU masks."""
+    from harness import ctr_models as M
+    from test_gpu_cin_parity import _GlueRecorder
+    from torecsys_amd import functional as F_
+    from torecsys_amd.fused import BCEWithLogitsLoss
+    sizes, off, idx, rows, labels = _step_case(dev, 2026)
+    rd = rows.to(dev)
+    torch.manual_seed(12)
+    inputs, emb, feat = _step_inputs(dev, sizes)
+    model = M.XDeepFactorizationMachineModel(embed_size=E, num_fields=N, cin_layer_sizes=[128, 128, 128],
+                                             deep_layer_sizes=[400, 400, 400])
+    for seq in model.cin.model:
+        seq.Batchnorm.running_mean.normal_(0.0, 0.05)
+        seq.Batchnorm.running_var.uniform_(0.5, 1.5)
+        seq.Batchnorm.weight.data.uniform_(0.5, 1.5)
+        seq.Batchnorm.bias.data.normal_(0.0, 0.2)
+    model = model.to(dev).to(torch.bfloat16)
+    model.train(mode == "train")
+    crit = BCEWithLogitsLoss()
+    stats_before = [(seq.Batchnorm.running_mean.clone(), seq.Batchnorm.running_var.clone()) for seq in model.cin.model]
+    d = inputs({"c0": idx.to(dev)})
+    with _GlueRecorder(F_) as rec:
+        out = model(**d)
+    loss = crit(out, labels.to(dev))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert len(rec.seen) == 3
+    logits = out.detach().float().cpu()
+    P = _cin_params(model.cin)
+    stats, masks = [], []
+    for k, (yT, bn, D, Hs) in enumerate(rec.seen):
+        if mode == "train":
+            y64 = yT.double()
+            mean, var = y64.mean(dim=(0, 1)), y64.var(dim=(0, 1), unbiased=False)
+            del y64
+        else:
+            mean, var = stats_before[k][0].double(), stats_before[k][1].double()
+        scale, shift = _affine_of(yT, bn, mean, var)
+        z = yT[rd].float() * scale.float() + shift.float()
+        masks.append((z > 0).float().transpose(1, 2).contiguous().cpu())
+        stats.append((mean.float().cpu(), var.float().cpu()))
+    gid, w, w1, loc = _reserved(emb, feat, off, dev)
+    zero_off = torch.zeros(N, dtype=torch.int64)
+    er, fr = O.multi_indices_embedding(w, loc, zero_off), O.multi_indices_embedding(w1, loc, zero_off)
+    ws, bs = _mlp_of(model.deep)
+    kw = dict(P, bn_running_means=[m.clone() for m, _ in stats], bn_running_vars=[v.clone() for _, v in stats],
+              training=False)
+    bias = model.bias.detach().float().cpu()
+    ref_plain = O.xdeepfm_model(fr, er, kw, ws, bs, bias)
+    with torch.no_grad():
+        _, _, pooled = O.cin_layer(er, **kw, return_intermediates=True)
+        terms = (pooled.abs() @ P["fc_weight"].detach().abs().t() + P["fc_bias"].abs() + fr.abs().sum(dim=1)
+                 + O.mlp(er.reshape(S, -1), ws, bs).abs() + bias.abs())
+    le = sum_err(logits[rows], ref_plain.detach(), terms)
+    print(f"xdeepfm[{mode}]: logits sum_err {le:.2e}  loss {float(loss):.6f}")
+    assert le <= TOL
+    if mode == "train":
+        return
+    acts = [(lambda t, m=m: t * m) for m in masks]
+    ref = O.xdeepfm_model(fr, er, dict(kw, activation=acts), ws, bs, bias)
+    (torch.nn.functional.binary_cross_entropy_with_logits(ref, labels[rows], reduction="sum") / B).backward()
+    gw = emb.embedding.weight.grad[gid.to(dev)].float().cpu()
+    gw1 = feat.embedding.weight.grad[gid.to(dev)].float().cpu()
+    ge, gr, g1 = rel_err(gw, w.grad), rel_err_rows(gw.view(S, -1), w.grad.view(S, -1)), rel_err(gw1, w1.grad)
+    print(f"xdeepfm[eval]: table-grad rel {ge:.2e} per-sample-row {gr:.2e}  first-order grad {g1:.2e}")
+    assert ge <= TOL and gr <= TOL and g1 <= TOL
