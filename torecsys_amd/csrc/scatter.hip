@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void csr2_rowid_kernel(const IdxT* __restrict_
       const int64_t lo = offsets[n], hi = n + 1 < N ? offsets[n + 1] : V;
       if (hi > lo) items += (hi - lo + chunk - 1) / chunk;
     }
-    if (items > max_items) flags[0] = 1;
+    if (items > max_items || offsets[0] != 0) flags[0] = 1;      // (rows in front of the first field: covered by no chunk)
   }
   const int64_t b0 = (int64_t)blockIdx.x * CSR2_TB;
   const int nb = (int)((B - b0) < CSR2_TB ? (B - b0) : CSR2_TB);
@@ -1263,6 +1263,25 @@ __global__ __launch_bounds__(256) void zero2_i32_kernel(int32_t* __restrict__ p,
   }
 }
 
+// partitioned build: the LDS-counter count pass writes EVERY entry of row_start[0, V) itself, so the 4 MB zero fill of
+// the counters (54 us inside the DeepFM step, squeezed in beside the fused MLP backward) is only needed when the build
+// falls back to global atomics: a few words here (fall-back flags, the scan's status words, row_start[V]) ...
+__global__ __launch_bounds__(256) void csr_zero_small_kernel(int32_t* __restrict__ flags, int32_t* __restrict__ status,
+                                                            int nstatus, int32_t* __restrict__ last) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 64 + nstatus + 1; i += gridDim.x * blockDim.x) {
+    if (i < 64) flags[i] = 0;
+    else if (i < 64 + nstatus) status[i - 64] = 0;
+    else *last = 0;
+  }
+}
+// ... and the whole fill only behind a raised fall-back flag
+__global__ __launch_bounds__(256) void zero_gated_i32_kernel(int32_t* __restrict__ p, int64_t n,
+                                                            const int32_t* __restrict__ gate) {
+  if (*gate == 0) return;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0;
+}
+
 }  // namespace trs
 
 using namespace trs;
@@ -1307,11 +1326,16 @@ extern "C" int trs_csr_build(const void* idx, int32_t idx_dtype, const int64_t* 
                     max_items <= 16384;
   // one-pass scan: the status words hold 30-bit sums (B*N lookups in total) and are zeroed with the counters
   const bool onepass = (n + SCAN_TILE - 1) / SCAN_TILE <= 2048 && BN < ((int64_t)1 << 30);
-  hipLaunchKernelGGL(zero2_i32_kernel, dim3(stream_grid(n, 256, 1024)), dim3(256), 0, s, row_start, n, tile_sums,
-                     (int64_t)(onepass ? ntiles + 1 : 0));
+  static const bool lazy_zero = !(getenv("TRS_CSR_LAZY_ZERO") && getenv("TRS_CSR_LAZY_ZERO")[0] == '0');
+  if (part && lazy_zero)
+    hipLaunchKernelGGL(csr_zero_small_kernel, dim3(8), dim3(256), 0, s, flags, tile_sums, onepass ? ntiles + 1 : 0,
+                       row_start + V);
+  else
+    hipLaunchKernelGGL(zero2_i32_kernel, dim3(stream_grid(n, 256, 1024)), dim3(256), 0, s, row_start, n, tile_sums,
+                       (int64_t)(onepass ? ntiles + 1 : 0));
   const int32_t* gate = nullptr;
   if (part) {
-    zero_i32(flags, 64, s);
+    if (!lazy_zero) zero_i32(flags, 64, s);
     const int tiles = (int)((B + CSR2_TB - 1) / CSR2_TB);
     const size_t lds = (size_t)N * (CSR2_TB + 1) * 4;
     if (idx_dtype == TRS_I64)
@@ -1323,6 +1347,7 @@ extern "C" int trs_csr_build(const void* idx, int32_t idx_dtype, const int64_t* 
     hipLaunchKernelGGL((csr2_pass_kernel<false>), dim3((int)max_items), dim3(CSR2_THREADS), 0, s, rowT, offsets, B, N, V,
                        row_start, perm, flags, (int)chunk, 0);
     gate = flags;
+    if (lazy_zero) hipLaunchKernelGGL(zero_gated_i32_kernel, dim3(256), dim3(256), 0, s, row_start, n, gate);
   }
   if (BN > 0) {
     // behind the partitioned build these kernels normally exit at once: a small grid keeps them off the CUs (the
