@@ -85,6 +85,12 @@ def parse():
     ap.add_argument("--time-every", type=int, default=4,
                     help="bracket every n-th launch of the roofline kernel with HIP events (1 = all launches)")
     ap.add_argument("--force-sharded", action="store_true", help="use the row-sharded path even with one rank (test)")
+    ap.add_argument("--shard-graph", default="auto", choices=["auto", "whole", "region", "off"],
+                    help="row-sharded runs: what is replayed from a hipGraph.  region: the dense part of the step behind eager "
+                         "lookups / exchanges (cross-step pipeline on the communication stream); whole: the entire step, "
+                         "exchanges included, as ONE graph (no cross-step overlap: the exchanges run where the step needs "
+                         "them); auto = whole on one rank (no wire time to hide; the host leaves the critical path), region "
+                         "on more than one")
     ap.add_argument("--model", default="deepfm", choices=["deepfm", "fm", "dcn", "xdeepfm"],
                     help="deepfm = the headline metric (BASELINE configs[1]); dcn / xdeepfm = configs[2] / [3]")
     ap.add_argument("--no-tunableop", action="store_true", help="do not use PyTorch TunableOp for the nn.Linear GEMMs")
@@ -540,6 +546,7 @@ def run(a):
     torch.manual_seed(7)
     pipelined = False
     dense_graph = False
+    shard_whole = False
     if not sharded:
         emb = MultiIndicesEmbedding(embed_size=E, field_sizes=sizes, fuse_fm=not a.no_fuse)
         feat = MultiIndicesEmbedding(embed_size=1, field_sizes=sizes)
@@ -549,10 +556,17 @@ def run(a):
         if a.capacity == 0.0 and world > 1 and not a.dedup:
             a.capacity = 1.1       # default at N > 1: fixed-capacity slots -- equal all-to-all splits, no split size read on
         cap = a.capacity if a.capacity >= 1.0 else None        # the host (--capacity -1: exact, data-dependent splits)
-        pipelined = not a.no_pipeline and a.optimizer == "none" and (a.microbatches or 1) == 1
+        mode = a.shard_graph if a.shard_graph != "auto" else ("whole" if world == 1 else "region")
+        if a.eager:
+            mode = "off"
+        # whole: ONE graph per step, lookups and exchanges inside (a captured step must end with every stream joined, so
+        # nothing is left running across the step boundary: no cross-step pipeline)
+        shard_whole = (mode == "whole" and a.optimizer in ("none", "sgd") and (a.microbatches or 1) == 1 and not a.dedup
+                       and (world == 1 or a.capacity >= 1.0) and a.model in ("deepfm", "fm"))
+        pipelined = (not a.no_pipeline and a.optimizer == "none" and (a.microbatches or 1) == 1 and not shard_whole)
         # the dense part of the step (deep branch, head, loss and their backward) replayed from a hipGraph while the
         # lookups and their exchanges stay eager on the compute / communication streams (graph.GraphedRegion)
-        dense_graph = (not a.eager and a.optimizer == "none" and (a.microbatches or 1) == 1 and not a.no_fuse
+        dense_graph = (mode == "region" and a.optimizer == "none" and (a.microbatches or 1) == 1 and not a.no_fuse
                        and a.model in ("deepfm", "fm") and not a.dedup)
         emb = RowShardedMultiIndicesEmbedding(embed_size=E, field_sizes=sizes, fuse_fm=not a.no_fuse,
                                               dtype=dt, device=dev, dedup=a.dedup, capacity=cap,
@@ -733,7 +747,8 @@ def run(a):
         roof_kernel = "trs_embed_fm_fields"     # TRS_PAIR_FIRST_ORDER=1: the first-order lookup rides in the same launch
     want_graph = a.graph or (not a.eager and a.model in ("deepfm", "fm") and not a.host_indices
                              and not os.environ.get("TRS_BENCH_PHASES") and not os.environ.get("TRS_BENCH_CPROFILE"))
-    use_graph = want_graph and world == 1 and MB == 1 and not sharded and a.optimizer in ("none", "sgd")
+    use_graph = (want_graph and MB == 1 and a.optimizer in ("none", "sgd")
+                 and ((world == 1 and not sharded) or shard_whole))
     eager_step = step
     for _ in range(a.warmup if not use_graph else max(3, a.warmup // 2)):
         eager_step()
@@ -958,8 +973,11 @@ def run(a):
         _d.phase_events.clear()
         for kk in _d.wire_bytes:
             _d.wire_bytes[kk] = 0
+        if use_graph:             # phase events cannot be read out of a replayed graph: the same step, eagerly, for this leg
+            loss = None
+            gstep.release_outputs()
         for _ in range(6):
-            step()
+            (eager_step if use_graph else step)()
         torch.cuda.synchronize()
         ph = _d.phase_times_ms()
         _d.PROFILE = False
@@ -1076,6 +1094,8 @@ def run(a):
                        **({"hipgraph_scope": "dense region (deep branch, head, loss, their backward) replayed; lookups, "
                                              "exchanges and the dense all-reduce eager on the compute / communication streams"}
                           if (dense_graph and dense_ready[0]) else {}),
+                       **({"hipgraph_scope": "whole step (lookups, exchanges, dense part, backward) in one graph; no "
+                                             "cross-step overlap of the exchanges"} if (sharded and use_graph) else {}),
                        "indices_from_host": bool(host_idx),
                        "fused_lookup_fm": not a.no_fuse, "loss": final_loss,
                        "host_enqueue_ms_per_step": round(enqueue_s / a.steps * 1e3, 4),

@@ -414,6 +414,16 @@ int trs_bucket_by_owner(const void* idx, int32_t idx_dtype, const int64_t* offse
                         int64_t rows_per_rank, int32_t world, int64_t* counts, int32_t* send_ids,
                         int32_t* send_pos, int32_t* inv_pos, void* workspace, size_t ws_bytes,
                         trs_stream_t stream);
+/* Un-permute of the sharded lookup (step 5 of torecsys_amd/dist.py's forward) with the lookups this rank owns ITSELF read
+ * straight from its shard: slot s = inv_pos[p]; s in [self_lo, self_lo + self_n) -> row local[send_ids[s]] (ids outside
+ * [0, n_valid) read as zero rows and raise err_flag); every other slot -> back[s - (s >= self_lo + self_n ? self_n : 0)]
+ * (the received rows are stored WITHOUT the self segment: back_rows of them).  Writes emb (B,N,E), and -- optional, as
+ * trs_embed_fm -- the FM second-order term fm (B,E) and the fp32 field sums fm_sum (B,E).  New: the reference has no
+ * distributed code. */
+int trs_embed_fm_sharded(const void* back, int64_t back_rows, const void* local, int64_t local_rows, int64_t n_valid,
+                         int32_t E, int32_t dtype, const int32_t* inv_pos, const int32_t* send_ids, int32_t self_lo,
+                         int32_t self_n, int64_t B, int32_t N, void* emb, void* fm, float* fm_sum, int32_t* err_flag,
+                         trs_stream_t stream);
 /* out[pos[k],:] = rows[k,:]  (un-permute received rows into the (B*N,E) block) */
 int trs_scatter_by_pos(const void* rows, const int32_t* pos, int64_t K, int32_t E, int32_t dtype,
                        void* out, trs_stream_t stream);

@@ -30,11 +30,34 @@ class CpuOps:
         inv[order] = torch.arange(order.numel(), dtype=torch.int32)
         return counts, send_ids, send_pos, inv
 
-    def gather_local(self, weight, ids, n_valid=None, padded=False):
-        out = weight.detach()[ids.long().clamp(0, weight.shape[0] - 1)]
+    def gather_local(self, weight, ids, n_valid=None, padded=False, out=None):
+        res = weight.detach()[ids.long().clamp(0, weight.shape[0] - 1)]
         if n_valid is not None:
-            out = out * ((ids >= 0) & (ids < n_valid)).unsqueeze(-1).to(out.dtype)
-        return out
+            res = res * ((ids >= 0) & (ids < n_valid)).unsqueeze(-1).to(res.dtype)
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
+
+    def unpermute_local(self, back, weight, n_valid, inv_pos, send_ids, self_lo, self_n, B, N, want_fm, out=None):
+        """HipOps.unpermute_local: slots [self_lo, self_lo + self_n) read this rank's own shard, the others the received
+        rows, which are stored without that segment"""
+        from oracle import cpu_ref as O
+        s = inv_pos.long()
+        E = weight.shape[1]
+        is_local = (s >= self_lo) & (s < self_lo + self_n)
+        rows = torch.zeros(s.numel(), E, dtype=weight.dtype)
+        ids = send_ids.long()[s.clamp(0, max(send_ids.numel() - 1, 0))] if send_ids.numel() else torch.zeros_like(s)
+        ok = is_local & (ids >= 0) & (ids < n_valid)
+        rows[ok] = weight.detach()[ids[ok]]
+        rem = ~is_local
+        bi = s - (s >= self_lo + self_n).long() * self_n
+        if rem.any():
+            rows[rem] = back[bi[rem]]
+        block = rows.reshape(B, N, E)
+        if not want_fm:
+            return block, None, None
+        return block, O.fm_layer(block.float()).to(block.dtype), block.float().sum(1)
 
     def unique_route(self, idx, offsets, rows_per_rank, world):
         g = (idx.long() + offsets.view(1, -1)).reshape(-1)
@@ -81,13 +104,17 @@ class CpuOps:
             return block, None, None
         return block, O.fm_layer(block.float()).to(block.dtype), block.float().sum(1)
 
-    def permute_grad(self, g_block, send_pos, g_fm, fm_sum, block):
+    def permute_grad(self, g_block, send_pos, g_fm, fm_sum, block, out=None):
         if g_fm is not None:
             dx = g_fm.unsqueeze(1).float() * (fm_sum.unsqueeze(1) - block.float())
             g_block = dx.to(block.dtype) if g_block is None else g_block + dx.to(block.dtype)
         E = g_block.shape[-1]
-        out = g_block.reshape(-1, E)[send_pos.long().clamp_min(0)]
-        return out * (send_pos >= 0).unsqueeze(-1).to(out.dtype)          # padding slots: zero rows
+        res = g_block.reshape(-1, E)[send_pos.long().clamp_min(0)]
+        res = res * (send_pos >= 0).unsqueeze(-1).to(res.dtype)          # padding slots: zero rows
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
 
     def shard_grad_dense(self, weight, ids, grad_rows, padded=False):
         if padded:
@@ -207,6 +234,15 @@ def _run(world, *args):
 @pytest.mark.parametrize("world,fuse,sparse", [(2, False, False), (2, True, False), (2, True, True), (3, False, True)])
 def test_row_sharded_lookup_gloo(world, fuse, sparse):
     _run(world, fuse, sparse)
+
+
+@pytest.mark.parametrize("world,fuse,sparse,capacity", [(2, True, False, None), (3, False, True, None), (2, True, False, 2.0)])
+def test_row_sharded_lookup_through_the_buffers_gloo(world, fuse, sparse, capacity, monkeypatch):
+    """TRS_SHARD_LOCAL_DIRECT=0: the round-5 arrangement -- this rank's own lookups travel through the gather / exchange
+    buffers like everybody else's (the default since round 6 reads them straight from the shard: every other test here
+    runs that way) -- must keep producing the same block and gradients"""
+    monkeypatch.setenv("TRS_SHARD_LOCAL_DIRECT", "0")
+    _run(world, fuse, sparse, False, None, capacity)
 
 
 @pytest.mark.parametrize("world,fuse,sparse", [(2, False, False), (2, True, False), (3, True, True)])

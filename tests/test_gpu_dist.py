@@ -397,3 +397,54 @@ def test_cfg5_real_shard_one_rank(pg):
     assert torch.equal(rows, shard.index_select(0, mine.long()))
     del shard, rows
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,N,E,want_fm", [(700, 39, 64, True), (513, 7, 16, True), (300, 39, 1, False), (64, 5, 10, True),
+                                           (1, 1, 8, False)])
+def test_embed_fm_sharded_two_sources(pg, dtype, B, N, E, want_fm):
+    """trs_embed_fm_sharded alone, with BOTH sources in play (what a rank of a larger world sees; the world-1 module tests
+    only ever take the local branch): slots of a self segment in the middle of the exchange order read the shard through
+    send_ids, all others the received rows stored without that segment; block bit-exact against the same selection in
+    torch, FM / field sums against the oracle; an id outside the shard reads as a zero row and raises the index flag."""
+    from oracle import cpu_ref as O
+    from torecsys_amd import functional as F_
+    from torecsys_amd.dist import HipOps
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B + N + E)
+    K = B * N
+    V = 500
+    self_lo, self_n = K // 3, K // 4
+    perm = torch.randperm(K, generator=g)
+    inv_pos = perm.to(torch.int32)                                   # slot of every lookup
+    send_ids = torch.randint(0, V, (K,), generator=g).to(torch.int32)
+    shard = torch.randn(V, E, generator=g).to(dtype)
+    back = torch.randn(K - self_n, E, generator=g).to(dtype)
+    s = inv_pos.long()
+    is_self = (s >= self_lo) & (s < self_lo + self_n)
+    want = torch.empty(K, E, dtype=dtype)
+    want[is_self] = shard[send_ids.long()[s[is_self]]]
+    want[~is_self] = back[(s - (s >= self_lo + self_n).long() * self_n)[~is_self]]
+    F_.index_errors_seen()
+    ops = HipOps()
+    block, fm, fm_sum = ops.unpermute_local(back.to(dev), shard.to(dev), V, inv_pos.to(dev), send_ids.to(dev), self_lo,
+                                            self_n, B, N, want_fm)
+    torch.cuda.synchronize()
+    assert not F_.index_errors_seen()
+    assert torch.equal(block.cpu().reshape(K, E), want)
+    if want_fm:
+        ref = want.float().reshape(B, N, E)
+        tol = 1e-5 if dtype == torch.float32 else 1e-2
+        assert rel_err(fm.float().cpu(), O.fm_layer(ref)) <= tol
+        assert rel_err(fm_sum.cpu(), ref.sum(1)) <= 1e-5
+    # an id past the valid rows of the shard: zero row + flag
+    if self_n:
+        bad = send_ids.clone()
+        k_bad = int(s[is_self][0])
+        bad[k_bad] = V + 3
+        block2, _, _ = ops.unpermute_local(back.to(dev), shard.to(dev), V, inv_pos.to(dev), bad.to(dev), self_lo, self_n,
+                                           B, N, False)
+        torch.cuda.synchronize()
+        assert F_.index_errors_seen()
+        p_bad = int((s == k_bad).nonzero()[0])
+        assert float(block2.reshape(K, E)[p_bad].float().abs().max()) == 0.0

@@ -428,7 +428,7 @@ def test_deepfm_step_full_size(dev):
     le, ge, gr, g1 = _check_step("deepfm", logits[rows], ref.detach(), terms,
                                  emb.embedding.weight.grad[gid.to(dev)].float().cpu(), w.grad,
                                  feat.embedding.weight.grad[gid.to(dev)].float().cpu(), w1.grad, float(loss), loss_ref)
-    assert le <= TOL and ge <= TOL and gr <= TOL_ROWS_RELU and g1 <= TOL
+    assert le <= TOL and ge <= TOL and gr <= TOL and g1 <= TOL      # (measured 6e-3 per sample: no looser bound needed here)
 
 
 def test_dcn_step_full_size(dev):

@@ -130,6 +130,8 @@ SIGNATURES = {
     "trs_bce_logits_bwd": (c_int32, [_P, _I32, _P, _I32, _P, _I64, _P, _P]),
     "trs_bucket_workspace_bytes": (_SZ, [_I64, _I32]),
     "trs_bucket_by_owner": (c_int32, [_P, _I32, _P, _I64, _I32, _I64, _I32, _P, _P, _P, _P, _P, _SZ, _P]),
+    "trs_embed_fm_sharded": (c_int32, [_P, _I64, _P, _I64, _I64, _I32, _I32, _P, _P, _I32, _I32, _I64, _I32, _P, _P, _P, _P,
+                                       _P]),
     "trs_permute_grad": (c_int32, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _P]),
     "trs_scatter_by_pos": (c_int32, [_P, _P, _I64, _I32, _I32, _P, _P]),
     "trs_gather_by_pos": (c_int32, [_P, _P, _I64, _I32, _I32, _P, _P]),

@@ -1326,7 +1326,10 @@ extern "C" int trs_csr_build(const void* idx, int32_t idx_dtype, const int64_t* 
                     max_items <= 16384;
   // one-pass scan: the status words hold 30-bit sums (B*N lookups in total) and are zeroed with the counters
   const bool onepass = (n + SCAN_TILE - 1) / SCAN_TILE <= 2048 && BN < ((int64_t)1 << 30);
-  static const bool lazy_zero = !(getenv("TRS_CSR_LAZY_ZERO") && getenv("TRS_CSR_LAZY_ZERO")[0] == '0');
+  // TRS_CSR_LAZY_ZERO=1 (off by default): measured alternately on one box, DeepFM step 1.152-1.158 ms with the fill,
+  // 1.159-1.166 without (profiles/r06_logs/ab_csr_lazy_zero.txt): the fill's 54 us inside the step were time spent WAITING
+  // for wave slots beside the fused MLP backward, not work -- what replaces it on the side stream waits just the same
+  static const bool lazy_zero = getenv("TRS_CSR_LAZY_ZERO") && getenv("TRS_CSR_LAZY_ZERO")[0] == '1';
   if (part && lazy_zero)
     hipLaunchKernelGGL(csr_zero_small_kernel, dim3(8), dim3(256), 0, s, flags, tile_sums, onepass ? ntiles + 1 : 0,
                        row_start + V);

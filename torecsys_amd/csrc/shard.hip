@@ -74,6 +74,174 @@ __global__ void bucket_zero_kernel(unsigned long long* __restrict__ a, unsigned 
 
 static size_t align_up_s(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// ---- un-permute of the sharded lookup with the LOCALLY-OWNED lookups read straight from this rank's shard ------------
+// The requester's lookups are numbered in exchange order (slot s = inv_pos[p], grouped by owner).  The slots
+// [self_lo, self_lo + self_n) are the ones this rank owns itself: their rows never travel (no owner-side gather into a send
+// buffer, no all-to-all copy, no second read out of the receive buffer) -- the row is local[send_ids[s]].  Every other slot
+// reads the received rows, which are stored WITHOUT the self segment: back[s - (s >= self_lo + self_n ? self_n : 0)].
+// A local id outside [0, n_valid) (a global id past the table, the short last shard) reads as a zero row and raises
+// err_flag, exactly as the owner-side gather does for ids that arrive over the wire.
+// Same lane layout as embed_fm_group_kernel (fm.hip): L = E*s/16 lanes own a sample, four rows in flight, running sum and
+// sum of squares of the lane's own columns in registers; writes the (B,N,E) block, FM second order and the fp32 field sum.
+template <typename T, int LOG2L, bool STREAM>
+__global__ __launch_bounds__(256) void embed_fm_sharded_group_kernel(
+    const uint4* __restrict__ back, const uint4* __restrict__ local, const int32_t* __restrict__ inv_pos,
+    const int32_t* __restrict__ send_ids, int32_t self_lo, int32_t self_n, int64_t n_valid, int64_t B, int N,
+    uint4* __restrict__ emb, uint4* __restrict__ fm, float* __restrict__ fm_sum, int32_t* __restrict__ err_flag) {
+  constexpr int L = 1 << LOG2L;
+  constexpr int VE = Vec16<T>::VE;
+  constexpr int CH = 4;
+  const int lane_v = threadIdx.x & (L - 1);
+  const int32_t self_hi = self_lo + self_n;
+  const int64_t groups = ((int64_t)gridDim.x * blockDim.x) >> LOG2L;
+  for (int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> LOG2L; b < B; b += groups) {
+    float sm[VE], q[VE];
+#pragma unroll
+    for (int k = 0; k < VE; ++k) { sm[k] = 0.f; q[k] = 0.f; }
+    for (int n0 = 0; n0 < N; n0 += CH) {
+      int32_t sl[CH];
+      int64_t r[CH];       // >= 0: row of `back`;  <= -2: local row -2 - r;  -1: nothing to read (zero row)
+      uint4 v[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) sl[c] = n0 + c < N ? inv_pos[b * N + n0 + c] : -1;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        r[c] = -1;
+        if (n0 + c < N && sl[c] >= 0) {
+          if (sl[c] >= self_lo && sl[c] < self_hi) {
+            const int64_t id = send_ids[sl[c]];
+            if (id >= 0 && id < n_valid) r[c] = -2 - id;
+            else if (err_flag != nullptr) *err_flag = 1;
+          } else {
+            r[c] = sl[c] - (sl[c] >= self_hi ? self_n : 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        v[c] = make_uint4(0, 0, 0, 0);
+        if (r[c] >= 0) v[c] = back[r[c] * L + lane_v];
+        else if (r[c] <= -2) v[c] = STREAM ? load_stream(&local[(-2 - r[c]) * L + lane_v]) : local[(-2 - r[c]) * L + lane_v];
+      }
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int n = n0 + c;
+        if (n < N) {
+          float x[VE];
+          Vec16<T>::unpack(v[c], x);
+#pragma unroll
+          for (int k = 0; k < VE; ++k) { sm[k] += x[k]; q[k] = fmaf(x[k], x[k], q[k]); }
+          if (emb != nullptr) store_stream(&emb[(b * N + n) * L + lane_v], v[c]);
+        }
+      }
+    }
+    if (fm != nullptr) {
+      float o[VE];
+#pragma unroll
+      for (int k = 0; k < VE; ++k) o[k] = 0.5f * (sm[k] * sm[k] - q[k]);
+      fm[b * L + lane_v] = Vec16<T>::pack(o);
+    }
+    if (fm_sum != nullptr) {
+      float4* dst = reinterpret_cast<float4*>(fm_sum + (b * L + lane_v) * VE);
+#pragma unroll
+      for (int k = 0; k < VE; k += 4) dst[k / 4] = make_float4(sm[k], sm[k + 1], sm[k + 2], sm[k + 3]);
+    }
+  }
+}
+
+// any E (the E = 1 first-order table): one thread per element of the block; FM outputs (rare at such widths) by a
+// per-(b, e) loop over the fields
+template <typename T>
+__global__ __launch_bounds__(256) void gather_sharded_elem_kernel(
+    const T* __restrict__ back, const T* __restrict__ local, const int32_t* __restrict__ inv_pos,
+    const int32_t* __restrict__ send_ids, int32_t self_lo, int32_t self_n, int64_t n_valid, int64_t BN, int E,
+    T* __restrict__ emb, int32_t* __restrict__ err_flag) {
+  const int64_t total = BN * E, stride = (int64_t)gridDim.x * blockDim.x;
+  const int32_t self_hi = self_lo + self_n;
+  const bool f32 = total < ((int64_t)1 << 32);
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t p = udiv_fast(t, E, f32);
+    const int e = (int)(t - p * E);
+    const int32_t sl = inv_pos[p];
+    T val = T{};
+    if (sl >= 0) {
+      if (sl >= self_lo && sl < self_hi) {
+        const int64_t id = send_ids[sl];
+        if (id >= 0 && id < n_valid) val = local[id * E + e];
+        else if (err_flag != nullptr) *err_flag = 1;
+      } else {
+        val = back[(int64_t)(sl - (sl >= self_hi ? self_n : 0)) * E + e];
+      }
+    }
+    emb[t] = val;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void fm_of_block_elem_kernel(const T* __restrict__ x, int64_t B, int N, int E,
+                                                               T* __restrict__ fm, float* __restrict__ fm_sum) {
+  const int64_t total = B * E, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const int64_t b = t / E;
+    const int e = (int)(t - b * E);
+    float s = 0.f, q = 0.f;
+    for (int n = 0; n < N; ++n) {
+      const float v = to_f32(x[(b * N + n) * E + e]);
+      s += v;
+      q = fmaf(v, v, q);
+    }
+    if (fm != nullptr) fm[t] = from_f32<T>(0.5f * (s * s - q));
+    if (fm_sum != nullptr) fm_sum[t] = s;
+  }
+}
+
+template <typename T>
+static int embed_fm_sharded_launch(const void* back, const void* local, const int32_t* inv_pos, const int32_t* send_ids,
+                                   int32_t self_lo, int32_t self_n, int64_t n_valid, int64_t local_rows, int64_t B, int N,
+                                   int E, void* emb, void* fm, float* fm_sum, int32_t* err_flag, hipStream_t s) {
+  const int rb = E * (int)sizeof(T);
+  int lg = -1;
+  if (rb % 16 == 0 && is_pow2(rb / 16) && rb / 16 <= 64) {
+    lg = 0;
+    while ((1 << lg) < rb / 16) ++lg;
+  }
+  const bool al = aligned16(back) && aligned16(local) && aligned16(emb) && aligned16(fm) && aligned16(fm_sum);
+  if (lg >= 0 && al) {
+    const int L = 1 << lg;
+    const int grid = stream_grid(B * L, 256, 256 * 16);
+    const bool stream = (size_t)local_rows * rb > ((size_t)512 << 20);      // as embed_fm: a table far beyond the caches
+#define TRS_SH2(LG, ST)                                                                                               \
+  hipLaunchKernelGGL((embed_fm_sharded_group_kernel<T, LG, ST>), dim3(grid), dim3(256), 0, s, (const uint4*)back,     \
+                     (const uint4*)local, inv_pos, send_ids, self_lo, self_n, n_valid, B, N, (uint4*)emb, (uint4*)fm, \
+                     fm_sum, err_flag)
+#define TRS_SH(LG)      \
+  if (stream) {         \
+    TRS_SH2(LG, true);  \
+  } else {              \
+    TRS_SH2(LG, false); \
+  }
+    switch (lg) {
+      case 0: TRS_SH(0); break;
+      case 1: TRS_SH(1); break;
+      case 2: TRS_SH(2); break;
+      case 3: TRS_SH(3); break;
+      case 4: TRS_SH(4); break;
+      case 5: TRS_SH(5); break;
+      default: TRS_SH(6); break;
+    }
+#undef TRS_SH
+#undef TRS_SH2
+  } else {
+    if (emb == nullptr) return fail(TRS_EINVAL, "embed_fm_sharded: rows that are not whole 16-byte vectors need the block");
+    hipLaunchKernelGGL((gather_sharded_elem_kernel<T>), dim3(stream_grid(B * N * E, 256, 256 * 32)), dim3(256), 0, s,
+                       (const T*)back, (const T*)local, inv_pos, send_ids, self_lo, self_n, n_valid, B * N, E, (T*)emb,
+                       err_flag);
+    if (fm != nullptr || fm_sum != nullptr)
+      hipLaunchKernelGGL((fm_of_block_elem_kernel<T>), dim3(stream_grid(B * E, 256, 256 * 16)), dim3(256), 0, s,
+                         (const T*)emb, B, N, E, (T*)fm, fm_sum);
+  }
+  return check_launch("embed_fm_sharded");
+}
+
 }  // namespace trs
 
 using namespace trs;
@@ -116,4 +284,26 @@ extern "C" int trs_bucket_by_owner(const void* idx, int32_t idx_dtype, const int
                        rows_per_rank, world, cnt, cursor, send_ids, send_pos, inv_pos);
   }
   return check_launch("bucket_by_owner");
+}
+
+/* see include/trs_abi.h */
+extern "C" int trs_embed_fm_sharded(const void* back, int64_t back_rows, const void* local, int64_t local_rows,
+                                    int64_t n_valid, int32_t E, int32_t dtype, const int32_t* inv_pos,
+                                    const int32_t* send_ids, int32_t self_lo, int32_t self_n, int64_t B, int32_t N,
+                                    void* emb, void* fm, float* fm_sum, int32_t* err_flag, trs_stream_t stream) {
+  if (B == 0) return TRS_OK;
+  TRS_REQUIRE(inv_pos && (emb || fm || fm_sum), TRS_EINVAL, "embed_fm_sharded: NULL pointer");
+  TRS_REQUIRE(self_n == 0 || (local && send_ids), TRS_EINVAL, "embed_fm_sharded: a self segment needs the shard and send_ids");
+  TRS_REQUIRE(back_rows == 0 || back, TRS_EINVAL, "embed_fm_sharded: NULL receive buffer");
+  TRS_REQUIRE(E > 0 && N > 0 && B > 0 && self_lo >= 0 && self_n >= 0 && back_rows >= 0 && local_rows >= 0 &&
+                  n_valid >= 0 && n_valid <= local_rows,
+              TRS_EINVAL, "embed_fm_sharded: bad size");
+  TRS_REQUIRE(B * (int64_t)N < (int64_t)0x7fffffff, TRS_ESHAPE, "embed_fm_sharded: B*N must fit int32");
+  TRS_REQUIRE(dtype == TRS_F32 || dtype == TRS_BF16, TRS_EDTYPE, "embed_fm_sharded: dtype %d", dtype);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == TRS_F32)
+    return embed_fm_sharded_launch<float>(back, local, inv_pos, send_ids, self_lo, self_n, n_valid, local_rows, B, N, E, emb,
+                                          fm, fm_sum, err_flag, s);
+  return embed_fm_sharded_launch<bf16_t>(back, local, inv_pos, send_ids, self_lo, self_n, n_valid, local_rows, B, N, E, emb,
+                                         fm, fm_sum, err_flag, s);
 }

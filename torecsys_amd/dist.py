@@ -87,7 +87,7 @@ class HipOps:
         return counts, send_ids, send_pos, inv_pos
 
     def gather_local(self, weight: torch.Tensor, ids: torch.Tensor, n_valid: Optional[int] = None,
-                     padded: bool = False) -> torch.Tensor:
+                     padded: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """rows ``ids`` of this rank's shard.  Ids outside [0, n_valid) -- a global id past the table, a negative id,
         the short last shard -- read as zero rows and raise the device-side index flag
         (functional.index_errors_seen() / TRS_CHECK_INDICES=1) instead of touching foreign memory.
@@ -97,7 +97,8 @@ class HipOps:
             ids = ids.clamp_min(0)
         K = ids.numel()
         V, E = weight.shape
-        out = torch.empty(K, E, dtype=weight.dtype, device=weight.device)
+        if out is None:
+            out = torch.empty(K, E, dtype=weight.dtype, device=weight.device)
         if K:
             flag = F_._ErrFlag(weight.device)
             call("trs_gather_rows", ptr(weight), V if n_valid is None else min(V, n_valid), E, value_dtype_code(weight),
@@ -171,14 +172,36 @@ class HipOps:
                  ptr(None), B, N, ptr(block), ptr(fm), ptr(fm_sum), ptr(None), ptr(None), ptr(None), stream_ptr())
         return block, fm, fm_sum
 
-    def permute_grad(self, g_block: Optional[torch.Tensor], send_pos: torch.Tensor, g_fm, fm_sum, block):
+    def unpermute_local(self, back: torch.Tensor, weight: torch.Tensor, n_valid: int, inv_pos: torch.Tensor,
+                        send_ids: torch.Tensor, self_lo: int, self_n: int, B: int, N: int, want_fm: bool, out=None):
+        """``unpermute`` with the lookups this rank owns itself -- slots [self_lo, self_lo + self_n) of the exchange order --
+        read straight from its shard (trs_embed_fm_sharded); ``back`` holds the received rows WITHOUT that segment."""
+        E = weight.shape[1]
+        fm = fm_sum = None
+        if out is not None:
+            block, fm, fm_sum = out
+        else:
+            block = torch.empty(B, N, E, dtype=weight.dtype, device=weight.device)
+            if want_fm:
+                fm = torch.empty(B, E, dtype=weight.dtype, device=weight.device)
+                fm_sum = torch.empty(B, E, dtype=torch.float32, device=weight.device)
+        if B:
+            flag = F_._ErrFlag(weight.device)
+            call("trs_embed_fm_sharded", ptr(back if back.numel() else None), back.shape[0], ptr(weight), weight.shape[0],
+                 min(weight.shape[0], n_valid), E, value_dtype_code(weight), ptr(inv_pos), ptr(send_ids), int(self_lo),
+                 int(self_n), B, N, ptr(block), ptr(fm), ptr(fm_sum), ptr(flag.t), stream_ptr())
+            flag.check("sharded lookup")
+        return block, fm, fm_sum
+
+    def permute_grad(self, g_block: Optional[torch.Tensor], send_pos: torch.Tensor, g_fm, fm_sum, block, out=None):
         """rows of d(block) in exchange order: g_block[pos[k]] (+ g_fm*(S - x) when the FM term was fused) -- one
-        kernel (trs_permute_grad)."""
+        kernel (trs_permute_grad).  ``out``: (K, E) rows to write into."""
         B, N, E = block.shape
         K = send_pos.numel()
         gb = None if g_block is None else g_block.contiguous()
         gf = None if g_fm is None else g_fm.contiguous()
-        out = torch.empty(K, E, dtype=block.dtype, device=block.device)
+        if out is None:
+            out = torch.empty(K, E, dtype=block.dtype, device=block.device)
         if K:
             call("trs_permute_grad", ptr(gb), ptr(gf), ptr(fm_sum if gf is not None else None),
                  ptr(block if gf is not None else None), ptr(send_pos), K, N, E, value_dtype_code(block), ptr(out),
@@ -310,7 +333,22 @@ class RoutePlan:
     per-peer split sizes (host ints) and the local row ids every peer asked this rank for.  Tables looked up
     with the same index tensor (the E=64 embeddings and the E=1 first-order weights of one model) share it,
     so the bucketing, the count exchange (one host sync) and the id all-to-all happen once per batch."""
-    __slots__ = ("send_pos", "inv_pos", "send_splits", "recv_splits", "recv_ids", "cap", "event", "stream")
+    __slots__ = ("send_pos", "inv_pos", "send_splits", "recv_splits", "recv_ids", "cap", "event", "stream",
+                 "send_ids", "self_lo", "self_n", "recv_lo", "_owner_ids")
+
+    def owner_ids(self, local_direct: bool) -> torch.Tensor:
+        """the local row ids the owner-side reduction runs over, in the order of the gradient rows it receives: with
+        ``local_direct`` the rows that arrive over the wire (``recv_ids`` without this rank's own segment) followed by the
+        lookups this rank owns itself, whose gradient rows never travel; ``recv_ids`` otherwise"""
+        if not local_direct:
+            return self.recv_ids
+        if self._owner_ids is None:
+            lo, n, rlo = self.self_lo, self.self_n, self.recv_lo
+            if self.recv_ids.numel() == n:          # one rank: everything is local
+                self._owner_ids = self.send_ids[lo:lo + n]
+            else:
+                self._owner_ids = torch.cat([self.recv_ids[:rlo], self.recv_ids[rlo + n:], self.send_ids[lo:lo + n]])
+        return self._owner_ids
 
     def use_on(self, cur) -> None:
         """A plan built on the communication stream (prefetch_lookup) sits in the shared route cache: a later hit from
@@ -320,7 +358,7 @@ class RoutePlan:
         if ev is None or cur is None or cur == self.stream:
             return
         cur.wait_event(ev)
-        for t in (self.send_pos, self.inv_pos, self.recv_ids):
+        for t in (self.send_pos, self.inv_pos, self.recv_ids, self.send_ids, self._owner_ids):
             if t is not None and t.is_cuda:
                 t.record_stream(cur)
 
@@ -419,6 +457,7 @@ def _route_plan(idx: torch.Tensor, mod) -> "RoutePlan":
             pr = _start_route(idx, mod)
     p = RoutePlan()
     p.send_pos, p.inv_pos, p.cap = pr.send_pos, pr.inv_pos, 0
+    p.send_ids, p._owner_ids = pr.send_ids, None
     p.event, p.stream = None, (torch.cuda.current_stream(idx.device) if idx.is_cuda else None)
     if pr.host_counts is None and mod.world > 1:
         # fixed-capacity slots: equal splits, nothing to read on the host
@@ -440,16 +479,43 @@ def _route_plan(idx: torch.Tensor, mod) -> "RoutePlan":
         with _phase("id all-to-all", idx.device):
             _all_to_all(p.recv_ids, pr.send_ids, p.recv_splits, p.send_splits, mod.group)
         _count_wire("ids", p.send_splits, mod.rank, 4, 0, mod.world)
+    # this rank's own segment of the exchange order (send side) and where it sits among the ids it receives
+    if mod.world == 1:
+        p.self_lo, p.self_n, p.recv_lo = 0, int(pr.send_ids.numel()), 0
+    elif p.cap:
+        p.self_lo, p.self_n, p.recv_lo = mod.rank * p.cap, p.cap, mod.rank * p.cap
+    else:
+        p.self_lo, p.self_n = sum(p.send_splits[:mod.rank]), p.send_splits[mod.rank]
+        p.recv_lo = sum(p.recv_splits[:mod.rank])
     _route_cache.append((key, idx, p))
     if len(_route_cache) > 2:
         _route_cache.pop(0)
     return p
 
 
-def _exchange(out_rows: int, inp: torch.Tensor, out_splits, in_splits, mod) -> torch.Tensor:
-    """all-to-all of row blocks; a one-rank group hands the tensor through"""
+def _self_zero(splits, rank: int, world: int, cap: int):
+    """split sizes of an exchange whose self segment does not travel: the given per-peer sizes (or ``cap`` each) with
+    this rank's own entry zeroed"""
+    out = list(splits) if splits is not None else [cap] * world
+    out[rank] = 0
+    return out
+
+
+def _exchange(out_rows: int, inp: torch.Tensor, out_splits, in_splits, mod, zero_row: bool = False,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """all-to-all of row blocks; a one-rank group hands the tensor through.  ``zero_row`` (explicit splits): one more,
+    zeroed, row behind the received ones; ``out``: receive into this (out_rows, E) tensor."""
     if mod.world == 1:
         return inp
+    if out_splits is not None and (zero_row or out is not None):
+        if out is None:
+            buf = torch.empty(out_rows + 1, inp.shape[1], dtype=inp.dtype, device=inp.device)
+            buf[out_rows:].zero_()
+            out = buf[:out_rows]
+        else:
+            buf = out
+        _all_to_all(out, inp, out_splits, in_splits, mod.group)
+        return buf
     if out_splits is None:            # fixed-capacity slots: one more (zero) row behind the received ones for lookups
         buf = torch.empty(out_rows + 1, inp.shape[1], dtype=inp.dtype, device=inp.device)      # that did not fit
         buf[out_rows:].zero_()
@@ -460,13 +526,35 @@ def _exchange(out_rows: int, inp: torch.Tensor, out_splits, in_splits, mod) -> t
     return out
 
 
-def _fetch_rows(weight: torch.Tensor, idx: torch.Tensor, mod):
-    """Steps 1-4 of the forward: route plan, owner-side gather, rows back.  -> (plan, rows in exchange order)"""
+def _fetch_rows(weight: torch.Tensor, idx: torch.Tensor, mod, local: Optional[bool] = None):
+    """Steps 1-4 of the forward: route plan, owner-side gather, rows back.  -> (plan, rows in exchange order; with
+    ``local`` (default: the module's ``local_direct``) without this rank's own segment)"""
     ops = mod.ops
+    local = mod.local_direct if local is None else local
     plan = _route_plan(idx, mod)
     padded = plan.cap > 0
     n_valid = mod.row_range[1] - mod.row_range[0]
     row_bytes = weight.shape[1] * weight.element_size()
+    if local:
+        # the lookups this rank owns itself never travel: gathered for the OTHER requesters only, exchanged with a zero
+        # self split; forward reads its own rows straight from the shard (ops.unpermute_local)
+        n, rlo = plan.self_n, plan.recv_lo
+        Kr = plan.recv_ids.numel() - n
+        rows = torch.empty(Kr, weight.shape[1], dtype=weight.dtype, device=weight.device)
+        with _phase("owner gather", idx.device):
+            if rlo:
+                ops.gather_local(weight, plan.recv_ids[:rlo], n_valid, padded=padded, out=rows[:rlo])
+            if Kr - rlo:
+                ops.gather_local(weight, plan.recv_ids[rlo + n:], n_valid, padded=padded, out=rows[rlo:])
+        with _phase("row all-to-all (forward)", idx.device):
+            if mod.world == 1:
+                back = rows
+            else:
+                outs = _self_zero(plan.send_splits, mod.rank, mod.world, plan.cap)
+                ins = _self_zero(plan.recv_splits, mod.rank, mod.world, plan.cap)
+                back = _exchange(sum(outs), rows, outs, ins, mod, zero_row=padded)
+                _count_wire("rows_fwd", ins, mod.rank, row_bytes, 0, mod.world)
+        return plan, back
     with _phase("owner gather", idx.device):
         rows = ops.gather_local(weight, plan.recv_ids, n_valid, padded=True) if padded else \
             ops.gather_local(weight, plan.recv_ids, n_valid)                                    # rows of my shard
@@ -482,7 +570,7 @@ def _fetch_rows(weight: torch.Tensor, idx: torch.Tensor, mod):
 class _PrefetchedLookup:
     """rows of a batch fetched ahead of its forward (prefetch_lookup): the plan, the received rows, the event on the
     communication stream after which they are complete"""
-    __slots__ = ("plan", "back", "event", "version", "stale_ok")
+    __slots__ = ("plan", "back", "event", "version", "stale_ok", "local")
 
 
 _lookup_cache: List[tuple] = []      # [(key, idx kept alive, weight id, _PrefetchedLookup)]
@@ -511,7 +599,10 @@ def prefetch_lookup(idx: torch.Tensor, mod, stale_ok: bool = False) -> None:
         cs.wait_stream(torch.cuda.current_stream(idx.device))     # the indices (and any update of the shard) come first
     with _on_stream(cs), torch.no_grad():
         pl = _PrefetchedLookup()
-        pl.plan, pl.back = _fetch_rows(weight.detach(), idx, mod)
+        # an early lookup under a fused owner-side optimizer (stale_ok) must read EVERY row as of now -- one update behind,
+        # consistently: the rows this rank owns itself go through the buffers too instead of being read at forward time
+        pl.local = mod.local_direct and mod.fused_optimizer is None
+        pl.plan, pl.back = _fetch_rows(weight.detach(), idx, mod, pl.local)
         pl.event = None
         if cs is not None:
             pl.event = torch.cuda.Event()
@@ -549,30 +640,35 @@ class _ShardedLookup(Function):
         pl = _take_prefetched(idx, weight, mod)
         if pl is not None:
             lookup_stats["prefetched"] += 1
-            plan, back = pl.plan, pl.back
+            plan, back, local = pl.plan, pl.back, pl.local
             if pl.event is not None:
                 cur = torch.cuda.current_stream(idx.device)
                 cur.wait_event(pl.event)
-                for t in (back, plan.inv_pos, plan.send_pos, plan.recv_ids):      # made on the communication stream, used here
+                for t in (back, plan.inv_pos, plan.send_pos, plan.recv_ids, plan.send_ids):      # made on the communication stream, used here
                     if t is not None:
                         t.record_stream(cur)
         else:
             lookup_stats["inline"] += 1
             mod.order_after_grad()      # an owner-side update / reduction still running on the communication stream
-            plan, back = _fetch_rows(weight, idx, mod)
+            local = mod.local_direct
+            plan, back = _fetch_rows(weight, idx, mod, local)
         padded = plan.cap > 0
         with _phase("un-permute (+FM)", idx.device):
-            if mod.persistent_outputs:
-                block, fm, fm_sum = ops.unpermute(back, plan.inv_pos, B, N, mod.fuse_fm,
-                                                  out=mod.output_buffers(B, N, weight))
+            bufs = {"out": mod.output_buffers(B, N, weight)} if mod.persistent_outputs else {}
+            if local:
+                block, fm, fm_sum = ops.unpermute_local(back, weight.detach(), mod.row_range[1] - mod.row_range[0],
+                                                        plan.inv_pos, plan.send_ids, plan.self_lo, plan.self_n, B, N,
+                                                        mod.fuse_fm, **bufs)
             else:
-                block, fm, fm_sum = ops.unpermute(back, plan.inv_pos, B, N, mod.fuse_fm)
+                block, fm, fm_sum = ops.unpermute(back, plan.inv_pos, B, N, mod.fuse_fm, **bufs)
+        owner_ids = plan.owner_ids(local)
         if weight.shape[0] <= mod.dense_grad_max_rows and hasattr(ops, "prefetch_owner_buckets"):
-            ops.prefetch_owner_buckets(weight, plan.recv_ids, padded, pipelined=bool(mod.overlap_grad_exchange))
+            ops.prefetch_owner_buckets(weight, owner_ids, padded, pipelined=bool(mod.overlap_grad_exchange))
         ctx.mod = mod
         ctx.padded = padded
         ctx.splits = (plan.send_splits, plan.recv_splits)
-        ctx.save_for_backward(weight, plan.recv_ids, plan.send_pos if plan.send_pos is not None else plan.inv_pos,
+        ctx.local = (plan.self_lo, plan.self_n, plan.cap) if local else None
+        ctx.save_for_backward(weight, owner_ids, plan.send_pos if plan.send_pos is not None else plan.inv_pos,
                               block if mod.fuse_fm else None, fm_sum, back if mod.dedup else None)
         ctx.set_materialize_grads(False)
         if fm is None:
@@ -590,6 +686,8 @@ class _ShardedLookup(Function):
         if g_block is None and g_fm is None:
             return None, None, None
         dev = weight.device
+        if ctx.local is not None:
+            return _ShardedLookup._backward_local(ctx, g_block, g_fm, weight, recv_ids, pos, block, fm_sum)
         with _phase("permute gradient", dev):
             if mod.dedup:
                 # one gradient row per DISTINCT row of the local batch (duplicates summed before they travel)
@@ -634,6 +732,71 @@ class _ShardedLookup(Function):
                 mod._grad_event.record(cs)
         return gw, None, None
 
+    @staticmethod
+    def _owner_reduce(mod, weight, ids, rows, padded):
+        """the owner-side end of the gradient path: fused optimizer step, dense shard gradient or sparse COO gradient"""
+        ops = mod.ops
+        dense_index = weight.shape[0] <= mod.dense_grad_max_rows
+        pad_kw = {"padded": True} if padded else {}
+        if mod.fused_optimizer is not None:
+            # the owner steps its rows right here: no gradient tensor of any kind (weight.grad stays None)
+            ops.shard_update(weight, ids, rows, mod.fused_optimizer, dense_index, **pad_kw)
+            return None
+        if dense_index:
+            return ops.shard_grad_dense(weight, ids, rows, **pad_kw)
+        ids = ids.clamp_min(0) if padded else ids          # padding: zero rows added to row 0
+        return torch.sparse_coo_tensor(ids.long().unsqueeze(0), rows, size=weight.shape)
+
+    @staticmethod
+    def _backward_local(ctx, g_block, g_fm, weight, owner_ids, pos, block, fm_sum):
+        """backward with ``local_direct``: only the gradient rows of lookups OTHER ranks own are permuted into exchange
+        order and sent; the rows of this rank's own lookups are written straight behind the received ones (G = [rows that
+        arrived | own rows], the order of ``RoutePlan.owner_ids``) and the owner-side reduction runs over G."""
+        mod = ctx.mod
+        ops = mod.ops
+        dev = weight.device
+        lo, n, cap = ctx.local
+        send_splits, recv_splits = ctx.splits
+        if block is None:
+            block = g_block         # shape carrier only
+        gf = g_fm if mod.fuse_fm else None
+        E = block.shape[-1]
+        Ks = pos.numel()
+        Kr = owner_ids.numel() - n
+        G = torch.empty(Kr + n, E, dtype=block.dtype, device=dev)
+        g_send = None
+        with _phase("permute gradient", dev):
+            if Ks - n:
+                g_send = torch.empty(Ks - n, E, dtype=block.dtype, device=dev)
+                if lo:
+                    ops.permute_grad(g_block, pos[:lo], gf, fm_sum, block, out=g_send[:lo])
+                if Ks - n - lo:
+                    ops.permute_grad(g_block, pos[lo + n:], gf, fm_sum, block, out=g_send[lo:])
+            if n:
+                ops.permute_grad(g_block, pos[lo:lo + n], gf, fm_sum, block, out=G[Kr:])
+        cs = comm_stream(dev) if (mod.overlap_grad_exchange and weight.grad is None) else None
+        if cs is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            cs.wait_event(ev)
+            for t in (G, g_send, owner_ids):
+                if t is not None:
+                    t.record_stream(cs)
+        with _on_stream(cs):
+            if mod.world > 1:
+                with _phase("row all-to-all (gradient)", dev):
+                    ins = _self_zero(send_splits, mod.rank, mod.world, cap)       # what this rank sends back to each owner
+                    outs = _self_zero(recv_splits, mod.rank, mod.world, cap)      # what it receives as an owner
+                    _exchange(Kr, g_send, outs, ins, mod, out=G[:Kr])
+                _count_wire("rows_bwd", ins, mod.rank, E * G.element_size(), 0, mod.world)
+            wire_bytes["steps"] += 1
+            with _phase("owner reduce / update", dev):
+                gw = _ShardedLookup._owner_reduce(mod, weight, owner_ids, G, ctx.padded)
+            if cs is not None:
+                mod._grad_event = torch.cuda.Event()
+                mod._grad_event.record(cs)
+        return gw, None, None
+
 
 class RowShardedMultiIndicesEmbedding(BaseInput):
     """``MultiIndicesEmbedding`` (multi_indices_emb.py:18-112) with the table row-sharded over the process
@@ -646,7 +809,7 @@ class RowShardedMultiIndicesEmbedding(BaseInput):
                  dtype: torch.dtype = torch.float32, device='cpu', process_group=None, ops=None,
                  dense_grad_max_rows: int = DENSE_GRAD_MAX_ROWS, dedup: bool = False,
                  capacity: Optional[float] = None, overlap_grad_exchange: bool = False,
-                 persistent_outputs: bool = False):
+                 persistent_outputs: bool = False, local_direct: Optional[bool] = None):
         super().__init__()
         if not dist.is_initialized():
             raise RuntimeError("RowShardedMultiIndicesEmbedding needs torch.distributed to be initialised")
@@ -681,6 +844,13 @@ class RowShardedMultiIndicesEmbedding(BaseInput):
         self._out_bufs = {}
         self._grad_event = None
         self._caps = {}
+        # local_direct: lookups this rank owns itself are read straight from its shard by the un-permute kernel and their
+        # gradient rows are written straight into the owner-side reduction's input -- no gather into a send buffer, no
+        # self copy inside the all-to-alls (TRS_SHARD_LOCAL_DIRECT=0: everything through the exchange buffers, the round-5
+        # arrangement; dedup keeps it: its backward needs the received rows of every distinct id)
+        self.local_direct = bool(local_direct if local_direct is not None else
+                                 __import__("os").environ.get("TRS_SHARD_LOCAL_DIRECT", "1") != "0") \
+            and hasattr(self.ops, "unpermute_local") and not self.dedup
         self.route_key = (tuple(int(f) for f in field_sizes), self.world, id(process_group), self.dedup, self.capacity)
         self.length = embed_size * len(field_sizes) if flatten else embed_size
 
