@@ -116,6 +116,31 @@ class CpuOps:
             return out
         return res
 
+    def prefetch_own_buckets(self, weight, idx, offsets_local):
+        pass
+
+    def own_grad_dense(self, weight, idx, offsets_local, g_block, g_fm, fm_sum):
+        """HipOps.own_grad_dense: dense gradient of the lookups that land inside this rank's shard, straight from the
+        block gradient with the FM term folded in (x = the table row itself)"""
+        V, E = weight.shape
+        B, N = idx.shape
+        r = (idx.long() + offsets_local.view(1, -1)).reshape(-1)
+        ok = (r >= 0) & (r < V)
+        g = torch.zeros(B * N, E) if g_block is None else g_block.reshape(-1, E).float().clone()
+        if g_fm is not None:
+            x = torch.zeros(B * N, E)
+            x[ok] = weight.detach()[r[ok]].float()
+            g = g + (g_fm.unsqueeze(1).float() * (fm_sum.unsqueeze(1) - x.reshape(B, N, E))).reshape(-1, E)
+        out = torch.zeros(V, E)
+        out.index_add_(0, r[ok], g[ok])
+        return out.to(weight.dtype)
+
+    def accumulate_rows(self, gw, ids, rows, padded=False):
+        if padded:
+            keep = ids >= 0
+            ids, rows = ids[keep], rows[keep]
+        gw.index_add_(0, ids.long(), rows.to(gw.dtype))
+
     def shard_grad_dense(self, weight, ids, grad_rows, padded=False):
         if padded:
             keep = ids >= 0
@@ -243,6 +268,15 @@ def test_row_sharded_lookup_through_the_buffers_gloo(world, fuse, sparse, capaci
     runs that way) -- must keep producing the same block and gradients"""
     monkeypatch.setenv("TRS_SHARD_LOCAL_DIRECT", "0")
     _run(world, fuse, sparse, False, None, capacity)
+
+
+@pytest.mark.parametrize("world,fuse,capacity", [(2, True, None), (3, False, None), (2, True, 2.0)])
+def test_row_sharded_lookup_own_rows_permuted_gloo(world, fuse, capacity, monkeypatch):
+    """TRS_SHARD_OWN_DIRECT=0: dense shard gradient with this rank's own gradient rows permuted behind the received ones
+    and reduced together (the path a fused optimizer or a sparse gradient always takes) instead of the default, the
+    unsharded backward on the rank's own lookups + accumulation of what arrived"""
+    monkeypatch.setenv("TRS_SHARD_OWN_DIRECT", "0")
+    _run(world, fuse, False, False, None, capacity)
 
 
 @pytest.mark.parametrize("world,fuse,sparse", [(2, False, False), (2, True, False), (3, True, True)])

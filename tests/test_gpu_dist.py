@@ -448,3 +448,55 @@ def test_embed_fm_sharded_two_sources(pg, dtype, B, N, E, want_fm):
         assert F_.index_errors_seen()
         p_bad = int((s == k_bad).nonzero()[0])
         assert float(block2.reshape(K, E)[p_bad].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,fuse", [(4096, True), (4096, False), (300, True)])
+def test_own_grad_dense_as_a_middle_rank(pg, dtype, B, fuse):
+    """HipOps.own_grad_dense / accumulate_rows as rank 1 of 3 would run them (the world-1 module tests only see a shard
+    that starts at row 0): field offsets shifted by the shard's first row -- fields below the shard start at negative
+    rows, one field straddles each end, fields above lie past its last row -- so lookups of other ranks' rows must be
+    skipped by the per-field bucket build (B >= 2048: the LDS-counter form with chunks cut from the clamped ranges) and
+    the walk must fold the FM term with the shard's own rows; then gradient rows 'from the wire' are added on top."""
+    from oracle import cpu_ref as O
+    from torecsys_amd.dist import HipOps, shard_ranges
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(17 + B)
+    N, E = 12, 64
+    fs = [700 + 37 * i for i in range(N)]
+    V = sum(fs)
+    per, ranges = shard_ranges(V, 3)
+    lo, hi = ranges[1]
+    off = O.field_offsets(fs)
+    idx = torch.cat([torch.randint(0, f, (B, 1), generator=g) for f in fs], 1)
+    shard = torch.randn(hi - lo, E, generator=g).to(dtype)
+    g_block = torch.randn(B, N, E, generator=g).to(dtype)
+    g_fm = torch.randn(B, E, generator=g).to(dtype) if fuse else None
+    gid = (idx + off.view(1, N)).reshape(-1)
+    own = (gid >= lo) & (gid < hi)
+    assert 0 < int(own.sum()) < B * N
+    # the block as the forward would have produced it matters only through fm_sum (the sum over ALL fields of a sample):
+    # any values do for this test
+    fm_sum = torch.randn(B, E, generator=g) if fuse else None
+    ops = HipOps()
+    gw = ops.own_grad_dense(shard.to(dev).requires_grad_(), idx.to(dev), (off - lo).to(dev), g_block.to(dev),
+                            None if g_fm is None else g_fm.to(dev), None if fm_sum is None else fm_sum.to(dev))
+    rows = gid[own] - lo
+    contrib = g_block.reshape(-1, E)[own].float()
+    if fuse:
+        b_of = (torch.arange(B * N) // N)[own]
+        contrib = contrib + g_fm.float()[b_of] * (fm_sum[b_of] - shard.float()[rows])
+    want = torch.zeros(hi - lo, E).index_add_(0, rows, contrib)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_err(gw.float().cpu(), want) <= tol
+    untouched = torch.ones(hi - lo, dtype=torch.bool)
+    untouched[rows] = False
+    assert float(gw.float().cpu()[untouched].abs().max()) == 0.0
+    # rows that arrived over the wire: added on top (with repeats)
+    K = 5000
+    ids = torch.randint(0, hi - lo, (K,), generator=g).to(torch.int32)
+    wire = torch.randn(K, E, generator=g).to(dtype)
+    base = gw.float().cpu().clone()
+    ops.accumulate_rows(gw, ids.to(dev), wire.to(dev))
+    want2 = base.index_add_(0, ids.long(), wire.float())
+    assert rel_err(gw.float().cpu(), want2) <= tol

@@ -264,20 +264,26 @@ constexpr int CSR2_COPIES = 16;
 constexpr int CSR2_TB = 128;           // samples per transpose tile
 constexpr int CSR2_MAX_FIELDS = 120;   // transpose tile (N x 129 int32) stays under 64 KB
 
+// Field ranges may reach outside [0, V): the owner-side build of a row-sharded table passes offsets shifted by the first
+// row of its shard (fields below the shard start at negative rows, fields above it past V); lookups that land outside
+// are skipped by the row-id pass, and the chunks are cut from the part of every field's range that lies inside.
+__device__ __forceinline__ int64_t csr2_clamp(int64_t r, int64_t V) { return r < 0 ? 0 : (r > V ? V : r); }
+
 template <typename IdxT>
 __global__ __launch_bounds__(256) void csr2_rowid_kernel(const IdxT* __restrict__ idx,
                                                          const int64_t* __restrict__ offsets, int64_t B, int N,
                                                          int64_t V, int32_t* __restrict__ rowT,
                                                          int32_t* __restrict__ flags, int32_t* __restrict__ err_flag,
-                                                         int max_items, int chunk) {
+                                                         int max_items, int chunk, int need_cover) {
   extern __shared__ int32_t tile[];     // [N][CSR2_TB + 1]
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     int64_t items = 0;
     for (int n = 0; n < N; ++n) {
-      const int64_t lo = offsets[n], hi = n + 1 < N ? offsets[n + 1] : V;
+      const int64_t lo = csr2_clamp(offsets[n], V), hi = n + 1 < N ? csr2_clamp(offsets[n + 1], V) : V;
       if (hi > lo) items += (hi - lo + chunk - 1) / chunk;
     }
-    if (items > max_items || offsets[0] != 0) flags[0] = 1;      // (rows in front of the first field: covered by no chunk)
+    // need_cover (the build that does not zero the counters first): rows in front of the first field belong to no chunk
+    if (items > max_items || (need_cover && offsets[0] > 0)) flags[0] = 1;
   }
   const int64_t b0 = (int64_t)blockIdx.x * CSR2_TB;
   const int nb = (int)((B - b0) < CSR2_TB ? (B - b0) : CSR2_TB);
@@ -306,7 +312,7 @@ __device__ __forceinline__ bool csr2_item(const int64_t* __restrict__ offsets, i
                                           int* field, int64_t* base, int* len) {
   int64_t acc = 0;
   for (int n = 0; n < N; ++n) {
-    const int64_t lo = offsets[n], hi = n + 1 < N ? offsets[n + 1] : V;
+    const int64_t lo = csr2_clamp(offsets[n], V), hi = n + 1 < N ? csr2_clamp(offsets[n + 1], V) : V;
     if (hi <= lo) continue;
     const int64_t nch = (hi - lo + chunk - 1) / chunk;
     if (item < acc + nch) {
@@ -1343,10 +1349,10 @@ extern "C" int trs_csr_build(const void* idx, int32_t idx_dtype, const int64_t* 
     const size_t lds = (size_t)N * (CSR2_TB + 1) * 4;
     if (idx_dtype == TRS_I64)
       hipLaunchKernelGGL((csr2_rowid_kernel<int64_t>), dim3(tiles), dim3(256), lds, s, (const int64_t*)idx, offsets, B,
-                         N, V, rowT, flags, err_flag, (int)max_items, (int)chunk);
+                         N, V, rowT, flags, err_flag, (int)max_items, (int)chunk, lazy_zero ? 1 : 0);
     else
       hipLaunchKernelGGL((csr2_rowid_kernel<int32_t>), dim3(tiles), dim3(256), lds, s, (const int32_t*)idx, offsets, B,
-                         N, V, rowT, flags, err_flag, (int)max_items, (int)chunk);
+                         N, V, rowT, flags, err_flag, (int)max_items, (int)chunk, lazy_zero ? 1 : 0);
     hipLaunchKernelGGL((csr2_pass_kernel<false>), dim3((int)max_items), dim3(CSR2_THREADS), 0, s, rowT, offsets, B, N, V,
                        row_start, perm, flags, (int)chunk, 0);
     gate = flags;

@@ -7,6 +7,28 @@ namespace trs {
 constexpr int MAX_WORLD = 256;
 constexpr int CHUNK = 4096;  // positions per workgroup in the fill pass
 
+// hist[w] += 1 for every active lane, returning the value each lane's own atomic would have returned -- with ONE LDS
+// atomic per distinct owner in the wave instead of one per lane: the lanes of a wave hit at most `world` different
+// counters (a single one on a one-rank group), and an LDS atomic on one address retires about one lane per clock.  The
+// loop runs once per distinct owner among the wave's lanes; every ballot / shuffle is executed by the whole wave.
+__device__ __forceinline__ int wave_agg_inc(int* hist, int w, bool active) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long todo = __ballot(active);
+  int res = 0;
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int w0 = __shfl(w, leader, 64);
+    const bool mine = active && w == w0;
+    const unsigned long long m = __ballot(mine);
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&hist[w0], __popcll(m));
+    base = __shfl(base, leader, 64);
+    if (mine) res = base + __popcll(m & ((1ull << lane) - 1ull));
+    todo &= ~m;
+  }
+  return res;
+}
+
 template <typename IdxT>
 __global__ __launch_bounds__(256) void bucket_count_kernel(const IdxT* __restrict__ idx,
                                                            const int64_t* __restrict__ offsets, int64_t BN, int N,
@@ -15,11 +37,16 @@ __global__ __launch_bounds__(256) void bucket_count_kernel(const IdxT* __restric
   for (int w = threadIdx.x; w < W; w += blockDim.x) hist[w] = 0;
   __syncthreads();
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < BN; p += stride) {
-    const int64_t r = load_row_id(idx, offsets, p, (int)((uint64_t)p < ((uint64_t)1 << 32) ? (unsigned)p % (unsigned)N : p % N));
-    int w = (int)(r / per);
-    w = w < 0 ? 0 : (w >= W ? W - 1 : w);
-    atomicAdd(&hist[w], 1);
+  for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x; p0 < BN; p0 += stride) {      // (uniform trip count per wave)
+    const int64_t p = p0 + threadIdx.x;
+    const bool active = p < BN;
+    int w = 0;
+    if (active) {
+      const int64_t r = load_row_id(idx, offsets, p, (int)((uint64_t)p < ((uint64_t)1 << 32) ? (unsigned)p % (unsigned)N : p % N));
+      w = (int)(r / per);
+      w = w < 0 ? 0 : (w >= W ? W - 1 : w);
+    }
+    wave_agg_inc(hist, w, active);
   }
   __syncthreads();
   for (int w = threadIdx.x; w < W; w += blockDim.x)
@@ -39,11 +66,16 @@ __global__ __launch_bounds__(256) void bucket_fill_kernel(const IdxT* __restrict
   const int64_t p1 = p0 + CHUNK < BN ? p0 + CHUNK : BN;
   for (int w = threadIdx.x; w < W; w += blockDim.x) hist[w] = 0;
   __syncthreads();
-  for (int64_t p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
-    const int64_t r = load_row_id(idx, offsets, p, (int)((uint64_t)p < ((uint64_t)1 << 32) ? (unsigned)p % (unsigned)N : p % N));
-    int w = (int)(r / per);
-    w = w < 0 ? 0 : (w >= W ? W - 1 : w);
-    atomicAdd(&hist[w], 1);
+  for (int64_t q0 = p0; q0 < p1; q0 += blockDim.x) {
+    const int64_t p = q0 + threadIdx.x;
+    const bool active = p < p1;
+    int w = 0;
+    if (active) {
+      const int64_t r = load_row_id(idx, offsets, p, (int)((uint64_t)p < ((uint64_t)1 << 32) ? (unsigned)p % (unsigned)N : p % N));
+      w = (int)(r / per);
+      w = w < 0 ? 0 : (w >= W ? W - 1 : w);
+    }
+    wave_agg_inc(hist, w, active);
   }
   __syncthreads();
   if (threadIdx.x < W) {
@@ -55,14 +87,23 @@ __global__ __launch_bounds__(256) void bucket_fill_kernel(const IdxT* __restrict
   __syncthreads();
   for (int w = threadIdx.x; w < W; w += blockDim.x) hist[w] = 0;
   __syncthreads();
-  for (int64_t p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
-    const int64_t r = load_row_id(idx, offsets, p, (int)((uint64_t)p < ((uint64_t)1 << 32) ? (unsigned)p % (unsigned)N : p % N));
-    int w = (int)(r / per);
-    w = w < 0 ? 0 : (w >= W ? W - 1 : w);
-    const long long slot = base[w] + atomicAdd(&hist[w], 1);
-    send_ids[slot] = (int32_t)(r - (int64_t)w * per);
-    send_pos[slot] = (int32_t)p;
-    if (inv_pos) inv_pos[p] = (int32_t)slot;
+  for (int64_t q0 = p0; q0 < p1; q0 += blockDim.x) {
+    const int64_t p = q0 + threadIdx.x;
+    const bool active = p < p1;
+    int w = 0;
+    int64_t r = 0;
+    if (active) {
+      r = load_row_id(idx, offsets, p, (int)((uint64_t)p < ((uint64_t)1 << 32) ? (unsigned)p % (unsigned)N : p % N));
+      w = (int)(r / per);
+      w = w < 0 ? 0 : (w >= W ? W - 1 : w);
+    }
+    const int k = wave_agg_inc(hist, w, active);
+    if (active) {
+      const long long slot = base[w] + k;
+      send_ids[slot] = (int32_t)(r - (int64_t)w * per);
+      send_pos[slot] = (int32_t)p;
+      if (inv_pos) inv_pos[p] = (int32_t)slot;
+    }
   }
 }
 

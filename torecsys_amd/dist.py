@@ -208,10 +208,48 @@ class HipOps:
                  stream_ptr())
         return out
 
+    # ---- dense shard gradient with the lookups this rank owns itself reduced STRAIGHT from the block gradient: the
+    # unsharded backward (functional._EmbedFM.backward) on this rank's rows -- per-field LDS-counter bucket build started at
+    # forward time on the side stream, one bucket walk with the FM term folded in -- instead of permute (1 GB of traffic at
+    # the BASELINE shape) + a global-atomic bucket build over ids without field structure + a plain walk.
+    def prefetch_own_buckets(self, weight: torch.Tensor, idx: torch.Tensor, offsets_local: torch.Tensor) -> None:
+        if weight.requires_grad:
+            F_.prefetch_row_buckets(idx, offsets_local, weight.shape[0], check=False)
+
+    def own_grad_dense(self, weight: torch.Tensor, idx: torch.Tensor, offsets_local: torch.Tensor, g_block, g_fm,
+                       fm_sum) -> torch.Tensor:
+        """``offsets_local`` = field offsets minus the first row of the shard: a lookup of another rank's row lands
+        outside [0, rows of the shard) and is skipped (check=False: no index flag for those)"""
+        rb = F_.row_buckets(idx, offsets_local, weight.shape[0], check=False)
+        if g_fm is not None:
+            return F_.scatter_rows(rb, weight, g_rows=None if g_block is None else g_block.contiguous(),
+                                   g_bcast=F_._fm_grad_operand(g_fm), fm_sum=fm_sum)
+        return F_.scatter_rows(rb, weight, g_rows=g_block.contiguous())
+
+    def accumulate_rows(self, gw: torch.Tensor, ids: torch.Tensor, rows: torch.Tensor, padded: bool = False) -> None:
+        """gw[ids[k]] += rows[k] (fp32 sums per row, one read-modify-write per touched row): the gradient rows that
+        arrived over the wire, added to the dense gradient of this rank's own lookups"""
+        if ids.numel() == 0:
+            return
+        rb = F_.row_buckets(ids.view(-1, 1), None, gw.shape[0], check=not padded)
+        with torch.no_grad():
+            F_.scatter_rows_update(rb, gw, _ACCUMULATE, g_rows=rows.contiguous(), key=gw)
+
     def shard_grad_dense(self, weight: torch.Tensor, ids: torch.Tensor, grad_rows: torch.Tensor,
                          padded: bool = False) -> torch.Tensor:
         rb = F_.row_buckets(ids.view(-1, 1), None, weight.shape[0], check=not padded)
         return F_.scatter_rows(rb, weight, g_rows=grad_rows.contiguous())
+
+
+class _Accumulate:
+    """the fused-SGD row sink with lr = -1: w[r] -= lr * g[r] adds the reduced rows into the table it is pointed at"""
+    kind, lr, eps = 1, -1.0, 0.0
+
+    def state_for(self, table, key=None):
+        return None
+
+
+_ACCUMULATE = _Accumulate()
 
 
 def shard_ranges(num_rows: int, world: int):
@@ -262,6 +300,11 @@ class _on_stream:
 PROFILE = __import__("os").environ.get("TRS_DIST_PROFILE", "0") == "1"
 phase_events = {}       # phase -> [(start event, end event)]   (TRS_DIST_PROFILE=1; read by phase_times_ms())
 wire_bytes = {"ids": 0, "rows_fwd": 0, "rows_bwd": 0, "steps": 0}      # bytes this rank SENT to other ranks
+
+
+def _pn(name: str, weight: torch.Tensor) -> str:
+    """phase name with the table's width: the E = 64 table and its E = 1 first-order companion are timed apart"""
+    return f"{name} [E={weight.shape[1]}]" if PROFILE else name
 
 
 class _phase:
@@ -541,12 +584,12 @@ def _fetch_rows(weight: torch.Tensor, idx: torch.Tensor, mod, local: Optional[bo
         n, rlo = plan.self_n, plan.recv_lo
         Kr = plan.recv_ids.numel() - n
         rows = torch.empty(Kr, weight.shape[1], dtype=weight.dtype, device=weight.device)
-        with _phase("owner gather", idx.device):
+        with _phase(_pn("owner gather", weight), idx.device):
             if rlo:
                 ops.gather_local(weight, plan.recv_ids[:rlo], n_valid, padded=padded, out=rows[:rlo])
             if Kr - rlo:
                 ops.gather_local(weight, plan.recv_ids[rlo + n:], n_valid, padded=padded, out=rows[rlo:])
-        with _phase("row all-to-all (forward)", idx.device):
+        with _phase(_pn("row all-to-all (forward)", weight), idx.device):
             if mod.world == 1:
                 back = rows
             else:
@@ -555,10 +598,10 @@ def _fetch_rows(weight: torch.Tensor, idx: torch.Tensor, mod, local: Optional[bo
                 back = _exchange(sum(outs), rows, outs, ins, mod, zero_row=padded)
                 _count_wire("rows_fwd", ins, mod.rank, row_bytes, 0, mod.world)
         return plan, back
-    with _phase("owner gather", idx.device):
+    with _phase(_pn("owner gather", weight), idx.device):
         rows = ops.gather_local(weight, plan.recv_ids, n_valid, padded=True) if padded else \
             ops.gather_local(weight, plan.recv_ids, n_valid)                                    # rows of my shard
-    with _phase("row all-to-all (forward)", idx.device):
+    with _phase(_pn("row all-to-all (forward)", weight), idx.device):
         if padded:
             back = _exchange(plan.recv_ids.numel(), rows, None, None, mod)
         else:
@@ -653,7 +696,7 @@ class _ShardedLookup(Function):
             local = mod.local_direct
             plan, back = _fetch_rows(weight, idx, mod, local)
         padded = plan.cap > 0
-        with _phase("un-permute (+FM)", idx.device):
+        with _phase(_pn("un-permute (+FM)", weight), idx.device):
             bufs = {"out": mod.output_buffers(B, N, weight)} if mod.persistent_outputs else {}
             if local:
                 block, fm, fm_sum = ops.unpermute_local(back, weight.detach(), mod.row_range[1] - mod.row_range[0],
@@ -661,15 +704,27 @@ class _ShardedLookup(Function):
                                                         mod.fuse_fm, **bufs)
             else:
                 block, fm, fm_sum = ops.unpermute(back, plan.inv_pos, B, N, mod.fuse_fm, **bufs)
+        # own_direct: dense shard gradient, no fused optimizer -- this rank's own lookups are reduced straight from the
+        # block gradient by the unsharded backward (ops.own_grad_dense); only rows that arrived over the wire go through
+        # the permuted / exchanged path
+        own_direct = (local and mod.fused_optimizer is None and weight.shape[0] <= mod.dense_grad_max_rows
+                      and hasattr(ops, "own_grad_dense") and mod.own_direct)
         owner_ids = plan.owner_ids(local)
-        if weight.shape[0] <= mod.dense_grad_max_rows and hasattr(ops, "prefetch_owner_buckets"):
+        if own_direct:
+            remote_ids = owner_ids[: owner_ids.numel() - plan.self_n]
+            ops.prefetch_own_buckets(weight, idx, mod.offsets_local)
+            if remote_ids.numel() and hasattr(ops, "prefetch_owner_buckets"):
+                ops.prefetch_owner_buckets(weight, remote_ids, padded, pipelined=bool(mod.overlap_grad_exchange))
+        elif weight.shape[0] <= mod.dense_grad_max_rows and hasattr(ops, "prefetch_owner_buckets"):
             ops.prefetch_owner_buckets(weight, owner_ids, padded, pipelined=bool(mod.overlap_grad_exchange))
         ctx.mod = mod
         ctx.padded = padded
         ctx.splits = (plan.send_splits, plan.recv_splits)
         ctx.local = (plan.self_lo, plan.self_n, plan.cap) if local else None
+        ctx.own_direct = own_direct
         ctx.save_for_backward(weight, owner_ids, plan.send_pos if plan.send_pos is not None else plan.inv_pos,
-                              block if mod.fuse_fm else None, fm_sum, back if mod.dedup else None)
+                              block if mod.fuse_fm else None, fm_sum, back if mod.dedup else None,
+                              idx if own_direct else None)
         ctx.set_materialize_grads(False)
         if fm is None:
             fm = torch.empty(0, dtype=block.dtype, device=block.device)
@@ -681,14 +736,14 @@ class _ShardedLookup(Function):
     def backward(ctx, g_block, g_fm):
         mod = ctx.mod
         ops = mod.ops
-        weight, recv_ids, pos, block, fm_sum, back = ctx.saved_tensors
+        weight, recv_ids, pos, block, fm_sum, back, idx = ctx.saved_tensors
         send_splits, recv_splits = ctx.splits
         if g_block is None and g_fm is None:
             return None, None, None
         dev = weight.device
         if ctx.local is not None:
-            return _ShardedLookup._backward_local(ctx, g_block, g_fm, weight, recv_ids, pos, block, fm_sum)
-        with _phase("permute gradient", dev):
+            return _ShardedLookup._backward_local(ctx, g_block, g_fm, weight, recv_ids, pos, block, fm_sum, idx)
+        with _phase(_pn("permute gradient", weight), dev):
             if mod.dedup:
                 # one gradient row per DISTINCT row of the local batch (duplicates summed before they travel)
                 g_rows = ops.reduce_grad_unique(g_block, pos, back, g_fm if mod.fuse_fm else None, fm_sum)
@@ -708,7 +763,7 @@ class _ShardedLookup(Function):
                 t.record_stream(cs)
         row_bytes = g_rows.shape[1] * g_rows.element_size()
         with _on_stream(cs):
-            with _phase("row all-to-all (gradient)", dev):
+            with _phase(_pn("row all-to-all (gradient)", weight), dev):
                 if ctx.padded:  # equal splits; padding slots carry zero rows (pos = PAD) and update nothing on the owner
                     recv_g = _exchange(g_rows.shape[0], g_rows, None, None, mod)[: g_rows.shape[0]]
                 else:
@@ -718,7 +773,7 @@ class _ShardedLookup(Function):
             dense_index = weight.shape[0] <= mod.dense_grad_max_rows
             pad_kw = {"padded": True} if ctx.padded else {}
             gw = None
-            with _phase("owner reduce / update", dev):
+            with _phase(_pn("owner reduce / update", weight), dev):
                 if mod.fused_optimizer is not None:
                     # the owner steps its rows right here: no gradient tensor of any kind (weight.grad stays None)
                     ops.shard_update(weight, recv_ids, recv_g, mod.fused_optimizer, dense_index, **pad_kw)
@@ -748,7 +803,7 @@ class _ShardedLookup(Function):
         return torch.sparse_coo_tensor(ids.long().unsqueeze(0), rows, size=weight.shape)
 
     @staticmethod
-    def _backward_local(ctx, g_block, g_fm, weight, owner_ids, pos, block, fm_sum):
+    def _backward_local(ctx, g_block, g_fm, weight, owner_ids, pos, block, fm_sum, idx=None):
         """backward with ``local_direct``: only the gradient rows of lookups OTHER ranks own are permuted into exchange
         order and sent; the rows of this rank's own lookups are written straight behind the received ones (G = [rows that
         arrived | own rows], the order of ``RoutePlan.owner_ids``) and the owner-side reduction runs over G."""
@@ -763,35 +818,44 @@ class _ShardedLookup(Function):
         E = block.shape[-1]
         Ks = pos.numel()
         Kr = owner_ids.numel() - n
-        G = torch.empty(Kr + n, E, dtype=block.dtype, device=dev)
+        own = ctx.own_direct
+        G = torch.empty(Kr + (0 if own else n), E, dtype=block.dtype, device=dev)
         g_send = None
-        with _phase("permute gradient", dev):
+        with _phase(_pn("permute gradient", weight), dev):
             if Ks - n:
                 g_send = torch.empty(Ks - n, E, dtype=block.dtype, device=dev)
                 if lo:
                     ops.permute_grad(g_block, pos[:lo], gf, fm_sum, block, out=g_send[:lo])
                 if Ks - n - lo:
                     ops.permute_grad(g_block, pos[lo + n:], gf, fm_sum, block, out=g_send[lo:])
-            if n:
+            if n and not own:
                 ops.permute_grad(g_block, pos[lo:lo + n], gf, fm_sum, block, out=G[Kr:])
+        gw_own = None
+        if own:
+            with _phase(_pn("own lookups: bucket walk", weight), dev):
+                gw_own = ops.own_grad_dense(weight, idx, mod.offsets_local, g_block, gf, fm_sum if gf is not None else None)
         cs = comm_stream(dev) if (mod.overlap_grad_exchange and weight.grad is None) else None
         if cs is not None:
             ev = torch.cuda.Event()
             ev.record()
             cs.wait_event(ev)
-            for t in (G, g_send, owner_ids):
+            for t in (G, g_send, owner_ids, gw_own):
                 if t is not None:
                     t.record_stream(cs)
         with _on_stream(cs):
             if mod.world > 1:
-                with _phase("row all-to-all (gradient)", dev):
+                with _phase(_pn("row all-to-all (gradient)", weight), dev):
                     ins = _self_zero(send_splits, mod.rank, mod.world, cap)       # what this rank sends back to each owner
                     outs = _self_zero(recv_splits, mod.rank, mod.world, cap)      # what it receives as an owner
                     _exchange(Kr, g_send, outs, ins, mod, out=G[:Kr])
                 _count_wire("rows_bwd", ins, mod.rank, E * G.element_size(), 0, mod.world)
             wire_bytes["steps"] += 1
-            with _phase("owner reduce / update", dev):
-                gw = _ShardedLookup._owner_reduce(mod, weight, owner_ids, G, ctx.padded)
+            with _phase(_pn("owner reduce / update", weight), dev):
+                if own:
+                    gw = gw_own
+                    ops.accumulate_rows(gw, owner_ids[:Kr], G, ctx.padded)
+                else:
+                    gw = _ShardedLookup._owner_reduce(mod, weight, owner_ids, G, ctx.padded)
             if cs is not None:
                 mod._grad_event = torch.cuda.Event()
                 mod._grad_event.record(cs)
@@ -851,6 +915,10 @@ class RowShardedMultiIndicesEmbedding(BaseInput):
         self.local_direct = bool(local_direct if local_direct is not None else
                                  __import__("os").environ.get("TRS_SHARD_LOCAL_DIRECT", "1") != "0") \
             and hasattr(self.ops, "unpermute_local") and not self.dedup
+        # own_direct: with a dense shard gradient and no fused optimizer, this rank's own lookups are reduced by the unsharded
+        # backward straight from the block gradient (TRS_SHARD_OWN_DIRECT=0: permuted and reduced with the received rows)
+        self.own_direct = __import__("os").environ.get("TRS_SHARD_OWN_DIRECT", "1") != "0"
+        self.register_buffer('offsets_local', self.offsets - self.row_range[0], persistent=False)
         self.route_key = (tuple(int(f) for f in field_sizes), self.world, id(process_group), self.dedup, self.capacity)
         self.length = embed_size * len(field_sizes) if flatten else embed_size
 
