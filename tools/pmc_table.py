@@ -17,8 +17,8 @@ def parse(path):
     return d
 
 
-print("| kernel | matrix pipe busy | VALU instr / MFMA | LDS instr / MFMA | LDS unit busy | bank-conflict cycles | wait_any | wait_inst |")
-print("|---|---:|---:|---:|---:|---:|---:|---:|")
+print("| kernel | matrix pipe busy | VALU busy | VALU instr / MFMA | LDS instr / MFMA | LDS unit busy | bank-conflict cycles | wait_any | wait_inst |")
+print("|---|---:|---:|---:|---:|---:|---:|---:|---:|")
 for out in sys.argv[1:]:
     a, b = parse(out + "/pmc_a.txt"), parse(out + "/pmc_b.txt")
     for k in a:
@@ -27,6 +27,7 @@ for out in sys.argv[1:]:
             continue
         cu_cycles = B["GRBM_GUI_ACTIVE"] / 8            # GRBM_GUI_ACTIVE sums the 8 XCDs
         print(f"| `{k}` | {A['SQ_VALU_MFMA_BUSY_CYCLES'] / (cu_cycles * 1024) * 100:.1f} % | "
+              f"{A.get('SQ_ACTIVE_INST_VALU', 0.0) / (cu_cycles * 1024) * 100:.1f} % | "
               f"{B['SQ_INSTS_VALU'] / B['SQ_INSTS_MFMA']:.2f} | {B['SQ_INSTS_LDS'] / B['SQ_INSTS_MFMA']:.2f} | "
               f"{B['SQ_LDS_IDX_ACTIVE'] / (cu_cycles * 256) * 100:.0f} % | {A['SQ_LDS_BANK_CONFLICT']:.2e} | "
               f"{A['SQ_WAIT_ANY'] / A['SQ_WAVE_CYCLES']:.2f} | {A['SQ_WAIT_INST_ANY'] / A['SQ_WAVE_CYCLES']:.2f} |")

@@ -27,6 +27,11 @@ FILE_FLAGS = {"cin_mfma.hip": ["-fno-slp-vectorize"], "cross_mfma.hip": ["-fno-s
               **{f"mlp_ro_{k}.hip": ["-fno-slp-vectorize"] for k in ("dcn_fwd", "dcn_bwd", "tail_fwd", "tail_bwd")}}
 
 
+# developer A/B: TRS_BUILD_SLP="cross_mfma.hip,cin_mfma.hip" compiles those files WITH the SLP vectoriser (packed fp32 math)
+for _f in filter(None, os.environ.get("TRS_BUILD_SLP", "").split(",")):
+    FILE_FLAGS[_f] = [x for x in FILE_FLAGS.get(_f, []) if x != "-fno-slp-vectorize"]
+
+
 def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 

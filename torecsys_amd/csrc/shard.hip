@@ -7,6 +7,27 @@ namespace trs {
 constexpr int MAX_WORLD = 256;
 constexpr int CHUNK = 4096;  // positions per workgroup in the fill pass
 
+// owner of global row r: floor(r / per) clamped into [0, W) without a 64-bit division (~80 emulated instructions per
+// lookup: it was most of this pass's 23 + 30 us): a float-reciprocal estimate, exact after one step either way
+// (r < 2^40 and W <= 256 keep the estimate within one of the quotient)
+__device__ __forceinline__ int owner_of(int64_t r, int64_t per, float inv_per, int W) {
+  if (r <= 0) return 0;
+  int w = (int)((float)r * inv_per);
+  w = w >= W ? W - 1 : w;
+  if (r < (int64_t)w * per) --w;
+  else if (w + 1 < W && r >= (int64_t)(w + 1) * per) ++w;
+  return w;
+}
+// field of flat lookup p = p % N, same trick (exact for p < 2^24, the plain remainder beyond)
+__device__ __forceinline__ int field_of(int64_t p, int N, float inv_n) {
+  if (p >= (1 << 24)) return (int)(p % N);
+  const int q = (int)((float)(int)p * inv_n);
+  int rem = (int)p - q * N;
+  if (rem < 0) rem += N;
+  else if (rem >= N) rem -= N;
+  return rem;
+}
+
 // hist[w] += 1 for every active lane, returning the value each lane's own atomic would have returned -- with ONE LDS
 // atomic per distinct owner in the wave instead of one per lane: the lanes of a wave hit at most `world` different
 // counters (a single one on a one-rank group), and an LDS atomic on one address retires about one lane per clock.  The
@@ -34,6 +55,7 @@ __global__ __launch_bounds__(256) void bucket_count_kernel(const IdxT* __restric
                                                            const int64_t* __restrict__ offsets, int64_t BN, int N,
                                                            int64_t per, int W, unsigned long long* __restrict__ counts) {
   __shared__ int hist[MAX_WORLD];
+  const float inv_per = 1.0f / (float)per, inv_n = 1.0f / (float)N;
   for (int w = threadIdx.x; w < W; w += blockDim.x) hist[w] = 0;
   __syncthreads();
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -42,9 +64,8 @@ __global__ __launch_bounds__(256) void bucket_count_kernel(const IdxT* __restric
     const bool active = p < BN;
     int w = 0;
     if (active) {
-      const int64_t r = load_row_id(idx, offsets, p, (int)((uint64_t)p < ((uint64_t)1 << 32) ? (unsigned)p % (unsigned)N : p % N));
-      w = (int)(r / per);
-      w = w < 0 ? 0 : (w >= W ? W - 1 : w);
+      const int64_t r = load_row_id(idx, offsets, p, field_of(p, N, inv_n));
+      w = owner_of(r, per, inv_per, W);
     }
     wave_agg_inc(hist, w, active);
   }
@@ -62,6 +83,7 @@ __global__ __launch_bounds__(256) void bucket_fill_kernel(const IdxT* __restrict
                                                           int32_t* __restrict__ inv_pos) {
   __shared__ int hist[MAX_WORLD];
   __shared__ long long base[MAX_WORLD];
+  const float inv_per = 1.0f / (float)per, inv_n = 1.0f / (float)N;
   const int64_t p0 = (int64_t)blockIdx.x * CHUNK;
   const int64_t p1 = p0 + CHUNK < BN ? p0 + CHUNK : BN;
   for (int w = threadIdx.x; w < W; w += blockDim.x) hist[w] = 0;
@@ -71,9 +93,8 @@ __global__ __launch_bounds__(256) void bucket_fill_kernel(const IdxT* __restrict
     const bool active = p < p1;
     int w = 0;
     if (active) {
-      const int64_t r = load_row_id(idx, offsets, p, (int)((uint64_t)p < ((uint64_t)1 << 32) ? (unsigned)p % (unsigned)N : p % N));
-      w = (int)(r / per);
-      w = w < 0 ? 0 : (w >= W ? W - 1 : w);
+      const int64_t r = load_row_id(idx, offsets, p, field_of(p, N, inv_n));
+      w = owner_of(r, per, inv_per, W);
     }
     wave_agg_inc(hist, w, active);
   }
@@ -93,9 +114,8 @@ __global__ __launch_bounds__(256) void bucket_fill_kernel(const IdxT* __restrict
     int w = 0;
     int64_t r = 0;
     if (active) {
-      r = load_row_id(idx, offsets, p, (int)((uint64_t)p < ((uint64_t)1 << 32) ? (unsigned)p % (unsigned)N : p % N));
-      w = (int)(r / per);
-      w = w < 0 ? 0 : (w >= W ? W - 1 : w);
+      r = load_row_id(idx, offsets, p, field_of(p, N, inv_n));
+      w = owner_of(r, per, inv_per, W);
     }
     const int k = wave_agg_inc(hist, w, active);
     if (active) {
