@@ -500,3 +500,53 @@ def test_own_grad_dense_as_a_middle_rank(pg, dtype, B, fuse):
     ops.accumulate_rows(gw, ids.to(dev), wire.to(dev))
     want2 = base.index_add_(0, ids.long(), wire.float())
     assert rel_err(gw.float().cpu(), want2) <= tol
+
+
+@pytest.mark.timeout(180, method="thread")
+def test_whole_sharded_step_with_rccl_inside_one_hipgraph(pg, monkeypatch):
+    """The row-sharded step with its all-to-alls INSIDE one captured hipGraph.  A one-rank group normally takes no
+    collective; TRS_SHARD_FORCE_COLLECTIVES makes it issue the same RCCL all_to_all_single calls a larger world does
+    (ids, rows forward, rows backward -- sending to itself), everything through the exchange buffers
+    (local_direct=False).  Capture (GraphedStep: warm-up on a side stream, thread-local capture mode so the process
+    group's watchdog thread cannot invalidate it), three replays on three batches: block bit-exact, FM and the dense
+    shard gradient equal to the eager run of the same module.  This is what `bench.py --shard-graph whole` relies on at
+    more than one rank (fixed-capacity slots: static split sizes)."""
+    from torecsys_amd import dist as D
+    from torecsys_amd.dist import RowShardedMultiIndicesEmbedding
+    from torecsys_amd.graph import GraphedStep
+    from torecsys_amd.layers import FMLayer
+    monkeypatch.setattr(D, "FORCE_COLLECTIVES", True)
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(21)
+    B, N, E = 4096, 39, 64
+    fs = [300 + 11 * i for i in range(N)]
+    m = RowShardedMultiIndicesEmbedding(embed_size=E, field_sizes=fs, fuse_fm=True, dtype=torch.bfloat16, device=dev,
+                                        local_direct=False)
+    batches = [torch.cat([torch.randint(0, f, (B, 1), generator=g) for f in fs], 1).to(dev) for _ in range(3)]
+    gb = (torch.randn(B, N, E, generator=g) * 0.1).bfloat16().to(dev)
+    held = {}
+
+    def fn(ix):
+        out = m(ix)
+        y = FMLayer()(out)
+        loss = (out.rename(None).float() * gb.float()).sum() + (y.rename(None).float() ** 2).sum()
+        loss.backward()
+        held["out"], held["fm"] = out.rename(None).detach(), y.rename(None).detach()
+        return loss
+
+    eager = []
+    for ix in batches:
+        m.embedding.weight.grad = None
+        fn(ix)
+        torch.cuda.synchronize()
+        eager.append((held["out"].clone(), held["fm"].clone(), m.embedding.weight.grad.clone()))
+    m.embedding.weight.grad = None
+    held.clear()
+    D.clear_route_caches()
+    step = GraphedStep(fn, (batches[0],), params=[m.embedding.weight], warmup=1)
+    for k, ix in enumerate(batches):
+        step(ix)
+        torch.cuda.synchronize()
+        assert torch.equal(held["out"], eager[k][0]), k
+        assert torch.equal(held["fm"], eager[k][1]), k
+        assert rel_err(m.embedding.weight.grad.float(), eager[k][2].float()) <= 4e-3, k      # (bucket order is not fixed: one bf16 ulp)

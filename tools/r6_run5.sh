@@ -13,8 +13,8 @@ PY
 run whole_1m
 run whole_125m --rows-per-gpu 125000000
 python tools/kbench.py --what cross > $O/kbench_cross_default.txt 2>&1
-bash tools/pmc_run.sh $O/pmc_cross cross_mfma -- python tools/kbench.py --what cross > /dev/null 2>&1
-bash tools/pmc_run.sh $O/pmc_cin cin_ -- python tools/kbench.py --what cin > /dev/null 2>&1
+bash tools/pmc_run.sh $O/pmc_cross cross_mfma -- python $PWD/tools/kbench.py --what cross > /dev/null 2>&1
+bash tools/pmc_run.sh $O/pmc_cin cin_ -- python $PWD/tools/kbench.py --what cin > /dev/null 2>&1
 python tools/pmc_table.py $O/pmc_cross $O/pmc_cin > $O/pmc_table.md 2>&1
 python tools/kbench.py --what cin > $O/kbench_cin.txt 2>&1
 # A/B: cross_mfma.hip compiled WITH the SLP vectoriser (packed fp32 math in the VALU-bound chain waves)

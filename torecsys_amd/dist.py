@@ -262,6 +262,10 @@ def _all_to_all(out: torch.Tensor, inp: torch.Tensor, out_splits: List[int], in_
 
 
 PAD = -1        # id / position of a padding slot
+# TRS_SHARD_FORCE_COLLECTIVES=1 (tests): a one-rank group normally takes no collective at all; with this switch it issues
+# the same all_to_all_single calls a larger world does (RCCL sending to itself), so that their capture into a hipGraph can
+# be exercised on the one GPU the build boxes have
+FORCE_COLLECTIVES = __import__("os").environ.get("TRS_SHARD_FORCE_COLLECTIVES", "0") == "1"
 
 # ---- communication stream and per-phase device times --------------------------------------------------------------------
 _comm_streams = {}
@@ -513,6 +517,9 @@ def _route_plan(idx: torch.Tensor, mod) -> "RoutePlan":
     elif mod.world == 1:
         n = int(pr.send_ids.numel())                 # a shape, not a device value: no synchronisation
         p.send_splits, p.recv_splits, p.recv_ids = [n], [n], pr.send_ids
+        if FORCE_COLLECTIVES and pr.send_ids.is_cuda:
+            p.recv_ids = torch.empty_like(pr.send_ids)
+            dist.all_to_all_single(p.recv_ids, pr.send_ids, group=mod.group)
     else:
         if pr.ready is not None:
             pr.ready.synchronize()                 # waits for the tiny count copy only (long done when prefetched)
@@ -548,7 +555,7 @@ def _exchange(out_rows: int, inp: torch.Tensor, out_splits, in_splits, mod, zero
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """all-to-all of row blocks; a one-rank group hands the tensor through.  ``zero_row`` (explicit splits): one more,
     zeroed, row behind the received ones; ``out``: receive into this (out_rows, E) tensor."""
-    if mod.world == 1:
+    if mod.world == 1 and not (FORCE_COLLECTIVES and inp.is_cuda):
         return inp
     if out_splits is not None and (zero_row or out is not None):
         if out is None:
