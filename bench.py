@@ -831,6 +831,10 @@ def run(a):
                         if j:
                             for p in params:
                                 p.grad = None          # (host-side: every step of the graph writes fresh gradient tensors)
+                        if sharded and j + 1 < ksteps:
+                            # the NEXT step's owner bucketing (it depends on its indices only) forks onto the "route" side
+                            # stream here and runs beside this step; its forward joins it (dist.prefetch_route)
+                            emb.prefetch_route(flat[2 * (j + 1)])
                         l_ = graph_fn(flat[2 * j], flat[2 * j + 1])
                     return l_
 

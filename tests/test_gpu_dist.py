@@ -502,7 +502,7 @@ def test_own_grad_dense_as_a_middle_rank(pg, dtype, B, fuse):
     assert rel_err(gw.float().cpu(), want2) <= tol
 
 
-@pytest.mark.timeout(180, method="thread")
+@pytest.mark.timeout(900, method="thread")
 def test_whole_sharded_step_with_rccl_inside_one_hipgraph(pg, monkeypatch):
     """The row-sharded step with its all-to-alls INSIDE one captured hipGraph.  A one-rank group normally takes no
     collective; TRS_SHARD_FORCE_COLLECTIVES makes it issue the same RCCL all_to_all_single calls a larger world does

@@ -417,7 +417,7 @@ class _PendingRoute:
     """First half of a route plan (owner bucketing + count exchange), started early for the NEXT batch -- the way
     a data loader prefetches -- so that the host-side read of the split sizes finds them already copied to pinned
     memory and never stalls the launch queue behind the current step's work."""
-    __slots__ = ("send_ids", "send_pos", "inv_pos", "host_counts", "ready")
+    __slots__ = ("send_ids", "send_pos", "inv_pos", "host_counts", "ready", "side_event", "side_stream")
 
 
 def _route_key(idx, mod):
@@ -440,6 +440,7 @@ F_._clear_hooks.append(clear_route_caches)      # F_.clear_caches() (GraphedStep
 def _start_route(idx: torch.Tensor, mod) -> "_PendingRoute":
     ops, group, world = mod.ops, mod.group, mod.world
     pr = _PendingRoute()
+    pr.side_event = pr.side_stream = None
     if mod.dedup:
         counts, send_ids, inv = ops.unique_route(idx, mod.offsets, mod.rows_per_rank, world)
         pr.send_ids, pr.send_pos, pr.inv_pos = send_ids, None, inv
@@ -470,8 +471,13 @@ def _start_route(idx: torch.Tensor, mod) -> "_PendingRoute":
     return pr
 
 
+ROUTE_SIDE = __import__("os").environ.get("TRS_ROUTE_SIDE", "1") != "0"
+
+
 def prefetch_route(idx: torch.Tensor, mod) -> None:
-    """Start routing ``idx`` (a batch that will be looked up soon) now; the next ``forward`` picks it up."""
+    """Start routing ``idx`` (a batch that will be looked up soon) now; the next ``forward`` picks it up.  On a HIP
+    device the owner bucketing runs on the "route" side stream, beside whatever the caller's stream is busy with (it
+    depends on the indices only); the forward that picks the plan up waits for its event."""
     idx = idx.rename(None) if idx.has_names() else idx
     if idx.dtype not in (torch.int64, torch.int32):
         idx = idx.long()
@@ -479,7 +485,15 @@ def prefetch_route(idx: torch.Tensor, mod) -> None:
     key = _route_key(idx, mod)
     if any(k == key for k, _, _ in _pending_routes) or any(k == key for k, _, _ in _route_cache):
         return
-    _pending_routes.append((key, idx, _start_route(idx, mod)))
+    if idx.is_cuda and ROUTE_SIDE and (mod.world == 1 or (mod.capacity is not None and not mod.dedup)):
+        # (the exact-split mode issues a count exchange and a host copy from inside _start_route: it keeps the caller's
+        # stream, where it is ordered with the other collectives)
+        pr, ev, side = F_.run_on_side(idx.device, "route", lambda: _start_route(idx, mod))
+        idx.record_stream(side)
+        pr.side_event, pr.side_stream = ev, side
+    else:
+        pr = _start_route(idx, mod)
+    _pending_routes.append((key, idx, pr))
     if len(_pending_routes) > MAX_PENDING_ROUTES:
         _pending_routes.pop(0)
 
@@ -502,6 +516,13 @@ def _route_plan(idx: torch.Tensor, mod) -> "RoutePlan":
         route_stats["cold"] += 1
         with _phase("route (bucket by owner)", idx.device):
             pr = _start_route(idx, mod)
+    elif pr.side_event is not None:
+        cur = torch.cuda.current_stream(idx.device)
+        if cur != pr.side_stream:          # routed ahead on the side stream: its tensors are used on this one from here on
+            cur.wait_event(pr.side_event)
+            for t in (pr.send_ids, pr.send_pos, pr.inv_pos):
+                if t is not None:
+                    t.record_stream(cur)
     p = RoutePlan()
     p.send_pos, p.inv_pos, p.cap = pr.send_pos, pr.inv_pos, 0
     p.send_ids, p._owner_ids = pr.send_ids, None
