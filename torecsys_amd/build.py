@@ -32,6 +32,12 @@ for _f in filter(None, os.environ.get("TRS_BUILD_SLP", "").split(",")):
     FILE_FLAGS[_f] = [x for x in FILE_FLAGS.get(_f, []) if x != "-fno-slp-vectorize"]
 
 
+# developer A/B: TRS_BUILD_DEFS="cross_mfma.hip:-DTRS_B3_BARRIER" adds compiler options to single files
+for _e in filter(None, os.environ.get("TRS_BUILD_DEFS", "").split(",")):
+    _f, _, _d = _e.partition(":")
+    FILE_FLAGS[_f] = FILE_FLAGS.get(_f, []) + [_d]
+
+
 def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 

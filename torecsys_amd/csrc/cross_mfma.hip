@@ -394,6 +394,22 @@ __device__ long long b3_trace[2][1024];
 #define B3_STAMP(who, idx) do {} while (0)
 #endif
 
+// -DTRS_B3_FLAGS (round 6 experiment, OFF: measured 760-780 us against 633-679 us for the barrier form on one box,
+// profiles/r06_logs/ab_cross_flags.txt): slab hand-over between the two wave roles without workgroup barriers -- a
+// counter per slab slot and direction in LDS.  ready[slot] counts the chain waves that have written their piece of the slot's current use, done[slot] the dW
+// waves that have finished reading it; both only ever grow, so use k of a slot is complete at CHAIN * (k + 1) /
+// DW * (k + 1).  A chain wave no longer waits for the OTHER chain waves at every layer (the s_barrier made all eight waves
+// meet eleven times per group: the slowest wave of every step set the pace), only -- before it overwrites a slot -- for the
+// dW waves to be done with that slot's previous use, two steps earlier.  LDS operations of one wave execute in order, and
+// the counter is bumped behind an explicit s_waitcnt, so a reader that sees the count sees the data.
+__device__ __forceinline__ void b3_wait_ge(int* flag, int target) {
+  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+}
+__device__ __forceinline__ void b3_signal(int* flag, int lane) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (lane == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 template <int NT, int L, bool DETACH>
 __global__ __launch_bounds__(64 * (B3<NT>::CHAIN + B3<NT>::DW), 2) void cross_mfma_bwd3_kernel(
     const uint4* __restrict__ x, const uint4* __restrict__ gout, const uint4* __restrict__ Wp,
@@ -413,6 +429,8 @@ __global__ __launch_bounds__(64 * (B3<NT>::CHAIN + B3<NT>::DW), 2) void cross_mf
   float* bs = reinterpret_cast<float*>(Wts + (L - 1) * FRAG);
   char* duslab = reinterpret_cast<char*>(bs + L * E);         // [slot 2][panel NT][B3_ROWS][32 B]
   char* xslab = duslab + 2 * TENSOR;                          // same
+  __shared__ int flags[4];                                    // ready[2], done[2] (static: their address is a constant)
+  if (threadIdx.x < 4) flags[threadIdx.x] = 0;
   for (int i = threadIdx.x; i < L * FRAG; i += blockDim.x) Ws[i] = Wp[i];
   for (int i = threadIdx.x; i < (L - 1) * FRAG; i += blockDim.x) Wts[i] = Wtp[i];
   for (int i = threadIdx.x; i < L * E; i += blockDim.x) bs[i] = bp[i] + 1.f;      // the backward only ever needs u_l + 1
@@ -519,6 +537,9 @@ __global__ __launch_bounds__(64 * (B3<NT>::CHAIN + B3<NT>::DW), 2) void cross_mf
         pack_tile<NT>(du, Bdu);
         char* dslot = duslab + ((step & 1) ? TENSOR : 0) + pc0;
         char* xslot = xslab + ((step & 1) ? TENSOR : 0) + pc0;
+#ifdef TRS_B3_FLAGS
+        if (step >= 2) b3_wait_ge(flags + 2 + (step & 1), B3_DW * (step >> 1));      // the slot's previous use has been read
+#endif
 #pragma unroll
         for (int c = 0; c < KS; ++c) {
           *reinterpret_cast<uint4*>(dslot + 2 * c * B3_PANEL) = Bdu[c];
@@ -532,10 +553,16 @@ __global__ __launch_bounds__(64 * (B3<NT>::CHAIN + B3<NT>::DW), 2) void cross_mf
             for (int i = 0; i < 4; ++i) nx.v[mt][i] = x0f.v[mt][i] * up[mt][i];
           pack_tile<NT>(nx, Bx);
         }
+#ifndef TRS_B3_FLAGS
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (wave == 0 && l < 3) B3_STAMP(0, gi * 8 + 2 + 2 * l);      // before / after the barrier of steps 0..2
         __builtin_amdgcn_s_barrier();
         if (wave == 0 && l < 3) B3_STAMP(0, gi * 8 + 3 + 2 * l);
+#else
+        if (wave == 0 && l < 3) B3_STAMP(0, gi * 8 + 2 + 2 * l);
+        b3_signal(flags + (step & 1), lane);                            // this wave's piece of the slot is in LDS
+        if (wave == 0 && l < 3) B3_STAMP(0, gi * 8 + 3 + 2 * l);
+#endif
       }
       if (detach_first == 0) {
 #pragma unroll
@@ -574,10 +601,16 @@ __global__ __launch_bounds__(64 * (B3<NT>::CHAIN + B3<NT>::DW), 2) void cross_mf
     for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x, ++gi) {
 #pragma unroll
       for (int l = 0; l < L; ++l, ++step) {
+#ifndef TRS_B3_FLAGS
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (wq == 0 && l < 4) B3_STAMP(1, gi * 8 + 2 * l);             // arrival at / release from the barrier
         __builtin_amdgcn_s_barrier();                   // the chain waves have written slot step & 1 (layer l)
         if (wq == 0 && l < 4) B3_STAMP(1, gi * 8 + 2 * l + 1);
+#else
+        if (wq == 0 && l < 4) B3_STAMP(1, gi * 8 + 2 * l);
+        b3_wait_ge(flags + (step & 1), B3_CHAIN * ((step >> 1) + 1));   // every chain wave has written slot step & 1 (layer l)
+        if (wq == 0 && l < 4) B3_STAMP(1, gi * 8 + 2 * l + 1);
+#endif
         const char* du_t = duslab + ((step & 1) ? TENSOR : 0);
         const char* x_t = xslab + ((step & 1) ? TENSOR : 0);
         const unsigned hot = (r == l) ? 0x3f803f80u : 0u;               // bf16 1.0 pairs in column l
@@ -599,6 +632,9 @@ __global__ __launch_bounds__(64 * (B3<NT>::CHAIN + B3<NT>::DW), 2) void cross_mf
                                                                __builtin_bit_cast(bf16x8, onehot), dbacc[m], 0, 0, 0);
           }
         }
+#endif
+#ifdef TRS_B3_FLAGS
+        b3_signal(flags + 2 + (step & 1), lane);                        // this wave has read the slot
 #endif
       }
     }
