@@ -429,8 +429,10 @@ __global__ __launch_bounds__(64 * (B3<NT>::CHAIN + B3<NT>::DW), 2) void cross_mf
   float* bs = reinterpret_cast<float*>(Wts + (L - 1) * FRAG);
   char* duslab = reinterpret_cast<char*>(bs + L * E);         // [slot 2][panel NT][B3_ROWS][32 B]
   char* xslab = duslab + 2 * TENSOR;                          // same
+#ifdef TRS_B3_FLAGS
   __shared__ int flags[4];                                    // ready[2], done[2] (static: their address is a constant)
   if (threadIdx.x < 4) flags[threadIdx.x] = 0;
+#endif
   for (int i = threadIdx.x; i < L * FRAG; i += blockDim.x) Ws[i] = Wp[i];
   for (int i = threadIdx.x; i < (L - 1) * FRAG; i += blockDim.x) Wts[i] = Wtp[i];
   for (int i = threadIdx.x; i < L * E; i += blockDim.x) bs[i] = bp[i] + 1.f;      // the backward only ever needs u_l + 1
