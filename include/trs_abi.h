@@ -304,6 +304,21 @@ int trs_cin_dw(const void* gy, const void* x0, const void* xk, int64_t B, int32_
                int32_t E, int32_t dtype, int32_t tri, float* dW, void* workspace, size_t ws_bytes,
                trs_stream_t stream);
 
+/* The same two gradients for a layer whose output channels beyond the first C receive NO gradient: the reference splits
+ * EVERY CIN layer's 2H output channels into a "direct" and a "hidden" half (compress_interaction_network.py:151-156: the
+ * `i != len-1` guard is always true) and never uses the LAST layer's hidden half (:176-181 reads the direct halves only),
+ * so dL/dy of those channels is exactly zero -- through BatchNorm and the activation too, which act per channel.  Their
+ * terms of the contraction over c (data gradients) and their rows of dW are zeros that need not be computed:
+ *   gyT (B,E,>=C) with ldg channels between two pixels, Wc = the first C rows of the layer's weight; results identical
+ *   to trs_cin_cl_bwd_data on the full tensors (the omitted terms are exact zeros);
+ *   gy (B,>=C,E) with gy_batch_stride elements between two samples; dW (C, N*H) = the first C rows of the gradient (the
+ *   caller zero-fills the rest).                                                                                      */
+int trs_cin_cl_bwd_data_live(const void* x0T, int32_t ld0, const void* xkT, int32_t ldk, const void* gyT, int32_t ldg,
+                             const void* Wc, int64_t B, int32_t N, int32_t H, int32_t C, int32_t E, int32_t dtype,
+                             void* dx0T, void* dxkT, int32_t ldo, void* workspace, size_t ws_bytes, trs_stream_t stream);
+int trs_cin_dw_live(const void* gy, int64_t gy_batch_stride, const void* x0, const void* xk, int64_t B, int32_t N, int32_t H,
+                    int32_t C, int32_t E, int32_t dtype, float* dW, void* workspace, size_t ws_bytes, trs_stream_t stream);
+
 /* ---- MLP backward epilogue (the GEMMs stay on hipBLASLt) -----------------------------------------------
  * y = relu(linear(x)):  gz = gy * (y > 0) and gb[c] = sum_r gz[r,c] (fp32) in ONE pass over (rows, C) instead of
  * ATen's threshold_backward + column sum.  C*sizeof(T) must be a multiple of 16 and <= 4096.

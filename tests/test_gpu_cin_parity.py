@@ -287,3 +287,46 @@ def test_transpose_pad_is_the_padded_transposition_bit_for_bit(dev, B, N, E, ld)
     y.backward(go)
     assert torch.equal(x.grad, go[:, :, :N].transpose(1, 2).contiguous())
     assert not F_.transpose_pad_supported(x, 128) and not F_.transpose_pad_supported(x.float(), ld)
+
+
+@pytest.mark.parametrize("B,N,E,sizes", [(256, 39, 64, [128, 128, 128]), (64, 39, 64, [64, 128]), (96, 10, 32, [32, 64])])
+@pytest.mark.parametrize("train", [True, False])
+def test_last_layer_backward_skips_the_dead_half_exactly(dev, monkeypatch, B, N, E, sizes, train):
+    """The last CIN layer's "hidden" half is computed, split off and never used (compress_interaction_network.py:151-156,
+    176-181), so its gradient is exactly zero; the backward of that layer's contraction leaves those channels out
+    (trs_cin_cl_bwd_data_live / trs_cin_dw_live).  Leaving out exact zeros must change NOTHING: every gradient of the layer
+    -- input, all convolution weights and biases, BatchNorm affine parameters, fc -- bit-identical with the switch off,
+    and the dead rows of the last convolution's weight gradient exactly zero."""
+    from torecsys_amd import functional as F_
+    from torecsys_amd.layers import CompressInteractionNetworkLayer
+    torch.manual_seed(B + N)
+    lay = CompressInteractionNetworkLayer(embed_size=E, num_fields=N, output_size=1, layer_sizes=sizes).to(dev).bfloat16()
+    lay.train(train)
+    x0 = (0.5 * torch.randn(B, N, E)).bfloat16().to(dev)
+    gy = torch.randn(B, 1).bfloat16().to(dev)
+    res = []
+    for skip in (True, False):
+        monkeypatch.setattr(F_, "CIN_SKIP_DEAD", skip)
+        for p in lay.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_()
+        state = {k: v.clone() for k, v in lay.state_dict().items()}
+        y = lay(x)
+        y.rename(None).backward(gy)
+        torch.cuda.synchronize()
+        res.append(([x.grad.clone()] + [p.grad.clone() for p in lay.parameters()], y.rename(None).detach().clone()))
+        lay.load_state_dict(state)            # (train mode moved the running statistics: same start for the second run)
+    assert torch.equal(res[0][1], res[1][1])
+    names = ["input"] + [n for n, _ in lay.named_parameters()]
+    last_w = f"model.{len(sizes) - 1}.Conv1d.weight"
+    for n, a, b in zip(names, res[0][0], res[1][0]):
+        if n == last_w:
+            # the one tensor whose SUMMATION ORDER changes: half as many channel blocks -> twice as many sample ranges in
+            # the split-K weight gradient (fp32 partials added in another order, then one bf16 rounding)
+            assert rel_err(a.float().cpu(), b.float().cpu()) <= 4e-3, n
+        else:
+            assert torch.equal(a, b), n
+    last = lay.model[-1].Conv1d
+    C = last.out_channels
+    assert float(last.weight.grad[C // 2:].float().abs().max()) == 0.0
+    assert float(last.weight.grad[: C // 2].float().abs().max()) > 0.0

@@ -115,6 +115,9 @@ SIGNATURES = {
                                       _P, _SZ, _P]),
     "trs_cin_dw_workspace_bytes": (_SZ, [_I64, _I32, _I32, _I32]),
     "trs_cin_dw": (c_int32, [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _SZ, _P]),
+    "trs_cin_cl_bwd_data_live": (c_int32, [_P, _I32, _P, _I32, _P, _I32, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _I32,
+                                           _P, _SZ, _P]),
+    "trs_cin_dw_live": (c_int32, [_P, _I64, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P, _SZ, _P]),
     "trs_relu_bwd_bias_workspace_bytes": (_SZ, [_I64, _I32]),
     "trs_relu_bwd_bias": (c_int32, [_P, _P, _I64, _I32, _I32, _P, _P, _P, _SZ, _P]),
     "trs_mlp_fused_supported": (c_int32, [_I32, _P]),

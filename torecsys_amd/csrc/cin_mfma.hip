@@ -377,7 +377,7 @@ template <int KC, int P, int NS, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void cin_cl_bwd_data_kernel(
     const bf16_t* __restrict__ x0T, int ld0, const bf16_t* __restrict__ xkT, int ldk, const bf16_t* __restrict__ gyT,
     const uint4* __restrict__ WpT, bf16_t* __restrict__ dx0T, bf16_t* __restrict__ dxkT, int ldo, int64_t B, int N, int H,
-    int C, int E, int npass, int tri) {
+    int C, int E, int npass, int tri, int ldg /* channels between two pixels of gyT (>= C: only the first C are read) */) {
   constexpr int NT = 64 * WAVES;
   constexpr int PIX = 16 * P;
   constexpr int G = 2 * NS;
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(64 * WAVES) void cin_cl_bwd_data_kernel(
           for (int t = 0; t < P; ++t)
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc) {
-              const uint4 v = *reinterpret_cast<const uint4*>(gyT + (pix0 + 16 * t + r) * (int64_t)C + 32 * (pass * KC + kc) + 8 * q);
+              const uint4 v = *reinterpret_cast<const uint4*>(gyT + (pix0 + 16 * t + r) * (int64_t)ldg + 32 * (pass * KC + kc) + 8 * q);
               Bg[t][kc] = live ? v : make_uint4(0, 0, 0, 0);
             }
         }
@@ -596,8 +596,10 @@ size_t cin_mfma_bwd_data_workspace_bytes(int N, int H, int C) {
 
 int cin_cl_bwd_data(const void* x0T, int ld0, const void* xkT, int ldk, const void* gyT, const void* Wc, int64_t B, int N,
                     int H, int C, int E, int tri, void* dx0T, void* dxkT, int ldo, void* workspace, size_t ws_bytes,
-                    hipStream_t s) {
+                    hipStream_t s, int ldg = 0) {
   const int KSH = (H + 31) / 32, KCT = C / 32;
+  if (ldg == 0) ldg = C;
+  if (ldg < C || ldg % 8 != 0) return 1;
   if (C % 32 != 0 || E % 16 != 0 || !(KCT == 1 || KCT == 2 || KCT == 4 || KCT == 8) || ld0 % 8 != 0 || ldk % 8 != 0 ||
       ldk < 32 * KSH || ldo < 32 * KSH || ldo % 8 != 0 || workspace == nullptr)
     return 1;
@@ -642,7 +644,8 @@ int cin_cl_bwd_data(const void* x0T, int ld0, const void* xkT, int ldk, const vo
         attr_lds = lds;
       }
       hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * 8), lds, s, (const bf16_t*)x0T, ld0, (const bf16_t*)xkT, ldk,
-                         (const bf16_t*)gyT, (const uint4*)WpT, (bf16_t*)dx0T, (bf16_t*)dxkT, ldo, B, N, H, C, E, npass, tri);
+                         (const bf16_t*)gyT, (const uint4*)WpT, (bf16_t*)dx0T, (bf16_t*)dxkT, ldo, B, N, H, C, E, npass, tri,
+                         ldg);
     }
   };
   auto launch_ns = [&](auto kc_c, auto p_c) {
@@ -686,7 +689,8 @@ constexpr int DW_WAVES = 8;
 template <int NW, int WH, int HW /* h tiles per wave */, int KE /* E/32 */>
 __global__ __launch_bounds__(512) void cin_dw_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x0,
                                                      const bf16_t* __restrict__ xk, float* __restrict__ dWpart,
-                                                     int64_t B, int N, int H, int C, int nsplit) {
+                                                     int64_t B, int N, int H, int C, int nsplit,
+                                                     int gy_bs /* elements between two samples of gy (>= C*E) */) {
   constexpr int FG = DW_NG / NW;            // field groups (waves along the fields)
   constexpr int CW = DW_WAVES / (FG * WH);  // waves along c
   constexpr int CB = 32 * CW;               // channels per block
@@ -731,7 +735,7 @@ __global__ __launch_bounds__(512) void cin_dw_kernel(const bf16_t* __restrict__ 
       const int row = v / VPR, col = v - row * VPR;
       doff[k] = row * RS + col * 16;
       if (row < CB) {
-        sstride[k] = C * E;
+        sstride[k] = gy_bs;
         src[k] = gy + b_lo * sstride[k] + (int64_t)(CB * cb + row) * E + col * 8;
       } else if (row < CB + HBK) {
         const int h = HBK * hb + (row - CB);
@@ -1029,10 +1033,12 @@ static int cin_dw_tri(const void* gy, const void* x0, int64_t B, int N, int C, i
 // gy (B,C,E), x0 (B,N,E), xk (B,H,E) contiguous bf16; dW (C, N*H) fp32 accumulated into.
 // tri: xk is x0 (same pointer, H == N): the symmetric first-layer form, cin_dw_tri_kernel where it covers the shape
 int cin_dw(const void* gy, const void* x0, const void* xk, int64_t B, int N, int H, int C, int E, int tri, float* dW,
-           void* workspace, size_t ws_bytes, hipStream_t s) {
+           void* workspace, size_t ws_bytes, hipStream_t s, int64_t gy_bs = 0) {
   if (!(C == 64 || C == 128 || C == 256) || !(E == 32 || E == 64 || E == 128) || workspace == nullptr ||
       !aligned16(gy) || !aligned16(x0) || !aligned16(xk))
     return 1;
+  if (gy_bs == 0) gy_bs = (int64_t)C * E;
+  if (gy_bs < (int64_t)C * E || gy_bs % 8 != 0 || gy_bs >= ((int64_t)1 << 31) || (tri && gy_bs != (int64_t)C * E)) return 1;
   if (ws_bytes < cin_dw_workspace_bytes(B, N, H, C)) return fail(TRS_EWORKSPACE, "cin_dw: workspace too small");
   const int KE = E / 32;
   if (tri && xk == x0 && H == N && C % 128 == 0 && KE <= 2) {
@@ -1074,7 +1080,7 @@ int cin_dw(const void* gy, const void* x0, const void* xk, int64_t B, int N, int
       attr_lds = lds;                                                                                            \
     }                                                                                                            \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, (const bf16_t*)gy, (const bf16_t*)x0, (const bf16_t*)xk, \
-                       part, B, N, H, C, nsplit);                                                                \
+                       part, B, N, H, C, nsplit, (int)gy_bs);                                                    \
   } while (0)
 #define TRS_DW_KE(WH_, HW_)                                                              \
   do {                                                                                   \
@@ -1170,5 +1176,34 @@ extern "C" int trs_cin_dw(const void* gy, const void* x0, const void* xk, int64_
   TRS_REQUIRE(!tri || (xk == x0 && N == H), TRS_EINVAL, "cin_dw: tri needs xk to be x0 (N %d, H %d)", N, H);
   const int rc = cin_dw(gy, x0, xk, B, N, H, C, E, tri != 0, dW, workspace, ws_bytes, (hipStream_t)stream);
   if (rc == 1) return fail(TRS_ESHAPE, "cin_dw: shape not covered (C in {64,128,256}, E in {32,64,128})");
+  return rc;
+}
+
+/* see include/trs_abi.h: the two gradients of the contraction when only the first C of the layer's Ct output channels can
+ * carry a gradient */
+extern "C" int trs_cin_cl_bwd_data_live(const void* x0T, int32_t ld0, const void* xkT, int32_t ldk, const void* gyT,
+                                        int32_t ldg, const void* Wc, int64_t B, int32_t N, int32_t H, int32_t C, int32_t E,
+                                        int32_t dtype, void* dx0T, void* dxkT, int32_t ldo, void* workspace,
+                                        size_t ws_bytes, trs_stream_t stream) {
+  if (B == 0) return TRS_OK;
+  TRS_REQUIRE(x0T && xkT && gyT && Wc && dx0T && dxkT, TRS_EINVAL, "cin_cl_bwd_data_live: NULL pointer");
+  TRS_REQUIRE(B > 0 && N > 0 && H > 0 && C > 0 && E > 0 && ldg >= C, TRS_EINVAL, "cin_cl_bwd_data_live: bad size");
+  TRS_REQUIRE(dtype == TRS_BF16, TRS_EDTYPE, "cin_cl_bwd_data_live: bf16 only (dtype %d)", dtype);
+  const int rc = cin_cl_bwd_data(x0T, ld0, xkT, ldk, gyT, Wc, B, N, H, C, E, false, dx0T, dxkT, ldo, workspace, ws_bytes,
+                                 (hipStream_t)stream, ldg);
+  if (rc == 1) return fail(TRS_ESHAPE, "cin_cl_bwd_data_live: shape not covered (C in {32,64,128,256}, E%%16==0, ldg%%8==0)");
+  return rc;
+}
+
+extern "C" int trs_cin_dw_live(const void* gy, int64_t gy_batch_stride, const void* x0, const void* xk, int64_t B, int32_t N,
+                               int32_t H, int32_t C, int32_t E, int32_t dtype, float* dW, void* workspace, size_t ws_bytes,
+                               trs_stream_t stream) {
+  if (B == 0) return TRS_OK;
+  TRS_REQUIRE(gy && x0 && xk && dW, TRS_EINVAL, "cin_dw_live: NULL pointer");
+  TRS_REQUIRE(B > 0 && N > 0 && H > 0 && C > 0 && E > 0 && gy_batch_stride >= (int64_t)C * E, TRS_EINVAL,
+              "cin_dw_live: bad size");
+  TRS_REQUIRE(dtype == TRS_BF16, TRS_EDTYPE, "cin_dw_live: bf16 only (dtype %d)", dtype);
+  const int rc = cin_dw(gy, x0, xk, B, N, H, C, E, false, dW, workspace, ws_bytes, (hipStream_t)stream, gy_batch_stride);
+  if (rc == 1) return fail(TRS_ESHAPE, "cin_dw_live: shape not covered (C in {64,128,256}, E in {32,64,128})");
   return rc;
 }

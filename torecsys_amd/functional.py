@@ -1499,6 +1499,8 @@ def cin_cl_supported(x: torch.Tensor, out_channels: Sequence[int], hidden_sizes:
 
 
 CIN_FOLD_SYMMETRIC = os.environ.get("TRS_CIN_FOLD", "1") != "0"
+# the last CIN layer's backward leaves out the output channels that provably carry no gradient (see _CINContractCL.forward)
+CIN_SKIP_DEAD = os.environ.get("TRS_CIN_SKIP_DEAD", "1") != "0"
 
 
 def cin_fold_symmetric(Wc: torch.Tensor, N: int) -> torch.Tensor:
@@ -1512,7 +1514,7 @@ def cin_fold_symmetric(Wc: torch.Tensor, N: int) -> torch.Tensor:
 
 class _CINContractCL(Function):
     @staticmethod
-    def forward(ctx, x0T, xkT, Wc, bias, N, H, x0_cf=None, xk_cf=None):
+    def forward(ctx, x0T, xkT, Wc, bias, N, H, x0_cf=None, xk_cf=None, live=None):
         require_device(x0T, xkT, Wc, bias)
         B, E, ld0 = x0T.shape
         ldk = xkT.stride(1)
@@ -1534,6 +1536,10 @@ class _CINContractCL(Function):
         call("trs_cin_cl_fwd", ptr(x0T), ld0, ptr(xkT), ldk, ptr(w), ptr(bb), B, N, H, C, E, _abi.TRS_BF16, tri, ptr(yT),
              ptr(ws), ws_bytes, stream_ptr())
         ctx.tri = tri
+        # live: the caller's promise that the gradient of the output channels [live, C) is exactly zero (the LAST layer's
+        # "hidden" half, which the reference computes, splits off and never uses -- compress_interaction_network.py:151-156,
+        # 176-181): the backward then leaves their (zero) terms out of both contractions
+        ctx.live = int(live) if (live is not None and 0 < int(live) < C and not tri and CIN_SKIP_DEAD) else None
         ctx.save_for_backward(x0T, xkT, w)
         ctx.x0_cf = x0_cf        # the caller's channels-first (B,N,E) input, if it has one (saves a transpose per layer)
         ctx.xk_cf = xk_cf        # likewise the hidden state (B,H,E), emitted by the glue pass of the previous layer
@@ -1568,6 +1574,38 @@ class _CINContractCL(Function):
         dx0T = dxkT = dW = None
         mfma_data = C in (32, 64, 128, 256)
         mfma_dw = C in (64, 128, 256) and E in (32, 64, 128)
+        Cl = ctx.live
+        if Cl is not None and not (Cl in (64, 128, 256) and mfma_data and mfma_dw and (gy_cf is None or gy_cf.is_contiguous())):
+            Cl = None
+        if Cl is not None:
+            # the channels [Cl, C) carry no gradient: contraction over the first Cl channels only, the rest of dW stays zero
+            if need_x0 or need_xk:
+                ldo = ((H + 31) // 32) * 32
+                dx0T = torch.empty_like(x0T)
+                dxk_pad = torch.empty(B, E, ldo, dtype=torch.bfloat16, device=dev)
+                ws_bytes = size_query("trs_cin_cl_bwd_data_workspace_bytes", N, H, Cl)
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+                call("trs_cin_cl_bwd_data_live", ptr(x0T), ld0, ptr(xkT), ldk, ptr(gyT), C, ptr(w), B, N, H, Cl, E,
+                     _abi.TRS_BF16, ptr(dx0T), ptr(dxk_pad), ldo, ptr(ws), ws_bytes, stream_ptr())
+                if tuple(dxk_pad.shape) == tuple(xkT.shape):
+                    dxkT = dxk_pad
+                else:
+                    dxkT = torch.zeros(xkT.shape, dtype=xkT.dtype, device=dev)
+                    dxkT[:, :, :H] = dxk_pad[:, :, :H]
+            if need_w:
+                x0_cf, xk_cf = ctx.x0_cf, ctx.xk_cf
+                x0 = x0_cf if (x0_cf is not None and tuple(x0_cf.shape) == (B, N, E) and x0_cf.is_contiguous()) \
+                    else x0T[:, :, :N].transpose(1, 2).contiguous()
+                xk = xk_cf if (xk_cf is not None and tuple(xk_cf.shape) == (B, H, E) and xk_cf.is_contiguous()) \
+                    else xkT[:, :, :H].transpose(1, 2).contiguous()
+                gy = gy_cf if (gy_cf is not None and tuple(gy_cf.shape) == (B, C, E)) else gyT.transpose(1, 2).contiguous()
+                dW = torch.zeros(C, N * H, dtype=torch.float32, device=dev)
+                ws_bytes = size_query("trs_cin_dw_workspace_bytes", B, N, H, Cl)
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+                call("trs_cin_dw_live", ptr(gy), C * E, ptr(x0), ptr(xk), B, N, H, Cl, E, _abi.TRS_BF16, ptr(dW), ptr(ws),
+                     ws_bytes, stream_ptr())
+            return (dx0T if need_x0 else None, dxkT if need_xk else None, (dW.to(wdt) if need_w else None), db, None, None,
+                    None, None, None)
         if need_x0 or need_xk:
             if mfma_data:
                 ldo = ((H + 31) // 32) * 32
@@ -1627,15 +1665,18 @@ class _CINContractCL(Function):
                  ptr(ws), ws_bytes, stream_ptr())
         return (dx0T if need_x0 else None, dxkT if (need_xk and dxkT is not None) else None,
                 (dW.to(wdt) if need_w else None), db, None, None,
-                None, None)
+                None, None, None)
 
 
 def cin_contract_cl(x0T: torch.Tensor, xkT: torch.Tensor, Wc: torch.Tensor, bias: Optional[torch.Tensor], N: int,
-                    H: int, x0_cf: Optional[torch.Tensor] = None, xk_cf: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    H: int, x0_cf: Optional[torch.Tensor] = None, xk_cf: Optional[torch.Tensor] = None,
+                    live: Optional[int] = None) -> torch.Tensor:
     """channels-last CIN contraction on the matrix cores: x0T (B,E,ld0>=N, zero padded), xkT (B,E,>=H view).
-    ``x0_cf`` / ``xk_cf``: channels-first copies (B,N,E) / (B,H,E) of the same values when the caller has them."""
+    ``x0_cf`` / ``xk_cf``: channels-first copies (B,N,E) / (B,H,E) of the same values when the caller has them.
+    ``live``: the caller's promise that only the first ``live`` output channels can receive a gradient (the rest feed
+    nothing downstream): the backward leaves the others' exactly-zero terms out."""
     return _CINContractCL.apply(x0T, xkT, Wc, bias, N, H, None if x0_cf is None else x0_cf.detach(),
-                                None if xk_cf is None else xk_cf.detach())
+                                None if xk_cf is None else xk_cf.detach(), live)
 
 
 # --------------------------------------------------------------------------------------------

@@ -494,17 +494,25 @@ class CompressInteractionNetworkLayer(BaseLayer):
             x0T[:, :, :N] = x0.transpose(1, 2)
         hiddenT, H = x0T, N
         pooled = []
-        for seq in self.model:
+        n_layers = len(self.model)
+        for li, seq in enumerate(self.model):
             conv = seq.Conv1d
             C = conv.out_channels
-            yT = F_.cin_contract_cl(x0T, hiddenT, conv.weight.squeeze(-1), conv.bias, N, H,
-                                    x0_cf=x0 if x0.is_contiguous() else None,
-                                    xk_cf=getattr(hiddenT, '_trs_cf', None))                     # (B,E,C)
             D, Hs = (C, 0) if self.is_direct else (C // 2, C // 2)
             rest = [(name, mod) for name, mod in seq.named_children() if name != 'Conv1d']
             names = [name for name, _ in rest]
-            fusable = (names in (['Batchnorm', 'Activation'], ['Activation']) and type(rest[-1][1]) is nn.ReLU
-                       and (len(rest) == 1 or type(rest[0][1]) is nn.BatchNorm1d) and F_.cin_glue_supported(yT, D, Hs))
+            per_channel = (names in (['Batchnorm', 'Activation'], ['Activation']) and type(rest[-1][1]) is nn.ReLU
+                           and (len(rest) == 1 or type(rest[0][1]) is nn.BatchNorm1d))
+            # The LAST layer's "hidden" half (channels [D, C)) is split off and never used (the reference does the same:
+            # compress_interaction_network.py:151-156 splits every layer, :176-181 reads the direct halves only): its
+            # gradient is exactly zero, through BatchNorm1d and ReLU too (both act per channel), and the contraction's
+            # backward is told so.  The forward still computes those channels: BatchNorm's running statistics of them are
+            # part of the module's state.
+            live = D if (li == n_layers - 1 and not self.is_direct and per_channel) else None
+            yT = F_.cin_contract_cl(x0T, hiddenT, conv.weight.squeeze(-1), conv.bias, N, H,
+                                    x0_cf=x0 if x0.is_contiguous() else None,
+                                    xk_cf=getattr(hiddenT, '_trs_cf', None), live=live)          # (B,E,C)
+            fusable = per_channel and F_.cin_glue_supported(yT, D, Hs)
             if fusable:
                 # BatchNorm1d + ReLU + chunk + the sum over E of the direct half in two HIP passes (trs_cin_glue_*)
                 hiddenT, pool = F_.cin_glue(yT, rest[0][1] if len(rest) == 2 else None, D, Hs)
