@@ -309,11 +309,16 @@ def model_kernel_roofline(model, kernel, mtimes, B, N, E, esz):
                 "2*rows*E^2*(3L-1) FLOP, detached first layer")
         hbm_alg = 3 * rows_ * E * esz
     else:
+        from torecsys_amd import functional as _F
         Hs = [N, 128, 128]
-        flops = sum(2.0 * B * E * 256 * N * h for h in Hs)   # S_n = W_n^T gy over the three layers of a step
+        # channels of gy the contraction runs over: the last layer's "hidden" half carries no gradient and is left out of
+        # its backward (functional.CIN_SKIP_DEAD): those FLOPs are NOT executed and are NOT counted
+        Cs = [256, 256, 128 if _F.CIN_SKIP_DEAD else 256]
+        flops = sum(2.0 * B * E * c * N * h for h, c in zip(Hs, Cs))   # S_n = W_n^T gy over the three layers of a step
         per_step = 3
-        what = (kernel.replace("trs_", "") + ", the three layers of a step together: sum_k 2*B*E*C*N*H_k FLOP (C = 256; "
-                "the first layer runs the symmetric fold and does about half of its share)")
+        what = (kernel.replace("trs_", "") + ", the three layers of a step together: sum_k 2*B*E*C_k*N*H_k FLOP (C_k = "
+                + "/".join(str(c) for c in Cs) + ": the last layer's unused hidden half is skipped, not counted; the first "
+                "layer runs the symmetric fold and does about half of its share)")
         hbm_alg = None
     tsum = sum(mtimes) / len(mtimes) * per_step * 1e-3       # seconds per step in this kernel
     out = {"bound": "mfma", "kernel": kernel.replace("trs_", ""), "what": what,

@@ -514,8 +514,11 @@ class CompressInteractionNetworkLayer(BaseLayer):
                                     xk_cf=getattr(hiddenT, '_trs_cf', None), live=live)          # (B,E,C)
             fusable = per_channel and F_.cin_glue_supported(yT, D, Hs)
             if fusable:
-                # BatchNorm1d + ReLU + chunk + the sum over E of the direct half in two HIP passes (trs_cin_glue_*)
-                hiddenT, pool = F_.cin_glue(yT, rest[0][1] if len(rest) == 2 else None, D, Hs)
+                # BatchNorm1d + ReLU + chunk + the sum over E of the direct half in two HIP passes (trs_cin_glue_*).
+                # Last layer: its hidden half feeds nothing, so the pass does not write it out (Hs = C: no hidden
+                # channels; the statistics pass still covers every channel)
+                hs_out = C if live is not None else Hs
+                hiddenT, pool = F_.cin_glue(yT, rest[0][1] if len(rest) == 2 else None, D, hs_out)
                 H = C - Hs
                 pooled.append(pool)
                 continue
