@@ -489,7 +489,10 @@ def variant_legs(a):
                          "value": r["value"], "unit": r["unit"], "loss": r["config"]["loss"],
                          "hipgraph": r["config"]["hipgraph"],
                          "roofline": {k: rf.get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_us",
-                                                             "launches_timed")} if rf else None}
+                                                             "launches_timed")} if rf else None,
+                         "note": "achieved = ALGORITHMIC bytes (SURVEY 8d) / launch time: on skewed ids most rows are served "
+                                 "by L2 / the Infinity Cache, not HBM, so the ratio to the HBM peak can pass 1 -- it is a rate "
+                                 "of useful bytes, not of HBM traffic"}
         except Exception as exc:      # noqa: BLE001 -- a failed variant must not cost the headline line
             out[name] = {"error": f"{type(exc).__name__}: {exc}"}
         torch.cuda.synchronize()

@@ -15,8 +15,13 @@ run python bench.py --no-cpu-baseline --no-large-table --no-other-models --field
 run python bench.py --no-cpu-baseline --no-large-table --no-other-models --field-layout skewed --zipf 2>/dev/null | tail -1 > $O/bench_deepfm_skewed_zipf.json
 run python bench.py --no-cpu-baseline --no-large-table --no-other-models --optimizer adagrad 2>/dev/null | tail -1 > $O/bench_deepfm_adagrad.json
 run python bench.py --no-cpu-baseline --no-large-table --force-sharded 2>/dev/null | tail -1 > $O/bench_deepfm_sharded1.json
-run python bench.py --no-cpu-baseline --no-large-table --force-sharded --no-pipeline 2>/dev/null | tail -1 > $O/bench_deepfm_sharded1_nopipe.json
+run python bench.py --no-cpu-baseline --no-large-table --force-sharded --rows-per-gpu 125000000 2>/dev/null | tail -1 > $O/bench_deepfm_sharded1_125m.json
+run python bench.py --no-cpu-baseline --no-large-table --force-sharded --shard-graph region 2>/dev/null | tail -1 > $O/bench_deepfm_sharded1_region.json
+run python bench.py --no-cpu-baseline --no-large-table --force-sharded --shard-graph region --rows-per-gpu 125000000 2>/dev/null | tail -1 > $O/bench_deepfm_sharded1_region_125m.json
+TRS_SHARD_LOCAL_DIRECT=0 run python bench.py --no-cpu-baseline --no-large-table --force-sharded 2>/dev/null | tail -1 > $O/bench_deepfm_sharded1_buffers.json
+TRS_SHARD_LOCAL_DIRECT=0 run python bench.py --no-cpu-baseline --no-large-table --force-sharded --rows-per-gpu 125000000 2>/dev/null | tail -1 > $O/bench_deepfm_sharded1_buffers_125m.json
 run python bench.py --no-cpu-baseline --no-large-table --force-sharded --optimizer adagrad 2>/dev/null | tail -1 > $O/bench_deepfm_sharded1_adagrad.json
+run python bench.py --no-cpu-baseline --no-large-table --force-sharded --optimizer adagrad --rows-per-gpu 125000000 2>/dev/null | tail -1 > $O/bench_deepfm_sharded1_adagrad_125m.json
 run python tools/kbench.py 2>&1 | grep -v Warn > $O/kbench.txt
 run python tools/kbench.py --what pairx,mlpf 2>&1 | grep -v Warn > $O/kbench_pairx_mlpf.txt
 run python tools/kbench.py --what ffm 2>&1 | grep -v Warn > $O/kbench_ffm.txt
