@@ -352,21 +352,27 @@ def test_cfg5_real_shard_one_rank(pg):
     assert int(gid.max()) > 2 ** 26
     opt = FusedSparseSGD(0.5)
     m.set_fused_optimizer(opt)
-    w_before = m.embedding.weight.detach()[gid.reshape(-1)].float()          # rows the step touches (with repeats)
-    out = m(idx.to(dev))
-    block = out.rename(None)
-    assert torch.equal(block.detach().reshape(B * N, E), m.embedding.weight.detach().index_select(0, gid.reshape(-1)))
-    gb = (torch.randn(B, N, E, generator=g) * 0.1).bfloat16().to(dev)
-    (block.float() * gb.float()).sum().backward()
-    torch.cuda.synchronize()
-    assert m.embedding.weight.grad is None
-    uniq, inv = torch.unique(gid.reshape(-1), return_inverse=True)
-    acc = torch.zeros(uniq.numel(), E, dtype=torch.float32, device=dev).index_add_(0, inv, gb.float().reshape(-1, E))
-    first = torch.zeros(uniq.numel(), dtype=torch.int64, device=dev).scatter_(0, inv, torch.arange(B * N, device=dev))
-    want = w_before[first] - 0.5 * acc
-    got = m.embedding.weight.detach()[uniq].float()
-    assert rel_err(got, want) <= 1e-2
-    del m, out, block, w_before, acc, want, got, opt
+    # two steps: the owner-side update through the bucket index over all 125 M rows (0.5 GB; the default up to 256 M rows),
+    # then through the compact list of distinct touched rows (torch.unique + trs_scatter_rows_update_mapped)
+    for path in ("dense index", "compact rows"):
+        if path == "compact rows":
+            m.dense_index_max_rows = 0
+        w_before = m.embedding.weight.detach()[gid.reshape(-1)].float()          # rows the step touches (with repeats)
+        out = m(idx.to(dev))
+        block = out.rename(None)
+        assert torch.equal(block.detach().reshape(B * N, E), m.embedding.weight.detach().index_select(0, gid.reshape(-1)))
+        gb = (torch.randn(B, N, E, generator=g) * 0.1).bfloat16().to(dev)
+        (block.float() * gb.float()).sum().backward()
+        torch.cuda.synchronize()
+        assert m.embedding.weight.grad is None
+        uniq, inv = torch.unique(gid.reshape(-1), return_inverse=True)
+        acc = torch.zeros(uniq.numel(), E, dtype=torch.float32, device=dev).index_add_(0, inv, gb.float().reshape(-1, E))
+        first = torch.zeros(uniq.numel(), dtype=torch.int64, device=dev).scatter_(0, inv, torch.arange(B * N, device=dev))
+        want = w_before[first] - 0.5 * acc
+        got = m.embedding.weight.detach()[uniq].float()
+        assert rel_err(got, want) <= 1e-2, path
+        del out, block, w_before, acc, want, got
+    del m, opt
     torch.cuda.empty_cache()
     # ---- (b) the 8-rank route of the 1 B-row table, this GPU as owner 7
     V, W = 1_000_000_000, 8

@@ -798,18 +798,8 @@ class _ShardedLookup(Function):
                     recv_g = _exchange(sum(recv_splits), g_rows, recv_splits, send_splits, mod)      # reverse exchange
             _count_wire("rows_bwd", None if ctx.padded else send_splits, mod.rank, row_bytes, g_rows.shape[0], mod.world)
             wire_bytes["steps"] += 1
-            dense_index = weight.shape[0] <= mod.dense_grad_max_rows
-            pad_kw = {"padded": True} if ctx.padded else {}
-            gw = None
             with _phase(_pn("owner reduce / update", weight), dev):
-                if mod.fused_optimizer is not None:
-                    # the owner steps its rows right here: no gradient tensor of any kind (weight.grad stays None)
-                    ops.shard_update(weight, recv_ids, recv_g, mod.fused_optimizer, dense_index, **pad_kw)
-                elif dense_index:
-                    gw = ops.shard_grad_dense(weight, recv_ids, recv_g, **pad_kw)
-                else:
-                    ids = recv_ids.clamp_min(0) if ctx.padded else recv_ids      # padding: zero rows added to row 0
-                    gw = torch.sparse_coo_tensor(ids.long().unsqueeze(0), recv_g, size=weight.shape)
+                gw = _ShardedLookup._owner_reduce(mod, weight, recv_ids, recv_g, ctx.padded)
             if cs is not None:
                 mod._grad_event = torch.cuda.Event()
                 mod._grad_event.record(cs)
@@ -822,8 +812,11 @@ class _ShardedLookup(Function):
         dense_index = weight.shape[0] <= mod.dense_grad_max_rows
         pad_kw = {"padded": True} if padded else {}
         if mod.fused_optimizer is not None:
-            # the owner steps its rows right here: no gradient tensor of any kind (weight.grad stays None)
-            ops.shard_update(weight, ids, rows, mod.fused_optimizer, dense_index, **pad_kw)
+            # the owner steps its rows right here: no gradient tensor of any kind (weight.grad stays None).  The bucket
+            # INDEX over the shard's rows (4 bytes per row: 0.5 GB for 125 M rows, against 16 GB for a dense gradient) is
+            # affordable far beyond the size at which a dense gradient is: above it the distinct touched rows are
+            # compacted first (torch.unique, a sort of the B*N ids)
+            ops.shard_update(weight, ids, rows, mod.fused_optimizer, weight.shape[0] <= mod.dense_index_max_rows, **pad_kw)
             return None
         if dense_index:
             return ops.shard_grad_dense(weight, ids, rows, **pad_kw)
@@ -946,6 +939,10 @@ class RowShardedMultiIndicesEmbedding(BaseInput):
         # own_direct: with a dense shard gradient and no fused optimizer, this rank's own lookups are reduced by the unsharded
         # backward straight from the block gradient (TRS_SHARD_OWN_DIRECT=0: permuted and reduced with the received rows)
         self.own_direct = __import__("os").environ.get("TRS_SHARD_OWN_DIRECT", "1") != "0"
+        # fused optimizer: shards up to this many rows are stepped through a bucket index over ALL their rows (see
+        # _owner_reduce); TRS_SHARD_DENSE_INDEX_ROWS=0 restores the compact-row path above dense_grad_max_rows
+        self.dense_index_max_rows = max(int(dense_grad_max_rows), int(__import__("os").environ.get(
+            "TRS_SHARD_DENSE_INDEX_ROWS", str(256_000_000)))) if dense_grad_max_rows > 0 else 0
         self.register_buffer('offsets_local', self.offsets - self.row_range[0], persistent=False)
         self.route_key = (tuple(int(f) for f in field_sizes), self.world, id(process_group), self.dedup, self.capacity)
         self.length = embed_size * len(field_sizes) if flatten else embed_size
