@@ -352,11 +352,11 @@ def test_cfg5_real_shard_one_rank(pg):
     assert int(gid.max()) > 2 ** 26
     opt = FusedSparseSGD(0.5)
     m.set_fused_optimizer(opt)
-    # two steps: the owner-side update through the bucket index over all 125 M rows (0.5 GB; the default up to 256 M rows),
-    # then through the compact list of distinct touched rows (torch.unique + trs_scatter_rows_update_mapped)
-    for path in ("dense index", "compact rows"):
-        if path == "compact rows":
-            m.dense_index_max_rows = 0
+    # two steps: the owner-side update through the compact list of distinct touched rows (torch.unique +
+    # trs_scatter_rows_update_mapped: the default at this size), then through a bucket index over all 125 M rows
+    # (0.5 GB; TRS_SHARD_DENSE_INDEX_ROWS: measured slower here, kept correct)
+    for path in ("compact rows", "dense index"):
+        m.dense_index_max_rows = 0 if path == "compact rows" else 256_000_000
         w_before = m.embedding.weight.detach()[gid.reshape(-1)].float()          # rows the step touches (with repeats)
         out = m(idx.to(dev))
         block = out.rename(None)
