@@ -70,6 +70,7 @@ OWNER_PREFETCH = __import__("os").environ.get("TRS_SHARD_PREFETCH", "auto")
 
 class HipOps:
     """Device-side pieces of the sharded lookup, on libtrs_hip.so."""
+    _uniq_cache = None      # (key, ids kept alive, distinct ids, inverse) of the last compact-row optimizer step
 
     def bucket_by_owner(self, idx: torch.Tensor, offsets: torch.Tensor, rows_per_rank: int, world: int):
         require_device(idx, offsets)
@@ -140,8 +141,23 @@ class HipOps:
                 rb = F_.row_buckets(ids.view(-1, 1), None, weight.shape[0], check=not padded)
                 F_.scatter_rows_update(rb, weight.data, opt, g_rows=grad_rows.contiguous(), key=weight)
             else:
-                uniq, inv = torch.unique(ids, return_inverse=True)
-                rb = F_.row_buckets(inv.to(torch.int32).view(-1, 1), None, uniq.numel())
+                # the distinct touched rows of this step: shared by every table looked up with the same indices (the
+                # E = 64 table and its E = 1 companion receive the same owner ids: one sort instead of two)
+                key = (ids.data_ptr(), ids._version, ids.numel())
+                cur = torch.cuda.current_stream(ids.device)
+                hit = HipOps._uniq_cache if HipOps._uniq_cache is not None and HipOps._uniq_cache[0] == key else None
+                if hit is None:
+                    uniq, inv = torch.unique(ids, return_inverse=True)
+                    inv32 = inv.to(torch.int32).view(-1, 1)
+                    ev = torch.cuda.Event()
+                    ev.record(cur)
+                    HipOps._uniq_cache = hit = (key, ids, uniq, inv32, ev, cur)
+                _, _, uniq, inv32, ev, made_on = hit
+                if cur != made_on:        # the companion table's backward may run on the "lookup" side stream
+                    cur.wait_event(ev)
+                    uniq.record_stream(cur)
+                    inv32.record_stream(cur)
+                rb = F_.row_buckets(inv32, None, uniq.numel())
                 # ids outside the shard (the lookup read them as zero rows and raised the index flag) stay in ``uniq``:
                 # trs_scatter_rows_update_mapped skips row_map entries outside [0, V), so they update nothing
                 F_.scatter_rows_update_mapped(rb, weight.data, opt, grad_rows, uniq.to(torch.int32), key=weight)
@@ -435,6 +451,7 @@ def clear_route_caches():
 
 
 F_._clear_hooks.append(clear_route_caches)      # F_.clear_caches() (GraphedStep) drops the route plans too
+F_._clear_hooks.append(lambda: setattr(HipOps, "_uniq_cache", None))
 
 
 def _start_route(idx: torch.Tensor, mod) -> "_PendingRoute":
