@@ -569,7 +569,10 @@ def run(a):
             mode = "off"
         # whole: ONE graph per step, lookups and exchanges inside (a captured step must end with every stream joined, so
         # nothing is left running across the step boundary: no cross-step pipeline)
-        shard_whole = (mode == "whole" and a.optimizer in ("none", "sgd") and (a.microbatches or 1) == 1 and not a.dedup
+        # (a fused optimizer on a shard beyond the dense-index size compacts the touched rows with torch.unique: a
+        # data-dependent shape, not capturable)
+        shard_whole = (mode == "whole" and (a.optimizer == "none" or (a.optimizer == "sgd" and rows_local <= 8_000_000))
+                       and (a.microbatches or 1) == 1 and not a.dedup
                        and (world == 1 or a.capacity >= 1.0) and a.model in ("deepfm", "fm"))
         pipelined = (not a.no_pipeline and a.optimizer == "none" and (a.microbatches or 1) == 1 and not shard_whole)
         # the dense part of the step (deep branch, head, loss and their backward) replayed from a hipGraph while the
