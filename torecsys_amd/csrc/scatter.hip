@@ -901,7 +901,31 @@ __global__ __launch_bounds__(256) void scatter_long_rows_finish_kernel(
     float acc[VE], gsum[VE];
 #pragma unroll
     for (int k = 0; k < VE; ++k) { acc[k] = 0.f; gsum[k] = 0.f; }
-    for (int c = 0; c < nch; ++c) {
+    // A Zipf head row or a row of a 4-row field collects 16 k-20 k lookups = 64-80 chunk partials, each a cross-XCD read
+    // of ~1 k cycles: added one after the other this loop kept the kernel on the critical path for 42 us on the
+    // criteo-skewed Zipf batch (profiles/r06_logs/skewed_zipf_timeline_before.md).  Eight partials are requested before
+    // the first is added.  (The same sum spread over the lane groups of a wave with a shuffle tree at the end made hipcc
+    // run for more than 20 minutes on this file; this form compiles in its usual 30 s.)
+    constexpr int U = 8;
+    int c = 0;
+    for (; c + U <= nch; c += U) {
+      float4 va[U][VE / 4], vg[U][VE / 4];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float4* sa = reinterpret_cast<const float4*>(scratch + ((size_t)(i + c + u) * 2) * (L * VE) + lane_v * VE);
+        const float4* sg = reinterpret_cast<const float4*>(scratch + ((size_t)(i + c + u) * 2 + 1) * (L * VE) + lane_v * VE);
+#pragma unroll
+        for (int k = 0; k < VE / 4; ++k) { va[u][k] = sa[k]; vg[u][k] = sg[k]; }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int k = 0; k < VE / 4; ++k) {
+          acc[4 * k] += va[u][k].x; acc[4 * k + 1] += va[u][k].y; acc[4 * k + 2] += va[u][k].z; acc[4 * k + 3] += va[u][k].w;
+          gsum[4 * k] += vg[u][k].x; gsum[4 * k + 1] += vg[u][k].y; gsum[4 * k + 2] += vg[u][k].z; gsum[4 * k + 3] += vg[u][k].w;
+        }
+    }
+    for (; c < nch; ++c) {
       const float* sa = scratch + ((size_t)(i + c) * 2) * (L * VE) + lane_v * VE;
 #pragma unroll
       for (int k = 0; k < VE; ++k) { acc[k] += sa[k]; gsum[k] += sa[L * VE + k]; }
