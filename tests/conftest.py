@@ -76,7 +76,30 @@ def _report(kind, val):
 def rel_err(a, b):
     a = a.detach().double()
     b = b.detach().double()
+    if os.environ.get("TRS_ROWS_REPORT") and a.dim() >= 2 and a.shape == b.shape and a.shape[0] > 1:
+        # calibration aid: what the per-row norm would say where only the global one is asserted
+        a2, b2 = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
+        scale = b2.abs().amax(dim=1).clamp_min(1e-2 * float(b2.abs().max().clamp_min(1e-30)))
+        import inspect
+        fr = inspect.stack()[1]
+        with open(os.environ["TRS_ROWS_REPORT"], "a") as f:
+            f.write(f"{os.path.basename(fr.filename)}:{fr.lineno}\trows\t{float(((a2 - b2).abs().amax(dim=1) / scale).max()):.3e}\t"
+                    f"global\t{float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)):.3e}\n")
     return _report("rel_err", float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)))
+
+
+def rel_err_both(a, b, rows_slack=1.5):
+    """max(global norm, per-row norm / rows_slack): the assert `rel_err_both(a, b) <= tol` holds the tensor to ``tol`` in
+    the max norm AND every leading-index row to ``rows_slack * tol`` relative to the row's OWN largest reference value
+    (floored at 1 % of the tensor's), so a wrong row of small values cannot hide behind a large value elsewhere.  Slack:
+    a row's own maximum is typically 2-3 x below the tensor's while its absolute rounding error is not; calibrated over
+    every assert site of tests/test_gpu_layers.py and tests/test_gpu_pairx.py (round 6, TRS_ROWS_REPORT): per-row errors
+    1.7-2.4 x the global ones, never above 0.98e-2 for bf16 and 2.7e-6 for fp32."""
+    g = rel_err(a, b)
+    a2, b2 = a.detach().double(), b.detach().double()
+    if a2.dim() < 2 or a2.shape != b2.shape or a2.shape[0] < 2:
+        return g
+    return max(g, rel_err_rows(a2, b2) / rows_slack)
 
 
 def rel_err_rows(a, b, floor_frac=1e-2):

@@ -4,7 +4,7 @@ bf16-rounded inputs."""
 import pytest
 import torch
 
-from conftest import CIN_CASES, LAYER_SHAPES, rel_err
+from conftest import CIN_CASES, LAYER_SHAPES, rel_err_both as rel_err      # rel_err here = max norm AND per-row norm (conftest.rel_err_both)
 from oracle import cpu_ref as O
 
 pytestmark = pytest.mark.gpu

@@ -4,7 +4,7 @@ CPU oracle on the same inputs."""
 import pytest
 import torch
 
-from conftest import PAIR_SHAPES, pair_heavy_ok, rel_err, rel_err_rows
+from conftest import PAIR_SHAPES, pair_heavy_ok, rel_err_both as rel_err, rel_err_rows      # rel_err here = max norm AND per-row norm (conftest.rel_err_both)
 from oracle import cpu_ref as O
 
 pytestmark = pytest.mark.gpu
