@@ -135,7 +135,10 @@ __global__ __launch_bounds__(GLUE_THREADS) void glue_bwd_reduce_kernel(
   }
   const bool is_hidden = g.c0 >= Hs, is_direct = g.c0 < D;
   const int HW = C - Hs;
-  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+  // channels that receive no gradient at all (neither pooled nor fed to a next layer: the last CIN layer's hidden half):
+  // their sums are exact zeros, y is not read for them
+  const bool dead = !(is_direct && g_pooled != nullptr) && !(is_hidden && g_hidden != nullptr);
+  for (int64_t b = blockIdx.x; b < B && !dead; b += gridDim.x) {
     const uint4* rows = reinterpret_cast<const uint4*>(y + b * E * (int64_t)C);
     float gp8[8];
 #pragma unroll
@@ -180,6 +183,7 @@ __global__ __launch_bounds__(GLUE_THREADS) void glue_bwd_apply_kernel(
   }
   const bool is_hidden = g.c0 >= Hs, is_direct = g.c0 < D;
   const int HW = C - Hs;
+  const bool dead = !(is_direct && g_pooled != nullptr) && !(is_hidden && g_hidden != nullptr);
   for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
     const uint4* rows = reinterpret_cast<const uint4*>(y + b * E * (int64_t)C);
     uint4* out = reinterpret_cast<uint4*>(gy + b * E * (int64_t)C);
@@ -190,6 +194,10 @@ __global__ __launch_bounds__(GLUE_THREADS) void glue_bwd_apply_kernel(
       Vec16<bf16_t>::unpack(*reinterpret_cast<const uint4*>(g_pooled + b * (int64_t)D + g.c0), gp8);
     for (int e = g.rr; e < E; e += g.rpp) {
       float x[8], gz[8];
+      if (dead) {          // no gradient reaches these channels (c1 = c2 = 0 for them too): zeros, y not read
+        out[(int64_t)e * g.vpr + g.v] = make_uint4(0, 0, 0, 0);
+        continue;
+      }
       Vec16<bf16_t>::unpack(rows[(int64_t)e * g.vpr + g.v], x);
       glue_gz(g_hidden, gp8, is_hidden, is_direct, b * E + e, HW, g.c0 - Hs, gz);
 #pragma unroll
@@ -290,6 +298,7 @@ __global__ __launch_bounds__(GLUE_THREADS) void glue_bwd_apply_cf_kernel(
   }
   const bool is_hidden = g.c0 >= Hs, is_direct = g.c0 < D;
   const int HW = C - Hs;
+  const bool dead = !(is_direct && g_pooled != nullptr) && !(is_hidden && g_hidden != nullptr);      // see glue_bwd_reduce_kernel
   const int e0 = g.rr * 8;
   extern __shared__ float lds[];
   bf16_t* tile = reinterpret_cast<bf16_t*>(lds);       // [C][E + 8]: see glue_apply_fwd_cf_kernel
@@ -304,7 +313,7 @@ __global__ __launch_bounds__(GLUE_THREADS) void glue_bwd_apply_cf_kernel(
       Vec16<bf16_t>::unpack(*reinterpret_cast<const uint4*>(g_pooled + b * (int64_t)D + g.c0), gp8);
     uint4 raw[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) raw[j] = rows[(int64_t)(e0 + j) * g.vpr + g.v];
+    for (int j = 0; j < 8; ++j) raw[j] = dead ? make_uint4(0, 0, 0, 0) : rows[(int64_t)(e0 + j) * g.vpr + g.v];
     float t[8][8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -314,7 +323,7 @@ __global__ __launch_bounds__(GLUE_THREADS) void glue_bwd_apply_cf_kernel(
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const float m = fmaf(x[k], a[k], sh[k]) > 0.f ? t[j][k] : 0.f;
-        t[j][k] = a[k] * (m - k1[k] - (x[k] - mu[k]) * is[k] * k2[k]);
+        t[j][k] = dead ? 0.f : a[k] * (m - k1[k] - (x[k] - mu[k]) * is[k] * k2[k]);
       }
       const uint4 pk = Vec16<bf16_t>::pack(t[j]);
       out[(int64_t)(e0 + j) * g.vpr + g.v] = pk;
