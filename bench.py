@@ -465,6 +465,8 @@ def self_launch_argv(gpus, argv, env):
             "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(argv[0]), *argv[1:]]
 
 
+_teardown = []       # what main() runs after printing the result line (process-group teardown)
+
 VARIANTS = {"zipf": dict(zipf=True, field_layout="uniform"), "skewed": dict(zipf=False, field_layout="skewed"),
             "skewed_zipf": dict(zipf=True, field_layout="skewed")}
 
@@ -514,9 +516,24 @@ def main():
         sys.stdout.flush()
         ctypes.CDLL(None).fflush(None)
         print(json.dumps(res), flush=True)
+    if _teardown:
+        # The process group is torn down AFTER the result is printed, under a deadline: with RCCL all-to-alls captured
+        # inside a hipGraph (--shard-graph whole with forced / real collectives) destroy_process_group() was seen to wait
+        # for ever on the one-rank communicator (round 6: the run itself had finished -- the stack dump showed the main
+        # thread inside destroy_process_group); a rank that hangs there would keep the launcher from returning
+        import threading
+        killer = threading.Timer(30.0, lambda: os._exit(0))
+        killer.daemon = True
+        killer.start()
+        for fn in _teardown:
+            fn()
+        killer.cancel()
 
 
 def run(a):
+    if os.environ.get("TRS_BENCH_WATCHDOG"):      # developer aid: dump every thread's Python stack and exit if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["TRS_BENCH_WATCHDOG"]), exit=True, file=sys.stderr)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -1142,7 +1159,7 @@ def run(a):
     else:
         res = None
     if sharded:
-        dist.destroy_process_group()
+        _teardown.append(dist.destroy_process_group)      # after the JSON line is out: see main()
     return res
 
 

@@ -516,10 +516,10 @@ def test_whole_sharded_step_with_rccl_inside_one_hipgraph():
     group's watchdog thread cannot invalidate it), three replays on three batches: block bit-exact, FM and the dense
     shard gradient equal to the eager run of the same module (tests/rccl_graph_worker.py).
 
-    Runs in a process of its own with a deadline: RCCL inside a capture is the one thing in this suite that can stall
-    instead of failing (round 6: the same arrangement at the BENCHMARK's size -- 327 MB all-to-alls, four steps per graph
-    -- did not finish within 600 s on a one-rank communicator, which is why `bench.py --shard-graph whole` stays opt-in
-    at more than one rank).  A stall is reported as a skip with that reason, wrong numbers as a failure."""
+    Runs in a process of its own with a deadline: a process that has captured RCCL work is the one thing in this suite
+    that can stall instead of failing (round 6: after such a capture `destroy_process_group()` waited for ever at exit;
+    the worker leaves through os._exit, bench.py tears its group down under a deadline behind its result line).  A stall is
+    reported as a skip with that reason, wrong numbers as a failure."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
