@@ -201,8 +201,13 @@ def cpu_baseline(a, sizes):
     ncpu = os.cpu_count() or 1
     forced = int(os.environ.get("TRS_CPU_THREADS", "0"))
     runs = {}
+    threads_before = torch.get_num_threads()
     for th in ([forced] if forced else sorted({min(16, ncpu), ncpu})):
         runs[th] = rate(th, 6.0)
+    # back to what the process ran on: left at all 256 host threads, the small CPU ops of everything behind this leg (the
+    # index generation of the variants: 39 x 4 tensors of 65 536 values) crawl -- the default run took 4.5 minutes, 3.5 of
+    # them there
+    torch.set_num_threads(threads_before)
     best = max(runs, key=lambda t: runs[t][0])
     listing = ", ".join(f"{t} threads: {runs[t][0]:.0f} samples/s ({runs[t][1]} steps)" for t in sorted(runs))
     return {"value": round(runs[best][0], 1), "unit": "samples/s", "cores": best, "kind": "port", "host_cores": ncpu,
@@ -530,6 +535,15 @@ def main():
         killer.cancel()
 
 
+_T0 = time.perf_counter()
+
+
+def _stage(name):
+    """TRS_BENCH_STAGES=1: wall-clock seconds since start at every stage of the run, on stderr (where the minutes go)"""
+    if os.environ.get("TRS_BENCH_STAGES"):
+        print(f"[bench stage] {time.perf_counter() - _T0:7.1f} s  {name}", file=sys.stderr, flush=True)
+
+
 def run(a):
     if os.environ.get("TRS_BENCH_WATCHDOG"):      # developer aid: dump every thread's Python stack and exit if the run stalls
         import faulthandler
@@ -568,6 +582,7 @@ def run(a):
     idx_ring = [synth_indices(B, sizes, gen, a.zipf).to(dev) for _ in range(RING)]
     label_ring = [(torch.rand(B, 1, generator=gen) < 0.25).float().to(dev) for _ in range(RING)]
 
+    _stage("index ring built")
     torch.manual_seed(7)
     pipelined = False
     dense_graph = False
@@ -760,6 +775,7 @@ def run(a):
             bucket.reduce()
         return loss
 
+    _stage("modules built")
     roof_kernel = "trs_embed_fm" if not a.no_fuse else "trs_gather_rows"
     # dcn / xdeepfm: the dominant kernel of THEIR step is a matrix-core kernel (cross = MFMA-bound, CIN =
     # MFMA-bound): its FLOPs / time against the dense bf16 MFMA peak, next to the fused lookup launch
@@ -781,6 +797,7 @@ def run(a):
     for _ in range(a.warmup if not use_graph else max(3, a.warmup // 2)):
         eager_step()
     torch.cuda.synchronize()
+    _stage("eager warm-up done")
     if dense_graph:
         try:
             dense_ready[0] = True
@@ -935,6 +952,7 @@ def run(a):
             dist.barrier()
         counter[0] = 0
         phases[:] = [0.0, 0.0, 0.0, 0]
+    _stage("capture and re-warm done")
     dev_allocs0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
     prof = None
     if os.environ.get("TRS_BENCH_CPROFILE"):      # developer diagnostic: which host call blocks inside the timed region
@@ -995,6 +1013,7 @@ def run(a):
         print("box probe: bf16 GEMM 8192^3 %.0f TFLOP/s, device copy %.0f GB/s (read+write)" %
               (20 * 2 * 8192 ** 3 / (e0.elapsed_time(e1) * 1e-3) / 1e12,
                20 * 2 * (1 << 28) / (e1.elapsed_time(e2) * 1e-3) / 1e9), file=sys.stderr)
+    _stage("timed region done")
     device_span_ms = span0.elapsed_time(span1)
     shard_diag = None
     if sharded:
@@ -1094,6 +1113,7 @@ def run(a):
                             "roofline_large_table repeats the same launch on a table that does not"}
         big = big_fm = None
         if roof is not None and not a.no_large_table and world == 1:
+            _stage("timed region and kernel sampling done")
             big = large_table_roofline(a, dev, dt, esz)
             if not a.no_fuse:
                 big_fm = large_table_roofline(a, dev, dt, esz, fm_only=True)
@@ -1144,18 +1164,23 @@ def run(a):
         if model_roof is not None:
             res["roofline_model_kernel"] = model_roof
         if world == 1 and not a.no_cpu_baseline:
+            _stage("large-table rooflines done")
             res["cpu_baseline"] = cpu_baseline(a, field_sizes(1_000_000, N, a.field_layout))
+            _stage("cpu baseline done")
             if not sharded and a.optimizer == "none" and a.model in ("deepfm", "fm"):
                 res["self_check"] = self_check(a, inputs, model, idx_ring[0], sizes)
         if (world == 1 and not sharded and a.model == "deepfm" and not a.no_other_models and a.optimizer == "none"
                 and not a.no_fuse):
             # BASELINE configs[2] and [3] ride along: a few steps each, reported beside the headline (never as `value`)
+            _stage("self check done")
             res["other_models"] = {m: other_model_leg(m, a, dev, dt, inputs, idx_ring, label_ring, esz, sizes)
                                    for m in ("dcn", "xdeepfm")}
+            _stage("dcn / xdeepfm legs done")
         if (world == 1 and not sharded and a.model == "deepfm" and not getattr(a, "no_variants", False)
                 and not a.no_other_models and a.optimizer == "none" and not a.no_fuse and not a.zipf and a.field_layout == "uniform"
                 and not a.host_indices):
             res["variants"] = variant_legs(a)
+            _stage("variants done")
     else:
         res = None
     if sharded:

@@ -1,0 +1,2 @@
+#!/bin/bash
+s=$(date +%s); TRS_BENCH_STAGES=1 timeout 900 python bench.py --no-cpu-baseline --no-large-table 2>&1 >/dev/null | grep "bench stage"; echo "total $(( $(date +%s) - s )) s"
