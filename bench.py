@@ -379,22 +379,47 @@ def other_model_leg(name, a, dev, dt, inputs, idx_ring, label_ring, esz, sizes=N
     for k in range(max(1, a.other_warmup)):
         one(k)
     torch.cuda.synchronize()
+    # The timed steps replay from a hipGraph like the headline leg (one step per replay, the batch copied into the static
+    # inputs): launched eagerly a DCN step is ~140 launches and its rate follows the HOST -- 9.2 ms on a warm box, 15-16 ms
+    # in the first run on a fresh one (round 6).  Capture refused: the eager loop, as before.
+    gstep = None
+    if not a.eager and os.environ.get("TRS_OTHER_GRAPH", "1") != "0":
+        try:
+            from torecsys_amd.graph import GraphedStep
+
+            def gfn(ix, lab):
+                d = inputs({"c0": ix})
+                out = model(**d) if name != "dcn" else model(emb_inputs=d["emb_inputs"])
+                l_ = _loss(crit, out, lab)
+                l_.backward()
+                return l_
+
+            gstep = GraphedStep(gfn, (idx_ring[0], label_ring[0]), params=params, warmup=1)
+        except Exception as exc:      # noqa: BLE001
+            print(f"bench.py: hipGraph capture of the {name} step failed ({type(exc).__name__}: {exc}); running eager",
+                  file=sys.stderr)
+            gstep = None
+            torch.cuda.synchronize()
+    timed = (lambda k: gstep(idx_ring[k % ring], label_ring[k % ring])) if gstep is not None else one
     kernels = MODEL_KERNELS[name] if dt == torch.bfloat16 else []
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     import gc
     gc.collect()          # as in the headline leg: a generation-2 pass (~65 ms on the host) inside five 10 ms steps lets the
     gc.disable()          # device run dry -- seen as 19.2 instead of 10.3 ms per DCN step
-    one(0)                # one more untimed step behind that pause: the device idled through it and comes back at a lower
+    timed(0)              # one more untimed step behind that pause: the device idled through it and comes back at a lower
     torch.cuda.synchronize()      # clock (five DCN steps: 9.6 ms each against 9.2 in a 20-step run on the same box)
     e0.record()
     for k in range(a.other_steps):
-        loss = one(k)
+        loss = timed(k)
     e1.record()
     gc.enable()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.other_steps
     leg = {"workload": WORKLOADS[name], "steps": a.other_steps, "ms_per_step": round(ms, 4),
-           "value": round(B / ms * 1e3, 1), "unit": "samples/s", "loss": float(loss.detach()), "hipgraph": False}
+           "value": round(B / ms * 1e3, 1), "unit": "samples/s", "loss": float(loss.detach()), "hipgraph": gstep is not None}
+    if gstep is not None:
+        loss = None
+        gstep.release_outputs()
     # the dominant matrix-core kernel: sampled in steps of their own, AFTER the timed ones (events around every launch make
     # the host wait on the runtime's profiling signals: they do not belong inside a timed step)
     for kn in kernels:
@@ -414,7 +439,7 @@ def other_model_leg(name, a, dev, dt, inputs, idx_ring, label_ring, esz, sizes=N
             leg["self_check"] = other_model_self_check(name, a, inputs, model, idx_ring[0], sizes)
         except Exception as exc:          # noqa: BLE001 -- the checker must not cost the line
             leg["self_check"] = {"ok": False, "error": f"{type(exc).__name__}: {exc}"}
-    del model
+    del model, gstep
     return leg
 
 
@@ -1163,16 +1188,13 @@ def run(a):
             res["roofline_full_unit"] = full_unit
         if model_roof is not None:
             res["roofline_model_kernel"] = model_roof
-        if world == 1 and not a.no_cpu_baseline:
-            _stage("large-table rooflines done")
-            res["cpu_baseline"] = cpu_baseline(a, field_sizes(1_000_000, N, a.field_layout))
-            _stage("cpu baseline done")
-            if not sharded and a.optimizer == "none" and a.model in ("deepfm", "fm"):
-                res["self_check"] = self_check(a, inputs, model, idx_ring[0], sizes)
+        # GPU legs first, the CPU baseline LAST: its 256-thread run leaves the host's OpenMP pool spinning, which slows the
+        # Python threads that enqueue the eager DCN / xDeepFM steps (seen as 15 instead of 9 ms per DCN step) and the small
+        # CPU ops of the variants' index generation (the default run took 4.5 minutes with the baseline in front)
+        _stage("large-table rooflines done")
         if (world == 1 and not sharded and a.model == "deepfm" and not a.no_other_models and a.optimizer == "none"
                 and not a.no_fuse):
             # BASELINE configs[2] and [3] ride along: a few steps each, reported beside the headline (never as `value`)
-            _stage("self check done")
             res["other_models"] = {m: other_model_leg(m, a, dev, dt, inputs, idx_ring, label_ring, esz, sizes)
                                    for m in ("dcn", "xdeepfm")}
             _stage("dcn / xdeepfm legs done")
@@ -1181,6 +1203,12 @@ def run(a):
                 and not a.host_indices):
             res["variants"] = variant_legs(a)
             _stage("variants done")
+        if world == 1 and not a.no_cpu_baseline:
+            if not sharded and a.optimizer == "none" and a.model in ("deepfm", "fm"):
+                res["self_check"] = self_check(a, inputs, model, idx_ring[0], sizes)
+                _stage("self check done")
+            res["cpu_baseline"] = cpu_baseline(a, field_sizes(1_000_000, N, a.field_layout))
+            _stage("cpu baseline done")
     else:
         res = None
     if sharded:
